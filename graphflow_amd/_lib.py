@@ -1,0 +1,65 @@
+"""Loads graphflow_amd/csrc/libgf_hip.so (the C-ABI of include/gf_hip.h) and declares its prototypes.
+
+There is NO fallback: if the shared library is missing or a symbol is absent this module raises, and every op in the
+package fails with it.  Building happens in-tree (`make -C graphflow_amd/csrc`, driven by __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libgf_hip.so")
+
+GF_OK, GF_ERR_INVALID, GF_ERR_HIP, GF_ERR_NOMEM, GF_ERR_UNSUPPORTED = range(5)
+
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/gf_hip.h one to one (tests/test_abi.py checks the two agree)
+PROTOTYPES = {
+    "gf_ctx_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp]),
+    "gf_ctx_destroy": (C.c_int, [_vp]),
+    "gf_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "gf_ctx_get_stream": (_vp, [_vp]),
+    "gf_ctx_synchronize": (C.c_int, [_vp]),
+    "gf_ctx_reserve": (C.c_int, [_vp, C.c_size_t]),
+    "gf_ctx_set_timing": (C.c_int, [_vp, C.c_int]),
+    "gf_ctx_timing_count": (C.c_int, [_vp]),
+    "gf_ctx_timing_get": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "gf_last_error": (C.c_char_p, [_vp]),
+    "gf_version": (C.c_char_p, []),
+    "gf_contract_forward_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "gf_contract_backward_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gf_contract_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gf_contract_forward_host_f64": (C.c_int, [_vp, C.c_int, C.POINTER(_dp), _dp, _dp, C.c_int, C.c_int]),
+    "gf_contract_backward_host_f64": (C.c_int, [_vp, C.c_int, _dp, _dp, C.POINTER(_dp), C.c_int, C.c_int]),
+    "gf_contract_forward_host_f32": (C.c_int, [_vp, C.c_int, C.POINTER(_fp), _fp, _fp, C.c_int, C.c_int]),
+    "gf_contract_backward_host_f32": (C.c_int, [_vp, C.c_int, _fp, _fp, C.POINTER(_fp), C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """hipcc --offload-arch=gfx950 build of the shared library (cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", _CSRC, "-j4"], stdout=out)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "graphflow_amd: %s is missing -- build it with `make -C graphflow_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

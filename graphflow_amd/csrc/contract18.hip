@@ -1,0 +1,973 @@
+// contract18.hip -- RisiContraction_18 forward/backward for gfx950 (MI355X), factorised O(N^3 C) form.
+//
+// Replaces GraphFlow/RisiContraction_18.h:73-331 (forward) and :333-560 (backward), whose loop nests cost
+// O(nnz(A) N^3 C).  Every one of the 18 cases factorises into (i) one streaming pass over P[a][b][c][f] that
+// builds a handful of N x N (per channel) tables and (ii) tiny N x N products with the gated adjacency
+// A+ = A*[A>0].  The pass is HBM-bound; nothing here is GEMM-shaped enough for MFMA.
+//
+// Decomposition (per graph g, channel window of CW = 4*LPC channels):
+//   forward   F1 "slab" : one workgroup per (g, b) streams the slab P[g][:, b, :, :] once (coalesced 16 B/lane over
+//                         the channel axis, lanes = (c-group, channel quad)), owns every quantity indexed by b
+//                         (S_ab[:,b], S_bc[b,:], the r-weighted sums, the diagonals) and writes 10 of the 18 slices
+//                         directly; it leaves S_ab[:,b], P[:,b,b] and 4 partial scalars in a small workspace.
+//             F2 "rows" : one workgroup per (g, a) finishes the 8 slices that need a sum over b from that workspace.
+//   backward  B1 "rows" : one workgroup per (g, a) reduces the 8 (a,d)- and (d,e)-indexed gradient slices to two
+//                         N x N x C tables and 4 partial scalars.
+//             B2 "slab" : one workgroup per (g, b) builds the per-b tables from the other 10 slices and streams
+//                         dP[g][:, b, :, :] out (write-only, or read-modify-write when accumulate != 0).
+// Algorithmic HBM bytes per graph (fp32): fwd 4(N^3 C + N^2 + 18 N^2 C), bwd the same (+4 N^3 C with accumulate);
+// the workspace adds 2 x 4(2 N^2 C + 4 N C) per direction (about 8 % at N=32, C=64).
+//
+// Shapes outside the slab kernels' reach (C % 4 != 0, misaligned pointers, N > 8 * 64/LPC) take the "generic"
+// kernels at the bottom of this file: same maths, one thread per output element, no layout assumptions.
+#include "gf_internal.h"
+
+namespace gf {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kK = 18;
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+__device__ __forceinline__ f4 splat(float x) { return f4{x, x, x, x}; }
+
+__device__ __forceinline__ f4 shfl_xor4(f4 v, int m) {
+    f4 r;
+    r.x = __shfl_xor(v.x, m);
+    r.y = __shfl_xor(v.y, m);
+    r.z = __shfl_xor(v.z, m);
+    r.w = __shfl_xor(v.w, m);
+    return r;
+}
+
+// Sum over the c-groups of a wave (lanes that share the same channel quad): xor-butterfly over lane bits >= log2(LPC).
+template <int LPC>
+__device__ __forceinline__ f4 reduce_cgroups(f4 v) {
+#pragma unroll
+    for (int m = LPC; m < 64; m <<= 1) v += shfl_xor4(v, m);
+    return v;
+}
+
+// LDS carve shared by the four kernels: gated adjacency with row stride N+1 (bank-conflict-free column walks),
+// its row sums r[d], then tot = sum A+, tr = trace A+.
+struct AdjLds {
+    float *A;   // [N][N+1]
+    float *r;   // [Np]
+    float *st;  // [4]: tot, tr
+    __device__ __forceinline__ float at(int d, int e, int N) const { return A[d * (N + 1) + e]; }
+};
+
+__host__ __device__ __forceinline__ int pad4(int x) { return (x + 3) & ~3; }
+__host__ __device__ __forceinline__ int adj_lds_floats(int N) { return pad4(N * (N + 1)) + pad4(N) + 4; }
+
+// Loads A[g] (transposed when TR) with RisiContraction_18's `adj_value > 0` gate (RisiContraction_18.h:90,345) and
+// derives r[d] = sum_e A+[d][e] (always the row sums of the UNtransposed matrix), tot and tr.
+template <bool TR>
+__device__ __forceinline__ AdjLds load_adjacency(float *smem, const float *__restrict__ Ag, int N) {
+    AdjLds L;
+    L.A = smem;
+    L.r = smem + pad4(N * (N + 1));
+    L.st = L.r + pad4(N);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N * N; i += kThreads) {
+        const int d = i / N, e = i - d * N;
+        float a = Ag[i];
+        a = (a > 0.f) ? a : 0.f;
+        if (TR)
+            L.A[e * (N + 1) + d] = a;
+        else
+            L.A[d * (N + 1) + e] = a;
+    }
+    __syncthreads();
+    if (tid < N) {
+        float s = 0.f;
+        for (int e = 0; e < N; ++e) s += TR ? L.A[e * (N + 1) + tid] : L.A[tid * (N + 1) + e];
+        L.r[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 64) {  // tot and tr by one wave: strided partials, then a 6-step butterfly
+        float t = 0.f, d = 0.f;
+        for (int i = tid; i < N; i += 64) {
+            t += L.r[i];
+            d += L.A[i * (N + 1) + i];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            t += __shfl_xor(t, m);
+            d += __shfl_xor(d, m);
+        }
+        if (tid == 0) {
+            L.st[0] = t;
+            L.st[1] = d;
+        }
+    }
+    __syncthreads();
+    return L;
+}
+
+// out[y] (y = first; first+step; ...) = sum_e M[y][e] * T[e][channel quad], for up to three tables at once.
+// M is the LDS adjacency (already transposed if the caller needs A^T); rows are walked with stride N+1.
+template <int NT, int CW>
+__device__ __forceinline__ void small_matvec(const AdjLds &L, int N, int y, int fl, const float *const (&T)[NT],
+                                             f4 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = splat(0.f);
+    const float *row = L.A + y * (N + 1);
+    for (int e = 0; e < N; ++e) {
+        const float w = row[e];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] += w * ld4(T[t] + e * CW + 4 * fl);
+    }
+}
+
+struct BlockId {
+    int g, i, win;
+};
+__device__ __forceinline__ BlockId decode_block(int N, int nwin) {
+    int bid = blockIdx.x;
+    BlockId r;
+    r.win = bid % nwin;
+    bid /= nwin;
+    r.i = bid % N;
+    r.g = bid / N;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// F1: forward slab kernel.  Workgroup (g, b).  Wave w owns rows a = w, w+4, ...; lane = (cg, fl):
+// c = i*PPW + cg for load i, channels f0 + 4*fl .. +3.  Per row: NI coalesced 16 B loads per lane (+1 for the two
+// diagonal elements P[a,b,b], P[a,b,a]), register accumulation over a (S_bc, T10) and shuffle reduction over c
+// (S_ab, T6).  Rows are double-buffered in registers so the next row's loads are in flight while this one is reduced.
+// The streaming loop is branch-free: ragged shapes (FULL == false: N < NI*PPW or C % CW != 0) clamp the load
+// address into the row and multiply the value by a 0/1 lane mask instead of predicating the load.
+// ------------------------------------------------------------------------------------------------------------
+template <int LPC, int NI>
+struct SlabLane {
+    int coff[NI];    // element offset of this lane's i-th load inside a row (clamped to a valid c)
+    float cmask[NI];  // 1 where (c < N and channel quad in range), else 0
+};
+
+template <int LPC, int NI, bool FULL>
+__device__ __forceinline__ void load_slab_row(const float *__restrict__ row, const SlabLane<LPC, NI> &ln, int dgoff,
+                                              f4 (&v)[NI], f4 &dg) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = ld4(row + ln.coff[i]);
+    dg = ld4(row + dgoff);
+}
+
+template <int LPC, int NI, bool FULL>
+__global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict__ P, const float *__restrict__ A,
+                                                         float *__restrict__ Out, float *__restrict__ wsSab,
+                                                         float *__restrict__ wsDbb, float *__restrict__ wsScal, int N,
+                                                         int C, int nwin) {
+    constexpr int PPW = 64 / LPC;
+    constexpr int CW = 4 * LPC;
+    constexpr int NCP = NI * PPW;  // padded c extent (>= N)
+    static_assert(PPW >= 4, "row epilogue uses four c-groups");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = lane / LPC, fl = lane % LPC;
+    const BlockId B = decode_block(N, nwin);
+    const int g = B.g, b = B.i;
+    const int f = B.win * CW + 4 * fl;
+    const bool fok = FULL || f < C;
+    const int fld = fok ? f : 0;  // clamped channel offset for loads
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AdjLds L = load_adjacency<false>(smem, A + (size_t)g * N * N, N);
+    float *sSab = smem + adj_lds_floats(N);  // [N][CW]    S_ab[e, b]
+    float *sDac = sSab + N * CW;             // [N][CW]    P[e, b, e]
+    float *sSbc = sDac + N * CW;             // [NCP][CW]  S_bc[b, e]
+    float *sRed = sSbc + NCP * CW;           // [2][NCP][CW] cross-wave reduction buffer
+    float *sMisc = sRed + 2 * NCP * CW;      // [kWaves][2][CW] diagonal sums, then [CW] colsum
+    const float tot = L.st[0], tr = L.st[1];
+
+    SlabLane<LPC, NI> ln;
+    float rc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = i * PPW + cg;
+        const bool ok = FULL || (c < N);
+        ln.coff[i] = (ok ? c : 0) * C + fld;
+        ln.cmask[i] = (ok && fok) ? 1.f : 0.f;
+        rc[i] = (ok && fok) ? L.r[ok ? c : 0] : 0.f;
+    }
+    const float dmask = (cg < 2 && fok) ? 1.f : 0.f;
+
+    const float *Pg = P + (size_t)g * N * N * N * C;
+    const size_t rowStride = (size_t)N * N * C;
+    const float *row0 = Pg + (size_t)b * N * C;  // + a*rowStride
+
+    f4 sbc[NI], t10[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) sbc[i] = t10[i] = splat(0.f);
+    f4 dgsum = splat(0.f);  // cg==0: sum_a P[a,b,b]   cg==1: sum_a P[a,b,a]
+
+    f4 cur[NI], nxt[NI], dcur, dnxt;
+    load_slab_row<LPC, NI, FULL>(row0 + (wave < N ? wave : 0) * rowStride, ln,
+                                 ((cg == 0) ? b : (wave < N ? wave : 0)) * C + fld, cur, dcur);
+    for (int a = wave; a < N; a += kWaves) {
+        const int an = (a + kWaves < N) ? a + kWaves : a;  // last iteration re-reads its own row (L1/L2 hit)
+        load_slab_row<LPC, NI, FULL>(row0 + an * rowStride, ln, ((cg == 0) ? b : an) * C + fld, nxt, dnxt);
+        const float ra = L.r[a];
+        f4 sab = splat(0.f), t6 = splat(0.f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const f4 v = cur[i];
+            sbc[i] += v;  // lanes with c >= N accumulate clamped duplicates that are never stored
+            t10[i] += ra * v;
+            if (FULL)
+                sab += v;
+            else
+                sab += ln.cmask[i] * v;
+            t6 += rc[i] * v;
+        }
+        sab = reduce_cgroups<LPC>(sab);
+        t6 = reduce_cgroups<LPC>(t6);
+        const f4 dv = dcur * dmask;
+        dgsum += dv;
+        // row epilogue: four c-groups each issue one 16 B store per lane (256 B segments at C=64)
+        const size_t oab = (((size_t)g * N + a) * N + b) * (size_t)(kK * C) + f;  // Out[g][a][b][.][f]
+        const size_t wab = (((size_t)g * N + a) * N + b) * (size_t)C + f;         // ws[g][a][b][f]
+        if (cg == 0) {
+            if (fok) {
+                st4(Out + oab + 0 * C, sab * tot);  // k0  S_ab*tot
+                st4(wsDbb + wab, dv);               // P[a,b,b] for F2
+            }
+        } else if (cg == 1) {
+            if (fok) st4(Out + oab + 6 * C, sab * tr);  // k6  S_ab*tr
+            st4(sDac + a * CW + 4 * fl, dv);            // P[a,b,a]
+        } else if (cg == 2) {
+            if (fok) st4(Out + oab + 5 * C, t6);  // k5  sum_c P[a,b,c] r[c]
+        } else if (cg == 3) {
+            if (fok) st4(wsSab + wab, sab);
+            st4(sSab + a * CW + 4 * fl, sab);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) cur[i] = nxt[i];
+        dcur = dnxt;
+    }
+
+    // cross-wave reduction of the a-sums: waves 1..3 hand their partials to wave 0 one at a time (deterministic
+    // order).  The buffers are padded to NCP rows so no lane needs a bounds branch.
+#pragma unroll 1
+    for (int w = 1; w < kWaves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                st4(sRed + (i * PPW + cg) * CW + 4 * fl, sbc[i]);
+                st4(sRed + (NCP + i * PPW + cg) * CW + 4 * fl, t10[i]);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                sbc[i] += ld4(sRed + (i * PPW + cg) * CW + 4 * fl);
+                t10[i] += ld4(sRed + (NCP + i * PPW + cg) * CW + 4 * fl);
+            }
+        }
+        __syncthreads();
+    }
+    if (cg < 2) st4(sMisc + (wave * 2 + cg) * CW + 4 * fl, dgsum);
+    if (wave == 0) {
+        f4 cs = splat(0.f);
+        float *obc = Out + (((size_t)g * N + b) * N) * (size_t)(kK * C) + f;  // Out[g][b][c][.][f]
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = i * PPW + cg;
+            const f4 sv = FULL ? sbc[i] : sbc[i] * ln.cmask[i];
+            cs += sv;
+            st4(sSbc + c * CW + 4 * fl, sv);
+            if (FULL || ln.cmask[i] != 0.f) {
+                st4(obc + (size_t)c * (kK * C) + 2 * C, sbc[i] * tot);  // k2  S_bc*tot
+                st4(obc + (size_t)c * (kK * C) + 9 * C, t10[i]);        // k9  sum_a r[a] P[a,b,c]
+            }
+        }
+        cs = reduce_cgroups<LPC>(cs);
+        if (cg == 0) st4(sMisc + kWaves * 2 * CW + 4 * fl, cs);  // colsum_b = sum_{a,c} P[a,b,c]
+    }
+    __syncthreads();
+
+    // (b,d)-indexed slices: three N x N products with A+ plus two outer products with r.
+    // Table-building role: thread = (row group grp, channel quad fl); LPC divides 64 so tid % LPC == fl.
+    constexpr int NGRP = kThreads / LPC;
+    const int grp = tid / LPC;
+    f4 dbbtot = splat(0.f), dactot = splat(0.f);
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        dbbtot += ld4(sMisc + (w * 2 + 0) * CW + 4 * fl);
+        dactot += ld4(sMisc + (w * 2 + 1) * CW + 4 * fl);
+    }
+    const f4 colsum = ld4(sMisc + kWaves * 2 * CW + 4 * fl);
+    const float *const T[3] = {sSab, sSbc, sDac};
+    for (int d = grp; d < N; d += NGRP) {
+        f4 m[3];
+        small_matvec<3, CW>(L, N, d, fl, T, m);
+        const float rd = L.r[d];
+        if (fok) {
+            float *o = Out + (((size_t)g * N + b) * N + d) * (size_t)(kK * C) + f;
+            st4(o + 3 * C, colsum * rd);   // k3   (sum_{a,c} P[a,b,c]) r[d]
+            st4(o + 10 * C, dactot * rd);  // k10  (sum_a P[a,b,a]) r[d]
+            st4(o + 11 * C, m[0]);         // k11  sum_e A[d,e] S_ab[e,b]
+            st4(o + 12 * C, m[1]);         // k12  sum_e A[d,e] S_bc[b,e]
+            st4(o + 16 * C, m[2]);         // k16  sum_e A[d,e] P[e,b,e]
+        }
+    }
+    if (grp == 0 && fok) {
+        float *s = wsScal + ((size_t)g * N + b) * 4 * (size_t)C + f;
+        st4(s + 0 * C, colsum);                       // -> total = sum_b colsum_b
+        st4(s + 1 * C, ld4(sSab + b * CW + 4 * fl));  // -> s14   = sum_a S_ab[a,a]
+        st4(s + 2 * C, dbbtot);                       // -> s15   = sum_{a,b} P[a,b,b]
+        st4(s + 3 * C, ld4(sDac + b * CW + 4 * fl));  // -> s18   = sum_a P[a,a,a]
+    }
+}
+
+template <int LPC, int NI>
+static size_t fwd_slab_lds_bytes(int N) {
+    constexpr int CW = 4 * LPC;
+    constexpr int NCP = NI * (64 / LPC);
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + 2 * (size_t)N * CW + 3 * (size_t)NCP * CW + (kWaves * 2 + 1) * CW);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// F2: forward row kernel.  Workgroup (g, a) finishes the (a,d)- and (d=a,e)-indexed slices.
+// ------------------------------------------------------------------------------------------------------------
+template <int LPC>
+__global__ __launch_bounds__(kThreads) void r18_fwd_rows(const float *__restrict__ A, float *__restrict__ Out,
+                                                         const float *__restrict__ wsSab,
+                                                         const float *__restrict__ wsDbb,
+                                                         const float *__restrict__ wsScal, int N, int C, int nwin) {
+    constexpr int CW = 4 * LPC;
+    constexpr int NGRP = kThreads / LPC;
+    const int tid = threadIdx.x;
+    const int grp = tid / LPC, fl = tid % LPC;
+    const BlockId B = decode_block(N, nwin);
+    const int g = B.g, a = B.i;
+    const int f = B.win * CW + 4 * fl;
+    const bool fok = f < C;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AdjLds L = load_adjacency<false>(smem, A + (size_t)g * N * N, N);
+    float *sT0 = smem + adj_lds_floats(N);  // [N][CW] S_ab[a, e]
+    float *sT1 = sT0 + N * CW;              // [N][CW] P[a, e, e]
+    float *sS = sT1 + N * CW;               // [4][CW] total, s14, s15, s18
+
+    for (int e = grp; e < N; e += NGRP) {
+        const size_t w = (((size_t)g * N + a) * N + e) * (size_t)C + f;
+        st4(sT0 + e * CW + 4 * fl, fok ? ld4(wsSab + w) : splat(0.f));
+        st4(sT1 + e * CW + 4 * fl, fok ? ld4(wsDbb + w) : splat(0.f));
+    }
+    if (grp < 4) {
+        f4 s = splat(0.f);
+        if (fok)
+            for (int bb = 0; bb < N; ++bb) s += ld4(wsScal + (((size_t)g * N + bb) * 4 + grp) * (size_t)C + f);
+        st4(sS + grp * CW + 4 * fl, s);
+    }
+    __syncthreads();
+
+    f4 rowsum = splat(0.f), d8 = splat(0.f);
+    for (int e = 0; e < N; ++e) {
+        rowsum += ld4(sT0 + e * CW + 4 * fl);
+        d8 += ld4(sT1 + e * CW + 4 * fl);
+    }
+    const f4 total = ld4(sS + 0 * CW + 4 * fl), s14 = ld4(sS + 1 * CW + 4 * fl);
+    const f4 s15 = ld4(sS + 2 * CW + 4 * fl), s18 = ld4(sS + 3 * CW + 4 * fl);
+    const float *const T[2] = {sT0, sT1};
+    for (int y = grp; y < N; y += NGRP) {
+        f4 m[2];
+        small_matvec<2, CW>(L, N, y, fl, T, m);
+        const float ry = L.r[y], aay = L.at(a, y, N);
+        if (fok) {
+            float *o = Out + (((size_t)g * N + a) * N + y) * (size_t)(kK * C) + f;
+            st4(o + 1 * C, rowsum * ry);  // k1   (sum_{b,c} P[a,b,c]) r[d]
+            st4(o + 7 * C, d8 * ry);      // k7   (sum_b P[a,b,b]) r[d]
+            st4(o + 8 * C, m[0]);         // k8   sum_e A[d,e] S_ab[a,e]
+            st4(o + 15 * C, m[1]);        // k15  sum_e A[d,e] P[a,e,e]
+            st4(o + 4 * C, total * aay);  // k4   A[d,e] sum_{abc} P          (d = a, e = y)
+            st4(o + 13 * C, s14 * aay);   // k13  A[d,e] sum_{a,c} P[a,a,c]
+            st4(o + 14 * C, s15 * aay);   // k14  A[d,e] sum_{a,b} P[a,b,b]
+            st4(o + 17 * C, s18 * aay);   // k17  A[d,e] sum_a P[a,a,a]
+        }
+    }
+}
+
+template <int LPC>
+static size_t fwd_rows_lds_bytes(int N) {
+    constexpr int CW = 4 * LPC;
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + 2 * (size_t)N * CW + 4 * CW);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// B1: backward row kernel.  Workgroup (g, a): from G[g][a][d][k] (k = 1,7,8,15) and G[g][a][e][k] (k = 4,13,14,17)
+//   WX[a,b] = sum_d G1[a,d] r[d] + sum_d G8[a,d] A[d,b]        (cases 2, 9)
+//   WZ[a,b] = sum_d G7[a,d] r[d] + sum_d G15[a,d] A[d,b]       (cases 8, 16; applied where b == c)
+//   part[a][j] = sum_e G_{4,13,14,17}[a,e] A[a,e]              (row a of the four (d,e)-indexed cases)
+// ------------------------------------------------------------------------------------------------------------
+template <int LPC>
+__global__ __launch_bounds__(kThreads) void r18_bwd_rows(const float *__restrict__ G, const float *__restrict__ A,
+                                                         float *__restrict__ wsWX, float *__restrict__ wsWZ,
+                                                         float *__restrict__ wsPart, int N, int C, int nwin) {
+    constexpr int CW = 4 * LPC;
+    constexpr int NGRP = kThreads / LPC;
+    static_assert(NGRP >= 6, "six reductions are spread over thread groups");
+    const int tid = threadIdx.x;
+    const int grp = tid / LPC, fl = tid % LPC;
+    const BlockId B = decode_block(N, nwin);
+    const int g = B.g, a = B.i;
+    const int f = B.win * CW + 4 * fl;
+    const bool fok = f < C;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AdjLds L = load_adjacency<true>(smem, A + (size_t)g * N * N, N);  // L.A[b][d] = A+[d][b]
+    float *sT8 = smem + adj_lds_floats(N);  // [N][CW] G8[a, d]
+    float *sT15 = sT8 + N * CW;             // [N][CW] G15[a, d]
+    float *sU = sT15 + N * CW;              // [6][CW]
+
+    const float *Grow = G + (((size_t)g * N + a) * N) * (size_t)(kK * C) + f;  // + (y*18 + k)*C
+    for (int d = grp; d < N; d += NGRP) {
+        st4(sT8 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 8) * C) : splat(0.f));
+        st4(sT15 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 15) * C) : splat(0.f));
+    }
+    if (grp < 6) {
+        const int kk = (grp == 0) ? 1 : (grp == 1) ? 7 : (grp == 2) ? 4 : (grp == 3) ? 13 : (grp == 4) ? 14 : 17;
+        f4 s = splat(0.f);
+        if (fok)
+            for (int y = 0; y < N; ++y) {
+                const float w = (grp < 2) ? L.r[y] : L.A[y * (N + 1) + a];  // r[d]  or  A+[a][e]
+                s += w * ld4(Grow + ((size_t)y * kK + kk) * C);
+            }
+        st4(sU + grp * CW + 4 * fl, s);
+    }
+    __syncthreads();
+
+    const f4 u2 = ld4(sU + 0 * CW + 4 * fl), u8 = ld4(sU + 1 * CW + 4 * fl);
+    const float *const T[2] = {sT8, sT15};
+    for (int bb = grp; bb < N; bb += NGRP) {
+        f4 m[2];
+        small_matvec<2, CW>(L, N, bb, fl, T, m);  // sum_d A+[d][bb] * G[a,d]
+        if (fok) {
+            const size_t w = (((size_t)g * N + a) * N + bb) * (size_t)C + f;
+            st4(wsWX + w, u2 + m[0]);
+            st4(wsWZ + w, u8 + m[1]);
+        }
+    }
+    if (grp < 4 && fok) st4(wsPart + (((size_t)g * N + a) * 4 + grp) * (size_t)C + f, ld4(sU + (2 + grp) * CW + 4 * fl));
+}
+
+template <int LPC>
+static size_t bwd_rows_lds_bytes(int N) {
+    constexpr int CW = 4 * LPC;
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + 2 * (size_t)N * CW + 6 * CW);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// B2: backward slab kernel.  Workgroup (g, b) writes dP[g][:, b, :, :]:
+//   dP[a,b,c] = X[a] + Y[c] + G5[a,b] r[c] + G9[b,c] r[a] + [c==b] Z1[a] + [c==a] Z2[a]
+//   X[a]  = tot G0[a,b] + tr G6[a,b] + WX[a,b] + U4 + u5 + V12[a] + [a==b] u14
+//   Y[c]  = tot G2[b,c] + V13[c]
+//   Z1[a] = WZ[a,b] + u15 + [a==b] u18          Z2[a] = U11 + V17[a]
+//   U4 = sum_d G3[b,d] r[d], U11 = sum_d G10[b,d] r[d], V12[a] = sum_d G11[b,d] A[d,a], V13[c] = sum_d G12[b,d] A[d,c],
+//   V17[a] = sum_d G16[b,d] A[d,a];  u5,u14,u15,u18 = sum_a part[a][.]
+// ------------------------------------------------------------------------------------------------------------
+template <int LPC, int NI, bool FULL, bool ACC>
+__global__ __launch_bounds__(kThreads) void r18_bwd_slab(const float *__restrict__ G, const float *__restrict__ A,
+                                                         float *__restrict__ dP, const float *__restrict__ wsWX,
+                                                         const float *__restrict__ wsWZ,
+                                                         const float *__restrict__ wsPart, int N, int C, int nwin) {
+    constexpr int PPW = 64 / LPC;
+    constexpr int CW = 4 * LPC;
+    constexpr int NGRP = kThreads / LPC;
+    static_assert(NGRP >= 6, "six reductions are spread over thread groups");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = lane / LPC, fl = lane % LPC;  // streaming role
+    const int grp = tid / LPC;                   // table-building role (same fl: LPC divides 64)
+    const BlockId B = decode_block(N, nwin);
+    const int g = B.g, b = B.i;
+    const int f = B.win * CW + 4 * fl;
+    const bool fok = f < C;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AdjLds L = load_adjacency<true>(smem, A + (size_t)g * N * N, N);  // L.A[y][d] = A+[d][y]
+    float *sT11 = smem + adj_lds_floats(N);  // [N][CW] G11[b, d]
+    float *sT12 = sT11 + N * CW;             //         G12[b, d]
+    float *sT16 = sT12 + N * CW;             //         G16[b, d]
+    float *sX = sT16 + N * CW;               // [N][CW]
+    float *sY = sX + N * CW;
+    float *sG5 = sY + N * CW;
+    float *sZ1 = sG5 + N * CW;
+    float *sZ2 = sZ1 + N * CW;
+    float *sU = sZ2 + N * CW;  // [6][CW]: U4, U11, u5, u14, u15, u18
+    const float tot = L.st[0], tr = L.st[1];
+
+    const float *Grow = G + (((size_t)g * N + b) * N) * (size_t)(kK * C) + f;  // G[g][b][y][k][f]
+    for (int d = grp; d < N; d += NGRP) {
+        st4(sT11 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 11) * C) : splat(0.f));
+        st4(sT12 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 12) * C) : splat(0.f));
+        st4(sT16 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 16) * C) : splat(0.f));
+    }
+    if (grp < 6) {
+        f4 s = splat(0.f);
+        if (fok) {
+            if (grp < 2) {
+                const int kk = (grp == 0) ? 3 : 10;
+                for (int d = 0; d < N; ++d) s += L.r[d] * ld4(Grow + ((size_t)d * kK + kk) * C);
+            } else {
+                for (int aa = 0; aa < N; ++aa) s += ld4(wsPart + (((size_t)g * N + aa) * 4 + (grp - 2)) * (size_t)C + f);
+            }
+        }
+        st4(sU + grp * CW + 4 * fl, s);
+    }
+    __syncthreads();
+
+    {
+        const f4 u4 = ld4(sU + 0 * CW + 4 * fl), u11 = ld4(sU + 1 * CW + 4 * fl), u5 = ld4(sU + 2 * CW + 4 * fl);
+        const f4 u14 = ld4(sU + 3 * CW + 4 * fl), u15 = ld4(sU + 4 * CW + 4 * fl), u18 = ld4(sU + 5 * CW + 4 * fl);
+        const float *const T[3] = {sT11, sT12, sT16};
+        for (int y = grp; y < N; y += NGRP) {
+            f4 m[3];
+            small_matvec<3, CW>(L, N, y, fl, T, m);  // V12[y], V13[y], V17[y]
+            f4 g0 = splat(0.f), g6 = splat(0.f), g5 = splat(0.f), wx = splat(0.f), wz = splat(0.f), g2 = splat(0.f);
+            if (fok) {
+                const float *gab = G + (((size_t)g * N + y) * N + b) * (size_t)(kK * C) + f;  // G[g][y][b][k][f]
+                g0 = ld4(gab + 0 * C);
+                g6 = ld4(gab + 6 * C);
+                g5 = ld4(gab + 5 * C);
+                const size_t w = (((size_t)g * N + y) * N + b) * (size_t)C + f;
+                wx = ld4(wsWX + w);
+                wz = ld4(wsWZ + w);
+                g2 = ld4(Grow + ((size_t)y * kK + 2) * C);
+            }
+            f4 x = tot * g0 + tr * g6 + wx + u4 + u5 + m[0];
+            f4 z1 = wz + u15;
+            if (y == b) {
+                x += u14;
+                z1 += u18;
+            }
+            st4(sX + y * CW + 4 * fl, x);
+            st4(sY + y * CW + 4 * fl, tot * g2 + m[1]);
+            st4(sG5 + y * CW + 4 * fl, g5);
+            st4(sZ1 + y * CW + 4 * fl, z1);
+            st4(sZ2 + y * CW + 4 * fl, u11 + m[2]);
+        }
+    }
+    __syncthreads();
+
+    // streaming phase: lane-resident Y[c], G9[b,c], r[c]; one row of dP per iteration.  Branch-free like F1: ragged
+    // lanes compute on clamped addresses and only their stores are predicated.
+    f4 yv[NI], g9[NI];
+    float rc[NI];
+    int coff[NI];
+    bool live[NI];
+    const int fld = fok ? f : 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = i * PPW + cg;
+        const bool ok = FULL || (c < N);
+        const int cc = ok ? c : 0;
+        live[i] = ok && fok;
+        coff[i] = cc * C + fld;
+        rc[i] = L.r[cc];
+        yv[i] = ld4(sY + cc * CW + 4 * fl);
+        g9[i] = ld4(G + (((size_t)g * N + b) * N + cc) * (size_t)(kK * C) + 9 * C + fld);
+    }
+    const int ib = b / PPW, cgb = b % PPW;
+    float *dPg = dP + (size_t)g * N * N * N * C + (size_t)b * N * C;
+    const size_t rowStride = (size_t)N * N * C;
+    for (int a = wave; a < N; a += kWaves) {
+        float *row = dPg + a * rowStride;
+        f4 old[NI];
+        if (ACC) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) old[i] = ld4(row + coff[i]);
+        }
+        const f4 xa = ld4(sX + a * CW + 4 * fl), g5a = ld4(sG5 + a * CW + 4 * fl);
+        const float ra = L.r[a];
+        const int ia = a / PPW, cga = a % PPW;
+        const f4 z1 = ld4(sZ1 + a * CW + 4 * fl) * ((cg == cgb) ? 1.f : 0.f);
+        const f4 z2 = ld4(sZ2 + a * CW + 4 * fl) * ((cg == cga) ? 1.f : 0.f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            f4 o = xa + yv[i] + g5a * rc[i] + g9[i] * ra;
+            if (i == ib) o += z1;  // wave-uniform conditions: scalar branches
+            if (i == ia) o += z2;
+            if (ACC) o += old[i];
+            if (FULL || live[i]) st4(row + coff[i], o);
+        }
+    }
+}
+
+template <int LPC>
+static size_t bwd_slab_lds_bytes(int N) {
+    constexpr int CW = 4 * LPC;
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + 8 * (size_t)N * CW + 6 * CW);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Generic kernels: any N, any C, any alignment.  One thread per table / output element; used for shapes the slab
+// kernels do not cover and as an independent second implementation in the tests.
+// ------------------------------------------------------------------------------------------------------------
+// workspace per graph: Aplus[N*N], r[N], st[2] (tot, tr)
+__global__ void r18_gen_adj(const float *__restrict__ A, float *__restrict__ Ap, float *__restrict__ r,
+                            float *__restrict__ st, int N) {
+    const int g = blockIdx.x;
+    const float *Ag = A + (size_t)g * N * N;
+    float *Apg = Ap + (size_t)g * N * N;
+    __shared__ float sh[2];
+    if (threadIdx.x == 0) sh[0] = sh[1] = 0.f;
+    __syncthreads();
+    for (int d = threadIdx.x; d < N; d += blockDim.x) {
+        float s = 0.f;
+        for (int e = 0; e < N; ++e) {
+            float a = Ag[d * N + e];
+            a = (a > 0.f) ? a : 0.f;
+            Apg[d * N + e] = a;
+            s += a;
+        }
+        r[(size_t)g * N + d] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f, dg = 0.f;
+        for (int d = 0; d < N; ++d) {
+            t += r[(size_t)g * N + d];
+            dg += Apg[d * N + d];
+        }
+        st[2 * g] = t;
+        st[2 * g + 1] = dg;
+    }
+}
+
+// tables[g][4][N][N][C]: S_ab, T6 (r-weighted over c), S_bc, T10 (r-weighted over a)
+__global__ void r18_gen_tables(const float *__restrict__ P, const float *__restrict__ r, float *__restrict__ tab, int N,
+                               int C, size_t total) {
+    const size_t NNC = (size_t)N * N * C;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int f = idx % C;
+        size_t t = idx / C;
+        const int j = t % N;
+        t /= N;
+        const int i = t % N;
+        const size_t g = t / N;
+        const float *Pg = P + g * NNC * N;
+        const float *rg = r + g * N;
+        float sab = 0.f, t6 = 0.f, sbc = 0.f, t10 = 0.f;
+        for (int s = 0; s < N; ++s) {
+            const float pij = Pg[(((size_t)i * N + j) * N + s) * C + f];  // P[i][j][s]
+            sab += pij;
+            t6 += pij * rg[s];
+            const float psij = Pg[(((size_t)s * N + i) * N + j) * C + f];  // P[s][i][j]
+            sbc += psij;
+            t10 += psij * rg[s];
+        }
+        float *tg = tab + g * 4 * NNC + ((size_t)i * N + j) * C + f;
+        tg[0 * NNC] = sab;
+        tg[1 * NNC] = t6;
+        tg[2 * NNC] = sbc;
+        tg[3 * NNC] = t10;
+    }
+}
+
+__global__ void r18_gen_forward(const float *__restrict__ P, const float *__restrict__ Ap, const float *__restrict__ r,
+                                const float *__restrict__ st, const float *__restrict__ tab, float *__restrict__ Out,
+                                int N, int C, size_t total) {
+    const size_t NNC = (size_t)N * N * C;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int f = idx % C;
+        size_t t = idx / C;
+        const int y = t % N;
+        t /= N;
+        const int x = t % N;
+        const size_t g = t / N;
+        const float *Pg = P + g * NNC * N;
+        const float *Ag = Ap + g * N * N;
+        const float *rg = r + g * N;
+        const float tot = st[2 * g], tr = st[2 * g + 1];
+        const float *Sab = tab + g * 4 * NNC, *T6 = Sab + NNC, *Sbc = T6 + NNC, *T10 = Sbc + NNC;
+#define TAB(T, i, j) T[((size_t)(i) * N + (j)) * C + f]
+#define PP(a, b, c) Pg[(((size_t)(a) * N + (b)) * N + (c)) * C + f]
+        float rowsum = 0.f, colsum = 0.f, d8 = 0.f, d11 = 0.f, m8 = 0.f, m11 = 0.f, m12 = 0.f, m15 = 0.f, m16 = 0.f;
+        for (int e = 0; e < N; ++e) {
+            rowsum += TAB(Sab, x, e);
+            colsum += TAB(Sab, e, x);
+            d8 += PP(x, e, e);
+            d11 += PP(e, x, e);
+            const float w = Ag[y * N + e];
+            m8 += w * TAB(Sab, x, e);
+            m11 += w * TAB(Sab, e, x);
+            m12 += w * TAB(Sbc, x, e);
+            m15 += w * PP(x, e, e);
+            m16 += w * PP(e, x, e);
+        }
+        float total_ = 0.f, s14 = 0.f, s15 = 0.f, s18 = 0.f;
+        for (int i = 0; i < N; ++i) {
+            s14 += TAB(Sab, i, i);
+            s18 += PP(i, i, i);
+            for (int j = 0; j < N; ++j) {
+                total_ += TAB(Sab, i, j);
+                s15 += PP(i, j, j);
+            }
+        }
+        const float axy = Ag[x * N + y], ry = rg[y];
+        float *o = Out + (((size_t)g * N + x) * N + y) * (size_t)(kK * C) + f;
+        o[0 * C] = TAB(Sab, x, y) * tot;
+        o[1 * C] = rowsum * ry;
+        o[2 * C] = TAB(Sbc, x, y) * tot;
+        o[3 * C] = colsum * ry;
+        o[4 * C] = axy * total_;
+        o[5 * C] = TAB(T6, x, y);
+        o[6 * C] = TAB(Sab, x, y) * tr;
+        o[7 * C] = d8 * ry;
+        o[8 * C] = m8;
+        o[9 * C] = TAB(T10, x, y);
+        o[10 * C] = d11 * ry;
+        o[11 * C] = m11;
+        o[12 * C] = m12;
+        o[13 * C] = axy * s14;
+        o[14 * C] = axy * s15;
+        o[15 * C] = m15;
+        o[16 * C] = m16;
+        o[17 * C] = axy * s18;
+#undef TAB
+#undef PP
+    }
+}
+
+// scal[g][4][C]: u5, u14, u15, u18 = sum_{d,e} G_{4,13,14,17}[d,e] A+[d,e]
+__global__ void r18_gen_bwd_scalars(const float *__restrict__ G, const float *__restrict__ Ap, float *__restrict__ scal,
+                                    int N, int C, size_t total) {
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int f = idx % C;
+        const int j = (idx / C) % 4;
+        const size_t g = idx / (4 * (size_t)C);
+        const int kk = (j == 0) ? 4 : (j == 1) ? 13 : (j == 2) ? 14 : 17;
+        const float *Gg = G + g * (size_t)N * N * kK * C;
+        const float *Ag = Ap + g * N * N;
+        float s = 0.f;
+        for (int d = 0; d < N; ++d)
+            for (int e = 0; e < N; ++e) s += Gg[(((size_t)d * N + e) * kK + kk) * C + f] * Ag[d * N + e];
+        scal[idx] = s;
+    }
+}
+
+__global__ void r18_gen_backward(const float *__restrict__ G, const float *__restrict__ Ap, const float *__restrict__ r,
+                                 const float *__restrict__ st, const float *__restrict__ scal, float *__restrict__ dP,
+                                 int N, int C, size_t total, int accumulate) {
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int f = idx % C;
+        size_t t = idx / C;
+        const int c = t % N;
+        t /= N;
+        const int b = t % N;
+        t /= N;
+        const int a = t % N;
+        const size_t g = t / N;
+        const float *Gg = G + g * (size_t)N * N * kK * C;
+        const float *Ag = Ap + g * N * N;
+        const float *rg = r + g * N;
+        const float tot = st[2 * g], tr = st[2 * g + 1];
+        const float *sc = scal + g * 4 * (size_t)C;
+#define GG(x, y, k) Gg[(((size_t)(x) * N + (y)) * kK + (k)) * C + f]
+        float v = tot * GG(a, b, 0) + tr * GG(a, b, 6) + GG(a, b, 5) * rg[c] + tot * GG(b, c, 2) + GG(b, c, 9) * rg[a] +
+                  sc[0 * C + f];
+        float u2 = 0.f, u4 = 0.f, u8 = 0.f, u11 = 0.f, v9 = 0.f, v12 = 0.f, v13 = 0.f, v16 = 0.f, v17 = 0.f;
+        for (int d = 0; d < N; ++d) {
+            const float rd = rg[d];
+            u2 += GG(a, d, 1) * rd;
+            u4 += GG(b, d, 3) * rd;
+            u8 += GG(a, d, 7) * rd;
+            u11 += GG(b, d, 10) * rd;
+            v9 += GG(a, d, 8) * Ag[d * N + b];
+            v12 += GG(b, d, 11) * Ag[d * N + a];
+            v13 += GG(b, d, 12) * Ag[d * N + c];
+            v16 += GG(a, d, 15) * Ag[d * N + b];
+            v17 += GG(b, d, 16) * Ag[d * N + a];
+        }
+        v += u2 + u4 + v9 + v12 + v13;
+        if (b == c) v += u8 + v16 + sc[2 * C + f];
+        if (a == c) v += u11 + v17;
+        if (a == b) v += sc[1 * C + f];
+        if (a == b && b == c) v += sc[3 * C + f];
+#undef GG
+        if (accumulate)
+            dP[idx] += v;
+        else
+            dP[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+struct FastShape {
+    int lpc, ni, nwin;
+};
+
+bool fast_shape(int N, int C, const void *p0, const void *p1, const void *p2, FastShape *fs) {
+    if (C % 4 != 0) return false;
+    if (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15u) return false;
+    const int lpc = (C <= 16) ? 4 : (C <= 32) ? 8 : 16;
+    const int ppw = 64 / lpc;
+    const int ni = (N + ppw - 1) / ppw;
+    if (ni > 8) return false;
+    fs->lpc = lpc;
+    fs->ni = (ni <= 1) ? 1 : (ni <= 2) ? 2 : (ni <= 4) ? 4 : 8;
+    fs->nwin = (C + 4 * lpc - 1) / (4 * lpc);
+    return true;
+}
+
+// Kernels that want more than the default dynamic-LDS window must opt in once; `granted` is per instantiation.
+template <typename Kern>
+gf_status set_lds(gf_ctx *ctx, Kern kern, size_t bytes, size_t *granted) {
+    if (bytes > 160 * 1024) return fail(ctx, GF_ERR_UNSUPPORTED, "kernel needs %zu B of LDS (> 160 KiB)", bytes);
+    if (bytes > 32 * 1024 && bytes > *granted) {
+        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        *granted = bytes;
+    }
+    return GF_OK;
+}
+
+template <int LPC, int NI, bool FULL>
+gf_status launch_fwd_slab(gf_ctx *ctx, const float *P, const float *A, float *Out, float *wsSab, float *wsDbb,
+                          float *wsScal, int N, int C, unsigned grid, int nwin) {
+    const size_t l1 = fwd_slab_lds_bytes<LPC, NI>(N);
+    static size_t g1 = 0;
+    gf_status st = set_lds(ctx, r18_fwd_slab<LPC, NI, FULL>, l1, &g1);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, "r18_fwd_slab", (r18_fwd_slab<LPC, NI, FULL>), dim3(grid), dim3(kThreads), l1, P, A, Out, wsSab,
+                       wsDbb, wsScal, N, C, nwin);
+    return GF_OK;
+}
+
+template <int LPC, int NI>
+gf_status launch_fwd(gf_ctx *ctx, const float *P, const float *A, float *Out, float *wsSab, float *wsDbb, float *wsScal,
+                     int N, int C, int batch, int nwin) {
+    const unsigned grid = (unsigned)((size_t)batch * N * nwin);
+    const size_t l2 = fwd_rows_lds_bytes<LPC>(N);
+    static size_t g2 = 0;
+    const bool full = (N == NI * (64 / LPC)) && (C % (4 * LPC) == 0);
+    gf_status st = full ? launch_fwd_slab<LPC, NI, true>(ctx, P, A, Out, wsSab, wsDbb, wsScal, N, C, grid, nwin)
+                        : launch_fwd_slab<LPC, NI, false>(ctx, P, A, Out, wsSab, wsDbb, wsScal, N, C, grid, nwin);
+    if (st != GF_OK) return st;
+    st = set_lds(ctx, r18_fwd_rows<LPC>, l2, &g2);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, "r18_fwd_rows", (r18_fwd_rows<LPC>), dim3(grid), dim3(kThreads), l2, A, Out, wsSab, wsDbb, wsScal, N,
+                       C, nwin);
+    return GF_OK;
+}
+
+template <int LPC, int NI, bool FULL, bool ACC>
+gf_status launch_bwd_slab(gf_ctx *ctx, const float *G, const float *A, float *dP, float *wsWX, float *wsWZ,
+                          float *wsPart, int N, int C, unsigned grid, int nwin) {
+    const size_t l2 = bwd_slab_lds_bytes<LPC>(N);
+    static size_t g2 = 0;
+    gf_status st = set_lds(ctx, r18_bwd_slab<LPC, NI, FULL, ACC>, l2, &g2);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, "r18_bwd_slab", (r18_bwd_slab<LPC, NI, FULL, ACC>), dim3(grid), dim3(kThreads), l2, G, A, dP, wsWX,
+                       wsWZ, wsPart, N, C, nwin);
+    return GF_OK;
+}
+
+template <int LPC, int NI>
+gf_status launch_bwd(gf_ctx *ctx, const float *G, const float *A, float *dP, float *wsWX, float *wsWZ, float *wsPart,
+                     int N, int C, int batch, int nwin, int accumulate) {
+    const unsigned grid = (unsigned)((size_t)batch * N * nwin);
+    const size_t l1 = bwd_rows_lds_bytes<LPC>(N);
+    static size_t g1 = 0;
+    gf_status st = set_lds(ctx, r18_bwd_rows<LPC>, l1, &g1);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, "r18_bwd_rows", (r18_bwd_rows<LPC>), dim3(grid), dim3(kThreads), l1, G, A, wsWX, wsWZ, wsPart, N, C,
+                       nwin);
+    const bool full = (N == NI * (64 / LPC)) && (C % (4 * LPC) == 0);
+    if (full)
+        return accumulate ? launch_bwd_slab<LPC, NI, true, true>(ctx, G, A, dP, wsWX, wsWZ, wsPart, N, C, grid, nwin)
+                          : launch_bwd_slab<LPC, NI, true, false>(ctx, G, A, dP, wsWX, wsWZ, wsPart, N, C, grid, nwin);
+    return accumulate ? launch_bwd_slab<LPC, NI, false, true>(ctx, G, A, dP, wsWX, wsWZ, wsPart, N, C, grid, nwin)
+                      : launch_bwd_slab<LPC, NI, false, false>(ctx, G, A, dP, wsWX, wsWZ, wsPart, N, C, grid, nwin);
+}
+
+#define GF_DISPATCH_NI(FN, LPC, ...)                     \
+    switch (fs.ni) {                                     \
+        case 1: return FN<LPC, 1>(__VA_ARGS__);          \
+        case 2: return FN<LPC, 2>(__VA_ARGS__);          \
+        case 4: return FN<LPC, 4>(__VA_ARGS__);          \
+        default: return FN<LPC, 8>(__VA_ARGS__);         \
+    }
+#define GF_DISPATCH(FN, ...)                                           \
+    switch (fs.lpc) {                                                  \
+        case 4: GF_DISPATCH_NI(FN, 4, __VA_ARGS__)                     \
+        case 8: GF_DISPATCH_NI(FN, 8, __VA_ARGS__)                     \
+        default: GF_DISPATCH_NI(FN, 16, __VA_ARGS__)                   \
+    }
+
+unsigned gen_grid(size_t total) {
+    size_t blocks = (total + 255) / 256;
+    return (unsigned)(blocks > 65536 ? 65536 : (blocks == 0 ? 1 : blocks));
+}
+
+size_t fast_ws_floats(int N, int C, int batch) { return (size_t)batch * (2 * (size_t)N * N * C + 4 * (size_t)N * C); }
+size_t gen_ws_floats(int N, int C, int batch) {
+    return (size_t)batch * ((size_t)N * N + N + 2 + 4 * (size_t)N * N * C + 4 * (size_t)C) + 64;
+}
+
+}  // namespace
+
+size_t r18_workspace_bytes(int N, int C, int batch) {
+    const size_t a = fast_ws_floats(N, C, batch), b = gen_ws_floats(N, C, batch);
+    return sizeof(float) * (a > b ? a : b) + 256;
+}
+
+static int g_force_generic = 0;  // test hook (gf_debug_force_generic)
+
+gf_status r18_forward(gf_ctx *ctx, const float *P, const float *A, float *Out, int N, int C, int batch) {
+    gf_status st = ensure_ws(ctx, r18_workspace_bytes(N, C, batch));
+    if (st != GF_OK) return st;
+    float *ws = static_cast<float *>(ctx->ws);
+    FastShape fs;
+    if (!g_force_generic && fast_shape(N, C, P, Out, nullptr, &fs)) {
+        const size_t nnc = (size_t)batch * N * N * C;
+        float *wsSab = ws, *wsDbb = ws + nnc, *wsScal = ws + 2 * nnc;
+        GF_DISPATCH(launch_fwd, ctx, P, A, Out, wsSab, wsDbb, wsScal, N, C, batch, fs.nwin)
+    }
+    float *Ap = ws;
+    float *r = Ap + (size_t)batch * N * N;
+    float *stv = r + (size_t)batch * N;
+    float *tab = stv + align_up((size_t)batch * 2, 4);
+    GF_LAUNCH(ctx, "r18_gen_adj", r18_gen_adj, dim3(batch), dim3(64), 0, A, Ap, r, stv, N);
+    const size_t total = (size_t)batch * N * N * C;
+    GF_LAUNCH(ctx, "r18_gen_tables", r18_gen_tables, dim3(gen_grid(total)), dim3(256), 0, P, r, tab, N, C, total);
+    GF_LAUNCH(ctx, "r18_gen_forward", r18_gen_forward, dim3(gen_grid(total)), dim3(256), 0, P, Ap, r, stv, tab, Out, N, C,
+                       total);
+    return GF_OK;
+}
+
+gf_status r18_backward(gf_ctx *ctx, const float *G, const float *A, float *dP, int N, int C, int batch, int accumulate) {
+    gf_status st = ensure_ws(ctx, r18_workspace_bytes(N, C, batch));
+    if (st != GF_OK) return st;
+    float *ws = static_cast<float *>(ctx->ws);
+    FastShape fs;
+    if (!g_force_generic && fast_shape(N, C, G, dP, nullptr, &fs)) {
+        const size_t nnc = (size_t)batch * N * N * C;
+        float *wsWX = ws, *wsWZ = ws + nnc, *wsPart = ws + 2 * nnc;
+        GF_DISPATCH(launch_bwd, ctx, G, A, dP, wsWX, wsWZ, wsPart, N, C, batch, fs.nwin, accumulate)
+    }
+    float *Ap = ws;
+    float *r = Ap + (size_t)batch * N * N;
+    float *stv = r + (size_t)batch * N;
+    float *scal = stv + align_up((size_t)batch * 2, 4);
+    GF_LAUNCH(ctx, "r18_gen_adj", r18_gen_adj, dim3(batch), dim3(64), 0, A, Ap, r, stv, N);
+    const size_t nsc = (size_t)batch * 4 * C;
+    GF_LAUNCH(ctx, "r18_gen_bwd_scalars", r18_gen_bwd_scalars, dim3(gen_grid(nsc)), dim3(256), 0, G, Ap, scal, N, C, nsc);
+    const size_t total = (size_t)batch * N * N * N * C;
+    GF_LAUNCH(ctx, "r18_gen_backward", r18_gen_backward, dim3(gen_grid(total)), dim3(256), 0, G, Ap, r, stv, scal, dP, N, C,
+                       total, accumulate);
+    return GF_OK;
+}
+
+void r18_force_generic(int on) { g_force_generic = on; }
+
+}  // namespace gf

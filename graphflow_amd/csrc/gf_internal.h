@@ -1,0 +1,91 @@
+// gf_internal.h -- shared by the translation units of libgf_hip.so (not part of the public ABI).
+#ifndef GF_INTERNAL_H_INCLUDED
+#define GF_INTERNAL_H_INCLUDED
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdio>
+#include <vector>
+
+#include "gf_hip.h"
+
+struct gf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    void *ws = nullptr;  // device scratch, grown on demand (never inside a timed region if gf_ctx_reserve was called)
+    size_t ws_bytes = 0;
+    void *stage = nullptr;  // device staging for the host-pointer (mode A) entry points
+    size_t stage_bytes = 0;
+    void *pinned = nullptr;  // pinned host staging for mode A
+    size_t pinned_bytes = 0;
+    char err[512] = {0};
+    // optional per-kernel timing (gf_ctx_set_timing): HIP events around every launch on ctx->stream
+    bool timing = false;
+    struct Timer {
+        const char *name;
+        double ms;
+        long long launches;
+    };
+    struct Pending {
+        int slot;
+        hipEvent_t start, stop;
+    };
+    std::vector<Timer> timers;
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace gf {
+
+gf_status fail(gf_ctx *ctx, gf_status st, const char *fmt, ...);
+gf_status ensure_ws(gf_ctx *ctx, size_t bytes);
+gf_status ensure_stage(gf_ctx *ctx, size_t bytes);
+gf_status ensure_pinned(gf_ctx *ctx, size_t bytes);
+
+#define GF_HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return gf::fail((ctx), GF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                            __FILE__, __LINE__);                                                   \
+    } while (0)
+
+#define GF_LAUNCH_CHECK(ctx, what)                                                                  \
+    do {                                                                                            \
+        hipError_t e__ = hipGetLastError();                                                         \
+        if (e__ != hipSuccess)                                                                      \
+            return gf::fail((ctx), GF_ERR_HIP, "launch of %s failed: %s", (what), hipGetErrorString(e__)); \
+    } while (0)
+
+// Brackets one kernel launch with HIP events when ctx->timing is on (otherwise free).
+struct LaunchTimer {
+    gf_ctx *ctx;
+    int slot = -1;
+    hipEvent_t start = nullptr, stop = nullptr;
+    LaunchTimer(gf_ctx *c, const char *name);
+    void done();
+};
+gf_status resolve_timers(gf_ctx *ctx);
+
+#define GF_LAUNCH(ctx, name, kern, grid, block, lds, ...)                                  \
+    do {                                                                                   \
+        gf::LaunchTimer lt__((ctx), (name));                                               \
+        hipLaunchKernelGGL(kern, grid, block, lds, (ctx)->stream, __VA_ARGS__);           \
+        lt__.done();                                                                       \
+        GF_LAUNCH_CHECK((ctx), (name));                                                    \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- contraction back ends (device pointers, stream = ctx->stream) --------------------------------------------
+// r18: hand-specialised slab kernels (contract18.hip); fall back to the generic table kernels when the shape is
+// outside the fast path.
+gf_status r18_forward(gf_ctx *ctx, const float *P, const float *A, float *Out, int N, int C, int batch);
+gf_status r18_backward(gf_ctx *ctx, const float *G, const float *A, float *dP, int N, int C, int batch, int accumulate);
+size_t r18_workspace_bytes(int N, int C, int batch);
+
+}  // namespace gf
+#endif

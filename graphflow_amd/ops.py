@@ -1,0 +1,115 @@
+"""Device-pointer ("mode B") entry points of the C ABI, taking torch CUDA tensors for storage only."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class GraphFlowHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("gf_hip status %d: %s" % (status, message))
+        self.status = status
+
+
+class Context:
+    """gf_ctx wrapper.  By default it runs on torch's current stream of `device`, so torch ops and gf kernels
+    order naturally; pass own_stream=True for a private non-blocking stream (gf_ctx_create with stream == NULL)."""
+
+    def __init__(self, device=0, own_stream=False):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise GraphFlowHipError(_lib.GF_ERR_HIP, "no HIP device visible to torch; graphflow_amd has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        handle = C.c_void_p()
+        stream = None if own_stream else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        st = self.lib.gf_ctx_create(C.byref(handle), device, stream)
+        if st != _lib.GF_OK:
+            raise GraphFlowHipError(st, self.lib.gf_last_error(None).decode())
+        self.handle = handle
+
+    def check(self, st):
+        if st != _lib.GF_OK:
+            raise GraphFlowHipError(st, self.lib.gf_last_error(self.handle).decode())
+
+    def use_torch_stream(self, stream=None):
+        stream = stream or torch.cuda.current_stream(self.device)
+        self.check(self.lib.gf_ctx_set_stream(self.handle, C.c_void_p(stream.cuda_stream)))
+
+    @property
+    def stream_handle(self):
+        return self.lib.gf_ctx_get_stream(self.handle)
+
+    def synchronize(self):
+        self.check(self.lib.gf_ctx_synchronize(self.handle))
+
+    def reserve(self, nbytes):
+        self.check(self.lib.gf_ctx_reserve(self.handle, int(nbytes)))
+
+    def set_timing(self, enable=True):
+        """Per-kernel HIP-event timing on the context stream (gf_ctx_set_timing)."""
+        self.check(self.lib.gf_ctx_set_timing(self.handle, 1 if enable else 0))
+
+    def timings(self):
+        """{kernel name: (total_ms, launches)} since timing was enabled; synchronises the stream."""
+        out = {}
+        for i in range(self.lib.gf_ctx_timing_count(self.handle)):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_longlong()
+            self.check(self.lib.gf_ctx_timing_get(self.handle, i, C.byref(name), C.byref(ms), C.byref(n)))
+            out[name.value.decode()] = (ms.value, n.value)
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gf_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = {}
+
+
+def default_context(device=0):
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]
+
+
+def _dev_f32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise TypeError("%s must be a contiguous float32 CUDA tensor" % name)
+    return C.c_void_p(t.data_ptr())
+
+
+def contract_workspace_bytes(K, N, C_, batch):
+    return _lib.load().gf_contract_workspace_bytes(K, N, C_, batch)
+
+
+def contract_forward(P, A, K=18, out=None, ctx=None):
+    """P [B,N,N,N,C], A [B,N,N] (ignored for K=4) -> Out [B,N,N,K,C].  RisiContraction_K::forward."""
+    B, N, _, _, C_ = P.shape
+    ctx = ctx or default_context(P.device.index or 0)
+    if out is None:
+        out = torch.empty((B, N, N, K, C_), dtype=torch.float32, device=P.device)
+    a_ptr = _dev_f32(A, "A") if A is not None else None
+    ctx.check(ctx.lib.gf_contract_forward_f32(ctx.handle, K, _dev_f32(P, "P"), a_ptr, _dev_f32(out, "out"), N, C_, B))
+    return out
+
+
+def contract_backward(G, A, K=18, dP=None, accumulate=False, ctx=None):
+    """G [B,N,N,K,C] -> dP [B,N,N,N,C] (+= when accumulate).  RisiContraction_K::backward; A gets no gradient."""
+    B, N, _, _, C_ = G.shape
+    ctx = ctx or default_context(G.device.index or 0)
+    if dP is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs the dP tensor to accumulate into")
+        dP = torch.empty((B, N, N, N, C_), dtype=torch.float32, device=G.device)
+    a_ptr = _dev_f32(A, "A") if A is not None else None
+    ctx.check(ctx.lib.gf_contract_backward_f32(ctx.handle, K, _dev_f32(G, "G"), a_ptr, _dev_f32(dP, "dP"), N, C_, B,
+                                               1 if accumulate else 0))
+    return dP

@@ -1,0 +1,92 @@
+/*
+ * gf_hip.h -- C ABI of libgf_hip.so: MI355X (gfx950) kernels for GraphFlow's second-order CCN/SMP hot path.
+ *
+ * Boundary contract.  Plain pointers and sizes only; no C++/torch types.  Every entry point
+ * returns a gf_status (never aborts, unlike the reference's assert()s) and records a message retrievable with
+ * gf_last_error().  Each declaration cites the reference interface it replaces (paths relative to the
+ * HyTruongSon/GraphFlow tree).
+ *
+ * Two calling modes share the same kernels:
+ *   mode B "device"  *_f32   : device pointers, a batch of independent graphs, asynchronous on the context's
+ *                              HIP stream.  This is the measured path.
+ *   mode A "host"    *_host_*: host pointers in the reference's own container layout (N separate Tensor3D
+ *                              buffers, double or float); the call stages H2D, runs the same kernels, stages D2H
+ *                              and synchronises -- what an Entity-style op's forward()/backward() calls, exactly
+ *                              as GraphFlow_gpu/RisiContraction_18_gpu.h:1509-1562 does around its CUDA kernel.
+ *
+ * Layouts (row-major, channel fastest):
+ *   P   [batch][N][N][N][C]   P[g][a][b][c][f]  == tensors[a]->value[(b*N+c)*C+f]     (RisiContraction_18.h:48-53)
+ *   A   [batch][N][N]         adj->value[d*N+e]                                        (Matrix.h:34-36)
+ *   Out [batch][N][N][K][C]   value[(x*N+y)*K*C + k*C + f]                             (RisiContraction_18.h:29,103)
+ *   G   same shape as Out (the op's own `gradient`), dP same shape as P (the inputs' `gradient`).
+ */
+#ifndef GF_HIP_H_INCLUDED
+#define GF_HIP_H_INCLUDED
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gf_ctx gf_ctx;
+
+typedef enum {
+    GF_OK = 0,
+    GF_ERR_INVALID = 1,     /* bad argument (null pointer, non-positive size, unknown K) */
+    GF_ERR_HIP = 2,         /* a HIP runtime call or kernel launch failed */
+    GF_ERR_NOMEM = 3,       /* workspace allocation failed */
+    GF_ERR_UNSUPPORTED = 4  /* shape outside what the kernels implement */
+} gf_status;
+
+/* ---- context: device + stream + workspace ---------------------------------------------------------------------
+ * Replaces the per-op-object cudaMalloc'd buffers and optional cudaStream_t of RisiContraction_18_gpu
+ * (GraphFlow_gpu/RisiContraction_18_gpu.h:853-874, 947-955).  One context per host thread / per GPU; not thread-safe,
+ * matching the reference's "one model clone per worker thread" rule (SMP_omega.h:115-129).
+ * `stream` is a hipStream_t (NULL = the context creates and owns a non-blocking stream).                          */
+gf_status gf_ctx_create(gf_ctx **out, int device, void *stream);
+gf_status gf_ctx_destroy(gf_ctx *ctx);
+gf_status gf_ctx_set_stream(gf_ctx *ctx, void *stream);     /* RisiContraction_18_gpu::set_gpu_stream (:947) */
+void     *gf_ctx_get_stream(gf_ctx *ctx);
+gf_status gf_ctx_synchronize(gf_ctx *ctx);                  /* cudaStreamSynchronize in SMP_omega_gpu_multistreams.h:765-771 */
+gf_status gf_ctx_reserve(gf_ctx *ctx, size_t workspace_bytes); /* pre-size the scratch so timed regions never allocate */
+/* Tracing: per-kernel HIP-event timing on the context's stream (the reference only has wall-clock gettimeofday in its
+ * tests, tests/test_RisiContraction_18_gpu.cu:31-40).  Enabling resets the table; reading synchronises the stream. */
+gf_status gf_ctx_set_timing(gf_ctx *ctx, int enable);
+int       gf_ctx_timing_count(gf_ctx *ctx);
+gf_status gf_ctx_timing_get(gf_ctx *ctx, int index, const char **name, double *total_ms, long long *launches);
+const char *gf_last_error(gf_ctx *ctx);                     /* valid until the next call on ctx; ctx may be NULL for create errors */
+const char *gf_version(void);
+
+/* ---- tensor contractions, mode B (device pointers, batched) -----------------------------------------------------
+ * K selects the family: 4, 10, 18 or 50.
+ *   K=18: RisiContraction_18::forward/backward (GraphFlow/RisiContraction_18.h:73-331, 333-560), A gated by A>0 (:90,:345)
+ *   K=10: RisiContraction_10 (RisiContraction_10.h:73-153, 155-225), no gate
+ *   K=50: RisiContraction_50 (RisiContraction_50.h:73-441, 443-802), no gate
+ *   K=4 : RisiContraction_4  (RisiContraction_4.h:68-125, 127-173), A ignored (may be NULL)
+ * forward : Out is overwritten (the reference zeroes value first).
+ * backward: accumulate != 0 -> dP += vjp (the reference's `+=` contract); accumulate == 0 -> dP = vjp (write-only
+ *           fast path, legal when dP has a single consumer, as in the SMP DAG).  A receives no gradient.             */
+gf_status gf_contract_forward_f32(gf_ctx *ctx, int K, const float *P, const float *A, float *Out,
+                                  int N, int C, int batch);
+gf_status gf_contract_backward_f32(gf_ctx *ctx, int K, const float *G, const float *A, float *dP,
+                                   int N, int C, int batch, int accumulate);
+/* Scratch bytes the two calls above need for (K,N,C,batch); gf_ctx_reserve(max over your shapes) up front. */
+size_t gf_contract_workspace_bytes(int K, int N, int C, int batch);
+
+/* ---- tensor contractions, mode A (host pointers, one graph, reference container layout) --------------------------
+ * tensors[a] points at the a-th neighbour's Tensor3D::value ([N][N][C]); grads[a] at its ::gradient (always `+=`).
+ * Blocking: returns after the result is in host memory.                                                              */
+gf_status gf_contract_forward_host_f64(gf_ctx *ctx, int K, const double *const *tensors, const double *A,
+                                       double *out_value, int N, int C);
+gf_status gf_contract_backward_host_f64(gf_ctx *ctx, int K, const double *out_gradient, const double *A,
+                                        double *const *grads, int N, int C);
+gf_status gf_contract_forward_host_f32(gf_ctx *ctx, int K, const float *const *tensors, const float *A,
+                                       float *out_value, int N, int C);
+gf_status gf_contract_backward_host_f32(gf_ctx *ctx, int K, const float *out_gradient, const float *A,
+                                        float *const *grads, int N, int C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GF_HIP_H_INCLUDED */

@@ -1,0 +1,212 @@
+"""ctypes bindings for the CHECKERS: oracle/libgf_oracle.so (our fp64 restatement) and, when present,
+oracle/_ref/libgf_ref.so (the real reference, built from /root/reference by oracle/Makefile).
+
+TEST INFRASTRUCTURE ONLY -- importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (graphflow_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i = C.c_int
+
+
+def build(force=False):
+    """Compile the C restatement (and the reference shim when /root/reference is mounted)."""
+    so = os.path.join(_HERE, "libgf_oracle.so")
+    src = os.path.join(_HERE, "gf_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libgf_oracle.so"])
+    ref_root = os.environ.get("GF_REFERENCE", "/root/reference")
+    ref_so = os.path.join(_HERE, "_ref", "libgf_ref.so")
+    shim = os.path.join(_HERE, "ref_shim.cpp")
+    if os.path.isdir(os.path.join(ref_root, "GraphFlow")):
+        if force or not os.path.exists(ref_so) or os.path.getmtime(ref_so) < os.path.getmtime(shim):
+            subprocess.check_call(["make", "-C", _HERE, "ref", "GF_REFERENCE=" + ref_root])
+
+
+def _load(path):
+    return C.CDLL(path) if os.path.exists(path) else None
+
+
+class _Lib:
+    """Shared numpy-facing surface of both checkers (prefix 'gfo_' or 'ref_')."""
+
+    def __init__(self, lib, kind):
+        self.lib = lib
+        self.kind = kind
+
+    # -- contractions -------------------------------------------------------------------------
+    def contract_forward(self, K, P, A=None):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        N, C_ = P.shape[0], P.shape[3]
+        out = np.zeros((N, N, K, C_), dtype=np.float64)
+        if K == 4:
+            f = getattr(self.lib, self._n("r4_forward"))
+            f.argtypes = [_dp, _dp, _i, _i]
+            f.restype = None
+            f(P, out, N, C_)
+            return out
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        if self.kind == "oracle":
+            f = self.lib.gfo_contract_forward
+            f.argtypes = [_i, _dp, _dp, _dp, _i, _i]
+            f.restype = _i
+            assert f(K, P, A, out, N, C_) == 0
+        else:
+            f = getattr(self.lib, "ref_r%d_forward" % K)
+            f.argtypes = [_dp, _dp, _dp, _i, _i]
+            f.restype = None
+            f(P, A, out, N, C_)
+        return out
+
+    def contract_backward(self, K, G, A=None, dP0=None):
+        """Returns dP0 + vjp (the reference accumulates into the inputs' gradient)."""
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        N, C_ = G.shape[0], G.shape[3]
+        dP = np.zeros((N, N, N, C_), dtype=np.float64) if dP0 is None else np.array(dP0, dtype=np.float64, order="C")
+        if K == 4:
+            f = getattr(self.lib, self._n("r4_backward"))
+            f.argtypes = [_dp, _dp, _i, _i]
+            f.restype = None
+            f(G, dP, N, C_)
+            return dP
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        if self.kind == "oracle":
+            f = self.lib.gfo_contract_backward
+            f.argtypes = [_i, _dp, _dp, _dp, _i, _i]
+            f.restype = _i
+            assert f(K, G, A, dP, N, C_) == 0
+        else:
+            f = getattr(self.lib, "ref_r%d_backward" % K)
+            f.argtypes = [_dp, _dp, _dp, _i, _i]
+            f.restype = None
+            f(G, A, dP, N, C_)
+        return dP
+
+    def r18_thread_forward(self, P, A):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        N, C_ = P.shape[0], P.shape[3]
+        out = np.zeros((N, N, 18, C_), dtype=np.float64)
+        f = getattr(self.lib, self._n("r18_thread_forward"))
+        f.argtypes = [_dp, _dp, _dp, _i, _i]
+        f.restype = None
+        f(P, A, out, N, C_)
+        return out
+
+    # -- mixers ---------------------------------------------------------------------------------
+    def matmul_forward(self, A, B):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        M, K = A.shape
+        N = B.shape[1]
+        out = np.zeros((M, N))
+        f = getattr(self.lib, self._n("matmul_forward"))
+        f.argtypes = [_dp, _dp, _dp, _i, _i, _i]
+        f.restype = None
+        f(A, B, out, M, K, N)
+        return out
+
+    def matmul_backward(self, dC, A, B, dA0=None, dB0=None):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        dC = np.ascontiguousarray(dC, dtype=np.float64)
+        M, K = A.shape
+        N = B.shape[1]
+        dA = np.zeros_like(A) if dA0 is None else np.array(dA0, dtype=np.float64, order="C")
+        dB = np.zeros_like(B) if dB0 is None else np.array(dB0, dtype=np.float64, order="C")
+        f = getattr(self.lib, self._n("matmul_backward"))
+        f.argtypes = [_dp, _dp, _dp, _dp, _dp, _i, _i, _i]
+        f.restype = None
+        f(dC, A, B, dA, dB, M, K, N)
+        return dA, dB
+
+    def _tm(self, name, first, second, out_shape, dims):
+        out = np.zeros(out_shape)
+        f = getattr(self.lib, self._n(name))
+        f.argtypes = [_dp, _dp, _dp, _i, _i, _i, _i]
+        f.restype = None
+        f(np.ascontiguousarray(first, dtype=np.float64), np.ascontiguousarray(second, dtype=np.float64), out, *dims)
+        return out
+
+    def mattensormul_forward(self, X, F):
+        R, Kd = X.shape
+        _, J, D = F.shape
+        return self._tm("mattensormul_forward", X, F, (R, J, D), (R, Kd, J, D))
+
+    def tensormatmul_forward(self, F, Y):
+        R, Kd, D = F.shape
+        J = Y.shape[1]
+        return self._tm("tensormatmul_forward", F, Y, (R, J, D), (R, Kd, J, D))
+
+    def _tmb(self, name, G, first, second, dims):
+        d1 = np.zeros(np.shape(first))
+        d2 = np.zeros(np.shape(second))
+        f = getattr(self.lib, self._n(name))
+        f.argtypes = [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i]
+        f.restype = None
+        f(np.ascontiguousarray(G, dtype=np.float64), np.ascontiguousarray(first, dtype=np.float64),
+          np.ascontiguousarray(second, dtype=np.float64), d1, d2, *dims)
+        return d1, d2
+
+    def mattensormul_backward(self, G, X, F):
+        R, Kd = X.shape
+        _, J, D = F.shape
+        return self._tmb("mattensormul_backward", G, X, F, (R, Kd, J, D))  # (dX, dF)
+
+    def tensormatmul_backward(self, G, F, Y):
+        R, Kd, D = F.shape
+        J = Y.shape[1]
+        return self._tmb("tensormatmul_backward", G, F, Y, (R, Kd, J, D))  # (dF, dY)
+
+    def _n(self, name):
+        return ("gfo_" if self.kind == "oracle" else "ref_") + name
+
+
+def oracle():
+    build()
+    return _Lib(C.CDLL(os.path.join(_HERE, "libgf_oracle.so")), "oracle")
+
+
+def reference():
+    """The real reference, or None when oracle/_ref/libgf_ref.so has not been built/shipped."""
+    lib = _load(os.path.join(_HERE, "_ref", "libgf_ref.so"))
+    return _Lib(lib, "reference") if lib is not None else None
+
+
+# -- CPU-baseline timing entry points (bench.py) -----------------------------------------------------
+def time_r18_fwd_bwd(P, A, G, prefer_reference=True):
+    """Seconds for ONE RisiContraction_18 forward+backward on one graph, single host thread.
+    Returns (seconds, kind) with kind 'reference' (real GraphFlow code) or 'port' (gf_oracle.c loop nests)."""
+    import time
+
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    G = np.ascontiguousarray(G, dtype=np.float64)
+    N, C_ = P.shape[0], P.shape[3]
+    out = np.zeros((N, N, 18, C_))
+    dP = np.zeros_like(P)
+    ref = reference() if prefer_reference else None
+    if ref is not None:
+        f = ref.lib.ref_r18_fwd_bwd
+        f.argtypes = [_dp, _dp, _dp, _dp, _dp, _i, _i]
+        f.restype = None
+        t0 = time.perf_counter()
+        f(P, A, G, out, dP, N, C_)
+        return time.perf_counter() - t0, "reference", out, dP
+    orc = oracle()
+    fw = orc.lib.gfo_r18_loops_forward
+    fw.argtypes = [_dp, _dp, _dp, _i, _i]
+    fw.restype = None
+    bw = orc.lib.gfo_r18_loops_backward
+    bw.argtypes = [_dp, _dp, _dp, _i, _i]
+    bw.restype = None
+    t0 = time.perf_counter()
+    fw(P, A, out, N, C_)
+    bw(G, A, dP, N, C_)
+    return time.perf_counter() - t0, "port", out, dP

@@ -1,0 +1,250 @@
+// ref_shim.cpp -- C-ABI shim around the REAL reference headers (fp64 GraphFlow/ variant).
+//
+// TEST INFRASTRUCTURE ONLY.  Built by oracle/Makefile with
+//     g++ -std=c++11 -O2 -DNDEBUG -pthread -I$(GF_REFERENCE)/GraphFlow ref_shim.cpp
+// into oracle/_ref/libgf_ref.so (git-ignored; it is a build of GPL-3 reference code and never
+// enters history).  No reference source is copied here: this file only #includes the headers
+// where they lie under /root/reference and marshals plain buffers in and out of the reference's
+// own op objects.  Used to (a) generate tests/golden/*.npz, (b) validate oracle/gf_oracle.c,
+// (c) serve as the "reference"-kind CPU baseline in bench.py.
+//
+// -DNDEBUG is required because RisiContraction_18_thread's constructors assert(DEPRECATED == false)
+// (RisiContraction_18_thread.h:27,33,784).
+#include <cstddef>
+#include <vector>
+
+#include "Matrix.h"
+#include "Tensor3D.h"
+#include "Tensor4D.h"
+#include "RisiContraction_4.h"
+#include "RisiContraction_10.h"
+#include "RisiContraction_18.h"
+#include "RisiContraction_18_thread.h"
+#include "RisiContraction_50.h"
+#include "MatMul.h"
+#include "MatTensorMul.h"
+#include "TensorMatMul.h"
+#include "StackTensor3D.h"
+
+namespace {
+
+struct Neighbourhood {
+    std::vector<Tensor3D *> t;
+    Matrix *adj;
+    int N, C;
+    Neighbourhood(const double *P, const double *dP, const double *A, int N_, int C_) : adj(NULL), N(N_), C(C_) {
+        const size_t per = (size_t)N * N * C;
+        for (int a = 0; a < N; ++a) {
+            Tensor3D *x = new Tensor3D(N, N, C);
+            for (size_t i = 0; i < per; ++i) {
+                x->value[i] = P ? P[a * per + i] : 0.0;
+                x->gradient[i] = dP ? dP[a * per + i] : 0.0;
+            }
+            t.push_back(x);
+        }
+        if (A) {
+            adj = new Matrix(N, N);
+            for (int i = 0; i < N * N; ++i) adj->value[i] = A[i];
+        }
+    }
+    void grads_out(double *dP) const {
+        const size_t per = (size_t)N * N * C;
+        for (int a = 0; a < N; ++a)
+            for (size_t i = 0; i < per; ++i) dP[a * per + i] = t[a]->gradient[i];
+    }
+    ~Neighbourhood() {
+        for (size_t i = 0; i < t.size(); ++i) delete t[i];
+        delete adj;
+    }
+};
+
+template <class Op>
+void bind(Op &op, Neighbourhood &nb, bool with_adj) {
+    op.clear();
+    for (int a = 0; a < nb.N; ++a) op.add_tensor(nb.t[a]);
+    (void)with_adj;
+}
+
+template <class Op>
+void contract_fwd(const double *P, const double *A, double *Out, int N, int C) {
+    Neighbourhood nb(P, NULL, A, N, C);
+    Op op(N, C);
+    bind(op, nb, true);
+    op.set_adjacency(nb.adj);
+    op.forward();
+    for (int i = 0; i < op.size; ++i) Out[i] = op.value[i];
+}
+
+template <class Op>
+void contract_bwd(const double *G, const double *A, double *dP, int N, int C) {
+    Neighbourhood nb(NULL, dP, A, N, C);
+    Op op(N, C);
+    bind(op, nb, true);
+    op.set_adjacency(nb.adj);
+    for (int i = 0; i < op.size; ++i) op.gradient[i] = G[i];
+    op.backward();
+    nb.grads_out(dP);
+}
+
+}  // namespace
+
+extern "C" {
+
+void ref_r18_forward(const double *P, const double *A, double *Out, int N, int C) {
+    contract_fwd<RisiContraction_18>(P, A, Out, N, C);
+}
+void ref_r18_backward(const double *G, const double *A, double *dP, int N, int C) {
+    contract_bwd<RisiContraction_18>(G, A, dP, N, C);
+}
+void ref_r18_thread_forward(const double *P, const double *A, double *Out, int N, int C) {
+    contract_fwd<RisiContraction_18_thread>(P, A, Out, N, C);
+}
+void ref_r10_forward(const double *P, const double *A, double *Out, int N, int C) {
+    contract_fwd<RisiContraction_10>(P, A, Out, N, C);
+}
+void ref_r10_backward(const double *G, const double *A, double *dP, int N, int C) {
+    contract_bwd<RisiContraction_10>(G, A, dP, N, C);
+}
+void ref_r50_forward(const double *P, const double *A, double *Out, int N, int C) {
+    contract_fwd<RisiContraction_50>(P, A, Out, N, C);
+}
+void ref_r50_backward(const double *G, const double *A, double *dP, int N, int C) {
+    contract_bwd<RisiContraction_50>(G, A, dP, N, C);
+}
+
+void ref_r4_forward(const double *P, double *Out, int N, int C) {
+    Neighbourhood nb(P, NULL, NULL, N, C);
+    RisiContraction_4 op(N, C);
+    bind(op, nb, false);
+    op.forward();
+    for (int i = 0; i < op.size; ++i) Out[i] = op.value[i];
+}
+void ref_r4_backward(const double *G, double *dP, int N, int C) {
+    Neighbourhood nb(NULL, dP, NULL, N, C);
+    RisiContraction_4 op(N, C);
+    bind(op, nb, false);
+    for (int i = 0; i < op.size; ++i) op.gradient[i] = G[i];
+    op.backward();
+    nb.grads_out(dP);
+}
+
+// Timed entry for the CPU baseline: forward + backward of RisiContraction_18 on one graph,
+// objects built outside the timed calls is not possible through a flat ABI, so the caller times
+// this whole function; construction is O(N^3 C) copies, negligible next to the O(nnz N^3 C) loops.
+void ref_r18_fwd_bwd(const double *P, const double *A, const double *G, double *Out, double *dP, int N, int C) {
+    Neighbourhood nb(P, dP, A, N, C);
+    RisiContraction_18 op(N, C);
+    bind(op, nb, true);
+    op.set_adjacency(nb.adj);
+    op.forward();
+    for (int i = 0; i < op.size; ++i) {
+        Out[i] = op.value[i];
+        op.gradient[i] = G[i];
+    }
+    op.backward();
+    nb.grads_out(dP);
+}
+
+static void fill(Vector *v, const double *val, const double *grad) {
+    for (int i = 0; i < v->size; ++i) {
+        v->value[i] = val ? val[i] : 0.0;
+        v->gradient[i] = grad ? grad[i] : 0.0;
+    }
+}
+
+void ref_matmul_forward(const double *A, const double *B, double *C, int M, int K, int N) {
+    Matrix a(M, K), b(K, N);
+    fill(&a, A, NULL);
+    fill(&b, B, NULL);
+    MatMul op(&a, &b);
+    op.forward();
+    for (int i = 0; i < op.size; ++i) C[i] = op.value[i];
+}
+void ref_matmul_backward(const double *dC, const double *A, const double *B, double *dA, double *dB, int M, int K,
+                         int N) {
+    Matrix a(M, K), b(K, N);
+    fill(&a, A, dA);
+    fill(&b, B, dB);
+    MatMul op(&a, &b);
+    for (int i = 0; i < op.size; ++i) op.gradient[i] = dC[i];
+    op.backward();
+    for (int i = 0; i < a.size; ++i) dA[i] = a.gradient[i];
+    for (int i = 0; i < b.size; ++i) dB[i] = b.gradient[i];
+}
+
+void ref_mattensormul_forward(const double *X, const double *F, double *Out, int R, int Kd, int J, int D) {
+    Matrix x(R, Kd);
+    Tensor3D f(Kd, J, D);
+    fill(&x, X, NULL);
+    fill(&f, F, NULL);
+    MatTensorMul op(&x, &f);
+    op.forward();
+    for (int i = 0; i < op.size; ++i) Out[i] = op.value[i];
+}
+void ref_mattensormul_backward(const double *G, const double *X, const double *F, double *dX, double *dF, int R,
+                               int Kd, int J, int D) {
+    Matrix x(R, Kd);
+    Tensor3D f(Kd, J, D);
+    fill(&x, X, dX);
+    fill(&f, F, dF);
+    MatTensorMul op(&x, &f);
+    for (int i = 0; i < op.size; ++i) op.gradient[i] = G[i];
+    op.backward();
+    for (int i = 0; i < x.size; ++i) dX[i] = x.gradient[i];
+    for (int i = 0; i < f.size; ++i) dF[i] = f.gradient[i];
+}
+
+void ref_tensormatmul_forward(const double *F, const double *Y, double *Out, int R, int Kd, int J, int D) {
+    Tensor3D f(R, Kd, D);
+    Matrix y(Kd, J);
+    fill(&f, F, NULL);
+    fill(&y, Y, NULL);
+    TensorMatMul op(&f, &y);
+    op.forward();
+    for (int i = 0; i < op.size; ++i) Out[i] = op.value[i];
+}
+void ref_tensormatmul_backward(const double *G, const double *F, const double *Y, double *dF, double *dY, int R,
+                               int Kd, int J, int D) {
+    Tensor3D f(R, Kd, D);
+    Matrix y(Kd, J);
+    fill(&f, F, dF);
+    fill(&y, Y, dY);
+    TensorMatMul op(&f, &y);
+    for (int i = 0; i < op.size; ++i) op.gradient[i] = G[i];
+    op.backward();
+    for (int i = 0; i < f.size; ++i) dF[i] = f.gradient[i];
+    for (int i = 0; i < y.size; ++i) dY[i] = y.gradient[i];
+}
+
+// StackTensor3D round trip on nRows tensors of [nCols][n1][n2] given contiguously.
+void ref_stack_forward(const double *T, double *Out, int nRows, int nCols, int n1, int n2) {
+    const size_t per = (size_t)nCols * n1 * n2;
+    std::vector<Tensor3D *> t;
+    StackTensor3D op(nRows, nCols, n1, n2);
+    for (int r = 0; r < nRows; ++r) {
+        t.push_back(new Tensor3D(nCols, n1, n2));
+        fill(t[r], T + r * per, NULL);
+        op.add_tensor(t[r]);
+    }
+    op.forward();
+    for (int i = 0; i < op.size; ++i) Out[i] = op.value[i];
+    for (int r = 0; r < nRows; ++r) delete t[r];
+}
+void ref_stack_backward(const double *G, double *dT, int nRows, int nCols, int n1, int n2) {
+    const size_t per = (size_t)nCols * n1 * n2;
+    std::vector<Tensor3D *> t;
+    StackTensor3D op(nRows, nCols, n1, n2);
+    for (int r = 0; r < nRows; ++r) {
+        t.push_back(new Tensor3D(nCols, n1, n2));
+        fill(t[r], NULL, dT + r * per);
+        op.add_tensor(t[r]);
+    }
+    for (int i = 0; i < op.size; ++i) op.gradient[i] = G[i];
+    op.backward();
+    for (int r = 0; r < nRows; ++r) {
+        for (size_t i = 0; i < per; ++i) dT[r * per + i] = t[r]->gradient[i];
+        delete t[r];
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz + structural_50.json from the REAL reference.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden.py
+It drives oracle/_ref/libgf_ref.so -- the reference's own GraphFlow/ (fp64) op classes compiled by
+oracle/Makefile from the headers where they lie -- and, for the structural known-answer, compiles and
+runs the reference's own tests/test_RisiContraction_50.cpp and records its stdout.
+
+Fixtures are DATA (inputs + the reference's outputs); no reference source text is stored.
+Inputs are float32-representable so the fp32 HIP path and the fp64 checkers see identical numbers.
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from oracle import pyoracle  # noqa: E402
+from inputs import adjacency, f32exact  # noqa: E402
+
+REF_ROOT = os.environ.get("GF_REFERENCE", "/root/reference")
+
+
+def contraction_fixtures(ref):
+    out = {}
+    shapes = {4: [(3, 2), (5, 3), (8, 4), (16, 8)], 10: [(3, 2), (5, 3), (8, 4)],
+              18: [(3, 2), (5, 3), (8, 4), (16, 8)], 50: [(3, 2), (5, 3), (8, 4)]}
+    for K, lst in shapes.items():
+        for (N, C) in lst:
+            rng = np.random.default_rng(1000 * K + 10 * N + C)
+            P = f32exact(rng.uniform(-1, 1, (N, N, N, C)))
+            G = f32exact(rng.uniform(0, 1, (N, N, K, C)))
+            dP0 = f32exact(rng.uniform(-1, 1, (N, N, N, C)))
+            kinds = ["none"] if K == 4 else (["sym01"] if (N, C) == (16, 8) else ["sym01", "weighted", "signed"])
+            for kind in kinds:
+                A = None if K == 4 else adjacency(kind, N, rng)
+                tag = "r%d_N%d_C%d_%s" % (K, N, C, kind)
+                out[tag + "__P"] = P.astype(np.float32)
+                out[tag + "__G"] = G.astype(np.float32)
+                out[tag + "__dP0"] = dP0.astype(np.float32)
+                if A is not None:
+                    out[tag + "__A"] = A.astype(np.float32)
+                out[tag + "__Out"] = ref.contract_forward(K, P, A)
+                out[tag + "__dP"] = ref.contract_backward(K, G, A, dP0)  # = dP0 + vjp (pins the `+=`)
+    # the 6-thread forward (no gate): differs from r18 only on the 'signed' adjacency
+    rng = np.random.default_rng(77)
+    N, C = 5, 3
+    P = f32exact(rng.uniform(-1, 1, (N, N, N, C)))
+    A = adjacency("signed", N, rng)
+    out["r18thread_N5_C3_signed__P"] = P.astype(np.float32)
+    out["r18thread_N5_C3_signed__A"] = A.astype(np.float32)
+    out["r18thread_N5_C3_signed__Out"] = ref.r18_thread_forward(P, A)
+    return out
+
+
+def selection_matrix(s, sw, rng):
+    """0/1 selection X[i,k] = [phi_l(v)_i == phi_{l-1}(w)_k] as SMP builds it (SMP_omega.h:461-474)."""
+    X = np.zeros((s, sw))
+    rows = rng.permutation(s)[:sw]
+    for k, i in enumerate(rows):
+        X[i, k] = 1.0
+    return X
+
+
+def mixer_fixtures(ref):
+    out = {}
+    rng = np.random.default_rng(4242)
+    # MatMul at the shape family of tests/test_MatMul_gpu.cu:22-26 (1600x720 . 720x40), down-scaled 10x, plus a K-projection-like one
+    for tag, (M, K, N) in {"mm_160x72x40": (160, 72, 40), "mm_kproj_36x144x8": (36, 144, 8), "mm_1x7x1": (1, 7, 1)}.items():
+        A = f32exact(rng.uniform(-1, 1, (M, K)))
+        B = f32exact(rng.uniform(-1, 1, (K, N)))
+        dC = f32exact(rng.uniform(-1, 1, (M, N)))
+        dA0 = f32exact(rng.uniform(-1, 1, (M, K)))
+        dB0 = f32exact(rng.uniform(-1, 1, (K, N)))
+        out[tag + "__A"], out[tag + "__B"], out[tag + "__dC"] = A.astype(np.float32), B.astype(np.float32), dC.astype(np.float32)
+        out[tag + "__dA0"], out[tag + "__dB0"] = dA0.astype(np.float32), dB0.astype(np.float32)
+        out[tag + "__C"] = ref.matmul_forward(A, B)
+        dA, dB = ref.matmul_backward(dC, A, B, dA0, dB0)
+        out[tag + "__dA"], out[tag + "__dB"] = dA, dB
+    # MatTensorMul / TensorMatMul with a selection matrix (the SMP use) and with a dense matrix
+    for tag, dense in (("sel", False), ("dense", True)):
+        s, sw, D = 6, 4, 5
+        X = f32exact(rng.uniform(-1, 1, (s, sw))) if dense else selection_matrix(s, sw, rng)
+        F = f32exact(rng.uniform(-1, 1, (sw, sw, D)))
+        T1 = ref.mattensormul_forward(X, F)            # [s, sw, D]
+        T2 = ref.tensormatmul_forward(T1, X.T.copy())  # [s, s, D]  = X F X^T
+        G2 = f32exact(rng.uniform(-1, 1, (s, s, D)))
+        dT1, dY = ref.tensormatmul_backward(G2, T1, X.T.copy())
+        dX, dF = ref.mattensormul_backward(dT1, X, F)
+        p = "promote_" + tag
+        out[p + "__X"], out[p + "__F"], out[p + "__G2"] = X.astype(np.float32), F.astype(np.float32), G2.astype(np.float32)
+        out[p + "__T1"], out[p + "__T2"], out[p + "__dT1"], out[p + "__dF"] = T1, T2, dT1, dF
+        out[p + "__dX"], out[p + "__dY"] = dX, dY
+    return out
+
+
+def structural_50():
+    """Compile + run the reference's own tests/test_RisiContraction_50.cpp, keep its stdout."""
+    src = os.path.join(REF_ROOT, "tests", "test_RisiContraction_50.cpp")
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "t50")
+        subprocess.check_call(["g++", "-std=c++11", "-O2", "-pthread", "-w", "-o", exe, src], cwd=os.path.join(REF_ROOT, "tests"))
+        txt = subprocess.check_output([exe], cwd=td).decode()
+    groups = []
+    for line in txt.strip().splitlines():
+        head, rest = line.split(":")
+        groups.append([int(x) for x in rest.split()])
+    return {"source": "stdout of reference tests/test_RisiContraction_50.cpp (N=10, C=5, symmetric inputs, zero-diagonal 0/1 adjacency)",
+            "groups": groups}
+
+
+def main():
+    pyoracle.build()
+    ref = pyoracle.reference()
+    if ref is None:
+        sys.exit("oracle/_ref/libgf_ref.so missing: needs /root/reference (build container only)")
+    np.savez_compressed(os.path.join(HERE, "contractions.npz"), **contraction_fixtures(ref))
+    np.savez_compressed(os.path.join(HERE, "mixers.npz"), **mixer_fixtures(ref))
+    with open(os.path.join(HERE, "structural_50.json"), "w") as fh:
+        json.dump(structural_50(), fh, indent=1)
+    for f in ("contractions.npz", "mixers.npz", "structural_50.json"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()
