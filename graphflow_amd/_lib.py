@@ -19,6 +19,7 @@ _vp = C.c_void_p
 # name -> (restype, argtypes); mirrors include/gf_hip.h one to one (tests/test_abi.py checks the two agree)
 PROTOTYPES = {
     "gf_ctx_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp]),
+    "gf_ctx_use_private_stream": (C.c_int, [_vp]),
     "gf_ctx_destroy": (C.c_int, [_vp]),
     "gf_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "gf_ctx_get_stream": (_vp, [_vp]),

@@ -212,17 +212,18 @@ gf_status gf_ctx_create(gf_ctx **out, int device, void *stream) {
     if (e != hipSuccess) return gf::fail(nullptr, GF_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
     gf_ctx *ctx = new gf_ctx();
     ctx->device = device;
-    if (stream) {
-        ctx->stream = static_cast<hipStream_t>(stream);
-    } else {
-        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            delete ctx;
-            return gf::fail(nullptr, GF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
-        }
+    ctx->stream = static_cast<hipStream_t>(stream);  // NULL = the device's default stream, like the reference's ops
+    *out = ctx;
+    return GF_OK;
+}
+
+gf_status gf_ctx_use_private_stream(gf_ctx *ctx) {
+    if (!ctx) return gf::fail(nullptr, GF_ERR_INVALID, "null context");
+    GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->owns_stream) {
+        GF_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->owns_stream = true;
     }
-    *out = ctx;
     return GF_OK;
 }
 
@@ -247,12 +248,7 @@ gf_status gf_ctx_set_stream(gf_ctx *ctx, void *stream) {
         GF_HIP_TRY(ctx, hipStreamDestroy(ctx->stream));
         ctx->owns_stream = false;
     }
-    if (stream) {
-        ctx->stream = static_cast<hipStream_t>(stream);
-    } else {
-        GF_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->owns_stream = true;
-    }
+    ctx->stream = static_cast<hipStream_t>(stream);  // NULL = the default stream
     return GF_OK;
 }
 

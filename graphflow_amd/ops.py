@@ -14,7 +14,8 @@ class GraphFlowHipError(RuntimeError):
 
 class Context:
     """gf_ctx wrapper.  By default it runs on torch's current stream of `device`, so torch ops and gf kernels
-    order naturally; pass own_stream=True for a private non-blocking stream (gf_ctx_create with stream == NULL)."""
+    order naturally; pass own_stream=True for a private non-blocking stream (gf_ctx_use_private_stream) -- the caller
+    must then order it against torch's stream itself."""
 
     def __init__(self, device=0, own_stream=False):
         self.lib = _lib.load()
@@ -22,11 +23,14 @@ class Context:
             raise GraphFlowHipError(_lib.GF_ERR_HIP, "no HIP device visible to torch; graphflow_amd has no CPU fallback")
         self.device = torch.device("cuda", device)
         handle = C.c_void_p()
-        stream = None if own_stream else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # torch's default stream has handle 0 == HIP's null stream, which is also gf_ctx_create's default
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         st = self.lib.gf_ctx_create(C.byref(handle), device, stream)
         if st != _lib.GF_OK:
             raise GraphFlowHipError(st, self.lib.gf_last_error(None).decode())
         self.handle = handle
+        if own_stream:
+            self.check(self.lib.gf_ctx_use_private_stream(handle))
 
     def check(self, st):
         if st != _lib.GF_OK:

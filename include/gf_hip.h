@@ -43,8 +43,11 @@ typedef enum {
  * Replaces the per-op-object cudaMalloc'd buffers and optional cudaStream_t of RisiContraction_18_gpu
  * (GraphFlow_gpu/RisiContraction_18_gpu.h:853-874, 947-955).  One context per host thread / per GPU; not thread-safe,
  * matching the reference's "one model clone per worker thread" rule (SMP_omega.h:115-129).
- * `stream` is a hipStream_t (NULL = the context creates and owns a non-blocking stream).                          */
+ * `stream` is a hipStream_t; NULL is the device's default (null) stream, which is where the reference's GPU ops run
+ * until set_gpu_stream is called.  gf_ctx_use_private_stream gives the context its own non-blocking stream, the
+ * analogue of the per-worker cudaStream_t of SMP_omega_gpu_multistreams.h:130-135.                                 */
 gf_status gf_ctx_create(gf_ctx **out, int device, void *stream);
+gf_status gf_ctx_use_private_stream(gf_ctx *ctx);
 gf_status gf_ctx_destroy(gf_ctx *ctx);
 gf_status gf_ctx_set_stream(gf_ctx *ctx, void *stream);     /* RisiContraction_18_gpu::set_gpu_stream (:947) */
 void     *gf_ctx_get_stream(gf_ctx *ctx);
