@@ -297,6 +297,7 @@ size_t gf_contract_workspace_bytes(int K, int N, int C, int batch) {
     if (N <= 0 || C <= 0 || batch <= 0) return 0;
     switch (K) {
         case 18: return gf::r18_workspace_bytes(N, C, batch);
+        case 4: case 10: case 50: return gf::family_workspace_bytes(K, N, C, batch);
         default: return 0;
     }
 }
@@ -308,7 +309,7 @@ gf_status gf_contract_forward_f32(gf_ctx *ctx, int K, const float *P, const floa
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     switch (K) {
         case 18: return gf::r18_forward(ctx, P, A, Out, N, C, batch);
-        default: return gf::fail(ctx, GF_ERR_UNSUPPORTED, "contraction family K=%d not built yet", K);
+        default: return gf::family_forward(ctx, K, P, A, Out, N, C, batch);
     }
 }
 
@@ -319,7 +320,7 @@ gf_status gf_contract_backward_f32(gf_ctx *ctx, int K, const float *G, const flo
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     switch (K) {
         case 18: return gf::r18_backward(ctx, G, A, dP, N, C, batch, accumulate);
-        default: return gf::fail(ctx, GF_ERR_UNSUPPORTED, "contraction family K=%d not built yet", K);
+        default: return gf::family_backward(ctx, K, G, A, dP, N, C, batch, accumulate);
     }
 }
 

@@ -86,6 +86,11 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 gf_status r18_forward(gf_ctx *ctx, const float *P, const float *A, float *Out, int N, int C, int batch);
 gf_status r18_backward(gf_ctx *ctx, const float *G, const float *A, float *dP, int N, int C, int batch, int accumulate);
 size_t r18_workspace_bytes(int N, int C, int batch);
+// r4 / r10 / r50: table kernels (contract_families.hip)
+gf_status family_forward(gf_ctx *ctx, int K, const float *P, const float *A, float *Out, int N, int C, int batch);
+gf_status family_backward(gf_ctx *ctx, int K, const float *G, const float *A, float *dP, int N, int C, int batch,
+                          int accumulate);
+size_t family_workspace_bytes(int K, int N, int C, int batch);
 
 }  // namespace gf
 #endif

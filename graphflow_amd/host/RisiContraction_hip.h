@@ -1,0 +1,118 @@
+// RisiContraction_hip.h -- drop-in Entity-style ops RisiContraction_{4,10,18,50}_hip.
+//
+// Same contract as the reference ops (GraphFlow/RisiContraction_18.h:25-63 for the add_tensor interface,
+// GraphFlow_gpu/RisiContraction_18_gpu.h:879-955 for the Tensor4D + stream interface):
+//   ctor(max N, max channels) allocates value/gradient for [N][N][K*C]; setParameter() rebinds logical dims;
+//   clear()/add_tensor()/set_adjacency() bind non-owning input pointers (asserting shapes);
+//   forward()  overwrites value, then zeroes own gradient;
+//   backward() accumulates into the inputs' gradient (`+=`), reads own gradient; the adjacency gets no gradient.
+// The arithmetic happens in libgf_hip.so on the GPU (host-pointer mode of the C ABI); nothing is computed here.
+#ifndef RISICONTRACTION_HIP_H_INCLUDED
+#define RISICONTRACTION_HIP_H_INCLUDED
+
+#include <cassert>
+#include <vector>
+
+#include "gf_containers.h"
+#include "gf_runtime.h"
+
+template <int K>
+class RisiContraction_hip : public Tensor3D {
+public:
+    static const int nContractions = K;
+
+    RisiContraction_hip(int max_N, int max_nChanels)
+        : Tensor3D(max_N, max_N, K * max_nChanels), N(max_N), nChanels(max_nChanels), adj(NULL), stacked(NULL), ctx(NULL) {}
+
+    // --- CPU-op style binding (RisiContraction_18.h:36-63) ---
+    void setParameter(int N_, int nChanels_) {
+        N = N_;
+        nChanels = nChanels_;
+        Tensor3D::setParameter(N, N, K * nChanels);
+        tensors.clear();
+        stacked = NULL;
+    }
+    void clear() {
+        tensors.clear();
+        stacked = NULL;
+    }
+    void add_tensor(Tensor3D *t) {
+        assert(t->nRows == N && t->nColumns == N && t->nDepth == nChanels);
+        tensors.push_back(t);
+    }
+    void set_adjacency(Matrix *a) {
+        assert(a->nRows == N && a->nColumns == N);
+        adj = a;
+    }
+
+    // --- GPU-op style binding: one pre-stacked Tensor4D [N][N][N][C] (RisiContraction_18_gpu.h:920-936) ---
+    void setParameter(Tensor4D *tensor, Matrix *a) {
+        N = tensor->nRows;
+        nChanels = tensor->nChanels2;
+        assert(tensor->nColumns == N && tensor->nChanels1 == N);
+        if (K != 4) assert(a != NULL && a->nRows == N && a->nColumns == N);
+        Tensor3D::setParameter(N, N, K * nChanels);
+        tensors.clear();
+        stacked = tensor;
+        adj = a;
+    }
+
+    // RisiContraction_18_gpu::set_gpu_stream / turn_off_gpu_stream (:947-955).  `stream` is a hipStream_t.
+    void set_gpu_stream(void *stream) {
+        gf_status st = gf_ctx_set_stream(context(), stream);
+        if (st != GF_OK) gfhost::die(context(), "gf_ctx_set_stream", st);
+    }
+    void turn_off_gpu_stream() { set_gpu_stream(NULL); }
+    void set_context(gf_ctx *c) { ctx = c; }
+
+    void forward() {
+        gather(false);
+        gf_status st = gfhost::contract_forward_host(context(), K, &vptr[0], K == 4 ? NULL : adj->value, value, N, nChanels);
+        if (st != GF_OK) gfhost::die(context(), "RisiContraction_hip::forward", st);
+        for (int i = 0; i < size; ++i) gradient[i] = 0;
+    }
+
+    void backward() {
+        gather(true);
+        gf_status st = gfhost::contract_backward_host(context(), K, gradient, K == 4 ? NULL : adj->value, &gptr[0], N, nChanels);
+        if (st != GF_OK) gfhost::die(context(), "RisiContraction_hip::backward", st);
+    }
+
+    int N;
+    int nChanels;
+    std::vector<Tensor3D *> tensors;
+    Matrix *adj;
+
+private:
+    gf_ctx *context() { return ctx ? ctx : gfhost::default_context(); }
+    void gather(bool grads) {
+        vptr.resize(N);
+        gptr.resize(N);
+        if (stacked) {
+            const size_t per = (size_t)N * N * nChanels;
+            for (int a = 0; a < N; ++a) {
+                vptr[a] = stacked->value + a * per;
+                gptr[a] = stacked->gradient + a * per;
+            }
+        } else {
+            assert((int)tensors.size() == N);
+            for (int a = 0; a < N; ++a) {
+                vptr[a] = tensors[a]->value;
+                gptr[a] = tensors[a]->gradient;
+            }
+        }
+        if (K != 4) assert(adj != NULL);
+        (void)grads;
+    }
+    Tensor4D *stacked;
+    gf_ctx *ctx;
+    std::vector<const gf_real *> vptr;
+    std::vector<gf_real *> gptr;
+};
+
+typedef RisiContraction_hip<4> RisiContraction_4_hip;
+typedef RisiContraction_hip<10> RisiContraction_10_hip;
+typedef RisiContraction_hip<18> RisiContraction_18_hip;
+typedef RisiContraction_hip<50> RisiContraction_50_hip;
+
+#endif

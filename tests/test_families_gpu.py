@@ -1,0 +1,108 @@
+"""GPU parity suite for RisiContraction_4 / _10 / _50 (through the C ABI) vs golden vectors and the fp64 oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from inputs import adjacency, f32exact
+from util import REL_TOL_F32, golden_cases, rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.parametrize("K", [4, 10, 50])
+def test_golden_vectors(gf, golden, K):
+    cases = golden_cases(golden, "r%d_" % K)
+    assert cases
+    for tag, c in cases.items():
+        A = dev(c["A"][None]) if "A" in c else None
+        out = gf.contract_forward(dev(c["P"][None]), A, K)
+        assert rel_err(host(out)[0], c["Out"]) <= REL_TOL_F32, tag
+        dP = dev(c["dP0"][None])
+        gf.contract_backward(dev(c["G"][None]), A, K, dP=dP, accumulate=True)
+        assert rel_err(host(dP)[0], c["dP"]) <= REL_TOL_F32, tag
+
+
+@pytest.mark.parametrize("K", [4, 10, 50])
+@pytest.mark.parametrize("N,C", [(1, 1), (2, 3), (6, 5), (9, 4), (12, 2)])
+def test_forward_backward_vs_oracle(gf, oracle, K, N, C):
+    rng = np.random.default_rng(1000 * K + 10 * N + C)
+    B = 3
+    P = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
+    A = np.stack([adjacency(k, N, rng) for k in ("sym01", "weighted", "signed")])
+    G = f32exact(rng.uniform(-1, 1, (B, N, N, K, C)))
+    d0 = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
+    Ad = dev(A) if K != 4 else None
+    out = host(gf.contract_forward(dev(P), Ad, K))
+    dw = host(gf.contract_backward(dev(G), Ad, K))
+    da = dev(d0)
+    gf.contract_backward(dev(G), Ad, K, dP=da, accumulate=True)
+    da = host(da)
+    for g in range(B):
+        assert rel_err(out[g], oracle.contract_forward(K, P[g], A[g])) <= REL_TOL_F32
+        ref = oracle.contract_backward(K, G[g], A[g])
+        assert rel_err(dw[g], ref) <= REL_TOL_F32
+        assert rel_err(da[g], ref + d0[g]) <= REL_TOL_F32
+
+
+def test_structural_50_collapse_on_gpu(gf):
+    """The reference's own known-answer (tests/test_RisiContraction_50.cpp): 50 slices -> the 18 recorded groups,
+    bit-identical, for integer tensors symmetric in (b,c) and a symmetric zero-diagonal 0/1 adjacency."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "structural_50.json")) as fh:
+        expected = json.load(fh)["groups"]
+    rng = np.random.default_rng(50)
+    N, C = 10, 5
+    P = rng.integers(0, 100, (N, N, N, C)).astype(np.float64)
+    P = np.triu(P.transpose(0, 3, 1, 2), 0)
+    P = (P + np.triu(P, 1).transpose(0, 1, 3, 2)).transpose(0, 2, 3, 1).copy()
+    U = np.triu((rng.uniform(0, 1, (N, N)) < 0.5).astype(np.float64), 1)
+    A = U + U.T
+    out = host(gf.contract_forward(dev(P[None]), dev(A[None]), 50))[0]
+    free, groups = [True] * 50, []
+    for i in range(50):
+        if free[i]:
+            grp = [j + 1 for j in range(i, 50) if np.array_equal(out[:, :, i, :], out[:, :, j, :])]
+            for j in grp:
+                free[j - 1] = False
+            groups.append(grp)
+    assert groups == expected
+
+
+def test_r18_is_the_gated_subset_of_r50(gf):
+    """RisiContraction_18's slices are cases {1,3,5,6,10,11,13,17,18,23,26,27,28,38,40,43,46,50} of _50 on A+."""
+    rng = np.random.default_rng(18)
+    N, C = 7, 8
+    P = dev(rng.uniform(-1, 1, (2, N, N, N, C)))
+    A = rng.uniform(-1, 1, (2, N, N))
+    o18 = host(gf.contract_forward(P, dev(A), 18))
+    o50 = host(gf.contract_forward(P, dev(np.where(A > 0, A, 0.0)), 50))
+    sel = [c - 1 for c in (1, 3, 5, 6, 10, 11, 13, 17, 18, 23, 26, 27, 28, 38, 40, 43, 46, 50)]
+    assert rel_err(o18, o50[:, :, :, sel, :]) <= REL_TOL_F32
+
+
+def test_cfg5_full_size_properties(gf):
+    """BASELINE cfg5 (RisiContraction_50, N=24, C=32), batch 64: adjoint identity and linearity."""
+    B, N, C, K = 64, 24, 32, 50
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    P = torch.rand((B, N, N, N, C), device="cuda", generator=gen) * 2 - 1
+    G = torch.rand((B, N, N, K, C), device="cuda", generator=gen)
+    U = (torch.rand((B, N, N), device="cuda", generator=gen) < 0.5).float().triu(1)
+    A = U + U.transpose(1, 2) + torch.eye(N, device="cuda")
+    out = gf.contract_forward(P, A, K)
+    dP = gf.contract_backward(G, A, K)
+    lhs = (out.double() * G.double()).sum(dim=(1, 2, 3, 4))
+    rhs = (P.double() * dP.double()).sum(dim=(1, 2, 3, 4))
+    mag = (out.double().abs() * G.double()).sum(dim=(1, 2, 3, 4)).clamp_min(1.0)
+    assert float(((lhs - rhs).abs() / mag).max()) <= 1e-5
+    assert torch.equal(out, gf.contract_forward(P, A, K))
