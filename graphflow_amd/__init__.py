@@ -6,7 +6,9 @@ streams, every op call goes straight through the C ABI.  Nothing here computes o
 """
 from . import _lib
 from .ops import (Context, GraphFlowHipError, contract_backward, contract_forward,  # noqa: F401
-                  contract_workspace_bytes, default_context)
+                  contract_workspace_bytes, default_context, matmul_backward, matmul_forward,
+                  mattensormul_backward, mattensormul_forward, stack_backward, stack_forward,
+                  tensormatmul_backward, tensormatmul_forward)
 
 __all__ = ["Context", "GraphFlowHipError", "contract_forward", "contract_backward", "contract_workspace_bytes",
            "default_context", "build"]

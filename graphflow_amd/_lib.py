@@ -39,6 +39,26 @@ PROTOTYPES = {
     "gf_contract_backward_host_f32": (C.c_int, [_vp, C.c_int, _fp, _fp, C.POINTER(_fp), C.c_int, C.c_int]),
 }
 
+_i = C.c_int
+for _sfx, _t in (("f64", _dp), ("f32", _fp)):
+    PROTOTYPES["gf_matmul_forward_host_" + _sfx] = (_i, [_vp, _t, _t, _t, _i, _i, _i])
+    PROTOTYPES["gf_stack_forward_host_" + _sfx] = (_i, [_vp, C.POINTER(_t), _t, _i, C.c_size_t])
+    PROTOTYPES["gf_stack_backward_host_" + _sfx] = (_i, [_vp, _t, C.POINTER(_t), _i, C.c_size_t])
+    PROTOTYPES["gf_matmul_backward_host_" + _sfx] = (_i, [_vp, _t, _t, _t, _t, _t, _i, _i, _i])
+    for _op in ("mattensormul", "tensormatmul"):
+        PROTOTYPES["gf_%s_forward_host_%s" % (_op, _sfx)] = (_i, [_vp, _t, _t, _t, _i, _i, _i, _i])
+        PROTOTYPES["gf_%s_backward_host_%s" % (_op, _sfx)] = (_i, [_vp, _t, _t, _t, _t, _t, _i, _i, _i, _i])
+PROTOTYPES.update({
+    "gf_matmul_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
+    "gf_matmul_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "gf_mattensormul_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "gf_mattensormul_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gf_tensormatmul_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "gf_tensormatmul_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gf_stack_forward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
+    "gf_stack_backward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
+})
+
 _lib = None
 
 

@@ -192,6 +192,187 @@ gf_status contract_backward_host(gf_ctx *ctx, int K, const T *out_gradient, cons
     return GF_OK;
 }
 
+
+// ---- generic host-pointer staging for the mixers (mode A) -----------------------------------------------------
+// Declare the operands of one op call; begin() packs the inputs into pinned memory, uploads them in one copy and
+// converts to f32 on the device; end() converts the outputs back, downloads them in one copy, synchronises and
+// either stores or adds them into the caller's buffers (`+=` is how every reference backward() writes gradients).
+template <typename T>
+class HostStaging {
+public:
+    explicit HostStaging(gf_ctx *c) : ctx(c) {}
+    int in(const T *p, size_t n) { return push(const_cast<T *>(p), n, true, false, false); }
+    int out(T *p, size_t n) { return push(p, n, false, true, false); }
+    int out_add(T *p, size_t n) { return push(p, n, false, true, true); }
+    float *dev(int i) { return fbase + bufs[i].off; }
+
+    gf_status begin() {
+        size_t total = 0;
+        for (auto &b : bufs) {
+            b.off = total;
+            total += (b.n + 3) & ~(size_t)3;  // keep every operand 16-byte aligned in the f32 image
+        }
+        ntotal = total;
+        gf_status st = ensure_pinned(ctx, sizeof(T) * total);
+        if (st != GF_OK) return st;
+        st = ensure_stage(ctx, align_up(sizeof(T) * total, 256) + sizeof(float) * total + 256);
+        if (st != GF_OK) return st;
+        hbase = static_cast<T *>(ctx->pinned);
+        tbase = static_cast<T *>(ctx->stage);
+        fbase = reinterpret_cast<float *>(static_cast<char *>(ctx->stage) + align_up(sizeof(T) * total, 256));
+        for (auto &b : bufs)
+            if (b.up && b.n) std::memcpy(hbase + b.off, b.host, sizeof(T) * b.n);
+        // inputs are declared first, so [0, in_end) is one contiguous upload
+        size_t in_end = 0;
+        for (auto &b : bufs)
+            if (b.up) in_end = b.off + ((b.n + 3) & ~(size_t)3);
+        if (in_end) {
+            GF_HIP_TRY(ctx, hipMemcpyAsync(tbase, hbase, sizeof(T) * in_end, hipMemcpyHostToDevice, ctx->stream));
+            GF_LAUNCH(ctx, "cast_to_f32", cast_to_f32<T>, dim3(cast_grid(in_end)), dim3(256), 0, tbase, fbase, in_end);
+        }
+        out_begin = in_end;
+        return GF_OK;
+    }
+
+    gf_status end() {
+        const size_t n = ntotal - out_begin;
+        if (n) {
+            GF_LAUNCH(ctx, "cast_from_f32", cast_from_f32<T>, dim3(cast_grid(n)), dim3(256), 0, fbase + out_begin,
+                      tbase + out_begin, n);
+            GF_HIP_TRY(ctx, hipMemcpyAsync(hbase + out_begin, tbase + out_begin, sizeof(T) * n, hipMemcpyDeviceToHost,
+                                           ctx->stream));
+        }
+        GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto &b : bufs) {
+            if (!b.down) continue;
+            const T *src = hbase + b.off;
+            if (b.add)
+                for (size_t i = 0; i < b.n; ++i) b.host[i] += src[i];
+            else
+                std::memcpy(b.host, src, sizeof(T) * b.n);
+        }
+        return GF_OK;
+    }
+
+private:
+    struct Buf {
+        T *host;
+        size_t n, off;
+        bool up, down, add;
+    };
+    int push(T *p, size_t n, bool up, bool down, bool add) {
+        bufs.push_back({p, n, 0, up, down, add});
+        return (int)bufs.size() - 1;
+    }
+    gf_ctx *ctx;
+    std::vector<Buf> bufs;
+    T *hbase = nullptr, *tbase = nullptr;
+    float *fbase = nullptr;
+    size_t ntotal = 0, out_begin = 0;
+};
+
+template <typename T>
+gf_status matmul_forward_host(gf_ctx *ctx, const T *A, const T *B, T *C, int M, int K, int N) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!A || !B || !C || M <= 0 || K <= 0 || N <= 0) return fail(ctx, GF_ERR_INVALID, "matmul_forward_host: bad argument");
+    HostStaging<T> s(ctx);
+    const int a = s.in(A, (size_t)M * K), b = s.in(B, (size_t)K * N), c = s.out(C, (size_t)M * N);
+    gf_status st = s.begin();
+    if (st != GF_OK) return st;
+    st = gf_matmul_forward_f32(ctx, s.dev(a), s.dev(b), s.dev(c), M, K, N);
+    if (st != GF_OK) return st;
+    return s.end();
+}
+
+template <typename T>
+gf_status matmul_backward_host(gf_ctx *ctx, const T *dC, const T *A, const T *B, T *dA, T *dB, int M, int K, int N) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!dC || !A || !B || M <= 0 || K <= 0 || N <= 0) return fail(ctx, GF_ERR_INVALID, "matmul_backward_host: bad argument");
+    HostStaging<T> s(ctx);
+    const int g = s.in(dC, (size_t)M * N), a = s.in(A, (size_t)M * K), b = s.in(B, (size_t)K * N);
+    const int da = dA ? s.out_add(dA, (size_t)M * K) : -1, db = dB ? s.out_add(dB, (size_t)K * N) : -1;
+    gf_status st = s.begin();
+    if (st != GF_OK) return st;
+    st = gf_matmul_backward_f32(ctx, s.dev(g), s.dev(a), s.dev(b), dA ? s.dev(da) : nullptr, dB ? s.dev(db) : nullptr, M, K,
+                                N, 0);
+    if (st != GF_OK) return st;
+    return s.end();
+}
+
+// which = 0: MatTensorMul (first = X[R,Kd], second = F[Kd,J,D]); which = 1: TensorMatMul (first = F[R,Kd,D], second = Y[Kd,J])
+template <typename T>
+gf_status tensormul_forward_host(gf_ctx *ctx, int which, const T *first, const T *second, T *Out, int R, int Kd, int J, int D) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!first || !second || !Out || R <= 0 || Kd <= 0 || J <= 0 || D <= 0)
+        return fail(ctx, GF_ERR_INVALID, "tensormul_forward_host: bad argument");
+    const size_t n1 = which == 0 ? (size_t)R * Kd : (size_t)R * Kd * D, n2 = which == 0 ? (size_t)Kd * J * D : (size_t)Kd * J;
+    HostStaging<T> s(ctx);
+    const int a = s.in(first, n1), b = s.in(second, n2), c = s.out(Out, (size_t)R * J * D);
+    gf_status st = s.begin();
+    if (st != GF_OK) return st;
+    st = which == 0 ? gf_mattensormul_forward_f32(ctx, s.dev(a), s.dev(b), s.dev(c), R, Kd, J, D)
+                    : gf_tensormatmul_forward_f32(ctx, s.dev(a), s.dev(b), s.dev(c), R, Kd, J, D);
+    if (st != GF_OK) return st;
+    return s.end();
+}
+
+template <typename T>
+gf_status tensormul_backward_host(gf_ctx *ctx, int which, const T *G, const T *first, const T *second, T *d1, T *d2, int R,
+                                  int Kd, int J, int D) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!G || !first || !second || R <= 0 || Kd <= 0 || J <= 0 || D <= 0)
+        return fail(ctx, GF_ERR_INVALID, "tensormul_backward_host: bad argument");
+    const size_t n1 = which == 0 ? (size_t)R * Kd : (size_t)R * Kd * D, n2 = which == 0 ? (size_t)Kd * J * D : (size_t)Kd * J;
+    HostStaging<T> s(ctx);
+    const int g = s.in(G, (size_t)R * J * D), a = s.in(first, n1), b = s.in(second, n2);
+    const int o1 = d1 ? s.out_add(d1, n1) : -1, o2 = d2 ? s.out_add(d2, n2) : -1;
+    gf_status st = s.begin();
+    if (st != GF_OK) return st;
+    float *p1 = d1 ? s.dev(o1) : nullptr, *p2 = d2 ? s.dev(o2) : nullptr;
+    st = which == 0 ? gf_mattensormul_backward_f32(ctx, s.dev(g), s.dev(a), s.dev(b), p1, p2, R, Kd, J, D, 0)
+                    : gf_tensormatmul_backward_f32(ctx, s.dev(g), s.dev(a), s.dev(b), p1, p2, R, Kd, J, D, 0);
+    if (st != GF_OK) return st;
+    return s.end();
+}
+
+// StackTensor3D in host mode: staging the nRows tensors into one device image IS the stack; the copy kernel makes
+// it contiguous, then one D2H.  Backward: upload G once, scatter-add into the nRows gradient buffers on return.
+template <typename T>
+gf_status stack_forward_host(gf_ctx *ctx, const T *const *tensors, T *out, int nRows, size_t per) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!tensors || !out || nRows <= 0) return fail(ctx, GF_ERR_INVALID, "stack_forward_host: bad argument");
+    HostStaging<T> s(ctx);
+    std::vector<int> ids(nRows);
+    for (int r = 0; r < nRows; ++r) {
+        if (!tensors[r]) return fail(ctx, GF_ERR_INVALID, "tensors[%d] is null", r);
+        ids[r] = s.in(tensors[r], per);
+    }
+    const int o = s.out(out, (size_t)nRows * per);
+    gf_status st = s.begin();
+    if (st != GF_OK) return st;
+    for (int r = 0; r < nRows; ++r)
+        GF_HIP_TRY(ctx, hipMemcpyAsync(s.dev(o) + (size_t)r * per, s.dev(ids[r]), sizeof(float) * per,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+    return s.end();
+}
+template <typename T>
+gf_status stack_backward_host(gf_ctx *ctx, const T *G, T *const *grads, int nRows, size_t per) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!G || !grads || nRows <= 0) return fail(ctx, GF_ERR_INVALID, "stack_backward_host: bad argument");
+    HostStaging<T> s(ctx);
+    const int g = s.in(G, (size_t)nRows * per);
+    std::vector<int> ids(nRows);
+    for (int r = 0; r < nRows; ++r) {
+        if (!grads[r]) return fail(ctx, GF_ERR_INVALID, "grads[%d] is null", r);
+        ids[r] = s.out_add(grads[r], per);
+    }
+    gf_status st = s.begin();
+    if (st != GF_OK) return st;
+    for (int r = 0; r < nRows; ++r)
+        GF_HIP_TRY(ctx, hipMemcpyAsync(s.dev(ids[r]), s.dev(g) + (size_t)r * per, sizeof(float) * per,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+    return s.end();
+}
 }  // namespace
 }  // namespace gf
 
@@ -340,6 +521,39 @@ gf_status gf_contract_backward_host_f32(gf_ctx *ctx, int K, const float *out_gra
                                         float *const *grads, int N, int C) {
     return gf::contract_backward_host<float>(ctx, K, out_gradient, A, grads, N, C);
 }
+
+#define GF_HOST_MIXERS(SFX, T)                                                                                      \
+    gf_status gf_matmul_forward_host_##SFX(gf_ctx *ctx, const T *A, const T *B, T *C, int M, int K, int N) {           \
+        return gf::matmul_forward_host<T>(ctx, A, B, C, M, K, N);                                                       \
+    }                                                                                                                   \
+    gf_status gf_matmul_backward_host_##SFX(gf_ctx *ctx, const T *dC, const T *A, const T *B, T *dA, T *dB, int M,     \
+                                            int K, int N) {                                                             \
+        return gf::matmul_backward_host<T>(ctx, dC, A, B, dA, dB, M, K, N);                                             \
+    }                                                                                                                   \
+    gf_status gf_mattensormul_forward_host_##SFX(gf_ctx *ctx, const T *X, const T *F, T *Out, int R, int Kd, int J,    \
+                                                 int D) {                                                               \
+        return gf::tensormul_forward_host<T>(ctx, 0, X, F, Out, R, Kd, J, D);                                           \
+    }                                                                                                                   \
+    gf_status gf_mattensormul_backward_host_##SFX(gf_ctx *ctx, const T *G, const T *X, const T *F, T *dX, T *dF, int R, \
+                                                  int Kd, int J, int D) {                                               \
+        return gf::tensormul_backward_host<T>(ctx, 0, G, X, F, dX, dF, R, Kd, J, D);                                    \
+    }                                                                                                                   \
+    gf_status gf_tensormatmul_forward_host_##SFX(gf_ctx *ctx, const T *F, const T *Y, T *Out, int R, int Kd, int J,    \
+                                                 int D) {                                                               \
+        return gf::tensormul_forward_host<T>(ctx, 1, F, Y, Out, R, Kd, J, D);                                           \
+    }                                                                                                                   \
+    gf_status gf_tensormatmul_backward_host_##SFX(gf_ctx *ctx, const T *G, const T *F, const T *Y, T *dF, T *dY, int R, \
+                                                  int Kd, int J, int D) {                                               \
+        return gf::tensormul_backward_host<T>(ctx, 1, G, F, Y, dF, dY, R, Kd, J, D);                                    \
+    }                                                                                                                   \
+    gf_status gf_stack_forward_host_##SFX(gf_ctx *ctx, const T *const *tensors, T *out, int nRows, size_t per_tensor) { \
+        return gf::stack_forward_host<T>(ctx, tensors, out, nRows, per_tensor);                                         \
+    }                                                                                                                   \
+    gf_status gf_stack_backward_host_##SFX(gf_ctx *ctx, const T *G, T *const *grads, int nRows, size_t per_tensor) {    \
+        return gf::stack_backward_host<T>(ctx, G, grads, nRows, per_tensor);                                            \
+    }
+GF_HOST_MIXERS(f64, double)
+GF_HOST_MIXERS(f32, float)
 
 /* test hook, not declared in the public header: force the generic (layout-agnostic) kernels */
 void gf_debug_force_generic(int on) { gf::r18_force_generic(on); }

@@ -16,6 +16,7 @@
 #include <utility>
 #include <vector>
 
+#include "Mixers_hip.h"
 #include "RisiContraction_hip.h"
 #include "gf_containers.h"
 
@@ -41,6 +42,10 @@ public:
         bind<RisiContraction_10_hip>(gftags::RISICONTRACTION_10_HIP);
         bind<RisiContraction_18_hip>(gftags::RISICONTRACTION_18_HIP);
         bind<RisiContraction_50_hip>(gftags::RISICONTRACTION_50_HIP);
+        bind<MatMul_hip>(gftags::MATMUL_HIP);
+        bind<MatTensorMul_hip>(gftags::MATTENSORMUL_HIP);
+        bind<TensorMatMul_hip>(gftags::TENSORMATMUL_HIP);
+        bind<StackTensor3D_hip>(gftags::STACKTENSOR3D_HIP);
     }
 
     // Teach the executor a (tag -> class) pair.  The class needs public non-virtual forward()/backward().

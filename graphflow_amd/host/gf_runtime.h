@@ -44,5 +44,35 @@ inline gf_status contract_backward_host(gf_ctx *c, int K, const float *g, const 
     return gf_contract_backward_host_f32(c, K, g, A, d, N, C);
 }
 
+#define GF_HOST_OVERLOAD2(NAME, ARGS_D, ARGS_F, CALL)                              \
+    inline gf_status NAME ARGS_D { return gf_##NAME##_f64 CALL; }                   \
+    inline gf_status NAME ARGS_F { return gf_##NAME##_f32 CALL; }
+
+GF_HOST_OVERLOAD2(matmul_forward_host, (gf_ctx * c, const double *A, const double *B, double *C, int M, int K, int N),
+                  (gf_ctx * c, const float *A, const float *B, float *C, int M, int K, int N), (c, A, B, C, M, K, N))
+GF_HOST_OVERLOAD2(matmul_backward_host,
+                  (gf_ctx * c, const double *g, const double *A, const double *B, double *dA, double *dB, int M, int K, int N),
+                  (gf_ctx * c, const float *g, const float *A, const float *B, float *dA, float *dB, int M, int K, int N),
+                  (c, g, A, B, dA, dB, M, K, N))
+GF_HOST_OVERLOAD2(mattensormul_forward_host,
+                  (gf_ctx * c, const double *X, const double *F, double *O, int R, int Kd, int J, int D),
+                  (gf_ctx * c, const float *X, const float *F, float *O, int R, int Kd, int J, int D), (c, X, F, O, R, Kd, J, D))
+GF_HOST_OVERLOAD2(mattensormul_backward_host,
+                  (gf_ctx * c, const double *g, const double *X, const double *F, double *dX, double *dF, int R, int Kd, int J, int D),
+                  (gf_ctx * c, const float *g, const float *X, const float *F, float *dX, float *dF, int R, int Kd, int J, int D),
+                  (c, g, X, F, dX, dF, R, Kd, J, D))
+GF_HOST_OVERLOAD2(tensormatmul_forward_host,
+                  (gf_ctx * c, const double *F, const double *Y, double *O, int R, int Kd, int J, int D),
+                  (gf_ctx * c, const float *F, const float *Y, float *O, int R, int Kd, int J, int D), (c, F, Y, O, R, Kd, J, D))
+GF_HOST_OVERLOAD2(tensormatmul_backward_host,
+                  (gf_ctx * c, const double *g, const double *F, const double *Y, double *dF, double *dY, int R, int Kd, int J, int D),
+                  (gf_ctx * c, const float *g, const float *F, const float *Y, float *dF, float *dY, int R, int Kd, int J, int D),
+                  (c, g, F, Y, dF, dY, R, Kd, J, D))
+GF_HOST_OVERLOAD2(stack_forward_host, (gf_ctx * c, const double *const *t, double *o, int n, size_t per),
+                  (gf_ctx * c, const float *const *t, float *o, int n, size_t per), (c, t, o, n, per))
+GF_HOST_OVERLOAD2(stack_backward_host, (gf_ctx * c, const double *g, double *const *d, int n, size_t per),
+                  (gf_ctx * c, const float *g, float *const *d, int n, size_t per), (c, g, d, n, per))
+#undef GF_HOST_OVERLOAD2
+
 }  // namespace gfhost
 #endif

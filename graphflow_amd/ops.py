@@ -117,3 +117,82 @@ def contract_backward(G, A, K=18, dP=None, accumulate=False, ctx=None):
     ctx.check(ctx.lib.gf_contract_backward_f32(ctx.handle, K, _dev_f32(G, "G"), a_ptr, _dev_f32(dP, "dP"), N, C_, B,
                                                1 if accumulate else 0))
     return dP
+
+
+def _opt(t, name):
+    return _dev_f32(t, name) if t is not None else None
+
+
+def matmul_forward(A, B, out=None, ctx=None):
+    """C[M,N] = A[M,K] B[K,N]  (MatMul::forward)."""
+    M, K = A.shape
+    N = B.shape[1]
+    ctx = ctx or default_context(A.device.index or 0)
+    out = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
+    ctx.check(ctx.lib.gf_matmul_forward_f32(ctx.handle, _dev_f32(A, "A"), _dev_f32(B, "B"), _dev_f32(out, "C"), M, K, N))
+    return out
+
+
+def matmul_backward(dC, A, B, dA=None, dB=None, accumulate=False, ctx=None):
+    """dA (+)= dC B^T, dB (+)= A^T dC  (MatMul::backward); pass dA/dB tensors to select what is computed."""
+    M, K = A.shape
+    N = B.shape[1]
+    ctx = ctx or default_context(A.device.index or 0)
+    ctx.check(ctx.lib.gf_matmul_backward_f32(ctx.handle, _dev_f32(dC, "dC"), _dev_f32(A, "A"), _dev_f32(B, "B"),
+                                             _opt(dA, "dA"), _opt(dB, "dB"), M, K, N, 1 if accumulate else 0))
+    return dA, dB
+
+
+def mattensormul_forward(X, F, ctx=None):
+    R, Kd = X.shape
+    _, J, D = F.shape
+    ctx = ctx or default_context(X.device.index or 0)
+    out = torch.empty((R, J, D), dtype=torch.float32, device=X.device)
+    ctx.check(ctx.lib.gf_mattensormul_forward_f32(ctx.handle, _dev_f32(X, "X"), _dev_f32(F, "F"), _dev_f32(out, "Out"), R, Kd, J, D))
+    return out
+
+
+def mattensormul_backward(G, X, F, dX=None, dF=None, accumulate=False, ctx=None):
+    R, Kd = X.shape
+    _, J, D = F.shape
+    ctx = ctx or default_context(X.device.index or 0)
+    ctx.check(ctx.lib.gf_mattensormul_backward_f32(ctx.handle, _dev_f32(G, "G"), _dev_f32(X, "X"), _dev_f32(F, "F"),
+                                                   _opt(dX, "dX"), _opt(dF, "dF"), R, Kd, J, D, 1 if accumulate else 0))
+    return dX, dF
+
+
+def tensormatmul_forward(F, Y, ctx=None):
+    R, Kd, D = F.shape
+    J = Y.shape[1]
+    ctx = ctx or default_context(F.device.index or 0)
+    out = torch.empty((R, J, D), dtype=torch.float32, device=F.device)
+    ctx.check(ctx.lib.gf_tensormatmul_forward_f32(ctx.handle, _dev_f32(F, "F"), _dev_f32(Y, "Y"), _dev_f32(out, "Out"), R, Kd, J, D))
+    return out
+
+
+def tensormatmul_backward(G, F, Y, dF=None, dY=None, accumulate=False, ctx=None):
+    R, Kd, D = F.shape
+    J = Y.shape[1]
+    ctx = ctx or default_context(F.device.index or 0)
+    ctx.check(ctx.lib.gf_tensormatmul_backward_f32(ctx.handle, _dev_f32(G, "G"), _dev_f32(F, "F"), _dev_f32(Y, "Y"),
+                                                   _opt(dF, "dF"), _opt(dY, "dY"), R, Kd, J, D, 1 if accumulate else 0))
+    return dF, dY
+
+
+def stack_forward(tensors, ctx=None):
+    """StackTensor3D::forward on device: a list of equally sized CUDA tensors -> one contiguous [n, ...] tensor."""
+    ctx = ctx or default_context(tensors[0].device.index or 0)
+    per = tensors[0].numel()
+    ptrs = torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=tensors[0].device)
+    out = torch.empty((len(tensors),) + tuple(tensors[0].shape), dtype=torch.float32, device=tensors[0].device)
+    ctx.check(ctx.lib.gf_stack_forward_f32(ctx.handle, C.c_void_p(ptrs.data_ptr()), _dev_f32(out, "out"), len(tensors), per))
+    return out
+
+
+def stack_backward(G, grads, ctx=None):
+    """StackTensor3D::backward on device: grads[r] += G[r]."""
+    ctx = ctx or default_context(G.device.index or 0)
+    per = grads[0].numel()
+    ptrs = torch.tensor([t.data_ptr() for t in grads], dtype=torch.int64, device=G.device)
+    ctx.check(ctx.lib.gf_stack_backward_f32(ctx.handle, _dev_f32(G, "G"), C.c_void_p(ptrs.data_ptr()), len(grads), per))
+    return grads

@@ -89,6 +89,51 @@ gf_status gf_contract_forward_host_f32(gf_ctx *ctx, int K, const float *const *t
 gf_status gf_contract_backward_host_f32(gf_ctx *ctx, int K, const float *out_gradient, const float *A,
                                         float *const *grads, int N, int C);
 
+/* ---- dense feature mixers, mode B (device pointers) ------------------------------------------------------------------
+ * All row-major.  One strided-batched fp32 MFMA GEMM underneath (v_mfma_f32_32x32x2_f32, exact fp32).
+ * backward: a NULL gradient pointer skips that operand; accumulate != 0 -> `+=` (the reference contract), else `=`.
+ *   MatMul        C[M,N] = A[M,K] B[K,N]                       GraphFlow/MatMul.h:48-67 / :69-82
+ *                 (GPU prior art: GraphFlow_gpu/MatMul_gpu.h:28-111)
+ *   MatTensorMul  Out[R,J,D] = sum_k X[R,Kd] F[Kd,J,D]         GraphFlow/MatTensorMul.h:47-68 / :70-85
+ *   TensorMatMul  Out[R,J,D] = sum_k F[R,Kd,D] Y[Kd,J]         GraphFlow/TensorMatMul.h:46-67 / :69-84                  */
+gf_status gf_matmul_forward_f32(gf_ctx *ctx, const float *A, const float *B, float *C, int M, int K, int N);
+gf_status gf_matmul_backward_f32(gf_ctx *ctx, const float *dC, const float *A, const float *B, float *dA, float *dB,
+                                 int M, int K, int N, int accumulate);
+gf_status gf_mattensormul_forward_f32(gf_ctx *ctx, const float *X, const float *F, float *Out, int R, int Kd, int J, int D);
+gf_status gf_mattensormul_backward_f32(gf_ctx *ctx, const float *G, const float *X, const float *F, float *dX, float *dF,
+                                       int R, int Kd, int J, int D, int accumulate);
+gf_status gf_tensormatmul_forward_f32(gf_ctx *ctx, const float *F, const float *Y, float *Out, int R, int Kd, int J, int D);
+gf_status gf_tensormatmul_backward_f32(gf_ctx *ctx, const float *G, const float *F, const float *Y, float *dF, float *dY,
+                                       int R, int Kd, int J, int D, int accumulate);
+/* StackTensor3D (GraphFlow/StackTensor3D.h:54-73 / :75-90): `tensors` / `grads` are DEVICE arrays of nRows device
+ * pointers, each to per_tensor floats; forward copies them into one contiguous buffer, backward scatter-adds back. */
+gf_status gf_stack_forward_f32(gf_ctx *ctx, const float *const *tensors, float *out, int nRows, size_t per_tensor);
+gf_status gf_stack_backward_f32(gf_ctx *ctx, const float *G, float *const *grads, int nRows, size_t per_tensor);
+
+/* ---- dense feature mixers, mode A (host pointers; gradients are always `+=`; NULL gradient pointers are skipped) --- */
+gf_status gf_matmul_forward_host_f64(gf_ctx *ctx, const double *A, const double *B, double *C, int M, int K, int N);
+gf_status gf_matmul_backward_host_f64(gf_ctx *ctx, const double *dC, const double *A, const double *B, double *dA,
+                                      double *dB, int M, int K, int N);
+gf_status gf_mattensormul_forward_host_f64(gf_ctx *ctx, const double *X, const double *F, double *Out, int R, int Kd, int J, int D);
+gf_status gf_mattensormul_backward_host_f64(gf_ctx *ctx, const double *G, const double *X, const double *F, double *dX,
+                                            double *dF, int R, int Kd, int J, int D);
+gf_status gf_tensormatmul_forward_host_f64(gf_ctx *ctx, const double *F, const double *Y, double *Out, int R, int Kd, int J, int D);
+gf_status gf_tensormatmul_backward_host_f64(gf_ctx *ctx, const double *G, const double *F, const double *Y, double *dF,
+                                            double *dY, int R, int Kd, int J, int D);
+gf_status gf_stack_forward_host_f64(gf_ctx *ctx, const double *const *tensors, double *out, int nRows, size_t per_tensor);
+gf_status gf_stack_backward_host_f64(gf_ctx *ctx, const double *G, double *const *grads, int nRows, size_t per_tensor);
+gf_status gf_stack_forward_host_f32(gf_ctx *ctx, const float *const *tensors, float *out, int nRows, size_t per_tensor);
+gf_status gf_stack_backward_host_f32(gf_ctx *ctx, const float *G, float *const *grads, int nRows, size_t per_tensor);
+gf_status gf_matmul_forward_host_f32(gf_ctx *ctx, const float *A, const float *B, float *C, int M, int K, int N);
+gf_status gf_matmul_backward_host_f32(gf_ctx *ctx, const float *dC, const float *A, const float *B, float *dA, float *dB,
+                                      int M, int K, int N);
+gf_status gf_mattensormul_forward_host_f32(gf_ctx *ctx, const float *X, const float *F, float *Out, int R, int Kd, int J, int D);
+gf_status gf_mattensormul_backward_host_f32(gf_ctx *ctx, const float *G, const float *X, const float *F, float *dX,
+                                            float *dF, int R, int Kd, int J, int D);
+gf_status gf_tensormatmul_forward_host_f32(gf_ctx *ctx, const float *F, const float *Y, float *Out, int R, int Kd, int J, int D);
+gf_status gf_tensormatmul_backward_host_f32(gf_ctx *ctx, const float *G, const float *F, const float *Y, float *dF,
+                                            float *dY, int R, int Kd, int J, int D);
+
 #ifdef __cplusplus
 }
 #endif

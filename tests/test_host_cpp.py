@@ -50,3 +50,10 @@ def test_entity_style_op_parity_f64(bins, N, C, K):
 def test_entity_style_op_parity_f32_containers(bins):
     r = subprocess.run([os.path.join(bins, "test_RisiContraction_hip_f32"), "16", "8", "18"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_entity_style_mixers_and_vertex_chain(bins):
+    r = subprocess.run([os.path.join(bins, "test_Mixers_hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASSED" in r.stdout
