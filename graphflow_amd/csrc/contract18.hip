@@ -35,6 +35,22 @@ __device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<con
 __device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
 __device__ __forceinline__ f4 splat(float x) { return f4{x, x, x, x}; }
 
+// Buffer addressing (cdna guide T8/T20): a wave-uniform 128-bit descriptor in SGPRs + a loop-invariant 32-bit
+// per-lane byte offset + a scalar row offset.  Keeps the streaming loops free of 64-bit VALU address arithmetic and
+// of the VGPR pairs that flat addressing would pin for every load.  The descriptor base must be provably uniform
+// (built from kernel arguments and blockIdx only).
+using u4 = __attribute__((ext_vector_type(4))) unsigned int;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, size_t bytes) {
+    const unsigned n = bytes > 0xfffffffcull ? 0xfffffffcu : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ f4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
+}
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes, f4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff_bytes, soff_bytes, 0);
+}
+
 __device__ __forceinline__ f4 shfl_xor4(f4 v, int m) {
     f4 r;
     r.x = __shfl_xor(v.x, m);
@@ -124,6 +140,24 @@ __device__ __forceinline__ void small_matvec(const AdjLds &L, int N, int y, int 
     }
 }
 
+// sum_{y in [lo,hi)} w(y) * ld4(base + y*stride): the loads of a batch of 8 are all issued before the first add, so a
+// length-N reduction costs ceil(N/8) memory latencies instead of N.
+template <typename W>
+__device__ __forceinline__ f4 batched_sum(const float *base, size_t stride, int lo, int hi, W weight) {
+    f4 s = splat(0.f);
+    for (int y0 = lo; y0 < hi; y0 += 8) {
+        f4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int y = (y0 + j < hi) ? y0 + j : lo;  // clamped re-read, weight forced to 0 below
+            t[j] = ld4(base + (size_t)y * stride);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += ((y0 + j < hi) ? weight(y0 + j) : 0.f) * t[j];
+    }
+    return s;
+}
+
 struct BlockId {
     int g, i, win;
 };
@@ -147,16 +181,16 @@ __device__ __forceinline__ BlockId decode_block(int N, int nwin) {
 // ------------------------------------------------------------------------------------------------------------
 template <int LPC, int NI>
 struct SlabLane {
-    int coff[NI];    // element offset of this lane's i-th load inside a row (clamped to a valid c)
+    int coff[NI];    // BYTE offset of this lane's i-th load inside a row (clamped to a valid c)
     float cmask[NI];  // 1 where (c < N and channel quad in range), else 0
 };
 
 template <int LPC, int NI, bool FULL>
-__device__ __forceinline__ void load_slab_row(const float *__restrict__ row, const SlabLane<LPC, NI> &ln, int dgoff,
-                                              f4 (&v)[NI], f4 &dg) {
+__device__ __forceinline__ void load_slab_row(__amdgpu_buffer_rsrc_t slab, int row_bytes, const SlabLane<LPC, NI> &ln,
+                                              int dgoff_bytes, f4 (&v)[NI], f4 &dg) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) v[i] = ld4(row + ln.coff[i]);
-    dg = ld4(row + dgoff);
+    for (int i = 0; i < NI; ++i) v[i] = buf_ld4(slab, ln.coff[i], row_bytes);
+    dg = buf_ld4(slab, dgoff_bytes, row_bytes);
 }
 
 template <int LPC, int NI, bool FULL>
@@ -168,7 +202,8 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
     constexpr int CW = 4 * LPC;
     constexpr int NCP = NI * PPW;  // padded c extent (>= N)
     static_assert(PPW >= 4, "row epilogue uses four c-groups");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row base addresses stay in SGPRs
     const int cg = lane / LPC, fl = lane % LPC;
     const BlockId B = decode_block(N, nwin);
     const int g = B.g, b = B.i;
@@ -191,15 +226,17 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
     for (int i = 0; i < NI; ++i) {
         const int c = i * PPW + cg;
         const bool ok = FULL || (c < N);
-        ln.coff[i] = (ok ? c : 0) * C + fld;
+        ln.coff[i] = ((ok ? c : 0) * C + fld) * 4;
         ln.cmask[i] = (ok && fok) ? 1.f : 0.f;
         rc[i] = (ok && fok) ? L.r[ok ? c : 0] : 0.f;
     }
     const float dmask = (cg < 2 && fok) ? 1.f : 0.f;
 
-    const float *Pg = P + (size_t)g * N * N * N * C;
-    const size_t rowStride = (size_t)N * N * C;
-    const float *row0 = Pg + (size_t)b * N * C;  // + a*rowStride
+    // slab descriptor: base P[g][0][b][0][0]; row a starts a*N*N*C floats further (scalar offset)
+    const float *slab0 = P + (size_t)g * N * N * N * C + (size_t)b * N * C;
+    const __amdgpu_buffer_rsrc_t slab = make_rsrc(slab0, ((size_t)N * N * N * C - (size_t)b * N * C) * 4);
+    const int rowBytes = N * N * C * 4;
+    const int dgA = fld * 4 + C * 4 * b;  // lanes cg==0 read P[a,b,b]; lanes cg!=0 read P[a,b,a] (offset depends on a)
 
     f4 sbc[NI], t10[NI];
 #pragma unroll
@@ -207,11 +244,13 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
     f4 dgsum = splat(0.f);  // cg==0: sum_a P[a,b,b]   cg==1: sum_a P[a,b,a]
 
     f4 cur[NI], nxt[NI], dcur, dnxt;
-    load_slab_row<LPC, NI, FULL>(row0 + (wave < N ? wave : 0) * rowStride, ln,
-                                 ((cg == 0) ? b : (wave < N ? wave : 0)) * C + fld, cur, dcur);
+    {
+        const int a0 = wave < N ? wave : 0;
+        load_slab_row<LPC, NI, FULL>(slab, a0 * rowBytes, ln, (cg == 0) ? dgA : (fld + C * a0) * 4, cur, dcur);
+    }
     for (int a = wave; a < N; a += kWaves) {
         const int an = (a + kWaves < N) ? a + kWaves : a;  // last iteration re-reads its own row (L1/L2 hit)
-        load_slab_row<LPC, NI, FULL>(row0 + an * rowStride, ln, ((cg == 0) ? b : an) * C + fld, nxt, dnxt);
+        load_slab_row<LPC, NI, FULL>(slab, an * rowBytes, ln, (cg == 0) ? dgA : (fld + C * an) * 4, nxt, dnxt);
         const float ra = L.r[a];
         f4 sab = splat(0.f), t6 = splat(0.f);
 #pragma unroll
@@ -354,20 +393,41 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_rows(const float *__restrict
     const AdjLds L = load_adjacency<false>(smem, A + (size_t)g * N * N, N);
     float *sT0 = smem + adj_lds_floats(N);  // [N][CW] S_ab[a, e]
     float *sT1 = sT0 + N * CW;              // [N][CW] P[a, e, e]
-    float *sS = sT1 + N * CW;               // [4][CW] total, s14, s15, s18
+    float *sS = sT1 + N * CW;               // [(NPART+1)*4][CW] pieces, then total, s14, s15, s18
 
     for (int e = grp; e < N; e += NGRP) {
         const size_t w = (((size_t)g * N + a) * N + e) * (size_t)C + f;
         st4(sT0 + e * CW + 4 * fl, fok ? ld4(wsSab + w) : splat(0.f));
         st4(sT1 + e * CW + 4 * fl, fok ? ld4(wsDbb + w) : splat(0.f));
     }
-    if (grp < 4) {
-        f4 s = splat(0.f);
-        if (fok)
-            for (int bb = 0; bb < N; ++bb) s += ld4(wsScal + (((size_t)g * N + bb) * 4 + grp) * (size_t)C + f);
-        st4(sS + grp * CW + 4 * fl, s);
+    {   // four length-N sums of the partial scalars, each split in NPART pieces over the thread groups
+        constexpr int NPART = (NGRP >= 16) ? 4 : 1;
+        const int j = grp % 4, part = grp / 4;
+        if (part < NPART) {
+            f4 sum = splat(0.f);
+            if (fok) {
+                const int per = (N + NPART - 1) / NPART;
+                const int lo = part * per, hi = (lo + per < N) ? lo + per : N;
+                if (lo < hi)
+                    sum = batched_sum(wsScal + ((size_t)g * N * 4 + j) * (size_t)C + f, 4 * (size_t)C, lo, hi,
+                                      [](int) { return 1.f; });
+            }
+            st4(sS + (part * 4 + j) * CW + 4 * fl, sum);
+        }
     }
     __syncthreads();
+    if (tid < 4 * LPC) {  // fold the pieces
+        constexpr int NPART = (NGRP >= 16) ? 4 : 1;
+        f4 sum = splat(0.f);
+#pragma unroll
+        for (int p = 0; p < NPART; ++p) sum += ld4(sS + (p * 4 + grp) * CW + 4 * fl);
+        st4(sS + (NPART * 4 + grp) * CW + 4 * fl, sum);
+    }
+    __syncthreads();
+    {
+        constexpr int NPART = (NGRP >= 16) ? 4 : 1;
+        sS += NPART * 4 * CW;  // folded totals live behind the pieces
+    }
 
     f4 rowsum = splat(0.f), d8 = splat(0.f);
     for (int e = 0; e < N; ++e) {
@@ -398,7 +458,7 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_rows(const float *__restrict
 template <int LPC>
 static size_t fwd_rows_lds_bytes(int N) {
     constexpr int CW = 4 * LPC;
-    return sizeof(float) * ((size_t)adj_lds_floats(N) + 2 * (size_t)N * CW + 4 * CW);
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + 2 * (size_t)N * CW + 20 * CW);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -413,7 +473,7 @@ __global__ __launch_bounds__(kThreads) void r18_bwd_rows(const float *__restrict
                                                          float *__restrict__ wsPart, int N, int C, int nwin) {
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
-    static_assert(NGRP >= 6, "six reductions are spread over thread groups");
+    static_assert(NGRP >= 12, "six reductions in two halves are spread over thread groups");
     const int tid = threadIdx.x;
     const int grp = tid / LPC, fl = tid % LPC;
     const BlockId B = decode_block(N, nwin);
@@ -432,19 +492,25 @@ __global__ __launch_bounds__(kThreads) void r18_bwd_rows(const float *__restrict
         st4(sT8 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 8) * C) : splat(0.f));
         st4(sT15 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 15) * C) : splat(0.f));
     }
-    if (grp < 6) {
-        const int kk = (grp == 0) ? 1 : (grp == 1) ? 7 : (grp == 2) ? 4 : (grp == 3) ? 13 : (grp == 4) ? 14 : 17;
-        f4 s = splat(0.f);
-        if (fok)
-            for (int y = 0; y < N; ++y) {
-                const float w = (grp < 2) ? L.r[y] : L.A[y * (N + 1) + a];  // r[d]  or  A+[a][e]
-                s += w * ld4(Grow + ((size_t)y * kK + kk) * C);
+    {   // six length-N reductions, each split in two halves over 12 thread groups
+        const int j = grp % 6, half = grp / 6;
+        if (half < 2) {
+            const int kk = (j == 0) ? 1 : (j == 1) ? 7 : (j == 2) ? 4 : (j == 3) ? 13 : (j == 4) ? 14 : 17;
+            f4 sum = splat(0.f);
+            if (fok) {
+                const int lo = half ? (N + 1) / 2 : 0, hi = half ? N : (N + 1) / 2;
+                const float *w = (j < 2) ? L.r : (L.A + a);          // r[d]  or  A+[a][e] (stored transposed)
+                const int ws = (j < 2) ? 1 : (N + 1);
+                if (lo < hi)
+                    sum = batched_sum(Grow + (size_t)kk * C, (size_t)kK * C, lo, hi, [=](int y) { return w[y * ws]; });
             }
-        st4(sU + grp * CW + 4 * fl, s);
+            st4(sU + (half * 6 + j) * CW + 4 * fl, sum);
+        }
     }
     __syncthreads();
 
-    const f4 u2 = ld4(sU + 0 * CW + 4 * fl), u8 = ld4(sU + 1 * CW + 4 * fl);
+    const f4 u2 = ld4(sU + 0 * CW + 4 * fl) + ld4(sU + 6 * CW + 4 * fl);
+    const f4 u8 = ld4(sU + 1 * CW + 4 * fl) + ld4(sU + 7 * CW + 4 * fl);
     const float *const T[2] = {sT8, sT15};
     for (int bb = grp; bb < N; bb += NGRP) {
         f4 m[2];
@@ -455,13 +521,15 @@ __global__ __launch_bounds__(kThreads) void r18_bwd_rows(const float *__restrict
             st4(wsWZ + w, u8 + m[1]);
         }
     }
-    if (grp < 4 && fok) st4(wsPart + (((size_t)g * N + a) * 4 + grp) * (size_t)C + f, ld4(sU + (2 + grp) * CW + 4 * fl));
+    if (grp < 4 && fok)
+        st4(wsPart + (((size_t)g * N + a) * 4 + grp) * (size_t)C + f,
+            ld4(sU + (2 + grp) * CW + 4 * fl) + ld4(sU + (8 + grp) * CW + 4 * fl));
 }
 
 template <int LPC>
 static size_t bwd_rows_lds_bytes(int N) {
     constexpr int CW = 4 * LPC;
-    return sizeof(float) * ((size_t)adj_lds_floats(N) + 2 * (size_t)N * CW + 6 * CW);
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + 2 * (size_t)N * CW + 12 * CW);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -474,15 +542,16 @@ static size_t bwd_rows_lds_bytes(int N) {
 //   V17[a] = sum_d G16[b,d] A[d,a];  u5,u14,u15,u18 = sum_a part[a][.]
 // ------------------------------------------------------------------------------------------------------------
 template <int LPC, int NI, bool FULL, bool ACC>
-__global__ __launch_bounds__(kThreads) void r18_bwd_slab(const float *__restrict__ G, const float *__restrict__ A,
+__global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restrict__ G, const float *__restrict__ A,
                                                          float *__restrict__ dP, const float *__restrict__ wsWX,
                                                          const float *__restrict__ wsWZ,
                                                          const float *__restrict__ wsPart, int N, int C, int nwin) {
     constexpr int PPW = 64 / LPC;
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
-    static_assert(NGRP >= 6, "six reductions are spread over thread groups");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert(NGRP >= 12, "six reductions in two halves are spread over thread groups");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row base addresses stay in SGPRs
     const int cg = lane / LPC, fl = lane % LPC;  // streaming role
     const int grp = tid / LPC;                   // table-building role (same fl: LPC divides 64)
     const BlockId B = decode_block(N, nwin);
@@ -492,15 +561,17 @@ __global__ __launch_bounds__(kThreads) void r18_bwd_slab(const float *__restrict
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AdjLds L = load_adjacency<true>(smem, A + (size_t)g * N * N, N);  // L.A[y][d] = A+[d][y]
+    // LDS: phase (i) holds the three G tables feeding the A^T products; phase (ii) overwrites them with the five
+    // tables the streaming loop reads (the products are held in registers across the barrier in between).
     float *sT11 = smem + adj_lds_floats(N);  // [N][CW] G11[b, d]
     float *sT12 = sT11 + N * CW;             //         G12[b, d]
     float *sT16 = sT12 + N * CW;             //         G16[b, d]
-    float *sX = sT16 + N * CW;               // [N][CW]
-    float *sY = sX + N * CW;
-    float *sG5 = sY + N * CW;
-    float *sZ1 = sG5 + N * CW;
+    float *sX = sT11;                        // [N][CW] (aliases)
+    float *sY = sT12;
+    float *sG5 = sT16;
+    float *sZ1 = sT16 + N * CW;
     float *sZ2 = sZ1 + N * CW;
-    float *sU = sZ2 + N * CW;  // [6][CW]: U4, U11, u5, u14, u15, u18
+    float *sU = sZ2 + N * CW;  // [2][6][CW]: two half-sums of U4, U11, u5, u14, u15, u18
     const float tot = L.st[0], tr = L.st[1];
 
     const float *Grow = G + (((size_t)g * N + b) * N) * (size_t)(kK * C) + f;  // G[g][b][y][k][f]
@@ -509,49 +580,71 @@ __global__ __launch_bounds__(kThreads) void r18_bwd_slab(const float *__restrict
         st4(sT12 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 12) * C) : splat(0.f));
         st4(sT16 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 16) * C) : splat(0.f));
     }
-    if (grp < 6) {
-        f4 s = splat(0.f);
-        if (fok) {
-            if (grp < 2) {
-                const int kk = (grp == 0) ? 3 : 10;
-                for (int d = 0; d < N; ++d) s += L.r[d] * ld4(Grow + ((size_t)d * kK + kk) * C);
-            } else {
-                for (int aa = 0; aa < N; ++aa) s += ld4(wsPart + (((size_t)g * N + aa) * 4 + (grp - 2)) * (size_t)C + f);
+    {   // six length-N reductions, each split in two halves over 12 thread groups
+        const int j = grp % 6, half = grp / 6;
+        if (half < 2) {
+            f4 s = splat(0.f);
+            if (fok) {
+                const int lo = half ? (N + 1) / 2 : 0, hi = half ? N : (N + 1) / 2;
+                if (lo < hi) {
+                    if (j < 2) {
+                        const float *rr = L.r;
+                        s = batched_sum(Grow + (size_t)((j == 0) ? 3 : 10) * C, (size_t)kK * C, lo, hi,
+                                        [=](int d) { return rr[d]; });
+                    } else {
+                        s = batched_sum(wsPart + ((size_t)g * N * 4 + (j - 2)) * (size_t)C + f, 4 * (size_t)C, lo, hi,
+                                        [](int) { return 1.f; });
+                    }
+                }
             }
+            st4(sU + (half * 6 + j) * CW + 4 * fl, s);
         }
-        st4(sU + grp * CW + 4 * fl, s);
     }
     __syncthreads();
 
     {
-        const f4 u4 = ld4(sU + 0 * CW + 4 * fl), u11 = ld4(sU + 1 * CW + 4 * fl), u5 = ld4(sU + 2 * CW + 4 * fl);
-        const f4 u14 = ld4(sU + 3 * CW + 4 * fl), u15 = ld4(sU + 4 * CW + 4 * fl), u18 = ld4(sU + 5 * CW + 4 * fl);
+        f4 u[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) u[j] = ld4(sU + j * CW + 4 * fl) + ld4(sU + (6 + j) * CW + 4 * fl);
+        const f4 u4 = u[0], u11 = u[1], u5 = u[2], u14 = u[3], u15 = u[4], u18 = u[5];
         const float *const T[3] = {sT11, sT12, sT16};
-        for (int y = grp; y < N; y += NGRP) {
+        constexpr int YB = (8 * PPW + NGRP - 1) / NGRP;  // rows per thread group: N <= 8*PPW  =>  YB <= 2
+        f4 tx[YB], ty[YB], tg5[YB], tz1[YB], tz2[YB];
+#pragma unroll
+        for (int q = 0; q < YB; ++q) {
+            const int y = grp + q * NGRP;
+            const int yy = y < N ? y : 0;
             f4 m[3];
-            small_matvec<3, CW>(L, N, y, fl, T, m);  // V12[y], V13[y], V17[y]
-            f4 g0 = splat(0.f), g6 = splat(0.f), g5 = splat(0.f), wx = splat(0.f), wz = splat(0.f), g2 = splat(0.f);
-            if (fok) {
-                const float *gab = G + (((size_t)g * N + y) * N + b) * (size_t)(kK * C) + f;  // G[g][y][b][k][f]
-                g0 = ld4(gab + 0 * C);
-                g6 = ld4(gab + 6 * C);
-                g5 = ld4(gab + 5 * C);
-                const size_t w = (((size_t)g * N + y) * N + b) * (size_t)C + f;
-                wx = ld4(wsWX + w);
-                wz = ld4(wsWZ + w);
-                g2 = ld4(Grow + ((size_t)y * kK + 2) * C);
-            }
+            small_matvec<3, CW>(L, N, yy, fl, T, m);  // V12[y], V13[y], V17[y]
+            const int fc = fok ? f : 0;
+            const float *gab = G + (((size_t)g * N + yy) * N + b) * (size_t)(kK * C) + fc;  // G[g][y][b][k][f]
+            const f4 g0 = ld4(gab + 0 * C), g6 = ld4(gab + 6 * C), g5 = ld4(gab + 5 * C);
+            const size_t w = (((size_t)g * N + yy) * N + b) * (size_t)C + fc;
+            const f4 wx = ld4(wsWX + w), wz = ld4(wsWZ + w);
+            const f4 g2 = ld4(G + (((size_t)g * N + b) * N + yy) * (size_t)(kK * C) + 2 * C + fc);
             f4 x = tot * g0 + tr * g6 + wx + u4 + u5 + m[0];
             f4 z1 = wz + u15;
-            if (y == b) {
+            if (yy == b) {
                 x += u14;
                 z1 += u18;
             }
-            st4(sX + y * CW + 4 * fl, x);
-            st4(sY + y * CW + 4 * fl, tot * g2 + m[1]);
-            st4(sG5 + y * CW + 4 * fl, g5);
-            st4(sZ1 + y * CW + 4 * fl, z1);
-            st4(sZ2 + y * CW + 4 * fl, u11 + m[2]);
+            tx[q] = x;
+            ty[q] = tot * g2 + m[1];
+            tg5[q] = g5;
+            tz1[q] = z1;
+            tz2[q] = u11 + m[2];
+        }
+        __syncthreads();  // every thread is done reading the G tables: overwrite them
+#pragma unroll
+        for (int q = 0; q < YB; ++q) {
+            const int y = grp + q * NGRP;
+            if (y < N) {
+                st4(sX + y * CW + 4 * fl, tx[q]);
+                st4(sY + y * CW + 4 * fl, ty[q]);
+                st4(sG5 + y * CW + 4 * fl, tg5[q]);
+                st4(sZ1 + y * CW + 4 * fl, tz1[q]);
+                st4(sZ2 + y * CW + 4 * fl, tz2[q]);
+            }
         }
     }
     __syncthreads();
@@ -603,7 +696,7 @@ __global__ __launch_bounds__(kThreads) void r18_bwd_slab(const float *__restrict
 template <int LPC>
 static size_t bwd_slab_lds_bytes(int N) {
     constexpr int CW = 4 * LPC;
-    return sizeof(float) * ((size_t)adj_lds_floats(N) + 8 * (size_t)N * CW + 6 * CW);
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + 5 * (size_t)N * CW + 12 * CW);
 }
 
 // ------------------------------------------------------------------------------------------------------------
