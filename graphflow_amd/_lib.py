@@ -55,6 +55,15 @@ PROTOTYPES.update({
     "gf_mattensormul_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gf_tensormatmul_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "gf_tensormatmul_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gf_smp_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "gf_smp_destroy": (_i, [_vp]),
+    "gf_smp_param_count": (C.c_size_t, [_vp]),
+    "gf_smp_prepare": (_i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
+    "gf_smp_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "gf_smp_backward": (_i, [_vp, _vp, _vp, _i]),
+    "gf_smp_prepare_molecule_host": (_i, [_vp, _i, C.POINTER(C.c_int), _dp, C.POINTER(C.c_int), _dp]),
+    "gf_smp_receptive_field": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int), _i]),
+    "gf_smp_level_sizes": (_i, [_vp, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "gf_stack_forward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
     "gf_stack_backward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
 })

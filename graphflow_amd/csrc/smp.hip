@@ -1,0 +1,539 @@
+// smp.hip -- batched SMP_omega (second-order CCN) forward/backward on the device.
+//
+// Reproduces the op DAG that SMP_omega::complete_computation_graph builds per molecule
+// (GraphFlow/SMP_omega.h:607-692) for a whole BATCH of molecules at once:
+//   level 0   f_0[v] = LeakyReLU(H x_v)                                         (:617-626)
+//   level l   T_w = X_vw f_{l-1}[w] X_vw^T  for w in phi_l(v)   -> index gather (MatTensorMul + TensorMatMul, :641-645)
+//             P = stack_w T_w ; Q = RisiContraction_18(P, A_v)                  (:647-651)
+//             f_l[v] = LeakyReLU(reshape(Q)[s^2,18C] K_l + b_l)                 (:654-669)
+//   readout   g = sum_v LeakyReLU(sum_ij f_L[v]) ; y = <g, W> ; loss = (y - t)^2 / 2   (:676-692)
+// and the reverse sweep (GraphFlow.h:729: reverse insertion order; every op `+=` into its inputs).
+// The X matrices are 0/1 selections, so X F X^T is F[pi(i), pi(j)] or 0 (verified exact in the tests): the promotion
+// is an index gather forward and a deterministic consumer-list gather backward (no atomics).
+// Nodes of a level are bucketed by receptive-field size; each bucket is one uniform-N contraction launch and all
+// buckets share one tall K-projection GEMM per level.
+#include <cstring>
+#include <string>
+
+#include "gf_internal.h"
+#include "smp_prep.h"
+
+namespace gf {
+gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *A, int lda, long long sA, const float *B,
+               int ldb, long long sB, float *C, int ldc, long long sC, int batch, int accumulate);
+}
+
+struct gf_smp {
+    gf_ctx *ctx = nullptr;
+    gfsmp::Config cfg;
+    gfsmp::BatchLayout lay;
+    bool prepared = false, forwarded = false;
+    // device buffers (owned)
+    struct DevLevel {
+        int *node_s = nullptr;
+        long long *node_row = nullptr, *node_p = nullptr, *node_pair = nullptr;
+        float *adj = nullptr;
+        int *pair_node = nullptr, *pair_src_s = nullptr, *cons_s = nullptr;
+        long long *pair_src_row = nullptr, *cons_ptr = nullptr, *cons_slab = nullptr, *cons_inv_off = nullptr;
+        short *pi = nullptr, *inv = nullptr;
+        float *f = nullptr, *df = nullptr, *Q = nullptr;  // activations [rows][C], their gradient, contraction out [rows][18C]
+    };
+    std::vector<DevLevel> lv;
+    float *x = nullptr;      // [nVertices][FD]
+    float *P = nullptr;      // shared promotion / dP buffer, max over levels of ppos*C
+    float *sh = nullptr, *vf = nullptr;  // [nNodes][C] readout pre/post activation
+    float *g = nullptr;      // [nMol][C] graph features
+    float *yhat = nullptr, *dy = nullptr;  // [nMol]
+    float *colpart = nullptr;  // partial column sums for bias gradients
+    int *top_node_mol = nullptr, *mol_ptr = nullptr, *mol_nodes = nullptr;
+    std::vector<void *> allocs;
+};
+
+namespace gf {
+namespace {
+
+constexpr float kAlpha = 0.01f;  // LeakyReLU3D.h:41, LeakyReLU.h default
+constexpr int kK = 18;
+
+#define GRID_STRIDE(idx, total) \
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < (total); idx += (size_t)gridDim.x * blockDim.x)
+
+unsigned grid_for(size_t total, int per_block = 256) {
+    size_t blocks = (total + per_block - 1) / per_block;
+    return (unsigned)(blocks > 1048576 ? 1048576 : (blocks == 0 ? 1 : blocks));
+}
+
+__device__ __forceinline__ float lrelu(float z) { return z > 0.f ? z : kAlpha * z; }
+
+// ---- promotion: P[n][a][b][c][:] = f_prev[src(n,a)][pi(b)][pi(c)][:] or 0 -------------------------------------------
+// one workgroup per (node, neighbour) pair; threads run over (b, c, channel) with the channel fastest (coalesced)
+__global__ void promote_forward(const float *__restrict__ fprev, float *__restrict__ P, const int *__restrict__ node_s,
+                                const long long *__restrict__ node_row, const long long *__restrict__ node_p,
+                                const long long *__restrict__ node_pair, const int *__restrict__ pair_node,
+                                const long long *__restrict__ pair_src_row, const int *__restrict__ pair_src_s,
+                                const short *__restrict__ pi, int C) {
+    const long long e = blockIdx.x;
+    const int n = pair_node[e];
+    const int s = node_s[n], a = (int)(e - node_pair[n]), sw = pair_src_s[e];
+    const short *map = pi + node_row[n] + (long long)a * s;
+    const float *src = fprev + pair_src_row[e] * C;
+    float *dst = P + (node_p[n] + (long long)a * s * s) * C;
+    const int total = s * s * C;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int f = i % C, bc = i / C;
+        const int b = bc / s, c = bc - b * s;
+        const int pb = map[b], pc = map[c];
+        dst[i] = (pb >= 0 && pc >= 0) ? src[((size_t)pb * sw + pc) * C + f] : 0.f;
+    }
+}
+
+// backward: df_prev[w][p][q][:] = sum over consumers (n,a) of dP[n][a][inv(p)][inv(q)][:]
+__global__ void promote_backward(const float *__restrict__ dP, float *__restrict__ dfprev,
+                                 const int *__restrict__ prev_s, const long long *__restrict__ prev_row,
+                                 const long long *__restrict__ cons_ptr, const long long *__restrict__ cons_slab,
+                                 const int *__restrict__ cons_s, const long long *__restrict__ cons_inv_off,
+                                 const short *__restrict__ inv, int C) {
+    const int w = blockIdx.x;
+    const int sw = prev_s[w];
+    float *dst = dfprev + prev_row[w] * C;
+    const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
+    const int total = sw * sw * C;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int f = i % C, pq = i / C;
+        const int p = pq / sw, q = pq - p * sw;
+        float acc = 0.f;
+        for (long long e = c0; e < c1; ++e) {
+            const short *iv = inv + cons_inv_off[e];
+            const int ib = iv[p], ic = iv[q];
+            if (ib >= 0 && ic >= 0) acc += dP[(cons_slab[e] + (long long)ib * cons_s[e] + ic) * C + f];
+        }
+        dst[i] = acc;
+    }
+}
+
+// ---- bias + LeakyReLU ---------------------------------------------------------------------------------------------
+__global__ void bias_lrelu_forward(float *__restrict__ Y, const float *__restrict__ b, int C, size_t total) {
+    GRID_STRIDE(i, total) Y[i] = lrelu(Y[i] + (b ? b[i % C] : 0.f));
+}
+
+// dZ = dF * lrelu'(z), decided from the sign of the stored activation (LeakyReLU is monotone: f > 0 <=> z > 0);
+// also leaves per-block partial column sums of dZ for the bias gradient (VectorAddTensor.h:61-72)
+__global__ void lrelu_backward_colsum(const float *__restrict__ F, float *__restrict__ dF, float *__restrict__ part, int C,
+                                      long long rows, int rows_per_block) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+    for (int f = threadIdx.x; f < C; f += blockDim.x) {
+        float s = 0.f;
+        for (long long r = r0; r < r1; ++r) {
+            const size_t i = (size_t)r * C + f;
+            const float d = dF[i] * (F[i] > 0.f ? 1.f : kAlpha);
+            dF[i] = d;
+            s += d;
+        }
+        part[(size_t)blockIdx.x * C + f] = s;
+    }
+}
+
+__global__ void colsum_finish(const float *__restrict__ part, float *__restrict__ out, int C, int nblocks) {
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < C; f += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * C + f];
+        out[f] += s;
+    }
+}
+
+// ---- readout ----------------------------------------------------------------------------------------------------------
+// sh[n][:] = sum_{ij} f_L[n][i][j][:]  (ShrinkTensor.h:37-50), vf = LeakyReLU(sh)
+__global__ void readout_nodes(const float *__restrict__ fL, const int *__restrict__ node_s,
+                              const long long *__restrict__ node_row, float *__restrict__ sh, float *__restrict__ vf,
+                              int C, size_t total) {
+    GRID_STRIDE(i, total) {
+        const int f = i % C;
+        const size_t n = i / C;
+        const int s = node_s[n];
+        const float *src = fL + node_row[n] * C + f;
+        float acc = 0.f;
+        for (int r = 0; r < s * s; ++r) acc += src[(size_t)r * C];
+        sh[i] = acc;
+        vf[i] = lrelu(acc);
+    }
+}
+
+// one workgroup per molecule: g = sum_v vf (SumVectors), y = <g, W> (InnerProduct.h:39-46), loss (SquaredLoss.h:45-53)
+__global__ void readout_molecules(const float *__restrict__ vf, const int *__restrict__ mol_ptr,
+                                  const int *__restrict__ mol_nodes, const float *__restrict__ W,
+                                  const float *__restrict__ target, float *__restrict__ g, float *__restrict__ yhat,
+                                  float *__restrict__ loss, float *__restrict__ dy, int C) {
+    __shared__ float red[256];
+    const int m = blockIdx.x;
+    float part = 0.f;
+    for (int f = threadIdx.x; f < C; f += blockDim.x) {
+        float acc = 0.f;
+        for (int k = mol_ptr[m]; k < mol_ptr[m + 1]; ++k) acc += vf[(size_t)mol_nodes[k] * C + f];
+        g[(size_t)m * C + f] = acc;
+        part += acc * W[f];
+    }
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float y = red[0], t = target ? target[m] : 0.f;
+        yhat[m] = y;
+        if (loss) loss[m] = 0.5f * (y - t) * (y - t);
+        dy[m] = y - t;  // SquaredLoss::backward: predict->gradient += predict - target
+    }
+}
+
+// dW[f] += sum_m dy[m] g[m][f]   (InnerProduct.h:48-53, second operand)
+__global__ void readout_dW(const float *__restrict__ dy, const float *__restrict__ g, float *__restrict__ dW, int C, int nMol) {
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < C; f += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int m = 0; m < nMol; ++m) acc += dy[m] * g[(size_t)m * C + f];
+        dW[f] += acc;
+    }
+}
+
+// df_L[n][i][j][:] = dy[mol(n)] * W[:] * lrelu'(sh[n][:])   (InnerProduct first operand -> SumVectors -> LeakyReLU
+// -> ShrinkTensor::backward broadcast, ShrinkTensor.h:52-61)
+__global__ void readout_backward_nodes(const float *__restrict__ dy, const float *__restrict__ W, const float *__restrict__ sh,
+                                       const int *__restrict__ node_mol, const int *__restrict__ node_s,
+                                       const long long *__restrict__ node_row, float *__restrict__ dfL, int C) {
+    const int n = blockIdx.x;
+    const int s = node_s[n];
+    float *dst = dfL + node_row[n] * C;
+    const float d = dy[node_mol[n]];
+    const int total = s * s * C;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int f = i % C;
+        dst[i] = d * W[f] * (sh[(size_t)n * C + f] > 0.f ? 1.f : kAlpha);
+    }
+}
+
+__global__ void zero_f32(float *p, size_t n) { GRID_STRIDE(i, n) p[i] = 0.f; }
+
+template <typename T>
+gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
+    *dst = nullptr;
+    const size_t bytes = sizeof(T) * (count ? count : 1);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(s->ctx, GF_ERR_NOMEM, "smp: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    s->allocs.push_back(p);
+    if (src && count) GF_HIP_TRY(s->ctx, hipMemcpyAsync(p, src, sizeof(T) * count, hipMemcpyHostToDevice, s->ctx->stream));
+    *dst = static_cast<T *>(p);
+    return GF_OK;
+}
+
+void release(gf_smp *s) {
+    if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
+    for (void *p : s->allocs) (void)hipFree(p);
+    s->allocs.clear();
+    s->lv.clear();
+    s->prepared = s->forwarded = false;
+}
+
+struct ParamView {
+    const float *H, *W;
+    std::vector<const float *> K, b;
+};
+size_t param_count(const gfsmp::Config &c) {
+    return (size_t)c.nChanels * c.fdim() + (size_t)c.nLevels * ((size_t)kK * c.nChanels * c.nChanels + c.nChanels) + c.nChanels;
+}
+// order H, (K_1, b_1), ..., (K_L, b_L), W -- the registration order of SMP_omega.h:289-295 (= save_model order)
+template <typename P>
+void view_params(const gfsmp::Config &c, P *base, P **H, std::vector<P *> *K, std::vector<P *> *b, P **W) {
+    P *p = base;
+    *H = p;
+    p += (size_t)c.nChanels * c.fdim();
+    K->assign(c.nLevels + 1, nullptr);
+    b->assign(c.nLevels + 1, nullptr);
+    for (int l = 1; l <= c.nLevels; ++l) {
+        (*K)[l] = p;
+        p += (size_t)kK * c.nChanels * c.nChanels;
+        (*b)[l] = p;
+        p += c.nChanels;
+    }
+    *W = p;
+}
+
+}  // namespace
+}  // namespace gf
+
+using gf::fail;
+
+extern "C" {
+
+gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!cfg || !out) return fail(ctx, GF_ERR_INVALID, "gf_smp_create: null argument");
+    if (cfg->nLevels < 1 || cfg->nChanels < 1 || cfg->nFeatures < 1 || cfg->nDepth < 0 || cfg->max_receptive_field < 1)
+        return fail(ctx, GF_ERR_INVALID, "gf_smp_create: bad configuration");
+    gf_smp *s = new gf_smp();
+    s->ctx = ctx;
+    s->cfg.nLevels = cfg->nLevels;
+    s->cfg.nChanels = cfg->nChanels;
+    s->cfg.nFeatures = cfg->nFeatures;
+    s->cfg.nDepth = cfg->nDepth;
+    s->cfg.max_receptive_field = cfg->max_receptive_field;
+    s->cfg.has_WL_ordering = cfg->has_WL_ordering;
+    *out = s;
+    return GF_OK;
+}
+
+gf_status gf_smp_destroy(gf_smp *s) {
+    if (!s) return GF_OK;
+    gf::release(s);
+    delete s;
+    return GF_OK;
+}
+
+size_t gf_smp_param_count(const gf_smp *s) { return s ? gf::param_count(s->cfg) : 0; }
+
+gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *adj, const double *feature) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    gf_ctx *ctx = s->ctx;
+    if (nMol <= 0 || !nVertices || !adj || !feature) return fail(ctx, GF_ERR_INVALID, "gf_smp_prepare: bad argument");
+    for (int m = 0; m < nMol; ++m)
+        if (nVertices[m] <= 0 || nVertices[m] > 32767) return fail(ctx, GF_ERR_INVALID, "molecule %d has %d vertices", m, nVertices[m]);
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gf::release(s);
+    gfsmp::build_batch(s->cfg, nMol, nVertices, adj, feature, &s->lay);
+    const gfsmp::BatchLayout &B = s->lay;
+    const int L = s->cfg.nLevels, C = s->cfg.nChanels;
+    s->lv.assign(L + 1, gf_smp::DevLevel());
+    gf_status st;
+#define UP(dst, vec)                                                         \
+    st = gf::upload(s, &(dst), (vec).empty() ? nullptr : &(vec)[0], (vec).size()); \
+    if (st != GF_OK) return st;
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64 layout");
+    long long maxp = 0;
+    size_t contract_ws = 0;
+    for (int l = 0; l <= L; ++l) {
+        const gfsmp::LevelLayout &h = B.level[l];
+        gf_smp::DevLevel &d = s->lv[l];
+        UP(d.node_s, h.node_s);
+        st = gf::upload(s, &d.node_row, &h.node_row[0], h.node_row.size());
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &d.f, nullptr, (size_t)h.rows * C);
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &d.df, nullptr, (size_t)h.rows * C);
+        if (st != GF_OK) return st;
+        if (l == 0) continue;
+        st = gf::upload(s, &d.node_p, &h.node_p[0], h.node_p.size());
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &d.node_pair, &h.node_pair[0], h.node_pair.size());
+        if (st != GF_OK) return st;
+        UP(d.adj, h.adj);
+        UP(d.pair_node, h.pair_node);
+        UP(d.pair_src_s, h.pair_src_s);
+        UP(d.cons_s, h.cons_s);
+        st = gf::upload(s, &d.pair_src_row, &h.pair_src_row[0], h.pair_src_row.size());
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &d.cons_ptr, &h.cons_ptr[0], h.cons_ptr.size());
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &d.cons_slab, h.cons_slab.empty() ? nullptr : &h.cons_slab[0], h.cons_slab.size());
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &d.cons_inv_off, h.cons_inv_off.empty() ? nullptr : &h.cons_inv_off[0], h.cons_inv_off.size());
+        if (st != GF_OK) return st;
+        UP(d.pi, h.pi);
+        UP(d.inv, h.inv);
+        st = gf::upload(s, &d.Q, nullptr, (size_t)h.rows * gf::kK * C);
+        if (st != GF_OK) return st;
+        if (h.ppos > maxp) maxp = h.ppos;
+        for (size_t b = 0; b < h.buckets.size(); ++b) {
+            const size_t w = gf_contract_workspace_bytes(18, h.buckets[b].s, C, h.buckets[b].count);
+            if (w > contract_ws) contract_ws = w;
+        }
+    }
+    UP(s->x, B.x);
+    st = gf::upload(s, &s->P, nullptr, (size_t)maxp * C);
+    if (st != GF_OK) return st;
+    const gfsmp::LevelLayout &top = B.level[L];
+    st = gf::upload(s, &s->sh, nullptr, (size_t)top.nNodes * C);
+    if (st != GF_OK) return st;
+    st = gf::upload(s, &s->vf, nullptr, (size_t)top.nNodes * C);
+    if (st != GF_OK) return st;
+    st = gf::upload(s, &s->g, nullptr, (size_t)nMol * C);
+    if (st != GF_OK) return st;
+    st = gf::upload(s, &s->yhat, nullptr, (size_t)nMol);
+    if (st != GF_OK) return st;
+    st = gf::upload(s, &s->dy, nullptr, (size_t)nMol);
+    if (st != GF_OK) return st;
+    UP(s->top_node_mol, top.node_mol);
+    std::vector<int> mol_ptr(nMol + 1, 0), mol_nodes(top.nNodes);
+    for (int m = 0; m < nMol; ++m) mol_ptr[m + 1] = B.mol_first_vertex[m + 1];
+    for (int gv = 0; gv < top.nNodes; ++gv) mol_nodes[gv] = B.top_node_of_vertex[gv];  // vertices of a molecule are contiguous
+    UP(s->mol_ptr, mol_ptr);
+    UP(s->mol_nodes, mol_nodes);
+    long long maxrows = 0;
+    for (int l = 0; l <= L; ++l) maxrows = std::max(maxrows, (long long)B.level[l].rows);
+    st = gf::upload(s, &s->colpart, nullptr, (size_t)((maxrows + 1023) / 1024 + 1) * C);
+    if (st != GF_OK) return st;
+#undef UP
+    // split-K partials of the weight gradients also live in the context workspace
+    const size_t gemm_ws = sizeof(float) * 1200 * (size_t)gf::kK * C * C + (1 << 20);
+    st = gf::ensure_ws(ctx, std::max(contract_ws, gemm_ws));
+    if (st != GF_OK) return st;
+    GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    s->prepared = true;
+    return GF_OK;
+}
+
+gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, float *predict, float *loss,
+                         float *graph_feature) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    gf_ctx *ctx = s->ctx;
+    if (!s->prepared) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward before gf_smp_prepare");
+    if (!params) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward: null params");
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const gfsmp::BatchLayout &B = s->lay;
+    const int L = s->cfg.nLevels, C = s->cfg.nChanels, FD = s->cfg.fdim();
+    const float *H, *W;
+    std::vector<const float *> K, b;
+    gf::view_params<const float>(s->cfg, params, &H, &K, &b, &W);
+    gf_status st;
+    // level 0: f_0 = LeakyReLU(X H^T)   (MatMul(H, x_v) per vertex, SMP_omega.h:618)
+    const int nV = B.level[0].nNodes;
+    st = gf::gemm(ctx, false, true, nV, C, FD, s->x, FD, 0, H, FD, 0, s->lv[0].f, C, 0, 1, 0);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)nV * C)), dim3(256), 0, s->lv[0].f,
+              (const float *)nullptr, C, (size_t)nV * C);
+    for (int l = 1; l <= L; ++l) {
+        const gfsmp::LevelLayout &h = B.level[l];
+        const gf_smp::DevLevel &d = s->lv[l];
+        GF_LAUNCH(ctx, "smp_promote_fwd", gf::promote_forward, dim3((unsigned)h.pairs), dim3(256), 0, s->lv[l - 1].f, s->P,
+                  d.node_s, d.node_row, d.node_p, d.node_pair, d.pair_node, d.pair_src_row, d.pair_src_s, d.pi, C);
+        for (size_t k = 0; k < h.buckets.size(); ++k) {
+            const gfsmp::Bucket &bk = h.buckets[k];
+            st = gf_contract_forward_f32(ctx, 18, s->P + bk.first_p * C, d.adj + bk.first_row,
+                                         d.Q + bk.first_row * (long long)(gf::kK * C), bk.s, C, bk.count);
+            if (st != GF_OK) return st;
+        }
+        // K-projection over all buckets at once: [rows, 18C] x [18C, C]
+        st = gf::gemm(ctx, false, false, (int)h.rows, C, gf::kK * C, d.Q, gf::kK * C, 0, K[l], C, 0, d.f, C, 0, 1, 0);
+        if (st != GF_OK) return st;
+        GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)h.rows * C)), dim3(256), 0, d.f,
+                  b[l], C, (size_t)h.rows * C);
+    }
+    const gfsmp::LevelLayout &top = B.level[L];
+    GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes, dim3(gf::grid_for((size_t)top.nNodes * C)), dim3(256), 0,
+              s->lv[L].f, s->lv[L].node_s, s->lv[L].node_row, s->sh, s->vf, C, (size_t)top.nNodes * C);
+    GF_LAUNCH(ctx, "smp_readout_mol", gf::readout_molecules, dim3(B.nMol), dim3(256), 0, s->vf, s->mol_ptr, s->mol_nodes, W,
+              targets, s->g, s->yhat, loss, s->dy, C);
+    if (predict) GF_HIP_TRY(ctx, hipMemcpyAsync(predict, s->yhat, sizeof(float) * B.nMol, hipMemcpyDeviceToDevice, ctx->stream));
+    if (graph_feature)
+        GF_HIP_TRY(ctx, hipMemcpyAsync(graph_feature, s->g, sizeof(float) * (size_t)B.nMol * C, hipMemcpyDeviceToDevice, ctx->stream));
+    s->forwarded = true;
+    return GF_OK;
+}
+
+gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accumulate) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    gf_ctx *ctx = s->ctx;
+    if (!s->forwarded) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward before gf_smp_forward");
+    if (!params || !grads) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: null argument");
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const gfsmp::BatchLayout &B = s->lay;
+    const int L = s->cfg.nLevels, C = s->cfg.nChanels, FD = s->cfg.fdim();
+    const float *H, *W;
+    std::vector<const float *> K, b;
+    gf::view_params<const float>(s->cfg, params, &H, &K, &b, &W);
+    float *dH, *dW;
+    std::vector<float *> dK, db;
+    gf::view_params<float>(s->cfg, grads, &dH, &dK, &db, &dW);
+    const size_t np = gf::param_count(s->cfg);
+    if (!accumulate) GF_LAUNCH(ctx, "smp_zero", gf::zero_f32, dim3(gf::grid_for(np)), dim3(256), 0, grads, np);
+    gf_status st;
+    const gfsmp::LevelLayout &top = B.level[L];
+    GF_LAUNCH(ctx, "smp_readout_dW", gf::readout_dW, dim3(1), dim3(256), 0, s->dy, s->g, dW, C, B.nMol);
+    GF_LAUNCH(ctx, "smp_readout_bwd", gf::readout_backward_nodes, dim3(top.nNodes), dim3(256), 0, s->dy, W, s->sh,
+              s->top_node_mol, s->lv[L].node_s, s->lv[L].node_row, s->lv[L].df, C);
+    for (int l = L; l >= 1; --l) {
+        const gfsmp::LevelLayout &h = B.level[l];
+        const gf_smp::DevLevel &d = s->lv[l];
+        // dZ = dF * lrelu'(z) in place; db_l += column sums
+        const int rpb = 1024;
+        const int nb = (int)((h.rows + rpb - 1) / rpb);
+        GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(64), 0, d.f, d.df, s->colpart, C,
+                  (long long)h.rows, rpb);
+        GF_LAUNCH(ctx, "smp_colsum", gf::colsum_finish, dim3(1), dim3(256), 0, s->colpart, db[l], C, nb);
+        // dK_l += Q^T dZ   (MatMul::backward second operand), then dQ = dZ K_l^T overwrites Q (first operand)
+        st = gf::gemm(ctx, true, false, gf::kK * C, C, (int)h.rows, d.Q, gf::kK * C, 0, d.df, C, 0, dK[l], C, 0, 1, 1);
+        if (st != GF_OK) return st;
+        st = gf::gemm(ctx, false, true, (int)h.rows, gf::kK * C, C, d.df, C, 0, K[l], C, 0, d.Q, gf::kK * C, 0, 1, 0);
+        if (st != GF_OK) return st;
+        for (size_t k = 0; k < h.buckets.size(); ++k) {
+            const gfsmp::Bucket &bk = h.buckets[k];
+            st = gf_contract_backward_f32(ctx, 18, d.Q + bk.first_row * (long long)(gf::kK * C), d.adj + bk.first_row,
+                                          s->P + bk.first_p * C, bk.s, C, bk.count, /*accumulate=*/0);
+            if (st != GF_OK) return st;
+        }
+        const gf_smp::DevLevel &pv = s->lv[l - 1];
+        GF_LAUNCH(ctx, "smp_promote_bwd", gf::promote_backward, dim3(B.level[l - 1].nNodes), dim3(256), 0, s->P, pv.df,
+                  pv.node_s, pv.node_row, d.cons_ptr, d.cons_slab, d.cons_s, d.cons_inv_off, d.inv, C);
+    }
+    // level 0: dZ0 = dF0 * lrelu'; dH += dZ0^T X
+    {
+        const int nV = B.level[0].nNodes;
+        const int rpb = 1024, nb = (nV + rpb - 1) / rpb;
+        GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(64), 0, s->lv[0].f, s->lv[0].df, s->colpart,
+                  C, (long long)nV, rpb);
+        st = gf::gemm(ctx, true, false, C, FD, nV, s->lv[0].df, C, 0, s->x, FD, 0, dH, FD, 0, 1, 1);
+        if (st != GF_OK) return st;
+    }
+    return GF_OK;
+}
+
+/* Host-only graph preparation of ONE molecule (no device needed): receptive fields phi[l][v] as
+ * [L+1][V][cap+1] ints (slot 0 = size) and, optionally, the WL features [V][F(D+1)].  Lets the host logic be tested
+ * on a CPU-only box and inspected by callers. */
+gf_status gf_smp_prepare_molecule_host(const gf_smp_config *cfg, int V, const int *adj, const double *feature,
+                                       int *phi_out, double *wl_out) {
+    if (!cfg || V <= 0 || !adj || !feature || !phi_out) return fail(nullptr, GF_ERR_INVALID, "gf_smp_prepare_molecule_host: bad argument");
+    gfsmp::Config c;
+    c.nLevels = cfg->nLevels;
+    c.nChanels = cfg->nChanels;
+    c.nFeatures = cfg->nFeatures;
+    c.nDepth = cfg->nDepth;
+    c.max_receptive_field = cfg->max_receptive_field;
+    c.has_WL_ordering = cfg->has_WL_ordering;
+    gfsmp::Molecule m;
+    gfsmp::prepare_molecule(c, V, adj, feature, &m);
+    const int cap = c.max_receptive_field;
+    for (int l = 0; l <= c.nLevels; ++l)
+        for (int v = 0; v < V; ++v) {
+            int *p = phi_out + ((size_t)l * V + v) * (cap + 1);
+            const std::vector<int> &f = m.phi[l][v];
+            p[0] = (int)f.size();
+            for (int i = 0; i < cap; ++i) p[1 + i] = i < (int)f.size() ? f[i] : -1;
+        }
+    if (wl_out)
+        for (size_t i = 0; i < m.wl.size(); ++i) wl_out[i] = m.wl[i];
+    return GF_OK;
+}
+
+/* introspection for parity tests: receptive field phi_level(v) of molecule mol; returns its size */
+int gf_smp_receptive_field(const gf_smp *s, int mol, int level, int v, int *out, int capacity) {
+    if (!s || !s->prepared || mol < 0 || mol >= s->lay.nMol || level < 0 || level > s->cfg.nLevels) return -1;
+    const gfsmp::Molecule &M = s->lay.mols[mol];
+    if (v < 0 || v >= M.V) return -1;
+    const std::vector<int> &f = M.phi[level][v];
+    for (int i = 0; i < (int)f.size() && i < capacity; ++i) out[i] = f[i];
+    return (int)f.size();
+}
+
+/* counts used by the bench to report algorithmic work: rows = sum s^2, ppos = sum s^3 at a level */
+gf_status gf_smp_level_sizes(const gf_smp *s, int level, long long *nodes, long long *rows, long long *ppos) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    if (!s->prepared || level < 0 || level > s->cfg.nLevels) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_level_sizes: bad level");
+    const gfsmp::LevelLayout &h = s->lay.level[level];
+    if (nodes) *nodes = h.nNodes;
+    if (rows) *rows = h.rows;
+    if (ppos) *ppos = h.ppos;
+    return GF_OK;
+}
+
+}  // extern "C"

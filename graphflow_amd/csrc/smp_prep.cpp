@@ -1,0 +1,236 @@
+// smp_prep.cpp -- see smp_prep.h.  Pure host C++; every routine cites the reference lines whose RESULT it must
+// reproduce exactly (tie-breaking included: the reference's exchange sorts are not stable, so they are restated
+// swap for swap rather than replaced by std::sort).
+#include "smp_prep.h"
+
+#include <algorithm>
+#include <map>
+#include <utility>
+
+namespace gfsmp {
+namespace {
+
+const int kInf = 1000000000;  // SMP_omega.h:1064
+
+// SMP_omega.h:358-380.  The initialisation visits (i,j) in row-major order and, on an edge, writes BOTH [i][j] and
+// [j][i]; a later visit of (j,i) overwrites [j][i] again.  Restated literally so asymmetric inputs behave the same.
+void hop_distances(int V, const int *adj, std::vector<int> *out) {
+    std::vector<int> &sp = *out;
+    sp.assign((size_t)V * V, 0);
+    for (int i = 0; i < V; ++i)
+        for (int j = 0; j < V; ++j) {
+            sp[i * V + j] = (i == j) ? 0 : kInf;
+            if (i != j && adj[i * V + j] > 0) {
+                sp[i * V + j] = 1;
+                sp[j * V + i] = 1;
+            }
+        }
+    for (int k = 0; k < V; ++k)
+        for (int i = 0; i < V; ++i)
+            for (int j = 0; j < V; ++j) sp[i * V + j] = std::min(sp[i * V + j], sp[i * V + k] + sp[k * V + j]);
+}
+
+// SMP_omega.h:382-404: histogram[v][d*F + f] = sum of the raw feature f over vertices at hop distance exactly d.
+void wl_features(const Config &cfg, int V, const double *feature, const std::vector<int> &sp, std::vector<double> *out) {
+    const int F = cfg.nFeatures, FD = cfg.fdim();
+    out->assign((size_t)V * FD, 0.0);
+    for (int v = 0; v < V; ++v)
+        for (int d = 0; d <= cfg.nDepth; ++d)
+            for (int u = 0; u < V; ++u)
+                if (sp[u * V + v] == d)
+                    for (int f = 0; f < F; ++f) (*out)[(size_t)v * FD + d * F + f] += feature[(size_t)u * F + f];
+}
+
+// SMP_omega.h:406-434: lexicographic compare of the histograms, exchange sort into DESCENDING order, rank = position.
+int compare_wl(const std::vector<double> &wl, int FD, int u, int v) {
+    for (int f = 0; f < FD; ++f) {
+        if (wl[(size_t)u * FD + f] < wl[(size_t)v * FD + f]) return -1;
+        if (wl[(size_t)u * FD + f] > wl[(size_t)v * FD + f]) return 1;
+    }
+    return 0;
+}
+
+void rank_vertices(int V, int FD, const std::vector<double> &wl, std::vector<int> *rank) {
+    std::vector<int> order(V);
+    for (int v = 0; v < V; ++v) order[v] = v;
+    for (int i = 0; i < V; ++i)
+        for (int j = i + 1; j < V; ++j)
+            if (compare_wl(wl, FD, order[i], order[j]) < 0) std::swap(order[i], order[j]);
+    rank->assign(V, 0);
+    for (int i = 0; i < V; ++i) (*rank)[order[i]] = i;
+}
+
+// SMP_omega.h:476-507: order by (hop distance from v, rank) with the reference's exchange sort, then drop whole
+// farthest hop shells until the field fits.
+void cap_field(int v, int V, int cap, const std::vector<int> &sp, const std::vector<int> &rank, std::vector<int> *field) {
+    std::vector<int> &A = *field;
+    for (size_t i = 0; i < A.size(); ++i)
+        for (size_t j = i + 1; j < A.size(); ++j) {
+            const int di = sp[v * V + A[i]], dj = sp[v * V + A[j]];
+            if (di > dj) {
+                std::swap(A[i], A[j]);
+            } else if (di == dj && rank[A[i]] > rank[A[j]]) {
+                std::swap(A[i], A[j]);
+            }
+        }
+    while ((int)A.size() > cap) {
+        const int d = sp[v * V + A.back()];
+        while (!A.empty() && sp[v * V + A.back()] == d) A.pop_back();
+    }
+}
+
+}  // namespace
+
+void prepare_molecule(const Config &cfg, int V, const int *adj, const double *feature, Molecule *out) {
+    out->V = V;
+    hop_distances(V, adj, &out->hops);
+    wl_features(cfg, V, feature, out->hops, &out->wl);
+    rank_vertices(V, cfg.fdim(), out->wl, &out->rank);
+    // receptive fields, SMP_omega.h:509-537
+    out->phi.assign(cfg.nLevels + 1, std::vector<std::vector<int> >(V));
+    for (int v = 0; v < V; ++v) out->phi[0][v].assign(1, v);
+    for (int l = 1; l <= cfg.nLevels; ++l)
+        for (int v = 0; v < V; ++v) {
+            std::vector<int> &field = out->phi[l][v];
+            for (int u = 0; u < V; ++u) {
+                if (out->hops[u * V + v] > 1) continue;
+                const std::vector<int> &B = out->phi[l - 1][u];  // union_set (:436-449): append unseen, keep order
+                for (size_t i = 0; i < B.size(); ++i)
+                    if (std::find(field.begin(), field.end(), B[i]) == field.end()) field.push_back(B[i]);
+            }
+            if ((int)field.size() > cfg.max_receptive_field)
+                cap_field(v, V, cfg.max_receptive_field, out->hops, out->rank, &field);
+            if (cfg.has_WL_ordering)  // sort() at :451-459: exchange sort by ascending rank
+                for (size_t i = 0; i < field.size(); ++i)
+                    for (size_t j = i + 1; j < field.size(); ++j)
+                        if (out->rank[field[i]] > out->rank[field[j]]) std::swap(field[i], field[j]);
+        }
+}
+
+void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *adj, const double *feature,
+                 BatchLayout *out) {
+    const int L = cfg.nLevels, FD = cfg.fdim(), F = cfg.nFeatures;
+    out->nMol = nMol;
+    out->mols.assign(nMol, Molecule());
+    out->mol_first_vertex.assign(nMol + 1, 0);
+    std::vector<size_t> adj_off(nMol + 1, 0);
+    for (int m = 0; m < nMol; ++m) {
+        out->mol_first_vertex[m + 1] = out->mol_first_vertex[m] + nVertices[m];
+        adj_off[m + 1] = adj_off[m] + (size_t)nVertices[m] * nVertices[m];
+    }
+    const int totalV = out->mol_first_vertex[nMol];
+    out->x.assign((size_t)totalV * FD, 0.f);
+    for (int m = 0; m < nMol; ++m) {
+        const int V = nVertices[m], v0 = out->mol_first_vertex[m];
+        prepare_molecule(cfg, V, adj + adj_off[m], feature + (size_t)v0 * F, &out->mols[m]);
+        for (size_t i = 0; i < (size_t)V * FD; ++i) out->x[(size_t)v0 * FD + i] = (float)out->mols[m].wl[i];
+    }
+
+    out->level.assign(L + 1, LevelLayout());
+    // node numbering per level: level 0 in (molecule, vertex) order; level >= 1 bucketed by field size (stable)
+    std::vector<std::vector<int> > node_of(L + 1, std::vector<int>(totalV, -1));  // [level][global vertex] -> node
+    for (int l = 0; l <= L; ++l) {
+        LevelLayout &lv = out->level[l];
+        std::vector<std::pair<int, int> > order;  // (size, global vertex)
+        for (int m = 0; m < nMol; ++m)
+            for (int v = 0; v < nVertices[m]; ++v)
+                order.push_back(std::make_pair((int)out->mols[m].phi[l][v].size(), out->mol_first_vertex[m] + v));
+        if (l > 0) std::stable_sort(order.begin(), order.end(),
+                                    [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+        lv.nNodes = totalV;
+        lv.node_s.resize(totalV);
+        lv.node_mol.resize(totalV);
+        lv.node_vertex.resize(totalV);
+        lv.node_row.resize(totalV);
+        lv.node_p.resize(totalV);
+        lv.node_pair.resize(totalV);
+        int64_t row = 0, pp = 0, pair = 0;
+        for (int n = 0; n < totalV; ++n) {
+            const int s = order[n].first, gv = order[n].second;
+            const int m = (int)(std::upper_bound(out->mol_first_vertex.begin(), out->mol_first_vertex.end(), gv) -
+                                out->mol_first_vertex.begin()) - 1;
+            node_of[l][gv] = n;
+            lv.node_s[n] = s;
+            lv.node_mol[n] = m;
+            lv.node_vertex[n] = gv - out->mol_first_vertex[m];
+            lv.node_row[n] = row;
+            lv.node_p[n] = pp;
+            lv.node_pair[n] = pair;
+            if (lv.buckets.empty() || lv.buckets.back().s != s) {
+                Bucket b = {s, 0, n, row, pp};
+                lv.buckets.push_back(b);
+            }
+            lv.buckets.back().count += 1;
+            row += (int64_t)s * s;
+            pp += (int64_t)s * s * s;
+            pair += s;
+        }
+        lv.rows = row;
+        lv.ppos = pp;
+        lv.pairs = pair;
+    }
+    out->top_node_of_vertex = node_of[L];
+
+    for (int l = 1; l <= L; ++l) {
+        LevelLayout &lv = out->level[l];
+        const LevelLayout &prev = out->level[l - 1];
+        lv.adj.assign((size_t)lv.rows, 0.f);
+        lv.pair_node.assign((size_t)lv.pairs, 0);
+        lv.pair_src_row.assign((size_t)lv.pairs, 0);
+        lv.pair_src_s.assign((size_t)lv.pairs, 0);
+        lv.pi.assign((size_t)lv.rows, (int16_t)-1);
+        std::vector<std::vector<int64_t> > consumers(prev.nNodes);  // source node -> list of pair ids
+        for (int n = 0; n < lv.nNodes; ++n) {
+            const int m = lv.node_mol[n], v = lv.node_vertex[n], s = lv.node_s[n];
+            const int V = nVertices[m], v0 = out->mol_first_vertex[m];
+            const int *madj = adj + adj_off[m];
+            const std::vector<int> &field = out->mols[m].phi[l][v];
+            // reduced adjacency (:556-581, adjacency mode): 1 on the diagonal, adj[v1][v2] elsewhere
+            for (int i = 0; i < s; ++i)
+                for (int j = 0; j < s; ++j)
+                    lv.adj[(size_t)lv.node_row[n] + (size_t)i * s + j] =
+                        (field[i] == field[j]) ? 1.f : (float)madj[field[i] * V + field[j]];
+            for (int a = 0; a < s; ++a) {
+                const int w = field[a];
+                const int64_t e = lv.node_pair[n] + a;
+                const int src = node_of[l - 1][v0 + w];
+                const std::vector<int> &wf = out->mols[m].phi[l - 1][w];
+                lv.pair_node[(size_t)e] = n;
+                lv.pair_src_row[(size_t)e] = prev.node_row[src];
+                lv.pair_src_s[(size_t)e] = (int)wf.size();
+                // selection map: X[i][k] = [phi_l(v)[i] == phi_{l-1}(w)[k]]   (:461-474)
+                for (int p = 0; p < s; ++p) {
+                    const std::vector<int>::const_iterator it = std::find(wf.begin(), wf.end(), field[p]);
+                    lv.pi[(size_t)lv.node_row[n] + (size_t)a * s + p] = (it == wf.end()) ? (int16_t)-1 : (int16_t)(it - wf.begin());
+                }
+                consumers[src].push_back(e);
+            }
+        }
+        // inverse index for the backward gather
+        lv.cons_ptr.assign((size_t)prev.nNodes + 1, 0);
+        lv.cons_slab.clear();
+        lv.cons_s.clear();
+        lv.cons_inv_off.clear();
+        lv.inv.clear();
+        for (int w = 0; w < prev.nNodes; ++w) {
+            const int sw = prev.node_s[w];
+            for (size_t c = 0; c < consumers[w].size(); ++c) {
+                const int64_t e = consumers[w][c];
+                const int n = lv.pair_node[(size_t)e];
+                const int s = lv.node_s[n], a = (int)(e - lv.node_pair[n]);
+                lv.cons_slab.push_back(lv.node_p[n] + (int64_t)a * s * s);
+                lv.cons_s.push_back(s);
+                lv.cons_inv_off.push_back((int64_t)lv.inv.size());
+                const size_t base = lv.inv.size();
+                lv.inv.resize(base + sw, (int16_t)-1);
+                for (int p = 0; p < s; ++p) {
+                    const int16_t k = lv.pi[(size_t)lv.node_row[n] + (size_t)a * s + p];
+                    if (k >= 0) lv.inv[base + k] = (int16_t)p;
+                }
+            }
+            lv.cons_ptr[(size_t)w + 1] = (int64_t)lv.cons_slab.size();
+        }
+    }
+}
+
+}  // namespace gfsmp

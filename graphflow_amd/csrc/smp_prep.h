@@ -1,0 +1,77 @@
+// smp_prep.h -- host-side graph preparation of the batched SMP_omega driver.
+//
+// Restates, per molecule, what SMP_omega::complete_computation_graph does before it builds the op DAG
+// (GraphFlow/SMP_omega.h:584-605): Floyd-Warshall hop distances (:358-380), Weisfeiler-Lehman histogram features
+// (:382-404), lexicographic vertex ranking (:406-434), receptive fields phi_l(v) with the omega cap (:476-537),
+// selection maps (the 0/1 matrices X of :461-474, :539-554, kept as index lists) and reduced adjacencies (:556-581).
+// Then it lays a BATCH of molecules out for the device: per level, nodes (= one (molecule, vertex) pair) are sorted
+// into buckets of equal receptive-field size so each bucket is one uniform-N contraction launch.
+#ifndef GF_SMP_PREP_H_INCLUDED
+#define GF_SMP_PREP_H_INCLUDED
+
+#include <cstdint>
+#include <vector>
+
+namespace gfsmp {
+
+struct Config {
+    int nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering;
+    int fdim() const { return nFeatures * (nDepth + 1); }
+};
+
+// everything the reference derives from one molecule
+struct Molecule {
+    int V = 0;
+    std::vector<int> hops;                            // [V][V] shortest paths
+    std::vector<double> wl;                           // [V][F(D+1)] WL histogram features
+    std::vector<int> rank;                            // [V]
+    std::vector<std::vector<std::vector<int> > > phi;  // [L+1][V] receptive fields
+};
+
+void prepare_molecule(const Config &cfg, int V, const int *adj, const double *feature, Molecule *out);
+
+struct Bucket {
+    int s;             // receptive-field size of every node in the bucket
+    int count;         // nodes
+    int first_node;    // index of the first node (nodes of a level are numbered in bucket order)
+    int64_t first_row; // offset in (i,j) rows (sum of s^2 before the bucket)
+    int64_t first_p;   // offset in (a,b,c) positions (sum of s^3 before the bucket)
+};
+
+// one level of the batch, host copy of what gets uploaded
+struct LevelLayout {
+    int nNodes = 0;
+    int64_t rows = 0;   // sum s^2
+    int64_t ppos = 0;   // sum s^3
+    int64_t pairs = 0;  // sum s   (one (node, neighbour) pair per promoted tensor)
+    std::vector<Bucket> buckets;
+    std::vector<int> node_s, node_mol, node_vertex;
+    std::vector<int64_t> node_row, node_p, node_pair;
+    std::vector<float> adj;  // [rows] reduced adjacency, node-major [s][s]
+    // forward gather (levels >= 1): per pair e = node_pair[n] + a
+    std::vector<int> pair_node;        // [pairs]
+    std::vector<int64_t> pair_src_row;  // [pairs] first row of the source node's tensor in level l-1
+    std::vector<int> pair_src_s;       // [pairs]
+    std::vector<int16_t> pi;           // [rows]  pi[node_row[n] + a*s + p] = index of phi_l(v)[p] in phi_{l-1}(w_a), or -1
+    // backward gather, indexed by the SOURCE node (level l-1): consumers = pairs that read it
+    std::vector<int64_t> cons_ptr;      // [nNodes(l-1) + 1]
+    std::vector<int64_t> cons_slab;     // [pairs] position offset (units of C floats) of the consumer's [s][s] slab in P
+    std::vector<int> cons_s;           // [pairs] consumer's s
+    std::vector<int64_t> cons_inv_off;  // [pairs] offset into inv
+    std::vector<int16_t> inv;          // per consumer: [s_w] position in the consumer's field of source position p, or -1
+};
+
+struct BatchLayout {
+    int nMol = 0;
+    std::vector<int> mol_first_vertex;  // [nMol+1] prefix sum of vertex counts (level-0 node = global vertex id)
+    std::vector<float> x;               // [nVertices][F(D+1)] WL features, level-0 input
+    std::vector<LevelLayout> level;     // [L+1]; level[0] has only node bookkeeping
+    std::vector<int> top_node_of_vertex;  // [nVertices] node index at level L of global vertex id
+    std::vector<Molecule> mols;         // kept for introspection (receptive fields)
+};
+
+void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *adj, const double *feature,
+                 BatchLayout *out);
+
+}  // namespace gfsmp
+#endif

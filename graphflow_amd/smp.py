@@ -1,0 +1,76 @@
+"""Python handle on the batched SMP_omega driver of the C ABI (gf_smp_*).  Plumbing only: torch owns the parameter,
+gradient and output buffers; everything else lives in libgf_hip.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import default_context
+
+
+class SMPConfig(C.Structure):
+    _fields_ = [("nLevels", C.c_int), ("nChanels", C.c_int), ("nFeatures", C.c_int), ("nDepth", C.c_int),
+                ("max_receptive_field", C.c_int), ("has_WL_ordering", C.c_int)]
+
+
+class SMPOmega:
+    """Batched SMP_omega (GraphFlow/SMP_omega.h).  Parameters/gradients are one flat fp32 tensor in the reference's
+    registration order: H[C, F(D+1)], (K_l[18C, C], b_l[C]) for l = 1..L, W[C]."""
+
+    def __init__(self, nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering=True, ctx=None):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        self.cfg = SMPConfig(nLevels, nChanels, nFeatures, nDepth, max_receptive_field, 1 if has_WL_ordering else 0)
+        h = C.c_void_p()
+        self.ctx.check(self.lib.gf_smp_create(self.ctx.handle, C.byref(self.cfg), C.byref(h)))
+        self.handle = h
+        self.n_params = self.lib.gf_smp_param_count(h)
+        self.n_mol = 0
+
+    def prepare(self, molecules):
+        """molecules: list of (adj int[V,V], feature float[V,F]).  Host graph preparation + upload (blocking)."""
+        nV = np.array([len(a) for a, _ in molecules], dtype=np.int32)
+        adj = np.concatenate([np.ascontiguousarray(a, dtype=np.int32).ravel() for a, _ in molecules])
+        feat = np.concatenate([np.ascontiguousarray(f, dtype=np.float64).ravel() for _, f in molecules])
+        self.ctx.check(self.lib.gf_smp_prepare(self.handle, len(molecules), nV.ctypes.data_as(C.POINTER(C.c_int)),
+                                               adj.ctypes.data_as(C.POINTER(C.c_int)),
+                                               feat.ctypes.data_as(C.POINTER(C.c_double))))
+        self.n_mol = len(molecules)
+        dev = self.ctx.device
+        self.predict = torch.empty(self.n_mol, dtype=torch.float32, device=dev)
+        self.loss = torch.empty(self.n_mol, dtype=torch.float32, device=dev)
+        self.feature = torch.empty((self.n_mol, self.cfg.nChanels), dtype=torch.float32, device=dev)
+
+    def forward(self, params, targets=None):
+        t = C.c_void_p(targets.data_ptr()) if targets is not None else None
+        self.ctx.check(self.lib.gf_smp_forward(self.handle, C.c_void_p(params.data_ptr()), t,
+                                               C.c_void_p(self.predict.data_ptr()), C.c_void_p(self.loss.data_ptr()),
+                                               C.c_void_p(self.feature.data_ptr())))
+        return self.predict, self.loss, self.feature
+
+    def backward(self, params, grads, accumulate=False):
+        self.ctx.check(self.lib.gf_smp_backward(self.handle, C.c_void_p(params.data_ptr()), C.c_void_p(grads.data_ptr()),
+                                                1 if accumulate else 0))
+        return grads
+
+    def receptive_field(self, mol, level, v):
+        buf = (C.c_int * 4096)()
+        n = self.lib.gf_smp_receptive_field(self.handle, mol, level, v, buf, 4096)
+        return list(buf[:n])
+
+    def level_sizes(self, level):
+        a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        self.ctx.check(self.lib.gf_smp_level_sizes(self.handle, level, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gf_smp_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -134,6 +134,35 @@ gf_status gf_tensormatmul_forward_host_f32(gf_ctx *ctx, const float *F, const fl
 gf_status gf_tensormatmul_backward_host_f32(gf_ctx *ctx, const float *G, const float *F, const float *Y, float *dF,
                                             float *dY, int R, int Kd, int J, int D);
 
+/* ---- batched SMP_omega driver (mode B): the caller of the ops above ------------------------------------------------
+ * Reproduces the op DAG of SMP_omega::complete_computation_graph (GraphFlow/SMP_omega.h:584-693) for a batch of
+ * molecules: host graph preparation (Floyd-Warshall :358, WL features :382, ranking :406, receptive fields with the
+ * omega cap :476-537, selection maps :461, reduced adjacency :556) + device levels (promotion as an index gather,
+ * RisiContraction_18, K-projection, bias, LeakyReLU) + readout (:676-692) + the reverse sweep.
+ * Parameters are ONE flat fp32 device buffer in the reference's registration / save_model order
+ * (SMP_omega.h:289-295, 1033-1055): H[C][F(D+1)], then K_l[18C][C], b_l[C] for l = 1..L, then W[C];
+ * gradients have the same layout and hold the SUM over the batch (what sum_gradients accumulates, :808-820), so a
+ * data-parallel step is one all-reduce of that buffer.                                                                */
+typedef struct gf_smp gf_smp;
+typedef struct {
+    int nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering;
+} gf_smp_config;
+gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out);
+gf_status gf_smp_destroy(gf_smp *smp);
+size_t    gf_smp_param_count(const gf_smp *smp);
+/* Host pointers: nVertices[nMol]; adj = the molecules' V x V int adjacency matrices back to back (DenseGraph::adj);
+ * feature = their V x nFeatures matrices back to back (DenseGraph::feature).  Blocking (uploads index tables). */
+gf_status gf_smp_prepare(gf_smp *smp, int nMol, const int *nVertices, const int *adj, const double *feature);
+/* Device pointers.  targets may be NULL (Predict / Feature); predict, loss [nMol] and graph_feature [nMol][C] are
+ * optional outputs (graph_feature is what SMP_omega::Feature returns, :984-996). */
+gf_status gf_smp_forward(gf_smp *smp, const float *params, const float *targets, float *predict, float *loss,
+                         float *graph_feature);
+gf_status gf_smp_backward(gf_smp *smp, const float *params, float *grads, int accumulate);
+gf_status gf_smp_prepare_molecule_host(const gf_smp_config *cfg, int V, const int *adj, const double *feature,
+                                       int *phi_out, double *wl_out);  /* host only; phi_out [L+1][V][cap+1], slot 0 = size */
+int       gf_smp_receptive_field(const gf_smp *smp, int mol, int level, int v, int *out, int capacity);
+gf_status gf_smp_level_sizes(const gf_smp *smp, int level, long long *nodes, long long *rows, long long *ppos);
+
 #ifdef __cplusplus
 }
 #endif

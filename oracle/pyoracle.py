@@ -210,3 +210,39 @@ def time_r18_fwd_bwd(P, A, G, prefer_reference=True):
     fw(P, A, out, N, C_)
     bw(G, A, dP, N, C_)
     return time.perf_counter() - t0, "port", out, dP
+
+
+def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, max_nVertices=None):
+    """Run the REAL reference SMP_omega on one molecule with the given (dumped) parameters.  None if _ref is absent."""
+    ref = reference()
+    if ref is None:
+        return None
+    adj = np.ascontiguousarray(adj, dtype=np.int32)
+    feature = np.ascontiguousarray(feature, dtype=np.float64)
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    V, F = feature.shape
+    maxV = max_nVertices or V
+    L = nLevels
+    gfeat = np.zeros(C)
+    pred = np.zeros(1)
+    loss = np.zeros(1)
+    grads = np.zeros_like(params)
+    phi = np.zeros((L + 1, V, cap + 1), dtype=np.int32)
+    radj = np.zeros((L + 1, V, cap * cap))
+    f = ref.lib.ref_smp_omega_run
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f.argtypes = [_i] * 8 + [ip, _dp, C_double, _dp, _dp, _dp, _dp, _dp, ip, _dp]
+    f.restype = _i
+    n = f(maxV, cap, L, C, F, nDepth, 1 if has_wl else 0, V, adj, feature, float(target), params, gfeat, pred, loss, grads, phi, radj)
+    assert n == params.size, (n, params.size)
+    fields = [[list(phi[l, v, 1:1 + phi[l, v, 0]]) for v in range(V)] for l in range(L + 1)]
+    red = [[None] * V for _ in range(L + 1)]
+    for l in range(1, L + 1):
+        for v in range(V):
+            s = phi[l, v, 0]
+            red[l][v] = radj[l, v, :s * s].reshape(s, s).copy()
+    return {"phi": fields, "reduced_adj": red, "graph_feature": gfeat, "predict": float(pred[0]), "loss": float(loss[0]),
+            "grads": grads}
+
+
+C_double = C.c_double

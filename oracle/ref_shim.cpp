@@ -248,3 +248,49 @@ void ref_stack_backward(const double *G, double *dT, int nRows, int nCols, int n
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// SMP_omega (the caller of the ops above), driven with DUMPED parameters so goldens do not depend on rand():
+// the flat parameter / gradient layout is the registration order of SMP_omega.h:289-295 (H, K_1, b_1, ..., W).
+// ---------------------------------------------------------------------------------------------------------------
+#include "SMP_omega.h"
+
+extern "C" int ref_smp_omega_run(int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int nDepth,
+                                 int has_WL, int V, const int *adj, const double *feature, double target,
+                                 const double *params, double *graph_feature, double *predict, double *loss,
+                                 double *grads, int *phi /* [L+1][V][max_rf+1], slot 0 = size */,
+                                 double *reduced_adj /* [L+1][V][max_rf*max_rf] */) {
+    // heap-allocated and intentionally leaked: ~SMP_omega / ~DenseGraph free memory the executor's destructor also
+    // frees (SURVEY.md 8b "Ownership"), which is fatal in a long-lived process
+    SMP_omega &net = *new SMP_omega(max_nVertices, max_rf, nLevels, nChanels, nFeatures, nDepth, has_WL != 0);
+    size_t off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) net.sgd->params[i]->value[j] = params[off++];
+    DenseGraph &g = *new DenseGraph(V, nFeatures);
+    for (int i = 0; i < V; ++i) {
+        for (int j = 0; j < V; ++j) g.adj[i][j] = adj[i * V + j];
+        for (int f = 0; f < nFeatures; ++f) g.feature[i][f] = feature[i * nFeatures + f];
+    }
+    net.complete_computation_graph(&g);
+    net.target->value[0] = target;
+    net.graph->forward();
+    net.graph->backward();
+    for (int f = 0; f < nChanels; ++f) graph_feature[f] = net.graph_feature->value[f];
+    *predict = net.predict->value[0];
+    *loss = net.sql->getLoss();
+    off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) grads[off++] = net.sgd->params[i]->gradient[j];
+    for (int l = 0; l <= nLevels; ++l)
+        for (int v = 0; v < V; ++v) {
+            int *p = phi + ((size_t)l * V + v) * (max_rf + 1);
+            const std::vector<int> &f = net.level[l]->phi[v];
+            p[0] = (int)f.size();
+            for (size_t i = 0; i < f.size(); ++i) p[1 + i] = f[i];
+            if (l > 0 && reduced_adj) {
+                double *a = reduced_adj + ((size_t)l * V + v) * max_rf * max_rf;
+                for (int i = 0; i < net.level[l]->adj[v]->size; ++i) a[i] = net.level[l]->adj[v]->value[i];
+            }
+        }
+    return (int)off;
+}

@@ -33,3 +33,94 @@ def cfg_graph(N, C, seed, K=18):
     A = adjacency("sym01", N, rng)
     G = f32exact(rng.uniform(0, 1, (N, N, K, C)))
     return P, A, G
+
+
+# ---- molecules (data only) ------------------------------------------------------------------------------------------
+def toy_molecules():
+    """The four hand-built molecules of the reference's tests/test_SMP_omega.cpp:71-147 (edges + atom labels; features are
+    one-hot over C,H,N,O; target = number of atoms).  Returns [(name, adj[V,V] int, feature[V,4], target)]."""
+    spec = {
+        "CH4": ([(0, 1), (0, 2), (0, 3), (0, 4)], "CHHHH"),
+        "NH3": ([(0, 1), (0, 2), (0, 3)], "NHHH"),
+        "H2O": ([(0, 1), (0, 2)], "OHH"),
+        "C2H4": ([(0, 1), (0, 2), (0, 3), (3, 4), (3, 5)], "CHHCHH"),
+    }
+    out = []
+    for name, (edges, labels) in spec.items():
+        V = len(labels)
+        adj = np.zeros((V, V), dtype=np.int32)
+        for u, v in edges:
+            adj[u, v] = adj[v, u] = 1
+        feat = np.zeros((V, 4))
+        for v, ch in enumerate(labels):
+            feat[v, "CHNO".index(ch)] = 1.0
+        out.append((name, adj, feat, float(V)))
+    return out
+
+
+def er_graph(V, p, nFeatures, seed):
+    """Erdos-Renyi graph with random one-hot vertex labels (shape of tests/test_SMP_similarity.cu:34-53)."""
+    rng = np.random.default_rng(seed)
+    U = np.triu((rng.uniform(0, 1, (V, V)) < p).astype(np.int32), 1)
+    adj = U + U.T
+    feat = np.zeros((V, nFeatures))
+    feat[np.arange(V), rng.integers(0, nFeatures, V)] = 1.0
+    return adj, feat
+
+
+def synthetic_molecule(seed, nV=None):
+    """QM9-size synthetic molecule: nV ~ U{3..29}; ceil(9 nV / 20) heavy atoms forming a random tree
+    with degree <= 4 plus up to one ring closure; the rest are H attached to heavy atoms with free valence.
+    Features: one-hot over (H, C, N, O, F).  Target = nV.  Returns (adj int32 [V,V], feature [V,5], target)."""
+    rng = np.random.default_rng(seed)
+    if nV is None:
+        nV = int(rng.integers(3, 30))
+    nheavy = min(nV, max(1, -(-9 * nV // 20)))
+    adj = np.zeros((nV, nV), dtype=np.int32)
+    deg = np.zeros(nV, dtype=np.int64)
+    for v in range(1, nheavy):
+        cand = [u for u in range(v) if deg[u] < 4]
+        u = int(rng.choice(cand)) if cand else 0
+        adj[u, v] = adj[v, u] = 1
+        deg[u] += 1
+        deg[v] += 1
+    if nheavy >= 4 and rng.uniform() < 0.5:  # one ring closure
+        free = [u for u in range(nheavy) if deg[u] < 4]
+        rng.shuffle(free)
+        for i in range(len(free)):
+            for j in range(i + 1, len(free)):
+                u, v = free[i], free[j]
+                if not adj[u, v]:
+                    adj[u, v] = adj[v, u] = 1
+                    deg[u] += 1
+                    deg[v] += 1
+                    break
+            else:
+                continue
+            break
+    for h in range(nheavy, nV):
+        cand = [u for u in range(nheavy) if deg[u] < 4]
+        u = int(rng.choice(cand)) if cand else int(rng.integers(0, nheavy))
+        adj[u, h] = adj[h, u] = 1
+        deg[u] += 1
+        deg[h] += 1
+    feat = np.zeros((nV, 5))
+    feat[nheavy:, 0] = 1.0
+    heavy_type = rng.choice([1, 1, 1, 2, 3, 4], size=nheavy)
+    feat[np.arange(nheavy), heavy_type] = 1.0
+    return adj, feat, float(nV)
+
+
+def smp_param_count(C, F, D, L):
+    return C * F * (D + 1) + L * (18 * C * C + C) + C
+
+
+def smp_params(C, F, D, L, seed, scale=None):
+    """Random parameters, float32-exact, sized like uniform_init's range (GraphFlow.h:1297-1306): |w| < 1/size-ish."""
+    rng = np.random.default_rng(seed)
+    parts = [rng.uniform(-1, 1, C * F * (D + 1)) / np.sqrt(F * (D + 1))]
+    for _ in range(L):
+        parts.append(rng.uniform(-1, 1, 18 * C * C) / np.sqrt(18 * C))
+        parts.append(rng.uniform(-0.1, 0.1, C))
+    parts.append(rng.uniform(-1, 1, C) / np.sqrt(C))
+    return f32exact(np.concatenate(parts))

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 from oracle import pyoracle  # noqa: E402
-from inputs import adjacency, f32exact  # noqa: E402
+from inputs import adjacency, er_graph, f32exact, smp_params, synthetic_molecule, toy_molecules  # noqa: E402
 
 REF_ROOT = os.environ.get("GF_REFERENCE", "/root/reference")
 
@@ -115,6 +115,42 @@ def structural_50():
             "groups": groups}
 
 
+def smp_cases():
+    """(tag, adj, feature, target, cfg) with cfg = (L, C, D, cap, has_wl, max_nVertices)."""
+    cases = []
+    for name, adj, feat, tgt in toy_molecules():  # the configuration of tests/test_SMP_omega.cpp:22-34
+        cases.append(("toy_" + name, adj, feat, tgt, (2, 10, 5, 4, 1, 10)))
+    adj, feat = er_graph(20, 0.2, 4, 3)
+    cases.append(("er20_wl", adj, feat, 1.5, (2, 8, 3, 10, 1, 20)))
+    cases.append(("er20_nowl", adj, feat, 1.5, (2, 8, 3, 10, 0, 20)))
+    adj, feat, tgt = synthetic_molecule(5, 12)
+    cases.append(("syn12", adj, feat, tgt, (3, 4, 2, 12, 1, 12)))
+    adj, feat, tgt = synthetic_molecule(9, 17)
+    cases.append(("syn17_cap6", adj, feat, tgt, (3, 4, 2, 6, 1, 17)))
+    return cases
+
+
+def smp_fixtures():
+    out = {}
+    for i, (tag, adj, feat, tgt, (L, C, D, cap, wl, maxV)) in enumerate(smp_cases()):
+        F = feat.shape[1]
+        params = smp_params(C, F, D, L, 100 + i)
+        r = pyoracle.reference_smp_omega(adj, feat, tgt, params, L, C, D, cap, has_wl=bool(wl), max_nVertices=maxV)
+        V = len(adj)
+        phi = np.full((L + 1, V, cap + 1), -1, dtype=np.int32)
+        for l in range(L + 1):
+            for v in range(V):
+                phi[l, v, 0] = len(r["phi"][l][v])
+                phi[l, v, 1:1 + len(r["phi"][l][v])] = r["phi"][l][v]
+        p = "smp_" + tag
+        out[p + "__adj"], out[p + "__feature"], out[p + "__target"] = adj.astype(np.int32), feat, np.array([tgt])
+        out[p + "__cfg"] = np.array([L, C, D, cap, wl], dtype=np.int32)
+        out[p + "__params"] = params.astype(np.float32)
+        out[p + "__phi"], out[p + "__graph_feature"] = phi, r["graph_feature"]
+        out[p + "__predict"], out[p + "__loss"], out[p + "__grads"] = np.array([r["predict"]]), np.array([r["loss"]]), r["grads"]
+    return out
+
+
 def main():
     pyoracle.build()
     ref = pyoracle.reference()
@@ -122,9 +158,10 @@ def main():
         sys.exit("oracle/_ref/libgf_ref.so missing: needs /root/reference (build container only)")
     np.savez_compressed(os.path.join(HERE, "contractions.npz"), **contraction_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "mixers.npz"), **mixer_fixtures(ref))
+    np.savez_compressed(os.path.join(HERE, "smp.npz"), **smp_fixtures())
     with open(os.path.join(HERE, "structural_50.json"), "w") as fh:
         json.dump(structural_50(), fh, indent=1)
-    for f in ("contractions.npz", "mixers.npz", "structural_50.json"):
+    for f in ("contractions.npz", "mixers.npz", "smp.npz", "structural_50.json"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -1,0 +1,115 @@
+"""GPU parity suite for the batched SMP_omega driver (gf_smp_*) vs reference goldens and the fp64 oracle."""
+import numpy as np
+import pytest
+
+from inputs import smp_params, synthetic_molecule, toy_molecules
+from util import golden_cases, rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+# End-to-end tolerance: every op is within 1e-5 of fp64 (tests/util.py); through L levels of contraction + GEMM the
+# fp32 rounding compounds, so the chain is held to 1e-4 relative (forward quantities) / 2e-4 (parameter gradients).
+TOL_FWD, TOL_GRAD = 1e-4, 2e-4
+
+
+def dev(x, dtype=np.float32):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=dtype)).cuda()
+
+
+def run_batch(gf, mols, targets, params, L, C, F, D, cap, wl=True):
+    from graphflow_amd.smp import SMPOmega
+    net = SMPOmega(L, C, F, D, cap, wl)
+    net.prepare(mols)
+    p = dev(params)
+    pred, loss, feat = net.forward(p, dev(targets))
+    grads = torch.empty(net.n_params, device="cuda")
+    net.backward(p, grads)
+    out = (pred.cpu().numpy().astype(np.float64), loss.cpu().numpy().astype(np.float64),
+           feat.cpu().numpy().astype(np.float64), grads.cpu().numpy().astype(np.float64), net)
+    return out
+
+
+def test_reference_goldens_one_molecule_at_a_time(gf, golden):
+    cs = golden_cases(golden, "smp_")
+    for tag, c in cs.items():
+        L, C, D, cap, wl = (int(x) for x in c["cfg"])
+        F = c["feature"].shape[1]
+        pred, loss, feat, grads, net = run_batch(gf, [(c["adj"], c["feature"])], c["target"], c["params"], L, C, F, D, cap, bool(wl))
+        V = len(c["adj"])
+        for l in range(L + 1):
+            for v in range(V):
+                n = c["phi"][l, v, 0]
+                assert net.receptive_field(0, l, v) == list(c["phi"][l, v, 1:1 + n]), tag
+        assert rel_err(feat[0], c["graph_feature"]) <= TOL_FWD, tag
+        assert rel_err(pred, c["predict"]) <= TOL_FWD, tag
+        assert rel_err(loss, c["loss"]) <= 2 * TOL_FWD, tag
+        assert rel_err(grads, c["grads"]) <= TOL_GRAD, tag
+
+
+def test_batch_equals_sum_of_molecules(gf, golden):
+    """The four toy molecules of tests/test_SMP_omega.cpp as ONE batch: per-molecule outputs unchanged, gradient = sum
+    (what sum_gradients accumulates in BatchLearn, SMP_omega.h:808-820)."""
+    cs = {k: v for k, v in golden_cases(golden, "smp_toy").items()}
+    names = sorted(cs)
+    c0 = cs[names[0]]
+    L, C, D, cap, wl = (int(x) for x in c0["cfg"])
+    params = c0["params"]  # any one parameter set for all four
+    from oracle import smp_oracle
+    mols = [(cs[n]["adj"], cs[n]["feature"]) for n in names]
+    tg = np.array([cs[n]["target"][0] for n in names])
+    pred, loss, feat, grads, _ = run_batch(gf, mols, tg, params, L, C, 4, D, cap)
+    ref = [smp_oracle.run(cs[n]["adj"], cs[n]["feature"], float(cs[n]["target"][0]), params.astype(np.float64), L, C, D, cap)
+           for n in names]
+    assert rel_err(pred, np.array([r["predict"] for r in ref])) <= TOL_FWD
+    assert rel_err(loss, np.array([r["loss"] for r in ref])) <= 2 * TOL_FWD
+    assert rel_err(feat, np.stack([r["graph_feature"] for r in ref])) <= TOL_FWD
+    assert rel_err(grads, sum(r["grads"] for r in ref)) <= TOL_GRAD
+
+
+@pytest.mark.parametrize("C,L,cap", [(8, 2, 6), (16, 3, 8), (64, 2, 12)])
+def test_synthetic_batch_vs_oracle(gf, C, L, cap):
+    from oracle import smp_oracle
+    F, D = 5, 2
+    mols, tg = [], []
+    for seed in range(6):
+        adj, feat, t = synthetic_molecule(100 + seed, nV=3 + 2 * seed)
+        mols.append((adj, feat))
+        tg.append(t)
+    params = smp_params(C, F, D, L, 7)
+    pred, loss, feat, grads, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    ref = [smp_oracle.run(a, f, t, params, L, C, D, cap) for (a, f), t in zip(mols, tg)]
+    assert rel_err(pred, np.array([r["predict"] for r in ref])) <= TOL_FWD
+    assert rel_err(feat, np.stack([r["graph_feature"] for r in ref])) <= TOL_FWD
+    assert rel_err(grads, sum(r["grads"] for r in ref)) <= TOL_GRAD
+
+
+def test_vertex_permutation_invariance(gf):
+    """tests/test_graph_permutation_invariant.cpp: Feature() of a graph and of a vertex-permuted copy agree."""
+    F, D, C, L, cap = 5, 3, 16, 2, 10
+    adj, feat, _ = synthetic_molecule(77, nV=14)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(adj))
+    adj2, feat2 = adj[np.ix_(perm, perm)], feat[perm]
+    params = smp_params(C, F, D, L, 5)
+    _, _, f, _, _ = run_batch(gf, [(adj, feat), (adj2, feat2)], np.zeros(2), params, L, C, F, D, cap)
+    assert rel_err(f[0], f[1]) <= TOL_FWD
+
+
+def test_forward_is_deterministic_and_backward_accumulates(gf):
+    from graphflow_amd.smp import SMPOmega
+    F, D, C, L, cap = 5, 2, 8, 2, 8
+    mols = [synthetic_molecule(s, nV=9)[:2] for s in range(4)]
+    net = SMPOmega(L, C, F, D, cap)
+    net.prepare(mols)
+    p = dev(smp_params(C, F, D, L, 1))
+    t = dev(np.arange(4))
+    a = net.forward(p, t)[0].clone()
+    b = net.forward(p, t)[0].clone()
+    assert torch.equal(a, b)
+    g1 = torch.empty(net.n_params, device="cuda")
+    net.backward(p, g1)
+    g2 = g1.clone()
+    net.forward(p, t)
+    net.backward(p, g2, accumulate=True)
+    assert float((g2 - 2 * g1).abs().max()) <= 1e-5 * float(g1.abs().max())
