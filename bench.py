@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- one JSON line per run (driver contract).
 
-Workload (N=1 and per rank for N>1, weak scaling): BASELINE.json configs[1] ("cfg2") --
-RisiContraction_18 forward+backward, N=32 vertices, 64 channels, batch 256 graphs, fp32, device-resident.
-A "step" is one forward + one backward pass over the rank's batch.  Graphs are independent, so ranks shard the
-batch with no data-path collective; torch.distributed (RCCL) is only used for the barrier and the max-over-ranks time.
+Default workload = BASELINE.json configs[2] ("cfg3"), the configuration the headline metric is quoted on:
+SMP_omega (second-order CCN), 3 levels, 64 channels, nFeatures 5, nDepth 5, receptive-field cap 29, a batch of 1024
+synthetic QM9-size molecules per GPU (nV ~ U{3..29}), fp32, device-resident.  A "step" = forward + backward over the
+rank's batch (+ the single all-reduce of the flat parameter-gradient buffer when N > 1).  Host graph preparation
+(receptive fields, index tables) is input preparation: done once before the timed region and reported as prep_s.
+`--workload cfg2` runs BASELINE configs[1]: RisiContraction_18 fwd+bwd, N=32, C=64, batch 256 (the north_star target line).
 
-roofline: per-kernel HIP-event durations come from the library's own launch timers (gf_ctx_set_timing) on the stream
-the kernels run on; `achieved` = algorithmic bytes of the dominant kernel's call / its mean duration.
-cpu_baseline: the REAL reference (oracle/_ref/libgf_ref.so, kind "reference") when shipped, else our loop-nest port,
-one graph of the same shape on one host core (about 20 s).
+Multi-GPU: molecules / graphs are independent, so ranks shard them (weak scaling: the per-GPU batch is fixed);
+the only collective is the gradient all-reduce (RCCL).  Timing: barrier + synchronize on both sides, max over ranks.
+
+roofline: per-kernel HIP-event durations from the library's own launch timers (gf_ctx_set_timing, same stream as the
+kernels), for the kernel with the largest total device time; bytes / flops are the algorithmic figures of DESIGN.md.
+cpu_baseline: the REAL reference build (oracle/_ref/libgf_ref.so, kind "reference") when shipped, else our port, on one
+host core, on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -21,45 +26,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable with a float4 copy)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable with a float4 copy)
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 
 
-def algorithmic_bytes(K, N, C, accumulate=False):
-    """fwd 4(N^3 C + N^2 + K N^2 C); bwd 4(K N^2 C + N^2 + N^3 C) (+4 N^3 C when accumulating)."""
+def contraction_bytes(K, N, C):
+    """fwd 4(N^3 C + N^2 + K N^2 C); bwd 4(K N^2 C + N^2 + N^3 C) (write-only dP)."""
     fwd = 4 * (N ** 3 * C + N * N + K * N * N * C)
-    bwd = 4 * (K * N * N * C + N * N + N ** 3 * C) + (4 * N ** 3 * C if accumulate else 0)
-    return fwd, bwd
+    return fwd, fwd
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="graphs per GPU")
-    ap.add_argument("--N", type=int, default=32)
-    ap.add_argument("--C", type=int, default=64)
-    ap.add_argument("--K", type=int, default=18)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    import torch
-    import graphflow_amd as gf
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
-
-    B, N, C, K = args.batch, args.N, args.C, args.K
+def run_cfg2(args, torch, gf, dev, world, rank):
+    B, N, C, K = args.batch or 256, args.N, args.C, 18
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     P = torch.rand((B, N, N, N, C), device=dev, generator=gen) * 2 - 1          # U(-1,1)
     U = (torch.rand((B, N, N), device=dev, generator=gen) < 0.5).float().triu(1)
@@ -67,13 +45,156 @@ def main():
     G = torch.rand((B, N, N, K, C), device=dev, generator=gen)                   # U(0,1)
     Out = torch.empty((B, N, N, K, C), device=dev)
     dP = torch.empty((B, N, N, N, C), device=dev)
-
     ctx = gf.Context(dev.index)
     ctx.reserve(gf.contract_workspace_bytes(K, N, C, B))
 
     def step():
         gf.contract_forward(P, A, K, out=Out, ctx=ctx)
         gf.contract_backward(G, A, K, dP=dP, accumulate=False, ctx=ctx)
+
+    def finish(timers, ms_per_step):
+        fwd_b, bwd_b = contraction_bytes(K, N, C)
+        per = {k: v[0] / max(v[1], 1) for k, v in timers.items()}
+        dom = max(timers, key=lambda k: timers[k][0])
+        fwd_ms = sum(v for k, v in per.items() if "fwd" in k)
+        bwd_ms = sum(v for k, v in per.items() if "bwd" in k)
+        call_ms, call_b, which = (fwd_ms, fwd_b, "forward") if "fwd" in dom else (bwd_ms, bwd_b, "backward")
+        ach = call_b * B / (call_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom,
+                "kernel_ms": {k: round(v, 4) for k, v in per.items()},
+                "note": "achieved = algorithmic bytes of one %s call over the batch / (its slab+rows kernel time)" % which,
+                "step_GBps": round((fwd_b + bwd_b) * B / (ms_per_step * 1e-3) / 1e9, 1)}
+        return roof
+
+    def cpu():
+        from oracle import pyoracle
+        from inputs import cfg_graph
+        Pc, Ac, Gc = cfg_graph(N, C, 1000, K=18)
+        secs, kind, _, _ = pyoracle.time_r18_fwd_bwd(Pc, Ac, Gc)
+        return {"value": round(1.0 / secs, 5), "unit": "graphs/s", "cores": 1, "kind": kind,
+                "sample": "1 graph, RisiContraction_18 fwd+bwd, N=%d C=%d fp64, %.1f s" % (N, C, secs)}
+
+    meta = {"metric": "RisiContraction_18 graphs/sec fwd+bwd (second-order CCN contraction step)", "unit": "graphs/s",
+            "units_per_step": B,
+            "config": {"workload": "cfg2: RisiContraction_18 fwd+bwd, N=%d, C=%d, batch=%d graphs/GPU, device-resident" % (N, C, B),
+                       "parallelism": "graph-sharded x%d, no collective" % world}}
+    return ctx, step, finish, cpu, meta, None
+
+
+def run_cfg3(args, torch, gf, dev, world, rank, dist):
+    import numpy as np
+    from graphflow_amd.smp import SMPOmega
+    from graphflow_amd import dist as gd
+    from inputs import smp_params, synthetic_molecule
+    B = args.batch or 1024
+    L, C, F, D, cap = 3, args.C, 5, 5, 29
+    mols, tg = [], []
+    for i in range(B):
+        adj, feat, t = synthetic_molecule(rank * 1000003 + i)   # seed = molecule index, disjoint across ranks
+        mols.append((adj, feat))
+        tg.append(t)
+    ctx = gf.Context(dev.index)
+    net = SMPOmega(L, C, F, D, cap, True, ctx=ctx)
+    t0 = time.perf_counter()
+    net.prepare(mols)
+    prep_s = time.perf_counter() - t0
+    params = torch.as_tensor(smp_params(C, F, D, L, 1).astype(np.float32)).to(dev)
+    targets = torch.as_tensor(np.array(tg, dtype=np.float32)).to(dev)
+    grads = torch.empty(net.n_params, device=dev)
+    sizes = [net.level_sizes(l) for l in range(L + 1)]   # (nodes, rows = sum s^2, ppos = sum s^3)
+
+    def step():
+        net.forward(params, targets)
+        net.backward(params, grads)
+        gd.allreduce_sum_(grads, dist)   # the one exchange of the path (SMP_omega.h:784-786)
+
+    # algorithmic work per step: per level l>=1, with R = sum s^2, S = sum s^3
+    fwd_bytes = bwd_bytes = 0
+    gemm_flops = 0
+    contract_bytes = 0
+    for l in range(1, L + 1):
+        _, R, S = sizes[l]
+        contract = 4 * (S * C + R + 18 * R * C)                 # read P + A, write Q
+        promote = 4 * (2 * S * C)                               # gather read (upper bound) + write P
+        kproj = 4 * (18 * R * C + 18 * C * C + R * C)           # read Q, K; write f
+        act = 4 * (2 * R * C)
+        fwd_bytes += contract + promote + kproj + act
+        bwd_bytes += contract + promote + 2 * kproj + act
+        contract_bytes += contract
+        gemm_flops += 2 * R * 18 * C * C
+    work = {"levels": [{"nodes": n, "rows_sum_s2": r, "ppos_sum_s3": s} for (n, r, s) in sizes]}
+
+    def finish(timers, ms_per_step):
+        tot = {k: v[0] / args.steps for k, v in timers.items()}   # ms per step per kernel name
+        dom = max(tot, key=tot.get)
+        if dom.startswith("gemm"):
+            ach = gemm_flops / (tot[dom] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                    "note": "fp32-input MFMA GEMM; flops = sum over levels of 2*rows*18C*C (the K-projection or one of its two gradients)"}
+        else:
+            which = "fwd" if "fwd" in dom else "bwd"
+            ms = sum(v for k, v in tot.items() if k.startswith("r18_" + which))
+            ach = contract_bytes / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "note": "RisiContraction_18 %s over all buckets and levels: algorithmic bytes / (slab+rows kernel time)" % which}
+        roof["kernel"] = dom
+        roof["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
+        roof["step_GBps"] = round((fwd_bytes + bwd_bytes) / (ms_per_step * 1e-3) / 1e9, 1)
+        roof["step_gemm_TFLOPs"] = round(3 * gemm_flops / (ms_per_step * 1e-3) / 1e12, 2)
+        return roof
+
+    def cpu():
+        from oracle import pyoracle
+        # bounded sample: the batch's first molecules until about 20 s of reference work (cost grows steeply with nV)
+        sample, est = [], 0.0
+        for (a, f), t in zip(mols, tg):
+            sample.append(((a, f), t))
+            est += 3.5e-4 * len(a) ** 3   # rough: 8.3 s at 29 atoms
+            if est > 20.0 or len(sample) >= 16:
+                break
+        secs = pyoracle.time_reference_smp_omega([m for m, _ in sample], [t for _, t in sample], L, C, D, cap)
+        if secs is None:
+            return None
+        return {"value": round(len(sample) / secs, 4), "unit": "molecules/s", "cores": 1, "kind": "reference",
+                "sample": "first %d molecules of the batch (nV %s), SMP_omega complete_computation_graph+forward+backward, fp64, %.1f s"
+                          % (len(sample), [len(m[0]) for m, _ in sample], secs)}
+
+    meta = {"metric": "CCN-2D (SMP_omega) molecules/sec fwd+bwd", "unit": "molecules/s", "units_per_step": B,
+            "config": {"workload": "cfg3: SMP_omega 3 levels, C=%d, F=5, D=5, cap=29, batch=%d synthetic QM9-size molecules/GPU, device-resident"
+                                   % (C, B),
+                       "parallelism": "molecule-sharded x%d, one RCCL all-reduce of %d gradient floats per step" % (world, net.n_params)
+                       if world > 1 else "single GPU", "prep_s": round(prep_s, 3), "work": work}}
+    return ctx, step, finish, cpu, meta, net
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3"])
+    ap.add_argument("--batch", type=int, default=0, help="graphs / molecules per GPU (default 256 for cfg2, 1024 for cfg3)")
+    ap.add_argument("--N", type=int, default=32)
+    ap.add_argument("--C", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import graphflow_amd as gf
+    from graphflow_amd import dist as gd
+
+    world, rank, local = gd.env_world()
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    dist = gd.init(backend="nccl", device=dev) if world > 1 else None
+
+    if args.workload == "cfg2":
+        ctx, step, finish, cpu, meta, keep = run_cfg2(args, torch, gf, dev, world, rank)
+    else:
+        ctx, step, finish, cpu, meta, keep = run_cfg3(args, torch, gf, dev, world, rank, dist)
 
     def fence():
         if dist is not None:
@@ -92,48 +213,19 @@ def main():
     fence()
     timers = ctx.timings()
     ctx.set_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = gd.max_over_ranks(elapsed, dist, dev)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        graphs_per_s = world * B * args.steps / elapsed
-        fwd_b, bwd_b = algorithmic_bytes(K, N, C)
-        # dominant kernel = the one with the largest total device time
-        per_kernel = {k: v[0] / max(v[1], 1) for k, v in timers.items()}
-        dom = max(timers, key=lambda k: timers[k][0]) if timers else None
-        # algorithmic bytes are defined per CALL (fwd or bwd); a call's duration = its two kernels
-        fwd_ms = sum(v for k, v in per_kernel.items() if "fwd" in k)
-        bwd_ms = sum(v for k, v in per_kernel.items() if "bwd" in k)
-        call_ms, call_bytes = (fwd_ms, fwd_b) if (dom and "fwd" in dom) else (bwd_ms, bwd_b)
-        achieved = (call_bytes * B / (call_ms * 1e-3)) / 1e9 if call_ms > 0 else 0.0
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "kernel": dom, "kernel_ms": {k: round(v, 4) for k, v in per_kernel.items()},
-                    "note": "achieved = algorithmic bytes of one %s call over the batch / (its slab+rows kernel time)"
-                            % ("forward" if (dom and "fwd" in dom) else "backward"),
-                    "step_GBps": round((fwd_b + bwd_b) * B / (ms_per_step * 1e-3) / 1e9, 1)}
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import pyoracle
-            from inputs import cfg_graph
-            Pc, Ac, Gc = cfg_graph(N, C, 1000, K=18)
-            secs, kind, _, _ = pyoracle.time_r18_fwd_bwd(Pc, Ac, Gc)
-            cpu = {"value": round(1.0 / secs, 5), "unit": "graphs/s", "cores": 1, "kind": kind,
-                   "sample": "1 graph, RisiContraction_18 fwd+bwd, N=%d C=%d fp64, %.1f s" % (N, C, secs)}
-        line = {
-            "metric": "RisiContraction_18 graphs/sec fwd+bwd (second-order CCN contraction step)",
-            "value": round(graphs_per_s, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg2: RisiContraction_%d fwd+bwd, N=%d, C=%d, batch=%d graphs/GPU, device-resident"
-                                   % (K, N, C, B), "parallelism": "graph-sharded x%d, no collective" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
+        value = world * meta["units_per_step"] * args.steps / elapsed
+        line = {"metric": meta["metric"], "value": round(value, 1), "unit": meta["unit"], "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": meta["config"], "roofline": finish(timers, ms_per_step),
+                "cpu_baseline": (cpu() if (world == 1 and not args.no_cpu_baseline) else None)}
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -246,3 +246,21 @@ def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, h
 
 
 C_double = C.c_double
+
+
+def time_reference_smp_omega(molecules, targets, nLevels, C, nDepth, cap):
+    """Seconds the REAL reference spends on complete_computation_graph + forward + backward over `molecules`
+    (list of (adj, feature)), single host thread, or None when oracle/_ref is absent."""
+    ref = reference()
+    if ref is None:
+        return None
+    nV = np.array([len(a) for a, _ in molecules], dtype=np.int32)
+    adj = np.concatenate([np.ascontiguousarray(a, dtype=np.int32).ravel() for a, _ in molecules])
+    feat = np.concatenate([np.ascontiguousarray(f, dtype=np.float64).ravel() for _, f in molecules])
+    tg = np.ascontiguousarray(targets, dtype=np.float64)
+    F = molecules[0][1].shape[1]
+    f = ref.lib.ref_smp_omega_time
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f.argtypes = [_i] * 7 + [ip, ip, _dp, _dp]
+    f.restype = C.c_double
+    return float(f(int(nV.max()), cap, nLevels, C, F, nDepth, len(molecules), nV, adj, feat, tg))

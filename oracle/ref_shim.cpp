@@ -294,3 +294,35 @@ extern "C" int ref_smp_omega_run(int max_nVertices, int max_rf, int nLevels, int
         }
     return (int)off;
 }
+
+// CPU baseline for the SMP_omega workload: one model instance, nMol molecules, the per-molecule body of
+// SMP_omega::BatchLearn's gradient loop (complete_computation_graph + forward + backward, SMP_omega.h:810-818);
+// returns the seconds spent in that loop (construction and allocation are outside the clock).
+#include <sys/time.h>
+extern "C" double ref_smp_omega_time(int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int nDepth,
+                                     int nMol, const int *nV, const int *adj, const double *feature,
+                                     const double *targets) {
+    SMP_omega &net = *new SMP_omega(max_nVertices, max_rf, nLevels, nChanels, nFeatures, nDepth);
+    std::vector<DenseGraph *> mol(nMol);
+    size_t ao = 0, fo = 0;
+    for (int m = 0; m < nMol; ++m) {
+        const int V = nV[m];
+        mol[m] = new DenseGraph(V, nFeatures);
+        for (int i = 0; i < V; ++i) {
+            for (int j = 0; j < V; ++j) mol[m]->adj[i][j] = adj[ao + (size_t)i * V + j];
+            for (int f = 0; f < nFeatures; ++f) mol[m]->feature[i][f] = feature[fo + (size_t)i * nFeatures + f];
+        }
+        ao += (size_t)V * V;
+        fo += (size_t)V * nFeatures;
+    }
+    struct timeval t0, t1;
+    gettimeofday(&t0, NULL);
+    for (int m = 0; m < nMol; ++m) {
+        net.complete_computation_graph(mol[m]);
+        net.target->value[0] = targets[m];
+        net.graph->forward();
+        net.graph->backward();
+    }
+    gettimeofday(&t1, NULL);
+    return (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
+}
