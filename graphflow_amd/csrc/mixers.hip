@@ -27,83 +27,96 @@ struct GemmArgs {
     long long sA, sB, sC;  // batch strides (elements)
     int kchunk;            // K range per split (multiple of BK); splits = gridDim.z / batch
     int batch;
+    int ntiles_n;
     int accumulate;        // C += result (only when not splitting)
 };
 
 // element (m,k) of op(A): TA ? A[k*lda + m] : A[m*lda + k];   element (k,n) of op(B): TB ? B[n*ldb + k] : B[k*ldb + n]
-template <bool TA, bool TB>
+// VEC: every operand is 16-byte aligned with leading dimensions and extents that are multiples of 4, so global
+// traffic moves as float4 along each operand's contiguous direction and the C tile leaves through LDS as float4 rows.
+template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
-    __shared__ float As[BM * (BK + 1)];
-    __shared__ float Bs[BK * (BN + 1)];
+    constexpr int LDA_S = BK + 1, LDB_S = BN + 1, LDC_S = BN + 4;
+    constexpr int kSmem = (BM * LDC_S > BM * LDA_S + BK * LDB_S) ? BM * LDC_S : BM * LDA_S + BK * LDB_S;
+    __shared__ __attribute__((aligned(16))) float smem[kSmem];
+    float *As = smem, *Bs = smem + BM * LDA_S, *Cs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // M tiles on x: M = sum s^2 can be millions of rows
+    // tile order: the N tile varies fastest, so the workgroups that share one A row-panel run back to back and the
+    // panel is read from HBM once (dQ = dZ K^T has 18 N tiles per panel); M tiles can be millions (M = sum s^2)
+    const int ntn = g.ntiles_n;
+    const int m0 = (int)(blockIdx.x / ntn) * BM, n0 = (int)(blockIdx.x % ntn) * BN;
     const int bz = blockIdx.z % g.batch, split = blockIdx.z / g.batch;
     const float *A = g.A + bz * g.sA, *B = g.B + bz * g.sB;
     const int kbeg = split * g.kchunk;
     const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
 
-    float ra[8], rb[8];
+    constexpr int NLD = VEC ? 2 : 8;
+    float4 va[VEC ? 2 : 1], vb[VEC ? 2 : 1];
+    float ra[VEC ? 1 : 8], rb[VEC ? 1 : 8];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < NLD; ++e) {
             const int idx = tid + e * kThreads;
-            int m, k;
-            if (TA) {
-                m = idx % BM;
-                k = idx / BM;
+            if (VEC) {
+                int m, k;
+                if (TA) { m = (idx % (BM / 4)) * 4; k = idx / (BM / 4); } else { k = (idx % (BK / 4)) * 4; m = idx / (BK / 4); }
+                const int gm = m0 + m, gk = k0 + k;
+                const bool ok = gm < g.M && gk < kend;
+                const size_t off = TA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk;
+                va[e] = ok ? *reinterpret_cast<const float4 *>(A + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                int kk, n;
+                if (TB) { kk = (idx % (BK / 4)) * 4; n = idx / (BK / 4); } else { n = (idx % (BN / 4)) * 4; kk = idx / (BN / 4); }
+                const int gn = n0 + n, gk2 = k0 + kk;
+                const bool ok2 = gn < g.N && gk2 < kend;
+                const size_t off2 = TB ? (size_t)gn * g.ldb + gk2 : (size_t)gk2 * g.ldb + gn;
+                vb[e] = ok2 ? *reinterpret_cast<const float4 *>(B + off2) : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                k = idx % BK;
-                m = idx / BK;
+                int m, k;
+                if (TA) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
+                const int gm = m0 + m, gk = k0 + k;
+                const size_t off = TA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk;
+                ra[e] = (gm < g.M && gk < kend) ? A[off] : 0.f;
+                int kk, n;
+                if (TB) { kk = idx % BK; n = idx / BK; } else { n = idx % BN; kk = idx / BN; }
+                const int gn = n0 + n, gk2 = k0 + kk;
+                const size_t off2 = TB ? (size_t)gn * g.ldb + gk2 : (size_t)gk2 * g.ldb + gn;
+                rb[e] = (gn < g.N && gk2 < kend) ? B[off2] : 0.f;
             }
-            const int gm = m0 + m, gk = k0 + k;
-            const bool ok = gm < g.M && gk < kend;
-            const size_t off = TA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk;
-            ra[e] = ok ? A[off] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = tid + e * kThreads;
-            int k, n;
-            if (TB) {
-                k = idx % BK;
-                n = idx / BK;
-            } else {
-                n = idx % BN;
-                k = idx / BN;
-            }
-            const int gn = n0 + n, gk = k0 + k;
-            const bool ok = gn < g.N && gk < kend;
-            const size_t off = TB ? (size_t)gn * g.ldb + gk : (size_t)gk * g.ldb + gn;
-            rb[e] = ok ? B[off] : 0.f;
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < NLD; ++e) {
             const int idx = tid + e * kThreads;
-            int m, k;
-            if (TA) {
-                m = idx % BM;
-                k = idx / BM;
-            } else {
-                k = idx % BK;
-                m = idx / BK;
-            }
-            As[m * (BK + 1) + k] = ra[e];
-        }
+            if (VEC) {
+                const float a4[4] = {va[e].x, va[e].y, va[e].z, va[e].w}, b4[4] = {vb[e].x, vb[e].y, vb[e].z, vb[e].w};
+                if (TA) {
+                    const int m = (idx % (BM / 4)) * 4, k = idx / (BM / 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = tid + e * kThreads;
-            int k, n;
-            if (TB) {
-                k = idx % BK;
-                n = idx / BK;
+                    for (int j = 0; j < 4; ++j) As[(m + j) * LDA_S + k] = a4[j];
+                } else {
+                    const int k = (idx % (BK / 4)) * 4, m = idx / (BK / 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) As[m * LDA_S + k + j] = a4[j];
+                }
+                if (TB) {
+                    const int k = (idx % (BK / 4)) * 4, n = idx / (BK / 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Bs[(k + j) * LDB_S + n] = b4[j];
+                } else {
+                    const int n = (idx % (BN / 4)) * 4, k = idx / (BN / 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Bs[k * LDB_S + n + j] = b4[j];
+                }
             } else {
-                n = idx % BN;
-                k = idx / BN;
+                int m, k;
+                if (TA) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
+                As[m * LDA_S + k] = ra[e];
+                int kk, n;
+                if (TB) { kk = idx % BK; n = idx / BK; } else { n = idx % BN; kk = idx / BN; }
+                Bs[kk * LDB_S + n] = rb[e];
             }
-            Bs[k * (BN + 1) + n] = rb[e];
         }
     };
 
@@ -118,11 +131,11 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             const bool more = k0 + BK < kend;
             if (more) load_tiles(k0 + BK);
-            const float *ap = As + (wm * 32 + (lane & 31)) * (BK + 1) + (lane >> 5);
-            const float *bp = Bs + (lane >> 5) * (BN + 1) + wn * 32 + (lane & 31);
+            const float *ap = As + (wm * 32 + (lane & 31)) * LDA_S + (lane >> 5);
+            const float *bp = Bs + (lane >> 5) * LDB_S + wn * 32 + (lane & 31);
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * (BN + 1)], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * LDB_S], acc, 0, 0, 0);
             __syncthreads();
             if (more) {
                 store_tiles();
@@ -134,14 +147,41 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int splits = gridDim.z / g.batch;
     float *C = g.C + (splits > 1 ? (size_t)split * g.M * g.ldc : (size_t)0) + bz * g.sC;
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < g.N) {
+    if (VEC) {
+        // stage the 64x64 tile in LDS (the operand tiles are dead: the k-loop ended on a barrier), then 16 B row stores
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < g.M) {
-                float *c = C + (size_t)row * g.ldc + col;
-                *c = g.accumulate ? *c + acc[r] : acc[r];
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Cs[row * LDC_S + wn * 32 + (lane & 31)] = acc[r];
+        }
+        __syncthreads();
+        const int c4 = (tid % (BN / 4)) * 4, r0 = tid / (BN / 4);
+#pragma unroll
+        for (int p = 0; p < BM / (kThreads / (BN / 4)); ++p) {
+            const int row = r0 + p * (kThreads / (BN / 4));
+            if (m0 + row < g.M && n0 + c4 < g.N) {
+                float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC_S + c4);
+                float4 *dst = reinterpret_cast<float4 *>(C + (size_t)(m0 + row) * g.ldc + n0 + c4);
+                if (g.accumulate) {
+                    const float4 o = *dst;
+                    v.x += o.x;
+                    v.y += o.y;
+                    v.z += o.z;
+                    v.w += o.w;
+                }
+                *dst = v;
+            }
+        }
+    } else {
+        const int col = n0 + wn * 32 + (lane & 31);
+        if (col < g.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.M) {
+                    float *c = C + (size_t)row * g.ldc + col;
+                    *c = g.accumulate ? *c + acc[r] : acc[r];
+                }
             }
         }
     }
@@ -181,7 +221,7 @@ gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *
     int splits = 1;
     const long long tiles = (long long)gx * gy * batch;
     if (batch == 1 && tiles < 512 && K >= 8 * BK) {
-        splits = (int)((1024 + tiles - 1) / tiles);
+        splits = (int)((4096 + tiles - 1) / tiles);  // about 16 workgroups per CU: each one is a latency-bound k-loop
         const int maxs = K / (2 * BK);
         if (splits > maxs) splits = maxs;
         if (splits < 1) splits = 1;
@@ -202,11 +242,24 @@ gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *
         g.ldc = N;
         g.accumulate = 0;
     }
-    const dim3 grid(gy, gx, batch * splits);
-    if (!ta && !tb) GF_LAUNCH(ctx, "gemm_nn", (gemm_f32_mfma<false, false>), grid, dim3(kThreads), 0, g);
-    if (!ta && tb) GF_LAUNCH(ctx, "gemm_nt", (gemm_f32_mfma<false, true>), grid, dim3(kThreads), 0, g);
-    if (ta && !tb) GF_LAUNCH(ctx, "gemm_tn", (gemm_f32_mfma<true, false>), grid, dim3(kThreads), 0, g);
-    if (ta && tb) GF_LAUNCH(ctx, "gemm_tt", (gemm_f32_mfma<true, true>), grid, dim3(kThreads), 0, g);
+    g.ntiles_n = gx;
+    const dim3 grid((unsigned)((size_t)gx * gy), 1, batch * splits);
+    // vector path: 16-byte aligned operands, extents and leading dimensions in multiples of 4
+    const bool vec = (((uintptr_t)A | (uintptr_t)B | (uintptr_t)g.C) & 15) == 0 && (M % 4 == 0) && (N % 4 == 0) &&
+                     (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (g.ldc % 4 == 0) && (sA % 4 == 0) &&
+                     (sB % 4 == 0) && (sC % 4 == 0);
+#define GF_GEMM_LAUNCH(TA_, TB_, NAME)                                                                         \
+    do {                                                                                                       \
+        if (vec)                                                                                               \
+            GF_LAUNCH(ctx, NAME, (gemm_f32_mfma<TA_, TB_, true>), grid, dim3(kThreads), 0, g);                 \
+        else                                                                                                   \
+            GF_LAUNCH(ctx, NAME, (gemm_f32_mfma<TA_, TB_, false>), grid, dim3(kThreads), 0, g);                \
+    } while (0)
+    if (!ta && !tb) GF_GEMM_LAUNCH(false, false, "gemm_nn");
+    if (!ta && tb) GF_GEMM_LAUNCH(false, true, "gemm_nt");
+    if (ta && !tb) GF_GEMM_LAUNCH(true, false, "gemm_tn");
+    if (ta && tb) GF_GEMM_LAUNCH(true, true, "gemm_tt");
+#undef GF_GEMM_LAUNCH
     if (splits > 1) {
         const size_t n = (size_t)M * N;
         size_t blocks = (n + 255) / 256;

@@ -78,6 +78,21 @@ __global__ void promote_forward(const float *__restrict__ fprev, float *__restri
     const short *map = pi + node_row[n] + (long long)a * s;
     const float *src = fprev + pair_src_row[e] * C;
     float *dst = P + (node_p[n] + (long long)a * s * s) * C;
+    if ((C & 3) == 0) {  // 16 B per lane over the channel axis; (c, quad) flattened per row b
+        const int Q = C >> 2, per_row = s * Q;
+        for (int b = 0; b < s; ++b) {
+            const int pb = map[b];
+            float4 *drow = reinterpret_cast<float4 *>(dst + (size_t)b * s * C);
+            for (int i = threadIdx.x; i < per_row; i += blockDim.x) {
+                const int c = i / Q, q = i - c * Q;
+                const int pc = map[c];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pb >= 0 && pc >= 0) v = reinterpret_cast<const float4 *>(src + ((size_t)pb * sw + pc) * C)[q];
+                drow[i] = v;
+            }
+        }
+        return;
+    }
     const int total = s * s * C;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int f = i % C, bc = i / C;
@@ -97,6 +112,27 @@ __global__ void promote_backward(const float *__restrict__ dP, float *__restrict
     const int sw = prev_s[w];
     float *dst = dfprev + prev_row[w] * C;
     const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
+    if ((C & 3) == 0) {
+        const int Q = C >> 2, total4 = sw * sw * Q;
+        for (int i = threadIdx.x; i < total4; i += blockDim.x) {
+            const int q4 = i % Q, pq = i / Q;
+            const int p = pq / sw, q = pq - p * sw;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (long long e = c0; e < c1; ++e) {
+                const short *iv = inv + cons_inv_off[e];
+                const int ib = iv[p], ic = iv[q];
+                if (ib >= 0 && ic >= 0) {
+                    const float4 v = reinterpret_cast<const float4 *>(dP + (cons_slab[e] + (long long)ib * cons_s[e] + ic) * C)[q4];
+                    acc.x += v.x;
+                    acc.y += v.y;
+                    acc.z += v.z;
+                    acc.w += v.w;
+                }
+            }
+            reinterpret_cast<float4 *>(dst)[i] = acc;
+        }
+        return;
+    }
     const int total = sw * sw * C;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int f = i % C, pq = i / C;
@@ -120,25 +156,51 @@ __global__ void bias_lrelu_forward(float *__restrict__ Y, const float *__restric
 // also leaves per-block partial column sums of dZ for the bias gradient (VectorAddTensor.h:61-72)
 __global__ void lrelu_backward_colsum(const float *__restrict__ F, float *__restrict__ dF, float *__restrict__ part, int C,
                                       long long rows, int rows_per_block) {
+    __shared__ float red[256];
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
-    for (int f = threadIdx.x; f < C; f += blockDim.x) {
+    const int lanes = (C < 256) ? C : 256;          // channel lanes per row
+    const int rl = 256 / lanes;                     // rows handled concurrently
+    const int f0 = threadIdx.x % lanes, rr = threadIdx.x / lanes;
+    for (int fb = 0; fb < C; fb += lanes) {
+        const int f = fb + f0;
         float s = 0.f;
-        for (long long r = r0; r < r1; ++r) {
-            const size_t i = (size_t)r * C + f;
-            const float d = dF[i] * (F[i] > 0.f ? 1.f : kAlpha);
-            dF[i] = d;
-            s += d;
+        if (f < C && rr < rl)
+            for (long long r = r0 + rr; r < r1; r += rl) {
+                const size_t i = (size_t)r * C + f;
+                const float d = dF[i] * (F[i] > 0.f ? 1.f : kAlpha);
+                dF[i] = d;
+                s += d;
+            }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rr == 0 && f < C) {
+            float t = 0.f;
+            for (int k = 0; k < rl; ++k) t += red[k * lanes + f0];
+            part[(size_t)blockIdx.x * C + f] = t;
         }
-        part[(size_t)blockIdx.x * C + f] = s;
+        __syncthreads();
     }
 }
 
+// out[f] += sum_b part[b][f]; one workgroup, row lanes in parallel then a fixed-order fold
 __global__ void colsum_finish(const float *__restrict__ part, float *__restrict__ out, int C, int nblocks) {
-    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < C; f += gridDim.x * blockDim.x) {
+    __shared__ float red[256];
+    const int lanes = (C < 256) ? C : 256, rl = 256 / lanes;
+    const int f0 = threadIdx.x % lanes, rr = threadIdx.x / lanes;
+    for (int fb = 0; fb < C; fb += lanes) {
+        const int f = fb + f0;
         float s = 0.f;
-        for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * C + f];
-        out[f] += s;
+        if (f < C && rr < rl)
+            for (int b = rr; b < nblocks; b += rl) s += part[(size_t)b * C + f];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rr == 0 && f < C) {
+            float t = 0.f;
+            for (int k = 0; k < rl; ++k) t += red[k * lanes + f0];
+            out[f] += t;
+        }
+        __syncthreads();
     }
 }
 
@@ -189,10 +251,22 @@ __global__ void readout_molecules(const float *__restrict__ vf, const int *__res
 
 // dW[f] += sum_m dy[m] g[m][f]   (InnerProduct.h:48-53, second operand)
 __global__ void readout_dW(const float *__restrict__ dy, const float *__restrict__ g, float *__restrict__ dW, int C, int nMol) {
-    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < C; f += gridDim.x * blockDim.x) {
+    __shared__ float red[256];
+    const int lanes = (C < 256) ? C : 256, rl = 256 / lanes;
+    const int f0 = threadIdx.x % lanes, rr = threadIdx.x / lanes;
+    for (int fb = 0; fb < C; fb += lanes) {
+        const int f = fb + f0;
         float acc = 0.f;
-        for (int m = 0; m < nMol; ++m) acc += dy[m] * g[(size_t)m * C + f];
-        dW[f] += acc;
+        if (f < C && rr < rl)
+            for (int m = rr; m < nMol; m += rl) acc += dy[m] * g[(size_t)m * C + f];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (rr == 0 && f < C) {
+            float t = 0.f;
+            for (int k = 0; k < rl; ++k) t += red[k * lanes + f0];
+            dW[f] += t;
+        }
+        __syncthreads();
     }
 }
 
@@ -374,7 +448,7 @@ gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *a
     if (st != GF_OK) return st;
 #undef UP
     // split-K partials of the weight gradients also live in the context workspace
-    const size_t gemm_ws = sizeof(float) * 1200 * (size_t)gf::kK * C * C + (1 << 20);
+    const size_t gemm_ws = sizeof(float) * 4200 * (size_t)gf::kK * C * C / 18 + sizeof(float) * 4200 * (size_t)C * s->cfg.fdim() + (1 << 20);
     st = gf::ensure_ws(ctx, std::max(contract_ws, gemm_ws));
     if (st != GF_OK) return st;
     GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -457,7 +531,7 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
         // dZ = dF * lrelu'(z) in place; db_l += column sums
         const int rpb = 1024;
         const int nb = (int)((h.rows + rpb - 1) / rpb);
-        GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(64), 0, d.f, d.df, s->colpart, C,
+        GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(256), 0, d.f, d.df, s->colpart, C,
                   (long long)h.rows, rpb);
         GF_LAUNCH(ctx, "smp_colsum", gf::colsum_finish, dim3(1), dim3(256), 0, s->colpart, db[l], C, nb);
         // dK_l += Q^T dZ   (MatMul::backward second operand), then dQ = dZ K_l^T overwrites Q (first operand)
@@ -479,7 +553,7 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     {
         const int nV = B.level[0].nNodes;
         const int rpb = 1024, nb = (nV + rpb - 1) / rpb;
-        GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(64), 0, s->lv[0].f, s->lv[0].df, s->colpart,
+        GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(256), 0, s->lv[0].f, s->lv[0].df, s->colpart,
                   C, (long long)nV, rpb);
         st = gf::gemm(ctx, true, false, C, FD, nV, s->lv[0].df, C, 0, s->x, FD, 0, dH, FD, 0, 1, 1);
         if (st != GF_OK) return st;

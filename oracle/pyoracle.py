@@ -248,7 +248,7 @@ def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, h
 C_double = C.c_double
 
 
-def time_reference_smp_omega(molecules, targets, nLevels, C, nDepth, cap):
+def time_reference_smp_omega(molecules, targets, nLevels, nChanels, nDepth, cap):
     """Seconds the REAL reference spends on complete_computation_graph + forward + backward over `molecules`
     (list of (adj, feature)), single host thread, or None when oracle/_ref is absent."""
     ref = reference()
@@ -262,5 +262,5 @@ def time_reference_smp_omega(molecules, targets, nLevels, C, nDepth, cap):
     f = ref.lib.ref_smp_omega_time
     ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
     f.argtypes = [_i] * 7 + [ip, ip, _dp, _dp]
-    f.restype = C.c_double
-    return float(f(int(nV.max()), cap, nLevels, C, F, nDepth, len(molecules), nV, adj, feat, tg))
+    f.restype = C_double
+    return float(f(int(nV.max()), cap, nLevels, nChanels, F, nDepth, len(molecules), nV, adj, feat, tg))
