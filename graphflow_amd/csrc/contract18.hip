@@ -158,17 +158,46 @@ __device__ __forceinline__ f4 batched_sum(const float *base, size_t stride, int 
     return s;
 }
 
-struct BlockId {
-    int g, i, win;
+// Where a workgroup works.  Uniform batches (pair_node == nullptr): graph g = blk / N, index i = blk % N, everything
+// at g * N^k.  Ragged batches (the SMP driver): one workgroup per (node, index) "pair"; the node table gives its size
+// and the offsets of its P block (in positions = units of C floats), of its rows (N^2 per node: adjacency, Out/G rows,
+// N x N workspace tables) and of its first pair (per-(node, index) partial scalars).
+struct Ragged {
+    const int *pair_node;        // [pairs] or nullptr
+    const int *node_s;           // [nodes]
+    const long long *node_p;     // [nodes] sum of s^3 before the node
+    const long long *node_row;   // [nodes] sum of s^2 before the node
+    const long long *node_pair;  // [nodes] sum of s   before the node
+    long long pair_base;         // first pair of this launch
+    int N;                       // uniform size (uniform batches), maximum size in the launch (ragged)
 };
-__device__ __forceinline__ BlockId decode_block(int N, int nwin) {
-    int bid = blockIdx.x;
-    BlockId r;
-    r.win = bid % nwin;
-    bid /= nwin;
-    r.i = bid % N;
-    r.g = bid / N;
-    return r;
+struct Where {
+    int N, i, win;
+    size_t pbase, rowbase, pairbase;
+};
+__device__ __forceinline__ Where locate(const Ragged &R, int nwin) {
+    Where w;
+    long long blk = blockIdx.x;
+    w.win = (int)(blk % nwin);
+    blk /= nwin;
+    if (R.pair_node) {
+        const long long e = R.pair_base + blk;
+        const int n = R.pair_node[e];
+        w.N = R.node_s[n];
+        w.pairbase = (size_t)R.node_pair[n];
+        w.i = (int)(e - R.node_pair[n]);
+        w.pbase = (size_t)R.node_p[n];
+        w.rowbase = (size_t)R.node_row[n];
+    } else {
+        const int N = R.N;
+        const size_t g = (size_t)(blk / N);
+        w.N = N;
+        w.i = (int)(blk % N);
+        w.pbase = g * N * N * N;
+        w.rowbase = g * N * N;
+        w.pairbase = g * N;
+    }
+    return w;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -196,7 +225,7 @@ __device__ __forceinline__ void load_slab_row(__amdgpu_buffer_rsrc_t slab, int r
 template <int LPC, int NI, bool FULL>
 __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict__ P, const float *__restrict__ A,
                                                          float *__restrict__ Out, float *__restrict__ wsSab,
-                                                         float *__restrict__ wsDbb, float *__restrict__ wsScal, int N,
+                                                         float *__restrict__ wsDbb, float *__restrict__ wsScal, Ragged R,
                                                          int C, int nwin) {
     constexpr int PPW = 64 / LPC;
     constexpr int CW = 4 * LPC;
@@ -205,14 +234,17 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row base addresses stay in SGPRs
     const int cg = lane / LPC, fl = lane % LPC;
-    const BlockId B = decode_block(N, nwin);
-    const int g = B.g, b = B.i;
-    const int f = B.win * CW + 4 * fl;
+    const Where W = locate(R, nwin);
+    const int N = W.N, b = W.i;
+    const size_t rowbase = W.rowbase, pbase = W.pbase, pairbase = W.pairbase;
+    (void)pbase;
+    (void)pairbase;
+    const int f = W.win * CW + 4 * fl;
     const bool fok = FULL || f < C;
     const int fld = fok ? f : 0;  // clamped channel offset for loads
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const AdjLds L = load_adjacency<false>(smem, A + (size_t)g * N * N, N);
+    const AdjLds L = load_adjacency<false>(smem, A + rowbase, N);
     float *sSab = smem + adj_lds_floats(N);  // [N][CW]    S_ab[e, b]
     float *sDac = sSab + N * CW;             // [N][CW]    P[e, b, e]
     float *sSbc = sDac + N * CW;             // [NCP][CW]  S_bc[b, e]
@@ -233,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
     const float dmask = (cg < 2 && fok) ? 1.f : 0.f;
 
     // slab descriptor: base P[g][0][b][0][0]; row a starts a*N*N*C floats further (scalar offset)
-    const float *slab0 = P + (size_t)g * N * N * N * C + (size_t)b * N * C;
+    const float *slab0 = P + pbase * C + (size_t)b * N * C;
     const __amdgpu_buffer_rsrc_t slab = make_rsrc(slab0, ((size_t)N * N * N * C - (size_t)b * N * C) * 4);
     const int rowBytes = N * N * C * 4;
     const int dgA = fld * 4 + C * 4 * b;  // lanes cg==0 read P[a,b,b]; lanes cg!=0 read P[a,b,a] (offset depends on a)
@@ -269,8 +301,8 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
         const f4 dv = dcur * dmask;
         dgsum += dv;
         // row epilogue: four c-groups each issue one 16 B store per lane (256 B segments at C=64)
-        const size_t oab = (((size_t)g * N + a) * N + b) * (size_t)(kK * C) + f;  // Out[g][a][b][.][f]
-        const size_t wab = (((size_t)g * N + a) * N + b) * (size_t)C + f;         // ws[g][a][b][f]
+        const size_t oab = (rowbase + (size_t)a * N + b) * (size_t)(kK * C) + f;  // Out[g][a][b][.][f]
+        const size_t wab = (rowbase + (size_t)a * N + b) * (size_t)C + f;         // ws[g][a][b][f]
         if (cg == 0) {
             if (fok) {
                 st4(Out + oab + 0 * C, sab * tot);  // k0  S_ab*tot
@@ -314,7 +346,7 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
     if (cg < 2) st4(sMisc + (wave * 2 + cg) * CW + 4 * fl, dgsum);
     if (wave == 0) {
         f4 cs = splat(0.f);
-        float *obc = Out + (((size_t)g * N + b) * N) * (size_t)(kK * C) + f;  // Out[g][b][c][.][f]
+        float *obc = Out + (rowbase + (size_t)b * N) * (size_t)(kK * C) + f;  // Out[g][b][c][.][f]
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int c = i * PPW + cg;
@@ -348,7 +380,7 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
         small_matvec<3, CW>(L, N, d, fl, T, m);
         const float rd = L.r[d];
         if (fok) {
-            float *o = Out + (((size_t)g * N + b) * N + d) * (size_t)(kK * C) + f;
+            float *o = Out + (rowbase + (size_t)b * N + d) * (size_t)(kK * C) + f;
             st4(o + 3 * C, colsum * rd);   // k3   (sum_{a,c} P[a,b,c]) r[d]
             st4(o + 10 * C, dactot * rd);  // k10  (sum_a P[a,b,a]) r[d]
             st4(o + 11 * C, m[0]);         // k11  sum_e A[d,e] S_ab[e,b]
@@ -357,7 +389,7 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
         }
     }
     if (grp == 0 && fok) {
-        float *s = wsScal + ((size_t)g * N + b) * 4 * (size_t)C + f;
+        float *s = wsScal + (pairbase + b) * 4 * (size_t)C + f;
         st4(s + 0 * C, colsum);                       // -> total = sum_b colsum_b
         st4(s + 1 * C, ld4(sSab + b * CW + 4 * fl));  // -> s14   = sum_a S_ab[a,a]
         st4(s + 2 * C, dbbtot);                       // -> s15   = sum_{a,b} P[a,b,b]
@@ -379,24 +411,27 @@ template <int LPC>
 __global__ __launch_bounds__(kThreads) void r18_fwd_rows(const float *__restrict__ A, float *__restrict__ Out,
                                                          const float *__restrict__ wsSab,
                                                          const float *__restrict__ wsDbb,
-                                                         const float *__restrict__ wsScal, int N, int C, int nwin) {
+                                                         const float *__restrict__ wsScal, Ragged R, int C, int nwin) {
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
     const int tid = threadIdx.x;
     const int grp = tid / LPC, fl = tid % LPC;
-    const BlockId B = decode_block(N, nwin);
-    const int g = B.g, a = B.i;
-    const int f = B.win * CW + 4 * fl;
+    const Where W = locate(R, nwin);
+    const int N = W.N, a = W.i;
+    const size_t rowbase = W.rowbase, pbase = W.pbase, pairbase = W.pairbase;
+    (void)pbase;
+    (void)pairbase;
+    const int f = W.win * CW + 4 * fl;
     const bool fok = f < C;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const AdjLds L = load_adjacency<false>(smem, A + (size_t)g * N * N, N);
+    const AdjLds L = load_adjacency<false>(smem, A + rowbase, N);
     float *sT0 = smem + adj_lds_floats(N);  // [N][CW] S_ab[a, e]
     float *sT1 = sT0 + N * CW;              // [N][CW] P[a, e, e]
     float *sS = sT1 + N * CW;               // [(NPART+1)*4][CW] pieces, then total, s14, s15, s18
 
     for (int e = grp; e < N; e += NGRP) {
-        const size_t w = (((size_t)g * N + a) * N + e) * (size_t)C + f;
+        const size_t w = (rowbase + (size_t)a * N + e) * (size_t)C + f;
         st4(sT0 + e * CW + 4 * fl, fok ? ld4(wsSab + w) : splat(0.f));
         st4(sT1 + e * CW + 4 * fl, fok ? ld4(wsDbb + w) : splat(0.f));
     }
@@ -409,7 +444,7 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_rows(const float *__restrict
                 const int per = (N + NPART - 1) / NPART;
                 const int lo = part * per, hi = (lo + per < N) ? lo + per : N;
                 if (lo < hi)
-                    sum = batched_sum(wsScal + ((size_t)g * N * 4 + j) * (size_t)C + f, 4 * (size_t)C, lo, hi,
+                    sum = batched_sum(wsScal + (pairbase * 4 + j) * (size_t)C + f, 4 * (size_t)C, lo, hi,
                                       [](int) { return 1.f; });
             }
             st4(sS + (part * 4 + j) * CW + 4 * fl, sum);
@@ -442,7 +477,7 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_rows(const float *__restrict
         small_matvec<2, CW>(L, N, y, fl, T, m);
         const float ry = L.r[y], aay = L.at(a, y, N);
         if (fok) {
-            float *o = Out + (((size_t)g * N + a) * N + y) * (size_t)(kK * C) + f;
+            float *o = Out + (rowbase + (size_t)a * N + y) * (size_t)(kK * C) + f;
             st4(o + 1 * C, rowsum * ry);  // k1   (sum_{b,c} P[a,b,c]) r[d]
             st4(o + 7 * C, d8 * ry);      // k7   (sum_b P[a,b,b]) r[d]
             st4(o + 8 * C, m[0]);         // k8   sum_e A[d,e] S_ab[a,e]
@@ -470,24 +505,27 @@ static size_t fwd_rows_lds_bytes(int N) {
 template <int LPC>
 __global__ __launch_bounds__(kThreads) void r18_bwd_rows(const float *__restrict__ G, const float *__restrict__ A,
                                                          float *__restrict__ wsWX, float *__restrict__ wsWZ,
-                                                         float *__restrict__ wsPart, int N, int C, int nwin) {
+                                                         float *__restrict__ wsPart, Ragged R, int C, int nwin) {
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
     static_assert(NGRP >= 12, "six reductions in two halves are spread over thread groups");
     const int tid = threadIdx.x;
     const int grp = tid / LPC, fl = tid % LPC;
-    const BlockId B = decode_block(N, nwin);
-    const int g = B.g, a = B.i;
-    const int f = B.win * CW + 4 * fl;
+    const Where W = locate(R, nwin);
+    const int N = W.N, a = W.i;
+    const size_t rowbase = W.rowbase, pbase = W.pbase, pairbase = W.pairbase;
+    (void)pbase;
+    (void)pairbase;
+    const int f = W.win * CW + 4 * fl;
     const bool fok = f < C;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const AdjLds L = load_adjacency<true>(smem, A + (size_t)g * N * N, N);  // L.A[b][d] = A+[d][b]
+    const AdjLds L = load_adjacency<true>(smem, A + rowbase, N);  // L.A[b][d] = A+[d][b]
     float *sT8 = smem + adj_lds_floats(N);  // [N][CW] G8[a, d]
     float *sT15 = sT8 + N * CW;             // [N][CW] G15[a, d]
     float *sU = sT15 + N * CW;              // [6][CW]
 
-    const float *Grow = G + (((size_t)g * N + a) * N) * (size_t)(kK * C) + f;  // + (y*18 + k)*C
+    const float *Grow = G + (rowbase + (size_t)a * N) * (size_t)(kK * C) + f;  // + (y*18 + k)*C
     for (int d = grp; d < N; d += NGRP) {
         st4(sT8 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 8) * C) : splat(0.f));
         st4(sT15 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 15) * C) : splat(0.f));
@@ -516,13 +554,13 @@ __global__ __launch_bounds__(kThreads) void r18_bwd_rows(const float *__restrict
         f4 m[2];
         small_matvec<2, CW>(L, N, bb, fl, T, m);  // sum_d A+[d][bb] * G[a,d]
         if (fok) {
-            const size_t w = (((size_t)g * N + a) * N + bb) * (size_t)C + f;
+            const size_t w = (rowbase + (size_t)a * N + bb) * (size_t)C + f;
             st4(wsWX + w, u2 + m[0]);
             st4(wsWZ + w, u8 + m[1]);
         }
     }
     if (grp < 4 && fok)
-        st4(wsPart + (((size_t)g * N + a) * 4 + grp) * (size_t)C + f,
+        st4(wsPart + ((pairbase + a) * 4 + grp) * (size_t)C + f,
             ld4(sU + (2 + grp) * CW + 4 * fl) + ld4(sU + (8 + grp) * CW + 4 * fl));
 }
 
@@ -545,7 +583,7 @@ template <int LPC, int NI, bool FULL, bool ACC>
 __global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restrict__ G, const float *__restrict__ A,
                                                          float *__restrict__ dP, const float *__restrict__ wsWX,
                                                          const float *__restrict__ wsWZ,
-                                                         const float *__restrict__ wsPart, int N, int C, int nwin) {
+                                                         const float *__restrict__ wsPart, Ragged R, int C, int nwin) {
     constexpr int PPW = 64 / LPC;
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
@@ -554,13 +592,16 @@ __global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row base addresses stay in SGPRs
     const int cg = lane / LPC, fl = lane % LPC;  // streaming role
     const int grp = tid / LPC;                   // table-building role (same fl: LPC divides 64)
-    const BlockId B = decode_block(N, nwin);
-    const int g = B.g, b = B.i;
-    const int f = B.win * CW + 4 * fl;
+    const Where W = locate(R, nwin);
+    const int N = W.N, b = W.i;
+    const size_t rowbase = W.rowbase, pbase = W.pbase, pairbase = W.pairbase;
+    (void)pbase;
+    (void)pairbase;
+    const int f = W.win * CW + 4 * fl;
     const bool fok = f < C;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const AdjLds L = load_adjacency<true>(smem, A + (size_t)g * N * N, N);  // L.A[y][d] = A+[d][y]
+    const AdjLds L = load_adjacency<true>(smem, A + rowbase, N);  // L.A[y][d] = A+[d][y]
     // LDS: phase (i) holds the three G tables feeding the A^T products; phase (ii) overwrites them with the five
     // tables the streaming loop reads (the products are held in registers across the barrier in between).
     float *sT11 = smem + adj_lds_floats(N);  // [N][CW] G11[b, d]
@@ -574,7 +615,7 @@ __global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restr
     float *sU = sZ2 + N * CW;  // [2][6][CW]: two half-sums of U4, U11, u5, u14, u15, u18
     const float tot = L.st[0], tr = L.st[1];
 
-    const float *Grow = G + (((size_t)g * N + b) * N) * (size_t)(kK * C) + f;  // G[g][b][y][k][f]
+    const float *Grow = G + (rowbase + (size_t)b * N) * (size_t)(kK * C) + f;  // G[g][b][y][k][f]
     for (int d = grp; d < N; d += NGRP) {
         st4(sT11 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 11) * C) : splat(0.f));
         st4(sT12 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 12) * C) : splat(0.f));
@@ -592,7 +633,7 @@ __global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restr
                         s = batched_sum(Grow + (size_t)((j == 0) ? 3 : 10) * C, (size_t)kK * C, lo, hi,
                                         [=](int d) { return rr[d]; });
                     } else {
-                        s = batched_sum(wsPart + ((size_t)g * N * 4 + (j - 2)) * (size_t)C + f, 4 * (size_t)C, lo, hi,
+                        s = batched_sum(wsPart + (pairbase * 4 + (j - 2)) * (size_t)C + f, 4 * (size_t)C, lo, hi,
                                         [](int) { return 1.f; });
                     }
                 }
@@ -617,11 +658,11 @@ __global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restr
             f4 m[3];
             small_matvec<3, CW>(L, N, yy, fl, T, m);  // V12[y], V13[y], V17[y]
             const int fc = fok ? f : 0;
-            const float *gab = G + (((size_t)g * N + yy) * N + b) * (size_t)(kK * C) + fc;  // G[g][y][b][k][f]
+            const float *gab = G + (rowbase + (size_t)yy * N + b) * (size_t)(kK * C) + fc;  // G[g][y][b][k][f]
             const f4 g0 = ld4(gab + 0 * C), g6 = ld4(gab + 6 * C), g5 = ld4(gab + 5 * C);
-            const size_t w = (((size_t)g * N + yy) * N + b) * (size_t)C + fc;
+            const size_t w = (rowbase + (size_t)yy * N + b) * (size_t)C + fc;
             const f4 wx = ld4(wsWX + w), wz = ld4(wsWZ + w);
-            const f4 g2 = ld4(G + (((size_t)g * N + b) * N + yy) * (size_t)(kK * C) + 2 * C + fc);
+            const f4 g2 = ld4(G + (rowbase + (size_t)b * N + yy) * (size_t)(kK * C) + 2 * C + fc);
             f4 x = tot * g0 + tr * g6 + wx + u4 + u5 + m[0];
             f4 z1 = wz + u15;
             if (yy == b) {
@@ -665,10 +706,10 @@ __global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restr
         coff[i] = cc * C + fld;
         rc[i] = L.r[cc];
         yv[i] = ld4(sY + cc * CW + 4 * fl);
-        g9[i] = ld4(G + (((size_t)g * N + b) * N + cc) * (size_t)(kK * C) + 9 * C + fld);
+        g9[i] = ld4(G + (rowbase + (size_t)b * N + cc) * (size_t)(kK * C) + 9 * C + fld);
     }
     const int ib = b / PPW, cgb = b % PPW;
-    float *dPg = dP + (size_t)g * N * N * N * C + (size_t)b * N * C;
+    float *dPg = dP + pbase * C + (size_t)b * N * C;
     const size_t rowStride = (size_t)N * N * C;
     for (int a = wave; a < N; a += kWaves) {
         float *row = dPg + a * rowStride;
@@ -924,63 +965,65 @@ gf_status set_lds(gf_ctx *ctx, Kern kern, size_t bytes, size_t *granted) {
     return GF_OK;
 }
 
+// One launch set = `blocks` (node/graph, index) pairs x nwin channel windows; R says where each pair lives.
+// smax = largest N among them (sizes the LDS); `uniform_full` enables the unmasked fast variant.
 template <int LPC, int NI, bool FULL>
 gf_status launch_fwd_slab(gf_ctx *ctx, const float *P, const float *A, float *Out, float *wsSab, float *wsDbb,
-                          float *wsScal, int N, int C, unsigned grid, int nwin) {
-    const size_t l1 = fwd_slab_lds_bytes<LPC, NI>(N);
+                          float *wsScal, const Ragged &R, int smax, int C, unsigned grid, int nwin) {
+    const size_t l1 = fwd_slab_lds_bytes<LPC, NI>(smax);
     static size_t g1 = 0;
     gf_status st = set_lds(ctx, r18_fwd_slab<LPC, NI, FULL>, l1, &g1);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "r18_fwd_slab", (r18_fwd_slab<LPC, NI, FULL>), dim3(grid), dim3(kThreads), l1, P, A, Out, wsSab,
-                       wsDbb, wsScal, N, C, nwin);
+                       wsDbb, wsScal, R, C, nwin);
     return GF_OK;
 }
 
 template <int LPC, int NI>
 gf_status launch_fwd(gf_ctx *ctx, const float *P, const float *A, float *Out, float *wsSab, float *wsDbb, float *wsScal,
-                     int N, int C, int batch, int nwin) {
-    const unsigned grid = (unsigned)((size_t)batch * N * nwin);
-    const size_t l2 = fwd_rows_lds_bytes<LPC>(N);
+                     Ragged R, long long blocks, int smax, int C, int nwin) {
+    const unsigned grid = (unsigned)((size_t)blocks * nwin);
+    const size_t l2 = fwd_rows_lds_bytes<LPC>(smax);
     static size_t g2 = 0;
-    const bool full = (N == NI * (64 / LPC)) && (C % (4 * LPC) == 0);
-    gf_status st = full ? launch_fwd_slab<LPC, NI, true>(ctx, P, A, Out, wsSab, wsDbb, wsScal, N, C, grid, nwin)
-                        : launch_fwd_slab<LPC, NI, false>(ctx, P, A, Out, wsSab, wsDbb, wsScal, N, C, grid, nwin);
+    const bool full = !R.pair_node && (smax == NI * (64 / LPC)) && (C % (4 * LPC) == 0);
+    gf_status st = full ? launch_fwd_slab<LPC, NI, true>(ctx, P, A, Out, wsSab, wsDbb, wsScal, R, smax, C, grid, nwin)
+                        : launch_fwd_slab<LPC, NI, false>(ctx, P, A, Out, wsSab, wsDbb, wsScal, R, smax, C, grid, nwin);
     if (st != GF_OK) return st;
     st = set_lds(ctx, r18_fwd_rows<LPC>, l2, &g2);
     if (st != GF_OK) return st;
-    GF_LAUNCH(ctx, "r18_fwd_rows", (r18_fwd_rows<LPC>), dim3(grid), dim3(kThreads), l2, A, Out, wsSab, wsDbb, wsScal, N,
+    GF_LAUNCH(ctx, "r18_fwd_rows", (r18_fwd_rows<LPC>), dim3(grid), dim3(kThreads), l2, A, Out, wsSab, wsDbb, wsScal, R,
                        C, nwin);
     return GF_OK;
 }
 
 template <int LPC, int NI, bool FULL, bool ACC>
 gf_status launch_bwd_slab(gf_ctx *ctx, const float *G, const float *A, float *dP, float *wsWX, float *wsWZ,
-                          float *wsPart, int N, int C, unsigned grid, int nwin) {
-    const size_t l2 = bwd_slab_lds_bytes<LPC>(N);
+                          float *wsPart, const Ragged &R, int smax, int C, unsigned grid, int nwin) {
+    const size_t l2 = bwd_slab_lds_bytes<LPC>(smax);
     static size_t g2 = 0;
     gf_status st = set_lds(ctx, r18_bwd_slab<LPC, NI, FULL, ACC>, l2, &g2);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "r18_bwd_slab", (r18_bwd_slab<LPC, NI, FULL, ACC>), dim3(grid), dim3(kThreads), l2, G, A, dP, wsWX,
-                       wsWZ, wsPart, N, C, nwin);
+                       wsWZ, wsPart, R, C, nwin);
     return GF_OK;
 }
 
 template <int LPC, int NI>
 gf_status launch_bwd(gf_ctx *ctx, const float *G, const float *A, float *dP, float *wsWX, float *wsWZ, float *wsPart,
-                     int N, int C, int batch, int nwin, int accumulate) {
-    const unsigned grid = (unsigned)((size_t)batch * N * nwin);
-    const size_t l1 = bwd_rows_lds_bytes<LPC>(N);
+                     Ragged R, long long blocks, int smax, int C, int nwin, int accumulate) {
+    const unsigned grid = (unsigned)((size_t)blocks * nwin);
+    const size_t l1 = bwd_rows_lds_bytes<LPC>(smax);
     static size_t g1 = 0;
     gf_status st = set_lds(ctx, r18_bwd_rows<LPC>, l1, &g1);
     if (st != GF_OK) return st;
-    GF_LAUNCH(ctx, "r18_bwd_rows", (r18_bwd_rows<LPC>), dim3(grid), dim3(kThreads), l1, G, A, wsWX, wsWZ, wsPart, N, C,
+    GF_LAUNCH(ctx, "r18_bwd_rows", (r18_bwd_rows<LPC>), dim3(grid), dim3(kThreads), l1, G, A, wsWX, wsWZ, wsPart, R, C,
                        nwin);
-    const bool full = (N == NI * (64 / LPC)) && (C % (4 * LPC) == 0);
+    const bool full = !R.pair_node && (smax == NI * (64 / LPC)) && (C % (4 * LPC) == 0);
     if (full)
-        return accumulate ? launch_bwd_slab<LPC, NI, true, true>(ctx, G, A, dP, wsWX, wsWZ, wsPart, N, C, grid, nwin)
-                          : launch_bwd_slab<LPC, NI, true, false>(ctx, G, A, dP, wsWX, wsWZ, wsPart, N, C, grid, nwin);
-    return accumulate ? launch_bwd_slab<LPC, NI, false, true>(ctx, G, A, dP, wsWX, wsWZ, wsPart, N, C, grid, nwin)
-                      : launch_bwd_slab<LPC, NI, false, false>(ctx, G, A, dP, wsWX, wsWZ, wsPart, N, C, grid, nwin);
+        return accumulate ? launch_bwd_slab<LPC, NI, true, true>(ctx, G, A, dP, wsWX, wsWZ, wsPart, R, smax, C, grid, nwin)
+                          : launch_bwd_slab<LPC, NI, true, false>(ctx, G, A, dP, wsWX, wsWZ, wsPart, R, smax, C, grid, nwin);
+    return accumulate ? launch_bwd_slab<LPC, NI, false, true>(ctx, G, A, dP, wsWX, wsWZ, wsPart, R, smax, C, grid, nwin)
+                      : launch_bwd_slab<LPC, NI, false, false>(ctx, G, A, dP, wsWX, wsWZ, wsPart, R, smax, C, grid, nwin);
 }
 
 #define GF_DISPATCH_NI(FN, LPC, ...)                     \
@@ -996,6 +1039,11 @@ gf_status launch_bwd(gf_ctx *ctx, const float *G, const float *A, float *dP, flo
         case 8: GF_DISPATCH_NI(FN, 8, __VA_ARGS__)                     \
         default: GF_DISPATCH_NI(FN, 16, __VA_ARGS__)                   \
     }
+
+Ragged uniform_batch(int N) {
+    Ragged R = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, N};
+    return R;
+}
 
 unsigned gen_grid(size_t total) {
     size_t blocks = (total + 255) / 256;
@@ -1024,7 +1072,7 @@ gf_status r18_forward(gf_ctx *ctx, const float *P, const float *A, float *Out, i
     if (!g_force_generic && fast_shape(N, C, P, Out, nullptr, &fs)) {
         const size_t nnc = (size_t)batch * N * N * C;
         float *wsSab = ws, *wsDbb = ws + nnc, *wsScal = ws + 2 * nnc;
-        GF_DISPATCH(launch_fwd, ctx, P, A, Out, wsSab, wsDbb, wsScal, N, C, batch, fs.nwin)
+        GF_DISPATCH(launch_fwd, ctx, P, A, Out, wsSab, wsDbb, wsScal, uniform_batch(N), (long long)batch * N, N, C, fs.nwin)
     }
     float *Ap = ws;
     float *r = Ap + (size_t)batch * N * N;
@@ -1046,7 +1094,7 @@ gf_status r18_backward(gf_ctx *ctx, const float *G, const float *A, float *dP, i
     if (!g_force_generic && fast_shape(N, C, G, dP, nullptr, &fs)) {
         const size_t nnc = (size_t)batch * N * N * C;
         float *wsWX = ws, *wsWZ = ws + nnc, *wsPart = ws + 2 * nnc;
-        GF_DISPATCH(launch_bwd, ctx, G, A, dP, wsWX, wsWZ, wsPart, N, C, batch, fs.nwin, accumulate)
+        GF_DISPATCH(launch_bwd, ctx, G, A, dP, wsWX, wsWZ, wsPart, uniform_batch(N), (long long)batch * N, N, C, fs.nwin, accumulate)
     }
     float *Ap = ws;
     float *r = Ap + (size_t)batch * N * N;
@@ -1062,5 +1110,48 @@ gf_status r18_backward(gf_ctx *ctx, const float *G, const float *A, float *dP, i
 }
 
 void r18_force_generic(int on) { g_force_generic = on; }
+
+// ---- ragged batches (SMP driver): nodes of different sizes in one launch ------------------------------------------
+// Pairs [pair_lo, pair_hi) are (node, index) workgroups; all their nodes have size <= smax <= 8 * 64/LPC.
+// Workspace: two [total_rows][C] tables + [total_pairs][4][C] partial scalars, addressed with the node offsets.
+bool r18_ragged_supported(int smax, int C, const void *p0, const void *p1) {
+    FastShape fs;
+    return fast_shape(smax, C, p0, p1, nullptr, &fs);
+}
+
+size_t r18_ragged_workspace_bytes(long long total_rows, long long total_pairs, int C) {
+    return sizeof(float) * (2 * (size_t)total_rows * C + 4 * (size_t)total_pairs * C) + 256;
+}
+
+static Ragged ragged_of(const gf_ragged_nodes &t, long long pair_lo, int smax) {
+    Ragged R = {t.pair_node, t.node_s, t.node_p, t.node_row, t.node_pair, pair_lo, smax};
+    return R;
+}
+
+gf_status r18_forward_ragged(gf_ctx *ctx, const float *P, const float *A, float *Out, const gf_ragged_nodes &t,
+                             long long pair_lo, long long pair_hi, int smax, int C) {
+    if (pair_hi <= pair_lo) return GF_OK;
+    gf_status st = ensure_ws(ctx, r18_ragged_workspace_bytes(t.total_rows, t.total_pairs, C));
+    if (st != GF_OK) return st;
+    FastShape fs;
+    if (!fast_shape(smax, C, P, Out, nullptr, &fs)) return fail(ctx, GF_ERR_UNSUPPORTED, "ragged r18: shape outside the slab kernels (smax=%d C=%d)", smax, C);
+    float *ws = static_cast<float *>(ctx->ws);
+    const size_t nnc = (size_t)t.total_rows * C;
+    float *wsSab = ws, *wsDbb = ws + nnc, *wsScal = ws + 2 * nnc;
+    GF_DISPATCH(launch_fwd, ctx, P, A, Out, wsSab, wsDbb, wsScal, ragged_of(t, pair_lo, smax), pair_hi - pair_lo, smax, C, fs.nwin)
+}
+
+gf_status r18_backward_ragged(gf_ctx *ctx, const float *G, const float *A, float *dP, const gf_ragged_nodes &t,
+                              long long pair_lo, long long pair_hi, int smax, int C, int accumulate) {
+    if (pair_hi <= pair_lo) return GF_OK;
+    gf_status st = ensure_ws(ctx, r18_ragged_workspace_bytes(t.total_rows, t.total_pairs, C));
+    if (st != GF_OK) return st;
+    FastShape fs;
+    if (!fast_shape(smax, C, G, dP, nullptr, &fs)) return fail(ctx, GF_ERR_UNSUPPORTED, "ragged r18: shape outside the slab kernels (smax=%d C=%d)", smax, C);
+    float *ws = static_cast<float *>(ctx->ws);
+    const size_t nnc = (size_t)t.total_rows * C;
+    float *wsWX = ws, *wsWZ = ws + nnc, *wsPart = ws + 2 * nnc;
+    GF_DISPATCH(launch_bwd, ctx, G, A, dP, wsWX, wsWZ, wsPart, ragged_of(t, pair_lo, smax), pair_hi - pair_lo, smax, C, fs.nwin, accumulate)
+}
 
 }  // namespace gf

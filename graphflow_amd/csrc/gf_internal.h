@@ -86,6 +86,19 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 gf_status r18_forward(gf_ctx *ctx, const float *P, const float *A, float *Out, int N, int C, int batch);
 gf_status r18_backward(gf_ctx *ctx, const float *G, const float *A, float *dP, int N, int C, int batch, int accumulate);
 size_t r18_workspace_bytes(int N, int C, int batch);
+// ragged batches: device-resident node tables (see contract18.hip "Ragged")
+struct gf_ragged_nodes {
+    const int *pair_node;
+    const int *node_s;
+    const long long *node_p, *node_row, *node_pair;
+    long long total_rows, total_pairs;
+};
+bool r18_ragged_supported(int smax, int C, const void *p0, const void *p1);
+size_t r18_ragged_workspace_bytes(long long total_rows, long long total_pairs, int C);
+gf_status r18_forward_ragged(gf_ctx *ctx, const float *P, const float *A, float *Out, const gf_ragged_nodes &t,
+                             long long pair_lo, long long pair_hi, int smax, int C);
+gf_status r18_backward_ragged(gf_ctx *ctx, const float *G, const float *A, float *dP, const gf_ragged_nodes &t,
+                              long long pair_lo, long long pair_hi, int smax, int C, int accumulate);
 // r4 / r10 / r50: table kernels (contract_families.hip)
 gf_status family_forward(gf_ctx *ctx, int K, const float *P, const float *A, float *Out, int N, int C, int batch);
 gf_status family_backward(gf_ctx *ctx, int K, const float *G, const float *A, float *dP, int N, int C, int batch,

@@ -15,9 +15,11 @@
 namespace gf {
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int BM = 128, BN = 64, BK = 32;
 constexpr int kThreads = 256;
+constexpr int LDS_ROW = BK + 4;  // 36 floats = 144 B: 16-byte aligned rows, conflict-free ds_read_b128 across 16 rows
 using f16v = __attribute__((ext_vector_type(16))) float;
+using f4v = __attribute__((ext_vector_type(4))) float;
 
 struct GemmArgs {
     const float *A, *B;
@@ -31,17 +33,23 @@ struct GemmArgs {
     int accumulate;        // C += result (only when not splitting)
 };
 
+// Position of k inside an LDS row: even k first, then odd k.  The f32 MFMA 32x32x2 gives lane (i, h = lane >> 5) the
+// operand element k = 2 j + h at step j, so with this order each lane's 16 operands of a BK = 32 tile are contiguous
+// (four ds_read_b128 instead of sixteen ds_read_b32).
+__device__ __forceinline__ int kpos(int k) { return (k & 1) * (BK / 2) + (k >> 1); }
+
 // element (m,k) of op(A): TA ? A[k*lda + m] : A[m*lda + k];   element (k,n) of op(B): TB ? B[n*ldb + k] : B[k*ldb + n]
-// VEC: every operand is 16-byte aligned with leading dimensions and extents that are multiples of 4, so global
-// traffic moves as float4 along each operand's contiguous direction and the C tile leaves through LDS as float4 rows.
+// LDS images: As[m][kpos(k)] (128 x 36) and Bs[n][kpos(k)] (64 x 36).  2 x 2 waves; wave (wm, wn) owns rows
+// [64 wm, 64 wm + 64) x cols [32 wn, 32 wn + 32) as two independent 32 x 32 accumulators, so each k-step issues two
+// MFMAs that share one B fragment and hide each other's 64-cycle dependent latency.
+// VEC: every operand is 16-byte aligned with leading dimensions and extents that are multiples of 4: global traffic
+// moves as float4 along each operand's contiguous direction and the C tile leaves through LDS as float4 rows.
 template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
-    constexpr int LDA_S = BK + 1, LDB_S = BN + 1, LDC_S = BN + 4;
-    constexpr int kSmem = (BM * LDC_S > BM * LDA_S + BK * LDB_S) ? BM * LDC_S : BM * LDA_S + BK * LDB_S;
-    __shared__ __attribute__((aligned(16))) float smem[kSmem];
-    float *As = smem, *Bs = smem + BM * LDA_S, *Cs = smem;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
+    float *As = smem, *Bs = smem + BM * LDS_ROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
     // tile order: the N tile varies fastest, so the workgroups that share one A row-panel run back to back and the
     // panel is read from HBM once (dQ = dZ K^T has 18 N tiles per panel); M tiles can be millions (M = sum s^2)
     const int ntn = g.ntiles_n;
@@ -51,91 +59,126 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
     const int kbeg = split * g.kchunk;
     const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
 
-    constexpr int NLD = VEC ? 2 : 8;
-    float4 va[VEC ? 2 : 1], vb[VEC ? 2 : 1];
-    float ra[VEC ? 1 : 8], rb[VEC ? 1 : 8];
+    constexpr int NA = VEC ? 4 : 16, NB = VEC ? 2 : 8;  // loads per thread per tile
+    f4v va[VEC ? NA : 1], vb[VEC ? NB : 1];
+    float ra[VEC ? 1 : NA], rb[VEC ? 1 : NB];
+    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+
     auto load_tiles = [&](int k0) {
+        if (VEC) {
 #pragma unroll
-        for (int e = 0; e < NLD; ++e) {
-            const int idx = tid + e * kThreads;
-            if (VEC) {
+            for (int e = 0; e < NA; ++e) {
+                const int idx = tid + e * kThreads;
                 int m, k;
                 if (TA) { m = (idx % (BM / 4)) * 4; k = idx / (BM / 4); } else { k = (idx % (BK / 4)) * 4; m = idx / (BK / 4); }
                 const int gm = m0 + m, gk = k0 + k;
-                const bool ok = gm < g.M && gk < kend;
                 const size_t off = TA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk;
-                va[e] = ok ? *reinterpret_cast<const float4 *>(A + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-                int kk, n;
-                if (TB) { kk = (idx % (BK / 4)) * 4; n = idx / (BK / 4); } else { n = (idx % (BN / 4)) * 4; kk = idx / (BN / 4); }
-                const int gn = n0 + n, gk2 = k0 + kk;
-                const bool ok2 = gn < g.N && gk2 < kend;
-                const size_t off2 = TB ? (size_t)gn * g.ldb + gk2 : (size_t)gk2 * g.ldb + gn;
-                vb[e] = ok2 ? *reinterpret_cast<const float4 *>(B + off2) : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
+                va[e] = (gm < g.M && gk < kend) ? *reinterpret_cast<const f4v *>(A + off) : zero4;
+            }
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int idx = tid + e * kThreads;
+                int k, n;
+                if (TB) { k = (idx % (BK / 4)) * 4; n = idx / (BK / 4); } else { n = (idx % (BN / 4)) * 4; k = idx / (BN / 4); }
+                const int gn = n0 + n, gk = k0 + k;
+                const size_t off = TB ? (size_t)gn * g.ldb + gk : (size_t)gk * g.ldb + gn;
+                vb[e] = (gn < g.N && gk < kend) ? *reinterpret_cast<const f4v *>(B + off) : zero4;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NA; ++e) {
+                const int idx = tid + e * kThreads;
                 int m, k;
                 if (TA) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
                 const int gm = m0 + m, gk = k0 + k;
                 const size_t off = TA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk;
                 ra[e] = (gm < g.M && gk < kend) ? A[off] : 0.f;
-                int kk, n;
-                if (TB) { kk = idx % BK; n = idx / BK; } else { n = idx % BN; kk = idx / BN; }
-                const int gn = n0 + n, gk2 = k0 + kk;
-                const size_t off2 = TB ? (size_t)gn * g.ldb + gk2 : (size_t)gk2 * g.ldb + gn;
-                rb[e] = (gn < g.N && gk2 < kend) ? B[off2] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int idx = tid + e * kThreads;
+                int k, n;
+                if (TB) { k = idx % BK; n = idx / BK; } else { n = idx % BN; k = idx / BN; }
+                const int gn = n0 + n, gk = k0 + k;
+                const size_t off = TB ? (size_t)gn * g.ldb + gk : (size_t)gk * g.ldb + gn;
+                rb[e] = (gn < g.N && gk < kend) ? B[off] : 0.f;
             }
         }
     };
     auto store_tiles = [&]() {
+        if (VEC) {
 #pragma unroll
-        for (int e = 0; e < NLD; ++e) {
-            const int idx = tid + e * kThreads;
-            if (VEC) {
-                const float a4[4] = {va[e].x, va[e].y, va[e].z, va[e].w}, b4[4] = {vb[e].x, vb[e].y, vb[e].z, vb[e].w};
-                if (TA) {
-                    const int m = (idx % (BM / 4)) * 4, k = idx / (BM / 4);
+            for (int e = 0; e < NA; ++e) {
+                const int idx = tid + e * kThreads;
+                if (TA) {  // four consecutive m at one k
+                    const int m = (idx % (BM / 4)) * 4, kp = kpos(idx / (BM / 4));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) As[(m + j) * LDA_S + k] = a4[j];
-                } else {
+                    for (int j = 0; j < 4; ++j) As[(m + j) * LDS_ROW + kp] = va[e][j];
+                } else {   // four consecutive k of one row: even pair and odd pair are each contiguous
                     const int k = (idx % (BK / 4)) * 4, m = idx / (BK / 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) As[m * LDA_S + k + j] = a4[j];
+                    float2 ev = make_float2(va[e][0], va[e][2]), od = make_float2(va[e][1], va[e][3]);
+                    *reinterpret_cast<float2 *>(As + m * LDS_ROW + (k >> 1)) = ev;
+                    *reinterpret_cast<float2 *>(As + m * LDS_ROW + BK / 2 + (k >> 1)) = od;
                 }
+            }
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int idx = tid + e * kThreads;
                 if (TB) {
                     const int k = (idx % (BK / 4)) * 4, n = idx / (BK / 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Bs[(k + j) * LDB_S + n] = b4[j];
+                    float2 ev = make_float2(vb[e][0], vb[e][2]), od = make_float2(vb[e][1], vb[e][3]);
+                    *reinterpret_cast<float2 *>(Bs + n * LDS_ROW + (k >> 1)) = ev;
+                    *reinterpret_cast<float2 *>(Bs + n * LDS_ROW + BK / 2 + (k >> 1)) = od;
                 } else {
-                    const int n = (idx % (BN / 4)) * 4, k = idx / (BN / 4);
+                    const int n = (idx % (BN / 4)) * 4, kp = kpos(idx / (BN / 4));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) Bs[k * LDB_S + n + j] = b4[j];
+                    for (int j = 0; j < 4; ++j) Bs[(n + j) * LDS_ROW + kp] = vb[e][j];
                 }
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NA; ++e) {
+                const int idx = tid + e * kThreads;
                 int m, k;
                 if (TA) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
-                As[m * LDA_S + k] = ra[e];
-                int kk, n;
-                if (TB) { kk = idx % BK; n = idx / BK; } else { n = idx % BN; kk = idx / BN; }
-                Bs[kk * LDB_S + n] = rb[e];
+                As[m * LDS_ROW + kpos(k)] = ra[e];
+            }
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int idx = tid + e * kThreads;
+                int k, n;
+                if (TB) { k = idx % BK; n = idx / BK; } else { n = idx % BN; k = idx / BN; }
+                Bs[n * LDS_ROW + kpos(k)] = rb[e];
             }
         }
     };
 
-    f16v acc;
+    f16v acc0, acc1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
 
     if (kbeg < kend) {
         load_tiles(kbeg);
         store_tiles();
         __syncthreads();
+        const float *a0p = As + (wm * 64 + li) * LDS_ROW + lh * (BK / 2);
+        const float *a1p = a0p + 32 * LDS_ROW;
+        const float *bp = Bs + (wn * 32 + li) * LDS_ROW + lh * (BK / 2);
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             const bool more = k0 + BK < kend;
             if (more) load_tiles(k0 + BK);
-            const float *ap = As + (wm * 32 + (lane & 31)) * LDA_S + (lane >> 5);
-            const float *bp = Bs + (lane >> 5) * LDB_S + wn * 32 + (lane & 31);
+            f4v fa0[4], fa1[4], fb[4];
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * LDB_S], acc, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                fa0[q] = *reinterpret_cast<const f4v *>(a0p + 4 * q);
+                fa1[q] = *reinterpret_cast<const f4v *>(a1p + 4 * q);
+                fb[q] = *reinterpret_cast<const f4v *>(bp + 4 * q);
+            }
+#pragma unroll
+            for (int j = 0; j < BK / 2; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j >> 2][j & 3], fb[j >> 2][j & 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j >> 2][j & 3], fb[j >> 2][j & 3], acc1, 0, 0, 0);
+            }
             __syncthreads();
             if (more) {
                 store_tiles();
@@ -148,39 +191,47 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
     const int splits = gridDim.z / g.batch;
     float *C = g.C + (splits > 1 ? (size_t)split * g.M * g.ldc : (size_t)0) + bz * g.sC;
     if (VEC) {
-        // stage the 64x64 tile in LDS (the operand tiles are dead: the k-loop ended on a barrier), then 16 B row stores
+        // stage 64 rows at a time in LDS (operand tiles are dead: the k-loop ended on a barrier), then 16 B row stores
+        constexpr int LDC_S = BN + 4;
+        float *Cs = smem;  // 64 x 68 floats <= (128 + 64) x 36
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            Cs[row * LDC_S + wn * 32 + (lane & 31)] = acc[r];
-        }
-        __syncthreads();
-        const int c4 = (tid % (BN / 4)) * 4, r0 = tid / (BN / 4);
+        for (int half = 0; half < 2; ++half) {
+            if (wm == half) {
 #pragma unroll
-        for (int p = 0; p < BM / (kThreads / (BN / 4)); ++p) {
-            const int row = r0 + p * (kThreads / (BN / 4));
-            if (m0 + row < g.M && n0 + c4 < g.N) {
-                float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC_S + c4);
-                float4 *dst = reinterpret_cast<float4 *>(C + (size_t)(m0 + row) * g.ldc + n0 + c4);
-                if (g.accumulate) {
-                    const float4 o = *dst;
-                    v.x += o.x;
-                    v.y += o.y;
-                    v.z += o.z;
-                    v.w += o.w;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    Cs[row * LDC_S + wn * 32 + li] = acc0[r];
+                    Cs[(32 + row) * LDC_S + wn * 32 + li] = acc1[r];
                 }
-                *dst = v;
             }
+            __syncthreads();
+            const int c4 = (tid % (BN / 4)) * 4, r0 = tid / (BN / 4);
+#pragma unroll
+            for (int p = 0; p < 64 / (kThreads / (BN / 4)); ++p) {
+                const int row = r0 + p * (kThreads / (BN / 4));
+                const int gm = m0 + half * 64 + row;
+                if (gm < g.M && n0 + c4 < g.N) {
+                    f4v v = *reinterpret_cast<const f4v *>(Cs + row * LDC_S + c4);
+                    f4v *dst = reinterpret_cast<f4v *>(C + (size_t)gm * g.ldc + n0 + c4);
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+            __syncthreads();
         }
     } else {
-        const int col = n0 + wn * 32 + (lane & 31);
+        const int col = n0 + wn * 32 + li;
         if (col < g.N) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = m0 + wm * 64 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < g.M) {
                     float *c = C + (size_t)row * g.ldc + col;
-                    *c = g.accumulate ? *c + acc[r] : acc[r];
+                    *c = g.accumulate ? *c + acc0[r] : acc0[r];
+                }
+                if (row + 32 < g.M) {
+                    float *c = C + (size_t)(row + 32) * g.ldc + col;
+                    *c = g.accumulate ? *c + acc1[r] : acc1[r];
                 }
             }
         }

@@ -333,6 +333,41 @@ void view_params(const gfsmp::Config &c, P *base, P **H, std::vector<P *> *K, st
     *W = p;
 }
 
+// RisiContraction_18 over every node of level l.  Nodes are sorted by receptive-field size, so consecutive buckets are
+// merged into at most four launches (size classes s <= PPW, 2 PPW, 4 PPW, 8 PPW of the slab kernels) through the ragged
+// entry points; anything larger falls back to one uniform launch per bucket.
+gf_status smp_contract(gf_smp *s, int l, bool backward) {
+    gf_ctx *ctx = s->ctx;
+    const gfsmp::LevelLayout &h = s->lay.level[l];
+    const gf_smp::DevLevel &d = s->lv[l];
+    const int C = s->cfg.nChanels;
+    const int ppw = (C <= 16) ? 16 : (C <= 32) ? 8 : 4;
+    const gf_ragged_nodes t = {d.pair_node, d.node_s, d.node_p, d.node_row, d.node_pair, (long long)h.rows, (long long)h.pairs};
+    const bool ragged_ok = r18_ragged_supported(ppw, C, s->P, d.Q);
+    size_t k = 0;
+    gf_status st = GF_OK;
+    for (int cls = 1; cls <= 8 && ragged_ok && k < h.buckets.size(); cls *= 2) {
+        const int smax_cls = cls * ppw;
+        const size_t k0 = k;
+        int smax = 0;
+        while (k < h.buckets.size() && h.buckets[k].s <= smax_cls) smax = h.buckets[k++].s;
+        if (k == k0) continue;
+        const long long lo = h.node_pair[h.buckets[k0].first_node];
+        const long long hi = (k < h.buckets.size()) ? h.node_pair[h.buckets[k].first_node] : (long long)h.pairs;
+        st = backward ? r18_backward_ragged(ctx, d.Q, d.adj, s->P, t, lo, hi, smax, C, 0)
+                      : r18_forward_ragged(ctx, s->P, d.adj, d.Q, t, lo, hi, smax, C);
+        if (st != GF_OK) return st;
+    }
+    for (; k < h.buckets.size(); ++k) {  // sizes beyond the slab kernels (or unaligned C): uniform launches
+        const gfsmp::Bucket &bk = h.buckets[k];
+        float *Pb = s->P + bk.first_p * C, *Qb = d.Q + bk.first_row * (long long)(kK * C);
+        st = backward ? gf_contract_backward_f32(ctx, 18, Qb, d.adj + bk.first_row, Pb, bk.s, C, bk.count, 0)
+                      : gf_contract_forward_f32(ctx, 18, Pb, d.adj + bk.first_row, Qb, bk.s, C, bk.count);
+        if (st != GF_OK) return st;
+    }
+    return GF_OK;
+}
+
 }  // namespace
 }  // namespace gf
 
@@ -421,6 +456,7 @@ gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *a
             const size_t w = gf_contract_workspace_bytes(18, h.buckets[b].s, C, h.buckets[b].count);
             if (w > contract_ws) contract_ws = w;
         }
+        contract_ws = std::max(contract_ws, gf::r18_ragged_workspace_bytes((long long)h.rows, (long long)h.pairs, C));
     }
     UP(s->x, B.x);
     st = gf::upload(s, &s->P, nullptr, (size_t)maxp * C);
@@ -480,12 +516,8 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
         const gf_smp::DevLevel &d = s->lv[l];
         GF_LAUNCH(ctx, "smp_promote_fwd", gf::promote_forward, dim3((unsigned)h.pairs), dim3(256), 0, s->lv[l - 1].f, s->P,
                   d.node_s, d.node_row, d.node_p, d.node_pair, d.pair_node, d.pair_src_row, d.pair_src_s, d.pi, C);
-        for (size_t k = 0; k < h.buckets.size(); ++k) {
-            const gfsmp::Bucket &bk = h.buckets[k];
-            st = gf_contract_forward_f32(ctx, 18, s->P + bk.first_p * C, d.adj + bk.first_row,
-                                         d.Q + bk.first_row * (long long)(gf::kK * C), bk.s, C, bk.count);
-            if (st != GF_OK) return st;
-        }
+        st = gf::smp_contract(s, l, /*backward=*/false);
+        if (st != GF_OK) return st;
         // K-projection over all buckets at once: [rows, 18C] x [18C, C]
         st = gf::gemm(ctx, false, false, (int)h.rows, C, gf::kK * C, d.Q, gf::kK * C, 0, K[l], C, 0, d.f, C, 0, 1, 0);
         if (st != GF_OK) return st;
@@ -539,12 +571,8 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
         if (st != GF_OK) return st;
         st = gf::gemm(ctx, false, true, (int)h.rows, gf::kK * C, C, d.df, C, 0, K[l], C, 0, d.Q, gf::kK * C, 0, 1, 0);
         if (st != GF_OK) return st;
-        for (size_t k = 0; k < h.buckets.size(); ++k) {
-            const gfsmp::Bucket &bk = h.buckets[k];
-            st = gf_contract_backward_f32(ctx, 18, d.Q + bk.first_row * (long long)(gf::kK * C), d.adj + bk.first_row,
-                                          s->P + bk.first_p * C, bk.s, C, bk.count, /*accumulate=*/0);
-            if (st != GF_OK) return st;
-        }
+        st = gf::smp_contract(s, l, /*backward=*/true);
+        if (st != GF_OK) return st;
         const gf_smp::DevLevel &pv = s->lv[l - 1];
         GF_LAUNCH(ctx, "smp_promote_bwd", gf::promote_backward, dim3(B.level[l - 1].nNodes), dim3(256), 0, s->P, pv.df,
                   pv.node_s, pv.node_row, d.cons_ptr, d.cons_slab, d.cons_s, d.cons_inv_off, d.inv, C);
