@@ -60,8 +60,15 @@ def run_cfg2(args, torch, gf, dev, world, rank):
         bwd_ms = sum(v for k, v in per.items() if "bwd" in k)
         call_ms, call_b, which = (fwd_ms, fwd_b, "forward") if "fwd" in dom else (bwd_ms, bwd_b, "backward")
         ach = call_b * B / (call_ms * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch of the dominant kernel from the committed PMC passes (same shape only)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_cfg2_hbm_bytes.json")
+        if (B, N, C) == (256, 32, 64) and os.path.exists(pmc):
+            with open(pmc) as fh:
+                t = json.load(fh).get(dom)
+            if t:
+                traffic = round(t["fetch"] + t["write"])
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": dom,
                 "kernel_ms": {k: round(v, 4) for k, v in per.items()},
                 "note": "achieved = algorithmic bytes of one %s call over the batch / (its slab+rows kernel time)" % which,
                 "step_GBps": round((fwd_b + bwd_b) * B / (ms_per_step * 1e-3) / 1e9, 1)}
