@@ -116,41 +116,61 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
         net.backward(params, grads)
         gd.allreduce_sum_(grads, dist)   # the one exchange of the path (SMP_omega.h:784-786)
 
-    # algorithmic work per step: per level l>=1, with R = sum s^2, S = sum s^3
-    fwd_bytes = bwd_bytes = 0
-    gemm_flops = 0
-    contract_bytes = 0
+    # algorithmic work per step and per kernel: per level l >= 1 with R = sum s^2 (rows), S = sum s^3
+    # (positions), Rp = rows of the level below; bytes are fp32 HBM bytes that MUST move, flops are MFMA flops.
+    fused = not args.unfused
+    net.set_fused(fused)
+    kb = {}   # kernel name -> algorithmic bytes per step
+    kf = {}   # kernel name -> flops per step
+
+    def add(d, k, v):
+        d[k] = d.get(k, 0) + v
+
     for l in range(1, L + 1):
         _, R, S = sizes[l]
-        contract = 4 * (S * C + R + 18 * R * C)                 # read P + A, write Q
-        promote = 4 * (2 * S * C)                               # gather read (upper bound) + write P
-        kproj = 4 * (18 * R * C + 18 * C * C + R * C)           # read Q, K; write f
-        act = 4 * (2 * R * C)
-        fwd_bytes += contract + promote + kproj + act
-        bwd_bytes += contract + promote + 2 * kproj + act
-        contract_bytes += contract
-        gemm_flops += 2 * R * 18 * C * C
-    work = {"levels": [{"nodes": n, "rows_sum_s2": r, "ppos_sum_s3": s} for (n, r, s) in sizes]}
+        _, Rp, _ = sizes[l - 1]
+        unit = 2 * R * C * C                                     # one C x C block product over all rows
+        if fused:
+            add(kb, "smpf_tables_fwd", 4 * (Rp * C + 6 * R * C))        # gather f_{l-1} (cached), write 6 tables
+            add(kb, "smpf_combine_fwd", 4 * (5 * R * C + R * C))
+            add(kb, "smpf_combine_bwd", 4 * (2 * R * C + 5 * R * C))
+            add(kb, "smpf_tables_bwd", 4 * (6 * R * C + S * C))
+            add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
+            for k in ("gemm_nn", "gemm_nt", "gemm_tn"):
+                add(kf, k, 10 * unit)
+                add(kb, k, 4 * (10 * R * C + 5 * R * C))
+        else:
+            add(kb, "smp_promote_fwd", 4 * (Rp * C + S * C))
+            add(kb, "r18_fwd_slab", 4 * (S * C + 10 * R * C))
+            add(kb, "r18_fwd_rows", 4 * (8 * R * C))
+            add(kb, "r18_bwd_rows", 4 * (8 * R * C))
+            add(kb, "r18_bwd_slab", 4 * (10 * R * C + S * C))
+            add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
+            for k in ("gemm_nn", "gemm_nt", "gemm_tn"):
+                add(kf, k, 18 * unit)
+                add(kb, k, 4 * (18 * R * C + R * C))
+    step_bytes = sum(kb.values())
+    step_flops = sum(kf.values())
+    work = {"levels": [{"nodes": n, "rows_sum_s2": r, "ppos_sum_s3": s} for (n, r, s) in sizes],
+            "algorithmic_GB_per_step": round(step_bytes / 1e9, 2), "gemm_GFLOP_per_step": round(step_flops / 1e9, 1)}
 
     def finish(timers, ms_per_step):
         tot = {k: v[0] / args.steps for k, v in timers.items()}   # ms per step per kernel name
         dom = max(tot, key=tot.get)
-        if dom.startswith("gemm"):
-            ach = gemm_flops / (tot[dom] * 1e-3) / 1e12
+        if dom in kf:
+            ach = kf[dom] / (tot[dom] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None,
-                    "note": "fp32-input MFMA GEMM; flops = sum over levels of 2*rows*18C*C (the K-projection or one of its two gradients)"}
+                    "note": "fp32-input MFMA GEMM (v_mfma_f32_32x32x2_f32): block products of the level projection summed over levels"}
         else:
-            which = "fwd" if "fwd" in dom else "bwd"
-            ms = sum(v for k, v in tot.items() if k.startswith("r18_" + which))
-            ach = contract_bytes / (ms * 1e-3) / 1e9
+            ach = kb.get(dom, 0) / (tot[dom] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "note": "RisiContraction_18 %s over all buckets and levels: algorithmic bytes / (slab+rows kernel time)" % which}
+                    "note": "algorithmic bytes of this kernel over all levels / its device time per step"}
         roof["kernel"] = dom
         roof["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
-        roof["step_GBps"] = round((fwd_bytes + bwd_bytes) / (ms_per_step * 1e-3) / 1e9, 1)
-        roof["step_gemm_TFLOPs"] = round(3 * gemm_flops / (ms_per_step * 1e-3) / 1e12, 2)
+        roof["step_GBps"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
+        roof["step_gemm_TFLOPs"] = round(step_flops / (ms_per_step * 1e-3) / 1e12, 2)
         return roof
 
     def cpu():
@@ -170,8 +190,8 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
                           % (len(sample), [len(m[0]) for m, _ in sample], secs)}
 
     meta = {"metric": "CCN-2D (SMP_omega) molecules/sec fwd+bwd", "unit": "molecules/s", "units_per_step": B,
-            "config": {"workload": "cfg3: SMP_omega 3 levels, C=%d, F=5, D=5, cap=29, batch=%d synthetic QM9-size molecules/GPU, device-resident"
-                                   % (C, B),
+            "config": {"workload": "cfg3: SMP_omega 3 levels, C=%d, F=5, D=5, cap=29, batch=%d synthetic QM9-size molecules/GPU, device-resident, %s levels"
+                                   % (C, B, "fused" if fused else "op-by-op"),
                        "parallelism": "molecule-sharded x%d, one RCCL all-reduce of %d gradient floats per step" % (world, net.n_params)
                        if world > 1 else "single GPU", "prep_s": round(prep_s, 3), "work": work}}
     return ctx, step, finish, cpu, meta, net
@@ -187,6 +207,7 @@ def main():
     ap.add_argument("--N", type=int, default=32)
     ap.add_argument("--C", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="cfg3: op-by-op level pipeline instead of the fused level kernels")
     args = ap.parse_args()
 
     import torch

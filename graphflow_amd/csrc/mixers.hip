@@ -238,12 +238,18 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
     }
 }
 
-// C[i] (+)= sum_s part[s][i], fixed order
-__global__ void splitk_reduce(const float *__restrict__ part, float *__restrict__ C, size_t n, int splits, int accumulate) {
+// dst[c][i] = sum of part[s][i] over the c-th chunk of splits (chunk = ceil(splits / gridDim.y)); with gridDim.y == 1 and
+// accumulate it is the final  C[i] (+)= sum_s part[s][i].  Two passes of this kernel fold thousands of split-K partials
+// with full-chip parallelism and a fixed summation order (chunks in order, splits in order inside a chunk).
+__global__ void splitk_reduce(const float *__restrict__ part, float *__restrict__ dst, size_t n, int splits, int chunk,
+                              int accumulate) {
+    const int c = blockIdx.y;
+    const int s0 = c * chunk, s1 = (s0 + chunk < splits) ? s0 + chunk : splits;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
-        C[i] = accumulate ? C[i] + s : s;
+        for (int k = s0; k < s1; ++k) s += part[(size_t)k * n + i];
+        float *o = dst + (size_t)c * n + i;
+        *o = accumulate ? *o + s : s;
     }
 }
 
@@ -286,7 +292,7 @@ gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *
     float *part = nullptr;
     if (splits > 1 && ldc != N) return fail(ctx, GF_ERR_UNSUPPORTED, "split-K needs a dense C (ldc == N)");
     if (splits > 1) {
-        gf_status st = ensure_ws(ctx, sizeof(float) * (size_t)splits * M * N + 256);
+        gf_status st = ensure_ws(ctx, sizeof(float) * ((size_t)splits + (splits + 31) / 32) * M * N + 256);
         if (st != GF_OK) return st;
         part = static_cast<float *>(ctx->ws);
         g.C = part;
@@ -296,9 +302,11 @@ gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *
     g.ntiles_n = gx;
     const dim3 grid((unsigned)((size_t)gx * gy), 1, batch * splits);
     // vector path: 16-byte aligned operands, extents and leading dimensions in multiples of 4
-    const bool vec = (((uintptr_t)A | (uintptr_t)B | (uintptr_t)g.C) & 15) == 0 && (M % 4 == 0) && (N % 4 == 0) &&
-                     (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (g.ldc % 4 == 0) && (sA % 4 == 0) &&
-                     (sB % 4 == 0) && (sC % 4 == 0);
+    // (an extent only has to be a multiple of 4 along the directions that are actually loaded as float4:
+    //  M when A is stored m-contiguous (TA), K when A or B is k-contiguous (!TA or TB), N always (B !TB and the C rows))
+    const bool vec = (((uintptr_t)A | (uintptr_t)B | (uintptr_t)g.C) & 15) == 0 && (N % 4 == 0) && (!ta || M % 4 == 0) &&
+                     ((ta && !tb) || K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (g.ldc % 4 == 0) &&
+                     (sA % 4 == 0) && (sB % 4 == 0) && (sC % 4 == 0);
 #define GF_GEMM_LAUNCH(TA_, TB_, NAME)                                                                         \
     do {                                                                                                       \
         if (vec)                                                                                               \
@@ -314,8 +322,15 @@ gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *
     if (splits > 1) {
         const size_t n = (size_t)M * N;
         size_t blocks = (n + 255) / 256;
-        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, part,
-                  C, n, splits, accumulate);
+        const unsigned gx1 = (unsigned)(blocks > 4096 ? 4096 : blocks);
+        if (splits > 64) {  // two passes: [splits] -> [nchunks] partials (stored behind the split partials) -> C
+            const int chunk = 32, nchunks = (splits + chunk - 1) / chunk;
+            float *part2 = part + (size_t)splits * n;
+            GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, nchunks), dim3(256), 0, part, part2, n, splits, chunk, 0);
+            GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part2, C, n, nchunks, nchunks, accumulate);
+        } else {
+            GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part, C, n, splits, splits, accumulate);
+        }
     }
     return GF_OK;
 }

@@ -15,39 +15,7 @@
 #include <cstring>
 #include <string>
 
-#include "gf_internal.h"
-#include "smp_prep.h"
-
-namespace gf {
-gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *A, int lda, long long sA, const float *B,
-               int ldb, long long sB, float *C, int ldc, long long sC, int batch, int accumulate);
-}
-
-struct gf_smp {
-    gf_ctx *ctx = nullptr;
-    gfsmp::Config cfg;
-    gfsmp::BatchLayout lay;
-    bool prepared = false, forwarded = false;
-    // device buffers (owned)
-    struct DevLevel {
-        int *node_s = nullptr;
-        long long *node_row = nullptr, *node_p = nullptr, *node_pair = nullptr;
-        float *adj = nullptr;
-        int *pair_node = nullptr, *pair_src_s = nullptr, *cons_s = nullptr;
-        long long *pair_src_row = nullptr, *cons_ptr = nullptr, *cons_slab = nullptr, *cons_inv_off = nullptr;
-        short *pi = nullptr, *inv = nullptr;
-        float *f = nullptr, *df = nullptr, *Q = nullptr;  // activations [rows][C], their gradient, contraction out [rows][18C]
-    };
-    std::vector<DevLevel> lv;
-    float *x = nullptr;      // [nVertices][FD]
-    float *P = nullptr;      // shared promotion / dP buffer, max over levels of ppos*C
-    float *sh = nullptr, *vf = nullptr;  // [nNodes][C] readout pre/post activation
-    float *g = nullptr;      // [nMol][C] graph features
-    float *yhat = nullptr, *dy = nullptr;  // [nMol]
-    float *colpart = nullptr;  // partial column sums for bias gradients
-    int *top_node_mol = nullptr, *mol_ptr = nullptr, *mol_nodes = nullptr;
-    std::vector<void *> allocs;
-};
+#include "smp_internal.h"
 
 namespace gf {
 namespace {
@@ -451,6 +419,16 @@ gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *a
         UP(d.inv, h.inv);
         st = gf::upload(s, &d.Q, nullptr, (size_t)h.rows * gf::kK * C);
         if (st != GF_OK) return st;
+        {
+            float **bufs[] = {&d.Vt, &d.dVt, &d.St, &d.dSt, &d.scal, &d.Vout, &d.dVout, &d.Sout, &d.dSout, &d.dSpart, &d.dbpart, &d.Wst, &d.dWst};
+            const size_t sizes[] = {(size_t)h.pairs * 4 * C, (size_t)h.pairs * 4 * C, (size_t)h.nNodes * 4 * C, (size_t)h.nNodes * 4 * C,
+                                    (size_t)h.pairs * 4 * C, (size_t)h.pairs * C, (size_t)h.pairs * C, (size_t)h.nNodes * C,
+                                    (size_t)h.nNodes * C, (size_t)h.pairs * C, (size_t)h.pairs * C, (size_t)18 * C * C, (size_t)18 * C * C};
+            for (int q = 0; q < 13; ++q) {
+                st = gf::upload(s, bufs[q], nullptr, sizes[q]);
+                if (st != GF_OK) return st;
+            }
+        }
         if (h.ppos > maxp) maxp = h.ppos;
         for (size_t b = 0; b < h.buckets.size(); ++b) {
             const size_t w = gf_contract_workspace_bytes(18, h.buckets[b].s, C, h.buckets[b].count);
@@ -480,11 +458,13 @@ gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *a
     UP(s->mol_nodes, mol_nodes);
     long long maxrows = 0;
     for (int l = 0; l <= L; ++l) maxrows = std::max(maxrows, (long long)B.level[l].rows);
-    st = gf::upload(s, &s->colpart, nullptr, (size_t)((maxrows + 1023) / 1024 + 1) * C);
+    long long maxpairs = 0;
+    for (int l = 0; l <= L; ++l) maxpairs = std::max(maxpairs, (long long)B.level[l].pairs);
+    st = gf::upload(s, &s->colpart, nullptr, (size_t)((maxrows + 1023) / 1024 + (maxpairs + 255) / 256 + 2) * C);
     if (st != GF_OK) return st;
 #undef UP
     // split-K partials of the weight gradients also live in the context workspace
-    const size_t gemm_ws = sizeof(float) * 4200 * (size_t)gf::kK * C * C / 18 + sizeof(float) * 4200 * (size_t)C * s->cfg.fdim() + (1 << 20);
+    const size_t gemm_ws = sizeof(float) * 4400 * (size_t)4 * C * C + sizeof(float) * 4400 * (size_t)C * s->cfg.fdim() + (1 << 20);
     st = gf::ensure_ws(ctx, std::max(contract_ws, gemm_ws));
     if (st != GF_OK) return st;
     GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -514,6 +494,11 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     for (int l = 1; l <= L; ++l) {
         const gfsmp::LevelLayout &h = B.level[l];
         const gf_smp::DevLevel &d = s->lv[l];
+        if (s->fused && gf::smp_fused_supported(s, l)) {
+            st = gf::smp_fused_forward_level(s, l, K[l], b[l]);
+            if (st != GF_OK) return st;
+            continue;
+        }
         GF_LAUNCH(ctx, "smp_promote_fwd", gf::promote_forward, dim3((unsigned)h.pairs), dim3(256), 0, s->lv[l - 1].f, s->P,
                   d.node_s, d.node_row, d.node_p, d.node_pair, d.pair_node, d.pair_src_row, d.pair_src_s, d.pi, C);
         st = gf::smp_contract(s, l, /*backward=*/false);
@@ -560,19 +545,24 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     for (int l = L; l >= 1; --l) {
         const gfsmp::LevelLayout &h = B.level[l];
         const gf_smp::DevLevel &d = s->lv[l];
+        if (s->fused && gf::smp_fused_supported(s, l)) {
+            st = gf::smp_fused_backward_level(s, l, K[l], dK[l], db[l]);
+            if (st != GF_OK) return st;
+        } else {
         // dZ = dF * lrelu'(z) in place; db_l += column sums
-        const int rpb = 1024;
-        const int nb = (int)((h.rows + rpb - 1) / rpb);
-        GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(256), 0, d.f, d.df, s->colpart, C,
-                  (long long)h.rows, rpb);
-        GF_LAUNCH(ctx, "smp_colsum", gf::colsum_finish, dim3(1), dim3(256), 0, s->colpart, db[l], C, nb);
-        // dK_l += Q^T dZ   (MatMul::backward second operand), then dQ = dZ K_l^T overwrites Q (first operand)
-        st = gf::gemm(ctx, true, false, gf::kK * C, C, (int)h.rows, d.Q, gf::kK * C, 0, d.df, C, 0, dK[l], C, 0, 1, 1);
-        if (st != GF_OK) return st;
-        st = gf::gemm(ctx, false, true, (int)h.rows, gf::kK * C, C, d.df, C, 0, K[l], C, 0, d.Q, gf::kK * C, 0, 1, 0);
-        if (st != GF_OK) return st;
-        st = gf::smp_contract(s, l, /*backward=*/true);
-        if (st != GF_OK) return st;
+            const int rpb = 1024;
+            const int nb = (int)((h.rows + rpb - 1) / rpb);
+            GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(256), 0, d.f, d.df, s->colpart, C,
+                      (long long)h.rows, rpb);
+            GF_LAUNCH(ctx, "smp_colsum", gf::colsum_finish, dim3(1), dim3(256), 0, s->colpart, db[l], C, nb);
+            // dK_l += Q^T dZ   (MatMul::backward second operand), then dQ = dZ K_l^T overwrites Q (first operand)
+            st = gf::gemm(ctx, true, false, gf::kK * C, C, (int)h.rows, d.Q, gf::kK * C, 0, d.df, C, 0, dK[l], C, 0, 1, 1);
+            if (st != GF_OK) return st;
+            st = gf::gemm(ctx, false, true, (int)h.rows, gf::kK * C, C, d.df, C, 0, K[l], C, 0, d.Q, gf::kK * C, 0, 1, 0);
+            if (st != GF_OK) return st;
+            st = gf::smp_contract(s, l, /*backward=*/true);
+            if (st != GF_OK) return st;
+        }
         const gf_smp::DevLevel &pv = s->lv[l - 1];
         GF_LAUNCH(ctx, "smp_promote_bwd", gf::promote_backward, dim3(B.level[l - 1].nNodes), dim3(256), 0, s->P, pv.df,
                   pv.node_s, pv.node_row, d.cons_ptr, d.cons_slab, d.cons_s, d.cons_inv_off, d.inv, C);
@@ -614,6 +604,15 @@ gf_status gf_smp_prepare_molecule_host(const gf_smp_config *cfg, int V, const in
         }
     if (wl_out)
         for (size_t i = 0; i < m.wl.size(); ++i) wl_out[i] = m.wl[i];
+    return GF_OK;
+}
+
+/* 1 (default): fused level kernels where the shape allows; 0: the op-by-op pipeline (promotion, RisiContraction_18,
+ * MatMul, VectorAddTensor, LeakyReLU3D as separate kernels).  Both produce the same results within fp32 rounding. */
+gf_status gf_smp_set_fused(gf_smp *s, int on) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    s->fused = on ? 1 : 0;
+    s->forwarded = false;
     return GF_OK;
 }
 

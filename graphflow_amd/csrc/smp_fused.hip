@@ -1,0 +1,679 @@
+// smp_fused.hip -- fused SMP level: promotion + RisiContraction_18 + K-projection + bias + LeakyReLU without ever
+// materialising the promoted stack P (sum s^3 C floats) or the 18-slice contraction output Q (18 sum s^2 C floats).
+//
+// Same mathematics as the op-by-op pipeline of smp.hip (GraphFlow/SMP_omega.h:630-670), regrouped:
+//   Q_k = (N x N table) x (factor depending on A)  for every one of the 18 cases, and the
+//   K-projection is linear, so   sum_k Q_k K^(k)   is evaluated as
+//     tables  T = [Dac | S_ab | S_bc | Dbb | T6 | T10]      six N x N x C tables per node, built by ONE pass that gathers
+//                                                             the promoted tensors straight from f_{l-1}
+//     GEMMs   O_tot = [S_ab|S_bc][K0;K2]   O_tr = S_ab K6   O_dir = [T6|T10][K5;K9]
+//             Z = [S_ab|S_bc|Dbb][K8;K12;K15]   Z' = [Dac|S_ab][K16;K11]              10 C x C block products, not 18
+//             V = [rowsum_a|colsum_b|D8|D11][K1;K3;K7;K10]  (per (node,x))   S = [total|s14|s15|s18][K4;K13;K14;K17] (per node)
+//     combine f_l[x,y] = LeakyReLU(b + tot O_tot[x,y] + tr O_tr[x,y] + O_dir[x,y]
+//                                    + sum_e A[y,e] (Z[x,e] + Z'[e,x]) + r[y] V[x] + A[x,y] S)
+// The reverse sweep mirrors it: combine-backward -> block GEMMs (dT, dK) -> tables-backward (dP) -> consumer gather.
+// HBM traffic per level drops from about (2 S + 40 R) C floats to about (S_back + 27 R) C, GEMM flops from 18 to 10 units
+// (R = sum s^2, S = sum s^3).
+#include <algorithm>
+
+#include "r18_device.h"
+#include "smp_internal.h"
+
+using namespace gf::dev;
+
+namespace gf {
+namespace {
+
+constexpr float kAlphaF = 0.01f;
+__device__ __forceinline__ float lreluf(float z) { return z > 0.f ? z : kAlphaF * z; }
+
+// column blocks of the table matrix T [rows][6C]
+enum { T_DAC = 0, T_SAB = 1, T_SBC = 2, T_DBB = 3, T_T6 = 4, T_T10 = 5, T_COLS = 6 };
+// column blocks of the projected matrix O [rows][5C]
+enum { O_TOT = 0, O_TR = 1, O_DIR = 2, O_Z = 3, O_ZP = 4, O_COLS = 5 };
+// stacked weight layout: position p holds block K^(kperm[p]); groups are contiguous
+//   [0,2) tot | [2,3) tr | [3,5) dir | [5,8) Z | [8,10) Z' | [10,14) V | [14,18) S
+__constant__ int c_kperm[18] = {0, 2, 6, 5, 9, 8, 12, 15, 16, 11, 1, 3, 7, 10, 4, 13, 14, 17};
+
+// ---------------------------------------------------------------------------------------------------------------
+// T1: tables-forward.  Workgroup per (node, b).  Same lane mapping / reductions as r18_fwd_slab, but every row a of
+// the slab is gathered from f_{l-1}[src(n,a)] through the selection map pi_a (P[a][b][c] = F_a[pi_a(b)][pi_a(c)] or 0),
+// and the products are the six tables plus the b-owned vectors and partial scalars.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LPC, int NI>
+__global__ __launch_bounds__(kThreads) void smp_tables_fwd(const float *__restrict__ fprev, const float *__restrict__ A,
+                                                           float *__restrict__ T, float *__restrict__ Vt,
+                                                           float *__restrict__ scal, const long long *__restrict__ pair_src_row,
+                                                           const int *__restrict__ pair_src_s, const short *__restrict__ pi,
+                                                           Ragged R, int C, int nwin) {
+    constexpr int PPW = 64 / LPC;
+    constexpr int CW = 4 * LPC;
+    constexpr int NCP = NI * PPW;
+    static_assert(PPW >= 4, "row epilogue uses four c-groups");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = lane / LPC, fl = lane % LPC;
+    const Where W = locate(R, nwin);
+    const int N = W.N, b = W.i;
+    const size_t rowbase = W.rowbase, pairbase = W.pairbase;
+    const int f = W.win * CW + 4 * fl;
+    const bool fok = f < C;
+    const int fld = fok ? f : 0;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AdjLds L = load_adjacency<false>(smem, A + rowbase, N);
+    float *sRed = smem + adj_lds_floats(N);   // [2][NCP][CW] cross-wave reduction buffer
+    float *sMisc = sRed + 2 * NCP * CW;       // [kWaves][2][CW] diagonal sums
+    short *sPi = reinterpret_cast<short *>(sMisc + kWaves * 2 * CW);  // [N][N] selection maps of this node
+    for (int i = tid; i < N * N; i += kThreads) sPi[i] = pi[rowbase + i];
+    __syncthreads();
+
+    float rc[NI];
+    int cc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = i * PPW + cg;
+        cc[i] = (c < N) ? c : -1;
+        rc[i] = (c < N && fok) ? L.r[c] : 0.f;
+    }
+
+    f4 sbc[NI], t10[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) sbc[i] = t10[i] = splat(0.f);
+    f4 dgsum = splat(0.f);  // cg==0: sum_a P[a,b,b]   cg==1: sum_a P[a,b,a]
+
+    // gather one row: returns masked values (zero where the selection map has no image)
+    auto load_row = [&](int a, f4(&v)[NI], f4 &dg) {
+        const long long e = (long long)pairbase + a;
+        const float *src = fprev + pair_src_row[e] * C + fld;
+        const int sw = pair_src_s[e];
+        const short *map = sPi + a * N;
+        const int pb = map[b];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int pc = (cc[i] >= 0) ? map[cc[i]] : -1;
+            const bool ok = pb >= 0 && pc >= 0 && fok;
+            const f4 x = ld4(src + (ok ? ((size_t)pb * sw + pc) * C : 0));
+            v[i] = ok ? x : splat(0.f);
+        }
+        const int pd = (cg == 0) ? pb : map[a];  // P[a,b,b] or P[a,b,a]
+        const bool okd = cg < 2 && pb >= 0 && pd >= 0 && fok;
+        const f4 y = ld4(src + (okd ? ((size_t)pb * sw + pd) * C : 0));
+        dg = okd ? y : splat(0.f);
+    };
+
+    f4 cur[NI], nxt[NI], dcur, dnxt;
+    load_row(wave < N ? wave : 0, cur, dcur);
+    for (int a = wave; a < N; a += kWaves) {
+        const int an = (a + kWaves < N) ? a + kWaves : a;
+        load_row(an, nxt, dnxt);
+        const float ra = L.r[a];
+        f4 sab = splat(0.f), t6 = splat(0.f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const f4 v = cur[i];
+            sbc[i] += v;
+            t10[i] += ra * v;
+            sab += v;
+            t6 += rc[i] * v;
+        }
+        sab = reduce_cgroups<LPC>(sab);
+        t6 = reduce_cgroups<LPC>(t6);
+        dgsum += dcur;
+        if (fok) {
+            float *trow = T + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + f;  // table row (a, b)
+            if (cg == 0) {
+                st4(trow + T_SAB * C, sab);
+                st4(trow + T_DBB * C, dcur);  // P[a,b,b]
+                if (a == b) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);  // -> s18 = sum_a P[a,a,a]
+            } else if (cg == 1) {
+                st4(trow + T_DAC * C, dcur);  // P[a,b,a] = Dac[e=a][b]
+            } else if (cg == 2) {
+                st4(trow + T_T6 * C, t6);
+            } else if (cg == 3) {
+                if (a == b) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, sab);  // -> s14 = sum_a S_ab[a,a]
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) cur[i] = nxt[i];
+        dcur = dnxt;
+    }
+
+    // cross-wave reduction of the a-sums (fixed order), as in r18_fwd_slab
+#pragma unroll 1
+    for (int w = 1; w < kWaves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                st4(sRed + (i * PPW + cg) * CW + 4 * fl, sbc[i]);
+                st4(sRed + (NCP + i * PPW + cg) * CW + 4 * fl, t10[i]);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                sbc[i] += ld4(sRed + (i * PPW + cg) * CW + 4 * fl);
+                t10[i] += ld4(sRed + (NCP + i * PPW + cg) * CW + 4 * fl);
+            }
+        }
+        __syncthreads();
+    }
+    if (cg < 2) st4(sMisc + (wave * 2 + cg) * CW + 4 * fl, dgsum);
+    __syncthreads();
+    if (wave == 0) {
+        f4 cs = splat(0.f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (cc[i] >= 0) {
+                cs += sbc[i];
+                if (fok) {
+                    float *trow = T + (rowbase + (size_t)b * N + cc[i]) * (size_t)(T_COLS * C) + f;  // table row (b, c)
+                    st4(trow + T_SBC * C, sbc[i]);
+                    st4(trow + T_T10 * C, t10[i]);
+                }
+            }
+        }
+        cs = reduce_cgroups<LPC>(cs);  // colsum_b = sum_{a,c} P[a,b,c]
+        f4 dbbtot = splat(0.f), dactot = splat(0.f);
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            dbbtot += ld4(sMisc + (w * 2 + 0) * CW + 4 * fl);
+            dactot += ld4(sMisc + (w * 2 + 1) * CW + 4 * fl);
+        }
+        if (cg == 0 && fok) {
+            float *v = Vt + (pairbase + b) * 4 * (size_t)C + f;  // [rowsum_a | colsum_b | D8 | D11] of index b
+            st4(v + 1 * C, cs);
+            st4(v + 3 * C, dactot);                               // D11[b] = sum_a P[a,b,a]
+            float *s = scal + (pairbase + b) * 4 * (size_t)C + f;
+            st4(s + 0 * C, cs);                                   // -> total
+            st4(s + 2 * C, dbbtot);                               // -> s15 = sum_{a,b} P[a,b,b]
+        }
+    }
+}
+
+template <int LPC, int NI>
+size_t tables_fwd_lds(int N) {
+    constexpr int CW = 4 * LPC, NCP = NI * (64 / LPC);
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + 2 * (size_t)NCP * CW + kWaves * 2 * CW) + sizeof(short) * (size_t)N * N + 16;
+}
+
+// rowsum_a[x] = sum_b S_ab[x,b], D8[x] = sum_b Dbb[x,b] per (node, x); scalars per node = sum over b of the partials
+__global__ void smp_vectors(const float *__restrict__ T, float *__restrict__ Vt, const float *__restrict__ scal,
+                            float *__restrict__ St, const int *__restrict__ node_s, const long long *__restrict__ node_row,
+                            const long long *__restrict__ node_pair, int C) {
+    const int n = blockIdx.x;
+    const int s = node_s[n];
+    const size_t rowbase = (size_t)node_row[n], pairbase = (size_t)node_pair[n];
+    for (int i = threadIdx.x; i < s * C; i += blockDim.x) {
+        const int f = i % C, x = i / C;
+        float rs = 0.f, d8 = 0.f;
+        const float *t = T + (rowbase + (size_t)x * s) * (size_t)(T_COLS * C) + f;
+        for (int bb = 0; bb < s; ++bb) {
+            rs += t[(size_t)bb * T_COLS * C + T_SAB * C];
+            d8 += t[(size_t)bb * T_COLS * C + T_DBB * C];
+        }
+        Vt[(pairbase + x) * 4 * (size_t)C + 0 * C + f] = rs;
+        Vt[(pairbase + x) * 4 * (size_t)C + 2 * C + f] = d8;
+    }
+    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
+        float acc = 0.f;
+        for (int bb = 0; bb < s; ++bb) acc += scal[(pairbase + bb) * 4 * (size_t)C + i];
+        St[(size_t)n * 4 * C + i] = acc;
+    }
+}
+
+// stacked[p] = K^(kperm[p])  (gather), or  dK^(kperm[p]) += dstacked[p]  (scatter-add)
+__global__ void stack_weights(const float *__restrict__ K, float *__restrict__ stacked, int C) {
+    const int CC = C * C;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 18 * CC; i += gridDim.x * blockDim.x)
+        stacked[i] = K[(size_t)c_kperm[i / CC] * CC + i % CC];
+}
+__global__ void unstack_weight_grads(const float *__restrict__ dstacked, float *__restrict__ dK, int C) {
+    const int CC = C * C;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 18 * CC; i += gridDim.x * blockDim.x)
+        dK[(size_t)c_kperm[i / CC] * CC + i % CC] += dstacked[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// combine-forward.  Workgroup per (node, x): f_l[x, y, :] for all y.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LPC>
+__global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restrict__ O, const float *__restrict__ A,
+                                                            const float *__restrict__ Vout, const float *__restrict__ Sout,
+                                                            const float *__restrict__ bias, float *__restrict__ F,
+                                                            Ragged R, int C, int nwin) {
+    constexpr int CW = 4 * LPC;
+    constexpr int NGRP = kThreads / LPC;
+    const int tid = threadIdx.x;
+    const int grp = tid / LPC, fl = tid % LPC;
+    const Where W = locate(R, nwin);
+    const int N = W.N, x = W.i;
+    const size_t rowbase = W.rowbase, pairbase = W.pairbase;
+    const int f = W.win * CW + 4 * fl;
+    const bool fok = f < C;
+    const int fc = fok ? f : 0;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AdjLds L = load_adjacency<false>(smem, A + rowbase, N);
+    float *sU = smem + adj_lds_floats(N);  // [N][CW]  Z[x,e] + Z'[e,x]
+    for (int e = grp; e < N; e += NGRP) {
+        const f4 z = ld4(O + (rowbase + (size_t)x * N + e) * (size_t)(O_COLS * C) + O_Z * C + fc);
+        const f4 zp = ld4(O + (rowbase + (size_t)e * N + x) * (size_t)(O_COLS * C) + O_ZP * C + fc);
+        st4(sU + e * CW + 4 * fl, fok ? z + zp : splat(0.f));
+    }
+    __syncthreads();
+    const float tot = L.st[0], tr = L.st[1];
+    const f4 vout = ld4(Vout + (pairbase + x) * (size_t)C + fc);
+    const f4 sout = ld4(Sout + (size_t)W.node * C + fc);
+    const f4 bb = ld4(bias + fc);
+    const float *const Tt[1] = {sU};
+    for (int y = grp; y < N; y += NGRP) {
+        f4 m[1];
+        small_matvec<1, CW>(L, N, y, fl, Tt, m);
+        const float *o = O + (rowbase + (size_t)x * N + y) * (size_t)(O_COLS * C) + fc;
+        const f4 z = bb + tot * ld4(o + O_TOT * C) + tr * ld4(o + O_TR * C) + ld4(o + O_DIR * C) + m[0] + L.r[y] * vout +
+                     L.at(x, y, N) * sout;
+        if (fok) {
+            f4 out;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = lreluf(z[j]);
+            st4(F + (rowbase + (size_t)x * N + y) * (size_t)C + f, out);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// combine-backward.  Workgroup per (node, x): from dF[x,:,:] produce dO[(x,y)] (tot, tr, dir blocks), dZ[(x,e)],
+// dZ'[(e,x)] and the per-(node,x) partials dVout, dS-part, db-part.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LPC>
+__global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restrict__ F, const float *__restrict__ dF,
+                                                            const float *__restrict__ A, float *__restrict__ dO,
+                                                            float *__restrict__ dVout, float *__restrict__ dSpart,
+                                                            float *__restrict__ dbpart, Ragged R, int C, int nwin) {
+    constexpr int CW = 4 * LPC;
+    constexpr int NGRP = kThreads / LPC;
+    const int tid = threadIdx.x;
+    const int grp = tid / LPC, fl = tid % LPC;
+    const Where W = locate(R, nwin);
+    const int N = W.N, x = W.i;
+    const size_t rowbase = W.rowbase, pairbase = W.pairbase;
+    const int f = W.win * CW + 4 * fl;
+    const bool fok = f < C;
+    const int fc = fok ? f : 0;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AdjLds L = load_adjacency<true>(smem, A + rowbase, N);  // L.A[e][y] = A+[y][e]
+    float *sDz = smem + adj_lds_floats(N);  // [N][CW]
+    const float tot = L.st[0], tr = L.st[1];
+    for (int y = grp; y < N; y += NGRP) {
+        const size_t row = rowbase + (size_t)x * N + y;
+        const f4 fv = ld4(F + row * C + fc), g = ld4(dF + row * C + fc);
+        f4 dz;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dz[j] = fok ? g[j] * (fv[j] > 0.f ? 1.f : kAlphaF) : 0.f;
+        st4(sDz + y * CW + 4 * fl, dz);
+        if (fok) {
+            float *o = dO + row * (size_t)(O_COLS * C) + f;
+            st4(o + O_TOT * C, tot * dz);
+            st4(o + O_TR * C, tr * dz);
+            st4(o + O_DIR * C, dz);
+        }
+    }
+    __syncthreads();
+    const float *const Tt[1] = {sDz};
+    for (int e = grp; e < N; e += NGRP) {
+        f4 m[1];
+        small_matvec<1, CW>(L, N, e, fl, Tt, m);  // dU[e] = sum_y A+[y][e] dz[y]
+        if (fok) {
+            st4(dO + (rowbase + (size_t)x * N + e) * (size_t)(O_COLS * C) + O_Z * C + f, m[0]);
+            st4(dO + (rowbase + (size_t)e * N + x) * (size_t)(O_COLS * C) + O_ZP * C + f, m[0]);
+        }
+    }
+    if (grp < 3 && fok) {
+        f4 acc = splat(0.f);
+        for (int y = 0; y < N; ++y) {
+            const float w = (grp == 0) ? L.r[y] : (grp == 1) ? L.A[y * (N + 1) + x] : 1.f;  // r[y] | A+[x][y] | 1
+            acc += w * ld4(sDz + y * CW + 4 * fl);
+        }
+        float *dst = (grp == 0) ? dVout : (grp == 1) ? dSpart : dbpart;
+        st4(dst + (pairbase + x) * (size_t)C + f, acc);
+    }
+}
+
+// out[f] += sum_r part[r][f] over `rows` rows: chunked partial sums, then a fixed-order fold (deterministic)
+__global__ void colsum_chunks(const float *__restrict__ part, float *__restrict__ tmp, int C, long long rows, int rows_per_block) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+    for (int f = threadIdx.x; f < C; f += blockDim.x) {
+        float s = 0.f;
+        for (long long r = r0; r < r1; ++r) s += part[(size_t)r * C + f];
+        tmp[(size_t)blockIdx.x * C + f] = s;
+    }
+}
+__global__ void colsum_fold(const float *__restrict__ tmp, float *__restrict__ out, int C, int nblocks) {
+    __shared__ float red[256];
+    const int lanes = (C < 256) ? C : 256, rl = 256 / lanes;
+    const int f0 = threadIdx.x % lanes, rr = threadIdx.x / lanes;
+    for (int fb = 0; fb < C; fb += lanes) {
+        const int f = fb + f0;
+        float s = 0.f;
+        if (f < C && rr < rl)
+            for (int b = rr; b < nblocks; b += rl) s += tmp[(size_t)b * C + f];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rr == 0 && f < C) {
+            float t = 0.f;
+            for (int k = 0; k < rl; ++k) t += red[k * lanes + f0];
+            out[f] += t;
+        }
+        __syncthreads();
+    }
+}
+
+// dSout[n] = sum_x dSpart[(n,x)]
+__global__ void smp_node_sum(const float *__restrict__ part, float *__restrict__ out, const int *__restrict__ node_s,
+                             const long long *__restrict__ node_pair, int C) {
+    const int n = blockIdx.x;
+    const int s = node_s[n];
+    for (int f = threadIdx.x; f < C; f += blockDim.x) {
+        float acc = 0.f;
+        for (int x = 0; x < s; ++x) acc += part[((size_t)node_pair[n] + x) * C + f];
+        out[(size_t)n * C + f] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tables-backward.  Workgroup per (node, b): dP[:, b, :, :] from the table gradients.  Streaming phase as r18_bwd_slab.
+//   dP[a,b,c] = X[a] + Y[c] + G5[a] r[c] + G9[c] r[a] + [c==b] Z1[a] + [c==a] Z2[a]
+//   X[a]  = dS_ab[a,b] + d rowsum[a] + d colsum[b] + d total + [a==b] d s14
+//   Y[c]  = dS_bc[b,c]     G5[a] = dT6[a,b]     G9[c] = dT10[b,c]
+//   Z1[a] = dDbb[a,b] + dD8[a] + d s15 + [a==b] d s18          Z2[a] = dDac[a,b] + dD11[b]
+// ---------------------------------------------------------------------------------------------------------------
+template <int LPC, int NI>
+__global__ __launch_bounds__(kThreads, 3) void smp_tables_bwd(const float *__restrict__ dT, const float *__restrict__ dVt,
+                                                              const float *__restrict__ dSt, const float *__restrict__ A,
+                                                              float *__restrict__ dP, Ragged R, int C, int nwin) {
+    constexpr int PPW = 64 / LPC;
+    constexpr int CW = 4 * LPC;
+    constexpr int NGRP = kThreads / LPC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = lane / LPC, fl = lane % LPC;
+    const int grp = tid / LPC;
+    const Where W = locate(R, nwin);
+    const int N = W.N, b = W.i;
+    const size_t rowbase = W.rowbase, pbase = W.pbase, pairbase = W.pairbase;
+    const int f = W.win * CW + 4 * fl;
+    const bool fok = f < C;
+    const int fc = fok ? f : 0;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AdjLds L = load_adjacency<false>(smem, A + rowbase, N);
+    float *sX = smem + adj_lds_floats(N);
+    float *sG5 = sX + N * CW;
+    float *sZ1 = sG5 + N * CW;
+    float *sZ2 = sZ1 + N * CW;
+    {
+        const float *ds = dSt + (size_t)W.node * 4 * C + fc;
+        const f4 dtotal = ld4(ds + 0 * C), ds14 = ld4(ds + 1 * C), ds15 = ld4(ds + 2 * C), ds18 = ld4(ds + 3 * C);
+        const float *dvb = dVt + (pairbase + b) * 4 * (size_t)C + fc;
+        const f4 dcol = ld4(dvb + 1 * C), dd11 = ld4(dvb + 3 * C);
+        for (int a = grp; a < N; a += NGRP) {
+            const float *t = dT + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + fc;  // table row (a, b)
+            const float *dva = dVt + (pairbase + a) * 4 * (size_t)C + fc;
+            f4 x = ld4(t + T_SAB * C) + ld4(dva + 0 * C) + dcol + dtotal;
+            f4 z1 = ld4(t + T_DBB * C) + ld4(dva + 2 * C) + ds15;
+            if (a == b) {
+                x += ds14;
+                z1 += ds18;
+            }
+            const f4 m = fok ? splat(1.f) : splat(0.f);
+            st4(sX + a * CW + 4 * fl, x * m);
+            st4(sG5 + a * CW + 4 * fl, ld4(t + T_T6 * C) * m);
+            st4(sZ1 + a * CW + 4 * fl, z1 * m);
+            st4(sZ2 + a * CW + 4 * fl, (ld4(t + T_DAC * C) + dd11) * m);
+        }
+    }
+    __syncthreads();
+
+    f4 yv[NI], g9[NI];
+    float rc[NI];
+    int coff[NI];
+    bool live[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = i * PPW + cg;
+        const bool ok = c < N;
+        const int cx = ok ? c : 0;
+        live[i] = ok && fok;
+        coff[i] = cx * C + fc;
+        rc[i] = L.r[cx];
+        const float *t = dT + (rowbase + (size_t)b * N + cx) * (size_t)(T_COLS * C) + fc;  // table row (b, c)
+        yv[i] = ld4(t + T_SBC * C);
+        g9[i] = ld4(t + T_T10 * C);
+    }
+    const int ib = b / PPW, cgb = b % PPW;
+    float *dPg = dP + pbase * C + (size_t)b * N * C;
+    const size_t rowStride = (size_t)N * N * C;
+    for (int a = wave; a < N; a += kWaves) {
+        float *row = dPg + a * rowStride;
+        const f4 xa = ld4(sX + a * CW + 4 * fl), g5a = ld4(sG5 + a * CW + 4 * fl);
+        const float ra = L.r[a];
+        const int ia = a / PPW, cga = a % PPW;
+        const f4 z1 = ld4(sZ1 + a * CW + 4 * fl) * ((cg == cgb) ? 1.f : 0.f);
+        const f4 z2 = ld4(sZ2 + a * CW + 4 * fl) * ((cg == cga) ? 1.f : 0.f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            f4 o = xa + yv[i] + g5a * rc[i] + g9[i] * ra;
+            if (i == ib) o += z1;
+            if (i == ia) o += z2;
+            if (live[i]) st4(row + coff[i], o);
+        }
+    }
+}
+
+template <int LPC>
+size_t tables_bwd_lds(int N) {
+    constexpr int CW = 4 * LPC;
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + 4 * (size_t)N * CW);
+}
+template <int LPC>
+size_t combine_lds(int N) {
+    constexpr int CW = 4 * LPC;
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + (size_t)N * CW);
+}
+
+template <typename Kern>
+gf_status opt_in_lds(gf_ctx *ctx, Kern kern, size_t bytes, size_t *granted) {
+    if (bytes > 160 * 1024) return fail(ctx, GF_ERR_UNSUPPORTED, "fused SMP kernel needs %zu B of LDS", bytes);
+    if (bytes > 32 * 1024 && bytes > *granted) {
+        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)bytes));
+        *granted = bytes;
+    }
+    return GF_OK;
+}
+
+struct SizeClass {
+    long long lo, hi;  // pair range
+    int smax, ni;
+};
+
+// merge the level's size buckets into the slab kernels' NI classes (LPC = 16 only: C % 64 == 0 is the fused path's domain)
+std::vector<SizeClass> classes_of(const gfsmp::LevelLayout &h, int ppw) {
+    std::vector<SizeClass> out;
+    size_t k = 0;
+    for (int cls = 1; cls <= 8 && k < h.buckets.size(); cls *= 2) {
+        const size_t k0 = k;
+        int smax = 0;
+        while (k < h.buckets.size() && h.buckets[k].s <= cls * ppw) smax = h.buckets[k++].s;
+        if (k == k0) continue;
+        SizeClass c;
+        c.lo = h.node_pair[h.buckets[k0].first_node];
+        c.hi = (k < h.buckets.size()) ? h.node_pair[h.buckets[k].first_node] : (long long)h.pairs;
+        c.smax = smax;
+        c.ni = cls;
+        out.push_back(c);
+    }
+    return out;
+}
+
+Ragged ragged_for(const gf_smp::DevLevel &d, long long lo, int smax) {
+    Ragged R = {d.pair_node, d.node_s, d.node_p, d.node_row, d.node_pair, lo, smax};
+    return R;
+}
+
+template <int NI>
+gf_status launch_tables_fwd(gf_smp *s, int l, const SizeClass &c) {
+    gf_ctx *ctx = s->ctx;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
+    const size_t lds = tables_fwd_lds<16, NI>(c.smax);
+    static size_t granted = 0;
+    gf_status st = opt_in_lds(ctx, smp_tables_fwd<16, NI>, lds, &granted);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd<16, NI>), dim3((unsigned)((c.hi - c.lo) * nwin)), dim3(kThreads), lds,
+              s->lv[l - 1].f, d.adj, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, ragged_for(d, c.lo, c.smax), C, nwin);
+    return GF_OK;
+}
+
+template <int NI>
+gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *dT) {
+    gf_ctx *ctx = s->ctx;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
+    const size_t lds = tables_bwd_lds<16>(c.smax);
+    static size_t granted = 0;
+    gf_status st = opt_in_lds(ctx, smp_tables_bwd<16, NI>, lds, &granted);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, "smpf_tables_bwd", (smp_tables_bwd<16, NI>), dim3((unsigned)((c.hi - c.lo) * nwin)), dim3(kThreads), lds, dT,
+              d.dVt, d.dSt, d.adj, s->P, ragged_for(d, c.lo, c.smax), C, nwin);
+    return GF_OK;
+}
+
+}  // namespace
+
+bool smp_fused_supported(const gf_smp *s, int l) {
+    const int C = s->cfg.nChanels;
+    if (C % 4 != 0) return false;
+    const gfsmp::LevelLayout &h = s->lay.level[l];
+    if (h.buckets.empty()) return false;
+    return h.buckets.back().s <= 32;  // 8 * PPW at LPC = 16
+}
+
+// Q buffer of the level ([rows][18C]) is carved as  T [rows][6C] | O / dO [rows][5C] | dT [rows][6C]
+gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float *bl) {
+    gf_ctx *ctx = s->ctx;
+    const gfsmp::LevelLayout &h = s->lay.level[l];
+    const gf_smp::DevLevel &d = s->lv[l];
+    const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
+    const int rows = (int)h.rows, pairs = (int)h.pairs, nodes = h.nNodes;
+    float *T = d.Q, *O = d.Q + (size_t)h.rows * T_COLS * C;
+    gf_status st;
+    const std::vector<SizeClass> cls = classes_of(h, 4);
+    for (const SizeClass &c : cls) {
+        switch (c.ni) {
+            case 1: st = launch_tables_fwd<1>(s, l, c); break;
+            case 2: st = launch_tables_fwd<2>(s, l, c); break;
+            case 4: st = launch_tables_fwd<4>(s, l, c); break;
+            default: st = launch_tables_fwd<8>(s, l, c); break;
+        }
+        if (st != GF_OK) return st;
+    }
+    GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(256), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
+              d.node_pair, C);
+    GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C);
+    const size_t CC = (size_t)C * C;
+    const int ldt = T_COLS * C, ldo = O_COLS * C;
+    // block GEMMs: A = T column range, B = stacked weights, C = O column block
+    struct G { int tcol, kb, wpos, ocol; };
+    const G gs[5] = {{T_SAB, 2, 0, O_TOT}, {T_SAB, 1, 2, O_TR}, {T_T6, 2, 3, O_DIR}, {T_SAB, 3, 5, O_Z}, {T_DAC, 2, 8, O_ZP}};
+    for (const G &g : gs) {
+        st = gemm(ctx, false, false, rows, C, g.kb * C, T + g.tcol * C, ldt, 0, d.Wst + g.wpos * CC, C, 0, O + g.ocol * C, ldo, 0, 1, 0);
+        if (st != GF_OK) return st;
+    }
+    st = gemm(ctx, false, false, pairs, C, 4 * C, d.Vt, 4 * C, 0, d.Wst + 10 * CC, C, 0, d.Vout, C, 0, 1, 0);
+    if (st != GF_OK) return st;
+    st = gemm(ctx, false, false, nodes, C, 4 * C, d.St, 4 * C, 0, d.Wst + 14 * CC, C, 0, d.Sout, C, 0, 1, 0);
+    if (st != GF_OK) return st;
+    {
+        const size_t lds = combine_lds<16>(h.buckets.back().s);
+        static size_t granted = 0;
+        st = opt_in_lds(ctx, smp_combine_fwd<16>, lds, &granted);
+        if (st != GF_OK) return st;
+        GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd<16>), dim3((unsigned)(h.pairs * nwin)), dim3(kThreads), lds, O, d.adj,
+                  d.Vout, d.Sout, bl, d.f, ragged_for(d, 0, h.buckets.back().s), C, nwin);
+    }
+    return GF_OK;
+}
+
+// df_l is given in d.df; produces dP in s->P, accumulates dK_l and db_l; the caller then runs the promotion backward.
+gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl) {
+    gf_ctx *ctx = s->ctx;
+    const gfsmp::LevelLayout &h = s->lay.level[l];
+    const gf_smp::DevLevel &d = s->lv[l];
+    const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
+    const int rows = (int)h.rows, pairs = (int)h.pairs, nodes = h.nNodes;
+    float *T = d.Q, *dO = d.Q + (size_t)h.rows * T_COLS * C, *dT = dO + (size_t)h.rows * O_COLS * C;
+    const size_t CC = (size_t)C * C;
+    const int ldt = T_COLS * C, ldo = O_COLS * C;
+    gf_status st;
+    {
+        const size_t lds = combine_lds<16>(h.buckets.back().s);
+        static size_t granted = 0;
+        st = opt_in_lds(ctx, smp_combine_bwd<16>, lds, &granted);
+        if (st != GF_OK) return st;
+        GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.pairs * nwin)), dim3(kThreads), lds, d.f, d.df,
+                  d.adj, dO, d.dVout, d.dSpart, d.dbpart, ragged_for(d, 0, h.buckets.back().s), C, nwin);
+    }
+    GF_LAUNCH(ctx, "smpf_node_sum", smp_node_sum, dim3(nodes), dim3(64), 0, d.dSpart, d.dSout, d.node_s, d.node_pair, C);
+    // bias gradient: column sums of the per-(node,x) partials
+    {
+        const int rpb = 256, nb = (pairs + rpb - 1) / rpb;  // s->colpart holds (max rows / 1024 + 1) x C floats >= nb x C
+        GF_LAUNCH(ctx, "smpf_colsum", colsum_chunks, dim3(nb), dim3(64), 0, d.dbpart, s->colpart, C, (long long)pairs, rpb);
+        GF_LAUNCH(ctx, "smpf_colsum_fold", colsum_fold, dim3(1), dim3(256), 0, s->colpart, dbl, C, nb);
+    }
+    // weight gradients (stacked), then scatter-add into dK_l:  dW = T_blk^T dO_blk   (split-K over rows)
+    struct G { int tcol, kb, wpos, ocol; };
+    const G gs[5] = {{T_SAB, 2, 0, O_TOT}, {T_SAB, 1, 2, O_TR}, {T_T6, 2, 3, O_DIR}, {T_SAB, 3, 5, O_Z}, {T_DAC, 2, 8, O_ZP}};
+    for (const G &g : gs) {
+        st = gemm(ctx, true, false, g.kb * C, C, rows, T + g.tcol * C, ldt, 0, dO + g.ocol * C, ldo, 0, d.dWst + g.wpos * CC, C, 0, 1, 0);
+        if (st != GF_OK) return st;
+    }
+    st = gemm(ctx, true, false, 4 * C, C, pairs, d.Vt, 4 * C, 0, d.dVout, C, 0, d.dWst + 10 * CC, C, 0, 1, 0);
+    if (st != GF_OK) return st;
+    st = gemm(ctx, true, false, 4 * C, C, nodes, d.St, 4 * C, 0, d.dSout, C, 0, d.dWst + 14 * CC, C, 0, 1, 0);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, "smpf_unstack_dw", unstack_weight_grads, dim3(64), dim3(256), 0, d.dWst, dKl, C);
+    // table gradients: dT_blk (+)= dO_blk W_blk^T; every column range is written once before it is accumulated into
+    //   cols [C,4C) = dZ [K8;K12;K15]^T ; [C,3C) += dO_tot [K0;K2]^T ; [C,2C) += dO_tr K6^T ;
+    //   [0,C) = dZ' K16^T ; [C,2C) += dZ' K11^T ; [4C,6C) = dO_dir [K5;K9]^T
+    struct H { int ocol, wpos, kb, tcol, acc; };
+    const H hs[6] = {{O_Z, 5, 3, T_SAB, 0}, {O_TOT, 0, 2, T_SAB, 1}, {O_TR, 2, 1, T_SAB, 1},
+                     {O_ZP, 8, 1, T_DAC, 0}, {O_ZP, 9, 1, T_SAB, 1}, {O_DIR, 3, 2, T_T6, 0}};
+    for (const H &g : hs) {
+        st = gemm(ctx, false, true, rows, g.kb * C, C, dO + g.ocol * C, ldo, 0, d.Wst + g.wpos * CC, C, 0, dT + g.tcol * C, ldt, 0, 1, g.acc);
+        if (st != GF_OK) return st;
+    }
+    st = gemm(ctx, false, true, pairs, 4 * C, C, d.dVout, C, 0, d.Wst + 10 * CC, C, 0, d.dVt, 4 * C, 0, 1, 0);
+    if (st != GF_OK) return st;
+    st = gemm(ctx, false, true, nodes, 4 * C, C, d.dSout, C, 0, d.Wst + 14 * CC, C, 0, d.dSt, 4 * C, 0, 1, 0);
+    if (st != GF_OK) return st;
+    // rowsum_a / D8 were sums over b of S_ab / Dbb: their gradients broadcast back (handled inside tables-backward via dVt)
+    const std::vector<SizeClass> cls = classes_of(h, 4);
+    for (const SizeClass &c : cls) {
+        switch (c.ni) {
+            case 1: st = launch_tables_bwd<1>(s, l, c, dT); break;
+            case 2: st = launch_tables_bwd<2>(s, l, c, dT); break;
+            case 4: st = launch_tables_bwd<4>(s, l, c, dT); break;
+            default: st = launch_tables_bwd<8>(s, l, c, dT); break;
+        }
+        if (st != GF_OK) return st;
+    }
+    (void)Kl;
+    return GF_OK;
+}
+
+}  // namespace gf

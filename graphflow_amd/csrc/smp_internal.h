@@ -1,0 +1,55 @@
+// smp_internal.h -- state of one gf_smp handle, shared by smp.hip (op-by-op level pipeline) and smp_fused.hip.
+#ifndef GF_SMP_INTERNAL_H_INCLUDED
+#define GF_SMP_INTERNAL_H_INCLUDED
+
+#include <vector>
+
+#include "gf_internal.h"
+#include "smp_prep.h"
+
+namespace gf {
+gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *A, int lda, long long sA, const float *B,
+               int ldb, long long sB, float *C, int ldc, long long sC, int batch, int accumulate);
+}
+
+struct gf_smp {
+    gf_ctx *ctx = nullptr;
+    gfsmp::Config cfg;
+    gfsmp::BatchLayout lay;
+    bool prepared = false, forwarded = false;
+    int fused = 1;  // use the fused level path where supported (gf_smp_set_fused)
+    // device buffers (owned)
+    struct DevLevel {
+        int *node_s = nullptr;
+        long long *node_row = nullptr, *node_p = nullptr, *node_pair = nullptr;
+        float *adj = nullptr;
+        int *pair_node = nullptr, *pair_src_s = nullptr, *cons_s = nullptr;
+        long long *pair_src_row = nullptr, *cons_ptr = nullptr, *cons_slab = nullptr, *cons_inv_off = nullptr;
+        short *pi = nullptr, *inv = nullptr;
+        float *f = nullptr, *df = nullptr, *Q = nullptr;  // activations [rows][C], their gradient, contraction out [rows][18C]
+        // fused level (smp_fused.hip): small per-(node,x) / per-node tables and stacked weights
+        float *Vt = nullptr, *dVt = nullptr;        // [pairs][4C]  rowsum_a | colsum_b | D8 | D11
+        float *St = nullptr, *dSt = nullptr;        // [nodes][4C]  total | s14 | s15 | s18
+        float *scal = nullptr;                      // [pairs][4C]  partial scalars owned by (node, b)
+        float *Vout = nullptr, *dVout = nullptr;    // [pairs][C]
+        float *Sout = nullptr, *dSout = nullptr;    // [nodes][C]
+        float *dSpart = nullptr, *dbpart = nullptr; // [pairs][C]
+        float *Wst = nullptr, *dWst = nullptr;      // [18][C][C] block-permuted K_l and its gradient
+    };
+    std::vector<DevLevel> lv;
+    float *x = nullptr;      // [nVertices][FD]
+    float *P = nullptr;      // shared promotion / dP buffer, max over levels of ppos*C
+    float *sh = nullptr, *vf = nullptr;  // [nNodes][C] readout pre/post activation
+    float *g = nullptr;      // [nMol][C] graph features
+    float *yhat = nullptr, *dy = nullptr;  // [nMol]
+    float *colpart = nullptr;  // partial column sums for bias gradients
+    int *top_node_mol = nullptr, *mol_ptr = nullptr, *mol_nodes = nullptr;
+    std::vector<void *> allocs;
+};
+
+namespace gf {
+bool smp_fused_supported(const gf_smp *s, int l);
+gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float *bl);
+gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl);
+}
+#endif

@@ -54,6 +54,10 @@ class SMPOmega:
                                                 1 if accumulate else 0))
         return grads
 
+    def set_fused(self, on=True):
+        """Fused level kernels (default) vs the op-by-op pipeline; both give the same results within fp32 rounding."""
+        self.ctx.check(self.lib.gf_smp_set_fused(self.handle, 1 if on else 0))
+
     def receptive_field(self, mol, level, v):
         buf = (C.c_int * 4096)()
         n = self.lib.gf_smp_receptive_field(self.handle, mol, level, v, buf, 4096)

@@ -158,6 +158,9 @@ gf_status gf_smp_prepare(gf_smp *smp, int nMol, const int *nVertices, const int 
 gf_status gf_smp_forward(gf_smp *smp, const float *params, const float *targets, float *predict, float *loss,
                          float *graph_feature);
 gf_status gf_smp_backward(gf_smp *smp, const float *params, float *grads, int accumulate);
+/* 1 (default): fused level kernels (no promoted stack, no 18-slice contraction output in HBM) where the shape allows;
+ * 0: the op-by-op pipeline.  Same results within fp32 rounding; kept switchable for parity tests. */
+gf_status gf_smp_set_fused(gf_smp *smp, int on);
 gf_status gf_smp_prepare_molecule_host(const gf_smp_config *cfg, int V, const int *adj, const double *feature,
                                        int *phi_out, double *wl_out);  /* host only; phi_out [L+1][V][cap+1], slot 0 = size */
 int       gf_smp_receptive_field(const gf_smp *smp, int mol, int level, int v, int *out, int capacity);

@@ -17,9 +17,10 @@ def dev(x, dtype=np.float32):
     return torch.as_tensor(np.ascontiguousarray(x, dtype=dtype)).cuda()
 
 
-def run_batch(gf, mols, targets, params, L, C, F, D, cap, wl=True):
+def run_batch(gf, mols, targets, params, L, C, F, D, cap, wl=True, fused=True):
     from graphflow_amd.smp import SMPOmega
     net = SMPOmega(L, C, F, D, cap, wl)
+    net.set_fused(fused)
     net.prepare(mols)
     p = dev(params)
     pred, loss, feat = net.forward(p, dev(targets))
@@ -30,12 +31,13 @@ def run_batch(gf, mols, targets, params, L, C, F, D, cap, wl=True):
     return out
 
 
-def test_reference_goldens_one_molecule_at_a_time(gf, golden):
+@pytest.mark.parametrize("fused", [True, False])
+def test_reference_goldens_one_molecule_at_a_time(gf, golden, fused):
     cs = golden_cases(golden, "smp_")
     for tag, c in cs.items():
         L, C, D, cap, wl = (int(x) for x in c["cfg"])
         F = c["feature"].shape[1]
-        pred, loss, feat, grads, net = run_batch(gf, [(c["adj"], c["feature"])], c["target"], c["params"], L, C, F, D, cap, bool(wl))
+        pred, loss, feat, grads, net = run_batch(gf, [(c["adj"], c["feature"])], c["target"], c["params"], L, C, F, D, cap, bool(wl), fused=fused)
         V = len(c["adj"])
         for l in range(L + 1):
             for v in range(V):
@@ -67,8 +69,9 @@ def test_batch_equals_sum_of_molecules(gf, golden):
     assert rel_err(grads, sum(r["grads"] for r in ref)) <= TOL_GRAD
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("C,L,cap", [(8, 2, 6), (16, 3, 8), (64, 2, 12)])
-def test_synthetic_batch_vs_oracle(gf, C, L, cap):
+def test_synthetic_batch_vs_oracle(gf, C, L, cap, fused):
     from oracle import smp_oracle
     F, D = 5, 2
     mols, tg = [], []
@@ -77,7 +80,7 @@ def test_synthetic_batch_vs_oracle(gf, C, L, cap):
         mols.append((adj, feat))
         tg.append(t)
     params = smp_params(C, F, D, L, 7)
-    pred, loss, feat, grads, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    pred, loss, feat, grads, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap, fused=fused)
     ref = [smp_oracle.run(a, f, t, params, L, C, D, cap) for (a, f), t in zip(mols, tg)]
     assert rel_err(pred, np.array([r["predict"] for r in ref])) <= TOL_FWD
     assert rel_err(feat, np.stack([r["graph_feature"] for r in ref])) <= TOL_FWD
@@ -113,3 +116,18 @@ def test_forward_is_deterministic_and_backward_accumulates(gf):
     net.forward(p, t)
     net.backward(p, g2, accumulate=True)
     assert float((g2 - 2 * g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+
+
+def test_fused_and_op_by_op_levels_agree_at_scale(gf):
+    """64 channels, 3 levels, cap 29, 48 molecules up to 29 atoms: the fused level path against the op-by-op pipeline."""
+    F, D, C, L, cap = 5, 5, 64, 3, 29
+    mols, tg = [], []
+    for seed in range(48):
+        adj, feat, t = synthetic_molecule(500 + seed)
+        mols.append((adj, feat))
+        tg.append(t)
+    params = smp_params(C, F, D, L, 9)
+    p1, l1, f1, g1, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap, fused=True)
+    p0, l0, f0, g0, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap, fused=False)
+    assert rel_err(p1, p0) <= TOL_FWD and rel_err(f1, f0) <= TOL_FWD
+    assert rel_err(g1, g0) <= TOL_GRAD
