@@ -217,7 +217,7 @@ def main():
     world, rank, local = gd.env_world()
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
-    dist = gd.init(backend="nccl", device=dev) if world > 1 else None
+    dist = gd.init(backend="nccl", device=dev) if (world > 1 or os.environ.get("GF_FORCE_DIST")) else None
 
     if args.workload == "cfg2":
         ctx, step, finish, cpu, meta, keep = run_cfg2(args, torch, gf, dev, world, rank)

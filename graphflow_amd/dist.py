@@ -20,7 +20,7 @@ def shard(n_total, rank, world):
 def init(backend=None, device=None):
     import torch.distributed as dist
     world, rank, local = env_world()
-    if world == 1:
+    if world == 1 and not os.environ.get("GF_FORCE_DIST"):  # GF_FORCE_DIST=1: exercise the collective path with one rank
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
