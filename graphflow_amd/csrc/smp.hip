@@ -404,6 +404,9 @@ gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *a
         st = gf::upload(s, &d.node_pair, &h.node_pair[0], h.node_pair.size());
         if (st != GF_OK) return st;
         UP(d.adj, h.adj);
+        UP(d.rsum, h.rsum);
+        UP(d.quad_node, h.quad_node);
+        UP(d.quad_b0, h.quad_b0);
         UP(d.pair_node, h.pair_node);
         UP(d.pair_src_s, h.pair_src_s);
         UP(d.cons_s, h.cons_s);

@@ -89,6 +89,12 @@ __global__ __launch_bounds__(kThreads) void smp_tables_fwd(const float *__restri
         const int sw = pair_src_s[e];
         const short *map = sPi + a * N;
         const int pb = map[b];
+        if (pb < 0) {  // wave-uniform: row (a, b, :) of the promoted tensor is structurally zero -- nothing to fetch
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[i] = splat(0.f);
+            dg = splat(0.f);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int pc = (cc[i] >= 0) ? map[cc[i]] : -1;
@@ -189,6 +195,139 @@ __global__ __launch_bounds__(kThreads) void smp_tables_fwd(const float *__restri
             st4(s + 0 * C, cs);                                   // -> total
             st4(s + 2 * C, dbbtot);                               // -> s15 = sum_{a,b} P[a,b,b]
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// T1w: tables-forward for small receptive fields (s <= 4 NI, NI <= 4).  One WAVE per (node, b): a workgroup covers four
+// consecutive b of one node and shares the node's selection maps and row sums in LDS.  A wave walks all rows a of its
+// slab itself, so the sums over a stay in its registers: no cross-wave reduction, one barrier in the whole kernel.
+// (With workgroup-per-pair the fixed prologue/epilogue -- about ten barriers -- dominated when a wave owned <= 4 rows.)
+// ---------------------------------------------------------------------------------------------------------------
+template <int NI>
+__global__ __launch_bounds__(kThreads) void smp_tables_fwd_w(const float *__restrict__ fprev, const float *__restrict__ rsum,
+                                                             float *__restrict__ T, float *__restrict__ Vt,
+                                                             float *__restrict__ scal, const long long *__restrict__ pair_src_row,
+                                                             const int *__restrict__ pair_src_s, const short *__restrict__ pi,
+                                                             const int *__restrict__ quad_node, const int *__restrict__ quad_b0,
+                                                             const int *__restrict__ node_s, const long long *__restrict__ node_row,
+                                                             const long long *__restrict__ node_pair, int quad_base, int C, int nwin) {
+    constexpr int LPC = 16, PPW = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = lane / LPC, fl = lane % LPC;
+    const int q = quad_base + (int)(blockIdx.x / nwin), win = (int)(blockIdx.x % nwin);
+    const int n = quad_node[q];
+    const int N = node_s[n], b = quad_b0[q] + wave;
+    const size_t rowbase = (size_t)node_row[n], pairbase = (size_t)node_pair[n];
+    const int f = win * 64 + 4 * fl;
+    const bool fok = f < C;
+    const int fld = fok ? f : 0;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sR = smem;                                              // [N]
+    short *sPi = reinterpret_cast<short *>(smem + ((N + 3) & ~3));  // [N][N]
+    for (int i = tid; i < N; i += kThreads) sR[i] = rsum[pairbase + i];
+    for (int i = tid; i < N * N; i += kThreads) sPi[i] = pi[rowbase + i];
+    __syncthreads();
+    if (b >= N) return;
+
+    float rc[NI];
+    int cc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = i * PPW + cg;
+        cc[i] = (c < N) ? c : -1;
+        rc[i] = (c < N && fok) ? sR[c] : 0.f;
+    }
+    f4 sbc[NI], t10[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) sbc[i] = t10[i] = splat(0.f);
+    f4 dgsum = splat(0.f);
+
+    auto load_row = [&](int a, f4(&v)[NI], f4 &dg) {
+        const short *map = sPi + a * N;
+        const int pb = map[b];
+        if (pb < 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[i] = splat(0.f);
+            dg = splat(0.f);
+            return;
+        }
+        const long long e = (long long)pairbase + a;
+        const float *src = fprev + pair_src_row[e] * C + fld;
+        const int sw = pair_src_s[e];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int pc = (cc[i] >= 0) ? map[cc[i]] : -1;
+            const bool ok = pc >= 0 && fok;
+            const f4 x = ld4(src + (ok ? ((size_t)pb * sw + pc) * C : 0));
+            v[i] = ok ? x : splat(0.f);
+        }
+        const int pd = (cg == 0) ? pb : map[a];
+        const bool okd = cg < 2 && pd >= 0 && fok;
+        const f4 y = ld4(src + (okd ? ((size_t)pb * sw + pd) * C : 0));
+        dg = okd ? y : splat(0.f);
+    };
+
+    f4 cur[NI], nxt[NI], dcur, dnxt;
+    load_row(0, cur, dcur);
+    for (int a = 0; a < N; ++a) {
+        load_row(a + 1 < N ? a + 1 : a, nxt, dnxt);
+        const float ra = sR[a];
+        f4 sab = splat(0.f), t6 = splat(0.f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const f4 v = cur[i];
+            sbc[i] += v;
+            t10[i] += ra * v;
+            sab += v;
+            t6 += rc[i] * v;
+        }
+        sab = reduce_cgroups<LPC>(sab);
+        t6 = reduce_cgroups<LPC>(t6);
+        dgsum += dcur;
+        if (fok) {
+            float *trow = T + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + f;  // table row (a, b)
+            if (cg == 0) {
+                st4(trow + T_SAB * C, sab);
+                st4(trow + T_DBB * C, dcur);
+                if (a == b) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);
+            } else if (cg == 1) {
+                st4(trow + T_DAC * C, dcur);
+            } else if (cg == 2) {
+                st4(trow + T_T6 * C, t6);
+            } else if (cg == 3) {
+                if (a == b) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, sab);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) cur[i] = nxt[i];
+        dcur = dnxt;
+    }
+    f4 cs = splat(0.f);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (cc[i] >= 0) {
+            cs += sbc[i];
+            if (fok) {
+                float *trow = T + (rowbase + (size_t)b * N + cc[i]) * (size_t)(T_COLS * C) + f;  // table row (b, c)
+                st4(trow + T_SBC * C, sbc[i]);
+                st4(trow + T_T10 * C, t10[i]);
+            }
+        }
+    }
+    cs = reduce_cgroups<LPC>(cs);
+    // diagonal sums: lanes of c-group 0 hold sum_a P[a,b,b], c-group 1 holds sum_a P[a,b,a]
+    const f4 dactot = shfl_xor4(dgsum, 16);  // c-group 0 lanes receive c-group 1's sum
+    if (cg == 0 && fok) {
+        float *v = Vt + (pairbase + b) * 4 * (size_t)C + f;
+        st4(v + 1 * C, cs);
+        st4(v + 3 * C, dactot);
+        float *sc = scal + (pairbase + b) * 4 * (size_t)C + f;
+        st4(sc + 0 * C, cs);
+        st4(sc + 2 * C, dgsum);
     }
 }
 
@@ -394,7 +533,8 @@ __global__ void smp_node_sum(const float *__restrict__ part, float *__restrict__
 template <int LPC, int NI>
 __global__ __launch_bounds__(kThreads, 3) void smp_tables_bwd(const float *__restrict__ dT, const float *__restrict__ dVt,
                                                               const float *__restrict__ dSt, const float *__restrict__ A,
-                                                              float *__restrict__ dP, Ragged R, int C, int nwin) {
+                                                              float *__restrict__ dP, const short *__restrict__ pi, Ragged R,
+                                                              int C, int nwin) {
     constexpr int PPW = 64 / LPC;
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
@@ -415,6 +555,10 @@ __global__ __launch_bounds__(kThreads, 3) void smp_tables_bwd(const float *__res
     float *sG5 = sX + N * CW;
     float *sZ1 = sG5 + N * CW;
     float *sZ2 = sZ1 + N * CW;
+    // Selection maps of the node: dP[a][b][c] is only ever read by the consumer gather where pi_a(b) and pi_a(c) exist
+    // (the promoted tensor is zero elsewhere, about two thirds of it at QM9 sizes), so only those positions are written.
+    short *sPi = reinterpret_cast<short *>(sZ2 + N * CW);
+    for (int i = tid; i < N * N; i += kThreads) sPi[i] = pi[rowbase + i];
     {
         const float *ds = dSt + (size_t)W.node * 4 * C + fc;
         const f4 dtotal = ld4(ds + 0 * C), ds14 = ld4(ds + 1 * C), ds15 = ld4(ds + 2 * C), ds18 = ld4(ds + 3 * C);
@@ -440,13 +584,14 @@ __global__ __launch_bounds__(kThreads, 3) void smp_tables_bwd(const float *__res
 
     f4 yv[NI], g9[NI];
     float rc[NI];
-    int coff[NI];
+    int coff[NI], cxs[NI];
     bool live[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int c = i * PPW + cg;
         const bool ok = c < N;
         const int cx = ok ? c : 0;
+        cxs[i] = cx;
         live[i] = ok && fok;
         coff[i] = cx * C + fc;
         rc[i] = L.r[cx];
@@ -458,6 +603,8 @@ __global__ __launch_bounds__(kThreads, 3) void smp_tables_bwd(const float *__res
     float *dPg = dP + pbase * C + (size_t)b * N * C;
     const size_t rowStride = (size_t)N * N * C;
     for (int a = wave; a < N; a += kWaves) {
+        const short *map = sPi + a * N;
+        if (map[b] < 0) continue;  // wave-uniform: the whole row (a, b, :) of the promoted tensor is structurally zero
         float *row = dPg + a * rowStride;
         const f4 xa = ld4(sX + a * CW + 4 * fl), g5a = ld4(sG5 + a * CW + 4 * fl);
         const float ra = L.r[a];
@@ -469,7 +616,7 @@ __global__ __launch_bounds__(kThreads, 3) void smp_tables_bwd(const float *__res
             f4 o = xa + yv[i] + g5a * rc[i] + g9[i] * ra;
             if (i == ib) o += z1;
             if (i == ia) o += z2;
-            if (live[i]) st4(row + coff[i], o);
+            if (live[i] && map[cxs[i]] >= 0) st4(row + coff[i], o);
         }
     }
 }
@@ -477,7 +624,7 @@ __global__ __launch_bounds__(kThreads, 3) void smp_tables_bwd(const float *__res
 template <int LPC>
 size_t tables_bwd_lds(int N) {
     constexpr int CW = 4 * LPC;
-    return sizeof(float) * ((size_t)adj_lds_floats(N) + 4 * (size_t)N * CW);
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + 4 * (size_t)N * CW) + sizeof(short) * (size_t)N * N + 16;
 }
 template <int LPC>
 size_t combine_lds(int N) {
@@ -526,6 +673,25 @@ Ragged ragged_for(const gf_smp::DevLevel &d, long long lo, int smax) {
 }
 
 template <int NI>
+gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
+    gf_ctx *ctx = s->ctx;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const gfsmp::LevelLayout &h = s->lay.level[l];
+    const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
+    // quads of the class: nodes are sorted by size, so the class is a contiguous quad range
+    const int n_lo = h.pair_node[(size_t)c.lo], n_hi = (c.hi < (long long)h.pairs) ? h.pair_node[(size_t)c.hi] : h.nNodes;
+    int q_lo = 0, q_hi = (int)h.quad_node.size();
+    q_lo = (int)(std::lower_bound(h.quad_node.begin(), h.quad_node.end(), n_lo) - h.quad_node.begin());
+    q_hi = (int)(std::lower_bound(h.quad_node.begin(), h.quad_node.end(), n_hi) - h.quad_node.begin());
+    if (q_hi <= q_lo) return GF_OK;
+    const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + sizeof(short) * (size_t)c.smax * c.smax + 16;
+    GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
+              s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
+              d.node_row, d.node_pair, q_lo, C, nwin);
+    return GF_OK;
+}
+
+template <int NI>
 gf_status launch_tables_fwd(gf_smp *s, int l, const SizeClass &c) {
     gf_ctx *ctx = s->ctx;
     const gf_smp::DevLevel &d = s->lv[l];
@@ -549,7 +715,7 @@ gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *d
     gf_status st = opt_in_lds(ctx, smp_tables_bwd<16, NI>, lds, &granted);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smpf_tables_bwd", (smp_tables_bwd<16, NI>), dim3((unsigned)((c.hi - c.lo) * nwin)), dim3(kThreads), lds, dT,
-              d.dVt, d.dSt, d.adj, s->P, ragged_for(d, c.lo, c.smax), C, nwin);
+              d.dVt, d.dSt, d.adj, s->P, d.pi, ragged_for(d, c.lo, c.smax), C, nwin);
     return GF_OK;
 }
 
@@ -575,9 +741,9 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     const std::vector<SizeClass> cls = classes_of(h, 4);
     for (const SizeClass &c : cls) {
         switch (c.ni) {
-            case 1: st = launch_tables_fwd<1>(s, l, c); break;
-            case 2: st = launch_tables_fwd<2>(s, l, c); break;
-            case 4: st = launch_tables_fwd<4>(s, l, c); break;
+            case 1: st = launch_tables_fwd_w<1>(s, l, c); break;
+            case 2: st = launch_tables_fwd_w<2>(s, l, c); break;
+            case 4: st = launch_tables_fwd_w<4>(s, l, c); break;
             default: st = launch_tables_fwd<8>(s, l, c); break;
         }
         if (st != GF_OK) return st;

@@ -175,6 +175,9 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         LevelLayout &lv = out->level[l];
         const LevelLayout &prev = out->level[l - 1];
         lv.adj.assign((size_t)lv.rows, 0.f);
+        lv.rsum.assign((size_t)lv.pairs, 0.f);
+        lv.quad_node.clear();
+        lv.quad_b0.clear();
         lv.pair_node.assign((size_t)lv.pairs, 0);
         lv.pair_src_row.assign((size_t)lv.pairs, 0);
         lv.pair_src_s.assign((size_t)lv.pairs, 0);
@@ -190,6 +193,18 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 for (int j = 0; j < s; ++j)
                     lv.adj[(size_t)lv.node_row[n] + (size_t)i * s + j] =
                         (field[i] == field[j]) ? 1.f : (float)madj[field[i] * V + field[j]];
+            for (int i = 0; i < s; ++i) {  // gated row sums (RisiContraction_18.h:90: entries with A <= 0 are skipped)
+                float rs = 0.f;
+                for (int j = 0; j < s; ++j) {
+                    const float v = lv.adj[(size_t)lv.node_row[n] + (size_t)i * s + j];
+                    if (v > 0.f) rs += v;
+                }
+                lv.rsum[(size_t)lv.node_pair[n] + i] = rs;
+            }
+            for (int b0 = 0; b0 < s; b0 += 4) {
+                lv.quad_node.push_back(n);
+                lv.quad_b0.push_back(b0);
+            }
             for (int a = 0; a < s; ++a) {
                 const int w = field[a];
                 const int64_t e = lv.node_pair[n] + a;

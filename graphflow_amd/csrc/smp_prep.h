@@ -48,6 +48,9 @@ struct LevelLayout {
     std::vector<int> node_s, node_mol, node_vertex;
     std::vector<int64_t> node_row, node_p, node_pair;
     std::vector<float> adj;  // [rows] reduced adjacency, node-major [s][s]
+    std::vector<float> rsum; // [pairs] r[d] = sum_e A+[d][e] (A+ = A where A > 0), pair = node_pair[n] + d
+    // wave-per-pair kernels: one workgroup (4 waves) per group of 4 consecutive indices of one node
+    std::vector<int> quad_node, quad_b0;  // [quads]
     // forward gather (levels >= 1): per pair e = node_pair[n] + a
     std::vector<int> pair_node;        // [pairs]
     std::vector<int64_t> pair_src_row;  // [pairs] first row of the source node's tensor in level l-1
