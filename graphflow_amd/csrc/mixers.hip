@@ -10,7 +10,7 @@
 // staged through padded LDS, next tile's global loads issued before the current tile's MFMAs.  Reductions over a
 // long K with a small output (dB of the K-projection: K = sum s^2 rows) are split over K into a workspace and
 // summed by a second kernel in a fixed order, so results are deterministic (no atomics).
-#include "gf_internal.h"
+#include "smp_internal.h"
 
 namespace gf {
 namespace {
@@ -31,6 +31,24 @@ struct GemmArgs {
     int batch;
     int ntiles_n;
     int accumulate;        // C += result (only when not splitting)
+    // optional segmented K (grouped launches): K = sum of nseg pieces, piece s reads A + a_off[s], B + b_off[s] over
+    // klen[s] (a multiple of BK); nseg == 0 means the plain contiguous K of the fields above
+    long long split_stride;  // elements between consecutive split-K partial images of C
+    int nseg;
+    long long a_off[4], b_off[4];
+    int klen[4];
+};
+
+// Several GEMMs in ONE launch.  Tiles are ordered panel-major: all tiles of every group that belong to panel p (the
+// same rows of the shared operand, or the same split-K row range) are adjacent in the grid, so they run concurrently
+// and the shared operand is fetched from HBM once and hit in L2 by the others.
+constexpr int kMaxGroups = 8;
+struct GroupedArgs {
+    GemmArgs g[kMaxGroups];
+    int ngroups;
+    int tiles_per_panel;          // sum over groups of tiles in one panel
+    int tile_prefix[kMaxGroups];  // first tile of each group inside a panel
+    int panel_is_split;           // 0: panel = M tile (tile index = N tile); 1: panel = split (tile index = M tile, N tile 0)
 };
 
 // Position of k inside an LDS row: even k first, then odd k.  The f32 MFMA 32x32x2 gives lane (i, h = lane >> 5) the
@@ -45,19 +63,20 @@ __device__ __forceinline__ int kpos(int k) { return (k & 1) * (BK / 2) + (k >> 1
 // VEC: every operand is 16-byte aligned with leading dimensions and extents that are multiples of 4: global traffic
 // moves as float4 along each operand's contiguous direction and the C tile leaves through LDS as float4 rows.
 template <bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
+__device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0, int n0, int bz, int split, int splits) {
     float *As = smem, *Bs = smem + BM * LDS_ROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-    // tile order: the N tile varies fastest, so the workgroups that share one A row-panel run back to back and the
-    // panel is read from HBM once (dQ = dZ K^T has 18 N tiles per panel); M tiles can be millions (M = sum s^2)
-    const int ntn = g.ntiles_n;
-    const int m0 = (int)(blockIdx.x / ntn) * BM, n0 = (int)(blockIdx.x % ntn) * BN;
-    const int bz = blockIdx.z % g.batch, split = blockIdx.z / g.batch;
     const float *A = g.A + bz * g.sA, *B = g.B + bz * g.sB;
-    const int kbeg = split * g.kchunk;
-    const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    int kbeg = split * g.kchunk;
+    int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    int seg = 0;
+    if (g.nseg > 0) {  // segmented K: start on piece 0
+        A += g.a_off[0];
+        B += g.b_off[0];
+        kbeg = 0;
+        kend = g.klen[0];
+    }
 
     constexpr int NA = VEC ? 4 : 16, NB = VEC ? 2 : 8;  // loads per thread per tile
     f4v va[VEC ? NA : 1], vb[VEC ? NB : 1];
@@ -164,9 +183,20 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
         const float *a0p = As + (wm * 64 + li) * LDS_ROW + lh * (BK / 2);
         const float *a1p = a0p + 32 * LDS_ROW;
         const float *bp = Bs + (wn * 32 + li) * LDS_ROW + lh * (BK / 2);
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            const bool more = k0 + BK < kend;
-            if (more) load_tiles(k0 + BK);
+        int k0 = kbeg;
+        for (;;) {
+            // next tile: the following BK rows of this piece, or the first tile of the next piece
+            int kn = k0 + BK;
+            bool more = kn < kend;
+            if (!more && seg + 1 < g.nseg) {
+                ++seg;
+                A = g.A + bz * g.sA + g.a_off[seg];
+                B = g.B + bz * g.sB + g.b_off[seg];
+                kn = 0;
+                kend = g.klen[seg];
+                more = true;
+            }
+            if (more) load_tiles(kn);
             f4v fa0[4], fa1[4], fb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -180,16 +210,15 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j >> 2][j & 3], fb[j >> 2][j & 3], acc1, 0, 0, 0);
             }
             __syncthreads();
-            if (more) {
-                store_tiles();
-                __syncthreads();
-            }
+            if (!more) break;
+            store_tiles();
+            __syncthreads();
+            k0 = kn;
         }
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int splits = gridDim.z / g.batch;
-    float *C = g.C + (splits > 1 ? (size_t)split * g.M * g.ldc : (size_t)0) + bz * g.sC;
+    float *C = g.C + (splits > 1 ? (size_t)split * g.split_stride : (size_t)0) + bz * g.sC;
     if (VEC) {
         // stage 64 rows at a time in LDS (operand tiles are dead: the k-loop ended on a barrier), then 16 B row stores
         constexpr int LDC_S = BN + 4;
@@ -238,6 +267,31 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
     }
 }
 
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
+    // tile order: the N tile varies fastest, so the workgroups that share one A row-panel run back to back and the
+    // panel is read from HBM once (dQ = dZ K^T has 18 N tiles per panel); M tiles can be millions (M = sum s^2)
+    const int ntn = g.ntiles_n;
+    const int m0 = (int)(blockIdx.x / ntn) * BM, n0 = (int)(blockIdx.x % ntn) * BN;
+    gemm_tile<TA, TB, VEC>(g, smem, m0, n0, blockIdx.z % g.batch, blockIdx.z / g.batch, gridDim.z / g.batch);
+}
+
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(kThreads) void gemm_f32_mfma_grouped(GroupedArgs ga, int nsplits) {
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
+    const int panel = (int)(blockIdx.x / ga.tiles_per_panel), t = (int)(blockIdx.x % ga.tiles_per_panel);
+    int grp = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroups; ++i)
+        if (i < ga.ngroups && t >= ga.tile_prefix[i]) grp = i;
+    const int q = t - ga.tile_prefix[grp];
+    if (ga.panel_is_split)
+        gemm_tile<TA, TB, VEC>(ga.g[grp], smem, q * BM, 0, 0, panel, nsplits);
+    else
+        gemm_tile<TA, TB, VEC>(ga.g[grp], smem, panel * BM, q * BN, 0, 0, 1);
+}
+
 // dst[c][i] = sum of part[s][i] over the c-th chunk of splits (chunk = ceil(splits / gridDim.y)); with gridDim.y == 1 and
 // accumulate it is the final  C[i] (+)= sum_s part[s][i].  Two passes of this kernel fold thousands of split-K partials
 // with full-chip parallelism and a fixed summation order (chunks in order, splits in order inside a chunk).
@@ -273,6 +327,7 @@ gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sA = sA; g.sB = sB; g.sC = sC; g.batch = batch; g.accumulate = accumulate;
+    g.nseg = 0; g.split_stride = (long long)M * N;
     const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
     // split K when the output has too few tiles to fill 256 CUs and K is long (e.g. dB = A^T dC of the K-projection)
     int splits = 1;
@@ -331,6 +386,114 @@ gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *
         } else {
             GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part, C, n, splits, splits, accumulate);
         }
+    }
+    return GF_OK;
+}
+
+// ---- grouped launches -----------------------------------------------------------------------------------------
+// `specs` describe n <= kMaxGroups GEMMs (op flags shared).  rows_shared:
+//   panel_is_split == 0: every group has M == rows_shared (the row panels are shared; N tiles of all groups interleave)
+//   panel_is_split == 1: every group reduces over K == rows_shared (split-K row ranges are shared); the per-split
+//                        partial images are laid out [split][total] with group g at offset c_off[g]; `dest` receives
+//                        the ordered sum (total = sum M_g N_g contiguous floats).
+static bool spec_vec_ok(const GemmSpec &s, bool ta, bool tb) {
+    bool ok = (((uintptr_t)s.A | (uintptr_t)s.B | (uintptr_t)s.C) & 15) == 0 && (s.N % 4 == 0) && (!ta || s.M % 4 == 0) &&
+              (s.lda % 4 == 0) && (s.ldb % 4 == 0) && (s.ldc % 4 == 0);
+    if (s.nseg == 0) ok = ok && ((ta && !tb) || s.K % 4 == 0);
+    for (int i = 0; i < s.nseg; ++i) ok = ok && (s.klen[i] % BK == 0) && (s.a_off[i] % 4 == 0) && (s.b_off[i] % 4 == 0);
+    return ok;
+}
+
+static void fill_args(GemmArgs *g, const GemmSpec &s) {
+    g->A = s.A; g->B = s.B; g->C = s.C; g->M = s.M; g->N = s.N; g->K = s.K; g->lda = s.lda; g->ldb = s.ldb; g->ldc = s.ldc;
+    g->sA = g->sB = g->sC = 0; g->batch = 1; g->accumulate = 0; g->kchunk = s.K > 0 ? (s.K + BK - 1) / BK * BK : BK;
+    g->ntiles_n = (s.N + BN - 1) / BN; g->split_stride = 0; g->nseg = s.nseg;
+    for (int i = 0; i < 4; ++i) {
+        g->a_off[i] = s.a_off[i];
+        g->b_off[i] = s.b_off[i];
+        g->klen[i] = s.klen[i];
+    }
+}
+
+template <bool TA, bool TB>
+static gf_status launch_grouped(gf_ctx *ctx, const GroupedArgs &ga, unsigned grid, int nsplits, const char *name) {
+    GF_LAUNCH(ctx, name, (gemm_f32_mfma_grouped<TA, TB, true>), dim3(grid), dim3(kThreads), 0, ga, nsplits);
+    return GF_OK;
+}
+
+bool gemm_grouped_supported(const GemmSpec *specs, int n, bool ta, bool tb) {
+    if (n < 1 || n > kMaxGroups) return false;
+    for (int i = 0; i < n; ++i)
+        if (!spec_vec_ok(specs[i], ta, tb)) return false;
+    return true;
+}
+
+gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows) {
+    GroupedArgs ga;
+    ga.ngroups = n;
+    ga.panel_is_split = 0;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (specs[i].M != rows) return fail(ctx, GF_ERR_INVALID, "gemm_grouped_rows: group %d has M=%d, expected %d", i, specs[i].M, rows);
+        fill_args(&ga.g[i], specs[i]);
+        ga.tile_prefix[i] = tiles;
+        tiles += (specs[i].N + BN - 1) / BN;
+    }
+    for (int i = n; i < kMaxGroups; ++i) ga.tile_prefix[i] = 1 << 30;
+    ga.tiles_per_panel = tiles;
+    const unsigned grid = (unsigned)((size_t)((rows + BM - 1) / BM) * tiles);
+    if (!ta && !tb) return launch_grouped<false, false>(ctx, ga, grid, 1, "gemm_nn");
+    if (!ta && tb) return launch_grouped<false, true>(ctx, ga, grid, 1, "gemm_nt");
+    return fail(ctx, GF_ERR_UNSUPPORTED, "gemm_grouped_rows: transposed A is served by gemm_grouped_splitk");
+}
+
+gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int rows, float *dest, int accumulate) {
+    GroupedArgs ga;
+    ga.ngroups = n;
+    ga.panel_is_split = 1;
+    int tiles = 0;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (specs[i].K != rows || specs[i].N > BN)
+            return fail(ctx, GF_ERR_INVALID, "gemm_grouped_splitk: group %d must reduce over %d rows with N <= %d", i, rows, BN);
+        ga.tile_prefix[i] = tiles;
+        tiles += (specs[i].M + BM - 1) / BM;
+        total += (size_t)specs[i].M * specs[i].N;
+    }
+    for (int i = n; i < kMaxGroups; ++i) ga.tile_prefix[i] = 1 << 30;
+    ga.tiles_per_panel = tiles;
+    int splits = (4096 + tiles - 1) / tiles;
+    const int maxs = rows / (2 * BK);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    int kchunk = (rows + splits - 1) / splits;
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    splits = (rows + kchunk - 1) / kchunk;
+    const int chunk = 32, nchunks = (splits + chunk - 1) / chunk;
+    gf_status st = ensure_ws(ctx, sizeof(float) * ((size_t)splits + nchunks) * total + 256);
+    if (st != GF_OK) return st;
+    float *part = static_cast<float *>(ctx->ws);
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        fill_args(&ga.g[i], specs[i]);
+        ga.g[i].kchunk = kchunk;
+        ga.g[i].C = part + off;        // partial image of this group inside one split's block
+        ga.g[i].ldc = specs[i].N;
+        ga.g[i].split_stride = (long long)total;
+        off += (size_t)specs[i].M * specs[i].N;
+    }
+    const unsigned grid = (unsigned)((size_t)splits * tiles);
+    GF_LAUNCH(ctx, "gemm_tn", (gemm_f32_mfma_grouped<true, false, true>), dim3(grid), dim3(kThreads), 0, ga, splits + 1);
+    // (splits + 1: the tile function treats nsplits > 1 as "write partial images"; a single split still goes through
+    //  the ordered reduction below so the destination handling stays in one place)
+    size_t blocks = (total + 255) / 256;
+    const unsigned gx1 = (unsigned)(blocks > 4096 ? 4096 : blocks);
+    if (splits > 64) {
+        float *part2 = part + (size_t)splits * total;
+        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, nchunks), dim3(256), 0, part, part2, total, splits, chunk, 0);
+        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part2, dest, total, nchunks, nchunks, accumulate);
+    } else {
+        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part, dest, total, splits, splits, accumulate);
     }
     return GF_OK;
 }

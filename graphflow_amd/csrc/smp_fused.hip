@@ -753,12 +753,26 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C);
     const size_t CC = (size_t)C * C;
     const int ldt = T_COLS * C, ldo = O_COLS * C;
-    // block GEMMs: A = T column range, B = stacked weights, C = O column block
+    // block GEMMs: A = T column range, B = stacked weights, C = O column block -- one grouped launch (every row panel
+    // of T is fetched from HBM once and shared through L2 by the five products), separate launches as a fallback
     struct G { int tcol, kb, wpos, ocol; };
     const G gs[5] = {{T_SAB, 2, 0, O_TOT}, {T_SAB, 1, 2, O_TR}, {T_T6, 2, 3, O_DIR}, {T_SAB, 3, 5, O_Z}, {T_DAC, 2, 8, O_ZP}};
-    for (const G &g : gs) {
-        st = gemm(ctx, false, false, rows, C, g.kb * C, T + g.tcol * C, ldt, 0, d.Wst + g.wpos * CC, C, 0, O + g.ocol * C, ldo, 0, 1, 0);
-        if (st != GF_OK) return st;
+    {
+        GemmSpec sp[5];
+        for (int i = 0; i < 5; ++i) {
+            GemmSpec z = {T + gs[i].tcol * C, d.Wst + gs[i].wpos * CC, O + gs[i].ocol * C, rows, C, gs[i].kb * C, ldt, C, ldo, 0,
+                          {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            sp[i] = z;
+        }
+        if (gemm_grouped_supported(sp, 5, false, false)) {
+            st = gemm_grouped_rows(ctx, false, false, sp, 5, rows);
+            if (st != GF_OK) return st;
+        } else {
+            for (const G &g : gs) {
+                st = gemm(ctx, false, false, rows, C, g.kb * C, T + g.tcol * C, ldt, 0, d.Wst + g.wpos * CC, C, 0, O + g.ocol * C, ldo, 0, 1, 0);
+                if (st != GF_OK) return st;
+            }
+        }
     }
     st = gemm(ctx, false, false, pairs, C, 4 * C, d.Vt, 4 * C, 0, d.Wst + 10 * CC, C, 0, d.Vout, C, 0, 1, 0);
     if (st != GF_OK) return st;
@@ -801,12 +815,27 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         GF_LAUNCH(ctx, "smpf_colsum", colsum_chunks, dim3(nb), dim3(64), 0, d.dbpart, s->colpart, C, (long long)pairs, rpb);
         GF_LAUNCH(ctx, "smpf_colsum_fold", colsum_fold, dim3(1), dim3(256), 0, s->colpart, dbl, C, nb);
     }
-    // weight gradients (stacked), then scatter-add into dK_l:  dW = T_blk^T dO_blk   (split-K over rows)
+    // weight gradients (stacked), then scatter-add into dK_l:  dW = T_blk^T dO_blk   (split-K over rows).  Grouped: the
+    // five products share each split's row range of T and dO, and their partial images are folded by ONE ordered
+    // reduction straight into the first ten stacked blocks.
     struct G { int tcol, kb, wpos, ocol; };
     const G gs[5] = {{T_SAB, 2, 0, O_TOT}, {T_SAB, 1, 2, O_TR}, {T_T6, 2, 3, O_DIR}, {T_SAB, 3, 5, O_Z}, {T_DAC, 2, 8, O_ZP}};
-    for (const G &g : gs) {
-        st = gemm(ctx, true, false, g.kb * C, C, rows, T + g.tcol * C, ldt, 0, dO + g.ocol * C, ldo, 0, d.dWst + g.wpos * CC, C, 0, 1, 0);
-        if (st != GF_OK) return st;
+    {
+        GemmSpec sp[5];
+        for (int i = 0; i < 5; ++i) {
+            GemmSpec z = {T + gs[i].tcol * C, dO + gs[i].ocol * C, d.dWst + gs[i].wpos * CC, gs[i].kb * C, C, rows, ldt, ldo, C, 0,
+                          {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            sp[i] = z;
+        }
+        if (C <= 64 && gemm_grouped_supported(sp, 5, true, false)) {
+            st = gemm_grouped_splitk(ctx, sp, 5, rows, d.dWst, 0);  // stack positions 0..9 are contiguous in dWst
+            if (st != GF_OK) return st;
+        } else {
+            for (const G &g : gs) {
+                st = gemm(ctx, true, false, g.kb * C, C, rows, T + g.tcol * C, ldt, 0, dO + g.ocol * C, ldo, 0, d.dWst + g.wpos * CC, C, 0, 1, 0);
+                if (st != GF_OK) return st;
+            }
+        }
     }
     st = gemm(ctx, true, false, 4 * C, C, pairs, d.Vt, 4 * C, 0, d.dVout, C, 0, d.dWst + 10 * CC, C, 0, 1, 0);
     if (st != GF_OK) return st;
@@ -816,12 +845,30 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     // table gradients: dT_blk (+)= dO_blk W_blk^T; every column range is written once before it is accumulated into
     //   cols [C,4C) = dZ [K8;K12;K15]^T ; [C,3C) += dO_tot [K0;K2]^T ; [C,2C) += dO_tr K6^T ;
     //   [0,C) = dZ' K16^T ; [C,2C) += dZ' K11^T ; [4C,6C) = dO_dir [K5;K9]^T
-    struct H { int ocol, wpos, kb, tcol, acc; };
-    const H hs[6] = {{O_Z, 5, 3, T_SAB, 0}, {O_TOT, 0, 2, T_SAB, 1}, {O_TR, 2, 1, T_SAB, 1},
-                     {O_ZP, 8, 1, T_DAC, 0}, {O_ZP, 9, 1, T_SAB, 1}, {O_DIR, 3, 2, T_T6, 0}};
-    for (const H &g : hs) {
-        st = gemm(ctx, false, true, rows, g.kb * C, C, dO + g.ocol * C, ldo, 0, d.Wst + g.wpos * CC, C, 0, dT + g.tcol * C, ldt, 0, 1, g.acc);
-        if (st != GF_OK) return st;
+    {
+        // grouped: one group per output column block of dT, K segmented over the dO blocks that feed it (no read-modify-
+        // write of dT, dO read once per panel); fallback: six launches that accumulate in a fixed order
+        const long long oC = C, wCC = (long long)CC;
+        GemmSpec sp[5] = {
+            {dO, d.Wst, dT + T_DAC * C, rows, C, C, ldo, C, ldt, 1, {O_ZP * oC, 0, 0, 0}, {8 * wCC, 0, 0, 0}, {C, 0, 0, 0}},
+            {dO, d.Wst, dT + T_SAB * C, rows, C, 4 * C, ldo, C, ldt, 4, {O_TOT * oC, O_TR * oC, O_Z * oC, O_ZP * oC},
+             {0 * wCC, 2 * wCC, 5 * wCC, 9 * wCC}, {C, C, C, C}},
+            {dO, d.Wst, dT + T_SBC * C, rows, C, 2 * C, ldo, C, ldt, 2, {O_TOT * oC, O_Z * oC, 0, 0}, {1 * wCC, 6 * wCC, 0, 0}, {C, C, 0, 0}},
+            {dO, d.Wst, dT + T_DBB * C, rows, C, C, ldo, C, ldt, 1, {O_Z * oC, 0, 0, 0}, {7 * wCC, 0, 0, 0}, {C, 0, 0, 0}},
+            {dO, d.Wst, dT + T_T6 * C, rows, 2 * C, C, ldo, C, ldt, 1, {O_DIR * oC, 0, 0, 0}, {3 * wCC, 0, 0, 0}, {C, 0, 0, 0}},
+        };
+        if (gemm_grouped_supported(sp, 5, false, true)) {
+            st = gemm_grouped_rows(ctx, false, true, sp, 5, rows);
+            if (st != GF_OK) return st;
+        } else {
+            struct H { int ocol, wpos, kb, tcol, acc; };
+            const H hs[6] = {{O_Z, 5, 3, T_SAB, 0}, {O_TOT, 0, 2, T_SAB, 1}, {O_TR, 2, 1, T_SAB, 1},
+                             {O_ZP, 8, 1, T_DAC, 0}, {O_ZP, 9, 1, T_SAB, 1}, {O_DIR, 3, 2, T_T6, 0}};
+            for (const H &g : hs) {
+                st = gemm(ctx, false, true, rows, g.kb * C, C, dO + g.ocol * C, ldo, 0, d.Wst + g.wpos * CC, C, 0, dT + g.tcol * C, ldt, 0, 1, g.acc);
+                if (st != GF_OK) return st;
+            }
+        }
     }
     st = gemm(ctx, false, true, pairs, 4 * C, C, d.dVout, C, 0, d.Wst + 10 * CC, C, 0, d.dVt, 4 * C, 0, 1, 0);
     if (st != GF_OK) return st;

@@ -10,6 +10,18 @@
 namespace gf {
 gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *A, int lda, long long sA, const float *B,
                int ldb, long long sB, float *C, int ldc, long long sC, int batch, int accumulate);
+// one GEMM of a grouped launch (mixers.hip): op(A)[M,K] op(B)[K,N] -> C[M,N]; nseg > 0 splits K into pieces
+struct GemmSpec {
+    const float *A, *B;
+    float *C;
+    int M, N, K, lda, ldb, ldc;
+    int nseg;
+    long long a_off[4], b_off[4];
+    int klen[4];
+};
+bool gemm_grouped_supported(const GemmSpec *specs, int n, bool ta, bool tb);
+gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows);
+gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int rows, float *dest, int accumulate);
 }
 
 struct gf_smp {
