@@ -268,7 +268,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
 }
 
 template <bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
+__global__ __launch_bounds__(kThreads, 4) void gemm_f32_mfma(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
     // tile order: the N tile varies fastest, so the workgroups that share one A row-panel run back to back and the
     // panel is read from HBM once (dQ = dZ K^T has 18 N tiles per panel); M tiles can be millions (M = sum s^2)
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(GemmArgs g) {
 }
 
 template <bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(kThreads) void gemm_f32_mfma_grouped(GroupedArgs ga, int nsplits) {
+__global__ __launch_bounds__(kThreads, 4) void gemm_f32_mfma_grouped(GroupedArgs ga, int nsplits) {
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
     const int panel = (int)(blockIdx.x / ga.tiles_per_panel), t = (int)(blockIdx.x % ga.tiles_per_panel);
     int grp = 0;
