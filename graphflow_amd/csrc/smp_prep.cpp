@@ -4,11 +4,35 @@
 #include "smp_prep.h"
 
 #include <algorithm>
-#include <map>
+#include <cstdlib>
+#include <thread>
 #include <utility>
 
 namespace gfsmp {
 namespace {
+
+// fn(i) for i in [0, n) on up to GF_PREP_THREADS (default: hardware concurrency, at most 16) host threads; every
+// iteration writes disjoint memory, so the result does not depend on the thread count.
+template <typename Fn>
+void parallel_for(int n, const Fn &fn) {
+    int nt = (int)std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("GF_PREP_THREADS")) nt = std::atoi(e);
+    nt = std::max(1, std::min(nt, 16));
+    if (n < 64 || nt == 1) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const int chunk = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int lo = t * chunk, hi = std::min(n, lo + chunk);
+        if (lo >= hi) break;
+        pool.emplace_back([lo, hi, &fn]() {
+            for (int i = lo; i < hi; ++i) fn(i);
+        });
+    }
+    for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
+}
 
 const int kInf = 1000000000;  // SMP_omega.h:1064
 
@@ -120,11 +144,11 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
     }
     const int totalV = out->mol_first_vertex[nMol];
     out->x.assign((size_t)totalV * FD, 0.f);
-    for (int m = 0; m < nMol; ++m) {
+    parallel_for(nMol, [&](int m) {
         const int V = nVertices[m], v0 = out->mol_first_vertex[m];
         prepare_molecule(cfg, V, adj + adj_off[m], feature + (size_t)v0 * F, &out->mols[m]);
         for (size_t i = 0; i < (size_t)V * FD; ++i) out->x[(size_t)v0 * FD + i] = (float)out->mols[m].wl[i];
-    }
+    });
 
     out->level.assign(L + 1, LevelLayout());
     // node numbering per level: level 0 in (molecule, vertex) order; level >= 1 bucketed by field size (stable)
@@ -182,8 +206,13 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         lv.pair_src_row.assign((size_t)lv.pairs, 0);
         lv.pair_src_s.assign((size_t)lv.pairs, 0);
         lv.pi.assign((size_t)lv.rows, (int16_t)-1);
-        std::vector<std::vector<int64_t> > consumers(prev.nNodes);  // source node -> list of pair ids
-        for (int n = 0; n < lv.nNodes; ++n) {
+        std::vector<int> pair_src_node((size_t)lv.pairs, 0);
+        for (int n = 0; n < lv.nNodes; ++n)
+            for (int b0 = 0; b0 < lv.node_s[n]; b0 += 4) {
+                lv.quad_node.push_back(n);
+                lv.quad_b0.push_back(b0);
+            }
+        parallel_for(lv.nNodes, [&](int n) {
             const int m = lv.node_mol[n], v = lv.node_vertex[n], s = lv.node_s[n];
             const int V = nVertices[m], v0 = out->mol_first_vertex[m];
             const int *madj = adj + adj_off[m];
@@ -196,14 +225,10 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
             for (int i = 0; i < s; ++i) {  // gated row sums (RisiContraction_18.h:90: entries with A <= 0 are skipped)
                 float rs = 0.f;
                 for (int j = 0; j < s; ++j) {
-                    const float v = lv.adj[(size_t)lv.node_row[n] + (size_t)i * s + j];
-                    if (v > 0.f) rs += v;
+                    const float av = lv.adj[(size_t)lv.node_row[n] + (size_t)i * s + j];
+                    if (av > 0.f) rs += av;
                 }
                 lv.rsum[(size_t)lv.node_pair[n] + i] = rs;
-            }
-            for (int b0 = 0; b0 < s; b0 += 4) {
-                lv.quad_node.push_back(n);
-                lv.quad_b0.push_back(b0);
             }
             for (int a = 0; a < s; ++a) {
                 const int w = field[a];
@@ -211,6 +236,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 const int src = node_of[l - 1][v0 + w];
                 const std::vector<int> &wf = out->mols[m].phi[l - 1][w];
                 lv.pair_node[(size_t)e] = n;
+                pair_src_node[(size_t)e] = src;
                 lv.pair_src_row[(size_t)e] = prev.node_row[src];
                 lv.pair_src_s[(size_t)e] = (int)wf.size();
                 // selection map: X[i][k] = [phi_l(v)[i] == phi_{l-1}(w)[k]]   (:461-474)
@@ -218,33 +244,39 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                     const std::vector<int>::const_iterator it = std::find(wf.begin(), wf.end(), field[p]);
                     lv.pi[(size_t)lv.node_row[n] + (size_t)a * s + p] = (it == wf.end()) ? (int16_t)-1 : (int16_t)(it - wf.begin());
                 }
-                consumers[src].push_back(e);
             }
-        }
-        // inverse index for the backward gather
+        });
+        // inverse index for the backward gather: consumers of a source node in increasing pair order (= fixed
+        // summation order on the device), offsets by prefix sums, then a parallel fill
         lv.cons_ptr.assign((size_t)prev.nNodes + 1, 0);
-        lv.cons_slab.clear();
-        lv.cons_s.clear();
-        lv.cons_inv_off.clear();
-        lv.inv.clear();
-        for (int w = 0; w < prev.nNodes; ++w) {
-            const int sw = prev.node_s[w];
-            for (size_t c = 0; c < consumers[w].size(); ++c) {
-                const int64_t e = consumers[w][c];
+        for (int64_t e = 0; e < lv.pairs; ++e) lv.cons_ptr[(size_t)pair_src_node[(size_t)e] + 1] += 1;
+        for (int w = 0; w < prev.nNodes; ++w) lv.cons_ptr[(size_t)w + 1] += lv.cons_ptr[(size_t)w];
+        std::vector<int64_t> cons_pair((size_t)lv.pairs), cursor(lv.cons_ptr.begin(), lv.cons_ptr.end() - 1);
+        for (int64_t e = 0; e < lv.pairs; ++e) cons_pair[(size_t)cursor[(size_t)pair_src_node[(size_t)e]]++] = e;
+        lv.cons_slab.assign((size_t)lv.pairs, 0);
+        lv.cons_s.assign((size_t)lv.pairs, 0);
+        lv.cons_inv_off.assign((size_t)lv.pairs, 0);
+        int64_t inv_total = 0;
+        for (int w = 0; w < prev.nNodes; ++w)
+            for (int64_t c = lv.cons_ptr[(size_t)w]; c < lv.cons_ptr[(size_t)w + 1]; ++c) {
+                lv.cons_inv_off[(size_t)c] = inv_total;
+                inv_total += prev.node_s[w];
+            }
+        lv.inv.assign((size_t)inv_total, (int16_t)-1);
+        parallel_for(prev.nNodes, [&](int w) {
+            for (int64_t c = lv.cons_ptr[(size_t)w]; c < lv.cons_ptr[(size_t)w + 1]; ++c) {
+                const int64_t e = cons_pair[(size_t)c];
                 const int n = lv.pair_node[(size_t)e];
                 const int s = lv.node_s[n], a = (int)(e - lv.node_pair[n]);
-                lv.cons_slab.push_back(lv.node_p[n] + (int64_t)a * s * s);
-                lv.cons_s.push_back(s);
-                lv.cons_inv_off.push_back((int64_t)lv.inv.size());
-                const size_t base = lv.inv.size();
-                lv.inv.resize(base + sw, (int16_t)-1);
+                lv.cons_slab[(size_t)c] = lv.node_p[n] + (int64_t)a * s * s;
+                lv.cons_s[(size_t)c] = s;
+                int16_t *iv = &lv.inv[(size_t)lv.cons_inv_off[(size_t)c]];
                 for (int p = 0; p < s; ++p) {
                     const int16_t k = lv.pi[(size_t)lv.node_row[n] + (size_t)a * s + p];
-                    if (k >= 0) lv.inv[base + k] = (int16_t)p;
+                    if (k >= 0) iv[k] = (int16_t)p;
                 }
             }
-            lv.cons_ptr[(size_t)w + 1] = (int64_t)lv.cons_slab.size();
-        }
+        });
     }
 }
 
