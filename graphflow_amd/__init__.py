@@ -5,8 +5,9 @@ graphflow_amd/host/.  This Python package is plumbing for tests and benchmarks: 
 streams, every op call goes straight through the C ABI.  Nothing here computes on the CPU.
 """
 from . import _lib
-from .ops import (Context, GraphFlowHipError, contract_backward, contract_forward,  # noqa: F401
-                  contract_workspace_bytes, default_context, matmul_backward, matmul_forward,
+from .ops import (Context, GraphFlowHipError, contract18_dropout_backward, contract18_dropout_forward,  # noqa: F401
+                  contract_backward, contract_forward, contract_workspace_bytes, custommatmultensor_backward,
+                  custommatmultensor_forward, default_context, matmul_backward, matmul_forward,
                   mattensormul_backward, mattensormul_forward, stack_backward, stack_forward,
                   tensormatmul_backward, tensormatmul_forward)
 

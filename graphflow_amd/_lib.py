@@ -40,11 +40,21 @@ PROTOTYPES = {
 }
 
 _i = C.c_int
+PROTOTYPES.update({
+    "gf_contract18_dropout_forward_f32": (_i, [_vp, C.c_uint, C.c_float, _vp, _vp, _vp, _i, _i, _i]),
+    "gf_contract18_dropout_backward_f32": (_i, [_vp, C.c_uint, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "gf_contract18_dropout_forward_host_f64": (_i, [_vp, C.c_uint, C.c_double, C.POINTER(_dp), _dp, _dp, _i, _i]),
+    "gf_contract18_dropout_backward_host_f64": (_i, [_vp, C.c_uint, _dp, _dp, C.POINTER(_dp), _i, _i]),
+    "gf_contract18_dropout_forward_host_f32": (_i, [_vp, C.c_uint, C.c_double, C.POINTER(_fp), _fp, _fp, _i, _i]),
+    "gf_contract18_dropout_backward_host_f32": (_i, [_vp, C.c_uint, _fp, _fp, C.POINTER(_fp), _i, _i]),
+})
 for _sfx, _t in (("f64", _dp), ("f32", _fp)):
     PROTOTYPES["gf_matmul_forward_host_" + _sfx] = (_i, [_vp, _t, _t, _t, _i, _i, _i])
     PROTOTYPES["gf_stack_forward_host_" + _sfx] = (_i, [_vp, C.POINTER(_t), _t, _i, C.c_size_t])
     PROTOTYPES["gf_stack_backward_host_" + _sfx] = (_i, [_vp, _t, C.POINTER(_t), _i, C.c_size_t])
     PROTOTYPES["gf_matmul_backward_host_" + _sfx] = (_i, [_vp, _t, _t, _t, _t, _t, _i, _i, _i])
+    PROTOTYPES["gf_custommatmultensor_forward_host_" + _sfx] = (_i, [_vp, _t, _t, _t, C.c_longlong, _i, _i])
+    PROTOTYPES["gf_custommatmultensor_backward_host_" + _sfx] = (_i, [_vp, _t, _t, _t, _t, _t, C.c_longlong, _i, _i])
     for _op in ("mattensormul", "tensormatmul"):
         PROTOTYPES["gf_%s_forward_host_%s" % (_op, _sfx)] = (_i, [_vp, _t, _t, _t, _i, _i, _i, _i])
         PROTOTYPES["gf_%s_backward_host_%s" % (_op, _sfx)] = (_i, [_vp, _t, _t, _t, _t, _t, _i, _i, _i, _i])
@@ -55,12 +65,16 @@ PROTOTYPES.update({
     "gf_mattensormul_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gf_tensormatmul_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "gf_tensormatmul_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gf_custommatmultensor_forward_f32": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i]),
+    "gf_custommatmultensor_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i]),
     "gf_smp_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "gf_smp_destroy": (_i, [_vp]),
     "gf_smp_param_count": (C.c_size_t, [_vp]),
     "gf_smp_prepare": (_i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
     "gf_smp_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gf_smp_backward": (_i, [_vp, _vp, _vp, _i]),
+    "gf_smp_save_model": (_i, [_vp, _vp, C.c_char_p]),
+    "gf_smp_load_model": (_i, [_vp, _vp, C.c_char_p]),
     "gf_smp_set_fused": (_i, [_vp, _i]),
     "gf_smp_prepare_molecule_host": (_i, [_vp, _i, C.POINTER(C.c_int), _dp, C.POINTER(C.c_int), _dp]),
     "gf_smp_receptive_field": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int), _i]),

@@ -116,6 +116,22 @@ __global__ void cast_from_f32(const float *__restrict__ in, T *__restrict__ out,
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = (T)in[i];
 }
+// RisiContraction_18_dropout: per-slice factors (0 for a dropped slice) applied to an [.., 18, C] buffer
+struct SliceFactors {
+    float f[18];
+};
+__global__ void slice_scale(const float *__restrict__ in, float *__restrict__ out, size_t n, int C, SliceFactors fac) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float w = fac.f[(i / C) % 18];
+        out[i] = w == 0.f ? 0.f : in[i] * w;  // a dropped slice is exactly 0 even if the input is not finite
+    }
+}
+SliceFactors slice_factors(unsigned keep_mask, float scale) {
+    SliceFactors fac;
+    for (int k = 0; k < 18; ++k) fac.f[k] = ((keep_mask >> k) & 1u) ? scale : 0.f;
+    return fac;
+}
+
 unsigned cast_grid(size_t n) {
     size_t b = (n + 255) / 256;
     return (unsigned)(b > 8192 ? 8192 : (b ? b : 1));
@@ -192,6 +208,30 @@ gf_status contract_backward_host(gf_ctx *ctx, int K, const T *out_gradient, cons
     return GF_OK;
 }
 
+
+template <typename T>
+gf_status dropout_forward_host(gf_ctx *ctx, unsigned keep_mask, double scale, const T *const *tensors, const T *A, T *out_value,
+                               int N, int C) {
+    gf_status st = contract_forward_host<T>(ctx, 18, tensors, A, out_value, N, C);
+    if (st != GF_OK) return st;
+    const size_t n = (size_t)N * N * 18 * C;
+    for (size_t i = 0; i < n; ++i) {
+        if (!((keep_mask >> ((i / C) % 18)) & 1u)) out_value[i] = 0;
+        else if (scale != 1.0) out_value[i] = (T)(out_value[i] * scale);
+    }
+    return GF_OK;
+}
+
+template <typename T>
+gf_status dropout_backward_host(gf_ctx *ctx, unsigned keep_mask, const T *out_gradient, const T *A, T *const *grads, int N,
+                                int C) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!out_gradient || N <= 0 || C <= 0) return fail(ctx, GF_ERR_INVALID, "dropout_backward_host: bad argument");
+    const size_t n = (size_t)N * N * 18 * C;
+    std::vector<T> g(n);
+    for (size_t i = 0; i < n; ++i) g[i] = ((keep_mask >> ((i / C) % 18)) & 1u) ? out_gradient[i] : (T)0;
+    return contract_backward_host<T>(ctx, 18, g.data(), A, grads, N, C);
+}
 
 // ---- generic host-pointer staging for the mixers (mode A) -----------------------------------------------------
 // Declare the operands of one op call; begin() packs the inputs into pinned memory, uploads them in one copy and
@@ -331,6 +371,37 @@ gf_status tensormul_backward_host(gf_ctx *ctx, int which, const T *G, const T *f
     float *p1 = d1 ? s.dev(o1) : nullptr, *p2 = d2 ? s.dev(o2) : nullptr;
     st = which == 0 ? gf_mattensormul_backward_f32(ctx, s.dev(g), s.dev(a), s.dev(b), p1, p2, R, Kd, J, D, 0)
                     : gf_tensormatmul_backward_f32(ctx, s.dev(g), s.dev(a), s.dev(b), p1, p2, R, Kd, J, D, 0);
+    if (st != GF_OK) return st;
+    return s.end();
+}
+
+template <typename T>
+gf_status custommatmultensor_forward_host(gf_ctx *ctx, const T *W, const T *X, T *Out, long long rows, int V, int Kout) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!W || !X || !Out || rows <= 0 || V <= 0 || Kout <= 0)
+        return fail(ctx, GF_ERR_INVALID, "custommatmultensor_forward_host: bad argument");
+    HostStaging<T> s(ctx);
+    const int w = s.in(W, (size_t)Kout * V), x = s.in(X, (size_t)rows * V), o = s.out(Out, (size_t)rows * Kout);
+    gf_status st = s.begin();
+    if (st != GF_OK) return st;
+    st = gf_custommatmultensor_forward_f32(ctx, s.dev(w), s.dev(x), s.dev(o), rows, V, Kout);
+    if (st != GF_OK) return st;
+    return s.end();
+}
+
+template <typename T>
+gf_status custommatmultensor_backward_host(gf_ctx *ctx, const T *G, const T *W, const T *X, T *dW, T *dX, long long rows,
+                                           int V, int Kout) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!G || !W || !X || rows <= 0 || V <= 0 || Kout <= 0)
+        return fail(ctx, GF_ERR_INVALID, "custommatmultensor_backward_host: bad argument");
+    HostStaging<T> s(ctx);
+    const int g = s.in(G, (size_t)rows * Kout), w = s.in(W, (size_t)Kout * V), x = s.in(X, (size_t)rows * V);
+    const int ow = dW ? s.out_add(dW, (size_t)Kout * V) : -1, ox = dX ? s.out_add(dX, (size_t)rows * V) : -1;
+    gf_status st = s.begin();
+    if (st != GF_OK) return st;
+    st = gf_custommatmultensor_backward_f32(ctx, s.dev(g), s.dev(w), s.dev(x), dW ? s.dev(ow) : nullptr,
+                                            dX ? s.dev(ox) : nullptr, rows, V, Kout, 0);
     if (st != GF_OK) return st;
     return s.end();
 }
@@ -505,6 +576,49 @@ gf_status gf_contract_backward_f32(gf_ctx *ctx, int K, const float *G, const flo
     }
 }
 
+gf_status gf_contract18_dropout_forward_f32(gf_ctx *ctx, unsigned keep_mask, float scale, const float *P, const float *A,
+                                            float *Out, int N, int C, int batch) {
+    gf_status st = gf_contract_forward_f32(ctx, 18, P, A, Out, N, C, batch);
+    if (st != GF_OK || batch == 0) return st;
+    if ((keep_mask & 0x3ffffu) == 0x3ffffu && scale == 1.f) return GF_OK;
+    const size_t n = (size_t)batch * N * N * 18 * C;
+    GF_LAUNCH(ctx, "slice_scale", gf::slice_scale, dim3(gf::cast_grid(n)), dim3(256), 0, Out, Out, n, C,
+              gf::slice_factors(keep_mask, scale));
+    return GF_OK;
+}
+
+gf_status gf_contract18_dropout_backward_f32(gf_ctx *ctx, unsigned keep_mask, const float *G, const float *A, float *dP,
+                                             int N, int C, int batch, int accumulate) {
+    gf_status st = gf::check_contract_args(ctx, 18, G, A, dP, N, C, batch);
+    if (st != GF_OK || batch == 0) return st;
+    if ((keep_mask & 0x3ffffu) == 0x3ffffu) return gf_contract_backward_f32(ctx, 18, G, A, dP, N, C, batch, accumulate);
+    // dropped slices contribute nothing (RisiContraction_18_dropout.h:498-783 skips them): masked copy of G, then the plain vjp
+    const size_t n = (size_t)batch * N * N * 18 * C;
+    st = gf::ensure_stage(ctx, n * sizeof(float));
+    if (st != GF_OK) return st;
+    float *Gm = static_cast<float *>(ctx->stage);
+    GF_LAUNCH(ctx, "slice_scale", gf::slice_scale, dim3(gf::cast_grid(n)), dim3(256), 0, G, Gm, n, C,
+              gf::slice_factors(keep_mask, 1.f));
+    return gf_contract_backward_f32(ctx, 18, Gm, A, dP, N, C, batch, accumulate);
+}
+
+gf_status gf_contract18_dropout_forward_host_f64(gf_ctx *ctx, unsigned keep_mask, double scale, const double *const *tensors,
+                                                 const double *A, double *out_value, int N, int C) {
+    return gf::dropout_forward_host<double>(ctx, keep_mask, scale, tensors, A, out_value, N, C);
+}
+gf_status gf_contract18_dropout_backward_host_f64(gf_ctx *ctx, unsigned keep_mask, const double *out_gradient, const double *A,
+                                                  double *const *grads, int N, int C) {
+    return gf::dropout_backward_host<double>(ctx, keep_mask, out_gradient, A, grads, N, C);
+}
+gf_status gf_contract18_dropout_forward_host_f32(gf_ctx *ctx, unsigned keep_mask, double scale, const float *const *tensors,
+                                                 const float *A, float *out_value, int N, int C) {
+    return gf::dropout_forward_host<float>(ctx, keep_mask, scale, tensors, A, out_value, N, C);
+}
+gf_status gf_contract18_dropout_backward_host_f32(gf_ctx *ctx, unsigned keep_mask, const float *out_gradient, const float *A,
+                                                  float *const *grads, int N, int C) {
+    return gf::dropout_backward_host<float>(ctx, keep_mask, out_gradient, A, grads, N, C);
+}
+
 gf_status gf_contract_forward_host_f64(gf_ctx *ctx, int K, const double *const *tensors, const double *A,
                                        double *out_value, int N, int C) {
     return gf::contract_forward_host<double>(ctx, K, tensors, A, out_value, N, C);
@@ -545,6 +659,14 @@ gf_status gf_contract_backward_host_f32(gf_ctx *ctx, int K, const float *out_gra
     gf_status gf_tensormatmul_backward_host_##SFX(gf_ctx *ctx, const T *G, const T *F, const T *Y, T *dF, T *dY, int R, \
                                                   int Kd, int J, int D) {                                               \
         return gf::tensormul_backward_host<T>(ctx, 1, G, F, Y, dF, dY, R, Kd, J, D);                                    \
+    }                                                                                                                   \
+    gf_status gf_custommatmultensor_forward_host_##SFX(gf_ctx *ctx, const T *W, const T *X, T *Out, long long rows,     \
+                                                       int V, int Kout) {                                               \
+        return gf::custommatmultensor_forward_host<T>(ctx, W, X, Out, rows, V, Kout);                                   \
+    }                                                                                                                   \
+    gf_status gf_custommatmultensor_backward_host_##SFX(gf_ctx *ctx, const T *G, const T *W, const T *X, T *dW, T *dX, \
+                                                        long long rows, int V, int Kout) {                              \
+        return gf::custommatmultensor_backward_host<T>(ctx, G, W, X, dW, dX, rows, V, Kout);                            \
     }                                                                                                                   \
     gf_status gf_stack_forward_host_##SFX(gf_ctx *ctx, const T *const *tensors, T *out, int nRows, size_t per_tensor) { \
         return gf::stack_forward_host<T>(ctx, tensors, out, nRows, per_tensor);                                         \

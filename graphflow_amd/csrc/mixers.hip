@@ -563,6 +563,29 @@ gf_status gf_mattensormul_backward_f32(gf_ctx *ctx, const float *G, const float 
     return st;
 }
 
+gf_status gf_custommatmultensor_forward_f32(gf_ctx *ctx, const float *W, const float *T, float *Out, long long rows, int V,
+                                            int Kout) {
+    gf_status st = need(ctx, W && T && Out && rows > 0 && rows <= 0x7fffffffLL && V > 0 && Kout > 0,
+                        "gf_custommatmultensor_forward_f32: bad argument");
+    if (st != GF_OK) return st;
+    // Out[rows,Kout] = T[rows,V] W^T[V,Kout]
+    return gf::gemm(ctx, false, true, (int)rows, Kout, V, T, V, 0, W, V, 0, Out, Kout, 0, 1, 0);
+}
+
+gf_status gf_custommatmultensor_backward_f32(gf_ctx *ctx, const float *G, const float *W, const float *T, float *dW,
+                                             float *dT, long long rows, int V, int Kout, int accumulate) {
+    gf_status st = need(ctx, G && W && T && rows > 0 && rows <= 0x7fffffffLL && V > 0 && Kout > 0,
+                        "gf_custommatmultensor_backward_f32: bad argument");
+    if (st != GF_OK) return st;
+    if (dW) {  // dW[Kout,V] (+)= G^T[Kout,rows] T[rows,V]
+        st = gf::gemm(ctx, true, false, Kout, V, (int)rows, G, Kout, 0, T, V, 0, dW, V, 0, 1, accumulate);
+        if (st != GF_OK) return st;
+    }
+    if (dT)  // dT[rows,V] (+)= G[rows,Kout] W[Kout,V]
+        st = gf::gemm(ctx, false, false, (int)rows, V, Kout, G, Kout, 0, W, V, 0, dT, V, 0, 1, accumulate);
+    return st;
+}
+
 gf_status gf_tensormatmul_forward_f32(gf_ctx *ctx, const float *F, const float *Y, float *Out, int R, int Kd, int J, int D) {
     gf_status st = need(ctx, F && Y && Out && R > 0 && Kd > 0 && J > 0 && D > 0, "gf_tensormatmul_forward_f32: bad argument");
     if (st != GF_OK) return st;

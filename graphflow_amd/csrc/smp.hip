@@ -12,6 +12,7 @@
 // is an index gather forward and a deterministic consumer-list gather backward (no atomics).
 // Nodes of a level are bucketed by receptive-field size; each bucket is one uniform-N contraction launch and all
 // buckets share one tall K-projection GEMM per level.
+#include <cstdio>
 #include <cstring>
 #include <string>
 
@@ -368,6 +369,41 @@ gf_status gf_smp_destroy(gf_smp *s) {
 }
 
 size_t gf_smp_param_count(const gf_smp *s) { return s ? gf::param_count(s->cfg) : 0; }
+
+// Text checkpoints in the reference's format (SMP_omega.h:1033-1042 / :1044-1055): every parameter value in
+// registration order, printed with the default ostream format (= "%g", 6 significant digits) followed by one blank.
+gf_status gf_smp_save_model(const gf_smp *s, const float *params, const char *path) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp");
+    if (!params || !path) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_save_model: null argument");
+    const size_t n = gf::param_count(s->cfg);
+    std::vector<float> host(n);
+    GF_HIP_TRY(s->ctx, hipMemcpyAsync(host.data(), params, n * sizeof(float), hipMemcpyDeviceToHost, s->ctx->stream));
+    GF_HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    FILE *f = std::fopen(path, "w");
+    if (!f) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_save_model: cannot open %s", path);
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; ++i) ok = std::fprintf(f, "%g ", (double)host[i]) > 0;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? GF_OK : fail(s->ctx, GF_ERR_INVALID, "gf_smp_save_model: write to %s failed", path);
+}
+
+gf_status gf_smp_load_model(const gf_smp *s, float *params, const char *path) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp");
+    if (!params || !path) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_load_model: null argument");
+    const size_t n = gf::param_count(s->cfg);
+    FILE *f = std::fopen(path, "r");
+    if (!f) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_load_model: cannot open %s", path);
+    std::vector<float> host(n);
+    size_t got = 0;
+    double v;
+    while (got < n && std::fscanf(f, "%lf", &v) == 1) host[got++] = (float)v;
+    std::fclose(f);
+    // the reference would silently keep reading garbage; a short file is an error here
+    if (got != n) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_load_model: %s holds %zu values, the model has %zu", path, got, n);
+    GF_HIP_TRY(s->ctx, hipMemcpyAsync(params, host.data(), n * sizeof(float), hipMemcpyHostToDevice, s->ctx->stream));
+    GF_HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    return GF_OK;
+}
 
 gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *adj, const double *feature) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");

@@ -1,4 +1,5 @@
-// Mixers_hip.h -- drop-in Entity-style ops MatMul_hip, MatTensorMul_hip, TensorMatMul_hip, StackTensor3D_hip.
+// Mixers_hip.h -- drop-in Entity-style ops MatMul_hip, MatTensorMul_hip, TensorMatMul_hip, CustomMatMulTensor_hip,
+// StackTensor3D_hip.
 //
 // Same contracts as GraphFlow/MatMul.h:21-89, MatTensorMul.h:22-92, TensorMatMul.h:22-91, StackTensor3D.h:25-98
 // (and GraphFlow_gpu/MatMul_gpu.h:113-505 for the GPU flavour): ctor with maximum dims allocates; setParameter()
@@ -104,6 +105,36 @@ public:
     }
     Tensor3D *first;
     Matrix *second;
+};
+
+// Out[i,j,k] = sum_v first[k,v] * second[i,j,v]   (channel mix; GraphFlow/CustomMatMulTensor.h:22-91)
+class CustomMatMulTensor_hip : public Tensor3D {
+public:
+    CustomMatMulTensor_hip(int max_nRows, int max_nColumns, int max_nDepth)
+        : Tensor3D(max_nRows, max_nColumns, max_nDepth), first(NULL), second(NULL) {}
+    CustomMatMulTensor_hip(Matrix *a, Tensor3D *b) : Tensor3D(b->nRows, b->nColumns, a->nRows), first(NULL), second(NULL) {
+        setParameter(a, b);
+    }
+    void setParameter(Matrix *a, Tensor3D *b) {
+        assert(a->nColumns == b->nDepth);
+        first = a;
+        second = b;
+        Tensor3D::setParameter(b->nRows, b->nColumns, a->nRows);
+    }
+    void forward() {
+        gfhost::must(gfhost::custommatmultensor_forward_host(gfhost::default_context(), first->value, second->value, value,
+                                                             (long long)nRows * nColumns, second->nDepth, nDepth),
+                     "CustomMatMulTensor_hip::forward");
+        gfhost::zero_gradient(this);
+    }
+    void backward() {
+        gfhost::must(gfhost::custommatmultensor_backward_host(gfhost::default_context(), gradient, first->value,
+                                                              second->value, first->gradient, second->gradient,
+                                                              (long long)nRows * nColumns, second->nDepth, nDepth),
+                     "CustomMatMulTensor_hip::backward");
+    }
+    Matrix *first;
+    Tensor3D *second;
 };
 
 // value[row][col][c1][c2] = tensors[row]->value[col][c1][c2].  Only needed to feed ops that want one contiguous

@@ -13,6 +13,8 @@
 #include <cassert>
 #include <vector>
 
+#include <cstdlib>
+
 #include "gf_containers.h"
 #include "gf_runtime.h"
 
@@ -83,7 +85,7 @@ public:
     std::vector<Tensor3D *> tensors;
     Matrix *adj;
 
-private:
+protected:
     gf_ctx *context() { return ctx ? ctx : gfhost::default_context(); }
     void gather(bool grads) {
         vptr.resize(N);
@@ -114,5 +116,64 @@ typedef RisiContraction_hip<4> RisiContraction_4_hip;
 typedef RisiContraction_hip<10> RisiContraction_10_hip;
 typedef RisiContraction_hip<18> RisiContraction_18_hip;
 typedef RisiContraction_hip<50> RisiContraction_50_hip;
+
+// RisiContraction_18_dropout (GraphFlow/RisiContraction_18_dropout.h:22-803): slice dropout.  Train mode draws nKept of
+// the 18 slices with rand() -- the same draw loop, so the same srand() seed selects the same slices as the reference
+// (:113-125) -- drops the others in forward and backward; test mode uses all slices scaled by nKept/18 (:465-471).
+class RisiContraction_18_dropout_hip : public RisiContraction_hip<18> {
+public:
+    RisiContraction_18_dropout_hip(int max_N, int max_nChanels) : RisiContraction_hip<18>(max_N, max_nChanels), mode(true), nKept(0) {
+        for (int i = 0; i < nContractions; ++i) use[i] = false;
+    }
+    void setContractions(int nKept_) {
+        assert(nKept_ > 0 && nKept_ <= nContractions);
+        nKept = nKept_;
+    }
+    void setTrainMode() { mode = true; }
+    void setTestMode() { mode = false; }
+    void setMode(bool m) { mode = m; }
+
+    void forward() {
+        assert(nKept > 0);
+        if (mode) {
+            for (int i = 0; i < nContractions; ++i) use[i] = false;
+            for (int i = 0; i < nKept; ++i)
+                for (;;) {
+                    const int j = rand() % nContractions;
+                    if (!use[j]) {
+                        use[j] = true;
+                        break;
+                    }
+                }
+        } else {
+            for (int i = 0; i < nContractions; ++i) use[i] = true;
+        }
+        gather(false);
+        gf_status st = gfhost::contract18_dropout_forward_host(context(), mask(), mode ? 1.0 : (double)nKept / nContractions,
+                                                               &vptr[0], adj->value, value, N, nChanels);
+        if (st != GF_OK) gfhost::die(context(), "RisiContraction_18_dropout_hip::forward", st);
+        for (int i = 0; i < size; ++i) gradient[i] = 0;
+    }
+
+    void backward() {
+        assert(nKept > 0);
+        assert(mode == true);  // only for train mode (RisiContraction_18_dropout.h:484)
+        gather(true);
+        gf_status st = gfhost::contract18_dropout_backward_host(context(), mask(), gradient, adj->value, &gptr[0], N, nChanels);
+        if (st != GF_OK) gfhost::die(context(), "RisiContraction_18_dropout_hip::backward", st);
+    }
+
+    bool mode;  // true = train
+    bool use[18];
+    int nKept;
+
+private:
+    unsigned mask() const {
+        unsigned m = 0;
+        for (int k = 0; k < nContractions; ++k)
+            if (use[k]) m |= 1u << k;
+        return m;
+    }
+};
 
 #endif

@@ -26,7 +26,7 @@ const int VECTOR = 1, MATRIX = 2, TENSOR3D = 3, TENSOR4D = 4;
 // HIP ops (new)
 const int RISICONTRACTION_4_HIP = 110, RISICONTRACTION_10_HIP = 111, RISICONTRACTION_18_HIP = 112,
           RISICONTRACTION_50_HIP = 113, MATMUL_HIP = 114, MATTENSORMUL_HIP = 115, TENSORMATMUL_HIP = 116,
-          STACKTENSOR3D_HIP = 117;
+          STACKTENSOR3D_HIP = 117, CUSTOMMATMULTENSOR_HIP = 118, RISICONTRACTION_18_DROPOUT_HIP = 119;
 }  // namespace gftags
 
 class GraphFlowExec {
@@ -46,6 +46,8 @@ public:
         bind<MatTensorMul_hip>(gftags::MATTENSORMUL_HIP);
         bind<TensorMatMul_hip>(gftags::TENSORMATMUL_HIP);
         bind<StackTensor3D_hip>(gftags::STACKTENSOR3D_HIP);
+        bind<CustomMatMulTensor_hip>(gftags::CUSTOMMATMULTENSOR_HIP);
+        bind<RisiContraction_18_dropout_hip>(gftags::RISICONTRACTION_18_DROPOUT_HIP);
     }
 
     // Teach the executor a (tag -> class) pair.  The class needs public non-virtual forward()/backward().

@@ -44,6 +44,23 @@ inline gf_status contract_backward_host(gf_ctx *c, int K, const float *g, const 
     return gf_contract_backward_host_f32(c, K, g, A, d, N, C);
 }
 
+inline gf_status contract18_dropout_forward_host(gf_ctx *c, unsigned m, double sc, const double *const *t, const double *A,
+                                                 double *o, int N, int C) {
+    return gf_contract18_dropout_forward_host_f64(c, m, sc, t, A, o, N, C);
+}
+inline gf_status contract18_dropout_forward_host(gf_ctx *c, unsigned m, double sc, const float *const *t, const float *A,
+                                                 float *o, int N, int C) {
+    return gf_contract18_dropout_forward_host_f32(c, m, sc, t, A, o, N, C);
+}
+inline gf_status contract18_dropout_backward_host(gf_ctx *c, unsigned m, const double *g, const double *A, double *const *d,
+                                                  int N, int C) {
+    return gf_contract18_dropout_backward_host_f64(c, m, g, A, d, N, C);
+}
+inline gf_status contract18_dropout_backward_host(gf_ctx *c, unsigned m, const float *g, const float *A, float *const *d, int N,
+                                                  int C) {
+    return gf_contract18_dropout_backward_host_f32(c, m, g, A, d, N, C);
+}
+
 #define GF_HOST_OVERLOAD2(NAME, ARGS_D, ARGS_F, CALL)                              \
     inline gf_status NAME ARGS_D { return gf_##NAME##_f64 CALL; }                   \
     inline gf_status NAME ARGS_F { return gf_##NAME##_f32 CALL; }
@@ -68,6 +85,13 @@ GF_HOST_OVERLOAD2(tensormatmul_backward_host,
                   (gf_ctx * c, const double *g, const double *F, const double *Y, double *dF, double *dY, int R, int Kd, int J, int D),
                   (gf_ctx * c, const float *g, const float *F, const float *Y, float *dF, float *dY, int R, int Kd, int J, int D),
                   (c, g, F, Y, dF, dY, R, Kd, J, D))
+GF_HOST_OVERLOAD2(custommatmultensor_forward_host,
+                  (gf_ctx * c, const double *W, const double *T, double *O, long long rows, int V, int Kout),
+                  (gf_ctx * c, const float *W, const float *T, float *O, long long rows, int V, int Kout), (c, W, T, O, rows, V, Kout))
+GF_HOST_OVERLOAD2(custommatmultensor_backward_host,
+                  (gf_ctx * c, const double *g, const double *W, const double *T, double *dW, double *dT, long long rows, int V, int Kout),
+                  (gf_ctx * c, const float *g, const float *W, const float *T, float *dW, float *dT, long long rows, int V, int Kout),
+                  (c, g, W, T, dW, dT, rows, V, Kout))
 GF_HOST_OVERLOAD2(stack_forward_host, (gf_ctx * c, const double *const *t, double *o, int n, size_t per),
                   (gf_ctx * c, const float *const *t, float *o, int n, size_t per), (c, t, o, n, per))
 GF_HOST_OVERLOAD2(stack_backward_host, (gf_ctx * c, const double *g, double *const *d, int n, size_t per),

@@ -119,6 +119,40 @@ def contract_backward(G, A, K=18, dP=None, accumulate=False, ctx=None):
     return dP
 
 
+def _keep_mask(use):
+    m = 0
+    for k, u in enumerate(use):
+        if u:
+            m |= 1 << k
+    return m
+
+
+def contract18_dropout_forward(P, A, use, train=True, nKept=None, out=None, ctx=None):
+    """RisiContraction_18_dropout::forward.  use[18]: the kept slices (train mode); in test mode every slice is used and
+    the value is scaled by nKept/18 (RisiContraction_18_dropout.h:465-471)."""
+    B, N, _, _, C_ = P.shape
+    ctx = ctx or default_context(P.device.index or 0)
+    if out is None:
+        out = torch.empty((B, N, N, 18, C_), dtype=torch.float32, device=P.device)
+    mask, scale = (_keep_mask(use), 1.0) if train else (0x3ffff, float(nKept) / 18.0)
+    ctx.check(ctx.lib.gf_contract18_dropout_forward_f32(ctx.handle, mask, scale, _dev_f32(P, "P"), _dev_f32(A, "A"),
+                                                        _dev_f32(out, "out"), N, C_, B))
+    return out
+
+
+def contract18_dropout_backward(G, A, use, dP=None, accumulate=False, ctx=None):
+    """RisiContraction_18_dropout::backward (train mode only, like the reference's assert at :484)."""
+    B, N, _, _, C_ = G.shape
+    ctx = ctx or default_context(G.device.index or 0)
+    if dP is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs the dP tensor to accumulate into")
+        dP = torch.empty((B, N, N, N, C_), dtype=torch.float32, device=G.device)
+    ctx.check(ctx.lib.gf_contract18_dropout_backward_f32(ctx.handle, _keep_mask(use), _dev_f32(G, "G"), _dev_f32(A, "A"),
+                                                         _dev_f32(dP, "dP"), N, C_, B, 1 if accumulate else 0))
+    return dP
+
+
 def _opt(t, name):
     return _dev_f32(t, name) if t is not None else None
 
@@ -159,6 +193,27 @@ def mattensormul_backward(G, X, F, dX=None, dF=None, accumulate=False, ctx=None)
     ctx.check(ctx.lib.gf_mattensormul_backward_f32(ctx.handle, _dev_f32(G, "G"), _dev_f32(X, "X"), _dev_f32(F, "F"),
                                                    _opt(dX, "dX"), _opt(dF, "dF"), R, Kd, J, D, 1 if accumulate else 0))
     return dX, dF
+
+
+def custommatmultensor_forward(W, T, ctx=None):
+    """CustomMatMulTensor::forward (CustomMatMulTensor.h:47-68): Out[i,j,k] = sum_v W[k,v] T[i,j,v]."""
+    I, J, V = T.shape
+    Kout = W.shape[0]
+    ctx = ctx or default_context(T.device.index or 0)
+    out = torch.empty((I, J, Kout), dtype=torch.float32, device=T.device)
+    ctx.check(ctx.lib.gf_custommatmultensor_forward_f32(ctx.handle, _dev_f32(W, "W"), _dev_f32(T, "T"), _dev_f32(out, "Out"),
+                                                        I * J, V, Kout))
+    return out
+
+
+def custommatmultensor_backward(G, W, T, dW=None, dT=None, accumulate=False, ctx=None):
+    I, J, V = T.shape
+    Kout = W.shape[0]
+    ctx = ctx or default_context(T.device.index or 0)
+    ctx.check(ctx.lib.gf_custommatmultensor_backward_f32(ctx.handle, _dev_f32(G, "G"), _dev_f32(W, "W"), _dev_f32(T, "T"),
+                                                         _opt(dW, "dW"), _opt(dT, "dT"), I * J, V, Kout,
+                                                         1 if accumulate else 0))
+    return dW, dT
 
 
 def tensormatmul_forward(F, Y, ctx=None):

@@ -54,6 +54,15 @@ class SMPOmega:
                                                 1 if accumulate else 0))
         return grads
 
+    def save_model(self, params, path):
+        """SMP_omega::save_model (SMP_omega.h:1033-1042): text checkpoint the reference's load_model reads."""
+        self.ctx.check(self.lib.gf_smp_save_model(self.handle, C.c_void_p(params.data_ptr()), str(path).encode()))
+
+    def load_model(self, params, path):
+        """SMP_omega::load_model (SMP_omega.h:1044-1055) into the flat device parameter buffer."""
+        self.ctx.check(self.lib.gf_smp_load_model(self.handle, C.c_void_p(params.data_ptr()), str(path).encode()))
+        return params
+
     def set_fused(self, on=True):
         """Fused level kernels (default) vs the op-by-op pipeline; both give the same results within fp32 rounding."""
         self.ctx.check(self.lib.gf_smp_set_fused(self.handle, 1 if on else 0))

@@ -89,6 +89,23 @@ gf_status gf_contract_forward_host_f32(gf_ctx *ctx, int K, const float *const *t
 gf_status gf_contract_backward_host_f32(gf_ctx *ctx, int K, const float *out_gradient, const float *A,
                                         float *const *grads, int N, int C);
 
+/* ---- RisiContraction_18_dropout (GraphFlow/RisiContraction_18_dropout.h:106-477 / :479-783) ----------------------------
+ * keep_mask bit k = use[k]: a dropped slice is 0 in forward and ignored in backward.  Train mode: scale = 1 and the mask
+ * the host drew (:113-125); test mode: keep_mask = all 18 bits, scale = nKept/18 (:465-471).  The host side
+ * (graphflow_amd/host/RisiContraction_hip.h) draws the mask with rand() exactly as the reference does.                  */
+gf_status gf_contract18_dropout_forward_f32(gf_ctx *ctx, unsigned keep_mask, float scale, const float *P, const float *A,
+                                            float *Out, int N, int C, int batch);
+gf_status gf_contract18_dropout_backward_f32(gf_ctx *ctx, unsigned keep_mask, const float *G, const float *A, float *dP,
+                                             int N, int C, int batch, int accumulate);
+gf_status gf_contract18_dropout_forward_host_f64(gf_ctx *ctx, unsigned keep_mask, double scale, const double *const *tensors,
+                                                 const double *A, double *out_value, int N, int C);
+gf_status gf_contract18_dropout_backward_host_f64(gf_ctx *ctx, unsigned keep_mask, const double *out_gradient, const double *A,
+                                                  double *const *grads, int N, int C);
+gf_status gf_contract18_dropout_forward_host_f32(gf_ctx *ctx, unsigned keep_mask, double scale, const float *const *tensors,
+                                                 const float *A, float *out_value, int N, int C);
+gf_status gf_contract18_dropout_backward_host_f32(gf_ctx *ctx, unsigned keep_mask, const float *out_gradient, const float *A,
+                                                  float *const *grads, int N, int C);
+
 /* ---- dense feature mixers, mode B (device pointers) ------------------------------------------------------------------
  * All row-major.  One strided-batched fp32 MFMA GEMM underneath (v_mfma_f32_32x32x2_f32, exact fp32).
  * backward: a NULL gradient pointer skips that operand; accumulate != 0 -> `+=` (the reference contract), else `=`.
@@ -105,6 +122,13 @@ gf_status gf_mattensormul_backward_f32(gf_ctx *ctx, const float *G, const float 
 gf_status gf_tensormatmul_forward_f32(gf_ctx *ctx, const float *F, const float *Y, float *Out, int R, int Kd, int J, int D);
 gf_status gf_tensormatmul_backward_f32(gf_ctx *ctx, const float *G, const float *F, const float *Y, float *dF, float *dY,
                                        int R, int Kd, int J, int D, int accumulate);
+/* CustomMatMulTensor (GraphFlow/CustomMatMulTensor.h:47-68 / :70-85), the channel mix of the SMP_2D_ver6-8 drivers:
+ *   Out[rows,Kout] = T[rows,V] W^T,  W = [Kout,V] row-major, rows = nRows*nColumns positions of the Tensor3D.
+ *   backward: dW (+)= G^T T,  dT (+)= G W.                                                                           */
+gf_status gf_custommatmultensor_forward_f32(gf_ctx *ctx, const float *W, const float *T, float *Out, long long rows, int V,
+                                            int Kout);
+gf_status gf_custommatmultensor_backward_f32(gf_ctx *ctx, const float *G, const float *W, const float *T, float *dW,
+                                             float *dT, long long rows, int V, int Kout, int accumulate);
 /* StackTensor3D (GraphFlow/StackTensor3D.h:54-73 / :75-90): `tensors` / `grads` are DEVICE arrays of nRows device
  * pointers, each to per_tensor floats; forward copies them into one contiguous buffer, backward scatter-adds back. */
 gf_status gf_stack_forward_f32(gf_ctx *ctx, const float *const *tensors, float *out, int nRows, size_t per_tensor);
@@ -120,6 +144,14 @@ gf_status gf_mattensormul_backward_host_f64(gf_ctx *ctx, const double *G, const 
 gf_status gf_tensormatmul_forward_host_f64(gf_ctx *ctx, const double *F, const double *Y, double *Out, int R, int Kd, int J, int D);
 gf_status gf_tensormatmul_backward_host_f64(gf_ctx *ctx, const double *G, const double *F, const double *Y, double *dF,
                                             double *dY, int R, int Kd, int J, int D);
+gf_status gf_custommatmultensor_forward_host_f64(gf_ctx *ctx, const double *W, const double *T, double *Out, long long rows,
+                                                 int V, int Kout);
+gf_status gf_custommatmultensor_backward_host_f64(gf_ctx *ctx, const double *G, const double *W, const double *T, double *dW,
+                                                  double *dT, long long rows, int V, int Kout);
+gf_status gf_custommatmultensor_forward_host_f32(gf_ctx *ctx, const float *W, const float *T, float *Out, long long rows,
+                                                 int V, int Kout);
+gf_status gf_custommatmultensor_backward_host_f32(gf_ctx *ctx, const float *G, const float *W, const float *T, float *dW,
+                                                  float *dT, long long rows, int V, int Kout);
 gf_status gf_stack_forward_host_f64(gf_ctx *ctx, const double *const *tensors, double *out, int nRows, size_t per_tensor);
 gf_status gf_stack_backward_host_f64(gf_ctx *ctx, const double *G, double *const *grads, int nRows, size_t per_tensor);
 gf_status gf_stack_forward_host_f32(gf_ctx *ctx, const float *const *tensors, float *out, int nRows, size_t per_tensor);
@@ -161,6 +193,10 @@ gf_status gf_smp_backward(gf_smp *smp, const float *params, float *grads, int ac
 /* 1 (default): fused level kernels (no promoted stack, no 18-slice contraction output in HBM) where the shape allows;
  * 0: the op-by-op pipeline.  Same results within fp32 rounding; kept switchable for parity tests. */
 gf_status gf_smp_set_fused(gf_smp *smp, int on);
+/* Text checkpoints interchangeable with SMP_omega::save_model / load_model (GraphFlow/SMP_omega.h:1033-1055):
+ * whitespace-separated values in the flat parameter order above.  `params` is a device pointer.  Blocking. */
+gf_status gf_smp_save_model(const gf_smp *smp, const float *params, const char *path);
+gf_status gf_smp_load_model(const gf_smp *smp, float *params, const char *path);
 gf_status gf_smp_prepare_molecule_host(const gf_smp_config *cfg, int V, const int *adj, const double *feature,
                                        int *phi_out, double *wl_out);  /* host only; phi_out [L+1][V][cap+1], slot 0 = size */
 int       gf_smp_receptive_field(const gf_smp *smp, int mol, int level, int v, int *out, int capacity);

@@ -415,6 +415,69 @@ void gfo_tensormatmul_backward(const double *G, const double *F, const double *Y
             }
 }
 
+/* RisiContraction_18_dropout (RisiContraction_18_dropout.h:106-477, :479-783): slices with use[k] == 0 are skipped in
+ * forward (stay 0) and in backward; in test mode (train == 0) every slice is used and the value is scaled by nKept/18
+ * (:465-471).  The mask itself is drawn by the caller (the reference draws it with rand(), :113-125). */
+int gfo_r18_dropout_forward(const int *use, int train, int nKept, const double *P, const double *A, double *Out, int N, int C) {
+    if (gfo_contract_forward(18, P, A, Out, N, C) != 0) return -1;
+    for (size_t r = 0; r < (size_t)N * N; ++r)
+        for (int k = 0; k < 18; ++k)
+            for (int f = 0; f < C; ++f) {
+                double *o = &Out[(r * 18 + k) * C + f];
+                if (train) {
+                    if (!use[k]) *o = 0.0;
+                } else {
+                    *o *= (double)nKept / 18.0;
+                }
+            }
+    return 0;
+}
+
+int gfo_r18_dropout_backward(const int *use, const double *G, const double *A, double *dP, int N, int C) {
+    const size_t n = (size_t)N * N * 18 * C;
+    double *Gm = (double *)malloc(sizeof(double) * n);
+    for (size_t i = 0; i < n; ++i) Gm[i] = use[(i / C) % 18] ? G[i] : 0.0;
+    const int rc = gfo_contract_backward(18, Gm, A, dP, N, C);
+    free(Gm);
+    return rc;
+}
+
+/* Mask draw of RisiContraction_18_dropout::forward (:113-125) given the caller's rand() stream. */
+void gfo_r18_dropout_draw(int nKept, int *use, int (*next_rand)(void)) {
+    for (int i = 0; i < 18; ++i) use[i] = 0;
+    for (int i = 0; i < nKept; ++i)
+        for (;;) {
+            const int j = next_rand() % 18;
+            if (!use[j]) {
+                use[j] = 1;
+                break;
+            }
+        }
+}
+
+/* CustomMatMulTensor (CustomMatMulTensor.h:47-68, :70-85): channel mix Out[i][j][k] = sum_v W[k][v] * T[i][j][v]
+ * over rows = nRows*nColumns positions; W is [Kout][V]. */
+void gfo_custommatmultensor_forward(const double *W, const double *T, double *Out, int rows, int V, int Kout) {
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < Kout; ++k) {
+            double s = 0.0;
+            for (int v = 0; v < V; ++v) s += W[(size_t)k * V + v] * T[(size_t)r * V + v];
+            Out[(size_t)r * Kout + k] = s;
+        }
+}
+
+void gfo_custommatmultensor_backward(const double *G, const double *W, const double *T, double *dW, double *dT, int rows,
+                                     int V, int Kout) {
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < Kout; ++k) {
+            const double g = G[(size_t)r * Kout + k];
+            for (int v = 0; v < V; ++v) {
+                dW[(size_t)k * V + v] += g * T[(size_t)r * V + v];
+                dT[(size_t)r * V + v] += g * W[(size_t)k * V + v];
+            }
+        }
+}
+
 /* StackTensor3D (StackTensor3D.h:54-73, :75-90): copy nRows tensors [nCols][n1][n2] into one
  * contiguous [nRows][nCols][n1][n2]; backward scatter-adds the stacked gradient back. */
 void gfo_stack_forward(const double *const *tensors, double *Out, int nRows, size_t per) {

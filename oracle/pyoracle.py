@@ -164,6 +164,74 @@ class _Lib:
         J = Y.shape[1]
         return self._tmb("tensormatmul_backward", G, F, Y, (R, Kd, J, D))  # (dF, dY)
 
+    def r18_dropout(self, use, train, nKept, P, A, G=None, dP0=None, seed=None):
+        """oracle: mask `use` given; reference: mask drawn by the reference after srand(seed) and returned."""
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        N, Cc = P.shape[0], P.shape[3]
+        out = np.zeros((N, N, 18, Cc))
+        dP = None
+        ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        if G is not None:
+            G = np.ascontiguousarray(G, dtype=np.float64)
+            dP = np.zeros_like(P) if dP0 is None else np.array(dP0, dtype=np.float64, order="C")
+        if self.kind == "oracle":
+            u = np.ascontiguousarray(use, dtype=np.int32)
+            f = self.lib.gfo_r18_dropout_forward
+            f.argtypes = [ip, _i, _i, _dp, _dp, _dp, _i, _i]
+            f.restype = _i
+            assert f(u, 1 if train else 0, nKept, P, A, out, N, Cc) == 0
+            if G is not None:
+                b = self.lib.gfo_r18_dropout_backward
+                b.argtypes = [ip, _dp, _dp, _dp, _i, _i]
+                b.restype = _i
+                assert b(u, G, A, dP, N, Cc) == 0
+            return out, dP, u
+        u = np.zeros(18, dtype=np.int32)
+        f = self.lib.ref_r18_dropout
+        vp = C.c_void_p
+        f.argtypes = [C.c_uint, _i, _i, _dp, _dp, vp, _dp, vp, ip, _i, _i]
+        f.restype = None
+        f(int(seed), nKept, 1 if train else 0, P, A, G.ctypes.data if G is not None else None, out,
+          dP.ctypes.data if dP is not None else None, u, N, Cc)
+        return out, dP, u
+
+    def custommatmultensor_forward(self, W, T):
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        I, J, V = T.shape
+        Kout = W.shape[0]
+        out = np.zeros((I, J, Kout))
+        f = getattr(self.lib, self._n("custommatmultensor_forward"))
+        if self.kind == "oracle":
+            f.argtypes = [_dp, _dp, _dp, _i, _i, _i]
+            f.restype = None
+            f(W, T, out, I * J, V, Kout)
+        else:
+            f.argtypes = [_dp, _dp, _dp, _i, _i, _i, _i]
+            f.restype = None
+            f(W, T, out, I, J, V, Kout)
+        return out
+
+    def custommatmultensor_backward(self, G, W, T, dW0=None, dT0=None):
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        I, J, V = T.shape
+        Kout = W.shape[0]
+        dW = np.zeros_like(W) if dW0 is None else np.array(dW0, dtype=np.float64, order="C")
+        dT = np.zeros_like(T) if dT0 is None else np.array(dT0, dtype=np.float64, order="C")
+        f = getattr(self.lib, self._n("custommatmultensor_backward"))
+        if self.kind == "oracle":
+            f.argtypes = [_dp] * 5 + [_i, _i, _i]
+            f.restype = None
+            f(G, W, T, dW, dT, I * J, V, Kout)
+        else:
+            f.argtypes = [_dp] * 5 + [_i, _i, _i, _i]
+            f.restype = None
+            f(G, W, T, dW, dT, I, J, V, Kout)
+        return dW, dT
+
     def _n(self, name):
         return ("gfo_" if self.kind == "oracle" else "ref_") + name
 
@@ -210,6 +278,20 @@ def time_r18_fwd_bwd(P, A, G, prefer_reference=True):
     fw(P, A, out, N, C_)
     bw(G, A, dP, N, C_)
     return time.perf_counter() - t0, "port", out, dP
+
+
+def reference_save_model(path, params, nLevels, nChanels, nFeatures, nDepth, cap, max_nVertices):
+    """Text checkpoint written by the REAL reference's SMP_omega::save_model for the given parameter values."""
+    ref = reference()
+    if ref is None:
+        return None
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    f = ref.lib.ref_smp_omega_save_model
+    f.argtypes = [_i] * 6 + [_dp, C.c_char_p]
+    f.restype = _i
+    n = f(max_nVertices, cap, nLevels, nChanels, nFeatures, nDepth, params, path.encode())
+    assert n == params.size, (n, params.size)
+    return path
 
 
 def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, max_nVertices=None):

@@ -11,6 +11,7 @@
 // -DNDEBUG is required because RisiContraction_18_thread's constructors assert(DEPRECATED == false)
 // (RisiContraction_18_thread.h:27,33,784).
 #include <cstddef>
+#include <cstdlib>
 #include <vector>
 
 #include "Matrix.h"
@@ -20,11 +21,13 @@
 #include "RisiContraction_10.h"
 #include "RisiContraction_18.h"
 #include "RisiContraction_18_thread.h"
+#include "RisiContraction_18_dropout.h"
 #include "RisiContraction_50.h"
 #include "MatMul.h"
 #include "MatTensorMul.h"
 #include "TensorMatMul.h"
 #include "StackTensor3D.h"
+#include "CustomMatMulTensor.h"
 
 namespace {
 
@@ -98,6 +101,26 @@ void ref_r18_backward(const double *G, const double *A, double *dP, int N, int C
 }
 void ref_r18_thread_forward(const double *P, const double *A, double *Out, int N, int C) {
     contract_fwd<RisiContraction_18_thread>(P, A, Out, N, C);
+}
+// RisiContraction_18_dropout: srand(seed) then one forward (train mode draws the kept slices with rand(), :113-125),
+// optionally followed by backward.  use_out[18] receives the mask the reference drew.
+void ref_r18_dropout(unsigned seed, int nKept, int train, const double *P, const double *A, const double *G, double *Out,
+                     double *dP, int *use_out, int N, int C) {
+    Neighbourhood nb(P, dP, A, N, C);
+    RisiContraction_18_dropout op(N, C);
+    bind(op, nb, true);
+    op.set_adjacency(nb.adj);
+    op.setContractions(nKept);
+    op.setMode(train != 0);
+    srand(seed);
+    op.forward();
+    for (int i = 0; i < op.size; ++i) Out[i] = op.value[i];
+    for (int k = 0; k < 18; ++k) use_out[k] = op.use[k] ? 1 : 0;
+    if (train && G && dP) {
+        for (int i = 0; i < op.size; ++i) op.gradient[i] = G[i];
+        op.backward();
+        nb.grads_out(dP);
+    }
 }
 void ref_r10_forward(const double *P, const double *A, double *Out, int N, int C) {
     contract_fwd<RisiContraction_10>(P, A, Out, N, C);
@@ -216,6 +239,28 @@ void ref_tensormatmul_backward(const double *G, const double *F, const double *Y
     for (int i = 0; i < y.size; ++i) dY[i] = y.gradient[i];
 }
 
+void ref_custommatmultensor_forward(const double *W, const double *T, double *Out, int I, int J, int V, int Kout) {
+    Matrix w(Kout, V);
+    Tensor3D t(I, J, V);
+    fill(&w, W, NULL);
+    fill(&t, T, NULL);
+    CustomMatMulTensor op(&w, &t);
+    op.forward();
+    for (int i = 0; i < op.size; ++i) Out[i] = op.value[i];
+}
+void ref_custommatmultensor_backward(const double *G, const double *W, const double *T, double *dW, double *dT, int I, int J,
+                                     int V, int Kout) {
+    Matrix w(Kout, V);
+    Tensor3D t(I, J, V);
+    fill(&w, W, dW);
+    fill(&t, T, dT);
+    CustomMatMulTensor op(&w, &t);
+    for (int i = 0; i < op.size; ++i) op.gradient[i] = G[i];
+    op.backward();
+    for (int i = 0; i < w.size; ++i) dW[i] = w.gradient[i];
+    for (int i = 0; i < t.size; ++i) dT[i] = t.gradient[i];
+}
+
 // StackTensor3D round trip on nRows tensors of [nCols][n1][n2] given contiguously.
 void ref_stack_forward(const double *T, double *Out, int nRows, int nCols, int n1, int n2) {
     const size_t per = (size_t)nCols * n1 * n2;
@@ -292,6 +337,17 @@ extern "C" int ref_smp_omega_run(int max_nVertices, int max_rf, int nLevels, int
                 for (int i = 0; i < net.level[l]->adj[v]->size; ++i) a[i] = net.level[l]->adj[v]->value[i];
             }
         }
+    return (int)off;
+}
+
+// Text checkpoint written by the reference's own SMP_omega::save_model (SMP_omega.h:1033-1042) for given parameters.
+extern "C" int ref_smp_omega_save_model(int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int nDepth,
+                                        const double *params, const char *path) {
+    SMP_omega &net = *new SMP_omega(max_nVertices, max_rf, nLevels, nChanels, nFeatures, nDepth);
+    size_t off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) net.sgd->params[i]->value[j] = params[off++];
+    net.save_model(path);
     return (int)off;
 }
 

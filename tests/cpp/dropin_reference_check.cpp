@@ -7,6 +7,7 @@
 #include "Tensor4D.h"
 #include "StackTensor3D.h"
 
+#include "Mixers_hip.h"
 #include "RisiContraction_hip.h"
 #include "gf_executor.h"
 
@@ -25,7 +26,12 @@ int main() {
     contract2.setParameter(N, C);                 // CPU-op style binding on the reference's Tensor3D
     for (int i = 0; i < N; ++i) contract2.add_tensor(t[i]);
     contract2.set_adjacency(&adj);
+    Matrix W(C, 18 * C);
+    Tensor3D view(N, N, 18 * C);
+    CustomMatMulTensor_hip mix(&W, &view);        // SMP_2D_ver6-8 style channel mix on the reference's containers
     GraphFlowExec g;
+    g.add(&mix, gftags::CUSTOMMATMULTENSOR_HIP);
+    g.clear();
     g.add(&adj, gftags::MATRIX);
     g.add(&contract, gftags::RISICONTRACTION_18_HIP);
     return (int)g.size() - 2;

@@ -20,6 +20,8 @@ void gfo_mattensormul_forward(const double *X, const double *F, double *Out, int
 void gfo_mattensormul_backward(const double *G, const double *X, const double *F, double *dX, double *dF, int R, int Kd, int J, int D);
 void gfo_tensormatmul_forward(const double *F, const double *Y, double *Out, int R, int Kd, int J, int D);
 void gfo_tensormatmul_backward(const double *G, const double *F, const double *Y, double *dF, double *dY, int R, int Kd, int J, int D);
+void gfo_custommatmultensor_forward(const double *W, const double *T, double *Out, int rows, int V, int Kout);
+void gfo_custommatmultensor_backward(const double *G, const double *W, const double *T, double *dW, double *dT, int rows, int V, int Kout);
 int gfo_contract_forward(int K, const double *P, const double *A, double *Out, int N, int C);
 int gfo_contract_backward(int K, const double *G, const double *A, double *dP, int N, int C);
 }
@@ -175,9 +177,40 @@ static int part2_vertex_chain() {
     return bad;
 }
 
+// CustomMatMulTensor_hip as SMP_2D_ver6-8 use it: the K-projection applied straight to the contraction output
+// viewed as a Tensor3D [N][N][18C] (no Reshape2D), through the executor.
+static int part3_channel_mix() {
+    const int N = 9, V = 18 * 12, Kout = 12;
+    srand(99);
+    Matrix W(Kout, V);
+    Tensor3D T(N, N, V);
+    for (int i = 0; i < W.size; ++i) W.value[i] = (rand() % 200 - 100) / 50.0;
+    for (int i = 0; i < T.size; ++i) T.value[i] = (rand() % 200 - 100) / 50.0;
+    for (int i = 0; i < W.size; ++i) W.gradient[i] = rand() % 3;  // pins `+=`
+    for (int i = 0; i < T.size; ++i) T.gradient[i] = rand() % 3;
+    CustomMatMulTensor_hip mix(&W, &T);
+    GraphFlowExec graph;
+    graph.add(&W, gftags::MATRIX);
+    graph.add(&T, gftags::TENSOR3D);
+    graph.add(&mix, gftags::CUSTOMMATMULTENSOR_HIP);
+    std::vector<double> w = vals(&W), t = vals(&T), dw = vals(&W, true), dt = vals(&T, true);
+    graph.forward();
+    int bad = mix.nRows != N || mix.nColumns != N || mix.nDepth != Kout;
+    std::vector<double> ref((size_t)N * N * Kout), g(ref.size());
+    gfo_custommatmultensor_forward(&w[0], &t[0], &ref[0], N * N, V, Kout);
+    bad |= check("CustomMatMulTensor forward", vals(&mix), ref);
+    for (int i = 0; i < mix.size; ++i) mix.gradient[i] = g[i] = (rand() % 200 - 100) / 100.0;
+    graph.backward();
+    gfo_custommatmultensor_backward(&g[0], &w[0], &t[0], &dw[0], &dt[0], N * N, V, Kout);
+    bad |= check("CustomMatMulTensor backward (first)", vals(&W, true), dw);
+    bad |= check("CustomMatMulTensor backward (second)", vals(&T, true), dt);
+    return bad;
+}
+
 int main() {
     int bad = part1_matmul();
     bad |= part2_vertex_chain();
+    bad |= part3_channel_mix();
     std::printf(bad ? "FAILED\n" : "PASSED\n");
     return bad;
 }

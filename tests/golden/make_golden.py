@@ -59,6 +59,26 @@ def contraction_fixtures(ref):
     return out
 
 
+def dropout_fixtures(ref):
+    """RisiContraction_18_dropout: the reference draws the kept slices itself after srand(seed); the fixture keeps the mask."""
+    out = {}
+    rng = np.random.default_rng(777)
+    for tag, (N, C, seed, nKept, train) in {"drop_train_s2024_k7": (5, 3, 2024, 7, 1), "drop_train_s77_k12": (6, 4, 77, 12, 1),
+                                            "drop_train_s1_k1": (4, 2, 1, 1, 1), "drop_test_k7": (5, 3, 3, 7, 0)}.items():
+        P = f32exact(rng.uniform(-1, 1, (N, N, N, C)))
+        A = f32exact(adjacency("weighted", N, rng)) if "s77" in tag else f32exact((rng.uniform(0, 1, (N, N)) < 0.5).astype(float) + np.eye(N))
+        G = f32exact(rng.uniform(-1, 1, (N, N, 18, C)))
+        d0 = f32exact(rng.uniform(-1, 1, (N, N, N, C)))
+        o, dP, use = ref.r18_dropout(None, bool(train), nKept, P, A, G if train else None, d0 if train else None, seed=seed)
+        for k, v in (("P", P), ("A", A), ("G", G), ("dP0", d0)):
+            out[tag + "__" + k] = v.astype(np.float32)
+        out[tag + "__cfg"] = np.array([seed, nKept, train], dtype=np.int32)
+        out[tag + "__use"], out[tag + "__Out"] = use, o
+        if train:
+            out[tag + "__dP"] = dP
+    return out
+
+
 def selection_matrix(s, sw, rng):
     """0/1 selection X[i,k] = [phi_l(v)_i == phi_{l-1}(w)_k] as SMP builds it (SMP_omega.h:461-474)."""
     X = np.zeros((s, sw))
@@ -97,6 +117,18 @@ def mixer_fixtures(ref):
         out[p + "__X"], out[p + "__F"], out[p + "__G2"] = X.astype(np.float32), F.astype(np.float32), G2.astype(np.float32)
         out[p + "__T1"], out[p + "__T2"], out[p + "__dT1"], out[p + "__dF"] = T1, T2, dT1, dF
         out[p + "__dX"], out[p + "__dY"] = dX, dY
+    # CustomMatMulTensor (CustomMatMulTensor.h:47-85): the SMP_2D_ver6-8 K-projection shape [N,N,18C] -> [N,N,C] and a ragged one
+    rng = np.random.default_rng(4243)
+    for tag, (I, J, V, Kout) in {"cmix_5x5x36x2": (5, 5, 36, 2), "cmix_3x7x5x4": (3, 7, 5, 4), "cmix_1x1x1x1": (1, 1, 1, 1)}.items():
+        W = f32exact(rng.uniform(-1, 1, (Kout, V)))
+        T = f32exact(rng.uniform(-1, 1, (I, J, V)))
+        G = f32exact(rng.uniform(-1, 1, (I, J, Kout)))
+        dW0 = f32exact(rng.uniform(-1, 1, (Kout, V)))
+        dT0 = f32exact(rng.uniform(-1, 1, (I, J, V)))
+        for k, v in (("W", W), ("T", T), ("G", G), ("dW0", dW0), ("dT0", dT0)):
+            out[tag + "__" + k] = v.astype(np.float32)
+        out[tag + "__Out"] = ref.custommatmultensor_forward(W, T)
+        out[tag + "__dW"], out[tag + "__dT"] = ref.custommatmultensor_backward(G, W, T, dW0, dT0)
     return out
 
 
@@ -151,6 +183,15 @@ def smp_fixtures():
     return out
 
 
+def checkpoint_fixture():
+    """smp_syn12's parameters as SMP_omega::save_model writes them (SMP_omega.h:1033-1042): a data file, 6 significant digits."""
+    for i, (tag, adj, feat, tgt, (L, C, D, cap, wl, maxV)) in enumerate(smp_cases()):
+        if tag == "syn12":
+            params = smp_params(C, feat.shape[1], D, L, 100 + i)
+            pyoracle.reference_save_model(os.path.join(HERE, "smp_syn12_checkpoint.txt"), params.astype(np.float32), L, C,
+                                          feat.shape[1], D, cap, maxV)
+
+
 def main():
     pyoracle.build()
     ref = pyoracle.reference()
@@ -158,10 +199,12 @@ def main():
         sys.exit("oracle/_ref/libgf_ref.so missing: needs /root/reference (build container only)")
     np.savez_compressed(os.path.join(HERE, "contractions.npz"), **contraction_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "mixers.npz"), **mixer_fixtures(ref))
+    np.savez_compressed(os.path.join(HERE, "dropout.npz"), **dropout_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "smp.npz"), **smp_fixtures())
+    checkpoint_fixture()
     with open(os.path.join(HERE, "structural_50.json"), "w") as fh:
         json.dump(structural_50(), fh, indent=1)
-    for f in ("contractions.npz", "mixers.npz", "smp.npz", "structural_50.json"):
+    for f in ("contractions.npz", "mixers.npz", "smp.npz", "structural_50.json", "smp_syn12_checkpoint.txt", "dropout.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

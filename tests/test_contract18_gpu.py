@@ -189,3 +189,36 @@ def test_host_pointer_mode_f64(gf, oracle):
     ctx.check(lib.gf_contract_backward_host_f64(ctx.handle, 18, G.ctypes.data_as(dp), A.ctypes.data_as(dp), garr, N, Cc))
     assert rel_err(np.stack(grads), oracle.contract_backward(18, G, A, g0)) <= REL_TOL_F32
     ctx.close()
+
+
+def test_r18_dropout_golden(gf, golden):
+    """Slice dropout (RisiContraction_18_dropout.h): train-mode masks as the reference drew them, test-mode scaling."""
+    cases = golden_cases(golden, "drop_")
+    assert len(cases) == 4
+    for tag, c in cases.items():
+        seed, nKept, train = (int(x) for x in c["cfg"])
+        P, A, G = (torch.as_tensor(c[k]).cuda()[None] for k in ("P", "A", "G"))
+        out = gf.contract18_dropout_forward(P, A, c["use"], train=bool(train), nKept=nKept)
+        assert rel_err(out[0].cpu().numpy().astype(np.float64), c["Out"]) <= REL_TOL_F32, tag
+        if train:
+            dropped = [k for k in range(18) if not c["use"][k]]
+            assert not out[0][:, :, dropped, :].any(), tag
+            dP = torch.as_tensor(c["dP0"]).cuda()[None].clone()
+            gf.contract18_dropout_backward(G, A, c["use"], dP=dP, accumulate=True)
+            assert rel_err(dP[0].cpu().numpy().astype(np.float64), c["dP"]) <= REL_TOL_F32, tag
+
+
+def test_r18_dropout_batch_vs_oracle(gf, oracle):
+    rng = np.random.default_rng(31)
+    B, N, C = 3, 8, 8
+    use = np.zeros(18, dtype=np.int32)
+    use[[0, 3, 4, 9, 16, 17]] = 1
+    P = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
+    A = f32exact((rng.uniform(0, 1, (B, N, N)) < 0.5) * rng.uniform(0.5, 2, (B, N, N)))
+    G = f32exact(rng.uniform(-1, 1, (B, N, N, 18, C)))
+    out = gf.contract18_dropout_forward(torch.as_tensor(P, dtype=torch.float32).cuda(), torch.as_tensor(A, dtype=torch.float32).cuda(), use)
+    dP = gf.contract18_dropout_backward(torch.as_tensor(G, dtype=torch.float32).cuda(), torch.as_tensor(A, dtype=torch.float32).cuda(), use)
+    for b in range(B):
+        o, d, _ = oracle.r18_dropout(use, True, 6, P[b], A[b], G[b])
+        assert rel_err(out[b].cpu().numpy().astype(np.float64), o) <= REL_TOL_F32
+        assert rel_err(dP[b].cpu().numpy().astype(np.float64), d) <= REL_TOL_F32

@@ -57,3 +57,11 @@ def test_entity_style_mixers_and_vertex_chain(bins):
     r = subprocess.run([os.path.join(bins, "test_Mixers_hip")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASSED" in r.stdout
+
+
+@pytest.mark.gpu
+def test_entity_style_slice_dropout(bins):
+    """RisiContraction_18_dropout_hip: same rand() mask as the reference after the same srand(), train/test modes."""
+    r = subprocess.run([os.path.join(bins, "test_Dropout_hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASSED" in r.stdout

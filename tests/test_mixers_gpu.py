@@ -106,6 +106,37 @@ def test_tensor_mixers_vs_oracle(gf, oracle, R, Kd, J, D):
     assert rel_err(host(dF2), oF2) <= REL_TOL_F32 and rel_err(host(dY), oY) <= REL_TOL_F32
 
 
+def test_custommatmultensor_golden(gf, golden):
+    cases = golden_cases(golden, "cmix_")
+    assert len(cases) == 3
+    for tag, c in cases.items():
+        W, T, G = dev(c["W"]), dev(c["T"]), dev(c["G"])
+        assert rel_err(host(gf.custommatmultensor_forward(W, T)), c["Out"]) <= REL_TOL_F32, tag
+        dW, dT = dev(c["dW0"]), dev(c["dT0"])
+        gf.custommatmultensor_backward(G, W, T, dW=dW, dT=dT, accumulate=True)
+        assert rel_err(host(dW), c["dW"]) <= REL_TOL_F32, tag
+        assert rel_err(host(dT), c["dT"]) <= REL_TOL_F32, tag
+
+
+@pytest.mark.parametrize("I,J,V,Kout", [(2, 3, 5, 7), (29, 29, 1152, 64), (64, 64, 180, 10), (17, 5, 64, 33)])
+def test_custommatmultensor_vs_oracle(gf, oracle, I, J, V, Kout):
+    rng = np.random.default_rng(I + 3 * J + 5 * V + 7 * Kout)
+    W = f32exact(rng.uniform(-1, 1, (Kout, V)))
+    T = f32exact(rng.uniform(-1, 1, (I, J, V)))
+    G = f32exact(rng.uniform(-1, 1, (I, J, Kout)))
+    out = host(gf.custommatmultensor_forward(dev(W), dev(T)))
+    assert rel_err(out, np.einsum("kv,ijv->ijk", W, T)) <= REL_TOL_F32
+    dW = torch.empty((Kout, V), device="cuda")
+    dT = torch.empty((I, J, V), device="cuda")
+    gf.custommatmultensor_backward(dev(G), dev(W), dev(T), dW=dW, dT=dT, accumulate=False)
+    assert rel_err(host(dW), np.einsum("ijk,ijv->kv", G, T)) <= REL_TOL_F32
+    assert rel_err(host(dT), np.einsum("ijk,kv->ijv", G, W)) <= REL_TOL_F32
+    if I * J * V * Kout <= 300000:
+        assert rel_err(out, oracle.custommatmultensor_forward(W, T)) <= REL_TOL_F32
+        oW, oT = oracle.custommatmultensor_backward(G, W, T)
+        assert rel_err(host(dW), oW) <= REL_TOL_F32 and rel_err(host(dT), oT) <= REL_TOL_F32
+
+
 def test_stack_round_trip(gf):
     """StackTensor3D: forward is a bit-exact copy, backward scatter-adds (`+=`) into the sources' gradients."""
     N, C = 7, 12

@@ -118,6 +118,18 @@ def test_mixers_match_golden(oracle, golden):
         _close(dX, c["dX"])
 
 
+def test_custommatmultensor_matches_golden(oracle, golden):
+    cases = golden_cases(golden, "cmix_")
+    assert len(cases) == 3
+    for tag, c in cases.items():
+        W, T, G = (c[k].astype(np.float64) for k in ("W", "T", "G"))
+        _close(oracle.custommatmultensor_forward(W, T), c["Out"])
+        _close(oracle.custommatmultensor_forward(W, T), np.einsum("kv,ijv->ijk", W, T))
+        dW, dT = oracle.custommatmultensor_backward(G, W, T, c["dW0"].astype(np.float64), c["dT0"].astype(np.float64))
+        _close(dW, c["dW"])
+        _close(dT, c["dT"])
+
+
 def test_selection_promotion_is_a_gather(golden):
     """SURVEY 8(a8/a9): with a 0/1 selection X, X F X^T is exactly F[pi(i), pi(j), :] or 0."""
     c = golden_cases(golden, "promote_sel")["promote_sel"]
@@ -142,3 +154,22 @@ def test_oracle_against_live_reference(oracle, reference):
             d0 = rng.uniform(-1, 1, (N, N, N, Cc))
             _close(oracle.contract_forward(K, P, A), reference.contract_forward(K, P, A))
             _close(oracle.contract_backward(K, G, A, d0), reference.contract_backward(K, G, A, d0))
+
+
+def test_r18_dropout_matches_golden(oracle, golden):
+    """RisiContraction_18_dropout (RisiContraction_18_dropout.h:106-783): masks drawn by the reference itself."""
+    cases = golden_cases(golden, "drop_")
+    assert len(cases) == 4
+    for tag, c in cases.items():
+        seed, nKept, train = (int(x) for x in c["cfg"])
+        assert int(c["use"].sum()) == (nKept if train else 18), tag
+        P, A, G = (c[k].astype(np.float64) for k in ("P", "A", "G"))
+        out, dP, _ = oracle.r18_dropout(c["use"], bool(train), nKept, P, A, G if train else None,
+                                        c["dP0"].astype(np.float64) if train else None)
+        _close(out, c["Out"])
+        if train:
+            _close(dP, c["dP"])
+            dropped = [k for k in range(18) if not c["use"][k]]
+            assert not np.any(c["Out"][:, :, dropped, :])
+        else:
+            _close(c["Out"], oracle.contract_forward(18, P, A) * (nKept / 18.0))

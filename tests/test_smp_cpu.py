@@ -74,3 +74,15 @@ def test_oracle_against_live_reference_random_molecules():
         assert r["phi"] == [[list(map(int, f)) for f in lv] for lv in o["phi"]]
         assert abs(r["predict"] - o["predict"]) <= 1e-10 * max(1, abs(r["predict"]))
         assert np.abs(r["grads"] - o["grads"]).max() <= 1e-9 * max(1, np.abs(r["grads"]).max())
+
+
+def test_checkpoint_fixture_holds_the_golden_parameters(golden):
+    """The reference-written text checkpoint (SMP_omega::save_model, 6 significant digits) is the syn12 parameter set in
+    registration order H, (K_l, b_l)..., W -- the order the flat device buffer uses."""
+    import os
+    c = golden_cases(golden, "smp_syn12")["smp_syn12"]
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", "smp_syn12_checkpoint.txt")).read()
+    assert raw.endswith(" ") and "\n" not in raw
+    text = np.array(raw.split(), dtype=np.float64)
+    assert text.size == c["params"].size
+    assert np.max(np.abs(text - c["params"]) / np.maximum(np.abs(c["params"]), 1e-30)) < 1e-5

@@ -131,3 +131,31 @@ def test_fused_and_op_by_op_levels_agree_at_scale(gf):
     p0, l0, f0, g0, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap, fused=False)
     assert rel_err(p1, p0) <= TOL_FWD and rel_err(f1, f0) <= TOL_FWD
     assert rel_err(g1, g0) <= TOL_GRAD
+
+
+def test_text_checkpoint_is_interchangeable_with_the_reference(gf, golden, tmp_path):
+    """tests/golden/smp_syn12_checkpoint.txt was written by the REAL SMP_omega::save_model (SMP_omega.h:1033-1042).
+    load_model must read it, predict like the golden, and save_model must write the very same bytes back."""
+    import os
+    from graphflow_amd.smp import SMPOmega
+    path = os.path.join(os.path.dirname(__file__), "golden", "smp_syn12_checkpoint.txt")
+    c = golden_cases(golden, "smp_syn12")["smp_syn12"]
+    L, C, D, cap, wl = (int(x) for x in c["cfg"])
+    net = SMPOmega(L, C, c["feature"].shape[1], D, cap, bool(wl))
+    p = torch.zeros(net.n_params, device="cuda")
+    net.load_model(p, path)
+    text = np.array(open(path).read().split(), dtype=np.float64)
+    assert text.size == net.n_params
+    assert np.array_equal(p.cpu().numpy(), text.astype(np.float32))
+    assert rel_err(p.cpu().numpy().astype(np.float64), c["params"].astype(np.float64)) <= 1e-6  # 6 printed digits
+    net.prepare([(c["adj"], c["feature"])])
+    pred, loss, feat = net.forward(p, dev(c["target"]))
+    assert rel_err(pred.cpu().numpy().astype(np.float64), c["predict"]) <= TOL_FWD
+    out = tmp_path / "resaved.txt"
+    net.save_model(p, out)
+    assert open(out, "rb").read() == open(path, "rb").read()
+    # a short file is an error, not silent garbage
+    short = tmp_path / "short.txt"
+    short.write_text("1 2 3 ")
+    with pytest.raises(RuntimeError):
+        net.load_model(p, short)
