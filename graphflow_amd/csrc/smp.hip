@@ -17,9 +17,11 @@
 #include <string>
 
 #include "smp_internal.h"
+#include "r18_device.h"
 
 namespace gf {
 namespace {
+using namespace dev;
 
 constexpr float kAlpha = 0.01f;  // LeakyReLU3D.h:41, LeakyReLU.h default
 constexpr int kK = 18;
@@ -187,6 +189,33 @@ __global__ void readout_nodes(const float *__restrict__ fL, const int *__restric
         for (int r = 0; r < s * s; ++r) acc += src[(size_t)r * C];
         sh[i] = acc;
         vf[i] = lrelu(acc);
+    }
+}
+
+// C % 4 == 0 and C <= 1024: workgroup per node, 256 threads = (256 / (C/4)) row groups x C/4 float4 lanes; every group
+// sums rows g, g+ng, ... with batched loads, the groups are folded through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void readout_nodes_v(const float *__restrict__ fL, const int *__restrict__ node_s,
+                                                       const long long *__restrict__ node_row, float *__restrict__ sh,
+                                                       float *__restrict__ vf, int C) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    const int n = blockIdx.x, nl = C / 4, ng = 256 / nl;
+    const int g = threadIdx.x / nl, fl = threadIdx.x % nl;
+    const int rows = node_s[n] * node_s[n];
+    if (g < ng) {
+        const int cnt = (rows - g + ng - 1) / ng;
+        const f4 acc = batched_sum(fL + ((size_t)node_row[n] + g) * C + 4 * fl, (size_t)ng * C, 0, cnt > 0 ? cnt : 0,
+                                   [](int) { return 1.f; });
+        st4(red + g * C + 4 * fl, acc);
+    }
+    __syncthreads();
+    if (g == 0) {
+        f4 t = ld4(red + 4 * fl);
+        for (int k = 1; k < ng; ++k) t += ld4(red + k * C + 4 * fl);
+        f4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = lrelu(t[j]);
+        st4(sh + (size_t)n * C + 4 * fl, t);
+        st4(vf + (size_t)n * C + 4 * fl, v);
     }
 }
 
@@ -549,8 +578,13 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
                   b[l], C, (size_t)h.rows * C);
     }
     const gfsmp::LevelLayout &top = B.level[L];
-    GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes, dim3(gf::grid_for((size_t)top.nNodes * C)), dim3(256), 0,
-              s->lv[L].f, s->lv[L].node_s, s->lv[L].node_row, s->sh, s->vf, C, (size_t)top.nNodes * C);
+    if (C % 4 == 0 && C <= 1024) {
+        GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(top.nNodes), dim3(256), 0, s->lv[L].f, s->lv[L].node_s,
+                  s->lv[L].node_row, s->sh, s->vf, C);
+    } else {
+        GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes, dim3(gf::grid_for((size_t)top.nNodes * C)), dim3(256), 0,
+                  s->lv[L].f, s->lv[L].node_s, s->lv[L].node_row, s->sh, s->vf, C, (size_t)top.nNodes * C);
+    }
     GF_LAUNCH(ctx, "smp_readout_mol", gf::readout_molecules, dim3(B.nMol), dim3(256), 0, s->vf, s->mol_ptr, s->mol_nodes, W,
               targets, s->g, s->yhat, loss, s->dy, C);
     if (predict) GF_HIP_TRY(ctx, hipMemcpyAsync(predict, s->yhat, sizeof(float) * B.nMol, hipMemcpyDeviceToDevice, ctx->stream));

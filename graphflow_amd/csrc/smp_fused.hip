@@ -337,29 +337,26 @@ size_t tables_fwd_lds(int N) {
     return sizeof(float) * ((size_t)adj_lds_floats(N) + 2 * (size_t)NCP * CW + kWaves * 2 * CW) + sizeof(short) * (size_t)N * N + 16;
 }
 
-// rowsum_a[x] = sum_b S_ab[x,b], D8[x] = sum_b Dbb[x,b] per (node, x); scalars per node = sum over b of the partials
-__global__ void smp_vectors(const float *__restrict__ T, float *__restrict__ Vt, const float *__restrict__ scal,
-                            float *__restrict__ St, const int *__restrict__ node_s, const long long *__restrict__ node_row,
-                            const long long *__restrict__ node_pair, int C) {
+// rowsum_a[x] = sum_b S_ab[x,b], D8[x] = sum_b Dbb[x,b] per (node, x); scalars per node = sum over b of the partials.
+// Items = (x, float4 lane); the s loads of an item are issued in batches of 8 (batched_sum).
+__global__ __launch_bounds__(256) void smp_vectors(const float *__restrict__ T, float *__restrict__ Vt,
+                                                   const float *__restrict__ scal, float *__restrict__ St,
+                                                   const int *__restrict__ node_s, const long long *__restrict__ node_row,
+                                                   const long long *__restrict__ node_pair, int C) {
     const int n = blockIdx.x;
-    const int s = node_s[n];
+    const int s = node_s[n], nl = C / 4;
     const size_t rowbase = (size_t)node_row[n], pairbase = (size_t)node_pair[n];
-    for (int i = threadIdx.x; i < s * C; i += blockDim.x) {
-        const int f = i % C, x = i / C;
-        float rs = 0.f, d8 = 0.f;
-        const float *t = T + (rowbase + (size_t)x * s) * (size_t)(T_COLS * C) + f;
-        for (int bb = 0; bb < s; ++bb) {
-            rs += t[(size_t)bb * T_COLS * C + T_SAB * C];
-            d8 += t[(size_t)bb * T_COLS * C + T_DBB * C];
-        }
-        Vt[(pairbase + x) * 4 * (size_t)C + 0 * C + f] = rs;
-        Vt[(pairbase + x) * 4 * (size_t)C + 2 * C + f] = d8;
+    const auto one = [](int) { return 1.f; };
+    for (int i = threadIdx.x; i < s * nl; i += blockDim.x) {
+        const int fl = i % nl, x = i / nl;
+        const float *t = T + (rowbase + (size_t)x * s) * (size_t)(T_COLS * C) + 4 * fl;
+        const f4 rs = batched_sum(t + T_SAB * C, (size_t)T_COLS * C, 0, s, one);
+        const f4 d8 = batched_sum(t + T_DBB * C, (size_t)T_COLS * C, 0, s, one);
+        st4(Vt + (pairbase + x) * 4 * (size_t)C + 0 * C + 4 * fl, rs);
+        st4(Vt + (pairbase + x) * 4 * (size_t)C + 2 * C + 4 * fl, d8);
     }
-    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
-        float acc = 0.f;
-        for (int bb = 0; bb < s; ++bb) acc += scal[(pairbase + bb) * 4 * (size_t)C + i];
-        St[(size_t)n * 4 * C + i] = acc;
-    }
+    for (int i = threadIdx.x; i < C; i += blockDim.x)  // 4C floats = C float4
+        st4(St + (size_t)n * 4 * C + 4 * i, batched_sum(scal + pairbase * 4 * (size_t)C + 4 * i, (size_t)4 * C, 0, s, one));
 }
 
 // stacked[p] = K^(kperm[p])  (gather), or  dK^(kperm[p]) += dstacked[p]  (scatter-add)
@@ -481,14 +478,25 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
     }
 }
 
-// out[f] += sum_r part[r][f] over `rows` rows: chunked partial sums, then a fixed-order fold (deterministic)
-__global__ void colsum_chunks(const float *__restrict__ part, float *__restrict__ tmp, int C, long long rows, int rows_per_block) {
+// out[f] += sum_r part[r][f] over `rows` rows: chunked partial sums, then a fixed-order fold (deterministic).
+// 256 threads = row groups x C/4 float4 lanes (C % 4 == 0, C <= 1024), batched loads, ordered LDS fold of the groups.
+__global__ __launch_bounds__(256) void colsum_chunks(const float *__restrict__ part, float *__restrict__ tmp, int C, long long rows,
+                                                     int rows_per_block) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
     const long long r0 = (long long)blockIdx.x * rows_per_block;
-    const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
-    for (int f = threadIdx.x; f < C; f += blockDim.x) {
-        float s = 0.f;
-        for (long long r = r0; r < r1; ++r) s += part[(size_t)r * C + f];
-        tmp[(size_t)blockIdx.x * C + f] = s;
+    const int nr = (int)((r0 + rows_per_block < rows ? r0 + rows_per_block : rows) - r0);
+    const int nl = C / 4, ng = 256 / nl;
+    const int g = threadIdx.x / nl, fl = threadIdx.x % nl;
+    if (g < ng) {
+        const int cnt = (nr - g + ng - 1) / ng;
+        st4(red + g * C + 4 * fl, batched_sum(part + ((size_t)r0 + g) * C + 4 * fl, (size_t)ng * C, 0, cnt > 0 ? cnt : 0,
+                                              [](int) { return 1.f; }));
+    }
+    __syncthreads();
+    if (g == 0) {
+        f4 t = ld4(red + 4 * fl);
+        for (int k = 1; k < ng; ++k) t += ld4(red + k * C + 4 * fl);
+        st4(tmp + (size_t)blockIdx.x * C + 4 * fl, t);
     }
 }
 __global__ void colsum_fold(const float *__restrict__ tmp, float *__restrict__ out, int C, int nblocks) {
@@ -723,7 +731,7 @@ gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *d
 
 bool smp_fused_supported(const gf_smp *s, int l) {
     const int C = s->cfg.nChanels;
-    if (C % 4 != 0) return false;
+    if (C % 4 != 0 || C > 1024) return false;
     const gfsmp::LevelLayout &h = s->lay.level[l];
     if (h.buckets.empty()) return false;
     return h.buckets.back().s <= 32;  // 8 * PPW at LPC = 16
@@ -812,7 +820,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     // bias gradient: column sums of the per-(node,x) partials
     {
         const int rpb = 256, nb = (pairs + rpb - 1) / rpb;  // s->colpart holds (max rows / 1024 + 1) x C floats >= nb x C
-        GF_LAUNCH(ctx, "smpf_colsum", colsum_chunks, dim3(nb), dim3(64), 0, d.dbpart, s->colpart, C, (long long)pairs, rpb);
+        GF_LAUNCH(ctx, "smpf_colsum", colsum_chunks, dim3(nb), dim3(256), 0, d.dbpart, s->colpart, C, (long long)pairs, rpb);
         GF_LAUNCH(ctx, "smpf_colsum_fold", colsum_fold, dim3(1), dim3(256), 0, s->colpart, dbl, C, nb);
     }
     // weight gradients (stacked), then scatter-add into dK_l:  dW = T_blk^T dO_blk   (split-K over rows).  Grouped: the

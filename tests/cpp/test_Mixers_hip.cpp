@@ -186,15 +186,15 @@ static int part3_channel_mix() {
     Tensor3D T(N, N, V);
     for (int i = 0; i < W.size; ++i) W.value[i] = (rand() % 200 - 100) / 50.0;
     for (int i = 0; i < T.size; ++i) T.value[i] = (rand() % 200 - 100) / 50.0;
-    for (int i = 0; i < W.size; ++i) W.gradient[i] = rand() % 3;  // pins `+=`
-    for (int i = 0; i < T.size; ++i) T.gradient[i] = rand() % 3;
     CustomMatMulTensor_hip mix(&W, &T);
     GraphFlowExec graph;
     graph.add(&W, gftags::MATRIX);
     graph.add(&T, gftags::TENSOR3D);
     graph.add(&mix, gftags::CUSTOMMATMULTENSOR_HIP);
+    graph.forward();  // a container's forward() zeroes its gradient (Matrix.h:58-62), so pin `+=` after it
+    for (int i = 0; i < W.size; ++i) W.gradient[i] = rand() % 3;
+    for (int i = 0; i < T.size; ++i) T.gradient[i] = rand() % 3;
     std::vector<double> w = vals(&W), t = vals(&T), dw = vals(&W, true), dt = vals(&T, true);
-    graph.forward();
     int bad = mix.nRows != N || mix.nColumns != N || mix.nDepth != Kout;
     std::vector<double> ref((size_t)N * N * Kout), g(ref.size());
     gfo_custommatmultensor_forward(&w[0], &t[0], &ref[0], N * N, V, Kout);
