@@ -37,6 +37,12 @@ struct GemmArgs {
     int nseg;
     long long a_off[4], b_off[4];
     int klen[4];
+    // optional scaling of op(A): element (m,k) is multiplied by rs[row * rs_ld + scol[piece]] with row = m (A stored
+    // row-major, !TA) or row = k (TA, the reduction runs over the rows); scol < 0 or rs == nullptr: no scaling.
+    // (The fused SMP level folds the per-node factors `total` and `trace` of the adjacency into its block products.)
+    const float *rs;
+    int rs_ld;
+    int scol[4];
 };
 
 // Several GEMMs in ONE launch.  Tiles are ordered panel-major: all tiles of every group that belong to panel p (the
@@ -81,9 +87,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
     constexpr int NA = VEC ? 4 : 16, NB = VEC ? 2 : 8;  // loads per thread per tile
     f4v va[VEC ? NA : 1], vb[VEC ? NB : 1];
     float ra[VEC ? 1 : NA], rb[VEC ? 1 : NB];
+    float sa[VEC ? NA : 1];  // per-load row factors of op(A) (GemmArgs::rs); multiplied in when the tile goes to LDS so that
+    bool scaled = false;  // the factor loads stay in flight behind the MFMAs like the operand loads do
     const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto load_tiles = [&](int k0) {
+        const int sc = g.rs ? g.scol[seg] : -1;  // `seg` is the piece the tile being loaded belongs to
+        scaled = sc >= 0;
         if (VEC) {
 #pragma unroll
             for (int e = 0; e < NA; ++e) {
@@ -92,7 +102,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
                 if (TA) { m = (idx % (BM / 4)) * 4; k = idx / (BM / 4); } else { k = (idx % (BK / 4)) * 4; m = idx / (BK / 4); }
                 const int gm = m0 + m, gk = k0 + k;
                 const size_t off = TA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk;
-                va[e] = (gm < g.M && gk < kend) ? *reinterpret_cast<const f4v *>(A + off) : zero4;
+                const bool in = gm < g.M && gk < kend;
+                va[e] = in ? *reinterpret_cast<const f4v *>(A + off) : zero4;
+                if (TA && sc >= 0) sa[e] = in ? g.rs[(size_t)gk * g.rs_ld + sc] : 0.f;  // applied in store_tiles
             }
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
@@ -111,7 +123,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
                 if (TA) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
                 const int gm = m0 + m, gk = k0 + k;
                 const size_t off = TA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk;
-                ra[e] = (gm < g.M && gk < kend) ? A[off] : 0.f;
+                const bool in = gm < g.M && gk < kend;
+                ra[e] = in ? A[off] : 0.f;
+                if (sc >= 0 && in) ra[e] *= g.rs[(size_t)(TA ? gk : gm) * g.rs_ld + sc];  // (scalar path: no deferral)
             }
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
@@ -124,7 +138,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
             }
         }
     };
+    // !TA: a thread loads the same rows in every k-step, so its factors change only with the K piece
+    auto load_row_scales = [&]() {
+        if (VEC && !TA && g.rs) {
+            const int sc = g.scol[seg];
+#pragma unroll
+            for (int e = 0; e < (VEC ? NA : 1); ++e) {
+                const int gm = m0 + (tid + e * kThreads) / (BK / 4);
+                sa[e] = (sc >= 0 && gm < g.M) ? g.rs[(size_t)gm * g.rs_ld + sc] : 1.f;
+            }
+        }
+    };
     auto store_tiles = [&]() {
+        if (VEC && scaled) {
+#pragma unroll
+            for (int e = 0; e < (VEC ? NA : 1); ++e) va[e] *= sa[e];
+        }
         if (VEC) {
 #pragma unroll
             for (int e = 0; e < NA; ++e) {
@@ -177,6 +206,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
     for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
 
     if (kbeg < kend) {
+        load_row_scales();
         load_tiles(kbeg);
         store_tiles();
         __syncthreads();
@@ -195,6 +225,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
                 kn = 0;
                 kend = g.klen[seg];
                 more = true;
+                load_row_scales();
             }
             if (more) load_tiles(kn);
             f4v fa0[4], fa1[4], fb[4];
@@ -268,7 +299,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
 }
 
 template <bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(kThreads, 4) void gemm_f32_mfma(GemmArgs g) {
+__global__ __launch_bounds__(kThreads, VEC ? 4 : 2) void gemm_f32_mfma(GemmArgs g) {  // (scalar path: 16 + 8 staged loads)
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
     // tile order: the N tile varies fastest, so the workgroups that share one A row-panel run back to back and the
     // panel is read from HBM once (dQ = dZ K^T has 18 N tiles per panel); M tiles can be millions (M = sum s^2)
@@ -323,11 +354,20 @@ __global__ void scatter_add_rows(const T *__restrict__ G, T *const *__restrict__
 // op(A)[M,K] op(B)[K,N] -> C[M,N] (ldc = row stride of C), batched with element strides; accumulate: C += .
 gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *A, int lda, long long sA, const float *B,
                int ldb, long long sB, float *C, int ldc, long long sC, int batch, int accumulate) {
+    return gemm_rs(ctx, ta, tb, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, batch, accumulate, nullptr, 0, -1);
+}
+
+// the same with op(A) scaled per row: rs[row * rs_ld + scol] (see GemmArgs::rs)
+gf_status gemm_rs(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *A, int lda, long long sA, const float *B,
+                  int ldb, long long sB, float *C, int ldc, long long sC, int batch, int accumulate, const float *rs,
+                  int rs_ld, int scol) {
     if (M <= 0 || N <= 0 || batch <= 0) return GF_OK;
+    if (scol < 0) rs = nullptr;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sA = sA; g.sB = sB; g.sC = sC; g.batch = batch; g.accumulate = accumulate;
     g.nseg = 0; g.split_stride = (long long)M * N;
+    g.rs = rs; g.rs_ld = rs_ld; g.scol[0] = scol; g.scol[1] = g.scol[2] = g.scol[3] = -1;
     const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
     // split K when the output has too few tiles to fill 256 CUs and K is long (e.g. dB = A^T dC of the K-projection)
     int splits = 1;
@@ -412,7 +452,10 @@ static void fill_args(GemmArgs *g, const GemmSpec &s) {
         g->a_off[i] = s.a_off[i];
         g->b_off[i] = s.b_off[i];
         g->klen[i] = s.klen[i];
+        g->scol[i] = s.rs ? s.scol[i] : -1;
     }
+    g->rs = s.rs;
+    g->rs_ld = s.rs_ld;
 }
 
 template <bool TA, bool TB>

@@ -470,6 +470,7 @@ gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *a
         if (st != GF_OK) return st;
         UP(d.adj, h.adj);
         UP(d.rsum, h.rsum);
+        UP(d.rowscale, h.rowscale);
         UP(d.quad_node, h.quad_node);
         UP(d.quad_b0, h.quad_b0);
         UP(d.pair_node, h.pair_node);

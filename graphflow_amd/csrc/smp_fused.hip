@@ -29,8 +29,10 @@ __device__ __forceinline__ float lreluf(float z) { return z > 0.f ? z : kAlphaF 
 
 // column blocks of the table matrix T [rows][6C]
 enum { T_DAC = 0, T_SAB = 1, T_SBC = 2, T_DBB = 3, T_T6 = 4, T_T10 = 5, T_COLS = 6 };
-// column blocks of the projected matrix O [rows][5C]
-enum { O_TOT = 0, O_TR = 1, O_DIR = 2, O_Z = 3, O_ZP = 4, O_COLS = 5 };
+// column blocks of the projected matrix O [rows][3C].  O_LOC = tot O_tot + tr O_tr + O_dir: the per-node factors tot and
+// tr (the level's rowscale table) are applied to the T operand inside the GEMM, so the three row-local products
+// accumulate into one block.
+enum { O_LOC = 0, O_Z = 1, O_ZP = 2, O_COLS = 3 };
 // stacked weight layout: position p holds block K^(kperm[p]); groups are contiguous
 //   [0,2) tot | [2,3) tr | [3,5) dir | [5,8) Z | [8,10) Z' | [10,14) V | [14,18) S
 __constant__ int c_kperm[18] = {0, 2, 6, 5, 9, 8, 12, 15, 16, 11, 1, 3, 7, 10, 4, 13, 14, 17};
@@ -399,7 +401,6 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
         st4(sU + e * CW + 4 * fl, fok ? z + zp : splat(0.f));
     }
     __syncthreads();
-    const float tot = L.st[0], tr = L.st[1];
     const f4 vout = ld4(Vout + (pairbase + x) * (size_t)C + fc);
     const f4 sout = ld4(Sout + (size_t)W.node * C + fc);
     const f4 bb = ld4(bias + fc);
@@ -408,8 +409,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
         f4 m[1];
         small_matvec<1, CW>(L, N, y, fl, Tt, m);
         const float *o = O + (rowbase + (size_t)x * N + y) * (size_t)(O_COLS * C) + fc;
-        const f4 z = bb + tot * ld4(o + O_TOT * C) + tr * ld4(o + O_TR * C) + ld4(o + O_DIR * C) + m[0] + L.r[y] * vout +
-                     L.at(x, y, N) * sout;
+        const f4 z = bb + ld4(o + O_LOC * C) + m[0] + L.r[y] * vout + L.at(x, y, N) * sout;
         if (fok) {
             f4 out;
 #pragma unroll
@@ -442,7 +442,6 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AdjLds L = load_adjacency<true>(smem, A + rowbase, N);  // L.A[e][y] = A+[y][e]
     float *sDz = smem + adj_lds_floats(N);  // [N][CW]
-    const float tot = L.st[0], tr = L.st[1];
     for (int y = grp; y < N; y += NGRP) {
         const size_t row = rowbase + (size_t)x * N + y;
         const f4 fv = ld4(F + row * C + fc), g = ld4(dF + row * C + fc);
@@ -451,10 +450,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
         for (int j = 0; j < 4; ++j) dz[j] = fok ? g[j] * (fv[j] > 0.f ? 1.f : kAlphaF) : 0.f;
         st4(sDz + y * CW + 4 * fl, dz);
         if (fok) {
-            float *o = dO + row * (size_t)(O_COLS * C) + f;
-            st4(o + O_TOT * C, tot * dz);
-            st4(o + O_TR * C, tr * dz);
-            st4(o + O_DIR * C, dz);
+            st4(dO + row * (size_t)(O_COLS * C) + O_LOC * C + f, dz);
         }
     }
     __syncthreads();
@@ -737,7 +733,7 @@ bool smp_fused_supported(const gf_smp *s, int l) {
     return h.buckets.back().s <= 32;  // 8 * PPW at LPC = 16
 }
 
-// Q buffer of the level ([rows][18C]) is carved as  T [rows][6C] | O / dO [rows][5C] | dT [rows][6C]
+// Q buffer of the level ([rows][18C]) is carved as  T [rows][6C] | O / dO [rows][3C] | dT [rows][6C]
 gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float *bl) {
     gf_ctx *ctx = s->ctx;
     const gfsmp::LevelLayout &h = s->lay.level[l];
@@ -762,22 +758,28 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     const size_t CC = (size_t)C * C;
     const int ldt = T_COLS * C, ldo = O_COLS * C;
     // block GEMMs: A = T column range, B = stacked weights, C = O column block -- one grouped launch (every row panel
-    // of T is fetched from HBM once and shared through L2 by the five products), separate launches as a fallback
-    struct G { int tcol, kb, wpos, ocol; };
-    const G gs[5] = {{T_SAB, 2, 0, O_TOT}, {T_SAB, 1, 2, O_TR}, {T_T6, 2, 3, O_DIR}, {T_SAB, 3, 5, O_Z}, {T_DAC, 2, 8, O_ZP}};
+    // of T is fetched from HBM once and shared through L2 by the three products), separate launches as a fallback.
+    //   O_LOC = tot [S_ab|S_bc][K0;K2] + tr S_ab K6 + [T6|T10][K5;K9]   (three K pieces, the first two row-scaled)
     {
-        GemmSpec sp[5];
-        for (int i = 0; i < 5; ++i) {
-            GemmSpec z = {T + gs[i].tcol * C, d.Wst + gs[i].wpos * CC, O + gs[i].ocol * C, rows, C, gs[i].kb * C, ldt, C, ldo, 0,
-                          {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-            sp[i] = z;
-        }
-        if (gemm_grouped_supported(sp, 5, false, false)) {
-            st = gemm_grouped_rows(ctx, false, false, sp, 5, rows);
+        const long long tC = C, wCC = (long long)CC;
+        GemmSpec sp[3] = {
+            {T, d.Wst, O + O_LOC * C, rows, C, 5 * C, ldt, C, ldo, 3, {T_SAB * tC, T_SAB * tC, T_T6 * tC, 0}, {0 * wCC, 2 * wCC, 3 * wCC, 0},
+             {2 * C, C, 2 * C, 0}, d.rowscale, 2, {0, 1, -1, -1}},
+            {T + T_SAB * C, d.Wst + 5 * CC, O + O_Z * C, rows, C, 3 * C, ldt, C, ldo, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0,
+             {-1, -1, -1, -1}},
+            {T + T_DAC * C, d.Wst + 8 * CC, O + O_ZP * C, rows, C, 2 * C, ldt, C, ldo, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0,
+             {-1, -1, -1, -1}},
+        };
+        if (gemm_grouped_supported(sp, 3, false, false)) {
+            st = gemm_grouped_rows(ctx, false, false, sp, 3, rows);
             if (st != GF_OK) return st;
         } else {
+            struct G { int tcol, kb, wpos, ocol, scol, acc; };
+            const G gs[5] = {{T_SAB, 2, 0, O_LOC, 0, 0}, {T_SAB, 1, 2, O_LOC, 1, 1}, {T_T6, 2, 3, O_LOC, -1, 1},
+                             {T_SAB, 3, 5, O_Z, -1, 0}, {T_DAC, 2, 8, O_ZP, -1, 0}};
             for (const G &g : gs) {
-                st = gemm(ctx, false, false, rows, C, g.kb * C, T + g.tcol * C, ldt, 0, d.Wst + g.wpos * CC, C, 0, O + g.ocol * C, ldo, 0, 1, 0);
+                st = gemm_rs(ctx, false, false, rows, C, g.kb * C, T + g.tcol * C, ldt, 0, d.Wst + g.wpos * CC, C, 0, O + g.ocol * C, ldo,
+                             0, 1, g.acc, d.rowscale, 2, g.scol);
                 if (st != GF_OK) return st;
             }
         }
@@ -826,13 +828,13 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     // weight gradients (stacked), then scatter-add into dK_l:  dW = T_blk^T dO_blk   (split-K over rows).  Grouped: the
     // five products share each split's row range of T and dO, and their partial images are folded by ONE ordered
     // reduction straight into the first ten stacked blocks.
-    struct G { int tcol, kb, wpos, ocol; };
-    const G gs[5] = {{T_SAB, 2, 0, O_TOT}, {T_SAB, 1, 2, O_TR}, {T_T6, 2, 3, O_DIR}, {T_SAB, 3, 5, O_Z}, {T_DAC, 2, 8, O_ZP}};
+    struct G { int tcol, kb, wpos, ocol, scol; };  // scol: T rows scaled by tot (0) / tr (1) for the row-local products
+    const G gs[5] = {{T_SAB, 2, 0, O_LOC, 0}, {T_SAB, 1, 2, O_LOC, 1}, {T_T6, 2, 3, O_LOC, -1}, {T_SAB, 3, 5, O_Z, -1}, {T_DAC, 2, 8, O_ZP, -1}};
     {
         GemmSpec sp[5];
         for (int i = 0; i < 5; ++i) {
             GemmSpec z = {T + gs[i].tcol * C, dO + gs[i].ocol * C, d.dWst + gs[i].wpos * CC, gs[i].kb * C, C, rows, ldt, ldo, C, 0,
-                          {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                          {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, gs[i].scol >= 0 ? d.rowscale : nullptr, 2, {gs[i].scol, -1, -1, -1}};
             sp[i] = z;
         }
         if (C <= 64 && gemm_grouped_supported(sp, 5, true, false)) {
@@ -840,7 +842,8 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
             if (st != GF_OK) return st;
         } else {
             for (const G &g : gs) {
-                st = gemm(ctx, true, false, g.kb * C, C, rows, T + g.tcol * C, ldt, 0, dO + g.ocol * C, ldo, 0, d.dWst + g.wpos * CC, C, 0, 1, 0);
+                st = gemm_rs(ctx, true, false, g.kb * C, C, rows, T + g.tcol * C, ldt, 0, dO + g.ocol * C, ldo, 0, d.dWst + g.wpos * CC, C,
+                             0, 1, 0, d.rowscale, 2, g.scol);
                 if (st != GF_OK) return st;
             }
         }
@@ -858,22 +861,28 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         // write of dT, dO read once per panel); fallback: six launches that accumulate in a fixed order
         const long long oC = C, wCC = (long long)CC;
         GemmSpec sp[5] = {
-            {dO, d.Wst, dT + T_DAC * C, rows, C, C, ldo, C, ldt, 1, {O_ZP * oC, 0, 0, 0}, {8 * wCC, 0, 0, 0}, {C, 0, 0, 0}},
-            {dO, d.Wst, dT + T_SAB * C, rows, C, 4 * C, ldo, C, ldt, 4, {O_TOT * oC, O_TR * oC, O_Z * oC, O_ZP * oC},
-             {0 * wCC, 2 * wCC, 5 * wCC, 9 * wCC}, {C, C, C, C}},
-            {dO, d.Wst, dT + T_SBC * C, rows, C, 2 * C, ldo, C, ldt, 2, {O_TOT * oC, O_Z * oC, 0, 0}, {1 * wCC, 6 * wCC, 0, 0}, {C, C, 0, 0}},
-            {dO, d.Wst, dT + T_DBB * C, rows, C, C, ldo, C, ldt, 1, {O_Z * oC, 0, 0, 0}, {7 * wCC, 0, 0, 0}, {C, 0, 0, 0}},
-            {dO, d.Wst, dT + T_T6 * C, rows, 2 * C, C, ldo, C, ldt, 1, {O_DIR * oC, 0, 0, 0}, {3 * wCC, 0, 0, 0}, {C, 0, 0, 0}},
+            {dO, d.Wst, dT + T_DAC * C, rows, C, C, ldo, C, ldt, 1, {O_ZP * oC, 0, 0, 0}, {8 * wCC, 0, 0, 0}, {C, 0, 0, 0}, nullptr, 0,
+             {-1, -1, -1, -1}},
+            {dO, d.Wst, dT + T_SAB * C, rows, C, 4 * C, ldo, C, ldt, 4, {O_LOC * oC, O_LOC * oC, O_Z * oC, O_ZP * oC},
+             {0 * wCC, 2 * wCC, 5 * wCC, 9 * wCC}, {C, C, C, C}, d.rowscale, 2, {0, 1, -1, -1}},
+            {dO, d.Wst, dT + T_SBC * C, rows, C, 2 * C, ldo, C, ldt, 2, {O_LOC * oC, O_Z * oC, 0, 0}, {1 * wCC, 6 * wCC, 0, 0}, {C, C, 0, 0},
+             d.rowscale, 2, {0, -1, -1, -1}},
+            {dO, d.Wst, dT + T_DBB * C, rows, C, C, ldo, C, ldt, 1, {O_Z * oC, 0, 0, 0}, {7 * wCC, 0, 0, 0}, {C, 0, 0, 0}, nullptr, 0,
+             {-1, -1, -1, -1}},
+            {dO, d.Wst, dT + T_T6 * C, rows, 2 * C, C, ldo, C, ldt, 1, {O_LOC * oC, 0, 0, 0}, {3 * wCC, 0, 0, 0}, {C, 0, 0, 0}, nullptr, 0,
+             {-1, -1, -1, -1}},
         };
         if (gemm_grouped_supported(sp, 5, false, true)) {
             st = gemm_grouped_rows(ctx, false, true, sp, 5, rows);
             if (st != GF_OK) return st;
         } else {
-            struct H { int ocol, wpos, kb, tcol, acc; };
-            const H hs[6] = {{O_Z, 5, 3, T_SAB, 0}, {O_TOT, 0, 2, T_SAB, 1}, {O_TR, 2, 1, T_SAB, 1},
-                             {O_ZP, 8, 1, T_DAC, 0}, {O_ZP, 9, 1, T_SAB, 1}, {O_DIR, 3, 2, T_T6, 0}};
-            for (const H &g : hs) {
-                st = gemm(ctx, false, true, rows, g.kb * C, C, dO + g.ocol * C, ldo, 0, d.Wst + g.wpos * CC, C, 0, dT + g.tcol * C, ldt, 0, 1, g.acc);
+            struct H { int ocol, wpos, kb, tcol, acc, scol; };
+            const H hs[8] = {{O_Z, 5, 3, T_SAB, 0, -1}, {O_LOC, 0, 1, T_SAB, 1, 0}, {O_LOC, 1, 1, T_SBC, 1, 0}, {O_LOC, 2, 1, T_SAB, 1, 1},
+                             {O_ZP, 8, 1, T_DAC, 0, -1}, {O_ZP, 9, 1, T_SAB, 1, -1}, {O_LOC, 3, 2, T_T6, 0, -1}, {0, 0, 0, 0, 0, 0}};
+            for (int i = 0; i < 7; ++i) {
+                const H &g = hs[i];
+                st = gemm_rs(ctx, false, true, rows, g.kb * C, C, dO + g.ocol * C, ldo, 0, d.Wst + g.wpos * CC, C, 0, dT + g.tcol * C, ldt, 0,
+                             1, g.acc, d.rowscale, 2, g.scol);
                 if (st != GF_OK) return st;
             }
         }

@@ -10,6 +10,9 @@
 namespace gf {
 gf_status gemm(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *A, int lda, long long sA, const float *B,
                int ldb, long long sB, float *C, int ldc, long long sC, int batch, int accumulate);
+gf_status gemm_rs(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const float *A, int lda, long long sA, const float *B,
+                  int ldb, long long sB, float *C, int ldc, long long sC, int batch, int accumulate, const float *rs,
+                  int rs_ld, int scol);
 // one GEMM of a grouped launch (mixers.hip): op(A)[M,K] op(B)[K,N] -> C[M,N]; nseg > 0 splits K into pieces
 struct GemmSpec {
     const float *A, *B;
@@ -18,6 +21,9 @@ struct GemmSpec {
     int nseg;
     long long a_off[4], b_off[4];
     int klen[4];
+    const float *rs;  // optional per-row scaling of op(A) (GemmArgs::rs in mixers.hip); nullptr = none
+    int rs_ld;
+    int scol[4];      // column of rs per K piece (piece 0 when nseg == 0), < 0 = unscaled piece
 };
 bool gemm_grouped_supported(const GemmSpec *specs, int n, bool ta, bool tb);
 gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows);
@@ -34,7 +40,7 @@ struct gf_smp {
     struct DevLevel {
         int *node_s = nullptr;
         long long *node_row = nullptr, *node_p = nullptr, *node_pair = nullptr;
-        float *adj = nullptr, *rsum = nullptr;
+        float *adj = nullptr, *rsum = nullptr, *rowscale = nullptr;
         int *quad_node = nullptr, *quad_b0 = nullptr;
         int *pair_node = nullptr, *pair_src_s = nullptr, *cons_s = nullptr;
         long long *pair_src_row = nullptr, *cons_ptr = nullptr, *cons_slab = nullptr, *cons_inv_off = nullptr;

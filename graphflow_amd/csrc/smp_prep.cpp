@@ -200,6 +200,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         const LevelLayout &prev = out->level[l - 1];
         lv.adj.assign((size_t)lv.rows, 0.f);
         lv.rsum.assign((size_t)lv.pairs, 0.f);
+        lv.rowscale.assign((size_t)lv.rows * 2, 0.f);
         lv.quad_node.clear();
         lv.quad_b0.clear();
         lv.pair_node.assign((size_t)lv.pairs, 0);
@@ -229,6 +230,18 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                     if (av > 0.f) rs += av;
                 }
                 lv.rsum[(size_t)lv.node_pair[n] + i] = rs;
+            }
+            {  // tot = sum of the gated adjacency, tr = its trace: the factors of contraction cases 1/3 and 7 (Appendix A.2)
+                float tot = 0.f, tr = 0.f;
+                for (int i = 0; i < s; ++i) {
+                    tot += lv.rsum[(size_t)lv.node_pair[n] + i];
+                    const float av = lv.adj[(size_t)lv.node_row[n] + (size_t)i * s + i];
+                    if (av > 0.f) tr += av;
+                }
+                for (int r = 0; r < s * s; ++r) {
+                    lv.rowscale[2 * ((size_t)lv.node_row[n] + r)] = tot;
+                    lv.rowscale[2 * ((size_t)lv.node_row[n] + r) + 1] = tr;
+                }
             }
             for (int a = 0; a < s; ++a) {
                 const int w = field[a];

@@ -49,6 +49,7 @@ struct LevelLayout {
     std::vector<int64_t> node_row, node_p, node_pair;
     std::vector<float> adj;  // [rows] reduced adjacency, node-major [s][s]
     std::vector<float> rsum; // [pairs] r[d] = sum_e A+[d][e] (A+ = A where A > 0), pair = node_pair[n] + d
+    std::vector<float> rowscale;  // [rows][2] (tot, tr) of the row's node: per-row factors folded into the level's block GEMMs
     // wave-per-pair kernels: one workgroup (4 waves) per group of 4 consecutive indices of one node
     std::vector<int> quad_node, quad_b0;  // [quads]
     // forward gather (levels >= 1): per pair e = node_pair[n] + a
