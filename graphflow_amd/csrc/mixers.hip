@@ -298,20 +298,31 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
     }
 }
 
+// XCD-aware tile order.  The dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2), so tiles that share
+// an operand panel must not be NEIGHBOURS in blockIdx: this bijection hands every XCD one contiguous range of logical
+// tile ids, in dispatch order (block b is the (b / 8)-th block of XCD b % 8).  Speed only -- any mapping is correct.
+__device__ __forceinline__ unsigned xcd_tile_id(unsigned bid, unsigned nblocks) {
+    constexpr unsigned NX = 8;
+    const unsigned q = nblocks / NX, r = nblocks % NX, x = bid % NX;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / NX;
+}
+
 template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(kThreads, VEC ? 4 : 2) void gemm_f32_mfma(GemmArgs g) {  // (scalar path: 16 + 8 staged loads)
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
     // tile order: the N tile varies fastest, so the workgroups that share one A row-panel run back to back and the
     // panel is read from HBM once (dQ = dZ K^T has 18 N tiles per panel); M tiles can be millions (M = sum s^2)
     const int ntn = g.ntiles_n;
-    const int m0 = (int)(blockIdx.x / ntn) * BM, n0 = (int)(blockIdx.x % ntn) * BN;
+    const unsigned tile = xcd_tile_id(blockIdx.x, gridDim.x);
+    const int m0 = (int)(tile / ntn) * BM, n0 = (int)(tile % ntn) * BN;
     gemm_tile<TA, TB, VEC>(g, smem, m0, n0, blockIdx.z % g.batch, blockIdx.z / g.batch, gridDim.z / g.batch);
 }
 
 template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(kThreads, 4) void gemm_f32_mfma_grouped(GroupedArgs ga, int nsplits) {
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
-    const int panel = (int)(blockIdx.x / ga.tiles_per_panel), t = (int)(blockIdx.x % ga.tiles_per_panel);
+    const unsigned tile = xcd_tile_id(blockIdx.x, gridDim.x);
+    const int panel = (int)(tile / ga.tiles_per_panel), t = (int)(tile % ga.tiles_per_panel);
     int grp = 0;
 #pragma unroll
     for (int i = 1; i < kMaxGroups; ++i)
