@@ -62,6 +62,20 @@ struct GroupedArgs {
 // (four ds_read_b128 instead of sixteen ds_read_b32).
 __device__ __forceinline__ int kpos(int k) { return (k & 1) * (BK / 2) + (k >> 1); }
 
+// Word offset of (row, kp) inside an operand image.  The eight 16-byte slots of a row are XOR-swizzled by a function of
+// the row: unswizzled, the transposing stores (four scalar ds_write_b32 per float4, 36-word row stride, bank =
+// word % 32) put all 32 lanes of a store group on two banks (SQ_LDS_BANK_CONFLICT was 74 % of the LDS-active cycles);
+// with it they are 2-way (B) / 4-way (A^T), the ds_read_b128 fragment reads stay conflict-free (checked by
+// enumeration over the instruction's four 16-lane groups), and a slot still holds four consecutive kp.
+__device__ __forceinline__ int lds_swz(int row) { return (__builtin_popcount(row & 28) & 1) | ((row >> 4) & 2); }
+// k row taken by the q-th group of 16 lanes in the transposing B store: (0,2,1,3) inside every four, so that one 32-lane
+// store group holds k and k+2 (kp differs by 1: disjoint banks) instead of k and k+1 (kp differs by 16: same banks)
+__device__ __forceinline__ int bscat_k(int q) { return (q & ~3) | ((q & 1) << 1) | ((q >> 1) & 1); }
+// row taken by the q-th group of 8 lanes in the float4-along-k stores (two ds_write_b64 per float4).  Pairing rows r and
+// r + 4 in a 16-lane store group would make these stores conflict-free too (they are 2-way now), but measured no gain.
+__device__ __forceinline__ int rowst_m(int q) { return q; }
+__device__ __forceinline__ int lds_at(int row, int kp) { return row * LDS_ROW + ((((kp >> 2) ^ lds_swz(row)) << 2) | (kp & 3)); }
+
 // element (m,k) of op(A): TA ? A[k*lda + m] : A[m*lda + k];   element (k,n) of op(B): TB ? B[n*ldb + k] : B[k*ldb + n]
 // LDS images: As[m][kpos(k)] (128 x 36) and Bs[n][kpos(k)] (64 x 36).  2 x 2 waves; wave (wm, wn) owns rows
 // [64 wm, 64 wm + 64) x cols [32 wn, 32 wn + 32) as two independent 32 x 32 accumulators, so each k-step issues two
@@ -99,7 +113,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
             for (int e = 0; e < NA; ++e) {
                 const int idx = tid + e * kThreads;
                 int m, k;
-                if (TA) { m = (idx % (BM / 4)) * 4; k = idx / (BM / 4); } else { k = (idx % (BK / 4)) * 4; m = idx / (BK / 4); }
+                if (TA) { m = (idx % (BM / 4)) * 4; k = idx / (BM / 4); } else { k = (idx % (BK / 4)) * 4; m = rowst_m(idx / (BK / 4)); }
                 const int gm = m0 + m, gk = k0 + k;
                 const size_t off = TA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk;
                 const bool in = gm < g.M && gk < kend;
@@ -110,7 +124,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
             for (int e = 0; e < NB; ++e) {
                 const int idx = tid + e * kThreads;
                 int k, n;
-                if (TB) { k = (idx % (BK / 4)) * 4; n = idx / (BK / 4); } else { n = (idx % (BN / 4)) * 4; k = idx / (BN / 4); }
+                if (TB) { k = (idx % (BK / 4)) * 4; n = rowst_m(idx / (BK / 4)); } else { n = (idx % (BN / 4)) * 4; k = bscat_k(idx / (BN / 4)); }
                 const int gn = n0 + n, gk = k0 + k;
                 const size_t off = TB ? (size_t)gn * g.ldb + gk : (size_t)gk * g.ldb + gn;
                 vb[e] = (gn < g.N && gk < kend) ? *reinterpret_cast<const f4v *>(B + off) : zero4;
@@ -144,7 +158,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
             const int sc = g.scol[seg];
 #pragma unroll
             for (int e = 0; e < (VEC ? NA : 1); ++e) {
-                const int gm = m0 + (tid + e * kThreads) / (BK / 4);
+                const int gm = m0 + rowst_m((tid + e * kThreads) / (BK / 4));
                 sa[e] = (sc >= 0 && gm < g.M) ? g.rs[(size_t)gm * g.rs_ld + sc] : 1.f;
             }
         }
@@ -161,26 +175,26 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
                 if (TA) {  // four consecutive m at one k
                     const int m = (idx % (BM / 4)) * 4, kp = kpos(idx / (BM / 4));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) As[(m + j) * LDS_ROW + kp] = va[e][j];
+                    for (int j = 0; j < 4; ++j) As[lds_at(m + j, kp)] = va[e][j];
                 } else {   // four consecutive k of one row: even pair and odd pair are each contiguous
-                    const int k = (idx % (BK / 4)) * 4, m = idx / (BK / 4);
+                    const int k = (idx % (BK / 4)) * 4, m = rowst_m(idx / (BK / 4));
                     float2 ev = make_float2(va[e][0], va[e][2]), od = make_float2(va[e][1], va[e][3]);
-                    *reinterpret_cast<float2 *>(As + m * LDS_ROW + (k >> 1)) = ev;
-                    *reinterpret_cast<float2 *>(As + m * LDS_ROW + BK / 2 + (k >> 1)) = od;
+                    *reinterpret_cast<float2 *>(As + lds_at(m, k >> 1)) = ev;
+                    *reinterpret_cast<float2 *>(As + lds_at(m, BK / 2 + (k >> 1))) = od;
                 }
             }
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
                 const int idx = tid + e * kThreads;
                 if (TB) {
-                    const int k = (idx % (BK / 4)) * 4, n = idx / (BK / 4);
+                    const int k = (idx % (BK / 4)) * 4, n = rowst_m(idx / (BK / 4));
                     float2 ev = make_float2(vb[e][0], vb[e][2]), od = make_float2(vb[e][1], vb[e][3]);
-                    *reinterpret_cast<float2 *>(Bs + n * LDS_ROW + (k >> 1)) = ev;
-                    *reinterpret_cast<float2 *>(Bs + n * LDS_ROW + BK / 2 + (k >> 1)) = od;
+                    *reinterpret_cast<float2 *>(Bs + lds_at(n, k >> 1)) = ev;
+                    *reinterpret_cast<float2 *>(Bs + lds_at(n, BK / 2 + (k >> 1))) = od;
                 } else {
-                    const int n = (idx % (BN / 4)) * 4, kp = kpos(idx / (BN / 4));
+                    const int n = (idx % (BN / 4)) * 4, kp = kpos(bscat_k(idx / (BN / 4)));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) Bs[(n + j) * LDS_ROW + kp] = vb[e][j];
+                    for (int j = 0; j < 4; ++j) Bs[lds_at(n + j, kp)] = vb[e][j];
                 }
             }
         } else {
@@ -189,14 +203,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
                 const int idx = tid + e * kThreads;
                 int m, k;
                 if (TA) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
-                As[m * LDS_ROW + kpos(k)] = ra[e];
+                As[lds_at(m, kpos(k))] = ra[e];
             }
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
                 const int idx = tid + e * kThreads;
                 int k, n;
                 if (TB) { k = idx % BK; n = idx / BK; } else { n = idx % BN; k = idx / BN; }
-                Bs[n * LDS_ROW + kpos(k)] = rb[e];
+                Bs[lds_at(n, kpos(k))] = rb[e];
             }
         }
     };
@@ -210,9 +224,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
         load_tiles(kbeg);
         store_tiles();
         __syncthreads();
+        // fragment q of a lane = logical slot 4 lh + q of its row = physical slot 4 lh + (q ^ swizzle(row))  (swizzle < 4)
         const float *a0p = As + (wm * 64 + li) * LDS_ROW + lh * (BK / 2);
         const float *a1p = a0p + 32 * LDS_ROW;
         const float *bp = Bs + (wn * 32 + li) * LDS_ROW + lh * (BK / 2);
+        const int za0 = lds_swz(wm * 64 + li), za1 = lds_swz(wm * 64 + 32 + li), zb = lds_swz(wn * 32 + li);
         int k0 = kbeg;
         for (;;) {
             // next tile: the following BK rows of this piece, or the first tile of the next piece
@@ -231,9 +247,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
             f4v fa0[4], fa1[4], fb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                fa0[q] = *reinterpret_cast<const f4v *>(a0p + 4 * q);
-                fa1[q] = *reinterpret_cast<const f4v *>(a1p + 4 * q);
-                fb[q] = *reinterpret_cast<const f4v *>(bp + 4 * q);
+                fa0[q] = *reinterpret_cast<const f4v *>(a0p + 4 * (q ^ za0));
+                fa1[q] = *reinterpret_cast<const f4v *>(a1p + 4 * (q ^ za1));
+                fb[q] = *reinterpret_cast<const f4v *>(bp + 4 * (q ^ zb));
             }
 #pragma unroll
             for (int j = 0; j < BK / 2; ++j) {
