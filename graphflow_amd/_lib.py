@@ -73,6 +73,12 @@ PROTOTYPES.update({
     "gf_smp_prepare": (_i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
     "gf_smp_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gf_smp_backward": (_i, [_vp, _vp, _vp, _i]),
+    "gf_smp_parameters_upload": (_i, [_vp, _fp]),
+    "gf_smp_parameters_download": (_i, [_vp, _fp, _fp]),
+    "gf_smp_forward_host": (_i, [_vp, _dp, _dp, _dp, _dp]),
+    "gf_smp_adam_step": (_i, [_vp, _vp, _vp, C.c_double, _i]),
+    "gf_smp_adam_reset": (_i, [_vp]),
+    "gf_smp_uniform_init_host": (_i, [_vp, _fp]),
     "gf_smp_save_model": (_i, [_vp, _vp, C.c_char_p]),
     "gf_smp_load_model": (_i, [_vp, _vp, C.c_char_p]),
     "gf_smp_set_fused": (_i, [_vp, _i]),

@@ -13,6 +13,7 @@
 // Nodes of a level are bucketed by receptive-field size; each bucket is one uniform-N contraction launch and all
 // buckets share one tall K-projection GEMM per level.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -284,7 +285,29 @@ __global__ void readout_backward_nodes(const float *__restrict__ dy, const float
     }
 }
 
+// Adam::Learn(alpha, nBatch) (GraphFlow/Adam.h:106-133) on the flat parameter buffer.  The reference advances its
+// bias-correction powers INSIDE the element loop (beta1_t *= beta1 per element, :121,:125), so element i of the call that
+// starts after n0 processed elements uses beta^(n0 + i + 1); restated in closed form, in double like the reference.
+__global__ void adam_step(float *__restrict__ p, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
+                          size_t n, double alpha, double inv_batch, unsigned long long n0, double beta1, double beta2,
+                          double eps) {
+    const double l1 = log(beta1), l2 = log(beta2);
+    GRID_STRIDE(i, n) {
+        const double g = (double)grad[i] * inv_batch;
+        const double mi = beta1 * (double)m[i] + (1.0 - beta1) * g;
+        const double vi = beta2 * (double)v[i] + (1.0 - beta2) * g * g;
+        const double t = (double)(n0 + i + 1);
+        const double mh = mi / (1.0 - exp(t * l1)), vh = vi / (1.0 - exp(t * l2));
+        m[i] = (float)mi;
+        v[i] = (float)vi;
+        p[i] = (float)((double)p[i] - alpha * mh / (sqrt(vh) + eps));
+    }
+}
+
 __global__ void zero_f32(float *p, size_t n) { GRID_STRIDE(i, n) p[i] = 0.f; }
+
+size_t param_count(const gfsmp::Config &c);
+static size_t param_count_of(const gf_smp *s) { return param_count(s->cfg); }
 
 template <typename T>
 gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
@@ -304,7 +327,19 @@ void release(gf_smp *s) {
     for (void *p : s->allocs) (void)hipFree(p);
     s->allocs.clear();
     s->lv.clear();
+    s->own_t = s->own_y = s->own_loss = s->own_feat = nullptr;
     s->prepared = s->forwarded = false;
+}
+
+// the handle-owned parameter / gradient buffers (host-pointer mode), created on first use
+gf_status own_model(gf_smp *s) {
+    if (s->own_p) return GF_OK;
+    const size_t n = param_count_of(s);
+    GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->own_p), n * sizeof(float)));
+    GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->own_g), n * sizeof(float)));
+    GF_HIP_TRY(s->ctx, hipMemsetAsync(s->own_p, 0, n * sizeof(float), s->ctx->stream));
+    GF_HIP_TRY(s->ctx, hipMemsetAsync(s->own_g, 0, n * sizeof(float), s->ctx->stream));
+    return GF_OK;
 }
 
 struct ParamView {
@@ -393,16 +428,138 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
 gf_status gf_smp_destroy(gf_smp *s) {
     if (!s) return GF_OK;
     gf::release(s);
+    if (s->adam_m) (void)hipFree(s->adam_m);
+    if (s->adam_v) (void)hipFree(s->adam_v);
+    if (s->own_p) (void)hipFree(s->own_p);
+    if (s->own_g) (void)hipFree(s->own_g);
     delete s;
     return GF_OK;
 }
 
 size_t gf_smp_param_count(const gf_smp *s) { return s ? gf::param_count(s->cfg) : 0; }
 
+// ---- host-pointer mode of the driver: the handle owns the model, batches and results cross as host arrays -------------
+gf_status gf_smp_parameters_upload(gf_smp *s, const float *host) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    if (!host) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_parameters_upload: null argument");
+    gf_status st = gf::own_model(s);
+    if (st != GF_OK) return st;
+    GF_HIP_TRY(s->ctx, hipMemcpyAsync(s->own_p, host, gf::param_count(s->cfg) * sizeof(float), hipMemcpyHostToDevice, s->ctx->stream));
+    GF_HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    return GF_OK;
+}
+
+gf_status gf_smp_parameters_download(gf_smp *s, float *host_params, float *host_grads) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    if (!s->own_p) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_parameters_download: no handle-owned model");
+    const size_t bytes = gf::param_count(s->cfg) * sizeof(float);
+    if (host_params) GF_HIP_TRY(s->ctx, hipMemcpyAsync(host_params, s->own_p, bytes, hipMemcpyDeviceToHost, s->ctx->stream));
+    if (host_grads) GF_HIP_TRY(s->ctx, hipMemcpyAsync(host_grads, s->own_g, bytes, hipMemcpyDeviceToHost, s->ctx->stream));
+    GF_HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    return GF_OK;
+}
+
+gf_status gf_smp_forward_host(gf_smp *s, const double *targets, double *predict, double *loss, double *graph_feature) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    gf_ctx *ctx = s->ctx;
+    if (!s->prepared) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward_host before gf_smp_prepare");
+    if (!s->own_p) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward_host: no handle-owned model (gf_smp_parameters_upload)");
+    const int nMol = s->lay.nMol, C = s->cfg.nChanels;
+    gf_status st;
+    if (!s->own_y) {
+        st = gf::upload(s, &s->own_t, nullptr, (size_t)nMol);
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &s->own_y, nullptr, (size_t)nMol);
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &s->own_loss, nullptr, (size_t)nMol);
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &s->own_feat, nullptr, (size_t)nMol * C);
+        if (st != GF_OK) return st;
+    }
+    std::vector<float> tmp((size_t)nMol * (C > 1 ? C : 1));
+    if (targets) {
+        for (int m = 0; m < nMol; ++m) tmp[m] = (float)targets[m];
+        GF_HIP_TRY(ctx, hipMemcpyAsync(s->own_t, tmp.data(), sizeof(float) * nMol, hipMemcpyHostToDevice, ctx->stream));
+        GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // tmp is reused below
+    }
+    st = gf_smp_forward(s, s->own_p, targets ? s->own_t : nullptr, s->own_y, s->own_loss, s->own_feat);
+    if (st != GF_OK) return st;
+    struct Out { double *dst; const float *src; size_t n; } outs[3] = {
+        {predict, s->own_y, (size_t)nMol}, {targets ? loss : nullptr, s->own_loss, (size_t)nMol}, {graph_feature, s->own_feat, (size_t)nMol * C}};
+    for (const Out &o : outs) {
+        if (!o.dst) continue;
+        GF_HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), o.src, sizeof(float) * o.n, hipMemcpyDeviceToHost, ctx->stream));
+        GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < o.n; ++i) o.dst[i] = (double)tmp[i];
+    }
+    return GF_OK;
+}
+
+// One optimiser step of SMP_omega::BatchLearn (SMP_omega.h:820-821): grads hold the SUM over the batch (gf_smp_backward),
+// Adam::Learn(learning_rate, nBatch) divides by nBatch.  Defaults of Adam.h:26-29: beta1 0.9, beta2 0.999, epsilon 1e-8.
+gf_status gf_smp_adam_step(gf_smp *s, float *params, const float *grads, double learning_rate, int nBatch) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    gf_ctx *ctx = s->ctx;
+    if (!params && !grads && s->own_p) {
+        params = s->own_p;
+        grads = s->own_g;
+    }
+    if (!params || !grads || nBatch <= 0) return fail(ctx, GF_ERR_INVALID, "gf_smp_adam_step: bad argument");
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = gf::param_count(s->cfg);
+    if (!s->adam_m) {
+        GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->adam_m), n * sizeof(float)));
+        GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->adam_v), n * sizeof(float)));
+        GF_HIP_TRY(ctx, hipMemsetAsync(s->adam_m, 0, n * sizeof(float), ctx->stream));
+        GF_HIP_TRY(ctx, hipMemsetAsync(s->adam_v, 0, n * sizeof(float), ctx->stream));
+        s->adam_n = 0;
+    }
+    GF_LAUNCH(ctx, "smp_adam", gf::adam_step, dim3(gf::grid_for(n)), dim3(256), 0, params, grads, s->adam_m, s->adam_v, n,
+              learning_rate, 1.0 / (double)nBatch, s->adam_n, 0.9, 0.999, 1e-8);
+    s->adam_n += n;
+    return GF_OK;
+}
+
+gf_status gf_smp_adam_reset(gf_smp *s) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    if (s->adam_m) {
+        const size_t n = gf::param_count(s->cfg);
+        GF_HIP_TRY(s->ctx, hipMemsetAsync(s->adam_m, 0, n * sizeof(float), s->ctx->stream));
+        GF_HIP_TRY(s->ctx, hipMemsetAsync(s->adam_v, 0, n * sizeof(float), s->ctx->stream));
+    }
+    s->adam_n = 0;
+    return GF_OK;
+}
+
+// SMP_omega::weights_initialization (SMP_omega.h:334-338) = GraphFlow::uniform_init (GraphFlow.h:1297-1306) over the
+// parameters in registration order, drawn from the C library's rand() exactly as the reference draws them: after the
+// same srand() a model built here starts from the same weights as one built by the reference.  Host buffer.
+gf_status gf_smp_uniform_init_host(const gf_smp_config *cfg, float *params) {
+    if (!cfg || !params) return GF_ERR_INVALID;
+    gfsmp::Config c = {cfg->nLevels, cfg->nChanels, cfg->nFeatures, cfg->nDepth, cfg->max_receptive_field, cfg->has_WL_ordering};
+    const size_t C = (size_t)c.nChanels;
+    std::vector<size_t> sizes;
+    sizes.push_back(C * c.fdim());
+    for (int l = 1; l <= c.nLevels; ++l) {
+        sizes.push_back((size_t)gf::kK * C * C);
+        sizes.push_back(C);
+    }
+    sizes.push_back(C);
+    size_t off = 0;
+    for (size_t v = 0; v < sizes.size(); ++v)
+        for (size_t i = 0; i < sizes[v]; ++i) {
+            double x = (double)(rand() % 10) / (10.0 * (double)sizes[v]);
+            if (rand() % 2 == 1) x = -x;
+            params[off++] = (float)x;
+        }
+    return GF_OK;
+}
+
 // Text checkpoints in the reference's format (SMP_omega.h:1033-1042 / :1044-1055): every parameter value in
 // registration order, printed with the default ostream format (= "%g", 6 significant digits) followed by one blank.
 gf_status gf_smp_save_model(const gf_smp *s, const float *params, const char *path) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp");
+    if (!params) params = s->own_p;
     if (!params || !path) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_save_model: null argument");
     const size_t n = gf::param_count(s->cfg);
     std::vector<float> host(n);
@@ -416,8 +573,13 @@ gf_status gf_smp_save_model(const gf_smp *s, const float *params, const char *pa
     return ok ? GF_OK : fail(s->ctx, GF_ERR_INVALID, "gf_smp_save_model: write to %s failed", path);
 }
 
-gf_status gf_smp_load_model(const gf_smp *s, float *params, const char *path) {
+gf_status gf_smp_load_model(gf_smp *s, float *params, const char *path) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp");
+    if (!params) {
+        gf_status st0 = gf::own_model(s);
+        if (st0 != GF_OK) return st0;
+        params = s->own_p;
+    }
     if (!params || !path) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_load_model: null argument");
     const size_t n = gf::param_count(s->cfg);
     FILE *f = std::fopen(path, "r");
@@ -546,7 +708,10 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     gf_ctx *ctx = s->ctx;
     if (!s->prepared) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward before gf_smp_prepare");
-    if (!params) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward: null params");
+    if (!params) {  // the handle's own model (gf_smp_parameters_upload)
+        if (!s->own_p) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward: null params and no handle-owned model");
+        params = s->own_p;
+    }
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const gfsmp::BatchLayout &B = s->lay;
     const int L = s->cfg.nLevels, C = s->cfg.nChanels, FD = s->cfg.fdim();
@@ -599,6 +764,10 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     gf_ctx *ctx = s->ctx;
     if (!s->forwarded) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward before gf_smp_forward");
+    if (!params && !grads && s->own_p) {
+        params = s->own_p;
+        grads = s->own_g;
+    }
     if (!params || !grads) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: null argument");
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const gfsmp::BatchLayout &B = s->lay;

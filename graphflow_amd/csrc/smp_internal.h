@@ -64,6 +64,12 @@ struct gf_smp {
     float *colpart = nullptr;  // partial column sums for bias gradients
     int *top_node_mol = nullptr, *mol_ptr = nullptr, *mol_nodes = nullptr;
     std::vector<void *> allocs;
+    // Adam state (gf_smp_adam_step); survives gf_smp_prepare, freed by gf_smp_destroy
+    float *adam_m = nullptr, *adam_v = nullptr;
+    // handle-owned model (host-pointer mode of the driver): parameters and their gradient, [param_count] each
+    float *own_p = nullptr, *own_g = nullptr;
+    float *own_t = nullptr, *own_y = nullptr, *own_loss = nullptr, *own_feat = nullptr;  // per-batch, freed by release()
+    unsigned long long adam_n = 0;  // parameter elements processed so far (the reference's running beta powers)
 };
 
 namespace gf {

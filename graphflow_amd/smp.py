@@ -54,6 +54,23 @@ class SMPOmega:
                                                 1 if accumulate else 0))
         return grads
 
+    def adam_step(self, params, grads, learning_rate, nBatch):
+        """Adam::Learn(learning_rate, nBatch) as SMP_omega::BatchLearn applies it (SMP_omega.h:820-821); grads = batch sum."""
+        self.ctx.check(self.lib.gf_smp_adam_step(self.handle, C.c_void_p(params.data_ptr()), C.c_void_p(grads.data_ptr()),
+                                                 float(learning_rate), int(nBatch)))
+        return params
+
+    def adam_reset(self):
+        self.ctx.check(self.lib.gf_smp_adam_reset(self.handle))
+
+    def uniform_init(self):
+        """Initial weights exactly as SMP_omega's constructor draws them from rand() (host numpy array; call srand first)."""
+        out = np.zeros(self.n_params, dtype=np.float32)
+        st = self.lib.gf_smp_uniform_init_host(C.byref(self.cfg), out.ctypes.data_as(C.POINTER(C.c_float)))
+        if st != 0:
+            raise RuntimeError("gf_smp_uniform_init_host failed")
+        return out
+
     def save_model(self, params, path):
         """SMP_omega::save_model (SMP_omega.h:1033-1042): text checkpoint the reference's load_model reads."""
         self.ctx.check(self.lib.gf_smp_save_model(self.handle, C.c_void_p(params.data_ptr()), str(path).encode()))

@@ -193,10 +193,26 @@ gf_status gf_smp_backward(gf_smp *smp, const float *params, float *grads, int ac
 /* 1 (default): fused level kernels (no promoted stack, no 18-slice contraction output in HBM) where the shape allows;
  * 0: the op-by-op pipeline.  Same results within fp32 rounding; kept switchable for parity tests. */
 gf_status gf_smp_set_fused(gf_smp *smp, int on);
+/* Host-pointer mode of the driver (what graphflow_amd/host/SMP_omega_hip.h uses): the handle owns the model -- a device
+ * parameter buffer and its gradient.  Wherever the entry points of this section take `params` / `grads`, NULL selects the
+ * handle-owned buffers.  gf_smp_forward_host runs gf_smp_forward on them and returns per-molecule results as doubles
+ * (targets NULL: predict / Feature only; loss is 0.5 (y - t)^2 per molecule, SquaredLoss.h:45-53).  Blocking. */
+gf_status gf_smp_parameters_upload(gf_smp *smp, const float *host_params);
+gf_status gf_smp_parameters_download(gf_smp *smp, float *host_params, float *host_grads);
+gf_status gf_smp_forward_host(gf_smp *smp, const double *targets, double *predict, double *loss, double *graph_feature);
+/* Optimiser step of SMP_omega::BatchLearn (GraphFlow/SMP_omega.h:820-821 -> Adam::Learn(alpha, nBatch), Adam.h:106-133,
+ * including its per-element advance of the bias-correction powers): params -= ..., from grads = the batch SUM written by
+ * gf_smp_backward (all-reduced over ranks first in data-parallel runs; nBatch is then the GLOBAL batch).  The moment
+ * buffers live in the handle and survive gf_smp_prepare.  Device pointers. */
+gf_status gf_smp_adam_step(gf_smp *smp, float *params, const float *grads, double learning_rate, int nBatch);
+gf_status gf_smp_adam_reset(gf_smp *smp);
+/* SMP_omega::weights_initialization (SMP_omega.h:334-338; GraphFlow.h:1297-1306) into a HOST buffer of
+ * gf_smp_param_count floats, drawing from rand() in the reference's order: same srand() -> same initial weights. */
+gf_status gf_smp_uniform_init_host(const gf_smp_config *cfg, float *params);
 /* Text checkpoints interchangeable with SMP_omega::save_model / load_model (GraphFlow/SMP_omega.h:1033-1055):
  * whitespace-separated values in the flat parameter order above.  `params` is a device pointer.  Blocking. */
 gf_status gf_smp_save_model(const gf_smp *smp, const float *params, const char *path);
-gf_status gf_smp_load_model(const gf_smp *smp, float *params, const char *path);
+gf_status gf_smp_load_model(gf_smp *smp, float *params, const char *path);
 gf_status gf_smp_prepare_molecule_host(const gf_smp_config *cfg, int V, const int *adj, const double *feature,
                                        int *phi_out, double *wl_out);  /* host only; phi_out [L+1][V][cap+1], slot 0 = size */
 int       gf_smp_receptive_field(const gf_smp *smp, int mol, int level, int v, int *out, int capacity);

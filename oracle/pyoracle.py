@@ -280,6 +280,34 @@ def time_r18_fwd_bwd(P, A, G, prefer_reference=True):
     return time.perf_counter() - t0, "port", out, dP
 
 
+def reference_batchlearn(mols, targets, nLevels, nChanels, nDepth, cap, max_nVertices, nIter, learning_rate, params=None, seed=-1):
+    """nIter x the REAL SMP_omega::BatchLearn(nBatch, molecules, targets, learning_rate).  params given, or drawn by the
+    reference's own constructor after srand(seed).  Returns dict(params0, params, losses[nIter, 2])."""
+    ref = reference()
+    if ref is None:
+        return None
+    nV = np.array([len(a) for a, _ in mols], dtype=np.int32)
+    F = mols[0][1].shape[1]
+    adj = np.concatenate([np.asarray(a, dtype=np.int32).ravel() for a, _ in mols])
+    feat = np.concatenate([np.asarray(f, dtype=np.float64).ravel() for _, f in mols])
+    tg = np.ascontiguousarray(targets, dtype=np.float64)
+    n = smp_param_count_(nChanels, F, nDepth, nLevels)
+    p_in = np.zeros(n) if params is None else np.ascontiguousarray(params, dtype=np.float64)
+    p0, p1, losses = np.zeros(n), np.zeros(n), np.zeros((nIter, 2))
+    f = ref.lib.ref_smp_omega_batchlearn
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f.argtypes = [_i] * 7 + [ip, ip, _dp, _dp, _dp, _i, _dp, _i, C_double, _dp, _dp]
+    f.restype = _i
+    got = f(max_nVertices, cap, nLevels, nChanels, F, nDepth, len(mols), nV, adj, feat, tg, p_in, int(seed), p0, nIter,
+            float(learning_rate), losses, p1)
+    assert got == n, (got, n)
+    return {"params0": p0, "params": p1, "losses": losses}
+
+
+def smp_param_count_(C_, F, D, L):
+    return C_ * F * (D + 1) + L * (18 * C_ * C_ + C_) + C_
+
+
 def reference_save_model(path, params, nLevels, nChanels, nFeatures, nDepth, cap, max_nVertices):
     """Text checkpoint written by the REAL reference's SMP_omega::save_model for the given parameter values."""
     ref = reference()

@@ -351,6 +351,47 @@ extern "C" int ref_smp_omega_save_model(int max_nVertices, int max_rf, int nLeve
     return (int)off;
 }
 
+// nIter calls of the REAL SMP_omega::BatchLearn(nBatch, molecule, target, learning_rate) (SMP_omega.h:798-825: loss before,
+// summed gradients, Adam::Learn(alpha, nBatch), loss after) from given parameters; returns the parameters afterwards.
+// seed >= 0: ignore `params`, srand(seed) before constructing -- the constructor's own weights_initialization
+// (SMP_omega.h:334-338, GraphFlow.h:1297-1306) then draws the initial weights, which are returned in params0_out.
+extern "C" int ref_smp_omega_batchlearn(int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int nDepth,
+                                        int nMol, const int *nV, const int *adj, const double *feature, const double *targets,
+                                        const double *params, int seed, double *params0_out, int nIter, double learning_rate,
+                                        double *losses /* [nIter][2] */, double *params_out) {
+    if (seed >= 0) srand((unsigned)seed);
+    SMP_omega &net = *new SMP_omega(max_nVertices, max_rf, nLevels, nChanels, nFeatures, nDepth);
+    size_t off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) {
+            if (seed < 0) net.sgd->params[i]->value[j] = params[off];
+            if (params0_out) params0_out[off] = net.sgd->params[i]->value[j];
+            ++off;
+        }
+    std::vector<DenseGraph *> mol(nMol);
+    std::vector<double> tgt(targets, targets + nMol);
+    size_t ao = 0, fo = 0;
+    for (int m = 0; m < nMol; ++m) {
+        const int V = nV[m];
+        mol[m] = new DenseGraph(V, nFeatures);
+        for (int i = 0; i < V; ++i) {
+            for (int j = 0; j < V; ++j) mol[m]->adj[i][j] = adj[ao + (size_t)i * V + j];
+            for (int f = 0; f < nFeatures; ++f) mol[m]->feature[i][f] = feature[fo + (size_t)i * nFeatures + f];
+        }
+        ao += (size_t)V * V;
+        fo += (size_t)V * nFeatures;
+    }
+    for (int it = 0; it < nIter; ++it) {
+        std::pair<double, double> r = net.BatchLearn(nMol, &mol[0], &tgt[0], learning_rate);
+        losses[2 * it] = r.first;
+        losses[2 * it + 1] = r.second;
+    }
+    off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) params_out[off++] = net.sgd->params[i]->value[j];
+    return (int)off;
+}
+
 // CPU baseline for the SMP_omega workload: one model instance, nMol molecules, the per-molecule body of
 // SMP_omega::BatchLearn's gradient loop (complete_computation_graph + forward + backward, SMP_omega.h:810-818);
 // returns the seconds spent in that loop (construction and allocation are outside the clock).

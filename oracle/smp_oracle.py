@@ -209,3 +209,27 @@ def run(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, want
     grads.append(dW.ravel())
     out["grads"] = np.concatenate(grads)
     return out
+
+
+def adam_learn(params, grads_sum, m, v, n0, alpha, nBatch, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Adam::Learn(alpha, nBatch) (GraphFlow/Adam.h:106-133) on the flat parameter vector, fp64.  The reference multiplies
+    its bias-correction powers once PER ELEMENT (:121,:125), carried across calls: element i uses beta^(n0 + i + 1).
+    Returns (params, m, v, n0 + len(params)); the powers are formed by the same running products."""
+    p = np.array(params, dtype=np.float64)
+    m = np.array(m, dtype=np.float64)
+    v = np.array(v, dtype=np.float64)
+    # running products from the start of training (n0 factors already applied)
+    b1t, b2t = 1.0, 1.0
+    for _ in range(int(n0)):
+        b1t *= beta1
+        b2t *= beta2
+    for i in range(p.size):
+        g = grads_sum[i] / nBatch
+        m[i] = beta1 * m[i] + (1.0 - beta1) * g
+        v[i] = beta2 * v[i] + (1.0 - beta2) * g * g
+        b1t *= beta1
+        mh = m[i] / (1.0 - b1t)
+        b2t *= beta2
+        vh = v[i] / (1.0 - b2t)
+        p[i] -= alpha * mh / (np.sqrt(vh) + eps)
+    return p, m, v, int(n0) + p.size

@@ -6,10 +6,19 @@
 #include "Tensor3D.h"
 #include "Tensor4D.h"
 #include "StackTensor3D.h"
+#include "DenseGraph.h"
 
 #include "Mixers_hip.h"
 #include "RisiContraction_hip.h"
 #include "gf_executor.h"
+#include "SMP_omega_hip.h"
+
+// compiled, never called here (needs a GPU): the model-level drop-in takes the reference's own DenseGraph
+double model_level_dropin(DenseGraph **molecules, double *targets, int nBatch) {
+    SMP_omega_hip net(29, 29, 3, 64, molecules[0]->nFeatures, 5);
+    std::pair<double, double> loss = net.BatchLearn(nBatch, molecules, targets, 1e-3);
+    return loss.second + net.Predict(molecules[0]) + net.Feature(molecules[0])[0];
+}
 
 int main() {
     const int N = 4, C = 8;

@@ -1,0 +1,81 @@
+// test_SMP_omega_hip.cpp -- the model-level drop-in, driven like the reference's tests/test_SMP_omega.cpp: the four
+// hand-built molecules of that test (CH4, NH3, H2O, C2H4; one-hot C,H,N,O features; target = number of atoms;
+// :71-147), nLevels 2, nChanels 10, nDepth 5, max_receptive_field 4, max_nVertices 10.
+// Known answers: the REAL reference, constructed after srand(7), reports for three BatchLearn(4, molecules, targets,
+// 1e-3) calls the (before, after) losses below (captured by tests/golden/make_golden.py -> smp_train.npz).  The same
+// seed must give the same initial weights here (rand()-drawn like weights_initialization) and the same trajectory.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "SMP_omega_hip.h"
+
+struct Molecule {  // public fields of GraphFlow/DenseGraph.h
+    int nVertices, nFeatures;
+    int **adj;
+    double **feature;
+    Molecule(int V, int F) : nVertices(V), nFeatures(F) {
+        adj = new int *[V];
+        feature = new double *[V];
+        for (int i = 0; i < V; ++i) {
+            adj[i] = new int[V]();
+            feature[i] = new double[F]();
+        }
+    }
+};
+
+static Molecule *build(const char *labels, int nEdges, const int (*edges)[2]) {
+    const int V = (int)std::strlen(labels);
+    Molecule *m = new Molecule(V, 4);
+    for (int e = 0; e < nEdges; ++e) m->adj[edges[e][0]][edges[e][1]] = m->adj[edges[e][1]][edges[e][0]] = 1;
+    for (int v = 0; v < V; ++v) m->feature[v][std::strchr("CHNO", labels[v]) - "CHNO"] = 1.0;
+    return m;
+}
+
+static int close_to(const char *what, double got, double ref, double tol) {
+    const double rel = std::fabs(got - ref) / std::fmax(1.0, std::fabs(ref));
+    std::printf("%-28s %-14.8f reference %-14.8f rel %.2e %s\n", what, got, ref, rel, rel <= tol ? "" : "  <-- FAIL");
+    return rel > tol;
+}
+
+int main() {
+    static const int e1[][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}}, e2[][2] = {{0, 1}, {0, 2}, {0, 3}}, e3[][2] = {{0, 1}, {0, 2}},
+                     e4[][2] = {{0, 1}, {0, 2}, {0, 3}, {3, 4}, {3, 5}};
+    Molecule *mol[4] = {build("CHHHH", 4, e1), build("NHHH", 3, e2), build("OHH", 2, e3), build("CHHCHH", 5, e4)};
+    double target[4];
+    for (int i = 0; i < 4; ++i) target[i] = mol[i]->nVertices;
+
+    srand(7);
+    SMP_omega_hip net(10, 4, 2, 10, 4, 5);
+    net.init_multi_threads(4);
+    static const double ref[3][2] = {{40.06016881, 25.63279077}, {25.63279077, 12.07012937}, {12.07012937, 30.20855269}};
+    int bad = 0;
+    for (int it = 0; it < 3; ++it) {
+        std::pair<double, double> r = net.BatchLearn(4, mol, target, 1e-3);
+        char name[64];
+        std::snprintf(name, sizeof name, "BatchLearn %d loss before", it);
+        bad |= close_to(name, r.first, ref[it][0], 1e-4);
+        std::snprintf(name, sizeof name, "BatchLearn %d loss after", it);
+        bad |= close_to(name, r.second, ref[it][1], 5e-4);
+    }
+    // Predict / Threaded_Predict / getLoss agree with each other, Feature has nChanels entries
+    double y[4], loss = 0.0;
+    net.Threaded_Predict(4, mol, y);
+    for (int i = 0; i < 4; ++i) {
+        bad |= close_to("Predict == Threaded_Predict", net.Predict(mol[i]), y[i], 1e-6);
+        loss += 0.5 * (y[i] - target[i]) * (y[i] - target[i]);
+    }
+    bad |= close_to("getLoss == sum 0.5 (y-t)^2", net.getLoss(4, mol, target), loss, 1e-5);
+    bad |= (int)net.Feature(mol[0]).size() != 10;
+    // checkpoint round trip through the text format; Threaded_BatchLearn = BatchLearn's update
+    const char *path = "/tmp/gf_smp_omega_hip_ckpt.txt";
+    net.save_model(path);
+    srand(99);
+    SMP_omega_hip other(10, 4, 2, 10, 4, 5);
+    other.load_model(path);
+    bad |= close_to("loaded model predicts alike", other.Predict(mol[3]), y[3], 1e-5);  // 6 printed digits
+    std::printf(bad ? "FAILED\n" : "PASSED\n");
+    return bad;
+}

@@ -183,6 +183,21 @@ def smp_fixtures():
     return out
 
 
+def train_fixture():
+    """Three SMP_omega::BatchLearn steps of the real reference on the four toy molecules of tests/test_SMP_omega.cpp as one batch,
+    starting from the weights its own constructor draws after srand(7) (weights_initialization)."""
+    mols, tgts = [], []
+    for name, adj, feat, tgt in toy_molecules():
+        mols.append((adj, feat))
+        tgts.append(tgt)
+    L, C, D, cap, maxV = 2, 10, 5, 4, 10
+    r = pyoracle.reference_batchlearn(mols, tgts, L, C, D, cap, maxV, nIter=3, learning_rate=1e-3, seed=7)
+    out = {"train__cfg": np.array([L, C, D, cap, maxV, 7, 3], dtype=np.int32), "train__lr": np.array([1e-3]),
+           "train__targets": np.array(tgts, dtype=np.float64), "train__params0": r["params0"], "train__params": r["params"],
+           "train__losses": r["losses"]}
+    np.savez_compressed(os.path.join(HERE, "smp_train.npz"), **out)
+
+
 def checkpoint_fixture():
     """smp_syn12's parameters as SMP_omega::save_model writes them (SMP_omega.h:1033-1042): a data file, 6 significant digits."""
     for i, (tag, adj, feat, tgt, (L, C, D, cap, wl, maxV)) in enumerate(smp_cases()):
@@ -202,9 +217,10 @@ def main():
     np.savez_compressed(os.path.join(HERE, "dropout.npz"), **dropout_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "smp.npz"), **smp_fixtures())
     checkpoint_fixture()
+    train_fixture()
     with open(os.path.join(HERE, "structural_50.json"), "w") as fh:
         json.dump(structural_50(), fh, indent=1)
-    for f in ("contractions.npz", "mixers.npz", "smp.npz", "structural_50.json", "smp_syn12_checkpoint.txt", "dropout.npz"):
+    for f in ("contractions.npz", "mixers.npz", "smp.npz", "structural_50.json", "smp_syn12_checkpoint.txt", "dropout.npz", "smp_train.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -65,3 +65,12 @@ def test_entity_style_slice_dropout(bins):
     r = subprocess.run([os.path.join(bins, "test_Dropout_hip")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASSED" in r.stdout
+
+
+@pytest.mark.gpu
+def test_model_level_dropin_reproduces_reference_training(bins):
+    """SMP_omega_hip (BatchLearn / Predict / Feature / save_model / load_model) on the toy molecules of the reference's
+    tests/test_SMP_omega.cpp: same srand -> same initial weights -> the real reference's loss trajectory."""
+    r = subprocess.run([os.path.join(bins, "test_SMP_omega_hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASSED" in r.stdout

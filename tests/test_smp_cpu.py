@@ -86,3 +86,50 @@ def test_checkpoint_fixture_holds_the_golden_parameters(golden):
     text = np.array(raw.split(), dtype=np.float64)
     assert text.size == c["params"].size
     assert np.max(np.abs(text - c["params"]) / np.maximum(np.abs(c["params"]), 1e-30)) < 1e-5
+
+
+def _train_case():
+    import os
+    from inputs import toy_molecules
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "smp_train.npz"))
+    L, Cn, D, cap, maxV, seed, nIter = (int(x) for x in z["train__cfg"])
+    mols = [(adj, feat) for _, adj, feat, _ in toy_molecules()]
+    return z, (L, Cn, D, cap, maxV, seed, nIter), mols
+
+
+def test_uniform_init_draws_the_reference_weights(gf):
+    """gf_smp_uniform_init_host after srand(7) == the weights SMP_omega's constructor drew after srand(7) in the reference
+    (SMP_omega.h:334-338, GraphFlow.h:1297-1306); fixture tests/golden/smp_train.npz."""
+    from graphflow_amd import _lib
+    from graphflow_amd.smp import SMPConfig
+    z, (L, Cn, D, cap, maxV, seed, nIter), mols = _train_case()
+    lib = _lib.load()
+    cfg = SMPConfig(L, Cn, mols[0][1].shape[1], D, cap, 1)
+    out = np.zeros(z["train__params0"].size, dtype=np.float32)
+    C.CDLL(None).srand(seed)
+    assert lib.gf_smp_uniform_init_host(C.byref(cfg), out.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    assert np.array_equal(out, z["train__params0"].astype(np.float32))
+
+
+def test_oracle_batchlearn_matches_reference():
+    """Three BatchLearn steps (summed gradients + Adam::Learn(alpha, nBatch) with its per-element beta powers) restated
+    with the oracle reproduce the real reference's parameters and before/after losses."""
+    from oracle import smp_oracle
+    z, (L, Cn, D, cap, maxV, seed, nIter), mols = _train_case()
+    tg = z["train__targets"]
+    p = z["train__params0"].copy()
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    n0 = 0
+
+    def total_loss(p):
+        return sum(smp_oracle.run(a, f, float(t), p, L, Cn, D, cap, True, want_grads=False)["loss"] for (a, f), t in zip(mols, tg))
+
+    for it in range(nIter):
+        before = total_loss(p)
+        g = sum(smp_oracle.run(a, f, float(t), p, L, Cn, D, cap, True)["grads"] for (a, f), t in zip(mols, tg))
+        p, m, v, n0 = smp_oracle.adam_learn(p, g, m, v, n0, float(z["train__lr"][0]), len(mols))
+        after = total_loss(p)
+        assert abs(before - z["train__losses"][it, 0]) <= 1e-9 * max(1, before)
+        assert abs(after - z["train__losses"][it, 1]) <= 1e-7 * max(1, after)
+    assert np.abs(p - z["train__params"]).max() <= 1e-9

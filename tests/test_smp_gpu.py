@@ -159,3 +159,43 @@ def test_text_checkpoint_is_interchangeable_with_the_reference(gf, golden, tmp_p
     short.write_text("1 2 3 ")
     with pytest.raises(RuntimeError):
         net.load_model(p, short)
+
+
+def test_batchlearn_steps_match_the_reference(gf):
+    """Three optimiser steps = SMP_omega::BatchLearn x 3 of the real reference (tests/golden/smp_train.npz): initial weights
+    from gf_smp_uniform_init_host after srand(7), forward/backward on the four toy molecules as one batch, then
+    gf_smp_adam_step (Adam::Learn(alpha, nBatch) with its per-element bias-correction powers).
+    Tolerance: the fp32 path is held to 1e-4 on the losses and to 0.5 % of one Adam step (|step| = alpha = 1e-3) on every
+    parameter -- Adam normalises the gradient, so a parameter whose true gradient is ~0 turns fp32 rounding into a
+    visible fraction of a step; everything else agrees to ~1e-7."""
+    import ctypes as C
+    import os
+    from graphflow_amd.smp import SMPOmega
+    from inputs import toy_molecules
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "smp_train.npz"))
+    L, Cn, D, cap, maxV, seed, nIter = (int(x) for x in z["train__cfg"])
+    mols = [(adj, feat) for _, adj, feat, _ in toy_molecules()]
+    tg = dev(z["train__targets"])
+    lr = float(z["train__lr"][0])
+    net = SMPOmega(L, Cn, mols[0][1].shape[1], D, cap, True)
+    C.CDLL(None).srand(seed)
+    p = dev(net.uniform_init())
+    assert np.array_equal(p.cpu().numpy(), z["train__params0"].astype(np.float32))
+    net.prepare(mols)
+    grads = torch.empty(net.n_params, device="cuda")
+    worst = 0.0
+    for it in range(nIter):
+        _, loss, _ = net.forward(p, tg)
+        before = float(loss.sum())
+        net.backward(p, grads)
+        net.adam_step(p, grads, lr, len(mols))
+        _, loss, _ = net.forward(p, tg)
+        after = float(loss.sum())
+        assert abs(before - z["train__losses"][it, 0]) <= TOL_FWD * max(1.0, before), it
+        assert abs(after - z["train__losses"][it, 1]) <= 5 * TOL_FWD * max(1.0, after), it
+    err = np.abs(p.cpu().numpy().astype(np.float64) - z["train__params"])
+    print("max |param - reference| after %d steps: %.3e (median %.3e)" % (nIter, err.max(), np.median(err)))
+    assert err.max() <= 0.005 * lr
+    assert np.median(err) <= 1e-6
+    # a second model instance restarts the bias-correction powers; reset does the same on this one
+    net.adam_reset()
