@@ -30,6 +30,23 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s ach
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 
 
+def copy_ceiling_gbps(torch, dev):
+    """Measured device-to-device copy rate on this box (read + write bytes / time): the practical HBM ceiling that
+    SURVEY.md 8(d) asks to be reported beside the 8 TB/s spec figure."""
+    n = 1 << 28   # 1 GiB of fp32 each way
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.empty(n, dtype=torch.float32, device=dev)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def contraction_bytes(K, N, C):
     """fwd 4(N^3 C + N^2 + K N^2 C); bwd 4(K N^2 C + N^2 + N^3 C) (write-only dP)."""
     fwd = 4 * (N ** 3 * C + N * N + K * N * N * C)
@@ -139,13 +156,13 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
         unit = 2 * R * C * C                                     # one C x C block product over all rows
         if fused:
             add(kb, "smpf_tables_fwd", 4 * (Rp * C + 6 * R * C))        # gather f_{l-1} (cached), write 6 tables
-            add(kb, "smpf_combine_fwd", 4 * (5 * R * C + R * C))
-            add(kb, "smpf_combine_bwd", 4 * (2 * R * C + 5 * R * C))
+            add(kb, "smpf_combine_fwd", 4 * (3 * R * C + R * C))        # O = [O_loc | Z | Z'] in, f_l out
+            add(kb, "smpf_combine_bwd", 4 * (2 * R * C + 3 * R * C))
             add(kb, "smpf_tables_bwd", 4 * (6 * R * C + S * C))
             add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
             for k in ("gemm_nn", "gemm_nt", "gemm_tn"):
                 add(kf, k, 10 * unit)
-                add(kb, k, 4 * (10 * R * C + 5 * R * C))
+                add(kb, k, 4 * (6 * R * C + 3 * R * C))                  # T (6C) and O / dO (3C) per row, each once
         else:
             add(kb, "smp_promote_fwd", 4 * (Rp * C + S * C))
             add(kb, "r18_fwd_slab", 4 * (S * C + 10 * R * C))
@@ -250,6 +267,7 @@ def main():
     ctx.set_timing(False)
     elapsed = gd.max_over_ranks(elapsed, dist, dev)
 
+    ceiling = copy_ceiling_gbps(torch, dev) if rank == 0 else None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * meta["units_per_step"] * args.steps / elapsed
@@ -258,6 +276,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": meta["config"], "roofline": finish(timers, ms_per_step),
                 "cpu_baseline": (cpu() if (world == 1 and not args.no_cpu_baseline) else None)}
+        line["roofline"]["hbm_copy_measured_GBps"] = round(ceiling, 1)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
