@@ -124,3 +124,23 @@ def smp_params(C, F, D, L, seed, scale=None):
         parts.append(rng.uniform(-0.1, 0.1, C))
     parts.append(rng.uniform(-1, 1, C) / np.sqrt(C))
     return f32exact(np.concatenate(parts))
+
+
+def edge_molecules(F=5):
+    """Corner cases of the SMP driver: a single atom, a bonded pair, two disconnected fragments (Floyd-Warshall never joins
+    them: receptive fields stay inside a fragment), an isolated vertex beside a triangle, a 9-clique (every field is the
+    whole molecule from level 1 on) and a 12-path (fields keep growing over the levels).  [(name, adj, feature, target)]"""
+    def mk(V, edges, seed):
+        adj = np.zeros((V, V), dtype=np.int32)
+        for u, v in edges:
+            adj[u, v] = adj[v, u] = 1
+        rng = np.random.default_rng(seed)
+        feat = np.zeros((V, F))
+        feat[np.arange(V), rng.integers(0, F, V)] = 1.0
+        return adj, feat, float(V)
+    out = [("atom",) + mk(1, [], 1), ("pair",) + mk(2, [(0, 1)], 2),
+           ("two_fragments",) + mk(7, [(0, 1), (1, 2), (3, 4), (4, 5), (5, 6), (6, 3)], 3),
+           ("isolated_vertex",) + mk(4, [(0, 1), (1, 2), (2, 0)], 4),
+           ("clique9",) + mk(9, [(i, j) for i in range(9) for j in range(i + 1, 9)], 5),
+           ("path12",) + mk(12, [(i, i + 1) for i in range(11)], 6)]
+    return out

@@ -133,3 +133,18 @@ def test_oracle_batchlearn_matches_reference():
         assert abs(before - z["train__losses"][it, 0]) <= 1e-9 * max(1, before)
         assert abs(after - z["train__losses"][it, 1]) <= 1e-7 * max(1, after)
     assert np.abs(p - z["train__params"]).max() <= 1e-9
+
+
+def test_oracle_against_live_reference_edge_molecules():
+    """Single atom, bonded pair, disconnected fragments, isolated vertex, clique, long path (tests/golden/inputs.py)."""
+    from inputs import edge_molecules
+    from oracle import pyoracle, smp_oracle
+    if pyoracle.reference() is None:
+        pytest.skip("oracle/_ref/libgf_ref.so not present")
+    for name, adj, feat, tgt in edge_molecules():
+        params = smp_params(4, 5, 2, 3, 21)
+        r = pyoracle.reference_smp_omega(adj, feat, tgt, params, 3, 4, 2, 6, max_nVertices=12)
+        o = smp_oracle.run(adj, feat, tgt, params, 3, 4, 2, 6)
+        assert r["phi"] == [[list(map(int, f)) for f in lv] for lv in o["phi"]], name
+        assert abs(r["predict"] - o["predict"]) <= 1e-10 * max(1, abs(r["predict"])), name
+        assert np.abs(r["grads"] - o["grads"]).max() <= 1e-9 * max(1, np.abs(r["grads"]).max()), name

@@ -199,3 +199,37 @@ def test_batchlearn_steps_match_the_reference(gf):
     assert np.median(err) <= 1e-6
     # a second model instance restarts the bias-correction powers; reset does the same on this one
     net.adam_reset()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_edge_molecules_vs_oracle(gf, fused):
+    """Single atom, bonded pair, disconnected fragments, isolated vertex, 9-clique, 12-path -- one at a time (a batch of one
+    single-atom molecule is the smallest legal input) and as one ragged batch; the oracle is pinned to the real reference
+    on the same molecules in the CPU suite."""
+    from inputs import edge_molecules
+    from oracle import smp_oracle
+    L, C, F, D, cap = 3, 8, 5, 2, 6
+    params = smp_params(C, F, D, L, 21)
+    cases = edge_molecules()
+    refs = [smp_oracle.run(a, f, t, params, L, C, D, cap) for _, a, f, t in cases]
+    for (name, a, f, t), r in zip(cases, refs):
+        pred, loss, feat, grads, net = run_batch(gf, [(a, f)], np.array([t]), params, L, C, F, D, cap, fused=fused)
+        assert [net.receptive_field(0, L, v) for v in range(len(a))] == [list(map(int, x)) for x in r["phi"][L]], name
+        assert rel_err(pred, np.array([r["predict"]])) <= TOL_FWD, name
+        assert rel_err(feat[0], r["graph_feature"]) <= TOL_FWD, name
+        assert rel_err(grads, r["grads"]) <= TOL_GRAD, name
+    pred, loss, feat, grads, _ = run_batch(gf, [(a, f) for _, a, f, _ in cases], np.array([t for *_, t in cases]), params,
+                                           L, C, F, D, cap, fused=fused)
+    assert rel_err(pred, np.array([r["predict"] for r in refs])) <= TOL_FWD
+    assert rel_err(loss, np.array([r["loss"] for r in refs])) <= 2 * TOL_FWD
+    assert rel_err(grads, sum(r["grads"] for r in refs)) <= TOL_GRAD
+
+
+def test_prepare_rejects_bad_input(gf):
+    from graphflow_amd.smp import SMPOmega
+    net = SMPOmega(2, 8, 5, 2, 6, True)
+    with pytest.raises(Exception):
+        net.prepare([])
+    p = torch.zeros(net.n_params, device="cuda")
+    with pytest.raises(Exception):
+        net.forward(p)   # forward before prepare
