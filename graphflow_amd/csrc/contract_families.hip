@@ -227,16 +227,21 @@ __global__ void fam_scalars(const float *__restrict__ P, const float *__restrict
         if (slot<K>(c) >= 0) o[slot<K>(c) * C] = (expr); \
     } while (0)
 
+// Thread per (g, x, block of YB columns y, f): the nine operands of the N x N products that are indexed by (x, z) are
+// loaded once per z and serve all YB columns (they do not depend on y); only two adjacency entries are per column.
+constexpr int kYB = 4;
+
 template <int K>
-__global__ void fam_forward(const float *__restrict__ P, const float *__restrict__ A, const float *__restrict__ adjs,
-                            const float *__restrict__ tab, const float *__restrict__ vec, const float *__restrict__ sc,
-                            float *__restrict__ Out, int N, int C, size_t total) {
+__global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, const float *__restrict__ A,
+                                                   const float *__restrict__ adjs, const float *__restrict__ tab,
+                                                   const float *__restrict__ vec, const float *__restrict__ sc,
+                                                   float *__restrict__ Out, int N, int C, int nyb, size_t total) {
     const size_t NNC = (size_t)N * N * C, NC = (size_t)N * C;
     GRID_STRIDE(idx, total) {
         const int f = idx % C;
         size_t t = idx / C;
-        const int y = t % N;
-        t /= N;
+        const int y0 = (int)(t % nyb) * kYB;
+        t /= nyb;
         const int x = t % N;
         const size_t g = t / N;
         const float *Pg = P + g * NNC * N;
@@ -248,89 +253,101 @@ __global__ void fam_forward(const float *__restrict__ P, const float *__restrict
         const float *s = sc + g * kNSc * (size_t)C + f;
 #define TB(k, i, j) T[(k)*NNC + ((size_t)(i) * N + (j)) * C + f]
 #define PP(a, b, c) Pg[(((size_t)(a) * N + (b)) * N + (c)) * C + f]
-        float *o = Out + (((size_t)g * N + x) * N + y) * (size_t)(K * C) + f;
-        const float ry = r[y], qy = q[y], axy = Ag[x * N + y];
-        // "1+1+1"
-        OUTC(1, TB(0, x, y) * tot);
-        OUTC(2, TB(1, x, y) * tot);
-        OUTC(3, v[0 * NC + (size_t)x * C] * ry);
-        OUTC(4, v[0 * NC + (size_t)x * C] * qy);
-        OUTC(5, TB(2, x, y) * tot);
-        OUTC(6, v[1 * NC + (size_t)x * C] * ry);
-        OUTC(7, v[1 * NC + (size_t)x * C] * qy);
-        OUTC(8, v[2 * NC + (size_t)x * C] * ry);
-        OUTC(9, v[2 * NC + (size_t)x * C] * qy);
-        OUTC(10, s[0 * C] * axy);
+        const float va = v[0 * NC + (size_t)x * C], vb = v[1 * NC + (size_t)x * C], vc = v[2 * NC + (size_t)x * C];
+        float vbb = 0.f, vaba = 0.f, vaac = 0.f;
         if (K == 50) {
-            // "1+2" that are plain table reads or outer products
-            OUTC(11, TB(3, x, y));
-            OUTC(12, TB(4, x, y));
-            OUTC(13, TB(0, x, y) * tr);
-            OUTC(14, TB(6, x, y));
-            OUTC(15, TB(7, x, y));
-            OUTC(16, TB(1, x, y) * tr);
-            OUTC(17, v[3 * NC + (size_t)x * C] * ry);
-            OUTC(20, v[3 * NC + (size_t)x * C] * qy);
-            OUTC(23, TB(9, x, y));
-            OUTC(24, TB(10, x, y));
-            OUTC(25, TB(2, x, y) * tr);
-            OUTC(26, v[4 * NC + (size_t)x * C] * ry);
-            OUTC(29, v[4 * NC + (size_t)x * C] * qy);
-            OUTC(32, v[5 * NC + (size_t)x * C] * ry);
-            OUTC(35, v[5 * NC + (size_t)x * C] * qy);
-            OUTC(38, s[1 * C] * axy);
-            OUTC(39, s[2 * C] * axy);
-            OUTC(40, s[3 * C] * axy);
-            OUTC(41, TB(5, x, y));
-            OUTC(42, TB(8, x, y));
-            OUTC(45, TB(11, x, y));
-            OUTC(50, s[4 * C] * axy);
-            // N x N products with A: one pass over the contracted index
-            float m18 = 0, m19 = 0, m21 = 0, m22 = 0, m27 = 0, m28 = 0, m30 = 0, m31 = 0, m33 = 0, m34 = 0, m36 = 0,
-                  m37 = 0, m43 = 0, m44 = 0, m46 = 0, m47 = 0, m48 = 0, m49 = 0;
+            vbb = v[3 * NC + (size_t)x * C];
+            vaba = v[4 * NC + (size_t)x * C];
+            vaac = v[5 * NC + (size_t)x * C];
+        }
+#pragma unroll
+        for (int m = 0; m < kYB; ++m) {
+            const int y = y0 + m;
+            if (y >= N) break;
+            float *o = Out + (((size_t)g * N + x) * N + y) * (size_t)(K * C) + f;
+            const float ry = r[y], qy = q[y], axy = Ag[x * N + y];
+            const float sab = TB(0, x, y), sac = TB(1, x, y), sbc = TB(2, x, y);
+            // "1+1+1"
+            OUTC(1, sab * tot);
+            OUTC(2, sac * tot);
+            OUTC(3, va * ry);
+            OUTC(4, va * qy);
+            OUTC(5, sbc * tot);
+            OUTC(6, vb * ry);
+            OUTC(7, vb * qy);
+            OUTC(8, vc * ry);
+            OUTC(9, vc * qy);
+            OUTC(10, s[0 * C] * axy);
+            if (K == 50) {
+                // "1+2" that are plain table reads or outer products
+                OUTC(11, TB(3, x, y));
+                OUTC(12, TB(4, x, y));
+                OUTC(13, sab * tr);
+                OUTC(14, TB(6, x, y));
+                OUTC(15, TB(7, x, y));
+                OUTC(16, sac * tr);
+                OUTC(17, vbb * ry);
+                OUTC(20, vbb * qy);
+                OUTC(23, TB(9, x, y));
+                OUTC(24, TB(10, x, y));
+                OUTC(25, sbc * tr);
+                OUTC(26, vaba * ry);
+                OUTC(29, vaba * qy);
+                OUTC(32, vaac * ry);
+                OUTC(35, vaac * qy);
+                OUTC(38, s[1 * C] * axy);
+                OUTC(39, s[2 * C] * axy);
+                OUTC(40, s[3 * C] * axy);
+                OUTC(41, TB(5, x, y));
+                OUTC(42, TB(8, x, y));
+                OUTC(45, TB(11, x, y));
+                OUTC(50, s[4 * C] * axy);
+            }
+        }
+        if (K == 50) {
+            // N x N products with A: one pass over the contracted index for the whole column block
+            float mm[kYB][18];
+#pragma unroll
+            for (int m = 0; m < kYB; ++m)
+#pragma unroll
+                for (int k = 0; k < 18; ++k) mm[m][k] = 0.f;
             for (int z = 0; z < N; ++z) {
-                const float ayz = Ag[y * N + z], azy = Ag[z * N + y];
                 const float sab_xz = TB(0, x, z), sab_zx = TB(0, z, x);
                 const float sac_xz = TB(1, x, z), sac_zx = TB(1, z, x);
                 const float sbc_xz = TB(2, x, z), sbc_zx = TB(2, z, x);
                 const float pxzz = PP(x, z, z), pzxz = PP(z, x, z), pzzx = PP(z, z, x);
-                m18 += sab_xz * ayz;  // (a,d) tie(b,e): sum_b S_ab[a,b] A[d,b]
-                m19 += sac_xz * ayz;  // (a,d) tie(c,e)
-                m21 += sab_xz * azy;  // (a,e) tie(b,d): sum_b S_ab[a,b] A[b,e]
-                m22 += sac_xz * azy;  // (a,e) tie(c,d)
-                m27 += sab_zx * ayz;  // (b,d) tie(a,e): sum_a S_ab[a,b] A[d,a]
-                m28 += sbc_xz * ayz;  // (b,d) tie(c,e)
-                m30 += sab_zx * azy;  // (b,e) tie(a,d)
-                m31 += sbc_xz * azy;  // (b,e) tie(c,d)
-                m33 += sac_zx * ayz;  // (c,d) tie(a,e): sum_a S_ac[a,c] A[d,a]
-                m34 += sbc_zx * ayz;  // (c,d) tie(b,e)
-                m36 += sac_zx * azy;  // (c,e) tie(a,d)
-                m37 += sbc_zx * azy;  // (c,e) tie(b,d)
-                m43 += pxzz * ayz;    // (a,d) b=c=e
-                m44 += pxzz * azy;    // (a,e) b=c=d
-                m46 += pzxz * ayz;    // (b,d) a=c=e
-                m47 += pzxz * azy;    // (b,e) a=c=d
-                m48 += pzzx * ayz;    // (c,d) a=b=e
-                m49 += pzzx * azy;    // (c,e) a=b=d
+#pragma unroll
+                for (int m = 0; m < kYB; ++m) {
+                    const int y = (y0 + m < N) ? y0 + m : N - 1;
+                    const float ayz = Ag[y * N + z], azy = Ag[z * N + y];
+                    mm[m][0] += sab_xz * ayz;   // 18 (a,d) tie(b,e): sum_b S_ab[a,b] A[d,b]
+                    mm[m][1] += sac_xz * ayz;   // 19 (a,d) tie(c,e)
+                    mm[m][2] += sab_xz * azy;   // 21 (a,e) tie(b,d): sum_b S_ab[a,b] A[b,e]
+                    mm[m][3] += sac_xz * azy;   // 22 (a,e) tie(c,d)
+                    mm[m][4] += sab_zx * ayz;   // 27 (b,d) tie(a,e): sum_a S_ab[a,b] A[d,a]
+                    mm[m][5] += sbc_xz * ayz;   // 28 (b,d) tie(c,e)
+                    mm[m][6] += sab_zx * azy;   // 30 (b,e) tie(a,d)
+                    mm[m][7] += sbc_xz * azy;   // 31 (b,e) tie(c,d)
+                    mm[m][8] += sac_zx * ayz;   // 33 (c,d) tie(a,e): sum_a S_ac[a,c] A[d,a]
+                    mm[m][9] += sbc_zx * ayz;   // 34 (c,d) tie(b,e)
+                    mm[m][10] += sac_zx * azy;  // 36 (c,e) tie(a,d)
+                    mm[m][11] += sbc_zx * azy;  // 37 (c,e) tie(b,d)
+                    mm[m][12] += pxzz * ayz;    // 43 (a,d) b=c=e
+                    mm[m][13] += pxzz * azy;    // 44 (a,e) b=c=d
+                    mm[m][14] += pzxz * ayz;    // 46 (b,d) a=c=e
+                    mm[m][15] += pzxz * azy;    // 47 (b,e) a=c=d
+                    mm[m][16] += pzzx * ayz;    // 48 (c,d) a=b=e
+                    mm[m][17] += pzzx * azy;    // 49 (c,e) a=b=d
+                }
             }
-            OUTC(18, m18);
-            OUTC(19, m19);
-            OUTC(21, m21);
-            OUTC(22, m22);
-            OUTC(27, m27);
-            OUTC(28, m28);
-            OUTC(30, m30);
-            OUTC(31, m31);
-            OUTC(33, m33);
-            OUTC(34, m34);
-            OUTC(36, m36);
-            OUTC(37, m37);
-            OUTC(43, m43);
-            OUTC(44, m44);
-            OUTC(46, m46);
-            OUTC(47, m47);
-            OUTC(48, m48);
-            OUTC(49, m49);
+            constexpr int cases[18] = {18, 19, 21, 22, 27, 28, 30, 31, 33, 34, 36, 37, 43, 44, 46, 47, 48, 49};
+#pragma unroll
+            for (int m = 0; m < kYB; ++m) {
+                if (y0 + m >= N) break;
+                float *o = Out + (((size_t)g * N + x) * N + y0 + m) * (size_t)(K * C) + f;
+#pragma unroll
+                for (int k = 0; k < 18; ++k) o[(size_t)(cases[k] - 1) * C] = mm[m][k];
+            }
         }
 #undef TB
 #undef PP
@@ -338,38 +355,63 @@ __global__ void fam_forward(const float *__restrict__ P, const float *__restrict
 }
 #undef OUTC
 
-// backward scalars, bsc[g][5][C]: u10, u38, u39, u40, u50 = sum_{d,e} G_c[d,e] A[d,e]
+// backward scalars, bsc[g][5][C]: u10, u38, u39, u40, u50 = sum_{d,e} G_c[d,e] A[d,e].
+// Workgroup per graph: 256 threads = row groups x channel lanes; a group walks (d,e) = grp, grp + ngrp, ... with the
+// five slices side by side, the groups are folded through LDS in a fixed order (deterministic).
 template <int K>
-__global__ void fam_bwd_scalars(const float *__restrict__ G, const float *__restrict__ A, float *__restrict__ bsc, int N,
-                                int C, size_t total) {
-    GRID_STRIDE(idx, total) {
-        const int f = idx % C;
-        const int j = (idx / C) % 5;
-        const size_t g = idx / (5 * (size_t)C);
-        const int cs = (j == 0) ? 10 : (j == 1) ? 38 : (j == 2) ? 39 : (j == 3) ? 40 : 50;
-        float sum = 0.f;
-        if (slot<K>(cs) >= 0) {
-            const float *Gg = G + g * (size_t)N * N * K * C + (size_t)slot<K>(cs) * C + f;
-            const float *Ag = A + g * N * N;
-            for (int de = 0; de < N * N; ++de) sum += Gg[(size_t)de * K * C] * Ag[de];
+__global__ __launch_bounds__(256) void fam_bwd_scalars(const float *__restrict__ G, const float *__restrict__ A,
+                                                       float *__restrict__ bsc, int N, int C) {
+    __shared__ float red[5 * 256];
+    const size_t g = blockIdx.x;
+    const int nl = C < 256 ? C : 256, ngrp = 256 / nl;
+    const int fl = threadIdx.x % nl, grp = threadIdx.x / nl;
+    const float *Ag = A + g * N * N;
+    constexpr int cs[5] = {10, 38, 39, 40, 50};
+    for (int f0 = 0; f0 < C; f0 += nl) {
+        const int f = f0 + fl;
+        float sum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (grp < ngrp && f < C) {
+            const float *Gg = G + g * (size_t)N * N * K * C + f;
+            for (int de = grp; de < N * N; de += ngrp) {
+                const float a = Ag[de];
+                const float *row = Gg + (size_t)de * K * C;
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    if (slot<K>(cs[j]) >= 0) sum[j] += row[(size_t)slot<K>(cs[j]) * C] * a;
+            }
         }
-        bsc[idx] = sum;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) red[j * 256 + threadIdx.x] = sum[j];
+        __syncthreads();
+        if (grp == 0 && f < C) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                float t = red[j * 256 + fl];
+                for (int k = 1; k < ngrp; ++k) t += red[j * 256 + k * nl + fl];
+                bsc[g * 5 * (size_t)C + (size_t)j * C + f] = t;
+            }
+        }
+        __syncthreads();
     }
 }
 
 // backward pair tables, btab[g][6][N][N][C]:
 //   0 X_ab[a,b]  1 X_ac[a,c]  2 X_bc[b,c]  3 Z_bc[a,b] (applies at b==c)  4 Z_ac[b,a] (a==c)  5 Z_ab[c,a] (a==b)
+// Thread per (g, i, block of JB columns j, f): the twenty G slices indexed by (i,z) are loaded once per z and serve
+// all JB columns; only the ten slices indexed by (j,z) and four adjacency entries are per column.
 constexpr int kNBTab = 6;
+constexpr int kJB = 6;
 
 template <int K>
-__global__ void fam_bwd_tables(const float *__restrict__ G, const float *__restrict__ A, const float *__restrict__ adjs,
-                               const float *__restrict__ bsc, float *__restrict__ btab, int N, int C, size_t total) {
+__global__ __launch_bounds__(256) void fam_bwd_tables(const float *__restrict__ G, const float *__restrict__ A,
+                                                      const float *__restrict__ adjs, const float *__restrict__ bsc,
+                                                      float *__restrict__ btab, int N, int C, int njb, size_t total) {
     const size_t NNC = (size_t)N * N * C;
     GRID_STRIDE(idx, total) {
         const int f = idx % C;
         size_t t = idx / C;
-        const int j = t % N;
-        t /= N;
+        const int j0 = (int)(t % njb) * kJB;
+        t /= njb;
         const int i = t % N;
         const size_t g = t / N;
         const float *Gg = G + g * (size_t)N * N * K * C + f;
@@ -378,48 +420,72 @@ __global__ void fam_bwd_tables(const float *__restrict__ G, const float *__restr
         const float tot = st[0], tr = st[1];
         const float *u = bsc + g * 5 * (size_t)C + f;
 #define GC(c, x, y) (slot<K>(c) >= 0 ? Gg[(((size_t)(x) * N + (y)) * K + slot<K>(c)) * C] : 0.f)
-        float xab = tot * GC(1, i, j) + u[0 * C];
-        float xac = tot * GC(2, i, j);
-        float xbc = tot * GC(5, i, j);
-        float zbc = 0.f, zac = 0.f, zab = 0.f;
-        if (K == 50) {
-            xab += tr * GC(13, i, j);
-            xac += tr * GC(16, i, j);
-            xbc += tr * GC(25, i, j);
-            zbc = u[3 * C];  // u40
-            zac = u[2 * C];  // u39
-            zab = u[1 * C];  // u38
+        float xab[kJB], xac[kJB], xbc[kJB], zbc[kJB], zac[kJB], zab[kJB];
+        int jj[kJB];
+#pragma unroll
+        for (int m = 0; m < kJB; ++m) {
+            jj[m] = (j0 + m < N) ? j0 + m : N - 1;  // clamped duplicate, never stored
+            const int j = jj[m];
+            xab[m] = tot * GC(1, i, j) + u[0 * C];
+            xac[m] = tot * GC(2, i, j);
+            xbc[m] = tot * GC(5, i, j);
+            zbc[m] = zac[m] = zab[m] = 0.f;
+            if (K == 50) {
+                xab[m] += tr * GC(13, i, j);
+                xac[m] += tr * GC(16, i, j);
+                xbc[m] += tr * GC(25, i, j);
+                zbc[m] = u[3 * C];  // u40
+                zac[m] = u[2 * C];  // u39
+                zab[m] = u[1 * C];  // u38
+            }
         }
         for (int z = 0; z < N; ++z) {
             const float rz = r[z], qz = q[z];
-            // outer-product cases: X_ab[a=i,b=j] takes U3[a]+U4[a]+U6[b]+U7[b]; X_ac[a=i,c=j] takes U8[c]+U9[c]
-            xab += GC(3, i, z) * rz + GC(4, i, z) * qz + GC(6, j, z) * rz + GC(7, j, z) * qz;
-            xac += GC(8, j, z) * rz + GC(9, j, z) * qz;
+            // (i,z)-indexed slices: shared by every column of the block
+            const float g3 = GC(3, i, z), g4 = GC(4, i, z);
+            const float i34 = g3 * rz + g4 * qz;
+            float g18 = 0.f, g21 = 0.f, g19 = 0.f, g22 = 0.f, g28 = 0.f, g31 = 0.f, g43 = 0.f, g44 = 0.f, g46 = 0.f, g47 = 0.f,
+                  g48 = 0.f, g49 = 0.f, z17 = 0.f, z26 = 0.f, z32 = 0.f, azi = 0.f, aiz = 0.f;
             if (K == 50) {
-                const float azj = Ag[z * N + j], ajz = Ag[j * N + z], azi = Ag[z * N + i], aiz = Ag[i * N + z];
-                // X_ab[a=i, b=j]
-                xab += GC(18, i, z) * azj + GC(21, i, z) * ajz + GC(27, j, z) * azi + GC(30, j, z) * aiz;
-                // X_ac[a=i, c=j]
-                xac += GC(19, i, z) * azj + GC(22, i, z) * ajz + GC(33, j, z) * azi + GC(36, j, z) * aiz;
-                // X_bc[b=i, c=j]
-                xbc += GC(28, i, z) * azj + GC(31, i, z) * ajz + GC(34, j, z) * azi + GC(37, j, z) * aiz;
-                // Z_bc[a=i, b=j]  (b == c)
-                zbc += GC(17, i, z) * rz + GC(20, i, z) * qz + GC(43, i, z) * azj + GC(44, i, z) * ajz;
-                // Z_ac[b=i, a=j]  (a == c)
-                zac += GC(26, i, z) * rz + GC(29, i, z) * qz + GC(46, i, z) * azj + GC(47, i, z) * ajz;
-                // Z_ab[c=i, a=j]  (a == b)
-                zab += GC(32, i, z) * rz + GC(35, i, z) * qz + GC(48, i, z) * azj + GC(49, i, z) * ajz;
+                g18 = GC(18, i, z); g21 = GC(21, i, z); g19 = GC(19, i, z); g22 = GC(22, i, z);
+                g28 = GC(28, i, z); g31 = GC(31, i, z); g43 = GC(43, i, z); g44 = GC(44, i, z);
+                g46 = GC(46, i, z); g47 = GC(47, i, z); g48 = GC(48, i, z); g49 = GC(49, i, z);
+                z17 = GC(17, i, z) * rz + GC(20, i, z) * qz;
+                z26 = GC(26, i, z) * rz + GC(29, i, z) * qz;
+                z32 = GC(32, i, z) * rz + GC(35, i, z) * qz;
+                azi = Ag[z * N + i];
+                aiz = Ag[i * N + z];
+            }
+#pragma unroll
+            for (int m = 0; m < kJB; ++m) {
+                const int j = jj[m];
+                // outer-product cases: X_ab[a=i,b=j] takes U3[a]+U4[a]+U6[b]+U7[b]; X_ac[a=i,c=j] takes U8[c]+U9[c]
+                xab[m] += i34 + GC(6, j, z) * rz + GC(7, j, z) * qz;
+                xac[m] += GC(8, j, z) * rz + GC(9, j, z) * qz;
+                if (K == 50) {
+                    const float azj = Ag[z * N + j], ajz = Ag[j * N + z];
+                    xab[m] += g18 * azj + g21 * ajz + GC(27, j, z) * azi + GC(30, j, z) * aiz;   // X_ab[a=i, b=j]
+                    xac[m] += g19 * azj + g22 * ajz + GC(33, j, z) * azi + GC(36, j, z) * aiz;   // X_ac[a=i, c=j]
+                    xbc[m] += g28 * azj + g31 * ajz + GC(34, j, z) * azi + GC(37, j, z) * aiz;   // X_bc[b=i, c=j]
+                    zbc[m] += z17 + g43 * azj + g44 * ajz;                                        // Z_bc[a=i, b=j]  (b == c)
+                    zac[m] += z26 + g46 * azj + g47 * ajz;                                        // Z_ac[b=i, a=j]  (a == c)
+                    zab[m] += z32 + g48 * azj + g49 * ajz;                                        // Z_ab[c=i, a=j]  (a == b)
+                }
             }
         }
 #undef GC
-        float *bt = btab + g * kNBTab * NNC + ((size_t)i * N + j) * C + f;
-        bt[0 * NNC] = xab;
-        bt[1 * NNC] = xac;
-        bt[2 * NNC] = xbc;
-        if (K == 50) {
-            bt[3 * NNC] = zbc;
-            bt[4 * NNC] = zac;
-            bt[5 * NNC] = zab;
+#pragma unroll
+        for (int m = 0; m < kJB; ++m) {
+            if (j0 + m >= N) continue;
+            float *bt = btab + g * kNBTab * NNC + ((size_t)i * N + j0 + m) * C + f;
+            bt[0 * NNC] = xab[m];
+            bt[1 * NNC] = xac[m];
+            bt[2 * NNC] = xbc[m];
+            if (K == 50) {
+                bt[3 * NNC] = zbc[m];
+                bt[4 * NNC] = zac[m];
+                bt[5 * NNC] = zab[m];
+            }
         }
     }
 }
@@ -462,6 +528,65 @@ __global__ void fam_backward(const float *__restrict__ G, const float *__restric
     }
 }
 
+// The same combination with a workgroup per (g, a): the four (a,c)-indexed rows (X_ac and the G slices of cases 14, 15,
+// 42) are staged in LDS once and serve every b; a thread owns (b, f), keeps its (a,b)-indexed terms in registers and
+// walks c, so each output costs four global loads (the (b,c)-indexed terms) instead of twelve.
+template <int K>
+__global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict__ G, const float *__restrict__ adjs,
+                                                         const float *__restrict__ bsc, const float *__restrict__ btab,
+                                                         float *__restrict__ dP, int N, int C, int accumulate) {
+    extern __shared__ float srow[];  // [4][N][C]: X_ac(a,c) | G14(a,c) | G15(a,c) | G42(a,c)
+    const size_t NNC = (size_t)N * N * C, NC = (size_t)N * C;
+    const size_t g = blockIdx.x / N;
+    const int a = (int)(blockIdx.x % N);
+    const float *bt = btab + g * kNBTab * NNC;
+    const float *Gg = G + g * (size_t)N * N * K * C;
+    const float *r = adjs + g * adjs_stride(N), *q = r + N, *dg = q + N;
+#define GCF(cs, x, y, f) Gg[(((size_t)(x) * N + (y)) * K + slot<K>(cs)) * C + (f)]
+    for (int i = threadIdx.x; i < (int)NC; i += blockDim.x) {
+        const int c = i / C, f = i % C;
+        srow[0 * NC + i] = bt[1 * NNC + ((size_t)a * N + c) * C + f];
+        if (K == 50) {
+            srow[1 * NC + i] = GCF(14, a, c, f);
+            srow[2 * NC + i] = GCF(15, a, c, f);
+            srow[3 * NC + i] = GCF(42, a, c, f);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)NC; i += blockDim.x) {
+        const int b = i / C, f = i % C;
+        const float xab = bt[0 * NNC + ((size_t)a * N + b) * C + f];
+        float g11 = 0.f, g12 = 0.f, g41 = 0.f, zbc = 0.f, zac = 0.f, u50 = 0.f;
+        const float rb = r[b], qb = q[b], dgb = dg[b], ra = r[a], qa = q[a], dga = dg[a];
+        if (K == 50) {
+            g11 = GCF(11, a, b, f);
+            g12 = GCF(12, a, b, f);
+            g41 = GCF(41, a, b, f);
+            zbc = bt[3 * NNC + ((size_t)a * N + b) * C + f];   // applies at c == b
+            zac = bt[4 * NNC + ((size_t)b * N + a) * C + f];   // applies at c == a
+            u50 = bsc[g * 5 * (size_t)C + 4 * C + f];
+        }
+        float *out = dP + ((g * N + a) * N + b) * (size_t)N * C + f;
+        for (int c = 0; c < N; ++c) {
+            float v = xab + srow[0 * NC + (size_t)c * C + f] + bt[2 * NNC + ((size_t)b * N + c) * C + f];
+            if (K == 50) {
+                v += g11 * r[c] + g12 * q[c] + g41 * dg[c];
+                v += srow[1 * NC + (size_t)c * C + f] * rb + srow[2 * NC + (size_t)c * C + f] * qb + srow[3 * NC + (size_t)c * C + f] * dgb;
+                v += GCF(23, b, c, f) * ra + GCF(24, b, c, f) * qa + GCF(45, b, c, f) * dga;
+                if (b == c) v += zbc;
+                if (a == c) v += zac;
+                if (a == b) v += bt[5 * NNC + ((size_t)c * N + a) * C + f];
+                if (a == b && b == c) v += u50;
+            }
+            if (accumulate)
+                out[(size_t)c * C] += v;
+            else
+                out[(size_t)c * C] = v;
+        }
+    }
+#undef GCF
+}
+
 struct FamWs {
     float *adjs, *tab, *vec, *sc;
 };
@@ -490,8 +615,10 @@ gf_status fam_forward_launch(gf_ctx *ctx, const float *P, const float *A, float 
     GF_LAUNCH(ctx, "fam_tables", fam_tables<K>, dim3(grid_for(nn)), dim3(256), 0, P, w.adjs, w.tab, N, C, nn);
     GF_LAUNCH(ctx, "fam_vectors", fam_vectors, dim3(grid_for(nv)), dim3(256), 0, P, w.tab, w.vec, w.sc, N, C, nv);
     GF_LAUNCH(ctx, "fam_scalars", fam_scalars, dim3(grid_for(ns)), dim3(256), 0, P, w.vec, w.sc, N, C, ns);
-    GF_LAUNCH(ctx, "fam_forward", fam_forward<K>, dim3(grid_for(nn)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out,
-              N, C, nn);
+    const int nyb = (N + kYB - 1) / kYB;
+    const size_t nf = (size_t)batch * N * nyb * C;
+    GF_LAUNCH(ctx, "fam_forward", fam_forward<K>, dim3(grid_for(nf)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out,
+              N, C, nyb, nf);
     return GF_OK;
 }
 
@@ -501,13 +628,21 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     gf_status st = ensure_ws(ctx, sizeof(float) * fam_ws_floats(N, C, batch) + 256);
     if (st != GF_OK) return st;
     const FamWs w = carve(static_cast<float *>(ctx->ws), N, C, batch);  // tab doubles as btab, sc as bsc
-    const size_t nn = (size_t)batch * N * N * C, ns = (size_t)batch * 5 * C, np = nn * N;
+    const size_t nn = (size_t)batch * N * N * C, np = nn * N;
+    const int njb = (N + kJB - 1) / kJB;
+    const size_t nt = (size_t)batch * N * njb * C;
     GF_LAUNCH(ctx, "fam_adj", fam_adj, dim3(batch), dim3(64), 0, A, w.adjs, N);
-    GF_LAUNCH(ctx, "fam_bwd_scalars", fam_bwd_scalars<K>, dim3(grid_for(ns)), dim3(256), 0, G, A, w.sc, N, C, ns);
-    GF_LAUNCH(ctx, "fam_bwd_tables", fam_bwd_tables<K>, dim3(grid_for(nn)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N, C,
-              nn);
-    GF_LAUNCH(ctx, "fam_backward", fam_backward<K>, dim3(grid_for(np)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, dP, N, C,
-              np, accumulate);
+    GF_LAUNCH(ctx, "fam_bwd_scalars", fam_bwd_scalars<K>, dim3(batch), dim3(256), 0, G, A, w.sc, N, C);
+    GF_LAUNCH(ctx, "fam_bwd_tables", fam_bwd_tables<K>, dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N, C,
+              njb, nt);
+    const size_t row_lds = sizeof(float) * 4 * (size_t)N * C;
+    if (row_lds <= 48 * 1024 && (size_t)batch * N < 0x7fffffffu) {
+        GF_LAUNCH(ctx, "fam_backward", fam_backward_rows<K>, dim3((unsigned)((size_t)batch * N)), dim3(256), row_lds, G, w.adjs,
+                  w.sc, w.tab, dP, N, C, accumulate);
+    } else {
+        GF_LAUNCH(ctx, "fam_backward", fam_backward<K>, dim3(grid_for(np)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, dP, N, C,
+                  np, accumulate);
+    }
     return GF_OK;
 }
 
