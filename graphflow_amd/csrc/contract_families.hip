@@ -15,6 +15,8 @@
 //             fam_backward thread per (a,b,c,f): O(1) combination.
 // These are "table" kernels (coalesced over the channel axis, tables re-read through L2), not the LDS-staged slab
 // kernels RisiContraction_18 has; they are the correct-first implementation of the rarely used families.
+#include <cstdint>
+
 #include "gf_internal.h"
 
 namespace gf {
@@ -78,6 +80,25 @@ __global__ void r4_backward(const float *__restrict__ G, float *__restrict__ dP,
 // ---------------------------------------------------------------------------------------------------------------
 // RisiContraction_10 / _50
 // ---------------------------------------------------------------------------------------------------------------
+// channel vector width of the table kernels: 4 (16-byte loads and stores, C % 4 == 0 and aligned buffers) or 1
+using vf4 = __attribute__((ext_vector_type(4))) float;
+template <int VW>
+struct Vec;
+template <>
+struct Vec<1> {
+    using T = float;
+    static __device__ __forceinline__ T ld(const float *p) { return *p; }
+    static __device__ __forceinline__ void st(float *p, T v) { *p = v; }
+    static __device__ __forceinline__ T zero() { return 0.f; }
+};
+template <>
+struct Vec<4> {
+    using T = vf4;
+    static __device__ __forceinline__ T ld(const float *p) { return *reinterpret_cast<const vf4 *>(p); }
+    static __device__ __forceinline__ void st(float *p, T v) { *reinterpret_cast<vf4 *>(p) = v; }
+    static __device__ __forceinline__ T zero() { return vf4{0.f, 0.f, 0.f, 0.f}; }
+};
+
 // Output slot (0-based) of "case c" (1-based numbering of RisiContraction_50.h) in family K, or -1 when absent.
 template <int K>
 __host__ __device__ constexpr int slot(int c) {
@@ -120,27 +141,29 @@ __global__ void fam_adj(const float *__restrict__ A, float *__restrict__ adjs, i
 //   9 bc.r 10 bc.q 11 bc.dg                   sum_a P[a,i,j] w[a]      (cases 23, 24, 45)
 constexpr int kNTab = 12;
 
-template <int K>
+template <int K, int VW>
 __global__ void fam_tables(const float *__restrict__ P, const float *__restrict__ adjs, float *__restrict__ tab, int N,
                            int C, size_t total) {
+    using V = typename Vec<VW>::T;
     const size_t NNC = (size_t)N * N * C;
+    const int CV = C / VW;
     GRID_STRIDE(idx, total) {
-        const int f = idx % C;
-        size_t t = idx / C;
+        const int f = (int)(idx % CV) * VW;
+        size_t t = idx / CV;
         const int j = t % N;
         t /= N;
         const int i = t % N;
         const size_t g = t / N;
         const float *Pg = P + g * NNC * N;
         const float *r = adjs + g * adjs_stride(N), *q = r + N, *dg = q + N;
-        float acc[kNTab];
+        V acc[kNTab];
 #pragma unroll
-        for (int k = 0; k < kNTab; ++k) acc[k] = 0.f;
+        for (int k = 0; k < kNTab; ++k) acc[k] = Vec<VW>::zero();
         for (int s = 0; s < N; ++s) {
             const float rs = r[s], qs = q[s], ds = dg[s];
-            const float pab = Pg[(((size_t)i * N + j) * N + s) * C + f];  // P[i][j][s]
-            const float pac = Pg[(((size_t)i * N + s) * N + j) * C + f];  // P[i][s][j]
-            const float pbc = Pg[(((size_t)s * N + i) * N + j) * C + f];  // P[s][i][j]
+            const V pab = Vec<VW>::ld(Pg + (((size_t)i * N + j) * N + s) * C + f);  // P[i][j][s]
+            const V pac = Vec<VW>::ld(Pg + (((size_t)i * N + s) * N + j) * C + f);  // P[i][s][j]
+            const V pbc = Vec<VW>::ld(Pg + (((size_t)s * N + i) * N + j) * C + f);  // P[s][i][j]
             acc[0] += pab;
             acc[1] += pac;
             acc[2] += pbc;
@@ -158,7 +181,7 @@ __global__ void fam_tables(const float *__restrict__ P, const float *__restrict_
         }
         float *tg = tab + g * kNTab * NNC + ((size_t)i * N + j) * C + f;
 #pragma unroll
-        for (int k = 0; k < (K == 50 ? kNTab : 3); ++k) tg[k * NNC] = acc[k];
+        for (int k = 0; k < (K == 50 ? kNTab : 3); ++k) Vec<VW>::st(tg + k * NNC, acc[k]);
     }
 }
 
@@ -222,24 +245,26 @@ __global__ void fam_scalars(const float *__restrict__ P, const float *__restrict
     }
 }
 
-#define OUTC(c, expr)                                \
-    do {                                             \
-        if (slot<K>(c) >= 0) o[slot<K>(c) * C] = (expr); \
+#define OUTC(c, expr)                                                  \
+    do {                                                               \
+        if (slot<K>(c) >= 0) Vec<VW>::st(o + slot<K>(c) * C, (expr)); \
     } while (0)
 
 // Thread per (g, x, block of YB columns y, f): the nine operands of the N x N products that are indexed by (x, z) are
 // loaded once per z and serve all YB columns (they do not depend on y); only two adjacency entries are per column.
-constexpr int kYB = 4;
-
-template <int K>
+// (with 16-byte channel vectors a thread keeps one column: 18 x 4 accumulators)
+template <int K, int VW>
 __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, const float *__restrict__ A,
                                                    const float *__restrict__ adjs, const float *__restrict__ tab,
                                                    const float *__restrict__ vec, const float *__restrict__ sc,
                                                    float *__restrict__ Out, int N, int C, int nyb, size_t total) {
+    using V = typename Vec<VW>::T;
+    constexpr int kYB = (VW == 4) ? 1 : 4;
     const size_t NNC = (size_t)N * N * C, NC = (size_t)N * C;
+    const int CV = C / VW;
     GRID_STRIDE(idx, total) {
-        const int f = idx % C;
-        size_t t = idx / C;
+        const int f = (int)(idx % CV) * VW;
+        size_t t = idx / CV;
         const int y0 = (int)(t % nyb) * kYB;
         t /= nyb;
         const int x = t % N;
@@ -251,14 +276,20 @@ __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, 
         const float *T = tab + g * kNTab * NNC;
         const float *v = vec + g * kNVec * NC + f;
         const float *s = sc + g * kNSc * (size_t)C + f;
-#define TB(k, i, j) T[(k)*NNC + ((size_t)(i) * N + (j)) * C + f]
-#define PP(a, b, c) Pg[(((size_t)(a) * N + (b)) * N + (c)) * C + f]
-        const float va = v[0 * NC + (size_t)x * C], vb = v[1 * NC + (size_t)x * C], vc = v[2 * NC + (size_t)x * C];
-        float vbb = 0.f, vaba = 0.f, vaac = 0.f;
+#define TB(k, i, j) Vec<VW>::ld(T + (k)*NNC + ((size_t)(i) * N + (j)) * C + f)
+#define PP(a, b, c) Vec<VW>::ld(Pg + (((size_t)(a) * N + (b)) * N + (c)) * C + f)
+        const V va = Vec<VW>::ld(v + 0 * NC + (size_t)x * C), vb = Vec<VW>::ld(v + 1 * NC + (size_t)x * C),
+                vc = Vec<VW>::ld(v + 2 * NC + (size_t)x * C);
+        V vbb = Vec<VW>::zero(), vaba = Vec<VW>::zero(), vaac = Vec<VW>::zero();
+        V s0 = Vec<VW>::ld(s + 0 * C), s1 = Vec<VW>::zero(), s2 = Vec<VW>::zero(), s3 = Vec<VW>::zero(), s4 = Vec<VW>::zero();
         if (K == 50) {
-            vbb = v[3 * NC + (size_t)x * C];
-            vaba = v[4 * NC + (size_t)x * C];
-            vaac = v[5 * NC + (size_t)x * C];
+            vbb = Vec<VW>::ld(v + 3 * NC + (size_t)x * C);
+            vaba = Vec<VW>::ld(v + 4 * NC + (size_t)x * C);
+            vaac = Vec<VW>::ld(v + 5 * NC + (size_t)x * C);
+            s1 = Vec<VW>::ld(s + 1 * C);
+            s2 = Vec<VW>::ld(s + 2 * C);
+            s3 = Vec<VW>::ld(s + 3 * C);
+            s4 = Vec<VW>::ld(s + 4 * C);
         }
 #pragma unroll
         for (int m = 0; m < kYB; ++m) {
@@ -266,7 +297,7 @@ __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, 
             if (y >= N) break;
             float *o = Out + (((size_t)g * N + x) * N + y) * (size_t)(K * C) + f;
             const float ry = r[y], qy = q[y], axy = Ag[x * N + y];
-            const float sab = TB(0, x, y), sac = TB(1, x, y), sbc = TB(2, x, y);
+            const V sab = TB(0, x, y), sac = TB(1, x, y), sbc = TB(2, x, y);
             // "1+1+1"
             OUTC(1, sab * tot);
             OUTC(2, sac * tot);
@@ -277,7 +308,7 @@ __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, 
             OUTC(7, vb * qy);
             OUTC(8, vc * ry);
             OUTC(9, vc * qy);
-            OUTC(10, s[0 * C] * axy);
+            OUTC(10, s0 * axy);
             if (K == 50) {
                 // "1+2" that are plain table reads or outer products
                 OUTC(11, TB(3, x, y));
@@ -295,27 +326,27 @@ __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, 
                 OUTC(29, vaba * qy);
                 OUTC(32, vaac * ry);
                 OUTC(35, vaac * qy);
-                OUTC(38, s[1 * C] * axy);
-                OUTC(39, s[2 * C] * axy);
-                OUTC(40, s[3 * C] * axy);
+                OUTC(38, s1 * axy);
+                OUTC(39, s2 * axy);
+                OUTC(40, s3 * axy);
                 OUTC(41, TB(5, x, y));
                 OUTC(42, TB(8, x, y));
                 OUTC(45, TB(11, x, y));
-                OUTC(50, s[4 * C] * axy);
+                OUTC(50, s4 * axy);
             }
         }
         if (K == 50) {
             // N x N products with A: one pass over the contracted index for the whole column block
-            float mm[kYB][18];
+            V mm[kYB][18];
 #pragma unroll
             for (int m = 0; m < kYB; ++m)
 #pragma unroll
-                for (int k = 0; k < 18; ++k) mm[m][k] = 0.f;
+                for (int k = 0; k < 18; ++k) mm[m][k] = Vec<VW>::zero();
             for (int z = 0; z < N; ++z) {
-                const float sab_xz = TB(0, x, z), sab_zx = TB(0, z, x);
-                const float sac_xz = TB(1, x, z), sac_zx = TB(1, z, x);
-                const float sbc_xz = TB(2, x, z), sbc_zx = TB(2, z, x);
-                const float pxzz = PP(x, z, z), pzxz = PP(z, x, z), pzzx = PP(z, z, x);
+                const V sab_xz = TB(0, x, z), sab_zx = TB(0, z, x);
+                const V sac_xz = TB(1, x, z), sac_zx = TB(1, z, x);
+                const V sbc_xz = TB(2, x, z), sbc_zx = TB(2, z, x);
+                const V pxzz = PP(x, z, z), pzxz = PP(z, x, z), pzzx = PP(z, z, x);
 #pragma unroll
                 for (int m = 0; m < kYB; ++m) {
                     const int y = (y0 + m < N) ? y0 + m : N - 1;
@@ -346,7 +377,7 @@ __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, 
                 if (y0 + m >= N) break;
                 float *o = Out + (((size_t)g * N + x) * N + y0 + m) * (size_t)(K * C) + f;
 #pragma unroll
-                for (int k = 0; k < 18; ++k) o[(size_t)(cases[k] - 1) * C] = mm[m][k];
+                for (int k = 0; k < 18; ++k) Vec<VW>::st(o + (size_t)(cases[k] - 1) * C, mm[m][k]);
             }
         }
 #undef TB
@@ -356,40 +387,41 @@ __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, 
 #undef OUTC
 
 // backward scalars, bsc[g][5][C]: u10, u38, u39, u40, u50 = sum_{d,e} G_c[d,e] A[d,e].
-// Workgroup per graph: 256 threads = row groups x channel lanes; a group walks (d,e) = grp, grp + ngrp, ... with the
-// five slices side by side, the groups are folded through LDS in a fixed order (deterministic).
+// Workgroup per (graph, slice): 256 threads = row groups x channel lanes; a group walks (d,e) = grp, grp + ngrp, ...,
+// the groups are folded through LDS in a fixed order (deterministic).
 template <int K>
 __global__ __launch_bounds__(256) void fam_bwd_scalars(const float *__restrict__ G, const float *__restrict__ A,
                                                        float *__restrict__ bsc, int N, int C) {
-    __shared__ float red[5 * 256];
-    const size_t g = blockIdx.x;
+    __shared__ float red[256];
+    const size_t g = blockIdx.x / 5;
+    const int j = (int)(blockIdx.x % 5);
+    const int cs = (j == 0) ? 10 : (j == 1) ? 38 : (j == 2) ? 39 : (j == 3) ? 40 : 50;
+    const int sl = (K == 50) ? cs - 1 : (cs <= 10 ? cs - 1 : -1);
     const int nl = C < 256 ? C : 256, ngrp = 256 / nl;
     const int fl = threadIdx.x % nl, grp = threadIdx.x / nl;
     const float *Ag = A + g * N * N;
-    constexpr int cs[5] = {10, 38, 39, 40, 50};
     for (int f0 = 0; f0 < C; f0 += nl) {
         const int f = f0 + fl;
-        float sum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if (grp < ngrp && f < C) {
-            const float *Gg = G + g * (size_t)N * N * K * C + f;
-            for (int de = grp; de < N * N; de += ngrp) {
-                const float a = Ag[de];
-                const float *row = Gg + (size_t)de * K * C;
-#pragma unroll
-                for (int j = 0; j < 5; ++j)
-                    if (slot<K>(cs[j]) >= 0) sum[j] += row[(size_t)slot<K>(cs[j]) * C] * a;
+        float sum = 0.f;
+        if (sl >= 0 && grp < ngrp && f < C) {
+            const float *Gg = G + g * (size_t)N * N * K * C + (size_t)sl * C + f;
+            int de = grp;
+            for (; de + 3 * ngrp < N * N; de += 4 * ngrp) {  // four independent loads in flight
+                const float x0 = Gg[(size_t)de * K * C], x1 = Gg[(size_t)(de + ngrp) * K * C];
+                const float x2 = Gg[(size_t)(de + 2 * ngrp) * K * C], x3 = Gg[(size_t)(de + 3 * ngrp) * K * C];
+                sum += x0 * Ag[de];
+                sum += x1 * Ag[de + ngrp];
+                sum += x2 * Ag[de + 2 * ngrp];
+                sum += x3 * Ag[de + 3 * ngrp];
             }
+            for (; de < N * N; de += ngrp) sum += Gg[(size_t)de * K * C] * Ag[de];
         }
-#pragma unroll
-        for (int j = 0; j < 5; ++j) red[j * 256 + threadIdx.x] = sum[j];
+        red[threadIdx.x] = sum;
         __syncthreads();
         if (grp == 0 && f < C) {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                float t = red[j * 256 + fl];
-                for (int k = 1; k < ngrp; ++k) t += red[j * 256 + k * nl + fl];
-                bsc[g * 5 * (size_t)C + (size_t)j * C + f] = t;
-            }
+            float t = red[fl];
+            for (int k = 1; k < ngrp; ++k) t += red[k * nl + fl];
+            bsc[g * 5 * (size_t)C + (size_t)j * C + f] = t;
         }
         __syncthreads();
     }
@@ -400,16 +432,18 @@ __global__ __launch_bounds__(256) void fam_bwd_scalars(const float *__restrict__
 // Thread per (g, i, block of JB columns j, f): the twenty G slices indexed by (i,z) are loaded once per z and serve
 // all JB columns; only the ten slices indexed by (j,z) and four adjacency entries are per column.
 constexpr int kNBTab = 6;
-constexpr int kJB = 6;
 
-template <int K>
+template <int K, int VW>
 __global__ __launch_bounds__(256) void fam_bwd_tables(const float *__restrict__ G, const float *__restrict__ A,
                                                       const float *__restrict__ adjs, const float *__restrict__ bsc,
                                                       float *__restrict__ btab, int N, int C, int njb, size_t total) {
+    using V = typename Vec<VW>::T;
+    constexpr int kJB = (VW == 4) ? 2 : 6;
     const size_t NNC = (size_t)N * N * C;
+    const int CV = C / VW;
     GRID_STRIDE(idx, total) {
-        const int f = idx % C;
-        size_t t = idx / C;
+        const int f = (int)(idx % CV) * VW;
+        size_t t = idx / CV;
         const int j0 = (int)(t % njb) * kJB;
         t /= njb;
         const int i = t % N;
@@ -419,33 +453,42 @@ __global__ __launch_bounds__(256) void fam_bwd_tables(const float *__restrict__ 
         const float *r = adjs + g * adjs_stride(N), *q = r + N, *st = q + 2 * N;
         const float tot = st[0], tr = st[1];
         const float *u = bsc + g * 5 * (size_t)C + f;
-#define GC(c, x, y) (slot<K>(c) >= 0 ? Gg[(((size_t)(x) * N + (y)) * K + slot<K>(c)) * C] : 0.f)
-        float xab[kJB], xac[kJB], xbc[kJB], zbc[kJB], zac[kJB], zab[kJB];
+#define GC(c, x, y) (slot<K>(c) >= 0 ? Vec<VW>::ld(Gg + (((size_t)(x) * N + (y)) * K + slot<K>(c)) * C) : Vec<VW>::zero())
+        V xab[kJB], xac[kJB], xbc[kJB], zbc[kJB], zac[kJB], zab[kJB];
+        const V u10 = Vec<VW>::ld(u + 0 * C);
+        V u38 = Vec<VW>::zero(), u39 = Vec<VW>::zero(), u40 = Vec<VW>::zero();
+        if (K == 50) {
+            u38 = Vec<VW>::ld(u + 1 * C);
+            u39 = Vec<VW>::ld(u + 2 * C);
+            u40 = Vec<VW>::ld(u + 3 * C);
+        }
         int jj[kJB];
 #pragma unroll
         for (int m = 0; m < kJB; ++m) {
             jj[m] = (j0 + m < N) ? j0 + m : N - 1;  // clamped duplicate, never stored
             const int j = jj[m];
-            xab[m] = tot * GC(1, i, j) + u[0 * C];
+            xab[m] = tot * GC(1, i, j) + u10;
             xac[m] = tot * GC(2, i, j);
             xbc[m] = tot * GC(5, i, j);
-            zbc[m] = zac[m] = zab[m] = 0.f;
+            zbc[m] = zac[m] = zab[m] = Vec<VW>::zero();
             if (K == 50) {
                 xab[m] += tr * GC(13, i, j);
                 xac[m] += tr * GC(16, i, j);
                 xbc[m] += tr * GC(25, i, j);
-                zbc[m] = u[3 * C];  // u40
-                zac[m] = u[2 * C];  // u39
-                zab[m] = u[1 * C];  // u38
+                zbc[m] = u40;
+                zac[m] = u39;
+                zab[m] = u38;
             }
         }
         for (int z = 0; z < N; ++z) {
             const float rz = r[z], qz = q[z];
             // (i,z)-indexed slices: shared by every column of the block
-            const float g3 = GC(3, i, z), g4 = GC(4, i, z);
-            const float i34 = g3 * rz + g4 * qz;
-            float g18 = 0.f, g21 = 0.f, g19 = 0.f, g22 = 0.f, g28 = 0.f, g31 = 0.f, g43 = 0.f, g44 = 0.f, g46 = 0.f, g47 = 0.f,
-                  g48 = 0.f, g49 = 0.f, z17 = 0.f, z26 = 0.f, z32 = 0.f, azi = 0.f, aiz = 0.f;
+            const V g3 = GC(3, i, z), g4 = GC(4, i, z);
+            const V i34 = g3 * rz + g4 * qz;
+            const V zz = Vec<VW>::zero();
+            V g18 = zz, g21 = zz, g19 = zz, g22 = zz, g28 = zz, g31 = zz, g43 = zz, g44 = zz, g46 = zz, g47 = zz, g48 = zz, g49 = zz,
+              z17 = zz, z26 = zz, z32 = zz;
+            float azi = 0.f, aiz = 0.f;
             if (K == 50) {
                 g18 = GC(18, i, z); g21 = GC(21, i, z); g19 = GC(19, i, z); g22 = GC(22, i, z);
                 g28 = GC(28, i, z); g31 = GC(31, i, z); g43 = GC(43, i, z); g44 = GC(44, i, z);
@@ -478,13 +521,13 @@ __global__ __launch_bounds__(256) void fam_bwd_tables(const float *__restrict__ 
         for (int m = 0; m < kJB; ++m) {
             if (j0 + m >= N) continue;
             float *bt = btab + g * kNBTab * NNC + ((size_t)i * N + j0 + m) * C + f;
-            bt[0 * NNC] = xab[m];
-            bt[1 * NNC] = xac[m];
-            bt[2 * NNC] = xbc[m];
+            Vec<VW>::st(bt + 0 * NNC, xab[m]);
+            Vec<VW>::st(bt + 1 * NNC, xac[m]);
+            Vec<VW>::st(bt + 2 * NNC, xbc[m]);
             if (K == 50) {
-                bt[3 * NNC] = zbc[m];
-                bt[4 * NNC] = zac[m];
-                bt[5 * NNC] = zab[m];
+                Vec<VW>::st(bt + 3 * NNC, zbc[m]);
+                Vec<VW>::st(bt + 4 * NNC, zac[m]);
+                Vec<VW>::st(bt + 5 * NNC, zab[m]);
             }
         }
     }
@@ -531,57 +574,59 @@ __global__ void fam_backward(const float *__restrict__ G, const float *__restric
 // The same combination with a workgroup per (g, a): the four (a,c)-indexed rows (X_ac and the G slices of cases 14, 15,
 // 42) are staged in LDS once and serve every b; a thread owns (b, f), keeps its (a,b)-indexed terms in registers and
 // walks c, so each output costs four global loads (the (b,c)-indexed terms) instead of twelve.
-template <int K>
+template <int K, int VW>
 __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict__ G, const float *__restrict__ adjs,
                                                          const float *__restrict__ bsc, const float *__restrict__ btab,
                                                          float *__restrict__ dP, int N, int C, int accumulate) {
-    extern __shared__ float srow[];  // [4][N][C]: X_ac(a,c) | G14(a,c) | G15(a,c) | G42(a,c)
+    using V = typename Vec<VW>::T;
+    extern __shared__ __attribute__((aligned(16))) float srow[];  // [4][N][C]: X_ac(a,c) | G14(a,c) | G15(a,c) | G42(a,c)
     const size_t NNC = (size_t)N * N * C, NC = (size_t)N * C;
     const size_t g = blockIdx.x / N;
     const int a = (int)(blockIdx.x % N);
     const float *bt = btab + g * kNBTab * NNC;
     const float *Gg = G + g * (size_t)N * N * K * C;
     const float *r = adjs + g * adjs_stride(N), *q = r + N, *dg = q + N;
-#define GCF(cs, x, y, f) Gg[(((size_t)(x) * N + (y)) * K + slot<K>(cs)) * C + (f)]
-    for (int i = threadIdx.x; i < (int)NC; i += blockDim.x) {
-        const int c = i / C, f = i % C;
-        srow[0 * NC + i] = bt[1 * NNC + ((size_t)a * N + c) * C + f];
+#define GCF(cs, x, y, f) Vec<VW>::ld(Gg + (((size_t)(x) * N + (y)) * K + slot<K>(cs)) * C + (f))
+    const int CV = C / VW, items = N * CV;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int c = it / CV, f = (it % CV) * VW;
+        const size_t i = (size_t)c * C + f;
+        Vec<VW>::st(srow + 0 * NC + i, Vec<VW>::ld(bt + 1 * NNC + ((size_t)a * N + c) * C + f));
         if (K == 50) {
-            srow[1 * NC + i] = GCF(14, a, c, f);
-            srow[2 * NC + i] = GCF(15, a, c, f);
-            srow[3 * NC + i] = GCF(42, a, c, f);
+            Vec<VW>::st(srow + 1 * NC + i, GCF(14, a, c, f));
+            Vec<VW>::st(srow + 2 * NC + i, GCF(15, a, c, f));
+            Vec<VW>::st(srow + 3 * NC + i, GCF(42, a, c, f));
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (int)NC; i += blockDim.x) {
-        const int b = i / C, f = i % C;
-        const float xab = bt[0 * NNC + ((size_t)a * N + b) * C + f];
-        float g11 = 0.f, g12 = 0.f, g41 = 0.f, zbc = 0.f, zac = 0.f, u50 = 0.f;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int b = it / CV, f = (it % CV) * VW;
+        const V xab = Vec<VW>::ld(bt + 0 * NNC + ((size_t)a * N + b) * C + f);
+        V g11 = Vec<VW>::zero(), g12 = g11, g41 = g11, zbc = g11, zac = g11, u50 = g11;
         const float rb = r[b], qb = q[b], dgb = dg[b], ra = r[a], qa = q[a], dga = dg[a];
         if (K == 50) {
             g11 = GCF(11, a, b, f);
             g12 = GCF(12, a, b, f);
             g41 = GCF(41, a, b, f);
-            zbc = bt[3 * NNC + ((size_t)a * N + b) * C + f];   // applies at c == b
-            zac = bt[4 * NNC + ((size_t)b * N + a) * C + f];   // applies at c == a
-            u50 = bsc[g * 5 * (size_t)C + 4 * C + f];
+            zbc = Vec<VW>::ld(bt + 3 * NNC + ((size_t)a * N + b) * C + f);   // applies at c == b
+            zac = Vec<VW>::ld(bt + 4 * NNC + ((size_t)b * N + a) * C + f);   // applies at c == a
+            u50 = Vec<VW>::ld(bsc + g * 5 * (size_t)C + 4 * C + f);
         }
         float *out = dP + ((g * N + a) * N + b) * (size_t)N * C + f;
         for (int c = 0; c < N; ++c) {
-            float v = xab + srow[0 * NC + (size_t)c * C + f] + bt[2 * NNC + ((size_t)b * N + c) * C + f];
+            V v = xab + Vec<VW>::ld(srow + 0 * NC + (size_t)c * C + f) + Vec<VW>::ld(bt + 2 * NNC + ((size_t)b * N + c) * C + f);
             if (K == 50) {
                 v += g11 * r[c] + g12 * q[c] + g41 * dg[c];
-                v += srow[1 * NC + (size_t)c * C + f] * rb + srow[2 * NC + (size_t)c * C + f] * qb + srow[3 * NC + (size_t)c * C + f] * dgb;
+                v += Vec<VW>::ld(srow + 1 * NC + (size_t)c * C + f) * rb + Vec<VW>::ld(srow + 2 * NC + (size_t)c * C + f) * qb +
+                     Vec<VW>::ld(srow + 3 * NC + (size_t)c * C + f) * dgb;
                 v += GCF(23, b, c, f) * ra + GCF(24, b, c, f) * qa + GCF(45, b, c, f) * dga;
                 if (b == c) v += zbc;
                 if (a == c) v += zac;
-                if (a == b) v += bt[5 * NNC + ((size_t)c * N + a) * C + f];
+                if (a == b) v += Vec<VW>::ld(bt + 5 * NNC + ((size_t)c * N + a) * C + f);
                 if (a == b && b == c) v += u50;
             }
-            if (accumulate)
-                out[(size_t)c * C] += v;
-            else
-                out[(size_t)c * C] = v;
+            if (accumulate) v += Vec<VW>::ld(out + (size_t)c * C);
+            Vec<VW>::st(out + (size_t)c * C, v);
         }
     }
 #undef GCF
@@ -612,13 +657,23 @@ gf_status fam_forward_launch(gf_ctx *ctx, const float *P, const float *A, float 
     const FamWs w = carve(static_cast<float *>(ctx->ws), N, C, batch);
     const size_t nn = (size_t)batch * N * N * C, nv = (size_t)batch * N * C, ns = (size_t)batch * C;
     GF_LAUNCH(ctx, "fam_adj", fam_adj, dim3(batch), dim3(64), 0, A, w.adjs, N);
-    GF_LAUNCH(ctx, "fam_tables", fam_tables<K>, dim3(grid_for(nn)), dim3(256), 0, P, w.adjs, w.tab, N, C, nn);
+    const bool vec = C % 4 == 0 && (((uintptr_t)P | (uintptr_t)Out | (uintptr_t)w.tab) & 15) == 0;
+    if (vec)
+        GF_LAUNCH(ctx, "fam_tables", (fam_tables<K, 4>), dim3(grid_for(nn / 4)), dim3(256), 0, P, w.adjs, w.tab, N, C, nn / 4);
+    else
+        GF_LAUNCH(ctx, "fam_tables", (fam_tables<K, 1>), dim3(grid_for(nn)), dim3(256), 0, P, w.adjs, w.tab, N, C, nn);
     GF_LAUNCH(ctx, "fam_vectors", fam_vectors, dim3(grid_for(nv)), dim3(256), 0, P, w.tab, w.vec, w.sc, N, C, nv);
     GF_LAUNCH(ctx, "fam_scalars", fam_scalars, dim3(grid_for(ns)), dim3(256), 0, P, w.vec, w.sc, N, C, ns);
-    const int nyb = (N + kYB - 1) / kYB;
-    const size_t nf = (size_t)batch * N * nyb * C;
-    GF_LAUNCH(ctx, "fam_forward", fam_forward<K>, dim3(grid_for(nf)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out,
-              N, C, nyb, nf);
+    if (vec) {
+        const size_t nf = (size_t)batch * N * N * (C / 4);
+        GF_LAUNCH(ctx, "fam_forward", (fam_forward<K, 4>), dim3(grid_for(nf)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec, w.sc,
+                  Out, N, C, N, nf);
+    } else {
+        const int nyb = (N + 3) / 4;
+        const size_t nf = (size_t)batch * N * nyb * C;
+        GF_LAUNCH(ctx, "fam_forward", (fam_forward<K, 1>), dim3(grid_for(nf)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec, w.sc,
+                  Out, N, C, nyb, nf);
+    }
     return GF_OK;
 }
 
@@ -629,16 +684,32 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     if (st != GF_OK) return st;
     const FamWs w = carve(static_cast<float *>(ctx->ws), N, C, batch);  // tab doubles as btab, sc as bsc
     const size_t nn = (size_t)batch * N * N * C, np = nn * N;
-    const int njb = (N + kJB - 1) / kJB;
-    const size_t nt = (size_t)batch * N * njb * C;
+    const bool vec = C % 4 == 0 && (((uintptr_t)G | (uintptr_t)dP | (uintptr_t)w.tab | (uintptr_t)w.sc) & 15) == 0;
     GF_LAUNCH(ctx, "fam_adj", fam_adj, dim3(batch), dim3(64), 0, A, w.adjs, N);
-    GF_LAUNCH(ctx, "fam_bwd_scalars", fam_bwd_scalars<K>, dim3(batch), dim3(256), 0, G, A, w.sc, N, C);
-    GF_LAUNCH(ctx, "fam_bwd_tables", fam_bwd_tables<K>, dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N, C,
-              njb, nt);
+    GF_LAUNCH(ctx, "fam_bwd_scalars", fam_bwd_scalars<K>, dim3(batch * 5), dim3(256), 0, G, A, w.sc, N, C);
+    // (measured at cfg5: the 16-byte variants of the two kernels below are SLOWER -- with four channels per thread only
+    //  two columns fit in registers, the shared (i,z) operands are re-read three times as often and the kernels are
+    //  L2-bound -- so they keep one channel per thread; forward benefits and uses the vector path)
+    const bool vec_bt = false;
+    if (vec && vec_bt) {
+        const int njb = (N + 1) / 2;
+        const size_t nt = (size_t)batch * N * njb * (C / 4);
+        GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 4>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
+                  C, njb, nt);
+    } else {
+        const int njb = (N + 5) / 6;
+        const size_t nt = (size_t)batch * N * njb * C;
+        GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 1>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
+                  C, njb, nt);
+    }
     const size_t row_lds = sizeof(float) * 4 * (size_t)N * C;
     if (row_lds <= 48 * 1024 && (size_t)batch * N < 0x7fffffffu) {
-        GF_LAUNCH(ctx, "fam_backward", fam_backward_rows<K>, dim3((unsigned)((size_t)batch * N)), dim3(256), row_lds, G, w.adjs,
-                  w.sc, w.tab, dP, N, C, accumulate);
+        if (vec && vec_bt)
+            GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, 4>), dim3((unsigned)((size_t)batch * N)), dim3(256), row_lds, G,
+                      w.adjs, w.sc, w.tab, dP, N, C, accumulate);
+        else
+            GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, 1>), dim3((unsigned)((size_t)batch * N)), dim3(256), row_lds, G,
+                      w.adjs, w.sc, w.tab, dP, N, C, accumulate);
     } else {
         GF_LAUNCH(ctx, "fam_backward", fam_backward<K>, dim3(grid_for(np)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, dP, N, C,
                   np, accumulate);
