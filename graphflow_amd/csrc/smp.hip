@@ -12,6 +12,7 @@
 // is an index gather forward and a deterministic consumer-list gather backward (no atomics).
 // Nodes of a level are bucketed by receptive-field size; each bucket is one uniform-N contraction launch and all
 // buckets share one tall K-projection GEMM per level.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -313,22 +314,50 @@ template <typename T>
 gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
     *dst = nullptr;
     const size_t bytes = sizeof(T) * (count ? count : 1);
+    // best fit among the idle blocks of the pool (no block more than twice the request: keeps big blocks for big buffers)
+    int best = -1;
+    for (size_t i = 0; i < s->pool.size(); ++i) {
+        const gf_smp::Block &b = s->pool[i];
+        if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 && (best < 0 || b.bytes < s->pool[best].bytes)) best = (int)i;
+    }
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return fail(s->ctx, GF_ERR_NOMEM, "smp: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    s->allocs.push_back(p);
+    if (best >= 0) {
+        s->pool[best].used = true;
+        s->pool[best].idle = 0;
+        p = s->pool[best].p;
+    } else {
+        const size_t cap = bytes + bytes / 8 + 256;  // slack: the next batch is about, not exactly, this size
+        hipError_t e = hipMalloc(&p, cap);
+        if (e != hipSuccess) return fail(s->ctx, GF_ERR_NOMEM, "smp: hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        gf_smp::Block b = {p, cap, true, 0};
+        s->pool.push_back(b);
+    }
     if (src && count) GF_HIP_TRY(s->ctx, hipMemcpyAsync(p, src, sizeof(T) * count, hipMemcpyHostToDevice, s->ctx->stream));
     *dst = static_cast<T *>(p);
     return GF_OK;
 }
 
+// End of a batch: its buffers go back to the pool (blocks idle for three batches in a row are returned to the device).
 void release(gf_smp *s) {
     if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
-    for (void *p : s->allocs) (void)hipFree(p);
-    s->allocs.clear();
+    std::vector<gf_smp::Block> keep;
+    for (gf_smp::Block &b : s->pool) {
+        if (!b.used && ++b.idle >= 3) {
+            (void)hipFree(b.p);
+            continue;
+        }
+        b.used = false;
+        keep.push_back(b);
+    }
+    s->pool.swap(keep);
     s->lv.clear();
     s->own_t = s->own_y = s->own_loss = s->own_feat = nullptr;
     s->prepared = s->forwarded = false;
+}
+
+void release_pool(gf_smp *s) {
+    for (gf_smp::Block &b : s->pool) (void)hipFree(b.p);
+    s->pool.clear();
 }
 
 // the handle-owned parameter / gradient buffers (host-pointer mode), created on first use
@@ -428,6 +457,7 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
 gf_status gf_smp_destroy(gf_smp *s) {
     if (!s) return GF_OK;
     gf::release(s);
+    gf::release_pool(s);
     if (s->adam_m) (void)hipFree(s->adam_m);
     if (s->adam_v) (void)hipFree(s->adam_v);
     if (s->own_p) (void)hipFree(s->own_p);
@@ -601,10 +631,14 @@ gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *a
     gf_ctx *ctx = s->ctx;
     if (nMol <= 0 || !nVertices || !adj || !feature) return fail(ctx, GF_ERR_INVALID, "gf_smp_prepare: bad argument");
     for (int m = 0; m < nMol; ++m)
-        if (nVertices[m] <= 0 || nVertices[m] > 32767) return fail(ctx, GF_ERR_INVALID, "molecule %d has %d vertices", m, nVertices[m]);
+        if (nVertices[m] <= 0 || nVertices[m] > 4096) return fail(ctx, GF_ERR_INVALID, "molecule %d has %d vertices", m, nVertices[m]);
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool prep_timing = std::getenv("GF_PREP_TIMING") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     gf::release(s);
+    const auto tp1 = std::chrono::steady_clock::now();
     gfsmp::build_batch(s->cfg, nMol, nVertices, adj, feature, &s->lay);
+    const auto tp2 = std::chrono::steady_clock::now();
     const gfsmp::BatchLayout &B = s->lay;
     const int L = s->cfg.nLevels, C = s->cfg.nChanels;
     s->lv.assign(L + 1, gf_smp::DevLevel());
@@ -699,6 +733,14 @@ gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *a
     st = gf::ensure_ws(ctx, std::max(contract_ws, gemm_ws));
     if (st != GF_OK) return st;
     GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (prep_timing) {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        std::fprintf(stderr, "gf_smp_prepare: release %.1f ms, host graph preparation %.1f ms, device allocation + upload %.1f ms\n",
+                     ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3));
+    }
     s->prepared = true;
     return GF_OK;
 }

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(kThreads) void smp_tables_fwd(const float *__restri
 // (With workgroup-per-pair the fixed prologue/epilogue -- about ten barriers -- dominated when a wave owned <= 4 rows.)
 // ---------------------------------------------------------------------------------------------------------------
 template <int NI>
-__global__ __launch_bounds__(kThreads) void smp_tables_fwd_w(const float *__restrict__ fprev, const float *__restrict__ rsum,
+__global__ __launch_bounds__(kThreads, 4) void smp_tables_fwd_w(  // (NI = 4 sat at 130 VGPRs: capped to 128 -> 4 waves per SIMD)
+    const float *__restrict__ fprev, const float *__restrict__ rsum,
                                                              float *__restrict__ T, float *__restrict__ Vt,
                                                              float *__restrict__ scal, const long long *__restrict__ pair_src_row,
                                                              const int *__restrict__ pair_src_s, const short *__restrict__ pi,

@@ -63,7 +63,15 @@ struct gf_smp {
     float *yhat = nullptr, *dy = nullptr;  // [nMol]
     float *colpart = nullptr;  // partial column sums for bias gradients
     int *top_node_mol = nullptr, *mol_ptr = nullptr, *mol_nodes = nullptr;
-    std::vector<void *> allocs;
+    // device buffers of the current batch come from a pool that survives gf_smp_prepare: a training loop prepares a new
+    // batch every step, and hipMalloc of the level buffers (GBs) cost 4x the host graph preparation itself
+    struct Block {
+        void *p;
+        size_t bytes;
+        bool used;
+        int idle;  // consecutive prepares that did not use the block
+    };
+    std::vector<Block> pool;
     // Adam state (gf_smp_adam_step); survives gf_smp_prepare, freed by gf_smp_destroy
     float *adam_m = nullptr, *adam_v = nullptr;
     // handle-owned model (host-pointer mode of the driver): parameters and their gradient, [param_count] each

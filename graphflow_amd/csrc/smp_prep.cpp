@@ -5,32 +5,42 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <thread>
 #include <utility>
 
 namespace gfsmp {
 namespace {
 
-// fn(i) for i in [0, n) on up to GF_PREP_THREADS (default: hardware concurrency, at most 16) host threads; every
-// iteration writes disjoint memory, so the result does not depend on the thread count.
+constexpr int kMaxVertices = 4096;  // per molecule, for the stack-resident vertex tables of the batch builder
+
+// fn(i) for i in [0, n) on up to GF_PREP_THREADS (default: hardware concurrency, at most 32) host threads; every
+// iteration writes disjoint memory, so the result does not depend on the thread count or on the schedule.  Iterations
+// are handed out in small blocks from a shared counter: molecules differ a lot in cost (O(V^3) each).
 template <typename Fn>
 void parallel_for(int n, const Fn &fn) {
     int nt = (int)std::thread::hardware_concurrency();
     if (const char *e = std::getenv("GF_PREP_THREADS")) nt = std::atoi(e);
-    nt = std::max(1, std::min(nt, 16));
+    nt = std::max(1, std::min(nt, 32));
     if (n < 64 || nt == 1) {
         for (int i = 0; i < n; ++i) fn(i);
         return;
     }
-    std::vector<std::thread> pool;
-    const int chunk = (n + nt - 1) / nt;
-    for (int t = 0; t < nt; ++t) {
-        const int lo = t * chunk, hi = std::min(n, lo + chunk);
-        if (lo >= hi) break;
-        pool.emplace_back([lo, hi, &fn]() {
+    const int block = std::max(1, std::min(16, n / (nt * 8)));
+    std::atomic<int> next(0);
+    auto worker = [&]() {
+        for (;;) {
+            const int lo = next.fetch_add(block);
+            if (lo >= n) return;
+            const int hi = std::min(n, lo + block);
             for (int i = lo; i < hi; ++i) fn(i);
-        });
-    }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+    worker();
     for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
 }
 
@@ -134,6 +144,7 @@ void prepare_molecule(const Config &cfg, int V, const int *adj, const double *fe
 void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *adj, const double *feature,
                  BatchLayout *out) {
     const int L = cfg.nLevels, FD = cfg.fdim(), F = cfg.nFeatures;
+    const std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
     out->nMol = nMol;
     out->mols.assign(nMol, Molecule());
     out->mol_first_vertex.assign(nMol + 1, 0);
@@ -150,7 +161,11 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         for (size_t i = 0; i < (size_t)V * FD; ++i) out->x[(size_t)v0 * FD + i] = (float)out->mols[m].wl[i];
     });
 
-    out->level.assign(L + 1, LevelLayout());
+    const bool timing = std::getenv("GF_PREP_TIMING") != nullptr;
+    const std::chrono::steady_clock::time_point t_mol = std::chrono::steady_clock::now();
+    // keep the vectors of a previous batch (their capacity): re-faulting ~50 MB of fresh pages costs more than the work
+    out->level.resize(L + 1);
+    for (int l = 0; l <= L; ++l) out->level[l].buckets.clear();
     // node numbering per level: level 0 in (molecule, vertex) order; level >= 1 bucketed by field size (stable)
     std::vector<std::vector<int> > node_of(L + 1, std::vector<int>(totalV, -1));  // [level][global vertex] -> node
     for (int l = 0; l <= L; ++l) {
@@ -194,20 +209,22 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         lv.pairs = pair;
     }
     out->top_node_of_vertex = node_of[L];
+    const std::chrono::steady_clock::time_point t_order = std::chrono::steady_clock::now();
 
     for (int l = 1; l <= L; ++l) {
         LevelLayout &lv = out->level[l];
         const LevelLayout &prev = out->level[l - 1];
-        lv.adj.assign((size_t)lv.rows, 0.f);
-        lv.rsum.assign((size_t)lv.pairs, 0.f);
-        lv.rowscale.assign((size_t)lv.rows * 2, 0.f);
+        // every element of these is written by the node loop below: resize only (no fill pass over ~50 MB per batch)
+        lv.adj.resize((size_t)lv.rows);
+        lv.rsum.resize((size_t)lv.pairs);
+        lv.rowscale.resize((size_t)lv.rows * 2);
         lv.quad_node.clear();
         lv.quad_b0.clear();
-        lv.pair_node.assign((size_t)lv.pairs, 0);
-        lv.pair_src_row.assign((size_t)lv.pairs, 0);
-        lv.pair_src_s.assign((size_t)lv.pairs, 0);
-        lv.pi.assign((size_t)lv.rows, (int16_t)-1);
-        std::vector<int> pair_src_node((size_t)lv.pairs, 0);
+        lv.pair_node.resize((size_t)lv.pairs);
+        lv.pair_src_row.resize((size_t)lv.pairs);
+        lv.pair_src_s.resize((size_t)lv.pairs);
+        lv.pi.resize((size_t)lv.rows);
+        std::vector<int> pair_src_node((size_t)lv.pairs);
         for (int n = 0; n < lv.nNodes; ++n)
             for (int b0 = 0; b0 < lv.node_s[n]; b0 += 4) {
                 lv.quad_node.push_back(n);
@@ -243,6 +260,9 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                     lv.rowscale[2 * ((size_t)lv.node_row[n] + r) + 1] = tr;
                 }
             }
+            int16_t pos[kMaxVertices];  // position of a vertex inside phi_{l-1}(w), -1 outside; reset after each neighbour
+            if (V > kMaxVertices) std::abort();  // (gf_smp_prepare rejects such molecules before it gets here)
+            for (int i = 0; i < V; ++i) pos[i] = -1;
             for (int a = 0; a < s; ++a) {
                 const int w = field[a];
                 const int64_t e = lv.node_pair[n] + a;
@@ -253,10 +273,9 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 lv.pair_src_row[(size_t)e] = prev.node_row[src];
                 lv.pair_src_s[(size_t)e] = (int)wf.size();
                 // selection map: X[i][k] = [phi_l(v)[i] == phi_{l-1}(w)[k]]   (:461-474)
-                for (int p = 0; p < s; ++p) {
-                    const std::vector<int>::const_iterator it = std::find(wf.begin(), wf.end(), field[p]);
-                    lv.pi[(size_t)lv.node_row[n] + (size_t)a * s + p] = (it == wf.end()) ? (int16_t)-1 : (int16_t)(it - wf.begin());
-                }
+                for (size_t k = 0; k < wf.size(); ++k) pos[wf[k]] = (int16_t)k;
+                for (int p = 0; p < s; ++p) lv.pi[(size_t)lv.node_row[n] + (size_t)a * s + p] = pos[field[p]];
+                for (size_t k = 0; k < wf.size(); ++k) pos[wf[k]] = -1;
             }
         });
         // inverse index for the backward gather: consumers of a source node in increasing pair order (= fixed
@@ -290,6 +309,13 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 }
             }
         });
+    }
+    if (timing) {
+        const std::chrono::steady_clock::time_point t_end = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "build_batch: molecules %.1f ms, node order %.1f ms, level tables %.1f ms\n",
+                     std::chrono::duration<double, std::milli>(t_mol - t_begin).count(),
+                     std::chrono::duration<double, std::milli>(t_order - t_mol).count(),
+                     std::chrono::duration<double, std::milli>(t_end - t_order).count());
     }
 }
 

@@ -233,3 +233,42 @@ def test_prepare_rejects_bad_input(gf):
     p = torch.zeros(net.n_params, device="cuda")
     with pytest.raises(Exception):
         net.forward(p)   # forward before prepare
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_handle_reuse_across_batches_is_exact(gf, fused):
+    """A training loop prepares a new batch on the same handle every step; the device buffers come from a pool that is
+    reused (not re-allocated, not zeroed).  Results on batch B after batch A must be bit-identical to a fresh handle."""
+    from graphflow_amd.smp import SMPOmega
+    L, C, F, D, cap = 3, 16, 5, 2, 8
+    params = dev(smp_params(C, F, D, L, 3))
+
+    def batch(seeds, sizes):
+        mols, tg = [], []
+        for s, n in zip(seeds, sizes):
+            a, f, t = synthetic_molecule(s, nV=n)
+            mols.append((a, f))
+            tg.append(t)
+        return mols, dev(np.array(tg))
+
+    A = batch(range(200, 212), [5, 9, 14, 7, 11, 3, 16, 8, 12, 6, 10, 15])
+    B = batch(range(300, 309), [13, 4, 9, 17, 6, 11, 8, 15, 5])
+
+    def run(net, mols, tg):
+        net.set_fused(fused)
+        net.prepare(mols)
+        pred, loss, feat = net.forward(params, tg)
+        g = torch.empty(net.n_params, device="cuda")
+        net.backward(params, g)
+        return pred.clone(), feat.clone(), g
+
+    reused = SMPOmega(L, C, F, D, cap, True)
+    run(reused, *A)
+    got = run(reused, *B)
+    got_a = run(reused, *A)      # and back to the larger batch
+    fresh_b = run(SMPOmega(L, C, F, D, cap, True), *B)
+    fresh_a = run(SMPOmega(L, C, F, D, cap, True), *A)
+    for x, y in zip(got, fresh_b):
+        assert torch.equal(x, y)
+    for x, y in zip(got_a, fresh_a):
+        assert torch.equal(x, y)
