@@ -74,6 +74,14 @@ __device__ __forceinline__ int bscat_k(int q) { return (q & ~3) | ((q & 1) << 1)
 // row taken by the q-th group of 8 lanes in the float4-along-k stores (two ds_write_b64 per float4).  Pairing rows r and
 // r + 4 in a 16-lane store group would make these stores conflict-free too (they are 2-way now), but measured no gain.
 __device__ __forceinline__ int rowst_m(int q) { return q; }
+// transposing A store (TA): float4 idx -> (m, k).  Eight lanes take 32 consecutive m of one k row (128 B of global
+// memory), the next eight lanes the row k + 2, ... so that a 32-lane store group holds four different kp & 3 and eight
+// different swizzled slots: 2-way conflicts instead of 4-way with 32 lanes on one k row.
+__device__ __forceinline__ void ascat_mk(int idx, int *m, int *k) {
+    const int a = (idx & 7) + 8 * ((idx >> 5) & 3), kq = (idx >> 3) & 3, kh = idx >> 7;
+    *m = 4 * a;
+    *k = 2 * kq + (kh & 1) + 8 * (kh >> 1);
+}
 __device__ __forceinline__ int lds_at(int row, int kp) { return row * LDS_ROW + ((((kp >> 2) ^ lds_swz(row)) << 2) | (kp & 3)); }
 
 // element (m,k) of op(A): TA ? A[k*lda + m] : A[m*lda + k];   element (k,n) of op(B): TB ? B[n*ldb + k] : B[k*ldb + n]
@@ -113,7 +121,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
             for (int e = 0; e < NA; ++e) {
                 const int idx = tid + e * kThreads;
                 int m, k;
-                if (TA) { m = (idx % (BM / 4)) * 4; k = idx / (BM / 4); } else { k = (idx % (BK / 4)) * 4; m = rowst_m(idx / (BK / 4)); }
+                if (TA) { ascat_mk(idx, &m, &k); } else { k = (idx % (BK / 4)) * 4; m = rowst_m(idx / (BK / 4)); }
                 const int gm = m0 + m, gk = k0 + k;
                 const size_t off = TA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk;
                 const bool in = gm < g.M && gk < kend;
@@ -173,7 +181,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int m0
             for (int e = 0; e < NA; ++e) {
                 const int idx = tid + e * kThreads;
                 if (TA) {  // four consecutive m at one k
-                    const int m = (idx % (BM / 4)) * 4, kp = kpos(idx / (BM / 4));
+                    int m, k;
+                    ascat_mk(idx, &m, &k);
+                    const int kp = kpos(k);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) As[lds_at(m + j, kp)] = va[e][j];
                 } else {   // four consecutive k of one row: even pair and odd pair are each contiguous
