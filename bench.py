@@ -182,6 +182,8 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
             "algorithmic_GB_per_step": round(step_bytes / 1e9, 2), "gemm_GFLOP_per_step": round(step_flops / 1e9, 1)}
 
     def finish(timers, ms_per_step):
+        if not timers:   # GF_BENCH_NOTIMING=1 (diagnostic: step time without the per-launch events)
+            return {"note": "per-kernel timing disabled"}
         tot = {k: v[0] / args.steps for k, v in timers.items()}   # ms per step per kernel name
         dom = max(tot, key=tot.get)
         if dom in kf:
@@ -259,15 +261,34 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.set_timing(True)
+    # Per-kernel table: an identical pass of K steps with every launch bracketed by HIP events, OUTSIDE the timed region
+    # (the events cost about 5 % of a 72-launch step: they keep neighbouring kernels from overlapping).  The timed region
+    # then times only the dominant kernel live -- its average duration is what roofline.achieved is computed from.
+    notiming = bool(os.environ.get("GF_BENCH_NOTIMING"))
+    timers = {}
+    if not notiming:
+        ctx.set_timing_filter(None)
+        ctx.set_timing(True)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        timers = ctx.timings()
+        ctx.set_timing(False)
+        dominant = max(timers, key=lambda k: timers[k][0])
+        ctx.set_timing_filter(dominant)
+        fence()
+        ctx.set_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
-    timers = ctx.timings()
-    ctx.set_timing(False)
+    if not notiming:
+        live = ctx.timings()
+        ctx.set_timing(False)
+        ctx.set_timing_filter(None)
+        timers[dominant] = live[dominant]
     elapsed = gd.max_over_ranks(elapsed, dist, dev)
 
     ceiling = copy_ceiling_gbps(torch, dev) if rank == 0 else None
@@ -280,6 +301,8 @@ def main():
                 "config": meta["config"], "roofline": finish(timers, ms_per_step),
                 "cpu_baseline": (cpu() if (world == 1 and not args.no_cpu_baseline) else None)}
         line["roofline"]["hbm_copy_measured_GBps"] = round(ceiling, 1)
+        line["roofline"]["timing"] = ("HIP events on the kernels' stream: the dominant kernel live inside the timed region, "
+                                      "the other kernels in an identical pass of the same steps just before it")
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

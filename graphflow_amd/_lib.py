@@ -73,6 +73,7 @@ PROTOTYPES.update({
     "gf_smp_prepare": (_i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
     "gf_smp_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gf_smp_backward": (_i, [_vp, _vp, _vp, _i]),
+    "gf_ctx_set_timing_filter": (_i, [_vp, C.c_char_p]),
     "gf_smp_parameters_upload": (_i, [_vp, _fp]),
     "gf_smp_parameters_download": (_i, [_vp, _fp, _fp]),
     "gf_smp_forward_host": (_i, [_vp, _dp, _dp, _dp, _dp]),

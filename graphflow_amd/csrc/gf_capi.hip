@@ -48,6 +48,7 @@ void r18_force_generic(int on);
 
 LaunchTimer::LaunchTimer(gf_ctx *c, const char *name) : ctx(c) {
     if (!c->timing) return;
+    if (c->timing_filter[0] && std::strcmp(c->timing_filter, name) != 0) return;
     for (size_t i = 0; i < c->timers.size(); ++i)
         if (c->timers[i].name == name || std::strcmp(c->timers[i].name, name) == 0) slot = (int)i;
     if (slot < 0) {
@@ -523,6 +524,12 @@ gf_status gf_ctx_set_timing(gf_ctx *ctx, int enable) {
     if (st != GF_OK) return st;
     if (enable) ctx->timers.clear();
     ctx->timing = enable != 0;
+    return GF_OK;
+}
+
+gf_status gf_ctx_set_timing_filter(gf_ctx *ctx, const char *kernel_name) {
+    if (!ctx) return gf::fail(nullptr, GF_ERR_INVALID, "null context");
+    std::snprintf(ctx->timing_filter, sizeof ctx->timing_filter, "%s", kernel_name ? kernel_name : "");
     return GF_OK;
 }
 

@@ -24,6 +24,7 @@ struct gf_ctx {
     char err[512] = {0};
     // optional per-kernel timing (gf_ctx_set_timing): HIP events around every launch on ctx->stream
     bool timing = false;
+    char timing_filter[64] = {0};  // non-empty: only launches whose name equals it are timed (gf_ctx_set_timing_filter)
     struct Timer {
         const char *name;
         double ms;

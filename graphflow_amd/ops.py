@@ -54,6 +54,10 @@ class Context:
         """Per-kernel HIP-event timing on the context stream (gf_ctx_set_timing)."""
         self.check(self.lib.gf_ctx_set_timing(self.handle, 1 if enable else 0))
 
+    def set_timing_filter(self, kernel_name=None):
+        """Only launches named `kernel_name` are timed (None: all) -- see gf_ctx_set_timing_filter."""
+        self.check(self.lib.gf_ctx_set_timing_filter(self.handle, kernel_name.encode() if kernel_name else None))
+
     def timings(self):
         """{kernel name: (total_ms, launches)} since timing was enabled; synchronises the stream."""
         out = {}
