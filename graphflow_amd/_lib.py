@@ -71,6 +71,7 @@ PROTOTYPES.update({
     "gf_smp_destroy": (_i, [_vp]),
     "gf_smp_param_count": (C.c_size_t, [_vp]),
     "gf_smp_prepare": (_i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
+    "gf_smp_prepare_coulomb": (_i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp]),
     "gf_smp_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gf_smp_backward": (_i, [_vp, _vp, _vp, _i]),
     "gf_ctx_set_timing_filter": (_i, [_vp, C.c_char_p]),

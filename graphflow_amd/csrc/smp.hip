@@ -627,6 +627,11 @@ gf_status gf_smp_load_model(gf_smp *s, float *params, const char *path) {
 }
 
 gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *adj, const double *feature) {
+    return gf_smp_prepare_coulomb(s, nMol, nVertices, adj, feature, nullptr);
+}
+
+gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, const int *adj, const double *feature,
+                                 const double *coulomb) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     gf_ctx *ctx = s->ctx;
     if (nMol <= 0 || !nVertices || !adj || !feature) return fail(ctx, GF_ERR_INVALID, "gf_smp_prepare: bad argument");
@@ -637,7 +642,7 @@ gf_status gf_smp_prepare(gf_smp *s, int nMol, const int *nVertices, const int *a
     const auto tp0 = std::chrono::steady_clock::now();
     gf::release(s);
     const auto tp1 = std::chrono::steady_clock::now();
-    gfsmp::build_batch(s->cfg, nMol, nVertices, adj, feature, &s->lay);
+    gfsmp::build_batch(s->cfg, nMol, nVertices, adj, feature, coulomb, &s->lay);
     const auto tp2 = std::chrono::steady_clock::now();
     const gfsmp::BatchLayout &B = s->lay;
     const int L = s->cfg.nLevels, C = s->cfg.nChanels;

@@ -142,7 +142,7 @@ void prepare_molecule(const Config &cfg, int V, const int *adj, const double *fe
 }
 
 void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *adj, const double *feature,
-                 BatchLayout *out) {
+                 const double *coulomb, BatchLayout *out) {
     const int L = cfg.nLevels, FD = cfg.fdim(), F = cfg.nFeatures;
     const std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
     out->nMol = nMol;
@@ -235,11 +235,13 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
             const int V = nVertices[m], v0 = out->mol_first_vertex[m];
             const int *madj = adj + adj_off[m];
             const std::vector<int> &field = out->mols[m].phi[l][v];
-            // reduced adjacency (:556-581, adjacency mode): 1 on the diagonal, adj[v1][v2] elsewhere
+            // reduced adjacency (:556-581): 1 on the diagonal and adj[v1][v2] elsewhere, or the Coulomb entries
+            const double *mcoul = coulomb ? coulomb + adj_off[m] : nullptr;
             for (int i = 0; i < s; ++i)
                 for (int j = 0; j < s; ++j)
                     lv.adj[(size_t)lv.node_row[n] + (size_t)i * s + j] =
-                        (field[i] == field[j]) ? 1.f : (float)madj[field[i] * V + field[j]];
+                        mcoul ? (float)mcoul[field[i] * V + field[j]]
+                              : ((field[i] == field[j]) ? 1.f : (float)madj[field[i] * V + field[j]]);
             for (int i = 0; i < s; ++i) {  // gated row sums (RisiContraction_18.h:90: entries with A <= 0 are skipped)
                 float rs = 0.f;
                 for (int j = 0; j < s; ++j) {

@@ -74,8 +74,10 @@ struct BatchLayout {
     std::vector<Molecule> mols;         // kept for introspection (receptive fields)
 };
 
+// coulomb: NULL, or the molecules' V x V Coulomb matrices back to back (DenseGraph::coulomb) -- the reduced adjacency of
+// the use_coulomb constructors (SMP_omega.h:568-579) is then coulomb[v1][v2], diagonal included.
 void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *adj, const double *feature,
-                 BatchLayout *out);
+                 const double *coulomb, BatchLayout *out);
 
 }  // namespace gfsmp
 #endif

@@ -2,7 +2,7 @@
 // (GraphFlow/SMP_omega.h:29-1246) on top of the batched device driver of the C ABI (gf_smp_*, include/gf_hip.h).
 //
 //   reference                                              here
-//   SMP_omega(max_nVertices, max_receptive_field,          same arguments; the constructor draws the initial weights from
+//   SMP_omega([use_coulomb,] max_nVertices, max_rf,        same arguments; the constructor draws the initial weights from
 //             nLevels, nChanels, nFeatures, nDepth[, wl])  rand() exactly as weights_initialization does (:334-338)
 //   BatchLearn(nBatch, DenseGraph**, target, lr)  :798     one device pass over the whole batch (loss before, summed
 //                                                          gradients, Adam::Learn(lr, nBatch), loss after)
@@ -30,15 +30,28 @@ public:
     SMP_omega_hip(int max_nVertices, int max_receptive_field, int nLevels, int nChanels, int nFeatures, int nDepth,
                   bool has_WL_ordering = true)
         : max_nVertices(max_nVertices), max_receptive_field(max_receptive_field), nLevels(nLevels), nChanels(nChanels),
-          nFeatures(nFeatures), nDepth(nDepth), net(NULL) {
+          nFeatures(nFeatures), nDepth(nDepth), use_coulomb(false), net(NULL) {
+        init(has_WL_ordering);
+    }
+    // the use_coulomb constructors (SMP_omega.h:71-113): reduced adjacencies from molecule->coulomb
+    SMP_omega_hip(bool use_coulomb, int max_nVertices, int max_receptive_field, int nLevels, int nChanels, int nFeatures,
+                  int nDepth, bool has_WL_ordering = true)
+        : max_nVertices(max_nVertices), max_receptive_field(max_receptive_field), nLevels(nLevels), nChanels(nChanels),
+          nFeatures(nFeatures), nDepth(nDepth), use_coulomb(use_coulomb), net(NULL) {
+        init(has_WL_ordering);
+    }
+    ~SMP_omega_hip() { gf_smp_destroy(net); }
+
+private:
+    void init(bool has_WL_ordering) {
         gf_smp_config cfg = {nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering ? 1 : 0};
         must(gf_smp_create(gfhost::default_context(), &cfg, &net), "gf_smp_create");
         std::vector<float> w(gf_smp_param_count(net));
         must(gf_smp_uniform_init_host(&cfg, &w[0]), "gf_smp_uniform_init_host");  // weights_initialization()
         must(gf_smp_parameters_upload(net, &w[0]), "gf_smp_parameters_upload");
     }
-    ~SMP_omega_hip() { gf_smp_destroy(net); }
 
+public:
     void init_multi_threads(int) {}
 
     template <class Graph>
@@ -108,14 +121,22 @@ public:
     void set_parameters(const std::vector<float> &p) { must(gf_smp_parameters_upload(net, &p[0]), "gf_smp_parameters_upload"); }
 
     int max_nVertices, max_receptive_field, nLevels, nChanels, nFeatures, nDepth;
+    bool use_coulomb;
 
 private:
+    // molecule->coulomb when the molecule type has one (DenseGraph does), NULL otherwise
+    template <class Graph>
+    static auto coulomb_of(const Graph *g, int) -> decltype(&g->coulomb[0][0], (double **)0) { return g->coulomb; }
+    template <class Graph>
+    static double **coulomb_of(const Graph *, long) { return NULL; }
+
     // DenseGraph** -> the flat batch of gf_smp_prepare (host graph preparation + index upload)
     template <class Graph>
     void bind(int nBatch, Graph **molecule) {
         nV.resize(nBatch);
         adj.clear();
         feature.clear();
+        coulomb.clear();
         for (int m = 0; m < nBatch; ++m) {
             const Graph *g = molecule[m];
             if (g->nVertices > max_nVertices || g->nFeatures != nFeatures) {
@@ -128,8 +149,17 @@ private:
                 adj.insert(adj.end(), g->adj[i], g->adj[i] + g->nVertices);
                 feature.insert(feature.end(), g->feature[i], g->feature[i] + nFeatures);
             }
+            if (use_coulomb) {
+                double **cm = coulomb_of(g, 0);
+                if (!cm) {
+                    std::fprintf(stderr, "SMP_omega_hip: use_coulomb needs a molecule type with a `coulomb` matrix\n");
+                    std::abort();
+                }
+                for (int i = 0; i < g->nVertices; ++i) coulomb.insert(coulomb.end(), cm[i], cm[i] + g->nVertices);
+            }
         }
-        must(gf_smp_prepare(net, nBatch, &nV[0], &adj[0], &feature[0]), "gf_smp_prepare");
+        must(gf_smp_prepare_coulomb(net, nBatch, &nV[0], &adj[0], &feature[0], use_coulomb ? &coulomb[0] : NULL),
+             "gf_smp_prepare");
     }
     void step(double learning_rate, int nBatch) {
         must(gf_smp_backward(net, NULL, NULL, 0), "gf_smp_backward");
@@ -140,7 +170,7 @@ private:
     }
     gf_smp *net;
     std::vector<int> nV, adj;
-    std::vector<double> feature;
+    std::vector<double> feature, coulomb;
 };
 
 #endif

@@ -28,14 +28,20 @@ class SMPOmega:
         self.n_params = self.lib.gf_smp_param_count(h)
         self.n_mol = 0
 
-    def prepare(self, molecules):
-        """molecules: list of (adj int[V,V], feature float[V,F]).  Host graph preparation + upload (blocking)."""
-        nV = np.array([len(a) for a, _ in molecules], dtype=np.int32)
-        adj = np.concatenate([np.ascontiguousarray(a, dtype=np.int32).ravel() for a, _ in molecules])
-        feat = np.concatenate([np.ascontiguousarray(f, dtype=np.float64).ravel() for _, f in molecules])
-        self.ctx.check(self.lib.gf_smp_prepare(self.handle, len(molecules), nV.ctypes.data_as(C.POINTER(C.c_int)),
-                                               adj.ctypes.data_as(C.POINTER(C.c_int)),
-                                               feat.ctypes.data_as(C.POINTER(C.c_double))))
+    def prepare(self, molecules, coulomb=None):
+        """molecules: list of (adj int[V,V], feature float[V,F]); coulomb: optional list of float[V,V] Coulomb matrices
+        (the use_coulomb variant of SMP_omega).  Host graph preparation + upload (blocking)."""
+        nV = np.array([len(m[0]) for m in molecules], dtype=np.int32)
+        adj = np.concatenate([np.ascontiguousarray(m[0], dtype=np.int32).ravel() for m in molecules])
+        feat = np.concatenate([np.ascontiguousarray(m[1], dtype=np.float64).ravel() for m in molecules])
+        cm = None
+        if coulomb is not None:
+            cm = np.concatenate([np.ascontiguousarray(c, dtype=np.float64).ravel() for c in coulomb])
+            assert cm.size == adj.size
+        self.ctx.check(self.lib.gf_smp_prepare_coulomb(self.handle, len(molecules), nV.ctypes.data_as(C.POINTER(C.c_int)),
+                                                       adj.ctypes.data_as(C.POINTER(C.c_int)),
+                                                       feat.ctypes.data_as(C.POINTER(C.c_double)),
+                                                       cm.ctypes.data_as(C.POINTER(C.c_double)) if cm is not None else None))
         self.n_mol = len(molecules)
         dev = self.ctx.device
         self.predict = torch.empty(self.n_mol, dtype=torch.float32, device=dev)

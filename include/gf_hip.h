@@ -189,6 +189,11 @@ size_t    gf_smp_param_count(const gf_smp *smp);
 /* Host pointers: nVertices[nMol]; adj = the molecules' V x V int adjacency matrices back to back (DenseGraph::adj);
  * feature = their V x nFeatures matrices back to back (DenseGraph::feature).  Blocking (uploads index tables). */
 gf_status gf_smp_prepare(gf_smp *smp, int nMol, const int *nVertices, const int *adj, const double *feature);
+/* The use_coulomb constructors of SMP_omega (SMP_omega.h:71-113): the reduced adjacency of every receptive field is taken
+ * from the molecules' V x V Coulomb matrices (DenseGraph::coulomb, back to back; :568-579) instead of 1 / adj.  The
+ * bonds in `adj` still define hops, features and fields.  coulomb == NULL is gf_smp_prepare. */
+gf_status gf_smp_prepare_coulomb(gf_smp *smp, int nMol, const int *nVertices, const int *adj, const double *feature,
+                                 const double *coulomb);
 /* Device pointers.  targets may be NULL (Predict / Feature); predict, loss [nMol] and graph_feature [nMol][C] are
  * optional outputs (graph_feature is what SMP_omega::Feature returns, :984-996). */
 gf_status gf_smp_forward(gf_smp *smp, const float *params, const float *targets, float *predict, float *loss,

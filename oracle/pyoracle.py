@@ -322,7 +322,7 @@ def reference_save_model(path, params, nLevels, nChanels, nFeatures, nDepth, cap
     return path
 
 
-def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, max_nVertices=None):
+def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, max_nVertices=None, coulomb=None):
     """Run the REAL reference SMP_omega on one molecule with the given (dumped) parameters.  None if _ref is absent."""
     ref = reference()
     if ref is None:
@@ -341,9 +341,11 @@ def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, h
     radj = np.zeros((L + 1, V, cap * cap))
     f = ref.lib.ref_smp_omega_run
     ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
-    f.argtypes = [_i] * 8 + [ip, _dp, C_double, _dp, _dp, _dp, _dp, _dp, ip, _dp]
+    f.argtypes = [_i] * 8 + [ip, _dp, C_double, _dp, _dp, _dp, _dp, _dp, ip, _dp, ctypes_vp]
     f.restype = _i
-    n = f(maxV, cap, L, C, F, nDepth, 1 if has_wl else 0, V, adj, feature, float(target), params, gfeat, pred, loss, grads, phi, radj)
+    cm = None if coulomb is None else np.ascontiguousarray(coulomb, dtype=np.float64)
+    n = f(maxV, cap, L, C, F, nDepth, 1 if has_wl else 0, V, adj, feature, float(target), params, gfeat, pred, loss, grads, phi, radj,
+          None if cm is None else cm.ctypes.data)
     assert n == params.size, (n, params.size)
     fields = [[list(phi[l, v, 1:1 + phi[l, v, 0]]) for v in range(V)] for l in range(L + 1)]
     red = [[None] * V for _ in range(L + 1)]
@@ -356,6 +358,7 @@ def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, h
 
 
 C_double = C.c_double
+ctypes_vp = C.c_void_p
 
 
 def time_reference_smp_omega(molecules, targets, nLevels, nChanels, nDepth, cap):

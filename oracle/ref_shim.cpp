@@ -304,16 +304,20 @@ extern "C" int ref_smp_omega_run(int max_nVertices, int max_rf, int nLevels, int
                                  int has_WL, int V, const int *adj, const double *feature, double target,
                                  const double *params, double *graph_feature, double *predict, double *loss,
                                  double *grads, int *phi /* [L+1][V][max_rf+1], slot 0 = size */,
-                                 double *reduced_adj /* [L+1][V][max_rf*max_rf] */) {
+                                 double *reduced_adj /* [L+1][V][max_rf*max_rf] */,
+                                 const double *coulomb /* NULL, or V x V: the use_coulomb constructor (:91-113) */) {
     // heap-allocated and intentionally leaked: ~SMP_omega / ~DenseGraph free memory the executor's destructor also
     // frees (SURVEY.md 8b "Ownership"), which is fatal in a long-lived process
-    SMP_omega &net = *new SMP_omega(max_nVertices, max_rf, nLevels, nChanels, nFeatures, nDepth, has_WL != 0);
+    SMP_omega &net = coulomb ? *new SMP_omega(true, max_nVertices, max_rf, nLevels, nChanels, nFeatures, nDepth, has_WL != 0)
+                             : *new SMP_omega(max_nVertices, max_rf, nLevels, nChanels, nFeatures, nDepth, has_WL != 0);
     size_t off = 0;
     for (size_t i = 0; i < net.sgd->params.size(); ++i)
         for (int j = 0; j < net.sgd->params[i]->size; ++j) net.sgd->params[i]->value[j] = params[off++];
     DenseGraph &g = *new DenseGraph(V, nFeatures);
     for (int i = 0; i < V; ++i) {
         for (int j = 0; j < V; ++j) g.adj[i][j] = adj[i * V + j];
+        if (coulomb)
+            for (int j = 0; j < V; ++j) g.coulomb[i][j] = coulomb[i * V + j];
         for (int f = 0; f < nFeatures; ++f) g.feature[i][f] = feature[i * nFeatures + f];
     }
     net.complete_computation_graph(&g);

@@ -122,7 +122,7 @@ def split_params(params, C, FD, L):
     return H, K, b, W
 
 
-def run(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, want_grads=True):
+def run(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, want_grads=True, coulomb=None):
     """One molecule through SMP_omega::complete_computation_graph + forward (+ backward).
     Returns dict(phi, reduced_adj, graph_feature, predict, loss, grads)."""
     orc = pyoracle.oracle()
@@ -152,7 +152,10 @@ def run(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, want
             fld = phi[l][v]
             s = len(fld)
             # reduced adjacency (:556-581, adjacency mode)
-            A = np.array([[1.0 if fld[i] == fld[j] else float(adj[fld[i]][fld[j]]) for j in range(s)] for i in range(s)])
+            if coulomb is None:
+                A = np.array([[1.0 if fld[i] == fld[j] else float(adj[fld[i]][fld[j]]) for j in range(s)] for i in range(s)])
+            else:   # use_coulomb (:568-579): the Coulomb entries, diagonal included
+                A = np.array([[float(coulomb[fld[i]][fld[j]]) for j in range(s)] for i in range(s)])
             Ared[l][v] = A
             P = np.zeros((s, s, s, C))
             for a, w in enumerate(fld):

@@ -162,12 +162,31 @@ def smp_cases():
     return cases
 
 
+def coulomb_case():
+    """The use_coulomb constructor (SMP_omega.h:91-113): reduced adjacency = entries of a V x V 'Coulomb' matrix.  The
+    synthetic matrix is symmetric with a positive diagonal and some NEGATIVE / zero off-diagonal entries, so the `A > 0`
+    gate of RisiContraction_18 matters end to end."""
+    adj, feat, tgt = synthetic_molecule(21, 11)
+    rng = np.random.default_rng(2121)
+    V = len(adj)
+    M = rng.uniform(-0.5, 2.0, (V, V))
+    M = f32exact(0.5 * (M + M.T))
+    M[rng.uniform(0, 1, (V, V)) < 0.15] = 0.0
+    M = np.minimum(M, M.T)
+    np.fill_diagonal(M, f32exact(rng.uniform(1.0, 3.0, V)))
+    return ("syn11_coulomb", adj, feat, tgt, (2, 4, 2, 8, 1, 11)), M
+
+
 def smp_fixtures():
     out = {}
-    for i, (tag, adj, feat, tgt, (L, C, D, cap, wl, maxV)) in enumerate(smp_cases()):
+    ccase, cmat = coulomb_case()
+    for i, (tag, adj, feat, tgt, (L, C, D, cap, wl, maxV)) in enumerate(smp_cases() + [ccase]):
         F = feat.shape[1]
         params = smp_params(C, F, D, L, 100 + i)
-        r = pyoracle.reference_smp_omega(adj, feat, tgt, params, L, C, D, cap, has_wl=bool(wl), max_nVertices=maxV)
+        coul = cmat if tag == ccase[0] else None
+        r = pyoracle.reference_smp_omega(adj, feat, tgt, params, L, C, D, cap, has_wl=bool(wl), max_nVertices=maxV, coulomb=coul)
+        if coul is not None:
+            out["smp_" + tag + "__coulomb"] = coul
         V = len(adj)
         phi = np.full((L + 1, V, cap + 1), -1, dtype=np.int32)
         for l in range(L + 1):

@@ -21,10 +21,11 @@ def fields_of(phi):
 def test_oracle_matches_reference_goldens(golden):
     from oracle import smp_oracle
     cs = cases(golden)
-    assert len(cs) >= 8
+    assert len(cs) >= 9 and any("coulomb" in c for c in cs.values())
     for tag, c in cs.items():
         L, Cn, D, cap, wl = (int(x) for x in c["cfg"])
-        o = smp_oracle.run(c["adj"], c["feature"], float(c["target"][0]), c["params"].astype(np.float64), L, Cn, D, cap, bool(wl))
+        o = smp_oracle.run(c["adj"], c["feature"], float(c["target"][0]), c["params"].astype(np.float64), L, Cn, D, cap, bool(wl),
+                           coulomb=c.get("coulomb"))
         assert [[list(map(int, f)) for f in lv] for lv in o["phi"]] == fields_of(c["phi"]), tag
         assert abs(o["predict"] - c["predict"][0]) <= 1e-10 * max(1, abs(c["predict"][0])), tag
         assert abs(o["loss"] - c["loss"][0]) <= 1e-10 * max(1, abs(c["loss"][0])), tag

@@ -17,11 +17,11 @@ def dev(x, dtype=np.float32):
     return torch.as_tensor(np.ascontiguousarray(x, dtype=dtype)).cuda()
 
 
-def run_batch(gf, mols, targets, params, L, C, F, D, cap, wl=True, fused=True):
+def run_batch(gf, mols, targets, params, L, C, F, D, cap, wl=True, fused=True, coulomb=None):
     from graphflow_amd.smp import SMPOmega
     net = SMPOmega(L, C, F, D, cap, wl)
     net.set_fused(fused)
-    net.prepare(mols)
+    net.prepare(mols, coulomb=coulomb)
     p = dev(params)
     pred, loss, feat = net.forward(p, dev(targets))
     grads = torch.empty(net.n_params, device="cuda")
@@ -37,7 +37,8 @@ def test_reference_goldens_one_molecule_at_a_time(gf, golden, fused):
     for tag, c in cs.items():
         L, C, D, cap, wl = (int(x) for x in c["cfg"])
         F = c["feature"].shape[1]
-        pred, loss, feat, grads, net = run_batch(gf, [(c["adj"], c["feature"])], c["target"], c["params"], L, C, F, D, cap, bool(wl), fused=fused)
+        pred, loss, feat, grads, net = run_batch(gf, [(c["adj"], c["feature"])], c["target"], c["params"], L, C, F, D, cap, bool(wl), fused=fused,
+                                                 coulomb=[c["coulomb"]] if "coulomb" in c else None)
         V = len(c["adj"])
         for l in range(L + 1):
             for v in range(V):
