@@ -1,4 +1,4 @@
-// SMP_omega_hip.h -- drop-in for the public training / inference API of the reference's SMP_omega model class
+// SMP_omega_hip.h -- drop-in for the public training / inference API of the reference's SMP_omega / SMP_beta model classes
 // (GraphFlow/SMP_omega.h:29-1246) on top of the batched device driver of the C ABI (gf_smp_*, include/gf_hip.h).
 //
 //   reference                                              here
@@ -171,6 +171,17 @@ private:
     gf_smp *net;
     std::vector<int> nV, adj;
     std::vector<double> feature, coulomb;
+};
+
+// SMP_beta (GraphFlow/SMP_beta.h:29-1190): the same model without the receptive-field cap -- the constructors drop the
+// max_receptive_field argument (:31, :48, :65, :82); everything else is inherited.
+class SMP_beta_hip : public SMP_omega_hip {
+public:
+    SMP_beta_hip(int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth, bool has_WL_ordering = true)
+        : SMP_omega_hip(max_nVertices, max_nVertices, nLevels, nChanels, nFeatures, nDepth, has_WL_ordering) {}
+    SMP_beta_hip(bool use_coulomb, int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth,
+                 bool has_WL_ordering = true)
+        : SMP_omega_hip(use_coulomb, max_nVertices, max_nVertices, nLevels, nChanels, nFeatures, nDepth, has_WL_ordering) {}
 };
 
 #endif

@@ -280,6 +280,26 @@ def time_r18_fwd_bwd(P, A, G, prefer_reference=True):
     return time.perf_counter() - t0, "port", out, dP
 
 
+def reference_smp_beta(adj, feature, target, params, nLevels, nChanels, nDepth, has_wl=True, max_nVertices=None):
+    """The REAL SMP_beta (no receptive-field cap) on one molecule with dumped parameters."""
+    ref = reference()
+    if ref is None:
+        return None
+    adj = np.ascontiguousarray(adj, dtype=np.int32)
+    feature = np.ascontiguousarray(feature, dtype=np.float64)
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    V, F = feature.shape
+    gfeat, pred, loss, grads = np.zeros(nChanels), np.zeros(1), np.zeros(1), np.zeros_like(params)
+    f = ref.lib.ref_smp_beta_run
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f.argtypes = [_i] * 7 + [ip, _dp, C_double, _dp, _dp, _dp, _dp, _dp]
+    f.restype = _i
+    n = f(max_nVertices or V, nLevels, nChanels, F, nDepth, 1 if has_wl else 0, V, adj, feature, float(target), params, gfeat,
+          pred, loss, grads)
+    assert n == params.size
+    return {"graph_feature": gfeat, "predict": float(pred[0]), "loss": float(loss[0]), "grads": grads}
+
+
 def reference_batchlearn(mols, targets, nLevels, nChanels, nDepth, cap, max_nVertices, nIter, learning_rate, params=None, seed=-1):
     """nIter x the REAL SMP_omega::BatchLearn(nBatch, molecules, targets, learning_rate).  params given, or drawn by the
     reference's own constructor after srand(seed).  Returns dict(params0, params, losses[nIter, 2])."""

@@ -344,6 +344,33 @@ extern "C" int ref_smp_omega_run(int max_nVertices, int max_rf, int nLevels, int
     return (int)off;
 }
 
+// SMP_beta (GraphFlow/SMP_beta.h): the same model without the receptive-field cap.  One molecule, dumped parameters.
+#include "SMP_beta.h"
+extern "C" int ref_smp_beta_run(int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth, int has_WL, int V,
+                                const int *adj, const double *feature, double target, const double *params,
+                                double *graph_feature, double *predict, double *loss, double *grads) {
+    SMP_beta &net = *new SMP_beta(max_nVertices, nLevels, nChanels, nFeatures, nDepth, has_WL != 0);
+    size_t off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) net.sgd->params[i]->value[j] = params[off++];
+    DenseGraph &g = *new DenseGraph(V, nFeatures);
+    for (int i = 0; i < V; ++i) {
+        for (int j = 0; j < V; ++j) g.adj[i][j] = adj[i * V + j];
+        for (int f = 0; f < nFeatures; ++f) g.feature[i][f] = feature[i * nFeatures + f];
+    }
+    net.complete_computation_graph(&g);
+    net.target->value[0] = target;
+    net.graph->forward();
+    net.graph->backward();
+    for (int f = 0; f < nChanels; ++f) graph_feature[f] = net.graph_feature->value[f];
+    *predict = net.predict->value[0];
+    *loss = net.sql->getLoss();
+    off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) grads[off++] = net.sgd->params[i]->gradient[j];
+    return (int)off;
+}
+
 // Text checkpoint written by the reference's own SMP_omega::save_model (SMP_omega.h:1033-1042) for given parameters.
 extern "C" int ref_smp_omega_save_model(int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int nDepth,
                                         const double *params, const char *path) {

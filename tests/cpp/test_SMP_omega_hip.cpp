@@ -76,6 +76,12 @@ int main() {
     SMP_omega_hip other(10, 4, 2, 10, 4, 5);
     other.load_model(path);
     bad |= close_to("loaded model predicts alike", other.Predict(mol[3]), y[3], 1e-5);  // 6 printed digits
+    // SMP_beta = SMP_omega without the cap: same seed, same weights, same predictions as SMP_omega with cap = max_nVertices
+    srand(5);
+    SMP_beta_hip beta(10, 2, 10, 4, 5);
+    srand(5);
+    SMP_omega_hip uncapped(10, 10, 2, 10, 4, 5);
+    for (int i = 0; i < 4; ++i) bad |= close_to("SMP_beta_hip == uncapped SMP_omega_hip", beta.Predict(mol[i]), uncapped.Predict(mol[i]), 0.0);
     // "does it learn", the body of the reference's tests/test_SMP_omega.cpp:166-202: 1024 epochs of BatchLearn at 1e-3,
     // then save_model -> load_model into a second network -> the same predictions (the fp64 reference ends within 5e-5
     // of the targets; the fp32 device path is held to 1e-2)

@@ -199,6 +199,25 @@ def smp_fixtures():
         out[p + "__params"] = params.astype(np.float32)
         out[p + "__phi"], out[p + "__graph_feature"] = phi, r["graph_feature"]
         out[p + "__predict"], out[p + "__loss"], out[p + "__grads"] = np.array([r["predict"]]), np.array([r["loss"]]), r["grads"]
+    # SMP_beta (GraphFlow/SMP_beta.h) = the model without the receptive-field cap: outputs from the real SMP_beta, fields from
+    # SMP_omega run with the cap at max_nVertices (SMP_beta does not expose a different construction of them)
+    adj, feat, tgt = synthetic_molecule(31, 13)
+    L, C, D = 3, 4, 2
+    params = smp_params(C, feat.shape[1], D, L, 131)
+    rb = pyoracle.reference_smp_beta(adj, feat, tgt, params, L, C, D, True, 13)
+    ro = pyoracle.reference_smp_omega(adj, feat, tgt, params, L, C, D, 13, has_wl=True, max_nVertices=13)
+    V = len(adj)
+    phi = np.full((L + 1, V, 14), -1, dtype=np.int32)
+    for l in range(L + 1):
+        for v in range(V):
+            phi[l, v, 0] = len(ro["phi"][l][v])
+            phi[l, v, 1:1 + len(ro["phi"][l][v])] = ro["phi"][l][v]
+    p = "smp_beta_syn13"
+    out[p + "__adj"], out[p + "__feature"], out[p + "__target"] = adj.astype(np.int32), feat, np.array([tgt])
+    out[p + "__cfg"] = np.array([L, C, D, 13, 1], dtype=np.int32)
+    out[p + "__params"] = params.astype(np.float32)
+    out[p + "__phi"], out[p + "__graph_feature"] = phi, rb["graph_feature"]
+    out[p + "__predict"], out[p + "__loss"], out[p + "__grads"] = np.array([rb["predict"]]), np.array([rb["loss"]]), rb["grads"]
     return out
 
 
