@@ -26,7 +26,6 @@ namespace {
 using namespace dev;
 
 constexpr float kAlpha = 0.01f;  // LeakyReLU3D.h:41, LeakyReLU.h default
-constexpr int kK = 18;
 
 #define GRID_STRIDE(idx, total) \
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < (total); idx += (size_t)gridDim.x * blockDim.x)
@@ -376,7 +375,7 @@ struct ParamView {
     std::vector<const float *> K, b;
 };
 size_t param_count(const gfsmp::Config &c) {
-    return (size_t)c.nChanels * c.fdim() + (size_t)c.nLevels * ((size_t)kK * c.nChanels * c.nChanels + c.nChanels) + c.nChanels;
+    return (size_t)c.nChanels * c.fdim() + (size_t)c.nLevels * ((size_t)c.nContractions * c.nChanels * c.nChanels + c.nChanels) + c.nChanels;
 }
 // order H, (K_1, b_1), ..., (K_L, b_L), W -- the registration order of SMP_omega.h:289-295 (= save_model order)
 template <typename P>
@@ -388,7 +387,7 @@ void view_params(const gfsmp::Config &c, P *base, P **H, std::vector<P *> *K, st
     b->assign(c.nLevels + 1, nullptr);
     for (int l = 1; l <= c.nLevels; ++l) {
         (*K)[l] = p;
-        p += (size_t)kK * c.nChanels * c.nChanels;
+        p += (size_t)c.nContractions * c.nChanels * c.nChanels;
         (*b)[l] = p;
         p += c.nChanels;
     }
@@ -402,10 +401,11 @@ gf_status smp_contract(gf_smp *s, int l, bool backward) {
     gf_ctx *ctx = s->ctx;
     const gfsmp::LevelLayout &h = s->lay.level[l];
     const gf_smp::DevLevel &d = s->lv[l];
-    const int C = s->cfg.nChanels;
+    const int C = s->cfg.nChanels, nK = s->cfg.nContractions;
     const int ppw = (C <= 16) ? 16 : (C <= 32) ? 8 : 4;
     const gf_ragged_nodes t = {d.pair_node, d.node_s, d.node_p, d.node_row, d.node_pair, (long long)h.rows, (long long)h.pairs};
-    const bool ragged_ok = r18_ragged_supported(ppw, C, s->P, d.Q);
+    // (_10 / _50 of the SMP_2D_ver6 / ver7 wirings: one uniform launch per size bucket)
+    const bool ragged_ok = nK == 18 && r18_ragged_supported(ppw, C, s->P, d.Q);
     size_t k = 0;
     gf_status st = GF_OK;
     for (int cls = 1; cls <= 8 && ragged_ok && k < h.buckets.size(); cls *= 2) {
@@ -422,9 +422,9 @@ gf_status smp_contract(gf_smp *s, int l, bool backward) {
     }
     for (; k < h.buckets.size(); ++k) {  // sizes beyond the slab kernels (or unaligned C): uniform launches
         const gfsmp::Bucket &bk = h.buckets[k];
-        float *Pb = s->P + bk.first_p * C, *Qb = d.Q + bk.first_row * (long long)(kK * C);
-        st = backward ? gf_contract_backward_f32(ctx, 18, Qb, d.adj + bk.first_row, Pb, bk.s, C, bk.count, 0)
-                      : gf_contract_forward_f32(ctx, 18, Pb, d.adj + bk.first_row, Qb, bk.s, C, bk.count);
+        float *Pb = s->P + bk.first_p * C, *Qb = d.Q + bk.first_row * (long long)(nK * C);
+        st = backward ? gf_contract_backward_f32(ctx, nK, Qb, d.adj + bk.first_row, Pb, bk.s, C, bk.count, 0)
+                      : gf_contract_forward_f32(ctx, nK, Pb, d.adj + bk.first_row, Qb, bk.s, C, bk.count);
         if (st != GF_OK) return st;
     }
     return GF_OK;
@@ -450,6 +450,13 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
     s->cfg.nDepth = cfg->nDepth;
     s->cfg.max_receptive_field = cfg->max_receptive_field;
     s->cfg.has_WL_ordering = cfg->has_WL_ordering;
+    s->cfg.nContractions = cfg->nContractions ? cfg->nContractions : 18;
+    s->cfg.custom_matmul = cfg->custom_matmul ? 1 : 0;
+    if (s->cfg.nContractions != 10 && s->cfg.nContractions != 18 && s->cfg.nContractions != 50) {
+        const int bad = cfg->nContractions;
+        delete s;
+        return fail(ctx, GF_ERR_INVALID, "gf_smp_create: nContractions = %d (expected 10, 18 or 50)", bad);
+    }
     *out = s;
     return GF_OK;
 }
@@ -567,11 +574,12 @@ gf_status gf_smp_adam_reset(gf_smp *s) {
 gf_status gf_smp_uniform_init_host(const gf_smp_config *cfg, float *params) {
     if (!cfg || !params) return GF_ERR_INVALID;
     gfsmp::Config c = {cfg->nLevels, cfg->nChanels, cfg->nFeatures, cfg->nDepth, cfg->max_receptive_field, cfg->has_WL_ordering};
+    c.nContractions = cfg->nContractions ? cfg->nContractions : 18;
     const size_t C = (size_t)c.nChanels;
     std::vector<size_t> sizes;
     sizes.push_back(C * c.fdim());
     for (int l = 1; l <= c.nLevels; ++l) {
-        sizes.push_back((size_t)gf::kK * C * C);
+        sizes.push_back((size_t)c.nContractions * C * C);
         sizes.push_back(C);
     }
     sizes.push_back(C);
@@ -687,7 +695,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (st != GF_OK) return st;
         UP(d.pi, h.pi);
         UP(d.inv, h.inv);
-        st = gf::upload(s, &d.Q, nullptr, (size_t)h.rows * gf::kK * C);
+        st = gf::upload(s, &d.Q, nullptr, (size_t)h.rows * std::max(18, s->cfg.nContractions) * C);
         if (st != GF_OK) return st;
         {
             float **bufs[] = {&d.Vt, &d.dVt, &d.St, &d.dSt, &d.scal, &d.Vout, &d.dVout, &d.Sout, &d.dSout, &d.dSpart, &d.dbpart, &d.Wst, &d.dWst};
@@ -701,7 +709,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         }
         if (h.ppos > maxp) maxp = h.ppos;
         for (size_t b = 0; b < h.buckets.size(); ++b) {
-            const size_t w = gf_contract_workspace_bytes(18, h.buckets[b].s, C, h.buckets[b].count);
+            const size_t w = gf_contract_workspace_bytes(s->cfg.nContractions, h.buckets[b].s, C, h.buckets[b].count);
             if (w > contract_ws) contract_ws = w;
         }
         contract_ws = std::max(contract_ws, gf::r18_ragged_workspace_bytes((long long)h.rows, (long long)h.pairs, C));
@@ -784,8 +792,10 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
                   d.node_s, d.node_row, d.node_p, d.node_pair, d.pair_node, d.pair_src_row, d.pair_src_s, d.pi, C);
         st = gf::smp_contract(s, l, /*backward=*/false);
         if (st != GF_OK) return st;
-        // K-projection over all buckets at once: [rows, 18C] x [18C, C]
-        st = gf::gemm(ctx, false, false, (int)h.rows, C, gf::kK * C, d.Q, gf::kK * C, 0, K[l], C, 0, d.f, C, 0, 1, 0);
+        // K-projection over all buckets at once: [rows, KC] x [KC, C]  (CustomMatMulTensor layout: x K_l^T, K_l = [C, KC])
+        const int KC = s->cfg.nContractions * C;
+        st = s->cfg.custom_matmul ? gf::gemm(ctx, false, true, (int)h.rows, C, KC, d.Q, KC, 0, K[l], KC, 0, d.f, C, 0, 1, 0)
+                                  : gf::gemm(ctx, false, false, (int)h.rows, C, KC, d.Q, KC, 0, K[l], C, 0, d.f, C, 0, 1, 0);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)h.rows * C)), dim3(256), 0, d.f,
                   b[l], C, (size_t)h.rows * C);
@@ -846,9 +856,16 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
                       (long long)h.rows, rpb);
             GF_LAUNCH(ctx, "smp_colsum", gf::colsum_finish, dim3(1), dim3(256), 0, s->colpart, db[l], C, nb);
             // dK_l += Q^T dZ   (MatMul::backward second operand), then dQ = dZ K_l^T overwrites Q (first operand)
-            st = gf::gemm(ctx, true, false, gf::kK * C, C, (int)h.rows, d.Q, gf::kK * C, 0, d.df, C, 0, dK[l], C, 0, 1, 1);
-            if (st != GF_OK) return st;
-            st = gf::gemm(ctx, false, true, (int)h.rows, gf::kK * C, C, d.df, C, 0, K[l], C, 0, d.Q, gf::kK * C, 0, 1, 0);
+            const int KC = s->cfg.nContractions * C;
+            if (s->cfg.custom_matmul) {  // CustomMatMulTensor::backward (CustomMatMulTensor.h:70-85): dK_l [C, KC] += dZ^T Q, dQ = dZ K_l
+                st = gf::gemm(ctx, true, false, C, KC, (int)h.rows, d.df, C, 0, d.Q, KC, 0, dK[l], KC, 0, 1, 1);
+                if (st != GF_OK) return st;
+                st = gf::gemm(ctx, false, false, (int)h.rows, KC, C, d.df, C, 0, K[l], KC, 0, d.Q, KC, 0, 1, 0);
+            } else {
+                st = gf::gemm(ctx, true, false, KC, C, (int)h.rows, d.Q, KC, 0, d.df, C, 0, dK[l], C, 0, 1, 1);
+                if (st != GF_OK) return st;
+                st = gf::gemm(ctx, false, true, (int)h.rows, KC, C, d.df, C, 0, K[l], C, 0, d.Q, KC, 0, 1, 0);
+            }
             if (st != GF_OK) return st;
             st = gf::smp_contract(s, l, /*backward=*/true);
             if (st != GF_OK) return st;

@@ -729,6 +729,7 @@ gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *d
 bool smp_fused_supported(const gf_smp *s, int l) {
     const int C = s->cfg.nChanels;
     if (C % 4 != 0 || C > 1024) return false;
+    if (s->cfg.nContractions != 18 || s->cfg.custom_matmul) return false;  // SMP_2D_ver6-8 wirings: op-by-op levels
     const gfsmp::LevelLayout &h = s->lay.level[l];
     if (h.buckets.empty()) return false;
     return h.buckets.back().s <= 32;  // 8 * PPW at LPC = 16

@@ -16,6 +16,8 @@ namespace gfsmp {
 
 struct Config {
     int nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering;
+    int nContractions = 18;  // contraction family of the levels: 18 (SMP_omega/beta, SMP_2D_ver8), 10 (ver6), 50 (ver7)
+    int custom_matmul = 0;   // 1: K_l is [C][nContractions C] and applied by CustomMatMulTensor (SMP_2D_ver6-8)
     int fdim() const { return nFeatures * (nDepth + 1); }
 };
 

@@ -11,17 +11,21 @@ from .ops import default_context
 
 class SMPConfig(C.Structure):
     _fields_ = [("nLevels", C.c_int), ("nChanels", C.c_int), ("nFeatures", C.c_int), ("nDepth", C.c_int),
-                ("max_receptive_field", C.c_int), ("has_WL_ordering", C.c_int)]
+                ("max_receptive_field", C.c_int), ("has_WL_ordering", C.c_int), ("nContractions", C.c_int),
+                ("custom_matmul", C.c_int)]
 
 
 class SMPOmega:
     """Batched SMP_omega (GraphFlow/SMP_omega.h).  Parameters/gradients are one flat fp32 tensor in the reference's
     registration order: H[C, F(D+1)], (K_l[18C, C], b_l[C]) for l = 1..L, W[C]."""
 
-    def __init__(self, nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering=True, ctx=None):
+    def __init__(self, nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering=True, ctx=None,
+                 nContractions=18, custom_matmul=False):
+        """nContractions / custom_matmul select the SMP_2D_ver6 (10, True) / ver7 (50, True) / ver8 (18, True) wirings."""
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
-        self.cfg = SMPConfig(nLevels, nChanels, nFeatures, nDepth, max_receptive_field, 1 if has_WL_ordering else 0)
+        self.cfg = SMPConfig(nLevels, nChanels, nFeatures, nDepth, max_receptive_field, 1 if has_WL_ordering else 0,
+                             nContractions, 1 if custom_matmul else 0)
         h = C.c_void_p()
         self.ctx.check(self.lib.gf_smp_create(self.ctx.handle, C.byref(self.cfg), C.byref(h)))
         self.handle = h

@@ -182,6 +182,11 @@ gf_status gf_tensormatmul_backward_host_f32(gf_ctx *ctx, const float *G, const f
 typedef struct gf_smp gf_smp;
 typedef struct {
     int nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering;
+    /* The SMP_2D_ver6 / ver7 / ver8 wirings of the same DAG (GraphFlow/SMP_2D_ver6.h:456-560): contraction family
+     * nContractions = 10 / 50 / 18 (0 means 18) and, with custom_matmul = 1, the level weight K_l stored [C][nContractions C]
+     * and applied by CustomMatMulTensor instead of Reshape2D + MatMul on [nContractions C][C].  Zero-initialised trailing
+     * fields give SMP_omega.  Those models have no receptive-field cap: pass max_receptive_field = max_nVertices. */
+    int nContractions, custom_matmul;
 } gf_smp_config;
 gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out);
 gf_status gf_smp_destroy(gf_smp *smp);

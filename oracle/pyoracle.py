@@ -300,6 +300,29 @@ def reference_smp_beta(adj, feature, target, params, nLevels, nChanels, nDepth, 
     return {"graph_feature": gfeat, "predict": float(pred[0]), "loss": float(loss[0]), "grads": grads}
 
 
+def reference_smp_2d(version, adj, feature, target, params, nLevels, nChanels, nDepth, has_wl=True, max_nVertices=None):
+    """The REAL SMP_2D_ver6 / ver7 / ver8 on one molecule with dumped parameters (contraction _10 / _50 / _18)."""
+    ref = reference()
+    if ref is None:
+        return None
+    adj = np.ascontiguousarray(adj, dtype=np.int32)
+    feature = np.ascontiguousarray(feature, dtype=np.float64)
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    V, F = feature.shape
+    maxV = max_nVertices or V
+    gfeat, pred, loss, grads = np.zeros(nChanels), np.zeros(1), np.zeros(1), np.zeros_like(params)
+    phi = np.zeros((nLevels + 1, V, maxV + 1), dtype=np.int32)
+    f = ref.lib.ref_smp_2d_run
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f.argtypes = [_i] * 8 + [ip, _dp, C_double, _dp, _dp, _dp, _dp, _dp, ip, _i]
+    f.restype = _i
+    n = f(version, maxV, nLevels, nChanels, F, nDepth, 1 if has_wl else 0, V, adj, feature, float(target), params, gfeat, pred,
+          loss, grads, phi, maxV + 1)
+    assert n == params.size, (n, params.size)
+    fields = [[list(phi[l, v, 1:1 + phi[l, v, 0]]) for v in range(V)] for l in range(nLevels + 1)]
+    return {"phi": fields, "phi_array": phi, "graph_feature": gfeat, "predict": float(pred[0]), "loss": float(loss[0]), "grads": grads}
+
+
 def reference_batchlearn(mols, targets, nLevels, nChanels, nDepth, cap, max_nVertices, nIter, learning_rate, params=None, seed=-1):
     """nIter x the REAL SMP_omega::BatchLearn(nBatch, molecules, targets, learning_rate).  params given, or drawn by the
     reference's own constructor after srand(seed).  Returns dict(params0, params, losses[nIter, 2])."""

@@ -371,6 +371,63 @@ extern "C" int ref_smp_beta_run(int max_nVertices, int nLevels, int nChanels, in
     return (int)off;
 }
 
+// SMP_2D_ver6 / ver7 / ver8 (RisiContraction_10 / _50 / _18 + CustomMatMulTensor, no receptive-field cap).
+// (every one of these headers defines a global `const int INF`: give each its own name)
+#define INF INF_2d_ver6
+#include "SMP_2D_ver6.h"
+#undef INF
+#define INF INF_2d_ver7
+#include "SMP_2D_ver7.h"
+#undef INF
+#define INF INF_2d_ver8
+#include "SMP_2D_ver8.h"
+#undef INF
+namespace {
+template <class Net>
+int smp2d_run(int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth, int has_WL, int V, const int *adj,
+              const double *feature, double target, const double *params, double *graph_feature, double *predict, double *loss,
+              double *grads, int *phi, int phi_stride) {
+    Net &net = *new Net(max_nVertices, nLevels, nChanels, nFeatures, nDepth, 0.9, has_WL != 0);
+    size_t off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) net.sgd->params[i]->value[j] = params[off++];
+    DenseGraph &g = *new DenseGraph(V, nFeatures);
+    for (int i = 0; i < V; ++i) {
+        for (int j = 0; j < V; ++j) g.adj[i][j] = adj[i * V + j];
+        for (int f = 0; f < nFeatures; ++f) g.feature[i][f] = feature[i * nFeatures + f];
+    }
+    net.complete_computation_graph(&g);
+    net.target->value[0] = target;
+    net.graph->forward();
+    net.graph->backward();
+    for (int f = 0; f < nChanels; ++f) graph_feature[f] = net.graph_feature->value[f];
+    *predict = net.predict->value[0];
+    *loss = net.sql->getLoss();
+    off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) grads[off++] = net.sgd->params[i]->gradient[j];
+    for (int l = 0; l <= nLevels; ++l)
+        for (int v = 0; v < V; ++v) {
+            int *p = phi + ((size_t)l * V + v) * phi_stride;
+            const std::vector<int> &f = net.level[l]->phi[v];
+            p[0] = (int)f.size();
+            for (size_t i = 0; i < f.size(); ++i) p[1 + i] = f[i];
+        }
+    return (int)off;
+}
+}  // namespace
+extern "C" int ref_smp_2d_run(int version, int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth, int has_WL,
+                              int V, const int *adj, const double *feature, double target, const double *params,
+                              double *graph_feature, double *predict, double *loss, double *grads, int *phi, int phi_stride) {
+#define GF_RUN(N) smp2d_run<N>(max_nVertices, nLevels, nChanels, nFeatures, nDepth, has_WL, V, adj, feature, target, params, \
+                               graph_feature, predict, loss, grads, phi, phi_stride)
+    if (version == 6) return GF_RUN(SMP_2D_ver6);
+    if (version == 7) return GF_RUN(SMP_2D_ver7);
+    if (version == 8) return GF_RUN(SMP_2D_ver8);
+#undef GF_RUN
+    return -1;
+}
+
 // Text checkpoint written by the reference's own SMP_omega::save_model (SMP_omega.h:1033-1042) for given parameters.
 extern "C" int ref_smp_omega_save_model(int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int nDepth,
                                         const double *params, const char *path) {

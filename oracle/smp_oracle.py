@@ -105,16 +105,18 @@ def lrelu(z):
     return np.where(z > 0, z, ALPHA * z)
 
 
-def split_params(params, C, FD, L):
-    """Registration order :289-295: H[C,FD], (K_l[18C,C], b_l[C]) for l=1..L, W[C]."""
+def split_params(params, C, FD, L, nK=K18, custom=False):
+    """Registration order :289-295: H[C,FD], (K_l, b_l[C]) for l=1..L, W[C].  K_l is [nK C, C] (SMP_omega: Reshape2D +
+    MatMul) or, with custom=True, [C, nK C] (SMP_2D_ver6-8: CustomMatMulTensor, SMP_2D_ver6.h:130); returned as [nK C, C]."""
     p = np.asarray(params, dtype=np.float64)
     o = 0
     H = p[o:o + C * FD].reshape(C, FD)
     o += C * FD
     K, b = [None], [None]
     for _ in range(L):
-        K.append(p[o:o + K18 * C * C].reshape(K18 * C, C))
-        o += K18 * C * C
+        blk = p[o:o + nK * C * C]
+        K.append(blk.reshape(C, nK * C).T.copy() if custom else blk.reshape(nK * C, C))
+        o += nK * C * C
         b.append(p[o:o + C])
         o += C
     W = p[o:o + C]
@@ -122,8 +124,11 @@ def split_params(params, C, FD, L):
     return H, K, b, W
 
 
-def run(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, want_grads=True, coulomb=None):
+def run(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, want_grads=True, coulomb=None, nK=K18,
+        custom=False):
     """One molecule through SMP_omega::complete_computation_graph + forward (+ backward).
+    nK in {10, 18, 50} selects the contraction family and custom=True the CustomMatMulTensor weight layout: together they
+    are SMP_2D_ver6 (10) / ver7 (50) / ver8 (18) (GraphFlow/SMP_2D_ver6.h:456-560), which have no receptive-field cap.
     Returns dict(phi, reduced_adj, graph_feature, predict, loss, grads)."""
     orc = pyoracle.oracle()
     adj = np.asarray(adj)
@@ -131,7 +136,7 @@ def run(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, want
     V, F = feature.shape
     FD = F * (nDepth + 1)
     L = nLevels
-    H, K, b, W = split_params(params, C, FD, L)
+    H, K, b, W = split_params(params, C, FD, L, nK, custom)
     sp = hop_distances(adj.tolist())
     x = wl_features(feature, sp, nDepth)
     rank = rank_vertices(x.tolist())
@@ -165,8 +170,8 @@ def run(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, want
                 T1 = np.einsum("ik,kjd->ijd", Xm, f[l - 1][w])          # MatTensorMul.h:47-68
                 P[a] = np.einsum("ikd,kj->ijd", T1, Xm.T)               # TensorMatMul.h:46-67
             Pst[l][v] = P
-            Q[l][v] = orc.contract_forward(18, P, A)                    # RisiContraction_18.h:73-331
-            z[l][v] = (Q[l][v].reshape(s * s, K18 * C) @ K[l]).reshape(s, s, C) + b[l]   # :654-666
+            Q[l][v] = orc.contract_forward(nK, P, A)                    # RisiContraction_18.h:73-331 (or _10 / _50)
+            z[l][v] = (Q[l][v].reshape(s * s, nK * C) @ K[l]).reshape(s, s, C) + b[l]   # :654-666
             f[l][v] = lrelu(z[l][v])
     sh = np.stack([f[L][v].sum(axis=(0, 1)) for v in range(V)])         # ShrinkTensor.h:37-50
     vf = lrelu(sh)
@@ -195,10 +200,10 @@ def run(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, want
             dz = df[l][v] * np.where(z[l][v] > 0, 1.0, ALPHA)            # LeakyReLU3D.h:60-68
             db[l] += dz.sum(axis=(0, 1))                                 # VectorAddTensor.h:61-72
             dz2 = dz.reshape(s * s, C)
-            Q2 = Q[l][v].reshape(s * s, K18 * C)
+            Q2 = Q[l][v].reshape(s * s, nK * C)
             dK[l] += Q2.T @ dz2                                          # MatMul.h:69-82
-            dQ = (dz2 @ K[l].T).reshape(s, s, K18, C)
-            dP = orc.contract_backward(18, dQ, Ared[l][v])               # RisiContraction_18.h:333-560
+            dQ = (dz2 @ K[l].T).reshape(s, s, nK, C)
+            dP = orc.contract_backward(nK, dQ, Ared[l][v])               # RisiContraction_18.h:333-560
             for a, w in enumerate(fld):
                 Xm = X[l][v][w]
                 dT1 = np.einsum("ijd,kj->ikd", dP[a], Xm.T)              # TensorMatMul.h:69-84 (first operand)
@@ -208,7 +213,7 @@ def run(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, want
         dH += np.outer(dz0, x[v])                                        # MatMul.h:69-82
     grads = [dH.ravel()]
     for l in range(1, L + 1):
-        grads += [dK[l].ravel(), db[l].ravel()]
+        grads += [(dK[l].T if custom else dK[l]).ravel(), db[l].ravel()]
     grads.append(dW.ravel())
     out["grads"] = np.concatenate(grads)
     return out

@@ -212,6 +212,20 @@ def smp_fixtures():
         for v in range(V):
             phi[l, v, 0] = len(ro["phi"][l][v])
             phi[l, v, 1:1 + len(ro["phi"][l][v])] = ro["phi"][l][v]
+    # SMP_2D_ver6 / ver7 / ver8 (RisiContraction_10 / _50 / _18 + CustomMatMulTensor, K_l = [C][nContractions C])
+    adj2, feat2, tgt2 = synthetic_molecule(41, 9)
+    for ver, nK in ((6, 10), (7, 50), (8, 18)):
+        L2, C2, D2 = 2, 4, 2
+        n = C2 * feat2.shape[1] * (D2 + 1) + L2 * (nK * C2 * C2 + C2) + C2
+        prm = f32exact(np.random.default_rng(600 + ver).uniform(-0.3, 0.3, n))
+        r2 = pyoracle.reference_smp_2d(ver, adj2, feat2, tgt2, prm, L2, C2, D2, True, len(adj2))
+        q = "smp_2dver%d_syn9" % ver
+        out[q + "__adj"], out[q + "__feature"], out[q + "__target"] = adj2.astype(np.int32), feat2, np.array([tgt2])
+        out[q + "__cfg"] = np.array([L2, C2, D2, len(adj2), 1], dtype=np.int32)
+        out[q + "__wiring"] = np.array([nK, 1], dtype=np.int32)
+        out[q + "__params"] = prm.astype(np.float32)
+        out[q + "__phi"], out[q + "__graph_feature"] = r2["phi_array"], r2["graph_feature"]
+        out[q + "__predict"], out[q + "__loss"], out[q + "__grads"] = np.array([r2["predict"]]), np.array([r2["loss"]]), r2["grads"]
     p = "smp_beta_syn13"
     out[p + "__adj"], out[p + "__feature"], out[p + "__target"] = adj.astype(np.int32), feat, np.array([tgt])
     out[p + "__cfg"] = np.array([L, C, D, 13, 1], dtype=np.int32)

@@ -24,8 +24,9 @@ def test_oracle_matches_reference_goldens(golden):
     assert len(cs) >= 9 and any("coulomb" in c for c in cs.values())
     for tag, c in cs.items():
         L, Cn, D, cap, wl = (int(x) for x in c["cfg"])
+        nK, custom = (int(x) for x in c["wiring"]) if "wiring" in c else (18, 0)
         o = smp_oracle.run(c["adj"], c["feature"], float(c["target"][0]), c["params"].astype(np.float64), L, Cn, D, cap, bool(wl),
-                           coulomb=c.get("coulomb"))
+                           coulomb=c.get("coulomb"), nK=nK, custom=bool(custom))
         assert [[list(map(int, f)) for f in lv] for lv in o["phi"]] == fields_of(c["phi"]), tag
         assert abs(o["predict"] - c["predict"][0]) <= 1e-10 * max(1, abs(c["predict"][0])), tag
         assert abs(o["loss"] - c["loss"][0]) <= 1e-10 * max(1, abs(c["loss"][0])), tag

@@ -17,9 +17,9 @@ def dev(x, dtype=np.float32):
     return torch.as_tensor(np.ascontiguousarray(x, dtype=dtype)).cuda()
 
 
-def run_batch(gf, mols, targets, params, L, C, F, D, cap, wl=True, fused=True, coulomb=None):
+def run_batch(gf, mols, targets, params, L, C, F, D, cap, wl=True, fused=True, coulomb=None, wiring=(18, False)):
     from graphflow_amd.smp import SMPOmega
-    net = SMPOmega(L, C, F, D, cap, wl)
+    net = SMPOmega(L, C, F, D, cap, wl, nContractions=wiring[0], custom_matmul=wiring[1])
     net.set_fused(fused)
     net.prepare(mols, coulomb=coulomb)
     p = dev(params)
@@ -38,7 +38,8 @@ def test_reference_goldens_one_molecule_at_a_time(gf, golden, fused):
         L, C, D, cap, wl = (int(x) for x in c["cfg"])
         F = c["feature"].shape[1]
         pred, loss, feat, grads, net = run_batch(gf, [(c["adj"], c["feature"])], c["target"], c["params"], L, C, F, D, cap, bool(wl), fused=fused,
-                                                 coulomb=[c["coulomb"]] if "coulomb" in c else None)
+                                                 coulomb=[c["coulomb"]] if "coulomb" in c else None,
+                                                 wiring=(int(c["wiring"][0]), bool(c["wiring"][1])) if "wiring" in c else (18, False))
         V = len(c["adj"])
         for l in range(L + 1):
             for v in range(V):
