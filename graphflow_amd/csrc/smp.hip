@@ -465,6 +465,12 @@ gf_status gf_smp_destroy(gf_smp *s) {
     if (!s) return GF_OK;
     gf::release(s);
     gf::release_pool(s);
+    if (s->side) {
+        (void)hipStreamSynchronize(s->side);
+        (void)hipStreamDestroy(s->side);
+        (void)hipEventDestroy(s->ev_fork);
+        (void)hipEventDestroy(s->ev_join);
+    }
     if (s->adam_m) (void)hipFree(s->adam_m);
     if (s->adam_v) (void)hipFree(s->adam_v);
     if (s->own_p) (void)hipFree(s->own_p);
@@ -842,6 +848,16 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     GF_LAUNCH(ctx, "smp_readout_dW", gf::readout_dW, dim3(1), dim3(256), 0, s->dy, s->g, dW, C, B.nMol);
     GF_LAUNCH(ctx, "smp_readout_bwd", gf::readout_backward_nodes, dim3(top.nNodes), dim3(256), 0, s->dy, W, s->sh,
               s->top_node_mol, s->lv[L].node_s, s->lv[L].node_row, s->lv[L].df, C);
+    if (!s->side_tried) {  // the second stream of the fused backward (smp_internal.h), created on first use
+        s->side_tried = true;
+        const char *e = std::getenv("GF_SMP_OVERLAP");
+        if (!(e && e[0] == '0')) {
+            if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)
+                s->side = nullptr;
+        }
+    }
     for (int l = L; l >= 1; --l) {
         const gfsmp::LevelLayout &h = B.level[l];
         const gf_smp::DevLevel &d = s->lv[l];
@@ -873,6 +889,10 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
         const gf_smp::DevLevel &pv = s->lv[l - 1];
         GF_LAUNCH(ctx, "smp_promote_bwd", gf::promote_backward, dim3(B.level[l - 1].nNodes), dim3(256), 0, s->P, pv.df,
                   pv.node_s, pv.node_row, d.cons_ptr, d.cons_slab, d.cons_s, d.cons_inv_off, d.inv, C);
+    }
+    if (s->side_pending) {  // join: the weight gradients (and their use of the split-K workspace) are complete
+        GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
+        s->side_pending = false;
     }
     // level 0: dZ0 = dF0 * lrelu'; dH += dZ0^T X
     {

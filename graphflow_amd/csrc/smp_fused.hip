@@ -827,6 +827,22 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         GF_LAUNCH(ctx, "smpf_colsum", colsum_chunks, dim3(nb), dim3(256), 0, d.dbpart, s->colpart, C, (long long)pairs, rpb);
         GF_LAUNCH(ctx, "smpf_colsum_fold", colsum_fold, dim3(1), dim3(256), 0, s->colpart, dbl, C, nb);
     }
+    // The weight-gradient products below read T and dO and write only dWst / dK_l: they run on the handle's second stream
+    // while this stream continues with the table-gradient chain (dT GEMM -> tables-backward -> consumer gather).
+    struct StreamSwap {
+        gf_ctx *c;
+        hipStream_t saved;
+        bool on;
+        ~StreamSwap() {
+            if (on) c->stream = saved;
+        }
+    } swap = {ctx, ctx->stream, false};
+    if (s->side) {
+        GF_HIP_TRY(ctx, hipEventRecord(s->ev_fork, ctx->stream));
+        GF_HIP_TRY(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
+        ctx->stream = s->side;
+        swap.on = true;
+    }
     // weight gradients (stacked), then scatter-add into dK_l:  dW = T_blk^T dO_blk   (split-K over rows).  Grouped: the
     // five products share each split's row range of T and dO, and their partial images are folded by ONE ordered
     // reduction straight into the first ten stacked blocks.
@@ -855,6 +871,12 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     st = gemm(ctx, true, false, 4 * C, C, nodes, d.St, 4 * C, 0, d.dSout, C, 0, d.dWst + 14 * CC, C, 0, 1, 0);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smpf_unstack_dw", unstack_weight_grads, dim3(64), dim3(256), 0, d.dWst, dKl, C);
+    if (swap.on) {
+        GF_HIP_TRY(ctx, hipEventRecord(s->ev_join, s->side));
+        ctx->stream = swap.saved;
+        swap.on = false;
+        s->side_pending = true;
+    }
     // table gradients: dT_blk (+)= dO_blk W_blk^T; every column range is written once before it is accumulated into
     //   cols [C,4C) = dZ [K8;K12;K15]^T ; [C,3C) += dO_tot [K0;K2]^T ; [C,2C) += dO_tr K6^T ;
     //   [0,C) = dZ' K16^T ; [C,2C) += dZ' K11^T ; [4C,6C) = dO_dir [K5;K9]^T

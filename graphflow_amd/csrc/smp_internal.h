@@ -72,6 +72,11 @@ struct gf_smp {
         int idle;  // consecutive prepares that did not use the block
     };
     std::vector<Block> pool;
+    // second stream for the weight-gradient GEMMs of the fused backward (they only share inputs with the table-gradient
+    // chain): forked after combine-backward of a level, joined before gf_smp_backward returns.  GF_SMP_OVERLAP=0 disables.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_tried = false, side_pending = false;
     // Adam state (gf_smp_adam_step); survives gf_smp_prepare, freed by gf_smp_destroy
     float *adam_m = nullptr, *adam_v = nullptr;
     // handle-owned model (host-pointer mode of the driver): parameters and their gradient, [param_count] each
