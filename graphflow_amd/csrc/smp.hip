@@ -336,6 +336,18 @@ gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
     return GF_OK;
 }
 
+// the second stream of the fused levels (smp_internal.h), created on first use
+void ensure_side_stream(gf_smp *s) {
+    if (s->side_tried) return;
+    s->side_tried = true;
+    const char *e = std::getenv("GF_SMP_OVERLAP");
+    if (e && e[0] == '0') return;
+    if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)
+        s->side = nullptr;
+}
+
 // End of a batch: its buffers go back to the pool (blocks idle for three batches in a row are returned to the device).
 void release(gf_smp *s) {
     if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
@@ -780,6 +792,7 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     std::vector<const float *> K, b;
     gf::view_params<const float>(s->cfg, params, &H, &K, &b, &W);
     gf_status st;
+    gf::ensure_side_stream(s);
     // level 0: f_0 = LeakyReLU(X H^T)   (MatMul(H, x_v) per vertex, SMP_omega.h:618)
     const int nV = B.level[0].nNodes;
     st = gf::gemm(ctx, false, true, nV, C, FD, s->x, FD, 0, H, FD, 0, s->lv[0].f, C, 0, 1, 0);
@@ -848,16 +861,7 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     GF_LAUNCH(ctx, "smp_readout_dW", gf::readout_dW, dim3(1), dim3(256), 0, s->dy, s->g, dW, C, B.nMol);
     GF_LAUNCH(ctx, "smp_readout_bwd", gf::readout_backward_nodes, dim3(top.nNodes), dim3(256), 0, s->dy, W, s->sh,
               s->top_node_mol, s->lv[L].node_s, s->lv[L].node_row, s->lv[L].df, C);
-    if (!s->side_tried) {  // the second stream of the fused backward (smp_internal.h), created on first use
-        s->side_tried = true;
-        const char *e = std::getenv("GF_SMP_OVERLAP");
-        if (!(e && e[0] == '0')) {
-            if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)
-                s->side = nullptr;
-        }
-    }
+    gf::ensure_side_stream(s);
     for (int l = L; l >= 1; --l) {
         const gfsmp::LevelLayout &h = B.level[l];
         const gf_smp::DevLevel &d = s->lv[l];

@@ -754,10 +754,35 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         }
         if (st != GF_OK) return st;
     }
+    GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C);
+    // The per-(node,x) vectors and per-node scalars (smp_vectors + two small GEMMs) only need T and the stacked weights:
+    // they run on the handle's second stream beside the big row GEMM and are joined before combine-forward.
+    struct StreamSwap {
+        gf_ctx *c;
+        hipStream_t saved;
+        bool on;
+        ~StreamSwap() {
+            if (on) c->stream = saved;
+        }
+    } swap = {ctx, ctx->stream, false};
+    if (s->side) {
+        GF_HIP_TRY(ctx, hipEventRecord(s->ev_fork, ctx->stream));
+        GF_HIP_TRY(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
+        ctx->stream = s->side;
+        swap.on = true;
+    }
     GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(256), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
               d.node_pair, C);
-    GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C);
     const size_t CC = (size_t)C * C;
+    st = gemm(ctx, false, false, pairs, C, 4 * C, d.Vt, 4 * C, 0, d.Wst + 10 * CC, C, 0, d.Vout, C, 0, 1, 0);
+    if (st != GF_OK) return st;
+    st = gemm(ctx, false, false, nodes, C, 4 * C, d.St, 4 * C, 0, d.Wst + 14 * CC, C, 0, d.Sout, C, 0, 1, 0);
+    if (st != GF_OK) return st;
+    if (swap.on) {
+        GF_HIP_TRY(ctx, hipEventRecord(s->ev_join, s->side));
+        ctx->stream = swap.saved;
+        swap.on = false;
+    }
     const int ldt = T_COLS * C, ldo = O_COLS * C;
     // block GEMMs: A = T column range, B = stacked weights, C = O column block -- one grouped launch (every row panel
     // of T is fetched from HBM once and shared through L2 by the three products), separate launches as a fallback.
@@ -786,10 +811,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             }
         }
     }
-    st = gemm(ctx, false, false, pairs, C, 4 * C, d.Vt, 4 * C, 0, d.Wst + 10 * CC, C, 0, d.Vout, C, 0, 1, 0);
-    if (st != GF_OK) return st;
-    st = gemm(ctx, false, false, nodes, C, 4 * C, d.St, 4 * C, 0, d.Wst + 14 * CC, C, 0, d.Sout, C, 0, 1, 0);
-    if (st != GF_OK) return st;
+    if (s->side) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
     {
         const size_t lds = combine_lds<16>(h.buckets.back().s);
         static size_t granted = 0;
