@@ -75,6 +75,8 @@ __global__ void promote_forward(const float *__restrict__ fprev, float *__restri
 }
 
 // backward: df_prev[w][p][q][:] = sum over consumers (n,a) of dP[n][a][inv(p)][inv(q)][:]
+constexpr int kPromoteChunk = 64, kPromoteMaxS = 32;
+
 __global__ void promote_backward(const float *__restrict__ dP, float *__restrict__ dfprev,
                                  const int *__restrict__ prev_s, const long long *__restrict__ prev_row,
                                  const long long *__restrict__ cons_ptr, const long long *__restrict__ cons_slab,
@@ -84,7 +86,58 @@ __global__ void promote_backward(const float *__restrict__ dP, float *__restrict
     const int sw = prev_s[w];
     float *dst = dfprev + prev_row[w] * C;
     const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
-    if ((C & 3) == 0) {
+    if ((C & 3) == 0 && sw <= kPromoteMaxS) {
+        // consumer tables of this source node in LDS (chunks of kPromoteChunk consumers), then four consumers' loads in
+        // flight per item: clamped address + 0/1 weight instead of a branch around every load.  Same summation order.
+        __shared__ long long sSlab[kPromoteChunk];
+        __shared__ int sS[kPromoteChunk];
+        __shared__ short sInv[kPromoteChunk][kPromoteMaxS];
+        const int Q = C >> 2, total4 = sw * sw * Q;
+        const int npass = (total4 + (int)blockDim.x - 1) / (int)blockDim.x;
+        for (long long cb = c0; cb < c1 || cb == c0; cb += kPromoteChunk) {
+            const int nc = (int)((c1 - cb < kPromoteChunk) ? c1 - cb : kPromoteChunk);
+            __syncthreads();
+            for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+                sSlab[i] = cons_slab[cb + i];
+                sS[i] = cons_s[cb + i];
+            }
+            for (int i = threadIdx.x; i < nc * sw; i += blockDim.x) sInv[i / sw][i % sw] = inv[cons_inv_off[cb + i / sw] + i % sw];
+            __syncthreads();
+            for (int pass = 0; pass < npass; ++pass) {
+                const int i = pass * (int)blockDim.x + threadIdx.x;
+                if (i >= total4) break;
+                const int q4 = i % Q, pq = i / Q;
+                const int p = pq / sw, q = pq - p * sw;
+                float4 acc = (cb == c0) ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4 *>(dst)[i];
+                for (int e0 = 0; e0 < nc; e0 += 4) {
+                    float4 v[4];
+                    float m[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = (e0 + j < nc) ? e0 + j : e0;
+                        const int ib = sInv[e][p], ic = sInv[e][q];
+                        const bool ok = e0 + j < nc && ib >= 0 && ic >= 0;
+                        const long long pos = sSlab[e] + (ok ? (long long)ib * sS[e] + ic : 0);
+                        v[j] = reinterpret_cast<const float4 *>(dP + pos * C)[q4];
+                        m[j] = ok ? 1.f : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (m[j] != 0.f) {  // (select, not a multiply: a structurally-zero position holds stale data)
+                            acc.x += v[j].x;
+                            acc.y += v[j].y;
+                            acc.z += v[j].z;
+                            acc.w += v[j].w;
+                        }
+                    }
+                }
+                reinterpret_cast<float4 *>(dst)[i] = acc;
+            }
+            if (c1 == c0) break;
+        }
+        return;
+    }
+    if ((C & 3) == 0) {  // larger receptive fields than the LDS tables hold
         const int Q = C >> 2, total4 = sw * sw * Q;
         for (int i = threadIdx.x; i < total4; i += blockDim.x) {
             const int q4 = i % Q, pq = i / Q;
