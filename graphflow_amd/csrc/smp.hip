@@ -393,8 +393,10 @@ gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
 void ensure_side_stream(gf_smp *s) {
     if (s->side_tried) return;
     s->side_tried = true;
+    // Off unless GF_SMP_OVERLAP=1: worth -0.3 ms of a 16.5 ms cfg3 step, but two GEMMs sharing the machine make per-kernel
+    // durations (and the roofline fraction computed from them) meaningless, so the measured default keeps one stream.
     const char *e = std::getenv("GF_SMP_OVERLAP");
-    if (e && e[0] == '0') return;
+    if (!(e && e[0] == '1')) return;
     if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)

@@ -75,7 +75,7 @@ struct gf_smp {
     // second stream of the fused levels.  Backward: the weight-gradient GEMMs (they only share inputs with the
     // table-gradient chain), forked after combine-backward of a level, joined before gf_smp_backward returns.  Forward:
     // the per-(node,x) vectors / per-node scalars and their two small GEMMs, beside the big row GEMM, joined before
-    // combine-forward.  GF_SMP_OVERLAP=0 disables.
+    // combine-forward.  Opt-in: GF_SMP_OVERLAP=1.
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_tried = false, side_pending = false;
