@@ -196,6 +196,12 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "note": "algorithmic bytes of this kernel over all levels / its device time per step"}
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_cfg3_hbm_bytes.json")   # committed PMC passes, this exact workload only
+        if fused and (B, C) == (1024, 64) and os.path.exists(pmc):
+            with open(pmc) as fh:
+                t = json.load(fh).get(dom)
+            if t:
+                roof["traffic"] = round(t["fetch"] + t["write"])   # HBM bytes of all launches of the kernel in one step
         roof["kernel"] = dom
         roof["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
         roof["step_GBps"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
