@@ -80,6 +80,7 @@ PROTOTYPES.update({
     "gf_smp_forward_host": (_i, [_vp, _dp, _dp, _dp, _dp]),
     "gf_smp_adam_step": (_i, [_vp, _vp, _vp, C.c_double, _i]),
     "gf_smp_adam_reset": (_i, [_vp]),
+    "gf_smp_momentum_step": (_i, [_vp, _vp, _vp, C.c_double, _i, C.c_double]),
     "gf_smp_uniform_init_host": (_i, [_vp, _fp]),
     "gf_smp_save_model": (_i, [_vp, _vp, C.c_char_p]),
     "gf_smp_load_model": (_i, [_vp, _vp, C.c_char_p]),

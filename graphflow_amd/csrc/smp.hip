@@ -357,6 +357,16 @@ __global__ void adam_step(float *__restrict__ p, const float *__restrict__ grad,
     }
 }
 
+// Momentum::Learn(learning_rate, nBatch) (GraphFlow/Momentum.h:64-71): m = gamma m + lr g / nBatch;  p -= m
+__global__ void momentum_step(float *__restrict__ p, const float *__restrict__ grad, float *__restrict__ m, size_t n, double lr,
+                              double inv_batch, double gamma) {
+    GRID_STRIDE(i, n) {
+        const double mi = gamma * (double)m[i] + lr * (double)grad[i] * inv_batch;
+        m[i] = (float)mi;
+        p[i] = (float)((double)p[i] - mi);
+    }
+}
+
 __global__ void zero_f32(float *p, size_t n) { GRID_STRIDE(i, n) p[i] = 0.f; }
 
 size_t param_count(const gfsmp::Config &c);
@@ -627,6 +637,30 @@ gf_status gf_smp_adam_step(gf_smp *s, float *params, const float *grads, double 
     GF_LAUNCH(ctx, "smp_adam", gf::adam_step, dim3(gf::grid_for(n)), dim3(256), 0, params, grads, s->adam_m, s->adam_v, n,
               learning_rate, 1.0 / (double)nBatch, s->adam_n, 0.9, 0.999, 1e-8);
     s->adam_n += n;
+    return GF_OK;
+}
+
+// The optimiser of the SMP_2D_ver6-8 models (sgd = new Momentum(momentum_param), SMP_2D_ver6.h:204).  Shares the handle's
+// first moment buffer with Adam: a model uses one optimiser or the other.
+gf_status gf_smp_momentum_step(gf_smp *s, float *params, const float *grads, double learning_rate, int nBatch, double gamma) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    gf_ctx *ctx = s->ctx;
+    if (!params && !grads && s->own_p) {
+        params = s->own_p;
+        grads = s->own_g;
+    }
+    if (!params || !grads || nBatch <= 0) return fail(ctx, GF_ERR_INVALID, "gf_smp_momentum_step: bad argument");
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = gf::param_count(s->cfg);
+    if (!s->adam_m) {
+        GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->adam_m), n * sizeof(float)));
+        GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->adam_v), n * sizeof(float)));
+        GF_HIP_TRY(ctx, hipMemsetAsync(s->adam_m, 0, n * sizeof(float), ctx->stream));
+        GF_HIP_TRY(ctx, hipMemsetAsync(s->adam_v, 0, n * sizeof(float), ctx->stream));
+        s->adam_n = 0;
+    }
+    GF_LAUNCH(ctx, "smp_momentum", gf::momentum_step, dim3(gf::grid_for(n)), dim3(256), 0, params, grads, s->adam_m, n,
+              learning_rate, 1.0 / (double)nBatch, gamma);
     return GF_OK;
 }
 

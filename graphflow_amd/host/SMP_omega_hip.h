@@ -42,9 +42,26 @@ public:
     }
     ~SMP_omega_hip() { gf_smp_destroy(net); }
 
+protected:
+    // the SMP_2D_ver6 / ver7 / ver8 wirings (below): contraction family, CustomMatMulTensor weights, Momentum optimiser
+    SMP_omega_hip(int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth, bool has_WL_ordering,
+                  int nContractions, double momentum_param)
+        : max_nVertices(max_nVertices), max_receptive_field(max_nVertices), nLevels(nLevels), nChanels(nChanels),
+          nFeatures(nFeatures), nDepth(nDepth), use_coulomb(false), net(NULL) {
+        wiring_contractions = nContractions;
+        wiring_custom = 1;
+        momentum = momentum_param;
+        use_momentum = true;
+        init(has_WL_ordering);
+    }
+
 private:
+    int wiring_contractions = 0, wiring_custom = 0;
+    double momentum = 0.0;
+    bool use_momentum = false;
     void init(bool has_WL_ordering) {
-        gf_smp_config cfg = {nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering ? 1 : 0};
+        gf_smp_config cfg = {nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering ? 1 : 0,
+                             wiring_contractions, wiring_custom};
         must(gf_smp_create(gfhost::default_context(), &cfg, &net), "gf_smp_create");
         std::vector<float> w(gf_smp_param_count(net));
         must(gf_smp_uniform_init_host(&cfg, &w[0]), "gf_smp_uniform_init_host");  // weights_initialization()
@@ -163,7 +180,10 @@ private:
     }
     void step(double learning_rate, int nBatch) {
         must(gf_smp_backward(net, NULL, NULL, 0), "gf_smp_backward");
-        must(gf_smp_adam_step(net, NULL, NULL, learning_rate, nBatch), "gf_smp_adam_step");
+        if (use_momentum)
+            must(gf_smp_momentum_step(net, NULL, NULL, learning_rate, nBatch, momentum), "gf_smp_momentum_step");
+        else
+            must(gf_smp_adam_step(net, NULL, NULL, learning_rate, nBatch), "gf_smp_adam_step");
     }
     void must(gf_status st, const char *what) {
         if (st != GF_OK) gfhost::die(gfhost::default_context(), what, st);
@@ -182,6 +202,28 @@ public:
     SMP_beta_hip(bool use_coulomb, int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth,
                  bool has_WL_ordering = true)
         : SMP_omega_hip(use_coulomb, max_nVertices, max_nVertices, nLevels, nChanels, nFeatures, nDepth, has_WL_ordering) {}
+};
+
+// SMP_2D_ver6 / ver7 / ver8 (GraphFlow/SMP_2D_ver6.h:30-930 and its two siblings): the same DAG with RisiContraction_10 /
+// _50 / _18, the level weight [C][nContractions C] applied by CustomMatMulTensor, no receptive-field cap, and the
+// Momentum optimiser (sgd = new Momentum(momentum_param), :204).  Same public methods as above.
+class SMP_2D_ver6_hip : public SMP_omega_hip {
+public:
+    SMP_2D_ver6_hip(int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth, double momentum_param,
+                    bool has_WL_ordering = true)
+        : SMP_omega_hip(max_nVertices, nLevels, nChanels, nFeatures, nDepth, has_WL_ordering, 10, momentum_param) {}
+};
+class SMP_2D_ver7_hip : public SMP_omega_hip {
+public:
+    SMP_2D_ver7_hip(int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth, double momentum_param,
+                    bool has_WL_ordering = true)
+        : SMP_omega_hip(max_nVertices, nLevels, nChanels, nFeatures, nDepth, has_WL_ordering, 50, momentum_param) {}
+};
+class SMP_2D_ver8_hip : public SMP_omega_hip {
+public:
+    SMP_2D_ver8_hip(int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth, double momentum_param,
+                    bool has_WL_ordering = true)
+        : SMP_omega_hip(max_nVertices, nLevels, nChanels, nFeatures, nDepth, has_WL_ordering, 18, momentum_param) {}
 };
 
 #endif

@@ -70,6 +70,12 @@ class SMPOmega:
                                                  float(learning_rate), int(nBatch)))
         return params
 
+    def momentum_step(self, params, grads, learning_rate, nBatch, gamma=0.9):
+        """Momentum::Learn(learning_rate, nBatch) (Momentum.h:64-71): the optimiser of SMP_2D_ver6-8."""
+        self.ctx.check(self.lib.gf_smp_momentum_step(self.handle, C.c_void_p(params.data_ptr()), C.c_void_p(grads.data_ptr()),
+                                                     float(learning_rate), int(nBatch), float(gamma)))
+        return params
+
     def adam_reset(self):
         self.ctx.check(self.lib.gf_smp_adam_reset(self.handle))
 

@@ -219,7 +219,10 @@ gf_status gf_smp_forward_host(gf_smp *smp, const double *targets, double *predic
  * gf_smp_backward (all-reduced over ranks first in data-parallel runs; nBatch is then the GLOBAL batch).  The moment
  * buffers live in the handle and survive gf_smp_prepare.  Device pointers. */
 gf_status gf_smp_adam_step(gf_smp *smp, float *params, const float *grads, double learning_rate, int nBatch);
-gf_status gf_smp_adam_reset(gf_smp *smp);
+gf_status gf_smp_adam_reset(gf_smp *smp);   /* zeroes the moment buffers (Adam and Momentum) and Adam's element counter */
+/* Momentum::Learn(learning_rate, nBatch) (GraphFlow/Momentum.h:64-71), the optimiser of SMP_2D_ver6-8
+ * (SMP_2D_ver6.h:204, :593): m = gamma m + learning_rate * grads / nBatch, params -= m. */
+gf_status gf_smp_momentum_step(gf_smp *smp, float *params, const float *grads, double learning_rate, int nBatch, double gamma);
 /* SMP_omega::weights_initialization (SMP_omega.h:334-338; GraphFlow.h:1297-1306) into a HOST buffer of
  * gf_smp_param_count floats, drawing from rand() in the reference's order: same srand() -> same initial weights. */
 gf_status gf_smp_uniform_init_host(const gf_smp_config *cfg, float *params);

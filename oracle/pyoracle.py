@@ -323,6 +323,29 @@ def reference_smp_2d(version, adj, feature, target, params, nLevels, nChanels, n
     return {"phi": fields, "phi_array": phi, "graph_feature": gfeat, "predict": float(pred[0]), "loss": float(loss[0]), "grads": grads}
 
 
+def reference_smp_2d_batchlearn(version, mols, targets, nLevels, nChanels, nDepth, max_nVertices, momentum, nIter, learning_rate, seed):
+    """nIter x the REAL SMP_2D_ver6/7/8::BatchLearn (Momentum) from the constructor's own srand(seed) weights."""
+    ref = reference()
+    if ref is None:
+        return None
+    nK = {6: 10, 7: 50, 8: 18}[version]
+    nV = np.array([len(a) for a, _ in mols], dtype=np.int32)
+    F = mols[0][1].shape[1]
+    adj = np.concatenate([np.asarray(a, dtype=np.int32).ravel() for a, _ in mols])
+    feat = np.concatenate([np.asarray(f, dtype=np.float64).ravel() for _, f in mols])
+    tg = np.ascontiguousarray(targets, dtype=np.float64)
+    n = nChanels * F * (nDepth + 1) + nLevels * (nK * nChanels * nChanels + nChanels) + nChanels
+    p0, p1, losses = np.zeros(n), np.zeros(n), np.zeros((nIter, 2))
+    f = ref.lib.ref_smp_2d_batchlearn
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f.argtypes = [_i] * 6 + [C_double, _i, ip, ip, _dp, _dp, _i, _dp, _i, C_double, _dp, _dp]
+    f.restype = _i
+    got = f(version, max_nVertices, nLevels, nChanels, F, nDepth, float(momentum), len(mols), nV, adj, feat, tg, int(seed), p0,
+            nIter, float(learning_rate), losses, p1)
+    assert got == n, (got, n)
+    return {"params0": p0, "params": p1, "losses": losses}
+
+
 def reference_batchlearn(mols, targets, nLevels, nChanels, nDepth, cap, max_nVertices, nIter, learning_rate, params=None, seed=-1):
     """nIter x the REAL SMP_omega::BatchLearn(nBatch, molecules, targets, learning_rate).  params given, or drawn by the
     reference's own constructor after srand(seed).  Returns dict(params0, params, losses[nIter, 2])."""

@@ -416,6 +416,54 @@ int smp2d_run(int max_nVertices, int nLevels, int nChanels, int nFeatures, int n
     return (int)off;
 }
 }  // namespace
+namespace {
+template <class Net>
+int smp2d_batchlearn(int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth, double momentum_param, int nMol,
+                     const int *nV, const int *adj, const double *feature, const double *targets, int seed, double *params0_out,
+                     int nIter, double learning_rate, double *losses, double *params_out) {
+    srand((unsigned)seed);
+    Net &net = *new Net(max_nVertices, nLevels, nChanels, nFeatures, nDepth, momentum_param);
+    size_t off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) params0_out[off++] = net.sgd->params[i]->value[j];
+    std::vector<DenseGraph *> mol(nMol);
+    std::vector<double> tgt(targets, targets + nMol);
+    size_t ao = 0, fo = 0;
+    for (int m = 0; m < nMol; ++m) {
+        const int V = nV[m];
+        mol[m] = new DenseGraph(V, nFeatures);
+        for (int i = 0; i < V; ++i) {
+            for (int j = 0; j < V; ++j) mol[m]->adj[i][j] = adj[ao + (size_t)i * V + j];
+            for (int f = 0; f < nFeatures; ++f) mol[m]->feature[i][f] = feature[fo + (size_t)i * nFeatures + f];
+        }
+        ao += (size_t)V * V;
+        fo += (size_t)V * nFeatures;
+    }
+    for (int it = 0; it < nIter; ++it) {
+        std::pair<double, double> r = net.BatchLearn(nMol, &mol[0], &tgt[0], learning_rate);
+        losses[2 * it] = r.first;
+        losses[2 * it + 1] = r.second;
+    }
+    off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) params_out[off++] = net.sgd->params[i]->value[j];
+    return (int)off;
+}
+}  // namespace
+// nIter x the REAL SMP_2D_ver{6,7,8}::BatchLearn (Momentum optimiser) from the weights its constructor draws after srand(seed)
+extern "C" int ref_smp_2d_batchlearn(int version, int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth,
+                                     double momentum_param, int nMol, const int *nV, const int *adj, const double *feature,
+                                     const double *targets, int seed, double *params0_out, int nIter, double learning_rate,
+                                     double *losses, double *params_out) {
+#define GF_RUN(N) smp2d_batchlearn<N>(max_nVertices, nLevels, nChanels, nFeatures, nDepth, momentum_param, nMol, nV, adj, feature, \
+                                      targets, seed, params0_out, nIter, learning_rate, losses, params_out)
+    if (version == 6) return GF_RUN(SMP_2D_ver6);
+    if (version == 7) return GF_RUN(SMP_2D_ver7);
+    if (version == 8) return GF_RUN(SMP_2D_ver8);
+#undef GF_RUN
+    return -1;
+}
+
 extern "C" int ref_smp_2d_run(int version, int max_nVertices, int nLevels, int nChanels, int nFeatures, int nDepth, int has_WL,
                               int V, const int *adj, const double *feature, double target, const double *params,
                               double *graph_feature, double *predict, double *loss, double *grads, int *phi, int phi_stride) {

@@ -82,6 +82,21 @@ int main() {
     srand(5);
     SMP_omega_hip uncapped(10, 10, 2, 10, 4, 5);
     for (int i = 0; i < 4; ++i) bad |= close_to("SMP_beta_hip == uncapped SMP_omega_hip", beta.Predict(mol[i]), uncapped.Predict(mol[i]), 0.0);
+    // SMP_2D_ver6_hip: the real SMP_2D_ver6 after srand(11), three BatchLearn(4, molecules, targets, 1e-5) with momentum 0.9,
+    // reports these (before, after) losses (tests/golden/smp_train.npz, train2d6)
+    {
+        srand(11);
+        SMP_2D_ver6_hip v6(10, 2, 6, 4, 3, 0.9);
+        static const double ref6[3][2] = {{55.51807777, 32.64139581}, {32.64139581, 8.61713655}, {8.61713655, 5.44237135}};
+        for (int it = 0; it < 3; ++it) {
+            std::pair<double, double> r = v6.BatchLearn(4, mol, target, 1e-5);
+            bad |= close_to("SMP_2D_ver6 BatchLearn before", r.first, ref6[it][0], 5e-4);
+            bad |= close_to("SMP_2D_ver6 BatchLearn after", r.second, ref6[it][1], 5e-4);
+        }
+        SMP_2D_ver7_hip v7(10, 2, 6, 4, 3, 0.9);
+        SMP_2D_ver8_hip v8(10, 2, 6, 4, 3, 0.9);
+        bad |= !(v7.Predict(mol[0]) == v7.Predict(mol[0])) || !(v8.Predict(mol[3]) == v8.Predict(mol[3]));  // run, finite
+    }
     // "does it learn", the body of the reference's tests/test_SMP_omega.cpp:166-202: 1024 epochs of BatchLearn at 1e-3,
     // then save_model -> load_model into a second network -> the same predictions (the fp64 reference ends within 5e-5
     // of the targets; the fp32 device path is held to 1e-2)

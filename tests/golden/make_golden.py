@@ -247,6 +247,11 @@ def train_fixture():
     out = {"train__cfg": np.array([L, C, D, cap, maxV, 7, 3], dtype=np.int32), "train__lr": np.array([1e-3]),
            "train__targets": np.array(tgts, dtype=np.float64), "train__params0": r["params0"], "train__params": r["params"],
            "train__losses": r["losses"]}
+    # SMP_2D_ver6 (RisiContraction_10, CustomMatMulTensor weights, Momentum 0.9): three BatchLearn steps from srand(11)
+    r6 = pyoracle.reference_smp_2d_batchlearn(6, mols, tgts, 2, 6, 3, 10, 0.9, 3, 1e-5, 11)
+    out.update({"train2d6__cfg": np.array([2, 6, 3, 10, 11, 3], dtype=np.int32), "train2d6__lr": np.array([1e-5]),
+                "train2d6__momentum": np.array([0.9]), "train2d6__params0": r6["params0"], "train2d6__params": r6["params"],
+                "train2d6__losses": r6["losses"]})
     np.savez_compressed(os.path.join(HERE, "smp_train.npz"), **out)
 
 

@@ -274,3 +274,36 @@ def test_handle_reuse_across_batches_is_exact(gf, fused):
         assert torch.equal(x, y)
     for x, y in zip(got_a, fresh_a):
         assert torch.equal(x, y)
+
+
+def test_smp_2d_ver6_batchlearn_matches_the_reference(gf):
+    """Three BatchLearn steps of the real SMP_2D_ver6 (RisiContraction_10 + CustomMatMulTensor weights + Momentum 0.9;
+    tests/golden/smp_train.npz): same srand -> same initial weights, then forward/backward/gf_smp_momentum_step."""
+    import ctypes as C
+    import os
+    from graphflow_amd.smp import SMPOmega
+    from inputs import toy_molecules
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "smp_train.npz"))
+    L, Cn, D, maxV, seed, nIter = (int(x) for x in z["train2d6__cfg"])
+    mols = [(adj, feat) for _, adj, feat, _ in toy_molecules()]
+    tg = dev(np.array([t for *_, t in toy_molecules()]))
+    lr, gamma = float(z["train2d6__lr"][0]), float(z["train2d6__momentum"][0])
+    net = SMPOmega(L, Cn, mols[0][1].shape[1], D, maxV, True, nContractions=10, custom_matmul=True)
+    C.CDLL(None).srand(seed)
+    p = dev(net.uniform_init())
+    assert np.array_equal(p.cpu().numpy(), z["train2d6__params0"].astype(np.float32))
+    net.prepare(mols)
+    grads = torch.empty(net.n_params, device="cuda")
+    for it in range(nIter):
+        _, loss, _ = net.forward(p, tg)
+        before = float(loss.sum())
+        net.backward(p, grads)
+        net.momentum_step(p, grads, lr, len(mols), gamma)
+        _, loss, _ = net.forward(p, tg)
+        after = float(loss.sum())
+        assert abs(before - z["train2d6__losses"][it, 0]) <= 5 * TOL_FWD * max(1.0, before), it
+        assert abs(after - z["train2d6__losses"][it, 1]) <= 5 * TOL_FWD * max(1.0, after), it
+    err = np.abs(p.cpu().numpy().astype(np.float64) - z["train2d6__params"])
+    scale = np.abs(z["train2d6__params"] - z["train2d6__params0"]).max()
+    print("max |param - reference| %.3e, largest parameter change %.3e" % (err.max(), scale))
+    assert err.max() <= 1e-3 * scale
