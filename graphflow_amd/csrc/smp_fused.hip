@@ -362,16 +362,22 @@ __global__ __launch_bounds__(256) void smp_vectors(const float *__restrict__ T, 
         st4(St + (size_t)n * 4 * C + 4 * i, batched_sum(scal + pairbase * 4 * (size_t)C + 4 * i, (size_t)4 * C, 0, s, one));
 }
 
-// stacked[p] = K^(kperm[p])  (gather), or  dK^(kperm[p]) += dstacked[p]  (scatter-add)
-__global__ void stack_weights(const float *__restrict__ K, float *__restrict__ stacked, int C) {
-    const int CC = C * C;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 18 * CC; i += gridDim.x * blockDim.x)
-        stacked[i] = K[(size_t)c_kperm[i / CC] * CC + i % CC];
+// stacked[p] = K^(kperm[p])  (gather), or  dK^(kperm[p]) += dstacked[p]  (scatter-add).  Block k of the level weight is
+// K[(k C + ci) C + co] in the SMP_omega layout [18C][C] and K[co 18C + k C + ci] in the CustomMatMulTensor layout [C][18C]
+// (custom != 0, SMP_2D_ver8): the stacked copy is [ci][co] either way, so the block GEMMs do not care.
+__device__ __forceinline__ size_t weight_index(int k, int r, int C, int custom) {
+    const int ci = r / C, co = r % C;
+    return custom ? (size_t)co * 18 * C + (size_t)k * C + ci : ((size_t)k * C + ci) * C + co;
 }
-__global__ void unstack_weight_grads(const float *__restrict__ dstacked, float *__restrict__ dK, int C) {
+__global__ void stack_weights(const float *__restrict__ K, float *__restrict__ stacked, int C, int custom) {
     const int CC = C * C;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 18 * CC; i += gridDim.x * blockDim.x)
-        dK[(size_t)c_kperm[i / CC] * CC + i % CC] += dstacked[i];
+        stacked[i] = K[weight_index(c_kperm[i / CC], i % CC, C, custom)];
+}
+__global__ void unstack_weight_grads(const float *__restrict__ dstacked, float *__restrict__ dK, int C, int custom) {
+    const int CC = C * C;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 18 * CC; i += gridDim.x * blockDim.x)
+        dK[weight_index(c_kperm[i / CC], i % CC, C, custom)] += dstacked[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -729,7 +735,7 @@ gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *d
 bool smp_fused_supported(const gf_smp *s, int l) {
     const int C = s->cfg.nChanels;
     if (C % 4 != 0 || C > 1024) return false;
-    if (s->cfg.nContractions != 18 || s->cfg.custom_matmul) return false;  // SMP_2D_ver6-8 wirings: op-by-op levels
+    if (s->cfg.nContractions != 18) return false;  // SMP_2D_ver6 / ver7 (_10 / _50): op-by-op levels
     const gfsmp::LevelLayout &h = s->lay.level[l];
     if (h.buckets.empty()) return false;
     return h.buckets.back().s <= 32;  // 8 * PPW at LPC = 16
@@ -754,7 +760,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         }
         if (st != GF_OK) return st;
     }
-    GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C);
+    GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C, s->cfg.custom_matmul);
     // The per-(node,x) vectors and per-node scalars (smp_vectors + two small GEMMs) only need T and the stacked weights:
     // they run on the handle's second stream beside the big row GEMM and are joined before combine-forward.
     struct StreamSwap {
@@ -892,7 +898,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     if (st != GF_OK) return st;
     st = gemm(ctx, true, false, 4 * C, C, nodes, d.St, 4 * C, 0, d.dSout, C, 0, d.dWst + 14 * CC, C, 0, 1, 0);
     if (st != GF_OK) return st;
-    GF_LAUNCH(ctx, "smpf_unstack_dw", unstack_weight_grads, dim3(64), dim3(256), 0, d.dWst, dKl, C);
+    GF_LAUNCH(ctx, "smpf_unstack_dw", unstack_weight_grads, dim3(64), dim3(256), 0, d.dWst, dKl, C, s->cfg.custom_matmul);
     if (swap.on) {
         GF_HIP_TRY(ctx, hipEventRecord(s->ev_join, s->side));
         ctx->stream = swap.saved;
