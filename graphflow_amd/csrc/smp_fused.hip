@@ -38,177 +38,16 @@ enum { O_LOC = 0, O_Z = 1, O_ZP = 2, O_COLS = 3 };
 __constant__ int c_kperm[18] = {0, 2, 6, 5, 9, 8, 12, 15, 16, 11, 1, 3, 7, 10, 4, 13, 14, 17};
 
 // ---------------------------------------------------------------------------------------------------------------
-// T1: tables-forward.  Workgroup per (node, b).  Same lane mapping / reductions as r18_fwd_slab, but every row a of
-// the slab is gathered from f_{l-1}[src(n,a)] through the selection map pi_a (P[a][b][c] = F_a[pi_a(b)][pi_a(c)] or 0),
-// and the products are the six tables plus the b-owned vectors and partial scalars.
-// ---------------------------------------------------------------------------------------------------------------
-template <int LPC, int NI>
-__global__ __launch_bounds__(kThreads) void smp_tables_fwd(const float *__restrict__ fprev, const float *__restrict__ A,
-                                                           float *__restrict__ T, float *__restrict__ Vt,
-                                                           float *__restrict__ scal, const long long *__restrict__ pair_src_row,
-                                                           const int *__restrict__ pair_src_s, const short *__restrict__ pi,
-                                                           Ragged R, int C, int nwin) {
-    constexpr int PPW = 64 / LPC;
-    constexpr int CW = 4 * LPC;
-    constexpr int NCP = NI * PPW;
-    static_assert(PPW >= 4, "row epilogue uses four c-groups");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cg = lane / LPC, fl = lane % LPC;
-    const Where W = locate(R, nwin);
-    const int N = W.N, b = W.i;
-    const size_t rowbase = W.rowbase, pairbase = W.pairbase;
-    const int f = W.win * CW + 4 * fl;
-    const bool fok = f < C;
-    const int fld = fok ? f : 0;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const AdjLds L = load_adjacency<false>(smem, A + rowbase, N);
-    float *sRed = smem + adj_lds_floats(N);   // [2][NCP][CW] cross-wave reduction buffer
-    float *sMisc = sRed + 2 * NCP * CW;       // [kWaves][2][CW] diagonal sums
-    short *sPi = reinterpret_cast<short *>(sMisc + kWaves * 2 * CW);  // [N][N] selection maps of this node
-    for (int i = tid; i < N * N; i += kThreads) sPi[i] = pi[rowbase + i];
-    __syncthreads();
-
-    float rc[NI];
-    int cc[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int c = i * PPW + cg;
-        cc[i] = (c < N) ? c : -1;
-        rc[i] = (c < N && fok) ? L.r[c] : 0.f;
-    }
-
-    f4 sbc[NI], t10[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) sbc[i] = t10[i] = splat(0.f);
-    f4 dgsum = splat(0.f);  // cg==0: sum_a P[a,b,b]   cg==1: sum_a P[a,b,a]
-
-    // gather one row: returns masked values (zero where the selection map has no image)
-    auto load_row = [&](int a, f4(&v)[NI], f4 &dg) {
-        const long long e = (long long)pairbase + a;
-        const float *src = fprev + pair_src_row[e] * C + fld;
-        const int sw = pair_src_s[e];
-        const short *map = sPi + a * N;
-        const int pb = map[b];
-        if (pb < 0) {  // wave-uniform: row (a, b, :) of the promoted tensor is structurally zero -- nothing to fetch
-#pragma unroll
-            for (int i = 0; i < NI; ++i) v[i] = splat(0.f);
-            dg = splat(0.f);
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int pc = (cc[i] >= 0) ? map[cc[i]] : -1;
-            const bool ok = pb >= 0 && pc >= 0 && fok;
-            const f4 x = ld4(src + (ok ? ((size_t)pb * sw + pc) * C : 0));
-            v[i] = ok ? x : splat(0.f);
-        }
-        const int pd = (cg == 0) ? pb : map[a];  // P[a,b,b] or P[a,b,a]
-        const bool okd = cg < 2 && pb >= 0 && pd >= 0 && fok;
-        const f4 y = ld4(src + (okd ? ((size_t)pb * sw + pd) * C : 0));
-        dg = okd ? y : splat(0.f);
-    };
-
-    f4 cur[NI], nxt[NI], dcur, dnxt;
-    load_row(wave < N ? wave : 0, cur, dcur);
-    for (int a = wave; a < N; a += kWaves) {
-        const int an = (a + kWaves < N) ? a + kWaves : a;
-        load_row(an, nxt, dnxt);
-        const float ra = L.r[a];
-        f4 sab = splat(0.f), t6 = splat(0.f);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const f4 v = cur[i];
-            sbc[i] += v;
-            t10[i] += ra * v;
-            sab += v;
-            t6 += rc[i] * v;
-        }
-        sab = reduce_cgroups<LPC>(sab);
-        t6 = reduce_cgroups<LPC>(t6);
-        dgsum += dcur;
-        if (fok) {
-            float *trow = T + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + f;  // table row (a, b)
-            if (cg == 0) {
-                st4(trow + T_SAB * C, sab);
-                st4(trow + T_DBB * C, dcur);  // P[a,b,b]
-                if (a == b) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);  // -> s18 = sum_a P[a,a,a]
-            } else if (cg == 1) {
-                st4(trow + T_DAC * C, dcur);  // P[a,b,a] = Dac[e=a][b]
-            } else if (cg == 2) {
-                st4(trow + T_T6 * C, t6);
-            } else if (cg == 3) {
-                if (a == b) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, sab);  // -> s14 = sum_a S_ab[a,a]
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) cur[i] = nxt[i];
-        dcur = dnxt;
-    }
-
-    // cross-wave reduction of the a-sums (fixed order), as in r18_fwd_slab
-#pragma unroll 1
-    for (int w = 1; w < kWaves; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                st4(sRed + (i * PPW + cg) * CW + 4 * fl, sbc[i]);
-                st4(sRed + (NCP + i * PPW + cg) * CW + 4 * fl, t10[i]);
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                sbc[i] += ld4(sRed + (i * PPW + cg) * CW + 4 * fl);
-                t10[i] += ld4(sRed + (NCP + i * PPW + cg) * CW + 4 * fl);
-            }
-        }
-        __syncthreads();
-    }
-    if (cg < 2) st4(sMisc + (wave * 2 + cg) * CW + 4 * fl, dgsum);
-    __syncthreads();
-    if (wave == 0) {
-        f4 cs = splat(0.f);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (cc[i] >= 0) {
-                cs += sbc[i];
-                if (fok) {
-                    float *trow = T + (rowbase + (size_t)b * N + cc[i]) * (size_t)(T_COLS * C) + f;  // table row (b, c)
-                    st4(trow + T_SBC * C, sbc[i]);
-                    st4(trow + T_T10 * C, t10[i]);
-                }
-            }
-        }
-        cs = reduce_cgroups<LPC>(cs);  // colsum_b = sum_{a,c} P[a,b,c]
-        f4 dbbtot = splat(0.f), dactot = splat(0.f);
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            dbbtot += ld4(sMisc + (w * 2 + 0) * CW + 4 * fl);
-            dactot += ld4(sMisc + (w * 2 + 1) * CW + 4 * fl);
-        }
-        if (cg == 0 && fok) {
-            float *v = Vt + (pairbase + b) * 4 * (size_t)C + f;  // [rowsum_a | colsum_b | D8 | D11] of index b
-            st4(v + 1 * C, cs);
-            st4(v + 3 * C, dactot);                               // D11[b] = sum_a P[a,b,a]
-            float *s = scal + (pairbase + b) * 4 * (size_t)C + f;
-            st4(s + 0 * C, cs);                                   // -> total
-            st4(s + 2 * C, dbbtot);                               // -> s15 = sum_{a,b} P[a,b,b]
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// T1w: tables-forward for small receptive fields (s <= 4 NI, NI <= 4).  One WAVE per (node, b): a workgroup covers four
-// consecutive b of one node and shares the node's selection maps and row sums in LDS.  A wave walks all rows a of its
-// slab itself, so the sums over a stay in its registers: no cross-wave reduction, one barrier in the whole kernel.
-// (With workgroup-per-pair the fixed prologue/epilogue -- about ten barriers -- dominated when a wave owned <= 4 rows.)
+// T1w: tables-forward (s <= 4 NI, NI in {1, 2, 4, 8}).  One WAVE per (node, b): a workgroup covers four consecutive b of one
+// node and shares the node's selection maps and row sums in LDS.  Lane = (c-group cg, channel quad fl) as in r18_fwd_slab;
+// every row a of the slab P[:, b, :, :] is GATHERED straight from f_{l-1}[src(n, a)] through the selection map pi_a
+// (P[a][b][c] = F_a[pi_a(b)][pi_a(c)] or 0), one row prefetched ahead.  A wave walks all rows a itself, so the sums over a
+// stay in its registers: no cross-wave reduction, one barrier in the whole kernel.  (A workgroup-per-pair variant with the
+// rows split over four waves paid about ten barriers of prologue/epilogue and was slower in every size class: 3.3 -> 2.6 ms
+// for s <= 16, 0.73 -> 0.54 ms for 16 < s <= 32 at cfg3.)
 // ---------------------------------------------------------------------------------------------------------------
 template <int NI>
-__global__ __launch_bounds__(kThreads, 4) void smp_tables_fwd_w(  // (NI = 4 sat at 130 VGPRs: capped to 128 -> 4 waves per SIMD)
+__global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  // (NI = 4 sat at 130 VGPRs: capped to 128 -> 4 waves per SIMD)
     const float *__restrict__ fprev, const float *__restrict__ rsum,
                                                              float *__restrict__ T, float *__restrict__ Vt,
                                                              float *__restrict__ scal, const long long *__restrict__ pair_src_row,
@@ -332,12 +171,6 @@ __global__ __launch_bounds__(kThreads, 4) void smp_tables_fwd_w(  // (NI = 4 sat
         st4(sc + 0 * C, cs);
         st4(sc + 2 * C, dgsum);
     }
-}
-
-template <int LPC, int NI>
-size_t tables_fwd_lds(int N) {
-    constexpr int CW = 4 * LPC, NCP = NI * (64 / LPC);
-    return sizeof(float) * ((size_t)adj_lds_floats(N) + 2 * (size_t)NCP * CW + kWaves * 2 * CW) + sizeof(short) * (size_t)N * N + 16;
 }
 
 // rowsum_a[x] = sum_b S_ab[x,b], D8[x] = sum_b Dbb[x,b] per (node, x); scalars per node = sum over b of the partials.
@@ -703,20 +536,6 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
 }
 
 template <int NI>
-gf_status launch_tables_fwd(gf_smp *s, int l, const SizeClass &c) {
-    gf_ctx *ctx = s->ctx;
-    const gf_smp::DevLevel &d = s->lv[l];
-    const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
-    const size_t lds = tables_fwd_lds<16, NI>(c.smax);
-    static size_t granted = 0;
-    gf_status st = opt_in_lds(ctx, smp_tables_fwd<16, NI>, lds, &granted);
-    if (st != GF_OK) return st;
-    GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd<16, NI>), dim3((unsigned)((c.hi - c.lo) * nwin)), dim3(kThreads), lds,
-              s->lv[l - 1].f, d.adj, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, ragged_for(d, c.lo, c.smax), C, nwin);
-    return GF_OK;
-}
-
-template <int NI>
 gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *dT) {
     gf_ctx *ctx = s->ctx;
     const gf_smp::DevLevel &d = s->lv[l];
@@ -756,7 +575,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             case 1: st = launch_tables_fwd_w<1>(s, l, c); break;
             case 2: st = launch_tables_fwd_w<2>(s, l, c); break;
             case 4: st = launch_tables_fwd_w<4>(s, l, c); break;
-            default: st = launch_tables_fwd<8>(s, l, c); break;
+            default: st = launch_tables_fwd_w<8>(s, l, c); break;
         }
         if (st != GF_OK) return st;
     }
