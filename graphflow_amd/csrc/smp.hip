@@ -302,9 +302,11 @@ __global__ void readout_molecules(const float *__restrict__ vf, const int *__res
 }
 
 // dW[f] += sum_m dy[m] g[m][f]   (InnerProduct.h:48-53, second operand)
-__global__ void readout_dW(const float *__restrict__ dy, const float *__restrict__ g, float *__restrict__ dW, int C, int nMol) {
-    __shared__ float red[256];
-    const int lanes = (C < 256) ? C : 256, rl = 256 / lanes;
+__global__ __launch_bounds__(1024) void readout_dW(const float *__restrict__ dy, const float *__restrict__ g, float *__restrict__ dW,
+                                                   int C, int nMol) {
+    __shared__ float red[1024];
+    const int nt = (int)blockDim.x;
+    const int lanes = (C < nt) ? C : nt, rl = nt / lanes;
     const int f0 = threadIdx.x % lanes, rr = threadIdx.x / lanes;
     for (int fb = 0; fb < C; fb += lanes) {
         const int f = fb + f0;
@@ -845,7 +847,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     for (int l = 0; l <= L; ++l) maxrows = std::max(maxrows, (long long)B.level[l].rows);
     long long maxpairs = 0;
     for (int l = 0; l <= L; ++l) maxpairs = std::max(maxpairs, (long long)B.level[l].pairs);
-    st = gf::upload(s, &s->colpart, nullptr, (size_t)((maxrows + 1023) / 1024 + (maxpairs + 255) / 256 + 2) * C);
+    s->colpart_rows = (size_t)((maxrows + 1023) / 1024 + (maxpairs + 255) / 256 + 2);
+    st = gf::upload(s, &s->colpart, nullptr, s->colpart_rows * C);
     if (st != GF_OK) return st;
 #undef UP
     // split-K partials of the weight gradients also live in the context workspace
@@ -947,7 +950,7 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     if (!accumulate) GF_LAUNCH(ctx, "smp_zero", gf::zero_f32, dim3(gf::grid_for(np)), dim3(256), 0, grads, np);
     gf_status st;
     const gfsmp::LevelLayout &top = B.level[L];
-    GF_LAUNCH(ctx, "smp_readout_dW", gf::readout_dW, dim3(1), dim3(256), 0, s->dy, s->g, dW, C, B.nMol);
+    GF_LAUNCH(ctx, "smp_readout_dW", gf::readout_dW, dim3(1), dim3(1024), 0, s->dy, s->g, dW, C, B.nMol);
     GF_LAUNCH(ctx, "smp_readout_bwd", gf::readout_backward_nodes, dim3(top.nNodes), dim3(256), 0, s->dy, W, s->sh,
               s->top_node_mol, s->lv[L].node_s, s->lv[L].node_row, s->lv[L].df, C);
     gf::ensure_side_stream(s);
@@ -990,7 +993,11 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     // level 0: dZ0 = dF0 * lrelu'; dH += dZ0^T X
     {
         const int nV = B.level[0].nNodes;
-        const int rpb = 1024, nb = (nV + rpb - 1) / rpb;
+        // (level 0 has no bias: the column sums are discarded, so small row blocks cost nothing downstream; colpart holds
+        //  maxrows / 1024 + maxpairs / 256 + 2 rows and level 0 has at most maxpairs / 64 blocks... keep nb within it)
+        int rpb = 64;
+        while ((nV + rpb - 1) / rpb > (int)s->colpart_rows && rpb < 1024) rpb *= 2;
+        const int nb = (nV + rpb - 1) / rpb;
         GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(256), 0, s->lv[0].f, s->lv[0].df, s->colpart,
                   C, (long long)nV, rpb);
         st = gf::gemm(ctx, true, false, C, FD, nV, s->lv[0].df, C, 0, s->x, FD, 0, dH, FD, 0, 1, 1);

@@ -335,9 +335,10 @@ __global__ __launch_bounds__(256) void colsum_chunks(const float *__restrict__ p
         st4(tmp + (size_t)blockIdx.x * C + 4 * fl, t);
     }
 }
-__global__ void colsum_fold(const float *__restrict__ tmp, float *__restrict__ out, int C, int nblocks) {
-    __shared__ float red[256];
-    const int lanes = (C < 256) ? C : 256, rl = 256 / lanes;
+__global__ __launch_bounds__(1024) void colsum_fold(const float *__restrict__ tmp, float *__restrict__ out, int C, int nblocks) {
+    __shared__ float red[1024];
+    const int nt = (int)blockDim.x;  // 1024: sixteen row groups at C = 64 (a single workgroup keeps the fold ordered)
+    const int lanes = (C < nt) ? C : nt, rl = nt / lanes;
     const int f0 = threadIdx.x % lanes, rr = threadIdx.x / lanes;
     for (int fb = 0; fb < C; fb += lanes) {
         const int f = fb + f0;
@@ -672,7 +673,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     {
         const int rpb = 256, nb = (pairs + rpb - 1) / rpb;  // s->colpart holds (max rows / 1024 + 1) x C floats >= nb x C
         GF_LAUNCH(ctx, "smpf_colsum", colsum_chunks, dim3(nb), dim3(256), 0, d.dbpart, s->colpart, C, (long long)pairs, rpb);
-        GF_LAUNCH(ctx, "smpf_colsum_fold", colsum_fold, dim3(1), dim3(256), 0, s->colpart, dbl, C, nb);
+        GF_LAUNCH(ctx, "smpf_colsum_fold", colsum_fold, dim3(1), dim3(1024), 0, s->colpart, dbl, C, nb);
     }
     // The weight-gradient products below read T and dO and write only dWst / dK_l: they run on the handle's second stream
     // while this stream continues with the table-gradient chain (dT GEMM -> tables-backward -> consumer gather).

@@ -61,7 +61,8 @@ struct gf_smp {
     float *sh = nullptr, *vf = nullptr;  // [nNodes][C] readout pre/post activation
     float *g = nullptr;      // [nMol][C] graph features
     float *yhat = nullptr, *dy = nullptr;  // [nMol]
-    float *colpart = nullptr;  // partial column sums for bias gradients
+    float *colpart = nullptr;  // partial column sums for bias gradients, [colpart_rows][C]
+    size_t colpart_rows = 0;
     int *top_node_mol = nullptr, *mol_ptr = nullptr, *mol_nodes = nullptr;
     // device buffers of the current batch come from a pool that survives gf_smp_prepare: a training loop prepares a new
     // batch every step, and hipMalloc of the level buffers (GBs) cost 4x the host graph preparation itself
