@@ -369,6 +369,17 @@ __global__ void momentum_step(float *__restrict__ p, const float *__restrict__ g
     }
 }
 
+// the same per node only: dsh[n][:] = dy[mol(n)] * W[:] * lrelu'(sh[n][:]) -- the fused top level reads this vector instead
+// of a broadcast copy of it at every (i,j)
+__global__ void readout_backward_nodevec(const float *__restrict__ dy, const float *__restrict__ W, const float *__restrict__ sh,
+                                         const int *__restrict__ node_mol, float *__restrict__ dsh, int C, size_t total) {
+    GRID_STRIDE(i, total) {
+        const int f = i % C;
+        const size_t n = i / C;
+        dsh[i] = dy[node_mol[n]] * W[f] * (sh[i] > 0.f ? 1.f : kAlpha);
+    }
+}
+
 __global__ void zero_f32(float *p, size_t n) { GRID_STRIDE(i, n) p[i] = 0.f; }
 
 size_t param_count(const gfsmp::Config &c);
@@ -831,6 +842,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     if (st != GF_OK) return st;
     st = gf::upload(s, &s->vf, nullptr, (size_t)top.nNodes * C);
     if (st != GF_OK) return st;
+    st = gf::upload(s, &s->dsh, nullptr, (size_t)top.nNodes * C);
+    if (st != GF_OK) return st;
     st = gf::upload(s, &s->g, nullptr, (size_t)nMol * C);
     if (st != GF_OK) return st;
     st = gf::upload(s, &s->yhat, nullptr, (size_t)nMol);
@@ -951,14 +964,20 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     gf_status st;
     const gfsmp::LevelLayout &top = B.level[L];
     GF_LAUNCH(ctx, "smp_readout_dW", gf::readout_dW, dim3(1), dim3(1024), 0, s->dy, s->g, dW, C, B.nMol);
-    GF_LAUNCH(ctx, "smp_readout_bwd", gf::readout_backward_nodes, dim3(top.nNodes), dim3(256), 0, s->dy, W, s->sh,
-              s->top_node_mol, s->lv[L].node_s, s->lv[L].node_row, s->lv[L].df, C);
+    const bool top_fused = s->fused && gf::smp_fused_supported(s, L);
+    if (top_fused) {
+        GF_LAUNCH(ctx, "smp_readout_bwd", gf::readout_backward_nodevec, dim3(gf::grid_for((size_t)top.nNodes * C)), dim3(256), 0, s->dy,
+                  W, s->sh, s->top_node_mol, s->dsh, C, (size_t)top.nNodes * C);
+    } else {
+        GF_LAUNCH(ctx, "smp_readout_bwd", gf::readout_backward_nodes, dim3(top.nNodes), dim3(256), 0, s->dy, W, s->sh,
+                  s->top_node_mol, s->lv[L].node_s, s->lv[L].node_row, s->lv[L].df, C);
+    }
     gf::ensure_side_stream(s);
     for (int l = L; l >= 1; --l) {
         const gfsmp::LevelLayout &h = B.level[l];
         const gf_smp::DevLevel &d = s->lv[l];
         if (s->fused && gf::smp_fused_supported(s, l)) {
-            st = gf::smp_fused_backward_level(s, l, K[l], dK[l], db[l]);
+            st = gf::smp_fused_backward_level(s, l, K[l], dK[l], db[l], (l == L && top_fused) ? s->dsh : nullptr);
             if (st != GF_OK) return st;
         } else {
         // dZ = dF * lrelu'(z) in place; db_l += column sums

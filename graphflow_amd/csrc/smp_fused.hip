@@ -265,6 +265,8 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
 // ---------------------------------------------------------------------------------------------------------------
 template <int LPC>
 __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restrict__ F, const float *__restrict__ dF,
+                                                            const float *__restrict__ node_dF,  // [nodes][C] or null: dF is
+                                                            // the same C-vector at every (x,y) of a node (readout broadcast)
                                                             const float *__restrict__ A, float *__restrict__ dO,
                                                             float *__restrict__ dVout, float *__restrict__ dSpart,
                                                             float *__restrict__ dbpart, Ragged R, int C, int nwin) {
@@ -282,9 +284,10 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AdjLds L = load_adjacency<true>(smem, A + rowbase, N);  // L.A[e][y] = A+[y][e]
     float *sDz = smem + adj_lds_floats(N);  // [N][CW]
+    const f4 gnode = node_dF ? ld4(node_dF + (size_t)W.node * C + fc) : splat(0.f);
     for (int y = grp; y < N; y += NGRP) {
         const size_t row = rowbase + (size_t)x * N + y;
-        const f4 fv = ld4(F + row * C + fc), g = ld4(dF + row * C + fc);
+        const f4 fv = ld4(F + row * C + fc), g = node_dF ? gnode : ld4(dF + row * C + fc);
         f4 dz;
 #pragma unroll
         for (int j = 0; j < 4; ++j) dz[j] = fok ? g[j] * (fv[j] > 0.f ? 1.f : kAlphaF) : 0.f;
@@ -650,7 +653,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
 }
 
 // df_l is given in d.df; produces dP in s->P, accumulates dK_l and db_l; the caller then runs the promotion backward.
-gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl) {
+gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl, const float *node_df) {
     gf_ctx *ctx = s->ctx;
     const gfsmp::LevelLayout &h = s->lay.level[l];
     const gf_smp::DevLevel &d = s->lv[l];
@@ -666,7 +669,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         st = opt_in_lds(ctx, smp_combine_bwd<16>, lds, &granted);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.pairs * nwin)), dim3(kThreads), lds, d.f, d.df,
-                  d.adj, dO, d.dVout, d.dSpart, d.dbpart, ragged_for(d, 0, h.buckets.back().s), C, nwin);
+                  node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, ragged_for(d, 0, h.buckets.back().s), C, nwin);
     }
     GF_LAUNCH(ctx, "smpf_node_sum", smp_node_sum, dim3(nodes), dim3(64), 0, d.dSpart, d.dSout, d.node_s, d.node_pair, C);
     // bias gradient: column sums of the per-(node,x) partials

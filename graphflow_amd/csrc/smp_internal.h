@@ -59,6 +59,7 @@ struct gf_smp {
     float *x = nullptr;      // [nVertices][FD]
     float *P = nullptr;      // shared promotion / dP buffer, max over levels of ppos*C
     float *sh = nullptr, *vf = nullptr;  // [nNodes][C] readout pre/post activation
+    float *dsh = nullptr;                // [nNodes][C] gradient of sh (the fused top level reads it per node)
     float *g = nullptr;      // [nMol][C] graph features
     float *yhat = nullptr, *dy = nullptr;  // [nMol]
     float *colpart = nullptr;  // partial column sums for bias gradients, [colpart_rows][C]
@@ -91,6 +92,7 @@ struct gf_smp {
 namespace gf {
 bool smp_fused_supported(const gf_smp *s, int l);
 gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float *bl);
-gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl);
+// node_df != nullptr (top level): df_l is the same C-vector at every position of a node, given as [nodes][C]
+gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl, const float *node_df);
 }
 #endif
