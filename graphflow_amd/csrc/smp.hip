@@ -786,7 +786,10 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         const gfsmp::LevelLayout &h = B.level[l];
         gf_smp::DevLevel &d = s->lv[l];
         UP(d.node_s, h.node_s);
+        UP(d.node_center, h.node_center);
         st = gf::upload(s, &d.node_row, &h.node_row[0], h.node_row.size());
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &d.node_pair, &h.node_pair[0], h.node_pair.size());
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.f, nullptr, (size_t)h.rows * C);
         if (st != GF_OK) return st;
@@ -794,8 +797,6 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (st != GF_OK) return st;
         if (l == 0) continue;
         st = gf::upload(s, &d.node_p, &h.node_p[0], h.node_p.size());
-        if (st != GF_OK) return st;
-        st = gf::upload(s, &d.node_pair, &h.node_pair[0], h.node_pair.size());
         if (st != GF_OK) return st;
         UP(d.adj, h.adj);
         UP(d.rsum, h.rsum);
@@ -805,6 +806,18 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         UP(d.pair_node, h.pair_node);
         UP(d.pair_src_s, h.pair_src_s);
         UP(d.cons_s, h.cons_s);
+        UP(d.cons_a, h.cons_a);
+        st = gf::upload(s, &d.pair_src_pair, &h.pair_src_pair[0], h.pair_src_pair.size());
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &d.cons_row, h.cons_row.empty() ? nullptr : &h.cons_row[0], h.cons_row.size());
+        if (st != GF_OK) return st;
+        {
+            float **cb[] = {&d.Fdc, &d.Gc, &d.dGc, &d.dFdc};
+            for (int q = 0; q < 4; ++q) {
+                st = gf::upload(s, cb[q], nullptr, (size_t)B.level[l - 1].pairs * 2 * C);
+                if (st != GF_OK) return st;
+            }
+        }
         st = gf::upload(s, &d.pair_src_row, &h.pair_src_row[0], h.pair_src_row.size());
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.cons_ptr, &h.cons_ptr[0], h.cons_ptr.size());

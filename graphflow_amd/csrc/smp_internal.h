@@ -45,6 +45,9 @@ struct gf_smp {
         int *pair_node = nullptr, *pair_src_s = nullptr, *cons_s = nullptr;
         long long *pair_src_row = nullptr, *cons_ptr = nullptr, *cons_slab = nullptr, *cons_inv_off = nullptr;
         short *pi = nullptr, *inv = nullptr;
+        long long *pair_src_pair = nullptr, *cons_row = nullptr;  // compact diagonal path (smp_prep.h)
+        int *node_center = nullptr, *cons_a = nullptr;
+        float *Fdc = nullptr, *Gc = nullptr, *dGc = nullptr, *dFdc = nullptr;  // [pairs of level l-1][2C] each
         float *f = nullptr, *df = nullptr, *Q = nullptr;  // activations [rows][C], their gradient, contraction out [rows][18C]
         // fused level (smp_fused.hip): small per-(node,x) / per-node tables and stacked weights
         float *Vt = nullptr, *dVt = nullptr;        // [pairs][4C]  rowsum_a | colsum_b | D8 | D11

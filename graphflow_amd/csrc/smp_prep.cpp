@@ -207,6 +207,15 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         lv.rows = row;
         lv.ppos = pp;
         lv.pairs = pair;
+        lv.node_center.assign(totalV, 0);
+        for (int n = 0; n < totalV; ++n) {
+            const std::vector<int> &fld = out->mols[lv.node_mol[n]].phi[l][lv.node_vertex[n]];
+            const int v = lv.node_vertex[n];
+            int c = -1;
+            for (size_t i = 0; i < fld.size(); ++i)
+                if (fld[i] == v) c = (int)i;
+            lv.node_center[n] = c;  // always found: the centre survives the cap (SMP_omega.h:476-507)
+        }
     }
     out->top_node_of_vertex = node_of[L];
     const std::chrono::steady_clock::time_point t_order = std::chrono::steady_clock::now();
@@ -222,6 +231,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         lv.quad_b0.clear();
         lv.pair_node.resize((size_t)lv.pairs);
         lv.pair_src_row.resize((size_t)lv.pairs);
+        lv.pair_src_pair.resize((size_t)lv.pairs);
         lv.pair_src_s.resize((size_t)lv.pairs);
         lv.pi.resize((size_t)lv.rows);
         std::vector<int> pair_src_node((size_t)lv.pairs);
@@ -273,6 +283,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 lv.pair_node[(size_t)e] = n;
                 pair_src_node[(size_t)e] = src;
                 lv.pair_src_row[(size_t)e] = prev.node_row[src];
+                lv.pair_src_pair[(size_t)e] = prev.node_pair[src];
                 lv.pair_src_s[(size_t)e] = (int)wf.size();
                 // selection map: X[i][k] = [phi_l(v)[i] == phi_{l-1}(w)[k]]   (:461-474)
                 for (size_t k = 0; k < wf.size(); ++k) pos[wf[k]] = (int16_t)k;
@@ -289,6 +300,8 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         for (int64_t e = 0; e < lv.pairs; ++e) cons_pair[(size_t)cursor[(size_t)pair_src_node[(size_t)e]]++] = e;
         lv.cons_slab.assign((size_t)lv.pairs, 0);
         lv.cons_s.assign((size_t)lv.pairs, 0);
+        lv.cons_row.assign((size_t)lv.pairs, 0);
+        lv.cons_a.assign((size_t)lv.pairs, 0);
         lv.cons_inv_off.assign((size_t)lv.pairs, 0);
         int64_t inv_total = 0;
         for (int w = 0; w < prev.nNodes; ++w)
@@ -304,6 +317,8 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 const int s = lv.node_s[n], a = (int)(e - lv.node_pair[n]);
                 lv.cons_slab[(size_t)c] = lv.node_p[n] + (int64_t)a * s * s;
                 lv.cons_s[(size_t)c] = s;
+                lv.cons_row[(size_t)c] = lv.node_row[n];
+                lv.cons_a[(size_t)c] = a;
                 int16_t *iv = &lv.inv[(size_t)lv.cons_inv_off[(size_t)c]];
                 for (int p = 0; p < s; ++p) {
                     const int16_t k = lv.pi[(size_t)lv.node_row[n] + (size_t)a * s + p];

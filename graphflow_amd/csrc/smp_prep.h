@@ -59,6 +59,12 @@ struct LevelLayout {
     std::vector<int64_t> pair_src_row;  // [pairs] first row of the source node's tensor in level l-1
     std::vector<int> pair_src_s;       // [pairs]
     std::vector<int16_t> pi;           // [rows]  pi[node_row[n] + a*s + p] = index of phi_l(v)[p] in phi_{l-1}(w_a), or -1
+    // compact diagonal path (smp_fused.hip): the two tables D_bb[x,y] = P[x,y,y] and D_ac[x,y] = P[x,y,x] are plain gathers
+    // of the diagonal / the centre column of f_{l-1}[w_x], so their block products run on the sum-s rows of the level below
+    std::vector<int64_t> pair_src_pair; // [pairs] node_pair (level l-1) of the source node of pair e
+    std::vector<int> node_center;       // [nNodes] position of the node's own vertex inside its receptive field (every level)
+    std::vector<int64_t> cons_row;      // [pairs] node_row (level l) of the consumer's node
+    std::vector<int> cons_a;            // [pairs] the consumer's neighbour index a
     // backward gather, indexed by the SOURCE node (level l-1): consumers = pairs that read it
     std::vector<int64_t> cons_ptr;      // [nNodes(l-1) + 1]
     std::vector<int64_t> cons_slab;     // [pairs] position offset (units of C floats) of the consumer's [s][s] slab in P
