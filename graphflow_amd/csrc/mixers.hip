@@ -10,6 +10,9 @@
 // staged through padded LDS, next tile's global loads issued before the current tile's MFMAs.  Reductions over a
 // long K with a small output (dB of the K-projection: K = sum s^2 rows) are split over K into a workspace and
 // summed by a second kernel in a fixed order, so results are deterministic (no atomics).
+#include <algorithm>
+#include <cstdlib>
+
 #include "smp_internal.h"
 
 namespace gf {
@@ -55,6 +58,12 @@ struct GroupedArgs {
     int tiles_per_panel;          // sum over groups of tiles in one panel
     int tile_prefix[kMaxGroups];  // first tile of each group inside a panel
     int panel_is_split;           // 0: panel = M tile (tile index = N tile); 1: panel = split (tile index = M tile, N tile 0)
+    // Row-panel launches order their tiles in windows of `window` panels, tile-type-major inside a window: the workgroups
+    // that are co-resident on a CU (four consecutive ones of an XCD) then run the SAME kind of tile (same number of
+    // k-steps) of neighbouring panels, instead of the 8/4/2/2-step tiles of one panel whose phases line up -- with four
+    // tiles per panel that resonance cost 40 % of the table-gradient GEMM.  The panel's tiles stay within window * tiles
+    // consecutive workgroups of one XCD, so they still share its L2.
+    int npanels, window;
 };
 
 // Position of k inside an LDS row: even k first, then odd k.  The f32 MFMA 32x32x2 gives lane (i, h = lane >> 5) the
@@ -348,7 +357,15 @@ template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(kThreads, 4) void gemm_f32_mfma_grouped(GroupedArgs ga, int nsplits) {
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
     const unsigned tile = xcd_tile_id(blockIdx.x, gridDim.x);
-    const int panel = (int)(tile / ga.tiles_per_panel), t = (int)(tile % ga.tiles_per_panel);
+    int panel = (int)(tile / ga.tiles_per_panel), t = (int)(tile % ga.tiles_per_panel);
+    if (!ga.panel_is_split && ga.window > 1) {
+        const int per_window = ga.window * ga.tiles_per_panel;
+        const int w = (int)(tile / per_window), r = (int)(tile % per_window);
+        const int first = w * ga.window;
+        const int wl = (ga.npanels - first < ga.window) ? ga.npanels - first : ga.window;  // the last window may be short
+        t = r / wl;
+        panel = first + r % wl;
+    }
     int grp = 0;
 #pragma unroll
     for (int i = 1; i < kMaxGroups; ++i)
@@ -512,6 +529,9 @@ gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs
     GroupedArgs ga;
     ga.ngroups = n;
     ga.panel_is_split = 0;
+    ga.npanels = (rows + BM - 1) / BM;
+    ga.window = 8;
+    if (const char *e = std::getenv("GF_GEMM_WINDOW")) ga.window = std::max(1, std::atoi(e));
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         if (specs[i].M != rows) return fail(ctx, GF_ERR_INVALID, "gemm_grouped_rows: group %d has M=%d, expected %d", i, specs[i].M, rows);
@@ -531,6 +551,8 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
     GroupedArgs ga;
     ga.ngroups = n;
     ga.panel_is_split = 1;
+    ga.npanels = 0;
+    ga.window = 1;
     int tiles = 0;
     size_t total = 0;
     for (int i = 0; i < n; ++i) {

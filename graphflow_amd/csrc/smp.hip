@@ -81,9 +81,29 @@ __global__ void promote_backward(const float *__restrict__ dP, float *__restrict
                                  const int *__restrict__ prev_s, const long long *__restrict__ prev_row,
                                  const long long *__restrict__ cons_ptr, const long long *__restrict__ cons_slab,
                                  const int *__restrict__ cons_s, const long long *__restrict__ cons_inv_off,
-                                 const short *__restrict__ inv, int C) {
+                                 const short *__restrict__ inv, int C,
+                                 // compact-diagonal variant of the fused level (smp_fused.hip), else null: the gradients of
+                                 // f[w][p,p] and f[w][p,c_w] arrive as dFdc[node_pair[w] + p] = [ .. | .. ]
+                                 const float *__restrict__ dFdc, const long long *__restrict__ prev_pair,
+                                 const int *__restrict__ prev_center) {
     const int w = blockIdx.x;
     const int sw = prev_s[w];
+    const float *dfd = dFdc ? dFdc + (size_t)prev_pair[w] * 2 * C : nullptr;
+    const int cw = dFdc ? prev_center[w] : -1;
+    auto diag_terms = [&](int p, int q, int q4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dfd) {
+            if (p == q) {
+                const float4 v = reinterpret_cast<const float4 *>(dfd + (size_t)p * 2 * C)[q4];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            if (q == cw) {
+                const float4 v = reinterpret_cast<const float4 *>(dfd + (size_t)p * 2 * C + C)[q4];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+        }
+        return t;
+    };
     float *dst = dfprev + prev_row[w] * C;
     const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
     if ((C & 3) == 0 && sw <= kPromoteMaxS) {
@@ -108,7 +128,7 @@ __global__ void promote_backward(const float *__restrict__ dP, float *__restrict
                 if (i >= total4) break;
                 const int q4 = i % Q, pq = i / Q;
                 const int p = pq / sw, q = pq - p * sw;
-                float4 acc = (cb == c0) ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4 *>(dst)[i];
+                float4 acc = (cb == c0) ? diag_terms(p, q, q4) : reinterpret_cast<float4 *>(dst)[i];
                 for (int e0 = 0; e0 < nc; e0 += 4) {
                     float4 v[4];
                     float m[4];
@@ -142,7 +162,7 @@ __global__ void promote_backward(const float *__restrict__ dP, float *__restrict
         for (int i = threadIdx.x; i < total4; i += blockDim.x) {
             const int q4 = i % Q, pq = i / Q;
             const int p = pq / sw, q = pq - p * sw;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 acc = diag_terms(p, q, q4);
             for (long long e = c0; e < c1; ++e) {
                 const short *iv = inv + cons_inv_off[e];
                 const int ib = iv[p], ic = iv[q];
@@ -1015,8 +1035,10 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
             if (st != GF_OK) return st;
         }
         const gf_smp::DevLevel &pv = s->lv[l - 1];
+        const bool diag_level = s->fused && gf::smp_fused_supported(s, l);  // its D_bb / D_ac gradients arrive through dFdc
         GF_LAUNCH(ctx, "smp_promote_bwd", gf::promote_backward, dim3(B.level[l - 1].nNodes), dim3(256), 0, s->P, pv.df,
-                  pv.node_s, pv.node_row, d.cons_ptr, d.cons_slab, d.cons_s, d.cons_inv_off, d.inv, C);
+                  pv.node_s, pv.node_row, d.cons_ptr, d.cons_slab, d.cons_s, d.cons_inv_off, d.inv, C,
+                  diag_level ? d.dFdc : (const float *)nullptr, pv.node_pair, pv.node_center);
     }
     if (s->side_pending) {  // join: the weight gradients (and their use of the split-K workspace) are complete
         GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));

@@ -28,14 +28,14 @@ constexpr float kAlphaF = 0.01f;
 __device__ __forceinline__ float lreluf(float z) { return z > 0.f ? z : kAlphaF * z; }
 
 // column blocks of the table matrix T [rows][6C]
-enum { T_DAC = 0, T_SAB = 1, T_SBC = 2, T_DBB = 3, T_T6 = 4, T_T10 = 5, T_COLS = 6 };
+enum { T_SAB = 0, T_SBC = 1, T_T6 = 2, T_T10 = 3, T_COLS = 4 };
 // column blocks of the projected matrix O [rows][3C].  O_LOC = tot O_tot + tr O_tr + O_dir: the per-node factors tot and
 // tr (the level's rowscale table) are applied to the T operand inside the GEMM, so the three row-local products
 // accumulate into one block.
 enum { O_LOC = 0, O_Z = 1, O_ZP = 2, O_COLS = 3 };
 // stacked weight layout: position p holds block K^(kperm[p]); groups are contiguous
 //   [0,2) tot | [2,3) tr | [3,5) dir | [5,8) Z | [8,10) Z' | [10,14) V | [14,18) S
-__constant__ int c_kperm[18] = {0, 2, 6, 5, 9, 8, 12, 15, 16, 11, 1, 3, 7, 10, 4, 13, 14, 17};
+__constant__ int c_kperm[18] = {0, 2, 6, 5, 9, 8, 12, 11, 15, 16, 1, 3, 7, 10, 4, 13, 14, 17};
 
 // ---------------------------------------------------------------------------------------------------------------
 // T1w: tables-forward (s <= 4 NI, NI in {1, 2, 4, 8}).  One WAVE per (node, b): a workgroup covers four consecutive b of one
@@ -134,10 +134,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
             float *trow = T + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + f;  // table row (a, b)
             if (cg == 0) {
                 st4(trow + T_SAB * C, sab);
-                st4(trow + T_DBB * C, dcur);
                 if (a == b) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);
-            } else if (cg == 1) {
-                st4(trow + T_DAC * C, dcur);
             } else if (cg == 2) {
                 st4(trow + T_T6 * C, t6);
             } else if (cg == 3) {
@@ -178,7 +175,9 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
 __global__ __launch_bounds__(256) void smp_vectors(const float *__restrict__ T, float *__restrict__ Vt,
                                                    const float *__restrict__ scal, float *__restrict__ St,
                                                    const int *__restrict__ node_s, const long long *__restrict__ node_row,
-                                                   const long long *__restrict__ node_pair, int C) {
+                                                   const long long *__restrict__ node_pair, int C,
+                                                   const float *__restrict__ Fdc, const long long *__restrict__ pair_src_pair,
+                                                   const short *__restrict__ pi) {
     const int n = blockIdx.x;
     const int s = node_s[n], nl = C / 4;
     const size_t rowbase = (size_t)node_row[n], pairbase = (size_t)node_pair[n];
@@ -187,12 +186,79 @@ __global__ __launch_bounds__(256) void smp_vectors(const float *__restrict__ T, 
         const int fl = i % nl, x = i / nl;
         const float *t = T + (rowbase + (size_t)x * s) * (size_t)(T_COLS * C) + 4 * fl;
         const f4 rs = batched_sum(t + T_SAB * C, (size_t)T_COLS * C, 0, s, one);
-        const f4 d8 = batched_sum(t + T_DBB * C, (size_t)T_COLS * C, 0, s, one);
+        f4 d8;
+        {  // D8[x] = sum_b P[x,b,b] = sum over the images pi_x(b) of f_{l-1}[w_x][p,p]  (compact table Fdc)
+            const float *fd = Fdc + (size_t)pair_src_pair[pairbase + x] * 2 * C + 4 * fl;
+            const short *map = pi + rowbase + (size_t)x * s;
+            d8 = splat(0.f);
+            for (int b0 = 0; b0 < s; b0 += 8) {
+                f4 v[8];
+                bool ok[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = (b0 + j < s) ? map[b0 + j] : -1;
+                    ok[j] = p >= 0;
+                    v[j] = ld4(fd + (size_t)(ok[j] ? p : 0) * 2 * C);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (ok[j]) d8 += v[j];
+            }
+        }
         st4(Vt + (pairbase + x) * 4 * (size_t)C + 0 * C + 4 * fl, rs);
         st4(Vt + (pairbase + x) * 4 * (size_t)C + 2 * C + 4 * fl, d8);
     }
     for (int i = threadIdx.x; i < C; i += blockDim.x)  // 4C floats = C float4
         st4(St + (size_t)n * 4 * C + 4 * i, batched_sum(scal + pairbase * 4 * (size_t)C + 4 * i, (size_t)4 * C, 0, s, one));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Compact-diagonal variant.  D_bb[x,y] = P[x,y,y] = f_{l-1}[w_x][p,p] and D_ac[x,y] = P[x,y,x] = f_{l-1}[w_x][p,c] with
+// p = pi_x(y) and c = the position of w_x's own vertex in its receptive field: both tables are gathers of sum-s vectors per
+// source node.  So D_bb K15 and D_ac K16 are computed ONCE on those vectors ([pairs of level l-1] rows instead of
+// [rows of level l]: 24x fewer at level 3 of cfg3), combine-forward gathers the products, and the reverse sweep collects
+// their gradients with a consumer gather.  T and dT lose two of their six blocks and the row GEMMs two of ten products.
+//   Fdc[pr] = [ f[w][p,p] | f[w][p,c_w] ]   (pr = node_pair(l-1)[w] + p)        Gc = [ Fd K15 | Fc K16 ]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void diag_gather_fwd(const float *__restrict__ fprev, float *__restrict__ Fdc, const int *__restrict__ node_s,
+                                const long long *__restrict__ node_row, const long long *__restrict__ node_pair,
+                                const int *__restrict__ node_center, int C) {
+    const int w = blockIdx.x;
+    const int s = node_s[w], c = node_center[w], nl = C / 4;
+    const float *src = fprev + (size_t)node_row[w] * C;
+    float *dst = Fdc + (size_t)node_pair[w] * 2 * C;
+    for (int i = threadIdx.x; i < s * nl; i += blockDim.x) {
+        const int fl = i % nl, p = i / nl;
+        st4(dst + (size_t)p * 2 * C + 4 * fl, ld4(src + ((size_t)p * s + p) * C + 4 * fl));
+        st4(dst + (size_t)p * 2 * C + C + 4 * fl, ld4(src + ((size_t)p * s + c) * C + 4 * fl));
+    }
+}
+
+// dGc[pr] = [ sum_cons dU_n[a, inv(p)] | sum_cons dU_n[inv(p), a] ]  over the consumers (n, a) of source node w, in consumer
+// order (deterministic).  dU_n[x, e] is the Z block of dO at row (x, e) (written by combine-backward).
+__global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict__ dGc, const int *__restrict__ prev_s,
+                                const long long *__restrict__ prev_pair, const long long *__restrict__ cons_ptr,
+                                const long long *__restrict__ cons_row, const int *__restrict__ cons_s,
+                                const int *__restrict__ cons_a, const long long *__restrict__ cons_inv_off,
+                                const short *__restrict__ inv, int C) {
+    const int w = blockIdx.x;
+    const int sw = prev_s[w], nl = C / 4;
+    const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
+    float *dst = dGc + (size_t)prev_pair[w] * 2 * C;
+    for (int i = threadIdx.x; i < sw * nl; i += blockDim.x) {
+        const int fl = i % nl, p = i / nl;
+        f4 a15 = splat(0.f), a16 = splat(0.f);
+        for (long long e = c0; e < c1; ++e) {
+            const int ip = inv[cons_inv_off[e] + p];
+            if (ip < 0) continue;
+            const int s = cons_s[e], a = cons_a[e];
+            const float *base = dO + (size_t)cons_row[e] * (O_COLS * C) + O_Z * C + 4 * fl;
+            a15 += ld4(base + ((size_t)a * s + ip) * (size_t)(O_COLS * C));
+            a16 += ld4(base + ((size_t)ip * s + a) * (size_t)(O_COLS * C));
+        }
+        st4(dst + (size_t)p * 2 * C + 4 * fl, a15);
+        st4(dst + (size_t)p * 2 * C + C + 4 * fl, a16);
+    }
 }
 
 // stacked[p] = K^(kperm[p])  (gather), or  dK^(kperm[p]) += dstacked[p]  (scatter-add).  Block k of the level weight is
@@ -220,7 +286,9 @@ template <int LPC>
 __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restrict__ O, const float *__restrict__ A,
                                                             const float *__restrict__ Vout, const float *__restrict__ Sout,
                                                             const float *__restrict__ bias, float *__restrict__ F,
-                                                            Ragged R, int C, int nwin) {
+                                                            Ragged R, int C, int nwin, const float *__restrict__ Gc,
+                                                            const long long *__restrict__ pair_src_pair,
+                                                            const short *__restrict__ pi) {
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
     const int tid = threadIdx.x;
@@ -238,7 +306,15 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
     for (int e = grp; e < N; e += NGRP) {
         const f4 z = ld4(O + (rowbase + (size_t)x * N + e) * (size_t)(O_COLS * C) + O_Z * C + fc);
         const f4 zp = ld4(O + (rowbase + (size_t)e * N + x) * (size_t)(O_COLS * C) + O_ZP * C + fc);
-        st4(sU + e * CW + 4 * fl, fok ? z + zp : splat(0.f));
+        f4 u = z + zp;
+        {  // + D_bb[x,e] K15 + D_ac[e,x] K16, gathered from the compact products of the level below
+            const int pxe = pi[rowbase + (size_t)x * N + e], pex = pi[rowbase + (size_t)e * N + x];
+            const f4 g15 = ld4(Gc + (size_t)(pair_src_pair[pairbase + x] + (pxe >= 0 ? pxe : 0)) * 2 * C + fc);
+            const f4 g16 = ld4(Gc + (size_t)(pair_src_pair[pairbase + e] + (pex >= 0 ? pex : 0)) * 2 * C + C + fc);
+            if (pxe >= 0) u += g15;
+            if (pex >= 0) u += g16;
+        }
+        st4(sU + e * CW + 4 * fl, fok ? u : splat(0.f));
     }
     __syncthreads();
     const f4 vout = ld4(Vout + (pairbase + x) * (size_t)C + fc);
@@ -416,7 +492,8 @@ __global__ __launch_bounds__(kThreads, 3) void smp_tables_bwd(const float *__res
             const float *t = dT + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + fc;  // table row (a, b)
             const float *dva = dVt + (pairbase + a) * 4 * (size_t)C + fc;
             f4 x = ld4(t + T_SAB * C) + ld4(dva + 0 * C) + dcol + dtotal;
-            f4 z1 = ld4(t + T_DBB * C) + ld4(dva + 2 * C) + ds15;
+            // (the D_bb / D_ac table gradients reach df_{l-1} through the compact path: dFdc in the consumer gather)
+            f4 z1 = ld4(dva + 2 * C) + ds15;
             if (a == b) {
                 x += ds14;
                 z1 += ds18;
@@ -425,7 +502,7 @@ __global__ __launch_bounds__(kThreads, 3) void smp_tables_bwd(const float *__res
             st4(sX + a * CW + 4 * fl, x * m);
             st4(sG5 + a * CW + 4 * fl, ld4(t + T_T6 * C) * m);
             st4(sZ1 + a * CW + 4 * fl, z1 * m);
-            st4(sZ2 + a * CW + 4 * fl, (ld4(t + T_DAC * C) + dd11) * m);
+            st4(sZ2 + a * CW + 4 * fl, dd11 * m);
         }
     }
     __syncthreads();
@@ -584,6 +661,11 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         if (st != GF_OK) return st;
     }
     GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C, s->cfg.custom_matmul);
+    {  // Fdc = [f[w][p,p] | f[w][p,c_w]] of the level below (read by smp_vectors and by the compact products)
+        const gf_smp::DevLevel &pv = s->lv[l - 1];
+        GF_LAUNCH(ctx, "smpf_diag_gather", diag_gather_fwd, dim3(s->lay.level[l - 1].nNodes), dim3(256), 0, pv.f, d.Fdc, pv.node_s,
+                  pv.node_row, pv.node_pair, pv.node_center, C);
+    }
     // The per-(node,x) vectors and per-node scalars (smp_vectors + two small GEMMs) only need T and the stacked weights:
     // they run on the handle's second stream beside the big row GEMM and are joined before combine-forward.
     struct StreamSwap {
@@ -601,7 +683,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         swap.on = true;
     }
     GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(256), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
-              d.node_pair, C);
+              d.node_pair, C, d.Fdc, d.pair_src_pair, d.pi);
     const size_t CC = (size_t)C * C;
     st = gemm(ctx, false, false, pairs, C, 4 * C, d.Vt, 4 * C, 0, d.Wst + 10 * CC, C, 0, d.Vout, C, 0, 1, 0);
     if (st != GF_OK) return st;
@@ -621,9 +703,10 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         GemmSpec sp[3] = {
             {T, d.Wst, O + O_LOC * C, rows, C, 5 * C, ldt, C, ldo, 3, {T_SAB * tC, T_SAB * tC, T_T6 * tC, 0}, {0 * wCC, 2 * wCC, 3 * wCC, 0},
              {2 * C, C, 2 * C, 0}, d.rowscale, 2, {0, 1, -1, -1}},
-            {T + T_SAB * C, d.Wst + 5 * CC, O + O_Z * C, rows, C, 3 * C, ldt, C, ldo, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0,
+            // Z = [S_ab|S_bc][K8;K12] (stack 5,6), Z' = S_ab K11 (stack 7); the D_bb K15 / D_ac K16 terms come from Gc
+            {T + T_SAB * C, d.Wst + 5 * CC, O + O_Z * C, rows, C, 2 * C, ldt, C, ldo, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0,
              {-1, -1, -1, -1}},
-            {T + T_DAC * C, d.Wst + 8 * CC, O + O_ZP * C, rows, C, 2 * C, ldt, C, ldo, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0,
+            {T + T_SAB * C, d.Wst + 7 * CC, O + O_ZP * C, rows, C, C, ldt, C, ldo, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0,
              {-1, -1, -1, -1}},
         };
         if (gemm_grouped_supported(sp, 3, false, false)) {
@@ -632,13 +715,20 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         } else {
             struct G { int tcol, kb, wpos, ocol, scol, acc; };
             const G gs[5] = {{T_SAB, 2, 0, O_LOC, 0, 0}, {T_SAB, 1, 2, O_LOC, 1, 1}, {T_T6, 2, 3, O_LOC, -1, 1},
-                             {T_SAB, 3, 5, O_Z, -1, 0}, {T_DAC, 2, 8, O_ZP, -1, 0}};
+                             {T_SAB, 2, 5, O_Z, -1, 0}, {T_SAB, 1, 7, O_ZP, -1, 0}};
             for (const G &g : gs) {
                 st = gemm_rs(ctx, false, false, rows, C, g.kb * C, T + g.tcol * C, ldt, 0, d.Wst + g.wpos * CC, C, 0, O + g.ocol * C, ldo,
                              0, 1, g.acc, d.rowscale, 2, g.scol);
                 if (st != GF_OK) return st;
             }
         }
+    }
+    {  // Gc = [Fd K15 | Fc K16] on the compact rows of the level below
+        const int prevPairs = (int)s->lay.level[l - 1].pairs;
+        st = gemm(ctx, false, false, prevPairs, C, C, d.Fdc, 2 * C, 0, d.Wst + 8 * CC, C, 0, d.Gc, 2 * C, 0, 1, 0);
+        if (st != GF_OK) return st;
+        st = gemm(ctx, false, false, prevPairs, C, C, d.Fdc + C, 2 * C, 0, d.Wst + 9 * CC, C, 0, d.Gc + C, 2 * C, 0, 1, 0);
+        if (st != GF_OK) return st;
     }
     if (s->side) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
     {
@@ -647,7 +737,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         st = opt_in_lds(ctx, smp_combine_fwd<16>, lds, &granted);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd<16>), dim3((unsigned)(h.pairs * nwin)), dim3(kThreads), lds, O, d.adj,
-                  d.Vout, d.Sout, bl, d.f, ragged_for(d, 0, h.buckets.back().s), C, nwin);
+                  d.Vout, d.Sout, bl, d.f, ragged_for(d, 0, h.buckets.back().s), C, nwin, d.Gc, d.pair_src_pair, d.pi);
     }
     return GF_OK;
 }
@@ -678,6 +768,23 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         GF_LAUNCH(ctx, "smpf_colsum", colsum_chunks, dim3(nb), dim3(256), 0, d.dbpart, s->colpart, C, (long long)pairs, rpb);
         GF_LAUNCH(ctx, "smpf_colsum_fold", colsum_fold, dim3(1), dim3(1024), 0, s->colpart, dbl, C, nb);
     }
+    {
+        // compact diagonal path: gradients of Gc by a consumer gather over dU (the Z block of dO), then the two C x C
+        // products on the compact rows: dFdc = [dG15 K15^T | dG16 K16^T] (added to df_{l-1} by the consumer gather of the
+        // caller), dK15 = Fd^T dG15, dK16 = Fc^T dG16 (stack positions 8, 9)
+        const gf_smp::DevLevel &pv = s->lv[l - 1];
+        const int prevNodes = s->lay.level[l - 1].nNodes, prevPairs = (int)s->lay.level[l - 1].pairs;
+        GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(256), 0, dO, d.dGc, pv.node_s, pv.node_pair,
+                  d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C);
+        for (int half = 0; half < 2; ++half) {
+            st = gemm(ctx, false, true, prevPairs, C, C, d.dGc + half * C, 2 * C, 0, d.Wst + (8 + half) * CC, C, 0, d.dFdc + half * C,
+                      2 * C, 0, 1, 0);
+            if (st != GF_OK) return st;
+            st = gemm(ctx, true, false, C, C, prevPairs, d.Fdc + half * C, 2 * C, 0, d.dGc + half * C, 2 * C, 0, d.dWst + (8 + half) * CC,
+                      C, 0, 1, 0);
+            if (st != GF_OK) return st;
+        }
+    }
     // The weight-gradient products below read T and dO and write only dWst / dK_l: they run on the handle's second stream
     // while this stream continues with the table-gradient chain (dT GEMM -> tables-backward -> consumer gather).
     struct StreamSwap {
@@ -698,7 +805,8 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     // five products share each split's row range of T and dO, and their partial images are folded by ONE ordered
     // reduction straight into the first ten stacked blocks.
     struct G { int tcol, kb, wpos, ocol, scol; };  // scol: T rows scaled by tot (0) / tr (1) for the row-local products
-    const G gs[5] = {{T_SAB, 2, 0, O_LOC, 0}, {T_SAB, 1, 2, O_LOC, 1}, {T_T6, 2, 3, O_LOC, -1}, {T_SAB, 3, 5, O_Z, -1}, {T_DAC, 2, 8, O_ZP, -1}};
+    // Z: [S_ab|S_bc] -> stack 5,6;  Z': S_ab -> stack 7;  positions 0..7 are contiguous for the ordered reduction
+    const G gs[5] = {{T_SAB, 2, 0, O_LOC, 0}, {T_SAB, 1, 2, O_LOC, 1}, {T_T6, 2, 3, O_LOC, -1}, {T_SAB, 2, 5, O_Z, -1}, {T_SAB, 1, 7, O_ZP, -1}};
     {
         GemmSpec sp[5];
         for (int i = 0; i < 5; ++i) {
@@ -707,7 +815,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
             sp[i] = z;
         }
         if (C <= 64 && gemm_grouped_supported(sp, 5, true, false)) {
-            st = gemm_grouped_splitk(ctx, sp, 5, rows, d.dWst, 0);  // stack positions 0..9 are contiguous in dWst
+            st = gemm_grouped_splitk(ctx, sp, 5, rows, d.dWst, 0);  // stack positions 0..7 are contiguous in dWst
             if (st != GF_OK) return st;
         } else {
             for (const G &g : gs) {
@@ -728,34 +836,29 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         swap.on = false;
         s->side_pending = true;
     }
-    // table gradients: dT_blk (+)= dO_blk W_blk^T; every column range is written once before it is accumulated into
-    //   cols [C,4C) = dZ [K8;K12;K15]^T ; [C,3C) += dO_tot [K0;K2]^T ; [C,2C) += dO_tr K6^T ;
-    //   [0,C) = dZ' K16^T ; [C,2C) += dZ' K11^T ; [4C,6C) = dO_dir [K5;K9]^T
+    // table gradients: dT_blk = sum over the dO blocks that feed it of  dO_blk W_blk^T
+    //   S_ab <- tot dO_loc K0^T + tr dO_loc K6^T + dZ K8^T + dZ' K11^T      S_bc <- tot dO_loc K2^T + dZ K12^T
+    //   [T6|T10] <- dO_loc [K5;K9]^T
     {
         // grouped: one group per output column block of dT, K segmented over the dO blocks that feed it (no read-modify-
         // write of dT, dO read once per panel); fallback: six launches that accumulate in a fixed order
         const long long oC = C, wCC = (long long)CC;
-        GemmSpec sp[5] = {
-            {dO, d.Wst, dT + T_DAC * C, rows, C, C, ldo, C, ldt, 1, {O_ZP * oC, 0, 0, 0}, {8 * wCC, 0, 0, 0}, {C, 0, 0, 0}, nullptr, 0,
-             {-1, -1, -1, -1}},
+        GemmSpec dg[3] = {
             {dO, d.Wst, dT + T_SAB * C, rows, C, 4 * C, ldo, C, ldt, 4, {O_LOC * oC, O_LOC * oC, O_Z * oC, O_ZP * oC},
-             {0 * wCC, 2 * wCC, 5 * wCC, 9 * wCC}, {C, C, C, C}, d.rowscale, 2, {0, 1, -1, -1}},
+             {0 * wCC, 2 * wCC, 5 * wCC, 7 * wCC}, {C, C, C, C}, d.rowscale, 2, {0, 1, -1, -1}},
             {dO, d.Wst, dT + T_SBC * C, rows, C, 2 * C, ldo, C, ldt, 2, {O_LOC * oC, O_Z * oC, 0, 0}, {1 * wCC, 6 * wCC, 0, 0}, {C, C, 0, 0},
              d.rowscale, 2, {0, -1, -1, -1}},
-            {dO, d.Wst, dT + T_DBB * C, rows, C, C, ldo, C, ldt, 1, {O_Z * oC, 0, 0, 0}, {7 * wCC, 0, 0, 0}, {C, 0, 0, 0}, nullptr, 0,
-             {-1, -1, -1, -1}},
             {dO, d.Wst, dT + T_T6 * C, rows, 2 * C, C, ldo, C, ldt, 1, {O_LOC * oC, 0, 0, 0}, {3 * wCC, 0, 0, 0}, {C, 0, 0, 0}, nullptr, 0,
              {-1, -1, -1, -1}},
         };
-        if (gemm_grouped_supported(sp, 5, false, true)) {
-            st = gemm_grouped_rows(ctx, false, true, sp, 5, rows);
+        if (gemm_grouped_supported(dg, 3, false, true)) {
+            st = gemm_grouped_rows(ctx, false, true, dg, 3, rows);
             if (st != GF_OK) return st;
         } else {
             struct H { int ocol, wpos, kb, tcol, acc, scol; };
-            const H hs[8] = {{O_Z, 5, 3, T_SAB, 0, -1}, {O_LOC, 0, 1, T_SAB, 1, 0}, {O_LOC, 1, 1, T_SBC, 1, 0}, {O_LOC, 2, 1, T_SAB, 1, 1},
-                             {O_ZP, 8, 1, T_DAC, 0, -1}, {O_ZP, 9, 1, T_SAB, 1, -1}, {O_LOC, 3, 2, T_T6, 0, -1}, {0, 0, 0, 0, 0, 0}};
-            for (int i = 0; i < 7; ++i) {
-                const H &g = hs[i];
+            const H hs[6] = {{O_Z, 5, 2, T_SAB, 0, -1}, {O_LOC, 0, 1, T_SAB, 1, 0}, {O_LOC, 1, 1, T_SBC, 1, 0}, {O_LOC, 2, 1, T_SAB, 1, 1},
+                             {O_ZP, 7, 1, T_SAB, 1, -1}, {O_LOC, 3, 2, T_T6, 0, -1}};
+            for (const H &g : hs) {
                 st = gemm_rs(ctx, false, true, rows, g.kb * C, C, dO + g.ocol * C, ldo, 0, d.Wst + g.wpos * CC, C, 0, dT + g.tcol * C, ldt, 0,
                              1, g.acc, d.rowscale, 2, g.scol);
                 if (st != GF_OK) return st;
