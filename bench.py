@@ -158,14 +158,14 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
         _, Rp, _ = sizes[l - 1]
         unit = 2 * R * C * C                                     # one C x C block product over all rows
         if fused:
-            add(kb, "smpf_tables_fwd", 4 * (Rp * C + 6 * R * C))        # gather f_{l-1} (cached), write 6 tables
+            add(kb, "smpf_tables_fwd", 4 * (Rp * C + 4 * R * C))        # gather f_{l-1} (cached), write 4 tables
             add(kb, "smpf_combine_fwd", 4 * (3 * R * C + R * C))        # O = [O_loc | Z | Z'] in, f_l out
             add(kb, "smpf_combine_bwd", 4 * (2 * R * C + 3 * R * C))
-            add(kb, "smpf_tables_bwd", 4 * (6 * R * C + S * C))
+            add(kb, "smpf_tables_bwd", 4 * (4 * R * C + S * C))
             add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
             for k in ("gemm_nn", "gemm_nt", "gemm_tn"):
-                add(kf, k, 10 * unit)
-                add(kb, k, 4 * (6 * R * C + 3 * R * C))                  # T (6C) and O / dO (3C) per row, each once
+                add(kf, k, 8 * unit)                                     # (+ two C x C products on the compact rows below)
+                add(kb, k, 4 * (4 * R * C + 3 * R * C))                  # T (4C) and O / dO (3C) per row, each once
         else:
             add(kb, "smp_promote_fwd", 4 * (Rp * C + S * C))
             add(kb, "r18_fwd_slab", 4 * (S * C + 10 * R * C))

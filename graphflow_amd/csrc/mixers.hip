@@ -427,8 +427,8 @@ gf_status gemm_rs(gf_ctx *ctx, bool ta, bool tb, int M, int N, int K, const floa
     int splits = 1;
     const long long tiles = (long long)gx * gy * batch;
     if (batch == 1 && tiles < 512 && K >= 8 * BK) {
-        splits = (int)((4096 + tiles - 1) / tiles);  // about 16 workgroups per CU: each one is a latency-bound k-loop
-        const int maxs = K / (2 * BK);
+        splits = (int)((2048 + tiles - 1) / tiles);  // about 8 workgroups per CU: each one is a latency-bound k-loop
+        const int maxs = K / (8 * BK);              // at least eight k-steps per workgroup: fewer partial images to fold
         if (splits > maxs) splits = maxs;
         if (splits < 1) splits = 1;
     }
