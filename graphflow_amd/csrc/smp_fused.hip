@@ -4,16 +4,17 @@
 // Same mathematics as the op-by-op pipeline of smp.hip (GraphFlow/SMP_omega.h:630-670), regrouped:
 //   Q_k = (N x N table) x (factor depending on A)  for every one of the 18 cases, and the
 //   K-projection is linear, so   sum_k Q_k K^(k)   is evaluated as
-//     tables  T = [Dac | S_ab | S_bc | Dbb | T6 | T10]      six N x N x C tables per node, built by ONE pass that gathers
+//     tables  T = [S_ab | S_bc | T6 | T10]                   four N x N x C tables per node, built by ONE pass that gathers
 //                                                             the promoted tensors straight from f_{l-1}
-//     GEMMs   O_tot = [S_ab|S_bc][K0;K2]   O_tr = S_ab K6   O_dir = [T6|T10][K5;K9]
-//             Z = [S_ab|S_bc|Dbb][K8;K12;K15]   Z' = [Dac|S_ab][K16;K11]              10 C x C block products, not 18
+//     compact G15 = Fd K15, G16 = Fc K16 on the sum-s rows of the level below: the diagonal tables D_bb[x,y] = P[x,y,y] and
+//             D_ac[x,y] = P[x,y,x] are gathers of f_{l-1}[w_x][p,p] and f_{l-1}[w_x][p,centre]  (see diag_gather_fwd)
+//     GEMMs   O_loc = tot [S_ab|S_bc][K0;K2] + tr S_ab K6 + [T6|T10][K5;K9]     (tot, tr as per-row factors of the operand)
+//             Z = [S_ab|S_bc][K8;K12]   Z' = S_ab K11                              8 C x C block products on the rows, not 18
 //             V = [rowsum_a|colsum_b|D8|D11][K1;K3;K7;K10]  (per (node,x))   S = [total|s14|s15|s18][K4;K13;K14;K17] (per node)
-//     combine f_l[x,y] = LeakyReLU(b + tot O_tot[x,y] + tr O_tr[x,y] + O_dir[x,y]
-//                                    + sum_e A[y,e] (Z[x,e] + Z'[e,x]) + r[y] V[x] + A[x,y] S)
-// The reverse sweep mirrors it: combine-backward -> block GEMMs (dT, dK) -> tables-backward (dP) -> consumer gather.
-// HBM traffic per level drops from about (2 S + 40 R) C floats to about (S_back + 27 R) C, GEMM flops from 18 to 10 units
-// (R = sum s^2, S = sum s^3).
+//     combine f_l[x,y] = LeakyReLU(b + O_loc[x,y] + sum_e A[y,e] (Z[x,e] + Z'[e,x] + G15[x,e] + G16[e,x]) + r[y] V[x] + A[x,y] S)
+// The reverse sweep mirrors it: combine-backward -> compact gradients -> block GEMMs (dT, dK) -> tables-backward (dP) ->
+// consumer gather.  HBM traffic per level drops from about (2 S + 40 R) C floats to about (S_back + 19 R) C, GEMM flops
+// from 18 to 8 units (R = sum s^2, S = sum s^3).
 #include <algorithm>
 
 #include "r18_device.h"
