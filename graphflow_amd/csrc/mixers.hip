@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_f32_mfma_grouped(GroupedArgs
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
     const unsigned tile = xcd_tile_id(blockIdx.x, gridDim.x);
     int panel = (int)(tile / ga.tiles_per_panel), t = (int)(tile % ga.tiles_per_panel);
-    if (!ga.panel_is_split && ga.window > 1) {
+    if (ga.window > 1) {
         const int per_window = ga.window * ga.tiles_per_panel;
         const int w = (int)(tile / per_window), r = (int)(tile % per_window);
         const int first = w * ga.window;
@@ -551,8 +551,9 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
     GroupedArgs ga;
     ga.ngroups = n;
     ga.panel_is_split = 1;
-    ga.npanels = 0;
+    ga.npanels = 0;   // (set to the split count below)
     ga.window = 1;
+    if (const char *e = std::getenv("GF_GEMM_WINDOW_TN")) ga.window = std::max(1, std::atoi(e));
     int tiles = 0;
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
@@ -584,6 +585,7 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
         ga.g[i].split_stride = (long long)total;
         off += (size_t)specs[i].M * specs[i].N;
     }
+    ga.npanels = splits;
     const unsigned grid = (unsigned)((size_t)splits * tiles);
     GF_LAUNCH(ctx, "gemm_tn", (gemm_f32_mfma_grouped<true, false, true>), dim3(grid), dim3(kThreads), 0, ga, splits + 1);
     // (splits + 1: the tile function treats nsplits > 1 as "write partial images"; a single split still goes through
