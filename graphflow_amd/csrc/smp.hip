@@ -567,6 +567,10 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
         delete s;
         return fail(ctx, GF_ERR_INVALID, "gf_smp_create: nContractions = %d (expected 10, 18 or 50)", bad);
     }
+    {
+        const char *e = std::getenv("GF_SMP_BWD_GATHER");  // 0: keep the two-kernel tables-backward + consumer gather
+        s->bwd_gather = (e && e[0] == '0') ? 0 : 1;
+    }
     *out = s;
     return GF_OK;
 }
@@ -807,6 +811,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         gf_smp::DevLevel &d = s->lv[l];
         UP(d.node_s, h.node_s);
         UP(d.node_center, h.node_center);
+        UP(d.mol_order, h.mol_order);
         st = gf::upload(s, &d.node_row, &h.node_row[0], h.node_row.size());
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.node_pair, &h.node_pair[0], h.node_pair.size());
@@ -830,6 +835,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         st = gf::upload(s, &d.pair_src_pair, &h.pair_src_pair[0], h.pair_src_pair.size());
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.cons_row, h.cons_row.empty() ? nullptr : &h.cons_row[0], h.cons_row.size());
+        if (st != GF_OK) return st;
+        st = gf::upload(s, &d.cons_pair, h.cons_pair.empty() ? nullptr : &h.cons_pair[0], h.cons_pair.size());
         if (st != GF_OK) return st;
         {
             float **cb[] = {&d.Fdc, &d.Gc, &d.dGc, &d.dFdc};
@@ -1036,6 +1043,11 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
         }
         const gf_smp::DevLevel &pv = s->lv[l - 1];
         const bool diag_level = s->fused && gf::smp_fused_supported(s, l);  // its D_bb / D_ac gradients arrive through dFdc
+        if (diag_level && gf::smp_fused_gather_enabled(s, l)) {
+            st = gf::smp_fused_gather_backward(s, l);
+            if (st != GF_OK) return st;
+            continue;
+        }
         GF_LAUNCH(ctx, "smp_promote_bwd", gf::promote_backward, dim3(B.level[l - 1].nNodes), dim3(256), 0, s->P, pv.df,
                   pv.node_s, pv.node_row, d.cons_ptr, d.cons_slab, d.cons_s, d.cons_inv_off, d.inv, C,
                   diag_level ? d.dFdc : (const float *)nullptr, pv.node_pair, pv.node_center);

@@ -631,6 +631,142 @@ gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *d
     return GF_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// consumer gather with tables-backward folded in (GF_SMP_BWD_GATHER).  Workgroup per SOURCE node w of level l-1:
+//   df_{l-1}[w][p,q] = [p==q] dFd[p] + [q==c_w] dFc[p] + sum over consumers (n,a), in consumer order, of dP_n[a, b, c]
+// with b = inv(p), c = inv(q) both present, and dP_n[a,b,c] EVALUATED from the table gradients by the formula above
+// smp_tables_bwd (same expression, same order: the two paths agree to the last bit) instead of being written by one
+// kernel and read back by the next.  A thread owns (p, 4 channels) and keeps the sw accumulators of its row in registers.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kGatherChunk = 64, kGatherMaxS = 32;
+#ifndef GF_GATHER_QB
+#define GF_GATHER_QB 4
+#endif
+
+template <int SW>
+__global__ __launch_bounds__(256) void smp_bwd_gather(
+    const float *__restrict__ dT, const float *__restrict__ dVt, const float *__restrict__ dSt, const float *__restrict__ rsum,
+    float *__restrict__ dfprev, const float *__restrict__ dFdc, const int *__restrict__ prev_s, const long long *__restrict__ prev_row,
+    const long long *__restrict__ prev_pair, const int *__restrict__ prev_center, const long long *__restrict__ cons_ptr,
+    const long long *__restrict__ cons_row, const int *__restrict__ cons_s, const int *__restrict__ cons_a,
+    const long long *__restrict__ cons_pair, const int *__restrict__ pair_node, const long long *__restrict__ cons_inv_off,
+    const short *__restrict__ inv, int C, const int *__restrict__ order) {
+    constexpr int QB = (SW < GF_GATHER_QB) ? SW : GF_GATHER_QB;  // positions q whose loads are in flight together
+    __shared__ long long sRow[kGatherChunk], sPb[kGatherChunk];
+    __shared__ int sS[kGatherChunk], sA[kGatherChunk], sNode[kGatherChunk];
+    __shared__ short sInv[kGatherChunk][SW];
+    __shared__ float sR[kGatherChunk][kGatherMaxS];
+    // launch order: molecule-major, and every XCD (blockIdx % 8) gets a contiguous run of it -- the rows (b, c) of one
+    // consumer node are re-read by each of its sources, which then share an L2
+    int w;
+    {
+        const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8;
+        w = order[(x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8];
+    }
+    const int sw = prev_s[w], cw = prev_center[w];
+    const int nl = C >> 2, items = sw * nl;
+    const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
+    const size_t ldt = (size_t)T_COLS * C;
+    float *dst = dfprev + prev_row[w] * C;
+    const float *dfd = dFdc + (size_t)prev_pair[w] * 2 * C;
+    for (int base = 0; base < items; base += (int)blockDim.x) {
+        const int it = base + (int)threadIdx.x;
+        const bool live = it < items;
+        const int p = live ? it / nl : 0, f = 4 * (live ? it % nl : 0);
+        f4 acc[SW];
+#pragma unroll
+        for (int q = 0; q < SW; ++q) {
+            acc[q] = splat(0.f);
+            if (live && q < sw) {
+                if (p == q) acc[q] += ld4(dfd + (size_t)p * 2 * C + f);
+                if (q == cw) acc[q] += ld4(dfd + (size_t)p * 2 * C + C + f);
+            }
+        }
+        for (long long cb = c0; cb < c1; cb += kGatherChunk) {
+            const int nc = (int)((c1 - cb < kGatherChunk) ? c1 - cb : kGatherChunk);
+            __syncthreads();
+            for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+                const long long e = cons_pair[cb + i];
+                const int a = cons_a[cb + i];
+                sRow[i] = cons_row[cb + i];
+                sS[i] = cons_s[cb + i];
+                sA[i] = a;
+                sPb[i] = e - a;
+                sNode[i] = pair_node[e];
+            }
+            for (int i = threadIdx.x; i < nc * sw; i += blockDim.x) sInv[i / sw][i % sw] = inv[cons_inv_off[cb + i / sw] + i % sw];
+            __syncthreads();
+            for (int i = threadIdx.x; i < nc * kGatherMaxS; i += blockDim.x) {
+                const int e = i / kGatherMaxS, x = i % kGatherMaxS;
+                sR[e][x] = (x < sS[e]) ? rsum[sPb[e] + x] : 0.f;
+            }
+            __syncthreads();
+            if (!live) continue;
+            for (int e = 0; e < nc; ++e) {
+                const int b = sInv[e][p];
+                if (b < 0) continue;
+                const int s = sS[e], a = sA[e];
+                const float *trow = dT + (size_t)sRow[e] * ldt + f;
+                const float *tab = trow + ((size_t)a * s + b) * ldt;
+                const float *dva = dVt + (size_t)(sPb[e] + a) * 4 * C + f;
+                const float *dvb = dVt + (size_t)(sPb[e] + b) * 4 * C + f;
+                const float *ds = dSt + (size_t)sNode[e] * 4 * C + f;
+                f4 x = ld4(tab + T_SAB * C) + ld4(dva + 0 * C) + ld4(dvb + 1 * C) + ld4(ds + 0 * C);
+                f4 z1 = ld4(dva + 2 * C) + ld4(ds + 2 * C);
+                if (a == b) {
+                    x += ld4(ds + 1 * C);
+                    z1 += ld4(ds + 3 * C);
+                }
+                const f4 g5 = ld4(tab + T_T6 * C), z2 = ld4(dvb + 3 * C);
+                const float ra = sR[e][a];
+                const float *tb = trow + (size_t)b * s * ldt;
+#pragma unroll
+                for (int q0 = 0; q0 < SW; q0 += QB) {
+                    if (q0 >= sw) break;
+                    f4 y[QB], g9[QB];
+                    int cc[QB];
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) {
+                        const int q = q0 + j;
+                        const int c = (q < sw) ? sInv[e][q] : -1;
+                        cc[j] = c;
+                        const float *t = tb + (size_t)(c < 0 ? 0 : c) * ldt;
+                        y[j] = ld4(t + T_SBC * C);
+                        g9[j] = ld4(t + T_T10 * C);
+                    }
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) {
+                        const int c = cc[j];
+                        if (c < 0) continue;
+                        f4 o = x + y[j] + g5 * sR[e][c] + g9[j] * ra;
+                        if (c == b) o += z1;
+                        if (c == a) o += z2;
+                        acc[q0 + j] += o;
+                    }
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < SW; ++q)
+                if (q < sw) st4(dst + ((size_t)p * sw + q) * C + f, acc[q]);
+        }
+    }
+}
+
+template <int SW>
+gf_status launch_bwd_gather(gf_smp *s, int l, int w0, int w1, const float *dT) {
+    gf_ctx *ctx = s->ctx;
+    const gf_smp::DevLevel &d = s->lv[l], &pv = s->lv[l - 1];
+    const int C = s->cfg.nChanels;
+    int threads = SW * (C / 4);
+    threads = threads > 256 ? 256 : (threads + 63) / 64 * 64;
+    GF_LAUNCH(ctx, "smpf_bwd_gather", (smp_bwd_gather<SW>), dim3((unsigned)(w1 - w0)), dim3(threads), 0, dT, d.dVt, d.dSt, d.rsum, pv.df,
+              d.dFdc, pv.node_s, pv.node_row, pv.node_pair, pv.node_center, d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_pair,
+              d.pair_node, d.cons_inv_off, d.inv, C, pv.mol_order + w0);
+    return GF_OK;
+}
 }  // namespace
 
 bool smp_fused_supported(const gf_smp *s, int l) {
@@ -871,6 +1007,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     st = gemm(ctx, false, true, nodes, 4 * C, C, d.dSout, C, 0, d.Wst + 14 * CC, C, 0, d.dSt, 4 * C, 0, 1, 0);
     if (st != GF_OK) return st;
     // rowsum_a / D8 were sums over b of S_ab / Dbb: their gradients broadcast back (handled inside tables-backward via dVt)
+    if (smp_fused_gather_enabled(s, l)) return GF_OK;  // dP is evaluated inside the consumer gather (smp_fused_gather_backward)
     const std::vector<SizeClass> cls = classes_of(h, 4);
     for (const SizeClass &c : cls) {
         switch (c.ni) {
@@ -882,6 +1019,40 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         if (st != GF_OK) return st;
     }
     (void)Kl;
+    return GF_OK;
+}
+
+// the folded gather keeps a source node's row of accumulators in registers: receptive fields of level l-1 up to 32
+bool smp_fused_gather_enabled(const gf_smp *s, int l) {
+    const gfsmp::LevelLayout &hp = s->lay.level[l - 1];
+    return s->bwd_gather && !hp.buckets.empty() && hp.buckets.back().s <= kGatherMaxS;
+}
+
+// df_{l-1} from the table gradients of level l without materialising dP (see smp_bwd_gather)
+gf_status smp_fused_gather_backward(gf_smp *s, int l) {
+    const gfsmp::LevelLayout &h = s->lay.level[l], &hp = s->lay.level[l - 1];
+    const gf_smp::DevLevel &d = s->lv[l];
+    const int C = s->cfg.nChanels;
+    const float *dT = d.Q + (size_t)h.rows * T_COLS * C + (size_t)h.rows * O_COLS * C;
+    // source nodes are sorted by receptive-field size: one launch per register class of sw (the classes of mol_order)
+    size_t k = 0;
+    const int cls[5] = {1, 4, 8, 16, 32};
+    for (int ci = 0; ci < 5 && k < hp.buckets.size(); ++ci) {
+        const size_t k0 = k;
+        while (k < hp.buckets.size() && hp.buckets[k].s <= cls[ci]) ++k;
+        if (k == k0) continue;
+        const int w0 = hp.buckets[k0].first_node, w1 = (k < hp.buckets.size()) ? hp.buckets[k].first_node : hp.nNodes;
+        gf_status st;
+        switch (cls[ci]) {
+            case 1: st = launch_bwd_gather<1>(s, l, w0, w1, dT); break;
+            case 4: st = launch_bwd_gather<4>(s, l, w0, w1, dT); break;
+            case 8: st = launch_bwd_gather<8>(s, l, w0, w1, dT); break;
+            case 16: st = launch_bwd_gather<16>(s, l, w0, w1, dT); break;
+            default: st = launch_bwd_gather<32>(s, l, w0, w1, dT); break;
+        }
+        if (st != GF_OK) return st;
+    }
+    if (k < hp.buckets.size()) return fail(s->ctx, GF_ERR_UNSUPPORTED, "smp_fused_gather_backward: receptive field > 32");
     return GF_OK;
 }
 

@@ -36,6 +36,7 @@ struct gf_smp {
     gfsmp::BatchLayout lay;
     bool prepared = false, forwarded = false;
     int fused = 1;  // use the fused level path where supported (gf_smp_set_fused)
+    int bwd_gather = 0;  // fused levels: evaluate dP inside the consumer gather instead of materialising it (GF_SMP_BWD_GATHER)
     // device buffers (owned)
     struct DevLevel {
         int *node_s = nullptr;
@@ -45,8 +46,8 @@ struct gf_smp {
         int *pair_node = nullptr, *pair_src_s = nullptr, *cons_s = nullptr;
         long long *pair_src_row = nullptr, *cons_ptr = nullptr, *cons_slab = nullptr, *cons_inv_off = nullptr;
         short *pi = nullptr, *inv = nullptr;
-        long long *pair_src_pair = nullptr, *cons_row = nullptr;  // compact diagonal path (smp_prep.h)
-        int *node_center = nullptr, *cons_a = nullptr;
+        long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
+        int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr;
         float *Fdc = nullptr, *Gc = nullptr, *dGc = nullptr, *dFdc = nullptr;  // [pairs of level l-1][2C] each
         float *f = nullptr, *df = nullptr, *Q = nullptr;  // activations [rows][C], their gradient, contraction out [rows][18C]
         // fused level (smp_fused.hip): small per-(node,x) / per-node tables and stacked weights
@@ -97,5 +98,7 @@ bool smp_fused_supported(const gf_smp *s, int l);
 gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float *bl);
 // node_df != nullptr (top level): df_l is the same C-vector at every position of a node, given as [nodes][C]
 gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl, const float *node_df);
+gf_status smp_fused_gather_backward(gf_smp *s, int l);
+bool smp_fused_gather_enabled(const gf_smp *s, int l);
 }
 #endif

@@ -208,6 +208,14 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         lv.ppos = pp;
         lv.pairs = pair;
         lv.node_center.assign(totalV, 0);
+        {  // counting sort of the nodes by (register class of s, molecule); stable, so size-major order survives inside a key
+            auto cls = [](int s) { return s <= 1 ? 0 : s <= 4 ? 1 : s <= 8 ? 2 : s <= 16 ? 3 : 4; };
+            std::vector<int> start((size_t)5 * nMol + 1, 0);
+            for (int n = 0; n < totalV; ++n) start[(size_t)cls(lv.node_s[n]) * nMol + lv.node_mol[n] + 1] += 1;
+            for (size_t k = 0; k + 1 < start.size(); ++k) start[k + 1] += start[k];
+            lv.mol_order.assign(totalV, 0);
+            for (int n = 0; n < totalV; ++n) lv.mol_order[(size_t)start[(size_t)cls(lv.node_s[n]) * nMol + lv.node_mol[n]]++] = n;
+        }
         for (int n = 0; n < totalV; ++n) {
             const std::vector<int> &fld = out->mols[lv.node_mol[n]].phi[l][lv.node_vertex[n]];
             const int v = lv.node_vertex[n];
@@ -296,7 +304,9 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         lv.cons_ptr.assign((size_t)prev.nNodes + 1, 0);
         for (int64_t e = 0; e < lv.pairs; ++e) lv.cons_ptr[(size_t)pair_src_node[(size_t)e] + 1] += 1;
         for (int w = 0; w < prev.nNodes; ++w) lv.cons_ptr[(size_t)w + 1] += lv.cons_ptr[(size_t)w];
-        std::vector<int64_t> cons_pair((size_t)lv.pairs), cursor(lv.cons_ptr.begin(), lv.cons_ptr.end() - 1);
+        std::vector<int64_t> cursor(lv.cons_ptr.begin(), lv.cons_ptr.end() - 1);
+        std::vector<int64_t> &cons_pair = lv.cons_pair;
+        cons_pair.assign((size_t)lv.pairs, 0);
         for (int64_t e = 0; e < lv.pairs; ++e) cons_pair[(size_t)cursor[(size_t)pair_src_node[(size_t)e]]++] = e;
         lv.cons_slab.assign((size_t)lv.pairs, 0);
         lv.cons_s.assign((size_t)lv.pairs, 0);

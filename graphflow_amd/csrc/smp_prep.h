@@ -65,6 +65,9 @@ struct LevelLayout {
     std::vector<int> node_center;       // [nNodes] position of the node's own vertex inside its receptive field (every level)
     std::vector<int64_t> cons_row;      // [pairs] node_row (level l) of the consumer's node
     std::vector<int> cons_a;            // [pairs] the consumer's neighbour index a
+    std::vector<int64_t> cons_pair;     // [pairs] the consumer's pair id e = node_pair[n] + a (level l)
+    std::vector<int> mol_order;         // [nNodes] the level's nodes by (size class 1/4/8/16/32, molecule): launch order of the
+                                        // backward gather, so the sources that re-read one consumer's rows run together
     // backward gather, indexed by the SOURCE node (level l-1): consumers = pairs that read it
     std::vector<int64_t> cons_ptr;      // [nNodes(l-1) + 1]
     std::vector<int64_t> cons_slab;     // [pairs] position offset (units of C floats) of the consumer's [s][s] slab in P

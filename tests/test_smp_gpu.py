@@ -135,6 +135,22 @@ def test_fused_and_op_by_op_levels_agree_at_scale(gf):
     assert rel_err(g1, g0) <= TOL_GRAD
 
 
+def test_folded_backward_gather_equals_the_two_kernel_path(gf, monkeypatch):
+    """Fused levels evaluate dP inside the consumer gather (default) or write it with tables-backward and gather it
+    afterwards (GF_SMP_BWD_GATHER=0, also the route for receptive fields > 32): same expression, same summation order."""
+    F, D, C, L, cap = 5, 5, 64, 3, 29
+    mols, tg = [], []
+    for seed in range(24):
+        adj, feat, t = synthetic_molecule(900 + seed)
+        mols.append((adj, feat))
+        tg.append(t)
+    params = smp_params(C, F, D, L, 5)
+    g1 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)[3]
+    monkeypatch.setenv("GF_SMP_BWD_GATHER", "0")   # read when the handle is created
+    g0 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)[3]
+    assert rel_err(g1, g0) <= 1e-6
+
+
 def test_text_checkpoint_is_interchangeable_with_the_reference(gf, golden, tmp_path):
     """tests/golden/smp_syn12_checkpoint.txt was written by the REAL SMP_omega::save_model (SMP_omega.h:1033-1042).
     load_model must read it, predict like the golden, and save_model must write the very same bytes back."""
