@@ -161,8 +161,11 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
             add(kb, "smpf_tables_fwd", 4 * (Rp * C + 4 * R * C))        # gather f_{l-1} (cached), write 4 tables
             add(kb, "smpf_combine_fwd", 4 * (3 * R * C + R * C))        # O = [O_loc | Z | Z'] in, f_l out
             add(kb, "smpf_combine_bwd", 4 * (2 * R * C + 3 * R * C))
-            add(kb, "smpf_tables_bwd", 4 * (4 * R * C + S * C))
-            add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
+            if os.environ.get("GF_SMP_BWD_GATHER", "1") != "0":           # dP evaluated inside the consumer gather
+                add(kb, "smpf_bwd_gather", 4 * (4 * R * C + Rp * C))    # table gradients in (once), df_{l-1} out
+            else:
+                add(kb, "smpf_tables_bwd", 4 * (4 * R * C + S * C))
+                add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
             for k in ("gemm_nn", "gemm_nt", "gemm_tn"):
                 add(kf, k, 8 * unit)                                     # (+ two C x C products on the compact rows below)
                 add(kb, k, 4 * (4 * R * C + 3 * R * C))                  # T (4C) and O / dO (3C) per row, each once
@@ -307,6 +310,8 @@ def main():
                 "config": meta["config"], "roofline": finish(timers, ms_per_step),
                 "cpu_baseline": (cpu() if (world == 1 and not args.no_cpu_baseline) else None)}
         line["roofline"]["hbm_copy_measured_GBps"] = round(ceiling, 1)
+        if hasattr(keep, "device_bytes"):   # HBM held by the batch's buffers after the steps ran (lazy buffers included)
+            line["config"]["device_GB"] = round(keep.device_bytes()[0] / 1e9, 2)
         line["roofline"]["timing"] = ("HIP events on the kernels' stream: the dominant kernel live inside the timed region, "
                                       "the other kernels in an identical pass of the same steps just before it")
         print(json.dumps(line), flush=True)

@@ -432,6 +432,11 @@ gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
     return GF_OK;
 }
 
+gf_status ensure_P_impl(gf_smp *s) {
+    if (s->P) return GF_OK;
+    return upload(s, &s->P, nullptr, s->P_count);
+}
+
 // the second stream of the fused levels (smp_internal.h), created on first use
 void ensure_side_stream(gf_smp *s) {
     if (s->side_tried) return;
@@ -514,10 +519,11 @@ gf_status smp_contract(gf_smp *s, int l, bool backward) {
     const int C = s->cfg.nChanels, nK = s->cfg.nContractions;
     const int ppw = (C <= 16) ? 16 : (C <= 32) ? 8 : 4;
     const gf_ragged_nodes t = {d.pair_node, d.node_s, d.node_p, d.node_row, d.node_pair, (long long)h.rows, (long long)h.pairs};
+    gf_status st = ensure_P_impl(s);
+    if (st != GF_OK) return st;
     // (_10 / _50 of the SMP_2D_ver6 / ver7 wirings: one uniform launch per size bucket)
     const bool ragged_ok = nK == 18 && r18_ragged_supported(ppw, C, s->P, d.Q);
     size_t k = 0;
-    gf_status st = GF_OK;
     for (int cls = 1; cls <= 8 && ragged_ok && k < h.buckets.size(); cls *= 2) {
         const int smax_cls = cls * ppw;
         const size_t k0 = k;
@@ -541,6 +547,8 @@ gf_status smp_contract(gf_smp *s, int l, bool backward) {
 }
 
 }  // namespace
+
+gf_status ensure_P(gf_smp *s) { return ensure_P_impl(s); }
 }  // namespace gf
 
 using gf::fail;
@@ -875,8 +883,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         contract_ws = std::max(contract_ws, gf::r18_ragged_workspace_bytes((long long)h.rows, (long long)h.pairs, C));
     }
     UP(s->x, B.x);
-    st = gf::upload(s, &s->P, nullptr, (size_t)maxp * C);
-    if (st != GF_OK) return st;
+    s->P = nullptr;  // [max ppos][C]: by far the largest buffer of the op-by-op path, taken from the pool only when a level needs it
+    s->P_count = (size_t)maxp * C;
     const gfsmp::LevelLayout &top = B.level[L];
     st = gf::upload(s, &s->sh, nullptr, (size_t)top.nNodes * C);
     if (st != GF_OK) return st;
@@ -952,6 +960,8 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
             if (st != GF_OK) return st;
             continue;
         }
+        st = gf::ensure_P(s);
+        if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smp_promote_fwd", gf::promote_forward, dim3((unsigned)h.pairs), dim3(256), 0, s->lv[l - 1].f, s->P,
                   d.node_s, d.node_row, d.node_p, d.node_pair, d.pair_node, d.pair_src_row, d.pair_src_s, d.pi, C);
         st = gf::smp_contract(s, l, /*backward=*/false);
@@ -1102,6 +1112,18 @@ gf_status gf_smp_prepare_molecule_host(const gf_smp_config *cfg, int V, const in
 
 /* 1 (default): fused level kernels where the shape allows; 0: the op-by-op pipeline (promotion, RisiContraction_18,
  * MatMul, VectorAddTensor, LeakyReLU3D as separate kernels).  Both produce the same results within fp32 rounding. */
+gf_status gf_smp_device_bytes(const gf_smp *s, size_t *in_use, size_t *reserved) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    size_t u = 0, r = 0;
+    for (const gf_smp::Block &b : s->pool) {
+        r += b.bytes;
+        if (b.used) u += b.bytes;
+    }
+    if (in_use) *in_use = u;
+    if (reserved) *reserved = r;
+    return GF_OK;
+}
+
 gf_status gf_smp_set_fused(gf_smp *s, int on) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     s->fused = on ? 1 : 0;

@@ -1008,6 +1008,8 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     if (st != GF_OK) return st;
     // rowsum_a / D8 were sums over b of S_ab / Dbb: their gradients broadcast back (handled inside tables-backward via dVt)
     if (smp_fused_gather_enabled(s, l)) return GF_OK;  // dP is evaluated inside the consumer gather (smp_fused_gather_backward)
+    st = ensure_P(s);
+    if (st != GF_OK) return st;
     const std::vector<SizeClass> cls = classes_of(h, 4);
     for (const SizeClass &c : cls) {
         switch (c.ni) {

@@ -61,7 +61,8 @@ struct gf_smp {
     };
     std::vector<DevLevel> lv;
     float *x = nullptr;      // [nVertices][FD]
-    float *P = nullptr;      // shared promotion / dP buffer, max over levels of ppos*C
+    float *P = nullptr;      // shared promotion / dP buffer, max over levels of ppos*C; allocated on first use (ensure_P):
+    size_t P_count = 0;      // the fused levels with the folded backward gather never materialise it
     float *sh = nullptr, *vf = nullptr;  // [nNodes][C] readout pre/post activation
     float *dsh = nullptr;                // [nNodes][C] gradient of sh (the fused top level reads it per node)
     float *g = nullptr;      // [nMol][C] graph features
@@ -100,5 +101,6 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
 gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl, const float *node_df);
 gf_status smp_fused_gather_backward(gf_smp *s, int l);
 bool smp_fused_gather_enabled(const gf_smp *s, int l);
+gf_status ensure_P(gf_smp *s);
 }
 #endif

@@ -100,6 +100,12 @@ class SMPOmega:
         """Fused level kernels (default) vs the op-by-op pipeline; both give the same results within fp32 rounding."""
         self.ctx.check(self.lib.gf_smp_set_fused(self.handle, 1 if on else 0))
 
+    def device_bytes(self):
+        """(bytes held by the current batch, bytes the handle's pool keeps in total)."""
+        used, res = C.c_size_t(0), C.c_size_t(0)
+        self.ctx.check(self.lib.gf_smp_device_bytes(self.handle, C.byref(used), C.byref(res)))
+        return int(used.value), int(res.value)
+
     def receptive_field(self, mol, level, v):
         buf = (C.c_int * 4096)()
         n = self.lib.gf_smp_receptive_field(self.handle, mol, level, v, buf, 4096)

@@ -207,6 +207,9 @@ gf_status gf_smp_backward(gf_smp *smp, const float *params, float *grads, int ac
 /* 1 (default): fused level kernels (no promoted stack, no 18-slice contraction output in HBM) where the shape allows;
  * 0: the op-by-op pipeline.  Same results within fp32 rounding; kept switchable for parity tests. */
 gf_status gf_smp_set_fused(gf_smp *smp, int on);
+/* Device memory of the handle's buffer pool: bytes held by the current batch, and bytes the pool keeps in total (idle
+ * blocks included).  Sizing aid for batch selection (GraphFlow has no counterpart: its tensors live in host `new[]`). */
+gf_status gf_smp_device_bytes(const gf_smp *smp, size_t *in_use, size_t *reserved);
 /* Host-pointer mode of the driver (what graphflow_amd/host/SMP_omega_hip.h uses): the handle owns the model -- a device
  * parameter buffer and its gradient.  Wherever the entry points of this section take `params` / `grads`, NULL selects the
  * handle-owned buffers.  gf_smp_forward_host runs gf_smp_forward on them and returns per-molecule results as doubles
