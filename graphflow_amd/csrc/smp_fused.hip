@@ -245,17 +245,30 @@ __global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict_
     const int w = blockIdx.x;
     const int sw = prev_s[w], nl = C / 4;
     const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
+    const size_t ldo = (size_t)O_COLS * C;
     float *dst = dGc + (size_t)prev_pair[w] * 2 * C;
     for (int i = threadIdx.x; i < sw * nl; i += blockDim.x) {
         const int fl = i % nl, p = i / nl;
         f4 a15 = splat(0.f), a16 = splat(0.f);
-        for (long long e = c0; e < c1; ++e) {
-            const int ip = inv[cons_inv_off[e] + p];
-            if (ip < 0) continue;
-            const int s = cons_s[e], a = cons_a[e];
-            const float *base = dO + (size_t)cons_row[e] * (O_COLS * C) + O_Z * C + 4 * fl;
-            a15 += ld4(base + ((size_t)a * s + ip) * (size_t)(O_COLS * C));
-            a16 += ld4(base + ((size_t)ip * s + a) * (size_t)(O_COLS * C));
+        for (long long e0 = c0; e0 < c1; e0 += 4) {  // four consumers' loads in flight (clamped address + select), same order
+            f4 u[4], v[4];
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long e = (e0 + j < c1) ? e0 + j : e0;
+                const int ip = inv[cons_inv_off[e] + p];
+                ok[j] = e0 + j < c1 && ip >= 0;
+                const int s = cons_s[e], a = cons_a[e], ix = ok[j] ? ip : 0;
+                const float *base = dO + (size_t)cons_row[e] * ldo + O_Z * C + 4 * fl;
+                u[j] = ld4(base + ((size_t)a * s + ix) * ldo);
+                v[j] = ld4(base + ((size_t)ix * s + a) * ldo);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ok[j]) {
+                    a15 += u[j];
+                    a16 += v[j];
+                }
         }
         st4(dst + (size_t)p * 2 * C + 4 * fl, a15);
         st4(dst + (size_t)p * 2 * C + C + 4 * fl, a16);
