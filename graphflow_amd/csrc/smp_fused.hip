@@ -12,9 +12,11 @@
 //             Z = [S_ab|S_bc][K8;K12]   Z' = S_ab K11                              8 C x C block products on the rows, not 18
 //             V = [rowsum_a|colsum_b|D8|D11][K1;K3;K7;K10]  (per (node,x))   S = [total|s14|s15|s18][K4;K13;K14;K17] (per node)
 //     combine f_l[x,y] = LeakyReLU(b + O_loc[x,y] + sum_e A[y,e] (Z[x,e] + Z'[e,x] + G15[x,e] + G16[e,x]) + r[y] V[x] + A[x,y] S)
-// The reverse sweep mirrors it: combine-backward -> compact gradients -> block GEMMs (dT, dK) -> tables-backward (dP) ->
-// consumer gather.  HBM traffic per level drops from about (2 S + 40 R) C floats to about (S_back + 19 R) C, GEMM flops
-// from 18 to 8 units (R = sum s^2, S = sum s^3).
+// The reverse sweep mirrors it: combine-backward -> compact gradients -> block GEMMs (dT, dK) -> smp_bwd_gather, the
+// consumer gather of df_{l-1} that evaluates dP from the table gradients on the fly (dP is not materialised either; the
+// two-kernel form tables-backward -> promote_backward remains for GF_SMP_BWD_GATHER=0 and receptive fields > 32).
+// HBM traffic per level drops from about (2 S + 40 R) C floats to about 19 R C, GEMM flops from 18 to 8 units
+// (R = sum s^2, S = sum s^3).
 #include <algorithm>
 
 #include "r18_device.h"
@@ -28,7 +30,7 @@ namespace {
 constexpr float kAlphaF = 0.01f;
 __device__ __forceinline__ float lreluf(float z) { return z > 0.f ? z : kAlphaF * z; }
 
-// column blocks of the table matrix T [rows][6C]
+// column blocks of the table matrix T [rows][4C]
 enum { T_SAB = 0, T_SBC = 1, T_T6 = 2, T_T10 = 3, T_COLS = 4 };
 // column blocks of the projected matrix O [rows][3C].  O_LOC = tot O_tot + tr O_tr + O_dir: the per-node factors tot and
 // tr (the level's rowscale table) are applied to the T operand inside the GEMM, so the three row-local products
