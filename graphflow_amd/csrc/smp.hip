@@ -836,6 +836,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         UP(d.rowscale, h.rowscale);
         UP(d.quad_node, h.quad_node);
         UP(d.quad_b0, h.quad_b0);
+        UP(d.quad_order, h.quad_order);
         UP(d.pair_node, h.pair_node);
         UP(d.pair_src_s, h.pair_src_s);
         UP(d.cons_s, h.cons_s);

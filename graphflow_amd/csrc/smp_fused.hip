@@ -57,12 +57,20 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
                                                              const int *__restrict__ pair_src_s, const short *__restrict__ pi,
                                                              const int *__restrict__ quad_node, const int *__restrict__ quad_b0,
                                                              const int *__restrict__ node_s, const long long *__restrict__ node_row,
-                                                             const long long *__restrict__ node_pair, int quad_base, int C, int nwin) {
+                                                             const long long *__restrict__ node_pair, int quad_base, int C, int nwin,
+                                                             const int *__restrict__ quad_order) {
     constexpr int LPC = 16, PPW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = lane / LPC, fl = lane % LPC;
-    const int q = quad_base + (int)(blockIdx.x / nwin), win = (int)(blockIdx.x % nwin);
+    // launch order: molecule-major inside the size class, one contiguous run of it per XCD (blockIdx % 8): the source
+    // tensors f_{l-1}[w] of a molecule are gathered by ~s consumers each, which then share an L2
+    unsigned tile;
+    {
+        const unsigned nb = gridDim.x, qq = nb / 8, r = nb % 8, x = blockIdx.x % 8;
+        tile = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + blockIdx.x / 8;
+    }
+    const int q = quad_order[quad_base + (int)(tile / nwin)], win = (int)(tile % nwin);
     const int n = quad_node[q];
     const int N = node_s[n], b = quad_b0[q] + wave;
     const size_t rowbase = (size_t)node_row[n], pairbase = (size_t)node_pair[n];
@@ -628,7 +636,7 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + sizeof(short) * (size_t)c.smax * c.smax + 16;
     GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
               s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
-              d.node_row, d.node_pair, q_lo, C, nwin);
+              d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order);
     return GF_OK;
 }
 

@@ -248,6 +248,21 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 lv.quad_node.push_back(n);
                 lv.quad_b0.push_back(b0);
             }
+        {  // launch order of tables-forward: the consumers of one molecule's source tensors run together (stable counting sort)
+            auto cls = [](int s) { return s <= 4 ? 0 : s <= 8 ? 1 : s <= 16 ? 2 : 3; };
+            const size_t nq = lv.quad_node.size();
+            std::vector<int> start((size_t)4 * nMol + 1, 0);
+            for (size_t q = 0; q < nq; ++q) {
+                const int n = lv.quad_node[q];
+                start[(size_t)cls(lv.node_s[n]) * nMol + lv.node_mol[n] + 1] += 1;
+            }
+            for (size_t k = 0; k + 1 < start.size(); ++k) start[k + 1] += start[k];
+            lv.quad_order.assign(nq, 0);
+            for (size_t q = 0; q < nq; ++q) {
+                const int n = lv.quad_node[q];
+                lv.quad_order[(size_t)start[(size_t)cls(lv.node_s[n]) * nMol + lv.node_mol[n]]++] = (int)q;
+            }
+        }
         parallel_for(lv.nNodes, [&](int n) {
             const int m = lv.node_mol[n], v = lv.node_vertex[n], s = lv.node_s[n];
             const int V = nVertices[m], v0 = out->mol_first_vertex[m];

@@ -54,6 +54,7 @@ struct LevelLayout {
     std::vector<float> rowscale;  // [rows][2] (tot, tr) of the row's node: per-row factors folded into the level's block GEMMs
     // wave-per-pair kernels: one workgroup (4 waves) per group of 4 consecutive indices of one node
     std::vector<int> quad_node, quad_b0;  // [quads]
+    std::vector<int> quad_order;          // [quads] quads by (size class 4/8/16/32, molecule): launch order of tables-forward
     // forward gather (levels >= 1): per pair e = node_pair[n] + a
     std::vector<int> pair_node;        // [pairs]
     std::vector<int64_t> pair_src_row;  // [pairs] first row of the source node's tensor in level l-1
