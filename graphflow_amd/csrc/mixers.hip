@@ -392,6 +392,162 @@ __global__ void splitk_reduce(const float *__restrict__ part, float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients of the fused SMP level at C = 64, output-stationary.  The eight row block products of a level,
+//   dWst[p] = A_p^T B_p summed over the level's rows,   A_p in T = [S_ab|S_bc|T6|T10],  B_p in {dO_loc, tot dO_loc, tr dO_loc, dZ, dZ'}
+// (stack positions 0..7 of smp_fused.hip), share their operands: S_ab feeds four of them, dO_loc five.  As five groups of
+// the grouped split-K launch each product streams its own copy (7.5 GB fetched for 5.1 GB of T and dO at cfg3, PMC).
+// Here a workgroup of eight waves owns a row range, stages each 32-row slice of T (4C) and dO (3C) in LDS ONCE (two stages,
+// one barrier per slice), and wave p accumulates product p as a 64 x 64 register tile (2 x 2 MFMA 32x32 accumulators); the
+// tot / tr factors are applied to the dO_loc fragments in registers.  Every operand byte is read from HBM once per step,
+// 64 MFMAs per wave between barriers.
+// Partial images go through the same two-pass ordered reduction as every split-K launch (fixed order, deterministic).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWgThreads = 512, kWgARows = 256, kWgBRows = 192;
+constexpr int kWgStage = (kWgARows + kWgBRows) * LDS_ROW + 2 * BK;  // floats: A image, B image, the slice's tot / tr factors
+__constant__ int c_wg_ablk[8] = {0, 1, 0, 2, 3, 0, 1, 0};    // S_ab, S_bc, S_ab, T6, T10, S_ab, S_bc, S_ab
+__constant__ int c_wg_bblk[8] = {0, 0, 0, 0, 0, 1, 1, 2};    // dO_loc (x tot, x tot, x tr, plain, plain), dZ, dZ, dZ'
+__constant__ int c_wg_scale[8] = {0, 0, 1, -1, -1, -1, -1, -1};
+
+__global__ __launch_bounds__(kWgThreads, 1) void smp_wgrad_c64(const float *__restrict__ T, const float *__restrict__ dO,
+                                                               const float *__restrict__ rs, int rows, int kchunk,
+                                                               float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float wg_smem[];  // two stages: slice i is multiplied while slice i + 1 lands
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kbeg = blockIdx.x * kchunk;
+    const int kend = (kbeg + kchunk < rows) ? kbeg + kchunk : rows;
+    constexpr int LDT = 256, LDO = 192;
+    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // staging: A = four float4 per thread (transposing store, ascat_mk on each 128-row half), B = three (one per dO block).
+    struct Regs {
+        f4v va[4], vb[3];
+        float2 sc;
+    };
+    Regs R0;
+    int am[4], ak[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = tid + e * kWgThreads;
+        int m, k;
+        ascat_mk(idx & 1023, &m, &k);
+        am[e] = (idx >> 10) * 128 + m;
+        ak[e] = k;
+    }
+    const int bn = (tid % 16) * 4, bk = bscat_k(tid / 16);
+    auto load_tiles = [&](Regs &R, int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gk = k0 + ak[e];
+            R.va[e] = gk < kend ? *reinterpret_cast<const f4v *>(T + (size_t)gk * LDT + am[e]) : zero4;
+        }
+        const int gk = k0 + bk;
+        const bool in = gk < kend;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) R.vb[e] = in ? *reinterpret_cast<const f4v *>(dO + (size_t)gk * LDO + e * 64 + bn) : zero4;
+        if (bn == 0) R.sc = in ? *reinterpret_cast<const float2 *>(rs + (size_t)gk * 2) : make_float2(0.f, 0.f);
+    };
+    // one of eight pieces of the slice's LDS image (issued between the MFMAs of the running slice, or all at once)
+    auto store_piece = [&](const Regs &R, float *stage, int pc) {
+        float *As = stage, *Bs = stage + kWgARows * LDS_ROW, *Ss = Bs + kWgBRows * LDS_ROW;
+        if (pc < 4) {
+            const int kp = kpos(ak[pc]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[lds_at(am[pc] + j, kp)] = R.va[pc][j];
+        } else if (pc < 7) {
+            const int e = pc - 4, kp = kpos(bk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs[lds_at(e * 64 + bn + j, kp)] = R.vb[e][j];
+        } else if (bn == 0) {  // the slice's row factors, in the lanes' k order (kpos): lane half lh reads 16 consecutive ones
+            const int kp = kpos(bk);
+            Ss[kp] = R.sc.x;
+            Ss[BK + kp] = R.sc.y;
+        }
+    };
+
+    f16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kbeg < kend) {
+        const int a0 = c_wg_ablk[wave] * 64, b0 = c_wg_bblk[wave] * 64, skind = c_wg_scale[wave];
+        int aoff[2], boff[2], za[2], zb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            aoff[i] = (a0 + 32 * i + li) * LDS_ROW + lh * (BK / 2);
+            boff[i] = (kWgARows + b0 + 32 * i + li) * LDS_ROW + lh * (BK / 2);
+            za[i] = lds_swz(a0 + 32 * i + li);
+            zb[i] = lds_swz(b0 + 32 * i + li);
+        }
+        const int soff = (kWgARows + kWgBRows) * LDS_ROW + (skind > 0 ? BK : 0) + lh * (BK / 2);
+        // multiply the slice held in `stage`; meanwhile request the next slice (-> RL) and, in the second half, store it (RS) into `next`
+        auto slice = [&](const float *stage, float *next, Regs &RL, const Regs &RS, int k2, bool more1) {
+            if (k2 < kend) load_tiles(RL, k2);
+            // The slice is multiplied in two halves of 8 MFMA steps.  LDS traffic is issued BETWEEN the MFMAs (the matrix pipe
+            // runs each for 64 cycles while the wave goes on): the second half's fragments are read during the first half, the
+            // next slice's image is stored during the second.
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f4v fa[2][2], fb[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        fa[i][q] = *reinterpret_cast<const f4v *>(stage + aoff[i] + 4 * ((2 * h + q) ^ za[i]));
+                        fb[i][q] = *reinterpret_cast<const f4v *>(stage + boff[i] + 4 * ((2 * h + q) ^ zb[i]));
+                    }
+                if (skind >= 0) {  // (wave-uniform) B = tot dO_loc or tr dO_loc: the factor of row k on the fragment's element k
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f4v sv = *reinterpret_cast<const f4v *>(stage + soff + 4 * (2 * h + q));
+                        fb[0][q] *= sv;
+                        fb[1][q] *= sv;
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk >> 2][kk & 3], fb[j][kk >> 2][kk & 3], acc[i][j], 0, 0, 0);
+                    if (h == 1 && more1) store_piece(RS, next, kk);
+                }
+            }
+            __syncthreads();
+        };
+        float *st0 = wg_smem, *st1 = wg_smem + kWgStage;
+        load_tiles(R0, kbeg);
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) store_piece(R0, st0, pc);
+        __syncthreads();
+        // (a second register set, requesting slice i + 2 while slice i + 1 is stored, needs > 256 VGPRs: spills, 40 % slower)
+        for (int k0 = kbeg;;) {
+            bool more = k0 + BK < kend;
+            slice(st0, st1, R0, R0, k0 + BK, more);  // slice k0 from stage 0; slice k0 + BK: HBM -> R0 -> stage 1
+            if (!more) break;
+            k0 += BK;
+            more = k0 + BK < kend;
+            slice(st1, st0, R0, R0, k0 + BK, more);
+            if (!more) break;
+            k0 += BK;
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float *out = part + ((size_t)blockIdx.x * 8 + wave) * 4096;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + 32 * j + li] = acc[i][j][r];
+}
+
 template <typename T>
 __global__ void gather_rows(const T *const *__restrict__ src, T *__restrict__ dst, size_t per, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
@@ -598,6 +754,40 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
         GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part2, dest, total, nchunks, nchunks, accumulate);
     } else {
         GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part, dest, total, splits, splits, accumulate);
+    }
+    return GF_OK;
+}
+
+// dWst[0..8) = the eight row block products of a fused SMP level at C = 64 (see smp_wgrad_c64).  T = [rows][256],
+// dO = [rows][192], rowscale = [rows][2].  The row range per workgroup depends on `rows` only: results are reproducible.
+gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst) {
+    if (rows < 1) return GF_OK;
+    // one workgroup fits a CU (two LDS stages): aim at `target` row ranges, at least 8 slices each
+    int target = 256;
+    if (const char *e = std::getenv("GF_WGRAD_SPLITS")) target = std::max(1, std::atoi(e));
+    int kchunk = ((rows + target - 1) / target + BK - 1) / BK * BK;
+    if (kchunk < 8 * BK) kchunk = 8 * BK;
+    const int splits = (rows + kchunk - 1) / kchunk;
+    const size_t total = 8 * 4096;
+    const int chunk = 32, nchunks = (splits + chunk - 1) / chunk;
+    gf_status st = ensure_ws(ctx, sizeof(float) * ((size_t)splits + nchunks) * total + 256);
+    if (st != GF_OK) return st;
+    float *part = static_cast<float *>(ctx->ws);
+    const size_t lds = sizeof(float) * 2 * (size_t)kWgStage;
+    static bool opted = false;
+    if (!opted) {
+        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_wgrad_c64), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds));
+        opted = true;
+    }
+    GF_LAUNCH(ctx, "gemm_tn", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part);
+    const unsigned gx1 = (unsigned)((total + 255) / 256);
+    if (splits > 64) {
+        float *part2 = part + (size_t)splits * total;
+        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, nchunks), dim3(256), 0, part, part2, total, splits, chunk, 0);
+        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part2, dWst, total, nchunks, nchunks, 0);
+    } else {
+        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part, dWst, total, splits, splits, 0);
     }
     return GF_OK;
 }

@@ -974,7 +974,11 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
                           {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, gs[i].scol >= 0 ? d.rowscale : nullptr, 2, {gs[i].scol, -1, -1, -1}};
             sp[i] = z;
         }
-        if (C <= 64 && gemm_grouped_supported(sp, 5, true, false)) {
+        static const bool stationary = !(std::getenv("GF_SMP_WGRAD") && std::getenv("GF_SMP_WGRAD")[0] == '0');
+        if (C == 64 && stationary) {
+            st = smp_wgrad_stationary_c64(ctx, T, dO, d.rowscale, rows, d.dWst);  // every operand byte fetched once
+            if (st != GF_OK) return st;
+        } else if (C <= 64 && gemm_grouped_supported(sp, 5, true, false)) {
             st = gemm_grouped_splitk(ctx, sp, 5, rows, d.dWst, 0);  // stack positions 0..7 are contiguous in dWst
             if (st != GF_OK) return st;
         } else {
