@@ -403,149 +403,134 @@ __global__ void splitk_reduce(const float *__restrict__ part, float *__restrict_
 // 64 MFMAs per wave between barriers.
 // Partial images go through the same two-pass ordered reduction as every split-K launch (fixed order, deterministic).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kWgThreads = 512, kWgARows = 256, kWgBRows = 192;
+constexpr int kWgThreads = 1024, kWgARows = 256, kWgBRows = 192;
 constexpr int kWgStage = (kWgARows + kWgBRows) * LDS_ROW + 2 * BK;  // floats: A image, B image, the slice's tot / tr factors
 __constant__ int c_wg_ablk[8] = {0, 1, 0, 2, 3, 0, 1, 0};    // S_ab, S_bc, S_ab, T6, T10, S_ab, S_bc, S_ab
 __constant__ int c_wg_bblk[8] = {0, 0, 0, 0, 0, 1, 1, 2};    // dO_loc (x tot, x tot, x tr, plain, plain), dZ, dZ, dZ'
 __constant__ int c_wg_scale[8] = {0, 0, 1, -1, -1, -1, -1, -1};
 
+// sixteen waves: wave w owns columns [32 (w & 1), +32) of product w >> 1 as two 32 x 32 accumulators (the wave tile of the
+// general kernel); four waves per SIMD hide each other's LDS and barrier waits
 __global__ __launch_bounds__(kWgThreads, 1) void smp_wgrad_c64(const float *__restrict__ T, const float *__restrict__ dO,
                                                                const float *__restrict__ rs, int rows, int kchunk,
                                                                float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];  // two stages: slice i is multiplied while slice i + 1 lands
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int prod = wave >> 1, nh = wave & 1;
     const int kbeg = blockIdx.x * kchunk;
     const int kend = (kbeg + kchunk < rows) ? kbeg + kchunk : rows;
     constexpr int LDT = 256, LDO = 192;
     const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // staging: A = four float4 per thread (transposing store, ascat_mk on each 128-row half), B = three (one per dO block).
-    struct Regs {
-        f4v va[4], vb[3];
-        float2 sc;
-    };
-    Regs R0;
-    int am[4], ak[4];
+    // staging: A = two float4 per thread (transposing store, ascat_mk on each 128-row half), B = 1536 float4 over 1024 threads
+    f4v va[2], vb[2];
+    float2 sc;
+    int am[2], ak[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int idx = tid + e * kWgThreads;
+    for (int e = 0; e < 2; ++e) {
+        const int idx = tid + e * kWgThreads;  // e = 128-row half
         int m, k;
         ascat_mk(idx & 1023, &m, &k);
         am[e] = (idx >> 10) * 128 + m;
         ak[e] = k;
     }
-    const int bn = (tid % 16) * 4, bk = bscat_k(tid / 16);
-    auto load_tiles = [&](Regs &R, int k0) {
+    // B: float4 id = tid (blocks 0, 1) and 1024 + tid for tid < 512 (block 2); inside a block: 16 float4 per k row
+    const int bsub = tid & 511, bn = (bsub % 16) * 4, bk = bscat_k(bsub / 16), bblk0 = tid >> 9;
+    const bool b2 = tid < 512;
+    auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 2; ++e) {
             const int gk = k0 + ak[e];
-            R.va[e] = gk < kend ? *reinterpret_cast<const f4v *>(T + (size_t)gk * LDT + am[e]) : zero4;
+            va[e] = gk < kend ? *reinterpret_cast<const f4v *>(T + (size_t)gk * LDT + am[e]) : zero4;
         }
         const int gk = k0 + bk;
         const bool in = gk < kend;
-#pragma unroll
-        for (int e = 0; e < 3; ++e) R.vb[e] = in ? *reinterpret_cast<const f4v *>(dO + (size_t)gk * LDO + e * 64 + bn) : zero4;
-        if (bn == 0) R.sc = in ? *reinterpret_cast<const float2 *>(rs + (size_t)gk * 2) : make_float2(0.f, 0.f);
+        vb[0] = in ? *reinterpret_cast<const f4v *>(dO + (size_t)gk * LDO + bblk0 * 64 + bn) : zero4;
+        if (b2) vb[1] = in ? *reinterpret_cast<const f4v *>(dO + (size_t)gk * LDO + 128 + bn) : zero4;
+        if (tid < 512 && bn == 0) sc = in ? *reinterpret_cast<const float2 *>(rs + (size_t)gk * 2) : make_float2(0.f, 0.f);
     };
-    // one of eight pieces of the slice's LDS image (issued between the MFMAs of the running slice, or all at once)
-    auto store_piece = [&](const Regs &R, float *stage, int pc) {
+    // one of four pieces of the slice's LDS image (issued between the MFMAs of the running slice, or all at once)
+    auto store_piece = [&](float *stage, int pc) {
         float *As = stage, *Bs = stage + kWgARows * LDS_ROW, *Ss = Bs + kWgBRows * LDS_ROW;
-        if (pc < 4) {
+        if (pc < 2) {
             const int kp = kpos(ak[pc]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) As[lds_at(am[pc] + j, kp)] = R.va[pc][j];
-        } else if (pc < 7) {
-            const int e = pc - 4, kp = kpos(bk);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Bs[lds_at(e * 64 + bn + j, kp)] = R.vb[e][j];
-        } else if (bn == 0) {  // the slice's row factors, in the lanes' k order (kpos): lane half lh reads 16 consecutive ones
+            for (int j = 0; j < 4; ++j) As[lds_at(am[pc] + j, kp)] = va[pc][j];
+        } else if (pc == 2) {
             const int kp = kpos(bk);
-            Ss[kp] = R.sc.x;
-            Ss[BK + kp] = R.sc.y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs[lds_at(bblk0 * 64 + bn + j, kp)] = vb[0][j];
+        } else {
+            const int kp = kpos(bk);
+            if (b2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[lds_at(128 + bn + j, kp)] = vb[1][j];
+                if (bn == 0) {  // the slice's row factors, in the lanes' k order (kpos): lane half lh reads 16 consecutive ones
+                    Ss[kp] = sc.x;
+                    Ss[BK + kp] = sc.y;
+                }
+            }
         }
     };
 
-    f16v acc[2][2];
+    f16v acc0, acc1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 
     if (kbeg < kend) {
-        const int a0 = c_wg_ablk[wave] * 64, b0 = c_wg_bblk[wave] * 64, skind = c_wg_scale[wave];
-        int aoff[2], boff[2], za[2], zb[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            aoff[i] = (a0 + 32 * i + li) * LDS_ROW + lh * (BK / 2);
-            boff[i] = (kWgARows + b0 + 32 * i + li) * LDS_ROW + lh * (BK / 2);
-            za[i] = lds_swz(a0 + 32 * i + li);
-            zb[i] = lds_swz(b0 + 32 * i + li);
-        }
+        const int a0 = c_wg_ablk[prod] * 64, b0 = c_wg_bblk[prod] * 64 + 32 * nh, skind = c_wg_scale[prod];
+        const int aoff0 = (a0 + li) * LDS_ROW + lh * (BK / 2), aoff1 = aoff0 + 32 * LDS_ROW;
+        const int boff = (kWgARows + b0 + li) * LDS_ROW + lh * (BK / 2);
+        const int za0 = lds_swz(a0 + li), za1 = lds_swz(a0 + 32 + li), zb = lds_swz(b0 + li);
         const int soff = (kWgARows + kWgBRows) * LDS_ROW + (skind > 0 ? BK : 0) + lh * (BK / 2);
-        // multiply the slice held in `stage`; meanwhile request the next slice (-> RL) and, in the second half, store it (RS) into `next`
-        auto slice = [&](const float *stage, float *next, Regs &RL, const Regs &RS, int k2, bool more1) {
-            if (k2 < kend) load_tiles(RL, k2);
-            // The slice is multiplied in two halves of 8 MFMA steps.  LDS traffic is issued BETWEEN the MFMAs (the matrix pipe
-            // runs each for 64 cycles while the wave goes on): the second half's fragments are read during the first half, the
-            // next slice's image is stored during the second.
+        load_tiles(kbeg);
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) store_piece(wg_smem, pc);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = kbeg;;) {
+            const int kn = k0 + BK;
+            const bool more = kn < kend;
+            if (more) load_tiles(kn);
+            const float *stage = wg_smem + cur * kWgStage;
+            float *next = wg_smem + (cur ^ 1) * kWgStage;
+            // LDS stores of the next slice are issued BETWEEN the MFMAs of the second half (the matrix pipe runs each MFMA for
+            // 64 cycles while the wave goes on); they have had the first half to arrive from HBM
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                f4v fa[2][2], fb[2][2];
+                f4v fa0[2], fa1[2], fb[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        fa[i][q] = *reinterpret_cast<const f4v *>(stage + aoff[i] + 4 * ((2 * h + q) ^ za[i]));
-                        fb[i][q] = *reinterpret_cast<const f4v *>(stage + boff[i] + 4 * ((2 * h + q) ^ zb[i]));
-                    }
+                for (int q = 0; q < 2; ++q) {
+                    fa0[q] = *reinterpret_cast<const f4v *>(stage + aoff0 + 4 * ((2 * h + q) ^ za0));
+                    fa1[q] = *reinterpret_cast<const f4v *>(stage + aoff1 + 4 * ((2 * h + q) ^ za1));
+                    fb[q] = *reinterpret_cast<const f4v *>(stage + boff + 4 * ((2 * h + q) ^ zb));
+                }
                 if (skind >= 0) {  // (wave-uniform) B = tot dO_loc or tr dO_loc: the factor of row k on the fragment's element k
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const f4v sv = *reinterpret_cast<const f4v *>(stage + soff + 4 * (2 * h + q));
-                        fb[0][q] *= sv;
-                        fb[1][q] *= sv;
-                    }
+                    for (int q = 0; q < 2; ++q) fb[q] *= *reinterpret_cast<const f4v *>(stage + soff + 4 * (2 * h + q));
                 }
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk >> 2][kk & 3], fb[j][kk >> 2][kk & 3], acc[i][j], 0, 0, 0);
-                    if (h == 1 && more1) store_piece(RS, next, kk);
+                for (int j = 0; j < 8; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j >> 2][j & 3], fb[j >> 2][j & 3], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j >> 2][j & 3], fb[j >> 2][j & 3], acc1, 0, 0, 0);
+                    if (more && h == 1 && (j & 1) == 0) store_piece(next, j >> 1);
                 }
             }
             __syncthreads();
-        };
-        float *st0 = wg_smem, *st1 = wg_smem + kWgStage;
-        load_tiles(R0, kbeg);
-#pragma unroll
-        for (int pc = 0; pc < 8; ++pc) store_piece(R0, st0, pc);
-        __syncthreads();
-        // (a second register set, requesting slice i + 2 while slice i + 1 is stored, needs > 256 VGPRs: spills, 40 % slower)
-        for (int k0 = kbeg;;) {
-            bool more = k0 + BK < kend;
-            slice(st0, st1, R0, R0, k0 + BK, more);  // slice k0 from stage 0; slice k0 + BK: HBM -> R0 -> stage 1
             if (!more) break;
-            k0 += BK;
-            more = k0 + BK < kend;
-            slice(st1, st0, R0, R0, k0 + BK, more);
-            if (!more) break;
-            k0 += BK;
+            cur ^= 1;
+            k0 = kn;
         }
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float *out = part + ((size_t)blockIdx.x * 8 + wave) * 4096;
+    float *out = part + ((size_t)blockIdx.x * 8 + prod) * 4096 + 32 * nh + li;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + 32 * j + li] = acc[i][j][r];
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        out[row * 64] = acc0[r];
+        out[(32 + row) * 64] = acc1[r];
+    }
 }
 
 template <typename T>
