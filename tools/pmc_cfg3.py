@@ -12,7 +12,7 @@ def launch_name(k):
     base = re.sub(r"[<(].*", "", k).split("::")[-1]
     table = {"smp_tables_fwd": "smpf_tables_fwd", "smp_tables_fwd_w": "smpf_tables_fwd", "smp_tables_bwd": "smpf_tables_bwd",
              "smp_combine_fwd": "smpf_combine_fwd", "smp_combine_bwd": "smpf_combine_bwd", "promote_backward": "smp_promote_bwd",
-             "smp_vectors": "smpf_vectors", "smp_bwd_gather": "smpf_bwd_gather"}
+             "smp_vectors": "smpf_vectors", "smp_bwd_gather": "smpf_bwd_gather", "smp_wgrad_c64": "gemm_tn"}
     return table.get(base, base)
 
 
