@@ -1015,7 +1015,11 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
             {dO, d.Wst, dT + T_T6 * C, rows, 2 * C, C, ldo, C, ldt, 1, {O_LOC * oC, 0, 0, 0}, {3 * wCC, 0, 0, 0}, {C, 0, 0, 0}, nullptr, 0,
              {-1, -1, -1, -1}},
         };
-        if (gemm_grouped_supported(dg, 3, false, true)) {
+        static const bool panels = !(std::getenv("GF_SMP_DTABLE") && std::getenv("GF_SMP_DTABLE")[0] == '0');
+        if (C == 64 && panels) {
+            st = smp_dtable_panels_c64(ctx, dO, d.rowscale, d.Wst, dT, rows);  // persistent row-panel kernel, weights in registers
+            if (st != GF_OK) return st;
+        } else if (gemm_grouped_supported(dg, 3, false, true)) {
             st = gemm_grouped_rows(ctx, false, true, dg, 3, rows);
             if (st != GF_OK) return st;
         } else {
