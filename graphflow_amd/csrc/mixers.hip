@@ -534,175 +534,154 @@ __global__ __launch_bounds__(kWgThreads, 1) void smp_wgrad_c64(const float *__re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Table gradients of the fused SMP level at C = 64, row-panel stationary:  dT[rows][4C] from dO[rows][3C] = [L | Z | Z'],
-//   S_ab <- tot L W0^T + tr L W2^T + Z W5^T + Z' W7^T     S_bc <- tot L W1^T + Z W6^T     T6 <- L W3^T     T10 <- L W4^T
-// (W_p = stacked weight block p, [ci][co]).  As a grouped launch of 128 x 64 tiles these are reductions of 2..8 k-steps whose
-// prologues and epilogues dominate (75 TF/s).  Here a persistent workgroup of eight waves walks 64-row panels: the panel
-// of dO is staged in LDS once (two stages: the next panel is fetched into registers during the products and stored after
-// them), every wave keeps the B fragments of ITS two products in registers for the whole launch (no weight traffic), and
-// the sixteen 64 x 32 x 64 products of a panel are two per wave:
-//   w0,w1: S_ab cols [0,32) / [32,64):  tot L W0^T + tr L W2^T   (+ the partial of w2 / w3, handed over through LDS)
-//   w2,w3: S_ab, same columns:          Z W5^T + Z' W7^T         -> partial
-//   w4,w5: S_bc:                        tot L W1^T + Z W6^T
-//   w6:    T6, both column halves in turn:  L W3^T          w7: T10:  L W4^T
-// so a wave issues 128 MFMAs per panel between two barriers.  Row factors tot / tr scale the A fragments (one row per lane).
+// Row-panel products of the fused SMP level at C = 64 with the WEIGHTS resident in LDS and the row operand in registers.
+//   forward  (FWD):  O[rows][3C]  = [O_loc | Z | Z']       from T  = [S_ab | S_bc | T6 | T10]
+//                    O_loc = tot S_ab W0 + tr S_ab W2 + tot S_bc W1 + T6 W3 + T10 W4     Z = S_ab W5 + S_bc W6     Z' = S_ab W7
+//   backward (!FWD): dT[rows][4C] = [dS_ab|dS_bc|dT6|dT10] from dO = [L | Z | Z']
+//                    dS_ab = tot L W0^T + tr L W2^T + Z W5^T + Z' W7^T     dS_bc = tot L W1^T + Z W6^T     dT6 = L W3^T    dT10 = L W4^T
+// As tiled GEMMs these are reductions of 2..10 k-steps whose prologues, epilogues and barriers cost half the time.  Here the
+// eight 64 x 64 weight blocks (128 KB) are copied to LDS ONCE per workgroup in B-fragment order, and after that single
+// barrier every wave works alone: it takes a 32-row panel, reads its rows straight from global memory into A fragments --
+// lane (row i, half h) holds columns [32 h, 32 h + 32) of its row, i.e. the MFMA's k order is permuted consistently on
+// both operands -- and runs all sixteen 32 x 32 x 64 products of the panel (512 MFMAs) out of registers and LDS, one output
+// block (two accumulators) at a time.  No operand staging, no barriers, sixteen independent waves per CU.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kDtThreads = 512, kDtRows = 64;
-constexpr int kDtSlice = kDtRows * LDS_ROW;                 // one 32-wide k slice of the panel image
-constexpr int kDtStage = 6 * kDtSlice + 2 * kDtRows;        // six slices (3C = 192 columns) + tot / tr of the 64 rows
-constexpr int kDtPart = kDtRows * 33;                       // one 64 x 32 partial tile, padded rows
-__constant__ int c_dt_ablk[8][2] = {{0, 0}, {0, 0}, {1, 2}, {1, 2}, {0, 1}, {0, 1}, {0, 0}, {0, 0}};
-__constant__ int c_dt_scale[8][2] = {{0, 1}, {0, 1}, {-1, -1}, {-1, -1}, {0, -1}, {0, -1}, {-1, -1}, {-1, -1}};
-__constant__ int c_dt_wpos[8][2] = {{0, 2}, {0, 2}, {5, 7}, {5, 7}, {1, 6}, {1, 6}, {3, 3}, {4, 4}};
-__constant__ int c_dt_nh[8][2] = {{0, 0}, {1, 1}, {0, 0}, {1, 1}, {0, 0}, {1, 1}, {0, 1}, {0, 1}};
-__constant__ int c_dt_oblk[8] = {0, 0, 0, 0, 1, 1, 2, 3};
+constexpr int kRpThreads = 1024, kRpWRow = 36;
 
-__global__ __launch_bounds__(kDtThreads, 1) void smp_dtable_c64(const float *__restrict__ dO, const float *__restrict__ rs,
-                                                                const float *__restrict__ Wst, float *__restrict__ dT, int rows) {
-    extern __shared__ __attribute__((aligned(16))) float dt_smem[];  // stage 0 | stage 1 | partial tiles [2 buffers][2 waves]
-    float *parts = dt_smem + 2 * kDtStage;
+template <bool FWD>
+__global__ __launch_bounds__(kRpThreads, 1) void smp_rowpanel_c64(const float *__restrict__ A, const float *__restrict__ rs,
+                                                                  const float *__restrict__ Wst, float *__restrict__ Out, int rows) {
+    constexpr int LDA = FWD ? 256 : 192, LDOUT = FWD ? 192 : 256;
+    extern __shared__ __attribute__((aligned(16))) float rp_smem[];  // [8 pos][2 column halves][2 k halves][32 lanes][36]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int LDO = 192, LDT = 256;
-    const int npanels = (rows + kDtRows - 1) / kDtRows;
-    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    // B fragments of the wave's two products: element j of unit u = W[pos][32 nh + li][2 j + lh]   (B[k][n] = W[n][k])
-    float breg[2][32];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const float *w = Wst + (size_t)c_dt_wpos[wave][u] * 4096 + (size_t)(32 * c_dt_nh[wave][u] + li) * 64 + lh;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) breg[u][j] = w[2 * j];
-    }
-
-    // staging of a panel: 64 rows x 48 float4; thread t takes float4 ids t + 512 e
-    f4v pv[6];
-    float psc = 0.f;
-    auto load_panel = [&](int p) {
-        const int r0 = p * kDtRows;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) {
-            const int idx = tid + e * kDtThreads, m = idx / 48, c4 = idx % 48;
-            pv[e] = (r0 + m < rows) ? *reinterpret_cast<const f4v *>(dO + (size_t)(r0 + m) * LDO + 4 * c4) : zero4;
-        }
-        if (tid < 2 * kDtRows) psc = (r0 + (tid >> 1) < rows) ? rs[(size_t)(r0 + (tid >> 1)) * 2 + (tid & 1)] : 0.f;
-    };
-    auto store_panel = [&](float *stage) {
-#pragma unroll
-        for (int e = 0; e < 6; ++e) {
-            const int idx = tid + e * kDtThreads, m = idx / 48, c4 = idx % 48;
-            const int k = 4 * c4, sl = k >> 5, kk = k & 31;
-            float *img = stage + sl * kDtSlice;
-            *reinterpret_cast<float2 *>(img + lds_at(m, kk >> 1)) = make_float2(pv[e][0], pv[e][2]);
-            *reinterpret_cast<float2 *>(img + lds_at(m, BK / 2 + (kk >> 1))) = make_float2(pv[e][1], pv[e][3]);
-        }
-        if (tid < 2 * kDtRows) stage[6 * kDtSlice + (tid & 1) * kDtRows + (tid >> 1)] = psc;  // [tot x 64 | tr x 64]
-    };
-
-    const int off0 = li * LDS_ROW + lh * (BK / 2), off1 = off0 + 32 * LDS_ROW;
-    const int z0 = lds_swz(li), z1 = lds_swz(32 + li);
-    const int oblk = c_dt_oblk[wave];
-    const bool two_tiles = wave >= 6, gives = (wave == 2 || wave == 3), takes = wave < 2;
-
-    int p = blockIdx.x;
-    if (p < npanels) {
-        load_panel(p);
-        store_panel(dt_smem);
+    const int wave = tid >> 6;
+    // B fragment order: row ((pos 2 + nh) 2 + kh) 32 + i holds B[k = 32 kh + j][n = 32 nh + i] for j = 0..31, where
+    // B = W_pos (forward: W[k][n]) or W_pos^T (backward: W[n][k])
+    for (int e = tid; e < 8 * 4096; e += kRpThreads) {
+        const int pos = e >> 12, r = (e >> 6) & 63, c = e & 63;  // W_pos[r][c]
+        const int k = FWD ? r : c, n = FWD ? c : r;
+        rp_smem[((((pos * 2 + (n >> 5)) * 2 + (k >> 5)) * 32) + (n & 31)) * kRpWRow + (k & 31)] = Wst[e];
     }
     __syncthreads();
-    int cur = 0;
-    for (int it = 0; p < npanels; p += gridDim.x, ++it) {
-        const int pn = p + gridDim.x;
-        if (pn < npanels) load_panel(pn);
-        const float *stage = dt_smem + cur * kDtStage;
-        float *pbuf = parts + (it & 1) * 2 * kDtPart;
-        const int r0 = p * kDtRows;
-        f16v acc0, acc1;
+    const int npanels = (rows + 31) / 32;
+    const int nwaves = gridDim.x * (kRpThreads / 64);
+    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float *bbase = rp_smem + (lh * 32 + li) * kRpWRow;
+
+    struct Blk {
+        f4v a[8];
+    };
+    // columns [64 blk + 32 lh, +32) of row `li` of panel p -> A fragments (zeros past the end)
+    auto load_blk = [&](Blk &B, int p, int blk) {
+        const int row = p * 32 + li;
+        const bool ok = p < npanels && row < rows;
+        const float *src = A + (size_t)(ok ? row : 0) * LDA + blk * 64 + 32 * lh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) B.a[q] = ok ? *reinterpret_cast<const f4v *>(src + 4 * q) : zero4;
+    };
+    auto load_scale = [&](int p) {
+        const int row = p * 32 + li;
+        return (p < npanels && row < rows) ? *reinterpret_cast<const float2 *>(rs + (size_t)row * 2) : make_float2(0.f, 0.f);
+    };
+    // acc (two column halves) += (sc * B.a) x block wpos: 64 MFMAs, B fragments from the LDS image
+    auto prod = [&](const Blk &B, bool scaled, float sc, int wpos, f16v &acc0, f16v &acc1) {
+        const float *b0 = bbase + (size_t)(wpos * 4) * 32 * kRpWRow, *b1 = b0 + 2 * 32 * kRpWRow;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f4v bq0 = *reinterpret_cast<const f4v *>(b0 + 4 * q), bq1 = *reinterpret_cast<const f4v *>(b1 + 4 * q);
+            f4v av = B.a[q];
+            if (scaled) av *= sc;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bq0[c], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bq1[c], acc1, 0, 0, 0);
+            }
+        }
+    };
+    auto clear = [&](f16v &acc0, f16v &acc1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-        const bool full = r0 + kDtRows <= rows;
-        auto write_tile = [&](int nh) {
-            float *o = dT + (size_t)r0 * LDT + oblk * 64 + 32 * nh + li + (size_t)(4 * lh) * LDT;
-            if (full) {  // (uniform) no per-row tests: the compiler can count the stores it has in flight
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2);
-                    o[(size_t)row * LDT] = acc0[r];
-                    o[(size_t)(32 + row) * LDT] = acc1[r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2);
-                    if (r0 + 4 * lh + row < rows) o[(size_t)row * LDT] = acc0[r];
-                    if (r0 + 4 * lh + 32 + row < rows) o[(size_t)(32 + row) * LDT] = acc1[r];
-                }
-            }
-        };
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int ab = c_dt_ablk[wave][u], sk = c_dt_scale[wave][u];
-            float s0 = 1.f, s1 = 1.f;
-            if (sk >= 0) {
-                s0 = stage[6 * kDtSlice + sk * kDtRows + li];
-                s1 = stage[6 * kDtSlice + sk * kDtRows + 32 + li];
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float *img = stage + (2 * ab + h) * kDtSlice;
-                f4v fa0[4], fa1[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    fa0[q] = *reinterpret_cast<const f4v *>(img + off0 + 4 * (q ^ z0));
-                    fa1[q] = *reinterpret_cast<const f4v *>(img + off1 + 4 * (q ^ z1));
-                }
-                if (sk >= 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        fa0[q] *= s0;
-                        fa1[q] *= s1;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j >> 2][j & 3], breg[u][16 * h + j], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j >> 2][j & 3], breg[u][16 * h + j], acc1, 0, 0, 0);
-                }
-            }
-            if (u == 0) {
-                // the next panel has had one product (~3 us) to arrive; its stores wait on nothing younger than the previous
-                // panel's output stores (vmcnt counts loads and stores together)
-                if (pn < npanels) store_panel(dt_smem + (cur ^ 1) * kDtStage);
-                if (two_tiles) {  // (wave-uniform) T6 / T10: the two products are the two column halves of the block
-                    write_tile(0);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-                }
-            }
-        }
-        if (gives) {  // partial of S_ab for the wave with the same columns
-            float *pt = pbuf + (wave - 2) * kDtPart + li;
+    };
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    auto store_out = [&](int p, int o, const f16v &acc0, const f16v &acc1) {
+        const int r0 = p * 32;
+        float *out = Out + (size_t)(r0 + 4 * lh) * LDOUT + o * 64 + li;
+        if (r0 + 32 <= rows) {  // (uniform) unconditional stores: the compiler can count what it has in flight
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                pt[row * 33] = acc0[r];
-                pt[(32 + row) * 33] = acc1[r];
+                const int rr = (r & 3) + 8 * (r >> 2);
+                out[(size_t)rr * LDOUT] = acc0[r];
+                out[(size_t)rr * LDOUT + 32] = acc1[r];
             }
-        }
-        __syncthreads();
-        if (takes) {
-            const float *pt = pbuf + wave * kDtPart + li;
+        } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                acc0[r] += pt[row * 33];
-                acc1[r] += pt[(32 + row) * 33];
+                const int rr = (r & 3) + 8 * (r >> 2);
+                if (r0 + 4 * lh + rr < rows) {
+                    out[(size_t)rr * LDOUT] = acc0[r];
+                    out[(size_t)rr * LDOUT + 32] = acc1[r];
+                }
             }
         }
-        if (!gives) write_tile(two_tiles ? 1 : c_dt_nh[wave][0]);
-        cur ^= 1;
-    }
+    };
+
+    // One panel.  X holds the panel's block 0 on entry (fetched during the previous panel); Y is free.  The other blocks are
+    // requested one product (64 MFMAs) before their use, and BEFORE the output stores that precede that use in program
+    // order: vmcnt counts loads and stores together and in order, so a load issued after a store cannot be waited for
+    // without waiting for the store as well.  (Alternating the two buffers so that Z' is also requested early costs
+    // registers -- 160 B of scratch -- and measured the same.)
+    float2 sc = load_scale(blockIdx.x * (kRpThreads / 64) + wave), scn = make_float2(0.f, 0.f);
+    auto panel = [&](int p, Blk &X, Blk &Y) {
+        const int pn = p + nwaves;
+        f16v acc0, acc1;
+        if (FWD) {  // blocks: 0 S_ab, 1 S_bc, 2 T6, 3 T10; outputs: 0 O_loc, 1 Z, 2 Z'.  X = S_ab stays the resident block.
+            load_blk(Y, p, 1);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 7, acc0, acc1);
+            store_out(p, 2, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 5, acc0, acc1);
+            prod(Y, false, 1.f, 6, acc0, acc1);
+            store_out(p, 1, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, true, sc.x, 0, acc0, acc1);
+            prod(X, true, sc.y, 2, acc0, acc1);
+            load_blk(X, p, 2);                       // X <- T6 while S_bc runs
+            prod(Y, true, sc.x, 1, acc0, acc1);
+            load_blk(Y, p, 3);                       // Y <- T10 while T6 runs
+            scn = load_scale(pn);
+            prod(X, false, 1.f, 3, acc0, acc1);
+            load_blk(X, pn, 0);                      // X <- S_ab of the next panel while T10 runs
+            prod(Y, false, 1.f, 4, acc0, acc1);
+            store_out(p, 0, acc0, acc1);
+        } else {    // blocks: 0 L, 1 Z, 2 Z'; outputs: 0 dS_ab, 1 dS_bc, 2 dT6, 3 dT10.  X = L.
+            load_blk(Y, p, 1);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 3, acc0, acc1);
+            store_out(p, 2, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 4, acc0, acc1);
+            store_out(p, 3, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, true, sc.x, 1, acc0, acc1);
+            prod(Y, false, 1.f, 6, acc0, acc1);
+            store_out(p, 1, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, true, sc.x, 0, acc0, acc1);
+            prod(X, true, sc.y, 2, acc0, acc1);
+            prod(Y, false, 1.f, 5, acc0, acc1);
+            load_blk(Y, p, 2);                       // Y <- Z' (the one request of a panel that is waited for at once)
+            scn = load_scale(pn);
+            load_blk(X, pn, 0);                      // X <- L of the next panel while Z' runs
+            prod(Y, false, 1.f, 7, acc0, acc1);
+            store_out(p, 0, acc0, acc1);
+        }
+        sc = scn;
+    };
+    Blk B0, B1;
+    int p = blockIdx.x * (kRpThreads / 64) + wave;
+    load_blk(B0, p, 0);
+    for (; p < npanels; p += nwaves) panel(p, B0, B1);  // (block 0 of the next panel is back in B0 when a panel ends)
 }
 
 template <typename T>
@@ -949,8 +928,10 @@ gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO,
     return GF_OK;
 }
 
-// dT[rows][256] from dO[rows][192] and the stacked weights (see smp_dtable_c64); results do not depend on the grid size
-gf_status smp_dtable_panels_c64(gf_ctx *ctx, const float *dO, const float *rowscale, const float *Wst, float *dT, int rows) {
+// Row-panel products of a fused SMP level at C = 64 (see smp_rowpanel_c64): forward O from T, or backward dT from dO.
+// Every output element is produced by one wave in a fixed order: results do not depend on the grid size.
+gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
+                                    int rows) {
     if (rows < 1) return GF_OK;
     static int cus = 0;
     if (!cus) {
@@ -959,16 +940,22 @@ gf_status smp_dtable_panels_c64(gf_ctx *ctx, const float *dO, const float *rowsc
         GF_HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (cus < 1) cus = 256;
     }
-    const size_t lds = sizeof(float) * (2 * (size_t)kDtStage + 4 * (size_t)kDtPart);
+    const size_t lds = sizeof(float) * 8 * 2 * 2 * 32 * (size_t)kRpWRow;
     static bool opted = false;
     if (!opted) {
-        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_dtable_c64), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds));
+        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_rowpanel_c64<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_rowpanel_c64<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         opted = true;
     }
-    const int npanels = (rows + kDtRows - 1) / kDtRows;
-    const int grid = npanels < cus ? npanels : cus;  // one persistent workgroup per CU (144 KB of LDS)
-    GF_LAUNCH(ctx, "gemm_nt", smp_dtable_c64, dim3((unsigned)grid), dim3(kDtThreads), lds, dO, rowscale, Wst, dT, rows);
+    const int npanels = (rows + 31) / 32, per = kRpThreads / 64;
+    const int want = (npanels + per - 1) / per;
+    const int grid = want < cus ? want : cus;  // one persistent workgroup per CU (the weight image takes 144 KB of LDS)
+    if (forward)
+        GF_LAUNCH(ctx, "gemm_nn", smp_rowpanel_c64<true>, dim3((unsigned)grid), dim3(kRpThreads), lds, A, rowscale, Wst, Out, rows);
+    else
+        GF_LAUNCH(ctx, "gemm_nt", smp_rowpanel_c64<false>, dim3((unsigned)grid), dim3(kRpThreads), lds, A, rowscale, Wst, Out, rows);
     return GF_OK;
 }
 

@@ -27,6 +27,11 @@ using namespace gf::dev;
 namespace gf {
 namespace {
 
+bool env_is(const char *name, char v) {
+    const char *e = std::getenv(name);
+    return e && e[0] == v;
+}
+
 constexpr float kAlphaF = 0.01f;
 __device__ __forceinline__ float lreluf(float z) { return z > 0.f ? z : kAlphaF * z; }
 
@@ -869,7 +874,11 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             {T + T_SAB * C, d.Wst + 7 * CC, O + O_ZP * C, rows, C, C, ldt, C, ldo, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0,
              {-1, -1, -1, -1}},
         };
-        if (gemm_grouped_supported(sp, 3, false, false)) {
+        const bool panels = !env_is("GF_SMP_ROWPANEL", '0');  // (read per call: the parity tests switch it)
+        if (C == 64 && panels) {
+            st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows);  // weights in LDS, rows in registers
+            if (st != GF_OK) return st;
+        } else if (gemm_grouped_supported(sp, 3, false, false)) {
             st = gemm_grouped_rows(ctx, false, false, sp, 3, rows);
             if (st != GF_OK) return st;
         } else {
@@ -974,7 +983,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
                           {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, gs[i].scol >= 0 ? d.rowscale : nullptr, 2, {gs[i].scol, -1, -1, -1}};
             sp[i] = z;
         }
-        static const bool stationary = !(std::getenv("GF_SMP_WGRAD") && std::getenv("GF_SMP_WGRAD")[0] == '0');
+        const bool stationary = !env_is("GF_SMP_WGRAD", '0');
         if (C == 64 && stationary) {
             st = smp_wgrad_stationary_c64(ctx, T, dO, d.rowscale, rows, d.dWst);  // every operand byte fetched once
             if (st != GF_OK) return st;
@@ -1015,9 +1024,9 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
             {dO, d.Wst, dT + T_T6 * C, rows, 2 * C, C, ldo, C, ldt, 1, {O_LOC * oC, 0, 0, 0}, {3 * wCC, 0, 0, 0}, {C, 0, 0, 0}, nullptr, 0,
              {-1, -1, -1, -1}},
         };
-        static const bool panels = !(std::getenv("GF_SMP_DTABLE") && std::getenv("GF_SMP_DTABLE")[0] == '0');
+        const bool panels = !env_is("GF_SMP_ROWPANEL", '0');  // (read per call: the parity tests switch it)
         if (C == 64 && panels) {
-            st = smp_dtable_panels_c64(ctx, dO, d.rowscale, d.Wst, dT, rows);  // persistent row-panel kernel, weights in registers
+            st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows);  // weights in LDS, rows in registers
             if (st != GF_OK) return st;
         } else if (gemm_grouped_supported(dg, 3, false, true)) {
             st = gemm_grouped_rows(ctx, false, true, dg, 3, rows);

@@ -28,7 +28,8 @@ struct GemmSpec {
 bool gemm_grouped_supported(const GemmSpec *specs, int n, bool ta, bool tb);
 gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows);
 gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int rows, float *dest, int accumulate);
-gf_status smp_dtable_panels_c64(gf_ctx *ctx, const float *dO, const float *rowscale, const float *Wst, float *dT, int rows);
+gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
+                                    int rows);
 gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst);
 }
 

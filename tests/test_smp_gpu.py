@@ -151,6 +151,25 @@ def test_folded_backward_gather_equals_the_two_kernel_path(gf, monkeypatch):
     assert rel_err(g1, g0) <= 1e-6
 
 
+def test_c64_level_kernels_equal_the_tiled_gemm_path(gf, monkeypatch):
+    """At C = 64 the block products of a fused level run as dedicated kernels (weights resident in LDS with the rows in
+    registers; output-stationary weight gradients).  GF_SMP_ROWPANEL=0 / GF_SMP_WGRAD=0 select the grouped tiled GEMM
+    launches that every other channel count uses: same products, different summation order."""
+    F, D, C, L, cap = 5, 5, 64, 3, 29
+    mols, tg = [], []
+    for seed in range(40):   # 40 molecules: the row counts are not multiples of the 32-row panels / 32-row slices
+        adj, feat, t = synthetic_molecule(1300 + seed)
+        mols.append((adj, feat))
+        tg.append(t)
+    params = smp_params(C, F, D, L, 6)
+    p1, _, f1, g1, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    monkeypatch.setenv("GF_SMP_ROWPANEL", "0")
+    monkeypatch.setenv("GF_SMP_WGRAD", "0")
+    p0, _, f0, g0, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    assert rel_err(p1, p0) <= 1e-5 and rel_err(f1, f0) <= 1e-5
+    assert rel_err(g1, g0) <= 2e-5
+
+
 def test_text_checkpoint_is_interchangeable_with_the_reference(gf, golden, tmp_path):
     """tests/golden/smp_syn12_checkpoint.txt was written by the REAL SMP_omega::save_model (SMP_omega.h:1033-1042).
     load_model must read it, predict like the golden, and save_model must write the very same bytes back."""
