@@ -9,6 +9,9 @@ def launch_name(k):
     m = re.match(r"gf::gemm_f32_mfma(_grouped)?<(true|false), (true|false)", k)
     if m:
         return "gemm_" + ("t" if m.group(2) == "true" else "n") + ("t" if m.group(3) == "true" else "n")
+    m = re.match(r"gf::smp_rowpanel_c64<(true|false)>", k)
+    if m:
+        return "gemm_nn" if m.group(1) == "true" else "gemm_nt"
     base = re.sub(r"[<(].*", "", k).split("::")[-1]
     table = {"smp_tables_fwd": "smpf_tables_fwd", "smp_tables_fwd_w": "smpf_tables_fwd", "smp_tables_bwd": "smpf_tables_bwd",
              "smp_combine_fwd": "smpf_combine_fwd", "smp_combine_bwd": "smpf_combine_bwd", "promote_backward": "smp_promote_bwd",
