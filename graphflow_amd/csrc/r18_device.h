@@ -43,11 +43,39 @@ __device__ __forceinline__ f4 shfl_xor4(f4 v, int m) {
     return r;
 }
 
+// x + (x of lane ^ 16) and x + (x of lane ^ 32) on the VALU.  gfx950's v_permlane16_swap / v_permlane32_swap exchange the
+// odd 16-lane rows (the upper 32 lanes) of one register with the even rows (the lower 32 lanes) of another; fed two copies of
+// x they return {rows 0,0,2,2 | rows 1,1,3,3} ({lower, lower | upper, upper}), whose sum is the butterfly step in every
+// lane.  __shfl_xor compiles to ds_bpermute_b32, which goes through the LDS crossbar: the slab kernels issue 16 of those
+// per row, and that -- not HBM -- was what bounded them.
+__device__ __forceinline__ float xor16_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Sum over the c-groups of a wave (lanes that share the same channel quad): xor-butterfly over lane bits >= log2(LPC).
 template <int LPC>
 __device__ __forceinline__ f4 reduce_cgroups(f4 v) {
 #pragma unroll
-    for (int m = LPC; m < 64; m <<= 1) v += shfl_xor4(v, m);
+    for (int m = LPC; m < 16; m <<= 1) v += shfl_xor4(v, m);
+    if (LPC <= 16) {
+        v.x = xor16_sum(v.x);
+        v.y = xor16_sum(v.y);
+        v.z = xor16_sum(v.z);
+        v.w = xor16_sum(v.w);
+    }
+    if (LPC <= 32) {
+        v.x = xor32_sum(v.x);
+        v.y = xor32_sum(v.y);
+        v.z = xor32_sum(v.z);
+        v.w = xor32_sum(v.w);
+    }
     return v;
 }
 

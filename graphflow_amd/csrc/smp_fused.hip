@@ -82,6 +82,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
     const int f = win * 64 + 4 * fl;
     const bool fok = f < C;
     const int fld = fok ? f : 0;
+    const bool allok = (C & 63) == 0;  // (uniform) every lane of every window has channels
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sR = smem;                                              // [N]
@@ -146,7 +147,17 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
         sab = reduce_cgroups<LPC>(sab);
         t6 = reduce_cgroups<LPC>(t6);
         dgsum += dcur;
-        if (fok) {
+        if (allok) {
+            // every lane stores (c-groups 0/2 the S_ab block, 1/3 the T6 block; the pairs write identical values to the same
+            // address): a store that all paths issue can be COUNTED by the compiler, so waiting for the next row's loads
+            // (vmcnt is in order over loads and stores) need not include it; lane-conditional stores cannot (-5 %)
+            float *trow = T + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + f;  // table row (a, b)
+            st4(trow + ((cg & 1) ? T_T6 : T_SAB) * C, (cg & 1) ? t6 : sab);
+            if (a == b) {  // (wave-uniform)
+                if (cg == 0) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);
+                if (cg == 3) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, sab);
+            }
+        } else if (fok) {
             float *trow = T + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + f;  // table row (a, b)
             if (cg == 0) {
                 st4(trow + T_SAB * C, sab);
