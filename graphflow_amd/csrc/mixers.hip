@@ -6,23 +6,20 @@
 //   MatTensorMul  Out[R,J*D]  = X[R,Kd] F[Kd,J*D]              bwd  dX += G F^T,   dF += X^T G
 //   TensorMatMul  Out_i[J,D]  = Y^T[J,Kd] F_i[Kd,D], i < R     bwd  dF_i += Y G_i, dY += sum_i F_i G_i^T
 // using v_mfma_f32_32x32x2_f32 (exact fp32, the only fp32-input matrix instruction on gfx950; there is no
-// xf32/TF32).  Tile: 64 x 64 x 32 per 256-thread workgroup, 2 x 2 waves of one 32 x 32 accumulator each, operands
-// staged through padded LDS, next tile's global loads issued before the current tile's MFMAs.  Reductions over a
+// xf32/TF32).  Tile: 128 x 64 x 32 per 256-thread workgroup, 2 x 2 waves of two 32 x 32 accumulators each, operands
+// staged through a padded, swizzled LDS image (gemm_lds.h), next tile's global loads issued before the current tile's MFMAs.  Reductions over a
 // long K with a small output (dB of the K-projection: K = sum s^2 rows) are split over K into a workspace and
 // summed by a second kernel in a fixed order, so results are deterministic (no atomics).
 #include <algorithm>
 #include <cstdlib>
 
+#include "gemm_lds.h"
 #include "smp_internal.h"
 
 namespace gf {
 namespace {
 
-constexpr int BM = 128, BN = 64, BK = 32;
-constexpr int kThreads = 256;
-constexpr int LDS_ROW = BK + 4;  // 36 floats = 144 B: 16-byte aligned rows, conflict-free ds_read_b128 across 16 rows
-using f16v = __attribute__((ext_vector_type(16))) float;
-using f4v = __attribute__((ext_vector_type(4))) float;
+using namespace lds_image;
 
 struct GemmArgs {
     const float *A, *B;
@@ -65,33 +62,6 @@ struct GroupedArgs {
     // consecutive workgroups of one XCD, so they still share its L2.
     int npanels, window;
 };
-
-// Position of k inside an LDS row: even k first, then odd k.  The f32 MFMA 32x32x2 gives lane (i, h = lane >> 5) the
-// operand element k = 2 j + h at step j, so with this order each lane's 16 operands of a BK = 32 tile are contiguous
-// (four ds_read_b128 instead of sixteen ds_read_b32).
-__device__ __forceinline__ int kpos(int k) { return (k & 1) * (BK / 2) + (k >> 1); }
-
-// Word offset of (row, kp) inside an operand image.  The eight 16-byte slots of a row are XOR-swizzled by a function of
-// the row: unswizzled, the transposing stores (four scalar ds_write_b32 per float4, 36-word row stride, bank =
-// word % 32) put all 32 lanes of a store group on two banks (SQ_LDS_BANK_CONFLICT was 74 % of the LDS-active cycles);
-// with it they are 2-way (B) / 4-way (A^T), the ds_read_b128 fragment reads stay conflict-free (checked by
-// enumeration over the instruction's four 16-lane groups), and a slot still holds four consecutive kp.
-__device__ __forceinline__ int lds_swz(int row) { return (__builtin_popcount(row & 28) & 1) | ((row >> 4) & 2); }
-// k row taken by the q-th group of 16 lanes in the transposing B store: (0,2,1,3) inside every four, so that one 32-lane
-// store group holds k and k+2 (kp differs by 1: disjoint banks) instead of k and k+1 (kp differs by 16: same banks)
-__device__ __forceinline__ int bscat_k(int q) { return (q & ~3) | ((q & 1) << 1) | ((q >> 1) & 1); }
-// row taken by the q-th group of 8 lanes in the float4-along-k stores (two ds_write_b64 per float4).  Pairing rows r and
-// r + 4 in a 16-lane store group would make these stores conflict-free too (they are 2-way now), but measured no gain.
-__device__ __forceinline__ int rowst_m(int q) { return q; }
-// transposing A store (TA): float4 idx -> (m, k).  Eight lanes take 32 consecutive m of one k row (128 B of global
-// memory), the next eight lanes the row k + 2, ... so that a 32-lane store group holds four different kp & 3 and eight
-// different swizzled slots: 2-way conflicts instead of 4-way with 32 lanes on one k row.
-__device__ __forceinline__ void ascat_mk(int idx, int *m, int *k) {
-    const int a = (idx & 7) + 8 * ((idx >> 5) & 3), kq = (idx >> 3) & 3, kh = idx >> 7;
-    *m = 4 * a;
-    *k = 2 * kq + (kh & 1) + 8 * (kh >> 1);
-}
-__device__ __forceinline__ int lds_at(int row, int kp) { return row * LDS_ROW + ((((kp >> 2) ^ lds_swz(row)) << 2) | (kp & 3)); }
 
 // element (m,k) of op(A): TA ? A[k*lda + m] : A[m*lda + k];   element (k,n) of op(B): TB ? B[n*ldb + k] : B[k*ldb + n]
 // LDS images: As[m][kpos(k)] (128 x 36) and Bs[n][kpos(k)] (64 x 36).  2 x 2 waves; wave (wm, wn) owns rows
@@ -392,298 +362,6 @@ __global__ void splitk_reduce(const float *__restrict__ part, float *__restrict_
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Weight gradients of the fused SMP level at C = 64, output-stationary.  The eight row block products of a level,
-//   dWst[p] = A_p^T B_p summed over the level's rows,   A_p in T = [S_ab|S_bc|T6|T10],  B_p in {dO_loc, tot dO_loc, tr dO_loc, dZ, dZ'}
-// (stack positions 0..7 of smp_fused.hip), share their operands: S_ab feeds four of them, dO_loc five.  As five groups of
-// the grouped split-K launch each product streams its own copy (7.5 GB fetched for 5.1 GB of T and dO at cfg3, PMC).
-// Here a workgroup of eight waves owns a row range, stages each 32-row slice of T (4C) and dO (3C) in LDS ONCE (two stages,
-// one barrier per slice), and wave p accumulates product p as a 64 x 64 register tile (2 x 2 MFMA 32x32 accumulators); the
-// tot / tr factors are applied to the dO_loc fragments in registers.  Every operand byte is read from HBM once per step,
-// 64 MFMAs per wave between barriers.
-// Partial images go through the same two-pass ordered reduction as every split-K launch (fixed order, deterministic).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kWgThreads = 1024, kWgARows = 256, kWgBRows = 192;
-constexpr int kWgStage = (kWgARows + kWgBRows) * LDS_ROW + 2 * BK;  // floats: A image, B image, the slice's tot / tr factors
-__constant__ int c_wg_ablk[8] = {0, 1, 0, 2, 3, 0, 1, 0};    // S_ab, S_bc, S_ab, T6, T10, S_ab, S_bc, S_ab
-__constant__ int c_wg_bblk[8] = {0, 0, 0, 0, 0, 1, 1, 2};    // dO_loc (x tot, x tot, x tr, plain, plain), dZ, dZ, dZ'
-__constant__ int c_wg_scale[8] = {0, 0, 1, -1, -1, -1, -1, -1};
-
-// sixteen waves: wave w owns columns [32 (w & 1), +32) of product w >> 1 as two 32 x 32 accumulators (the wave tile of the
-// general kernel); four waves per SIMD hide each other's LDS and barrier waits
-__global__ __launch_bounds__(kWgThreads, 1) void smp_wgrad_c64(const float *__restrict__ T, const float *__restrict__ dO,
-                                                               const float *__restrict__ rs, int rows, int kchunk,
-                                                               float *__restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) float wg_smem[];  // two stages: slice i is multiplied while slice i + 1 lands
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int prod = wave >> 1, nh = wave & 1;
-    const int kbeg = blockIdx.x * kchunk;
-    const int kend = (kbeg + kchunk < rows) ? kbeg + kchunk : rows;
-    constexpr int LDT = 256, LDO = 192;
-    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    // staging: A = two float4 per thread (transposing store, ascat_mk on each 128-row half), B = 1536 float4 over 1024 threads
-    f4v va[2], vb[2];
-    float2 sc;
-    int am[2], ak[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int idx = tid + e * kWgThreads;  // e = 128-row half
-        int m, k;
-        ascat_mk(idx & 1023, &m, &k);
-        am[e] = (idx >> 10) * 128 + m;
-        ak[e] = k;
-    }
-    // B: float4 id = tid (blocks 0, 1) and 1024 + tid for tid < 512 (block 2); inside a block: 16 float4 per k row
-    const int bsub = tid & 511, bn = (bsub % 16) * 4, bk = bscat_k(bsub / 16), bblk0 = tid >> 9;
-    const bool b2 = tid < 512;
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int gk = k0 + ak[e];
-            va[e] = gk < kend ? *reinterpret_cast<const f4v *>(T + (size_t)gk * LDT + am[e]) : zero4;
-        }
-        const int gk = k0 + bk;
-        const bool in = gk < kend;
-        vb[0] = in ? *reinterpret_cast<const f4v *>(dO + (size_t)gk * LDO + bblk0 * 64 + bn) : zero4;
-        if (b2) vb[1] = in ? *reinterpret_cast<const f4v *>(dO + (size_t)gk * LDO + 128 + bn) : zero4;
-        if (tid < 512 && bn == 0) sc = in ? *reinterpret_cast<const float2 *>(rs + (size_t)gk * 2) : make_float2(0.f, 0.f);
-    };
-    // one of four pieces of the slice's LDS image (issued between the MFMAs of the running slice, or all at once)
-    auto store_piece = [&](float *stage, int pc) {
-        float *As = stage, *Bs = stage + kWgARows * LDS_ROW, *Ss = Bs + kWgBRows * LDS_ROW;
-        if (pc < 2) {
-            const int kp = kpos(ak[pc]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) As[lds_at(am[pc] + j, kp)] = va[pc][j];
-        } else if (pc == 2) {
-            const int kp = kpos(bk);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Bs[lds_at(bblk0 * 64 + bn + j, kp)] = vb[0][j];
-        } else {
-            const int kp = kpos(bk);
-            if (b2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[lds_at(128 + bn + j, kp)] = vb[1][j];
-                if (bn == 0) {  // the slice's row factors, in the lanes' k order (kpos): lane half lh reads 16 consecutive ones
-                    Ss[kp] = sc.x;
-                    Ss[BK + kp] = sc.y;
-                }
-            }
-        }
-    };
-
-    f16v acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-
-    if (kbeg < kend) {
-        const int a0 = c_wg_ablk[prod] * 64, b0 = c_wg_bblk[prod] * 64 + 32 * nh, skind = c_wg_scale[prod];
-        const int aoff0 = (a0 + li) * LDS_ROW + lh * (BK / 2), aoff1 = aoff0 + 32 * LDS_ROW;
-        const int boff = (kWgARows + b0 + li) * LDS_ROW + lh * (BK / 2);
-        const int za0 = lds_swz(a0 + li), za1 = lds_swz(a0 + 32 + li), zb = lds_swz(b0 + li);
-        const int soff = (kWgARows + kWgBRows) * LDS_ROW + (skind > 0 ? BK : 0) + lh * (BK / 2);
-        load_tiles(kbeg);
-#pragma unroll
-        for (int pc = 0; pc < 4; ++pc) store_piece(wg_smem, pc);
-        __syncthreads();
-        int cur = 0;
-        for (int k0 = kbeg;;) {
-            const int kn = k0 + BK;
-            const bool more = kn < kend;
-            if (more) load_tiles(kn);
-            const float *stage = wg_smem + cur * kWgStage;
-            float *next = wg_smem + (cur ^ 1) * kWgStage;
-            // LDS stores of the next slice are issued BETWEEN the MFMAs of the second half (the matrix pipe runs each MFMA for
-            // 64 cycles while the wave goes on); they have had the first half to arrive from HBM
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f4v fa0[2], fa1[2], fb[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    fa0[q] = *reinterpret_cast<const f4v *>(stage + aoff0 + 4 * ((2 * h + q) ^ za0));
-                    fa1[q] = *reinterpret_cast<const f4v *>(stage + aoff1 + 4 * ((2 * h + q) ^ za1));
-                    fb[q] = *reinterpret_cast<const f4v *>(stage + boff + 4 * ((2 * h + q) ^ zb));
-                }
-                if (skind >= 0) {  // (wave-uniform) B = tot dO_loc or tr dO_loc: the factor of row k on the fragment's element k
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) fb[q] *= *reinterpret_cast<const f4v *>(stage + soff + 4 * (2 * h + q));
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j >> 2][j & 3], fb[j >> 2][j & 3], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j >> 2][j & 3], fb[j >> 2][j & 3], acc1, 0, 0, 0);
-                    if (more && h == 1 && (j & 1) == 0) store_piece(next, j >> 1);
-                }
-            }
-            __syncthreads();
-            if (!more) break;
-            cur ^= 1;
-            k0 = kn;
-        }
-    }
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float *out = part + ((size_t)blockIdx.x * 8 + prod) * 4096 + 32 * nh + li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        out[row * 64] = acc0[r];
-        out[(32 + row) * 64] = acc1[r];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Row-panel products of the fused SMP level at C = 64 with the WEIGHTS resident in LDS and the row operand in registers.
-//   forward  (FWD):  O[rows][3C]  = [O_loc | Z | Z']       from T  = [S_ab | S_bc | T6 | T10]
-//                    O_loc = tot S_ab W0 + tr S_ab W2 + tot S_bc W1 + T6 W3 + T10 W4     Z = S_ab W5 + S_bc W6     Z' = S_ab W7
-//   backward (!FWD): dT[rows][4C] = [dS_ab|dS_bc|dT6|dT10] from dO = [L | Z | Z']
-//                    dS_ab = tot L W0^T + tr L W2^T + Z W5^T + Z' W7^T     dS_bc = tot L W1^T + Z W6^T     dT6 = L W3^T    dT10 = L W4^T
-// As tiled GEMMs these are reductions of 2..10 k-steps whose prologues, epilogues and barriers cost half the time.  Here the
-// eight 64 x 64 weight blocks (128 KB) are copied to LDS ONCE per workgroup in B-fragment order, and after that single
-// barrier every wave works alone: it takes a 32-row panel, reads its rows straight from global memory into A fragments --
-// lane (row i, half h) holds columns [32 h, 32 h + 32) of its row, i.e. the MFMA's k order is permuted consistently on
-// both operands -- and runs all sixteen 32 x 32 x 64 products of the panel (512 MFMAs) out of registers and LDS, one output
-// block (two accumulators) at a time.  No operand staging, no barriers, sixteen independent waves per CU.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kRpThreads = 1024, kRpWRow = 36;
-
-template <bool FWD>
-__global__ __launch_bounds__(kRpThreads, 1) void smp_rowpanel_c64(const float *__restrict__ A, const float *__restrict__ rs,
-                                                                  const float *__restrict__ Wst, float *__restrict__ Out, int rows) {
-    constexpr int LDA = FWD ? 256 : 192, LDOUT = FWD ? 192 : 256;
-    extern __shared__ __attribute__((aligned(16))) float rp_smem[];  // [8 pos][2 column halves][2 k halves][32 lanes][36]
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6;
-    // B fragment order: row ((pos 2 + nh) 2 + kh) 32 + i holds B[k = 32 kh + j][n = 32 nh + i] for j = 0..31, where
-    // B = W_pos (forward: W[k][n]) or W_pos^T (backward: W[n][k])
-    for (int e = tid; e < 8 * 4096; e += kRpThreads) {
-        const int pos = e >> 12, r = (e >> 6) & 63, c = e & 63;  // W_pos[r][c]
-        const int k = FWD ? r : c, n = FWD ? c : r;
-        rp_smem[((((pos * 2 + (n >> 5)) * 2 + (k >> 5)) * 32) + (n & 31)) * kRpWRow + (k & 31)] = Wst[e];
-    }
-    __syncthreads();
-    const int npanels = (rows + 31) / 32;
-    const int nwaves = gridDim.x * (kRpThreads / 64);
-    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
-    const float *bbase = rp_smem + (lh * 32 + li) * kRpWRow;
-
-    struct Blk {
-        f4v a[8];
-    };
-    // columns [64 blk + 32 lh, +32) of row `li` of panel p -> A fragments (zeros past the end)
-    auto load_blk = [&](Blk &B, int p, int blk) {
-        const int row = p * 32 + li;
-        const bool ok = p < npanels && row < rows;
-        const float *src = A + (size_t)(ok ? row : 0) * LDA + blk * 64 + 32 * lh;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) B.a[q] = ok ? *reinterpret_cast<const f4v *>(src + 4 * q) : zero4;
-    };
-    auto load_scale = [&](int p) {
-        const int row = p * 32 + li;
-        return (p < npanels && row < rows) ? *reinterpret_cast<const float2 *>(rs + (size_t)row * 2) : make_float2(0.f, 0.f);
-    };
-    // acc (two column halves) += (sc * B.a) x block wpos: 64 MFMAs, B fragments from the LDS image
-    auto prod = [&](const Blk &B, bool scaled, float sc, int wpos, f16v &acc0, f16v &acc1) {
-        const float *b0 = bbase + (size_t)(wpos * 4) * 32 * kRpWRow, *b1 = b0 + 2 * 32 * kRpWRow;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f4v bq0 = *reinterpret_cast<const f4v *>(b0 + 4 * q), bq1 = *reinterpret_cast<const f4v *>(b1 + 4 * q);
-            f4v av = B.a[q];
-            if (scaled) av *= sc;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bq0[c], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bq1[c], acc1, 0, 0, 0);
-            }
-        }
-    };
-    auto clear = [&](f16v &acc0, f16v &acc1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-    };
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    auto store_out = [&](int p, int o, const f16v &acc0, const f16v &acc1) {
-        const int r0 = p * 32;
-        float *out = Out + (size_t)(r0 + 4 * lh) * LDOUT + o * 64 + li;
-        if (r0 + 32 <= rows) {  // (uniform) unconditional stores: the compiler can count what it has in flight
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2);
-                out[(size_t)rr * LDOUT] = acc0[r];
-                out[(size_t)rr * LDOUT + 32] = acc1[r];
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2);
-                if (r0 + 4 * lh + rr < rows) {
-                    out[(size_t)rr * LDOUT] = acc0[r];
-                    out[(size_t)rr * LDOUT + 32] = acc1[r];
-                }
-            }
-        }
-    };
-
-    // One panel.  X holds the panel's block 0 on entry (fetched during the previous panel); Y is free.  The other blocks are
-    // requested one product (64 MFMAs) before their use, and BEFORE the output stores that precede that use in program
-    // order: vmcnt counts loads and stores together and in order, so a load issued after a store cannot be waited for
-    // without waiting for the store as well.  (Alternating the two buffers so that Z' is also requested early costs
-    // registers -- 160 B of scratch -- and measured the same.)
-    float2 sc = load_scale(blockIdx.x * (kRpThreads / 64) + wave), scn = make_float2(0.f, 0.f);
-    auto panel = [&](int p, Blk &X, Blk &Y) {
-        const int pn = p + nwaves;
-        f16v acc0, acc1;
-        if (FWD) {  // blocks: 0 S_ab, 1 S_bc, 2 T6, 3 T10; outputs: 0 O_loc, 1 Z, 2 Z'.  X = S_ab stays the resident block.
-            load_blk(Y, p, 1);
-            clear(acc0, acc1);
-            prod(X, false, 1.f, 7, acc0, acc1);
-            store_out(p, 2, acc0, acc1);
-            clear(acc0, acc1);
-            prod(X, false, 1.f, 5, acc0, acc1);
-            prod(Y, false, 1.f, 6, acc0, acc1);
-            store_out(p, 1, acc0, acc1);
-            clear(acc0, acc1);
-            prod(X, true, sc.x, 0, acc0, acc1);
-            prod(X, true, sc.y, 2, acc0, acc1);
-            load_blk(X, p, 2);                       // X <- T6 while S_bc runs
-            prod(Y, true, sc.x, 1, acc0, acc1);
-            load_blk(Y, p, 3);                       // Y <- T10 while T6 runs
-            scn = load_scale(pn);
-            prod(X, false, 1.f, 3, acc0, acc1);
-            load_blk(X, pn, 0);                      // X <- S_ab of the next panel while T10 runs
-            prod(Y, false, 1.f, 4, acc0, acc1);
-            store_out(p, 0, acc0, acc1);
-        } else {    // blocks: 0 L, 1 Z, 2 Z'; outputs: 0 dS_ab, 1 dS_bc, 2 dT6, 3 dT10.  X = L.
-            load_blk(Y, p, 1);
-            clear(acc0, acc1);
-            prod(X, false, 1.f, 3, acc0, acc1);
-            store_out(p, 2, acc0, acc1);
-            clear(acc0, acc1);
-            prod(X, false, 1.f, 4, acc0, acc1);
-            store_out(p, 3, acc0, acc1);
-            clear(acc0, acc1);
-            prod(X, true, sc.x, 1, acc0, acc1);
-            prod(Y, false, 1.f, 6, acc0, acc1);
-            store_out(p, 1, acc0, acc1);
-            clear(acc0, acc1);
-            prod(X, true, sc.x, 0, acc0, acc1);
-            prod(X, true, sc.y, 2, acc0, acc1);
-            prod(Y, false, 1.f, 5, acc0, acc1);
-            load_blk(Y, p, 2);                       // Y <- Z' (the one request of a panel that is waited for at once)
-            scn = load_scale(pn);
-            load_blk(X, pn, 0);                      // X <- L of the next panel while Z' runs
-            prod(Y, false, 1.f, 7, acc0, acc1);
-            store_out(p, 0, acc0, acc1);
-        }
-        sc = scn;
-    };
-    Blk B0, B1;
-    int p = blockIdx.x * (kRpThreads / 64) + wave;
-    load_blk(B0, p, 0);
-    for (; p < npanels; p += nwaves) panel(p, B0, B1);  // (block 0 of the next panel is back in B0 when a panel ends)
-}
-
 template <typename T>
 __global__ void gather_rows(const T *const *__restrict__ src, T *__restrict__ dst, size_t per, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
@@ -894,68 +572,19 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
     return GF_OK;
 }
 
-// dWst[0..8) = the eight row block products of a fused SMP level at C = 64 (see smp_wgrad_c64).  T = [rows][256],
-// dO = [rows][192], rowscale = [rows][2].  The row range per workgroup depends on `rows` only: results are reproducible.
-gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst) {
-    if (rows < 1) return GF_OK;
-    // one workgroup fits a CU (two LDS stages): aim at `target` row ranges, at least 8 slices each
-    int target = 256;
-    if (const char *e = std::getenv("GF_WGRAD_SPLITS")) target = std::max(1, std::atoi(e));
-    int kchunk = ((rows + target - 1) / target + BK - 1) / BK * BK;
-    if (kchunk < 8 * BK) kchunk = 8 * BK;
-    const int splits = (rows + kchunk - 1) / kchunk;
-    const size_t total = 8 * 4096;
+// part[s][i] (s < splits, i < total) -> dest[i] (+)= sum over s in a fixed order: one pass up to 64 partial images, else two
+// (chunks of 32).  `part` must have room for splits + ceil(splits / 32) images.
+gf_status splitk_fold(gf_ctx *ctx, const float *part, float *dest, size_t total, int splits, int accumulate) {
     const int chunk = 32, nchunks = (splits + chunk - 1) / chunk;
-    gf_status st = ensure_ws(ctx, sizeof(float) * ((size_t)splits + nchunks) * total + 256);
-    if (st != GF_OK) return st;
-    float *part = static_cast<float *>(ctx->ws);
-    const size_t lds = sizeof(float) * 2 * (size_t)kWgStage;
-    static bool opted = false;
-    if (!opted) {
-        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_wgrad_c64), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds));
-        opted = true;
-    }
-    GF_LAUNCH(ctx, "gemm_tn", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part);
-    const unsigned gx1 = (unsigned)((total + 255) / 256);
+    size_t blocks = (total + 255) / 256;
+    const unsigned gx1 = (unsigned)(blocks > 4096 ? 4096 : blocks);
     if (splits > 64) {
-        float *part2 = part + (size_t)splits * total;
+        float *part2 = const_cast<float *>(part) + (size_t)splits * total;
         GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, nchunks), dim3(256), 0, part, part2, total, splits, chunk, 0);
-        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part2, dWst, total, nchunks, nchunks, 0);
+        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part2, dest, total, nchunks, nchunks, accumulate);
     } else {
-        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part, dWst, total, splits, splits, 0);
+        GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part, dest, total, splits, splits, accumulate);
     }
-    return GF_OK;
-}
-
-// Row-panel products of a fused SMP level at C = 64 (see smp_rowpanel_c64): forward O from T, or backward dT from dO.
-// Every output element is produced by one wave in a fixed order: results do not depend on the grid size.
-gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                    int rows) {
-    if (rows < 1) return GF_OK;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GF_HIP_TRY(ctx, hipGetDevice(&dev));
-        GF_HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (cus < 1) cus = 256;
-    }
-    const size_t lds = sizeof(float) * 8 * 2 * 2 * 32 * (size_t)kRpWRow;
-    static bool opted = false;
-    if (!opted) {
-        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_rowpanel_c64<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_rowpanel_c64<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        opted = true;
-    }
-    const int npanels = (rows + 31) / 32, per = kRpThreads / 64;
-    const int want = (npanels + per - 1) / per;
-    const int grid = want < cus ? want : cus;  // one persistent workgroup per CU (the weight image takes 144 KB of LDS)
-    if (forward)
-        GF_LAUNCH(ctx, "gemm_nn", smp_rowpanel_c64<true>, dim3((unsigned)grid), dim3(kRpThreads), lds, A, rowscale, Wst, Out, rows);
-    else
-        GF_LAUNCH(ctx, "gemm_nt", smp_rowpanel_c64<false>, dim3((unsigned)grid), dim3(kRpThreads), lds, A, rowscale, Wst, Out, rows);
     return GF_OK;
 }
 

@@ -23,7 +23,7 @@ template <typename Fn>
 void parallel_for(int n, const Fn &fn) {
     int nt = (int)std::thread::hardware_concurrency();
     if (const char *e = std::getenv("GF_PREP_THREADS")) nt = std::atoi(e);
-    nt = std::max(1, std::min(nt, 32));
+    nt = std::max(1, std::min(nt, std::getenv("GF_PREP_THREADS") ? 128 : 32));
     if (n < 64 || nt == 1) {
         for (int i = 0; i < n; ++i) fn(i);
         return;
