@@ -8,6 +8,9 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <utility>
 
@@ -19,6 +22,69 @@ constexpr int kMaxVertices = 4096;  // per molecule, for the stack-resident vert
 // fn(i) for i in [0, n) on up to GF_PREP_THREADS (default: hardware concurrency, at most 32) host threads; every
 // iteration writes disjoint memory, so the result does not depend on the thread count or on the schedule.  Iterations
 // are handed out in small blocks from a shared counter: molecules differ a lot in cost (O(V^3) each).
+// Worker threads are kept between calls (a training loop prepares a batch per step: spawning 31 threads for each of the
+// seven parallel sections cost ~3 ms of a 24 ms preparation).  One job at a time; the caller takes part in it.
+class WorkerPool {
+public:
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (size_t t = 0; t < threads_.size(); ++t) threads_[t].join();
+    }
+    // runs job() on `helpers` pool threads and on the calling thread; returns when all of them have finished
+    void run(int helpers, const std::function<void()> &job) {
+        std::lock_guard<std::mutex> one_job(run_);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            while ((int)threads_.size() < helpers) {
+                const int id = (int)threads_.size();
+                threads_.emplace_back([this, id]() { loop(id); });
+            }
+            job_ = &job;
+            want_ = helpers;
+            pending_ = helpers;
+            ++generation_;
+        }
+        wake_.notify_all();
+        job();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this]() { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void loop(int id) {
+        unsigned seen = 0;
+        for (;;) {
+            const std::function<void()> *job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                wake_.wait(lk, [&]() { return stop_ || (generation_ != seen && id < want_); });
+                if (stop_) return;
+                seen = generation_;
+                job = job_;
+            }
+            (*job)();
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex run_, m_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void()> *job_ = nullptr;
+    unsigned generation_ = 0;
+    int want_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+WorkerPool &pool() {
+    static WorkerPool p;
+    return p;
+}
+
 template <typename Fn>
 void parallel_for(int n, const Fn &fn) {
     int nt = (int)std::thread::hardware_concurrency();
@@ -30,7 +96,7 @@ void parallel_for(int n, const Fn &fn) {
     }
     const int block = std::max(1, std::min(16, n / (nt * 8)));
     std::atomic<int> next(0);
-    auto worker = [&]() {
+    const std::function<void()> worker = [&]() {
         for (;;) {
             const int lo = next.fetch_add(block);
             if (lo >= n) return;
@@ -38,10 +104,25 @@ void parallel_for(int n, const Fn &fn) {
             for (int i = lo; i < hi; ++i) fn(i);
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
-    worker();
-    for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
+    pool().run(nt - 1, worker);
+}
+
+// a handful of independent tasks (one per level), each on its own thread
+template <typename Fn>
+void parallel_tasks(int n, const Fn &fn) {
+    if (std::getenv("GF_PREP_THREADS") && std::atoi(std::getenv("GF_PREP_THREADS")) <= 1) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<int> next(0);
+    const std::function<void()> worker = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) return;
+            fn(i);
+        }
+    };
+    pool().run(n - 1, worker);
 }
 
 const int kInf = 1000000000;  // SMP_omega.h:1064
@@ -121,7 +202,11 @@ void prepare_molecule(const Config &cfg, int V, const int *adj, const double *fe
     wl_features(cfg, V, feature, out->hops, &out->wl);
     rank_vertices(V, cfg.fdim(), out->wl, &out->rank);
     // receptive fields, SMP_omega.h:509-537
-    out->phi.assign(cfg.nLevels + 1, std::vector<std::vector<int> >(V));
+    out->phi.resize(cfg.nLevels + 1);
+    for (int l = 0; l <= cfg.nLevels; ++l) {  // reused storage: clear, keep capacity
+        out->phi[l].resize(V);
+        for (int v = 0; v < V; ++v) out->phi[l][v].clear();
+    }
     for (int v = 0; v < V; ++v) out->phi[0][v].assign(1, v);
     for (int l = 1; l <= cfg.nLevels; ++l)
         for (int v = 0; v < V; ++v) {
@@ -146,7 +231,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
     const int L = cfg.nLevels, FD = cfg.fdim(), F = cfg.nFeatures;
     const std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
     out->nMol = nMol;
-    out->mols.assign(nMol, Molecule());
+    out->mols.resize(nMol);  // (the molecules of the previous batch keep their vectors: no allocator traffic in steady state)
     out->mol_first_vertex.assign(nMol + 1, 0);
     std::vector<size_t> adj_off(nMol + 1, 0);
     for (int m = 0; m < nMol; ++m) {
@@ -168,9 +253,10 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
     for (int l = 0; l <= L; ++l) out->level[l].buckets.clear();
     // node numbering per level: level 0 in (molecule, vertex) order; level >= 1 bucketed by field size (stable)
     std::vector<std::vector<int> > node_of(L + 1, std::vector<int>(totalV, -1));  // [level][global vertex] -> node
-    for (int l = 0; l <= L; ++l) {
+    parallel_tasks(L + 1, [&](int l) {  // the levels are independent here
         LevelLayout &lv = out->level[l];
         std::vector<std::pair<int, int> > order;  // (size, global vertex)
+        order.reserve(totalV);
         for (int m = 0; m < nMol; ++m)
             for (int v = 0; v < nVertices[m]; ++v)
                 order.push_back(std::make_pair((int)out->mols[m].phi[l][v].size(), out->mol_first_vertex[m] + v));
@@ -224,7 +310,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 if (fld[i] == v) c = (int)i;
             lv.node_center[n] = c;  // always found: the centre survives the cap (SMP_omega.h:476-507)
         }
-    }
+    });
     out->top_node_of_vertex = node_of[L];
     const std::chrono::steady_clock::time_point t_order = std::chrono::steady_clock::now();
 
