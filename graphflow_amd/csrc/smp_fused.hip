@@ -105,34 +105,34 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
     for (int i = 0; i < NI; ++i) sbc[i] = t10[i] = splat(0.f);
     f4 dgsum = splat(0.f);
 
+    // Row a of the slab through a buffer descriptor of the source tensor f_{l-1}[src(n, a)] (wave-uniform base, 32-bit lane
+    // offsets): a structurally-zero position gets an out-of-range offset and the hardware returns 0 -- no 64-bit address
+    // arithmetic and no selects in the loop (the kernel is VALU-bound: ~170 instructions per row before, ~60 % of its time).
     auto load_row = [&](int a, f4(&v)[NI], f4 &dg) {
         const short *map = sPi + a * N;
         const int pb = map[b];
-        if (pb < 0) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) v[i] = splat(0.f);
-            dg = splat(0.f);
-            return;
-        }
         const long long e = (long long)pairbase + a;
-        const float *src = fprev + pair_src_row[e] * C + fld;
-        const int sw = pair_src_s[e];
+        const int sw = __builtin_amdgcn_readfirstlane(pair_src_s[e]);
+        const long long srow = pair_src_row[e];
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(srow & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((unsigned)(srow >> 32));
+        const float *src = fprev + (((long long)hi << 32) | lo) * C;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (size_t)sw * sw * C * sizeof(float));
+        const bool rowok = pb >= 0 && fok;
+        const int rowoff = (pb * sw * C + fld) * 4;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int pc = (cc[i] >= 0) ? map[cc[i]] : -1;
-            const bool ok = pc >= 0 && fok;
-            const f4 x = ld4(src + (ok ? ((size_t)pb * sw + pc) * C : 0));
-            v[i] = ok ? x : splat(0.f);
+            v[i] = buf_ld4(rs, (rowok && pc >= 0) ? rowoff + pc * C * 4 : -1, 0);
         }
         const int pd = (cg == 0) ? pb : map[a];
-        const bool okd = cg < 2 && pd >= 0 && fok;
-        const f4 y = ld4(src + (okd ? ((size_t)pb * sw + pd) * C : 0));
-        dg = okd ? y : splat(0.f);
+        dg = buf_ld4(rs, (rowok && cg < 2 && pd >= 0) ? rowoff + pd * C * 4 : -1, 0);
     };
 
-    f4 cur[NI], nxt[NI], dcur, dnxt;
-    load_row(0, cur, dcur);
-    for (int a = 0; a < N; ++a) {
+    // two row buffers used alternately (the loop is unrolled by two: no register copies between rows)
+    f4 bufA[NI], bufB[NI], dA, dB;
+    float *const tcol = T + (rowbase + b) * (size_t)(T_COLS * C) + f + ((cg & 1) ? T_T6 : T_SAB) * C;  // (+ a N ldt per row)
+    const size_t tstep = (size_t)N * (T_COLS * C);
+    auto row_step = [&](int a, const f4(&cur)[NI], const f4 &dcur, f4(&nxt)[NI], f4 &dnxt) {
         load_row(a + 1 < N ? a + 1 : a, nxt, dnxt);
         const float ra = sR[a];
         f4 sab = splat(0.f), t6 = splat(0.f);
@@ -151,8 +151,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
             // every lane stores (c-groups 0/2 the S_ab block, 1/3 the T6 block; the pairs write identical values to the same
             // address): a store that all paths issue can be COUNTED by the compiler, so waiting for the next row's loads
             // (vmcnt is in order over loads and stores) need not include it; lane-conditional stores cannot (-5 %)
-            float *trow = T + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + f;  // table row (a, b)
-            st4(trow + ((cg & 1) ? T_T6 : T_SAB) * C, (cg & 1) ? t6 : sab);
+            st4(tcol + a * tstep, (cg & 1) ? t6 : sab);  // table row (a, b)
             if (a == b) {  // (wave-uniform)
                 if (cg == 0) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);
                 if (cg == 3) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, sab);
@@ -168,9 +167,11 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
                 if (a == b) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, sab);
             }
         }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) cur[i] = nxt[i];
-        dcur = dnxt;
+    };
+    load_row(0, bufA, dA);
+    for (int a = 0; a < N; a += 2) {
+        row_step(a, bufA, dA, bufB, dB);
+        if (a + 1 < N) row_step(a + 1, bufB, dB, bufA, dA);
     }
     f4 cs = splat(0.f);
 #pragma unroll
