@@ -746,21 +746,29 @@ __global__ __launch_bounds__(256) void smp_bwd_gather(
             for (int e = 0; e < nc; ++e) {
                 const int b = sInv[e][p];
                 if (b < 0) continue;
-                const int s = sS[e], a = sA[e];
-                const float *trow = dT + (size_t)sRow[e] * ldt + f;
-                const float *tab = trow + ((size_t)a * s + b) * ldt;
-                const float *dva = dVt + (size_t)(sPb[e] + a) * 4 * C + f;
-                const float *dvb = dVt + (size_t)(sPb[e] + b) * 4 * C + f;
-                const float *ds = dSt + (size_t)sNode[e] * 4 * C + f;
-                f4 x = ld4(tab + T_SAB * C) + ld4(dva + 0 * C) + ld4(dvb + 1 * C) + ld4(ds + 0 * C);
-                f4 z1 = ld4(dva + 2 * C) + ld4(ds + 2 * C);
+                // the consumer's tables through buffer descriptors (wave-uniform bases, 32-bit lane offsets: no 64-bit address
+                // arithmetic per load; the kernel is instruction-bound)
+                const int s = __builtin_amdgcn_readfirstlane(sS[e]), a = __builtin_amdgcn_readfirstlane(sA[e]);
+                const long long row0 = sRow[e], pb0 = sPb[e];
+                const long long urow = ((long long)__builtin_amdgcn_readfirstlane((int)(row0 >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(row0 & 0xffffffffll));
+                const long long upb = ((long long)__builtin_amdgcn_readfirstlane((int)(pb0 >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(pb0 & 0xffffffffll));
+                const int unode = __builtin_amdgcn_readfirstlane(sNode[e]);
+                const __amdgpu_buffer_rsrc_t rT = make_rsrc(dT + (size_t)urow * ldt, (size_t)s * s * ldt * sizeof(float));
+                const __amdgpu_buffer_rsrc_t rV = make_rsrc(dVt + (size_t)upb * 4 * C, (size_t)s * 4 * C * sizeof(float));
+                const __amdgpu_buffer_rsrc_t rS = make_rsrc(dSt + (size_t)unode * 4 * C, (size_t)4 * C * sizeof(float));
+                const int C4 = C * 4, f4b = f * 4;
+                const int tab = ((a * s + b) * (int)ldt) * 4 + f4b, va = a * 4 * C4 + f4b, vb = b * 4 * C4 + f4b;
+                f4 x = buf_ld4(rT, tab, T_SAB * C4) + buf_ld4(rV, va, 0) + buf_ld4(rV, vb, C4) + buf_ld4(rS, f4b, 0);
+                f4 z1 = buf_ld4(rV, va, 2 * C4) + buf_ld4(rS, f4b, 2 * C4);
                 if (a == b) {
-                    x += ld4(ds + 1 * C);
-                    z1 += ld4(ds + 3 * C);
+                    x += buf_ld4(rS, f4b, C4);
+                    z1 += buf_ld4(rS, f4b, 3 * C4);
                 }
-                const f4 g5 = ld4(tab + T_T6 * C), z2 = ld4(dvb + 3 * C);
+                const f4 g5 = buf_ld4(rT, tab, T_T6 * C4), z2 = buf_ld4(rV, vb, 3 * C4);
                 const float ra = sR[e][a];
-                const float *tb = trow + (size_t)b * s * ldt;
+                const int tb = (b * s * (int)ldt) * 4 + f4b;
 #pragma unroll
                 for (int q0 = 0; q0 < SW; q0 += QB) {
                     if (q0 >= sw) break;
@@ -771,9 +779,9 @@ __global__ __launch_bounds__(256) void smp_bwd_gather(
                         const int q = q0 + j;
                         const int c = (q < sw) ? sInv[e][q] : -1;
                         cc[j] = c;
-                        const float *t = tb + (size_t)(c < 0 ? 0 : c) * ldt;
-                        y[j] = ld4(t + T_SBC * C);
-                        g9[j] = ld4(t + T_T10 * C);
+                        const int t = c < 0 ? -1 : tb + c * (int)ldt * 4;  // (out of range: the load returns 0 and is not used)
+                        y[j] = buf_ld4(rT, t, T_SBC * C4);
+                        g9[j] = buf_ld4(rT, t, T_T10 * C4);
                     }
 #pragma unroll
                     for (int j = 0; j < QB; ++j) {
