@@ -965,6 +965,10 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         const int prevNodes = s->lay.level[l - 1].nNodes, prevPairs = (int)s->lay.level[l - 1].pairs;
         GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(256), 0, dO, d.dGc, pv.node_s, pv.node_pair,
                   d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C);
+        if (s->side_pending) {  // GF_SMP_OVERLAP: the level above may still be folding split-K partials in the context's ONE
+            GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));  // workspace, which the products below use too
+            s->side_pending = false;
+        }
         for (int half = 0; half < 2; ++half) {
             st = gemm(ctx, false, true, prevPairs, C, C, d.dGc + half * C, 2 * C, 0, d.Wst + (8 + half) * CC, C, 0, d.dFdc + half * C,
                       2 * C, 0, 1, 0);
