@@ -427,7 +427,8 @@ gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
         gf_smp::Block b = {p, cap, true, 0};
         s->pool.push_back(b);
     }
-    if (src && count) GF_HIP_TRY(s->ctx, hipMemcpyAsync(p, src, sizeof(T) * count, hipMemcpyHostToDevice, s->ctx->stream));
+    if (src && count)
+        GF_HIP_TRY(s->ctx, hipMemcpyAsync(p, src, sizeof(T) * count, hipMemcpyHostToDevice, s->upload ? s->upload : s->ctx->stream));
     *dst = static_cast<T *>(p);
     return GF_OK;
 }
@@ -452,8 +453,21 @@ void ensure_side_stream(gf_smp *s) {
 }
 
 // End of a batch: its buffers go back to the pool (blocks idle for three batches in a row are returned to the device).
+// the handle's buffers were last touched by the launches before this mark
+void mark_used(gf_smp *s) {
+    if (s->ev_last && hipEventRecord(s->ev_last, s->ctx->stream) == hipSuccess) s->used = true;
+}
+
 void release(gf_smp *s) {
-    if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->ctx) {
+        // wait for this handle's own work only: another handle of the context may be in the middle of its step
+        if (s->ev_last) {
+            if (s->used) (void)hipEventSynchronize(s->ev_last);
+        } else {
+            (void)hipStreamSynchronize(s->ctx->stream);
+        }
+        s->used = false;
+    }
     std::vector<gf_smp::Block> keep;
     for (gf_smp::Block &b : s->pool) {
         if (!b.used && ++b.idle >= 3) {
@@ -587,6 +601,8 @@ gf_status gf_smp_destroy(gf_smp *s) {
     if (!s) return GF_OK;
     gf::release(s);
     gf::release_pool(s);
+    if (s->upload) (void)hipStreamDestroy(s->upload);
+    if (s->ev_last) (void)hipEventDestroy(s->ev_last);
     if (s->side) {
         (void)hipStreamSynchronize(s->side);
         (void)hipStreamDestroy(s->side);
@@ -682,6 +698,7 @@ gf_status gf_smp_adam_step(gf_smp *s, float *params, const float *grads, double 
     GF_LAUNCH(ctx, "smp_adam", gf::adam_step, dim3(gf::grid_for(n)), dim3(256), 0, params, grads, s->adam_m, s->adam_v, n,
               learning_rate, 1.0 / (double)nBatch, s->adam_n, 0.9, 0.999, 1e-8);
     s->adam_n += n;
+    gf::mark_used(s);
     return GF_OK;
 }
 
@@ -706,6 +723,7 @@ gf_status gf_smp_momentum_step(gf_smp *s, float *params, const float *grads, dou
     }
     GF_LAUNCH(ctx, "smp_momentum", gf::momentum_step, dim3(gf::grid_for(n)), dim3(256), 0, params, grads, s->adam_m, n,
               learning_rate, 1.0 / (double)nBatch, gamma);
+    gf::mark_used(s);
     return GF_OK;
 }
 
@@ -800,6 +818,14 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool prep_timing = std::getenv("GF_PREP_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
+    if (!s->upload) {
+        if (hipStreamCreateWithFlags(&s->upload, hipStreamNonBlocking) != hipSuccess) s->upload = nullptr;
+        if (s->upload && hipEventCreateWithFlags(&s->ev_last, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(s->upload);
+            s->upload = nullptr;
+            s->ev_last = nullptr;
+        }
+    }
     gf::release(s);
     const auto tp1 = std::chrono::steady_clock::now();
     gfsmp::build_batch(s->cfg, nMol, nVertices, adj, feature, coulomb, &s->lay);
@@ -917,7 +943,9 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     const size_t gemm_ws = sizeof(float) * 4400 * (size_t)4 * C * C + sizeof(float) * 4400 * (size_t)C * s->cfg.fdim() + (1 << 20);
     st = gf::ensure_ws(ctx, std::max(contract_ws, gemm_ws));
     if (st != GF_OK) return st;
-    GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // the tables are on the device when this returns (the host vectors are reused by the next batch); the context's stream
+    // is NOT waited for: it may be running another handle's step
+    GF_HIP_TRY(ctx, hipStreamSynchronize(s->upload ? s->upload : ctx->stream));
     if (prep_timing) {
         const auto tp3 = std::chrono::steady_clock::now();
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -989,6 +1017,7 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     if (graph_feature)
         GF_HIP_TRY(ctx, hipMemcpyAsync(graph_feature, s->g, sizeof(float) * (size_t)B.nMol * C, hipMemcpyDeviceToDevice, ctx->stream));
     s->forwarded = true;
+    gf::mark_used(s);
     return GF_OK;
 }
 
@@ -1080,6 +1109,7 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
         st = gf::gemm(ctx, true, false, C, FD, nV, s->lv[0].df, C, 0, s->x, FD, 0, dH, FD, 0, 1, 1);
         if (st != GF_OK) return st;
     }
+    gf::mark_used(s);
     return GF_OK;
 }
 

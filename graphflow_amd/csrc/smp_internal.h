@@ -87,6 +87,11 @@ struct gf_smp {
     // table-gradient chain), forked after combine-backward of a level, joined before gf_smp_backward returns.  Forward:
     // the per-(node,x) vectors / per-node scalars and their two small GEMMs, beside the big row GEMM, joined before
     // combine-forward.  Opt-in: GF_SMP_OVERLAP=1.
+    // Two handles on one context can alternate (prepare of one while the device runs the step of the other): uploads go
+    // through the handle's own stream, and recycling the handle's buffers waits for ITS last launch only, not for the stream.
+    hipStream_t upload = nullptr;
+    hipEvent_t ev_last = nullptr;
+    bool used = false;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_tried = false, side_pending = false;

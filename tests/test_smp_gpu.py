@@ -170,6 +170,44 @@ def test_c64_level_kernels_equal_the_tiled_gemm_path(gf, monkeypatch):
     assert rel_err(g1, g0) <= 2e-5
 
 
+def test_two_handles_alternate_without_waiting_for_each_other(gf):
+    """A training loop prepares batch i+1 on a second handle while the device runs step i on the first (uploads on the
+    handle's own stream; recycling a handle's buffers waits for ITS last launch only).  Same gradients as one handle that
+    prepares and steps in turn."""
+    from graphflow_amd.smp import SMPOmega
+    F, D, C, L, cap = 5, 3, 64, 2, 29
+    batches = []
+    for b in range(4):
+        mols, tg = [], []
+        for seed in range(30 + 7 * b):   # different sizes: the pools grow and get reused
+            adj, feat, t = synthetic_molecule(2000 + 100 * b + seed)
+            mols.append((adj, feat))
+            tg.append(t)
+        batches.append((mols, dev(np.array(tg))))
+    p = dev(smp_params(C, F, D, L, 2))
+
+    def loop(nh):
+        nets = [SMPOmega(L, C, F, D, cap, True) for _ in range(nh)]
+        out = []
+        nets[0].prepare(batches[0][0])
+        for it in range(8):
+            cur = nets[it % nh]
+            if nh == 1:
+                cur.prepare(batches[it % 4][0])
+            g = torch.empty(cur.n_params, device="cuda")
+            cur.forward(p, batches[it % 4][1])
+            cur.backward(p, g)
+            if nh == 2:   # no synchronisation between the launches above and this host work
+                nets[(it + 1) % 2].prepare(batches[(it + 1) % 4][0])
+            out.append(g)
+        torch.cuda.synchronize()
+        return [x.cpu().numpy() for x in out]
+
+    one, two = loop(1), loop(2)
+    for a, b in zip(one, two):
+        assert np.array_equal(a, b)
+
+
 def test_text_checkpoint_is_interchangeable_with_the_reference(gf, golden, tmp_path):
     """tests/golden/smp_syn12_checkpoint.txt was written by the REAL SMP_omega::save_model (SMP_omega.h:1033-1042).
     load_model must read it, predict like the golden, and save_model must write the very same bytes back."""
