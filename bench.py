@@ -175,8 +175,15 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
             else:
                 add(kb, "smpf_tables_bwd", 4 * (4 * R * C + S * C))
                 add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
-            for k in ("gemm_nn", "gemm_nt", "gemm_tn"):
-                add(kf, k, 8 * unit)                                     # (+ two C x C products on the compact rows below)
+            # the eight row block products of a level, per direction.  C = 64: dedicated kernels (smp_level_c64.hip); other C,
+            # or with GF_SMP_ROWPANEL / GF_SMP_WGRAD = 0: grouped launches of the generic GEMM (which also runs the small
+            # per-(node,x) / per-node / compact products under these names, not counted here)
+            c64 = C == 64
+            names = (("smpf_products_fwd" if c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0" else "gemm_nn"),
+                     ("smpf_products_bwd" if c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0" else "gemm_nt"),
+                     ("smpf_wgrad" if c64 and os.environ.get("GF_SMP_WGRAD", "1") != "0" else "gemm_tn"))
+            for k in names:
+                add(kf, k, 8 * unit)
                 add(kb, k, 4 * (4 * R * C + 3 * R * C))                  # T (4C) and O / dO (3C) per row, each once
         else:
             add(kb, "smp_promote_fwd", 4 * (Rp * C + S * C))
@@ -202,7 +209,7 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
             ach = kf[dom] / (tot[dom] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None,
-                    "note": "fp32-input MFMA GEMM (v_mfma_f32_32x32x2_f32): block products of the level projection summed over levels"}
+                    "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32): the eight block products of the level projection in this direction, summed over levels"}
         else:
             ach = kb.get(dom, 0) / (tot[dom] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -331,7 +331,7 @@ gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO,
                                             (int)lds));
         opted = true;
     }
-    GF_LAUNCH(ctx, "gemm_tn", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part);
+    GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part);
     return splitk_fold(ctx, part, dWst, total, splits, 0);
 }
 
@@ -360,9 +360,9 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
     const int want = (npanels + per - 1) / per;
     const int grid = want < cus ? want : cus;  // one persistent workgroup per CU (the weight image takes 144 KB of LDS)
     if (forward)
-        GF_LAUNCH(ctx, "gemm_nn", smp_rowpanel_c64<true>, dim3((unsigned)grid), dim3(kRpThreads), lds, A, rowscale, Wst, Out, rows);
+        GF_LAUNCH(ctx, "smpf_products_fwd", smp_rowpanel_c64<true>, dim3((unsigned)grid), dim3(kRpThreads), lds, A, rowscale, Wst, Out, rows);
     else
-        GF_LAUNCH(ctx, "gemm_nt", smp_rowpanel_c64<false>, dim3((unsigned)grid), dim3(kRpThreads), lds, A, rowscale, Wst, Out, rows);
+        GF_LAUNCH(ctx, "smpf_products_bwd", smp_rowpanel_c64<false>, dim3((unsigned)grid), dim3(kRpThreads), lds, A, rowscale, Wst, Out, rows);
     return GF_OK;
 }
 

@@ -11,11 +11,11 @@ def launch_name(k):
         return "gemm_" + ("t" if m.group(2) == "true" else "n") + ("t" if m.group(3) == "true" else "n")
     m = re.match(r"gf::smp_rowpanel_c64<(true|false)>", k)
     if m:
-        return "gemm_nn" if m.group(1) == "true" else "gemm_nt"
+        return "smpf_products_fwd" if m.group(1) == "true" else "smpf_products_bwd"
     base = re.sub(r"[<(].*", "", k).split("::")[-1]
     table = {"smp_tables_fwd": "smpf_tables_fwd", "smp_tables_fwd_w": "smpf_tables_fwd", "smp_tables_bwd": "smpf_tables_bwd",
              "smp_combine_fwd": "smpf_combine_fwd", "smp_combine_bwd": "smpf_combine_bwd", "promote_backward": "smp_promote_bwd",
-             "smp_vectors": "smpf_vectors", "smp_bwd_gather": "smpf_bwd_gather", "smp_wgrad_c64": "gemm_tn"}
+             "smp_vectors": "smpf_vectors", "smp_bwd_gather": "smpf_bwd_gather", "smp_wgrad_c64": "smpf_wgrad"}
     return table.get(base, base)
 
 
