@@ -676,7 +676,7 @@ gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *d
 // consumer gather with tables-backward folded in (GF_SMP_BWD_GATHER).  Workgroup per SOURCE node w of level l-1:
 //   df_{l-1}[w][p,q] = [p==q] dFd[p] + [q==c_w] dFc[p] + sum over consumers (n,a), in consumer order, of dP_n[a, b, c]
 // with b = inv(p), c = inv(q) both present, and dP_n[a,b,c] EVALUATED from the table gradients by the formula above
-// smp_tables_bwd (same expression, same order: the two paths agree to the last bit) instead of being written by one
+// smp_tables_bwd (same expression; only the two diagonal terms are summed separately) instead of being written by one
 // kernel and read back by the next.  A thread owns (p, 4 channels) and keeps the sw accumulators of its row in registers.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kGatherChunk = 64, kGatherMaxS = 32;
@@ -714,14 +714,16 @@ __global__ __launch_bounds__(256) void smp_bwd_gather(
         const int it = base + (int)threadIdx.x;
         const bool live = it < items;
         const int p = live ? it / nl : 0, f = 4 * (live ? it % nl : 0);
-        f4 acc[SW];
+        // The [c == b] and [c == a] terms of dP land on fixed positions of the row: c == b means q == p (inv is injective), and
+        // c == a means q == c_w (the source's own vertex sits at position a of the consumer).  They are summed over the
+        // consumers in two extra accumulators, which start from the compact-path gradients of the same two positions, and
+        // join the row at the end -- not one compare-and-select pair per element of the inner loop.
+        f4 acc[SW], accd = splat(0.f), accc = splat(0.f);
 #pragma unroll
-        for (int q = 0; q < SW; ++q) {
-            acc[q] = splat(0.f);
-            if (live && q < sw) {
-                if (p == q) acc[q] += ld4(dfd + (size_t)p * 2 * C + f);
-                if (q == cw) acc[q] += ld4(dfd + (size_t)p * 2 * C + C + f);
-            }
+        for (int q = 0; q < SW; ++q) acc[q] = splat(0.f);
+        if (live) {
+            accd = ld4(dfd + (size_t)p * 2 * C + f);
+            accc = ld4(dfd + (size_t)p * 2 * C + C + f);
         }
         for (long long cb = c0; cb < c1; cb += kGatherChunk) {
             const int nc = (int)((c1 - cb < kGatherChunk) ? c1 - cb : kGatherChunk);
@@ -787,18 +789,22 @@ __global__ __launch_bounds__(256) void smp_bwd_gather(
                     for (int j = 0; j < QB; ++j) {
                         const int c = cc[j];
                         if (c < 0) continue;
-                        f4 o = x + y[j] + g5 * sR[e][c] + g9[j] * ra;
-                        if (c == b) o += z1;
-                        if (c == a) o += z2;
-                        acc[q0 + j] += o;
+                        acc[q0 + j] += x + y[j] + g5 * sR[e][c] + g9[j] * ra;
                     }
                 }
+                accd += z1;
+                accc += z2;
             }
         }
         if (live) {
 #pragma unroll
             for (int q = 0; q < SW; ++q)
-                if (q < sw) st4(dst + ((size_t)p * sw + q) * C + f, acc[q]);
+                if (q < sw) {
+                    f4 o = acc[q];
+                    if (q == p) o += accd;
+                    if (q == cw) o += accc;
+                    st4(dst + ((size_t)p * sw + q) * C + f, o);
+                }
         }
     }
 }

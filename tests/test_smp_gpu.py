@@ -137,7 +137,8 @@ def test_fused_and_op_by_op_levels_agree_at_scale(gf):
 
 def test_folded_backward_gather_equals_the_two_kernel_path(gf, monkeypatch):
     """Fused levels evaluate dP inside the consumer gather (default) or write it with tables-backward and gather it
-    afterwards (GF_SMP_BWD_GATHER=0, also the route for receptive fields > 32): same expression, same summation order."""
+    afterwards (GF_SMP_BWD_GATHER=0, also the route for receptive fields > 32): same expression (the gather adds the two
+    diagonal terms of a row after the consumers instead of per consumer)."""
     F, D, C, L, cap = 5, 5, 64, 3, 29
     mols, tg = [], []
     for seed in range(24):
