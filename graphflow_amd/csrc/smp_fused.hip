@@ -32,6 +32,20 @@ bool env_is(const char *name, char v) {
     return e && e[0] == v;
 }
 
+// Totals of two tables over the four c-groups (16-lane rows) of a wave in ONE butterfly: v_permlane16_swap of (u, v) leaves
+// {u.r0, v.r0, u.r2, v.r2} and {u.r1, v.r1, u.r3, v.r3}, whose sum pairs rows 0+1 and 2+3 of u in the even rows and of v in
+// the odd rows; the xor-32 step finishes both.  Even c-groups end up with the total of u, odd ones with the total of v:
+// half the lane traffic of reducing each table to all lanes.
+__device__ __forceinline__ f4 fold_two_tables(f4 u, f4 v) {
+    f4 z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[k]), __float_as_uint(v[k]), false, false);
+        z[k] = xor32_sum(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+    }
+    return z;
+}
+
 constexpr float kAlphaF = 0.01f;
 __device__ __forceinline__ float lreluf(float z) { return z > 0.f ? z : kAlphaF * z; }
 
@@ -144,27 +158,26 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
             sab += v;
             t6 += rc[i] * v;
         }
-        sab = reduce_cgroups<LPC>(sab);
-        t6 = reduce_cgroups<LPC>(t6);
+        const f4 both = fold_two_tables(sab, t6);  // even c-groups: S_ab[a,b], odd c-groups: T6[a,b]
         dgsum += dcur;
         if (allok) {
             // every lane stores (c-groups 0/2 the S_ab block, 1/3 the T6 block; the pairs write identical values to the same
             // address): a store that all paths issue can be COUNTED by the compiler, so waiting for the next row's loads
             // (vmcnt is in order over loads and stores) need not include it; lane-conditional stores cannot (-5 %)
-            st4(tcol + a * tstep, (cg & 1) ? t6 : sab);  // table row (a, b)
+            st4(tcol + a * tstep, both);  // table row (a, b)
             if (a == b) {  // (wave-uniform)
                 if (cg == 0) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);
-                if (cg == 3) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, sab);
+                if (cg == 2) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, both);
             }
         } else if (fok) {
             float *trow = T + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + f;  // table row (a, b)
             if (cg == 0) {
-                st4(trow + T_SAB * C, sab);
+                st4(trow + T_SAB * C, both);
                 if (a == b) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);
+            } else if (cg == 1) {
+                st4(trow + T_T6 * C, both);
             } else if (cg == 2) {
-                st4(trow + T_T6 * C, t6);
-            } else if (cg == 3) {
-                if (a == b) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, sab);
+                if (a == b) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, both);
             }
         }
     };
