@@ -325,11 +325,12 @@ gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO,
     if (st != GF_OK) return st;
     float *part = static_cast<float *>(ctx->ws);
     const size_t lds = sizeof(float) * 2 * (size_t)kWgStage;
-    static bool opted = false;
-    if (!opted) {
+    static bool opted[64] = {};  // per device (one process per GPU is the design; a multi-device process still works)
+    const int di = ctx->device & 63;
+    if (!opted[di]) {
         GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_wgrad_c64), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds));
-        opted = true;
+        opted[di] = true;
     }
     GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part);
     return splitk_fold(ctx, part, dWst, total, splits, 0);
@@ -340,21 +341,21 @@ gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO,
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
                                     int rows) {
     if (rows < 1) return GF_OK;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GF_HIP_TRY(ctx, hipGetDevice(&dev));
-        GF_HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (cus < 1) cus = 256;
+    static int cu_count[64] = {};
+    const int di = ctx->device & 63;
+    if (!cu_count[di]) {
+        GF_HIP_TRY(ctx, hipDeviceGetAttribute(&cu_count[di], hipDeviceAttributeMultiprocessorCount, ctx->device));
+        if (cu_count[di] < 1) cu_count[di] = 256;
     }
+    const int cus = cu_count[di];
     const size_t lds = sizeof(float) * 8 * 2 * 2 * 32 * (size_t)kRpWRow;
-    static bool opted = false;
-    if (!opted) {
+    static bool opted[64] = {};
+    if (!opted[di]) {
         GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_rowpanel_c64<true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_rowpanel_c64<false>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        opted = true;
+        opted[di] = true;
     }
     const int npanels = (rows + 31) / 32, per = kRpThreads / 64;
     const int want = (npanels + per - 1) / per;
