@@ -209,6 +209,25 @@ def test_two_handles_alternate_without_waiting_for_each_other(gf):
         assert np.array_equal(a, b)
 
 
+def test_fused_levels_never_take_the_promotion_buffer(gf):
+    """gf_smp_device_bytes: the fused path with the folded backward gather materialises neither P nor dP, so its batch holds
+    less device memory than the op-by-op pipeline of the same batch (which takes the shared [sum s^3][C] buffer on first use)."""
+    F, D, C, L, cap = 5, 3, 64, 2, 29
+    mols, tg = [], []
+    for seed in range(16):
+        adj, feat, t = synthetic_molecule(3000 + seed)
+        mols.append((adj, feat))
+        tg.append(t)
+    params = smp_params(C, F, D, L, 4)
+    fused_net = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap, fused=True)[4]
+    plain_net = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap, fused=False)[4]
+    used_f, res_f = fused_net.device_bytes()
+    used_p, res_p = plain_net.device_bytes()
+    assert 0 < used_f <= res_f and 0 < used_p <= res_p
+    ppos = plain_net.level_sizes(L)[2]
+    assert used_p - used_f >= 4 * ppos * C * 0.9   # at least (most of) the promotion buffer
+
+
 def test_text_checkpoint_is_interchangeable_with_the_reference(gf, golden, tmp_path):
     """tests/golden/smp_syn12_checkpoint.txt was written by the REAL SMP_omega::save_model (SMP_omega.h:1033-1042).
     load_model must read it, predict like the golden, and save_model must write the very same bytes back."""
