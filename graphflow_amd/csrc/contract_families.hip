@@ -253,7 +253,7 @@ __global__ void fam_scalars(const float *__restrict__ P, const float *__restrict
 // Thread per (g, x, block of YB columns y, f): the nine operands of the N x N products that are indexed by (x, z) are
 // loaded once per z and serve all YB columns (they do not depend on y); only two adjacency entries are per column.
 // (with 16-byte channel vectors a thread keeps one column: 18 x 4 accumulators)
-template <int K, int VW>
+template <int K, int VW, bool PRODUCTS = true>
 __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, const float *__restrict__ A,
                                                    const float *__restrict__ adjs, const float *__restrict__ tab,
                                                    const float *__restrict__ vec, const float *__restrict__ sc,
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, 
                 OUTC(50, s4 * axy);
             }
         }
-        if (K == 50) {
+        if (K == 50 && PRODUCTS) {
             // N x N products with A: one pass over the contracted index for the whole column block
             V mm[kYB][18];
 #pragma unroll
@@ -385,6 +385,70 @@ __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, 
     }
 }
 #undef OUTC
+
+// The eighteen N x N products of RisiContraction_50 with the adjacency (cases 18,19,21,22,27,28,30,31,33,34,36,37,43,44,
+// 46-49), LDS-staged.  Workgroup per (graph, x): the nine operand rows indexed by (x, z) / (z, x) -- three pair tables in
+// both orientations and three diagonals of P, N rows of C floats each -- are read from global memory ONCE and shared by all
+// columns y (fam_forward re-reads them per column through L1: 24 x at cfg5); the adjacency of the graph sits beside them.
+// Thread = (column y, channel quad); 18 accumulators of four channels.
+template <int K>
+__global__ __launch_bounds__(256) void fam_products_lds(const float *__restrict__ P, const float *__restrict__ A,
+                                                        const float *__restrict__ tab, float *__restrict__ Out, int N, int C) {
+    static_assert(K == 50, "only RisiContraction_50 has these slices");
+    extern __shared__ __attribute__((aligned(16))) float fp_smem[];
+    const int g = blockIdx.x / N, x = blockIdx.x % N;
+    const int CV = C / 4, tid = threadIdx.x;
+    const size_t NNC = (size_t)N * N * C;
+    const float *Pg = P + (size_t)g * NNC * N, *T = tab + (size_t)g * kNTab * NNC, *Ag = A + (size_t)g * N * N;
+    float *ops = fp_smem;                   // [9][N][C]
+    float *As = fp_smem + (size_t)9 * N * C;  // [N][N]
+    for (int i = tid; i < 9 * N * CV; i += blockDim.x) {
+        const int fl = i % CV, z = (i / CV) % N, k = i / (CV * N);
+        const float *src;
+        switch (k) {
+            case 0: src = T + 0 * NNC + ((size_t)x * N + z) * C; break;   // S_ab[x,z]
+            case 1: src = T + 0 * NNC + ((size_t)z * N + x) * C; break;   // S_ab[z,x]
+            case 2: src = T + 1 * NNC + ((size_t)x * N + z) * C; break;   // S_ac[x,z]
+            case 3: src = T + 1 * NNC + ((size_t)z * N + x) * C; break;   // S_ac[z,x]
+            case 4: src = T + 2 * NNC + ((size_t)x * N + z) * C; break;   // S_bc[x,z]
+            case 5: src = T + 2 * NNC + ((size_t)z * N + x) * C; break;   // S_bc[z,x]
+            case 6: src = Pg + (((size_t)x * N + z) * N + z) * C; break;  // P[x,z,z]
+            case 7: src = Pg + (((size_t)z * N + x) * N + z) * C; break;  // P[z,x,z]
+            default: src = Pg + (((size_t)z * N + z) * N + x) * C; break;  // P[z,z,x]
+        }
+        *reinterpret_cast<float4 *>(ops + ((size_t)k * N + z) * C + 4 * fl) = *reinterpret_cast<const float4 *>(src + 4 * fl);
+    }
+    for (int i = tid; i < N * N; i += blockDim.x) As[i] = Ag[i];
+    __syncthreads();
+    const int fl = tid % CV, ypp = blockDim.x / CV;
+    constexpr int cases[18] = {18, 19, 21, 22, 27, 28, 30, 31, 33, 34, 36, 37, 43, 44, 46, 47, 48, 49};
+    // which operand (row block of `ops`) and which adjacency orientation (0: A[y,z], 1: A[z,y]) each product uses
+    constexpr int opnd[18] = {0, 2, 0, 2, 1, 4, 1, 4, 3, 5, 3, 5, 6, 6, 7, 7, 8, 8};
+    constexpr int ori[18] = {0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1, 0, 1};
+    for (int y = tid / CV; y < N; y += ypp) {
+        float4 mm[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) mm[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < N; ++z) {
+            const float ayz = As[y * N + z], azy = As[z * N + y];
+            float4 o[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[k] = *reinterpret_cast<const float4 *>(ops + ((size_t)k * N + z) * C + 4 * fl);
+#pragma unroll
+            for (int k = 0; k < 18; ++k) {
+                const float a = ori[k] == 0 ? ayz : azy;
+                const float4 v = o[opnd[k]];
+                mm[k].x += v.x * a;
+                mm[k].y += v.y * a;
+                mm[k].z += v.z * a;
+                mm[k].w += v.w * a;
+            }
+        }
+        float *o = Out + (((size_t)g * N + x) * N + y) * (size_t)(K * C) + 4 * fl;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) *reinterpret_cast<float4 *>(o + (size_t)(cases[k] - 1) * C) = mm[k];
+    }
+}
 
 // backward scalars, bsc[g][5][C]: u10, u38, u39, u40, u50 = sum_{d,e} G_c[d,e] A[d,e].
 // Workgroup per (graph, slice): 256 threads = row groups x channel lanes; a group walks (d,e) = grp, grp + ngrp, ...,
@@ -664,7 +728,20 @@ gf_status fam_forward_launch(gf_ctx *ctx, const float *P, const float *A, float 
         GF_LAUNCH(ctx, "fam_tables", (fam_tables<K, 1>), dim3(grid_for(nn)), dim3(256), 0, P, w.adjs, w.tab, N, C, nn);
     GF_LAUNCH(ctx, "fam_vectors", fam_vectors, dim3(grid_for(nv)), dim3(256), 0, P, w.tab, w.vec, w.sc, N, C, nv);
     GF_LAUNCH(ctx, "fam_scalars", fam_scalars, dim3(grid_for(ns)), dim3(256), 0, P, w.vec, w.sc, N, C, ns);
-    if (vec) {
+    const size_t prod_lds = sizeof(float) * ((size_t)9 * N * C + (size_t)N * N);
+    if (vec && K == 50 && prod_lds <= 150 * 1024 && C / 4 <= 256) {
+        // the plain slices by the element kernel, the eighteen adjacency products from LDS-staged operands
+        const size_t nf = (size_t)batch * N * N * (C / 4);
+        GF_LAUNCH(ctx, "fam_forward", (fam_forward<K, 4, false>), dim3(grid_for(nf)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec,
+                  w.sc, Out, N, C, N, nf);
+        static size_t granted = 0;
+        if (prod_lds > 48 * 1024 && prod_lds > granted) {
+            GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fam_products_lds<50>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)prod_lds));
+            granted = prod_lds;
+        }
+        GF_LAUNCH(ctx, "fam_products", (fam_products_lds<50>), dim3((unsigned)(batch * N)), dim3(256), prod_lds, P, A, w.tab, Out, N, C);
+    } else if (vec) {
         const size_t nf = (size_t)batch * N * N * (C / 4);
         GF_LAUNCH(ctx, "fam_forward", (fam_forward<K, 4>), dim3(grid_for(nf)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec, w.sc,
                   Out, N, C, N, nf);
