@@ -11,6 +11,7 @@
 //             fam_tables  thread per (i,j,f): 12 pair tables in one pass over the third index
 //             fam_vectors thread per (i,f) / per f: single-index marginals and scalars
 //             fam_forward thread per (x,y,f): all K outputs, one loop over the contracted index
+//             fam_products_lds (_50, C % 4 = 0): workgroup per (graph, x), the eighteen adjacency products from LDS
 //   backward  fam_bwd_scalars, fam_bwd_tables (thread per (i,j,f): X_ab, X_ac, X_bc, Z_bc, Z_ac, Z_ab),
 //             fam_backward thread per (a,b,c,f): O(1) combination.
 // These are "table" kernels (coalesced over the channel axis, tables re-read through L2), not the LDS-staged slab
