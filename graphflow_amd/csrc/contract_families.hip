@@ -23,8 +23,15 @@
 namespace gf {
 namespace {
 
+// Blocks are dispatched round-robin over the eight XCDs (block b runs on XCD b % 8, each with its own 4 MiB L2), while these
+// kernels re-read per-graph tables: the logical block handed to (XCD x, k-th block of that XCD) is the k-th of the x-th
+// eighth of the grid, so the threads of one graph -- consecutive logical blocks -- share an L2.  A bijection on [0, gridDim).
+__device__ __forceinline__ size_t xcd_block() {
+    const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8;
+    return (size_t)((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8);
+}
 #define GRID_STRIDE(idx, total) \
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < (total); idx += (size_t)gridDim.x * blockDim.x)
+    for (size_t idx = xcd_block() * (size_t)blockDim.x + threadIdx.x; idx < (total); idx += (size_t)gridDim.x * blockDim.x)
 
 unsigned grid_for(size_t total) {
     size_t blocks = (total + 255) / 256;
@@ -397,7 +404,8 @@ __global__ __launch_bounds__(256) void fam_products_lds(const float *__restrict_
                                                         const float *__restrict__ tab, float *__restrict__ Out, int N, int C) {
     static_assert(K == 50, "only RisiContraction_50 has these slices");
     extern __shared__ __attribute__((aligned(16))) float fp_smem[];
-    const int g = blockIdx.x / N, x = blockIdx.x % N;
+    const unsigned blk = (unsigned)xcd_block();
+    const int g = blk / N, x = blk % N;
     const int CV = C / 4, tid = threadIdx.x;
     const size_t NNC = (size_t)N * N * C;
     const float *Pg = P + (size_t)g * NNC * N, *T = tab + (size_t)g * kNTab * NNC, *Ag = A + (size_t)g * N * N;
@@ -646,8 +654,9 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
     using V = typename Vec<VW>::T;
     extern __shared__ __attribute__((aligned(16))) float srow[];  // [4][N][C]: X_ac(a,c) | G14(a,c) | G15(a,c) | G42(a,c)
     const size_t NNC = (size_t)N * N * C, NC = (size_t)N * C;
-    const size_t g = blockIdx.x / N;
-    const int a = (int)(blockIdx.x % N);
+    const size_t blk = xcd_block();
+    const size_t g = blk / N;
+    const int a = (int)(blk % N);
     const float *bt = btab + g * kNBTab * NNC;
     const float *Gg = G + g * (size_t)N * N * K * C;
     const float *r = adjs + g * adjs_stride(N), *q = r + N, *dg = q + N;
