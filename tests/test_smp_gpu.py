@@ -228,6 +228,33 @@ def test_fused_levels_never_take_the_promotion_buffer(gf):
     assert used_p - used_f >= 4 * ppos * C * 0.9   # at least (most of) the promotion buffer
 
 
+def test_cfg3_full_size_properties(gf):
+    """BASELINE configs[2] at full size (3 levels, C = 64, cap 29, 1024 synthetic QM9-size molecules), where the oracle is
+    out of reach: properties that do not depend on the size.  (1) Molecules are independent: a molecule's prediction does not
+    depend on its batch mates or on its position in the batch.  (2) The gradient buffer is the SUM over the batch: two
+    half batches add up to the full one.  (3) Run-to-run bit reproducibility."""
+    F, D, C, L, cap = 5, 5, 64, 3, 29
+    mols, tg = [], []
+    for seed in range(1024):
+        adj, feat, t = synthetic_molecule(seed)
+        mols.append((adj, feat))
+        tg.append(t)
+    tg = np.array(tg)
+    params = smp_params(C, F, D, L, 1)
+    p_all, _, f_all, g_all, _ = run_batch(gf, mols, tg, params, L, C, F, D, cap)
+    p_again, _, _, g_again, _ = run_batch(gf, mols, tg, params, L, C, F, D, cap)
+    assert np.array_equal(p_all, p_again) and np.array_equal(g_all, g_again)
+    h = 512
+    p_a, _, f_a, g_a, _ = run_batch(gf, mols[:h], tg[:h], params, L, C, F, D, cap)
+    p_b, _, f_b, g_b, _ = run_batch(gf, mols[h:], tg[h:], params, L, C, F, D, cap)
+    assert rel_err(np.concatenate([p_a, p_b]), p_all) <= 1e-6
+    assert rel_err(np.concatenate([f_a, f_b]), f_all) <= 1e-6
+    assert rel_err(g_a + g_b, g_all) <= 1e-5            # different split-K ranges / summation order, same sum
+    perm = np.random.default_rng(0).permutation(1024)
+    p_perm = run_batch(gf, [mols[i] for i in perm], tg[perm], params, L, C, F, D, cap)[0]
+    assert rel_err(p_perm, p_all[perm]) <= 1e-6
+
+
 def test_text_checkpoint_is_interchangeable_with_the_reference(gf, golden, tmp_path):
     """tests/golden/smp_syn12_checkpoint.txt was written by the REAL SMP_omega::save_model (SMP_omega.h:1033-1042).
     load_model must read it, predict like the golden, and save_model must write the very same bytes back."""
