@@ -136,6 +136,30 @@ __device__ __forceinline__ AdjLds load_adjacency(float *smem, const float *__res
     return L;
 }
 
+// The adjacency image alone, for callers that have the gated row sums precomputed (the SMP driver: `rsum` of the level) and
+// never read tot / tr: no reductions and NO barrier in here -- the caller's next __syncthreads() publishes the image (the
+// combine kernels run one workgroup per (node, x), 180 000 of them per level: three barriers and two serial folds each were
+// a fifth of their time).
+template <bool TR>
+__device__ __forceinline__ AdjLds load_adjacency_lite(float *smem, const float *__restrict__ Ag, const float *__restrict__ rsum, int N) {
+    AdjLds L;
+    L.A = smem;
+    L.r = smem + pad4(N * (N + 1));
+    L.st = L.r + pad4(N);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N * N; i += kThreads) {
+        const int d = i / N, e = i - d * N;
+        float a = Ag[i];
+        a = (a > 0.f) ? a : 0.f;
+        if (TR)
+            L.A[e * (N + 1) + d] = a;
+        else
+            L.A[d * (N + 1) + e] = a;
+    }
+    for (int i = tid; i < N; i += kThreads) L.r[i] = rsum[i];
+    return L;
+}
+
 // out[y] (y = first; first+step; ...) = sum_e M[y][e] * T[e][channel quad], for up to three tables at once.
 // M is the LDS adjacency (already transposed if the caller needs A^T); rows are walked with stride N+1.
 template <int NT, int CW>

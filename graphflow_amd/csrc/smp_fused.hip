@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
                                                             const float *__restrict__ bias, float *__restrict__ F,
                                                             Ragged R, int C, int nwin, const float *__restrict__ Gc,
                                                             const long long *__restrict__ pair_src_pair,
-                                                            const short *__restrict__ pi) {
+                                                            const short *__restrict__ pi, const float *__restrict__ rsum) {
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
     const int tid = threadIdx.x;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
     const int fc = fok ? f : 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const AdjLds L = load_adjacency<false>(smem, A + rowbase, N);
+    const AdjLds L = load_adjacency_lite<false>(smem, A + rowbase, rsum + pairbase, N);  // (published by the barrier below)
     float *sU = smem + adj_lds_floats(N);  // [N][CW]  Z[x,e] + Z'[e,x]
     for (int e = grp; e < N; e += NGRP) {
         const f4 z = ld4(O + (rowbase + (size_t)x * N + e) * (size_t)(O_COLS * C) + O_Z * C + fc);
@@ -399,7 +399,8 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                                                             // the same C-vector at every (x,y) of a node (readout broadcast)
                                                             const float *__restrict__ A, float *__restrict__ dO,
                                                             float *__restrict__ dVout, float *__restrict__ dSpart,
-                                                            float *__restrict__ dbpart, Ragged R, int C, int nwin) {
+                                                            float *__restrict__ dbpart, Ragged R, int C, int nwin,
+                                                            const float *__restrict__ rsum) {
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
     const int tid = threadIdx.x;
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
     const int fc = fok ? f : 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const AdjLds L = load_adjacency<true>(smem, A + rowbase, N);  // L.A[e][y] = A+[y][e]
+    const AdjLds L = load_adjacency_lite<true>(smem, A + rowbase, rsum + pairbase, N);  // L.A[e][y] = A+[y][e]; see the barrier below
     float *sDz = smem + adj_lds_floats(N);  // [N][CW]
     const f4 gnode = node_dF ? ld4(node_dF + (size_t)W.node * C + fc) : splat(0.f);
     for (int y = grp; y < N; y += NGRP) {
@@ -945,7 +946,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         st = opt_in_lds(ctx, smp_combine_fwd<16>, lds, &granted);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd<16>), dim3((unsigned)(h.pairs * nwin)), dim3(kThreads), lds, O, d.adj,
-                  d.Vout, d.Sout, bl, d.f, ragged_for(d, 0, h.buckets.back().s), C, nwin, d.Gc, d.pair_src_pair, d.pi);
+                  d.Vout, d.Sout, bl, d.f, ragged_for(d, 0, h.buckets.back().s), C, nwin, d.Gc, d.pair_src_pair, d.pi, d.rsum);
     }
     return GF_OK;
 }
@@ -967,7 +968,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         st = opt_in_lds(ctx, smp_combine_bwd<16>, lds, &granted);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.pairs * nwin)), dim3(kThreads), lds, d.f, d.df,
-                  node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, ragged_for(d, 0, h.buckets.back().s), C, nwin);
+                  node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, ragged_for(d, 0, h.buckets.back().s), C, nwin, d.rsum);
     }
     GF_LAUNCH(ctx, "smpf_node_sum", smp_node_sum, dim3(nodes), dim3(64), 0, d.dSpart, d.dSout, d.node_s, d.node_pair, C);
     // bias gradient: column sums of the per-(node,x) partials
