@@ -334,21 +334,45 @@ __global__ void unstack_weight_grads(const float *__restrict__ dstacked, float *
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// combine-forward.  Workgroup per (node, x): f_l[x, y, :] for all y.
+// combine-forward.  Workgroup per (node, four consecutive x) -- the quads of tables-forward: f_l[x, y, :] for all y.
+// A workgroup lives for little more than its memory latencies (one barrier between the gather of U = Z + Z'^T + compact
+// terms and the A-products), so four x per workgroup put four times the loads in flight per latency and read the
+// adjacency once instead of four times.  Items = (x, e) / (x, y) pairs dealt to the sixteen row groups.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kCombX = 4;
+struct QuadWhere {
+    int N, x0, cnt, node, win;
+    size_t rowbase, pairbase;
+};
+__device__ __forceinline__ QuadWhere locate_quad(const int *quad_node, const int *quad_b0, const int *node_s,
+                                                 const long long *node_row, const long long *node_pair, int nwin) {
+    QuadWhere w;
+    const int q = (int)(blockIdx.x / nwin);
+    w.win = (int)(blockIdx.x % nwin);
+    w.node = quad_node[q];
+    w.x0 = quad_b0[q];
+    w.N = node_s[w.node];
+    w.cnt = (w.N - w.x0 < kCombX) ? w.N - w.x0 : kCombX;
+    w.rowbase = (size_t)node_row[w.node];
+    w.pairbase = (size_t)node_pair[w.node];
+    return w;
+}
+
 template <int LPC>
 __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restrict__ O, const float *__restrict__ A,
                                                             const float *__restrict__ Vout, const float *__restrict__ Sout,
                                                             const float *__restrict__ bias, float *__restrict__ F,
-                                                            Ragged R, int C, int nwin, const float *__restrict__ Gc,
-                                                            const long long *__restrict__ pair_src_pair,
+                                                            const int *__restrict__ quad_node, const int *__restrict__ quad_b0,
+                                                            const int *__restrict__ node_s, const long long *__restrict__ node_row,
+                                                            const long long *__restrict__ node_pair, int C, int nwin,
+                                                            const float *__restrict__ Gc, const long long *__restrict__ pair_src_pair,
                                                             const short *__restrict__ pi, const float *__restrict__ rsum) {
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
     const int tid = threadIdx.x;
     const int grp = tid / LPC, fl = tid % LPC;
-    const Where W = locate(R, nwin);
-    const int N = W.N, x = W.i;
+    const QuadWhere W = locate_quad(quad_node, quad_b0, node_s, node_row, node_pair, nwin);
+    const int N = W.N, items = W.cnt * N;
     const size_t rowbase = W.rowbase, pairbase = W.pairbase;
     const int f = W.win * CW + 4 * fl;
     const bool fok = f < C;
@@ -356,8 +380,9 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AdjLds L = load_adjacency_lite<false>(smem, A + rowbase, rsum + pairbase, N);  // (published by the barrier below)
-    float *sU = smem + adj_lds_floats(N);  // [N][CW]  Z[x,e] + Z'[e,x]
-    for (int e = grp; e < N; e += NGRP) {
+    float *sU = smem + adj_lds_floats(N);  // [kCombX][N][CW]  Z[x,e] + Z'[e,x] (+ compact terms)
+    for (int it = grp; it < items; it += NGRP) {
+        const int xi = it / N, e = it - xi * N, x = W.x0 + xi;
         const f4 z = ld4(O + (rowbase + (size_t)x * N + e) * (size_t)(O_COLS * C) + O_Z * C + fc);
         const f4 zp = ld4(O + (rowbase + (size_t)e * N + x) * (size_t)(O_COLS * C) + O_ZP * C + fc);
         f4 u = z + zp;
@@ -368,16 +393,17 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
             if (pxe >= 0) u += g15;
             if (pex >= 0) u += g16;
         }
-        st4(sU + e * CW + 4 * fl, fok ? u : splat(0.f));
+        st4(sU + (size_t)it * CW + 4 * fl, fok ? u : splat(0.f));
     }
     __syncthreads();
-    const f4 vout = ld4(Vout + (pairbase + x) * (size_t)C + fc);
     const f4 sout = ld4(Sout + (size_t)W.node * C + fc);
     const f4 bb = ld4(bias + fc);
-    const float *const Tt[1] = {sU};
-    for (int y = grp; y < N; y += NGRP) {
+    for (int it = grp; it < items; it += NGRP) {
+        const int xi = it / N, y = it - xi * N, x = W.x0 + xi;
+        const float *const Tt[1] = {sU + (size_t)xi * N * CW};
         f4 m[1];
         small_matvec<1, CW>(L, N, y, fl, Tt, m);
+        const f4 vout = ld4(Vout + (pairbase + x) * (size_t)C + fc);
         const float *o = O + (rowbase + (size_t)x * N + y) * (size_t)(O_COLS * C) + fc;
         const f4 z = bb + ld4(o + O_LOC * C) + m[0] + L.r[y] * vout + L.at(x, y, N) * sout;
         if (fok) {
@@ -390,7 +416,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// combine-backward.  Workgroup per (node, x): from dF[x,:,:] produce dO[(x,y)] (tot, tr, dir blocks), dZ[(x,e)],
+// combine-backward.  Workgroup per (node, four consecutive x): from dF[x,:,:] produce dO[(x,y)] (the O_loc block), dZ[(x,e)],
 // dZ'[(e,x)] and the per-(node,x) partials dVout, dS-part, db-part.
 // ---------------------------------------------------------------------------------------------------------------
 template <int LPC>
@@ -399,14 +425,17 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                                                             // the same C-vector at every (x,y) of a node (readout broadcast)
                                                             const float *__restrict__ A, float *__restrict__ dO,
                                                             float *__restrict__ dVout, float *__restrict__ dSpart,
-                                                            float *__restrict__ dbpart, Ragged R, int C, int nwin,
+                                                            float *__restrict__ dbpart, const int *__restrict__ quad_node,
+                                                            const int *__restrict__ quad_b0, const int *__restrict__ node_s,
+                                                            const long long *__restrict__ node_row,
+                                                            const long long *__restrict__ node_pair, int C, int nwin,
                                                             const float *__restrict__ rsum) {
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
     const int tid = threadIdx.x;
     const int grp = tid / LPC, fl = tid % LPC;
-    const Where W = locate(R, nwin);
-    const int N = W.N, x = W.i;
+    const QuadWhere W = locate_quad(quad_node, quad_b0, node_s, node_row, node_pair, nwin);
+    const int N = W.N, items = W.cnt * N;
     const size_t rowbase = W.rowbase, pairbase = W.pairbase;
     const int f = W.win * CW + 4 * fl;
     const bool fok = f < C;
@@ -414,22 +443,24 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AdjLds L = load_adjacency_lite<true>(smem, A + rowbase, rsum + pairbase, N);  // L.A[e][y] = A+[y][e]; see the barrier below
-    float *sDz = smem + adj_lds_floats(N);  // [N][CW]
+    float *sDz = smem + adj_lds_floats(N);  // [kCombX][N][CW]
     const f4 gnode = node_dF ? ld4(node_dF + (size_t)W.node * C + fc) : splat(0.f);
-    for (int y = grp; y < N; y += NGRP) {
+    for (int it = grp; it < items; it += NGRP) {
+        const int xi = it / N, y = it - xi * N, x = W.x0 + xi;
         const size_t row = rowbase + (size_t)x * N + y;
         const f4 fv = ld4(F + row * C + fc), g = node_dF ? gnode : ld4(dF + row * C + fc);
         f4 dz;
 #pragma unroll
         for (int j = 0; j < 4; ++j) dz[j] = fok ? g[j] * (fv[j] > 0.f ? 1.f : kAlphaF) : 0.f;
-        st4(sDz + y * CW + 4 * fl, dz);
+        st4(sDz + (size_t)it * CW + 4 * fl, dz);
         if (fok) {
             st4(dO + row * (size_t)(O_COLS * C) + O_LOC * C + f, dz);
         }
     }
     __syncthreads();
-    const float *const Tt[1] = {sDz};
-    for (int e = grp; e < N; e += NGRP) {
+    for (int it = grp; it < items; it += NGRP) {
+        const int xi = it / N, e = it - xi * N, x = W.x0 + xi;
+        const float *const Tt[1] = {sDz + (size_t)xi * N * CW};
         f4 m[1];
         small_matvec<1, CW>(L, N, e, fl, Tt, m);  // dU[e] = sum_y A+[y][e] dz[y]
         if (fok) {
@@ -437,14 +468,18 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
             st4(dO + (rowbase + (size_t)e * N + x) * (size_t)(O_COLS * C) + O_ZP * C + f, m[0]);
         }
     }
-    if (grp < 3 && fok) {
-        f4 acc = splat(0.f);
-        for (int y = 0; y < N; ++y) {
-            const float w = (grp == 0) ? L.r[y] : (grp == 1) ? L.A[y * (N + 1) + x] : 1.f;  // r[y] | A+[x][y] | 1
-            acc += w * ld4(sDz + y * CW + 4 * fl);
+    if (fok) {
+        for (int it = grp; it < W.cnt * 3; it += NGRP) {  // (x, which) : r[y] | A+[x][y] | 1 weighted sums over y
+            const int xi = it / 3, k = it - xi * 3, x = W.x0 + xi;
+            const float *dz = sDz + (size_t)xi * N * CW + 4 * fl;
+            f4 acc = splat(0.f);
+            for (int y = 0; y < N; ++y) {
+                const float w = (k == 0) ? L.r[y] : (k == 1) ? L.A[y * (N + 1) + x] : 1.f;
+                acc += w * ld4(dz + y * CW);
+            }
+            float *dst = (k == 0) ? dVout : (k == 1) ? dSpart : dbpart;
+            st4(dst + (pairbase + x) * (size_t)C + f, acc);
         }
-        float *dst = (grp == 0) ? dVout : (grp == 1) ? dSpart : dbpart;
-        st4(dst + (pairbase + x) * (size_t)C + f, acc);
     }
 }
 
@@ -609,7 +644,7 @@ size_t tables_bwd_lds(int N) {
 template <int LPC>
 size_t combine_lds(int N) {
     constexpr int CW = 4 * LPC;
-    return sizeof(float) * ((size_t)adj_lds_floats(N) + (size_t)N * CW);
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + (size_t)kCombX * N * CW);
 }
 
 template <typename Kern>
@@ -945,8 +980,9 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         static size_t granted = 0;
         st = opt_in_lds(ctx, smp_combine_fwd<16>, lds, &granted);
         if (st != GF_OK) return st;
-        GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd<16>), dim3((unsigned)(h.pairs * nwin)), dim3(kThreads), lds, O, d.adj,
-                  d.Vout, d.Sout, bl, d.f, ragged_for(d, 0, h.buckets.back().s), C, nwin, d.Gc, d.pair_src_pair, d.pi, d.rsum);
+        GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, O,
+                  d.adj, d.Vout, d.Sout, bl, d.f, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C, nwin, d.Gc,
+                  d.pair_src_pair, d.pi, d.rsum);
     }
     return GF_OK;
 }
@@ -967,8 +1003,9 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         static size_t granted = 0;
         st = opt_in_lds(ctx, smp_combine_bwd<16>, lds, &granted);
         if (st != GF_OK) return st;
-        GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.pairs * nwin)), dim3(kThreads), lds, d.f, d.df,
-                  node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, ragged_for(d, 0, h.buckets.back().s), C, nwin, d.rsum);
+        GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
+                  d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
+                  nwin, d.rsum);
     }
     GF_LAUNCH(ctx, "smpf_node_sum", smp_node_sum, dim3(nodes), dim3(64), 0, d.dSpart, d.dSout, d.node_s, d.node_pair, C);
     // bias gradient: column sums of the per-(node,x) partials
