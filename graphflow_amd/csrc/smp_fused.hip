@@ -969,9 +969,8 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     }
     {  // Gc = [Fd K15 | Fc K16] on the compact rows of the level below
         const int prevPairs = (int)s->lay.level[l - 1].pairs;
-        st = gemm(ctx, false, false, prevPairs, C, C, d.Fdc, 2 * C, 0, d.Wst + 8 * CC, C, 0, d.Gc, 2 * C, 0, 1, 0);
-        if (st != GF_OK) return st;
-        st = gemm(ctx, false, false, prevPairs, C, C, d.Fdc + C, 2 * C, 0, d.Wst + 9 * CC, C, 0, d.Gc + C, 2 * C, 0, 1, 0);
+        // (one launch, batch of two: operand / weight / output of the second product sit C, C*C, C elements further on)
+        st = gemm(ctx, false, false, prevPairs, C, C, d.Fdc, 2 * C, C, d.Wst + 8 * CC, C, (long long)CC, d.Gc, 2 * C, C, 2, 0);
         if (st != GF_OK) return st;
     }
     if (s->side) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
@@ -1026,13 +1025,24 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
             GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));  // workspace, which the products below use too
             s->side_pending = false;
         }
+        // dFdc: one launch, batch of two; dK15 | dK16: one grouped split-K launch (both reduce over the compact rows)
+        st = gemm(ctx, false, true, prevPairs, C, C, d.dGc, 2 * C, C, d.Wst + 8 * CC, C, (long long)CC, d.dFdc, 2 * C, C, 2, 0);
+        if (st != GF_OK) return st;
+        GemmSpec ck[2];
         for (int half = 0; half < 2; ++half) {
-            st = gemm(ctx, false, true, prevPairs, C, C, d.dGc + half * C, 2 * C, 0, d.Wst + (8 + half) * CC, C, 0, d.dFdc + half * C,
-                      2 * C, 0, 1, 0);
+            GemmSpec z = {d.Fdc + half * C, d.dGc + half * C, d.dWst + (8 + half) * CC, C, C, prevPairs, 2 * C, 2 * C, C, 0,
+                          {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}};
+            ck[half] = z;
+        }
+        if (gemm_grouped_supported(ck, 2, true, false)) {
+            st = gemm_grouped_splitk(ctx, ck, 2, prevPairs, d.dWst + 8 * CC, 0);
             if (st != GF_OK) return st;
-            st = gemm(ctx, true, false, C, C, prevPairs, d.Fdc + half * C, 2 * C, 0, d.dGc + half * C, 2 * C, 0, d.dWst + (8 + half) * CC,
-                      C, 0, 1, 0);
-            if (st != GF_OK) return st;
+        } else {
+            for (int half = 0; half < 2; ++half) {
+                st = gemm(ctx, true, false, C, C, prevPairs, d.Fdc + half * C, 2 * C, 0, d.dGc + half * C, 2 * C, 0,
+                          d.dWst + (8 + half) * CC, C, 0, 1, 0);
+                if (st != GF_OK) return st;
+            }
         }
     }
     // The weight-gradient products below read T and dO and write only dWst / dK_l: they run on the handle's second stream
