@@ -811,20 +811,15 @@ __global__ __launch_bounds__(256) void smp_bwd_gather(
                 const __amdgpu_buffer_rsrc_t rS = make_rsrc(dSt + (size_t)unode * 4 * C, (size_t)4 * C * sizeof(float));
                 const int C4 = C * 4, f4b = f * 4;
                 const int tab = ((a * s + b) * (int)ldt) * 4 + f4b, va = a * 4 * C4 + f4b, vb = b * 4 * C4 + f4b;
-                f4 x = buf_ld4(rT, tab, T_SAB * C4) + buf_ld4(rV, va, 0) + buf_ld4(rV, vb, C4) + buf_ld4(rS, f4b, 0);
-                f4 z1 = buf_ld4(rV, va, 2 * C4) + buf_ld4(rS, f4b, 2 * C4);
-                if (a == b) {
-                    x += buf_ld4(rS, f4b, C4);
-                    z1 += buf_ld4(rS, f4b, 3 * C4);
-                }
+                // all of a consumer's row terms AND its first batch of (b, c) rows are requested before anything is summed: one
+                // memory latency for both instead of two in a row (a workgroup's time is the sum of its consumers' latencies)
+                const f4 l0 = buf_ld4(rT, tab, T_SAB * C4), l1 = buf_ld4(rV, va, 0), l2 = buf_ld4(rV, vb, C4), l3 = buf_ld4(rS, f4b, 0);
+                const f4 l4 = buf_ld4(rV, va, 2 * C4), l5 = buf_ld4(rS, f4b, 2 * C4);
+                const f4 l6 = buf_ld4(rS, f4b, C4), l7 = buf_ld4(rS, f4b, 3 * C4);
                 const f4 g5 = buf_ld4(rT, tab, T_T6 * C4), z2 = buf_ld4(rV, vb, 3 * C4);
                 const float ra = sR[e][a];
                 const int tb = (b * s * (int)ldt) * 4 + f4b;
-#pragma unroll
-                for (int q0 = 0; q0 < SW; q0 += QB) {
-                    if (q0 >= sw) break;
-                    f4 y[QB], g9[QB];
-                    int cc[QB];
+                auto load_batch = [&](int q0, f4(&y)[QB], f4(&g9)[QB], int(&cc)[QB]) {
 #pragma unroll
                     for (int j = 0; j < QB; ++j) {
                         const int q = q0 + j;
@@ -834,6 +829,20 @@ __global__ __launch_bounds__(256) void smp_bwd_gather(
                         y[j] = buf_ld4(rT, t, T_SBC * C4);
                         g9[j] = buf_ld4(rT, t, T_T10 * C4);
                     }
+                };
+                f4 y[QB], g9[QB];
+                int cc[QB];
+                load_batch(0, y, g9, cc);
+                f4 x = l0 + l1 + l2 + l3;
+                f4 z1 = l4 + l5;
+                if (a == b) {
+                    x += l6;
+                    z1 += l7;
+                }
+#pragma unroll
+                for (int q0 = 0; q0 < SW; q0 += QB) {
+                    if (q0 >= sw) break;
+                    if (q0 > 0) load_batch(q0, y, g9, cc);
 #pragma unroll
                     for (int j = 0; j < QB; ++j) {
                         const int c = cc[j];
@@ -1034,7 +1043,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
                           {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}};
             ck[half] = z;
         }
-        if (gemm_grouped_supported(ck, 2, true, false)) {
+        if (C <= 64 && gemm_grouped_supported(ck, 2, true, false)) {  // (the grouped split-K tiles are one BN = 64 wide)
             st = gemm_grouped_splitk(ctx, ck, 2, prevPairs, d.dWst + 8 * CC, 0);
             if (st != GF_OK) return st;
         } else {

@@ -72,7 +72,7 @@ def test_batch_equals_sum_of_molecules(gf, golden):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("C,L,cap", [(8, 2, 6), (16, 3, 8), (64, 2, 12)])
+@pytest.mark.parametrize("C,L,cap", [(8, 2, 6), (16, 3, 8), (20, 2, 8), (64, 2, 12), (128, 2, 8)])
 def test_synthetic_batch_vs_oracle(gf, C, L, cap, fused):
     from oracle import smp_oracle
     F, D = 5, 2
