@@ -221,6 +221,14 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
                 t = json.load(fh).get(dom)
             if t:
                 roof["traffic"] = round(t["fetch"] + t["write"])   # HBM bytes of all launches of the kernel in one step
+        # MFMA utilisation of the C = 64 product kernels from the committed PMC pass (SQ_VALU_MFMA_BUSY_CYCLES over four SIMDs x
+        # SQ_BUSY_CU_CYCLES), same workload only
+        busy = os.path.join(ROOT, "profiles", "r01_cfg3_mfma_busy.txt")
+        real = {"smpf_products_fwd": "smp_rowpanel_c64<true>", "smpf_products_bwd": "smp_rowpanel_c64<false>", "smpf_wgrad": "smp_wgrad_c64"}
+        if fused and (B, C) == (1024, 64) and dom in real and os.path.exists(busy):
+            for line in open(busy):
+                if line.startswith(real[dom]) and "MFMA busy" in line:
+                    roof["mfma_busy_pmc"] = float(line.rsplit("MFMA busy", 1)[1])
         roof["kernel"] = dom
         roof["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
         roof["step_GBps"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
