@@ -11,6 +11,8 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libgf_hip.so")
 
 GF_OK, GF_ERR_INVALID, GF_ERR_HIP, GF_ERR_NOMEM, GF_ERR_UNSUPPORTED = range(5)
+GF_OPT_R18_GENERIC_KERNELS = 1
+GF_DIST_ID_BYTES = 128
 
 _fp = C.POINTER(C.c_float)
 _dp = C.POINTER(C.c_double)
@@ -30,6 +32,14 @@ PROTOTYPES = {
     "gf_ctx_timing_get": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "gf_last_error": (C.c_char_p, [_vp]),
     "gf_version": (C.c_char_p, []),
+    "gf_ctx_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "gf_dist_unique_id": (C.c_int, [_vp, _vp]),
+    "gf_dist_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "gf_dist_finalize": (C.c_int, [_vp]),
+    "gf_dist_rank": (C.c_int, [_vp]),
+    "gf_dist_world": (C.c_int, [_vp]),
+    "gf_dist_allreduce_sum_f32": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "gf_dist_broadcast_f32": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     "gf_contract_forward_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "gf_contract_backward_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gf_contract_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -74,6 +84,7 @@ PROTOTYPES.update({
     "gf_smp_prepare_coulomb": (_i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp]),
     "gf_smp_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gf_smp_backward": (_i, [_vp, _vp, _vp, _i]),
+    "gf_smp_set_grad_allreduce": (_i, [_vp, _i]),
     "gf_ctx_set_timing_filter": (_i, [_vp, C.c_char_p]),
     "gf_smp_parameters_upload": (_i, [_vp, _fp]),
     "gf_smp_parameters_download": (_i, [_vp, _fp, _fp]),
@@ -88,6 +99,8 @@ PROTOTYPES.update({
     "gf_smp_device_bytes": (_i, [_vp, _vp, _vp]),
     "gf_smp_prepare_molecule_host": (_i, [_vp, _i, C.POINTER(C.c_int), _dp, C.POINTER(C.c_int), _dp]),
     "gf_smp_receptive_field": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int), _i]),
+    "gf_smp_read_activation": (C.c_longlong, [_vp, _i, _i, _i, _vp, C.c_size_t]),
+    "gf_smp_read_reduced_adjacency": (C.c_longlong, [_vp, _i, _i, _i, _vp, C.c_size_t]),
     "gf_smp_level_sizes": (_i, [_vp, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "gf_stack_forward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
     "gf_stack_backward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),

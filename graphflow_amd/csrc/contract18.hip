@@ -781,17 +781,6 @@ bool fast_shape(int N, int C, const void *p0, const void *p1, const void *p2, Fa
     return true;
 }
 
-// Kernels that want more than the default dynamic-LDS window must opt in once; `granted` is per instantiation.
-template <typename Kern>
-gf_status set_lds(gf_ctx *ctx, Kern kern, size_t bytes, size_t *granted) {
-    if (bytes > 160 * 1024) return fail(ctx, GF_ERR_UNSUPPORTED, "kernel needs %zu B of LDS (> 160 KiB)", bytes);
-    if (bytes > 32 * 1024 && bytes > *granted) {
-        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        *granted = bytes;
-    }
-    return GF_OK;
-}
 
 // One launch set = `blocks` (node/graph, index) pairs x nwin channel windows; R says where each pair lives.
 // smax = largest N among them (sizes the LDS); `uniform_full` enables the unmasked fast variant.
@@ -799,8 +788,7 @@ template <int LPC, int NI, bool FULL>
 gf_status launch_fwd_slab(gf_ctx *ctx, const float *P, const float *A, float *Out, float *wsSab, float *wsDbb,
                           float *wsScal, const Ragged &R, int smax, int C, unsigned grid, int nwin) {
     const size_t l1 = fwd_slab_lds_bytes<LPC, NI>(smax);
-    static size_t g1 = 0;
-    gf_status st = set_lds(ctx, r18_fwd_slab<LPC, NI, FULL>, l1, &g1);
+    gf_status st = opt_in_lds(ctx, r18_fwd_slab<LPC, NI, FULL>, l1);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "r18_fwd_slab", (r18_fwd_slab<LPC, NI, FULL>), dim3(grid), dim3(kThreads), l1, P, A, Out, wsSab,
                        wsDbb, wsScal, R, C, nwin);
@@ -812,12 +800,11 @@ gf_status launch_fwd(gf_ctx *ctx, const float *P, const float *A, float *Out, fl
                      Ragged R, long long blocks, int smax, int C, int nwin) {
     const unsigned grid = (unsigned)((size_t)blocks * nwin);
     const size_t l2 = fwd_rows_lds_bytes<LPC>(smax);
-    static size_t g2 = 0;
     const bool full = !R.pair_node && (smax == NI * (64 / LPC)) && (C % (4 * LPC) == 0);
     gf_status st = full ? launch_fwd_slab<LPC, NI, true>(ctx, P, A, Out, wsSab, wsDbb, wsScal, R, smax, C, grid, nwin)
                         : launch_fwd_slab<LPC, NI, false>(ctx, P, A, Out, wsSab, wsDbb, wsScal, R, smax, C, grid, nwin);
     if (st != GF_OK) return st;
-    st = set_lds(ctx, r18_fwd_rows<LPC>, l2, &g2);
+    st = opt_in_lds(ctx, r18_fwd_rows<LPC>, l2);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "r18_fwd_rows", (r18_fwd_rows<LPC>), dim3(grid), dim3(kThreads), l2, A, Out, wsSab, wsDbb, wsScal, R,
                        C, nwin);
@@ -828,8 +815,7 @@ template <int LPC, int NI, bool FULL, bool ACC>
 gf_status launch_bwd_slab(gf_ctx *ctx, const float *G, const float *A, float *dP, float *wsWX, float *wsWZ,
                           float *wsPart, const Ragged &R, int smax, int C, unsigned grid, int nwin) {
     const size_t l2 = bwd_slab_lds_bytes<LPC>(smax);
-    static size_t g2 = 0;
-    gf_status st = set_lds(ctx, r18_bwd_slab<LPC, NI, FULL, ACC>, l2, &g2);
+    gf_status st = opt_in_lds(ctx, r18_bwd_slab<LPC, NI, FULL, ACC>, l2);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "r18_bwd_slab", (r18_bwd_slab<LPC, NI, FULL, ACC>), dim3(grid), dim3(kThreads), l2, G, A, dP, wsWX,
                        wsWZ, wsPart, R, C, nwin);
@@ -841,8 +827,7 @@ gf_status launch_bwd(gf_ctx *ctx, const float *G, const float *A, float *dP, flo
                      Ragged R, long long blocks, int smax, int C, int nwin, int accumulate) {
     const unsigned grid = (unsigned)((size_t)blocks * nwin);
     const size_t l1 = bwd_rows_lds_bytes<LPC>(smax);
-    static size_t g1 = 0;
-    gf_status st = set_lds(ctx, r18_bwd_rows<LPC>, l1, &g1);
+    gf_status st = opt_in_lds(ctx, r18_bwd_rows<LPC>, l1);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "r18_bwd_rows", (r18_bwd_rows<LPC>), dim3(grid), dim3(kThreads), l1, G, A, wsWX, wsWZ, wsPart, R, C,
                        nwin);
@@ -890,14 +875,13 @@ size_t r18_workspace_bytes(int N, int C, int batch) {
     return sizeof(float) * (a > b ? a : b) + 256;
 }
 
-static int g_force_generic = 0;  // test hook (gf_debug_force_generic)
 
 gf_status r18_forward(gf_ctx *ctx, const float *P, const float *A, float *Out, int N, int C, int batch) {
     gf_status st = ensure_ws(ctx, r18_workspace_bytes(N, C, batch));
     if (st != GF_OK) return st;
     float *ws = static_cast<float *>(ctx->ws);
     FastShape fs;
-    if (!g_force_generic && fast_shape(N, C, P, Out, nullptr, &fs)) {
+    if (!ctx->r18_generic && fast_shape(N, C, P, Out, nullptr, &fs)) {
         const size_t nnc = (size_t)batch * N * N * C;
         float *wsSab = ws, *wsDbb = ws + nnc, *wsScal = ws + 2 * nnc;
         GF_DISPATCH(launch_fwd, ctx, P, A, Out, wsSab, wsDbb, wsScal, uniform_batch(N), (long long)batch * N, N, C, fs.nwin)
@@ -919,7 +903,7 @@ gf_status r18_backward(gf_ctx *ctx, const float *G, const float *A, float *dP, i
     if (st != GF_OK) return st;
     float *ws = static_cast<float *>(ctx->ws);
     FastShape fs;
-    if (!g_force_generic && fast_shape(N, C, G, dP, nullptr, &fs)) {
+    if (!ctx->r18_generic && fast_shape(N, C, G, dP, nullptr, &fs)) {
         const size_t nnc = (size_t)batch * N * N * C;
         float *wsWX = ws, *wsWZ = ws + nnc, *wsPart = ws + 2 * nnc;
         GF_DISPATCH(launch_bwd, ctx, G, A, dP, wsWX, wsWZ, wsPart, uniform_batch(N), (long long)batch * N, N, C, fs.nwin, accumulate)
@@ -937,7 +921,6 @@ gf_status r18_backward(gf_ctx *ctx, const float *G, const float *A, float *dP, i
     return GF_OK;
 }
 
-void r18_force_generic(int on) { g_force_generic = on; }
 
 // ---- ragged batches (SMP driver): nodes of different sizes in one launch ------------------------------------------
 // Pairs [pair_lo, pair_hi) are (node, index) workgroups; all their nodes have size <= smax <= 8 * 64/LPC.

@@ -744,11 +744,9 @@ gf_status fam_forward_launch(gf_ctx *ctx, const float *P, const float *A, float 
         const size_t nf = (size_t)batch * N * N * (C / 4);
         GF_LAUNCH(ctx, "fam_forward", (fam_forward<K, 4, false>), dim3(grid_for(nf)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec,
                   w.sc, Out, N, C, N, nf);
-        static size_t granted = 0;
-        if (prod_lds > 48 * 1024 && prod_lds > granted) {
-            GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fam_products_lds<50>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)prod_lds));
-            granted = prod_lds;
+        {
+            gf_status st = opt_in_lds(ctx, fam_products_lds<50>, prod_lds);
+            if (st != GF_OK) return st;
         }
         GF_LAUNCH(ctx, "fam_products", (fam_products_lds<50>), dim3((unsigned)(batch * N)), dim3(256), prod_lds, P, A, w.tab, Out, N, C);
     } else if (vec) {

@@ -19,6 +19,7 @@ gf_status fail(gf_ctx *ctx, gf_status st, const char *fmt, ...) {
 
 static gf_status grow(gf_ctx *ctx, void **buf, size_t *have, size_t want, bool pinned_host) {
     if (want <= *have) return GF_OK;
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // Growing means the old scratch may still be read by kernels in flight on the stream.
     GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (*buf) {
@@ -40,11 +41,23 @@ static gf_status grow(gf_ctx *ctx, void **buf, size_t *have, size_t want, bool p
     return GF_OK;
 }
 
+void dist_teardown(gf_ctx *ctx);  // gf_dist.hip
+
 gf_status ensure_ws(gf_ctx *ctx, size_t bytes) { return grow(ctx, &ctx->ws, &ctx->ws_bytes, bytes, false); }
 gf_status ensure_stage(gf_ctx *ctx, size_t bytes) { return grow(ctx, &ctx->stage, &ctx->stage_bytes, bytes, false); }
 gf_status ensure_pinned(gf_ctx *ctx, size_t bytes) { return grow(ctx, &ctx->pinned, &ctx->pinned_bytes, bytes, true); }
 
-void r18_force_generic(int on);
+gf_status opt_in_lds_fn(gf_ctx *ctx, const void *kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return fail(ctx, GF_ERR_UNSUPPORTED, "kernel needs %zu B of LDS (> 160 KiB)", bytes);
+    if (bytes <= 32 * 1024) return GF_OK;
+    size_t &granted = ctx->lds_granted[kernel];
+    if (bytes > granted) {
+        GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        GF_HIP_TRY(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        granted = bytes;
+    }
+    return GF_OK;
+}
 
 LaunchTimer::LaunchTimer(gf_ctx *c, const char *name) : ctx(c) {
     if (!c->timing) return;
@@ -484,6 +497,7 @@ gf_status gf_ctx_destroy(gf_ctx *ctx) {
     if (!ctx) return GF_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    gf::dist_teardown(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -492,6 +506,14 @@ gf_status gf_ctx_destroy(gf_ctx *ctx) {
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GF_OK;
+}
+
+gf_status gf_ctx_set_option(gf_ctx *ctx, int option, int value) {
+    if (!ctx) return gf::fail(nullptr, GF_ERR_INVALID, "null context");
+    switch (option) {
+        case GF_OPT_R18_GENERIC_KERNELS: ctx->r18_generic = value ? 1 : 0; return GF_OK;
+        default: return gf::fail(ctx, GF_ERR_INVALID, "gf_ctx_set_option: unknown option %d", option);
+    }
 }
 
 gf_status gf_ctx_set_stream(gf_ctx *ctx, void *stream) {
@@ -684,7 +706,5 @@ gf_status gf_contract_backward_host_f32(gf_ctx *ctx, int K, const float *out_gra
 GF_HOST_MIXERS(f64, double)
 GF_HOST_MIXERS(f32, float)
 
-/* test hook, not declared in the public header: force the generic (layout-agnostic) kernels */
-void gf_debug_force_generic(int on) { gf::r18_force_generic(on); }
 
 }  // extern "C"

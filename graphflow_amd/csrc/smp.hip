@@ -491,6 +491,7 @@ void release_pool(gf_smp *s) {
 // the handle-owned parameter / gradient buffers (host-pointer mode), created on first use
 gf_status own_model(gf_smp *s) {
     if (s->own_p) return GF_OK;
+    GF_HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     const size_t n = param_count_of(s);
     GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->own_p), n * sizeof(float)));
     GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->own_g), n * sizeof(float)));
@@ -563,6 +564,27 @@ gf_status smp_contract(gf_smp *s, int l, bool backward) {
 }  // namespace
 
 gf_status ensure_P(gf_smp *s) { return ensure_P_impl(s); }
+
+// Data-parallel reverse sweep.  The flat gradient buffer is H | K_1 b_1 | ... | K_L b_L | W; the segment of level l is
+// [K_l | b_l] (plus W for l = L: the readout gradient is the first thing the sweep computes) and H for l = 0.  The segment is
+// final on the context's current stream when this is called: the communicator's stream waits for that point and runs the
+// all-reduce there, while the sweep continues with the table gradients and the levels below.
+gf_status smp_dp_level_done(gf_smp *s, int l) {
+    if (!s->dp_grads) return GF_OK;
+    gf_ctx *ctx = s->ctx;
+    const gfsmp::Config &c = s->cfg;
+    const size_t C = (size_t)c.nChanels, nH = C * c.fdim(), per = (size_t)c.nContractions * C * C + C;
+    float *seg = s->dp_grads;
+    size_t n = nH;
+    if (l >= 1) {
+        seg += nH + (size_t)(l - 1) * per;
+        n = per + (l == c.nLevels ? C : 0);
+    }
+    hipStream_t comm = dist_stream(ctx);
+    GF_HIP_TRY(ctx, hipEventRecord(s->ev_grad, ctx->stream));
+    GF_HIP_TRY(ctx, hipStreamWaitEvent(comm, s->ev_grad, 0));
+    return dist_allreduce_on(ctx, seg, n, comm);
+}
 }  // namespace gf
 
 using gf::fail;
@@ -603,6 +625,8 @@ gf_status gf_smp_destroy(gf_smp *s) {
     gf::release_pool(s);
     if (s->upload) (void)hipStreamDestroy(s->upload);
     if (s->ev_last) (void)hipEventDestroy(s->ev_last);
+    if (s->ev_grad) (void)hipEventDestroy(s->ev_grad);
+    if (s->ev_comm) (void)hipEventDestroy(s->ev_comm);
     if (s->side) {
         (void)hipStreamSynchronize(s->side);
         (void)hipStreamDestroy(s->side);
@@ -1017,7 +1041,14 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     if (graph_feature)
         GF_HIP_TRY(ctx, hipMemcpyAsync(graph_feature, s->g, sizeof(float) * (size_t)B.nMol * C, hipMemcpyDeviceToDevice, ctx->stream));
     s->forwarded = true;
+    s->has_targets = targets != nullptr;
     gf::mark_used(s);
+    return GF_OK;
+}
+
+gf_status gf_smp_set_grad_allreduce(gf_smp *s, int on) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    s->grad_allreduce = on ? 1 : 0;
     return GF_OK;
 }
 
@@ -1025,6 +1056,8 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     gf_ctx *ctx = s->ctx;
     if (!s->forwarded) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward before gf_smp_forward");
+    if (!s->has_targets)  // Predict / Feature forward: dy would be y - 0, a gradient against a target nobody gave
+        return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: the last gf_smp_forward had no targets");
     if (!params && !grads && s->own_p) {
         params = s->own_p;
         grads = s->own_g;
@@ -1040,6 +1073,20 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     std::vector<float *> dK, db;
     gf::view_params<float>(s->cfg, grads, &dH, &dK, &db, &dW);
     const size_t np = gf::param_count(s->cfg);
+    const bool dp = gf::dist_active(ctx) && s->grad_allreduce;
+    if (dp && accumulate)
+        return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: accumulate with a communicator would re-sum earlier global sums "
+                                         "(gf_smp_set_grad_allreduce(smp, 0) and reduce once at the end instead)");
+    s->dp_grads = nullptr;
+    if (dp) {
+        if (!s->ev_grad) GF_HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_grad, hipEventDisableTiming));
+        if (!s->ev_comm) GF_HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
+        s->dp_grads = grads;
+    }
+    struct DpScope {  // whatever the exit path, the next call starts clean
+        gf_smp *s;
+        ~DpScope() { s->dp_grads = nullptr; }
+    } dp_scope = {s};
     if (!accumulate) GF_LAUNCH(ctx, "smp_zero", gf::zero_f32, dim3(gf::grid_for(np)), dim3(256), 0, grads, np);
     gf_status st;
     const gfsmp::LevelLayout &top = B.level[L];
@@ -1078,6 +1125,8 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
                 st = gf::gemm(ctx, false, true, (int)h.rows, KC, C, d.df, C, 0, K[l], C, 0, d.Q, KC, 0, 1, 0);
             }
             if (st != GF_OK) return st;
+            st = gf::smp_dp_level_done(s, l);
+            if (st != GF_OK) return st;
             st = gf::smp_contract(s, l, /*backward=*/true);
             if (st != GF_OK) return st;
         }
@@ -1108,6 +1157,12 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
                   C, (long long)nV, rpb);
         st = gf::gemm(ctx, true, false, C, FD, nV, s->lv[0].df, C, 0, s->x, FD, 0, dH, FD, 0, 1, 1);
         if (st != GF_OK) return st;
+    }
+    if (dp) {  // dH, then join: everything after this call on the context's stream sees the global sums
+        st = gf::smp_dp_level_done(s, 0);
+        if (st != GF_OK) return st;
+        GF_HIP_TRY(ctx, hipEventRecord(s->ev_comm, gf::dist_stream(ctx)));
+        GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_comm, 0));
     }
     gf::mark_used(s);
     return GF_OK;
@@ -1170,6 +1225,37 @@ int gf_smp_receptive_field(const gf_smp *s, int mol, int level, int v, int *out,
     const std::vector<int> &f = M.phi[level][v];
     for (int i = 0; i < (int)f.size() && i < capacity; ++i) out[i] = f[i];
     return (int)f.size();
+}
+
+/* introspection for parity tests: the level-`level` activation f_l[v] of molecule `mol` ([s][s][C], what level[l]->f[v]->value
+ * holds in the reference after forward(), SMP_omega.h:667-669) or its reduced adjacency ([s][s], level[l]->adj[v], :556-581),
+ * copied to a HOST buffer.  Returns the element count, or -1 (bad argument / capacity too small / not forwarded).  Blocking. */
+static long long smp_read_node(gf_smp *s, int mol, int level, int v, float *out, size_t capacity, bool adjacency) {
+    if (!s || !s->prepared || !out || mol < 0 || mol >= s->lay.nMol || level < 0 || level > s->cfg.nLevels) return -1;
+    if (adjacency ? level < 1 : !s->forwarded) return -1;
+    const gfsmp::LevelLayout &h = s->lay.level[level];
+    int n = -1;
+    if (level == 0) {
+        const int g = s->lay.mol_first_vertex[mol] + v;
+        if (v >= 0 && g < s->lay.mol_first_vertex[mol + 1]) n = g;
+    } else {
+        for (int i = 0; i < h.nNodes && n < 0; ++i)
+            if (h.node_mol[i] == mol && h.node_vertex[i] == v) n = i;
+    }
+    if (n < 0) return -1;
+    const size_t sz = (size_t)h.node_s[n], C = (size_t)s->cfg.nChanels;
+    const size_t count = adjacency ? sz * sz : sz * sz * C;
+    if (count > capacity) return -1;
+    const float *src = adjacency ? s->lv[level].adj + h.node_row[n] : s->lv[level].f + (size_t)h.node_row[n] * C;
+    if (hipMemcpyAsync(out, src, count * sizeof(float), hipMemcpyDeviceToHost, s->ctx->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) return -1;
+    return (long long)count;
+}
+long long gf_smp_read_activation(gf_smp *s, int mol, int level, int v, float *out, size_t capacity) {
+    return smp_read_node(s, mol, level, v, out, capacity, false);
+}
+long long gf_smp_read_reduced_adjacency(gf_smp *s, int mol, int level, int v, float *out, size_t capacity) {
+    return smp_read_node(s, mol, level, v, out, capacity, true);
 }
 
 /* counts used by the bench to report algorithmic work: rows = sum s^2, ppos = sum s^3 at a level */

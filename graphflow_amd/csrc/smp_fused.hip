@@ -647,17 +647,6 @@ size_t combine_lds(int N) {
     return sizeof(float) * ((size_t)adj_lds_floats(N) + (size_t)kCombX * N * CW);
 }
 
-template <typename Kern>
-gf_status opt_in_lds(gf_ctx *ctx, Kern kern, size_t bytes, size_t *granted) {
-    if (bytes > 160 * 1024) return fail(ctx, GF_ERR_UNSUPPORTED, "fused SMP kernel needs %zu B of LDS", bytes);
-    if (bytes > 32 * 1024 && bytes > *granted) {
-        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)bytes));
-        *granted = bytes;
-    }
-    return GF_OK;
-}
-
 struct SizeClass {
     long long lo, hi;  // pair range
     int smax, ni;
@@ -712,8 +701,7 @@ gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *d
     const gf_smp::DevLevel &d = s->lv[l];
     const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
     const size_t lds = tables_bwd_lds<16>(c.smax);
-    static size_t granted = 0;
-    gf_status st = opt_in_lds(ctx, smp_tables_bwd<16, NI>, lds, &granted);
+    gf_status st = opt_in_lds(ctx, smp_tables_bwd<16, NI>, lds);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smpf_tables_bwd", (smp_tables_bwd<16, NI>), dim3((unsigned)((c.hi - c.lo) * nwin)), dim3(kThreads), lds, dT,
               d.dVt, d.dSt, d.adj, s->P, d.pi, ragged_for(d, c.lo, c.smax), C, nwin);
@@ -985,8 +973,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     if (s->side) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
     {
         const size_t lds = combine_lds<16>(h.buckets.back().s);
-        static size_t granted = 0;
-        st = opt_in_lds(ctx, smp_combine_fwd<16>, lds, &granted);
+        st = opt_in_lds(ctx, smp_combine_fwd<16>, lds);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, O,
                   d.adj, d.Vout, d.Sout, bl, d.f, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C, nwin, d.Gc,
@@ -1008,8 +995,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     gf_status st;
     {
         const size_t lds = combine_lds<16>(h.buckets.back().s);
-        static size_t granted = 0;
-        st = opt_in_lds(ctx, smp_combine_bwd<16>, lds, &granted);
+        st = opt_in_lds(ctx, smp_combine_bwd<16>, lds);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
                   d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
@@ -1103,6 +1089,8 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     st = gemm(ctx, true, false, 4 * C, C, nodes, d.St, 4 * C, 0, d.dSout, C, 0, d.dWst + 14 * CC, C, 0, 1, 0);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smpf_unstack_dw", unstack_weight_grads, dim3(64), dim3(256), 0, d.dWst, dKl, C, s->cfg.custom_matmul);
+    st = smp_dp_level_done(s, l);  // data-parallel: dK_l and db_l are final -- their all-reduce runs beside what follows
+    if (st != GF_OK) return st;
     if (swap.on) {
         GF_HIP_TRY(ctx, hipEventRecord(s->ev_join, s->side));
         ctx->stream = swap.saved;

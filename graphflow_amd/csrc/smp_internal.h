@@ -39,6 +39,12 @@ struct gf_smp {
     gfsmp::Config cfg;
     gfsmp::BatchLayout lay;
     bool prepared = false, forwarded = false;
+    bool has_targets = false;  // the last gf_smp_forward was given targets: only then does dy hold a loss gradient
+    // data-parallel reverse sweep (the context has a communicator, gf_dist.hip): the gradient segment of a level is
+    // all-reduced on the communicator's stream as soon as it is complete, beside the rest of the sweep
+    int grad_allreduce = 1;
+    float *dp_grads = nullptr;           // gradient buffer of the running gf_smp_backward, null when not data-parallel
+    hipEvent_t ev_grad = nullptr, ev_comm = nullptr;
     int fused = 1;  // use the fused level path where supported (gf_smp_set_fused)
     int bwd_gather = 0;  // fused levels: evaluate dP inside the consumer gather instead of materialising it (GF_SMP_BWD_GATHER)
     // device buffers (owned)
@@ -111,5 +117,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
 gf_status smp_fused_gather_backward(gf_smp *s, int l);
 bool smp_fused_gather_enabled(const gf_smp *s, int l);
 gf_status ensure_P(gf_smp *s);
+// level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce
+gf_status smp_dp_level_done(gf_smp *s, int l);
 }
 #endif

@@ -325,13 +325,8 @@ gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO,
     if (st != GF_OK) return st;
     float *part = static_cast<float *>(ctx->ws);
     const size_t lds = sizeof(float) * 2 * (size_t)kWgStage;
-    static bool opted[64] = {};  // per device (one process per GPU is the design; a multi-device process still works)
-    const int di = ctx->device & 63;
-    if (!opted[di]) {
-        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_wgrad_c64), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds));
-        opted[di] = true;
-    }
+    st = opt_in_lds(ctx, smp_wgrad_c64, lds);
+    if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part);
     return splitk_fold(ctx, part, dWst, total, splits, 0);
 }
@@ -349,13 +344,9 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
     }
     const int cus = cu_count[di];
     const size_t lds = sizeof(float) * 8 * 2 * 2 * 32 * (size_t)kRpWRow;
-    static bool opted[64] = {};
-    if (!opted[di]) {
-        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_rowpanel_c64<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GF_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(smp_rowpanel_c64<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        opted[di] = true;
+    {
+        gf_status st = forward ? opt_in_lds(ctx, smp_rowpanel_c64<true>, lds) : opt_in_lds(ctx, smp_rowpanel_c64<false>, lds);
+        if (st != GF_OK) return st;
     }
     const int npanels = (rows + 31) / 32, per = kRpThreads / 64;
     const int want = (npanels + per - 1) / per;

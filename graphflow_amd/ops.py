@@ -58,6 +58,42 @@ class Context:
         """Only launches named `kernel_name` are timed (None: all) -- see gf_ctx_set_timing_filter."""
         self.check(self.lib.gf_ctx_set_timing_filter(self.handle, kernel_name.encode() if kernel_name else None))
 
+    def set_option(self, option, value):
+        """gf_ctx_set_option, e.g. (_lib.GF_OPT_R18_GENERIC_KERNELS, 1)."""
+        self.check(self.lib.gf_ctx_set_option(self.handle, int(option), int(value)))
+
+    # -- data parallelism: the context's RCCL communicator (gf_dist_*) ---------------------------------------------
+    def dist_unique_id(self):
+        """Rank 0: GF_DIST_ID_BYTES bytes to hand to every rank (any host channel) before dist_init."""
+        buf = C.create_string_buffer(_lib.GF_DIST_ID_BYTES)
+        self.check(self.lib.gf_dist_unique_id(self.handle, buf))
+        return buf.raw
+
+    def dist_init(self, unique_id, rank, world):
+        if len(unique_id) != _lib.GF_DIST_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % _lib.GF_DIST_ID_BYTES)
+        self.check(self.lib.gf_dist_init(self.handle, C.create_string_buffer(bytes(unique_id), _lib.GF_DIST_ID_BYTES), int(rank), int(world)))
+
+    def dist_finalize(self):
+        self.check(self.lib.gf_dist_finalize(self.handle))
+
+    @property
+    def dist_rank(self):
+        return self.lib.gf_dist_rank(self.handle)
+
+    @property
+    def dist_world(self):
+        return self.lib.gf_dist_world(self.handle)
+
+    def allreduce_sum_(self, t):
+        """In-place sum over ranks of a contiguous float32 CUDA tensor, ordered on the context's stream."""
+        self.check(self.lib.gf_dist_allreduce_sum_f32(self.handle, _dev_f32(t, "tensor"), t.numel()))
+        return t
+
+    def broadcast_(self, t, root=0):
+        self.check(self.lib.gf_dist_broadcast_f32(self.handle, _dev_f32(t, "tensor"), t.numel(), int(root)))
+        return t
+
     def timings(self):
         """{kernel name: (total_ms, launches)} since timing was enabled; synchronises the stream."""
         out = {}

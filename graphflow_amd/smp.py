@@ -52,7 +52,18 @@ class SMPOmega:
         self.loss = torch.empty(self.n_mol, dtype=torch.float32, device=dev)
         self.feature = torch.empty((self.n_mol, self.cfg.nChanels), dtype=torch.float32, device=dev)
 
+    def _flat(self, t, name):
+        """params / grads must be exactly the flat model: float32, contiguous, on the context's device, n_params long."""
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                and t.numel() == self.n_params and t.device == self.ctx.device):
+            raise TypeError("%s must be a contiguous float32 tensor of %d elements on %s" % (name, self.n_params, self.ctx.device))
+        return C.c_void_p(t.data_ptr())
+
     def forward(self, params, targets=None):
+        self._flat(params, "params")
+        if targets is not None and not (targets.is_cuda and targets.dtype == torch.float32 and targets.is_contiguous()
+                                        and targets.numel() == self.n_mol):
+            raise TypeError("targets must be a contiguous float32 CUDA tensor with one value per molecule (%d)" % self.n_mol)
         t = C.c_void_p(targets.data_ptr()) if targets is not None else None
         self.ctx.check(self.lib.gf_smp_forward(self.handle, C.c_void_p(params.data_ptr()), t,
                                                C.c_void_p(self.predict.data_ptr()), C.c_void_p(self.loss.data_ptr()),
@@ -60,18 +71,24 @@ class SMPOmega:
         return self.predict, self.loss, self.feature
 
     def backward(self, params, grads, accumulate=False):
+        self._flat(params, "params")
+        self._flat(grads, "grads")
         self.ctx.check(self.lib.gf_smp_backward(self.handle, C.c_void_p(params.data_ptr()), C.c_void_p(grads.data_ptr()),
                                                 1 if accumulate else 0))
         return grads
 
     def adam_step(self, params, grads, learning_rate, nBatch):
         """Adam::Learn(learning_rate, nBatch) as SMP_omega::BatchLearn applies it (SMP_omega.h:820-821); grads = batch sum."""
+        self._flat(params, "params")
+        self._flat(grads, "grads")
         self.ctx.check(self.lib.gf_smp_adam_step(self.handle, C.c_void_p(params.data_ptr()), C.c_void_p(grads.data_ptr()),
                                                  float(learning_rate), int(nBatch)))
         return params
 
     def momentum_step(self, params, grads, learning_rate, nBatch, gamma=0.9):
         """Momentum::Learn(learning_rate, nBatch) (Momentum.h:64-71): the optimiser of SMP_2D_ver6-8."""
+        self._flat(params, "params")
+        self._flat(grads, "grads")
         self.ctx.check(self.lib.gf_smp_momentum_step(self.handle, C.c_void_p(params.data_ptr()), C.c_void_p(grads.data_ptr()),
                                                      float(learning_rate), int(nBatch), float(gamma)))
         return params
@@ -110,6 +127,28 @@ class SMPOmega:
         buf = (C.c_int * 4096)()
         n = self.lib.gf_smp_receptive_field(self.handle, mol, level, v, buf, 4096)
         return list(buf[:n])
+
+    def activation(self, mol, level, v):
+        """f_level[v] of molecule `mol` after forward(): numpy [s, s, C] (level[l]->f[v]->value in the reference)."""
+        s = len(self.receptive_field(mol, level, v))
+        out = np.empty((s, s, self.cfg.nChanels), dtype=np.float32)
+        n = self.lib.gf_smp_read_activation(self.handle, mol, level, v, out.ctypes.data_as(C.c_void_p), out.size)
+        if n != out.size:
+            raise RuntimeError("gf_smp_read_activation(%d, %d, %d) returned %d" % (mol, level, v, n))
+        return out
+
+    def reduced_adjacency(self, mol, level, v):
+        """Reduced adjacency [s, s] of f_level[v] (level[l]->adj[v] in the reference), level >= 1."""
+        s = len(self.receptive_field(mol, level, v))
+        out = np.empty((s, s), dtype=np.float32)
+        n = self.lib.gf_smp_read_reduced_adjacency(self.handle, mol, level, v, out.ctypes.data_as(C.c_void_p), out.size)
+        if n != out.size:
+            raise RuntimeError("gf_smp_read_reduced_adjacency(%d, %d, %d) returned %d" % (mol, level, v, n))
+        return out
+
+    def set_grad_allreduce(self, on=True):
+        """Data-parallel runs (ctx.dist_init): backward() leaves the gradient summed over all ranks (default) or local."""
+        self.ctx.check(self.lib.gf_smp_set_grad_allreduce(self.handle, 1 if on else 0))
 
     def level_sizes(self, level):
         a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()

@@ -64,6 +64,33 @@ int       gf_ctx_timing_count(gf_ctx *ctx);
 gf_status gf_ctx_timing_get(gf_ctx *ctx, int index, const char **name, double *total_ms, long long *launches);
 const char *gf_last_error(gf_ctx *ctx);                     /* valid until the next call on ctx; ctx may be NULL for create errors */
 const char *gf_version(void);
+/* Per-context options.  GF_OPT_R18_GENERIC_KERNELS != 0 routes RisiContraction_18 through the layout-agnostic generic
+ * kernels (any N, any C, one thread per table / output element) instead of the slab kernels: the independent second
+ * implementation the parity tests hold the fast path against.  (The reference's GPU op has a comparable switch -- its CPU
+ * fallback under a complexity threshold, RisiContraction_18_gpu.h:961-968 -- but both routes here run on the device.) */
+typedef enum { GF_OPT_R18_GENERIC_KERNELS = 1 } gf_option;
+gf_status gf_ctx_set_option(gf_ctx *ctx, int option, int value);
+
+/* ---- data parallelism: one RCCL communicator per context ----------------------------------------------------------------
+ * Replaces the master/worker exchange of SMP_omega::Threaded_BatchLearn (GraphFlow/SMP_omega.h:750-792): copy_value of the
+ * master's parameters into every worker clone (:710-728, :771-773) = gf_dist_broadcast_f32; the serial add_gradient loop over
+ * the clones (:730-740, :784-786) = gf_dist_allreduce_sum_f32.  A worker is one GPU: one context per GPU, in one process per
+ * GPU (torchrun / mpirun style) or one host thread per GPU (the reference's std::thread style).
+ * Rank 0 calls gf_dist_unique_id and hands the GF_DIST_ID_BYTES bytes to the other ranks by any host channel (a file, a
+ * socket, MPI, torch.distributed, shared memory between threads); then EVERY rank calls gf_dist_init with the same id.
+ * Collectives are in place, asynchronous and ordered on the context's stream.  RCCL is loaded on the first gf_dist_* call;
+ * when it is missing the call fails with GF_ERR_UNSUPPORTED (nothing else in the library needs it).
+ * Once a context has a communicator, gf_smp_backward on it returns the gradient SUMMED OVER ALL RANKS: each level's weight
+ * gradients are all-reduced on the communicator's own stream as soon as the reverse sweep has produced them, while the sweep
+ * continues below (gf_smp_set_grad_allreduce(smp, 0) turns that off for a handle).                                          */
+#define GF_DIST_ID_BYTES 128
+gf_status gf_dist_unique_id(gf_ctx *ctx, void *id_out /* GF_DIST_ID_BYTES */);
+gf_status gf_dist_init(gf_ctx *ctx, const void *id /* GF_DIST_ID_BYTES */, int rank, int world);
+gf_status gf_dist_finalize(gf_ctx *ctx);                   /* also done by gf_ctx_destroy */
+int       gf_dist_rank(const gf_ctx *ctx);                 /* 0 when the context has no communicator */
+int       gf_dist_world(const gf_ctx *ctx);                /* 1 when the context has no communicator */
+gf_status gf_dist_allreduce_sum_f32(gf_ctx *ctx, float *buf, size_t n);
+gf_status gf_dist_broadcast_f32(gf_ctx *ctx, float *buf, size_t n, int root);
 
 /* ---- tensor contractions, mode B (device pointers, batched) -----------------------------------------------------
  * K selects the family: 4, 10, 18 or 50.
@@ -204,6 +231,10 @@ gf_status gf_smp_prepare_coulomb(gf_smp *smp, int nMol, const int *nVertices, co
 gf_status gf_smp_forward(gf_smp *smp, const float *params, const float *targets, float *predict, float *loss,
                          float *graph_feature);
 gf_status gf_smp_backward(gf_smp *smp, const float *params, float *grads, int accumulate);
+/* Data-parallel runs (the context has a communicator, gf_dist_init): 1 (default) = gf_smp_backward leaves the gradient
+ * summed over all ranks, the all-reduce of each level's [K_l | b_l] segment overlapped with the rest of the reverse sweep
+ * (accumulate must be 0 then); 0 = local gradients only (the caller reduces them).  No effect without a communicator. */
+gf_status gf_smp_set_grad_allreduce(gf_smp *smp, int on);
 /* 1 (default): fused level kernels (no promoted stack, no 18-slice contraction output in HBM) where the shape allows;
  * 0: the op-by-op pipeline.  Same results within fp32 rounding; kept switchable for parity tests. */
 gf_status gf_smp_set_fused(gf_smp *smp, int on);
@@ -236,6 +267,11 @@ gf_status gf_smp_load_model(gf_smp *smp, float *params, const char *path);
 gf_status gf_smp_prepare_molecule_host(const gf_smp_config *cfg, int V, const int *adj, const double *feature,
                                        int *phi_out, double *wl_out);  /* host only; phi_out [L+1][V][cap+1], slot 0 = size */
 int       gf_smp_receptive_field(const gf_smp *smp, int mol, int level, int v, int *out, int capacity);
+/* Introspection for parity checks against the reference's per-level state: f_l[v] of molecule `mol` as [s][s][C] floats
+ * (level[l]->f[v]->value after forward(), SMP_omega.h:667-669) and its reduced adjacency [s][s] (level[l]->adj[v], :556-581),
+ * copied to HOST buffers.  Return the element count, or -1 (bad argument, capacity too small, nothing forwarded).  Blocking. */
+long long gf_smp_read_activation(gf_smp *smp, int mol, int level, int v, float *host_out, size_t capacity);
+long long gf_smp_read_reduced_adjacency(gf_smp *smp, int mol, int level, int v, float *host_out, size_t capacity);
 gf_status gf_smp_level_sizes(const gf_smp *smp, int level, long long *nodes, long long *rows, long long *ppos);
 
 #ifdef __cplusplus

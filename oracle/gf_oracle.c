@@ -315,8 +315,49 @@ typedef struct {
     int N, C, k0, k1;
 } r18_job;
 
+/* value_at (:70-72): the product is formed anew at every use and the neighbour tensor is reached through the op's
+ * pointer table (tensors[a] -> value), as in the reference */
+#define VAL(a, b, c, d, e, f) (T[a][((b) * N + (c)) * C + (f)] * A[(d) * N + (e)])
+#define TIX(x, y, k, f) (((x) * N + (y)) * (18 * C) + (k) * C + (f)) /* Tensor3D::index with int arithmetic, as the reference */
+
 static void *r18_thread_job(void *arg) {
     r18_job *j = (r18_job *)arg;
+    const double *P = j->P, *A = j->A;
+    double *Out = j->Out;
+    const int N = j->N, C = j->C;
+    const double *T[64]; /* (N <= 64: the thread variant is only ever timed at the cfg2 shape) */
+    for (int a = 0; a < N && a < 64; ++a) T[a] = P + (size_t)a * N * N * C;
+    if (j->k0 == 0 && N <= 64) { /* job 0 (:79-113): cases 1-3 share ONE f-a-b-c-d-e nest, three updates per iteration */
+        for (int f = 0; f < C; ++f)
+            for (int a = 0; a < N; ++a)
+                for (int b = 0; b < N; ++b)
+                    for (int c = 0; c < N; ++c)
+                        for (int d = 0; d < N; ++d)
+                            for (int e = 0; e < N; ++e) {
+                                Out[TIX(a, b, 0, f)] += VAL(a, b, c, d, e, f);
+                                Out[TIX(a, d, 1, f)] += VAL(a, b, c, d, e, f);
+                                Out[TIX(b, c, 2, f)] += VAL(a, b, c, d, e, f);
+                            }
+        return NULL;
+    }
+    if (j->k0 == 3 && N <= 64) { /* job 1 (:116-165): cases 4-5 in one N^5 nest, case 6 (c == d) in an N^4 nest of its own */
+        for (int f = 0; f < C; ++f)
+            for (int a = 0; a < N; ++a)
+                for (int b = 0; b < N; ++b)
+                    for (int c = 0; c < N; ++c)
+                        for (int d = 0; d < N; ++d)
+                            for (int e = 0; e < N; ++e) {
+                                Out[TIX(b, d, 3, f)] += VAL(a, b, c, d, e, f);
+                                Out[TIX(d, e, 4, f)] += VAL(a, b, c, d, e, f);
+                            }
+        for (int f = 0; f < C; ++f)
+            for (int a = 0; a < N; ++a)
+                for (int b = 0; b < N; ++b)
+                    for (int c = 0; c < N; ++c)
+                        for (int e = 0; e < N; ++e) Out[TIX(a, b, 5, f)] += VAL(a, b, c, c, e, f);
+        return NULL;
+    }
+    /* jobs 2-5 (:168-408): N^4 nests and smaller, off the critical path -- evaluated through the case table */
     gfo_case cases[18];
     family_cases(18, cases);
     for (int k = j->k0; k < j->k1; ++k)

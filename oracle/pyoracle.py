@@ -19,7 +19,8 @@ def build(force=False):
     """Compile the C restatement (and the reference shim when /root/reference is mounted)."""
     so = os.path.join(_HERE, "libgf_oracle.so")
     src = os.path.join(_HERE, "gf_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [src, os.path.join(_HERE, "smp_port.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libgf_oracle.so"])
     ref_root = os.environ.get("GF_REFERENCE", "/root/reference")
     ref_so = os.path.join(_HERE, "_ref", "libgf_ref.so")
@@ -388,8 +389,10 @@ def reference_save_model(path, params, nLevels, nChanels, nFeatures, nDepth, cap
     return path
 
 
-def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, max_nVertices=None, coulomb=None):
-    """Run the REAL reference SMP_omega on one molecule with the given (dumped) parameters.  None if _ref is absent."""
+def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, has_wl=True, max_nVertices=None, coulomb=None,
+                        want_activations=False):
+    """Run the REAL reference SMP_omega on one molecule with the given (dumped) parameters.  None if _ref is absent.
+    want_activations: also return "f" = [[level[l]->f[v]->value as [s, s, C]]] for every level and vertex."""
     ref = reference()
     if ref is None:
         return None
@@ -405,22 +408,31 @@ def reference_smp_omega(adj, feature, target, params, nLevels, C, nDepth, cap, h
     grads = np.zeros_like(params)
     phi = np.zeros((L + 1, V, cap + 1), dtype=np.int32)
     radj = np.zeros((L + 1, V, cap * cap))
-    f = ref.lib.ref_smp_omega_run
+    f = ref.lib.ref_smp_omega_run_acts
     ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
-    f.argtypes = [_i] * 8 + [ip, _dp, C_double, _dp, _dp, _dp, _dp, _dp, ip, _dp, ctypes_vp]
+    f.argtypes = [_i] * 8 + [ip, _dp, C_double, _dp, _dp, _dp, _dp, _dp, ip, _dp, ctypes_vp, ctypes_vp]
     f.restype = _i
     cm = None if coulomb is None else np.ascontiguousarray(coulomb, dtype=np.float64)
+    acts = np.zeros((L + 1) * V * cap * cap * C) if want_activations else None   # upper bound; trimmed below
     n = f(maxV, cap, L, C, F, nDepth, 1 if has_wl else 0, V, adj, feature, float(target), params, gfeat, pred, loss, grads, phi, radj,
-          None if cm is None else cm.ctypes.data)
+          None if cm is None else cm.ctypes.data, None if acts is None else acts.ctypes.data)
     assert n == params.size, (n, params.size)
     fields = [[list(phi[l, v, 1:1 + phi[l, v, 0]]) for v in range(V)] for l in range(L + 1)]
+    fl = None
+    if want_activations:
+        fl, o = [[None] * V for _ in range(L + 1)], 0
+        for l in range(L + 1):
+            for v in range(V):
+                s = int(phi[l, v, 0])
+                fl[l][v] = acts[o:o + s * s * C].reshape(s, s, C).copy()
+                o += s * s * C
     red = [[None] * V for _ in range(L + 1)]
     for l in range(1, L + 1):
         for v in range(V):
             s = phi[l, v, 0]
             red[l][v] = radj[l, v, :s * s].reshape(s, s).copy()
     return {"phi": fields, "reduced_adj": red, "graph_feature": gfeat, "predict": float(pred[0]), "loss": float(loss[0]),
-            "grads": grads}
+            "grads": grads, "f": fl}
 
 
 C_double = C.c_double
@@ -443,3 +455,100 @@ def time_reference_smp_omega(molecules, targets, nLevels, nChanels, nDepth, cap)
     f.argtypes = [_i] * 7 + [ip, ip, _dp, _dp]
     f.restype = C_double
     return float(f(int(nV.max()), cap, nLevels, nChanels, F, nDepth, len(molecules), nV, adj, feat, tg))
+
+
+# -- the C port of the SMP step (oracle/smp_port.c): second restatement + the "port"-kind CPU baseline ---------------------
+def _port_inputs(molecules, L, nDepth, cap, has_wl=True):
+    """Graph preparation by the numpy restatement (oracle/smp_oracle.py), packed for gfo_smp_molecule / gfo_smp_batch."""
+    from . import smp_oracle
+    xs, phis, adjs, nV = [], [], [], []
+    for adj, feat in molecules:
+        adj = np.asarray(adj)
+        feat = np.asarray(feat, dtype=np.float64)
+        V = len(adj)
+        sp = smp_oracle.hop_distances(adj.tolist())
+        x = smp_oracle.wl_features(feat, sp, nDepth)
+        rank = smp_oracle.rank_vertices(x.tolist())
+        fields = smp_oracle.receptive_fields(sp, rank, L, cap, has_wl)
+        phi = np.full((L + 1, V, cap + 1), -1, dtype=np.int32)
+        for l in range(L + 1):
+            for v in range(V):
+                phi[l, v, 0] = len(fields[l][v])
+                phi[l, v, 1:1 + len(fields[l][v])] = fields[l][v]
+        xs.append(np.ascontiguousarray(x))
+        phis.append(phi)
+        adjs.append(np.ascontiguousarray(adj, dtype=np.int32))
+        nV.append(V)
+    return xs, phis, adjs, nV
+
+
+def port_smp_molecule(adj, feature, target, params, L, C, nDepth, cap, has_wl=True, coulomb=None, activation=None):
+    """One molecule through the C port.  activation=(level, vertex): also return that f[l][v] as "f"."""
+    lib = oracle().lib
+    xs, phis, adjs, nV = _port_inputs([(adj, feature)], L, nDepth, cap, has_wl)
+    x, phi, a, V = xs[0], phis[0], adjs[0], nV[0]
+    FD = x.shape[1]
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    gfeat, pred, loss, grads = np.zeros(C), np.zeros(1), np.zeros(1), np.zeros_like(params)
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f = lib.gfo_smp_molecule
+    f.argtypes = [_i] * 5 + [_dp, ip, ip, ctypes_vp, _dp, C_double, _i, _dp, _dp, _dp, _dp, _i, _i, ctypes_vp]
+    f.restype = _i
+    cm = None if coulomb is None else np.ascontiguousarray(coulomb, dtype=np.float64)
+    act = None
+    al, av = (-1, -1)
+    if activation is not None:
+        al, av = activation
+        s = int(phi[al, av, 0])
+        act = np.zeros((s, s, C))
+    rc = f(V, FD, L, C, cap, x, phi, a, None if cm is None else cm.ctypes.data, params, float(target), 1, gfeat, pred, loss, grads,
+           al, av, None if act is None else act.ctypes.data)
+    assert rc == 0
+    return {"graph_feature": gfeat, "predict": float(pred[0]), "loss": float(loss[0]), "grads": grads, "f": act}
+
+
+def port_smp_batch(molecules, targets, params, L, C, nDepth, cap, nThreads=1):
+    """(seconds, predict, loss, grads): the batch through gfo_smp_batch -- waves of nThreads molecules on host threads, the
+    shape of SMP_omega::Threaded_BatchLearn (nThreads = 1: the serial gradient loop of BatchLearn).  The clock covers the
+    op DAG (forward + backward of every molecule) only, not the numpy graph preparation."""
+    import time
+    lib = oracle().lib
+    xs, phis, adjs, nV = _port_inputs(molecules, L, nDepth, cap)
+    FD = xs[0].shape[1]
+    lp = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    x_off = np.cumsum([0] + [x.size for x in xs[:-1]]).astype(np.int64)
+    p_off = np.cumsum([0] + [p.size for p in phis[:-1]]).astype(np.int64)
+    a_off = np.cumsum([0] + [a.size for a in adjs[:-1]]).astype(np.int64)
+    x = np.concatenate([x.ravel() for x in xs])
+    phi = np.concatenate([p.ravel() for p in phis])
+    adj = np.concatenate([a.ravel() for a in adjs])
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    tg = np.ascontiguousarray(targets, dtype=np.float64)
+    n = len(molecules)
+    pred, loss, grads = np.zeros(n), np.zeros(n), np.zeros_like(params)
+    f = lib.gfo_smp_batch
+    f.argtypes = [_i, ip, _i, _i, _i, _i, _dp, lp, ip, lp, ip, lp, _dp, _dp, _i, _dp, _dp, _dp]
+    f.restype = _i
+    t0 = time.perf_counter()
+    rc = f(n, np.array(nV, dtype=np.int32), FD, L, C, cap, x, x_off, phi, p_off, adj, a_off, params, tg, int(nThreads), pred, loss, grads)
+    secs = time.perf_counter() - t0
+    assert rc == 0
+    return secs, pred, loss, grads
+
+
+def time_reference_smp_omega_threaded(molecules, targets, nLevels, nChanels, nDepth, cap, nThreads):
+    """Seconds of the REAL SMP_omega::Threaded_BatchLearn over `molecules` with init_multi_threads(nThreads); None without _ref."""
+    ref = reference()
+    if ref is None:
+        return None
+    nV = np.array([len(a) for a, _ in molecules], dtype=np.int32)
+    adj = np.concatenate([np.ascontiguousarray(a, dtype=np.int32).ravel() for a, _ in molecules])
+    feat = np.concatenate([np.ascontiguousarray(f, dtype=np.float64).ravel() for _, f in molecules])
+    tg = np.ascontiguousarray(targets, dtype=np.float64)
+    F = molecules[0][1].shape[1]
+    f = ref.lib.ref_smp_omega_threaded_time
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f.argtypes = [_i] * 8 + [ip, ip, _dp, _dp]
+    f.restype = C_double
+    return float(f(int(nThreads), int(nV.max()), cap, nLevels, nChanels, F, nDepth, len(molecules), nV, adj, feat, tg))

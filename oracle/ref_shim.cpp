@@ -300,12 +300,24 @@ void ref_stack_backward(const double *G, double *dT, int nRows, int nCols, int n
 // ---------------------------------------------------------------------------------------------------------------
 #include "SMP_omega.h"
 
-extern "C" int ref_smp_omega_run(int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int nDepth,
+extern "C" int ref_smp_omega_run_acts(int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int nDepth,
                                  int has_WL, int V, const int *adj, const double *feature, double target,
                                  const double *params, double *graph_feature, double *predict, double *loss,
                                  double *grads, int *phi /* [L+1][V][max_rf+1], slot 0 = size */,
                                  double *reduced_adj /* [L+1][V][max_rf*max_rf] */,
-                                 const double *coulomb /* NULL, or V x V: the use_coulomb constructor (:91-113) */) {
+                                 const double *coulomb /* NULL, or V x V: the use_coulomb constructor (:91-113) */,
+                                 double *acts /* NULL, or level[l]->f[v]->value ([s][s][C]) back to back in (l, v) order */);
+extern "C" int ref_smp_omega_run(int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int nDepth,
+                                 int has_WL, int V, const int *adj, const double *feature, double target,
+                                 const double *params, double *graph_feature, double *predict, double *loss,
+                                 double *grads, int *phi, double *reduced_adj, const double *coulomb) {
+    return ref_smp_omega_run_acts(max_nVertices, max_rf, nLevels, nChanels, nFeatures, nDepth, has_WL, V, adj, feature, target, params,
+                                  graph_feature, predict, loss, grads, phi, reduced_adj, coulomb, NULL);
+}
+extern "C" int ref_smp_omega_run_acts(int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int nDepth,
+                                 int has_WL, int V, const int *adj, const double *feature, double target,
+                                 const double *params, double *graph_feature, double *predict, double *loss,
+                                 double *grads, int *phi, double *reduced_adj, const double *coulomb, double *acts) {
     // heap-allocated and intentionally leaked: ~SMP_omega / ~DenseGraph free memory the executor's destructor also
     // frees (SURVEY.md 8b "Ownership"), which is fatal in a long-lived process
     SMP_omega &net = coulomb ? *new SMP_omega(true, max_nVertices, max_rf, nLevels, nChanels, nFeatures, nDepth, has_WL != 0)
@@ -341,6 +353,15 @@ extern "C" int ref_smp_omega_run(int max_nVertices, int max_rf, int nLevels, int
                 for (int i = 0; i < net.level[l]->adj[v]->size; ++i) a[i] = net.level[l]->adj[v]->value[i];
             }
         }
+    if (acts) {
+        size_t ao = 0;
+        for (int l = 0; l <= nLevels; ++l)
+            for (int v = 0; v < V; ++v) {
+                const size_t s = net.level[l]->phi[v].size(), n = s * s * nChanels;
+                for (size_t i = 0; i < n; ++i) acts[ao + i] = net.level[l]->f[v]->value[i];
+                ao += n;
+            }
+    }
     return (int)off;
 }
 
@@ -556,6 +577,34 @@ extern "C" double ref_smp_omega_time(int max_nVertices, int max_rf, int nLevels,
         net.graph->forward();
         net.graph->backward();
     }
+    gettimeofday(&t1, NULL);
+    return (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
+}
+
+// The all-cores CPU baseline of SURVEY 8(d)(iii): the REAL SMP_omega::Threaded_BatchLearn (SMP_omega.h:750-792) with
+// init_multi_threads(nThreads) -- one model clone per thread, the batch in waves of nThreads molecules.  Returns the seconds
+// of the call (clone construction outside the clock); includes the Adam step, which is negligible.
+extern "C" double ref_smp_omega_threaded_time(int nThreads, int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures,
+                                              int nDepth, int nMol, const int *nV, const int *adj, const double *feature,
+                                              const double *targets) {
+    SMP_omega &net = *new SMP_omega(max_nVertices, max_rf, nLevels, nChanels, nFeatures, nDepth);
+    net.init_multi_threads(nThreads);
+    std::vector<DenseGraph *> mol(nMol);
+    std::vector<double> tgt(targets, targets + nMol);
+    size_t ao = 0, fo = 0;
+    for (int m = 0; m < nMol; ++m) {
+        const int V = nV[m];
+        mol[m] = new DenseGraph(V, nFeatures);
+        for (int i = 0; i < V; ++i) {
+            for (int j = 0; j < V; ++j) mol[m]->adj[i][j] = adj[ao + (size_t)i * V + j];
+            for (int f = 0; f < nFeatures; ++f) mol[m]->feature[i][f] = feature[fo + (size_t)i * nFeatures + f];
+        }
+        ao += (size_t)V * V;
+        fo += (size_t)V * nFeatures;
+    }
+    struct timeval t0, t1;
+    gettimeofday(&t0, NULL);
+    net.Threaded_BatchLearn(nMol, &mol[0], &tgt[0], 1e-3);
     gettimeofday(&t1, NULL);
     return (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
 }

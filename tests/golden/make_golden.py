@@ -255,6 +255,64 @@ def train_fixture():
     np.savez_compressed(os.path.join(HERE, "smp_train.npz"), **out)
 
 
+def activation_digest(f):
+    """Two linear functionals of an activation tensor f [s, s, C] per channel: the plain sum over (i, j) and a sum with
+    position-dependent weights (detects transposed / permuted positions).  Weights are float32-exact by construction."""
+    s = f.shape[0]
+    i, j = np.meshgrid(np.arange(s), np.arange(s), indexing="ij")
+    w = ((3 * i + 5 * j) % 7 - 3).astype(np.float64) / 4.0
+    return np.stack([f.sum(axis=(0, 1)), (w[:, :, None] * f).sum(axis=(0, 1))])
+
+
+def headline_fixture():
+    """BASELINE configs[2]'s own shape pinned to the REAL reference: one 29-atom synthetic molecule through SMP_omega at
+    L = 3, receptive-field cap 29, C = 64, F = 5, D = 5 (GraphFlow/SMP_omega.h:584-693; about 8 s of reference time).
+    Kept: receptive fields, reduced adjacencies, Feature(), predict, loss, all 223,360 parameter gradients (fp32 storage),
+    and the per-level activations f[l][v] -- in full for levels 0-1 and for two vertices of levels 2 and 3 (the largest and
+    the smallest field), as two per-channel linear digests (activation_digest) for every vertex of every level.
+    The parameters are smp_params(64, 5, 5, 3, seed 2929) (float32-exact, regenerated by the test; their checksum is kept)."""
+    L, C, F, D, cap, seed_p = 3, 64, 5, 5, 29, 2929
+    adj, feat, tgt = synthetic_molecule(29029, 29)
+    V = len(adj)
+    params = smp_params(C, F, D, L, seed_p)
+    r = pyoracle.reference_smp_omega(adj, feat, tgt, params, L, C, D, cap, has_wl=True, max_nVertices=V, want_activations=True)
+    phi = np.full((L + 1, V, cap + 1), -1, dtype=np.int32)
+    radj = np.zeros((L + 1, V, cap, cap), dtype=np.int8)
+    sizes = np.zeros((L + 1, V), dtype=np.int32)
+    for l in range(L + 1):
+        for v in range(V):
+            n = len(r["phi"][l][v])
+            sizes[l, v] = n
+            phi[l, v, 0] = n
+            phi[l, v, 1:1 + n] = r["phi"][l][v]
+            if l > 0:
+                a = r["reduced_adj"][l][v]
+                assert np.array_equal(a, a.astype(np.int8)), "0/1 adjacency expected"
+                radj[l, v, :n, :n] = a
+    out = {"headline__adj": adj.astype(np.int32), "headline__feature": feat, "headline__target": np.array([tgt]),
+           "headline__cfg": np.array([L, C, D, cap, 1, seed_p], dtype=np.int32),
+           "headline__params_checksum": np.array([params.sum(), np.abs(params).sum(), (params * np.arange(params.size)).sum()]),
+           "headline__phi": phi, "headline__reduced_adj": radj, "headline__graph_feature": r["graph_feature"],
+           "headline__predict": np.array([r["predict"]]), "headline__loss": np.array([r["loss"]]),
+           "headline__grads": r["grads"].astype(np.float32)}
+    dig = np.zeros((L + 1, V, 2, C))
+    for l in range(L + 1):
+        for v in range(V):
+            dig[l, v] = activation_digest(r["f"][l][v])
+    out["headline__act_digest"] = dig
+    for l in (0, 1):
+        out["headline__act_level%d" % l] = np.concatenate([r["f"][l][v].ravel() for v in range(V)]).astype(np.float32)
+    picks = []
+    for l in (2, 3):
+        vmax, vmin = int(np.argmax(sizes[l])), int(np.argmin(sizes[l]))
+        for v in (vmax, vmin):
+            picks.append((l, v))
+            out["headline__act_l%d_v%d" % (l, v)] = r["f"][l][v].astype(np.float32)
+    out["headline__act_picks"] = np.array(picks, dtype=np.int32)
+    print("headline molecule: V = %d, max field sizes per level %s, predict %.6g" % (V, sizes.max(axis=1).tolist(), r["predict"]))
+    np.savez_compressed(os.path.join(HERE, "smp_headline.npz"), **out)
+
+
 def checkpoint_fixture():
     """smp_syn12's parameters as SMP_omega::save_model writes them (SMP_omega.h:1033-1042): a data file, 6 significant digits."""
     for i, (tag, adj, feat, tgt, (L, C, D, cap, wl, maxV)) in enumerate(smp_cases()):
@@ -275,11 +333,17 @@ def main():
     np.savez_compressed(os.path.join(HERE, "smp.npz"), **smp_fixtures())
     checkpoint_fixture()
     train_fixture()
+    headline_fixture()
     with open(os.path.join(HERE, "structural_50.json"), "w") as fh:
         json.dump(structural_50(), fh, indent=1)
-    for f in ("contractions.npz", "mixers.npz", "smp.npz", "structural_50.json", "smp_syn12_checkpoint.txt", "dropout.npz", "smp_train.npz"):
+    for f in ("contractions.npz", "mixers.npz", "smp.npz", "structural_50.json", "smp_syn12_checkpoint.txt", "dropout.npz", "smp_train.npz", "smp_headline.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "headline":   # only the (slow) headline fixture
+        pyoracle.build()
+        headline_fixture()
+        print("smp_headline.npz", os.path.getsize(os.path.join(HERE, "smp_headline.npz")), "bytes")
+    else:
+        main()

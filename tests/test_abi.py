@@ -28,6 +28,15 @@ def test_library_exports_every_declared_symbol(gf):
         assert hasattr(lib, name), "libgf_hip.so does not export %s" % name
 
 
+def test_library_exports_nothing_the_header_does_not_declare(gf):
+    """No undeclared gf_* entry points (test hooks, leftovers) in the product ABI: dynamic symbol table == header."""
+    import subprocess
+    from graphflow_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r" [TW] gf_[a-z0-9_]+$", ln)})
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
+
+
 def test_python_prototype_table_matches_header():
     from graphflow_amd import _lib
     assert sorted(_lib.PROTOTYPES) == declared_symbols()
@@ -59,6 +68,11 @@ def test_bad_arguments_are_rejected_without_device(gf):
     assert lib.gf_contract_forward_f32(None, 18, None, None, None, 4, 4, 1) == _lib.GF_ERR_INVALID
     assert lib.gf_contract_workspace_bytes(18, 32, 64, 256) > 0
     assert lib.gf_contract_workspace_bytes(18, 0, 64, 256) == 0
+    # data-parallel entry points: declared, exported, and refusing a null context rather than crashing
+    assert lib.gf_dist_init(None, None, 0, 1) == _lib.GF_ERR_INVALID
+    assert lib.gf_dist_allreduce_sum_f32(None, None, 0) == _lib.GF_ERR_INVALID
+    assert lib.gf_dist_rank(None) == 0 and lib.gf_dist_world(None) == 1
+    assert lib.gf_ctx_set_option(None, _lib.GF_OPT_R18_GENERIC_KERNELS, 1) == _lib.GF_ERR_INVALID
 
 
 def test_product_never_imports_the_oracle():

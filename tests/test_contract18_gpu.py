@@ -18,8 +18,10 @@ def host(t):
 
 
 def force_generic(gf, on):
+    """GF_OPT_R18_GENERIC_KERNELS on the default context: the layout-agnostic second implementation of RisiContraction_18."""
     from graphflow_amd import _lib
-    _lib.load().gf_debug_force_generic(1 if on else 0)
+    from graphflow_amd.ops import default_context
+    default_context(0).set_option(_lib.GF_OPT_R18_GENERIC_KERNELS, 1 if on else 0)
 
 
 @pytest.fixture(autouse=True)

@@ -1,0 +1,73 @@
+"""Data-parallel entry points of the C ABI (gf_dist_*) on one GPU: RCCL with a one-rank communicator.  The two-rank logic
+(sharding, the launcher, the single gradient exchange) is covered on CPU by tests/test_dist_cpu.py; a communicator with more
+than one rank needs more than one GPU (RCCL refuses two ranks on one device)."""
+import numpy as np
+import pytest
+
+from inputs import smp_params, synthetic_molecule
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_one_rank_collectives_through_rccl(gf):
+    ctx = gf.Context(0)
+    assert (ctx.dist_rank, ctx.dist_world) == (0, 1)
+    t = torch.arange(1000, dtype=torch.float32, device="cuda")
+    with pytest.raises(gf.GraphFlowHipError):
+        ctx.allreduce_sum_(t)                      # no communicator yet: refused, not silently skipped
+    uid = ctx.dist_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.dist_init(uid, 0, 1)
+    assert (ctx.dist_rank, ctx.dist_world) == (0, 1)
+    with pytest.raises(gf.GraphFlowHipError):
+        ctx.dist_init(uid, 0, 1)                   # one communicator per context
+    ref = t.clone()
+    ctx.allreduce_sum_(t)
+    ctx.broadcast_(t, 0)
+    ctx.synchronize()
+    assert torch.equal(t, ref)
+    with pytest.raises(gf.GraphFlowHipError):
+        ctx.broadcast_(t, 3)
+    ctx.dist_finalize()
+    assert ctx.dist_world == 1
+    ctx.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_smp_backward_reduces_its_gradient_segments_on_the_communicator(gf, fused):
+    """With a communicator on the context, gf_smp_backward all-reduces [K_L b_L W], [K_l b_l], ..., [H] on the communicator's
+    stream as the reverse sweep produces them and joins before returning: with one rank the result must be bit-identical to
+    the plain sweep (every segment reduced exactly once, none missed, ordering against the sweep correct)."""
+    from graphflow_amd.smp import SMPOmega
+    L, C, F, D, cap = 3, 64, 5, 3, 29
+    mols, tg = [], []
+    for seed in range(24):
+        a, f, t = synthetic_molecule(4100 + seed)
+        mols.append((a, f))
+        tg.append(t)
+    p = torch.as_tensor(smp_params(C, F, D, L, 8).astype(np.float32)).cuda()
+    t = torch.as_tensor(np.array(tg, dtype=np.float32)).cuda()
+
+    def grads(ctx, allreduce=True):
+        net = SMPOmega(L, C, F, D, cap, True, ctx=ctx)
+        net.set_fused(fused)
+        net.set_grad_allreduce(allreduce)
+        net.prepare(mols)
+        g = torch.full((net.n_params,), float("nan"), device="cuda")
+        for _ in range(3):   # re-running must not double-reduce anything
+            net.forward(p, t)
+            net.backward(p, g)
+        torch.cuda.synchronize()
+        return g.clone(), net
+
+    plain, _ = grads(gf.Context(0))
+    ctx = gf.Context(0)
+    ctx.dist_init(ctx.dist_unique_id(), 0, 1)
+    reduced, net = grads(ctx)
+    local, _ = grads(ctx, allreduce=False)
+    assert torch.equal(plain, reduced) and torch.equal(plain, local)
+    with pytest.raises(gf.GraphFlowHipError, match="accumulate"):
+        net.backward(p, reduced, accumulate=True)
+    net.close()
+    ctx.close()

@@ -91,6 +91,27 @@ def test_r18_is_the_gated_subset_of_r50(gf):
     assert rel_err(o18, o50[:, :, :, sel, :]) <= REL_TOL_F32
 
 
+@pytest.mark.parametrize("K", [50, 10])
+def test_cfg5_shape_one_graph_vs_oracle_spec_form(gf, oracle, K):
+    """BASELINE configs[4]'s shape (N = 24, C = 32): the lane mapping of fam_tables<50,4> / fam_products_lds<50> /
+    fam_bwd_tables<50,1> is only reached at C % 4 == 0 and this size.  Graph 0 of a 3-graph batch (weighted adjacency, so the
+    no-gate rule of _50 / _10 matters) against the oracle's table-driven spec form (RisiContraction_50.h:94-430) on two
+    channels -- channels are independent, so the oracle runs the O(N^5) form on a 2-channel copy."""
+    rng = np.random.default_rng(5050 + K)
+    B, N, C = 3, 24, 32
+    P = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
+    A = np.stack([adjacency(k, N, rng) for k in ("signed", "weighted", "sym01")])
+    G = f32exact(rng.uniform(-1, 1, (B, N, N, K, C)))
+    out = host(gf.contract_forward(dev(P), dev(A), K))
+    dP = host(gf.contract_backward(dev(G), dev(A), K))
+    sub = [3, 30]
+    for g in range(2):
+        ref_out = oracle.contract_forward(K, np.ascontiguousarray(P[g][..., sub]), A[g])
+        assert rel_err(out[g][..., sub], ref_out) <= REL_TOL_F32, g
+        ref_dp = oracle.contract_backward(K, np.ascontiguousarray(G[g][..., sub]), A[g])
+        assert rel_err(dP[g][..., sub], ref_dp) <= REL_TOL_F32, g
+
+
 def test_cfg5_full_size_properties(gf):
     """BASELINE cfg5 (RisiContraction_50, N=24, C=32), batch 64: adjoint identity and linearity."""
     B, N, C, K = 64, 24, 32, 50

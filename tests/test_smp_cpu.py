@@ -150,3 +150,73 @@ def test_oracle_against_live_reference_edge_molecules():
         assert r["phi"] == [[list(map(int, f)) for f in lv] for lv in o["phi"]], name
         assert abs(r["predict"] - o["predict"]) <= 1e-10 * max(1, abs(r["predict"])), name
         assert np.abs(r["grads"] - o["grads"]).max() <= 1e-9 * max(1, np.abs(r["grads"]).max()), name
+
+
+def test_c_port_matches_reference_goldens(golden):
+    """oracle/smp_port.c (the C restatement of the step body; also the "port"-kind CPU baseline of bench.py) against the
+    real-reference goldens: SMP_omega cases with the 18-contraction wiring, Coulomb adjacency included."""
+    from oracle import pyoracle
+    n = 0
+    for tag, c in cases(golden).items():
+        if "wiring" in c or "beta" in tag:
+            continue
+        L, Cn, D, cap, wl = (int(x) for x in c["cfg"])
+        o = pyoracle.port_smp_molecule(c["adj"], c["feature"], float(c["target"][0]), c["params"].astype(np.float64), L, Cn, D, cap,
+                                       bool(wl), coulomb=c.get("coulomb"))
+        assert abs(o["predict"] - c["predict"][0]) <= 1e-10 * max(1, abs(c["predict"][0])), tag
+        assert np.abs(o["graph_feature"] - c["graph_feature"]).max() <= 1e-10 * max(1, np.abs(c["graph_feature"]).max()), tag
+        assert np.abs(o["grads"] - c["grads"]).max() <= 1e-9 * max(1, np.abs(c["grads"]).max()), tag
+        n += 1
+    assert n >= 8
+
+
+def test_c_port_batch_driver_is_thread_count_independent():
+    """gfo_smp_batch (waves of nThreads molecules, the shape of Threaded_BatchLearn) sums the same gradients for any thread
+    count, and they equal the numpy restatement's."""
+    from oracle import pyoracle, smp_oracle
+    L, Cn, D, cap = 2, 4, 2, 8
+    params = smp_params(Cn, 5, D, L, 3)
+    mols = [synthetic_molecule(s, 6 + s)[:2] for s in range(5)]
+    tg = [6.0 + s for s in range(5)]
+    _, p1, l1, g1 = pyoracle.port_smp_batch(mols, tg, params, L, Cn, D, cap, 1)
+    _, p3, l3, g3 = pyoracle.port_smp_batch(mols, tg, params, L, Cn, D, cap, 3)
+    assert np.array_equal(p1, p3) and np.array_equal(l1, l3)
+    assert np.abs(g1 - g3).max() <= 1e-12 * max(1, np.abs(g1).max())   # (the order of the serial add differs with the wave size)
+    ref = [smp_oracle.run(a, f, t, params, L, Cn, D, cap) for (a, f), t in zip(mols, tg)]
+    assert np.abs(g1 - sum(r["grads"] for r in ref)).max() <= 1e-9 * max(1, np.abs(g1).max())
+    assert np.abs(p1 - np.array([r["predict"] for r in ref])).max() <= 1e-10 * max(1, np.abs(p1).max())
+
+
+def headline_golden():
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "smp_headline.npz"))
+    c = {k.split("__")[1]: z[k] for k in z.files}
+    L, Cn, D, cap, wl, seed_p = (int(x) for x in c["cfg"])
+    params = smp_params(Cn, c["feature"].shape[1], D, L, seed_p)
+    chk = np.array([params.sum(), np.abs(params).sum(), (params * np.arange(params.size)).sum()])
+    assert np.array_equal(chk, c["params_checksum"]), "smp_params(seed) no longer reproduces the fixture's parameters"
+    return c, (L, Cn, D, cap), params
+
+
+def activation_digest(f):
+    s = f.shape[0]
+    i, j = np.meshgrid(np.arange(s), np.arange(s), indexing="ij")
+    w = ((3 * i + 5 * j) % 7 - 3).astype(np.float64) / 4.0
+    return np.stack([f.sum(axis=(0, 1)), (w[:, :, None] * f).sum(axis=(0, 1))])
+
+
+def test_c_port_at_the_headline_shape(golden):
+    """BASELINE configs[2]'s own shape -- L = 3, cap 29, C = 64, a 29-atom molecule -- where the numpy restatement is out of
+    reach: the C port against the real reference's Feature / predict / loss / all 223,360 gradients and one full level-3
+    activation (tests/golden/smp_headline.npz, about 8 s of CPU)."""
+    from oracle import pyoracle
+    c, (L, Cn, D, cap), params = headline_golden()
+    l, v = (int(x) for x in c["act_picks"][2])   # the largest level-3 field
+    o = pyoracle.port_smp_molecule(c["adj"], c["feature"], float(c["target"][0]), params, L, Cn, D, cap, True, activation=(l, v))
+    assert abs(o["predict"] - c["predict"][0]) <= 1e-10 * abs(c["predict"][0])
+    assert abs(o["loss"] - c["loss"][0]) <= 1e-10 * abs(c["loss"][0])
+    assert np.abs(o["graph_feature"] - c["graph_feature"]).max() <= 1e-10 * np.abs(c["graph_feature"]).max()
+    assert np.abs(o["grads"] - c["grads"]).max() <= 1e-6 * np.abs(c["grads"]).max()   # the fixture keeps gradients in fp32
+    act = c["act_l%d_v%d" % (l, v)].astype(np.float64)
+    assert np.abs(o["f"] - act).max() <= 1e-6 * np.abs(act).max()
+    assert np.abs(activation_digest(o["f"]) - c["act_digest"][l, v]).max() <= 1e-10 * np.abs(c["act_digest"][l, v]).max()

@@ -8,9 +8,18 @@ from util import golden_cases, rel_err
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-# End-to-end tolerance: every op is within 1e-5 of fp64 (tests/util.py); through L levels of contraction + GEMM the
-# fp32 rounding compounds, so the chain is held to 1e-4 relative (forward quantities) / 2e-4 (parameter gradients).
-TOL_FWD, TOL_GRAD = 1e-4, 2e-4
+# End-to-end tolerance = north_star's 1e-5 (relative to the largest reference magnitude, tests/util.py:rel_err), forward
+# quantities and parameter gradients alike.  Measured maxima over the whole suite (printed by every test below, see
+# profiles/r02_parity_margins.txt): about 1e-6 forward, 3e-6 gradients -- the bound holds with a 3x margin.  The loss is
+# (y - t)^2 / 2 with |y - t| up to 1e4 x |t|: its relative error is twice the prediction's, hence 2 x.
+TOL_FWD, TOL_GRAD = 1e-5, 1e-5
+MARGINS = {}
+
+
+def note(name, **errs):
+    """Record the measured maxima (printed with -s and summarised by test_zz_print_margins)."""
+    for k, v in errs.items():
+        MARGINS[name + "." + k] = max(MARGINS.get(name + "." + k, 0.0), float(v))
 
 
 def dev(x, dtype=np.float32):
@@ -45,6 +54,8 @@ def test_reference_goldens_one_molecule_at_a_time(gf, golden, fused):
             for v in range(V):
                 n = c["phi"][l, v, 0]
                 assert net.receptive_field(0, l, v) == list(c["phi"][l, v, 1:1 + n]), tag
+        note("goldens_fused" if fused else "goldens_unfused", feat=rel_err(feat[0], c["graph_feature"]), pred=rel_err(pred, c["predict"]),
+             loss=rel_err(loss, c["loss"]), grads=rel_err(grads, c["grads"]))
         assert rel_err(feat[0], c["graph_feature"]) <= TOL_FWD, tag
         assert rel_err(pred, c["predict"]) <= TOL_FWD, tag
         assert rel_err(loss, c["loss"]) <= 2 * TOL_FWD, tag
@@ -84,9 +95,94 @@ def test_synthetic_batch_vs_oracle(gf, C, L, cap, fused):
     params = smp_params(C, F, D, L, 7)
     pred, loss, feat, grads, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap, fused=fused)
     ref = [smp_oracle.run(a, f, t, params, L, C, D, cap) for (a, f), t in zip(mols, tg)]
+    note("synthetic_vs_oracle", pred=rel_err(pred, np.array([r["predict"] for r in ref])),
+         feat=rel_err(feat, np.stack([r["graph_feature"] for r in ref])), grads=rel_err(grads, sum(r["grads"] for r in ref)))
     assert rel_err(pred, np.array([r["predict"] for r in ref])) <= TOL_FWD
     assert rel_err(feat, np.stack([r["graph_feature"] for r in ref])) <= TOL_FWD
     assert rel_err(grads, sum(r["grads"] for r in ref)) <= TOL_GRAD
+
+
+def _headline():
+    import os
+    from test_smp_cpu import activation_digest, headline_golden
+    c, cfg, params = headline_golden()
+    return c, cfg, params, activation_digest
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_headline_shape_against_the_real_reference(gf, fused):
+    """BASELINE configs[2]'s own shape pinned to the REAL reference (tests/golden/smp_headline.npz, generated by
+    tests/golden/make_golden.py from GraphFlow/SMP_omega.h:584-693): a 29-atom molecule at L = 3, cap 29, C = 64, F = 5, D = 5
+    (fields up to 20: the s <= 32 size classes of tables-forward, the 16-accumulator class of the folded gather, ragged 32-row
+    panels).  Receptive fields, reduced adjacencies, every level's activations (digests for all vertices, full tensors for
+    levels 0-1 and four picked nodes of levels 2-3), Feature(), predict, loss and all 223,360 parameter gradients."""
+    c, (L, C, D, cap), params, digest = _headline()
+    F = c["feature"].shape[1]
+    pred, loss, feat, grads, net = run_batch(gf, [(c["adj"], c["feature"])], c["target"], params, L, C, F, D, cap, True, fused=fused)
+    V = len(c["adj"])
+    worst_act = 0.0
+    for l in range(L + 1):
+        scale = max(np.abs(c["act_digest"][l]).max(), 1.0)
+        for v in range(V):
+            n = int(c["phi"][l, v, 0])
+            assert net.receptive_field(0, l, v) == list(c["phi"][l, v, 1:1 + n]), (l, v)
+            if l > 0:
+                assert np.array_equal(net.reduced_adjacency(0, l, v), c["reduced_adj"][l, v, :n, :n].astype(np.float32)), (l, v)
+            d = digest(net.activation(0, l, v).astype(np.float64))
+            worst_act = max(worst_act, np.abs(d - c["act_digest"][l, v]).max() / scale)
+    for l in (0, 1):
+        got = np.concatenate([net.activation(0, l, v).ravel() for v in range(V)]).astype(np.float64)
+        worst_act = max(worst_act, rel_err(got, c["act_level%d" % l].astype(np.float64)))
+    for l, v in c["act_picks"]:
+        worst_act = max(worst_act, rel_err(net.activation(0, int(l), int(v)).astype(np.float64), c["act_l%d_v%d" % (l, v)].astype(np.float64)))
+    e = dict(act=worst_act, feat=rel_err(feat[0], c["graph_feature"]), pred=rel_err(pred, c["predict"]), loss=rel_err(loss, c["loss"]),
+             grads=rel_err(grads, c["grads"].astype(np.float64)))
+    note("headline_fused" if fused else "headline_unfused", **e)
+    print("headline shape (%s): max rel err %s" % ("fused" if fused else "op-by-op", {k: "%.2e" % v for k, v in e.items()}))
+    assert e["act"] <= TOL_FWD and e["feat"] <= TOL_FWD and e["pred"] <= TOL_FWD and e["loss"] <= 2 * TOL_FWD
+    assert e["grads"] <= TOL_GRAD
+
+
+def test_headline_molecule_inside_a_batch(gf):
+    """The same molecule at position 17 of a 64-molecule batch (its nodes interleaved with the others' in every size class):
+    same Feature / predict / activations as alone, and the batch gradient = this molecule's golden gradient + the gradient of
+    the other 63 run without it."""
+    c, (L, C, D, cap), params, digest = _headline()
+    F = c["feature"].shape[1]
+    others, tg = [], []
+    for seed in range(63):
+        a, f, t = synthetic_molecule(7000 + seed)
+        others.append((a, f))
+        tg.append(t)
+    mols = others[:17] + [(c["adj"], c["feature"])] + others[17:]
+    tgs = np.array(tg[:17] + [float(c["target"][0])] + tg[17:])
+    pred, loss, feat, grads, net = run_batch(gf, mols, tgs, params, L, C, F, D, cap)
+    l, v = (int(x) for x in c["act_picks"][2])
+    e = dict(feat=rel_err(feat[17], c["graph_feature"]), pred=rel_err(pred[17:18], c["predict"]),
+             act=rel_err(net.activation(17, l, v).astype(np.float64), c["act_l%d_v%d" % (l, v)].astype(np.float64)))
+    g_others = run_batch(gf, others, np.array(tg), params, L, C, F, D, cap)[3]
+    e["grads"] = rel_err(grads - g_others, c["grads"].astype(np.float64))
+    note("headline_in_batch", **e)
+    assert e["feat"] <= TOL_FWD and e["pred"] <= TOL_FWD and e["act"] <= TOL_FWD
+    assert e["grads"] <= 2 * TOL_GRAD   # a difference of two fp32 batch sums, each within TOL_GRAD of its own truth
+
+
+def test_backward_needs_a_forward_with_targets(gf):
+    """A Predict / Feature forward (targets NULL) leaves no loss gradient: backward after it is refused, not run against 0."""
+    from graphflow_amd.smp import SMPOmega
+    net = SMPOmega(2, 8, 5, 2, 6, True)
+    net.prepare([synthetic_molecule(1, nV=6)[:2]])
+    p = dev(smp_params(8, 5, 2, 2, 1))
+    g = torch.empty(net.n_params, device="cuda")
+    net.forward(p)
+    with pytest.raises(Exception, match="no targets"):
+        net.backward(p, g)
+    net.forward(p, dev(np.array([6.0])))
+    net.backward(p, g)
+    with pytest.raises(TypeError):
+        net.backward(p, g[:-1])
+    with pytest.raises(TypeError):
+        net.forward(p.double())
 
 
 def test_vertex_permutation_invariance(gf):
@@ -427,3 +523,9 @@ def test_smp_2d_ver6_batchlearn_matches_the_reference(gf):
     scale = np.abs(z["train2d6__params"] - z["train2d6__params0"]).max()
     print("max |param - reference| %.3e, largest parameter change %.3e" % (err.max(), scale))
     assert err.max() <= 1e-3 * scale
+
+
+def test_zz_print_margins(gf):
+    """Not a check: prints the measured end-to-end maxima collected above (run with -s; copied to profiles/)."""
+    for k in sorted(MARGINS):
+        print("margin %-40s %.3e" % (k, MARGINS[k]))
