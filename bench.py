@@ -4,21 +4,30 @@
 Default workload = BASELINE.json configs[2] ("cfg3"), the configuration the headline metric is quoted on:
 SMP_omega (second-order CCN), 3 levels, 64 channels, nFeatures 5, nDepth 5, receptive-field cap 29, a batch of 1024
 synthetic QM9-size molecules per GPU (nV ~ U{3..29}), fp32, device-resident.  A "step" = forward + backward over the
-rank's batch (+ the single all-reduce of the flat parameter-gradient buffer when N > 1).  Host graph preparation
-(receptive fields, index tables) is input preparation: done once before the timed region and reported as prep_s.
-`--workload cfg2` runs BASELINE configs[1]: RisiContraction_18 fwd+bwd, N=32, C=64, batch 256 (the north_star target line).
+rank's batch; with N > 1 the backward leaves the parameter gradients summed over all ranks (RCCL all-reduce of each
+level's segment behind the C ABI, gf_dist_*, overlapped with the rest of the reverse sweep).
+`value` times the device step with the batch's index tables resident (host graph preparation is input preparation: once,
+before the timed region, reported as prep_s); `end_to_end` in the same line is the training-loop figure -- a NEW batch
+every step (host graph preparation + upload overlapped on a second handle) + forward + backward + Adam.
+`--workload cfg2` / `cfg5` run BASELINE configs[1] / configs[4] (RisiContraction_18 N=32 C=64, RisiContraction_50 N=24
+C=32, batch 256) as the headline; the default line carries both under `extra`, 20 steps each, with their own rooflines.
 
-Multi-GPU: molecules / graphs are independent, so ranks shard them (weak scaling: the per-GPU batch is fixed);
-the only collective is the gradient all-reduce (RCCL).  Timing: barrier + synchronize on both sides, max over ranks.
+Multi-GPU: `python bench.py --gpus N` spawns N ranks itself (torch.distributed.run on 127.0.0.1) unless it already runs
+under a launcher (WORLD_SIZE set, which must equal N).  Molecules / graphs are independent, so ranks shard them (weak
+scaling: the per-GPU batch is fixed).  Timing: barrier + synchronize on both sides, max over ranks.
 
 roofline: per-kernel HIP-event durations from the library's own launch timers (gf_ctx_set_timing, same stream as the
 kernels), for the kernel with the largest total device time; bytes / flops are the algorithmic figures of DESIGN.md.
-cpu_baseline: the REAL reference build (oracle/_ref/libgf_ref.so, kind "reference") when shipped, else our port, on one
-host core, on a bounded sample of the same workload.
+cpu_baseline: kind "port" -- oracle/gf_oracle.c + oracle/smp_port.c, the C restatement of the reference's loop nests, whose
+run time is held against the real reference in the build container (profiles/r02_port_vs_reference.json; the reference
+itself never travels to the GPU box) -- on one host core, on six threads (RisiContraction_18_thread's forward) and
+batch-parallel on all host cores (the shape of Threaded_BatchLearn), each on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -53,11 +62,60 @@ def contraction_bytes(K, N, C):
     return fwd, fwd
 
 
-def run_cfg2(args, torch, gf, dev, world, rank):
-    K = 50 if args.workload == "cfg5" else 18
-    if args.workload == "cfg5":   # BASELINE configs[4]: RisiContraction_50, N=24, 32 channels
-        args.N, args.C = 24, 32
-    B, N, C = args.batch or 256, args.N, args.C
+def host_threads():
+    """Threads of the all-cores CPU baseline: every host core, capped (a 29-atom molecule holds about 1 GB in the port)."""
+    return max(1, min(os.cpu_count() or 1, 32))
+
+
+def latest_profile(name):
+    """profiles/rNN_<name> of the newest round that committed one."""
+    best = None
+    for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if f.endswith(name) and f[0] == "r" and f[1:3].isdigit():
+            best = f
+    return os.path.join(ROOT, "profiles", best) if best else None
+
+
+# ---- the timed region (shared by the headline workload and the `extra` ones) ------------------------------------------
+def timed_run(torch, ctx, step, steps, warmup, fence, notiming=False):
+    """warmup untimed steps, then an identical pass of `steps` steps with every launch bracketed by HIP events OUTSIDE the
+    timed region (the per-kernel table: the events cost about 5 % of a 70-launch step, they keep neighbouring kernels from
+    overlapping), then the timed region proper, in which only the dominant kernel is timed live -- its average duration is
+    what roofline.achieved is computed from.  Returns (elapsed seconds of this rank, {kernel: (total ms, launches)})."""
+    for _ in range(warmup):
+        step()
+    fence()
+    timers, dominant = {}, None
+    if not notiming:
+        ctx.set_timing_filter(None)
+        ctx.set_timing(True)
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        timers = ctx.timings()
+        ctx.set_timing(False)
+        dominant = max(timers, key=lambda k: timers[k][0])
+        ctx.set_timing_filter(dominant)
+        fence()
+        ctx.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fence()
+    if not notiming:
+        live = ctx.timings()
+        ctx.set_timing(False)
+        ctx.set_timing_filter(None)
+        timers[dominant] = live[dominant]
+    return elapsed, timers
+
+
+# ---- cfg2 / cfg5: one contraction family, forward + backward ---------------------------------------------------------------
+def setup_contraction(workload, args, torch, gf, dev, world, rank, ctx):
+    K, N, C = (50, 24, 32) if workload == "cfg5" else (18, args.N, args.C)
+    B = (args.batch if workload == args.workload else 0) or 256
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     P = torch.rand((B, N, N, N, C), device=dev, generator=gen) * 2 - 1          # U(-1,1)
     U = (torch.rand((B, N, N), device=dev, generator=gen) < 0.5).float().triu(1)
@@ -65,15 +123,16 @@ def run_cfg2(args, torch, gf, dev, world, rank):
     G = torch.rand((B, N, N, K, C), device=dev, generator=gen)                   # U(0,1)
     Out = torch.empty((B, N, N, K, C), device=dev)
     dP = torch.empty((B, N, N, N, C), device=dev)
-    ctx = gf.Context(dev.index)
     ctx.reserve(gf.contract_workspace_bytes(K, N, C, B))
 
     def step():
         gf.contract_forward(P, A, K, out=Out, ctx=ctx)
         gf.contract_backward(G, A, K, dP=dP, accumulate=False, ctx=ctx)
 
-    def finish(timers, ms_per_step):
+    def finish(timers, ms_per_step, steps):
         fwd_b, bwd_b = contraction_bytes(K, N, C)
+        if not timers:
+            return {"note": "per-kernel timing disabled"}
         per = {k: v[0] / max(v[1], 1) for k, v in timers.items()}
         dom = max(timers, key=lambda k: timers[k][0])
         is_bwd = ("bwd" in dom) or ("backward" in dom)
@@ -81,51 +140,55 @@ def run_cfg2(args, torch, gf, dev, world, rank):
         bwd_ms = sum(v for k, v in per.items() if ("bwd" in k) or ("backward" in k))
         call_ms, call_b, which = (bwd_ms, bwd_b, "backward") if is_bwd else (fwd_ms, fwd_b, "forward")
         ach = call_b * B / (call_ms * 1e-3) / 1e9
-        traffic = None   # HBM bytes per launch of the dominant kernel from the committed PMC passes (same shape only)
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_cfg2_hbm_bytes.json")
-        if (B, N, C, K) == (256, 32, 64, 18) and os.path.exists(pmc):
+        traffic = None   # HBM bytes per step of the dominant kernel from the committed PMC passes (same shape only)
+        pmc = latest_profile("_pmc_%s_hbm_bytes.json" % workload)
+        if (B, N, C, K) in ((256, 32, 64, 18), (256, 24, 32, 50)) and pmc:
             with open(pmc) as fh:
                 t = json.load(fh).get(dom)
             if t:
                 traffic = round(t["fetch"] + t["write"])
-        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": dom,
                 "kernel_ms": {k: round(v, 4) for k, v in per.items()},
                 "note": "achieved = algorithmic bytes of one %s call over the batch / (the device time of that call's kernels)" % which,
-                "step_GBps": round((fwd_b + bwd_b) * B / (ms_per_step * 1e-3) / 1e9, 1)}
-        return roof
+                "step_GBps": round((fwd_b + bwd_b) * B / (ms_per_step * 1e-3) / 1e9, 1),
+                "step_frac_of_hbm_peak": round((fwd_b + bwd_b) * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     def cpu():
         from oracle import pyoracle
         from inputs import cfg_graph
         if K != 18:
-            return None   # the reference's RisiContraction_50 loops take ~8 s per graph at this shape; not re-timed here
+            return None   # the RisiContraction_50 loops take ~8 s per graph at this shape; not re-timed here
         Pc, Ac, Gc = cfg_graph(N, C, 1000, K=18)
-        secs, kind, _, _ = pyoracle.time_r18_fwd_bwd(Pc, Ac, Gc)
+        secs, kind, _, _ = pyoracle.time_r18_fwd_bwd(Pc, Ac, Gc, prefer_reference=False)
         out = {"value": round(1.0 / secs, 5), "unit": "graphs/s", "cores": 1, "kind": kind,
-               "sample": "1 graph, RisiContraction_18 fwd+bwd, N=%d C=%d fp64, %.1f s" % (N, C, secs)}
-        # north_star's multi-thread class, RisiContraction_18_thread (six std::threads by case group, no adjacency gate): its
-        # FORWARD only -- the backward races.  Slower than the single-thread op above (two of its six jobs carry
-        # the N^5 cases), so `value` stays the stronger baseline; reported beside it.
-        ref = pyoracle.reference()
-        if ref is not None:
-            t0 = time.perf_counter()
-            ref.r18_thread_forward(Pc, Ac)
-            out["thread_variant"] = {"class": "RisiContraction_18_thread", "threads": 6, "forward_s_per_graph": round(time.perf_counter() - t0, 2)}
+               "sample": "1 graph, RisiContraction_18 fwd+bwd (nnz-gated loop nests of RisiContraction_18.h:73-560), N=%d C=%d fp64, %.1f s" % (N, C, secs)}
+        # north_star's multi-thread class, RisiContraction_18_thread (six threads by case group, no adjacency gate): its FORWARD
+        # only -- the backward races.  Two of its six jobs carry the N^5 cases, so it is no faster than the
+        # single-thread op above; reported beside it.
+        orc = pyoracle.oracle()
+        t0 = time.perf_counter()
+        orc.r18_thread_forward(Pc, Ac)
+        out["thread_variant"] = {"class": "RisiContraction_18_thread (port of forward_job_0..5)", "threads": 6,
+                                 "forward_s_per_graph": round(time.perf_counter() - t0, 2)}
+        nT = host_threads()
+        secs_all = pyoracle.port_r18_batch_threads(Pc, Ac, Gc, nT, nT)
+        out["all_cores"] = {"value": round(nT / secs_all, 4), "unit": "graphs/s", "cores": nT, "kind": "port",
+                            "sample": "%d graphs fwd+bwd, one per host thread (batch-parallel), %.1f s" % (nT, secs_all)}
         return out
 
     meta = {"metric": "RisiContraction_%d graphs/sec fwd+bwd (second-order CCN contraction step)" % K, "unit": "graphs/s",
             "units_per_step": B,
             "config": {"workload": "%s: RisiContraction_%d fwd+bwd, N=%d, C=%d, batch=%d graphs/GPU, device-resident"
-                                   % (args.workload, K, N, C, B),
+                                   % (workload, K, N, C, B),
                        "parallelism": "graph-sharded x%d, no collective" % world}}
-    return ctx, step, finish, cpu, meta, None
+    return step, finish, cpu, meta, None
 
 
-def run_cfg3(args, torch, gf, dev, world, rank, dist):
+# ---- cfg3: the batched SMP_omega step --------------------------------------------------------------------------------------
+def setup_smp(args, torch, gf, dev, world, rank, ctx):
     import numpy as np
     from graphflow_amd.smp import SMPOmega
-    from graphflow_amd import dist as gd
     from inputs import smp_params, synthetic_molecule
     B = args.batch or 1024
     L, C, F, D, cap = 3, args.C, 5, 5, 29
@@ -134,7 +197,6 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
         adj, feat, t = synthetic_molecule(rank * 1000003 + i)   # seed = molecule index, disjoint across ranks
         mols.append((adj, feat))
         tg.append(t)
-    ctx = gf.Context(dev.index)
     net = SMPOmega(L, C, F, D, cap, True, ctx=ctx)
     t0 = time.perf_counter()
     net.prepare(mols)
@@ -146,18 +208,16 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
     targets = torch.as_tensor(np.array(tg, dtype=np.float32)).to(dev)
     grads = torch.empty(net.n_params, device=dev)
     sizes = [net.level_sizes(l) for l in range(L + 1)]   # (nodes, rows = sum s^2, ppos = sum s^3)
+    fused = not args.unfused
+    net.set_fused(fused)
 
     def step():
         net.forward(params, targets)
-        net.backward(params, grads)
-        gd.allreduce_sum_(grads, dist)   # the one exchange of the path (SMP_omega.h:784-786)
+        net.backward(params, grads)   # N > 1: returns the gradient summed over ranks (gf_dist_*, the one exchange of the path)
 
     # algorithmic work per step and per kernel: per level l >= 1 with R = sum s^2 (rows), S = sum s^3
     # (positions), Rp = rows of the level below; bytes are fp32 HBM bytes that MUST move, flops are MFMA flops.
-    fused = not args.unfused
-    net.set_fused(fused)
-    kb = {}   # kernel name -> algorithmic bytes per step
-    kf = {}   # kernel name -> flops per step
+    kb, kf = {}, {}
 
     def add(d, k, v):
         d[k] = d.get(k, 0) + v
@@ -175,9 +235,6 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
             else:
                 add(kb, "smpf_tables_bwd", 4 * (4 * R * C + S * C))
                 add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
-            # the eight row block products of a level, per direction.  C = 64: dedicated kernels (smp_level_c64.hip); other C,
-            # or with GF_SMP_ROWPANEL / GF_SMP_WGRAD = 0: grouped launches of the generic GEMM (which also runs the small
-            # per-(node,x) / per-node / compact products under these names, not counted here)
             c64 = C == 64
             names = (("smpf_products_fwd" if c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0" else "gemm_nn"),
                      ("smpf_products_bwd" if c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0" else "gemm_nt"),
@@ -200,10 +257,10 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
     work = {"levels": [{"nodes": n, "rows_sum_s2": r, "ppos_sum_s3": s} for (n, r, s) in sizes],
             "algorithmic_GB_per_step": round(step_bytes / 1e9, 2), "gemm_GFLOP_per_step": round(step_flops / 1e9, 1)}
 
-    def finish(timers, ms_per_step):
+    def finish(timers, ms_per_step, steps):
         if not timers:   # GF_BENCH_NOTIMING=1 (diagnostic: step time without the per-launch events)
             return {"note": "per-kernel timing disabled"}
-        tot = {k: v[0] / args.steps for k, v in timers.items()}   # ms per step per kernel name
+        tot = {k: v[0] / steps for k, v in timers.items()}   # ms per step per kernel name
         dom = max(tot, key=tot.get)
         if dom in kf:
             ach = kf[dom] / (tot[dom] * 1e-3) / 1e12
@@ -215,129 +272,253 @@ def run_cfg3(args, torch, gf, dev, world, rank, dist):
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "note": "algorithmic bytes of this kernel over all levels / its device time per step"}
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_cfg3_hbm_bytes.json")   # committed PMC passes, this exact workload only
-        if fused and (B, C) == (1024, 64) and os.path.exists(pmc):
+        pmc = latest_profile("_pmc_cfg3_hbm_bytes.json")   # committed PMC passes, this exact workload only
+        if fused and (B, C) == (1024, 64) and pmc:
             with open(pmc) as fh:
                 t = json.load(fh).get(dom)
             if t:
                 roof["traffic"] = round(t["fetch"] + t["write"])   # HBM bytes of all launches of the kernel in one step
-        # MFMA utilisation of the C = 64 product kernels from the committed PMC pass (SQ_VALU_MFMA_BUSY_CYCLES over four SIMDs x
-        # SQ_BUSY_CU_CYCLES), same workload only
-        busy = os.path.join(ROOT, "profiles", "r01_cfg3_mfma_busy.txt")
+                roof["traffic_source"] = os.path.basename(pmc)
+        busy = latest_profile("_cfg3_mfma_busy.txt")
         real = {"smpf_products_fwd": "smp_rowpanel_c64<true>", "smpf_products_bwd": "smp_rowpanel_c64<false>", "smpf_wgrad": "smp_wgrad_c64"}
-        if fused and (B, C) == (1024, 64) and dom in real and os.path.exists(busy):
+        if fused and (B, C) == (1024, 64) and dom in real and busy:
             for line in open(busy):
                 if line.startswith(real[dom]) and "MFMA busy" in line:
                     roof["mfma_busy_pmc"] = float(line.rsplit("MFMA busy", 1)[1])
         roof["kernel"] = dom
         roof["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
+        roof["launches_per_step"] = round(sum(v[1] for v in timers.values() if v[1] > steps / 2) / steps, 1) if steps else None
+        # every kernel with an algorithmic figure, against its own bound (the step is a composite of byte- and MFMA-bound kernels)
+        roof["per_kernel_frac"] = {k: round((kf[k] / (tot[k] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF) if k in kf
+                                            else (kb[k] / (tot[k] * 1e-3) / 1e9 / HBM_PEAK_GBS), 3)
+                                   for k in tot if (k in kf or k in kb) and tot[k] > 0}
+        ideal_ms = sum(kf[k] / (MFMA_F32_PEAK_TF * 1e12) * 1e3 if k in kf else kb[k] / (HBM_PEAK_GBS * 1e9) * 1e3 for k in set(kf) | set(kb))
+        roof["step_composite_frac"] = round(ideal_ms / ms_per_step, 4)
         roof["step_GBps"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
         roof["step_gemm_TFLOPs"] = round(step_flops / (ms_per_step * 1e-3) / 1e12, 2)
         return roof
 
     def cpu():
         from oracle import pyoracle
-        # bounded sample: the batch's first molecules until about 20 s of reference work (cost grows steeply with nV)
+        # bounded samples of the same batch: its first molecules until about 8 s of work on one core (cost grows steeply with
+        # nV: 8.3 s at 29 atoms in the reference), then one wave of the batch-parallel driver on every host core
         sample, est = [], 0.0
         for (a, f), t in zip(mols, tg):
             sample.append(((a, f), t))
-            est += 3.5e-4 * len(a) ** 3   # rough: 8.3 s at 29 atoms
-            if est > 20.0 or len(sample) >= 16:
+            est += 3.5e-4 * len(a) ** 3
+            if est > 8.0 or len(sample) >= 16:
                 break
-        secs = pyoracle.time_reference_smp_omega([m for m, _ in sample], [t for _, t in sample], L, C, D, cap)
-        if secs is None:
-            return None
-        return {"value": round(len(sample) / secs, 4), "unit": "molecules/s", "cores": 1, "kind": "reference",
-                "sample": "first %d molecules of the batch (nV %s), SMP_omega complete_computation_graph+forward+backward, fp64, %.1f s"
-                          % (len(sample), [len(m[0]) for m, _ in sample], secs)}
+        p64 = params.cpu().numpy().astype(np.float64)
+        secs, _, _, _ = pyoracle.port_smp_batch([m for m, _ in sample], [t for _, t in sample], p64, L, C, D, cap, 1)
+        out = {"value": round(len(sample) / secs, 4), "unit": "molecules/s", "cores": 1, "kind": "port",
+               "sample": "first %d molecules of the batch (nV %s), SMP_omega op DAG forward+backward (oracle/smp_port.c), fp64, %.1f s"
+                         % (len(sample), [len(m[0]) for m, _ in sample], secs)}
+        nT = host_threads()
+        wave = [(mols[i], tg[i]) for i in range(min(nT, len(mols)))]
+        secs_all, _, _, _ = pyoracle.port_smp_batch([m for m, _ in wave], [t for _, t in wave], p64, L, C, D, cap, nT)
+        out["all_cores"] = {"value": round(len(wave) / secs_all, 4), "unit": "molecules/s", "cores": nT, "kind": "port",
+                            "sample": "first %d molecules of the batch, one host thread each (the wave structure of Threaded_BatchLearn, SMP_omega.h:750-792), %.1f s"
+                                      % (len(wave), secs_all)}
+        return out
+
+    def end_to_end(steps):
+        """Training loop with a NEW batch every step: gf_smp_prepare (host graph preparation + upload) of batch i+1 on a second
+        handle while the device runs forward + backward + Adam of batch i.  molecules/s of this rank."""
+        pool = [synthetic_molecule(7000003 + rank * 1000003 + i) for i in range(3 * B)]
+        batches = [(mols, targets)]
+        for i in range(3):
+            sl = pool[i * B:(i + 1) * B]
+            batches.append(([(a, f) for a, f, _ in sl], torch.as_tensor(np.array([t for *_, t in sl], dtype=np.float32)).to(dev)))
+        nets = [net, SMPOmega(L, C, F, D, cap, True, ctx=ctx)]
+        nets[1].set_fused(fused)
+        p = params.clone()
+        for k, n in enumerate(nets):   # warm both pools
+            n.prepare(batches[k][0])
+            n.forward(p, batches[k][1])
+            n.backward(p, grads)
+        torch.cuda.synchronize()
+        nets[0].prepare(batches[0][0])
+        t0 = time.perf_counter()
+        for it in range(steps):
+            cur = nets[it % 2]
+            cur.forward(p, batches[it % 4][1])
+            cur.backward(p, grads)
+            net.adam_step(p, grads, 1e-5, B * world)
+            nets[(it + 1) % 2].prepare(batches[(it + 1) % 4][0])   # the host builds the next batch while the device works
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        net.prepare(mols)   # leave the handle as the timed region had it
+        nets[1].close()
+        return {"ms_per_step": round(dt * 1e3, 3), "value": round(B / dt, 1), "unit": "molecules/s per GPU", "steps": steps,
+                "what": "new batch every step: host graph preparation + upload (second handle, overlapped) + forward + backward + Adam"}
 
     meta = {"metric": "CCN-2D (SMP_omega) molecules/sec fwd+bwd", "unit": "molecules/s", "units_per_step": B,
             "config": {"workload": "cfg3: SMP_omega 3 levels, C=%d, F=5, D=5, cap=29, batch=%d synthetic QM9-size molecules/GPU, device-resident, %s levels"
                                    % (C, B, "fused" if fused else "op-by-op"),
-                       "parallelism": "molecule-sharded x%d, one RCCL all-reduce of %d gradient floats per step" % (world, net.n_params)
-                       if world > 1 else "single GPU", "prep_s": round(prep_s, 3), "prep_first_s": round(prep_first_s, 3), "work": work}}
-    return ctx, step, finish, cpu, meta, net
+                       "parallelism": ("molecule-sharded x%d, RCCL all-reduce of the %d gradient floats inside gf_smp_backward (per-level segments, overlapped)"
+                                       % (world, net.n_params)) if world > 1 else "single GPU",
+                       "timed_region": "device step (index tables resident); see end_to_end for the loop with a new batch every step",
+                       "prep_s": round(prep_s, 3), "prep_first_s": round(prep_first_s, 3), "work": work}}
+    return step, finish, cpu, meta, (net, end_to_end)
+
+
+# ---- launcher ---------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` outside a launcher: re-run this script as N ranks on this node."""
+    if not args.plumbing:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d but only %d HIP device(s) are visible; refusing to report a smaller run as n_gpus=%d"
+                     % (args.gpus, have, args.gpus))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def run_plumbing(args, world, rank):
+    """CPU-only check of everything around the kernels for N > 1: the launcher, rank/shard bookkeeping, the single exchange
+    (gloo all-reduce of a gradient-sized buffer), barrier + max-over-ranks timing and the one JSON line from rank 0.
+    No kernels run and nothing is measured: the line says so."""
+    import torch
+    from graphflow_amd import dist as gd
+    dist = gd.init(backend="gloo")
+    n_params = 64 * 30 + 3 * (18 * 64 * 64 + 64) + 64
+    lo, hi = gd.shard(1024 * world, rank, world)
+    g = torch.full((n_params,), float(rank + 1))
+
+    def step():
+        g.fill_(float(rank + 1))
+        gd.allreduce_sum_(g, dist)
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = gd.max_over_ranks(time.perf_counter() - t0, dist)
+    assert float(g[0]) == world * (world + 1) / 2, "all-reduce over %d ranks gave %r" % (world, float(g[0]))
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing check (no kernels ran, nothing measured)", "value": 0.0, "unit": "molecules/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "config": {"workload": "plumbing: launcher + sharding + gloo all-reduce of %d floats" % n_params,
+                                     "shard_of_rank0": [lo, hi]}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
-    ap.add_argument("--batch", type=int, default=0, help="graphs / molecules per GPU (default 256 for cfg2, 1024 for cfg3)")
+    ap.add_argument("--batch", type=int, default=0, help="graphs / molecules per GPU (default 256 for cfg2/cfg5, 1024 for cfg3)")
     ap.add_argument("--N", type=int, default=32)
     ap.add_argument("--C", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cfg2 / cfg5 / end_to_end sections of the default line")
     ap.add_argument("--unfused", action="store_true", help="cfg3: op-by-op level pipeline instead of the fused level kernels")
+    ap.add_argument("--plumbing", action="store_true", help="CPU-only check of the multi-rank plumbing (gloo); measures nothing")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_spawn(args)
+    from graphflow_amd import dist as gd
+    world, rank, local = gd.env_world()
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree" % (args.gpus, world))
+    if args.plumbing:
+        return run_plumbing(args, world, rank)
 
     import torch
     import graphflow_amd as gf
-    from graphflow_amd import dist as gd
 
-    world, rank, local = gd.env_world()
+    if torch.cuda.device_count() < (local + 1 if world > 1 else 1):
+        sys.exit("bench.py: rank %d needs HIP device %d, %d visible" % (rank, local, torch.cuda.device_count()))
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
-    dist = gd.init(backend="nccl", device=dev) if (world > 1 or os.environ.get("GF_FORCE_DIST")) else None
-
-    if args.workload in ("cfg2", "cfg5"):
-        ctx, step, finish, cpu, meta, keep = run_cfg2(args, torch, gf, dev, world, rank)
-    else:
-        ctx, step, finish, cpu, meta, keep = run_cfg3(args, torch, gf, dev, world, rank, dist)
+    force = bool(os.environ.get("GF_FORCE_DIST"))
+    dist = gd.init(backend="nccl", device=dev) if world > 1 else None   # torch.distributed: barrier + max-over-ranks only
+    ctx = gf.Context(dev.index)
+    if world > 1 or force:   # the path's own exchange lives behind the C ABI: one RCCL communicator on the context
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(ctx.dist_unique_id()), dtype=torch.uint8))
+        if dist is not None:
+            dist.broadcast(uid, src=0)
+        ctx.dist_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # Per-kernel table: an identical pass of K steps with every launch bracketed by HIP events, OUTSIDE the timed region
-    # (the events cost about 5 % of a 72-launch step: they keep neighbouring kernels from overlapping).  The timed region
-    # then times only the dominant kernel live -- its average duration is what roofline.achieved is computed from.
+    if args.workload in ("cfg2", "cfg5"):
+        step, finish, cpu, meta, keep = setup_contraction(args.workload, args, torch, gf, dev, world, rank, ctx)
+    else:
+        step, finish, cpu, meta, keep = setup_smp(args, torch, gf, dev, world, rank, ctx)
+
     notiming = bool(os.environ.get("GF_BENCH_NOTIMING"))
-    timers = {}
-    if not notiming:
-        ctx.set_timing_filter(None)
-        ctx.set_timing(True)
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        timers = ctx.timings()
-        ctx.set_timing(False)
-        dominant = max(timers, key=lambda k: timers[k][0])
-        ctx.set_timing_filter(dominant)
-        fence()
-        ctx.set_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    fence()
-    if not notiming:
-        live = ctx.timings()
-        ctx.set_timing(False)
-        ctx.set_timing_filter(None)
-        timers[dominant] = live[dominant]
+    elapsed, timers = timed_run(torch, ctx, step, args.steps, args.warmup, fence, notiming)
     elapsed = gd.max_over_ranks(elapsed, dist, dev)
 
-    ceiling = copy_ceiling_gbps(torch, dev) if rank == 0 else None
+    line = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * meta["units_per_step"] * args.steps / elapsed
         line = {"metric": meta["metric"], "value": round(value, 1), "unit": meta["unit"], "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": meta["config"], "roofline": finish(timers, ms_per_step),
-                "cpu_baseline": (cpu() if (world == 1 and not args.no_cpu_baseline) else None)}
-        line["roofline"]["hbm_copy_measured_GBps"] = round(ceiling, 1)
-        if hasattr(keep, "device_bytes"):   # HBM held by the batch's buffers after the steps ran (lazy buffers included)
-            line["config"]["device_GB"] = round(keep.device_bytes()[0] / 1e9, 2)
+                "config": meta["config"], "roofline": finish(timers, ms_per_step, args.steps)}
+        if ctx.dist_world > 1 or force:
+            line["config"]["collective"] = "gf_dist_* (RCCL) world %d" % ctx.dist_world
         line["roofline"]["timing"] = ("HIP events on the kernels' stream: the dominant kernel live inside the timed region, "
                                       "the other kernels in an identical pass of the same steps just before it")
+    # the sections below run on every rank that takes part in them, outside the timed region
+    e2e = None
+    if keep is not None and not args.no_extra:
+        net, end_to_end = keep
+        if rank == 0:
+            line["config"]["device_GB"] = round(net.device_bytes()[0] / 1e9, 2)   # HBM held by the batch's buffers (lazy ones included)
+        if world == 1 and not force:
+            e2e = end_to_end(min(40, max(8, args.steps)))
+    if rank == 0:
+        if e2e:
+            line["end_to_end"] = e2e
+        if world == 1 and not args.no_extra and args.workload == "cfg3" and not args.unfused:
+            # BASELINE configs[1] and configs[4] under the same clock: 20 steps each after 3 warm-ups
+            extra = {}
+            for wl in ("cfg2", "cfg5"):
+                ectx = gf.Context(dev.index)
+                estep, efinish, ecpu, emeta, _ = setup_contraction(wl, args, torch, gf, dev, 1, 0, ectx)
+                el, et = timed_run(torch, ectx, estep, 20, 3, torch.cuda.synchronize, notiming)
+                ems = 1e3 * el / 20
+                extra[wl] = {"metric": emeta["metric"], "value": round(emeta["units_per_step"] * 20 / el, 1), "unit": emeta["unit"],
+                             "steps": 20, "warmup": 3, "ms_per_step": round(ems, 4), "workload": emeta["config"]["workload"],
+                             "roofline": efinish(et, ems, 20)}
+                if not args.no_cpu_baseline:
+                    cb = ecpu()
+                    if cb:
+                        extra[wl]["cpu_baseline"] = cb
+                        extra[wl]["speedup_vs_cpu_1core"] = round(extra[wl]["value"] / cb["value"], 1)
+                del estep
+                ectx.close()
+                torch.cuda.empty_cache()
+            line["extra"] = extra
+        line["roofline"]["hbm_copy_measured_GBps"] = round(copy_ceiling_gbps(torch, dev), 1)
+        line["cpu_baseline"] = cpu() if (world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -552,3 +552,18 @@ def time_reference_smp_omega_threaded(molecules, targets, nLevels, nChanels, nDe
     f.argtypes = [_i] * 8 + [ip, ip, _dp, _dp]
     f.restype = C_double
     return float(f(int(nThreads), int(nV.max()), cap, nLevels, nChanels, F, nDepth, len(molecules), nV, adj, feat, tg))
+
+
+def port_r18_batch_threads(P, A, G, nGraphs, nThreads):
+    """Seconds for nGraphs x (RisiContraction_18 forward + backward, port loop nests) spread over nThreads host threads."""
+    import time
+    lib = oracle().lib
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    G = np.ascontiguousarray(G, dtype=np.float64)
+    f = lib.gfo_r18_batch_threads
+    f.argtypes = [_dp, _dp, _dp, _i, _i, _i, _i]
+    f.restype = _i
+    t0 = time.perf_counter()
+    assert f(P, A, G, P.shape[0], P.shape[3], int(nGraphs), int(nThreads)) == 0
+    return time.perf_counter() - t0

@@ -271,3 +271,41 @@ int gfo_smp_batch(int nMol, const int *nV, int FD, int L, int C, int cap, const 
     free(jobs);
     return rc;
 }
+
+/* ---- batch-parallel RisiContraction_18: the "best-effort CPU" of SURVEY 8(d)(iii) for the pure-op workload ------------------
+ * nGraphs independent graphs, forward + backward each (the nnz-gated single-thread loops), one graph per host thread at a
+ * time -- the batch-parallel shape Threaded_BatchLearn gives the SMP model, applied to the op benchmark.  All graphs share
+ * the same P / A / G buffers (read-only); each thread owns its Out / dP.                                                   */
+typedef struct {
+    const double *P, *A, *G;
+    int N, C, count;
+} r18_batch_job;
+
+static void *r18_batch_worker(void *arg) {
+    r18_batch_job *j = (r18_batch_job *)arg;
+    const size_t nOut = (size_t)j->N * j->N * 18 * j->C, nP = (size_t)j->N * j->N * j->N * j->C;
+    double *Out = zalloc(nOut), *dP = zalloc(nP);
+    for (int i = 0; i < j->count; ++i) {
+        gfo_r18_loops_forward(j->P, j->A, Out, j->N, j->C);
+        gfo_r18_loops_backward(j->G, j->A, dP, j->N, j->C);
+    }
+    free(Out);
+    free(dP);
+    return NULL;
+}
+
+int gfo_r18_batch_threads(const double *P, const double *A, const double *G, int N, int C, int nGraphs, int nThreads) {
+    if (nThreads < 1) nThreads = 1;
+    if (nThreads > nGraphs) nThreads = nGraphs;
+    pthread_t *th = (pthread_t *)calloc(nThreads, sizeof(pthread_t));
+    r18_batch_job *jobs = (r18_batch_job *)calloc(nThreads, sizeof(r18_batch_job));
+    for (int t = 0; t < nThreads; ++t) {
+        r18_batch_job j = {P, A, G, N, C, nGraphs / nThreads + (t < nGraphs % nThreads ? 1 : 0)};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, r18_batch_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nThreads; ++t) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+    return 0;
+}

@@ -45,3 +45,30 @@ def test_two_rank_gradient_allreduce_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_gpus_2_spawns_two_ranks_plumbing():
+    """`python bench.py --gpus 2` outside a launcher must start two ranks itself and print ONE line with n_gpus 2 (round 1
+    parsed --gpus and ignored it).  --plumbing runs the real entry point's launcher, rank bookkeeping, the single exchange
+    (gloo here, RCCL behind gf_dist_* on GPUs) and max-over-ranks timing without kernels."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and "plumbing" in out["metric"]
+
+
+def test_bench_refuses_a_world_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plumbing"], capture_output=True, text=True,
+                       env=env, timeout=120)
+    assert r.returncode != 0 and "must agree" in (r.stdout + r.stderr)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if not torch.cuda.is_available():   # asking for GPUs that are not there fails loudly instead of running fewer ranks
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode != 0 and "HIP device" in (r.stdout + r.stderr)
