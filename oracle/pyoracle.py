@@ -482,8 +482,12 @@ def _port_inputs(molecules, L, nDepth, cap, has_wl=True):
     return xs, phis, adjs, nV
 
 
-def port_smp_molecule(adj, feature, target, params, L, C, nDepth, cap, has_wl=True, coulomb=None, activation=None):
-    """One molecule through the C port.  activation=(level, vertex): also return that f[l][v] as "f"."""
+def port_smp_molecule(adj, feature, target, params, L, C, nDepth, cap, has_wl=True, coulomb=None, activation=None,
+                      ext_sign=None, kink_tol=0.0, want_acts=False):
+    """One molecule through the C port.  activation=(level, vertex): also return that f[l][v] as "f".
+    ext_sign: list [l][v] of arrays [s, s, C] (any dtype; > 0 means the implementation under test saw a positive activation):
+    inside the LeakyReLU kink tolerance (|z| <= kink_tol * max|z| of the level) the reverse sweep takes that slope; the
+    result then carries "n_override" / "n_conflict" (see gfo_smp_molecule_ex).  want_acts: "acts" = [[f[l][v]]]."""
     lib = oracle().lib
     xs, phis, adjs, nV = _port_inputs([(adj, feature)], L, nDepth, cap, has_wl)
     x, phi, a, V = xs[0], phis[0], adjs[0], nV[0]
@@ -491,8 +495,9 @@ def port_smp_molecule(adj, feature, target, params, L, C, nDepth, cap, has_wl=Tr
     params = np.ascontiguousarray(params, dtype=np.float64)
     gfeat, pred, loss, grads = np.zeros(C), np.zeros(1), np.zeros(1), np.zeros_like(params)
     ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
-    f = lib.gfo_smp_molecule
-    f.argtypes = [_i] * 5 + [_dp, ip, ip, ctypes_vp, _dp, C_double, _i, _dp, _dp, _dp, _dp, _i, _i, ctypes_vp]
+    f = lib.gfo_smp_molecule_ex
+    f.argtypes = [_i] * 5 + [_dp, ip, ip, ctypes_vp, _dp, C_double, _i, _dp, _dp, _dp, _dp, _i, _i, ctypes_vp,
+                  ctypes_vp, C_double, ctypes_vp, ctypes_vp, ctypes_vp]
     f.restype = _i
     cm = None if coulomb is None else np.ascontiguousarray(coulomb, dtype=np.float64)
     act = None
@@ -501,10 +506,29 @@ def port_smp_molecule(adj, feature, target, params, L, C, nDepth, cap, has_wl=Tr
         al, av = activation
         s = int(phi[al, av, 0])
         act = np.zeros((s, s, C))
+    sizes = [[int(phi[l, v, 0]) for v in range(V)] for l in range(L + 1)]
+    total = sum(s * s * C for row in sizes for s in row)
+    sign = None
+    if ext_sign is not None:
+        sign = np.concatenate([np.where(np.asarray(ext_sign[l][v]) > 0, 1, -1).astype(np.int8).ravel() for l in range(L + 1) for v in range(V)])
+        assert sign.size == total
+    acts = np.zeros(total) if want_acts else None
+    import ctypes as ct
+    n_over, n_conf = ct.c_longlong(0), ct.c_longlong(0)
     rc = f(V, FD, L, C, cap, x, phi, a, None if cm is None else cm.ctypes.data, params, float(target), 1, gfeat, pred, loss, grads,
-           al, av, None if act is None else act.ctypes.data)
+           al, av, None if act is None else act.ctypes.data, None if sign is None else sign.ctypes.data, float(kink_tol),
+           ct.addressof(n_over), ct.addressof(n_conf), None if acts is None else acts.ctypes.data)
     assert rc == 0
-    return {"graph_feature": gfeat, "predict": float(pred[0]), "loss": float(loss[0]), "grads": grads, "f": act}
+    out = {"graph_feature": gfeat, "predict": float(pred[0]), "loss": float(loss[0]), "grads": grads, "f": act,
+           "n_override": int(n_over.value), "n_conflict": int(n_conf.value), "n_elements": total}
+    if want_acts:
+        out["acts"], o = [[None] * V for _ in range(L + 1)], 0
+        for l in range(L + 1):
+            for v in range(V):
+                s = sizes[l][v]
+                out["acts"][l][v] = acts[o:o + s * s * C].reshape(s, s, C)
+                o += s * s * C
+    return out
 
 
 def port_smp_batch(molecules, targets, params, L, C, nDepth, cap, nThreads=1):

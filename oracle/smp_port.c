@@ -33,6 +33,18 @@ void gfo_tensormatmul_backward(const double *G, const double *F, const double *Y
 
 static double *zalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
 
+static double slope_of(double f, int ext, double tol, long long *overrides, long long *conflicts) {
+    const int own = f > 0 ? 1 : -1;
+    if (ext == 0 || ext == own) return own > 0 ? 1.0 : ALPHA;
+    const double z = f > 0 ? f : -f / ALPHA;
+    if (z <= tol) {
+        ++*overrides;
+        return ext > 0 ? 1.0 : ALPHA;
+    }
+    ++*conflicts;
+    return own > 0 ? 1.0 : ALPHA;
+}
+
 typedef struct {
     int s;          /* receptive-field size */
     const int *fld; /* the field: vertex ids */
@@ -49,9 +61,31 @@ typedef struct {
  * H[C][FD], (K_l[18C][C], b_l[C]) l = 1..L, W[C] (SMP_omega.h:289-295); grads is ACCUMULATED into (sum_gradients, :808-820).
  * act_level >= 0 && act_out: copy f[act_level][act_vertex] ([s][s][C]) out (parity checks of the per-level activations).
  * Returns 0, or -1 on allocation failure. */
+/* LeakyReLU's kink and fp32.  A pre-activation z within the fp32 rounding error of its own sum (|z| <= kink_tol * max|z| of
+ * its level) has no well-defined slope for an fp32 implementation: a different summation order lands it on either side of 0,
+ * and either one-sided derivative is a valid subgradient there.  With ext_sign given (one signed char per activation element,
+ * nodes in (level, vertex) order, each [s][s][C]: the sign the implementation under test saw) the reverse sweep takes THAT
+ * slope at such elements and its own everywhere else; *n_override counts the elements where this changed the slope and
+ * *n_conflict the elements OUTSIDE the tolerance whose external sign disagrees (a real forward error: must be 0).
+ * acts_out (optional): every f[l][v] back to back in the same order. */
+int gfo_smp_molecule_ex(int V, int FD, int L, int C, int cap, const double *x, const int *phi, const int *adj,
+                        const double *coulomb, const double *params, double target, int want_grads, double *graph_feature,
+                        double *predict, double *loss, double *grads, int act_level, int act_vertex, double *act_out,
+                        const signed char *ext_sign, double kink_tol, long long *n_override, long long *n_conflict,
+                        double *acts_out);
+
 int gfo_smp_molecule(int V, int FD, int L, int C, int cap, const double *x, const int *phi, const int *adj,
                      const double *coulomb, const double *params, double target, int want_grads, double *graph_feature,
                      double *predict, double *loss, double *grads, int act_level, int act_vertex, double *act_out) {
+    return gfo_smp_molecule_ex(V, FD, L, C, cap, x, phi, adj, coulomb, params, target, want_grads, graph_feature, predict, loss,
+                               grads, act_level, act_vertex, act_out, NULL, 0.0, NULL, NULL, NULL);
+}
+
+int gfo_smp_molecule_ex(int V, int FD, int L, int C, int cap, const double *x, const int *phi, const int *adj,
+                        const double *coulomb, const double *params, double target, int want_grads, double *graph_feature,
+                        double *predict, double *loss, double *grads, int act_level, int act_vertex, double *act_out,
+                        const signed char *ext_sign, double kink_tol, long long *n_override, long long *n_conflict,
+                        double *acts_out) {
     const size_t nH = (size_t)C * FD, nK = (size_t)18 * C * C;
     const double *H = params;
     const double *W = params + nH + (size_t)L * (nK + C);
@@ -113,6 +147,27 @@ int gfo_smp_molecule(int V, int FD, int L, int C, int cap, const double *x, cons
                     n->f[i * C + c] = z > 0 ? z : ALPHA * z; /* LeakyReLU3D, :667 */
                 }
         }
+    /* element offsets of the nodes in (level, vertex) order, the largest |z| of every level, optional dump */
+    size_t *node_off = (size_t *)calloc((size_t)(L + 1) * V + 1, sizeof(size_t));
+    double *zmax = zalloc(L + 1);
+    {
+        size_t o = 0;
+        for (int l = 0; l <= L; ++l)
+            for (int v = 0; v < V; ++v) {
+                const port_node *n = &ND(l, v);
+                const size_t cnt = (size_t)n->s * n->s * C;
+                node_off[(size_t)l * V + v] = o;
+                for (size_t i = 0; i < cnt; ++i) {
+                    const double z = n->f[i] > 0 ? n->f[i] : -n->f[i] / ALPHA;
+                    if (z > zmax[l]) zmax[l] = z;
+                }
+                if (acts_out) memcpy(acts_out + o, n->f, sizeof(double) * cnt);
+                o += cnt;
+            }
+    }
+    long long overrides = 0, conflicts = 0;
+/* slope of element i of node (l, v): the node's own sign, or the external one inside the kink tolerance */
+#define SLOPE(l, v, n, i) slope_of((n)->f[i], ext_sign ? ext_sign[node_off[(size_t)(l)*V + (v)] + (i)] : 0, kink_tol * zmax[l], &overrides, &conflicts)
     if (act_out && act_level >= 0 && act_level <= L && act_vertex >= 0 && act_vertex < V) {
         const port_node *n = &ND(act_level, act_vertex);
         memcpy(act_out, n->f, sizeof(double) * (size_t)n->s * n->s * C);
@@ -153,7 +208,7 @@ int gfo_smp_molecule(int V, int FD, int L, int C, int cap, const double *x, cons
                 double *dz = zalloc((size_t)s * s * C);
                 for (size_t i = 0; i < (size_t)s * s; ++i)
                     for (int c = 0; c < C; ++c) {
-                        const double d = n->df[i * C + c] * (n->f[i * C + c] > 0 ? 1.0 : ALPHA);
+                        const double d = n->df[i * C + c] * SLOPE(l, v, n, i * C + c);
                         dz[i * C + c] = d;
                         db[c] += d; /* VectorAddTensor.h:61-72 */
                     }
@@ -179,13 +234,17 @@ int gfo_smp_molecule(int V, int FD, int L, int C, int cap, const double *x, cons
         for (int v = V - 1; v >= 0; --v) {
             port_node *n = &ND(0, v);
             double dz0[1024], *dzp = C <= 1024 ? dz0 : zalloc(C);
-            for (int c = 0; c < C; ++c) dzp[c] = n->df[c] * (n->f[c] > 0 ? 1.0 : ALPHA);
+            for (int c = 0; c < C; ++c) dzp[c] = n->df[c] * SLOPE(0, v, n, c);
             double *dx = zalloc(FD);
             gfo_matmul_backward(dzp, H, x + (size_t)v * FD, dH, dx, C, FD, 1);
             free(dx);
             if (dzp != dz0) free(dzp);
         }
     }
+    if (n_override) *n_override = overrides;
+    if (n_conflict) *n_conflict = conflicts;
+    free(node_off);
+    free(zmax);
     free(sh);
     free(g);
     for (int l = 0; l <= L; ++l)

@@ -109,13 +109,38 @@ def _headline():
     return c, cfg, params, activation_digest
 
 
+# LeakyReLU's kink.  At this size a level holds 2.4e5 pre-activations spread over +-3.6e3, and a handful of them (4 at level 3
+# of the fixture, |z| = 7e-5 = 2e-8 of the level's largest) lie closer to 0 than fp32 can resolve the sum that produced them
+# (the forward itself agrees with fp64 to 8e-7 of the level's largest value).  An fp32 implementation -- any summation order --
+# lands such an element on either side of 0 and takes the other slope, 1 vs 0.01: either is a valid subgradient at the kink,
+# but the two parameter gradients differ by a visible 1e-4..1e-3 of the largest gradient.  So the gradient is held to 1e-5
+# against the fp64 C port (bit-identical to the real reference on this fixture, tests/test_smp_cpu.py) evaluated with the
+# slope the device saw at elements within KINK_TOL of the kink and ITS OWN slope everywhere else; a device sign that differs
+# from fp64 outside that tolerance is a forward error and fails the test (n_conflict).  Against the real reference's own
+# gradient (fp64's choice at every kink) the bound is the kink-limited KINK_GRAD.
+KINK_TOL, KINK_GRAD = 4e-6, 2e-3
+
+
+def kink_aware_reference(c, params, cfg, net, mol):
+    from oracle import pyoracle
+    L, C, D, cap = cfg
+    V = len(c["adj"])
+    signs = [[net.activation(mol, l, v) for v in range(V)] for l in range(L + 1)]
+    o = pyoracle.port_smp_molecule(c["adj"], c["feature"], float(c["target"][0]), params, L, C, D, cap, True, ext_sign=signs,
+                                   kink_tol=KINK_TOL)
+    assert o["n_conflict"] == 0, "%d activations have the wrong sign outside the kink tolerance" % o["n_conflict"]
+    assert o["n_override"] <= 1e-4 * o["n_elements"], (o["n_override"], o["n_elements"])
+    return o
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_headline_shape_against_the_real_reference(gf, fused):
     """BASELINE configs[2]'s own shape pinned to the REAL reference (tests/golden/smp_headline.npz, generated by
     tests/golden/make_golden.py from GraphFlow/SMP_omega.h:584-693): a 29-atom molecule at L = 3, cap 29, C = 64, F = 5, D = 5
     (fields up to 20: the s <= 32 size classes of tables-forward, the 16-accumulator class of the folded gather, ragged 32-row
     panels).  Receptive fields, reduced adjacencies, every level's activations (digests for all vertices, full tensors for
-    levels 0-1 and four picked nodes of levels 2-3), Feature(), predict, loss and all 223,360 parameter gradients."""
+    levels 0-1 and four picked nodes of levels 2-3), Feature(), predict, loss to 1e-5 of the real reference; all 223,360
+    parameter gradients to 1e-5 of the fp64 port with the device's slope at the LeakyReLU kinks (see KINK_TOL above)."""
     c, (L, C, D, cap), params, digest = _headline()
     F = c["feature"].shape[1]
     pred, loss, feat, grads, net = run_batch(gf, [(c["adj"], c["feature"])], c["target"], params, L, C, F, D, cap, True, fused=fused)
@@ -135,18 +160,21 @@ def test_headline_shape_against_the_real_reference(gf, fused):
         worst_act = max(worst_act, rel_err(got, c["act_level%d" % l].astype(np.float64)))
     for l, v in c["act_picks"]:
         worst_act = max(worst_act, rel_err(net.activation(0, int(l), int(v)).astype(np.float64), c["act_l%d_v%d" % (l, v)].astype(np.float64)))
+    o = kink_aware_reference(c, params, (L, C, D, cap), net, 0)
     e = dict(act=worst_act, feat=rel_err(feat[0], c["graph_feature"]), pred=rel_err(pred, c["predict"]), loss=rel_err(loss, c["loss"]),
-             grads=rel_err(grads, c["grads"].astype(np.float64)))
+             grads=rel_err(grads, o["grads"]), grads_vs_fp64_kinks=rel_err(grads, c["grads"].astype(np.float64)))
     note("headline_fused" if fused else "headline_unfused", **e)
-    print("headline shape (%s): max rel err %s" % ("fused" if fused else "op-by-op", {k: "%.2e" % v for k, v in e.items()}))
+    print("headline shape (%s): max rel err %s; %d of %d slopes taken from the device at the kink" %
+          ("fused" if fused else "op-by-op", {k: "%.2e" % v for k, v in e.items()}, o["n_override"], o["n_elements"]))
     assert e["act"] <= TOL_FWD and e["feat"] <= TOL_FWD and e["pred"] <= TOL_FWD and e["loss"] <= 2 * TOL_FWD
     assert e["grads"] <= TOL_GRAD
+    assert e["grads_vs_fp64_kinks"] <= KINK_GRAD
 
 
 def test_headline_molecule_inside_a_batch(gf):
     """The same molecule at position 17 of a 64-molecule batch (its nodes interleaved with the others' in every size class):
-    same Feature / predict / activations as alone, and the batch gradient = this molecule's golden gradient + the gradient of
-    the other 63 run without it."""
+    same Feature / predict / activations as alone, and the batch gradient minus the gradient of the other 63 run without it
+    = this molecule's gradient (fp64 port, device slopes at the kinks)."""
     c, (L, C, D, cap), params, digest = _headline()
     F = c["feature"].shape[1]
     others, tg = [], []
@@ -160,9 +188,13 @@ def test_headline_molecule_inside_a_batch(gf):
     l, v = (int(x) for x in c["act_picks"][2])
     e = dict(feat=rel_err(feat[17], c["graph_feature"]), pred=rel_err(pred[17:18], c["predict"]),
              act=rel_err(net.activation(17, l, v).astype(np.float64), c["act_l%d_v%d" % (l, v)].astype(np.float64)))
-    g_others = run_batch(gf, others, np.array(tg), params, L, C, F, D, cap)[3]
-    e["grads"] = rel_err(grads - g_others, c["grads"].astype(np.float64))
+    o = kink_aware_reference(c, params, (L, C, D, cap), net, 17)
+    p_o, _, f_o, g_others, _ = run_batch(gf, others, np.array(tg), params, L, C, F, D, cap)
+    # a molecule's forward does not depend on its batch mates: the other 63 took the same slopes in both runs
+    assert np.array_equal(np.delete(pred, 17), p_o) and np.array_equal(np.delete(feat, 17, axis=0), f_o)
+    e["grads"] = rel_err(grads - g_others, o["grads"])
     note("headline_in_batch", **e)
+    print("headline molecule inside a batch: %s" % {k: "%.2e" % x for k, x in e.items()})
     assert e["feat"] <= TOL_FWD and e["pred"] <= TOL_FWD and e["act"] <= TOL_FWD
     assert e["grads"] <= 2 * TOL_GRAD   # a difference of two fp32 batch sums, each within TOL_GRAD of its own truth
 
