@@ -28,6 +28,7 @@ struct GemmArgs {
     int lda, ldb, ldc;
     long long sA, sB, sC;  // batch strides (elements)
     int kchunk;            // K range per split (multiple of BK); splits = gridDim.z / batch
+    int nsplits;           // free-form grouped launches: this group's own split count (partial images split_stride apart)
     int batch;
     int ntiles_n;
     int accumulate;        // C += result (only when not splitting)
@@ -347,6 +348,30 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_f32_mfma_grouped(GroupedArgs
         gemm_tile<TA, TB, VEC>(ga.g[grp], smem, panel * BM, q * BN, 0, 0, 1);
 }
 
+// Free-form grouped launch: up to kMaxGroups GEMMs of UNRELATED shapes in one grid (the small per-(node,x) / per-node /
+// compact products of a fused SMP level: a few tiles each, latency-bound alone, concurrent here).  tile_prefix[i] = first
+// tile of group i in the grid.  !TA: a group's tiles are its (M tile, N tile) pairs, C written directly.  TA (reductions
+// over the rows): tiles are (split, M tile, N tile) with the group's own split count; partial images go to g.C + split *
+// split_stride and are folded by the caller in a fixed order.
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(kThreads, 4) void gemm_f32_mfma_free(GroupedArgs ga) {
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
+    const int tile = (int)blockIdx.x;
+    int grp = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroups; ++i)
+        if (i < ga.ngroups && tile >= ga.tile_prefix[i]) grp = i;
+    const GemmArgs &g = ga.g[grp];
+    int q = tile - ga.tile_prefix[grp];
+    const int ntn = g.ntiles_n, mt = (g.M + BM - 1) / BM;
+    const int n0 = (q % ntn) * BN;
+    q /= ntn;
+    if (TA)
+        gemm_tile<TA, TB, VEC>(g, smem, (q % mt) * BM, n0, 0, q / mt, 2);  // (2: "write a partial image", even for one split)
+    else
+        gemm_tile<TA, TB, VEC>(g, smem, q * BM, n0, 0, 0, 1);
+}
+
 // dst[c][i] = sum of part[s][i] over the c-th chunk of splits (chunk = ceil(splits / gridDim.y)); with gridDim.y == 1 and
 // accumulate it is the final  C[i] (+)= sum_s part[s][i].  Two passes of this kernel fold thousands of split-K partials
 // with full-chip parallelism and a fixed summation order (chunks in order, splits in order inside a chunk).
@@ -471,7 +496,7 @@ static bool spec_vec_ok(const GemmSpec &s, bool ta, bool tb) {
 static void fill_args(GemmArgs *g, const GemmSpec &s) {
     g->A = s.A; g->B = s.B; g->C = s.C; g->M = s.M; g->N = s.N; g->K = s.K; g->lda = s.lda; g->ldb = s.ldb; g->ldc = s.ldc;
     g->sA = g->sB = g->sC = 0; g->batch = 1; g->accumulate = 0; g->kchunk = s.K > 0 ? (s.K + BK - 1) / BK * BK : BK;
-    g->ntiles_n = (s.N + BN - 1) / BN; g->split_stride = 0; g->nseg = s.nseg;
+    g->ntiles_n = (s.N + BN - 1) / BN; g->split_stride = 0; g->nseg = s.nseg; g->nsplits = 1;
     for (int i = 0; i < 4; ++i) {
         g->a_off[i] = s.a_off[i];
         g->b_off[i] = s.b_off[i];
@@ -569,6 +594,83 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
     } else {
         GF_LAUNCH(ctx, "splitk_reduce", splitk_reduce, dim3(gx1, 1), dim3(256), 0, part, dest, total, splits, splits, accumulate);
     }
+    return GF_OK;
+}
+
+// n <= kMaxGroups unrelated products op(A_i)[M_i,K_i] B_i -> C_i in one launch (NN or NT; C written, not accumulated).
+gf_status gemm_grouped_free(gf_ctx *ctx, bool tb, const GemmSpec *specs, int n, const char *name) {
+    if (n < 1 || n > kMaxGroups) return fail(ctx, GF_ERR_INVALID, "gemm_grouped_free: %d groups", n);
+    GroupedArgs ga;
+    ga.ngroups = 0;
+    ga.panel_is_split = 0;
+    ga.npanels = 0;
+    ga.window = 1;
+    ga.tiles_per_panel = 0;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (specs[i].M <= 0 || specs[i].N <= 0) continue;
+        if (!spec_vec_ok(specs[i], false, tb) || specs[i].nseg != 0)
+            return fail(ctx, GF_ERR_UNSUPPORTED, "gemm_grouped_free: group %d is not 16-byte aligned / a multiple of 4", i);
+        const int k = ga.ngroups++;
+        fill_args(&ga.g[k], specs[i]);
+        ga.g[k].nsplits = 1;
+        ga.tile_prefix[k] = tiles;
+        tiles += ((specs[i].M + BM - 1) / BM) * ((specs[i].N + BN - 1) / BN);
+    }
+    for (int i = ga.ngroups; i < kMaxGroups; ++i) ga.tile_prefix[i] = 1 << 30;
+    if (tiles == 0) return GF_OK;
+    if (tb)
+        GF_LAUNCH(ctx, name, (gemm_f32_mfma_free<false, true, true>), dim3((unsigned)tiles), dim3(kThreads), 0, ga);
+    else
+        GF_LAUNCH(ctx, name, (gemm_f32_mfma_free<false, false, true>), dim3((unsigned)tiles), dim3(kThreads), 0, ga);
+    return GF_OK;
+}
+
+// n <= kMaxGroups unrelated reductions A_i^T B_i (A_i [K_i, M_i], B_i [K_i, N_i]) in one launch, each split over its OWN rows
+// into partial images laid out from `part` on: group i at out[i].part, out[i].splits images of out[i].n floats, back to back.
+// The split count of a group depends on its row count only (results reproducible).  The caller folds the images in order.
+gf_status gemm_grouped_free_tn(gf_ctx *ctx, const GemmSpec *specs, int n, float *part, size_t part_floats, FoldGroup *out,
+                               const char *name) {
+    if (n < 1 || n > kMaxGroups) return fail(ctx, GF_ERR_INVALID, "gemm_grouped_free_tn: %d groups", n);
+    GroupedArgs ga;
+    ga.ngroups = 0;
+    ga.panel_is_split = 1;
+    ga.npanels = 0;
+    ga.window = 1;
+    ga.tiles_per_panel = 0;
+    int tiles = 0;
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        const GemmSpec &sp = specs[i];
+        out[i].part = part + off;
+        out[i].n = (size_t)sp.M * sp.N;
+        out[i].splits = 0;
+        if (sp.M <= 0 || sp.N <= 0) continue;
+        if (!spec_vec_ok(sp, true, false) || sp.nseg != 0)
+            return fail(ctx, GF_ERR_UNSUPPORTED, "gemm_grouped_free_tn: group %d is not 16-byte aligned / a multiple of 4", i);
+        // at least four k-steps per workgroup, at most 64 partial images (one-pass ordered fold)
+        int splits = sp.K / (4 * BK);
+        if (splits > 64) splits = 64;
+        if (splits < 1) splits = 1;
+        int kchunk = ((sp.K + splits - 1) / splits + BK - 1) / BK * BK;
+        if (kchunk < BK) kchunk = BK;
+        splits = sp.K > 0 ? (sp.K + kchunk - 1) / kchunk : 1;
+        const int k = ga.ngroups++;
+        fill_args(&ga.g[k], sp);
+        ga.g[k].kchunk = kchunk;
+        ga.g[k].nsplits = splits;
+        ga.g[k].C = part + off;
+        ga.g[k].ldc = sp.N;
+        ga.g[k].split_stride = (long long)out[i].n;
+        ga.tile_prefix[k] = tiles;
+        tiles += splits * ((sp.M + BM - 1) / BM) * ((sp.N + BN - 1) / BN);
+        out[i].splits = splits;
+        off += (size_t)splits * out[i].n;
+    }
+    if (off > part_floats) return fail(ctx, GF_ERR_NOMEM, "gemm_grouped_free_tn: %zu floats of partial images, %zu available", off, part_floats);
+    for (int i = ga.ngroups; i < kMaxGroups; ++i) ga.tile_prefix[i] = 1 << 30;
+    if (tiles == 0) return GF_OK;
+    GF_LAUNCH(ctx, name, (gemm_f32_mfma_free<true, false, true>), dim3((unsigned)tiles), dim3(kThreads), 0, ga);
     return GF_OK;
 }
 

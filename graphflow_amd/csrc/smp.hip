@@ -960,6 +960,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     long long maxpairs = 0;
     for (int l = 0; l <= L; ++l) maxpairs = std::max(maxpairs, (long long)B.level[l].pairs);
     s->colpart_rows = (size_t)((maxrows + 1023) / 1024 + (maxpairs + 255) / 256 + 2);
+    s->colpart_rows = std::max(s->colpart_rows, (size_t)256 * (L + 1));  // fused levels: up to 256 column partials per level
     st = gf::upload(s, &s->colpart, nullptr, s->colpart_rows * C);
     if (st != GF_OK) return st;
 #undef UP
@@ -1005,6 +1006,10 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)nV * C)), dim3(256), 0, s->lv[0].f,
               (const float *)nullptr, C, (size_t)nV * C);
+    if (s->fused) {
+        st = gf::smp_fused_stack_all(s, K);
+        if (st != GF_OK) return st;
+    }
     for (int l = 1; l <= L; ++l) {
         const gfsmp::LevelLayout &h = B.level[l];
         const gf_smp::DevLevel &d = s->lv[l];

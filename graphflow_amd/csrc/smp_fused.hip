@@ -146,8 +146,20 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
     f4 bufA[NI], bufB[NI], dA, dB;
     float *const tcol = T + (rowbase + b) * (size_t)(T_COLS * C) + f + ((cg & 1) ? T_T6 : T_SAB) * C;  // (+ a N ldt per row)
     const size_t tstep = (size_t)N * (T_COLS * C);
-    auto row_step = [&](int a, const f4(&cur)[NI], const f4 &dcur, f4(&nxt)[NI], f4 &dnxt) {
-        load_row(a + 1 < N ? a + 1 : a, nxt, dnxt);
+    // Rows (a, b) whose source does not contain vertex b (pi_a(b) < 0) are structurally zero -- about 40 % of them at QM9
+    // sizes: they are never loaded or summed, only their two table entries are written as zeros.  `present` is wave-uniform
+    // (b is the wave's, a the loop's): bit a = row a has data.  The row of the node's own vertex (a == b) always has.
+    unsigned present = (unsigned)__ballot(lane < N && sPi[lane * N + b] >= 0);
+    present = __builtin_amdgcn_readfirstlane(present);
+    if (allok) {
+        for (unsigned z = ~present & (N >= 32 ? 0xffffffffu : ((1u << N) - 1u)); z; z &= z - 1)
+            st4(tcol + (__builtin_ctz(z)) * tstep, splat(0.f));
+    } else if (fok && cg < 2) {
+        for (unsigned z = ~present & (N >= 32 ? 0xffffffffu : ((1u << N) - 1u)); z; z &= z - 1)
+            st4(T + (rowbase + (size_t)__builtin_ctz(z) * N + b) * (size_t)(T_COLS * C) + f + (cg ? T_T6 : T_SAB) * C, splat(0.f));
+    }
+    auto row_step = [&](int a, int an, const f4(&cur)[NI], const f4 &dcur, f4(&nxt)[NI], f4 &dnxt) {
+        load_row(an >= 0 ? an : a, nxt, dnxt);
         const float ra = sR[a];
         f4 sab = splat(0.f), t6 = splat(0.f);
 #pragma unroll
@@ -181,10 +193,25 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
             }
         }
     };
-    load_row(0, bufA, dA);
-    for (int a = 0; a < N; a += 2) {
-        row_step(a, bufA, dA, bufB, dB);
-        if (a + 1 < N) row_step(a + 1, bufB, dB, bufA, dA);
+    {
+        auto pop = [&]() {  // next present row, or -1
+            if (!present) return -1;
+            const int a = __builtin_ctz(present);
+            present &= present - 1;
+            return a;
+        };
+        int a = pop();
+        load_row(a, bufA, dA);
+        for (;;) {
+            int an = pop();
+            row_step(a, an, bufA, dA, bufB, dB);
+            if (an < 0) break;
+            a = an;
+            an = pop();
+            row_step(a, an, bufB, dB, bufA, dA);
+            if (an < 0) break;
+            a = an;
+        }
     }
     f4 cs = splat(0.f);
 #pragma unroll
@@ -331,6 +358,103 @@ __global__ void unstack_weight_grads(const float *__restrict__ dstacked, float *
     const int CC = C * C;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 18 * CC; i += gridDim.x * blockDim.x)
         dK[weight_index(c_kperm[i / CC], i % CC, C, custom)] += dstacked[i];
+}
+
+// every level's stacked copy in one launch (the parameters are fixed for the whole forward pass)
+constexpr int kStackLevels = 8;
+struct StackAll {
+    const float *K[kStackLevels];
+    float *stacked[kStackLevels];
+    int n;
+};
+__global__ void stack_weights_all(StackAll a, int C, int custom) {
+    const int CC = C * C;
+    const float *K = a.K[blockIdx.y];
+    float *st = a.stacked[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 18 * CC; i += gridDim.x * blockDim.x)
+        st[i] = K[weight_index(c_kperm[i / CC], i % CC, C, custom)];
+}
+
+// One pass over the per-(node,x) partials of combine-backward for a block of nodes [n0, n1):
+//   dSout[n] = sum_x dSpart[(n,x)]                       (was smp_node_sum)
+//   colpart[block] = sum over the block's pairs of dbpart    (was colsum_chunks; folded in order by smp_fold_level)
+// 256 threads = row groups x C/4 float4 lanes (C % 4 == 0, C <= 1024); the groups are folded through LDS in a fixed order.
+__global__ __launch_bounds__(256) void smp_reduce_pairs(const float *__restrict__ dSpart, const float *__restrict__ dbpart,
+                                                        float *__restrict__ dSout, float *__restrict__ colpart,
+                                                        const int *__restrict__ node_s, const long long *__restrict__ node_pair,
+                                                        int C, int nodes, int nodes_per_block) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    const int n0 = blockIdx.x * nodes_per_block, n1 = (n0 + nodes_per_block < nodes) ? n0 + nodes_per_block : nodes;
+    const int nl = C / 4, ng = 256 / nl;
+    const int g = threadIdx.x / nl, fl = threadIdx.x % nl;
+    const auto one = [](int) { return 1.f; };
+    if (g < ng) {
+        for (int n = n0 + g; n < n1; n += ng)
+            st4(dSout + (size_t)n * C + 4 * fl, batched_sum(dSpart + (size_t)node_pair[n] * C + 4 * fl, (size_t)C, 0, node_s[n], one));
+        const long long p0 = node_pair[n0], p1 = (n1 < nodes) ? node_pair[n1] : node_pair[n1 - 1] + node_s[n1 - 1];
+        const int cnt = (int)((p1 - p0 - g + ng - 1) / ng);
+        st4(red + g * C + 4 * fl, batched_sum(dbpart + ((size_t)p0 + g) * C + 4 * fl, (size_t)ng * C, 0, cnt > 0 ? cnt : 0, one));
+    }
+    __syncthreads();
+    if (g == 0) {
+        f4 t = ld4(red + 4 * fl);
+        for (int k = 1; k < ng; ++k) t += ld4(red + k * C + 4 * fl);
+        st4(colpart + (size_t)blockIdx.x * C + 4 * fl, t);
+    }
+}
+
+// End of a level's reverse sweep: every partial image of its weight and bias gradients folded in ONE launch, in a fixed
+// order, straight into the caller's gradient buffers:
+//   stacked positions [0,8)  <- the row-range images of smp_wgrad_c64          (n = 8 C^2)
+//   [8,9), [9,10)            <- dK15, dK16 on the compact rows                  (n = C^2 each)
+//   [10,14), [14,18)         <- the per-(node,x) and per-node products          (n = 4 C^2 each)
+//   bias                     <- the column partials of smp_reduce_pairs         (n = C)
+// dK_l[weight_index(kperm[p], .)] += sum (the un-stacking permutation of unstack_weight_grads), db_l += sum.
+// 256 threads = 64 outputs x 4 split quarters: a quarter sums its run of images in order (8 loads in flight), the four
+// quarters are then added in order through LDS -- the summation tree depends on the image count only.
+constexpr int kFoldGroups = 6;
+struct FoldArgs {
+    const float *part[kFoldGroups];
+    int splits[kFoldGroups];
+    unsigned n[kFoldGroups], first[kFoldGroups];  // outputs [first, first + n) of the stacked index space (bias at 18 C^2)
+    int ngroups;
+};
+__global__ __launch_bounds__(256) void smp_fold_level(FoldArgs a, float *__restrict__ dK, float *__restrict__ db, int C, int custom,
+                                                      unsigned total) {
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, qtr = threadIdx.x >> 6;
+    const unsigned i = blockIdx.x * 64u + e;
+    float acc = 0.f;
+    if (i < total) {
+        int g = 0;
+#pragma unroll
+        for (int k = 1; k < kFoldGroups; ++k)
+            if (k < a.ngroups && i >= a.first[k]) g = k;
+        const unsigned j = i - a.first[g];
+        if (j < a.n[g]) {
+            const int S = a.splits[g], per = (S + 3) / 4;
+            const int s0 = qtr * per, s1 = (s0 + per < S) ? s0 + per : S;
+            const float *p = a.part[g] + j;
+            const size_t stride = a.n[g];
+            for (int sb = s0; sb < s1; sb += 8) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (sb + k < s1) ? p[(size_t)(sb + k) * stride] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += v[k];
+            }
+        }
+    }
+    red[qtr][e] = acc;
+    __syncthreads();
+    if (qtr == 0 && i < total) {
+        const float v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        const unsigned CC = (unsigned)C * C;
+        if (i < 18 * CC)
+            dK[weight_index(c_kperm[i / CC], (int)(i % CC), C, custom)] += v;
+        else
+            db[i - 18 * CC] += v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -869,6 +993,28 @@ gf_status launch_bwd_gather(gf_smp *s, int l, int w0, int w1, const float *dT) {
 }
 }  // namespace
 
+bool smp_grouped_small(const gf_smp *s);
+gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *dbl);
+
+// every level's block-permuted weight copy in one launch (gf_smp_forward, before the first level)
+gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K) {
+    if (!smp_grouped_small(s)) return GF_OK;
+    const int L = s->cfg.nLevels, C = s->cfg.nChanels;
+    for (int l0 = 1; l0 <= L; l0 += kStackLevels) {
+        StackAll a;
+        a.n = 0;
+        for (int l = l0; l <= L && a.n < kStackLevels; ++l) {
+            if (!(s->fused && smp_fused_supported(s, l))) continue;
+            a.K[a.n] = K[l];
+            a.stacked[a.n] = s->lv[l].Wst;
+            ++a.n;
+        }
+        if (a.n > 0)
+            GF_LAUNCH(s->ctx, "smpf_stack_w", stack_weights_all, dim3(64, a.n), dim3(256), 0, a, C, s->cfg.custom_matmul);
+    }
+    return GF_OK;
+}
+
 bool smp_fused_supported(const gf_smp *s, int l) {
     const int C = s->cfg.nChanels;
     if (C % 4 != 0 || C > 1024) return false;
@@ -897,7 +1043,8 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         }
         if (st != GF_OK) return st;
     }
-    GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C, s->cfg.custom_matmul);
+    const bool grouped = smp_grouped_small(s);
+    if (!grouped) GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C, s->cfg.custom_matmul);
     {  // Fdc = [f[w][p,p] | f[w][p,c_w]] of the level below (read by smp_vectors and by the compact products)
         const gf_smp::DevLevel &pv = s->lv[l - 1];
         GF_LAUNCH(ctx, "smpf_diag_gather", diag_gather_fwd, dim3(s->lay.level[l - 1].nNodes), dim3(256), 0, pv.f, d.Fdc, pv.node_s,
@@ -913,7 +1060,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             if (on) c->stream = saved;
         }
     } swap = {ctx, ctx->stream, false};
-    if (s->side) {
+    if (s->side && !grouped) {
         GF_HIP_TRY(ctx, hipEventRecord(s->ev_fork, ctx->stream));
         GF_HIP_TRY(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
         ctx->stream = s->side;
@@ -922,10 +1069,23 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(256), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
               d.node_pair, C, d.Fdc, d.pair_src_pair, d.pi);
     const size_t CC = (size_t)C * C;
+    if (grouped) {
+        // V = Vt [K1;K3;K7;K10], S = St [K4;K13;K14;K17], Gc = [Fd K15 | Fc K16]: four small products, ONE launch
+        const int prevPairs = (int)s->lay.level[l - 1].pairs;
+        const GemmSpec sm[4] = {
+            {d.Vt, d.Wst + 10 * CC, d.Vout, pairs, C, 4 * C, 4 * C, C, C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
+            {d.St, d.Wst + 14 * CC, d.Sout, nodes, C, 4 * C, 4 * C, C, C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
+            {d.Fdc, d.Wst + 8 * CC, d.Gc, prevPairs, C, C, 2 * C, C, 2 * C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
+            {d.Fdc + C, d.Wst + 9 * CC, d.Gc + C, prevPairs, C, C, 2 * C, C, 2 * C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
+        };
+        st = gemm_grouped_free(ctx, false, sm, 4, "smpf_small_nn");
+        if (st != GF_OK) return st;
+    } else {
     st = gemm(ctx, false, false, pairs, C, 4 * C, d.Vt, 4 * C, 0, d.Wst + 10 * CC, C, 0, d.Vout, C, 0, 1, 0);
     if (st != GF_OK) return st;
     st = gemm(ctx, false, false, nodes, C, 4 * C, d.St, 4 * C, 0, d.Wst + 14 * CC, C, 0, d.Sout, C, 0, 1, 0);
     if (st != GF_OK) return st;
+    }
     if (swap.on) {
         GF_HIP_TRY(ctx, hipEventRecord(s->ev_join, s->side));
         ctx->stream = swap.saved;
@@ -964,13 +1124,13 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             }
         }
     }
-    {  // Gc = [Fd K15 | Fc K16] on the compact rows of the level below
+    if (!grouped) {  // Gc = [Fd K15 | Fc K16] on the compact rows of the level below
         const int prevPairs = (int)s->lay.level[l - 1].pairs;
         // (one launch, batch of two: operand / weight / output of the second product sit C, C*C, C elements further on)
         st = gemm(ctx, false, false, prevPairs, C, C, d.Fdc, 2 * C, C, d.Wst + 8 * CC, C, (long long)CC, d.Gc, 2 * C, C, 2, 0);
         if (st != GF_OK) return st;
     }
-    if (s->side) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
+    if (s->side && !grouped) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
     {
         const size_t lds = combine_lds<16>(h.buckets.back().s);
         st = opt_in_lds(ctx, smp_combine_fwd<16>, lds);
@@ -978,6 +1138,185 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, O,
                   d.adj, d.Vout, d.Sout, bl, d.f, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C, nwin, d.Gc,
                   d.pair_src_pair, d.pi, d.rsum);
+    }
+    return GF_OK;
+}
+
+// GF_SMP_GROUPED=0 keeps one launch per small product / reduction (the round-1 schedule); read per call for the parity tests
+bool smp_grouped_small(const gf_smp *s) {
+    (void)s;
+    return !env_is("GF_SMP_GROUPED", '0');
+}
+
+// Remainder of a level's reverse sweep after combine-backward, with the small work batched:
+//   smp_reduce_pairs            dSout per node + column partials of the bias gradient          (was 3 launches)
+//   diag_gather_bwd             dGc
+//   ONE NT launch               dFdc = [dG15 K15^T | dG16 K16^T], dVt = dVout [K1;K3;K7;K10]^T, dSt = dSout [K4;..]^T   (was 3)
+//   smp_wgrad_c64               row-range images of the eight row products
+//   ONE TN launch               dK15, dK16, Vt^T dVout, St^T dSout, each split over its own rows    (was 4 + their folds)
+//   smp_fold_level              every image folded, un-stacked and added into dK_l / db_l          (was ~8 launches)
+//   row-panel products          dT
+gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *dbl) {
+    gf_ctx *ctx = s->ctx;
+    const gfsmp::LevelLayout &h = s->lay.level[l];
+    const gf_smp::DevLevel &d = s->lv[l], &pv = s->lv[l - 1];
+    const int C = s->cfg.nChanels;
+    const int rows = (int)h.rows, pairs = (int)h.pairs, nodes = h.nNodes;
+    const int prevNodes = s->lay.level[l - 1].nNodes, prevPairs = (int)s->lay.level[l - 1].pairs;
+    float *T = d.Q, *dO = d.Q + (size_t)h.rows * T_COLS * C, *dT = dO + (size_t)h.rows * O_COLS * C;
+    const size_t CC = (size_t)C * C;
+    const int ldt = T_COLS * C, ldo = O_COLS * C;
+    const GemmSpec none = {nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}};
+    auto spec = [&](const float *A, const float *B, float *Cm, int M, int N, int K, int lda, int ldb, int ldc) {
+        GemmSpec z = none;
+        z.A = A; z.B = B; z.C = Cm; z.M = M; z.N = N; z.K = K; z.lda = lda; z.ldb = ldb; z.ldc = ldc;
+        return z;
+    };
+    gf_status st;
+    const int npb = (nodes + 255) / 256, nb = (nodes + npb - 1) / npb;   // <= 256 column partials per level
+    float *colpart = s->colpart + (size_t)l * 256 * C;
+    GF_LAUNCH(ctx, "smpf_reduce_pairs", smp_reduce_pairs, dim3(nb), dim3(256), 0, d.dSpart, d.dbpart, d.dSout, colpart, d.node_s,
+              d.node_pair, C, nodes, npb);
+    GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(256), 0, dO, d.dGc, pv.node_s, pv.node_pair,
+              d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C);
+    {
+        const GemmSpec nt[4] = {spec(d.dGc, d.Wst + 8 * CC, d.dFdc, prevPairs, C, C, 2 * C, C, 2 * C),
+                                spec(d.dGc + C, d.Wst + 9 * CC, d.dFdc + C, prevPairs, C, C, 2 * C, C, 2 * C),
+                                spec(d.dVout, d.Wst + 10 * CC, d.dVt, pairs, 4 * C, C, C, C, 4 * C),
+                                spec(d.dSout, d.Wst + 14 * CC, d.dSt, nodes, 4 * C, C, C, C, 4 * C)};
+        st = gemm_grouped_free(ctx, true, nt, 4, "smpf_small_nt");
+        if (st != GF_OK) return st;
+    }
+    // weight gradients on the handle's second stream when GF_SMP_OVERLAP=1 (they only share inputs with what follows)
+    struct StreamSwap {
+        gf_ctx *c;
+        hipStream_t saved;
+        bool on;
+        ~StreamSwap() {
+            if (on) c->stream = saved;
+        }
+    } swap = {ctx, ctx->stream, false};
+    if (s->side) {
+        if (s->side_pending) {  // the level above still owns the context's one workspace on the second stream: same stream, ordered
+            s->side_pending = false;
+        }
+        GF_HIP_TRY(ctx, hipEventRecord(s->ev_fork, ctx->stream));
+        GF_HIP_TRY(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
+        ctx->stream = s->side;
+        swap.on = true;
+    }
+    FoldArgs fa;
+    fa.ngroups = 6;
+    float *ws = static_cast<float *>(ctx->ws);
+    size_t ws_floats = ctx->ws_bytes / sizeof(float), used = 0;
+    FoldGroup rowg;
+    const bool stationary = C == 64 && !env_is("GF_SMP_WGRAD", '0');
+    if (stationary) {
+        st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg);
+        if (st != GF_OK) return st;
+        used = (size_t)rowg.splits * rowg.n;
+    } else {  // other channel counts: the grouped split-K launch (its own ordered reduction) into the stacked image, one "image"
+        struct G { int tcol, kb, wpos, ocol, scol; };
+        const G gs[5] = {{T_SAB, 2, 0, O_LOC, 0}, {T_SAB, 1, 2, O_LOC, 1}, {T_T6, 2, 3, O_LOC, -1}, {T_SAB, 2, 5, O_Z, -1}, {T_SAB, 1, 7, O_ZP, -1}};
+        GemmSpec sp[5];
+        for (int i = 0; i < 5; ++i) {
+            sp[i] = spec(T + gs[i].tcol * C, dO + gs[i].ocol * C, d.dWst + gs[i].wpos * CC, gs[i].kb * C, C, rows, ldt, ldo, C);
+            sp[i].rs = gs[i].scol >= 0 ? d.rowscale : nullptr;
+            sp[i].rs_ld = 2;
+            sp[i].scol[0] = gs[i].scol;
+        }
+        if (C <= 64 && gemm_grouped_supported(sp, 5, true, false)) {
+            st = gemm_grouped_splitk(ctx, sp, 5, rows, d.dWst, 0);
+            if (st != GF_OK) return st;
+        } else {
+            for (int i = 0; i < 5; ++i) {
+                st = gemm_rs(ctx, true, false, gs[i].kb * C, C, rows, T + gs[i].tcol * C, ldt, 0, dO + gs[i].ocol * C, ldo, 0,
+                             d.dWst + gs[i].wpos * CC, C, 0, 1, 0, d.rowscale, 2, gs[i].scol);
+                if (st != GF_OK) return st;
+            }
+        }
+        rowg.part = d.dWst;
+        rowg.splits = 1;
+        rowg.n = 8 * CC;
+        // (the split launches above used the workspace from its base; their reductions have been issued, and the launch
+        //  below is ordered behind them on the same stream)
+    }
+    FoldGroup small[4];
+    {
+        const GemmSpec tn[4] = {spec(d.Fdc, d.dGc, nullptr, C, C, prevPairs, 2 * C, 2 * C, C),
+                                spec(d.Fdc + C, d.dGc + C, nullptr, C, C, prevPairs, 2 * C, 2 * C, C),
+                                spec(d.Vt, d.dVout, nullptr, 4 * C, C, pairs, 4 * C, C, C),
+                                spec(d.St, d.dSout, nullptr, 4 * C, C, nodes, 4 * C, C, C)};
+        GemmSpec tnc[4];
+        for (int i = 0; i < 4; ++i) {
+            tnc[i] = tn[i];
+            tnc[i].C = ws + used;  // (alignment check only: the launcher places the images itself)
+        }
+        st = gemm_grouped_free_tn(ctx, tnc, 4, ws + used, ws_floats - used, small, "smpf_small_tn");
+        if (st != GF_OK) return st;
+    }
+    const FoldGroup *grp[6] = {&rowg, &small[0], &small[1], &small[2], &small[3], nullptr};
+    const unsigned firsts[6] = {0u, (unsigned)(8 * CC), (unsigned)(9 * CC), (unsigned)(10 * CC), (unsigned)(14 * CC), (unsigned)(18 * CC)};
+    for (int g = 0; g < 5; ++g) {
+        fa.part[g] = grp[g]->part;
+        fa.splits[g] = grp[g]->splits;
+        fa.n[g] = (unsigned)grp[g]->n;
+        fa.first[g] = firsts[g];
+    }
+    fa.part[5] = colpart;
+    fa.splits[5] = nb;
+    fa.n[5] = (unsigned)C;
+    fa.first[5] = firsts[5];
+    const unsigned total = (unsigned)(18 * CC + C);
+    GF_LAUNCH(ctx, "smpf_fold", smp_fold_level, dim3((total + 63) / 64), dim3(256), 0, fa, dKl, dbl, C, s->cfg.custom_matmul, total);
+    st = smp_dp_level_done(s, l);  // data-parallel: dK_l and db_l are final -- their all-reduce runs beside what follows
+    if (st != GF_OK) return st;
+    if (swap.on) {
+        GF_HIP_TRY(ctx, hipEventRecord(s->ev_join, s->side));
+        ctx->stream = swap.saved;
+        swap.on = false;
+        s->side_pending = true;
+    }
+    // table gradients dT from dO
+    if (C == 64 && !env_is("GF_SMP_ROWPANEL", '0')) {
+        st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows);
+        if (st != GF_OK) return st;
+    } else {
+        const long long oC = C, wCC = (long long)CC;
+        GemmSpec dg[3] = {
+            {dO, d.Wst, dT + T_SAB * C, rows, C, 4 * C, ldo, C, ldt, 4, {O_LOC * oC, O_LOC * oC, O_Z * oC, O_ZP * oC},
+             {0 * wCC, 2 * wCC, 5 * wCC, 7 * wCC}, {C, C, C, C}, d.rowscale, 2, {0, 1, -1, -1}},
+            {dO, d.Wst, dT + T_SBC * C, rows, C, 2 * C, ldo, C, ldt, 2, {O_LOC * oC, O_Z * oC, 0, 0}, {1 * wCC, 6 * wCC, 0, 0}, {C, C, 0, 0},
+             d.rowscale, 2, {0, -1, -1, -1}},
+            {dO, d.Wst, dT + T_T6 * C, rows, 2 * C, C, ldo, C, ldt, 1, {O_LOC * oC, 0, 0, 0}, {3 * wCC, 0, 0, 0}, {C, 0, 0, 0}, nullptr, 0,
+             {-1, -1, -1, -1}},
+        };
+        if (gemm_grouped_supported(dg, 3, false, true)) {
+            st = gemm_grouped_rows(ctx, false, true, dg, 3, rows);
+            if (st != GF_OK) return st;
+        } else {
+            struct H { int ocol, wpos, kb, tcol, acc, scol; };
+            const H hs[6] = {{O_Z, 5, 2, T_SAB, 0, -1}, {O_LOC, 0, 1, T_SAB, 1, 0}, {O_LOC, 1, 1, T_SBC, 1, 0}, {O_LOC, 2, 1, T_SAB, 1, 1},
+                             {O_ZP, 7, 1, T_SAB, 1, -1}, {O_LOC, 3, 2, T_T6, 0, -1}};
+            for (const H &g : hs) {
+                st = gemm_rs(ctx, false, true, rows, g.kb * C, C, dO + g.ocol * C, ldo, 0, d.Wst + g.wpos * CC, C, 0, dT + g.tcol * C, ldt, 0,
+                             1, g.acc, d.rowscale, 2, g.scol);
+                if (st != GF_OK) return st;
+            }
+        }
+    }
+    if (smp_fused_gather_enabled(s, l)) return GF_OK;  // dP is evaluated inside the consumer gather (smp_fused_gather_backward)
+    st = ensure_P(s);
+    if (st != GF_OK) return st;
+    const std::vector<SizeClass> cls = classes_of(h, 4);
+    for (const SizeClass &c : cls) {
+        switch (c.ni) {
+            case 1: st = launch_tables_bwd<1>(s, l, c, dT); break;
+            case 2: st = launch_tables_bwd<2>(s, l, c, dT); break;
+            case 4: st = launch_tables_bwd<4>(s, l, c, dT); break;
+            default: st = launch_tables_bwd<8>(s, l, c, dT); break;
+        }
+        if (st != GF_OK) return st;
     }
     return GF_OK;
 }
@@ -1001,6 +1340,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
                   d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
                   nwin, d.rsum);
     }
+    if (smp_grouped_small(s)) return smp_fused_backward_level_grouped(s, l, dKl, dbl);
     GF_LAUNCH(ctx, "smpf_node_sum", smp_node_sum, dim3(nodes), dim3(64), 0, d.dSpart, d.dSout, d.node_s, d.node_pair, C);
     // bias gradient: column sums of the per-(node,x) partials
     {

@@ -25,6 +25,15 @@ struct GemmSpec {
     int rs_ld;
     int scol[4];      // column of rs per K piece (piece 0 when nseg == 0), < 0 = unscaled piece
 };
+// partial images of one product of a split launch: `splits` images of n floats back to back from `part` on
+struct FoldGroup {
+    const float *part;
+    int splits;
+    size_t n;
+};
+gf_status gemm_grouped_free(gf_ctx *ctx, bool tb, const GemmSpec *specs, int n, const char *name);
+gf_status gemm_grouped_free_tn(gf_ctx *ctx, const GemmSpec *specs, int n, float *part, size_t part_floats, FoldGroup *out,
+                               const char *name);
 bool gemm_grouped_supported(const GemmSpec *specs, int n, bool ta, bool tb);
 gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows);
 gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int rows, float *dest, int accumulate);
@@ -32,6 +41,9 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
                                     int rows);
 gf_status splitk_fold(gf_ctx *ctx, const float *part, float *dest, size_t total, int splits, int accumulate);
 gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst);
+// the same product, partial images only (fold == caller's): `part` receives out->splits images of 8 * 64 * 64 floats
+gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
+                                 size_t part_floats, FoldGroup *out);
 }
 
 struct gf_smp {
@@ -116,6 +128,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
 gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl, const float *node_df);
 gf_status smp_fused_gather_backward(gf_smp *s, int l);
 bool smp_fused_gather_enabled(const gf_smp *s, int l);
+gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status ensure_P(gf_smp *s);
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce
 gf_status smp_dp_level_done(gf_smp *s, int l);

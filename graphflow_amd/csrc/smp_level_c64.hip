@@ -309,9 +309,15 @@ __global__ __launch_bounds__(kRpThreads, 1) void smp_rowpanel_c64(const float *_
 
 }  // namespace
 
-// dWst[0..8) = the eight row block products of a fused SMP level at C = 64 (see smp_wgrad_c64).  T = [rows][256],
-// dO = [rows][192], rowscale = [rows][2].  The row range per workgroup depends on `rows` only: results are reproducible.
-gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst) {
+// The eight row block products A_p^T B_p of a fused SMP level at C = 64 (see smp_wgrad_c64) as PARTIAL images: one image of
+// 8 x 64 x 64 floats per row range.  T = [rows][256], dO = [rows][192], rowscale = [rows][2].  The row range per workgroup
+// depends on `rows` only: results are reproducible.  The caller folds the images in order.
+gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
+                                 size_t part_floats, FoldGroup *out) {
+    const size_t total = 8 * 4096;
+    out->part = part;
+    out->n = total;
+    out->splits = 0;
     if (rows < 1) return GF_OK;
     // one workgroup fits a CU (two LDS stages): aim at `target` row ranges, at least 8 slices each
     int target = 256;
@@ -319,16 +325,32 @@ gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO,
     int kchunk = ((rows + target - 1) / target + BK - 1) / BK * BK;
     if (kchunk < 8 * BK) kchunk = 8 * BK;
     const int splits = (rows + kchunk - 1) / kchunk;
-    const size_t total = 8 * 4096;
-    const int chunk = 32, nchunks = (splits + chunk - 1) / chunk;
-    gf_status st = ensure_ws(ctx, sizeof(float) * ((size_t)splits + nchunks) * total + 256);
-    if (st != GF_OK) return st;
-    float *part = static_cast<float *>(ctx->ws);
+    if ((size_t)splits * total > part_floats)
+        return fail(ctx, GF_ERR_NOMEM, "smp_wgrad_partials_c64: %d partial images, room for %zu", splits, part_floats / total);
     const size_t lds = sizeof(float) * 2 * (size_t)kWgStage;
-    st = opt_in_lds(ctx, smp_wgrad_c64, lds);
+    gf_status st = opt_in_lds(ctx, smp_wgrad_c64, lds);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part);
-    return splitk_fold(ctx, part, dWst, total, splits, 0);
+    out->splits = splits;
+    return GF_OK;
+}
+
+// the same, folded into dWst[0..8) by the two-pass ordered reduction (kept for GF_SMP_GROUPED=0)
+gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst) {
+    if (rows < 1) return GF_OK;
+    const size_t total = 8 * 4096;
+    int target = 256;
+    if (const char *e = std::getenv("GF_WGRAD_SPLITS")) target = std::max(1, std::atoi(e));
+    int kchunk = ((rows + target - 1) / target + BK - 1) / BK * BK;
+    if (kchunk < 8 * BK) kchunk = 8 * BK;
+    const int splits = (rows + kchunk - 1) / kchunk;
+    const int nchunks = (splits + 31) / 32;
+    gf_status st = ensure_ws(ctx, sizeof(float) * ((size_t)splits + nchunks) * total + 256);
+    if (st != GF_OK) return st;
+    FoldGroup fg;
+    st = smp_wgrad_partials_c64(ctx, T, dO, rowscale, rows, static_cast<float *>(ctx->ws), (size_t)splits * total, &fg);
+    if (st != GF_OK) return st;
+    return splitk_fold(ctx, fg.part, dWst, total, fg.splits, 0);
 }
 
 // Row-panel products of a fused SMP level at C = 64 (see smp_rowpanel_c64): forward O from T, or backward dT from dO.

@@ -299,6 +299,25 @@ def test_c64_level_kernels_equal_the_tiled_gemm_path(gf, monkeypatch):
     assert rel_err(g1, g0) <= 2e-5
 
 
+@pytest.mark.parametrize("C", [64, 16])
+def test_batched_small_launches_equal_one_launch_per_product(gf, monkeypatch, C):
+    """The per-(node,x) / per-node / compact products, their split-K folds, the bias and node sums and the weight un-stacking
+    run as a few batched launches per level (default) or one launch each (GF_SMP_GROUPED=0, the round-1 schedule): same
+    products, the reductions over rows split differently."""
+    F, D, L, cap = 5, 3, 3, 29
+    mols, tg = [], []
+    for seed in range(33):
+        adj, feat, t = synthetic_molecule(1700 + seed)
+        mols.append((adj, feat))
+        tg.append(t)
+    params = smp_params(C, F, D, L, 6)
+    p1, _, f1, g1, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    monkeypatch.setenv("GF_SMP_GROUPED", "0")
+    p0, _, f0, g0, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    assert np.array_equal(p1, p0) and np.array_equal(f1, f0)   # forward: the same tiles, launched together
+    assert rel_err(g1, g0) <= 2e-6
+
+
 def test_two_handles_alternate_without_waiting_for_each_other(gf):
     """A training loop prepares batch i+1 on a second handle while the device runs step i on the first (uploads on the
     handle's own stream; recycling a handle's buffers waits for ITS last launch only).  Same gradients as one handle that
