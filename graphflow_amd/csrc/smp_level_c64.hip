@@ -169,10 +169,12 @@ __global__ __launch_bounds__(kWgThreads, 1) void smp_wgrad_c64(const float *__re
 // both operands -- and runs all sixteen 32 x 32 x 64 products of the panel (512 MFMAs) out of registers and LDS, one output
 // block (two accumulators) at a time.  No operand staging, no barriers, sixteen independent waves per CU.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kRpThreads = 1024, kRpWRow = 36;
+constexpr int kRpWRow = 36;
 
-template <bool FWD>
-__global__ __launch_bounds__(kRpThreads, 1) void smp_rowpanel_c64(const float *__restrict__ A, const float *__restrict__ rs,
+// TH = threads per workgroup: 1024 (four waves per SIMD, 128 registers each) or 512 (two waves per SIMD, 256 registers: no
+// spills, at half the latency-hiding waves)
+template <bool FWD, int TH>
+__global__ __launch_bounds__(TH, 1) void smp_rowpanel_c64(const float *__restrict__ A, const float *__restrict__ rs,
                                                                   const float *__restrict__ Wst, float *__restrict__ Out, int rows) {
     constexpr int LDA = FWD ? 256 : 192, LDOUT = FWD ? 192 : 256;
     extern __shared__ __attribute__((aligned(16))) float rp_smem[];  // [8 pos][2 column halves][2 k halves][32 lanes][36]
@@ -180,14 +182,14 @@ __global__ __launch_bounds__(kRpThreads, 1) void smp_rowpanel_c64(const float *_
     const int wave = tid >> 6;
     // B fragment order: row ((pos 2 + nh) 2 + kh) 32 + i holds B[k = 32 kh + j][n = 32 nh + i] for j = 0..31, where
     // B = W_pos (forward: W[k][n]) or W_pos^T (backward: W[n][k])
-    for (int e = tid; e < 8 * 4096; e += kRpThreads) {
+    for (int e = tid; e < 8 * 4096; e += TH) {
         const int pos = e >> 12, r = (e >> 6) & 63, c = e & 63;  // W_pos[r][c]
         const int k = FWD ? r : c, n = FWD ? c : r;
         rp_smem[((((pos * 2 + (n >> 5)) * 2 + (k >> 5)) * 32) + (n & 31)) * kRpWRow + (k & 31)] = Wst[e];
     }
     __syncthreads();
     const int npanels = (rows + 31) / 32;
-    const int nwaves = gridDim.x * (kRpThreads / 64);
+    const int nwaves = gridDim.x * (TH / 64);
     const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
     const float *bbase = rp_smem + (lh * 32 + li) * kRpWRow;
 
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(kRpThreads, 1) void smp_rowpanel_c64(const float *_
     // order: vmcnt counts loads and stores together and in order, so a load issued after a store cannot be waited for
     // without waiting for the store as well.  (Alternating the two buffers so that Z' is also requested early costs
     // registers -- 160 B of scratch -- and measured the same.)
-    float2 sc = load_scale(blockIdx.x * (kRpThreads / 64) + wave), scn = make_float2(0.f, 0.f);
+    float2 sc = load_scale(blockIdx.x * (TH / 64) + wave), scn = make_float2(0.f, 0.f);
     auto panel = [&](int p, Blk &X, Blk &Y) {
         const int pn = p + nwaves;
         f16v acc0, acc1;
@@ -301,10 +303,65 @@ __global__ __launch_bounds__(kRpThreads, 1) void smp_rowpanel_c64(const float *_
         }
         sc = scn;
     };
+    // Two waves per SIMD (TH = 512) have 256 registers each: every block of the panel is requested when the panel starts, behind
+    // the first product (64 MFMAs, about 2 us: more than an HBM round trip), and block 0 of the next panel behind the last
+    // one -- no request is ever waited for at once, nothing spills.
+    auto panel_wide = [&](int p, Blk &X, Blk &Y, Blk &W, Blk &V) {
+        const int pn = p + nwaves;
+        f16v acc0, acc1;
+        if (FWD) {
+            load_blk(Y, p, 1);
+            load_blk(W, p, 2);
+            load_blk(V, p, 3);
+            scn = load_scale(pn);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 7, acc0, acc1);
+            store_out(p, 2, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 5, acc0, acc1);
+            prod(Y, false, 1.f, 6, acc0, acc1);
+            store_out(p, 1, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, true, sc.x, 0, acc0, acc1);
+            prod(X, true, sc.y, 2, acc0, acc1);
+            load_blk(X, pn, 0);                      // X <- S_ab of the next panel, three products ahead of its use
+            prod(Y, true, sc.x, 1, acc0, acc1);
+            prod(W, false, 1.f, 3, acc0, acc1);
+            prod(V, false, 1.f, 4, acc0, acc1);
+            store_out(p, 0, acc0, acc1);
+        } else {
+            load_blk(Y, p, 1);
+            load_blk(W, p, 2);
+            scn = load_scale(pn);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 3, acc0, acc1);
+            store_out(p, 2, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 4, acc0, acc1);
+            store_out(p, 3, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, true, sc.x, 1, acc0, acc1);
+            prod(Y, false, 1.f, 6, acc0, acc1);
+            store_out(p, 1, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, true, sc.x, 0, acc0, acc1);
+            prod(X, true, sc.y, 2, acc0, acc1);
+            load_blk(X, pn, 0);                      // X <- L of the next panel, two products ahead of its use
+            prod(Y, false, 1.f, 5, acc0, acc1);
+            prod(W, false, 1.f, 7, acc0, acc1);
+            store_out(p, 0, acc0, acc1);
+        }
+        sc = scn;
+    };
     Blk B0, B1;
-    int p = blockIdx.x * (kRpThreads / 64) + wave;
+    int p = blockIdx.x * (TH / 64) + wave;
     load_blk(B0, p, 0);
-    for (; p < npanels; p += nwaves) panel(p, B0, B1);  // (block 0 of the next panel is back in B0 when a panel ends)
+    if constexpr (TH == 512) {
+        Blk B2, B3;
+        for (; p < npanels; p += nwaves) panel_wide(p, B0, B1, B2, B3);
+    } else {
+        for (; p < npanels; p += nwaves) panel(p, B0, B1);  // (block 0 of the next panel is back in B0 when a panel ends)
+    }
 }
 
 }  // namespace
@@ -366,17 +423,26 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
     }
     const int cus = cu_count[di];
     const size_t lds = sizeof(float) * 8 * 2 * 2 * 32 * (size_t)kRpWRow;
+    // forward: four waves per SIMD (measured equal to two); backward: two waves per SIMD with 256 registers -- the 128-register
+    // build of the backward panel spills 100 B per lane and waits for one block request per panel (1.84 -> 1.66 ms at cfg3)
+    int th = forward ? 1024 : 512;
+    if (const char *e = std::getenv(forward ? "GF_RP_THREADS_FWD" : "GF_RP_THREADS_BWD")) th = std::atoi(e) == 512 ? 512 : 1024;
     {
-        gf_status st = forward ? opt_in_lds(ctx, smp_rowpanel_c64<true>, lds) : opt_in_lds(ctx, smp_rowpanel_c64<false>, lds);
+        gf_status st = forward ? (th == 512 ? opt_in_lds(ctx, smp_rowpanel_c64<true, 512>, lds) : opt_in_lds(ctx, smp_rowpanel_c64<true, 1024>, lds))
+                               : (th == 512 ? opt_in_lds(ctx, smp_rowpanel_c64<false, 512>, lds) : opt_in_lds(ctx, smp_rowpanel_c64<false, 1024>, lds));
         if (st != GF_OK) return st;
     }
-    const int npanels = (rows + 31) / 32, per = kRpThreads / 64;
+    const int npanels = (rows + 31) / 32, per = th / 64;
     const int want = (npanels + per - 1) / per;
     const int grid = want < cus ? want : cus;  // one persistent workgroup per CU (the weight image takes 144 KB of LDS)
-    if (forward)
-        GF_LAUNCH(ctx, "smpf_products_fwd", smp_rowpanel_c64<true>, dim3((unsigned)grid), dim3(kRpThreads), lds, A, rowscale, Wst, Out, rows);
+    if (forward && th == 512)
+        GF_LAUNCH(ctx, "smpf_products_fwd", (smp_rowpanel_c64<true, 512>), dim3((unsigned)grid), dim3(512), lds, A, rowscale, Wst, Out, rows);
+    else if (forward)
+        GF_LAUNCH(ctx, "smpf_products_fwd", (smp_rowpanel_c64<true, 1024>), dim3((unsigned)grid), dim3(1024), lds, A, rowscale, Wst, Out, rows);
+    else if (th == 512)
+        GF_LAUNCH(ctx, "smpf_products_bwd", (smp_rowpanel_c64<false, 512>), dim3((unsigned)grid), dim3(512), lds, A, rowscale, Wst, Out, rows);
     else
-        GF_LAUNCH(ctx, "smpf_products_bwd", smp_rowpanel_c64<false>, dim3((unsigned)grid), dim3(kRpThreads), lds, A, rowscale, Wst, Out, rows);
+        GF_LAUNCH(ctx, "smpf_products_bwd", (smp_rowpanel_c64<false, 1024>), dim3((unsigned)grid), dim3(1024), lds, A, rowscale, Wst, Out, rows);
     return GF_OK;
 }
 
