@@ -85,6 +85,12 @@ PROTOTYPES.update({
     "gf_smp_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gf_smp_backward": (_i, [_vp, _vp, _vp, _i]),
     "gf_smp_set_grad_allreduce": (_i, [_vp, _i]),
+    "gf_smp_feature_width": (C.c_size_t, [_vp]),
+    "gf_smp_backward_features": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "gf_head_param_count": (C.c_size_t, [_i, C.POINTER(C.c_int)]),
+    "gf_head_work_floats": (C.c_size_t, [_i, C.POINTER(C.c_int), _i]),
+    "gf_head_forward_f32": (_i, [_vp, _i, C.POINTER(C.c_int), _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gf_head_backward_f32": (_i, [_vp, _i, C.POINTER(C.c_int), _vp, _i, _vp, _vp, _vp, _vp]),
     "gf_ctx_set_timing_filter": (_i, [_vp, C.c_char_p]),
     "gf_smp_parameters_upload": (_i, [_vp, _fp]),
     "gf_smp_parameters_download": (_i, [_vp, _fp, _fp]),
@@ -104,6 +110,23 @@ PROTOTYPES.update({
     "gf_smp_level_sizes": (_i, [_vp, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "gf_stack_forward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
     "gf_stack_backward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
+})
+
+PROTOTYPES.update({
+    "gf_smp_dropout_masks": (_i, [_vp, _vp, C.c_float]),
+    "gf_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_double, _i, C.c_ulonglong]),
+    "gf_smp_model_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "gf_smp_model_destroy": (_i, [_vp]),
+    "gf_smp_model_param_count": (C.c_size_t, [_vp]),
+    "gf_smp_model_set_mode": (_i, [_vp, _i]),
+    "gf_smp_model_prepare": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gf_smp_model_forward": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "gf_smp_model_backward": (_i, [_vp, _vp, _vp, _i]),
+    "gf_smp_model_uniform_init_host": (_i, [_vp, _fp]),
+    "gf_smp_model_parameters_upload": (_i, [_vp, _fp]),
+    "gf_smp_model_parameters_download": (_i, [_vp, _fp, _fp]),
+    "gf_smp_model_forward_host": (_i, [_vp, _dp, _dp, _dp]),
+    "gf_smp_model_adam_step": (_i, [_vp, C.c_double, _i]),
 })
 
 _lib = None

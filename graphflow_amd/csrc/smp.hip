@@ -402,6 +402,48 @@ __global__ void readout_backward_nodevec(const float *__restrict__ dy, const flo
 
 __global__ void zero_f32(float *p, size_t n) { GRID_STRIDE(i, n) p[i] = 0.f; }
 
+// RisiContraction_18_dropout over the nodes of a level: slice k of node n is multiplied by scale if bit k of keep[n] is set,
+// else zeroed (RisiContraction_18_dropout.h:106-132 forward, :479-510 backward: dropped slices neither produce nor receive)
+__global__ void node_slice_scale(float *__restrict__ Q, const int *__restrict__ node_s, const long long *__restrict__ node_row,
+                                 const unsigned *__restrict__ keep, float scale, int C) {
+    const int n = blockIdx.x;
+    const unsigned m = keep[n];
+    const size_t cnt = (size_t)node_s[n] * node_s[n] * 18 * C;
+    float *q = Q + (size_t)node_row[n] * 18 * C;
+    for (size_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const int k = (int)((i / C) % 18);
+        q[i] = ((m >> k) & 1u) ? q[i] * scale : 0.f;
+    }
+}
+
+// physics towers: level_feature[l] = sum over the molecule's vertices of LeakyReLU(sum_ij f_l[v]) (SMP_omega_physics.h:572-588),
+// written into columns [off, off + C) of the molecule's feature row (ConcatVectors, :590)
+__global__ void level_feature_sum(const float *__restrict__ vf, const int *__restrict__ mol_ptr, const int *__restrict__ node_of_vertex,
+                                  float *__restrict__ feat, int C, int width, int off) {
+    const int m = blockIdx.x;
+    for (int f = threadIdx.x; f < C; f += blockDim.x) {
+        float acc = 0.f;
+        for (int k = mol_ptr[m]; k < mol_ptr[m + 1]; ++k) acc += vf[(size_t)node_of_vertex[k] * C + f];
+        feat[(size_t)m * width + off + f] = acc;
+    }
+}
+
+// reverse: df_l[n][i][j][:] (+)= dfeat[mol(n)][off + :] * lrelu'(sh_l[n][:])   (SumVectors -> LeakyReLU -> ShrinkTensor::backward)
+__global__ void level_feature_backward(const float *__restrict__ dfeat, const float *__restrict__ sh, const int *__restrict__ node_mol,
+                                       const int *__restrict__ node_s, const long long *__restrict__ node_row, float *__restrict__ df,
+                                       int C, int width, int off, int accumulate) {
+    const int n = blockIdx.x;
+    const int s = node_s[n];
+    float *dst = df + node_row[n] * C;
+    const float *g = dfeat + (size_t)node_mol[n] * width + off;
+    const int total = s * s * C;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int f = i % C;
+        const float v = g[f] * (sh[(size_t)n * C + f] > 0.f ? 1.f : kAlpha);
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+
 size_t param_count(const gfsmp::Config &c);
 static size_t param_count_of(const gf_smp *s) { return param_count(s->cfg); }
 
@@ -505,7 +547,10 @@ struct ParamView {
     std::vector<const float *> K, b;
 };
 size_t param_count(const gfsmp::Config &c) {
-    return (size_t)c.nChanels * c.fdim() + (size_t)c.nLevels * ((size_t)c.nContractions * c.nChanels * c.nChanels + c.nChanels) + c.nChanels;
+    size_t n = (size_t)c.nChanels * c.fdim();
+    for (int l = 1; l <= c.nLevels; ++l)
+        n += (size_t)c.nContractions * c.level_channels(l - 1) * c.level_channels(l) + c.level_channels(l);
+    return n + (c.physics ? 0 : c.nChanels);  // a physics tower ends in its level features: the head's weights are the caller's
 }
 // order H, (K_1, b_1), ..., (K_L, b_L), W -- the registration order of SMP_omega.h:289-295 (= save_model order)
 template <typename P>
@@ -517,9 +562,9 @@ void view_params(const gfsmp::Config &c, P *base, P **H, std::vector<P *> *K, st
     b->assign(c.nLevels + 1, nullptr);
     for (int l = 1; l <= c.nLevels; ++l) {
         (*K)[l] = p;
-        p += (size_t)c.nContractions * c.nChanels * c.nChanels;
+        p += (size_t)c.nContractions * c.level_channels(l - 1) * c.level_channels(l);
         (*b)[l] = p;
-        p += c.nChanels;
+        p += c.level_channels(l);
     }
     *W = p;
 }
@@ -531,7 +576,7 @@ gf_status smp_contract(gf_smp *s, int l, bool backward) {
     gf_ctx *ctx = s->ctx;
     const gfsmp::LevelLayout &h = s->lay.level[l];
     const gf_smp::DevLevel &d = s->lv[l];
-    const int C = s->cfg.nChanels, nK = s->cfg.nContractions;
+    const int C = s->cfg.level_channels(l - 1), nK = s->cfg.nContractions;  // the contraction runs on the level below's channels
     const int ppw = (C <= 16) ? 16 : (C <= 32) ? 8 : 4;
     const gf_ragged_nodes t = {d.pair_node, d.node_s, d.node_p, d.node_row, d.node_pair, (long long)h.rows, (long long)h.pairs};
     gf_status st = ensure_P_impl(s);
@@ -564,6 +609,11 @@ gf_status smp_contract(gf_smp *s, int l, bool backward) {
 }  // namespace
 
 gf_status ensure_P(gf_smp *s) { return ensure_P_impl(s); }
+size_t feature_width(const gfsmp::Config &c) {
+    size_t w = 0;
+    for (int l = 0; l <= c.nLevels; ++l) w += (size_t)c.level_channels(l);
+    return w;
+}
 
 // Data-parallel reverse sweep.  The flat gradient buffer is H | K_1 b_1 | ... | K_L b_L | W; the segment of level l is
 // [K_l | b_l] (plus W for l = L: the readout gradient is the first thing the sweep computes) and H for l = 0.  The segment is
@@ -606,6 +656,11 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
     s->cfg.has_WL_ordering = cfg->has_WL_ordering;
     s->cfg.nContractions = cfg->nContractions ? cfg->nContractions : 18;
     s->cfg.custom_matmul = cfg->custom_matmul ? 1 : 0;
+    s->cfg.physics = cfg->physics ? 1 : 0;
+    if (s->cfg.physics && (s->cfg.nDepth != 0 || s->cfg.nContractions != 18 || s->cfg.custom_matmul)) {
+        delete s;
+        return fail(ctx, GF_ERR_INVALID, "gf_smp_create: a physics tower has nDepth 0 (raw features), RisiContraction_18 and [18 C', C] weights");
+    }
     if (s->cfg.nContractions != 10 && s->cfg.nContractions != 18 && s->cfg.nContractions != 50) {
         const int bad = cfg->nContractions;
         delete s;
@@ -751,6 +806,18 @@ gf_status gf_smp_momentum_step(gf_smp *s, float *params, const float *grads, dou
     return GF_OK;
 }
 
+// Adam::Learn(learning_rate, nBatch) (GraphFlow/Adam.h:106-133) on any flat parameter buffer with caller-owned moments:
+// element i uses the bias-correction powers beta^(elements_before + i + 1) (the reference advances them per element).
+gf_status gf_adam_step_f32(gf_ctx *ctx, float *params, const float *grads, float *m, float *v, size_t n, double learning_rate,
+                           int nBatch, unsigned long long elements_before) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!params || !grads || !m || !v || nBatch <= 0) return fail(ctx, GF_ERR_INVALID, "gf_adam_step_f32: bad argument");
+    if (n == 0) return GF_OK;
+    GF_LAUNCH(ctx, "smp_adam", gf::adam_step, dim3(gf::grid_for(n)), dim3(256), 0, params, grads, m, v, n, learning_rate,
+              1.0 / (double)nBatch, elements_before, 0.9, 0.999, 1e-8);
+    return GF_OK;
+}
+
 gf_status gf_smp_adam_reset(gf_smp *s) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     if (s->adam_m) {
@@ -769,14 +836,15 @@ gf_status gf_smp_uniform_init_host(const gf_smp_config *cfg, float *params) {
     if (!cfg || !params) return GF_ERR_INVALID;
     gfsmp::Config c = {cfg->nLevels, cfg->nChanels, cfg->nFeatures, cfg->nDepth, cfg->max_receptive_field, cfg->has_WL_ordering};
     c.nContractions = cfg->nContractions ? cfg->nContractions : 18;
+    c.physics = cfg->physics ? 1 : 0;
     const size_t C = (size_t)c.nChanels;
     std::vector<size_t> sizes;
     sizes.push_back(C * c.fdim());
     for (int l = 1; l <= c.nLevels; ++l) {
-        sizes.push_back((size_t)c.nContractions * C * C);
-        sizes.push_back(C);
+        sizes.push_back((size_t)c.nContractions * c.level_channels(l - 1) * c.level_channels(l));
+        sizes.push_back((size_t)c.level_channels(l));
     }
-    sizes.push_back(C);
+    if (!c.physics) sizes.push_back(C);
     size_t off = 0;
     for (size_t v = 0; v < sizes.size(); ++v)
         for (size_t i = 0; i < sizes[v]; ++i) {
@@ -874,10 +942,22 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.node_pair, &h.node_pair[0], h.node_pair.size());
         if (st != GF_OK) return st;
-        st = gf::upload(s, &d.f, nullptr, (size_t)h.rows * C);
+        const int Cl = s->cfg.level_channels(l), Cp = l ? s->cfg.level_channels(l - 1) : Cl;
+        st = gf::upload(s, &d.f, nullptr, (size_t)h.rows * Cl);
         if (st != GF_OK) return st;
-        st = gf::upload(s, &d.df, nullptr, (size_t)h.rows * C);
+        st = gf::upload(s, &d.df, nullptr, (size_t)h.rows * Cl);
         if (st != GF_OK) return st;
+        if (s->cfg.physics) {  // every level is read out: per-node sums, their activation and gradient, the vertex -> node map
+            st = gf::upload(s, &d.sh, nullptr, (size_t)h.nNodes * Cl);
+            if (st != GF_OK) return st;
+            st = gf::upload(s, &d.vf, nullptr, (size_t)h.nNodes * Cl);
+            if (st != GF_OK) return st;
+            st = gf::upload(s, &d.node_of_vertex, &B.node_of_vertex[l][0], B.node_of_vertex[l].size());
+            if (st != GF_OK) return st;
+            UP(d.node_mol, h.node_mol);
+            st = gf::upload(s, &d.keep_mask, nullptr, (size_t)h.nNodes);
+            if (st != GF_OK) return st;
+        }
         if (l == 0) continue;
         st = gf::upload(s, &d.node_p, &h.node_p[0], h.node_p.size());
         if (st != GF_OK) return st;
@@ -914,9 +994,9 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (st != GF_OK) return st;
         UP(d.pi, h.pi);
         UP(d.inv, h.inv);
-        st = gf::upload(s, &d.Q, nullptr, (size_t)h.rows * std::max(18, s->cfg.nContractions) * C);
+        st = gf::upload(s, &d.Q, nullptr, (size_t)h.rows * std::max(18, s->cfg.nContractions) * Cp);
         if (st != GF_OK) return st;
-        {
+        if (!s->cfg.physics) {
             float **bufs[] = {&d.Vt, &d.dVt, &d.St, &d.dSt, &d.scal, &d.Vout, &d.dVout, &d.Sout, &d.dSout, &d.dSpart, &d.dbpart, &d.Wst, &d.dWst};
             const size_t sizes[] = {(size_t)h.pairs * 4 * C, (size_t)h.pairs * 4 * C, (size_t)h.nNodes * 4 * C, (size_t)h.nNodes * 4 * C,
                                     (size_t)h.pairs * 4 * C, (size_t)h.pairs * C, (size_t)h.pairs * C, (size_t)h.nNodes * C,
@@ -926,16 +1006,16 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                 if (st != GF_OK) return st;
             }
         }
-        if (h.ppos > maxp) maxp = h.ppos;
+        if (h.ppos * Cp > maxp) maxp = h.ppos * Cp;
         for (size_t b = 0; b < h.buckets.size(); ++b) {
-            const size_t w = gf_contract_workspace_bytes(s->cfg.nContractions, h.buckets[b].s, C, h.buckets[b].count);
+            const size_t w = gf_contract_workspace_bytes(s->cfg.nContractions, h.buckets[b].s, Cp, h.buckets[b].count);
             if (w > contract_ws) contract_ws = w;
         }
-        contract_ws = std::max(contract_ws, gf::r18_ragged_workspace_bytes((long long)h.rows, (long long)h.pairs, C));
+        contract_ws = std::max(contract_ws, gf::r18_ragged_workspace_bytes((long long)h.rows, (long long)h.pairs, Cp));
     }
     UP(s->x, B.x);
     s->P = nullptr;  // [max ppos][C]: by far the largest buffer of the op-by-op path, taken from the pool only when a level needs it
-    s->P_count = (size_t)maxp * C;
+    s->P_count = (size_t)maxp;  // (positions x channels of the level below, maximised over the levels)
     const gfsmp::LevelLayout &top = B.level[L];
     st = gf::upload(s, &s->sh, nullptr, (size_t)top.nNodes * C);
     if (st != GF_OK) return st;
@@ -943,7 +1023,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     if (st != GF_OK) return st;
     st = gf::upload(s, &s->dsh, nullptr, (size_t)top.nNodes * C);
     if (st != GF_OK) return st;
-    st = gf::upload(s, &s->g, nullptr, (size_t)nMol * C);
+    st = gf::upload(s, &s->g, nullptr, (size_t)nMol * (s->cfg.physics ? gf::feature_width(s->cfg) : (size_t)C));
     if (st != GF_OK) return st;
     st = gf::upload(s, &s->yhat, nullptr, (size_t)nMol);
     if (st != GF_OK) return st;
@@ -992,6 +1072,8 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
         if (!s->own_p) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward: null params and no handle-owned model");
         params = s->own_p;
     }
+    if (s->cfg.physics && (targets || predict || loss))
+        return fail(ctx, GF_ERR_INVALID, "gf_smp_forward: a physics tower only produces graph_feature (the head owns targets, predict and loss)");
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const gfsmp::BatchLayout &B = s->lay;
     const int L = s->cfg.nLevels, C = s->cfg.nChanels, FD = s->cfg.fdim();
@@ -1020,17 +1102,40 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
         }
         st = gf::ensure_P(s);
         if (st != GF_OK) return st;
+        const int Cp = s->cfg.level_channels(l - 1), Cc = s->cfg.level_channels(l);  // (equal unless a physics tower)
         GF_LAUNCH(ctx, "smp_promote_fwd", gf::promote_forward, dim3((unsigned)h.pairs), dim3(256), 0, s->lv[l - 1].f, s->P,
-                  d.node_s, d.node_row, d.node_p, d.node_pair, d.pair_node, d.pair_src_row, d.pair_src_s, d.pi, C);
+                  d.node_s, d.node_row, d.node_p, d.node_pair, d.pair_node, d.pair_src_row, d.pair_src_s, d.pi, Cp);
         st = gf::smp_contract(s, l, /*backward=*/false);
         if (st != GF_OK) return st;
+        if (s->drop_on)
+            GF_LAUNCH(ctx, "smp_slice_dropout", gf::node_slice_scale, dim3(h.nNodes), dim3(256), 0, d.Q, d.node_s, d.node_row, d.keep_mask,
+                      s->drop_scale, Cp);
         // K-projection over all buckets at once: [rows, KC] x [KC, C]  (CustomMatMulTensor layout: x K_l^T, K_l = [C, KC])
-        const int KC = s->cfg.nContractions * C;
-        st = s->cfg.custom_matmul ? gf::gemm(ctx, false, true, (int)h.rows, C, KC, d.Q, KC, 0, K[l], KC, 0, d.f, C, 0, 1, 0)
-                                  : gf::gemm(ctx, false, false, (int)h.rows, C, KC, d.Q, KC, 0, K[l], C, 0, d.f, C, 0, 1, 0);
+        const int KC = s->cfg.nContractions * Cp;
+        st = s->cfg.custom_matmul ? gf::gemm(ctx, false, true, (int)h.rows, Cc, KC, d.Q, KC, 0, K[l], KC, 0, d.f, Cc, 0, 1, 0)
+                                  : gf::gemm(ctx, false, false, (int)h.rows, Cc, KC, d.Q, KC, 0, K[l], Cc, 0, d.f, Cc, 0, 1, 0);
         if (st != GF_OK) return st;
-        GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)h.rows * C)), dim3(256), 0, d.f,
-                  b[l], C, (size_t)h.rows * C);
+        GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)h.rows * Cc)), dim3(256), 0, d.f,
+                  b[l], Cc, (size_t)h.rows * Cc);
+    }
+    if (s->cfg.physics) {  // every level read out into its block of the feature row; the head (MLP, loss) is the caller's
+        const int width = (int)gf::feature_width(s->cfg);
+        int off = 0;
+        for (int l = 0; l <= L; ++l) {
+            const gf_smp::DevLevel &d = s->lv[l];
+            const int Cc = s->cfg.level_channels(l);
+            GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes, dim3(gf::grid_for((size_t)B.level[l].nNodes * Cc)), dim3(256), 0, d.f,
+                      d.node_s, d.node_row, d.sh, d.vf, Cc, (size_t)B.level[l].nNodes * Cc);
+            GF_LAUNCH(ctx, "smp_level_feature", gf::level_feature_sum, dim3(B.nMol), dim3(64), 0, d.vf, s->mol_ptr, d.node_of_vertex, s->g,
+                      Cc, width, off);
+            off += Cc;
+        }
+        if (graph_feature)
+            GF_HIP_TRY(ctx, hipMemcpyAsync(graph_feature, s->g, sizeof(float) * (size_t)B.nMol * width, hipMemcpyDeviceToDevice, ctx->stream));
+        s->forwarded = true;
+        s->has_targets = false;
+        gf::mark_used(s);
+        return GF_OK;
     }
     const gfsmp::LevelLayout &top = B.level[L];
     if (C % 4 == 0 && C <= 1024) {
@@ -1051,18 +1156,47 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     return GF_OK;
 }
 
+// RisiContraction_18_dropout for the next forward / backward of a physics tower (SMP_sigma_pairgraphs): masks[(l-1) * nVertices + gv]
+// = kept-slice bits of the contraction of global vertex gv (molecules back to back) at level l, drawn by the caller in the
+// reference's order; scale = 1 (train) or nKept / 18 with all bits set (test).  masks == NULL: plain RisiContraction_18.
+gf_status gf_smp_dropout_masks(gf_smp *s, const unsigned *masks, float scale) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    gf_ctx *ctx = s->ctx;
+    if (!masks) {
+        s->drop_on = false;
+        return GF_OK;
+    }
+    if (!s->prepared || !s->cfg.physics) return fail(ctx, GF_ERR_INVALID, "gf_smp_dropout_masks: needs a prepared physics tower");
+    const gfsmp::BatchLayout &B = s->lay;
+    const int totalV = B.mol_first_vertex[B.nMol];
+    std::vector<unsigned> by_node((size_t)totalV);
+    for (int l = 1; l <= s->cfg.nLevels; ++l) {
+        for (int gv = 0; gv < totalV; ++gv) by_node[(size_t)B.node_of_vertex[l][gv]] = masks[(size_t)(l - 1) * totalV + gv];
+        GF_HIP_TRY(ctx, hipMemcpyAsync(s->lv[l].keep_mask, by_node.data(), sizeof(unsigned) * totalV, hipMemcpyHostToDevice, ctx->stream));
+        GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // by_node is reused
+    }
+    s->drop_on = true;
+    s->drop_scale = scale;
+    return GF_OK;
+}
+
 gf_status gf_smp_set_grad_allreduce(gf_smp *s, int on) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     s->grad_allreduce = on ? 1 : 0;
     return GF_OK;
 }
 
-gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accumulate) {
+// The reverse sweep.  dfeat == nullptr: from the loss of the last forward (SMP_omega / SMP_beta / SMP_2D).  dfeat != nullptr
+// (physics towers): from the gradient of the tower's feature rows, [nMol][feature_width], given by the caller's head.
+static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads, int accumulate, const float *dfeat) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     gf_ctx *ctx = s->ctx;
     if (!s->forwarded) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward before gf_smp_forward");
-    if (!s->has_targets)  // Predict / Feature forward: dy would be y - 0, a gradient against a target nobody gave
+    if (!dfeat && !s->has_targets)  // Predict / Feature forward: dy would be y - 0, a gradient against a target nobody gave
         return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: the last gf_smp_forward had no targets");
+    if ((dfeat != nullptr) != (s->cfg.physics != 0))
+        return fail(ctx, GF_ERR_INVALID, s->cfg.physics ? "a physics tower is differentiated with gf_smp_backward_features"
+                                                         : "gf_smp_backward_features needs a physics tower");
     if (!params && !grads && s->own_p) {
         params = s->own_p;
         grads = s->own_g;
@@ -1078,7 +1212,7 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     std::vector<float *> dK, db;
     gf::view_params<float>(s->cfg, grads, &dH, &dK, &db, &dW);
     const size_t np = gf::param_count(s->cfg);
-    const bool dp = gf::dist_active(ctx) && s->grad_allreduce;
+    const bool dp = gf::dist_active(ctx) && s->grad_allreduce && !s->cfg.physics;  // (towers: the composite model reduces its own flat buffer)
     if (dp && accumulate)
         return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: accumulate with a communicator would re-sum earlier global sums "
                                          "(gf_smp_set_grad_allreduce(smp, 0) and reduce once at the end instead)");
@@ -1095,9 +1229,22 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     if (!accumulate) GF_LAUNCH(ctx, "smp_zero", gf::zero_f32, dim3(gf::grid_for(np)), dim3(256), 0, grads, np);
     gf_status st;
     const gfsmp::LevelLayout &top = B.level[L];
-    GF_LAUNCH(ctx, "smp_readout_dW", gf::readout_dW, dim3(1), dim3(1024), 0, s->dy, s->g, dW, C, B.nMol);
-    const bool top_fused = s->fused && gf::smp_fused_supported(s, L);
-    if (top_fused) {
+    const int fwidth = dfeat ? (int)gf::feature_width(s->cfg) : 0;
+    std::vector<int> foff(L + 2, 0);
+    for (int l = 0; l <= L; ++l) foff[l + 1] = foff[l] + s->cfg.level_channels(l);
+    // physics: the read-out of level l adds  dfeat[mol][block l] * lrelu'(sh_l)  at every position of every node of the level
+    auto feature_backward = [&](int l, int acc) -> gf_status {
+        const gf_smp::DevLevel &dl = s->lv[l];
+        GF_LAUNCH(ctx, "smp_level_feature_bwd", gf::level_feature_backward, dim3(B.level[l].nNodes), dim3(256), 0, dfeat, dl.sh, dl.node_mol,
+                  dl.node_s, dl.node_row, dl.df, s->cfg.level_channels(l), fwidth, foff[l], acc);
+        return GF_OK;
+    };
+    if (!dfeat) GF_LAUNCH(ctx, "smp_readout_dW", gf::readout_dW, dim3(1), dim3(1024), 0, s->dy, s->g, dW, C, B.nMol);
+    const bool top_fused = !dfeat && s->fused && gf::smp_fused_supported(s, L);
+    if (dfeat) {
+        st = feature_backward(L, 0);
+        if (st != GF_OK) return st;
+    } else if (top_fused) {
         GF_LAUNCH(ctx, "smp_readout_bwd", gf::readout_backward_nodevec, dim3(gf::grid_for((size_t)top.nNodes * C)), dim3(256), 0, s->dy,
                   W, s->sh, s->top_node_mol, s->dsh, C, (size_t)top.nNodes * C);
     } else {
@@ -1113,25 +1260,29 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
             if (st != GF_OK) return st;
         } else {
         // dZ = dF * lrelu'(z) in place; db_l += column sums
+            const int Cc = s->cfg.level_channels(l), Cq = s->cfg.level_channels(l - 1);  // (equal unless a physics tower)
             const int rpb = 1024;
             const int nb = (int)((h.rows + rpb - 1) / rpb);
-            GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(256), 0, d.f, d.df, s->colpart, C,
+            GF_LAUNCH(ctx, "smp_lrelu_bwd", gf::lrelu_backward_colsum, dim3(nb), dim3(256), 0, d.f, d.df, s->colpart, Cc,
                       (long long)h.rows, rpb);
-            GF_LAUNCH(ctx, "smp_colsum", gf::colsum_finish, dim3(1), dim3(256), 0, s->colpart, db[l], C, nb);
+            GF_LAUNCH(ctx, "smp_colsum", gf::colsum_finish, dim3(1), dim3(256), 0, s->colpart, db[l], Cc, nb);
             // dK_l += Q^T dZ   (MatMul::backward second operand), then dQ = dZ K_l^T overwrites Q (first operand)
-            const int KC = s->cfg.nContractions * C;
+            const int KC = s->cfg.nContractions * Cq;
             if (s->cfg.custom_matmul) {  // CustomMatMulTensor::backward (CustomMatMulTensor.h:70-85): dK_l [C, KC] += dZ^T Q, dQ = dZ K_l
-                st = gf::gemm(ctx, true, false, C, KC, (int)h.rows, d.df, C, 0, d.Q, KC, 0, dK[l], KC, 0, 1, 1);
+                st = gf::gemm(ctx, true, false, Cc, KC, (int)h.rows, d.df, Cc, 0, d.Q, KC, 0, dK[l], KC, 0, 1, 1);
                 if (st != GF_OK) return st;
-                st = gf::gemm(ctx, false, false, (int)h.rows, KC, C, d.df, C, 0, K[l], KC, 0, d.Q, KC, 0, 1, 0);
+                st = gf::gemm(ctx, false, false, (int)h.rows, KC, Cc, d.df, Cc, 0, K[l], KC, 0, d.Q, KC, 0, 1, 0);
             } else {
-                st = gf::gemm(ctx, true, false, KC, C, (int)h.rows, d.Q, KC, 0, d.df, C, 0, dK[l], C, 0, 1, 1);
+                st = gf::gemm(ctx, true, false, KC, Cc, (int)h.rows, d.Q, KC, 0, d.df, Cc, 0, dK[l], Cc, 0, 1, 1);
                 if (st != GF_OK) return st;
-                st = gf::gemm(ctx, false, true, (int)h.rows, KC, C, d.df, C, 0, K[l], C, 0, d.Q, KC, 0, 1, 0);
+                st = gf::gemm(ctx, false, true, (int)h.rows, KC, Cc, d.df, Cc, 0, K[l], Cc, 0, d.Q, KC, 0, 1, 0);
             }
             if (st != GF_OK) return st;
             st = gf::smp_dp_level_done(s, l);
             if (st != GF_OK) return st;
+            if (s->drop_on)  // the dropped slices receive no gradient
+                GF_LAUNCH(ctx, "smp_slice_dropout", gf::node_slice_scale, dim3(h.nNodes), dim3(256), 0, d.Q, d.node_s, d.node_row,
+                          d.keep_mask, 1.f, Cq);
             st = gf::smp_contract(s, l, /*backward=*/true);
             if (st != GF_OK) return st;
         }
@@ -1143,8 +1294,12 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
             continue;
         }
         GF_LAUNCH(ctx, "smp_promote_bwd", gf::promote_backward, dim3(B.level[l - 1].nNodes), dim3(256), 0, s->P, pv.df,
-                  pv.node_s, pv.node_row, d.cons_ptr, d.cons_slab, d.cons_s, d.cons_inv_off, d.inv, C,
+                  pv.node_s, pv.node_row, d.cons_ptr, d.cons_slab, d.cons_s, d.cons_inv_off, d.inv, s->cfg.level_channels(l - 1),
                   diag_level ? d.dFdc : (const float *)nullptr, pv.node_pair, pv.node_center);
+        if (dfeat) {  // level l-1 is read out too: its own contribution joins what its consumers sent down
+            st = feature_backward(l - 1, 1);
+            if (st != GF_OK) return st;
+        }
     }
     if (s->side_pending) {  // join: the weight gradients (and their use of the split-K workspace) are complete
         GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
@@ -1173,6 +1328,22 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     return GF_OK;
 }
 
+gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accumulate) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    return smp_backward_impl(s, params, grads, accumulate, nullptr);
+}
+
+gf_status gf_smp_backward_features(gf_smp *s, const float *params, float *grads, const float *d_feature, int accumulate) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    if (!d_feature) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_backward_features: null feature gradient");
+    return smp_backward_impl(s, params, grads, accumulate, d_feature);
+}
+
+size_t gf_smp_feature_width(const gf_smp *s) {
+    if (!s) return 0;
+    return s->cfg.physics ? gf::feature_width(s->cfg) : (size_t)s->cfg.nChanels;
+}
+
 /* Host-only graph preparation of ONE molecule (no device needed): receptive fields phi[l][v] as
  * [L+1][V][cap+1] ints (slot 0 = size) and, optionally, the WL features [V][F(D+1)].  Lets the host logic be tested
  * on a CPU-only box and inspected by callers. */
@@ -1186,6 +1357,7 @@ gf_status gf_smp_prepare_molecule_host(const gf_smp_config *cfg, int V, const in
     c.nDepth = cfg->nDepth;
     c.max_receptive_field = cfg->max_receptive_field;
     c.has_WL_ordering = cfg->has_WL_ordering;
+    c.physics = cfg->physics ? 1 : 0;
     gfsmp::Molecule m;
     gfsmp::prepare_molecule(c, V, adj, feature, &m);
     const int cap = c.max_receptive_field;

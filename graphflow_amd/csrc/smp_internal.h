@@ -54,6 +54,8 @@ struct gf_smp {
     bool has_targets = false;  // the last gf_smp_forward was given targets: only then does dy hold a loss gradient
     // data-parallel reverse sweep (the context has a communicator, gf_dist.hip): the gradient segment of a level is
     // all-reduced on the communicator's stream as soon as it is complete, beside the rest of the sweep
+    bool drop_on = false;      // RisiContraction_18_dropout instead of RisiContraction_18 (SMP_sigma_pairgraphs)
+    float drop_scale = 1.f;    // test mode: nKept / 18 on every slice
     int grad_allreduce = 1;
     float *dp_grads = nullptr;           // gradient buffer of the running gf_smp_backward, null when not data-parallel
     hipEvent_t ev_grad = nullptr, ev_comm = nullptr;
@@ -72,6 +74,10 @@ struct gf_smp {
         int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr;
         float *Fdc = nullptr, *Gc = nullptr, *dGc = nullptr, *dFdc = nullptr;  // [pairs of level l-1][2C] each
         float *f = nullptr, *df = nullptr, *Q = nullptr;  // activations [rows][C], their gradient, contraction out [rows][18C]
+        // physics towers (every level is read out): per-node sums of f, their LeakyReLU, vertex -> node and node -> molecule maps
+        float *sh = nullptr, *vf = nullptr;
+        int *node_of_vertex = nullptr, *node_mol = nullptr;
+        unsigned *keep_mask = nullptr;  // [nodes] slice masks of RisiContraction_18_dropout for this forward (gf_smp_dropout_masks)
         // fused level (smp_fused.hip): small per-(node,x) / per-node tables and stacked weights
         float *Vt = nullptr, *dVt = nullptr;        // [pairs][4C]  rowsum_a | colsum_b | D8 | D11
         float *St = nullptr, *dSt = nullptr;        // [nodes][4C]  total | s14 | s15 | s18
@@ -130,6 +136,7 @@ gf_status smp_fused_gather_backward(gf_smp *s, int l);
 bool smp_fused_gather_enabled(const gf_smp *s, int l);
 gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status ensure_P(gf_smp *s);
+size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce
 gf_status smp_dp_level_done(gf_smp *s, int l);
 }

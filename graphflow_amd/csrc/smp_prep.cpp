@@ -177,14 +177,15 @@ void rank_vertices(int V, int FD, const std::vector<double> &wl, std::vector<int
 
 // SMP_omega.h:476-507: order by (hop distance from v, rank) with the reference's exchange sort, then drop whole
 // farthest hop shells until the field fits.
-void cap_field(int v, int V, int cap, const std::vector<int> &sp, const std::vector<int> &rank, std::vector<int> *field) {
+// use_rank = false: the `_physics` variant of limit_receptive_field (SMP_omega_physics.h:436-450) swaps on distance only.
+void cap_field(int v, int V, int cap, const std::vector<int> &sp, const std::vector<int> &rank, std::vector<int> *field, bool use_rank) {
     std::vector<int> &A = *field;
     for (size_t i = 0; i < A.size(); ++i)
         for (size_t j = i + 1; j < A.size(); ++j) {
             const int di = sp[v * V + A[i]], dj = sp[v * V + A[j]];
             if (di > dj) {
                 std::swap(A[i], A[j]);
-            } else if (di == dj && rank[A[i]] > rank[A[j]]) {
+            } else if (use_rank && di == dj && rank[A[i]] > rank[A[j]]) {
                 std::swap(A[i], A[j]);
             }
         }
@@ -218,8 +219,8 @@ void prepare_molecule(const Config &cfg, int V, const int *adj, const double *fe
                     if (std::find(field.begin(), field.end(), B[i]) == field.end()) field.push_back(B[i]);
             }
             if ((int)field.size() > cfg.max_receptive_field)
-                cap_field(v, V, cfg.max_receptive_field, out->hops, out->rank, &field);
-            if (cfg.has_WL_ordering)  // sort() at :451-459: exchange sort by ascending rank
+                cap_field(v, V, cfg.max_receptive_field, out->hops, out->rank, &field, !cfg.physics);
+            if (cfg.has_WL_ordering && !cfg.physics)  // sort() at :451-459: exchange sort by ascending rank
                 for (size_t i = 0; i < field.size(); ++i)
                     for (size_t j = i + 1; j < field.size(); ++j)
                         if (out->rank[field[i]] > out->rank[field[j]]) std::swap(field[i], field[j]);
@@ -312,6 +313,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         }
     });
     out->top_node_of_vertex = node_of[L];
+    out->node_of_vertex = node_of;
     const std::chrono::steady_clock::time_point t_order = std::chrono::steady_clock::now();
 
     for (int l = 1; l <= L; ++l) {

@@ -18,6 +18,15 @@ struct Config {
     int nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering;
     int nContractions = 18;  // contraction family of the levels: 18 (SMP_omega/beta, SMP_2D_ver8), 10 (ver6), 50 (ver7)
     int custom_matmul = 0;   // 1: K_l is [C][nContractions C] and applied by CustomMatMulTensor (SMP_2D_ver6-8)
+    // 1: the `_physics` / `_pairgraphs` family (GraphFlow/SMP_omega_physics.h): raw vertex features (no WL histogram, no
+    // WL ordering, and the cap orders by hop distance only, :436-450), channels halve from level to level (:141-151), every
+    // level is read out (:572-590).  One such model body is a "tower": its output is the concatenated level features.
+    int physics = 0;
+    int level_channels(int l) const {
+        if (!physics) return nChanels;
+        int c = nChanels >> l;
+        return c < 1 ? 1 : c;
+    }
     int fdim() const { return nFeatures * (nDepth + 1); }
 };
 
@@ -83,6 +92,7 @@ struct BatchLayout {
     std::vector<float> x;               // [nVertices][F(D+1)] WL features, level-0 input
     std::vector<LevelLayout> level;     // [L+1]; level[0] has only node bookkeeping
     std::vector<int> top_node_of_vertex;  // [nVertices] node index at level L of global vertex id
+    std::vector<std::vector<int> > node_of_vertex;  // [L+1][nVertices] the same for every level (per-level readout)
     std::vector<Molecule> mols;         // kept for introspection (receptive fields)
 };
 

@@ -12,7 +12,7 @@ from .ops import default_context
 class SMPConfig(C.Structure):
     _fields_ = [("nLevels", C.c_int), ("nChanels", C.c_int), ("nFeatures", C.c_int), ("nDepth", C.c_int),
                 ("max_receptive_field", C.c_int), ("has_WL_ordering", C.c_int), ("nContractions", C.c_int),
-                ("custom_matmul", C.c_int)]
+                ("custom_matmul", C.c_int), ("physics", C.c_int)]
 
 
 class SMPOmega:
@@ -20,12 +20,13 @@ class SMPOmega:
     registration order: H[C, F(D+1)], (K_l[18C, C], b_l[C]) for l = 1..L, W[C]."""
 
     def __init__(self, nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering=True, ctx=None,
-                 nContractions=18, custom_matmul=False):
-        """nContractions / custom_matmul select the SMP_2D_ver6 (10, True) / ver7 (50, True) / ver8 (18, True) wirings."""
+                 nContractions=18, custom_matmul=False, physics=False):
+        """nContractions / custom_matmul select the SMP_2D_ver6 (10, True) / ver7 (50, True) / ver8 (18, True) wirings;
+        physics=True makes the handle one tower of the _physics / _pairgraphs models (see gf_smp_config.physics)."""
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.cfg = SMPConfig(nLevels, nChanels, nFeatures, nDepth, max_receptive_field, 1 if has_WL_ordering else 0,
-                             nContractions, 1 if custom_matmul else 0)
+                             nContractions, 1 if custom_matmul else 0, 1 if physics else 0)
         h = C.c_void_p()
         self.ctx.check(self.lib.gf_smp_create(self.ctx.handle, C.byref(self.cfg), C.byref(h)))
         self.handle = h
@@ -50,7 +51,7 @@ class SMPOmega:
         dev = self.ctx.device
         self.predict = torch.empty(self.n_mol, dtype=torch.float32, device=dev)
         self.loss = torch.empty(self.n_mol, dtype=torch.float32, device=dev)
-        self.feature = torch.empty((self.n_mol, self.cfg.nChanels), dtype=torch.float32, device=dev)
+        self.feature = torch.empty((self.n_mol, int(self.lib.gf_smp_feature_width(self.handle))), dtype=torch.float32, device=dev)
 
     def _flat(self, t, name):
         """params / grads must be exactly the flat model: float32, contiguous, on the context's device, n_params long."""
@@ -59,8 +60,24 @@ class SMPOmega:
             raise TypeError("%s must be a contiguous float32 tensor of %d elements on %s" % (name, self.n_params, self.ctx.device))
         return C.c_void_p(t.data_ptr())
 
+    def backward_features(self, params, grads, d_feature, accumulate=False):
+        """Physics tower: the reverse sweep from the gradient of the feature rows (what the head's backward returns)."""
+        self._flat(params, "params")
+        self._flat(grads, "grads")
+        if not (d_feature.is_cuda and d_feature.dtype == torch.float32 and d_feature.is_contiguous() and d_feature.shape == self.feature.shape):
+            raise TypeError("d_feature must be a contiguous float32 CUDA tensor shaped like the feature rows")
+        self.ctx.check(self.lib.gf_smp_backward_features(self.handle, C.c_void_p(params.data_ptr()), C.c_void_p(grads.data_ptr()),
+                                                         C.c_void_p(d_feature.data_ptr()), 1 if accumulate else 0))
+        return grads
+
     def forward(self, params, targets=None):
         self._flat(params, "params")
+        if self.cfg.physics:
+            if targets is not None:
+                raise TypeError("a physics tower has no loss of its own: targets go to the head")
+            self.ctx.check(self.lib.gf_smp_forward(self.handle, C.c_void_p(params.data_ptr()), None, None, None,
+                                                   C.c_void_p(self.feature.data_ptr())))
+            return self.feature
         if targets is not None and not (targets.is_cuda and targets.dtype == torch.float32 and targets.is_contiguous()
                                         and targets.numel() == self.n_mol):
             raise TypeError("targets must be a contiguous float32 CUDA tensor with one value per molecule (%d)" % self.n_mol)
@@ -158,6 +175,69 @@ class SMPOmega:
     def close(self):
         if getattr(self, "handle", None):
             self.lib.gf_smp_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SMPModelConfig(C.Structure):
+    _fields_ = [("nTowers", C.c_int), ("nLevels", C.c_int), ("nChanels", C.c_int), ("max_receptive_field", C.c_int),
+                ("nFeatures", C.c_int * 2), ("nKept", C.c_int)]
+
+
+class SMPModel:
+    """The _physics (one tower) / _pairgraphs (two towers, nKept > 0: SMP_sigma_pairgraphs) models of GraphFlow through
+    gf_smp_model_*.  Parameters / gradients: one flat fp32 tensor in the class's registration order."""
+
+    def __init__(self, nLevels, nChanels, max_receptive_field, nFeatures, nKept=0, ctx=None):
+        feats = list(nFeatures) if isinstance(nFeatures, (list, tuple)) else [nFeatures]
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        self.cfg = SMPModelConfig(len(feats), nLevels, nChanels, max_receptive_field, (C.c_int * 2)(*(feats + [0])[:2]), nKept)
+        h = C.c_void_p()
+        self.ctx.check(self.lib.gf_smp_model_create(self.ctx.handle, C.byref(self.cfg), C.byref(h)))
+        self.handle = h
+        self.n_params = self.lib.gf_smp_model_param_count(h)
+        self.n_mol = 0
+
+    @staticmethod
+    def _pack(graphs):
+        nV = np.array([len(g[0]) for g in graphs], dtype=np.int32)
+        adj = np.concatenate([np.ascontiguousarray(g[0], dtype=np.int32).ravel() for g in graphs])
+        feat = np.concatenate([np.ascontiguousarray(g[1], dtype=np.float64).ravel() for g in graphs])
+        return nV, adj, feat
+
+    def prepare(self, graphs1, graphs2=None):
+        a = self._pack(graphs1)
+        b = self._pack(graphs2) if graphs2 is not None else (None, None, None)
+        ptr = lambda x: x.ctypes.data_as(C.c_void_p) if x is not None else None  # noqa: E731
+        self.ctx.check(self.lib.gf_smp_model_prepare(self.handle, len(graphs1), ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(b[0]), ptr(b[1]), ptr(b[2])))
+        self.n_mol = len(graphs1)
+        dev = self.ctx.device
+        self.predict = torch.empty(self.n_mol, dtype=torch.float32, device=dev)
+        self.loss = torch.empty(self.n_mol, dtype=torch.float32, device=dev)
+
+    def set_mode(self, train=True):
+        self.ctx.check(self.lib.gf_smp_model_set_mode(self.handle, 1 if train else 0))
+
+    def forward(self, params, targets=None):
+        t = C.c_void_p(targets.data_ptr()) if targets is not None else None
+        self.ctx.check(self.lib.gf_smp_model_forward(self.handle, C.c_void_p(params.data_ptr()), t, C.c_void_p(self.predict.data_ptr()),
+                                                     C.c_void_p(self.loss.data_ptr())))
+        return self.predict, self.loss
+
+    def backward(self, params, grads, accumulate=False):
+        self.ctx.check(self.lib.gf_smp_model_backward(self.handle, C.c_void_p(params.data_ptr()), C.c_void_p(grads.data_ptr()),
+                                                      1 if accumulate else 0))
+        return grads
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gf_smp_model_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -214,6 +214,14 @@ typedef struct {
      * and applied by CustomMatMulTensor instead of Reshape2D + MatMul on [nContractions C][C].  Zero-initialised trailing
      * fields give SMP_omega.  Those models have no receptive-field cap: pass max_receptive_field = max_nVertices. */
     int nContractions, custom_matmul;
+    /* physics = 1: one TOWER of the `_physics` / `_pairgraphs` models (GraphFlow/SMP_omega_physics.h:29-170, :480-606;
+     * SMP_omega_pairgraphs.h builds two of them): raw vertex features (nDepth must be 0; no WL histogram or ordering, the
+     * receptive-field cap orders by hop distance only, :436-450), channels halve from level to level (C_l = max(1, C_{l-1} / 2),
+     * K_l = [18 C_{l-1}][C_l], :141-156), and EVERY level is read out (:572-588).  Parameters: H[C][F], (K_l, b_l) l = 1..L -- no
+     * readout vector.  gf_smp_forward then only fills graph_feature = [nMol][gf_smp_feature_width] (the ConcatVectors row, :590;
+     * targets / predict / loss must be NULL) and the reverse sweep starts from gf_smp_backward_features.  The fully-connected
+     * head on top is gf_head_*.  SMP_beta_physics / _pairgraphs = the same with max_receptive_field = max_nVertices. */
+    int physics;
 } gf_smp_config;
 gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out);
 gf_status gf_smp_destroy(gf_smp *smp);
@@ -235,6 +243,22 @@ gf_status gf_smp_backward(gf_smp *smp, const float *params, float *grads, int ac
  * summed over all ranks, the all-reduce of each level's [K_l | b_l] segment overlapped with the rest of the reverse sweep
  * (accumulate must be 0 then); 0 = local gradients only (the caller reduces them).  No effect without a communicator. */
 gf_status gf_smp_set_grad_allreduce(gf_smp *smp, int on);
+/* Physics towers: columns of a feature row (sum of the levels' channel counts), and the reverse sweep from the gradient of
+ * the feature rows, d_feature [nMol][width] (what the head's backward hands down: ConcatVectors::backward). */
+size_t    gf_smp_feature_width(const gf_smp *smp);
+gf_status gf_smp_backward_features(gf_smp *smp, const float *params, float *grads, const float *d_feature, int accumulate);
+/* The fully-connected head of the `_physics` / `_pairgraphs` models for a batch of feature rows x [n][width[0]]:
+ *   h_i = LeakyReLU(W_i h_{i-1}) for i = 1..nLayers (W_i = [width[i]][width[i-1]], MatVecMul + LeakyReLU), y = <h_nLayers, w>,
+ *   loss = (y - t)^2 / 2      (SMP_omega_physics.h:229-238, :592-606: one hidden layer of nTotal / 2;
+ *                              SMP_omega_pairgraphs.h:330-345: two, max(nTotal / 2, 10) and max(that / 2, 10)).
+ * params / dparams: W_1, ..., W_nLayers, w back to back (the models' registration order).  `work` holds the activations between
+ * forward and backward: gf_head_work_floats floats.  backward: dx = gradient w.r.t. x, dparams += the weight gradients. */
+size_t    gf_head_param_count(int nLayers, const int *width);
+size_t    gf_head_work_floats(int nLayers, const int *width, int n);
+gf_status gf_head_forward_f32(gf_ctx *ctx, int nLayers, const int *width, const float *x, int n, const float *params,
+                              const float *targets, float *predict, float *loss, float *work);
+gf_status gf_head_backward_f32(gf_ctx *ctx, int nLayers, const int *width, const float *x, int n, const float *params, float *work,
+                               float *dx, float *dparams);
 /* 1 (default): fused level kernels (no promoted stack, no 18-slice contraction output in HBM) where the shape allows;
  * 0: the op-by-op pipeline.  Same results within fp32 rounding; kept switchable for parity tests. */
 gf_status gf_smp_set_fused(gf_smp *smp, int on);
@@ -273,6 +297,47 @@ int       gf_smp_receptive_field(const gf_smp *smp, int mol, int level, int v, i
 long long gf_smp_read_activation(gf_smp *smp, int mol, int level, int v, float *host_out, size_t capacity);
 long long gf_smp_read_reduced_adjacency(gf_smp *smp, int mol, int level, int v, float *host_out, size_t capacity);
 gf_status gf_smp_level_sizes(const gf_smp *smp, int level, long long *nodes, long long *rows, long long *ppos);
+
+/* RisiContraction_18_dropout inside a physics tower (SMP_sigma_pairgraphs.h:248-265, :632-651): masks[(l-1) * nVertices + gv] =
+ * kept-slice bits of the contraction of global vertex gv (molecules back to back) at level l, drawn by the caller in the
+ * reference's order (gf_smp_model_forward does); scale 1 in train mode, nKept / 18 with every bit set in test mode.  NULL: off. */
+gf_status gf_smp_dropout_masks(gf_smp *smp, const unsigned *masks, float scale);
+/* Adam::Learn(learning_rate, nBatch) (GraphFlow/Adam.h:106-133) on any flat device buffer with caller-owned moment buffers;
+ * element i uses the bias-correction powers beta^(elements_before + i + 1), as the reference's per-element advance gives. */
+gf_status gf_adam_step_f32(gf_ctx *ctx, float *params, const float *grads, float *m, float *v, size_t n, double learning_rate,
+                           int nBatch, unsigned long long elements_before);
+
+/* ---- the `_physics` / `_pairgraphs` models as one handle ------------------------------------------------------
+ * nTowers 1: SMP_omega_physics (GraphFlow/SMP_omega_physics.h:29-606) -- SMP_beta_physics with max_receptive_field =
+ *            max_nVertices; head = one hidden layer of nTotal / 2 units (:229-238).
+ * nTowers 2: SMP_omega_pairgraphs / SMP_beta_pairgraphs (GraphFlow/SMP_omega_pairgraphs.h:81-730): a graph and its partner (e.g.
+ *            its line graph) through two towers with their own weights, level features concatenated level by level (:699-704),
+ *            head = two hidden layers (:330-345).  nKept > 0: SMP_sigma_pairgraphs (RisiContraction_18_dropout keeping nKept
+ *            slices; masks drawn with rand() in the reference's order in train mode, all slices x nKept / 18 in test mode).
+ * params / grads: flat device buffers in the class's registration order -- physics H, (K_l, b_l)..., W1, W2 (:254-262);
+ * pairgraphs H_1, H_2, (K1_l, b1_l, K2_l, b2_l)..., W1, W2, W3 (SMP_omega_pairgraphs.h:361-375).  grads = the batch SUM.
+ * prepare: host pointers as gf_smp_prepare, one set per tower (the second set NULL for nTowers 1).                             */
+typedef struct gf_smp_model gf_smp_model;
+typedef struct {
+    int nTowers, nLevels, nChanels, max_receptive_field;
+    int nFeatures[2];
+    int nKept;   /* 0: RisiContraction_18; 1..18: RisiContraction_18_dropout */
+} gf_smp_model_config;
+gf_status gf_smp_model_create(gf_ctx *ctx, const gf_smp_model_config *cfg, gf_smp_model **out);
+gf_status gf_smp_model_destroy(gf_smp_model *model);
+size_t    gf_smp_model_param_count(const gf_smp_model *model);
+gf_status gf_smp_model_set_mode(gf_smp_model *model, int train);   /* SMP_sigma_pairgraphs::setMode (:139-149); default train */
+gf_status gf_smp_model_prepare(gf_smp_model *model, int nMol, const int *nVertices1, const int *adj1, const double *feature1,
+                               const int *nVertices2, const int *adj2, const double *feature2);
+gf_status gf_smp_model_forward(gf_smp_model *model, const float *params, const float *targets, float *predict, float *loss);
+gf_status gf_smp_model_backward(gf_smp_model *model, const float *params, float *grads, int accumulate);
+gf_status gf_smp_model_uniform_init_host(const gf_smp_model *model, float *host_params);
+/* host-pointer mode (graphflow_amd/host/SMP_physics_hip.h): the handle owns parameters, gradients and Adam moments; NULL
+ * params / grads in the two calls above select them */
+gf_status gf_smp_model_parameters_upload(gf_smp_model *model, const float *host_params);
+gf_status gf_smp_model_parameters_download(gf_smp_model *model, float *host_params, float *host_grads);
+gf_status gf_smp_model_forward_host(gf_smp_model *model, const double *targets, double *predict, double *loss);
+gf_status gf_smp_model_adam_step(gf_smp_model *model, double learning_rate, int nBatch);
 
 #ifdef __cplusplus
 }

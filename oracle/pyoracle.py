@@ -591,3 +591,89 @@ def port_r18_batch_threads(P, A, G, nGraphs, nThreads):
     t0 = time.perf_counter()
     assert f(P, A, G, P.shape[0], P.shape[3], int(nGraphs), int(nThreads)) == 0
     return time.perf_counter() - t0
+
+
+# -- the `_physics` / `_pairgraphs` drivers of the real reference (goldens for SURVEY 8 f3) ------------------------------------
+def physics_channels(C_, L):
+    return [max(1, C_ >> l) for l in range(L + 1)]
+
+
+def physics_tower_param_count(C_, F, L):
+    ch = physics_channels(C_, L)
+    return C_ * F + sum(18 * ch[l - 1] * ch[l] + ch[l] for l in range(1, L + 1))
+
+
+def reference_smp_physics(adj, feature, target, params, nLevels, C_, cap, beta=False, max_nVertices=None):
+    """The REAL SMP_omega_physics (or SMP_beta_physics) on one molecule, parameters in its registration order
+    H, (K_l, b_l)..., W1, W2."""
+    ref = reference()
+    if ref is None:
+        return None
+    adj = np.ascontiguousarray(adj, dtype=np.int32)
+    feature = np.ascontiguousarray(feature, dtype=np.float64)
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    V, F = feature.shape
+    maxV = max_nVertices or V
+    stride = maxV + 1
+    width = sum(physics_channels(C_, nLevels))
+    pred, loss, grads, gfeat = np.zeros(1), np.zeros(1), np.zeros_like(params), np.zeros(width)
+    phi = np.zeros((nLevels + 1, V, stride), dtype=np.int32)
+    f = ref.lib.ref_smp_physics_run
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f.argtypes = [_i] * 7 + [ip, _dp, C_double, _dp, _dp, _dp, _dp, ip, _i, _dp]
+    f.restype = _i
+    n = f(1 if beta else 0, maxV, cap, nLevels, C_, F, V, adj, feature, float(target), params, pred, loss, grads, phi, stride, gfeat)
+    assert n == params.size, (n, params.size)
+    return {"phi": phi, "predict": float(pred[0]), "loss": float(loss[0]), "grads": grads, "graph_feature": gfeat}
+
+
+def reference_smp_pairgraphs(kind, g1, g2, target, params, nLevels, C_, cap, nKept=18, train=True, seed=0, maxV=None):
+    """The REAL SMP_omega_pairgraphs (kind 0) / SMP_beta_pairgraphs (1) / SMP_sigma_pairgraphs (2) on one pair of graphs
+    g = (adj, feature); parameters in registration order H_1, H_2, (K1_l, b1_l, K2_l, b2_l)..., W1, W2, W3."""
+    ref = reference()
+    if ref is None:
+        return None
+    a1, f1 = np.ascontiguousarray(g1[0], dtype=np.int32), np.ascontiguousarray(g1[1], dtype=np.float64)
+    a2, f2 = np.ascontiguousarray(g2[0], dtype=np.int32), np.ascontiguousarray(g2[1], dtype=np.float64)
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    V1, V2 = len(a1), len(a2)
+    m = maxV or max(V1, V2)
+    stride = m + 1
+    width = 2 * sum(physics_channels(C_, nLevels))
+    pred, loss, grads, gfeat = np.zeros(1), np.zeros(1), np.zeros_like(params), np.zeros(width)
+    phi1 = np.zeros((nLevels + 1, V1, stride), dtype=np.int32)
+    phi2 = np.zeros((nLevels + 1, V2, stride), dtype=np.int32)
+    f = ref.lib.ref_smp_pairgraphs_run
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f.argtypes = [_i] * 9 + [ip, _dp, _i, ip, _dp, C_double, _dp, _i, _i, _i, _dp, _dp, _dp, ip, ip, _i, _dp]
+    f.restype = _i
+    n = f(kind, m, m, cap, nLevels, C_, f1.shape[1], f2.shape[1], V1, a1, f1, V2, a2, f2, float(target), params, int(nKept), 1 if train else 0,
+          int(seed), pred, loss, grads, phi1, phi2, stride, gfeat)
+    assert n == params.size, (n, params.size)
+    return {"phi1": phi1, "phi2": phi2, "predict": float(pred[0]), "loss": float(loss[0]), "grads": grads, "graph_feature": gfeat}
+
+
+def reference_model_batchlearn(kind, graphs1, graphs2, targets, nLevels, C_, cap, maxV, nIter, learning_rate, seed, n_params):
+    """nIter x the REAL BatchLearn of SMP_omega_physics (kind 0) / SMP_beta_physics (1) / SMP_omega_pairgraphs (10) /
+    SMP_beta_pairgraphs (11), weights drawn by the constructor after srand(seed)."""
+    ref = reference()
+    if ref is None:
+        return None
+
+    def pack(gs):
+        nV = np.array([len(a) for a, _ in gs], dtype=np.int32)
+        adj = np.concatenate([np.asarray(a, dtype=np.int32).ravel() for a, _ in gs])
+        feat = np.concatenate([np.asarray(f, dtype=np.float64).ravel() for _, f in gs])
+        return nV, adj, feat
+    a = pack(graphs1)
+    b = pack(graphs2 if graphs2 is not None else graphs1)
+    tg = np.ascontiguousarray(targets, dtype=np.float64)
+    p0, p1, losses = np.zeros(n_params), np.zeros(n_params), np.zeros((nIter, 2))
+    f = ref.lib.ref_smp_model_batchlearn
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f.argtypes = [_i] * 8 + [ip, ip, _dp, ip, ip, _dp, _dp, _i, _i, C_double, _dp, _dp, _dp]
+    f.restype = _i
+    n = f(kind, maxV, cap, nLevels, C_, graphs1[0][1].shape[1], (graphs2 or graphs1)[0][1].shape[1], len(graphs1), a[0], a[1], a[2], b[0], b[1],
+          b[2], tg, int(seed), nIter, float(learning_rate), p0, losses, p1)
+    assert n == n_params, (n, n_params)
+    return {"params0": p0, "params": p1, "losses": losses}

@@ -608,3 +608,165 @@ extern "C" double ref_smp_omega_threaded_time(int nThreads, int max_nVertices, i
     gettimeofday(&t1, NULL);
     return (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The `_physics` and `_pairgraphs` drivers: raw features, halving channels, every level read out, an MLP head.
+// One sample, dumped parameters in the class's own registration order (sgd->params), forward + backward.
+// ---------------------------------------------------------------------------------------------------------------
+#include "SMP_omega_physics.h"
+#include "SMP_beta_physics.h"
+#include "SMP_omega_pairgraphs.h"
+#include "SMP_beta_pairgraphs.h"
+#include "SMP_sigma_pairgraphs.h"
+
+namespace {
+DenseGraph *make_graph(int V, int F, const int *adj, const double *feature) {
+    DenseGraph *g = new DenseGraph(V, F);
+    for (int i = 0; i < V; ++i) {
+        for (int j = 0; j < V; ++j) g->adj[i][j] = adj[i * V + j];
+        for (int f = 0; f < F; ++f) g->feature[i][f] = feature[i * F + f];
+    }
+    return g;
+}
+template <class Net>
+int set_params(Net &net, const double *params) {
+    size_t off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) net.sgd->params[i]->value[j] = params[off++];
+    return (int)off;
+}
+template <class Net>
+int get_grads(Net &net, double *grads) {
+    size_t off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) grads[off++] = net.sgd->params[i]->gradient[j];
+    return (int)off;
+}
+template <class Level>
+void dump_phi(Level **level, int nLevels, int V, int stride, int *phi) {
+    for (int l = 0; l <= nLevels; ++l)
+        for (int v = 0; v < V; ++v) {
+            int *p = phi + ((size_t)l * V + v) * stride;
+            const std::vector<int> &f = level[l]->phi[v];
+            p[0] = (int)f.size();
+            for (size_t i = 0; i < f.size(); ++i) p[1 + i] = f[i];
+        }
+}
+template <class Net>
+int physics_run(Net &net, int nLevels, int nFeatures, int V, const int *adj, const double *feature, double target, const double *params,
+                double *predict, double *loss, double *grads, int *phi, int phi_stride, double *graph_feature) {
+    set_params(net, params);
+    DenseGraph *g = make_graph(V, nFeatures, adj, feature);
+    net.complete_computation_graph(g);
+    net.target->value[0] = target;
+    net.graph->forward();
+    net.graph->backward();
+    *predict = net.predict->value[0];
+    *loss = net.sql->getLoss();
+    if (graph_feature)
+        for (int i = 0; i < net.graph_feature->size; ++i) graph_feature[i] = net.graph_feature->value[i];
+    dump_phi(net.level, nLevels, V, phi_stride, phi);
+    return get_grads(net, grads);
+}
+template <class Net>
+int pair_run(Net &net, int nLevels, int F1, int F2, int V1, const int *adj1, const double *feat1, int V2, const int *adj2,
+             const double *feat2, double target, const double *params, double *predict, double *loss, double *grads, int *phi1,
+             int *phi2, int phi_stride, double *graph_feature) {
+    set_params(net, params);
+    DenseGraph *g1 = make_graph(V1, F1, adj1, feat1), *g2 = make_graph(V2, F2, adj2, feat2);
+    net.complete_computation_graph(g1, g2);
+    net.target->value[0] = target;
+    net.graph->forward();
+    net.graph->backward();
+    *predict = net.predict->value[0];
+    *loss = net.sql->getLoss();
+    if (graph_feature)
+        for (int i = 0; i < net.graph_feature->size; ++i) graph_feature[i] = net.graph_feature->value[i];
+    dump_phi(net.level_1, nLevels, V1, phi_stride, phi1);
+    dump_phi(net.level_2, nLevels, V2, phi_stride, phi2);
+    return get_grads(net, grads);
+}
+}  // namespace
+
+// beta != 0: SMP_beta_physics (no receptive-field cap).  Returns the parameter count.
+extern "C" int ref_smp_physics_run(int beta, int max_nVertices, int max_rf, int nLevels, int nChanels, int nFeatures, int V, const int *adj,
+                                   const double *feature, double target, const double *params, double *predict, double *loss,
+                                   double *grads, int *phi, int phi_stride, double *graph_feature) {
+    if (beta) {
+        SMP_beta_physics &net = *new SMP_beta_physics(max_nVertices, nLevels, nChanels, nFeatures);
+        return physics_run(net, nLevels, nFeatures, V, adj, feature, target, params, predict, loss, grads, phi, phi_stride, graph_feature);
+    }
+    SMP_omega_physics &net = *new SMP_omega_physics(max_nVertices, max_rf, nLevels, nChanels, nFeatures);
+    return physics_run(net, nLevels, nFeatures, V, adj, feature, target, params, predict, loss, grads, phi, phi_stride, graph_feature);
+}
+
+// kind 0: SMP_omega_pairgraphs, 1: SMP_beta_pairgraphs, 2: SMP_sigma_pairgraphs (RisiContraction_18_dropout; nKept slices kept;
+// train != 0: the masks are drawn with rand() after srand(seed), test mode otherwise).  Returns the parameter count.
+extern "C" int ref_smp_pairgraphs_run(int kind, int maxV1, int maxV2, int max_rf, int nLevels, int nChanels, int F1, int F2, int V1,
+                                      const int *adj1, const double *feat1, int V2, const int *adj2, const double *feat2, double target,
+                                      const double *params, int nKept, int train, int seed, double *predict, double *loss, double *grads,
+                                      int *phi1, int *phi2, int phi_stride, double *graph_feature) {
+    if (kind == 1) {
+        SMP_beta_pairgraphs &net = *new SMP_beta_pairgraphs(maxV1, maxV2, nLevels, nChanels, F1, F2);
+        return pair_run(net, nLevels, F1, F2, V1, adj1, feat1, V2, adj2, feat2, target, params, predict, loss, grads, phi1, phi2, phi_stride, graph_feature);
+    }
+    if (kind == 2) {
+        SMP_sigma_pairgraphs &net = *new SMP_sigma_pairgraphs(maxV1, maxV2, max_rf, nLevels, nChanels, F1, F2, nKept);
+        net.setMode(train != 0);
+        srand((unsigned)seed);
+        return pair_run(net, nLevels, F1, F2, V1, adj1, feat1, V2, adj2, feat2, target, params, predict, loss, grads, phi1, phi2, phi_stride, graph_feature);
+    }
+    SMP_omega_pairgraphs &net = *new SMP_omega_pairgraphs(maxV1, maxV2, max_rf, nLevels, nChanels, F1, F2);
+    return pair_run(net, nLevels, F1, F2, V1, adj1, feat1, V2, adj2, feat2, target, params, predict, loss, grads, phi1, phi2, phi_stride, graph_feature);
+}
+
+// nIter x the REAL BatchLearn of the `_physics` (kind 0 omega, 1 beta) or `_pairgraphs` (kind 10 omega, 11 beta) class from the
+// weights its constructor draws after srand(seed) (weights_initialization); returns params0, the (before, after) losses and the
+// parameters afterwards.  Graphs back to back as in ref_smp_omega_batchlearn; the second set is ignored for the physics kinds.
+namespace {
+std::vector<DenseGraph *> unpack_graphs(int nMol, int F, const int *nV, const int *adj, const double *feature) {
+    std::vector<DenseGraph *> g(nMol);
+    size_t ao = 0, fo = 0;
+    for (int m = 0; m < nMol; ++m) {
+        g[m] = make_graph(nV[m], F, adj + ao, feature + fo);
+        ao += (size_t)nV[m] * nV[m];
+        fo += (size_t)nV[m] * F;
+    }
+    return g;
+}
+template <class Net>
+int dump_params(Net &net, double *out) {
+    size_t off = 0;
+    for (size_t i = 0; i < net.sgd->params.size(); ++i)
+        for (int j = 0; j < net.sgd->params[i]->size; ++j) out[off++] = net.sgd->params[i]->value[j];
+    return (int)off;
+}
+}  // namespace
+
+extern "C" int ref_smp_model_batchlearn(int kind, int maxV, int max_rf, int nLevels, int nChanels, int F1, int F2, int nMol, const int *nV1,
+                                        const int *adj1, const double *feat1, const int *nV2, const int *adj2, const double *feat2,
+                                        const double *targets, int seed, int nIter, double learning_rate, double *params0,
+                                        double *losses /* [nIter][2] */, double *params_out) {
+    srand((unsigned)seed);
+    std::vector<DenseGraph *> g1 = unpack_graphs(nMol, F1, nV1, adj1, feat1), g2;
+    std::vector<double> tgt(targets, targets + nMol);
+    int n = 0;
+#define GF_RUN(NET, CALL)                                                   \
+    {                                                                       \
+        NET;                                                                \
+        dump_params(net, params0);                                          \
+        for (int it = 0; it < nIter; ++it) {                                \
+            std::pair<double, double> r = CALL;                             \
+            losses[2 * it] = r.first;                                       \
+            losses[2 * it + 1] = r.second;                                  \
+        }                                                                   \
+        n = dump_params(net, params_out);                                   \
+    }
+    if (kind == 0) GF_RUN(SMP_omega_physics &net = *new SMP_omega_physics(maxV, max_rf, nLevels, nChanels, F1), net.BatchLearn(nMol, &g1[0], &tgt[0], learning_rate))
+    if (kind == 1) GF_RUN(SMP_beta_physics &net = *new SMP_beta_physics(maxV, nLevels, nChanels, F1), net.BatchLearn(nMol, &g1[0], &tgt[0], learning_rate))
+    if (kind >= 10) g2 = unpack_graphs(nMol, F2, nV2, adj2, feat2);
+    if (kind == 10) GF_RUN(SMP_omega_pairgraphs &net = *new SMP_omega_pairgraphs(maxV, maxV, max_rf, nLevels, nChanels, F1, F2), net.BatchLearn(nMol, &g1[0], &g2[0], &tgt[0], learning_rate))
+    if (kind == 11) GF_RUN(SMP_beta_pairgraphs &net = *new SMP_beta_pairgraphs(maxV, maxV, nLevels, nChanels, F1, F2), net.BatchLearn(nMol, &g1[0], &g2[0], &tgt[0], learning_rate))
+#undef GF_RUN
+    return n;
+}

@@ -313,6 +313,80 @@ def headline_fixture():
     np.savez_compressed(os.path.join(HERE, "smp_headline.npz"), **out)
 
 
+def physics_fixtures():
+    """the `_physics` (one tower) and `_pairgraphs` (two towers) drivers of the real reference -- raw features, the
+    distance-only cap order, channels halving per level, every level read out, MLP heads -- and SMP_sigma_pairgraphs with
+    RisiContraction_18_dropout in train (masks drawn after srand) and test mode.  One sample each, dumped parameters in the
+    class's registration order; kept: receptive fields, the concatenated feature row, predict, loss, all parameter gradients."""
+    out = {}
+    rng = np.random.default_rng(8303)
+    g12 = synthetic_molecule(5, 12)
+    g9 = synthetic_molecule(6, 9)
+    g17 = synthetic_molecule(9, 17)
+
+    def tower_n(C, F, L):
+        return pyoracle.physics_tower_param_count(C, F, L)
+
+    for tag, (g, L, C, cap, beta) in {"phys_omega_cap6": (g12, 2, 8, 6, False), "phys_omega_L3_c10": (g17, 3, 10, 8, False),
+                                      "phys_beta": (g12, 2, 8, 12, True)}.items():
+        adj, feat, tgt = g
+        F = feat.shape[1]
+        width = sum(pyoracle.physics_channels(C, L))
+        nh = width // 2
+        n = tower_n(C, F, L) + nh * width + nh
+        params = f32exact(rng.uniform(-0.3, 0.3, n))
+        r = pyoracle.reference_smp_physics(adj, feat, tgt, params, L, C, cap, beta=beta, max_nVertices=len(adj))
+        p = "physics_" + tag
+        out[p + "__adj"], out[p + "__feature"], out[p + "__target"] = adj.astype(np.int32), feat, np.array([tgt])
+        out[p + "__cfg"] = np.array([1, L, C, cap, 0, 1], dtype=np.int32)   # towers, L, C, cap, nKept, train
+        out[p + "__params"] = params.astype(np.float32)
+        out[p + "__phi"], out[p + "__graph_feature"] = r["phi"], r["graph_feature"]
+        out[p + "__predict"], out[p + "__loss"], out[p + "__grads"] = np.array([r["predict"]]), np.array([r["loss"]]), r["grads"]
+    for tag, (kind, ga, gb, L, C, cap, nKept, train, seed) in {"pair_omega": (0, g12, g9, 2, 8, 6, 0, 1, 0), "pair_beta": (1, g9, g12, 2, 8, 12, 0, 1, 0),
+                                                               "pair_sigma_train": (2, g12, g9, 2, 8, 6, 7, 1, 5),
+                                                               "pair_sigma_test": (2, g12, g9, 2, 8, 6, 7, 0, 5)}.items():
+        F1, F2 = ga[1].shape[1], gb[1].shape[1]
+        nTot = 2 * sum(pyoracle.physics_channels(C, L))
+        h1 = max(nTot // 2, 10)
+        h2 = max(h1 // 2, 10)
+        n = tower_n(C, F1, L) + tower_n(C, F2, L) + h1 * nTot + h2 * h1 + h2
+        params = f32exact(rng.uniform(-0.3, 0.3, n))
+        tgt = ga[2]
+        maxV = max(len(ga[0]), len(gb[0]))
+        r = pyoracle.reference_smp_pairgraphs(kind, ga[:2], gb[:2], tgt, params, L, C, cap, nKept=max(nKept, 1), train=bool(train), seed=seed, maxV=maxV)
+        p = "physics_" + tag
+        out[p + "__adj"], out[p + "__feature"], out[p + "__target"] = ga[0].astype(np.int32), ga[1], np.array([tgt])
+        out[p + "__adj2"], out[p + "__feature2"] = gb[0].astype(np.int32), gb[1]
+        out[p + "__cfg"] = np.array([2, L, C, cap, nKept, train], dtype=np.int32)
+        out[p + "__seed"] = np.array([seed], dtype=np.int32)
+        out[p + "__params"] = params.astype(np.float32)
+        out[p + "__phi"], out[p + "__phi2"], out[p + "__graph_feature"] = r["phi1"], r["phi2"], r["graph_feature"]
+        out[p + "__predict"], out[p + "__loss"], out[p + "__grads"] = np.array([r["predict"]]), np.array([r["loss"]]), r["grads"]
+    # three BatchLearn steps of the real SMP_omega_physics / SMP_omega_pairgraphs on the toy molecules of the reference's
+    # tests/test_SMP_omega_physics.cpp / test_SMP_omega_pairgraphs.cpp (all 16 ordered pairs, target = difference of the atom
+    # counts), from the weights the constructors draw after srand(7)
+    mols = [(a, f) for _, a, f, _ in toy_molecules()]
+    tg = [t for *_, t in toy_molecules()]
+    L, C, cap, maxV = 2, 16, 4, 10
+    nt = tower_n(C, 4, L)
+    w = sum(pyoracle.physics_channels(C, L))
+    r = pyoracle.reference_model_batchlearn(0, mols, None, tg, L, C, cap, maxV, 3, 1e-3, 7, nt + (w // 2) * w + w // 2)
+    out.update({"trainphys__cfg": np.array([L, C, cap, maxV, 7, 3], dtype=np.int32), "trainphys__lr": np.array([1e-3]),
+                "trainphys__targets": np.array(tg), "trainphys__params0": r["params0"], "trainphys__params": r["params"],
+                "trainphys__losses": r["losses"]})
+    g1 = [mols[i] for i in range(4) for j in range(4)]
+    g2 = [mols[j] for i in range(4) for j in range(4)]
+    t2 = [tg[i] - tg[j] for i in range(4) for j in range(4)]
+    nTot = 2 * w
+    h1 = max(nTot // 2, 10)
+    h2 = max(h1 // 2, 10)
+    r = pyoracle.reference_model_batchlearn(10, g1, g2, t2, L, C, cap, maxV, 3, 1e-3, 7, 2 * nt + h1 * nTot + h2 * h1 + h2)
+    out.update({"trainpair__cfg": np.array([L, C, cap, maxV, 7, 3], dtype=np.int32), "trainpair__lr": np.array([1e-3]),
+                "trainpair__targets": np.array(t2), "trainpair__params0": r["params0"], "trainpair__params": r["params"],
+                "trainpair__losses": r["losses"]})
+    np.savez_compressed(os.path.join(HERE, "smp_physics.npz"), **out)
+
+
 def checkpoint_fixture():
     """smp_syn12's parameters as SMP_omega::save_model writes them (SMP_omega.h:1033-1042): a data file, 6 significant digits."""
     for i, (tag, adj, feat, tgt, (L, C, D, cap, wl, maxV)) in enumerate(smp_cases()):
@@ -333,15 +407,20 @@ def main():
     np.savez_compressed(os.path.join(HERE, "smp.npz"), **smp_fixtures())
     checkpoint_fixture()
     train_fixture()
+    physics_fixtures()
     headline_fixture()
     with open(os.path.join(HERE, "structural_50.json"), "w") as fh:
         json.dump(structural_50(), fh, indent=1)
-    for f in ("contractions.npz", "mixers.npz", "smp.npz", "structural_50.json", "smp_syn12_checkpoint.txt", "dropout.npz", "smp_train.npz", "smp_headline.npz"):
+    for f in ("contractions.npz", "mixers.npz", "smp.npz", "structural_50.json", "smp_syn12_checkpoint.txt", "dropout.npz", "smp_train.npz", "smp_headline.npz", "smp_physics.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "headline":   # only the (slow) headline fixture
+    if len(sys.argv) > 1 and sys.argv[1] == "physics":
+        pyoracle.build()
+        physics_fixtures()
+        print("smp_physics.npz", os.path.getsize(os.path.join(HERE, "smp_physics.npz")), "bytes")
+    elif len(sys.argv) > 1 and sys.argv[1] == "headline":   # only the (slow) headline fixture
         pyoracle.build()
         headline_fixture()
         print("smp_headline.npz", os.path.getsize(os.path.join(HERE, "smp_headline.npz")), "bytes")

@@ -74,3 +74,12 @@ def test_model_level_dropin_reproduces_reference_training(bins):
     r = subprocess.run([os.path.join(bins, "test_SMP_omega_hip")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASSED" in r.stdout
+
+
+@pytest.mark.gpu
+def test_physics_and_pairgraphs_dropins_reproduce_reference_training(bins):
+    """SMP_omega_physics_hip / SMP_omega_pairgraphs_hip (+ beta, sigma) on the toy molecules of the reference's
+    tests/test_SMP_omega_physics.cpp / test_SMP_omega_pairgraphs.cpp: same srand -> the real classes' loss trajectories."""
+    r = subprocess.run([os.path.join(bins, "test_SMP_physics_hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASSED" in r.stdout

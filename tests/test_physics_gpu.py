@@ -1,0 +1,82 @@
+"""GPU parity for SURVEY 8 f3's drivers: SMP_omega_physics / SMP_beta_physics (one tower) and SMP_omega_pairgraphs /
+SMP_beta_pairgraphs / SMP_sigma_pairgraphs (two towers, the last with RisiContraction_18_dropout), through gf_smp_model_*,
+against goldens captured from the REAL reference classes (tests/golden/smp_physics.npz, make_golden.py: physics_fixtures)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from util import golden_cases, rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+TOL = 1e-5
+
+
+def cases():
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "smp_physics.npz")) as z:
+        return golden_cases({k: z[k] for k in z.files}, "physics_")
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def run(c):
+    from graphflow_amd.smp import SMPModel
+    towers, L, Cn, cap, nKept, train = (int(x) for x in c["cfg"])
+    feats = [c["feature"].shape[1]] + ([c["feature2"].shape[1]] if towers == 2 else [])
+    net = SMPModel(L, Cn, cap, feats, nKept=nKept)
+    assert net.n_params == c["params"].size
+    net.prepare([(c["adj"], c["feature"])], [(c["adj2"], c["feature2"])] if towers == 2 else None)
+    net.set_mode(bool(train))
+    if nKept and train:
+        C.CDLL(None).srand(int(c["seed"][0]))   # the reference drew its slice masks with rand() after this srand
+    p = dev(c["params"])
+    pred, loss = net.forward(p, dev(c["target"]))
+    g = torch.full((net.n_params,), float("nan"), device="cuda")
+    if train:
+        net.backward(p, g)
+    return pred.cpu().numpy().astype(np.float64), loss.cpu().numpy().astype(np.float64), g.cpu().numpy().astype(np.float64), net
+
+
+def test_physics_and_pairgraphs_goldens(gf):
+    cs = cases()
+    assert len(cs) >= 7
+    for tag, c in cs.items():
+        pred, loss, grads, net = run(c)
+        e = (rel_err(pred, c["predict"]), rel_err(loss, c["loss"]))
+        assert e[0] <= TOL and e[1] <= 2 * TOL, (tag, e)
+        if int(c["cfg"][5]):
+            eg = rel_err(grads, c["grads"])
+            print("%-28s predict %.2e loss %.2e grads %.2e" % (tag, e[0], e[1], eg))
+            assert eg <= TOL, (tag, eg)
+        net.close()
+
+
+def test_batch_is_the_sum_of_its_samples(gf):
+    """Three copies of the pair sample and one different pair as one batch: per-sample predictions unchanged, gradient = sum."""
+    from graphflow_amd.smp import SMPModel
+    cs = cases()
+    a, b = cs["physics_pair_omega"], cs["physics_pair_beta"]
+    towers, L, Cn, cap, _, _ = (int(x) for x in a["cfg"])
+    net = SMPModel(L, Cn, 12, [5, 5])
+    p = dev(a["params"])
+    g1 = [(a["adj"], a["feature"]), (b["adj"], b["feature"]), (a["adj"], a["feature"])]
+    g2 = [(a["adj2"], a["feature2"]), (b["adj2"], b["feature2"]), (a["adj2"], a["feature2"])]
+    t = dev(np.array([12.0, 9.0, 3.0]))
+    net.prepare(g1, g2)
+    pred = net.forward(p, t)[0].clone()
+    g = torch.empty(net.n_params, device="cuda")
+    net.backward(p, g)
+    total = torch.zeros_like(g)
+    for i in range(3):
+        net.prepare([g1[i]], [g2[i]])
+        pi = net.forward(p, t[i:i + 1])[0]
+        assert abs(float(pi[0]) - float(pred[i])) <= 1e-6 * max(1.0, abs(float(pred[i])))
+        net.backward(p, total, accumulate=True)
+    assert rel_err(g.cpu().numpy(), total.cpu().numpy()) <= 2e-6
+    with pytest.raises(Exception):
+        net.forward(p)
+        net.backward(p, g)   # no targets in the last forward

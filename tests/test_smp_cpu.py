@@ -220,3 +220,30 @@ def test_c_port_at_the_headline_shape(golden):
     act = c["act_l%d_v%d" % (l, v)].astype(np.float64)
     assert np.abs(o["f"] - act).max() <= 1e-6 * np.abs(act).max()
     assert np.abs(activation_digest(o["f"]) - c["act_digest"][l, v]).max() <= 1e-10 * np.abs(c["act_digest"][l, v]).max()
+
+
+def test_physics_host_preparation_matches_reference_goldens(gf):
+    """The `_physics` / `_pairgraphs` receptive fields (no WL ordering, cap ordered by hop distance only:
+    SMP_omega_physics.h:436-478) from gf_smp_prepare_molecule_host with cfg.physics = 1, list for list."""
+    import os
+    from graphflow_amd import _lib
+    from graphflow_amd.smp import SMPConfig
+    lib = _lib.load()
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "smp_physics.npz")) as z:
+        cs = golden_cases({k: z[k] for k in z.files}, "physics_")
+    checked = 0
+    for tag, c in cs.items():
+        towers, L, Cn, cap, _, _ = (int(x) for x in c["cfg"])
+        for adj_k, feat_k, phi_k in (("adj", "feature", "phi"), ("adj2", "feature2", "phi2"))[:towers]:
+            adj = np.ascontiguousarray(c[adj_k], dtype=np.int32)
+            feat = np.ascontiguousarray(c[feat_k], dtype=np.float64)
+            V, F = feat.shape
+            cfg = SMPConfig(L, Cn, F, 0, min(cap, V) if "beta" in tag else cap, 0, 18, 0, 1)
+            stride = cfg.max_receptive_field + 1
+            phi = np.zeros((L + 1, V, stride), dtype=np.int32)
+            st = lib.gf_smp_prepare_molecule_host(C.byref(cfg), V, adj.ctypes.data_as(C.POINTER(C.c_int)),
+                                                  feat.ctypes.data_as(C.POINTER(C.c_double)), phi.ctypes.data_as(C.POINTER(C.c_int)), None)
+            assert st == 0
+            assert fields_of(phi) == fields_of(c[phi_k]), (tag, adj_k)
+            checked += 1
+    assert checked >= 10
