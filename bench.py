@@ -222,26 +222,28 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
     def add(d, k, v):
         d[k] = d.get(k, 0) + v
 
+    c64 = C == 64
+    # projected matrix O / dO: [O_loc | U] (2C) when the three dedicated C = 64 product kernels run, else [O_loc | Z | Z'] (3C)
+    oc = 2 if (c64 and all(os.environ.get(k, "1") != "0" for k in ("GF_SMP_ROWPANEL", "GF_SMP_WGRAD", "GF_SMP_GROUPED", "GF_SMP_COMPACT_O"))) else 3
     for l in range(1, L + 1):
         _, R, S = sizes[l]
         _, Rp, _ = sizes[l - 1]
         unit = 2 * R * C * C                                     # one C x C block product over all rows
         if fused:
             add(kb, "smpf_tables_fwd", 4 * (Rp * C + 4 * R * C))        # gather f_{l-1} (cached), write 4 tables
-            add(kb, "smpf_combine_fwd", 4 * (3 * R * C + R * C))        # O = [O_loc | Z | Z'] in, f_l out
-            add(kb, "smpf_combine_bwd", 4 * (2 * R * C + 3 * R * C))
+            add(kb, "smpf_combine_fwd", 4 * (oc * R * C + R * C))       # O in, f_l out
+            add(kb, "smpf_combine_bwd", 4 * (2 * R * C + oc * R * C))
             if os.environ.get("GF_SMP_BWD_GATHER", "1") != "0":           # dP evaluated inside the consumer gather
                 add(kb, "smpf_bwd_gather", 4 * (4 * R * C + Rp * C))    # table gradients in (once), df_{l-1} out
             else:
                 add(kb, "smpf_tables_bwd", 4 * (4 * R * C + S * C))
                 add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
-            c64 = C == 64
             names = (("smpf_products_fwd" if c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0" else "gemm_nn"),
                      ("smpf_products_bwd" if c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0" else "gemm_nt"),
                      ("smpf_wgrad" if c64 and os.environ.get("GF_SMP_WGRAD", "1") != "0" else "gemm_tn"))
             for k in names:
                 add(kf, k, 8 * unit)
-                add(kb, k, 4 * (4 * R * C + 3 * R * C))                  # T (4C) and O / dO (3C) per row, each once
+                add(kb, k, 4 * (4 * R * C + oc * R * C))                 # T (4C) and O / dO per row, each once
         else:
             add(kb, "smp_promote_fwd", 4 * (Rp * C + S * C))
             add(kb, "r18_fwd_slab", 4 * (S * C + 10 * R * C))
@@ -325,10 +327,11 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
         """Training loop with a NEW batch every step: gf_smp_prepare (host graph preparation + upload) of batch i+1 on a second
         handle while the device runs forward + backward + Adam of batch i.  molecules/s of this rank."""
         pool = [synthetic_molecule(7000003 + rank * 1000003 + i) for i in range(3 * B)]
-        batches = [(mols, targets)]
+        # (a data loader hands over flat arrays: packing the Python molecule lists is input generation, like drawing them)
+        batches = [(SMPOmega.pack(mols), targets)]
         for i in range(3):
             sl = pool[i * B:(i + 1) * B]
-            batches.append(([(a, f) for a, f, _ in sl], torch.as_tensor(np.array([t for *_, t in sl], dtype=np.float32)).to(dev)))
+            batches.append((SMPOmega.pack([(a, f) for a, f, _ in sl]), torch.as_tensor(np.array([t for *_, t in sl], dtype=np.float32)).to(dev)))
         nets = [net, SMPOmega(L, C, F, D, cap, True, ctx=ctx)]
         nets[1].set_fused(fused)
         p = params.clone()

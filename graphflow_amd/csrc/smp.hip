@@ -402,6 +402,13 @@ __global__ void readout_backward_nodevec(const float *__restrict__ dy, const flo
 
 __global__ void zero_f32(float *p, size_t n) { GRID_STRIDE(i, n) p[i] = 0.f; }
 
+// trow[row of (x, e)] = row of (e, x) inside the same node (compact O layout of the fused C = 64 level, smp_level_c64.hip)
+__global__ void build_trow(int *__restrict__ trow, const int *__restrict__ node_s, const long long *__restrict__ node_row) {
+    const int n = blockIdx.x, s = node_s[n];
+    const long long r0 = node_row[n];
+    for (int i = threadIdx.x; i < s * s; i += blockDim.x) trow[r0 + i] = (int)(r0 + (long long)(i % s) * s + i / s);
+}
+
 // RisiContraction_18_dropout over the nodes of a level: slice k of node n is multiplied by scale if bit k of keep[n] is set,
 // else zeroed (RisiContraction_18_dropout.h:106-132 forward, :479-510 backward: dropped slices neither produce nor receive)
 __global__ void node_slice_scale(float *__restrict__ Q, const int *__restrict__ node_s, const long long *__restrict__ node_row,
@@ -994,6 +1001,10 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (st != GF_OK) return st;
         UP(d.pi, h.pi);
         UP(d.inv, h.inv);
+        if (!s->cfg.physics && C == 64 && h.rows < 0x7fffffffll) {
+            st = gf::upload(s, &d.trow, nullptr, (size_t)h.rows);
+            if (st != GF_OK) return st;
+        }
         st = gf::upload(s, &d.Q, nullptr, (size_t)h.rows * std::max(18, s->cfg.nContractions) * Cp);
         if (st != GF_OK) return st;
         if (!s->cfg.physics) {
@@ -1013,6 +1024,11 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         }
         contract_ws = std::max(contract_ws, gf::r18_ragged_workspace_bytes((long long)h.rows, (long long)h.pairs, Cp));
     }
+    // (the node tables went up on the handle's upload stream: build the transposed-row tables there too, behind them)
+    for (int l = 1; l <= L; ++l)
+        if (s->lv[l].trow)
+            hipLaunchKernelGGL(gf::build_trow, dim3(B.level[l].nNodes), dim3(64), 0, s->upload ? s->upload : ctx->stream, s->lv[l].trow,
+                               s->lv[l].node_s, s->lv[l].node_row);
     UP(s->x, B.x);
     s->P = nullptr;  // [max ppos][C]: by far the largest buffer of the op-by-op path, taken from the pool only when a level needs it
     s->P_count = (size_t)maxp;  // (positions x channels of the level below, maximised over the levels)

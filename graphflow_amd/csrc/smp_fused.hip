@@ -308,11 +308,11 @@ __global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict_
                                 const long long *__restrict__ prev_pair, const long long *__restrict__ cons_ptr,
                                 const long long *__restrict__ cons_row, const int *__restrict__ cons_s,
                                 const int *__restrict__ cons_a, const long long *__restrict__ cons_inv_off,
-                                const short *__restrict__ inv, int C) {
+                                const short *__restrict__ inv, int C, int ocols) {
     const int w = blockIdx.x;
     const int sw = prev_s[w], nl = C / 4;
     const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
-    const size_t ldo = (size_t)O_COLS * C;
+    const size_t ldo = (size_t)ocols * C;
     float *dst = dGc + (size_t)prev_pair[w] * 2 * C;
     for (int i = threadIdx.x; i < sw * nl; i += blockDim.x) {
         const int fl = i % nl, p = i / nl;
@@ -490,8 +490,10 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
                                                             const int *__restrict__ node_s, const long long *__restrict__ node_row,
                                                             const long long *__restrict__ node_pair, int C, int nwin,
                                                             const float *__restrict__ Gc, const long long *__restrict__ pair_src_pair,
-                                                            const short *__restrict__ pi, const float *__restrict__ rsum) {
+                                                            const short *__restrict__ pi, const float *__restrict__ rsum,
+                                                            int ocols) {  // 3: O = [O_loc | Z | Z']; 2: O = [O_loc | U], U = Z + Z'^T
     constexpr int CW = 4 * LPC;
+    const size_t ldo = (size_t)ocols * C;
     constexpr int NGRP = kThreads / LPC;
     const int tid = threadIdx.x;
     const int grp = tid / LPC, fl = tid % LPC;
@@ -507,9 +509,8 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
     float *sU = smem + adj_lds_floats(N);  // [kCombX][N][CW]  Z[x,e] + Z'[e,x] (+ compact terms)
     for (int it = grp; it < items; it += NGRP) {
         const int xi = it / N, e = it - xi * N, x = W.x0 + xi;
-        const f4 z = ld4(O + (rowbase + (size_t)x * N + e) * (size_t)(O_COLS * C) + O_Z * C + fc);
-        const f4 zp = ld4(O + (rowbase + (size_t)e * N + x) * (size_t)(O_COLS * C) + O_ZP * C + fc);
-        f4 u = z + zp;
+        f4 u = ld4(O + (rowbase + (size_t)x * N + e) * ldo + O_Z * C + fc);
+        if (ocols == 3) u += ld4(O + (rowbase + (size_t)e * N + x) * ldo + O_ZP * C + fc);
         {  // + D_bb[x,e] K15 + D_ac[e,x] K16, gathered from the compact products of the level below
             const int pxe = pi[rowbase + (size_t)x * N + e], pex = pi[rowbase + (size_t)e * N + x];
             const f4 g15 = ld4(Gc + (size_t)(pair_src_pair[pairbase + x] + (pxe >= 0 ? pxe : 0)) * 2 * C + fc);
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
         f4 m[1];
         small_matvec<1, CW>(L, N, y, fl, Tt, m);
         const f4 vout = ld4(Vout + (pairbase + x) * (size_t)C + fc);
-        const float *o = O + (rowbase + (size_t)x * N + y) * (size_t)(O_COLS * C) + fc;
+        const float *o = O + (rowbase + (size_t)x * N + y) * ldo + fc;
         const f4 z = bb + ld4(o + O_LOC * C) + m[0] + L.r[y] * vout + L.at(x, y, N) * sout;
         if (fok) {
             f4 out;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                                                             const int *__restrict__ quad_b0, const int *__restrict__ node_s,
                                                             const long long *__restrict__ node_row,
                                                             const long long *__restrict__ node_pair, int C, int nwin,
-                                                            const float *__restrict__ rsum) {
+                                                            const float *__restrict__ rsum, int ocols) {
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
     const int tid = threadIdx.x;
@@ -564,6 +565,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
     const int f = W.win * CW + 4 * fl;
     const bool fok = f < C;
     const int fc = fok ? f : 0;
+    const size_t ldo = (size_t)ocols * C;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AdjLds L = load_adjacency_lite<true>(smem, A + rowbase, rsum + pairbase, N);  // L.A[e][y] = A+[y][e]; see the barrier below
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
         for (int j = 0; j < 4; ++j) dz[j] = fok ? g[j] * (fv[j] > 0.f ? 1.f : kAlphaF) : 0.f;
         st4(sDz + (size_t)it * CW + 4 * fl, dz);
         if (fok) {
-            st4(dO + row * (size_t)(O_COLS * C) + O_LOC * C + f, dz);
+            st4(dO + row * ldo + O_LOC * C + f, dz);
         }
     }
     __syncthreads();
@@ -588,8 +590,8 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
         f4 m[1];
         small_matvec<1, CW>(L, N, e, fl, Tt, m);  // dU[e] = sum_y A+[y][e] dz[y]
         if (fok) {
-            st4(dO + (rowbase + (size_t)x * N + e) * (size_t)(O_COLS * C) + O_Z * C + f, m[0]);
-            st4(dO + (rowbase + (size_t)e * N + x) * (size_t)(O_COLS * C) + O_ZP * C + f, m[0]);
+            st4(dO + (rowbase + (size_t)x * N + e) * ldo + O_Z * C + f, m[0]);
+            if (ocols == 3) st4(dO + (rowbase + (size_t)e * N + x) * ldo + O_ZP * C + f, m[0]);
         }
     }
     if (fok) {
@@ -994,6 +996,12 @@ gf_status launch_bwd_gather(gf_smp *s, int l, int w0, int w1, const float *dT) {
 }  // namespace
 
 bool smp_grouped_small(const gf_smp *s);
+// compact projected matrix O = [O_loc | U] (2C) instead of [O_loc | Z | Z'] (3C): needs the three dedicated C = 64 product kernels
+// (they gather the transposed rows themselves) and the batched reverse sweep; GF_SMP_COMPACT_O=0 keeps the three-block layout
+bool smp_compact_o(const gf_smp *s) {
+    return s->cfg.nChanels == 64 && smp_grouped_small(s) && !env_is("GF_SMP_ROWPANEL", '0') && !env_is("GF_SMP_WGRAD", '0') &&
+           !env_is("GF_SMP_COMPACT_O", '0');
+}
 gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *dbl);
 
 // every level's block-permuted weight copy in one launch (gf_smp_forward, before the first level)
@@ -1092,7 +1100,8 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         ctx->stream = swap.saved;
         swap.on = false;
     }
-    const int ldt = T_COLS * C, ldo = O_COLS * C;
+    const int ocols = smp_compact_o(s) ? 2 : O_COLS;
+    const int ldt = T_COLS * C, ldo = O_COLS * C;   // (the tiled launches below always use the three-block layout)
     // block GEMMs: A = T column range, B = stacked weights, C = O column block -- one grouped launch (every row panel
     // of T is fetched from HBM once and shared through L2 by the three products), separate launches as a fallback.
     //   O_LOC = tot [S_ab|S_bc][K0;K2] + tr S_ab K6 + [T6|T10][K5;K9]   (three K pieces, the first two row-scaled)
@@ -1109,7 +1118,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         };
         const bool panels = !env_is("GF_SMP_ROWPANEL", '0');  // (read per call: the parity tests switch it)
         if (C == 64 && panels) {
-            st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows);  // weights in LDS, rows in registers
+            st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, ocols == 2 ? d.trow : nullptr);  // weights in LDS
             if (st != GF_OK) return st;
         } else if (gemm_grouped_supported(sp, 3, false, false)) {
             st = gemm_grouped_rows(ctx, false, false, sp, 3, rows);
@@ -1138,7 +1147,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, O,
                   d.adj, d.Vout, d.Sout, bl, d.f, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C, nwin, d.Gc,
-                  d.pair_src_pair, d.pi, d.rsum);
+                  d.pair_src_pair, d.pi, d.rsum, ocols);
     }
     return GF_OK;
 }
@@ -1178,8 +1187,9 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     float *colpart = s->colpart + (size_t)l * 256 * C;
     GF_LAUNCH(ctx, "smpf_reduce_pairs", smp_reduce_pairs, dim3(nb), dim3(256), 0, d.dSpart, d.dbpart, d.dSout, colpart, d.node_s,
               d.node_pair, C, nodes, npb);
+    const int ocols = smp_compact_o(s) ? 2 : O_COLS;
     GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(256), 0, dO, d.dGc, pv.node_s, pv.node_pair,
-              d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C);
+              d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C, ocols);
     {
         const GemmSpec nt[4] = {spec(d.dGc, d.Wst + 8 * CC, d.dFdc, prevPairs, C, C, 2 * C, C, 2 * C),
                                 spec(d.dGc + C, d.Wst + 9 * CC, d.dFdc + C, prevPairs, C, C, 2 * C, C, 2 * C),
@@ -1213,7 +1223,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     FoldGroup rowg;
     const bool stationary = C == 64 && !env_is("GF_SMP_WGRAD", '0');
     if (stationary) {
-        st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg);
+        st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg, ocols == 2 ? d.trow : nullptr);
         if (st != GF_OK) return st;
         used = (size_t)rowg.splits * rowg.n;
     } else {  // other channel counts: the grouped split-K launch (its own ordered reduction) into the stacked image, one "image"
@@ -1280,7 +1290,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     }
     // table gradients dT from dO
     if (C == 64 && !env_is("GF_SMP_ROWPANEL", '0')) {
-        st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows);
+        st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows, ocols == 2 ? d.trow : nullptr);
         if (st != GF_OK) return st;
     } else {
         const long long oC = C, wCC = (long long)CC;
@@ -1339,7 +1349,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
                   d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
-                  nwin, d.rsum);
+                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS);
     }
     if (smp_grouped_small(s)) return smp_fused_backward_level_grouped(s, l, dKl, dbl);
     GF_LAUNCH(ctx, "smpf_node_sum", smp_node_sum, dim3(nodes), dim3(64), 0, d.dSpart, d.dSout, d.node_s, d.node_pair, C);
@@ -1356,7 +1366,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         const gf_smp::DevLevel &pv = s->lv[l - 1];
         const int prevNodes = s->lay.level[l - 1].nNodes, prevPairs = (int)s->lay.level[l - 1].pairs;
         GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(256), 0, dO, d.dGc, pv.node_s, pv.node_pair,
-                  d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C);
+                  d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C, (int)O_COLS);
         if (s->side_pending) {  // GF_SMP_OVERLAP: the level above may still be folding split-K partials in the context's ONE
             GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));  // workspace, which the products below use too
             s->side_pending = false;
@@ -1455,7 +1465,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         };
         const bool panels = !env_is("GF_SMP_ROWPANEL", '0');  // (read per call: the parity tests switch it)
         if (C == 64 && panels) {
-            st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows);  // weights in LDS, rows in registers
+            st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows, nullptr);  // weights in LDS, rows in registers
             if (st != GF_OK) return st;
         } else if (gemm_grouped_supported(dg, 3, false, true)) {
             st = gemm_grouped_rows(ctx, false, true, dg, 3, rows);

@@ -37,13 +37,14 @@ gf_status gemm_grouped_free_tn(gf_ctx *ctx, const GemmSpec *specs, int n, float 
 bool gemm_grouped_supported(const GemmSpec *specs, int n, bool ta, bool tb);
 gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows);
 gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int rows, float *dest, int accumulate);
+// trow != nullptr: compact O / dO layout ([O_loc | U], 2C wide) with the transposed-row gather inside the product (see kernel)
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                    int rows);
+                                    int rows, const int *trow);
 gf_status splitk_fold(gf_ctx *ctx, const float *part, float *dest, size_t total, int splits, int accumulate);
 gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst);
 // the same product, partial images only (fold == caller's): `part` receives out->splits images of 8 * 64 * 64 floats
 gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
-                                 size_t part_floats, FoldGroup *out);
+                                 size_t part_floats, FoldGroup *out, const int *trow);
 }
 
 struct gf_smp {
@@ -70,6 +71,7 @@ struct gf_smp {
         int *pair_node = nullptr, *pair_src_s = nullptr, *cons_s = nullptr;
         long long *pair_src_row = nullptr, *cons_ptr = nullptr, *cons_slab = nullptr, *cons_inv_off = nullptr;
         short *pi = nullptr, *inv = nullptr;
+        int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
         long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
         int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr;
         float *Fdc = nullptr, *Gc = nullptr, *dGc = nullptr, *dFdc = nullptr;  // [pairs of level l-1][2C] each

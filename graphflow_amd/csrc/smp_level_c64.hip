@@ -34,16 +34,20 @@ __constant__ int c_wg_scale[8] = {0, 0, 1, -1, -1, -1, -1, -1};
 
 // sixteen waves: wave w owns columns [32 (w & 1), +32) of product w >> 1 as two 32 x 32 accumulators (the wave tile of the
 // general kernel); four waves per SIMD hide each other's LDS and barrier waits
+// trow == nullptr: dO = [L | dZ | dZ'] (192 columns).  trow != nullptr (compact layout): dO = [L | dU] (128 columns) and the third
+// block of the B image is dU at the TRANSPOSED row of the node, trow[row] = the row of (e, x) for row (x, e):
+//   sum_rows S_ab[T(row)]^T dU[row] = sum_rows S_ab[row]^T dU[T(row)]     (the weight gradient of K11)
 __global__ __launch_bounds__(kWgThreads, 1) void smp_wgrad_c64(const float *__restrict__ T, const float *__restrict__ dO,
                                                                const float *__restrict__ rs, int rows, int kchunk,
-                                                               float *__restrict__ part) {
+                                                               float *__restrict__ part, const int *__restrict__ trow) {
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];  // two stages: slice i is multiplied while slice i + 1 lands
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int prod = wave >> 1, nh = wave & 1;
     const int kbeg = blockIdx.x * kchunk;
     const int kend = (kbeg + kchunk < rows) ? kbeg + kchunk : rows;
-    constexpr int LDT = 256, LDO = 192;
+    constexpr int LDT = 256;
+    const int LDO = trow ? 128 : 192;
     const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // staging: A = two float4 per thread (transposing store, ascat_mk on each 128-row half), B = 1536 float4 over 1024 threads
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(kWgThreads, 1) void smp_wgrad_c64(const float *__re
         const int gk = k0 + bk;
         const bool in = gk < kend;
         vb[0] = in ? *reinterpret_cast<const f4v *>(dO + (size_t)gk * LDO + bblk0 * 64 + bn) : zero4;
-        if (b2) vb[1] = in ? *reinterpret_cast<const f4v *>(dO + (size_t)gk * LDO + 128 + bn) : zero4;
+        if (b2) vb[1] = in ? *reinterpret_cast<const f4v *>(trow ? dO + (size_t)trow[gk] * LDO + 64 + bn : dO + (size_t)gk * LDO + 128 + bn) : zero4;
         if (tid < 512 && bn == 0) sc = in ? *reinterpret_cast<const float2 *>(rs + (size_t)gk * 2) : make_float2(0.f, 0.f);
     };
     // one of four pieces of the slice's LDS image (issued between the MFMAs of the running slice, or all at once)
@@ -173,10 +177,17 @@ constexpr int kRpWRow = 36;
 
 // TH = threads per workgroup: 1024 (four waves per SIMD, 128 registers each) or 512 (two waves per SIMD, 256 registers: no
 // spills, at half the latency-hiding waves)
-template <bool FWD, int TH>
+// COMPACT (TH = 512 only): the projected matrix is O = [O_loc | U] with U = Z + Z'^T formed by the product itself -- the S_ab
+// block of the K11 product is read at the TRANSPOSED row of the node (trow[row] = row of (e, x) for row (x, e)), so the
+// consumer needs no transposed read and O / dO are 2C wide instead of 3C (0.73 GB less written and read per direction at cfg3).
+//   forward  U    = S_ab W5 + S_bc W6 + S_ab[trow] W7
+//   backward dS_ab = tot L W0^T + tr L W2^T + dU W5^T + dU[trow] W7^T        dS_bc = tot L W1^T + dU W6^T
+template <bool FWD, int TH, bool COMPACT>
 __global__ __launch_bounds__(TH, 1) void smp_rowpanel_c64(const float *__restrict__ A, const float *__restrict__ rs,
-                                                                  const float *__restrict__ Wst, float *__restrict__ Out, int rows) {
-    constexpr int LDA = FWD ? 256 : 192, LDOUT = FWD ? 192 : 256;
+                                                                  const float *__restrict__ Wst, float *__restrict__ Out, int rows,
+                                                                  const int *__restrict__ trow) {
+    constexpr int OC = COMPACT ? 128 : 192;
+    constexpr int LDA = FWD ? 256 : OC, LDOUT = FWD ? OC : 256;
     extern __shared__ __attribute__((aligned(16))) float rp_smem[];  // [8 pos][2 column halves][2 k halves][32 lanes][36]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = tid >> 6;
@@ -201,6 +212,14 @@ __global__ __launch_bounds__(TH, 1) void smp_rowpanel_c64(const float *__restric
         const int row = p * 32 + li;
         const bool ok = p < npanels && row < rows;
         const float *src = A + (size_t)(ok ? row : 0) * LDA + blk * 64 + 32 * lh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) B.a[q] = ok ? *reinterpret_cast<const f4v *>(src + 4 * q) : zero4;
+    };
+    // the same block read at the transposed rows of the panel's rows (COMPACT)
+    auto load_blk_t = [&](Blk &B, int p, int blk) {
+        const int row = p * 32 + li;
+        const bool ok = p < npanels && row < rows;
+        const float *src = A + (size_t)(ok ? trow[row] : 0) * LDA + blk * 64 + 32 * lh;
 #pragma unroll
         for (int q = 0; q < 8; ++q) B.a[q] = ok ? *reinterpret_cast<const f4v *>(src + 4 * q) : zero4;
     };
@@ -309,7 +328,47 @@ __global__ __launch_bounds__(TH, 1) void smp_rowpanel_c64(const float *__restric
     auto panel_wide = [&](int p, Blk &X, Blk &Y, Blk &W, Blk &V) {
         const int pn = p + nwaves;
         f16v acc0, acc1;
-        if (FWD) {
+        if (COMPACT && FWD) {  // T blocks: 0 S_ab, 1 S_bc, 2 T6, 3 T10; outputs: 0 O_loc, 1 U
+            load_blk(Y, p, 1);
+            load_blk_t(W, p, 0);                     // W <- S_ab at the transposed rows
+            load_blk(V, p, 2);
+            scn = load_scale(pn);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 5, acc0, acc1);
+            prod(Y, false, 1.f, 6, acc0, acc1);
+            prod(W, false, 1.f, 7, acc0, acc1);
+            load_blk(W, p, 3);                       // W <- T10, four products ahead of its use
+            store_out(p, 1, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, true, sc.x, 0, acc0, acc1);
+            prod(X, true, sc.y, 2, acc0, acc1);
+            load_blk(X, pn, 0);                      // X <- S_ab of the next panel
+            prod(Y, true, sc.x, 1, acc0, acc1);
+            prod(V, false, 1.f, 3, acc0, acc1);
+            prod(W, false, 1.f, 4, acc0, acc1);
+            store_out(p, 0, acc0, acc1);
+        } else if (COMPACT) {  // dO blocks: 0 L, 1 dU; outputs: 0 dS_ab, 1 dS_bc, 2 dT6, 3 dT10
+            load_blk(Y, p, 1);
+            load_blk_t(W, p, 1);                     // W <- dU at the transposed rows
+            scn = load_scale(pn);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 3, acc0, acc1);
+            store_out(p, 2, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, false, 1.f, 4, acc0, acc1);
+            store_out(p, 3, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, true, sc.x, 1, acc0, acc1);
+            prod(Y, false, 1.f, 6, acc0, acc1);
+            store_out(p, 1, acc0, acc1);
+            clear(acc0, acc1);
+            prod(X, true, sc.x, 0, acc0, acc1);
+            prod(X, true, sc.y, 2, acc0, acc1);
+            load_blk(X, pn, 0);                      // X <- L of the next panel
+            prod(Y, false, 1.f, 5, acc0, acc1);
+            prod(W, false, 1.f, 7, acc0, acc1);
+            store_out(p, 0, acc0, acc1);
+        } else if (FWD) {
             load_blk(Y, p, 1);
             load_blk(W, p, 2);
             load_blk(V, p, 3);
@@ -370,7 +429,7 @@ __global__ __launch_bounds__(TH, 1) void smp_rowpanel_c64(const float *__restric
 // 8 x 64 x 64 floats per row range.  T = [rows][256], dO = [rows][192], rowscale = [rows][2].  The row range per workgroup
 // depends on `rows` only: results are reproducible.  The caller folds the images in order.
 gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
-                                 size_t part_floats, FoldGroup *out) {
+                                 size_t part_floats, FoldGroup *out, const int *trow) {
     const size_t total = 8 * 4096;
     out->part = part;
     out->n = total;
@@ -387,7 +446,7 @@ gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, c
     const size_t lds = sizeof(float) * 2 * (size_t)kWgStage;
     gf_status st = opt_in_lds(ctx, smp_wgrad_c64, lds);
     if (st != GF_OK) return st;
-    GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part);
+    GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part, trow);
     out->splits = splits;
     return GF_OK;
 }
@@ -405,7 +464,7 @@ gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO,
     gf_status st = ensure_ws(ctx, sizeof(float) * ((size_t)splits + nchunks) * total + 256);
     if (st != GF_OK) return st;
     FoldGroup fg;
-    st = smp_wgrad_partials_c64(ctx, T, dO, rowscale, rows, static_cast<float *>(ctx->ws), (size_t)splits * total, &fg);
+    st = smp_wgrad_partials_c64(ctx, T, dO, rowscale, rows, static_cast<float *>(ctx->ws), (size_t)splits * total, &fg, nullptr);
     if (st != GF_OK) return st;
     return splitk_fold(ctx, fg.part, dWst, total, fg.splits, 0);
 }
@@ -413,7 +472,7 @@ gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO,
 // Row-panel products of a fused SMP level at C = 64 (see smp_rowpanel_c64): forward O from T, or backward dT from dO.
 // Every output element is produced by one wave in a fixed order: results do not depend on the grid size.
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                    int rows) {
+                                    int rows, const int *trow) {
     if (rows < 1) return GF_OK;
     static int cu_count[64] = {};
     const int di = ctx->device & 63;
@@ -424,25 +483,32 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
     const int cus = cu_count[di];
     const size_t lds = sizeof(float) * 8 * 2 * 2 * 32 * (size_t)kRpWRow;
     // forward: four waves per SIMD (measured equal to two); backward: two waves per SIMD with 256 registers -- the 128-register
-    // build of the backward panel spills 100 B per lane and waits for one block request per panel (1.84 -> 1.66 ms at cfg3)
-    int th = forward ? 1024 : 512;
-    if (const char *e = std::getenv(forward ? "GF_RP_THREADS_FWD" : "GF_RP_THREADS_BWD")) th = std::atoi(e) == 512 ? 512 : 1024;
-    {
-        gf_status st = forward ? (th == 512 ? opt_in_lds(ctx, smp_rowpanel_c64<true, 512>, lds) : opt_in_lds(ctx, smp_rowpanel_c64<true, 1024>, lds))
-                               : (th == 512 ? opt_in_lds(ctx, smp_rowpanel_c64<false, 512>, lds) : opt_in_lds(ctx, smp_rowpanel_c64<false, 1024>, lds));
-        if (st != GF_OK) return st;
-    }
+    // build of the backward panel spills 100 B per lane and waits for one block request per panel (1.84 -> 1.66 ms at cfg3).
+    // The compact layout (trow given) keeps four operand blocks in registers: two waves per SIMD in both directions.
+    int th = (forward && !trow) ? 1024 : 512;
+    if (!trow)
+        if (const char *e = std::getenv(forward ? "GF_RP_THREADS_FWD" : "GF_RP_THREADS_BWD")) th = std::atoi(e) == 512 ? 512 : 1024;
     const int npanels = (rows + 31) / 32, per = th / 64;
     const int want = (npanels + per - 1) / per;
     const int grid = want < cus ? want : cus;  // one persistent workgroup per CU (the weight image takes 144 KB of LDS)
-    if (forward && th == 512)
-        GF_LAUNCH(ctx, "smpf_products_fwd", (smp_rowpanel_c64<true, 512>), dim3((unsigned)grid), dim3(512), lds, A, rowscale, Wst, Out, rows);
-    else if (forward)
-        GF_LAUNCH(ctx, "smpf_products_fwd", (smp_rowpanel_c64<true, 1024>), dim3((unsigned)grid), dim3(1024), lds, A, rowscale, Wst, Out, rows);
-    else if (th == 512)
-        GF_LAUNCH(ctx, "smpf_products_bwd", (smp_rowpanel_c64<false, 512>), dim3((unsigned)grid), dim3(512), lds, A, rowscale, Wst, Out, rows);
-    else
-        GF_LAUNCH(ctx, "smpf_products_bwd", (smp_rowpanel_c64<false, 1024>), dim3((unsigned)grid), dim3(1024), lds, A, rowscale, Wst, Out, rows);
+    const char *name = forward ? "smpf_products_fwd" : "smpf_products_bwd";
+#define GF_RP_LAUNCH(F, T, Cm)                                                                                              \
+    do {                                                                                                                    \
+        gf_status st__ = opt_in_lds(ctx, smp_rowpanel_c64<F, T, Cm>, lds);                                                  \
+        if (st__ != GF_OK) return st__;                                                                                     \
+        GF_LAUNCH(ctx, name, (smp_rowpanel_c64<F, T, Cm>), dim3((unsigned)grid), dim3(T), lds, A, rowscale, Wst, Out, rows, trow); \
+    } while (0)
+    if (trow) {
+        if (forward) GF_RP_LAUNCH(true, 512, true);
+        else GF_RP_LAUNCH(false, 512, true);
+    } else if (forward) {
+        if (th == 512) GF_RP_LAUNCH(true, 512, false);
+        else GF_RP_LAUNCH(true, 1024, false);
+    } else {
+        if (th == 512) GF_RP_LAUNCH(false, 512, false);
+        else GF_RP_LAUNCH(false, 1024, false);
+    }
+#undef GF_RP_LAUNCH
     return GF_OK;
 }
 

@@ -33,9 +33,10 @@ class SMPOmega:
         self.n_params = self.lib.gf_smp_param_count(h)
         self.n_mol = 0
 
-    def prepare(self, molecules, coulomb=None):
-        """molecules: list of (adj int[V,V], feature float[V,F]); coulomb: optional list of float[V,V] Coulomb matrices
-        (the use_coulomb variant of SMP_omega).  Host graph preparation + upload (blocking)."""
+    @staticmethod
+    def pack(molecules, coulomb=None):
+        """The flat host arrays gf_smp_prepare takes (vertex counts, adjacency and feature matrices back to back): a data
+        loader builds these once per batch; prepare() accepts the result in place of the molecule list."""
         nV = np.array([len(m[0]) for m in molecules], dtype=np.int32)
         adj = np.concatenate([np.ascontiguousarray(m[0], dtype=np.int32).ravel() for m in molecules])
         feat = np.concatenate([np.ascontiguousarray(m[1], dtype=np.float64).ravel() for m in molecules])
@@ -43,7 +44,15 @@ class SMPOmega:
         if coulomb is not None:
             cm = np.concatenate([np.ascontiguousarray(c, dtype=np.float64).ravel() for c in coulomb])
             assert cm.size == adj.size
-        self.ctx.check(self.lib.gf_smp_prepare_coulomb(self.handle, len(molecules), nV.ctypes.data_as(C.POINTER(C.c_int)),
+        return {"nV": nV, "adj": adj, "feature": feat, "coulomb": cm}
+
+    def prepare(self, molecules, coulomb=None):
+        """molecules: list of (adj int[V,V], feature float[V,F]) or the dict pack() returns; coulomb: optional list of
+        float[V,V] Coulomb matrices (the use_coulomb variant of SMP_omega).  Host graph preparation + upload (blocking)."""
+        pk = molecules if isinstance(molecules, dict) else self.pack(molecules, coulomb)
+        nV, adj, feat, cm = pk["nV"], pk["adj"], pk["feature"], pk["coulomb"]
+        molecules = nV
+        self.ctx.check(self.lib.gf_smp_prepare_coulomb(self.handle, len(nV), nV.ctypes.data_as(C.POINTER(C.c_int)),
                                                        adj.ctypes.data_as(C.POINTER(C.c_int)),
                                                        feat.ctypes.data_as(C.POINTER(C.c_double)),
                                                        cm.ctypes.data_as(C.POINTER(C.c_double)) if cm is not None else None))

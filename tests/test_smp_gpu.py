@@ -312,10 +312,16 @@ def test_batched_small_launches_equal_one_launch_per_product(gf, monkeypatch, C)
         tg.append(t)
     params = smp_params(C, F, D, L, 6)
     p1, _, f1, g1, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    monkeypatch.setenv("GF_SMP_COMPACT_O", "0")   # (C = 64: the two-block projected matrix U = Z + Z'^T vs the three-block one)
+    p2, _, f2, g2, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    # the forward sums U in a different order, so a few pre-activations land on the other side of LeakyReLU's kink (KINK_TOL
+    # above): the gradients of the two layouts agree to the kink-limited bound only; the compact layout's own gradient is held
+    # to 1e-5 against the fp64 port by the headline tests
+    assert rel_err(p1, p2) <= 1e-6 and rel_err(f1, f2) <= 1e-6 and rel_err(g1, g2) <= KINK_GRAD
     monkeypatch.setenv("GF_SMP_GROUPED", "0")
     p0, _, f0, g0, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
-    assert np.array_equal(p1, p0) and np.array_equal(f1, f0)   # forward: the same tiles, launched together
-    assert rel_err(g1, g0) <= 2e-6
+    assert np.array_equal(p2, p0) and np.array_equal(f2, f0)   # forward: the same tiles, launched together
+    assert rel_err(g2, g0) <= 2e-6
 
 
 def test_two_handles_alternate_without_waiting_for_each_other(gf):
