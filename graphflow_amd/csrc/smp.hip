@@ -402,6 +402,15 @@ __global__ void readout_backward_nodevec(const float *__restrict__ dy, const flo
 
 __global__ void zero_f32(float *p, size_t n) { GRID_STRIDE(i, n) p[i] = 0.f; }
 
+// rowscale[row] = (tot, tr) of the row's node (the per-row factors of the level's block products), from the per-node pairs
+__global__ void expand_rowscale(float2 *__restrict__ rowscale, const float2 *__restrict__ node_scale, const int *__restrict__ node_s,
+                                const long long *__restrict__ node_row) {
+    const int n = blockIdx.x, s = node_s[n];
+    const long long r0 = node_row[n];
+    const float2 v = node_scale[n];
+    for (int i = threadIdx.x; i < s * s; i += blockDim.x) rowscale[r0 + i] = v;
+}
+
 // trow[row of (x, e)] = row of (e, x) inside the same node (compact O layout of the fused C = 64 level, smp_level_c64.hip)
 __global__ void build_trow(int *__restrict__ trow, const int *__restrict__ node_s, const long long *__restrict__ node_row) {
     const int n = blockIdx.x, s = node_s[n];
@@ -453,6 +462,32 @@ __global__ void level_feature_backward(const float *__restrict__ dfeat, const fl
 
 size_t param_count(const gfsmp::Config &c);
 static size_t param_count_of(const gf_smp *s) { return param_count(s->cfg); }
+
+// page-locked host memory for the per-batch tables (smp_prep.h: table_alloc): their uploads then run on the DMA engines beside
+// the step that is executing, instead of blit kernels queued behind its compute kernels.  16-byte header: how it was obtained.
+void *pinned_table_alloc(size_t bytes) {
+    void *p = nullptr;
+    const size_t total = bytes + 16;
+    unsigned kind = 1;
+    if (std::getenv("GF_PINNED_TABLES") && std::getenv("GF_PINNED_TABLES")[0] == '0') p = nullptr;
+    else if (hipHostMalloc(&p, total, hipHostMallocDefault) != hipSuccess) p = nullptr;
+    if (!p) {
+        (void)hipGetLastError();
+        p = std::malloc(total);
+        kind = 0;
+        if (!p) return nullptr;
+    }
+    *static_cast<unsigned *>(p) = kind;
+    return static_cast<char *>(p) + 16;
+}
+void pinned_table_free(void *q) {
+    if (!q) return;
+    void *p = static_cast<char *>(q) - 16;
+    if (*static_cast<unsigned *>(p) == 1)
+        (void)hipHostFree(p);
+    else
+        std::free(p);
+}
 
 template <typename T>
 gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
@@ -653,6 +688,8 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
     if (!cfg || !out) return fail(ctx, GF_ERR_INVALID, "gf_smp_create: null argument");
     if (cfg->nLevels < 1 || cfg->nChanels < 1 || cfg->nFeatures < 1 || cfg->nDepth < 0 || cfg->max_receptive_field < 1)
         return fail(ctx, GF_ERR_INVALID, "gf_smp_create: bad configuration");
+    gfsmp::table_alloc = gf::pinned_table_alloc;   // (before the first table is built; idempotent)
+    gfsmp::table_free = gf::pinned_table_free;
     gf_smp *s = new gf_smp();
     s->ctx = ctx;
     s->cfg.nLevels = cfg->nLevels;
@@ -783,8 +820,7 @@ gf_status gf_smp_adam_step(gf_smp *s, float *params, const float *grads, double 
     }
     GF_LAUNCH(ctx, "smp_adam", gf::adam_step, dim3(gf::grid_for(n)), dim3(256), 0, params, grads, s->adam_m, s->adam_v, n,
               learning_rate, 1.0 / (double)nBatch, s->adam_n, 0.9, 0.999, 1e-8);
-    s->adam_n += n;
-    gf::mark_used(s);
+    s->adam_n += n;   // (touches the moment buffers only, not the batch's: the handle's next gf_smp_prepare need not wait for it)
     return GF_OK;
 }
 
@@ -809,7 +845,6 @@ gf_status gf_smp_momentum_step(gf_smp *s, float *params, const float *grads, dou
     }
     GF_LAUNCH(ctx, "smp_momentum", gf::momentum_step, dim3(gf::grid_for(n)), dim3(256), 0, params, grads, s->adam_m, n,
               learning_rate, 1.0 / (double)nBatch, gamma);
-    gf::mark_used(s);
     return GF_OK;
 }
 
@@ -970,7 +1005,9 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (st != GF_OK) return st;
         UP(d.adj, h.adj);
         UP(d.rsum, h.rsum);
-        UP(d.rowscale, h.rowscale);
+        UP(d.node_scale, h.rowscale);
+        st = gf::upload(s, &d.rowscale, nullptr, (size_t)h.rows * 2);
+        if (st != GF_OK) return st;
         UP(d.quad_node, h.quad_node);
         UP(d.quad_b0, h.quad_b0);
         UP(d.quad_order, h.quad_order);
@@ -1025,10 +1062,13 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         contract_ws = std::max(contract_ws, gf::r18_ragged_workspace_bytes((long long)h.rows, (long long)h.pairs, Cp));
     }
     // (the node tables went up on the handle's upload stream: build the transposed-row tables there too, behind them)
-    for (int l = 1; l <= L; ++l)
+    for (int l = 1; l <= L; ++l) {
+        hipStream_t up = s->upload ? s->upload : ctx->stream;
+        hipLaunchKernelGGL(gf::expand_rowscale, dim3(B.level[l].nNodes), dim3(64), 0, up, reinterpret_cast<float2 *>(s->lv[l].rowscale),
+                           reinterpret_cast<const float2 *>(s->lv[l].node_scale), s->lv[l].node_s, s->lv[l].node_row);
         if (s->lv[l].trow)
-            hipLaunchKernelGGL(gf::build_trow, dim3(B.level[l].nNodes), dim3(64), 0, s->upload ? s->upload : ctx->stream, s->lv[l].trow,
-                               s->lv[l].node_s, s->lv[l].node_row);
+            hipLaunchKernelGGL(gf::build_trow, dim3(B.level[l].nNodes), dim3(64), 0, up, s->lv[l].trow, s->lv[l].node_s, s->lv[l].node_row);
+    }
     UP(s->x, B.x);
     s->P = nullptr;  // [max ppos][C]: by far the largest buffer of the op-by-op path, taken from the pool only when a level needs it
     s->P_count = (size_t)maxp;  // (positions x channels of the level below, maximised over the levels)

@@ -100,8 +100,16 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sR = smem;                                              // [N]
-    short *sPi = reinterpret_cast<short *>(smem + ((N + 3) & ~3));  // [N][N]
-    for (int i = tid; i < N; i += kThreads) sR[i] = rsum[pairbase + i];
+    // the source tensor of every row a (first row, size): in LDS with the maps, so that a row's address chain is LDS reads
+    // only -- fetched per row from global memory they put two dependent round trips in front of every row's loads
+    long long *sSrcRow = reinterpret_cast<long long *>(smem + ((N + 3) & ~3));   // [N]
+    int *sSrcS = reinterpret_cast<int *>(sSrcRow + N);                            // [N]
+    short *sPi = reinterpret_cast<short *>(sSrcS + ((N + 3) & ~3));               // [N][N]
+    for (int i = tid; i < N; i += kThreads) {
+        sR[i] = rsum[pairbase + i];
+        sSrcRow[i] = pair_src_row[pairbase + i];
+        sSrcS[i] = pair_src_s[pairbase + i];
+    }
     for (int i = tid; i < N * N; i += kThreads) sPi[i] = pi[rowbase + i];
     __syncthreads();
     if (b >= N) return;
@@ -125,9 +133,8 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
     auto load_row = [&](int a, f4(&v)[NI], f4 &dg) {
         const short *map = sPi + a * N;
         const int pb = map[b];
-        const long long e = (long long)pairbase + a;
-        const int sw = __builtin_amdgcn_readfirstlane(pair_src_s[e]);
-        const long long srow = pair_src_row[e];
+        const int sw = __builtin_amdgcn_readfirstlane(sSrcS[a]);
+        const long long srow = sSrcRow[a];
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(srow & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((unsigned)(srow >> 32));
         const float *src = fprev + (((long long)hi << 32) | lo) * C;
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (size_t)sw * sw * C * sizeof(float));
@@ -814,7 +821,8 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     q_lo = (int)(std::lower_bound(h.quad_node.begin(), h.quad_node.end(), n_lo) - h.quad_node.begin());
     q_hi = (int)(std::lower_bound(h.quad_node.begin(), h.quad_node.end(), n_hi) - h.quad_node.begin());
     if (q_hi <= q_lo) return GF_OK;
-    const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + sizeof(short) * (size_t)c.smax * c.smax + 16;
+    const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + sizeof(long long) * c.smax + sizeof(int) * ((c.smax + 3) & ~3) +
+                       sizeof(short) * (size_t)c.smax * c.smax + 16;
     GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
               s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
               d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order);

@@ -66,7 +66,7 @@ struct gf_smp {
     struct DevLevel {
         int *node_s = nullptr;
         long long *node_row = nullptr, *node_p = nullptr, *node_pair = nullptr;
-        float *adj = nullptr, *rsum = nullptr, *rowscale = nullptr;
+        float *adj = nullptr, *rsum = nullptr, *rowscale = nullptr, *node_scale = nullptr;
         int *quad_node = nullptr, *quad_b0 = nullptr, *quad_order = nullptr;
         int *pair_node = nullptr, *pair_src_s = nullptr, *cons_s = nullptr;
         long long *pair_src_row = nullptr, *cons_ptr = nullptr, *cons_slab = nullptr, *cons_inv_off = nullptr;

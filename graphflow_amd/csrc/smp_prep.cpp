@@ -15,6 +15,12 @@
 #include <utility>
 
 namespace gfsmp {
+
+static void *default_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+static void default_free(void *p) { std::free(p); }
+void *(*table_alloc)(size_t) = default_alloc;
+void (*table_free)(void *) = default_free;
+
 namespace {
 
 constexpr int kMaxVertices = 4096;  // per molecule, for the stack-resident vertex tables of the batch builder
@@ -316,13 +322,21 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
     out->node_of_vertex = node_of;
     const std::chrono::steady_clock::time_point t_order = std::chrono::steady_clock::now();
 
-    for (int l = 1; l <= L; ++l) {
+    // The levels' tables are independent of each other (they only read node_of and the previous level's node bookkeeping), so
+    // the serial parts of all levels run side by side (one task per level) and the node loops of all levels share one
+    // parallel_for: four phases instead of four per level.
+    std::vector<std::vector<int> > src_node_of_pair(L + 1);
+    parallel_tasks(L, [&](int li) {   // phase A: sizes, quad tables and their launch order
+        const int l = li + 1;
         LevelLayout &lv = out->level[l];
         const LevelLayout &prev = out->level[l - 1];
+        std::vector<int> &pair_src_node = src_node_of_pair[l];
+        (void)prev;
+        (void)pair_src_node;
         // every element of these is written by the node loop below: resize only (no fill pass over ~50 MB per batch)
         lv.adj.resize((size_t)lv.rows);
         lv.rsum.resize((size_t)lv.pairs);
-        lv.rowscale.resize((size_t)lv.rows * 2);
+        lv.rowscale.resize((size_t)lv.nNodes * 2);
         lv.quad_node.clear();
         lv.quad_b0.clear();
         lv.pair_node.resize((size_t)lv.pairs);
@@ -330,7 +344,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         lv.pair_src_pair.resize((size_t)lv.pairs);
         lv.pair_src_s.resize((size_t)lv.pairs);
         lv.pi.resize((size_t)lv.rows);
-        std::vector<int> pair_src_node((size_t)lv.pairs);
+        pair_src_node.assign((size_t)lv.pairs, 0);
         for (int n = 0; n < lv.nNodes; ++n)
             for (int b0 = 0; b0 < lv.node_s[n]; b0 += 4) {
                 lv.quad_node.push_back(n);
@@ -351,7 +365,14 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 lv.quad_order[(size_t)start[(size_t)cls(lv.node_s[n]) * nMol + lv.node_mol[n]]++] = (int)q;
             }
         }
-        parallel_for(lv.nNodes, [&](int n) {
+    });
+    parallel_for(L * totalV, [&](int k) {   // phase B: per node -- reduced adjacency, row sums, selection maps
+        const int l = 1 + k / totalV, n = k % totalV;
+        LevelLayout &lv = out->level[l];
+        const LevelLayout &prev = out->level[l - 1];
+        std::vector<int> &pair_src_node = src_node_of_pair[l];
+        (void)prev;
+        (void)pair_src_node;
             const int m = lv.node_mol[n], v = lv.node_vertex[n], s = lv.node_s[n];
             const int V = nVertices[m], v0 = out->mol_first_vertex[m];
             const int *madj = adj + adj_off[m];
@@ -378,10 +399,8 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                     const float av = lv.adj[(size_t)lv.node_row[n] + (size_t)i * s + i];
                     if (av > 0.f) tr += av;
                 }
-                for (int r = 0; r < s * s; ++r) {
-                    lv.rowscale[2 * ((size_t)lv.node_row[n] + r)] = tot;
-                    lv.rowscale[2 * ((size_t)lv.node_row[n] + r) + 1] = tr;
-                }
+                lv.rowscale[2 * (size_t)n] = tot;      // (expanded to one pair per row on the device: gf_smp_prepare)
+                lv.rowscale[2 * (size_t)n + 1] = tr;
             }
             int16_t pos[kMaxVertices];  // position of a vertex inside phi_{l-1}(w), -1 outside; reset after each neighbour
             if (V > kMaxVertices) std::abort();  // (gf_smp_prepare rejects such molecules before it gets here)
@@ -401,14 +420,21 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 for (int p = 0; p < s; ++p) lv.pi[(size_t)lv.node_row[n] + (size_t)a * s + p] = pos[field[p]];
                 for (size_t k = 0; k < wf.size(); ++k) pos[wf[k]] = -1;
             }
-        });
+            });
+    parallel_tasks(L, [&](int li) {   // phase C: consumer lists of the backward gather (prefix sums: serial per level)
+        const int l = li + 1;
+        LevelLayout &lv = out->level[l];
+        const LevelLayout &prev = out->level[l - 1];
+        std::vector<int> &pair_src_node = src_node_of_pair[l];
+        (void)prev;
+        (void)pair_src_node;
         // inverse index for the backward gather: consumers of a source node in increasing pair order (= fixed
         // summation order on the device), offsets by prefix sums, then a parallel fill
         lv.cons_ptr.assign((size_t)prev.nNodes + 1, 0);
         for (int64_t e = 0; e < lv.pairs; ++e) lv.cons_ptr[(size_t)pair_src_node[(size_t)e] + 1] += 1;
         for (int w = 0; w < prev.nNodes; ++w) lv.cons_ptr[(size_t)w + 1] += lv.cons_ptr[(size_t)w];
         std::vector<int64_t> cursor(lv.cons_ptr.begin(), lv.cons_ptr.end() - 1);
-        std::vector<int64_t> &cons_pair = lv.cons_pair;
+        tvec<int64_t> &cons_pair = lv.cons_pair;
         cons_pair.assign((size_t)lv.pairs, 0);
         for (int64_t e = 0; e < lv.pairs; ++e) cons_pair[(size_t)cursor[(size_t)pair_src_node[(size_t)e]]++] = e;
         lv.cons_slab.assign((size_t)lv.pairs, 0);
@@ -423,9 +449,16 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 inv_total += prev.node_s[w];
             }
         lv.inv.assign((size_t)inv_total, (int16_t)-1);
-        parallel_for(prev.nNodes, [&](int w) {
+    });
+    parallel_for(L * totalV, [&](int k) {   // phase D: per source node -- its consumers' inverse maps
+        const int l = 1 + k / totalV, w = k % totalV;
+        LevelLayout &lv = out->level[l];
+        const LevelLayout &prev = out->level[l - 1];
+        std::vector<int> &pair_src_node = src_node_of_pair[l];
+        (void)prev;
+        (void)pair_src_node;
             for (int64_t c = lv.cons_ptr[(size_t)w]; c < lv.cons_ptr[(size_t)w + 1]; ++c) {
-                const int64_t e = cons_pair[(size_t)c];
+                const int64_t e = lv.cons_pair[(size_t)c];
                 const int n = lv.pair_node[(size_t)e];
                 const int s = lv.node_s[n], a = (int)(e - lv.node_pair[n]);
                 lv.cons_slab[(size_t)c] = lv.node_p[n] + (int64_t)a * s * s;
@@ -438,8 +471,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                     if (k >= 0) iv[k] = (int16_t)p;
                 }
             }
-        });
-    }
+            });
     if (timing) {
         const std::chrono::steady_clock::time_point t_end = std::chrono::steady_clock::now();
         std::fprintf(stderr, "build_batch: molecules %.1f ms, node order %.1f ms, level tables %.1f ms\n",

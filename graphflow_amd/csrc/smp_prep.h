@@ -9,10 +9,32 @@
 #ifndef GF_SMP_PREP_H_INCLUDED
 #define GF_SMP_PREP_H_INCLUDED
 
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
 namespace gfsmp {
+
+// Host memory of the tables that are uploaded every batch comes from these hooks: plain malloc / free by default (this file
+// is pure host C++), page-locked memory once the HIP side installs its pair -- an upload from pageable memory is staged through
+// blit KERNELS that queue behind the running step's compute kernels, from pinned memory it is a DMA-engine copy that overlaps.
+extern void *(*table_alloc)(size_t bytes);
+extern void (*table_free)(void *p);
+template <class T>
+struct TableAlloc {
+    typedef T value_type;
+    TableAlloc() {}
+    template <class U>
+    TableAlloc(const TableAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(table_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { table_free(p); }
+    template <class U>
+    bool operator==(const TableAlloc<U> &) const { return true; }
+    template <class U>
+    bool operator!=(const TableAlloc<U> &) const { return false; }
+};
+template <class T>
+using tvec = std::vector<T, TableAlloc<T> >;
 
 struct Config {
     int nLevels, nChanels, nFeatures, nDepth, max_receptive_field, has_WL_ordering;
@@ -56,40 +78,40 @@ struct LevelLayout {
     int64_t ppos = 0;   // sum s^3
     int64_t pairs = 0;  // sum s   (one (node, neighbour) pair per promoted tensor)
     std::vector<Bucket> buckets;
-    std::vector<int> node_s, node_mol, node_vertex;
-    std::vector<int64_t> node_row, node_p, node_pair;
-    std::vector<float> adj;  // [rows] reduced adjacency, node-major [s][s]
-    std::vector<float> rsum; // [pairs] r[d] = sum_e A+[d][e] (A+ = A where A > 0), pair = node_pair[n] + d
-    std::vector<float> rowscale;  // [rows][2] (tot, tr) of the row's node: per-row factors folded into the level's block GEMMs
+    tvec<int> node_s, node_mol, node_vertex;
+    tvec<int64_t> node_row, node_p, node_pair;
+    tvec<float> adj;  // [rows] reduced adjacency, node-major [s][s]
+    tvec<float> rsum; // [pairs] r[d] = sum_e A+[d][e] (A+ = A where A > 0), pair = node_pair[n] + d
+    tvec<float> rowscale;  // [nNodes][2] (tot, tr) of the node's gated adjacency: per-row factors of the level's block GEMMs
     // wave-per-pair kernels: one workgroup (4 waves) per group of 4 consecutive indices of one node
-    std::vector<int> quad_node, quad_b0;  // [quads]
-    std::vector<int> quad_order;          // [quads] quads by (size class 4/8/16/32, molecule): launch order of tables-forward
+    tvec<int> quad_node, quad_b0;  // [quads]
+    tvec<int> quad_order;          // [quads] quads by (size class 4/8/16/32, molecule): launch order of tables-forward
     // forward gather (levels >= 1): per pair e = node_pair[n] + a
-    std::vector<int> pair_node;        // [pairs]
-    std::vector<int64_t> pair_src_row;  // [pairs] first row of the source node's tensor in level l-1
-    std::vector<int> pair_src_s;       // [pairs]
-    std::vector<int16_t> pi;           // [rows]  pi[node_row[n] + a*s + p] = index of phi_l(v)[p] in phi_{l-1}(w_a), or -1
+    tvec<int> pair_node;        // [pairs]
+    tvec<int64_t> pair_src_row;  // [pairs] first row of the source node's tensor in level l-1
+    tvec<int> pair_src_s;       // [pairs]
+    tvec<int16_t> pi;           // [rows]  pi[node_row[n] + a*s + p] = index of phi_l(v)[p] in phi_{l-1}(w_a), or -1
     // compact diagonal path (smp_fused.hip): the two tables D_bb[x,y] = P[x,y,y] and D_ac[x,y] = P[x,y,x] are plain gathers
     // of the diagonal / the centre column of f_{l-1}[w_x], so their block products run on the sum-s rows of the level below
-    std::vector<int64_t> pair_src_pair; // [pairs] node_pair (level l-1) of the source node of pair e
-    std::vector<int> node_center;       // [nNodes] position of the node's own vertex inside its receptive field (every level)
-    std::vector<int64_t> cons_row;      // [pairs] node_row (level l) of the consumer's node
-    std::vector<int> cons_a;            // [pairs] the consumer's neighbour index a
-    std::vector<int64_t> cons_pair;     // [pairs] the consumer's pair id e = node_pair[n] + a (level l)
-    std::vector<int> mol_order;         // [nNodes] the level's nodes by (size class 1/4/8/16/32, molecule): launch order of the
+    tvec<int64_t> pair_src_pair; // [pairs] node_pair (level l-1) of the source node of pair e
+    tvec<int> node_center;       // [nNodes] position of the node's own vertex inside its receptive field (every level)
+    tvec<int64_t> cons_row;      // [pairs] node_row (level l) of the consumer's node
+    tvec<int> cons_a;            // [pairs] the consumer's neighbour index a
+    tvec<int64_t> cons_pair;     // [pairs] the consumer's pair id e = node_pair[n] + a (level l)
+    tvec<int> mol_order;         // [nNodes] the level's nodes by (size class 1/4/8/16/32, molecule): launch order of the
                                         // backward gather, so the sources that re-read one consumer's rows run together
     // backward gather, indexed by the SOURCE node (level l-1): consumers = pairs that read it
-    std::vector<int64_t> cons_ptr;      // [nNodes(l-1) + 1]
-    std::vector<int64_t> cons_slab;     // [pairs] position offset (units of C floats) of the consumer's [s][s] slab in P
-    std::vector<int> cons_s;           // [pairs] consumer's s
-    std::vector<int64_t> cons_inv_off;  // [pairs] offset into inv
-    std::vector<int16_t> inv;          // per consumer: [s_w] position in the consumer's field of source position p, or -1
+    tvec<int64_t> cons_ptr;      // [nNodes(l-1) + 1]
+    tvec<int64_t> cons_slab;     // [pairs] position offset (units of C floats) of the consumer's [s][s] slab in P
+    tvec<int> cons_s;           // [pairs] consumer's s
+    tvec<int64_t> cons_inv_off;  // [pairs] offset into inv
+    tvec<int16_t> inv;          // per consumer: [s_w] position in the consumer's field of source position p, or -1
 };
 
 struct BatchLayout {
     int nMol = 0;
     std::vector<int> mol_first_vertex;  // [nMol+1] prefix sum of vertex counts (level-0 node = global vertex id)
-    std::vector<float> x;               // [nVertices][F(D+1)] WL features, level-0 input
+    tvec<float> x;                      // [nVertices][F(D+1)] WL features, level-0 input
     std::vector<LevelLayout> level;     // [L+1]; level[0] has only node bookkeeping
     std::vector<int> top_node_of_vertex;  // [nVertices] node index at level L of global vertex id
     std::vector<std::vector<int> > node_of_vertex;  // [L+1][nVertices] the same for every level (per-level readout)

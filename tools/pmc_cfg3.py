@@ -20,7 +20,8 @@ def launch_name(k):
              "smp_combine_fwd": "smpf_combine_fwd", "smp_combine_bwd": "smpf_combine_bwd", "promote_backward": "smp_promote_bwd",
              "smp_vectors": "smpf_vectors", "smp_bwd_gather": "smpf_bwd_gather", "smp_wgrad_c64": "smpf_wgrad",
              "smp_reduce_pairs": "smpf_reduce_pairs", "smp_fold_level": "smpf_fold", "diag_gather_bwd": "smpf_diag_gather_bwd",
-             "diag_gather_fwd": "smpf_diag_gather", "stack_weights_all": "smpf_stack_w", "readout_nodes_v": "smp_readout_nodes"}
+             "diag_gather_fwd": "smpf_diag_gather", "stack_weights_all": "smpf_stack_w", "readout_nodes_v": "smp_readout_nodes",
+             "fam_backward_rows": "fam_backward", "fam_products_lds": "fam_products"}
     return table.get(base, base)
 
 
