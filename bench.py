@@ -522,14 +522,17 @@ def main():
             line["extra"] = extra
         line["roofline"]["hbm_copy_measured_GBps"] = round(copy_ceiling_gbps(torch, dev), 1)
         line["cpu_baseline"] = cpu() if (world == 1 and not args.no_cpu_baseline) else None
-        # RCCL prints its version banner through C stdio, which is block-buffered on a pipe: push it out BEFORE the JSON line so
-        # that the line is the last thing this process writes to stdout
-        sys.stdout.flush()
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
+    # RCCL prints its version banner through C stdio, which is block-buffered on a pipe: every rank pushes it out BEFORE rank 0
+    # writes the JSON line, so that the line is the last thing the job writes to stdout
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

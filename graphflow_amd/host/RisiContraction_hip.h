@@ -24,7 +24,10 @@ public:
     static const int nContractions = K;
 
     RisiContraction_hip(int max_N, int max_nChanels)
-        : Tensor3D(max_N, max_N, K * max_nChanels), N(max_N), nChanels(max_nChanels), adj(NULL), stacked(NULL), ctx(NULL) {}
+        : Tensor3D(max_N, max_N, K * max_nChanels), N(max_N), nChanels(max_nChanels), adj(NULL), stacked(NULL), ctx(NULL), own_ctx(NULL) {}
+    ~RisiContraction_hip() {
+        if (own_ctx) gf_ctx_destroy(own_ctx);
+    }
 
     // --- CPU-op style binding (RisiContraction_18.h:36-63) ---
     void setParameter(int N_, int nChanels_) {
@@ -60,11 +63,23 @@ public:
     }
 
     // RisiContraction_18_gpu::set_gpu_stream / turn_off_gpu_stream (:947-955).  `stream` is a hipStream_t.
+    // The stream belongs to THIS op, as in the reference (a per-object cudaStream_t): the op gets a context of its own the
+    // first time a stream is set on it, so the other ops of the thread keep running on the thread's default context.
     void set_gpu_stream(void *stream) {
-        gf_status st = gf_ctx_set_stream(context(), stream);
-        if (st != GF_OK) gfhost::die(context(), "gf_ctx_set_stream", st);
+        if (!own_ctx) {
+            const char *dev = std::getenv("GF_DEVICE");
+            gf_status st = gf_ctx_create(&own_ctx, dev ? std::atoi(dev) : 0, stream);
+            if (st != GF_OK) gfhost::die(NULL, "gf_ctx_create", st);
+            ctx = own_ctx;
+            return;
+        }
+        gf_status st = gf_ctx_set_stream(own_ctx, stream);
+        if (st != GF_OK) gfhost::die(own_ctx, "gf_ctx_set_stream", st);
+        ctx = own_ctx;
     }
-    void turn_off_gpu_stream() { set_gpu_stream(NULL); }
+    void turn_off_gpu_stream() {   // back to the thread's default context (the device's default stream)
+        if (ctx == own_ctx) ctx = NULL;
+    }
     void set_context(gf_ctx *c) { ctx = c; }
 
     void forward() {
@@ -108,6 +123,7 @@ protected:
     }
     Tensor4D *stacked;
     gf_ctx *ctx;
+    gf_ctx *own_ctx;   // created by set_gpu_stream, destroyed with the op
     std::vector<const gf_real *> vptr;
     std::vector<gf_real *> gptr;
 };

@@ -10,6 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include "gf_hip.h"
 
 namespace gfhost {
@@ -21,14 +24,25 @@ inline void die(gf_ctx *ctx, const char *where, gf_status st) {
 
 // One context per host thread, created on first use on device GF_DEVICE (default 0): the reference's threading
 // rule is one model clone per worker thread with no sharing (SMP_omega.h:115-129).
+// Destroyed when the thread exits (workspace, staging and pinned buffers go with it): models and ops of the thread must not
+// outlive the thread, as in the reference, where a worker's model clone is used by that worker only.
+struct ThreadContext {
+    gf_ctx *ctx;
+    ThreadContext() : ctx(NULL) {}
+    ~ThreadContext() {
+        // (not on the main thread: its thread-locals die BEFORE objects of static storage duration, and the reference's drivers
+        //  keep their models at file scope -- `SMP_omega train_network(...)`; the process is exiting there anyway)
+        if (ctx && (long)syscall(SYS_gettid) != (long)getpid()) gf_ctx_destroy(ctx);
+    }
+};
 inline gf_ctx *default_context() {
-    static thread_local gf_ctx *ctx = NULL;
-    if (!ctx) {
+    static thread_local ThreadContext holder;
+    if (!holder.ctx) {
         const char *dev = std::getenv("GF_DEVICE");
-        gf_status st = gf_ctx_create(&ctx, dev ? std::atoi(dev) : 0, NULL);
+        gf_status st = gf_ctx_create(&holder.ctx, dev ? std::atoi(dev) : 0, NULL);
         if (st != GF_OK) die(NULL, "gf_ctx_create", st);
     }
-    return ctx;
+    return holder.ctx;
 }
 
 inline gf_status contract_forward_host(gf_ctx *c, int K, const double *const *t, const double *A, double *out, int N, int C) {

@@ -143,6 +143,17 @@ int run(int N, int C) {
         for (size_t i = 0; i < per; ++i) bad |= (stack.gradient[a * per + i] != tensors[a]->gradient[i]);
     std::printf("Tensor4D binding identical to add_tensor binding: %s\n", bad ? "NO / FAILED" : "yes");
 
+    // set_gpu_stream is per op (RisiContraction_18_gpu.h:947-955): op2 moves to a context of its own, `op` stays where it was;
+    // results do not depend on the stream, and turn_off_gpu_stream brings op2 back
+    op2.set_gpu_stream(NULL);
+    op2.forward();
+    op.forward();
+    for (size_t i = 0; i < nO; ++i) bad |= (op2.value[i] != op.value[i]);
+    op2.turn_off_gpu_stream();
+    op2.forward();
+    for (size_t i = 0; i < nO; ++i) bad |= (op2.value[i] != op.value[i]);
+    std::printf("per-op stream context: %s\n", bad ? "FAILED" : "ok");
+
     for (int i = 0; i < N; ++i) delete tensors[i];
     std::printf(bad ? "FAILED\n" : "PASSED\n");
     return bad;
