@@ -471,6 +471,7 @@ __global__ __launch_bounds__(256) void smp_fold_level(FoldArgs a, float *__restr
 // adjacency once instead of four times.  Items = (x, e) / (x, y) pairs dealt to the sixteen row groups.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kCombX = 4;
+constexpr int kFusedMaxN = 32;  // receptive-field cap of the fused levels (smp_fused_supported)
 struct QuadWhere {
     int N, x0, cnt, node, win;
     size_t rowbase, pairbase;
@@ -514,9 +515,18 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AdjLds L = load_adjacency_lite<false>(smem, A + rowbase, rsum + pairbase, N);  // (published by the barrier below)
     float *sU = smem + adj_lds_floats(N);  // [kCombX][N][CW]  Z[x,e] + Z'[e,x] (+ compact terms)
-    for (int it = grp; it < items; it += NGRP) {
+    // Phase-2 item `it` = (xi, y) reads the O_loc block of the row whose U block phase-1 item `it` = (xi, e = y) reads:
+    // both are fetched here, so a workgroup pays one HBM round trip instead of one either side of the barrier.
+    constexpr int MAXIT = (kCombX * kFusedMaxN + NGRP - 1) / NGRP;  // fused levels: N <= 32 (smp_fused_supported)
+    f4 oloc[MAXIT];
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        const int it = grp + k * NGRP;
+        if (it >= items) break;
         const int xi = it / N, e = it - xi * N, x = W.x0 + xi;
-        f4 u = ld4(O + (rowbase + (size_t)x * N + e) * ldo + O_Z * C + fc);
+        const float *orow = O + (rowbase + (size_t)x * N + e) * ldo + fc;
+        f4 u = ld4(orow + O_Z * C);
+        oloc[k] = ld4(orow + O_LOC * C);
         if (ocols == 3) u += ld4(O + (rowbase + (size_t)e * N + x) * ldo + O_ZP * C + fc);
         {  // + D_bb[x,e] K15 + D_ac[e,x] K16, gathered from the compact products of the level below
             const int pxe = pi[rowbase + (size_t)x * N + e], pex = pi[rowbase + (size_t)e * N + x];
@@ -527,17 +537,21 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
         }
         st4(sU + (size_t)it * CW + 4 * fl, fok ? u : splat(0.f));
     }
-    __syncthreads();
+    float *sV = sU + (size_t)kCombX * N * CW;  // [kCombX][CW]  Vout rows of the quad's x
+    if (grp < W.cnt) st4(sV + grp * CW + 4 * fl, ld4(Vout + (pairbase + W.x0 + grp) * (size_t)C + fc));
     const f4 sout = ld4(Sout + (size_t)W.node * C + fc);
     const f4 bb = ld4(bias + fc);
-    for (int it = grp; it < items; it += NGRP) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        const int it = grp + k * NGRP;
+        if (it >= items) break;
         const int xi = it / N, y = it - xi * N, x = W.x0 + xi;
         const float *const Tt[1] = {sU + (size_t)xi * N * CW};
         f4 m[1];
         small_matvec<1, CW>(L, N, y, fl, Tt, m);
-        const f4 vout = ld4(Vout + (pairbase + x) * (size_t)C + fc);
-        const float *o = O + (rowbase + (size_t)x * N + y) * ldo + fc;
-        const f4 z = bb + ld4(o + O_LOC * C) + m[0] + L.r[y] * vout + L.at(x, y, N) * sout;
+        const f4 vout = ld4(sV + xi * CW + 4 * fl);
+        const f4 z = bb + oloc[k] + m[0] + L.r[y] * vout + L.at(x, y, N) * sout;
         if (fok) {
             f4 out;
 #pragma unroll
@@ -578,16 +592,31 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
     const AdjLds L = load_adjacency_lite<true>(smem, A + rowbase, rsum + pairbase, N);  // L.A[e][y] = A+[y][e]; see the barrier below
     float *sDz = smem + adj_lds_floats(N);  // [kCombX][N][CW]
     const f4 gnode = node_dF ? ld4(node_dF + (size_t)W.node * C + fc) : splat(0.f);
-    for (int it = grp; it < items; it += NGRP) {
-        const int xi = it / N, y = it - xi * N, x = W.x0 + xi;
-        const size_t row = rowbase + (size_t)x * N + y;
-        const f4 fv = ld4(F + row * C + fc), g = node_dF ? gnode : ld4(dF + row * C + fc);
-        f4 dz;
+    constexpr int UB = 4;  // rows whose loads are issued together, ahead of their stores
+    for (int it0 = grp; it0 < items; it0 += UB * NGRP) {
+        f4 fv[UB], g[UB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dz[j] = fok ? g[j] * (fv[j] > 0.f ? 1.f : kAlphaF) : 0.f;
-        st4(sDz + (size_t)it * CW + 4 * fl, dz);
-        if (fok) {
-            st4(dO + row * ldo + O_LOC * C + f, dz);
+        for (int u = 0; u < UB; ++u) {
+            const int it = it0 + u * NGRP;
+            if (it < items) {
+                const int xi = it / N, y = it - xi * N;
+                const size_t row = rowbase + (size_t)(W.x0 + xi) * N + y;
+                fv[u] = ld4(F + row * C + fc);
+                g[u] = node_dF ? gnode : ld4(dF + row * C + fc);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int it = it0 + u * NGRP;
+            if (it < items) {
+                const int xi = it / N, y = it - xi * N;
+                const size_t row = rowbase + (size_t)(W.x0 + xi) * N + y;
+                f4 dz;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dz[j] = fok ? g[u][j] * (fv[u][j] > 0.f ? 1.f : kAlphaF) : 0.f;
+                st4(sDz + (size_t)it * CW + 4 * fl, dz);
+                if (fok) st4(dO + row * ldo + O_LOC * C + f, dz);
+            }
         }
     }
     __syncthreads();
@@ -777,7 +806,7 @@ size_t tables_bwd_lds(int N) {
 template <int LPC>
 size_t combine_lds(int N) {
     constexpr int CW = 4 * LPC;
-    return sizeof(float) * ((size_t)adj_lds_floats(N) + (size_t)kCombX * N * CW);
+    return sizeof(float) * ((size_t)adj_lds_floats(N) + (size_t)kCombX * (N + 1) * CW);  // + the forward's Vout rows
 }
 
 struct SizeClass {

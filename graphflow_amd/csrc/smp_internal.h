@@ -40,6 +40,10 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
 // trow != nullptr: compact O / dO layout ([O_loc | U], 2C wide) with the transposed-row gather inside the product (see kernel)
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
                                     int rows, const int *trow);
+// the compact-layout products on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip; GF_SMP_SPLIT=0: fp32 MFMA)
+bool smp_split_products();
+gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
+                                 int rows, const int *trow, int cus);
 gf_status splitk_fold(gf_ctx *ctx, const float *part, float *dest, size_t total, int splits, int accumulate);
 gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst);
 // the same product, partial images only (fold == caller's): `part` receives out->splits images of 8 * 64 * 64 floats

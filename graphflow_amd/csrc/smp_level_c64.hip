@@ -481,6 +481,7 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
         if (cu_count[di] < 1) cu_count[di] = 256;
     }
     const int cus = cu_count[di];
+    if (trow && smp_split_products()) return smp_rowpanel_split_c64(ctx, forward, A, rowscale, Wst, Out, rows, trow, cus);
     const size_t lds = sizeof(float) * 8 * 2 * 2 * 32 * (size_t)kRpWRow;
     // forward: four waves per SIMD (measured equal to two); backward: two waves per SIMD with 256 registers -- the 128-register
     // build of the backward panel spills 100 B per lane and waits for one block request per panel (1.84 -> 1.66 ms at cfg3).
