@@ -1006,6 +1006,11 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         UP(d.adj, h.adj);
         UP(d.rsum, h.rsum);
         UP(d.node_scale, h.rowscale);
+        d.max_tot = d.max_tr = 0.f;
+        for (size_t i = 0; i + 1 < h.rowscale.size(); i += 2) {
+            d.max_tot = std::max(d.max_tot, std::fabs(h.rowscale[i]));
+            d.max_tr = std::max(d.max_tr, std::fabs(h.rowscale[i + 1]));
+        }
         st = gf::upload(s, &d.rowscale, nullptr, (size_t)h.rows * 2);
         if (st != GF_OK) return st;
         UP(d.quad_node, h.quad_node);
@@ -1073,6 +1078,11 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     s->P = nullptr;  // [max ppos][C]: by far the largest buffer of the op-by-op path, taken from the pool only when a level needs it
     s->P_count = (size_t)maxp;  // (positions x channels of the level below, maximised over the levels)
     const gfsmp::LevelLayout &top = B.level[L];
+    s->blkmax = nullptr;
+    if (!s->cfg.physics && C == 64) {
+        st = gf::upload(s, &s->blkmax, nullptr, (size_t)gf::kBlkCopies * gf::kBlkStride * (L + 1));
+        if (st != GF_OK) return st;
+    }
     st = gf::upload(s, &s->sh, nullptr, (size_t)top.nNodes * C);
     if (st != GF_OK) return st;
     st = gf::upload(s, &s->vf, nullptr, (size_t)top.nNodes * C);
@@ -1145,6 +1155,7 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)nV * C)), dim3(256), 0, s->lv[0].f,
               (const float *)nullptr, C, (size_t)nV * C);
     if (s->fused) {
+        if (s->blkmax) GF_HIP_TRY(ctx, hipMemsetAsync(s->blkmax, 0, sizeof(unsigned) * gf::kBlkCopies * gf::kBlkStride * (size_t)(L + 1), ctx->stream));
         st = gf::smp_fused_stack_all(s, K);
         if (st != GF_OK) return st;
     }

@@ -49,6 +49,25 @@ __device__ __forceinline__ f4 fold_two_tables(f4 u, f4 v) {
 constexpr float kAlphaF = 0.01f;
 __device__ __forceinline__ float lreluf(float z) { return z > 0.f ? z : kAlphaF * z; }
 
+// ---- block maxima for the split-operand weight gradients (smp_level_c64_split.hip): the producers of T and dO keep the largest
+// magnitude they write per 64-column block of the level (as float bits: non-negative floats order like integers).  Only the
+// exponent is used.
+__device__ __forceinline__ float amax4(f4 v, float m) {
+    m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), m);
+    return fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), m);
+}
+__device__ __forceinline__ unsigned row16_max(unsigned v) {  // maximum over each row of 16 lanes (DPP)
+    auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    return mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));  // row_mirror
+}
+// The maxima are kept in kBlkCopies copies, 128 B apart, chosen by the workgroup's index: unconditional atomics whose results
+// nobody waits for, spread over that many cache lines (one hot word per block would serialise ~10^5 atomics a step in one L2
+// channel).  The consumer takes the maximum over the copies.
+__device__ __forceinline__ unsigned *blkmax_copy(unsigned *blkmax) { return blkmax + (blockIdx.x % kBlkCopies) * kBlkStride; }
+
 // column blocks of the table matrix T [rows][4C]
 enum { T_SAB = 0, T_SBC = 1, T_T6 = 2, T_T10 = 3, T_COLS = 4 };
 // column blocks of the projected matrix O [rows][3C].  O_LOC = tot O_tot + tr O_tr + O_dir: the per-node factors tot and
@@ -77,7 +96,8 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
                                                              const int *__restrict__ quad_node, const int *__restrict__ quad_b0,
                                                              const int *__restrict__ node_s, const long long *__restrict__ node_row,
                                                              const long long *__restrict__ node_pair, int quad_base, int C, int nwin,
-                                                             const int *__restrict__ quad_order) {
+                                                             const int *__restrict__ quad_order,
+                                                             unsigned *__restrict__ blkmax) {  // [4] maxima of T's blocks, or null
     constexpr int LPC = 16, PPW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,6 +146,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
 #pragma unroll
     for (int i = 0; i < NI; ++i) sbc[i] = t10[i] = splat(0.f);
     f4 dgsum = splat(0.f);
+    float mx_both = 0.f;  // largest |S_ab| (even c-groups) / |T6| (odd c-groups) this lane has produced
 
     // Row a of the slab through a buffer descriptor of the source tensor f_{l-1}[src(n, a)] (wave-uniform base, 32-bit lane
     // offsets): a structurally-zero position gets an out-of-range offset and the hardware returns 0 -- no 64-bit address
@@ -178,6 +199,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
             t6 += rc[i] * v;
         }
         const f4 both = fold_two_tables(sab, t6);  // even c-groups: S_ab[a,b], odd c-groups: T6[a,b]
+        mx_both = amax4(both, mx_both);
         dgsum += dcur;
         if (allok) {
             // every lane stores (c-groups 0/2 the S_ab block, 1/3 the T6 block; the pairs write identical values to the same
@@ -242,6 +264,27 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
         float *sc = scal + (pairbase + b) * 4 * (size_t)C + f;
         st4(sc + 0 * C, cs);
         st4(sc + 2 * C, dgsum);
+    }
+    if (blkmax) {  // (uniform)
+        float mx_sbc = 0.f, mx_t10 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            mx_sbc = amax4(sbc[i], mx_sbc);  // (positions past the node hold zeros)
+            mx_t10 = amax4(t10[i], mx_t10);
+        }
+        const unsigned rb = row16_max(__float_as_uint(mx_both)), rsb = row16_max(__float_as_uint(mx_sbc)), rt = row16_max(__float_as_uint(mx_t10));
+        auto at = [](unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); };
+        auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+        const unsigned m_sab = mx(at(rb, 0), at(rb, 32)), m_t6 = mx(at(rb, 16), at(rb, 48));
+        const unsigned m_sbc = mx(mx(at(rsb, 0), at(rsb, 16)), mx(at(rsb, 32), at(rsb, 48)));
+        const unsigned m_t10 = mx(mx(at(rt, 0), at(rt, 16)), mx(at(rt, 32), at(rt, 48)));
+        if (lane == 0) {
+            unsigned *slot = blkmax_copy(blkmax);
+            atomicMax(slot + T_SAB, m_sab);
+            atomicMax(slot + T_SBC, m_sbc);
+            atomicMax(slot + T_T6, m_t6);
+            atomicMax(slot + T_T10, m_t10);
+        }
     }
 }
 
@@ -575,9 +618,11 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                                                             const int *__restrict__ quad_b0, const int *__restrict__ node_s,
                                                             const long long *__restrict__ node_row,
                                                             const long long *__restrict__ node_pair, int C, int nwin,
-                                                            const float *__restrict__ rsum, int ocols) {
+                                                            const float *__restrict__ rsum, int ocols,
+                                                            unsigned *__restrict__ blkmax) {  // [2] maxima of dO's blocks L | dU, or null
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
+    float mx_l = 0.f, mx_u = 0.f;
     const int tid = threadIdx.x;
     const int grp = tid / LPC, fl = tid % LPC;
     const QuadWhere W = locate_quad(quad_node, quad_b0, node_s, node_row, node_pair, nwin);
@@ -614,6 +659,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                 f4 dz;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dz[j] = fok ? g[u][j] * (fv[u][j] > 0.f ? 1.f : kAlphaF) : 0.f;
+                mx_l = amax4(dz, mx_l);
                 st4(sDz + (size_t)it * CW + 4 * fl, dz);
                 if (fok) st4(dO + row * ldo + O_LOC * C + f, dz);
             }
@@ -625,6 +671,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
         const float *const Tt[1] = {sDz + (size_t)xi * N * CW};
         f4 m[1];
         small_matvec<1, CW>(L, N, e, fl, Tt, m);  // dU[e] = sum_y A+[y][e] dz[y]
+        mx_u = amax4(m[0], mx_u);
         if (fok) {
             st4(dO + (rowbase + (size_t)x * N + e) * ldo + O_Z * C + f, m[0]);
             if (ocols == 3) st4(dO + (rowbase + (size_t)e * N + x) * ldo + O_ZP * C + f, m[0]);
@@ -641,6 +688,18 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
             }
             float *dst = (k == 0) ? dVout : (k == 1) ? dSpart : dbpart;
             st4(dst + (pairbase + x) * (size_t)C + f, acc);
+        }
+    }
+    if (blkmax) {  // (uniform)
+        const unsigned rl = row16_max(__float_as_uint(mx_l)), ru = row16_max(__float_as_uint(mx_u));
+        auto at = [](unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); };
+        auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+        const unsigned m_l = mx(mx(at(rl, 0), at(rl, 16)), mx(at(rl, 32), at(rl, 48)));
+        const unsigned m_u = mx(mx(at(ru, 0), at(ru, 16)), mx(at(ru, 32), at(ru, 48)));
+        if ((tid & 63) == 0) {
+            unsigned *slot = blkmax_copy(blkmax);
+            atomicMax(slot, m_l);
+            atomicMax(slot + 1, m_u);
         }
     }
 }
@@ -854,7 +913,7 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
                        sizeof(short) * (size_t)c.smax * c.smax + 16;
     GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
               s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
-              d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order);
+              d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order, s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr);
     return GF_OK;
 }
 
@@ -1260,7 +1319,8 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     FoldGroup rowg;
     const bool stationary = C == 64 && !env_is("GF_SMP_WGRAD", '0');
     if (stationary) {
-        st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg, ocols == 2 ? d.trow : nullptr);
+        st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg, ocols == 2 ? d.trow : nullptr,
+                                    s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr, d.max_tot, d.max_tr);
         if (st != GF_OK) return st;
         used = (size_t)rowg.splits * rowg.n;
     } else {  // other channel counts: the grouped split-K launch (its own ordered reduction) into the stacked image, one "image"
@@ -1386,7 +1446,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
                   d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
-                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS);
+                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS, s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride + 4 : nullptr);
     }
     if (smp_grouped_small(s)) return smp_fused_backward_level_grouped(s, l, dKl, dbl);
     GF_LAUNCH(ctx, "smpf_node_sum", smp_node_sum, dim3(nodes), dim3(64), 0, d.dSpart, d.dSout, d.node_s, d.node_pair, C);

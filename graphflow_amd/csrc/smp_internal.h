@@ -44,11 +44,19 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
 bool smp_split_products();
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
                                  int rows, const int *trow, int cus);
+// blkmax: the level's block maxima (gf_smp::blkmax), kept by the producers of T and dO; max_tot / max_tr: of the level's row factors
+gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
+                                       int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr);
 gf_status splitk_fold(gf_ctx *ctx, const float *part, float *dest, size_t total, int splits, int accumulate);
 gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst);
 // the same product, partial images only (fold == caller's): `part` receives out->splits images of 8 * 64 * 64 floats
 gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
-                                 size_t part_floats, FoldGroup *out, const int *trow);
+                                 size_t part_floats, FoldGroup *out, const int *trow, const unsigned *blkmax = nullptr,
+                                 float max_tot = 0.f, float max_tr = 0.f);
+}
+
+namespace gf {
+constexpr int kBlkCopies = 64, kBlkStride = 32;  // copies of a level's block maxima, words between them (128 B)
 }
 
 struct gf_smp {
@@ -76,6 +84,7 @@ struct gf_smp {
         long long *pair_src_row = nullptr, *cons_ptr = nullptr, *cons_slab = nullptr, *cons_inv_off = nullptr;
         short *pi = nullptr, *inv = nullptr;
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
+        float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients)
         long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
         int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr;
         float *Fdc = nullptr, *Gc = nullptr, *dGc = nullptr, *dFdc = nullptr;  // [pairs of level l-1][2C] each
@@ -94,6 +103,10 @@ struct gf_smp {
         float *Wst = nullptr, *dWst = nullptr;      // [18][C][C] block-permuted K_l and its gradient
     };
     std::vector<DevLevel> lv;
+    // [levels + 1][kBlkCopies][kBlkStride] largest magnitudes (float bits) written this step into T's four blocks (words [0..4) of a
+    // copy) and dO's two ([4..6)) of a level, kept by the producing kernels for the split-operand weight gradients
+    // (smp_level_c64_split.hip); C = 64 only
+    unsigned *blkmax = nullptr;
     float *x = nullptr;      // [nVertices][FD]
     float *P = nullptr;      // shared promotion / dP buffer, max over levels of ppos*C; allocated on first use (ensure_P):
     size_t P_count = 0;      // the fused levels with the folded backward gather never materialise it

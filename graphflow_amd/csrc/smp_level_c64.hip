@@ -429,7 +429,8 @@ __global__ __launch_bounds__(TH, 1) void smp_rowpanel_c64(const float *__restric
 // 8 x 64 x 64 floats per row range.  T = [rows][256], dO = [rows][192], rowscale = [rows][2].  The row range per workgroup
 // depends on `rows` only: results are reproducible.  The caller folds the images in order.
 gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
-                                 size_t part_floats, FoldGroup *out, const int *trow) {
+                                 size_t part_floats, FoldGroup *out, const int *trow, const unsigned *blkmax, float max_tot,
+                                 float max_tr) {
     const size_t total = 8 * 4096;
     out->part = part;
     out->n = total;
@@ -443,11 +444,13 @@ gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, c
     const int splits = (rows + kchunk - 1) / kchunk;
     if ((size_t)splits * total > part_floats)
         return fail(ctx, GF_ERR_NOMEM, "smp_wgrad_partials_c64: %d partial images, room for %zu", splits, part_floats / total);
+    out->splits = splits;
+    if (trow && blkmax && smp_split_products())
+        return smp_wgrad_partials_split_c64(ctx, T, dO, rowscale, rows, kchunk, splits, part, trow, blkmax, max_tot, max_tr);
     const size_t lds = sizeof(float) * 2 * (size_t)kWgStage;
     gf_status st = opt_in_lds(ctx, smp_wgrad_c64, lds);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part, trow);
-    out->splits = splits;
     return GF_OK;
 }
 

@@ -286,6 +286,207 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
     for (; p < npanels; p += nwaves) panel(p, R0, R1);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients of the fused level (compact layout), same split operands.  The eight row block products
+//   dWst[p] = sum over rows of A_p[row]^T B_p[row],   A_p in T = [S_ab|S_bc|T6|T10],   B_p in {L, tot L, tr L, dU, dU[trow]}
+// reduce over the ROWS, so a row's exponent cannot scale it (the terms of one MFMA accumulation must share their scale): each of
+// the nine operand blocks carries one exponent for the whole level, the exponent of the largest magnitude in the block, which
+// the kernels that write T and dO keep as they go (blkmax; smp_tables_fwd_w, smp_combine_bwd).  The error of every term is then
+// bounded by 2^-22 of the LARGEST term of the sum -- what the fp32 accumulation of that sum resolves.
+//
+// A workgroup of eight waves owns a row range (as smp_wgrad_c64) and walks it in 16-row slices, three slices in flight and ONE
+// barrier per slice.  In the interval of slice i a thread splits its share of slice i + 1 (raw in registers, requested two
+// intervals ago) and stores the halves TRANSPOSED ([column][row pair], 48-byte rows: conflict-free b128 fragment reads) into the
+// other stage's four f16 images (A h / l: 256 columns, B h / l: 320 columns), requests its share of slice i + 3 into the
+// registers just freed, and runs its wave's product on the images of slice i: a 64 x 64 output as 2 x 2 MFMA tiles, 12 MFMAs
+// of 8 passes.  Partial images and their fold are those of smp_wgrad_c64: fixed row ranges, fixed order, reproducible.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWsThreads = 512, kWsSlice = 16, kWsRowWords = 12;  // 16 rows = 8 words of f16 pairs, padded to 48 B
+constexpr int kWsACols = 256, kWsBCols = 320;
+constexpr int kWsStageWords = 2 * (kWsACols + kWsBCols) * kWsRowWords;
+constexpr size_t kWsLds = 2 * (size_t)kWsStageWords * 4;
+static_assert(kBlkCopies == 64, "one copy of the block maxima per lane");
+// maximum over the wave (uniform result): DPP inside the rows of 16, then the four row values
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));  // row_mirror
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return mx(mx(a, b), mx(c, d));
+}
+__constant__ int c_ws_ablk[8] = {0, 1, 0, 2, 3, 0, 1, 0};  // S_ab, S_bc, S_ab, T6, T10, S_ab, S_bc, S_ab
+__constant__ int c_ws_bblk[8] = {1, 1, 2, 0, 0, 3, 3, 4};  // tot L, tot L, tr L, L, L, dU, dU, dU[trow]
+
+__global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__restrict__ T, const float *__restrict__ dO,
+                                                                  const float *__restrict__ rs, int rows, int kchunk,
+                                                                  float *__restrict__ part, const int *__restrict__ trow,
+                                                                  const unsigned *__restrict__ blkmax, float max_tot, float max_tr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ws_smem[];  // stage s: A h | A l | B h | B l
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kbeg = blockIdx.x * kchunk;
+    const int kend = (kbeg + kchunk < rows) ? kbeg + kchunk : rows;
+
+    // ---- the blocks' scales.  tot L and tr L are bounded by the product of the maxima.
+    float sA[4], iA[4], sB[5], iB[5];
+    unsigned bm[6];  // maximum over the copies the producers spread their atomics over (lane = copy)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) bm[b] = wave_max_u32(blkmax[(size_t)lane * kBlkStride + b]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) pow2_scale(bm[b], &sA[b], &iA[b]);
+    {
+        // (only the EXPONENT of a kept maximum is defined -- its mantissa is whichever wave raised the exponent first: bounds are
+        //  built from the power of two above it)
+        const float ml = 2.f * __uint_as_float(bm[4] & 0x7f800000u);
+        pow2_scale(bm[4], &sB[0], &iB[0]);
+        pow2_scale(__float_as_uint(ml * max_tot), &sB[1], &iB[1]);
+        pow2_scale(__float_as_uint(ml * max_tr), &sB[2], &iB[2]);
+        pow2_scale(bm[5], &sB[3], &iB[3]);
+        sB[4] = sB[3], iB[4] = iB[3];
+    }
+    auto pickA = [&](int b, const float(&v)[4]) {  // v[b] for a wave-uniform b
+        float m = v[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) m = b == i ? v[i] : m;
+        return m;
+    };
+    auto pickB = [&](int b, const float(&v)[5]) {
+        float m = v[0];
+#pragma unroll
+        for (int i = 1; i < 5; ++i) m = b == i ? v[i] : m;
+        return m;
+    };
+
+    // ---- staging tasks: one task = rows (k, k + 1) x 4 columns; a wave's task group = 8 column quads (128 B of a row) x the 8
+    // row pairs of the slice.  A: group g = wave (8 groups of 32 columns: block g >> 1).  B: groups 0..9 = wave, wave + 8 (waves 0
+    // and 1): block g >> 1 of {L, tot L, tr L, dU, dU[trow]}, column half g & 1.
+    const int q_lo = lane & 7, pair = lane >> 3;
+    struct Task {
+        f4v v0, v1;  // rows k, k + 1
+    };
+    constexpr int NB = 2;
+    struct Set {  // one slice's share of a thread: raw rows on their way from HBM
+        Task ta, tb[NB];
+        float f0[NB], f1[NB];  // the two rows' factor (tot for the tot L copy, tr for the tr L copy, else unused)
+    };
+    const bool has_b1 = wave < 2;
+    const int a_quad = 8 * wave + q_lo;
+    auto b_blk = [&](int e) { return (wave + 8 * e) >> 1; };
+    auto b_quad = [&](int e) { return 8 * ((wave + 8 * e) & 1) + q_lo; };
+    const float a_scale = pickA(wave >> 1, sA);
+    float b_scale[NB];
+#pragma unroll
+    for (int e = 0; e < NB; ++e) b_scale[e] = pickB(b_blk(e) < 5 ? b_blk(e) : 0, sB);
+    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_slice = [&](Set &S, int k0) {
+        const int last = kend - 1, k = k0 + 2 * pair;
+        const int c0 = k < last ? k : last, c1 = k + 1 < last ? k + 1 : last;
+        S.ta.v0 = *reinterpret_cast<const f4v *>(T + (size_t)c0 * 256 + 4 * a_quad);
+        S.ta.v1 = *reinterpret_cast<const f4v *>(T + (size_t)c1 * 256 + 4 * a_quad);
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            if (e == 1 && !has_b1) break;
+            const int blk = b_blk(e);
+            int r0 = c0, r1 = c1;
+            S.f0[e] = rs[(size_t)r0 * 2 + (blk == 2)];
+            S.f1[e] = rs[(size_t)r1 * 2 + (blk == 2)];
+            if (blk == 4) r0 = trow[r0], r1 = trow[r1];
+            const float *src = dO + (blk >= 3 ? 64 : 0) + 4 * b_quad(e);
+            S.tb[e].v0 = *reinterpret_cast<const f4v *>(src + (size_t)r0 * 128);
+            S.tb[e].v1 = *reinterpret_cast<const f4v *>(src + (size_t)r1 * 128);
+        }
+    };
+    // word (column col0 + j, pair) of the images <- halves of (row k, row k + 1) at column col0 + j
+    auto store_task = [&](const f4v &v0, const f4v &v1, unsigned *H, unsigned *L, int col0, float s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h2 h, l;
+            split_pair(v0[j], v1[j], s, &h, &l);
+            H[(col0 + j) * kWsRowWords + pair] = __builtin_bit_cast(unsigned, h);
+            L[(col0 + j) * kWsRowWords + pair] = __builtin_bit_cast(unsigned, l);
+        }
+    };
+    // rows past the range contribute zeros; the scaled copies of L take their row factors (fp32, as the fp32 kernel applies them)
+    auto store_slice = [&](const Set &S, int k0, unsigned *stage) {
+        unsigned *Ah = stage, *Al = Ah + kWsACols * kWsRowWords, *Bh = Al + kWsACols * kWsRowWords, *Bl = Bh + kWsBCols * kWsRowWords;
+        const int k = k0 + 2 * pair;
+        const bool ok0 = k < kend, ok1 = k + 1 < kend;
+        store_task(ok0 ? S.ta.v0 : zero4, ok1 ? S.ta.v1 : zero4, Ah, Al, 4 * a_quad, a_scale);
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            if (e == 1 && !has_b1) break;
+            const int blk = b_blk(e);
+            const bool scaled = blk == 1 || blk == 2;
+            const float m0 = scaled ? S.f0[e] : 1.f, m1 = scaled ? S.f1[e] : 1.f;
+            store_task(ok0 ? S.tb[e].v0 * m0 : zero4, ok1 ? S.tb[e].v1 * m1 : zero4, Bh, Bl, 64 * blk + 4 * b_quad(e), b_scale[e]);
+        }
+    };
+
+    f16v acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][1][r] = acc[1][0][r] = acc[1][1][r] = 0.f;
+    const int ablk = c_ws_ablk[wave], bblk = c_ws_bblk[wave];
+    auto products = [&](const unsigned *stage) {
+        const unsigned *Ah = stage, *Al = Ah + kWsACols * kWsRowWords, *Bh = Al + kWsACols * kWsRowWords, *Bl = Bh + kWsBCols * kWsRowWords;
+        const int ao = (ablk * 64 + li) * kWsRowWords + 4 * lg, bo = (bblk * 64 + li) * kWsRowWords + 4 * lg;
+        h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            ah[t] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(Ah + ao + t * 32 * kWsRowWords));
+            al[t] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(Al + ao + t * 32 * kWsRowWords));
+            bh[t] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(Bh + bo + t * 32 * kWsRowWords));
+            bl[t] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(Bl + bo + t * 32 * kWsRowWords));
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+    };
+    // interval of slice i (rows k0 ..): Ra holds slice i + 1, Rb the requests of slice i + 2
+    auto interval = [&](Set &Ra, int i, int k0) {
+        if (k0 + kWsSlice < kend) {
+            store_slice(Ra, k0 + kWsSlice, ws_smem + ((i + 1) & 1) * kWsStageWords);
+            if (k0 + 3 * kWsSlice < kend) load_slice(Ra, k0 + 3 * kWsSlice);
+        }
+        products(ws_smem + (i & 1) * kWsStageWords);
+        __syncthreads();
+    };
+    if (kbeg < kend) {
+        Set S0, S1;
+        load_slice(S0, kbeg);
+        if (kbeg + kWsSlice < kend) load_slice(S1, kbeg + kWsSlice);
+        store_slice(S0, kbeg, ws_smem);
+        if (kbeg + 2 * kWsSlice < kend) load_slice(S0, kbeg + 2 * kWsSlice);
+        __syncthreads();
+        // now: images of slice 0 in stage 0; S1 = slice 1; S0 = requests of slice 2
+        int i = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * kWsSlice, i += 2) {
+            interval(S1, i, k0);
+            if (k0 + kWsSlice < kend) interval(S0, i + 1, k0 + kWsSlice);
+        }
+    }
+    // back to fp32 units; C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const float unscale = pickA(ablk, iA) * pickB(bblk, iB);
+    float *out = part + ((size_t)blockIdx.x * 8 + wave) * 4096 + li;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                out[row * 64 + 32 * nt] = acc[mt][nt][r] * unscale;
+            }
+}
+
 }  // namespace
 
 bool smp_split_products() {  // (read per call: the parity tests switch it)
@@ -313,6 +514,17 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
         GF_LAUNCH(ctx, "smpf_products_bwd", (smp_rowpanel_split<false>), dim3((unsigned)grid), dim3(kSpThreads), kSpLds, A, rowscale, Wst,
                   Out, rows, trow);
     }
+    return GF_OK;
+}
+
+// The eight row block products of a fused level at C = 64 (compact layout) as partial images, split operands: the contract of
+// smp_wgrad_partials_c64 (same row ranges, same image layout, folded by the caller).
+gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
+                                       int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr) {
+    gf_status st = opt_in_lds(ctx, smp_wgrad_split, kWsLds);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_split, dim3((unsigned)splits), dim3(kWsThreads), kWsLds, T, dO, rowscale, rows, kchunk, part,
+              trow, blkmax, max_tot, max_tr);
     return GF_OK;
 }
 
