@@ -225,6 +225,9 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
     c64 = C == 64
     # projected matrix O / dO: [O_loc | U] (2C) when the three dedicated C = 64 product kernels run, else [O_loc | Z | Z'] (3C)
     oc = 2 if (c64 and all(os.environ.get(k, "1") != "0" for k in ("GF_SMP_ROWPANEL", "GF_SMP_WGRAD", "GF_SMP_GROUPED", "GF_SMP_COMPACT_O"))) else 3
+    # ... and then the three product kernels run on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip): 3 MFMA
+    # flops of a 16x faster pipe per algorithmic flop -- they are HBM streams, priced against the HBM roofline
+    split = oc == 2 and os.environ.get("GF_SMP_SPLIT", "1") != "0"
     for l in range(1, L + 1):
         _, R, S = sizes[l]
         _, Rp, _ = sizes[l - 1]
@@ -264,7 +267,8 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
             return {"note": "per-kernel timing disabled"}
         tot = {k: v[0] / steps for k, v in timers.items()}   # ms per step per kernel name
         dom = max(tot, key=tot.get)
-        if dom in kf:
+        mfma_bound = set() if split else set(kf)
+        if dom in mfma_bound:
             ach = kf[dom] / (tot[dom] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None,
@@ -274,6 +278,9 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "note": "algorithmic bytes of this kernel over all levels / its device time per step"}
+        if split:
+            roof["products"] = ("block products on v_mfma_f32_32x32x16_f16 with two-half fp32 operands (3 MFMAs per product term): "
+                                "byte-bound, priced against HBM; GF_SMP_SPLIT=0 runs them on the fp32 pipe (MFMA-bound)")
         pmc = latest_profile("_pmc_cfg3_hbm_bytes.json")   # committed PMC passes, this exact workload only
         if fused and (B, C) == (1024, 64) and pmc:
             with open(pmc) as fh:
@@ -283,7 +290,7 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
                 roof["traffic_source"] = os.path.basename(pmc)
         busy = latest_profile("_cfg3_mfma_busy.txt")
         real = {"smpf_products_fwd": "smp_rowpanel_c64<true>", "smpf_products_bwd": "smp_rowpanel_c64<false>", "smpf_wgrad": "smp_wgrad_c64"}
-        if fused and (B, C) == (1024, 64) and dom in real and busy:
+        if fused and (B, C) == (1024, 64) and dom in real and dom in mfma_bound and busy:
             for line in open(busy):
                 if line.startswith(real[dom]) and "MFMA busy" in line:
                     roof["mfma_busy_pmc"] = float(line.rsplit("MFMA busy", 1)[1])
@@ -291,10 +298,11 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
         roof["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
         roof["launches_per_step"] = round(sum(v[1] for v in timers.values() if v[1] > steps / 2) / steps, 1) if steps else None
         # every kernel with an algorithmic figure, against its own bound (the step is a composite of byte- and MFMA-bound kernels)
-        roof["per_kernel_frac"] = {k: round((kf[k] / (tot[k] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF) if k in kf
+        roof["per_kernel_frac"] = {k: round((kf[k] / (tot[k] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF) if k in mfma_bound
                                             else (kb[k] / (tot[k] * 1e-3) / 1e9 / HBM_PEAK_GBS), 3)
-                                   for k in tot if (k in kf or k in kb) and tot[k] > 0}
-        ideal_ms = sum(kf[k] / (MFMA_F32_PEAK_TF * 1e12) * 1e3 if k in kf else kb[k] / (HBM_PEAK_GBS * 1e9) * 1e3 for k in set(kf) | set(kb))
+                                   for k in tot if (k in mfma_bound or k in kb) and tot[k] > 0}
+        ideal_ms = sum(kf[k] / (MFMA_F32_PEAK_TF * 1e12) * 1e3 if k in mfma_bound else kb[k] / (HBM_PEAK_GBS * 1e9) * 1e3
+                       for k in mfma_bound | set(kb))
         roof["step_composite_frac"] = round(ideal_ms / ms_per_step, 4)
         roof["step_GBps"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
         roof["step_gemm_TFLOPs"] = round(step_flops / (ms_per_step * 1e-3) / 1e12, 2)
