@@ -295,12 +295,12 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
 // the kernels that write T and dO keep as they go (blkmax; smp_tables_fwd_w, smp_combine_bwd).  The error of every term is then
 // bounded by 2^-22 of the LARGEST term of the sum -- what the fp32 accumulation of that sum resolves.
 //
-// A workgroup of eight waves owns a row range (as smp_wgrad_c64) and walks it in 16-row slices, three slices in flight and ONE
-// barrier per slice.  In the interval of slice i a thread splits its share of slice i + 1 (raw in registers, requested two
+// A workgroup of eight waves takes every gridDim-th 16-row slice of the level, four slices in flight and ONE
+// barrier per slice.  In the interval of slice i a thread splits its share of slice i + 1 (raw in registers, requested three
 // intervals ago) and stores the halves TRANSPOSED ([column][row pair], 48-byte rows: conflict-free b128 fragment reads) into the
-// other stage's four f16 images (A h / l: 256 columns, B h / l: 320 columns), requests its share of slice i + 3 into the
+// other stage's four f16 images (A h / l: 256 columns, B h / l: 320 columns), requests its share of slice i + 4 into the
 // registers just freed, and runs its wave's product on the images of slice i: a 64 x 64 output as 2 x 2 MFMA tiles, 12 MFMAs
-// of 8 passes.  Partial images and their fold are those of smp_wgrad_c64: fixed row ranges, fixed order, reproducible.
+// of 8 passes.  Partial images and their fold are those of smp_wgrad_c64: a fixed set of rows per image, fixed order, reproducible.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kWsThreads = 512, kWsSlice = 16, kWsRowWords = 12;  // 16 rows = 8 words of f16 pairs, padded to 48 B
 constexpr int kWsACols = 256, kWsBCols = 320;
@@ -328,8 +328,11 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
     extern __shared__ __attribute__((aligned(16))) unsigned ws_smem[];  // stage s: A h | A l | B h | B l
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kbeg = blockIdx.x * kchunk;
-    const int kend = (kbeg + kchunk < rows) ? kbeg + kchunk : rows;
+    // The workgroup's n-th slice is slice blockIdx.x + n gridDim.x of the level: at any time the workgroups read one contiguous
+    // window of T and dO (4 MB), spread over every HBM channel.  (A contiguous row range per workgroup, as the fp32 kernel has,
+    // makes 256 streams a multiple of 32 KB apart that advance in step: the loads alone then take 0.94 ms, 4.8 TB/s.)
+    const int kend = rows;
+    auto K = [&](int n) { return (long long)(blockIdx.x + (long long)n * gridDim.x) * kWsSlice; };
 
     // ---- the blocks' scales.  tot L and tr L are bounded by the product of the maxima.
     float sA[4], iA[4], sB[5], iB[5];
@@ -382,38 +385,65 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
 #pragma unroll
     for (int e = 0; e < NB; ++e) b_scale[e] = pickB(b_blk(e) < 5 ? b_blk(e) : 0, sB);
     const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_slice = [&](Set &S, int k0) {
-        const int last = kend - 1, k = k0 + 2 * pair;
-        const int c0 = k < last ? k : last, c1 = k + 1 < last ? k + 1 : last;
+    // The gathered rows' indices (dU[trow]: waves 0 and 1, second task) are requested TWO requests ahead: a request that had to
+    // wait for its own indices would wait for everything the wave has in flight before them (loads return in order) -- a full HBM
+    // round trip inside every interval, which the barrier hands to all eight waves (measured: the interval WAS that round trip).
+    int ia0 = 0, ia1 = 0, ib0 = 0, ib1 = 0;  // trow of the rows (k, k + 1) of the wave's next / next-but-one request
+    auto fetch_trow = [&](int m, int &t0, int &t1) {
+        const long long k = K(m) + 2 * pair, last = kend - 1;
+        t0 = trow[k < last ? k : last];
+        t1 = trow[k + 1 < last ? k + 1 : last];
+    };
+    // NO branch in a request or around it: every wave issues the same loads every interval (waves 2..7 repeat their T request as
+    // a second "task" that is never stored; requests past the end of the level re-read its last rows).  With a conditional load
+    // anywhere in the loop the compiler cannot count what is in flight at the join and waits for vmcnt(0) before every split --
+    // the whole queue, the requests just issued included (the interval was one HBM round trip for that reason, too).
+    auto load_slice = [&](Set &S, int m) {  // the workgroup's m-th slice; calls come with consecutive m
+        const int g0 = ia0, g1 = ia1;
+        ia0 = ib0, ia1 = ib1;
+        fetch_trow(m + 2, ib0, ib1);
+        const long long last = kend - 1, kk = K(m) + 2 * pair;
+        const int c0 = (int)(kk < last ? kk : last), c1 = (int)(kk + 1 < last ? kk + 1 : last);
         S.ta.v0 = *reinterpret_cast<const f4v *>(T + (size_t)c0 * 256 + 4 * a_quad);
         S.ta.v1 = *reinterpret_cast<const f4v *>(T + (size_t)c1 * 256 + 4 * a_quad);
 #pragma unroll
         for (int e = 0; e < NB; ++e) {
-            if (e == 1 && !has_b1) break;
-            const int blk = b_blk(e);
-            int r0 = c0, r1 = c1;
-            S.f0[e] = rs[(size_t)r0 * 2 + (blk == 2)];
-            S.f1[e] = rs[(size_t)r1 * 2 + (blk == 2)];
-            if (blk == 4) r0 = trow[r0], r1 = trow[r1];
-            const float *src = dO + (blk >= 3 ? 64 : 0) + 4 * b_quad(e);
-            S.tb[e].v0 = *reinterpret_cast<const f4v *>(src + (size_t)r0 * 128);
-            S.tb[e].v1 = *reinterpret_cast<const f4v *>(src + (size_t)r1 * 128);
+            const int blk = b_blk(e);  // (e == 1: 4 on waves 0 and 1, no block on the others)
+            S.f0[e] = rs[(size_t)c0 * 2 + (blk == 2)];
+            S.f1[e] = rs[(size_t)c1 * 2 + (blk == 2)];
+            const bool gathered = blk == 4;
+            const float *src = blk < 5 ? dO + (blk >= 3 ? 64 : 0) + 4 * b_quad(e) : T + 4 * a_quad;
+            const int ld = blk < 5 ? 128 : 256;
+            S.tb[e].v0 = *reinterpret_cast<const f4v *>(src + (size_t)(gathered ? g0 : c0) * ld);
+            S.tb[e].v1 = *reinterpret_cast<const f4v *>(src + (size_t)(gathered ? g1 : c1) * ld);
         }
     };
     // word (column col0 + j, pair) of the images <- halves of (row k, row k + 1) at column col0 + j
+    // The i-th store of a lane takes column (i + rot) & 3 of its quad, rot = (q_lo >> 1) & 3: with every lane on column i, the 32
+    // lanes of a store group (8 quads x 4 pairs; bank = word % 32, row stride 12 words, quad stride 48) sit on 8 banks, four to a
+    // bank (SQ_LDS_BANK_CONFLICT was twice the LDS-active cycles).  Rotated, the group covers the 32 banks once
+    // (16 (q_lo & 1) + 12 ((i + rot) & 3) + pair): no conflicts measured.  The rotation of the lane's two float4 is eight selects each.
+    const int rot = (q_lo >> 1) & 3;
+    auto rotate = [&](f4v v) {
+        if (rot & 1) v = f4v{v[1], v[2], v[3], v[0]};
+        if (rot & 2) v = f4v{v[2], v[3], v[0], v[1]};
+        return v;
+    };
     auto store_task = [&](const f4v &v0, const f4v &v1, unsigned *H, unsigned *L, int col0, float s) {
+        const f4v r0 = rotate(v0), r1 = rotate(v1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int i = 0; i < 4; ++i) {
             h2 h, l;
-            split_pair(v0[j], v1[j], s, &h, &l);
-            H[(col0 + j) * kWsRowWords + pair] = __builtin_bit_cast(unsigned, h);
-            L[(col0 + j) * kWsRowWords + pair] = __builtin_bit_cast(unsigned, l);
+            split_pair(r0[i], r1[i], s, &h, &l);
+            const int w = (col0 + ((i + rot) & 3)) * kWsRowWords + pair;
+            H[w] = __builtin_bit_cast(unsigned, h);
+            L[w] = __builtin_bit_cast(unsigned, l);
         }
     };
     // rows past the range contribute zeros; the scaled copies of L take their row factors (fp32, as the fp32 kernel applies them)
-    auto store_slice = [&](const Set &S, int k0, unsigned *stage) {
+    auto store_slice = [&](const Set &S, long long k0, unsigned *stage) {
         unsigned *Ah = stage, *Al = Ah + kWsACols * kWsRowWords, *Bh = Al + kWsACols * kWsRowWords, *Bl = Bh + kWsBCols * kWsRowWords;
-        const int k = k0 + 2 * pair;
+        const long long k = k0 + 2 * pair;
         const bool ok0 = k < kend, ok1 = k + 1 < kend;
         store_task(ok0 ? S.ta.v0 : zero4, ok1 ? S.ta.v1 : zero4, Ah, Al, 4 * a_quad, a_scale);
 #pragma unroll
@@ -450,28 +480,33 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
             }
     };
-    // interval of slice i (rows k0 ..): Ra holds slice i + 1, Rb the requests of slice i + 2
-    auto interval = [&](Set &Ra, int i, int k0) {
-        if (k0 + kWsSlice < kend) {
-            store_slice(Ra, k0 + kWsSlice, ws_smem + ((i + 1) & 1) * kWsStageWords);
-            if (k0 + 3 * kWsSlice < kend) load_slice(Ra, k0 + 3 * kWsSlice);
-        }
-        products(ws_smem + (i & 1) * kWsStageWords);
+    // interval of the workgroup's slice n: Ra holds slice n + 1; the requests of slices n + 2 and n + 3 are in the other two sets
+    auto interval = [&](Set &Ra, int n) {
+        store_slice(Ra, K(n + 1), ws_smem + ((n + 1) & 1) * kWsStageWords);  // (past the end: zeros)
+        load_slice(Ra, n + 4);
+        products(ws_smem + (n & 1) * kWsStageWords);
         __syncthreads();
     };
-    if (kbeg < kend) {
-        Set S0, S1;
-        load_slice(S0, kbeg);
-        if (kbeg + kWsSlice < kend) load_slice(S1, kbeg + kWsSlice);
-        store_slice(S0, kbeg, ws_smem);
-        if (kbeg + 2 * kWsSlice < kend) load_slice(S0, kbeg + 2 * kWsSlice);
+    if (K(0) < kend) {
+        Set S0, S1, S2;
+        fetch_trow(0, ia0, ia1);
+        fetch_trow(1, ib0, ib1);
+        load_slice(S0, 0);
+        load_slice(S1, 1);
+        load_slice(S2, 2);
+        store_slice(S0, K(0), ws_smem);
+        load_slice(S0, 3);
         __syncthreads();
-        // now: images of slice 0 in stage 0; S1 = slice 1; S0 = requests of slice 2
-        int i = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += 2 * kWsSlice, i += 2) {
-            interval(S1, i, k0);
-            if (k0 + kWsSlice < kend) interval(S0, i + 1, k0 + kWsSlice);
+        // now: images of slice 0 in stage 0; S1 = slice 1, S2 = slice 2, S0 = slice 3
+        int left = (int)((kend - K(0) + (long long)gridDim.x * kWsSlice - 1) / ((long long)gridDim.x * kWsSlice));  // slices of this workgroup
+        int n = 0;
+        for (; left >= 3; n += 3, left -= 3) {  // (nothing conditional inside: see load_slice)
+            interval(S1, n);
+            interval(S2, n + 1);
+            interval(S0, n + 2);
         }
+        if (left >= 1) interval(S1, n);
+        if (left >= 2) interval(S2, n + 1);
     }
     // back to fp32 units; C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const float unscale = pickA(ablk, iA) * pickB(bblk, iB);
