@@ -14,6 +14,7 @@
 // registers, and runs the panel's products out of registers and LDS.  Row factors (tot / tr of the node, the row's and the
 // block's exponents) multiply the product's 32 x 64 result on its way into the output accumulator.
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_lds.h"
 #include "gf_internal.h"
@@ -109,18 +110,26 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
     struct Spl {
         uint4 h[4], l[4];  // eight f16 each
     };
-    // columns [64 blk + 32 lh, +32) of row `li` of panel p (at the node's transposed row if `tr`).  Rows past the end read the last
-    // row instead (unconditional loads: no branch per request); what is computed from them is never stored.
-    auto load_raw = [&](Raw &R, int p, int blk, bool tr) {
+    // columns [64 blk + 32 lh, +32) of row `li` of panel p, or of the given row (the transposed one).  Rows past the end read the
+    // last row instead (unconditional loads: no branch per request); what is computed from them is never stored.
+    auto load_raw_at = [&](Raw &R, int src_row, int blk) {
         __builtin_amdgcn_sched_barrier(0);  // (requests stay where the schedule below puts them: hoisted to the top of the panel
                                             //  they would all be live at once)
-        int row = p * 32 + li;
-        row = row < rows ? row : rows - 1;
-        const int src_row = tr ? trow[row] : row;
+        asm volatile("" : "+v"(src_row));   // (nor is the address arithmetic on a prefetched row index moved up to its load)
         const float *src = A + (size_t)src_row * LDA + blk * 64 + 32 * lh;
 #pragma unroll
         for (int q = 0; q < 8; ++q) R.a[q] = *reinterpret_cast<const f4v *>(src + 4 * q);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_raw = [&](Raw &R, int p, int blk) {
+        const int row = p * 32 + li;
+        load_raw_at(R, row < rows ? row : rows - 1, blk);
+    };
+    // The transposed row of the lane's row of panel p.  Requested a panel ahead of the block request that uses it: a request
+    // that waits for its own index waits for everything the wave has in flight before it (loads and stores return in order).
+    auto fetch_trow = [&](int p) {
+        const int row = p * 32 + li;
+        return trow[row < rows ? row : rows - 1];
     };
     auto load_scale = [&](int p) {
         int row = p * 32 + li;
@@ -197,10 +206,13 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
     };
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    auto store_out = [&](int p, int o, const f16v &acc0, const f16v &acc1) {
+    // (FULL: a panel wholly inside the matrix -- unconditional stores.  A conditional store or load anywhere in the panel loop
+    //  makes the compiler give up counting the memory queue at the join: it then waits for vmcnt(0), requests just issued included,
+    //  before every split.  The one partial panel of the matrix runs a second copy of the panel code.)
+    auto store_out = [&](int p, int o, const f16v &acc0, const f16v &acc1, auto full) {
         const int r0 = p * 32;
         float *out = Out + (size_t)(r0 + 4 * lh) * LDOUT + o * 64 + li;
-        if (r0 + 32 <= rows) {
+        if constexpr (decltype(full)::value) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
@@ -222,68 +234,73 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
     // One panel.  On entry Ra and Rb hold (requests for) the panel's first two blocks; every other block is requested as soon as
     // a raw buffer has been split, one to three products (0.4 - 1 us) ahead of its use, and the first two blocks of the wave's
     // next panel go out behind the panel's last ones.
-    float2 sc = load_scale(blockIdx.x * (kSpThreads / 64) + wave), scn = make_float2(0.f, 0.f);
-    auto panel = [&](int p, Raw &Ra, Raw &Rb) {
+    int tnext = fetch_trow(blockIdx.x * (kSpThreads / 64) + wave);
+    auto panel = [&](int p, Raw &Ra, Raw &Rb, auto full) {
         const int pn = p + nwaves;
+        const int tcur = tnext;   // the transposed rows of this panel's rows (requested during the previous panel)
+        tnext = fetch_trow(pn);
+        (void)tcur;
+        const float2 sc = load_scale(p);  // (used after the panel's first products)
         f16v acc0, acc1;
         Spl X, Y, Z;
         float iX, iY, iZ;
         if (FWD) {  // T blocks: 0 S_ab, 1 S_bc, 2 T6, 3 T10; outputs: 0 O_loc, 1 U.  Entry: Ra = S_ab, Rb = S_ab at the transposed rows
             split_blk(Ra, X, iX);
-            load_raw(Ra, p, 1, false);               // S_bc
+            load_raw(Ra, p, 1);                      // S_bc
             split_blk(Rb, Z, iZ);
-            load_raw(Rb, p, 2, false);               // T6
-            scn = load_scale(pn);
+            load_raw(Rb, p, 2);                      // T6
             clear(acc0, acc1);
             prod(X, iX, 5, acc0, acc1);
             prod(Z, iZ, 7, acc0, acc1);
             split_blk(Ra, Y, iY);
             prod(Y, iY, 6, acc0, acc1);
-            store_out(p, 1, acc0, acc1);
+            store_out(p, 1, acc0, acc1, full);
             clear(acc0, acc1);
             prod(X, iX * sc.x, 0, acc0, acc1);
             prod(X, iX * sc.y, 2, acc0, acc1);
-            load_raw(Ra, p, 3, false);               // T10 (once S_ab's registers are free: X, Y and two requests do not fit)
             prod(Y, iY * sc.x, 1, acc0, acc1);
+            load_raw(Ra, p, 3);                      // T10, once X and Y are dead: with two requests beside them the panel spills,
+                                                     // and a scratch reload waits for the whole memory queue
             split_blk(Rb, Z, iZ);
-            load_raw(Rb, pn, 0, true);               // S_ab of the next panel at its transposed rows
+            load_raw_at(Rb, tnext, 0);               // S_ab of the next panel at its transposed rows
             prod(Z, iZ, 3, acc0, acc1);
             split_blk(Ra, Z, iZ);
-            load_raw(Ra, pn, 0, false);              // S_ab of the next panel
+            load_raw(Ra, pn, 0);                     // S_ab of the next panel
             prod(Z, iZ, 4, acc0, acc1);
-            store_out(p, 0, acc0, acc1);
+            store_out(p, 0, acc0, acc1, full);
         } else {    // dO blocks: 0 L, 1 dU; outputs: 0 dS_ab, 1 dS_bc, 2 dT6, 3 dT10.  Entry: Ra = L, Rb = dU
             split_blk(Ra, X, iX);
-            load_raw(Ra, p, 1, true);                // dU at the transposed rows
+            load_raw_at(Ra, tcur, 1);                // dU at the transposed rows
             split_blk(Rb, Y, iY);
-            load_raw(Rb, pn, 1, false);              // dU of the next panel
-            scn = load_scale(pn);
+            load_raw(Rb, pn, 1);                     // dU of the next panel
             clear(acc0, acc1);
             prod(X, iX, 3, acc0, acc1);
-            store_out(p, 2, acc0, acc1);
+            store_out(p, 2, acc0, acc1, full);
             clear(acc0, acc1);
             prod(X, iX, 4, acc0, acc1);
-            store_out(p, 3, acc0, acc1);
+            store_out(p, 3, acc0, acc1, full);
             clear(acc0, acc1);
             prod(X, iX * sc.x, 1, acc0, acc1);
             prod(Y, iY, 6, acc0, acc1);
-            store_out(p, 1, acc0, acc1);
+            store_out(p, 1, acc0, acc1, full);
             clear(acc0, acc1);
             prod(X, iX * sc.x, 0, acc0, acc1);
             prod(X, iX * sc.y, 2, acc0, acc1);
             prod(Y, iY, 5, acc0, acc1);
             split_blk(Ra, Z, iZ);
-            load_raw(Ra, pn, 0, false);              // L of the next panel
+            load_raw(Ra, pn, 0);                     // L of the next panel
             prod(Z, iZ, 7, acc0, acc1);
-            store_out(p, 0, acc0, acc1);
+            store_out(p, 0, acc0, acc1, full);
         }
-        sc = scn;
     };
     Raw R0, R1;
     int p = blockIdx.x * (kSpThreads / 64) + wave;
-    load_raw(R0, p, 0, false);
-    load_raw(R1, p, FWD ? 0 : 1, FWD);
-    for (; p < npanels; p += nwaves) panel(p, R0, R1);
+    load_raw(R0, p, 0);
+    if (FWD) load_raw_at(R1, tnext, 0);
+    else load_raw(R1, p, 1);
+    const int nfull = rows / 32;
+    for (; p < nfull; p += nwaves) panel(p, R0, R1, std::true_type{});
+    if (p < npanels) panel(p, R0, R1, std::false_type{});  // (the matrix's partial last panel: one wave of the grid)
 }
 
 
