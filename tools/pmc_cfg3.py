@@ -12,13 +12,13 @@ def launch_name(k):
     m = re.match(r"gf::gemm_f32_mfma_free<(true|false), (true|false)", k)
     if m:
         return "smpf_small_" + ("t" if m.group(1) == "true" else "n") + ("t" if m.group(2) == "true" else "n")
-    m = re.match(r"gf::smp_rowpanel_c64<(true|false)", k)
+    m = re.match(r"gf::smp_rowpanel_(?:c64|split)<(true|false)", k)
     if m:
         return "smpf_products_fwd" if m.group(1) == "true" else "smpf_products_bwd"
     base = re.sub(r"[<(].*", "", k).split("::")[-1]
     table = {"smp_tables_fwd": "smpf_tables_fwd", "smp_tables_fwd_w": "smpf_tables_fwd", "smp_tables_bwd": "smpf_tables_bwd",
              "smp_combine_fwd": "smpf_combine_fwd", "smp_combine_bwd": "smpf_combine_bwd", "promote_backward": "smp_promote_bwd",
-             "smp_vectors": "smpf_vectors", "smp_bwd_gather": "smpf_bwd_gather", "smp_wgrad_c64": "smpf_wgrad",
+             "smp_vectors": "smpf_vectors", "smp_bwd_gather": "smpf_bwd_gather", "smp_wgrad_c64": "smpf_wgrad", "smp_wgrad_split": "smpf_wgrad",
              "smp_reduce_pairs": "smpf_reduce_pairs", "smp_fold_level": "smpf_fold", "diag_gather_bwd": "smpf_diag_gather_bwd",
              "diag_gather_fwd": "smpf_diag_gather", "stack_weights_all": "smpf_stack_w", "readout_nodes_v": "smp_readout_nodes",
              "fam_backward_rows": "fam_backward", "fam_products_lds": "fam_products"}
