@@ -18,6 +18,7 @@
 // HBM traffic per level drops from about (2 S + 40 R) C floats to about 19 R C, GEMM flops from 18 to 8 units
 // (R = sum s^2, S = sum s^3).
 #include <algorithm>
+#include <type_traits>
 
 #include "r18_device.h"
 #include "smp_internal.h"
@@ -87,7 +88,7 @@ __constant__ int c_kperm[18] = {0, 2, 6, 5, 9, 8, 12, 11, 15, 16, 1, 3, 7, 10, 4
 // rows split over four waves paid about ten barriers of prologue/epilogue and was slower in every size class: 3.3 -> 2.6 ms
 // for s <= 16, 0.73 -> 0.54 ms for 16 < s <= 32 at cfg3.)
 // ---------------------------------------------------------------------------------------------------------------
-template <int NI>
+template <int NI, bool ALLOK>  // ALLOK: C is a multiple of 64 -- every lane of every window has channels
 __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  // (NI = 4 sat at 130 VGPRs: capped to 128 -> 4 waves per SIMD)
     const float *__restrict__ fprev, const float *__restrict__ rsum,
                                                              float *__restrict__ T, float *__restrict__ Vt,
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
     const int f = win * 64 + 4 * fl;
     const bool fok = f < C;
     const int fld = fok ? f : 0;
-    const bool allok = (C & 63) == 0;  // (uniform) every lane of every window has channels
+    constexpr bool allok = ALLOK;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sR = smem;                                              // [N]
@@ -159,14 +160,16 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(srow & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((unsigned)(srow >> 32));
         const float *src = fprev + (((long long)hi << 32) | lo) * C;
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (size_t)sw * sw * C * sizeof(float));
-        const bool rowok = pb >= 0 && fok;
+        // (only rows with pi_a(b) >= 0 are ever requested -- `present` below; with every lane on a channel the request is
+        //  unconditional: no branch, nothing for the compiler to lose count of the memory queue over)
+        const bool rowok = ALLOK ? true : (pb >= 0 && fok);
         const int rowoff = (pb * sw * C + fld) * 4;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int pc = (cc[i] >= 0) ? map[cc[i]] : -1;
             v[i] = buf_ld4(rs, (rowok && pc >= 0) ? rowoff + pc * C * 4 : -1, 0);
         }
-        const int pd = (cg == 0) ? pb : map[a];
+        const int pd = map[(cg == 0) ? b : a];  // (one unconditional read: pi_a(b) for c-group 0, pi_a(a) for the others)
         dg = buf_ld4(rs, (rowok && cg < 2 && pd >= 0) ? rowoff + pd * C * 4 : -1, 0);
     };
 
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
         for (unsigned z = ~present & (N >= 32 ? 0xffffffffu : ((1u << N) - 1u)); z; z &= z - 1)
             st4(T + (rowbase + (size_t)__builtin_ctz(z) * N + b) * (size_t)(T_COLS * C) + f + (cg ? T_T6 : T_SAB) * C, splat(0.f));
     }
-    auto row_step = [&](int a, int an, const f4(&cur)[NI], const f4 &dcur, f4(&nxt)[NI], f4 &dnxt) {
+    auto row_step = [&](int a, int an, const f4(&cur)[NI], const f4 &dcur, f4(&nxt)[NI], f4 &dnxt, auto own_row) {
         load_row(an >= 0 ? an : a, nxt, dnxt);
         const float ra = sR[a];
         f4 sab = splat(0.f), t6 = splat(0.f);
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
             // address): a store that all paths issue can be COUNTED by the compiler, so waiting for the next row's loads
             // (vmcnt is in order over loads and stores) need not include it; lane-conditional stores cannot (-5 %)
             st4(tcol + a * tstep, both);  // table row (a, b)
-            if (a == b) {  // (wave-uniform)
+            if constexpr (decltype(own_row)::value) {  // a == b: the peeled first row
                 if (cg == 0) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);
                 if (cg == 2) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, both);
             }
@@ -229,17 +232,37 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
             present &= present - 1;
             return a;
         };
-        int a = pop();
-        load_row(a, bufA, dA);
-        for (;;) {
-            int an = pop();
-            row_step(a, an, bufA, dA, bufB, dB);
-            if (an < 0) break;
-            a = an;
-            an = pop();
-            row_step(a, an, bufB, dB, bufA, dA);
-            if (an < 0) break;
-            a = an;
+        if (ALLOK) {
+            // Row a = b (the node's own vertex: always present) first, outside the loop, with its two extra stores; the loop over
+            // the other rows then has no conditional store and is entered with the memory queue its back edge leaves (a row's
+            // requests and one store): the compiler counts the queue (vmcnt(N)) instead of draining it -- stores included --
+            // at the top of every pair of rows.  (Row order changes the order of the sums over a, not their terms.)
+            present &= ~(1u << b);
+            int a = b, an = pop();
+            load_row(a, bufA, dA);
+            row_step(a, an, bufA, dA, bufB, dB, std::true_type{});
+            while (an >= 0) {
+                a = an;
+                an = pop();
+                row_step(a, an, bufB, dB, bufA, dA, std::false_type{});
+                if (an < 0) break;
+                a = an;
+                an = pop();
+                row_step(a, an, bufA, dA, bufB, dB, std::false_type{});
+            }
+        } else {
+            int a = pop();
+            load_row(a, bufA, dA);
+            for (;;) {
+                int an = pop();
+                row_step(a, an, bufA, dA, bufB, dB, std::false_type{});
+                if (an < 0) break;
+                a = an;
+                an = pop();
+                row_step(a, an, bufB, dB, bufA, dA, std::false_type{});
+                if (an < 0) break;
+                a = an;
+            }
         }
     }
     f4 cs = splat(0.f);
@@ -911,9 +934,15 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     if (q_hi <= q_lo) return GF_OK;
     const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + sizeof(long long) * c.smax + sizeof(int) * ((c.smax + 3) & ~3) +
                        sizeof(short) * (size_t)c.smax * c.smax + 16;
-    GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
-              s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
-              d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order, s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr);
+    unsigned *bm = s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr;
+    if ((C & 63) == 0)
+        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
+                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
+                  d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order, bm);
+    else
+        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, false>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
+                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
+                  d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order, bm);
     return GF_OK;
 }
 
