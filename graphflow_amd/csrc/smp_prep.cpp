@@ -86,8 +86,10 @@ private:
     int want_ = 0, pending_ = 0;
     bool stop_ = false;
 };
+// One pool per CALLING thread: a loop that prepares two batches at once on two host threads (the graph preparation of a batch
+// takes longer than its device step since round 2) gets two sets of workers instead of queueing on one.
 WorkerPool &pool() {
-    static WorkerPool p;
+    static thread_local WorkerPool p;
     return p;
 }
 

@@ -412,6 +412,77 @@ def test_two_handles_alternate_without_waiting_for_each_other(gf):
         assert np.array_equal(a, b)
 
 
+def test_loader_threads_prepare_batches_side_by_side(gf):
+    """The end-to-end loop of bench.py: two host threads call gf_smp_prepare on different handles at the same time (a worker pool
+    per calling thread) while the main thread launches steps on a third.  Same gradients, bit for bit, as preparing and stepping
+    in turn on one thread."""
+    import threading
+    from graphflow_amd.smp import SMPOmega
+    F, D, C, L, cap = 5, 3, 64, 2, 29
+    batches = []
+    for b in range(4):
+        mols, tg = [], []
+        for seed in range(70 + 9 * b):   # (enough molecules for the parallel sections of the preparation to use their pools)
+            adj, feat, t = synthetic_molecule(4000 + 100 * b + seed)
+            mols.append((adj, feat))
+            tg.append(t)
+        batches.append((SMPOmega.pack(mols), dev(np.array(tg))))
+    p = dev(smp_params(C, F, D, L, 2))
+    steps, NH, NLOAD = 12, 4, 2
+
+    def serial():
+        net = SMPOmega(L, C, F, D, cap, True)
+        out = []
+        for it in range(steps):
+            net.prepare(batches[it % 4][0])
+            g = torch.empty(net.n_params, device="cuda")
+            net.forward(p, batches[it % 4][1])
+            net.backward(p, g)
+            out.append(g)
+        torch.cuda.synchronize()
+        return [x.cpu().numpy() for x in out]
+
+    def threaded():
+        nets = [SMPOmega(L, C, F, D, cap, True) for _ in range(NH)]
+        ready = [threading.Semaphore(0) for _ in range(NH)]
+        free = [threading.Semaphore(1) for _ in range(NH)]
+        errors = []
+
+        def loader(t):
+            try:
+                for it in range(t, steps, NLOAD):
+                    h = it % NH
+                    free[h].acquire()
+                    nets[h].prepare(batches[it % 4][0])
+                    ready[h].release()
+            except Exception as e:   # noqa: BLE001
+                errors.append(e)
+                for r in ready:
+                    r.release()
+
+        ths = [threading.Thread(target=loader, args=(t,)) for t in range(NLOAD)]
+        for th in ths:
+            th.start()
+        out = []
+        for it in range(steps):
+            h = it % NH
+            ready[h].acquire()
+            assert not errors, errors
+            g = torch.empty(nets[h].n_params, device="cuda")
+            nets[h].forward(p, batches[it % 4][1])
+            nets[h].backward(p, g)
+            out.append(g)
+            free[h].release()
+        for th in ths:
+            th.join()
+        torch.cuda.synchronize()
+        return [x.cpu().numpy() for x in out]
+
+    one, two = serial(), threaded()
+    for a, b in zip(one, two):
+        assert np.array_equal(a, b)
+
+
 def test_fused_levels_never_take_the_promotion_buffer(gf):
     """gf_smp_device_bytes: the fused path with the folded backward gather materialises neither P nor dP, so its batch holds
     less device memory than the op-by-op pipeline of the same batch (which takes the shared [sum s^3][C] buffer on first use)."""
