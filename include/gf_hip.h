@@ -227,7 +227,10 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out);
 gf_status gf_smp_destroy(gf_smp *smp);
 size_t    gf_smp_param_count(const gf_smp *smp);
 /* Host pointers: nVertices[nMol]; adj = the molecules' V x V int adjacency matrices back to back (DenseGraph::adj);
- * feature = their V x nFeatures matrices back to back (DenseGraph::feature).  Blocking (uploads index tables). */
+ * feature = their V x nFeatures matrices back to back (DenseGraph::feature).  Blocking (uploads index tables).
+ * Thread safety: DIFFERENT handles of one context may be prepared at the same time from different host threads (each calling
+ * thread has its own pool of preparation workers), also while another thread enqueues forward / backward on a third handle:
+ * the data-loader pattern of bench.py's end_to_end loop.  One handle is used by one thread at a time. */
 gf_status gf_smp_prepare(gf_smp *smp, int nMol, const int *nVertices, const int *adj, const double *feature);
 /* The use_coulomb constructors of SMP_omega (SMP_omega.h:71-113): the reduced adjacency of every receptive field is taken
  * from the molecules' V x V Coulomb matrices (DenseGraph::coulomb, back to back; :568-579) instead of 1 / adj.  The
