@@ -3,8 +3,8 @@
 //     x 2^k = h + l,   h = rn_f16(x 2^k),  l = rn_f16(x 2^k - h)          (22 significant bits, k a per-row / per-block exponent)
 // and a product a b is evaluated as  ah bh + ah bl + al bh  (three v_mfma_f32_32x32x16_f16 with fp32 accumulation; products of
 // f16 values are exact in fp32, the dropped al bl is 2^-22 of the term).  Against an fp64 product of the same operands the result
-// is as close as the fp32 MFMA's (both are dominated by the fp32 accumulation; measured in tests/test_split_numerics_gpu.py and
-// held to the same 1e-5 bar by every SMP parity test), while 64 columns of reduction cost 12 MFMAs of 8 passes instead of 32 of
+// is as close as the fp32 MFMA's (both are dominated by the fp32 accumulation; the arithmetic is emulated in tests/test_split_numerics.py
+// and the kernels are held to the same 1e-5 bar by every SMP parity test, tests/test_smp_gpu.py::test_split_operand_products_*), while 64 columns of reduction cost 12 MFMAs of 8 passes instead of 32 of
 // 16: the three product kernels of a level stop being bound by the fp32 matrix pipe (0.71 of its 157 TF/s peak, 0.83 of what the
 // sustained clock allows -- no headroom) and become HBM streams.
 //
