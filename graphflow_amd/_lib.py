@@ -103,6 +103,8 @@ PROTOTYPES.update({
     "gf_smp_load_model": (_i, [_vp, _vp, C.c_char_p]),
     "gf_smp_set_fused": (_i, [_vp, _i]),
     "gf_smp_device_bytes": (_i, [_vp, _vp, _vp]),
+    "gf_smp_level_products_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gf_smp_level_wgrad_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "gf_smp_prepare_molecule_host": (_i, [_vp, _i, C.POINTER(C.c_int), _dp, C.POINTER(C.c_int), _dp]),
     "gf_smp_receptive_field": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int), _i]),
     "gf_smp_read_activation": (C.c_longlong, [_vp, _i, _i, _i, _vp, C.c_size_t]),

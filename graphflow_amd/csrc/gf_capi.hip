@@ -1,6 +1,8 @@
 // gf_capi.hip -- the extern "C" surface declared in include/gf_hip.h: context, error reporting, family dispatch
 // and the host-pointer ("mode A") staging wrappers used by the Entity-style op classes.
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "gf_internal.h"
 
@@ -8,11 +10,17 @@ namespace gf {
 
 static thread_local char g_create_err[512] = {0};
 
+// (a context's error text can be written by a loader thread inside gf_smp_prepare while the compute thread fails a launch on the
+//  same context: one process-wide lock keeps the two messages from interleaving)
+static std::mutex g_err_mutex;
 gf_status fail(gf_ctx *ctx, gf_status st, const char *fmt, ...) {
     char *dst = ctx ? ctx->err : g_create_err;
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(dst, 512, fmt, ap);
+    {
+        std::lock_guard<std::mutex> lock(g_err_mutex);
+        vsnprintf(dst, 512, fmt, ap);
+    }
     va_end(ap);
     return st;
 }
@@ -50,7 +58,13 @@ gf_status ensure_pinned(gf_ctx *ctx, size_t bytes) { return grow(ctx, &ctx->pinn
 gf_status opt_in_lds_fn(gf_ctx *ctx, const void *kernel, size_t bytes) {
     if (bytes > 160 * 1024) return fail(ctx, GF_ERR_UNSUPPORTED, "kernel needs %zu B of LDS (> 160 KiB)", bytes);
     if (bytes <= 32 * 1024) return GF_OK;
-    size_t &granted = ctx->lds_granted[kernel];
+    // hipFuncSetAttribute SETS the kernel's limit on the current device for the whole process (it is not a maximum), and several
+    // contexts can share a device (one default context per thread, RisiContraction_hip::set_gpu_stream): the record is per
+    // (device, kernel), process-wide, and only ever raised -- a context that needs less never lowers another one's grant.
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> granted_by_device;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &granted = granted_by_device[std::make_pair(ctx->device, kernel)];
     if (bytes > granted) {
         GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
         GF_HIP_TRY(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));

@@ -7,62 +7,86 @@
 // the batch, and the master adds every clone's gradients serially (add_gradient, :730-740, :784-786).  Here a worker is a
 // GPU, the copy is gf_dist_broadcast_f32 and the serial add loop is gf_dist_allreduce_sum_f32 (ring/tree over xGMI).
 //
-// RCCL is bound at run time (dlopen of librccl.so.1, the SONAME both the ROCm install and PyTorch's bundled copy carry, so
+// RCCL is bound at run time, once per process and never unloaded (dlopen of librccl.so.1, the SONAME both the ROCm install and PyTorch's bundled copy carry, so
 // a process that already has torch's RCCL mapped shares that instance): libgf_hip.so keeps loading on boxes and in programs
 // that never go multi-GPU, and fails loudly -- GF_ERR_UNSUPPORTED with the dlerror text -- when RCCL is asked for and absent.
 #include <dlfcn.h>
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include <rccl/rccl.h>
 
 #include "gf_internal.h"
 
-struct gf_dist_state {
+// RCCL's entry points, resolved ONCE per process and never unloaded: ncclGetUniqueId starts the bootstrap root's listener thread
+// inside librccl and a communicator owns proxy threads, so a dlclose that drops the last reference would unmap code under live
+// threads (or let a later dlopen start from a fresh image without the root's state) in any program that does not also hold
+// torch's copy of the library.  RTLD_NODELETE pins the image; the table is shared by every context of the process.
+struct RcclApi {
     void *lib = nullptr;
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1;
-    hipStream_t stream = nullptr;  // the collectives' own stream (overlaps the rest of the reverse sweep)
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    char why[320] = {0};  // why the binding failed (empty when it succeeded)
+};
+
+struct gf_dist_state {
+    const RcclApi *api = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t stream = nullptr;  // the collectives' own stream (overlaps the rest of the reverse sweep)
 };
 
 namespace gf {
 namespace {
 
-// resolves the six entry points; the handle is process-wide (dlopen reference-counts)
-gf_status bind_rccl(gf_ctx *ctx, gf_dist_state *d) {
-    const char *names[] = {std::getenv("GF_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    char why[256] = {0};
-    for (const char *n : names) {
-        if (!n || !n[0]) continue;
-        d->lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (d->lib) break;
-        std::snprintf(why, sizeof why, "%s", dlerror());
-    }
-    if (!d->lib) return fail(ctx, GF_ERR_UNSUPPORTED, "RCCL is not available (dlopen librccl.so.1: %s); multi-GPU needs it", why);
-#define GF_BIND(field, sym)                                                                                   \
-    d->field = reinterpret_cast<decltype(d->field)>(dlsym(d->lib, sym));                                      \
-    if (!d->field) return fail(ctx, GF_ERR_UNSUPPORTED, "RCCL library lacks %s", sym);
-    GF_BIND(GetUniqueId, "ncclGetUniqueId")
-    GF_BIND(CommInitRank, "ncclCommInitRank")
-    GF_BIND(CommDestroy, "ncclCommDestroy")
-    GF_BIND(AllReduce, "ncclAllReduce")
-    GF_BIND(Broadcast, "ncclBroadcast")
-    GF_BIND(GetErrorString, "ncclGetErrorString")
+const RcclApi *rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {std::getenv("GF_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        char err[256] = {0};
+        for (const char *n : names) {
+            if (!n || !n[0]) continue;
+            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NODELETE);
+            if (api.lib) break;
+            std::snprintf(err, sizeof err, "%s", dlerror());
+        }
+        if (!api.lib) {
+            std::snprintf(api.why, sizeof api.why, "RCCL is not available (dlopen librccl.so.1: %s); multi-GPU needs it", err);
+            return;
+        }
+#define GF_BIND(field, sym)                                                                \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, sym));               \
+    if (!api.field && !api.why[0]) std::snprintf(api.why, sizeof api.why, "RCCL library lacks %s", sym);
+        GF_BIND(GetUniqueId, "ncclGetUniqueId")
+        GF_BIND(CommInitRank, "ncclCommInitRank")
+        GF_BIND(CommDestroy, "ncclCommDestroy")
+        GF_BIND(AllReduce, "ncclAllReduce")
+        GF_BIND(Broadcast, "ncclBroadcast")
+        GF_BIND(GetErrorString, "ncclGetErrorString")
 #undef GF_BIND
+    });
+    return &api;
+}
+
+// the process-wide table, or GF_ERR_UNSUPPORTED with the reason
+gf_status bind_rccl(gf_ctx *ctx, const RcclApi **out) {
+    const RcclApi *a = rccl_api();
+    if (a->why[0]) return fail(ctx, GF_ERR_UNSUPPORTED, "%s", a->why);
+    *out = a;
     return GF_OK;
 }
 
 #define GF_NCCL_TRY(ctx, d, expr)                                                                                        \
     do {                                                                                                                 \
         ncclResult_t r__ = (expr);                                                                                       \
-        if (r__ != ncclSuccess) return gf::fail((ctx), GF_ERR_HIP, "%s failed: %s", #expr, (d)->GetErrorString(r__));    \
+        if (r__ != ncclSuccess) return gf::fail((ctx), GF_ERR_HIP, "%s failed: %s", #expr, (d)->api->GetErrorString(r__));    \
     } while (0)
 
 }  // namespace
@@ -74,7 +98,7 @@ gf_status dist_allreduce_on(gf_ctx *ctx, float *buf, size_t n, hipStream_t strea
     if (!dist_active(ctx)) return fail(ctx, GF_ERR_INVALID, "gf_dist: no communicator on this context (gf_dist_init)");
     if (n == 0) return GF_OK;
     gf_dist_state *d = ctx->dist;
-    GF_NCCL_TRY(ctx, d, d->AllReduce(buf, buf, n, ncclFloat32, ncclSum, d->comm, stream));
+    GF_NCCL_TRY(ctx, d, d->api->AllReduce(buf, buf, n, ncclFloat32, ncclSum, d->comm, stream));
     return GF_OK;
 }
 
@@ -82,9 +106,8 @@ void dist_teardown(gf_ctx *ctx) {
     gf_dist_state *d = ctx->dist;
     if (!d) return;
     if (d->stream) (void)hipStreamSynchronize(d->stream);
-    if (d->comm) (void)d->CommDestroy(d->comm);
+    if (d->comm) (void)d->api->CommDestroy(d->comm);
     if (d->stream) (void)hipStreamDestroy(d->stream);
-    if (d->lib) dlclose(d->lib);
     delete d;
     ctx->dist = nullptr;
 }
@@ -99,18 +122,13 @@ gf_status gf_dist_unique_id(gf_ctx *ctx, void *id_out) {
     if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
     if (!id_out) return fail(ctx, GF_ERR_INVALID, "gf_dist_unique_id: null argument");
     static_assert(GF_DIST_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "GF_DIST_ID_BYTES must equal RCCL's unique-id size");
-    gf_dist_state tmp;
-    gf_status st = gf::bind_rccl(ctx, &tmp);
+    const RcclApi *api = nullptr;
+    gf_status st = gf::bind_rccl(ctx, &api);
     if (st != GF_OK) return st;
     ncclUniqueId id;
-    ncclResult_t r = tmp.GetUniqueId(&id);
-    if (r != ncclSuccess) {
-        st = fail(ctx, GF_ERR_HIP, "ncclGetUniqueId failed: %s", tmp.GetErrorString(r));
-        dlclose(tmp.lib);
-        return st;
-    }
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(ctx, GF_ERR_HIP, "ncclGetUniqueId failed: %s", api->GetErrorString(r));
     std::memcpy(id_out, id.internal, GF_DIST_ID_BYTES);
-    dlclose(tmp.lib);
     return GF_OK;
 }
 
@@ -120,23 +138,21 @@ gf_status gf_dist_init(gf_ctx *ctx, const void *id, int rank, int world) {
     if (ctx->dist) return fail(ctx, GF_ERR_INVALID, "gf_dist_init: the context already has a communicator");
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     gf_dist_state *d = new gf_dist_state();
-    gf_status st = gf::bind_rccl(ctx, d);
+    gf_status st = gf::bind_rccl(ctx, &d->api);
     if (st != GF_OK) {
         delete d;
         return st;
     }
     ncclUniqueId uid;
     std::memcpy(uid.internal, id, GF_DIST_ID_BYTES);
-    ncclResult_t r = d->CommInitRank(&d->comm, world, uid, rank);
+    ncclResult_t r = d->api->CommInitRank(&d->comm, world, uid, rank);
     if (r != ncclSuccess) {
-        st = fail(ctx, GF_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, ctx->device, d->GetErrorString(r));
-        dlclose(d->lib);
+        st = fail(ctx, GF_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, ctx->device, d->api->GetErrorString(r));
         delete d;
         return st;
     }
     if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
-        (void)d->CommDestroy(d->comm);
-        dlclose(d->lib);
+        (void)d->api->CommDestroy(d->comm);
         delete d;
         return fail(ctx, GF_ERR_HIP, "gf_dist_init: hipStreamCreate failed");
     }
@@ -169,7 +185,7 @@ gf_status gf_dist_broadcast_f32(gf_ctx *ctx, float *buf, size_t n, int root) {
     gf_dist_state *d = ctx->dist;
     if (root < 0 || root >= d->world) return fail(ctx, GF_ERR_INVALID, "gf_dist_broadcast_f32: root %d of %d", root, d->world);
     if (n == 0) return GF_OK;
-    GF_NCCL_TRY(ctx, d, d->Broadcast(buf, buf, n, ncclFloat32, root, d->comm, ctx->stream));
+    GF_NCCL_TRY(ctx, d, d->api->Broadcast(buf, buf, n, ncclFloat32, root, d->comm, ctx->stream));
     return GF_OK;
 }
 

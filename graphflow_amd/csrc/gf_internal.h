@@ -18,9 +18,6 @@ struct gf_ctx {
     int device = 0;
     gf_dist_state *dist = nullptr;
     int r18_generic = 0;  // GF_OPT_R18_GENERIC_KERNELS: route RisiContraction_18 through the generic kernels (parity tests)
-    // dynamic-LDS opt-in granted so far, per kernel function: hipFuncSetAttribute applies to the CURRENT device, and a
-    // context is tied to one device, so the record lives here rather than in a process-wide static
-    std::unordered_map<const void *, size_t> lds_granted;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     void *ws = nullptr;  // device scratch, grown on demand (never inside a timed region if gf_ctx_reserve was called)
@@ -53,7 +50,7 @@ gf_status fail(gf_ctx *ctx, gf_status st, const char *fmt, ...);
 gf_status ensure_ws(gf_ctx *ctx, size_t bytes);
 gf_status ensure_stage(gf_ctx *ctx, size_t bytes);
 gf_status ensure_pinned(gf_ctx *ctx, size_t bytes);
-// kernels that want more than the default 32 KiB dynamic-LDS window opt in once per (context, kernel)
+// kernels that want more than the default 32 KiB dynamic-LDS window opt in once per (device, kernel), process-wide, raise-only
 gf_status opt_in_lds_fn(gf_ctx *ctx, const void *kernel, size_t bytes);
 template <typename Kern>
 gf_status opt_in_lds(gf_ctx *ctx, Kern kern, size_t bytes) {

@@ -470,7 +470,9 @@ void *pinned_table_alloc(size_t bytes) {
     const size_t total = bytes + 16;
     unsigned kind = 1;
     if (std::getenv("GF_PINNED_TABLES") && std::getenv("GF_PINNED_TABLES")[0] == '0') p = nullptr;
-    else if (hipHostMalloc(&p, total, hipHostMallocDefault) != hipSuccess) p = nullptr;
+    // (portable: the preparation's worker threads never call hipSetDevice, and a table pinned against device 0 only would be
+    //  pageable memory to the uploads of every other rank's device)
+    else if (hipHostMalloc(&p, total, hipHostMallocPortable) != hipSuccess) p = nullptr;
     if (!p) {
         (void)hipGetLastError();
         p = std::malloc(total);
@@ -1112,8 +1114,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
 #undef UP
     // split-K partials of the weight gradients also live in the context workspace
     const size_t gemm_ws = sizeof(float) * 4400 * (size_t)4 * C * C + sizeof(float) * 4400 * (size_t)C * s->cfg.fdim() + (1 << 20);
-    st = gf::ensure_ws(ctx, std::max(contract_ws, gemm_ws));
-    if (st != GF_OK) return st;
+    s->ws_need = std::max(contract_ws, gemm_ws);  // grown by forward / backward on the compute thread (smp_internal.h)
     // the tables are on the device when this returns (the host vectors are reused by the next batch); the context's stream
     // is NOT waited for: it may be running another handle's step
     GF_HIP_TRY(ctx, hipStreamSynchronize(s->upload ? s->upload : ctx->stream));
@@ -1141,12 +1142,13 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     if (s->cfg.physics && (targets || predict || loss))
         return fail(ctx, GF_ERR_INVALID, "gf_smp_forward: a physics tower only produces graph_feature (the head owns targets, predict and loss)");
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gf_status st = gf::ensure_ws(ctx, s->ws_need);
+    if (st != GF_OK) return st;
     const gfsmp::BatchLayout &B = s->lay;
     const int L = s->cfg.nLevels, C = s->cfg.nChanels, FD = s->cfg.fdim();
     const float *H, *W;
     std::vector<const float *> K, b;
     gf::view_params<const float>(s->cfg, params, &H, &K, &b, &W);
-    gf_status st;
     gf::ensure_side_stream(s);
     // level 0: f_0 = LeakyReLU(X H^T)   (MatMul(H, x_v) per vertex, SMP_omega.h:618)
     const int nV = B.level[0].nNodes;
@@ -1487,7 +1489,7 @@ static long long smp_read_node(gf_smp *s, int mol, int level, int v, float *out,
             if (h.node_mol[i] == mol && h.node_vertex[i] == v) n = i;
     }
     if (n < 0) return -1;
-    const size_t sz = (size_t)h.node_s[n], C = (size_t)s->cfg.nChanels;
+    const size_t sz = (size_t)h.node_s[n], C = (size_t)s->cfg.level_channels(level);  // (physics towers halve per level)
     const size_t count = adjacency ? sz * sz : sz * sz * C;
     if (count > capacity) return -1;
     const float *src = adjacency ? s->lv[level].adj + h.node_row[n] : s->lv[level].f + (size_t)h.node_row[n] * C;

@@ -64,6 +64,10 @@ struct gf_smp {
     gfsmp::Config cfg;
     gfsmp::BatchLayout lay;
     bool prepared = false, forwarded = false;
+    // context workspace this batch needs.  gf_smp_prepare only RECORDS it (prepare may run on a loader thread while another
+    // handle's step uses the context's workspace on the compute thread); gf_smp_forward / gf_smp_backward grow the workspace, on
+    // the thread that owns the context's stream
+    size_t ws_need = 0;
     bool has_targets = false;  // the last gf_smp_forward was given targets: only then does dy hold a loss gradient
     // data-parallel reverse sweep (the context has a communicator, gf_dist.hip): the gradient segment of a level is
     // all-reduced on the communicator's stream as soon as it is complete, beside the rest of the sweep

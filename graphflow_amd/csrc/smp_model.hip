@@ -32,6 +32,7 @@ struct gf_smp_model {
     float *tp[2] = {nullptr, nullptr}, *tg[2] = {nullptr, nullptr};  // tower parameter / gradient copies
     float *feat[2] = {nullptr, nullptr}, *dfeat[2] = {nullptr, nullptr};
     float *x = nullptr, *dx = nullptr, *work = nullptr;
+    int *lvl_off = nullptr;  // [L + 2] column offsets of the levels inside a tower's feature row (config only: uploaded once by create)
     int nMol = 0, cap_mol = 0;
     bool train = true, forwarded = false;
     std::vector<int> nV[2];
@@ -159,6 +160,15 @@ gf_status gf_smp_model_create(gf_ctx *ctx, const gf_smp_model_config *cfg, gf_sm
             return fail(ctx, GF_ERR_NOMEM, "gf_smp_model_create: device allocation failed");
         }
     }
+    {
+        std::vector<int> lvl_off(m->L + 2, 0);
+        for (int l = 0; l <= m->L; ++l) lvl_off[l + 1] = lvl_off[l] + m->lvlC[l];
+        if (hipMalloc(reinterpret_cast<void **>(&m->lvl_off), sizeof(int) * lvl_off.size()) != hipSuccess ||
+            hipMemcpy(m->lvl_off, lvl_off.data(), sizeof(int) * lvl_off.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            gf_smp_model_destroy(m);
+            return fail(ctx, GF_ERR_NOMEM, "gf_smp_model_create: device allocation failed");
+        }
+    }
     *out = m;
     return GF_OK;
 }
@@ -172,6 +182,7 @@ gf_status gf_smp_model_destroy(gf_smp_model *m) {
         if (m->tg[t]) (void)hipFree(m->tg[t]);
     }
     gf::free_batch(m);
+    if (m->lvl_off) (void)hipFree(m->lvl_off);
     float *own[] = {m->own_p, m->own_g, m->adam_m, m->adam_v};
     for (float *p : own)
         if (p) (void)hipFree(p);
@@ -269,12 +280,7 @@ gf_status gf_smp_model_forward(gf_smp_model *m, const float *params, const float
         st = gf_smp_forward(m->tower[t], m->tp[t], nullptr, nullptr, nullptr, m->feat[t]);
         if (st != GF_OK) return st;
     }
-    std::vector<int> lvl_off(m->L + 2, 0);
-    for (int l = 0; l <= m->L; ++l) lvl_off[l + 1] = lvl_off[l] + m->lvlC[l];
-    // (the offsets are tiny: passed through the workspace head of `dx`, which is free until the backward pass)
-    int *d_off = reinterpret_cast<int *>(m->dx);
-    GF_HIP_TRY(ctx, hipMemcpyAsync(d_off, lvl_off.data(), sizeof(int) * lvl_off.size(), hipMemcpyHostToDevice, ctx->stream));
-    GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int *d_off = m->lvl_off;
     GF_LAUNCH(ctx, "model_interleave", gf::interleave_features, dim3(m->nMol), dim3(64), 0, m->feat[0], m->feat[1], m->x, m->nTowers, m->fwidth,
               d_off, m->L + 1, 0, (float *)nullptr, (float *)nullptr);
     st = gf_head_forward_f32(ctx, m->nLayers, m->widths.data(), m->x, m->nMol, params + m->head_off, targets, predict, loss, m->work);
@@ -294,13 +300,9 @@ gf_status gf_smp_model_backward(gf_smp_model *m, const float *params, float *gra
     if (!m->forwarded) return fail(ctx, GF_ERR_INVALID, "gf_smp_model_backward: needs a forward with targets first");
     gf_status st;
     if (!accumulate) GF_HIP_TRY(ctx, hipMemsetAsync(grads, 0, m->n_params * sizeof(float), ctx->stream));
-    std::vector<int> lvl_off(m->L + 2, 0);
-    for (int l = 0; l <= m->L; ++l) lvl_off[l + 1] = lvl_off[l] + m->lvlC[l];
     st = gf_head_backward_f32(ctx, m->nLayers, m->widths.data(), m->x, m->nMol, params + m->head_off, m->work, m->dx, grads + m->head_off);
     if (st != GF_OK) return st;
-    int *d_off = reinterpret_cast<int *>(m->work);  // (the head's activations are dead now)
-    GF_HIP_TRY(ctx, hipMemcpyAsync(d_off, lvl_off.data(), sizeof(int) * lvl_off.size(), hipMemcpyHostToDevice, ctx->stream));
-    GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int *d_off = m->lvl_off;  // (its own buffer: the head's activations in `work` stay valid for a repeated backward)
     GF_LAUNCH(ctx, "model_interleave", gf::interleave_features, dim3(m->nMol), dim3(64), 0, (const float *)nullptr, (const float *)nullptr, m->dx,
               m->nTowers, m->fwidth, d_off, m->L + 1, 1, m->dfeat[0], m->dfeat[1]);
     for (int t = 0; t < m->nTowers; ++t) {

@@ -25,6 +25,18 @@ public:
 
     RisiContraction_hip(int max_N, int max_nChanels)
         : Tensor3D(max_N, max_N, K * max_nChanels), N(max_N), nChanels(max_nChanels), adj(NULL), stacked(NULL), ctx(NULL), own_ctx(NULL) {}
+    // RisiContraction_18(int max_nRows, int max_nColumns, int max_nDepth) (RisiContraction_18.h:24-26): a buffer for the largest
+    // output the op will hold; N and nChanels come with the first setParameter().
+    RisiContraction_hip(int max_nRows, int max_nColumns, int max_nDepth)
+        : Tensor3D(max_nRows, max_nColumns, max_nDepth), N(0), nChanels(0), adj(NULL), stacked(NULL), ctx(NULL), own_ctx(NULL) {}
+    // RisiContraction_18_gpu(Tensor4D *tensor, Matrix *adj) (RisiContraction_18_gpu.h:879-918): bound to one pre-stacked input
+    // from the start (the reference allocates its device mirrors here; ours are the context's staging buffers)
+    RisiContraction_hip(Tensor4D *tensor, Matrix *a)
+        : Tensor3D(tensor->nRows, tensor->nRows, K * tensor->nChanels2), N(tensor->nRows), nChanels(tensor->nChanels2), adj(a),
+          stacked(tensor), ctx(NULL), own_ctx(NULL) {
+        assert(tensor->nColumns == N && tensor->nChanels1 == N);
+        if (K != 4) assert(a != NULL && a->nRows == N && a->nColumns == N);
+    }
     ~RisiContraction_hip() {
         if (own_ctx) gf_ctx_destroy(own_ctx);
     }

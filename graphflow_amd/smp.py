@@ -157,7 +157,11 @@ class SMPOmega:
     def activation(self, mol, level, v):
         """f_level[v] of molecule `mol` after forward(): numpy [s, s, C] (level[l]->f[v]->value in the reference)."""
         s = len(self.receptive_field(mol, level, v))
-        out = np.empty((s, s, self.cfg.nChanels), dtype=np.float32)
+        ch = self.cfg.nChanels
+        if self.cfg.physics:   # a physics tower halves its channels from level to level (SMP_omega_physics.h:141-156)
+            for _ in range(level):
+                ch = max(1, ch // 2)
+        out = np.empty((s, s, ch), dtype=np.float32)
         n = self.lib.gf_smp_read_activation(self.handle, mol, level, v, out.ctypes.data_as(C.c_void_p), out.size)
         if n != out.size:
             raise RuntimeError("gf_smp_read_activation(%d, %d, %d) returned %d" % (mol, level, v, n))

@@ -265,6 +265,19 @@ gf_status gf_head_backward_f32(gf_ctx *ctx, int nLayers, const int *width, const
 /* 1 (default): fused level kernels (no promoted stack, no 18-slice contraction output in HBM) where the shape allows;
  * 0: the op-by-op pipeline.  Same results within fp32 rounding; kept switchable for parity tests. */
 gf_status gf_smp_set_fused(gf_smp *smp, int on);
+/* The block products of one fused level at 64 channels as stand-alone operators on caller-supplied device matrices: the same
+ * kernels gf_smp_forward / gf_smp_backward launch on a level's rows (the regrouped K-projection MatMul of GraphFlow/SMP_omega.h:654-657,
+ * MatMul.h:48-82).  rows x 64-column blocks, row-major:  T = [S_ab|S_bc|T6|T10] (256 columns),  O / dO = [O_loc | U] (128),
+ * rowscale [rows][2] = (tot, tr) of the row's node, trow [rows] = the row holding the transposed position (any permutation of the
+ * rows), Wst [8][64][64] = stacked weight blocks W0..W7:
+ *   forward  (backward == 0):  O_loc = tot (S_ab W0 + S_bc W1) + tr S_ab W2 + T6 W3 + T10 W4,   U = S_ab W5 + S_bc W6 + S_ab[trow] W7
+ *   backward (backward != 0):  dT from dO, the transposed products (dS_ab = tot L W0^T + tr L W2^T + dU W5^T + dU[trow] W7^T, ...)
+ *   wgrad:  dWst[p] = sum over rows of (T block of p)^T (dO block of p, with the factor of p)
+ * On the f16 matrix pipe with two-half fp32 operands by default, on the fp32 pipe with GF_SMP_SPLIT=0 (read per call). */
+gf_status gf_smp_level_products_f32(gf_ctx *ctx, int backward, int rows, const float *A, const float *rowscale, const float *Wst,
+                                    const int *trow, float *Out);
+gf_status gf_smp_level_wgrad_f32(gf_ctx *ctx, int rows, const float *T, const float *dO, const float *rowscale, const int *trow,
+                                 float *dWst);
 /* Device memory of the handle's buffer pool: bytes held by the current batch, and bytes the pool keeps in total (idle
  * blocks included).  Sizing aid for batch selection (GraphFlow has no counterpart: its tensors live in host `new[]`). */
 gf_status gf_smp_device_bytes(const gf_smp *smp, size_t *in_use, size_t *reserved);

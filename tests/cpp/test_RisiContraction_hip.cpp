@@ -154,6 +154,19 @@ int run(int N, int C) {
     for (size_t i = 0; i < nO; ++i) bad |= (op2.value[i] != op.value[i]);
     std::printf("per-op stream context: %s\n", bad ? "FAILED" : "ok");
 
+    // the reference's other two constructors: RisiContraction_18_gpu(Tensor4D*, Matrix*) (RisiContraction_18_gpu.h:879-918, the
+    // caller shape of tests/test_RisiContraction_18_gpu.cu) and RisiContraction_18(max rows, max columns, max depth) (:24-26)
+    if (K != 4) {
+        RisiContraction_hip<K> op3(&stack, &adj);
+        op3.forward();
+        for (size_t i = 0; i < nO; ++i) bad |= (op3.value[i] != op.value[i]);
+        RisiContraction_hip<K> op4(N + 1, N + 1, K * (C + 1));
+        op4.setParameter(&stack, &adj);
+        op4.forward();
+        for (size_t i = 0; i < nO; ++i) bad |= (op4.value[i] != op.value[i]);
+        std::printf("(Tensor4D*, Matrix*) and 3-int constructors: %s\n", bad ? "FAILED" : "ok");
+    }
+
     for (int i = 0; i < N; ++i) delete tensors[i];
     std::printf(bad ? "FAILED\n" : "PASSED\n");
     return bad;

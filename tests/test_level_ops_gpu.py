@@ -1,0 +1,179 @@
+"""The fused level's block products at C = 64 (gf_smp_level_products_f32 / gf_smp_level_wgrad_f32: the kernels of
+smp_level_c64_split.hip on the f16 matrix pipe with two-half fp32 operands, and of smp_level_c64.hip on the fp32 pipe) against the
+fp64 product of the same operands -- normalised PER OUTPUT ROW and per 32-column half (forward / backward products) and PER ROW of
+every weight-gradient block, not by one global maximum (round-2 review, weak #2): a global max-norm cannot see a precision loss
+confined to the small entries of a row whose largest entry is 10^6 times bigger.
+
+What the split arithmetic is: x 2^k = h + l with f16 halves, k chosen per (row, 64-column block) so that the block's largest
+magnitude lands in [2^13, 2^14).  f16 is a floating-point format, so an element keeps 22 significant bits OF ITS OWN as long as its
+l half stays normal -- down to 2^-17 of the row maximum -- and loses one bit per binary order below that (l goes subnormal,
+quantum 2^-24).  At 10^6 : 1 (2^20) inside one block the small entries keep 19 bits: 2e-6 of themselves.  These tests pin that
+window; beyond about 2^21 : 1 inside one row block the split path is not component-wise fp32-grade and GF_SMP_SPLIT=0 (the fp32
+pipe, same entry points, timed beside the split step by bench.py) is the path to use."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TOL = 1e-5
+
+
+def dev(x, dtype=np.float32):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=dtype)).cuda()
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def involution(rows, rng):
+    """a random pairing of the rows (trow of a level is the transposition (x, e) <-> (e, x): an involution with fixed points)"""
+    p = rng.permutation(rows)
+    t = np.arange(rows, dtype=np.int32)
+    for i in range(0, rows - 1 - (rows % 3), 2):
+        t[p[i]], t[p[i + 1]] = p[i + 1], p[i]
+    return t
+
+
+def forward_ref(T, rs, W, trow):
+    T = T.astype(np.float64)
+    W = W.astype(np.float64)
+    tot, tr = rs[:, :1].astype(np.float64), rs[:, 1:2].astype(np.float64)
+    Sab, Sbc, T6, T10 = (T[:, 64 * i:64 * i + 64] for i in range(4))
+    oloc = tot * (Sab @ W[0] + Sbc @ W[1]) + tr * (Sab @ W[2]) + T6 @ W[3] + T10 @ W[4]
+    u = Sab @ W[5] + Sbc @ W[6] + Sab[trow] @ W[7]
+    return np.concatenate([oloc, u], axis=1)
+
+
+def backward_ref(dO, rs, W, trow):
+    dO = dO.astype(np.float64)
+    W = W.astype(np.float64)
+    tot, tr = rs[:, :1].astype(np.float64), rs[:, 1:2].astype(np.float64)
+    L, dU = dO[:, :64], dO[:, 64:]
+    dSab = tot * (L @ W[0].T) + tr * (L @ W[2].T) + dU @ W[5].T + dU[trow] @ W[7].T
+    dSbc = tot * (L @ W[1].T) + dU @ W[6].T
+    return np.concatenate([dSab, dSbc, L @ W[3].T, L @ W[4].T], axis=1)
+
+
+def wgrad_ref(T, dO, rs, trow):
+    T, dO = T.astype(np.float64), dO.astype(np.float64)
+    tot, tr = rs[:, :1].astype(np.float64), rs[:, 1:2].astype(np.float64)
+    Sab, Sbc, T6, T10 = (T[:, 64 * i:64 * i + 64] for i in range(4))
+    L, dU = dO[:, :64], dO[:, 64:]
+    return np.stack([Sab.T @ (tot * L), Sbc.T @ (tot * L), Sab.T @ (tr * L), T6.T @ L, T10.T @ L, Sab.T @ dU, Sbc.T @ dU,
+                     Sab.T @ dU[trow]])
+
+
+def run_products(gf, backward, A, rs, W, trow):
+    from graphflow_amd.ops import default_context
+    ctx = default_context(0)
+    rows = A.shape[0]
+    out = torch.empty((rows, 256 if backward else 128), device="cuda")
+    a, r, w, t = dev(A), dev(rs), dev(W), dev(trow, np.int32)
+    ctx.check(ctx.lib.gf_smp_level_products_f32(ctx.handle, 1 if backward else 0, rows, ptr(a), ptr(r), ptr(w), ptr(t), ptr(out)))
+    torch.cuda.synchronize()
+    return out.cpu().numpy().astype(np.float64)
+
+
+def run_wgrad(gf, T, dO, rs, trow):
+    from graphflow_amd.ops import default_context
+    ctx = default_context(0)
+    out = torch.empty((8, 64, 64), device="cuda")
+    a, b, r, t = dev(T), dev(dO), dev(rs), dev(trow, np.int32)
+    ctx.check(ctx.lib.gf_smp_level_wgrad_f32(ctx.handle, T.shape[0], ptr(a), ptr(b), ptr(r), ptr(t), ptr(out)))
+    torch.cuda.synchronize()
+    return out.cpu().numpy().astype(np.float64)
+
+
+def row_half_err(x, ref):
+    """max over (row, 32-column half) of max|x - ref| / max|ref| within that half-row (halves whose reference is all zero: absolute)"""
+    rows = x.shape[0]
+    d = np.abs(x - ref).reshape(rows, -1, 32).max(axis=2)
+    m = np.abs(ref).reshape(rows, -1, 32).max(axis=2)
+    return float((d / np.where(m > 0, m, 1.0)).max())
+
+
+def make_case(rng, rows, width, big=1e6):
+    """rows of O(1) entries whose scale wanders over eight decades from row to row; in every 64-column block one channel is `big`
+    times larger than the rest of its row.  The weights IGNORE that channel in output columns [0, 32) of every product (zero rows)
+    and see it in [32, 64)."""
+    A = rng.standard_normal((rows, width)) * np.exp(rng.uniform(-9, 9, (rows, 1)))
+    hot = [64 * b + int(rng.integers(64)) for b in range(width // 64)]
+    A[:, hot] *= big
+    return A.astype(np.float32), hot
+
+
+@pytest.mark.parametrize("pipe", ["split", "fp32"])
+@pytest.mark.parametrize("rows", [1000, 4099])
+def test_products_per_row_with_1e6_range_inside_a_block(gf, monkeypatch, pipe, rows):
+    if pipe == "fp32":
+        monkeypatch.setenv("GF_SMP_SPLIT", "0")
+    rng = np.random.default_rng(rows)
+    trow = involution(rows, rng)
+    rs = np.stack([rng.uniform(1, 29, rows), rng.uniform(1, 6, rows)], axis=1).astype(np.float32)
+    # forward: T [rows][256] -> O [rows][128]
+    T, hot = make_case(rng, rows, 256)
+    W = rng.uniform(-1, 1, (8, 64, 64)).astype(np.float32)
+    for h in hot:   # input channel h % 64 of every block that multiplies T's block h // 64 is ignored by output columns [0, 32)
+        W[:, h % 64, :32] = 0.0
+    got, ref = run_products(gf, False, T, rs, W, trow), forward_ref(T, rs, W, trow)
+    e_f = row_half_err(got, ref)
+    # backward: dO [rows][128] -> dT [rows][256]  (products with W^T: the ignored INPUT channel is a zeroed COLUMN of W)
+    dO, hot = make_case(rng, rows, 128)
+    W = rng.uniform(-1, 1, (8, 64, 64)).astype(np.float32)
+    for h in hot:
+        W[:, :32, h % 64] = 0.0
+    got, ref = run_products(gf, True, dO, rs, W, trow), backward_ref(dO, rs, W, trow)
+    e_b = row_half_err(got, ref)
+    print("block products (%s pipe, %d rows): per-(row, half) rel err forward %.2e, backward %.2e" % (pipe, rows, e_f, e_b))
+    assert e_f <= TOL and e_b <= TOL, (e_f, e_b)
+
+
+@pytest.mark.parametrize("pipe", ["split", "fp32"])
+def test_wgrad_per_row_when_one_molecule_dominates_the_level(gf, monkeypatch, pipe):
+    """Weight gradients reduce over the rows, so the split path carries ONE exponent per operand block per level.  200 rows of one
+    'molecule' are 10^6 times larger than the other 5000 -- but only in half of the channels: the rows of dW that belong to the other
+    channels are sums of small terms only, and are held to the fp64 product relative to THEIR OWN largest entry."""
+    if pipe == "fp32":
+        monkeypatch.setenv("GF_SMP_SPLIT", "0")
+    rng = np.random.default_rng(7)
+    rows = 5200
+    trow = involution(rows, rng)
+    rs = np.stack([rng.uniform(1, 29, rows), rng.uniform(1, 6, rows)], axis=1).astype(np.float32)
+    T = rng.standard_normal((rows, 256))
+    dO = rng.standard_normal((rows, 128))
+    loud = rng.permutation(64)[:32]
+    for b in range(4):
+        T[:200, 64 * b + loud] *= 1e6
+    for b in range(2):
+        dO[:200, 64 * b + loud] *= 1e6
+    T, dO = T.astype(np.float32), dO.astype(np.float32)
+    got, ref = run_wgrad(gf, T, dO, rs, trow), wgrad_ref(T, dO, rs, trow)
+    # per (block, row of dW, loud / quiet output columns): four magnitudes 10^12 apart live in one block
+    quiet = np.setdiff1d(np.arange(64), loud)
+    worst = 0.0
+    for cols in (loud, quiet):
+        d = np.abs(got[:, :, cols] - ref[:, :, cols]).max(axis=2)
+        m = np.abs(ref[:, :, cols]).max(axis=2)
+        worst = max(worst, float((d / m).max()))
+    print("weight gradients (%s pipe): per-(block, row, column class) rel err %.2e" % (pipe, worst))
+    assert worst <= TOL, worst
+
+
+def test_products_scale_window_is_documented(gf):
+    """The edge of the window: at 2^24 : 1 inside one row block the small entries keep ~15 bits on the split path --
+    this is the documented limit, shown, not hidden: the per-row error is above 1e-5 there and well below 1e-3."""
+    rng = np.random.default_rng(3)
+    rows = 512
+    trow = involution(rows, rng)
+    rs = np.ones((rows, 2), dtype=np.float32)
+    T, hot = make_case(rng, rows, 256, big=2.0 ** 24)
+    W = rng.uniform(-1, 1, (8, 64, 64)).astype(np.float32)
+    for h in hot:
+        W[:, h % 64, :32] = 0.0
+    e = row_half_err(run_products(gf, False, T, rs, W, trow), forward_ref(T, rs, W, trow))
+    print("block products (split pipe) at 2^24 : 1 inside a row block: per-(row, half) rel err %.2e" % e)
+    assert e <= 1e-3
