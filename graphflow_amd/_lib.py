@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_CSRC, "libgf_hip.so")
 
 GF_OK, GF_ERR_INVALID, GF_ERR_HIP, GF_ERR_NOMEM, GF_ERR_UNSUPPORTED = range(5)
 GF_OPT_R18_GENERIC_KERNELS = 1
+GF_OPT_SMP_FP32_PRODUCTS = 2
 GF_DIST_ID_BYTES = 128
 
 _fp = C.POINTER(C.c_float)

@@ -1,5 +1,6 @@
 // gf_capi.hip -- the extern "C" surface declared in include/gf_hip.h: context, error reporting, family dispatch
 // and the host-pointer ("mode A") staging wrappers used by the Entity-style op classes.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -25,6 +26,17 @@ gf_status fail(gf_ctx *ctx, gf_status st, const char *fmt, ...) {
     return st;
 }
 
+// GF_POISON=1: every device buffer the library hands out WITHOUT contents (workspace, staging, the SMP handle's pool blocks) is
+// filled with 0xff bytes (NaN as floats, -1 as indices) first, so a kernel that reads what nobody wrote shows up in the parity
+// tests instead of depending on what the allocation happened to hold.  Debug aid; off by default.
+bool poison_buffers() {
+    static const bool on = [] {
+        const char *e = std::getenv("GF_POISON");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
 static gf_status grow(gf_ctx *ctx, void **buf, size_t *have, size_t want, bool pinned_host) {
     if (want <= *have) return GF_OK;
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -46,6 +58,7 @@ static gf_status grow(gf_ctx *ctx, void **buf, size_t *have, size_t want, bool p
                     pinned_host ? "pinned host memory" : "device memory", hipGetErrorString(e));
     }
     *have = want;
+    if (!pinned_host && poison_buffers()) GF_HIP_TRY(ctx, hipMemset(*buf, 0xff, want));  // GF_POISON=1 (debug): see poison_buffers()
     return GF_OK;
 }
 
@@ -526,6 +539,7 @@ gf_status gf_ctx_set_option(gf_ctx *ctx, int option, int value) {
     if (!ctx) return gf::fail(nullptr, GF_ERR_INVALID, "null context");
     switch (option) {
         case GF_OPT_R18_GENERIC_KERNELS: ctx->r18_generic = value ? 1 : 0; return GF_OK;
+        case GF_OPT_SMP_FP32_PRODUCTS: ctx->fp32_products = value ? 1 : 0; return GF_OK;
         default: return gf::fail(ctx, GF_ERR_INVALID, "gf_ctx_set_option: unknown option %d", option);
     }
 }

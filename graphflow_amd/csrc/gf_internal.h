@@ -17,6 +17,7 @@ struct gf_dist_state;  // gf_dist.hip: RCCL communicator of the context (gf_dist
 struct gf_ctx {
     int device = 0;
     gf_dist_state *dist = nullptr;
+    int fp32_products = 0;  // GF_OPT_SMP_FP32_PRODUCTS: the C = 64 level's block products on the fp32 matrix pipe
     int r18_generic = 0;  // GF_OPT_R18_GENERIC_KERNELS: route RisiContraction_18 through the generic kernels (parity tests)
     hipStream_t stream = nullptr;
     bool owns_stream = false;
@@ -47,6 +48,7 @@ struct gf_ctx {
 namespace gf {
 
 gf_status fail(gf_ctx *ctx, gf_status st, const char *fmt, ...);
+bool poison_buffers();  // GF_POISON=1 (gf_capi.hip)
 gf_status ensure_ws(gf_ctx *ctx, size_t bytes);
 gf_status ensure_stage(gf_ctx *ctx, size_t bytes);
 gf_status ensure_pinned(gf_ctx *ctx, size_t bytes);

@@ -515,6 +515,8 @@ gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
     }
     if (src && count)
         GF_HIP_TRY(s->ctx, hipMemcpyAsync(p, src, sizeof(T) * count, hipMemcpyHostToDevice, s->upload ? s->upload : s->ctx->stream));
+    else if (gf::poison_buffers())  // GF_POISON=1 (debug): a buffer handed out without contents is filled with NaN bit patterns, so a
+        GF_HIP_TRY(s->ctx, hipMemsetAsync(p, 0xff, bytes, s->upload ? s->upload : s->ctx->stream));  // read-before-write shows
     *dst = static_cast<T *>(p);
     return GF_OK;
 }
@@ -982,6 +984,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         UP(d.node_s, h.node_s);
         UP(d.node_center, h.node_center);
         UP(d.mol_order, h.mol_order);
+        UP(d.gather_order, h.gather_order);
         st = gf::upload(s, &d.node_row, &h.node_row[0], h.node_row.size());
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.node_pair, &h.node_pair[0], h.node_pair.size());
@@ -1045,6 +1048,14 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (st != GF_OK) return st;
         UP(d.pi, h.pi);
         UP(d.inv, h.inv);
+        if (!s->cfg.physics && s->cfg.nContractions == 18 && C % 4 == 0 && s->bwd_gather) {  // fused levels: tables of the gather
+            st = gf::upload(s, &d.cons_hdr, nullptr, (size_t)h.pairs * 2);
+            if (st != GF_OK) return st;
+            st = gf::upload(s, &d.cons_qrec, nullptr, (size_t)h.qrec_total);
+            if (st != GF_OK) return st;
+            st = gf::upload(s, &d.cons_qbase, h.cons_qbase.empty() ? nullptr : &h.cons_qbase[0], h.cons_qbase.size());
+            if (st != GF_OK) return st;
+        }
         if (!s->cfg.physics && C == 64 && h.rows < 0x7fffffffll) {
             st = gf::upload(s, &d.trow, nullptr, (size_t)h.rows);
             if (st != GF_OK) return st;
@@ -1073,6 +1084,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         hipStream_t up = s->upload ? s->upload : ctx->stream;
         hipLaunchKernelGGL(gf::expand_rowscale, dim3(B.level[l].nNodes), dim3(64), 0, up, reinterpret_cast<float2 *>(s->lv[l].rowscale),
                            reinterpret_cast<const float2 *>(s->lv[l].node_scale), s->lv[l].node_s, s->lv[l].node_row);
+        st = gf::smp_build_gather_records(s, l, up);
+        if (st != GF_OK) return st;
         if (s->lv[l].trow)
             hipLaunchKernelGGL(gf::build_trow, dim3(B.level[l].nNodes), dim3(64), 0, up, s->lv[l].trow, s->lv[l].node_s, s->lv[l].node_row);
     }

@@ -1106,6 +1106,217 @@ __global__ __launch_bounds__(256) void smp_bwd_gather(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same gather with nothing but memory requests and sums inside the consumer loop (round 3; GF_SMP_GATHER=1 keeps the kernel
+// above).  What the kernel above spends per consumer is three dependent round trips -- LDS staging behind barriers, the row terms
+// with the first four positions, the next four positions -- at three waves per SIMD: it is latency-bound (rocprof: the loop's
+// instructions account for a tenth of its time), not issue-bound.  Here:
+//   * everything wave-uniform about a consumer comes from two per-batch tables built on the device at prepare time
+//     (build_gather_records): an 8-dword header per consumer entry (size, index, row / pair bases, node, r[a]) and a 4-dword record
+//     per (entry, source position q): byte offset of the consumer's row (b = 0, c = inv(q)), r[c], presence m, m r[a].  They are
+//     read with SCALAR loads, the header one consumer ahead: no LDS, no barrier, no readfirstlane, no per-lane address arithmetic
+//     per position -- a position's two requests are buffer loads with a per-lane row offset (b s ldt) and a scalar column offset;
+//   * the lane's own index b = inv(p) is requested one consumer ahead;
+//   * ALL requests of a consumer (ten row terms + two per position, QB = SW positions at a time for SW <= 16) are issued before
+//     the first sum: one round trip per consumer, 26 - 42 KB in flight per wave;
+//   * absent positions (uniform) read the consumer's row c = 0 and are multiplied by m = 0; absent b (per lane) sends every
+//     request of the lane out of range (zeros): no branch anywhere in the loop, so the memory queue is counted, not drained.
+// Same expression, same consumer order as the kernel above: results agree to the last bit of the fp32 sums' rounding order
+// (x + y first, then the two products), tests/test_smp_gpu.py::test_gather_kernels_agree.
+// ---------------------------------------------------------------------------------------------------------------
+struct GatherTables {
+    const int4 *hdr;   // [entries][2]: {s, a, row lo, row hi} {pair base lo, hi, node, r[a] bits}
+    const int4 *qrec;  // gather_pad(s_w) records per entry: {row-c byte offset (0 when absent), r[c] bits, m bits, m r[a] bits}
+};
+
+// block per source node w: its consumer entries' headers and records (positions past s_w and absent positions: m = 0, row 0)
+__global__ __launch_bounds__(64) void build_gather_records(const int *__restrict__ prev_s, const long long *__restrict__ cons_ptr,
+                                     const long long *__restrict__ cons_qbase, const int *__restrict__ cons_s,
+                                     const int *__restrict__ cons_a, const long long *__restrict__ cons_row,
+                                     const long long *__restrict__ cons_pair, const int *__restrict__ pair_node,
+                                     const long long *__restrict__ cons_inv_off, const short *__restrict__ inv,
+                                     const float *__restrict__ rsum, int ldt_bytes, int4 *__restrict__ hdr, int4 *__restrict__ qrec) {
+    const int w = blockIdx.x, sw = prev_s[w];
+    const int pad = gfsmp::gather_pad(sw);
+    const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1], qb = cons_qbase[w];
+    for (long long ce = c0 + threadIdx.x; ce < c1; ce += blockDim.x) {
+        const long long row = cons_row[ce], pe = cons_pair[ce], pb = pe - cons_a[ce];
+        hdr[2 * ce] = make_int4(cons_s[ce], cons_a[ce], (int)(unsigned)(row & 0xffffffffll), (int)(row >> 32));
+        hdr[2 * ce + 1] = make_int4((int)(unsigned)(pb & 0xffffffffll), (int)(pb >> 32), pair_node[pe], __float_as_int(rsum[pe]));
+    }
+    const long long n = (c1 - c0) * pad;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const long long ce = c0 + i / pad;
+        const int q = (int)(i % pad);
+        const long long pe = cons_pair[ce], pb = pe - cons_a[ce];
+        const int c = q < sw ? (int)inv[cons_inv_off[ce] + q] : -1;
+        const float ra = rsum[pe], rho = c >= 0 ? rsum[pb + c] : 0.f, m = c >= 0 ? 1.f : 0.f;
+        qrec[qb + i] = make_int4(c >= 0 ? c * ldt_bytes : 0, __float_as_int(rho), __float_as_int(m), __float_as_int(m * ra));
+    }
+}
+
+// Scalar loads written out (s_load_dwordx4 + an explicit wait that "produces" the loaded values, so that nothing reads them before
+// it).  Left to the compiler, a uniform global load becomes a scalar load only when it can prove that no store of the kernel
+// clobbers it -- which it gives up on behind a scheduling barrier, behind a struct of pointers, and in every path of a switch but
+// the first (observed): the fallback is a per-lane load plus a readfirstlane waterfall per use, ten times the instructions.
+typedef int si4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ si4 s_load4(const int4 *p) {  // p must be wave-uniform
+    si4 r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(r) : "s"(p));
+    return r;
+}
+__device__ __forceinline__ void s_wait2(si4 &a, si4 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+template <int N>
+__device__ __forceinline__ void s_wait(si4 (&r)[N]) {
+    if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r[0]));
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r[0]), "+s"(r[1]));
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r[0]), "+s"(r[1]), "+s"(r[2]), "+s"(r[3]));
+    else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r[0]), "+s"(r[1]), "+s"(r[2]), "+s"(r[3]), "+s"(r[4]));
+    else if constexpr (N == 6)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r[0]), "+s"(r[1]), "+s"(r[2]), "+s"(r[3]), "+s"(r[4]), "+s"(r[5]));
+    else {
+        static_assert(N == 8, "batch sizes of the gather");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+s"(r[0]), "+s"(r[1]), "+s"(r[2]), "+s"(r[3]), "+s"(r[4]), "+s"(r[5]), "+s"(r[6]), "+s"(r[7]));
+    }
+}
+
+constexpr int kOor = 0x40000000;  // a lane offset no consumer's tables reach (<= 32 x 32 rows of 16 C bytes): the load returns 0
+
+#define GF_GATHER_PARAMS                                                                                                          \
+    const float *__restrict__ dT, const float *__restrict__ dVt, const float *__restrict__ dSt, float *__restrict__ dfprev,            \
+        const float *__restrict__ dFdc, const int *__restrict__ prev_s, const long long *__restrict__ prev_row,                      \
+        const long long *__restrict__ prev_pair, const int *__restrict__ prev_center, const long long *__restrict__ cons_ptr,        \
+        const long long *__restrict__ cons_inv_off, const long long *__restrict__ cons_qbase, const short *__restrict__ inv,         \
+        GatherTables G, int C
+#define GF_GATHER_ARGS dT, dVt, dSt, dfprev, dFdc, prev_s, prev_row, prev_pair, prev_center, cons_ptr, cons_inv_off, cons_qbase, inv, G, C
+
+// one source node w: SWP = gfsmp::gather_pad(s_w) accumulators and records per consumer; QB positions requested together.
+// (The pointers stay individual __restrict__ kernel parameters: handed over in a struct they lose the no-alias guarantee against
+//  the store of df, and the uniform table loads are then no longer selected as scalar loads.)
+template <int SWP, int QB>
+__device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w) {
+    static_assert(SWP % QB == 0, "whole batches");
+    const int sw = prev_s[w], cw = prev_center[w];
+    const int nl = C >> 2, items = sw * nl;
+    const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
+    const int C4 = C * 4, ldtb = T_COLS * C4;  // bytes of a C-block, of a row of dT
+    float *dst = dfprev + prev_row[w] * C;
+    const float *dfd = dFdc + (size_t)prev_pair[w] * 2 * C;
+    const long long ioff0 = c0 < c1 ? cons_inv_off[c0] : 0;  // (the entries of a source are consecutive in inv: sw shorts each)
+    const int4 *qr0 = G.qrec + cons_qbase[w];
+    for (int base = 0; base < items; base += (int)blockDim.x) {
+        const int it = base + (int)threadIdx.x;
+        const bool live = it < items;
+        const int p = live ? it / nl : 0, f4b = 16 * (live ? it % nl : 0);
+        f4 acc[SWP], accd = splat(0.f), accc = splat(0.f);
+#pragma unroll
+        for (int q = 0; q < SWP; ++q) acc[q] = splat(0.f);
+        if (live) {
+            accd = ld4(dfd + (size_t)p * 2 * C + (f4b >> 2));
+            accc = ld4(dfd + (size_t)p * 2 * C + C + (f4b >> 2));
+        }
+        if (c0 < c1) {
+            si4 h0 = s_load4(G.hdr + 2 * c0), h1 = s_load4(G.hdr + 2 * c0 + 1);
+            s_wait2(h0, h1);
+            int b = inv[ioff0 + p];  // (idle lanes read position 0 and are sent out of range below: no branch around a request)
+            b = live ? b : -1;
+            for (long long ce = c0; ce < c1; ++ce) {
+                // header and lane index of the NEXT consumer (clamped re-read at the end: unconditional)
+                const long long cn = ce + 1 < c1 ? ce + 1 : ce;
+                si4 n0 = s_load4(G.hdr + 2 * cn), n1 = s_load4(G.hdr + 2 * cn + 1);  // (waited for at the end of this consumer)
+                int bn = inv[ioff0 + (cn - c0) * sw + p];
+                bn = live ? bn : -1;
+                const int s = h0.x, a = h0.y;
+                const long long urow = ((long long)h0.w << 32) | (unsigned)h0.z, upb = ((long long)h1.y << 32) | (unsigned)h1.x;
+                const int unode = h1.z;
+                const __amdgpu_buffer_rsrc_t rT = make_rsrc(dT + (size_t)urow * (T_COLS * C), (size_t)s * s * ldtb);
+                const __amdgpu_buffer_rsrc_t rV = make_rsrc(dVt + (size_t)upb * 4 * C, (size_t)s * 4 * C4);
+                const __amdgpu_buffer_rsrc_t rS = make_rsrc(dSt + (size_t)unode * 4 * C, (size_t)4 * C4);
+                const bool has = b >= 0;
+                const int tab = has ? (a * s + b) * ldtb + f4b : kOor;  // row (a, b) of the consumer's tables
+                const int va = has ? a * 4 * C4 + f4b : kOor, vb = has ? b * 4 * C4 + f4b : kOor;
+                const int vs = has ? f4b : kOor, vd = (has && p == cw) ? f4b : kOor;  // a == b  <=>  p is the source's own vertex
+                const int tb = has ? b * s * ldtb + f4b : kOor;                          // row (b, 0)
+                const f4 l0 = buf_ld4(rT, tab + T_SAB * C4, 0), g5 = buf_ld4(rT, tab + T_T6 * C4, 0);
+                const f4 l1 = buf_ld4(rV, va, 0), l4 = buf_ld4(rV, va + 2 * C4, 0);
+                const f4 l2 = buf_ld4(rV, vb + C4, 0), z2 = buf_ld4(rV, vb + 3 * C4, 0);
+                const f4 l3 = buf_ld4(rS, vs, 0), l5 = buf_ld4(rS, vs + 2 * C4, 0);
+                const f4 l6 = buf_ld4(rS, vd + C4, 0), l7 = buf_ld4(rS, vd + 3 * C4, 0);
+                const int4 *qr = qr0 + (ce - c0) * SWP;
+                f4 x = splat(0.f);
+#pragma unroll
+                for (int q0 = 0; q0 < SWP; q0 += QB) {
+                    f4 y[QB], g9[QB];
+                    si4 rec[QB];
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) rec[j] = s_load4(qr + q0 + j);
+                    s_wait(rec);  // (behind the row terms' requests; also lands the next header)
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) {
+                        y[j] = buf_ld4(rT, tb + T_SBC * C4, rec[j].x);
+                        g9[j] = buf_ld4(rT, tb + T_T10 * C4, rec[j].x);
+                    }
+                    if (q0 == 0) x = ((l0 + l1) + (l2 + l3)) + l6;
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) {
+                        const float rho = __int_as_float(rec[j].y), m = __int_as_float(rec[j].z), mra = __int_as_float(rec[j].w);
+                        acc[q0 + j] += m * (x + y[j]) + g5 * rho + g9[j] * mra;
+                    }
+                    // (no sched_barrier between the batches: the intrinsic counts as a memory clobber, after which the uniform
+                    //  record loads of the loop are no longer selected as scalar loads but as per-lane loads + waterfall loops)
+                }
+                accd += (l4 + l5) + l7;
+                accc += z2;
+                s_wait2(n0, n1);
+                h0 = n0;
+                h1 = n1;
+                b = bn;
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < SWP; ++q)
+                if (q < sw) {
+                    f4 o = acc[q];
+                    if (q == p) o += accd;
+                    if (q == cw) o += accc;
+                    st4(dst + ((size_t)p * sw + q) * C + (f4b >> 2), o);
+                }
+        }
+    }
+}
+
+// ONE launch per level for every source up to 16 positions, molecule by molecule (gather_order): the rows (b, c) of a consumer are
+// re-read by each of its ~s sources, of whatever size -- launched per size class, a molecule's table gradients were fetched from
+// HBM once per class (rocprof: 1.24 -> 1.53 ms for the same kernel when the classes of the launch order were refined).  The
+// register budget is the largest path's (three waves per SIMD); each workgroup runs the path of its source's size.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void smp_bwd_gather_all(GF_GATHER_PARAMS,
+                                                                                                      const int *__restrict__ order) {
+    int w;
+    {
+        const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8;
+        w = order[(x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8];
+    }
+    const int sw = prev_s[w];
+    if ((int)threadIdx.x >= ((sw * (C >> 2) + 63) & ~63)) return;  // (whole waves beyond the source's positions: nothing to do)
+    switch (gfsmp::gather_pad(sw)) {
+        case 1: gather_source<1, 1>(GF_GATHER_ARGS, w); break;
+        case 2: gather_source<2, 2>(GF_GATHER_ARGS, w); break;
+        case 4: gather_source<4, 4>(GF_GATHER_ARGS, w); break;
+        case 5: gather_source<5, 5>(GF_GATHER_ARGS, w); break;
+        case 6: gather_source<6, 6>(GF_GATHER_ARGS, w); break;
+        case 8: gather_source<8, 8>(GF_GATHER_ARGS, w); break;
+        case 10: gather_source<10, 5>(GF_GATHER_ARGS, w); break;
+        case 12: gather_source<12, 6>(GF_GATHER_ARGS, w); break;
+        default: gather_source<16, 4>(GF_GATHER_ARGS, w); break;
+    }
+}
+// sources of more than 16 positions (rare at QM9 sizes): their own launch, one wave per SIMD
+__global__ __launch_bounds__(256) void smp_bwd_gather_big(GF_GATHER_PARAMS, const int *__restrict__ order) {
+    gather_source<32, 4>(GF_GATHER_ARGS, order[blockIdx.x]);
+}
+
 template <int SW>
 gf_status launch_bwd_gather(gf_smp *s, int l, int w0, int w1, const float *dT) {
     gf_ctx *ctx = s->ctx;
@@ -1629,6 +1840,21 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     return GF_OK;
 }
 
+// per-batch tables of smp_bwd_gather_v2, built on the device at prepare time on the handle's upload stream (behind the uploads
+// of the consumer lists they are derived from)
+gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream) {
+    gf_smp::DevLevel &d = s->lv[l];
+    const gf_smp::DevLevel &pv = s->lv[l - 1];
+    const gfsmp::LevelLayout &h = s->lay.level[l];
+    if (!d.cons_hdr || h.pairs == 0) return GF_OK;
+    const int C = s->cfg.nChanels;
+    hipLaunchKernelGGL(build_gather_records, dim3((unsigned)s->lay.level[l - 1].nNodes), dim3(64), 0, stream, pv.node_s, d.cons_ptr,
+                       d.cons_qbase, d.cons_s, d.cons_a, d.cons_row, d.cons_pair, d.pair_node, d.cons_inv_off, d.inv, d.rsum,
+                       T_COLS * C * 4, d.cons_hdr, d.cons_qrec);
+    GF_LAUNCH_CHECK(s->ctx, "build_gather_records");
+    return GF_OK;
+}
+
 // the folded gather keeps a source node's row of accumulators in registers: receptive fields of level l-1 up to 32
 bool smp_fused_gather_enabled(const gf_smp *s, int l) {
     const gfsmp::LevelLayout &hp = s->lay.level[l - 1];
@@ -1643,6 +1869,28 @@ gf_status smp_fused_gather_backward(gf_smp *s, int l) {
     const float *dT = d.Q + (size_t)h.rows * T_COLS * C + (size_t)h.rows * O_COLS * C;
     // source nodes are sorted by receptive-field size: one launch per register class of sw (the classes of mol_order)
     size_t k = 0;
+    if (d.cons_hdr && !env_is("GF_SMP_GATHER", '1')) {
+        const gf_smp::DevLevel &pv = s->lv[l - 1];
+        gf_ctx *ctx = s->ctx;
+        const GatherTables G = {d.cons_hdr, d.cons_qrec};
+        const int small = hp.gather_small, big = hp.nNodes - small;
+        if (small > 0) {
+            int smax = 1;
+            for (const gfsmp::Bucket &bk : hp.buckets)
+                if (bk.s <= 16 && bk.s > smax) smax = bk.s;
+            int threads = (smax * (C / 4) + 63) / 64 * 64;
+            threads = threads > 256 ? 256 : threads;
+            GF_LAUNCH(ctx, "smpf_bwd_gather", smp_bwd_gather_all, dim3((unsigned)small), dim3(threads), 0, dT, d.dVt, d.dSt, pv.df, d.dFdc,
+                      pv.node_s, pv.node_row, pv.node_pair, pv.node_center, d.cons_ptr, d.cons_inv_off, d.cons_qbase, d.inv, G, C,
+                      pv.gather_order);
+        }
+        if (big > 0)
+            GF_LAUNCH(ctx, "smpf_bwd_gather", smp_bwd_gather_big, dim3((unsigned)big), dim3(256), 0, dT, d.dVt, d.dSt, pv.df, d.dFdc, pv.node_s,
+                      pv.node_row, pv.node_pair, pv.node_center, d.cons_ptr, d.cons_inv_off, d.cons_qbase, d.inv, G, C,
+                      pv.gather_order + small);
+        k = hp.buckets.size();
+        if (!hp.buckets.empty() && hp.buckets.back().s > 32) return fail(s->ctx, GF_ERR_UNSUPPORTED, "smp_fused_gather_backward: receptive field > 32");
+    } else {
     const int cls[5] = {1, 4, 8, 16, 32};
     for (int ci = 0; ci < 5 && k < hp.buckets.size(); ++ci) {
         const size_t k0 = k;
@@ -1658,6 +1906,7 @@ gf_status smp_fused_gather_backward(gf_smp *s, int l) {
             default: st = launch_bwd_gather<32>(s, l, w0, w1, dT); break;
         }
         if (st != GF_OK) return st;
+    }
     }
     if (k < hp.buckets.size()) return fail(s->ctx, GF_ERR_UNSUPPORTED, "smp_fused_gather_backward: receptive field > 32");
     return GF_OK;

@@ -41,7 +41,7 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
                                     int rows, const int *trow);
 // the compact-layout products on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip; GF_SMP_SPLIT=0: fp32 MFMA)
-bool smp_split_products();
+bool smp_split_products(const gf_ctx *ctx);
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
                                  int rows, const int *trow, int cus);
 // blkmax: the level's block maxima (gf_smp::blkmax), kept by the producers of T and dO; max_tot / max_tr: of the level's row factors
@@ -87,10 +87,12 @@ struct gf_smp {
         int *pair_node = nullptr, *pair_src_s = nullptr, *cons_s = nullptr;
         long long *pair_src_row = nullptr, *cons_ptr = nullptr, *cons_slab = nullptr, *cons_inv_off = nullptr;
         short *pi = nullptr, *inv = nullptr;
+        int4 *cons_hdr = nullptr, *cons_qrec = nullptr;  // tables of smp_bwd_gather_v2 (smp_fused.hip: build_gather_records)
+        long long *cons_qbase = nullptr;                 // [nodes of level l-1] first record of the source's consumer entries
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
         float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients)
         long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
-        int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr;
+        int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr, *gather_order = nullptr;
         float *Fdc = nullptr, *Gc = nullptr, *dGc = nullptr, *dFdc = nullptr;  // [pairs of level l-1][2C] each
         float *f = nullptr, *df = nullptr, *Q = nullptr;  // activations [rows][C], their gradient, contraction out [rows][18C]
         // physics towers (every level is read out): per-node sums of f, their LeakyReLU, vertex -> node and node -> molecule maps
@@ -158,6 +160,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
 gf_status smp_fused_gather_backward(gf_smp *s, int l);
 bool smp_fused_gather_enabled(const gf_smp *s, int l);
 gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
+gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce

@@ -445,7 +445,7 @@ gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, c
     if ((size_t)splits * total > part_floats)
         return fail(ctx, GF_ERR_NOMEM, "smp_wgrad_partials_c64: %d partial images, room for %zu", splits, part_floats / total);
     out->splits = splits;
-    if (trow && blkmax && smp_split_products())
+    if (trow && blkmax && smp_split_products(ctx))
         return smp_wgrad_partials_split_c64(ctx, T, dO, rowscale, rows, kchunk, splits, part, trow, blkmax, max_tot, max_tr);
     const size_t lds = sizeof(float) * 2 * (size_t)kWgStage;
     gf_status st = opt_in_lds(ctx, smp_wgrad_c64, lds);
@@ -484,7 +484,7 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
         if (cu_count[di] < 1) cu_count[di] = 256;
     }
     const int cus = cu_count[di];
-    if (trow && smp_split_products()) return smp_rowpanel_split_c64(ctx, forward, A, rowscale, Wst, Out, rows, trow, cus);
+    if (trow && smp_split_products(ctx)) return smp_rowpanel_split_c64(ctx, forward, A, rowscale, Wst, Out, rows, trow, cus);
     const size_t lds = sizeof(float) * 8 * 2 * 2 * 32 * (size_t)kRpWRow;
     // forward: four waves per SIMD (measured equal to two); backward: two waves per SIMD with 256 registers -- the 128-register
     // build of the backward panel spills 100 B per lane and waits for one block request per panel (1.84 -> 1.66 ms at cfg3).

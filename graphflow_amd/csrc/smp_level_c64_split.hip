@@ -541,7 +541,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
 
 }  // namespace
 
-bool smp_split_products() {  // (read per call: the parity tests switch it)
+bool smp_split_products(const gf_ctx *ctx) {  // (read per call: the parity tests switch it)
+    if (ctx && ctx->fp32_products) return false;  // GF_OPT_SMP_FP32_PRODUCTS
     const char *e = std::getenv("GF_SMP_SPLIT");
     return !(e && e[0] == '0');
 }

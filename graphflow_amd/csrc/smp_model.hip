@@ -32,7 +32,13 @@ struct gf_smp_model {
     float *tp[2] = {nullptr, nullptr}, *tg[2] = {nullptr, nullptr};  // tower parameter / gradient copies
     float *feat[2] = {nullptr, nullptr}, *dfeat[2] = {nullptr, nullptr};
     float *x = nullptr, *dx = nullptr, *work = nullptr;
-    int *lvl_off = nullptr;  // [L + 2] column offsets of the levels inside a tower's feature row (config only: uploaded once by create)
+    // [L + 2] column offsets of the levels inside a tower's feature row (configuration only).  Allocated by create, UPLOADED by the
+    // first prepare: create must not copy anything to the device -- a host-to-device copy makes the HIP runtime draw from rand()
+    // (observed: a varying number of draws), and the reference's classes are constructed right after srand(seed) with the weights
+    // drawn from rand() next (gf_smp_model_uniform_init_host): the same seed has to give the same model.
+    int *lvl_off = nullptr;
+    std::vector<int> lvl_off_host;
+    bool lvl_off_uploaded = false;
     int nMol = 0, cap_mol = 0;
     bool train = true, forwarded = false;
     std::vector<int> nV[2];
@@ -160,14 +166,11 @@ gf_status gf_smp_model_create(gf_ctx *ctx, const gf_smp_model_config *cfg, gf_sm
             return fail(ctx, GF_ERR_NOMEM, "gf_smp_model_create: device allocation failed");
         }
     }
-    {
-        std::vector<int> lvl_off(m->L + 2, 0);
-        for (int l = 0; l <= m->L; ++l) lvl_off[l + 1] = lvl_off[l] + m->lvlC[l];
-        if (hipMalloc(reinterpret_cast<void **>(&m->lvl_off), sizeof(int) * lvl_off.size()) != hipSuccess ||
-            hipMemcpy(m->lvl_off, lvl_off.data(), sizeof(int) * lvl_off.size(), hipMemcpyHostToDevice) != hipSuccess) {
-            gf_smp_model_destroy(m);
-            return fail(ctx, GF_ERR_NOMEM, "gf_smp_model_create: device allocation failed");
-        }
+    m->lvl_off_host.assign(m->L + 2, 0);
+    for (int l = 0; l <= m->L; ++l) m->lvl_off_host[l + 1] = m->lvl_off_host[l] + m->lvlC[l];
+    if (hipMalloc(reinterpret_cast<void **>(&m->lvl_off), sizeof(int) * m->lvl_off_host.size()) != hipSuccess) {
+        gf_smp_model_destroy(m);
+        return fail(ctx, GF_ERR_NOMEM, "gf_smp_model_create: device allocation failed");
     }
     *out = m;
     return GF_OK;
@@ -212,6 +215,10 @@ gf_status gf_smp_model_prepare(gf_smp_model *m, int nMol, const int *nVertices1,
         m->nV[t].assign(nv[t], nv[t] + nMol);
     }
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!m->lvl_off_uploaded) {  // (not in create: see lvl_off)
+        GF_HIP_TRY(ctx, hipMemcpyAsync(m->lvl_off, m->lvl_off_host.data(), sizeof(int) * m->lvl_off_host.size(), hipMemcpyHostToDevice, ctx->stream));
+        m->lvl_off_uploaded = true;
+    }
     if (nMol > m->cap_mol) {
         GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         gf::free_batch(m);
@@ -226,6 +233,12 @@ gf_status gf_smp_model_prepare(gf_smp_model *m, int nMol, const int *nVertices1,
         GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&m->own_t), (size_t)nMol * sizeof(float)));
         GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&m->own_y), (size_t)nMol * sizeof(float)));
         GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&m->own_loss), (size_t)nMol * sizeof(float)));
+        if (gf::poison_buffers()) {  // GF_POISON=1 (debug): NaN patterns in everything nobody has written yet
+            float *bufs[] = {m->feat[0], m->feat[1], m->dfeat[0], m->dfeat[1], m->x, m->dx, m->work};
+            const size_t n[] = {fw, fw, fw, fw, xw, xw, gf_head_work_floats(m->nLayers, m->widths.data(), nMol)};
+            for (int i = 0; i < 7; ++i)
+                if (bufs[i]) GF_HIP_TRY(ctx, hipMemset(bufs[i], 0xff, n[i] * sizeof(float)));
+        }
         m->cap_mol = nMol;
     }
     m->nMol = nMol;

@@ -311,6 +311,18 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
             lv.mol_order.assign(totalV, 0);
             for (int n = 0; n < totalV; ++n) lv.mol_order[(size_t)start[(size_t)cls(lv.node_s[n]) * nMol + lv.node_mol[n]]++] = n;
         }
+        {  // the same with two classes (s <= 16, s > 16): the order of the one-launch gather
+            std::vector<int> start((size_t)2 * nMol + 1, 0);
+            lv.gather_small = 0;
+            for (int n = 0; n < totalV; ++n) {
+                const int c = lv.node_s[n] <= 16 ? 0 : 1;
+                start[(size_t)c * nMol + lv.node_mol[n] + 1] += 1;
+                lv.gather_small += c == 0;
+            }
+            for (size_t k = 0; k + 1 < start.size(); ++k) start[k + 1] += start[k];
+            lv.gather_order.assign(totalV, 0);
+            for (int n = 0; n < totalV; ++n) lv.gather_order[(size_t)start[(size_t)(lv.node_s[n] <= 16 ? 0 : 1) * nMol + lv.node_mol[n]]++] = n;
+        }
         for (int n = 0; n < totalV; ++n) {
             const std::vector<int> &fld = out->mols[lv.node_mol[n]].phi[l][lv.node_vertex[n]];
             const int v = lv.node_vertex[n];
@@ -451,6 +463,13 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 inv_total += prev.node_s[w];
             }
         lv.inv.assign((size_t)inv_total, (int16_t)-1);
+        lv.cons_qbase.assign((size_t)prev.nNodes, 0);
+        int64_t q = 0;
+        for (int w = 0; w < prev.nNodes; ++w) {
+            lv.cons_qbase[(size_t)w] = q;
+            q += (lv.cons_ptr[(size_t)w + 1] - lv.cons_ptr[(size_t)w]) * gather_pad(prev.node_s[w]);
+        }
+        lv.qrec_total = q;
     });
     parallel_for(L * totalV, [&](int k) {   // phase D: per source node -- its consumers' inverse maps
         const int l = 1 + k / totalV, w = k % totalV;

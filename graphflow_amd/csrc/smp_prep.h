@@ -100,13 +100,30 @@ struct LevelLayout {
     tvec<int64_t> cons_pair;     // [pairs] the consumer's pair id e = node_pair[n] + a (level l)
     tvec<int> mol_order;         // [nNodes] the level's nodes by (size class 1/4/8/16/32, molecule): launch order of the
                                         // backward gather, so the sources that re-read one consumer's rows run together
+    tvec<int> gather_order;      // [nNodes] the same by (s <= 16 | s > 16, molecule): ONE launch of smp_bwd_gather_all takes every
+    int gather_small = 0;        // source up to 16 (the first gather_small entries) molecule by molecule
     // backward gather, indexed by the SOURCE node (level l-1): consumers = pairs that read it
     tvec<int64_t> cons_ptr;      // [nNodes(l-1) + 1]
     tvec<int64_t> cons_slab;     // [pairs] position offset (units of C floats) of the consumer's [s][s] slab in P
     tvec<int> cons_s;           // [pairs] consumer's s
     tvec<int64_t> cons_inv_off;  // [pairs] offset into inv
     tvec<int16_t> inv;          // per consumer: [s_w] position in the consumer's field of source position p, or -1
+    // records of the backward gather (smp_fused.hip: smp_bwd_gather_v2): gather_pad(s_w) four-dword records per consumer entry,
+    // the entries of a source back to back from cons_qbase[w] on
+    tvec<int64_t> cons_qbase;    // [nNodes(l-1)]
+    int64_t qrec_total = 0;
 };
+
+// Register classes of the backward gather: a source of size s_w runs the code path with gather_pad(s_w) accumulators (and
+// gather_pad(s_w) records per consumer: no size test inside its loops).
+#ifdef __HIPCC__
+#define GF_PREP_HD __host__ __device__
+#else
+#define GF_PREP_HD
+#endif
+GF_PREP_HD inline int gather_pad(int s) {
+    return s <= 1 ? 1 : s <= 2 ? 2 : s <= 4 ? 4 : s <= 5 ? 5 : s <= 6 ? 6 : s <= 8 ? 8 : s <= 10 ? 10 : s <= 12 ? 12 : s <= 16 ? 16 : 32;
+}
 
 struct BatchLayout {
     int nMol = 0;

@@ -68,7 +68,13 @@ const char *gf_version(void);
  * kernels (any N, any C, one thread per table / output element) instead of the slab kernels: the independent second
  * implementation the parity tests hold the fast path against.  (The reference's GPU op has a comparable switch -- its CPU
  * fallback under a complexity threshold, RisiContraction_18_gpu.h:961-968 -- but both routes here run on the device.) */
-typedef enum { GF_OPT_R18_GENERIC_KERNELS = 1 } gf_option;
+typedef enum {
+    GF_OPT_R18_GENERIC_KERNELS = 1,
+    /* != 0: the block products of the fused SMP level at 64 channels run on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) instead of
+     * the f16 pipe with two-half fp32 operands (the default; component-wise fp32-grade inside a 2^17 window per 64-column block,
+     * DESIGN.md section 5).  The environment variable GF_SMP_SPLIT=0 selects the same for every context of the process. */
+    GF_OPT_SMP_FP32_PRODUCTS = 2
+} gf_option;
 gf_status gf_ctx_set_option(gf_ctx *ctx, int option, int value);
 
 /* ---- data parallelism: one RCCL communicator per context ----------------------------------------------------------------
