@@ -984,7 +984,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         UP(d.node_s, h.node_s);
         UP(d.node_center, h.node_center);
         UP(d.mol_order, h.mol_order);
-        UP(d.gather_order, h.gather_order);
+        UP(d.gather_items, h.gather_items);
         st = gf::upload(s, &d.node_row, &h.node_row[0], h.node_row.size());
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.node_pair, &h.node_pair[0], h.node_pair.size());

@@ -1194,8 +1194,11 @@ constexpr int kOor = 0x40000000;  // a lane offset no consumer's tables reach (<
 // one source node w: SWP = gfsmp::gather_pad(s_w) accumulators and records per consumer; QB positions requested together.
 // (The pointers stay individual __restrict__ kernel parameters: handed over in a struct they lose the no-alias guarantee against
 //  the store of df, and the uniform table loads are then no longer selected as scalar loads.)
-template <int SWP, int QB>
-__device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w) {
+// One wave-sized work item: lanes [64 chunk, 64 chunk + 64) of source w's (row p, channel quad) space.  RS = records per consumer
+// entry of this source (SWP, or 32 for the sources of 17 .. 32 positions, which run as two items of sixteen positions each:
+// positions [qoff, qoff + 16)).
+template <int SWP, int QB, int RS = SWP>
+__device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w, int chunk, int qoff = 0) {
     static_assert(SWP % QB == 0, "whole batches");
     const int sw = prev_s[w], cw = prev_center[w];
     const int nl = C >> 2, items = sw * nl;
@@ -1205,8 +1208,8 @@ __device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w) {
     const float *dfd = dFdc + (size_t)prev_pair[w] * 2 * C;
     const long long ioff0 = c0 < c1 ? cons_inv_off[c0] : 0;  // (the entries of a source are consecutive in inv: sw shorts each)
     const int4 *qr0 = G.qrec + cons_qbase[w];
-    for (int base = 0; base < items; base += (int)blockDim.x) {
-        const int it = base + (int)threadIdx.x;
+    {
+        const int it = chunk * 64 + (int)(threadIdx.x & 63);
         const bool live = it < items;
         const int p = live ? it / nl : 0, f4b = 16 * (live ? it % nl : 0);
         f4 acc[SWP], accd = splat(0.f), accc = splat(0.f);
@@ -1243,7 +1246,7 @@ __device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w) {
                 const f4 l2 = buf_ld4(rV, vb + C4, 0), z2 = buf_ld4(rV, vb + 3 * C4, 0);
                 const f4 l3 = buf_ld4(rS, vs, 0), l5 = buf_ld4(rS, vs + 2 * C4, 0);
                 const f4 l6 = buf_ld4(rS, vd + C4, 0), l7 = buf_ld4(rS, vd + 3 * C4, 0);
-                const int4 *qr = qr0 + (ce - c0) * SWP;
+                const int4 *qr = qr0 + (ce - c0) * RS + qoff;
                 f4 x = splat(0.f);
 #pragma unroll
                 for (int q0 = 0; q0 < SWP; q0 += QB) {
@@ -1277,11 +1280,11 @@ __device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w) {
         if (live) {
 #pragma unroll
             for (int q = 0; q < SWP; ++q)
-                if (q < sw) {
+                if (qoff + q < sw) {
                     f4 o = acc[q];
-                    if (q == p) o += accd;
-                    if (q == cw) o += accc;
-                    st4(dst + ((size_t)p * sw + q) * C + (f4b >> 2), o);
+                    if (qoff + q == p) o += accd;
+                    if (qoff + q == cw) o += accc;
+                    st4(dst + ((size_t)p * sw + qoff + q) * C + (f4b >> 2), o);
                 }
         }
     }
@@ -1291,30 +1294,40 @@ __device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w) {
 // re-read by each of its ~s sources, of whatever size -- launched per size class, a molecule's table gradients were fetched from
 // HBM once per class (rocprof: 1.24 -> 1.53 ms for the same kernel when the classes of the launch order were refined).  The
 // register budget is the largest path's (three waves per SIMD); each workgroup runs the path of its source's size.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void smp_bwd_gather_all(GF_GATHER_PARAMS,
-                                                                                                      const int *__restrict__ order) {
-    int w;
+// Every wave of the grid takes one work item of the level's list (gfsmp::LevelLayout::gather_items: the sources above 16 positions
+// first -- as one 32-accumulator workgroup at one wave per SIMD they ran alone for 0.2 ms after everything else had finished --
+// then every other source molecule by molecule).  Waves are independent (no LDS, no barrier): a workgroup is just four
+// consecutive items, whatever their sources' sizes; nothing is launched for rows a source does not have (idle waves of a
+// workgroup-per-source grid cost 0.15 - 0.3 ms of wave launches per step).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void smp_bwd_gather_all(GF_GATHER_PARAMS,
+                                                                                                      const int2 *__restrict__ items,
+                                                                                                      int n_items) {
+    // launch order: each XCD (blockIdx % 8) takes a contiguous run of the list
+    unsigned blk;
     {
         const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8;
-        w = order[(x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8];
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8;
     }
+    const int i = __builtin_amdgcn_readfirstlane((int)(blk * 4 + (threadIdx.x >> 6)));
+    if (i >= n_items) return;
+    const int2 item = items[i];
+    const int w = __builtin_amdgcn_readfirstlane(item.x), chunk = __builtin_amdgcn_readfirstlane(item.y & 0xffff);
     const int sw = prev_s[w];
-    if ((int)threadIdx.x >= ((sw * (C >> 2) + 63) & ~63)) return;  // (whole waves beyond the source's positions: nothing to do)
-    switch (gfsmp::gather_pad(sw)) {
-        case 1: gather_source<1, 1>(GF_GATHER_ARGS, w); break;
-        case 2: gather_source<2, 2>(GF_GATHER_ARGS, w); break;
-        case 4: gather_source<4, 4>(GF_GATHER_ARGS, w); break;
-        case 5: gather_source<5, 5>(GF_GATHER_ARGS, w); break;
-        case 6: gather_source<6, 6>(GF_GATHER_ARGS, w); break;
-        case 8: gather_source<8, 8>(GF_GATHER_ARGS, w); break;
-        case 10: gather_source<10, 5>(GF_GATHER_ARGS, w); break;
-        case 12: gather_source<12, 6>(GF_GATHER_ARGS, w); break;
-        default: gather_source<16, 4>(GF_GATHER_ARGS, w); break;
+    if (sw > 16) {
+        gather_source<16, 4, 32>(GF_GATHER_ARGS, w, chunk, 16 * __builtin_amdgcn_readfirstlane(item.y >> 16));
+        return;
     }
-}
-// sources of more than 16 positions (rare at QM9 sizes): their own launch, one wave per SIMD
-__global__ __launch_bounds__(256) void smp_bwd_gather_big(GF_GATHER_PARAMS, const int *__restrict__ order) {
-    gather_source<32, 4>(GF_GATHER_ARGS, order[blockIdx.x]);
+    switch (gfsmp::gather_pad(sw)) {
+        case 1: gather_source<1, 1>(GF_GATHER_ARGS, w, chunk); break;
+        case 2: gather_source<2, 2>(GF_GATHER_ARGS, w, chunk); break;
+        case 4: gather_source<4, 4>(GF_GATHER_ARGS, w, chunk); break;
+        case 5: gather_source<5, 5>(GF_GATHER_ARGS, w, chunk); break;
+        case 6: gather_source<6, 6>(GF_GATHER_ARGS, w, chunk); break;
+        case 8: gather_source<8, 8>(GF_GATHER_ARGS, w, chunk); break;
+        case 10: gather_source<10, 5>(GF_GATHER_ARGS, w, chunk); break;
+        case 12: gather_source<12, 6>(GF_GATHER_ARGS, w, chunk); break;
+        default: gather_source<16, 4>(GF_GATHER_ARGS, w, chunk); break;
+    }
 }
 
 template <int SW>
@@ -1873,21 +1886,11 @@ gf_status smp_fused_gather_backward(gf_smp *s, int l) {
         const gf_smp::DevLevel &pv = s->lv[l - 1];
         gf_ctx *ctx = s->ctx;
         const GatherTables G = {d.cons_hdr, d.cons_qrec};
-        const int small = hp.gather_small, big = hp.nNodes - small;
-        if (small > 0) {
-            int smax = 1;
-            for (const gfsmp::Bucket &bk : hp.buckets)
-                if (bk.s <= 16 && bk.s > smax) smax = bk.s;
-            int threads = (smax * (C / 4) + 63) / 64 * 64;
-            threads = threads > 256 ? 256 : threads;
-            GF_LAUNCH(ctx, "smpf_bwd_gather", smp_bwd_gather_all, dim3((unsigned)small), dim3(threads), 0, dT, d.dVt, d.dSt, pv.df, d.dFdc,
-                      pv.node_s, pv.node_row, pv.node_pair, pv.node_center, d.cons_ptr, d.cons_inv_off, d.cons_qbase, d.inv, G, C,
-                      pv.gather_order);
-        }
-        if (big > 0)
-            GF_LAUNCH(ctx, "smpf_bwd_gather", smp_bwd_gather_big, dim3((unsigned)big), dim3(256), 0, dT, d.dVt, d.dSt, pv.df, d.dFdc, pv.node_s,
-                      pv.node_row, pv.node_pair, pv.node_center, d.cons_ptr, d.cons_inv_off, d.cons_qbase, d.inv, G, C,
-                      pv.gather_order + small);
+        const int n_items = (int)(hp.gather_items.size() / 2);
+        if (n_items > 0)
+            GF_LAUNCH(ctx, "smpf_bwd_gather", smp_bwd_gather_all, dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, dT, d.dVt, d.dSt, pv.df,
+                      d.dFdc, pv.node_s, pv.node_row, pv.node_pair, pv.node_center, d.cons_ptr, d.cons_inv_off, d.cons_qbase, d.inv, G, C,
+                      reinterpret_cast<const int2 *>(pv.gather_items), n_items);
         k = hp.buckets.size();
         if (!hp.buckets.empty() && hp.buckets.back().s > 32) return fail(s->ctx, GF_ERR_UNSUPPORTED, "smp_fused_gather_backward: receptive field > 32");
     } else {

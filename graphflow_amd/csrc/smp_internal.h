@@ -92,7 +92,7 @@ struct gf_smp {
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
         float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients)
         long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
-        int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr, *gather_order = nullptr;
+        int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr, *gather_items = nullptr;
         float *Fdc = nullptr, *Gc = nullptr, *dGc = nullptr, *dFdc = nullptr;  // [pairs of level l-1][2C] each
         float *f = nullptr, *df = nullptr, *Q = nullptr;  // activations [rows][C], their gradient, contraction out [rows][18C]
         // physics towers (every level is read out): per-node sums of f, their LeakyReLU, vertex -> node and node -> molecule maps

@@ -311,17 +311,34 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
             lv.mol_order.assign(totalV, 0);
             for (int n = 0; n < totalV; ++n) lv.mol_order[(size_t)start[(size_t)cls(lv.node_s[n]) * nMol + lv.node_mol[n]]++] = n;
         }
-        {  // the same with two classes (s <= 16, s > 16): the order of the one-launch gather
-            std::vector<int> start((size_t)2 * nMol + 1, 0);
-            lv.gather_small = 0;
-            for (int n = 0; n < totalV; ++n) {
-                const int c = lv.node_s[n] <= 16 ? 0 : 1;
-                start[(size_t)c * nMol + lv.node_mol[n] + 1] += 1;
-                lv.gather_small += c == 0;
-            }
+        {  // work items of the one-launch gather (smp_prep.h): large sources first, the others molecule-major
+            const int nl = std::max(1, cfg.nChanels / 4);
+            std::vector<int> start((size_t)nMol + 1, 0);
+            for (int n = 0; n < totalV; ++n)
+                if (lv.node_s[n] <= 16) start[(size_t)lv.node_mol[n] + 1] += 1;
             for (size_t k = 0; k + 1 < start.size(); ++k) start[k + 1] += start[k];
-            lv.gather_order.assign(totalV, 0);
-            for (int n = 0; n < totalV; ++n) lv.gather_order[(size_t)start[(size_t)(lv.node_s[n] <= 16 ? 0 : 1) * nMol + lv.node_mol[n]]++] = n;
+            std::vector<int> small((size_t)start.back());
+            lv.gather_items.clear();
+            for (int n = 0; n < totalV; ++n) {
+                const int s = lv.node_s[n];
+                if (s <= 16) {
+                    small[(size_t)start[(size_t)lv.node_mol[n]]++] = n;
+                    continue;
+                }
+                const int chunks = (s * nl + 63) / 64;
+                for (int h = 0; h < 2; ++h)
+                    for (int c = 0; c < chunks; ++c) {
+                        lv.gather_items.push_back(n);
+                        lv.gather_items.push_back(c | (h << 16));
+                    }
+            }
+            for (size_t i = 0; i < small.size(); ++i) {
+                const int n = small[i], chunks = (lv.node_s[n] * nl + 63) / 64;
+                for (int c = 0; c < chunks; ++c) {
+                    lv.gather_items.push_back(n);
+                    lv.gather_items.push_back(c);
+                }
+            }
         }
         for (int n = 0; n < totalV; ++n) {
             const std::vector<int> &fld = out->mols[lv.node_mol[n]].phi[l][lv.node_vertex[n]];

@@ -100,8 +100,10 @@ struct LevelLayout {
     tvec<int64_t> cons_pair;     // [pairs] the consumer's pair id e = node_pair[n] + a (level l)
     tvec<int> mol_order;         // [nNodes] the level's nodes by (size class 1/4/8/16/32, molecule): launch order of the
                                         // backward gather, so the sources that re-read one consumer's rows run together
-    tvec<int> gather_order;      // [nNodes] the same by (s <= 16 | s > 16, molecule): ONE launch of smp_bwd_gather_all takes every
-    int gather_small = 0;        // source up to 16 (the first gather_small entries) molecule by molecule
+    // ONE launch of smp_bwd_gather_all per level: wave-sized work items (source node, 64-lane chunk of its (row p, channel quad)
+    // space, half of the positions q for sources above 16), the sources above 16 first, then every other source molecule by
+    // molecule.  item = {node, chunk | qhalf << 16}
+    tvec<int> gather_items;      // [2 * n_items]
     // backward gather, indexed by the SOURCE node (level l-1): consumers = pairs that read it
     tvec<int64_t> cons_ptr;      // [nNodes(l-1) + 1]
     tvec<int64_t> cons_slab;     // [pairs] position offset (units of C floats) of the consumer's [s][s] slab in P
