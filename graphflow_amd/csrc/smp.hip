@@ -1059,6 +1059,25 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (!s->cfg.physics && C == 64 && h.rows < 0x7fffffffll) {
             st = gf::upload(s, &d.trow, nullptr, (size_t)h.rows);
             if (st != GF_OK) return st;
+            if (s->cfg.nContractions == 18 && h.rows * 256 < 0x3fffffffll && !h.buckets.empty() && h.buckets.back().s <= 32) {
+                // row panels of the fused forward level (smp_level_c64_fwd.hip): a node of size s has ceil(s / max(1, 32 / s)) panels
+                std::vector<int> node_panel((size_t)h.nNodes);
+                int np = 0;
+                for (int n = 0; n < h.nNodes; ++n) {
+                    node_panel[(size_t)n] = np;
+                    const int sz = h.node_s[n], gpp = sz >= 32 ? 1 : std::min(8, 32 / sz);
+                    np += (sz + gpp - 1) / gpp;
+                }
+                d.fwd_npanels = np;
+                UP(d.node_panel, node_panel);
+                GF_HIP_TRY(ctx, hipStreamSynchronize(s->upload ? s->upload : ctx->stream));  // (node_panel is a local)
+                st = gf::upload(s, &d.fwd_pan, nullptr, (size_t)np);
+                if (st != GF_OK) return st;
+                st = gf::upload(s, &d.fwd_pan_node, nullptr, (size_t)np);
+                if (st != GF_OK) return st;
+                st = gf::upload(s, &d.fwd_goff, nullptr, (size_t)h.rows);
+                if (st != GF_OK) return st;
+            }
         }
         st = gf::upload(s, &d.Q, nullptr, (size_t)h.rows * std::max(18, s->cfg.nContractions) * Cp);
         if (st != GF_OK) return st;
@@ -1085,6 +1104,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         hipLaunchKernelGGL(gf::expand_rowscale, dim3(B.level[l].nNodes), dim3(64), 0, up, reinterpret_cast<float2 *>(s->lv[l].rowscale),
                            reinterpret_cast<const float2 *>(s->lv[l].node_scale), s->lv[l].node_s, s->lv[l].node_row);
         st = gf::smp_build_gather_records(s, l, up);
+        if (st != GF_OK) return st;
+        st = gf::smp_fwd_fused_build_tables(s, l, up);
         if (st != GF_OK) return st;
         if (s->lv[l].trow)
             hipLaunchKernelGGL(gf::build_trow, dim3(B.level[l].nNodes), dim3(64), 0, up, s->lv[l].trow, s->lv[l].node_s, s->lv[l].node_row);

@@ -1466,6 +1466,23 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
              {-1, -1, -1, -1}},
         };
         const bool panels = !env_is("GF_SMP_ROWPANEL", '0');  // (read per call: the parity tests switch it)
+        // products + combine in one kernel, O never written (smp_level_c64_fwd.hip): the split-operand compact layout only
+        // (opt-in, GF_SMP_FUSE_FWD=1: correct -- tests/test_smp_gpu.py::test_fused_forward_level... -- but at 3.6 ms against 1.0 + 0.73 ms
+        //  for the two kernels it replaces: U and M together with a panel's operands do not fit 256 registers at two waves per SIMD,
+        //  and at one wave per SIMD the compiler's remaining spills sit in the panel loop, where every scratch reload drains the
+        //  in-order memory queue -- prefetch included.  DESIGN.md section 9.)
+        const bool fuse_fwd = C == 64 && panels && ocols == 2 && d.fwd_pan && smp_split_products(ctx) && env_is("GF_SMP_FUSE_FWD", '1');
+        if (fuse_fwd) {
+            if (!grouped) {  // (the compact products Gc are read by the fused kernel: they must be there before it)
+                const int prevPairs = (int)s->lay.level[l - 1].pairs;
+                st = gemm(ctx, false, false, prevPairs, C, C, d.Fdc, 2 * C, C, d.Wst + 8 * CC, C, (long long)CC, d.Gc, 2 * C, C, 2, 0);
+                if (st != GF_OK) return st;
+            }
+            if (s->side && !grouped) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
+            int cus = 256;
+            GF_HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+            return smp_level_fwd_fused_c64(s, l, T, bl, cus < 1 ? 256 : cus);
+        }
         if (C == 64 && panels) {
             st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, ocols == 2 ? d.trow : nullptr);  // weights in LDS
             if (st != GF_OK) return st;

@@ -89,6 +89,11 @@ struct gf_smp {
         short *pi = nullptr, *inv = nullptr;
         int4 *cons_hdr = nullptr, *cons_qrec = nullptr;  // tables of smp_bwd_gather_v2 (smp_fused.hip: build_gather_records)
         long long *cons_qbase = nullptr;                 // [nodes of level l-1] first record of the source's consumer entries
+        // fused forward level at C = 64 (smp_level_c64_fwd.hip): row panels of whole (node, x) groups, per-row gather indices
+        int4 *fwd_pan = nullptr;
+        int *fwd_pan_node = nullptr, *node_panel = nullptr;
+        int2 *fwd_goff = nullptr;
+        int fwd_npanels = 0;
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
         float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients)
         long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
@@ -161,6 +166,8 @@ gf_status smp_fused_gather_backward(gf_smp *s, int l);
 bool smp_fused_gather_enabled(const gf_smp *s, int l);
 gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
+gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream);
+gf_status smp_level_fwd_fused_c64(gf_smp *s, int l, const float *T, const float *bias, int cus);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce

@@ -356,6 +356,31 @@ def test_gather_kernels_agree(gf, monkeypatch, C):
     assert rel_err(g1, g0) <= 1e-6
 
 
+def test_fused_forward_level_equals_products_plus_combine(gf, monkeypatch):
+    """At C = 64 the forward block products and combine-forward can run as ONE kernel (GF_SMP_FUSE_FWD=1, smp_level_c64_fwd.hip: the
+    projected matrix O stays in the MFMA accumulators, the adjacency products and rank-one terms are fp32 MFMAs on them; opt-in:
+    it is slower than the two kernels so far) or as two (default: products write O, combine-forward reads it
+    back): same sums, different association."""
+    F, D, C, L, cap = 5, 5, 64, 3, 29
+    mols, tg = [], []
+    for seed in range(40):   # 29-atom molecules: one-group panels (s >= 17), ragged last panels, several groups per panel
+        adj, feat, t = synthetic_molecule(1500 + seed, nV=29 if seed % 4 == 0 else None)
+        mols.append((adj, feat))
+        tg.append(t)
+    params = smp_params(C, F, D, L, 6)
+    monkeypatch.setenv("GF_SMP_FUSE_FWD", "1")
+    p1, _, f1, g1, n1 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    a1 = [n1.activation(0, l, 0) for l in (1, 2, 3)]
+    monkeypatch.setenv("GF_SMP_FUSE_FWD", "0")
+    p0, _, f0, g0, n0 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    a0 = [n0.activation(0, l, 0) for l in (1, 2, 3)]
+    assert not np.array_equal(f1, f0)   # (the switch switches something)
+    for x, y in zip(a1, a0):
+        assert rel_err(x.astype(np.float64), y.astype(np.float64)) <= 2e-6
+    note("fused_forward_vs_two_kernels", pred=rel_err(p1, p0), feat=rel_err(f1, f0), grads=rel_err(g1, g0))
+    assert rel_err(p1, p0) <= 2e-6 and rel_err(f1, f0) <= 2e-6 and rel_err(g1, g0) <= KINK_GRAD
+
+
 def test_c64_level_kernels_equal_the_tiled_gemm_path(gf, monkeypatch):
     """At C = 64 the block products of a fused level run as dedicated kernels (weights resident in LDS with the rows in
     registers; output-stationary weight gradients).  GF_SMP_ROWPANEL=0 / GF_SMP_WGRAD=0 select the grouped tiled GEMM
