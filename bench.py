@@ -116,6 +116,8 @@ def timed_run(torch, ctx, step, steps, warmup, fence, notiming=False):
 def setup_contraction(workload, args, torch, gf, dev, world, rank, ctx):
     K, N, C = (50, 24, 32) if workload == "cfg5" else (18, args.N, args.C)
     B = (args.batch if workload == args.workload else 0) or 256
+    if args.scaling == "strong" and workload == args.workload:
+        B = (args.batch or 2048) // world
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     P = torch.rand((B, N, N, N, C), device=dev, generator=gen) * 2 - 1          # U(-1,1)
     U = (torch.rand((B, N, N), device=dev, generator=gen) < 0.5).float().triu(1)
@@ -157,8 +159,11 @@ def setup_contraction(workload, args, torch, gf, dev, world, rank, ctx):
     def cpu():
         from oracle import pyoracle
         from inputs import cfg_graph
-        if K != 18:
-            return None   # the RisiContraction_50 loops take ~8 s per graph at this shape; not re-timed here
+        if K != 18:   # cfg5: the loop-nest port of RisiContraction_50 (one five-deep nest per channel, 50 predicated updates inside)
+            Pc, Ac, Gc = cfg_graph(N, C, 1000, K=K)
+            secs, _, _ = pyoracle.time_r50_fwd_bwd(Pc, Ac, Gc)
+            return {"value": round(1.0 / secs, 5), "unit": "graphs/s", "cores": 1, "kind": "port",
+                    "sample": "1 graph, RisiContraction_50 fwd+bwd (loop nests of RisiContraction_50.h:73-802), N=%d C=%d fp64, %.1f s" % (N, C, secs)}
         Pc, Ac, Gc = cfg_graph(N, C, 1000, K=18)
         secs, kind, _, _ = pyoracle.time_r18_fwd_bwd(Pc, Ac, Gc, prefer_reference=False)
         out = {"value": round(1.0 / secs, 5), "unit": "graphs/s", "cores": 1, "kind": kind,
@@ -190,13 +195,15 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
     import numpy as np
     from graphflow_amd.smp import SMPOmega
     from inputs import smp_params, synthetic_molecule
-    B = args.batch or 1024
+    B = (args.batch or 8192) // world if args.scaling == "strong" else (args.batch or 1024)
     L, C, F, D, cap = 3, args.C, 5, 5, 29
     mols, tg = [], []
     for i in range(B):
         adj, feat, t = synthetic_molecule(rank * 1000003 + i)   # seed = molecule index, disjoint across ranks
         mols.append((adj, feat))
         tg.append(t)
+    if world > 1:   # N ranks share the host: each rank's two loader threads get their share of the cores for graph preparation
+        os.environ.setdefault("GF_PREP_THREADS", str(max(2, min(32, (os.cpu_count() or 8) // (2 * world)))))
     net = SMPOmega(L, C, F, D, cap, True, ctx=ctx)
     t0 = time.perf_counter()
     net.prepare(mols)
@@ -474,6 +481,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg2 / cfg5 / end_to_end sections of the default line")
     ap.add_argument("--unfused", action="store_true", help="cfg3: op-by-op level pipeline instead of the fused level kernels")
     ap.add_argument("--plumbing", action="store_true", help="CPU-only check of the multi-rank plumbing (gloo); measures nothing")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch (default 1024 molecules / 256 graphs) PER GPU; strong: --batch (default 8192 / 2048) in TOTAL, split "
+                         "evenly over the ranks (SURVEY 8d cfg4 asks for both)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -523,7 +533,7 @@ def main():
         value = world * meta["units_per_step"] * args.steps / elapsed
         line = {"metric": meta["metric"], "value": round(value, 1), "unit": meta["unit"], "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": meta["config"], "roofline": finish(timers, ms_per_step, args.steps)}
         if ctx.dist_world > 1 or force:
             line["config"]["collective"] = "gf_dist_* (RCCL) world %d" % ctx.dist_world
@@ -535,14 +545,30 @@ def main():
         net, end_to_end = keep
         if rank == 0:
             line["config"]["device_GB"] = round(net.device_bytes()[0] / 1e9, 2)   # HBM held by the batch's buffers (lazy ones included)
-        if world == 1 and not force:
+        if not force:
+            # every rank runs its own loader threads and handles; the loop's gradients are summed over the ranks inside backward, so
+            # the ranks step together: the reported time is the slowest rank's
             e2e = end_to_end(min(40, max(8, args.steps)))
+            if world > 1:
+                dt = gd.max_over_ranks(e2e["ms_per_step"], dist, dev)
+                e2e.update(ms_per_step=round(dt, 3), value=round(world * meta["units_per_step"] / (dt * 1e-3), 1), unit="molecules/s, all %d GPUs" % world,
+                           host_threads_per_rank=os.environ.get("GF_PREP_THREADS"))
     if rank == 0:
         if e2e:
             line["end_to_end"] = e2e
         if world == 1 and not args.no_extra and args.workload == "cfg3" and not args.unfused:
             # BASELINE configs[1] and configs[4] under the same clock: 20 steps each after 3 warm-ups
             extra = {}
+            if args.C == 64 and os.environ.get("GF_SMP_SPLIT", "1") != "0":
+                # the headline step again with the C = 64 block products on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) instead of the
+                # f16 pipe with two-half operands: the same step without the operand-width caveat, under the same clock
+                from graphflow_amd import _lib
+                ctx.set_option(_lib.GF_OPT_SMP_FP32_PRODUCTS, 1)
+                el, _ = timed_run(torch, ctx, step, 20, 3, torch.cuda.synchronize, True)
+                ctx.set_option(_lib.GF_OPT_SMP_FP32_PRODUCTS, 0)
+                extra["cfg3_fp32_products"] = {"metric": meta["metric"], "value": round(meta["units_per_step"] * 20 / el, 1), "unit": meta["unit"],
+                                               "steps": 20, "warmup": 3, "ms_per_step": round(1e3 * el / 20, 4),
+                                               "what": "GF_OPT_SMP_FP32_PRODUCTS: the level's block products on the fp32 MFMA pipe, everything else as in the headline step"}
             for wl in ("cfg2", "cfg5"):
                 ectx = gf.Context(dev.index)
                 estep, efinish, ecpu, emeta, _ = setup_contraction(wl, args, torch, gf, dev, 1, 0, ectx)

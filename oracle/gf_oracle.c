@@ -293,6 +293,42 @@ static void r18_loops(int dir, const double *P, const double *A, double *Out, co
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * RisiContraction_50 as the reference runs it (RisiContraction_50.h:73-441 forward, :443-802 backward): per channel ONE loop nest
+ * over (a, b, c, d, e) with all 50 predicated updates inside, value_at = P[a][b][c][f] * A[d][e] (:65-67), no adjacency gate.
+ * The CPU baseline of cfg5 (bench.py); bit-identical to the spec form above on the goldens (tests/test_oracle_golden.py). */
+void gfo_r50_loops_forward(const double *P, const double *A, double *Out, int N, int C) {
+    const size_t NC = (size_t)N * C;
+    memset(Out, 0, sizeof(double) * (size_t)N * N * 50 * C);
+    for (int f = 0; f < C; ++f)
+        for (int a = 0; a < N; ++a)
+            for (int b = 0; b < N; ++b)
+                for (int c = 0; c < N; ++c)
+                    for (int d = 0; d < N; ++d)
+                        for (int e = 0; e < N; ++e) {
+                            const double v = P[((size_t)a * N + b) * NC + (size_t)c * C + f] * A[(size_t)d * N + e];
+#define X(k, i, j) Out[((size_t)(i) * N + (j)) * 50 * C + (size_t)(k) * C + f] += v
+#include "gf_oracle_r50_cases.inc"
+#undef X
+                        }
+}
+
+void gfo_r50_loops_backward(const double *G, const double *A, double *dP, int N, int C) {
+    const size_t NC = (size_t)N * C;
+    for (int f = 0; f < C; ++f)
+        for (int a = 0; a < N; ++a)
+            for (int b = 0; b < N; ++b)
+                for (int c = 0; c < N; ++c)
+                    for (int d = 0; d < N; ++d)
+                        for (int e = 0; e < N; ++e) {
+                            const double w = A[(size_t)d * N + e];
+                            double *dst = &dP[((size_t)a * N + b) * NC + (size_t)c * C + f];
+#define X(k, i, j) *dst += G[((size_t)(i) * N + (j)) * 50 * C + (size_t)(k) * C + f] * w
+#include "gf_oracle_r50_cases.inc"
+#undef X
+                        }
+}
+
 void gfo_r18_loops_forward(const double *P, const double *A, double *Out, int N, int C) {
     memset(Out, 0, sizeof(double) * (size_t)N * N * 18 * C);
     r18_loops(0, P, A, Out, NULL, NULL, N, C);

@@ -281,6 +281,27 @@ def time_r18_fwd_bwd(P, A, G, prefer_reference=True):
     return time.perf_counter() - t0, "port", out, dP
 
 
+def time_r50_fwd_bwd(P, A, G):
+    """Seconds for ONE RisiContraction_50 forward + backward on one graph, single host thread, through the loop-nest port
+    (gfo_r50_loops_*: the reference's one-nest-per-channel structure with all 50 predicated updates inside).  Returns (s, out, dP)."""
+    import time
+
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    G = np.ascontiguousarray(G, dtype=np.float64)
+    N, C_ = P.shape[0], P.shape[3]
+    out = np.zeros((N, N, 50, C_))
+    dP = np.zeros_like(P)
+    orc = oracle()
+    fw, bw = orc.lib.gfo_r50_loops_forward, orc.lib.gfo_r50_loops_backward
+    fw.argtypes = bw.argtypes = [_dp, _dp, _dp, _i, _i]
+    fw.restype = bw.restype = None
+    t0 = time.perf_counter()
+    fw(P, A, out, N, C_)
+    bw(G, A, dP, N, C_)
+    return time.perf_counter() - t0, out, dP
+
+
 def reference_smp_beta(adj, feature, target, params, nLevels, nChanels, nDepth, has_wl=True, max_nVertices=None):
     """The REAL SMP_beta (no receptive-field cap) on one molecule with dumped parameters."""
     ref = reference()

@@ -71,3 +71,50 @@ def test_smp_backward_reduces_its_gradient_segments_on_the_communicator(gf, fuse
         net.backward(p, reduced, accumulate=True)
     net.close()
     ctx.close()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: arms itself on a multi-GPU node")
+def test_ranks_on_separate_gpus_sum_their_gradients(gf, tmp_path):
+    """N = min(4, GPUs) ranks, one per GPU, through RCCL over xGMI: every rank's gf_smp_backward returns the SAME gradient, equal
+    (to fp32 summation order) to the single-GPU gradient of the whole batch -- and the real `bench.py --gpus 2` prints one line
+    with n_gpus 2 and the RCCL world in it.  Skipped on one-GPU boxes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from graphflow_amd.smp import SMPOmega
+    from util import rel_err
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = min(4, torch.cuda.device_count())
+    out = str(tmp_path / "g.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "tools", "dist_check.py"), out],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = np.load(out).astype(np.float64)
+    L, C, F, D, cap = 3, 64, 5, 3, 29
+    mols, tg = [], []
+    for seed in range(32):
+        a, f, t = synthetic_molecule(4100 + seed)
+        mols.append((a, f))
+        tg.append(t)
+    net = SMPOmega(L, C, F, D, cap, True)
+    net.prepare(mols)
+    p = torch.as_tensor(smp_params(C, F, D, L, 8).astype(np.float32)).cuda()
+    g = torch.empty(net.n_params, device="cuda")
+    net.forward(p, torch.as_tensor(np.array(tg, dtype=np.float32)).cuda())
+    net.backward(p, g)
+    assert rel_err(got, g.cpu().numpy().astype(np.float64)) <= 2e-6
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "64",
+                        "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "world 2" in line["config"]["collective"]

@@ -71,6 +71,26 @@ def test_r18_loop_nest_form_equals_spec_form(oracle):
     _close(dP, oracle.contract_backward(18, G, A))
 
 
+def test_r50_loop_nest_port_equals_spec_form_and_goldens(oracle, golden):
+    """The CPU baseline of cfg5 (gfo_r50_loops_*: one five-deep nest per channel with the 50 predicated updates inside, the
+    structure of RisiContraction_50.h:73-802) against the spec form on a signed adjacency and against the real reference's goldens."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(6)
+    N, Cc = 5, 3
+    P = f32exact(rng.uniform(-1, 1, (N, N, N, Cc)))
+    A = adjacency("signed", N, rng)
+    G = f32exact(rng.uniform(0, 1, (N, N, 50, Cc)))
+    _, out, dP = po.time_r50_fwd_bwd(P, A, G)
+    _close(out, oracle.contract_forward(50, P, A))
+    _close(dP, oracle.contract_backward(50, G, A))
+    cases = golden_cases(golden, "r50_")
+    assert cases
+    for tag, c in cases.items():
+        _, out, dP = po.time_r50_fwd_bwd(c["P"], c["A"], c["G"])
+        _close(out, c["Out"])
+        _close(dP + c["dP0"], c["dP"])
+
+
 def test_structural_50_collapse(oracle):
     """Known-answer of the reference's own tests/test_RisiContraction_50.cpp: with tensors symmetric in (b,c) and a
     symmetric zero-diagonal 0/1 adjacency the 50 slices fall into exactly the 18 recorded groups (bit-identical)."""
