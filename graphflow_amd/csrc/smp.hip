@@ -412,10 +412,14 @@ __global__ void expand_rowscale(float2 *__restrict__ rowscale, const float2 *__r
 }
 
 // trow[row of (x, e)] = row of (e, x) inside the same node (compact O layout of the fused C = 64 level, smp_level_c64.hip)
-__global__ void build_trow(int *__restrict__ trow, const int *__restrict__ node_s, const long long *__restrict__ node_row) {
+__global__ void build_trow(int *__restrict__ trow, const int *__restrict__ node_s, const long long *__restrict__ node_row,
+                           const short *__restrict__ pi, unsigned char *__restrict__ rowflag) {
     const int n = blockIdx.x, s = node_s[n];
     const long long r0 = node_row[n];
-    for (int i = threadIdx.x; i < s * s; i += blockDim.x) trow[r0 + i] = (int)(r0 + (long long)(i % s) * s + i / s);
+    for (int i = threadIdx.x; i < s * s; i += blockDim.x) {
+        trow[r0 + i] = (int)(r0 + (long long)(i % s) * s + i / s);
+        rowflag[r0 + i] = pi[r0 + i] >= 0 ? 1 : 0;  // row (a, b) of the S_ab / T6 blocks is written by tables-forward (DevLevel::t_zeros)
+    }
 }
 
 // RisiContraction_18_dropout over the nodes of a level: slice k of node n is multiplied by scale if bit k of keep[n] is set,
@@ -1059,6 +1063,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (!s->cfg.physics && C == 64 && h.rows < 0x7fffffffll) {
             st = gf::upload(s, &d.trow, nullptr, (size_t)h.rows);
             if (st != GF_OK) return st;
+            st = gf::upload(s, &d.rowflag, nullptr, (size_t)h.rows);
+            if (st != GF_OK) return st;
             if (s->cfg.nContractions == 18 && h.rows * 256 < 0x3fffffffll && !h.buckets.empty() && h.buckets.back().s <= 32) {
                 // row panels of the fused forward level (smp_level_c64_fwd.hip): a node of size s has ceil(s / max(1, 32 / s)) panels
                 std::vector<int> node_panel((size_t)h.nNodes);
@@ -1108,7 +1114,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         st = gf::smp_fwd_fused_build_tables(s, l, up);
         if (st != GF_OK) return st;
         if (s->lv[l].trow)
-            hipLaunchKernelGGL(gf::build_trow, dim3(B.level[l].nNodes), dim3(64), 0, up, s->lv[l].trow, s->lv[l].node_s, s->lv[l].node_row);
+            hipLaunchKernelGGL(gf::build_trow, dim3(B.level[l].nNodes), dim3(64), 0, up, s->lv[l].trow, s->lv[l].node_s, s->lv[l].node_row,
+                               s->lv[l].pi, s->lv[l].rowflag);
     }
     UP(s->x, B.x);
     s->P = nullptr;  // [max ppos][C]: by far the largest buffer of the op-by-op path, taken from the pool only when a level needs it
@@ -1203,6 +1210,7 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
             if (st != GF_OK) return st;
             continue;
         }
+        s->lv[l].t_zeros = false;  // (the op-by-op level uses all of Q: the zeros kept in the fused level's T region are gone)
         st = gf::ensure_P(s);
         if (st != GF_OK) return st;
         const int Cp = s->cfg.level_channels(l - 1), Cc = s->cfg.level_channels(l);  // (equal unless a physics tower)

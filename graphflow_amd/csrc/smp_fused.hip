@@ -98,7 +98,8 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
                                                              const int *__restrict__ node_s, const long long *__restrict__ node_row,
                                                              const long long *__restrict__ node_pair, int quad_base, int C, int nwin,
                                                              const int *__restrict__ quad_order,
-                                                             unsigned *__restrict__ blkmax) {  // [4] maxima of T's blocks, or null
+                                                             unsigned *__restrict__ blkmax,    // [4] maxima of T's blocks, or null
+                                                             int zeros_kept) {  // != 0: the structurally-zero rows (a, b) hold their zeros
     constexpr int LPC = 16, PPW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,8 +184,9 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
     unsigned present = (unsigned)__ballot(lane < N && sPi[lane * N + b] >= 0);
     present = __builtin_amdgcn_readfirstlane(present);
     if (allok) {
-        for (unsigned z = ~present & (N >= 32 ? 0xffffffffu : ((1u << N) - 1u)); z; z &= z - 1)
-            st4(tcol + (__builtin_ctz(z)) * tstep, splat(0.f));
+        if (!zeros_kept)  // (the zeros of these rows are already in the buffer, written once for this batch: DevLevel::t_zeros)
+            for (unsigned z = ~present & (N >= 32 ? 0xffffffffu : ((1u << N) - 1u)); z; z &= z - 1)
+                st4(tcol + (__builtin_ctz(z)) * tstep, splat(0.f));
     } else if (fok && cg < 2) {
         for (unsigned z = ~present & (N >= 32 ? 0xffffffffu : ((1u << N) - 1u)); z; z &= z - 1)
             st4(T + (rowbase + (size_t)__builtin_ctz(z) * N + b) * (size_t)(T_COLS * C) + f + (cg ? T_T6 : T_SAB) * C, splat(0.f));
@@ -413,6 +415,15 @@ __global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict_
         st4(dst + (size_t)p * 2 * C + 4 * fl, a15);
         st4(dst + (size_t)p * 2 * C + C + 4 * fl, a16);
     }
+}
+
+// zeros into the S_ab and T6 blocks of the rows (a, b) tables-forward never writes: once per prepared batch (DevLevel::t_zeros)
+__global__ void tables_zero_fill(float *__restrict__ T, const unsigned char *__restrict__ rowflag, long long rows) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row = i >> 5;
+    if (row >= rows || rowflag[row]) return;
+    const int q = (int)(i & 31);  // 32 float4 = the two 64-column blocks
+    st4(T + row * (T_COLS * 64) + (q < 16 ? T_SAB * 64 + 4 * q : T_T6 * 64 + 4 * (q - 16)), splat(0.f));
 }
 
 // stacked[p] = K^(kperm[p])  (gather), or  dK^(kperm[p]) += dstacked[p]  (scatter-add).  Block k of the level weight is
@@ -938,11 +949,11 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     if ((C & 63) == 0)
         GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
-                  d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order, bm);
+                  d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order, bm, (d.t_zeros && (C & 63) == 0) ? 1 : 0);
     else
         GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, false>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
-                  d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order, bm);
+                  d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order, bm, (d.t_zeros && (C & 63) == 0) ? 1 : 0);
     return GF_OK;
 }
 
@@ -1391,6 +1402,17 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     const int rows = (int)h.rows, pairs = (int)h.pairs, nodes = h.nNodes;
     float *T = d.Q, *O = d.Q + (size_t)h.rows * T_COLS * C;
     gf_status st;
+    // The structurally-zero rows of the S_ab / T6 blocks (half of the rows at QM9 sizes, 0.73 GB of zeros a step at cfg3) are the
+    // same rows every step of a prepared batch and nothing else writes there: their zeros go in once, tables-forward skips them.
+    if (C == 64 && d.rowflag && !env_is("GF_SMP_KEEP_ZEROS", '0')) {
+        if (!d.t_zeros) {
+            GF_LAUNCH(ctx, "smpf_tables_fill", tables_zero_fill, dim3((unsigned)(((long long)rows * 32 + 255) / 256)), dim3(256), 0, T, d.rowflag,
+                      (long long)rows);
+            s->lv[l].t_zeros = true;
+        }
+    } else {
+        s->lv[l].t_zeros = false;
+    }
     const std::vector<SizeClass> cls = classes_of(h, 4);
     for (const SizeClass &c : cls) {
         switch (c.ni) {

@@ -94,6 +94,12 @@ struct gf_smp {
         int *fwd_pan_node = nullptr, *node_panel = nullptr;
         int2 *fwd_goff = nullptr;
         int fwd_npanels = 0;
+        // Rows (a, b) of T whose source a does not contain vertex b (pi < 0: half of them at QM9 sizes) are structurally zero in
+        // the S_ab and T6 blocks.  Their zeros are written ONCE per prepared batch (tables_zero_fill, the first fused forward) and
+        // tables-forward then skips them; rowflag[row] = 1 where the row is written every step.  t_zeros goes false whenever
+        // something else may have overwritten the T region of Q (an op-by-op forward of the level).
+        bool t_zeros = false;
+        unsigned char *rowflag = nullptr;
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
         float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients)
         long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
