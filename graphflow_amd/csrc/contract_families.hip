@@ -18,6 +18,8 @@
 // kernels RisiContraction_18 has; they are the correct-first implementation of the rarely used families.
 #include <cstdint>
 
+#include <cstdlib>
+
 #include "gf_internal.h"
 
 namespace gf {
@@ -606,6 +608,102 @@ __global__ __launch_bounds__(256) void fam_bwd_tables(const float *__restrict__ 
     }
 }
 
+// The same tables with every G row read ONCE (round 3).  Workgroup per (graph g, row x, channel window): the slices of row x
+// that are contracted over their second index z are staged in LDS -- the twenty indexed (i, z) (they feed row i = x of the six
+// tables above) and the ten indexed (j, z) (cases 6..9, 27, 30, 33, 36, 34, 37: they feed COLUMN j = x) -- together with the
+// graph's adjacency; a thread owns (t, four channels) and walks z once.  The column role cannot add into rows other workgroups
+// own, so its three sums go to tables of their own, stored transposed:
+//   btab[6] J_ab[j, i]   btab[7] J_ac[j, i]   btab[8] J_bc[j, i]      X_ab[i, j] = btab[0][i, j] + btab[6][j, i]  (etc.)
+// fam_backward_rows adds the two halves where it reads them.  The thread-per-(i, columns, f) kernel above re-read the (i, z)
+// slices once per column block and the (j, z) slices once per row: 11x the bytes of G through L1 / L2.
+constexpr int kNBTabJ = 9;  // six tables + the three column-role partials
+constexpr int kBtI = 20, kBtJ = 10;
+__constant__ int c_bt_islices[kBtI] = {3, 4, 18, 21, 19, 22, 28, 31, 43, 44, 46, 47, 48, 49, 17, 20, 26, 29, 32, 35};
+__constant__ int c_bt_jslices[kBtJ] = {6, 7, 27, 30, 8, 9, 33, 36, 34, 37};
+
+template <int K>
+__global__ __launch_bounds__(256) void fam_bwd_tables_lds(const float *__restrict__ G, const float *__restrict__ A,
+                                                          const float *__restrict__ adjs, const float *__restrict__ bsc,
+                                                          float *__restrict__ btab, int N, int C, int CW, int nwin) {
+    extern __shared__ __attribute__((aligned(16))) float bt_smem[];
+    constexpr int NS = (K == 50) ? kBtI + kBtJ : 6;  // K = 10: slices 3, 4 (row role) and 6, 7, 8, 9 (column role)
+    const size_t blk = xcd_block();
+    const int win = (int)(blk % nwin);
+    const int x = (int)((blk / nwin) % N);
+    const size_t g = blk / nwin / N;
+    const int f0 = win * CW, cw = (C - f0 < CW) ? C - f0 : CW, cv = cw / 4;
+    const size_t NNC = (size_t)N * N * C;
+    float *sl = bt_smem;                         // [NS][N][CW]
+    float *As = bt_smem + (size_t)NS * N * CW;   // [N][N]
+    const float *Gx = G + (g * N + x) * (size_t)N * K * C;  // row x: [z][K][C]
+    const float *Ag = A + g * N * N;
+    for (int i = threadIdx.x; i < NS * N * cv; i += blockDim.x) {
+        const int fl = i % cv, z = (i / cv) % N, k = i / (cv * N);
+        int cs;
+        if (K == 50) cs = k < kBtI ? c_bt_islices[k] : c_bt_jslices[k - kBtI];
+        else cs = (k < 2) ? 3 + k : 4 + k;  // 3, 4 | 6, 7, 8, 9
+        *reinterpret_cast<vf4 *>(sl + ((size_t)k * N + z) * CW + 4 * fl) =
+            *reinterpret_cast<const vf4 *>(Gx + ((size_t)z * K + slot<K>(cs)) * C + f0 + 4 * fl);
+    }
+    for (int i = threadIdx.x; i < N * N; i += blockDim.x) As[i] = Ag[i];
+    __syncthreads();
+    const float *r = adjs + g * adjs_stride(N), *q = r + N, *st = q + 2 * N;
+    const float tot = st[0], tr = st[1];
+    const float *u = bsc + g * 5 * (size_t)C;
+#define SL(k, z) (*reinterpret_cast<const vf4 *>(sl + ((size_t)(k) * N + (z)) * CW + 4 * fl))
+#define GD(c, xx, yy) (slot<K>(c) >= 0 ? *reinterpret_cast<const vf4 *>(G + (((g * N + (xx)) * (size_t)N + (yy)) * K + slot<K>(c)) * C + f) : vf4{0.f, 0.f, 0.f, 0.f})
+    for (int it = threadIdx.x; it < N * cv; it += blockDim.x) {
+        const int fl = it % cv, t = it / cv, f = f0 + 4 * fl;
+        const vf4 z4 = {0.f, 0.f, 0.f, 0.f};
+        // row role: i = x, j = t
+        vf4 xab = tot * GD(1, x, t) + *reinterpret_cast<const vf4 *>(u + 0 * C + f);
+        vf4 xac = tot * GD(2, x, t), xbc = tot * GD(5, x, t);
+        vf4 zbc = z4, zac = z4, zab = z4, jab = z4, jac = z4, jbc = z4;
+        if (K == 50) {
+            xab += tr * GD(13, x, t);
+            xac += tr * GD(16, x, t);
+            xbc += tr * GD(25, x, t);
+            zbc = *reinterpret_cast<const vf4 *>(u + 3 * C + f);
+            zac = *reinterpret_cast<const vf4 *>(u + 2 * C + f);
+            zab = *reinterpret_cast<const vf4 *>(u + 1 * C + f);
+        }
+        for (int z = 0; z < N; ++z) {
+            const float rz = r[z], qz = q[z];
+            if (K == 50) {
+                const float azt = As[z * N + t], atz = As[t * N + z];
+                xab += SL(0, z) * rz + SL(1, z) * qz + SL(2, z) * azt + SL(3, z) * atz;       // 3 r + 4 q + 18 A[z,j] + 21 A[j,z]
+                xac += SL(4, z) * azt + SL(5, z) * atz;                                        // 19, 22
+                xbc += SL(6, z) * azt + SL(7, z) * atz;                                        // 28, 31
+                zbc += SL(14, z) * rz + SL(15, z) * qz + SL(8, z) * azt + SL(9, z) * atz;      // 17 r + 20 q + 43, 44
+                zac += SL(16, z) * rz + SL(17, z) * qz + SL(10, z) * azt + SL(11, z) * atz;    // 26 r + 29 q + 46, 47
+                zab += SL(18, z) * rz + SL(19, z) * qz + SL(12, z) * azt + SL(13, z) * atz;    // 32 r + 35 q + 48, 49
+                // column role: j = x, i = t
+                jab += SL(20, z) * rz + SL(21, z) * qz + SL(22, z) * azt + SL(23, z) * atz;    // 6 r + 7 q + 27 A[z,i] + 30 A[i,z]
+                jac += SL(24, z) * rz + SL(25, z) * qz + SL(26, z) * azt + SL(27, z) * atz;    // 8 r + 9 q + 33, 36
+                jbc += SL(28, z) * azt + SL(29, z) * atz;                                      // 34, 37
+            } else {
+                xab += SL(0, z) * rz + SL(1, z) * qz;
+                jab += SL(2, z) * rz + SL(3, z) * qz;
+                jac += SL(4, z) * rz + SL(5, z) * qz;
+            }
+        }
+        float *bt = btab + g * kNBTabJ * NNC + ((size_t)x * N + t) * C + f;
+        *reinterpret_cast<vf4 *>(bt + 0 * NNC) = xab;
+        *reinterpret_cast<vf4 *>(bt + 1 * NNC) = xac;
+        *reinterpret_cast<vf4 *>(bt + 2 * NNC) = xbc;
+        if (K == 50) {
+            *reinterpret_cast<vf4 *>(bt + 3 * NNC) = zbc;
+            *reinterpret_cast<vf4 *>(bt + 4 * NNC) = zac;
+            *reinterpret_cast<vf4 *>(bt + 5 * NNC) = zab;
+        }
+        *reinterpret_cast<vf4 *>(bt + 6 * NNC) = jab;
+        *reinterpret_cast<vf4 *>(bt + 7 * NNC) = jac;
+        if (K == 50) *reinterpret_cast<vf4 *>(bt + 8 * NNC) = jbc;
+    }
+#undef SL
+#undef GD
+}
+
 template <int K>
 __global__ void fam_backward(const float *__restrict__ G, const float *__restrict__ A, const float *__restrict__ adjs,
                              const float *__restrict__ bsc, const float *__restrict__ btab, float *__restrict__ dP, int N,
@@ -650,14 +748,15 @@ __global__ void fam_backward(const float *__restrict__ G, const float *__restric
 template <int K, int VW>
 __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict__ G, const float *__restrict__ adjs,
                                                          const float *__restrict__ bsc, const float *__restrict__ btab,
-                                                         float *__restrict__ dP, int N, int C, int accumulate) {
+                                                         float *__restrict__ dP, int N, int C, int accumulate,
+                                                         int jt) {  // != 0: tables of fam_bwd_tables_lds (column-role partials 6..8)
     using V = typename Vec<VW>::T;
     extern __shared__ __attribute__((aligned(16))) float srow[];  // [4][N][C]: X_ac(a,c) | G14(a,c) | G15(a,c) | G42(a,c)
     const size_t NNC = (size_t)N * N * C, NC = (size_t)N * C;
     const size_t blk = xcd_block();
     const size_t g = blk / N;
     const int a = (int)(blk % N);
-    const float *bt = btab + g * kNBTab * NNC;
+    const float *bt = btab + g * (jt ? kNBTabJ : kNBTab) * NNC;
     const float *Gg = G + g * (size_t)N * N * K * C;
     const float *r = adjs + g * adjs_stride(N), *q = r + N, *dg = q + N;
 #define GCF(cs, x, y, f) Vec<VW>::ld(Gg + (((size_t)(x) * N + (y)) * K + slot<K>(cs)) * C + (f))
@@ -665,7 +764,9 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int c = it / CV, f = (it % CV) * VW;
         const size_t i = (size_t)c * C + f;
-        Vec<VW>::st(srow + 0 * NC + i, Vec<VW>::ld(bt + 1 * NNC + ((size_t)a * N + c) * C + f));
+        V xac = Vec<VW>::ld(bt + 1 * NNC + ((size_t)a * N + c) * C + f);
+        if (jt) xac += Vec<VW>::ld(bt + 7 * NNC + ((size_t)c * N + a) * C + f);
+        Vec<VW>::st(srow + 0 * NC + i, xac);
         if (K == 50) {
             Vec<VW>::st(srow + 1 * NC + i, GCF(14, a, c, f));
             Vec<VW>::st(srow + 2 * NC + i, GCF(15, a, c, f));
@@ -675,7 +776,8 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
     __syncthreads();
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int b = it / CV, f = (it % CV) * VW;
-        const V xab = Vec<VW>::ld(bt + 0 * NNC + ((size_t)a * N + b) * C + f);
+        V xab = Vec<VW>::ld(bt + 0 * NNC + ((size_t)a * N + b) * C + f);
+        if (jt) xab += Vec<VW>::ld(bt + 6 * NNC + ((size_t)b * N + a) * C + f);
         V g11 = Vec<VW>::zero(), g12 = g11, g41 = g11, zbc = g11, zac = g11, u50 = g11;
         const float rb = r[b], qb = q[b], dgb = dg[b], ra = r[a], qa = q[a], dga = dg[a];
         if (K == 50) {
@@ -689,6 +791,7 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
         float *out = dP + ((g * N + a) * N + b) * (size_t)N * C + f;
         for (int c = 0; c < N; ++c) {
             V v = xab + Vec<VW>::ld(srow + 0 * NC + (size_t)c * C + f) + Vec<VW>::ld(bt + 2 * NNC + ((size_t)b * N + c) * C + f);
+            if (jt && K == 50) v += Vec<VW>::ld(bt + 8 * NNC + ((size_t)c * N + b) * C + f);
             if (K == 50) {
                 v += g11 * r[c] + g12 * q[c] + g41 * dg[c];
                 v += Vec<VW>::ld(srow + 1 * NC + (size_t)c * C + f) * rb + Vec<VW>::ld(srow + 2 * NC + (size_t)c * C + f) * qb +
@@ -776,7 +879,23 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     //  two columns fit in registers, the shared (i,z) operands are re-read three times as often and the kernels are
     //  L2-bound -- so they keep one channel per thread; forward benefits and uses the vector path)
     const bool vec_bt = false;
-    if (vec && vec_bt) {
+    // LDS-staged tables (every G row read once): C % 4 == 0, the staged slices of a row fit 96 KB per channel window
+    int cwin = 0;
+    if (vec && N <= 64) {
+        const int ns = (K == 50) ? kBtI + kBtJ : 6;
+        cwin = (int)((96 * 1024 - sizeof(float) * (size_t)N * N) / (sizeof(float) * (size_t)ns * N)) / 4 * 4;
+        if (cwin > C) cwin = C;
+        if (cwin < 4 || N * (cwin / 4) > 1024 || std::getenv("GF_FAM_BWD_LDS") != nullptr) cwin = 0;  // (GF_FAM_BWD_LDS set: the older kernel)
+        if (sizeof(float) * 4 * (size_t)N * C > 48 * 1024 || (size_t)batch * N >= 0x7fffffffu) cwin = 0;  // (only fam_backward_rows adds the halves)
+    }
+    if (cwin > 0) {
+        const int nwin = (C + cwin - 1) / cwin;
+        const size_t lds = sizeof(float) * ((size_t)((K == 50) ? kBtI + kBtJ : 6) * N * cwin + (size_t)N * N);
+        st = opt_in_lds(ctx, fam_bwd_tables_lds<K>, lds);
+        if (st != GF_OK) return st;
+        GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables_lds<K>), dim3((unsigned)((size_t)batch * N * nwin)), dim3(256), lds, G, A, w.adjs,
+                  w.sc, w.tab, N, C, cwin, nwin);
+    } else if (vec && vec_bt) {
         const int njb = (N + 1) / 2;
         const size_t nt = (size_t)batch * N * njb * (C / 4);
         GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 4>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
@@ -791,10 +910,10 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     if (row_lds <= 48 * 1024 && (size_t)batch * N < 0x7fffffffu) {
         if (vec && vec_bt)
             GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, 4>), dim3((unsigned)((size_t)batch * N)), dim3(256), row_lds, G,
-                      w.adjs, w.sc, w.tab, dP, N, C, accumulate);
+                      w.adjs, w.sc, w.tab, dP, N, C, accumulate, cwin > 0 ? 1 : 0);
         else
             GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, 1>), dim3((unsigned)((size_t)batch * N)), dim3(256), row_lds, G,
-                      w.adjs, w.sc, w.tab, dP, N, C, accumulate);
+                      w.adjs, w.sc, w.tab, dP, N, C, accumulate, cwin > 0 ? 1 : 0);
     } else {
         GF_LAUNCH(ctx, "fam_backward", fam_backward<K>, dim3(grid_for(np)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, dP, N, C,
                   np, accumulate);

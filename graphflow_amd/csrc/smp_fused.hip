@@ -1529,6 +1529,8 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         if (st != GF_OK) return st;
     }
     if (s->side && !grouped) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
+    if (C == 64 && ocols == 2 && d.fwd_pan && (long long)rows * 512 < 0x3fffffffll && !env_is("GF_SMP_COMBINE_PANELS", '0'))
+        return smp_combine_fwd_panels_c64(s, l, O, bl);  // wave per row panel, the adjacency product on the matrix pipe
     {
         const size_t lds = combine_lds<16>(h.buckets.back().s);
         st = opt_in_lds(ctx, smp_combine_fwd<16>, lds);

@@ -174,6 +174,7 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_level_fwd_fused_c64(gf_smp *s, int l, const float *T, const float *bias, int cus);
+gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce

@@ -352,6 +352,123 @@ __global__ __launch_bounds__(kFfThreads, 1) void smp_level_fwd_fused(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// combine-forward on the same row panels, as a kernel of its own (default at C = 64, compact O): the epilogue of the kernel above
+// with O_loc and U read from the projected matrix instead of computed.  One WAVE per panel, no LDS, no barrier: every operand of
+// the panel -- its rows of O, the 64 gathered compact products, the lane's half row of the block-diagonal adjacency, the
+// rank-one operands -- is requested up front (one round trip), the adjacency product and the rank-one terms are fp32 MFMAs on
+// registers laid out as the MFMA's C/D tile, f_l leaves as 128-byte row segments.  Replaces smp_combine_fwd<16> (workgroup per
+// (node, four x): adjacency image in LDS, a barrier between its two phases, a quarter of its waves idle on ragged quads).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void smp_combine_fwd_panels(
+    const float *__restrict__ O, float *__restrict__ F, const int4 *__restrict__ pan, const int *__restrict__ pan_node, int npanels,
+    int rows, const int2 *__restrict__ goff, const float *__restrict__ Gc, long long gc_rows, const float *__restrict__ adj,
+    const float *__restrict__ rsum, const float *__restrict__ Vout, long long pairs, const float *__restrict__ Sout,
+    const float *__restrict__ bias) {
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    unsigned blk;
+    {
+        const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8;
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8;
+    }
+    const int p = __builtin_amdgcn_readfirstlane((int)(blk * 4 + (threadIdx.x >> 6)));
+    if (p >= npanels) return;
+    auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const int4 Pv = pan[p];
+    const int4 P = make_int4(rfl(Pv.x), rfl(Pv.y), rfl(Pv.z), rfl(Pv.w));
+    const int node = rfl(pan_node[p]);
+    const int nrows = P.y & 0xff, s = (P.y >> 8) & 0xff, G = (P.y >> 16) & 0xff, x0 = (P.y >> 24) & 0xff;
+    const bool rowok = li < nrows;
+    const int row = P.x + (rowok ? li : nrows - 1);
+    const int2 go = goff[row];
+    const __amdgpu_buffer_rsrc_t rO = ff_rsrc(O, (size_t)rows * 128 * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rGc = ff_rsrc(Gc, (size_t)gc_rows * 128 * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rAdj = ff_rsrc(adj, (size_t)rows * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rV = ff_rsrc(Vout, (size_t)pairs * 64 * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rF = ff_rsrc(F, (size_t)rows * 64 * sizeof(float));
+    const int gs = (int)((li + 0.5f) * __builtin_amdgcn_rcpf((float)s));
+    const int y_li = li - gs * s;
+    // operands that do not depend on the gather indices first
+    f16v m0, m1, u0, u1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int vo = rr < nrows ? (P.x + rr) * 512 + li * 4 : kFfOor;
+        m0[r] = ff_ld1(rO, vo);
+        m1[r] = ff_ld1(rO, vo + 128);
+        u0[r] = ff_ld1(rO, vo + 256);
+        u1[r] = ff_ld1(rO, vo + 384);
+    }
+    float aval[16], vb0[5], vb1[5];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int er = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int e = er - gs * s;
+        const bool in = rowok && e >= 0 && e < s && er < nrows;
+        aval[r] = ff_ld1(rAdj, in ? (P.z + y_li * s + e) * 4 : kFfOor);
+    }
+    {
+        const float *p0 = lh ? bias : Sout + (size_t)node * 64;
+        vb0[0] = p0[li];
+        vb1[0] = p0[32 + li];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int g = 2 * t + lh;
+            const int vo = g < G ? (int)(((long long)P.w + x0 + g) * 256) + li * 4 : kFfOor;
+            vb0[t + 1] = ff_ld1(rV, vo);
+            vb1[t + 1] = ff_ld1(rV, vo + 128);
+        }
+    }
+    const float axy = rowok ? adj[row] : 0.f;
+    const float r_y = rowok ? rsum[(size_t)P.w + y_li] : 0.f;
+    // the compact products G15[x, e] + G16[e, x] of the panel's rows
+    float g0[16], g1[16], g2[16], g3[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2);
+        const int a15 = __builtin_amdgcn_readlane(go.x, rr), b15 = __builtin_amdgcn_readlane(go.x, rr + 4);
+        const int a16 = __builtin_amdgcn_readlane(go.y, rr), b16 = __builtin_amdgcn_readlane(go.y, rr + 4);
+        const int i15 = lh ? b15 : a15, i16 = lh ? b16 : a16;
+        const int v15 = i15 < 0 ? kFfOor : i15 * 512 + li * 4, v16 = i16 < 0 ? kFfOor : i16 * 512 + 256 + li * 4;
+        g0[r] = ff_ld1(rGc, v15);
+        g1[r] = ff_ld1(rGc, v16);
+        g2[r] = ff_ld1(rGc, v15 + 128);
+        g3[r] = ff_ld1(rGc, v16 + 128);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        u0[r] += g0[r] + g1[r];
+        u1[r] += g2[r] + g3[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float a = aval[r] > 0.f ? aval[r] : 0.f;  // the gate of RisiContraction_18 (RisiContraction_18.h:90)
+        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u0[r], m0, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u1[r], m1, 0, 0, 0);
+    }
+    {
+        const float a0 = lh ? 1.f : (axy > 0.f ? axy : 0.f);
+        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, vb0[0], m0, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, vb1[0], m1, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (2 * t < G) {  // (uniform; nothing is requested in here)
+                const float a = (2 * t + lh) == gs ? r_y : 0.f;
+                m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vb0[t + 1], m0, 0, 0, 0);
+                m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vb1[t + 1], m1, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int vo = rr < nrows ? (P.x + rr) * 256 + li * 4 : kFfOor;
+        const float z0 = m0[r], z1 = m1[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z0 > 0.f ? z0 : kAlphaFf * z0), rF, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z1 > 0.f ? z1 : kAlphaFf * z1), rF, vo + 128, 0, 0);
+    }
+}
+
 // ---- per-level tables of the kernel above, built on the device at prepare time
 // node_panel[n] = first panel of node n; a node of size s has ceil(s / gpp) panels of gpp = max(1, 32 / s) row groups
 __global__ void build_fwd_panels(const int *__restrict__ node_s, const long long *__restrict__ node_row,
@@ -389,6 +506,19 @@ gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream) {
     hipLaunchKernelGGL(build_fwd_goff, dim3((unsigned)h.nNodes), dim3(64), 0, stream, d.node_s, d.node_row, d.node_pair, d.pair_src_pair,
                        d.pi, d.fwd_goff);
     GF_LAUNCH_CHECK(s->ctx, "build_fwd_panels");
+    return GF_OK;
+}
+
+// f_l from the projected matrix O = [O_loc | U] (compact layout) of a fused level at C = 64: smp_combine_fwd_panels
+gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias) {
+    gf_ctx *ctx = s->ctx;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const gfsmp::LevelLayout &h = s->lay.level[l];
+    const int npanels = d.fwd_npanels;
+    if (npanels < 1) return GF_OK;
+    GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
+              d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
+              (long long)h.pairs, d.Sout, bias);
     return GF_OK;
 }
 

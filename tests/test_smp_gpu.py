@@ -356,6 +356,29 @@ def test_gather_kernels_agree(gf, monkeypatch, C):
     assert rel_err(g1, g0) <= 1e-6
 
 
+def test_panel_combine_forward_equals_the_quad_kernel(gf, monkeypatch):
+    """combine-forward at C = 64: one wave per row panel with the adjacency product and the rank-one terms as fp32 MFMAs on registers
+    (smp_combine_fwd_panels, default) against the round-2 kernel (GF_SMP_COMBINE_PANELS=0: workgroup per (node, four x), adjacency
+    image in LDS): same sums, different association."""
+    F, D, C, L, cap = 5, 5, 64, 3, 29
+    mols, tg = [], []
+    for seed in range(40):   # 29-atom molecules: one-group panels (s >= 17), ragged last panels, up to eight groups per panel
+        adj, feat, t = synthetic_molecule(1500 + seed, nV=29 if seed % 4 == 0 else None)
+        mols.append((adj, feat))
+        tg.append(t)
+    params = smp_params(C, F, D, L, 6)
+    p1, _, f1, g1, n1 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    a1 = [n1.activation(0, l, 0) for l in (1, 2, 3)]
+    monkeypatch.setenv("GF_SMP_COMBINE_PANELS", "0")
+    p0, _, f0, g0, n0 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    a0 = [n0.activation(0, l, 0) for l in (1, 2, 3)]
+    assert not np.array_equal(f1, f0)   # (the switch switches something)
+    for x, y in zip(a1, a0):
+        assert rel_err(x.astype(np.float64), y.astype(np.float64)) <= 2e-6
+    note("panel_combine_vs_quad_combine", pred=rel_err(p1, p0), feat=rel_err(f1, f0), grads=rel_err(g1, g0))
+    assert rel_err(p1, p0) <= 2e-6 and rel_err(f1, f0) <= 2e-6 and rel_err(g1, g0) <= KINK_GRAD
+
+
 def test_fused_forward_level_equals_products_plus_combine(gf, monkeypatch):
     """At C = 64 the forward block products and combine-forward can run as ONE kernel (GF_SMP_FUSE_FWD=1, smp_level_c64_fwd.hip: the
     projected matrix O stays in the MFMA accumulators, the adjacency products and rank-one terms are fp32 MFMAs on them; opt-in:
