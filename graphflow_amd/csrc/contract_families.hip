@@ -637,13 +637,24 @@ __global__ __launch_bounds__(256) void fam_bwd_tables_lds(const float *__restric
     float *As = bt_smem + (size_t)NS * N * CW;   // [N][N]
     const float *Gx = G + (g * N + x) * (size_t)N * K * C;  // row x: [z][K][C]
     const float *Ag = A + g * N * N;
-    for (int i = threadIdx.x; i < NS * N * cv; i += blockDim.x) {
-        const int fl = i % cv, z = (i / cv) % N, k = i / (cv * N);
-        int cs;
-        if (K == 50) cs = k < kBtI ? c_bt_islices[k] : c_bt_jslices[k - kBtI];
-        else cs = (k < 2) ? 3 + k : 4 + k;  // 3, 4 | 6, 7, 8, 9
-        *reinterpret_cast<vf4 *>(sl + ((size_t)k * N + z) * CW + 4 * fl) =
-            *reinterpret_cast<const vf4 *>(Gx + ((size_t)z * K + slot<K>(cs)) * C + f0 + 4 * fl);
+    // (eight requests per thread in flight: one at a time, the staging of a row was 45 us of round trips per workgroup)
+    const int nst = NS * N * cv;
+    for (int i0 = threadIdx.x; i0 < nst; i0 += 8 * blockDim.x) {
+        vf4 v[8];
+        int dst[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * blockDim.x, ic = i < nst ? i : nst - 1;
+            const int fl = ic % cv, z = (ic / cv) % N, k = ic / (cv * N);
+            int cs;
+            if (K == 50) cs = k < kBtI ? c_bt_islices[k] : c_bt_jslices[k - kBtI];
+            else cs = (k < 2) ? 3 + k : 4 + k;  // 3, 4 | 6, 7, 8, 9
+            dst[j] = i < nst ? (k * N + z) * CW + 4 * fl : -1;
+            v[j] = *reinterpret_cast<const vf4 *>(Gx + ((size_t)z * K + slot<K>(cs)) * C + f0 + 4 * fl);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (dst[j] >= 0) *reinterpret_cast<vf4 *>(sl + dst[j]) = v[j];
     }
     for (int i = threadIdx.x; i < N * N; i += blockDim.x) As[i] = Ag[i];
     __syncthreads();
@@ -883,9 +894,13 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     int cwin = 0;
     if (vec && N <= 64) {
         const int ns = (K == 50) ? kBtI + kBtJ : 6;
-        cwin = (int)((96 * 1024 - sizeof(float) * (size_t)N * N) / (sizeof(float) * (size_t)ns * N)) / 4 * 4;
+        const char *lim = std::getenv("GF_FAM_BWD_KB");  // LDS budget per workgroup (default 48 KB: three workgroups per CU)
+        const size_t budget = (size_t)(lim ? std::atoi(lim) : 48) * 1024;
+        cwin = (int)((budget - sizeof(float) * (size_t)N * N) / (sizeof(float) * (size_t)ns * N)) / 4 * 4;
         if (cwin > C) cwin = C;
-        if (cwin < 4 || N * (cwin / 4) > 1024 || std::getenv("GF_FAM_BWD_LDS") != nullptr) cwin = 0;  // (GF_FAM_BWD_LDS set: the older kernel)
+        if (cwin < 4 || N * (cwin / 4) > 1024 || !(std::getenv("GF_FAM_BWD_LDS") && std::getenv("GF_FAM_BWD_LDS")[0] == '1')) cwin = 0;
+        // (opt-in: measured at cfg5 the LDS-staged tables are LDS-bandwidth bound -- every thread of a row reads all 30 staged
+        //  slices per z -- 0.56 ms against 0.40 ms for fam_bwd_tables, and fam_backward_rows pays 0.11 ms for the transposed halves)
         if (sizeof(float) * 4 * (size_t)N * C > 48 * 1024 || (size_t)batch * N >= 0x7fffffffu) cwin = 0;  // (only fam_backward_rows adds the halves)
     }
     if (cwin > 0) {

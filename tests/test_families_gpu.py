@@ -91,12 +91,14 @@ def test_r18_is_the_gated_subset_of_r50(gf):
     assert rel_err_slices(o18, o50[:, :, :, sel, :]) <= REL_TOL_F32
 
 
+@pytest.mark.parametrize("lds", ["0", "1"])
 @pytest.mark.parametrize("K", [50, 10])
-def test_cfg5_shape_one_graph_vs_oracle_spec_form(gf, oracle, K):
+def test_cfg5_shape_one_graph_vs_oracle_spec_form(gf, oracle, monkeypatch, K, lds):
     """BASELINE configs[4]'s shape (N = 24, C = 32): the lane mapping of fam_tables<50,4> / fam_products_lds<50> /
     fam_bwd_tables<50,1> is only reached at C % 4 == 0 and this size.  Graph 0 of a 3-graph batch (weighted adjacency, so the
     no-gate rule of _50 / _10 matters) against the oracle's table-driven spec form (RisiContraction_50.h:94-430) on two
     channels -- channels are independent, so the oracle runs the O(N^5) form on a 2-channel copy."""
+    monkeypatch.setenv("GF_FAM_BWD_LDS", lds)   # 1: the LDS-staged backward tables (fam_bwd_tables_lds, opt-in: DESIGN.md 6)
     rng = np.random.default_rng(5050 + K)
     B, N, C = 3, 24, 32
     P = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
