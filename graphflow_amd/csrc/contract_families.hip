@@ -508,28 +508,31 @@ __global__ __launch_bounds__(256) void fam_bwd_scalars(const float *__restrict__
 // all JB columns; only the ten slices indexed by (j,z) and four adjacency entries are per column.
 constexpr int kNBTab = 6;
 
-template <int K, int VW>
+template <int K, int VW, int IB>
 __global__ __launch_bounds__(256) void fam_bwd_tables(const float *__restrict__ G, const float *__restrict__ A,
                                                       const float *__restrict__ adjs, const float *__restrict__ bsc,
                                                       float *__restrict__ btab, int N, int C, int njb, size_t total) {
+    // IB rows i x kJB columns j per thread (round 3: IB = 2 -- per z a thread loads the twenty (i,z) slices of each row and the ten
+    // (j,z) slices of each column, (20 IB + 10 kJB) loads for IB kJB outputs: 13.3 per output at 1 x 6, 8.3 at 2 x 6; the kernel
+    // is bound by those loads through L1)
     using V = typename Vec<VW>::T;
     constexpr int kJB = (VW == 4) ? 2 : 6;
     const size_t NNC = (size_t)N * N * C;
-    const int CV = C / VW;
+    const int CV = C / VW, nib = (N + IB - 1) / IB;
     GRID_STRIDE(idx, total) {
         const int f = (int)(idx % CV) * VW;
         size_t t = idx / CV;
         const int j0 = (int)(t % njb) * kJB;
         t /= njb;
-        const int i = t % N;
-        const size_t g = t / N;
+        const int i0 = (int)(t % nib) * IB;
+        const size_t g = t / nib;
         const float *Gg = G + g * (size_t)N * N * K * C + f;
         const float *Ag = A + g * N * N;
         const float *r = adjs + g * adjs_stride(N), *q = r + N, *st = q + 2 * N;
         const float tot = st[0], tr = st[1];
         const float *u = bsc + g * 5 * (size_t)C + f;
 #define GC(c, x, y) (slot<K>(c) >= 0 ? Vec<VW>::ld(Gg + (((size_t)(x) * N + (y)) * K + slot<K>(c)) * C) : Vec<VW>::zero())
-        V xab[kJB], xac[kJB], xbc[kJB], zbc[kJB], zac[kJB], zab[kJB];
+        V xab[IB][kJB], xac[IB][kJB], xbc[IB][kJB], zbc[IB][kJB], zac[IB][kJB], zab[IB][kJB];
         const V u10 = Vec<VW>::ld(u + 0 * C);
         V u38 = Vec<VW>::zero(), u39 = Vec<VW>::zero(), u40 = Vec<VW>::zero();
         if (K == 50) {
@@ -537,72 +540,97 @@ __global__ __launch_bounds__(256) void fam_bwd_tables(const float *__restrict__ 
             u39 = Vec<VW>::ld(u + 2 * C);
             u40 = Vec<VW>::ld(u + 3 * C);
         }
-        int jj[kJB];
+        int jj[kJB], ii[IB];
+#pragma unroll
+        for (int n = 0; n < IB; ++n) ii[n] = (i0 + n < N) ? i0 + n : N - 1;  // clamped duplicates, never stored
 #pragma unroll
         for (int m = 0; m < kJB; ++m) {
-            jj[m] = (j0 + m < N) ? j0 + m : N - 1;  // clamped duplicate, never stored
+            jj[m] = (j0 + m < N) ? j0 + m : N - 1;
             const int j = jj[m];
-            xab[m] = tot * GC(1, i, j) + u10;
-            xac[m] = tot * GC(2, i, j);
-            xbc[m] = tot * GC(5, i, j);
-            zbc[m] = zac[m] = zab[m] = Vec<VW>::zero();
-            if (K == 50) {
-                xab[m] += tr * GC(13, i, j);
-                xac[m] += tr * GC(16, i, j);
-                xbc[m] += tr * GC(25, i, j);
-                zbc[m] = u40;
-                zac[m] = u39;
-                zab[m] = u38;
+#pragma unroll
+            for (int n = 0; n < IB; ++n) {
+                const int i = ii[n];
+                xab[n][m] = tot * GC(1, i, j) + u10;
+                xac[n][m] = tot * GC(2, i, j);
+                xbc[n][m] = tot * GC(5, i, j);
+                zbc[n][m] = zac[n][m] = zab[n][m] = Vec<VW>::zero();
+                if (K == 50) {
+                    xab[n][m] += tr * GC(13, i, j);
+                    xac[n][m] += tr * GC(16, i, j);
+                    xbc[n][m] += tr * GC(25, i, j);
+                    zbc[n][m] = u40;
+                    zac[n][m] = u39;
+                    zab[n][m] = u38;
+                }
             }
         }
         for (int z = 0; z < N; ++z) {
             const float rz = r[z], qz = q[z];
             // (i,z)-indexed slices: shared by every column of the block
-            const V g3 = GC(3, i, z), g4 = GC(4, i, z);
-            const V i34 = g3 * rz + g4 * qz;
             const V zz = Vec<VW>::zero();
-            V g18 = zz, g21 = zz, g19 = zz, g22 = zz, g28 = zz, g31 = zz, g43 = zz, g44 = zz, g46 = zz, g47 = zz, g48 = zz, g49 = zz,
-              z17 = zz, z26 = zz, z32 = zz;
-            float azi = 0.f, aiz = 0.f;
-            if (K == 50) {
-                g18 = GC(18, i, z); g21 = GC(21, i, z); g19 = GC(19, i, z); g22 = GC(22, i, z);
-                g28 = GC(28, i, z); g31 = GC(31, i, z); g43 = GC(43, i, z); g44 = GC(44, i, z);
-                g46 = GC(46, i, z); g47 = GC(47, i, z); g48 = GC(48, i, z); g49 = GC(49, i, z);
-                z17 = GC(17, i, z) * rz + GC(20, i, z) * qz;
-                z26 = GC(26, i, z) * rz + GC(29, i, z) * qz;
-                z32 = GC(32, i, z) * rz + GC(35, i, z) * qz;
-                azi = Ag[z * N + i];
-                aiz = Ag[i * N + z];
+            V i34[IB], g18[IB], g21[IB], g19[IB], g22[IB], g28[IB], g31[IB], g43[IB], g44[IB], g46[IB], g47[IB], g48[IB], g49[IB], z17[IB],
+                z26[IB], z32[IB];
+            float azi[IB], aiz[IB];
+#pragma unroll
+            for (int n = 0; n < IB; ++n) {
+                const int i = ii[n];
+                i34[n] = GC(3, i, z) * rz + GC(4, i, z) * qz;
+                g18[n] = g21[n] = g19[n] = g22[n] = g28[n] = g31[n] = g43[n] = g44[n] = g46[n] = g47[n] = g48[n] = g49[n] = z17[n] = z26[n] =
+                    z32[n] = zz;
+                azi[n] = aiz[n] = 0.f;
+                if (K == 50) {
+                    g18[n] = GC(18, i, z); g21[n] = GC(21, i, z); g19[n] = GC(19, i, z); g22[n] = GC(22, i, z);
+                    g28[n] = GC(28, i, z); g31[n] = GC(31, i, z); g43[n] = GC(43, i, z); g44[n] = GC(44, i, z);
+                    g46[n] = GC(46, i, z); g47[n] = GC(47, i, z); g48[n] = GC(48, i, z); g49[n] = GC(49, i, z);
+                    z17[n] = GC(17, i, z) * rz + GC(20, i, z) * qz;
+                    z26[n] = GC(26, i, z) * rz + GC(29, i, z) * qz;
+                    z32[n] = GC(32, i, z) * rz + GC(35, i, z) * qz;
+                    azi[n] = Ag[z * N + i];
+                    aiz[n] = Ag[i * N + z];
+                }
             }
 #pragma unroll
             for (int m = 0; m < kJB; ++m) {
                 const int j = jj[m];
+                // (j,z)-indexed slices: shared by every row of the block
                 // outer-product cases: X_ab[a=i,b=j] takes U3[a]+U4[a]+U6[b]+U7[b]; X_ac[a=i,c=j] takes U8[c]+U9[c]
-                xab[m] += i34 + GC(6, j, z) * rz + GC(7, j, z) * qz;
-                xac[m] += GC(8, j, z) * rz + GC(9, j, z) * qz;
+                const V j67 = GC(6, j, z) * rz + GC(7, j, z) * qz, j89 = GC(8, j, z) * rz + GC(9, j, z) * qz;
+                V g27 = zz, g30 = zz, g33 = zz, g36 = zz, g34 = zz, g37 = zz;
+                float azj = 0.f, ajz = 0.f;
                 if (K == 50) {
-                    const float azj = Ag[z * N + j], ajz = Ag[j * N + z];
-                    xab[m] += g18 * azj + g21 * ajz + GC(27, j, z) * azi + GC(30, j, z) * aiz;   // X_ab[a=i, b=j]
-                    xac[m] += g19 * azj + g22 * ajz + GC(33, j, z) * azi + GC(36, j, z) * aiz;   // X_ac[a=i, c=j]
-                    xbc[m] += g28 * azj + g31 * ajz + GC(34, j, z) * azi + GC(37, j, z) * aiz;   // X_bc[b=i, c=j]
-                    zbc[m] += z17 + g43 * azj + g44 * ajz;                                        // Z_bc[a=i, b=j]  (b == c)
-                    zac[m] += z26 + g46 * azj + g47 * ajz;                                        // Z_ac[b=i, a=j]  (a == c)
-                    zab[m] += z32 + g48 * azj + g49 * ajz;                                        // Z_ab[c=i, a=j]  (a == b)
+                    g27 = GC(27, j, z); g30 = GC(30, j, z); g33 = GC(33, j, z); g36 = GC(36, j, z); g34 = GC(34, j, z); g37 = GC(37, j, z);
+                    azj = Ag[z * N + j], ajz = Ag[j * N + z];
+                }
+#pragma unroll
+                for (int n = 0; n < IB; ++n) {
+                    xab[n][m] += i34[n] + j67;
+                    xac[n][m] += j89;
+                    if (K == 50) {
+                        xab[n][m] += g18[n] * azj + g21[n] * ajz + g27 * azi[n] + g30 * aiz[n];   // X_ab[a=i, b=j]
+                        xac[n][m] += g19[n] * azj + g22[n] * ajz + g33 * azi[n] + g36 * aiz[n];   // X_ac[a=i, c=j]
+                        xbc[n][m] += g28[n] * azj + g31[n] * ajz + g34 * azi[n] + g37 * aiz[n];   // X_bc[b=i, c=j]
+                        zbc[n][m] += z17[n] + g43[n] * azj + g44[n] * ajz;                        // Z_bc[a=i, b=j]  (b == c)
+                        zac[n][m] += z26[n] + g46[n] * azj + g47[n] * ajz;                        // Z_ac[b=i, a=j]  (a == c)
+                        zab[n][m] += z32[n] + g48[n] * azj + g49[n] * ajz;                        // Z_ab[c=i, a=j]  (a == b)
+                    }
                 }
             }
         }
 #undef GC
 #pragma unroll
-        for (int m = 0; m < kJB; ++m) {
-            if (j0 + m >= N) continue;
-            float *bt = btab + g * kNBTab * NNC + ((size_t)i * N + j0 + m) * C + f;
-            Vec<VW>::st(bt + 0 * NNC, xab[m]);
-            Vec<VW>::st(bt + 1 * NNC, xac[m]);
-            Vec<VW>::st(bt + 2 * NNC, xbc[m]);
-            if (K == 50) {
-                Vec<VW>::st(bt + 3 * NNC, zbc[m]);
-                Vec<VW>::st(bt + 4 * NNC, zac[m]);
-                Vec<VW>::st(bt + 5 * NNC, zab[m]);
+        for (int n = 0; n < IB; ++n) {
+#pragma unroll
+            for (int m = 0; m < kJB; ++m) {
+                if (j0 + m >= N || i0 + n >= N) continue;
+                float *bt = btab + g * kNBTab * NNC + ((size_t)(i0 + n) * N + j0 + m) * C + f;
+                Vec<VW>::st(bt + 0 * NNC, xab[n][m]);
+                Vec<VW>::st(bt + 1 * NNC, xac[n][m]);
+                Vec<VW>::st(bt + 2 * NNC, xbc[n][m]);
+                if (K == 50) {
+                    Vec<VW>::st(bt + 3 * NNC, zbc[n][m]);
+                    Vec<VW>::st(bt + 4 * NNC, zac[n][m]);
+                    Vec<VW>::st(bt + 5 * NNC, zab[n][m]);
+                }
             }
         }
     }
@@ -753,68 +781,93 @@ __global__ void fam_backward(const float *__restrict__ G, const float *__restric
     }
 }
 
-// The same combination with a workgroup per (g, a): the four (a,c)-indexed rows (X_ac and the G slices of cases 14, 15,
-// 42) are staged in LDS once and serve every b; a thread owns (b, f), keeps its (a,b)-indexed terms in registers and
-// walks c, so each output costs four global loads (the (b,c)-indexed terms) instead of twelve.
-template <int K, int VW>
+// The same combination with a workgroup per (g, AB consecutive a): the four (a,c)-indexed rows (X_ac and the G slices of cases
+// 14, 15, 42) of each a are staged in LDS once and serve every b; a thread owns (b, f), keeps its (a,b)-indexed terms in
+// registers and walks c.  The (b,c)-indexed terms (X_bc and the slices of cases 23, 24, 45: four global loads per output with one
+// a per workgroup, N x the bytes of those tables through L2 -- the kernel's bound at cfg5) are loaded once per c and serve the AB
+// rows a of the workgroup.
+template <int K, int VW, int AB>
 __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict__ G, const float *__restrict__ adjs,
                                                          const float *__restrict__ bsc, const float *__restrict__ btab,
                                                          float *__restrict__ dP, int N, int C, int accumulate,
                                                          int jt) {  // != 0: tables of fam_bwd_tables_lds (column-role partials 6..8)
     using V = typename Vec<VW>::T;
-    extern __shared__ __attribute__((aligned(16))) float srow[];  // [4][N][C]: X_ac(a,c) | G14(a,c) | G15(a,c) | G42(a,c)
+    extern __shared__ __attribute__((aligned(16))) float srow[];  // [AB][4][N][C]: X_ac(a,c) | G14(a,c) | G15(a,c) | G42(a,c)
     const size_t NNC = (size_t)N * N * C, NC = (size_t)N * C;
     const size_t blk = xcd_block();
-    const size_t g = blk / N;
-    const int a = (int)(blk % N);
+    const int na = (N + AB - 1) / AB;
+    const size_t g = blk / na;
+    const int a0 = (int)(blk % na) * AB;
     const float *bt = btab + g * (jt ? kNBTabJ : kNBTab) * NNC;
     const float *Gg = G + g * (size_t)N * N * K * C;
     const float *r = adjs + g * adjs_stride(N), *q = r + N, *dg = q + N;
 #define GCF(cs, x, y, f) Vec<VW>::ld(Gg + (((size_t)(x) * N + (y)) * K + slot<K>(cs)) * C + (f))
     const int CV = C / VW, items = N * CV;
-    for (int it = threadIdx.x; it < items; it += blockDim.x) {
-        const int c = it / CV, f = (it % CV) * VW;
-        const size_t i = (size_t)c * C + f;
+    for (int it = threadIdx.x; it < AB * items; it += blockDim.x) {
+        const int m = it / items, c = (it % items) / CV, f = (it % CV) * VW;
+        const int a = (a0 + m < N) ? a0 + m : N - 1;  // (rows past the end: a clamped copy, never stored)
+        float *sr = srow + (size_t)m * 4 * NC + (size_t)c * C + f;
         V xac = Vec<VW>::ld(bt + 1 * NNC + ((size_t)a * N + c) * C + f);
         if (jt) xac += Vec<VW>::ld(bt + 7 * NNC + ((size_t)c * N + a) * C + f);
-        Vec<VW>::st(srow + 0 * NC + i, xac);
+        Vec<VW>::st(sr + 0 * NC, xac);
         if (K == 50) {
-            Vec<VW>::st(srow + 1 * NC + i, GCF(14, a, c, f));
-            Vec<VW>::st(srow + 2 * NC + i, GCF(15, a, c, f));
-            Vec<VW>::st(srow + 3 * NC + i, GCF(42, a, c, f));
+            Vec<VW>::st(sr + 1 * NC, GCF(14, a, c, f));
+            Vec<VW>::st(sr + 2 * NC, GCF(15, a, c, f));
+            Vec<VW>::st(sr + 3 * NC, GCF(42, a, c, f));
         }
     }
     __syncthreads();
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int b = it / CV, f = (it % CV) * VW;
-        V xab = Vec<VW>::ld(bt + 0 * NNC + ((size_t)a * N + b) * C + f);
-        if (jt) xab += Vec<VW>::ld(bt + 6 * NNC + ((size_t)b * N + a) * C + f);
-        V g11 = Vec<VW>::zero(), g12 = g11, g41 = g11, zbc = g11, zac = g11, u50 = g11;
-        const float rb = r[b], qb = q[b], dgb = dg[b], ra = r[a], qa = q[a], dga = dg[a];
-        if (K == 50) {
-            g11 = GCF(11, a, b, f);
-            g12 = GCF(12, a, b, f);
-            g41 = GCF(41, a, b, f);
-            zbc = Vec<VW>::ld(bt + 3 * NNC + ((size_t)a * N + b) * C + f);   // applies at c == b
-            zac = Vec<VW>::ld(bt + 4 * NNC + ((size_t)b * N + a) * C + f);   // applies at c == a
-            u50 = Vec<VW>::ld(bsc + g * 5 * (size_t)C + 4 * C + f);
-        }
-        float *out = dP + ((g * N + a) * N + b) * (size_t)N * C + f;
-        for (int c = 0; c < N; ++c) {
-            V v = xab + Vec<VW>::ld(srow + 0 * NC + (size_t)c * C + f) + Vec<VW>::ld(bt + 2 * NNC + ((size_t)b * N + c) * C + f);
-            if (jt && K == 50) v += Vec<VW>::ld(bt + 8 * NNC + ((size_t)c * N + b) * C + f);
+        V xab[AB], g11[AB], g12[AB], g41[AB], zbc[AB], zac[AB];
+        float ra[AB], qa[AB], dga[AB];
+        const float rb = r[b], qb = q[b], dgb = dg[b];
+        V u50 = Vec<VW>::zero();
+        if (K == 50) u50 = Vec<VW>::ld(bsc + g * 5 * (size_t)C + 4 * C + f);
+#pragma unroll
+        for (int m = 0; m < AB; ++m) {
+            const int a = (a0 + m < N) ? a0 + m : N - 1;
+            xab[m] = Vec<VW>::ld(bt + 0 * NNC + ((size_t)a * N + b) * C + f);
+            if (jt) xab[m] += Vec<VW>::ld(bt + 6 * NNC + ((size_t)b * N + a) * C + f);
+            g11[m] = g12[m] = g41[m] = zbc[m] = zac[m] = Vec<VW>::zero();
+            ra[m] = r[a], qa[m] = q[a], dga[m] = dg[a];
             if (K == 50) {
-                v += g11 * r[c] + g12 * q[c] + g41 * dg[c];
-                v += Vec<VW>::ld(srow + 1 * NC + (size_t)c * C + f) * rb + Vec<VW>::ld(srow + 2 * NC + (size_t)c * C + f) * qb +
-                     Vec<VW>::ld(srow + 3 * NC + (size_t)c * C + f) * dgb;
-                v += GCF(23, b, c, f) * ra + GCF(24, b, c, f) * qa + GCF(45, b, c, f) * dga;
-                if (b == c) v += zbc;
-                if (a == c) v += zac;
-                if (a == b) v += Vec<VW>::ld(bt + 5 * NNC + ((size_t)c * N + a) * C + f);
-                if (a == b && b == c) v += u50;
+                g11[m] = GCF(11, a, b, f);
+                g12[m] = GCF(12, a, b, f);
+                g41[m] = GCF(41, a, b, f);
+                zbc[m] = Vec<VW>::ld(bt + 3 * NNC + ((size_t)a * N + b) * C + f);   // applies at c == b
+                zac[m] = Vec<VW>::ld(bt + 4 * NNC + ((size_t)b * N + a) * C + f);   // applies at c == a
             }
-            if (accumulate) v += Vec<VW>::ld(out + (size_t)c * C);
-            Vec<VW>::st(out + (size_t)c * C, v);
+        }
+        for (int c = 0; c < N; ++c) {
+            V xbc = Vec<VW>::ld(bt + 2 * NNC + ((size_t)b * N + c) * C + f);
+            if (jt && K == 50) xbc += Vec<VW>::ld(bt + 8 * NNC + ((size_t)c * N + b) * C + f);
+            V g23 = Vec<VW>::zero(), g24 = g23, g45 = g23;
+            float rc = 0.f, qc = 0.f, dgc = 0.f;
+            if (K == 50) {
+                g23 = GCF(23, b, c, f), g24 = GCF(24, b, c, f), g45 = GCF(45, b, c, f);
+                rc = r[c], qc = q[c], dgc = dg[c];
+            }
+#pragma unroll
+            for (int m = 0; m < AB; ++m) {
+                const int a = a0 + m;
+                const float *sr = srow + (size_t)m * 4 * NC + (size_t)c * C + f;
+                V v = xab[m] + Vec<VW>::ld(sr + 0 * NC) + xbc;
+                if (K == 50) {
+                    v += g11[m] * rc + g12[m] * qc + g41[m] * dgc;
+                    v += Vec<VW>::ld(sr + 1 * NC) * rb + Vec<VW>::ld(sr + 2 * NC) * qb + Vec<VW>::ld(sr + 3 * NC) * dgb;
+                    v += g23 * ra[m] + g24 * qa[m] + g45 * dga[m];
+                    if (b == c) v += zbc[m];
+                    if (a == c) v += zac[m];
+                    if (a == b) v += Vec<VW>::ld(bt + 5 * NNC + ((size_t)c * N + (a < N ? a : N - 1)) * C + f);
+                    if (a == b && b == c) v += u50;
+                }
+                if (a < N) {
+                    float *out = dP + ((g * N + a) * N + b) * (size_t)N * C + (size_t)c * C + f;
+                    if (accumulate) v += Vec<VW>::ld(out);
+                    Vec<VW>::st(out, v);
+                }
+            }
         }
     }
 #undef GCF
@@ -886,9 +939,9 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     const bool vec = C % 4 == 0 && (((uintptr_t)G | (uintptr_t)dP | (uintptr_t)w.tab | (uintptr_t)w.sc) & 15) == 0;
     GF_LAUNCH(ctx, "fam_adj", fam_adj, dim3(batch), dim3(64), 0, A, w.adjs, N);
     GF_LAUNCH(ctx, "fam_bwd_scalars", fam_bwd_scalars<K>, dim3(batch * 5), dim3(256), 0, G, A, w.sc, N, C);
-    // (measured at cfg5: the 16-byte variants of the two kernels below are SLOWER -- with four channels per thread only
-    //  two columns fit in registers, the shared (i,z) operands are re-read three times as often and the kernels are
-    //  L2-bound -- so they keep one channel per thread; forward benefits and uses the vector path)
+    // (measured at cfg5: the 16-byte variant of the TABLES kernel is slower -- with four channels per thread only two columns fit
+    //  in registers and the shared (i,z) operands are re-read three times as often -- so it keeps one channel per thread, two rows
+    //  x six columns; the rows kernel below takes 16-byte lanes)
     const bool vec_bt = false;
     // LDS-staged tables (every G row read once): C % 4 == 0, the staged slices of a row fit 96 KB per channel window
     int cwin = 0;
@@ -913,22 +966,50 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     } else if (vec && vec_bt) {
         const int njb = (N + 1) / 2;
         const size_t nt = (size_t)batch * N * njb * (C / 4);
-        GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 4>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
+        GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 4, 1>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
                   C, njb, nt);
     } else {
         const int njb = (N + 5) / 6;
-        const size_t nt = (size_t)batch * N * njb * C;
-        GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 1>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
-                  C, njb, nt);
+        const char *e = std::getenv("GF_FAM_BWD_IB");
+        const int ib = e ? std::atoi(e) : ((size_t)batch * ((N + 1) / 2) * njb * C >= 256 * 1024 ? 2 : 1);  // (two rows per thread once the grid fills the part)
+        if (ib == 2) {
+            const size_t nt = (size_t)batch * ((N + 1) / 2) * njb * C;
+            GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 1, 2>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
+                      C, njb, nt);
+        } else if (ib == 4) {
+            const size_t nt = (size_t)batch * ((N + 3) / 4) * njb * C;
+            GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 1, 4>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
+                      C, njb, nt);
+        } else {
+            const size_t nt = (size_t)batch * N * njb * C;
+            GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 1, 1>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
+                      C, njb, nt);
+        }
     }
     const size_t row_lds = sizeof(float) * 4 * (size_t)N * C;
     if (row_lds <= 48 * 1024 && (size_t)batch * N < 0x7fffffffu) {
-        if (vec && vec_bt)
-            GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, 4>), dim3((unsigned)((size_t)batch * N)), dim3(256), row_lds, G,
-                      w.adjs, w.sc, w.tab, dP, N, C, accumulate, cwin > 0 ? 1 : 0);
-        else
-            GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, 1>), dim3((unsigned)((size_t)batch * N)), dim3(256), row_lds, G,
-                      w.adjs, w.sc, w.tab, dP, N, C, accumulate, cwin > 0 ? 1 : 0);
+        // rows a per workgroup (GF_FAM_BWD_AB overrides): two while their staged rows fit 64 KB and the grid still fills the part
+        // (cfg5: 0.30 / 0.25 / 0.28 ms at one / two / four)
+        int ab = (2 * row_lds <= 64 * 1024 && (size_t)batch * ((N + 1) / 2) >= 1024) ? 2 : 1;
+        if (const char *e = std::getenv("GF_FAM_BWD_AB")) ab = std::atoi(e);
+        if (ab != 4 && ab != 2) ab = 1;
+        if ((size_t)ab * row_lds > 64 * 1024) ab = 1;
+        const int jt = cwin > 0 ? 1 : 0;
+        const unsigned nb = (unsigned)((size_t)batch * ((N + ab - 1) / ab));
+#define GF_FAM_ROWS(VW, AB)                                                                                                        \
+    do {                                                                                                                           \
+        st = opt_in_lds(ctx, fam_backward_rows<K, VW, AB>, AB * row_lds);                                                          \
+        if (st != GF_OK) return st;                                                                                                \
+        GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, VW, AB>), dim3(nb), dim3(256), AB * row_lds, G, w.adjs, w.sc, w.tab, dP, N, \
+                  C, accumulate, jt);                                                                                              \
+    } while (0)
+        const char *ev = std::getenv("GF_FAM_ROWS_VW");
+        if (vec && !(ev && ev[0] == '1')) {  // (16-byte lanes: 0.26 -> 0.23 ms at cfg5; GF_FAM_ROWS_VW=1 keeps one channel per thread)
+            if (ab == 4) GF_FAM_ROWS(4, 4); else if (ab == 2) GF_FAM_ROWS(4, 2); else GF_FAM_ROWS(4, 1);
+        } else {
+            if (ab == 4) GF_FAM_ROWS(1, 4); else if (ab == 2) GF_FAM_ROWS(1, 2); else GF_FAM_ROWS(1, 1);
+        }
+#undef GF_FAM_ROWS
     } else {
         GF_LAUNCH(ctx, "fam_backward", fam_backward<K>, dim3(grid_for(np)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, dP, N, C,
                   np, accumulate);
