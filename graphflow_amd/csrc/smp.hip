@@ -413,12 +413,16 @@ __global__ void expand_rowscale(float2 *__restrict__ rowscale, const float2 *__r
 
 // trow[row of (x, e)] = row of (e, x) inside the same node (compact O layout of the fused C = 64 level, smp_level_c64.hip)
 __global__ void build_trow(int *__restrict__ trow, const int *__restrict__ node_s, const long long *__restrict__ node_row,
-                           const short *__restrict__ pi, unsigned char *__restrict__ rowflag) {
+                           const short *__restrict__ pi, unsigned char *__restrict__ rowflag, int *__restrict__ trowf) {
     const int n = blockIdx.x, s = node_s[n];
     const long long r0 = node_row[n];
     for (int i = threadIdx.x; i < s * s; i += blockDim.x) {
-        trow[r0 + i] = (int)(r0 + (long long)(i % s) * s + i / s);
-        rowflag[r0 + i] = pi[r0 + i] >= 0 ? 1 : 0;  // row (a, b) of the S_ab / T6 blocks is written by tables-forward (DevLevel::t_zeros)
+        const int it = (i % s) * s + i / s;
+        const long long t = r0 + it;
+        trow[r0 + i] = (int)t;
+        const bool own = pi[r0 + i] >= 0, tr = pi[r0 + it] >= 0;
+        rowflag[r0 + i] = own ? 1 : 0;  // row (a, b) of the S_ab / T6 blocks is written by tables-forward (DevLevel::t_zeros)
+        if (trowf) trowf[r0 + i] = (t < (1ll << 30)) ? (int)((unsigned)t | (own ? 0x80000000u : 0u) | (tr ? 0x40000000u : 0u)) : -1;
     }
 }
 
@@ -1062,6 +1066,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         }
         if (!s->cfg.physics && C == 64 && h.rows < 0x7fffffffll) {
             st = gf::upload(s, &d.trow, nullptr, (size_t)h.rows);
+            if (st == GF_OK) st = gf::upload(s, &d.trowf, nullptr, (size_t)h.rows);
             if (st != GF_OK) return st;
             st = gf::upload(s, &d.rowflag, nullptr, (size_t)h.rows);
             if (st != GF_OK) return st;
@@ -1115,7 +1120,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (st != GF_OK) return st;
         if (s->lv[l].trow)
             hipLaunchKernelGGL(gf::build_trow, dim3(B.level[l].nNodes), dim3(64), 0, up, s->lv[l].trow, s->lv[l].node_s, s->lv[l].node_row,
-                               s->lv[l].pi, s->lv[l].rowflag);
+                               s->lv[l].pi, s->lv[l].rowflag, s->lv[l].trowf);
     }
     UP(s->x, B.x);
     s->P = nullptr;  // [max ppos][C]: by far the largest buffer of the op-by-op path, taken from the pool only when a level needs it

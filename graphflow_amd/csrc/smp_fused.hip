@@ -88,8 +88,17 @@ __constant__ int c_kperm[18] = {0, 2, 6, 5, 9, 8, 12, 11, 15, 16, 1, 3, 7, 10, 4
 // rows split over four waves paid about ten barriers of prologue/epilogue and was slower in every size class: 3.3 -> 2.6 ms
 // for s <= 16, 0.73 -> 0.54 ms for 16 < s <= 32 at cfg3.)
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef GF_TF_DEPTH2
+#define GF_TF_DEPTH2 0
+#endif
+#ifndef GF_TF_OCC
+#define GF_TF_OCC 4
+#endif
+#ifndef GF_TF_D2NI
+#define GF_TF_D2NI 4
+#endif
 template <int NI, bool ALLOK>  // ALLOK: C is a multiple of 64 -- every lane of every window has channels
-__global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  // (NI = 4 sat at 130 VGPRs: capped to 128 -> 4 waves per SIMD)
+__global__ __launch_bounds__(kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_fwd_w(  // (NI = 4 sat at 130 VGPRs: capped to 128 -> 4 waves per SIMD)
     const float *__restrict__ fprev, const float *__restrict__ rsum,
                                                              float *__restrict__ T, float *__restrict__ Vt,
                                                              float *__restrict__ scal, const long long *__restrict__ pair_src_row,
@@ -121,18 +130,27 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
     constexpr bool allok = ALLOK;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sR = smem;                                              // [N]
-    // the source tensor of every row a (first row, size): in LDS with the maps, so that a row's address chain is LDS reads
-    // only -- fetched per row from global memory they put two dependent round trips in front of every row's loads
-    long long *sSrcRow = reinterpret_cast<long long *>(smem + ((N + 3) & ~3));   // [N]
-    int *sSrcS = reinterpret_cast<int *>(sSrcRow + N);                            // [N]
-    short *sPi = reinterpret_cast<short *>(sSrcS + ((N + 3) & ~3));               // [N][N]
+    // The address chain of a row is LDS reads only, and few of them: per row a the source tensor's descriptor words, per (a, c) the
+    // BYTE offset of column pi_a(c) inside a row of the source (kAbsent -- beyond any source tensor, the buffer load returns 0 --
+    // where pi_a(c) < 0 and in the padding c >= N), rows padded to the class's 4 NI positions so that a lane's NI reads are
+    // unconditional and a constant 16 bytes apart.  (Round 3: the maps were shorts read one at a time behind a lane mask, each waited
+    // for, multiplied and selected before its request went out: ~45 VALU and five LDS round trips per row in front of the loads.)
+    constexpr int ST = 4 * NI;
+    constexpr int kAbsent = 0x40000000;
+    float *sR = smem;                                               // [N]
+    int4 *sRow = reinterpret_cast<int4 *>(smem + ((N + 3) & ~3));   // [N] {address lo, hi, bytes, s_w} of f_{l-1}[src(n, a)]
+    int *sOff = reinterpret_cast<int *>(sRow + N);                  // [N][ST]
     for (int i = tid; i < N; i += kThreads) {
         sR[i] = rsum[pairbase + i];
-        sSrcRow[i] = pair_src_row[pairbase + i];
-        sSrcS[i] = pair_src_s[pairbase + i];
+        const int sw = pair_src_s[pairbase + i];
+        const unsigned long long addr = reinterpret_cast<unsigned long long>(fprev + pair_src_row[pairbase + i] * C);
+        sRow[i] = make_int4((int)(unsigned)addr, (int)(unsigned)(addr >> 32), sw * sw * C * 4, sw);
     }
-    for (int i = tid; i < N * N; i += kThreads) sPi[i] = pi[rowbase + i];
+    for (int i = tid; i < N * ST; i += kThreads) {
+        const int a = i / ST, c = i % ST;
+        const int p = (c < N) ? pi[rowbase + a * N + c] : -1;
+        sOff[i] = p >= 0 ? p * C * 4 : kAbsent;
+    }
     __syncthreads();
     if (b >= N) return;
 
@@ -150,28 +168,28 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
     f4 dgsum = splat(0.f);
     float mx_both = 0.f;  // largest |S_ab| (even c-groups) / |T6| (odd c-groups) this lane has produced
 
-    // Row a of the slab through a buffer descriptor of the source tensor f_{l-1}[src(n, a)] (wave-uniform base, 32-bit lane
-    // offsets): a structurally-zero position gets an out-of-range offset and the hardware returns 0 -- no 64-bit address
-    // arithmetic and no selects in the loop (the kernel is VALU-bound: ~170 instructions per row before, ~60 % of its time).
+    // Row a of the slab through a buffer descriptor of the source tensor f_{l-1}[src(n, a)] (wave-uniform base and row offset,
+    // 32-bit lane offsets): a structurally-zero position gets an out-of-range offset and the hardware returns 0 -- no 64-bit
+    // address arithmetic and no selects in the loop.  Only rows with pi_a(b) >= 0 are ever requested (`present` below), and every
+    // lane requests: no branch, nothing for the compiler to lose count of the memory queue over.
+    const int lane_off = fok ? fld * 4 : kAbsent;        // (lanes without channels -- C % 64 != 0 -- fetch nothing)
+    const int diag_off = (cg < 2) ? lane_off : kAbsent;  // (the diagonal entries are c-groups 0 and 1's)
     auto load_row = [&](int a, f4(&v)[NI], f4 &dg) {
-        const short *map = sPi + a * N;
-        const int pb = map[b];
-        const int sw = __builtin_amdgcn_readfirstlane(sSrcS[a]);
-        const long long srow = sSrcRow[a];
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(srow & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((unsigned)(srow >> 32));
-        const float *src = fprev + (((long long)hi << 32) | lo) * C;
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (size_t)sw * sw * C * sizeof(float));
-        // (only rows with pi_a(b) >= 0 are ever requested -- `present` below; with every lane on a channel the request is
-        //  unconditional: no branch, nothing for the compiler to lose count of the memory queue over)
-        const bool rowok = ALLOK ? true : (pb >= 0 && fok);
-        const int rowoff = (pb * sw * C + fld) * 4;
+        const int4 ri = sRow[a];
+        const int *orow = sOff + a * ST;
+        const int ob = orow[b];
+        int oc[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int pc = (cc[i] >= 0) ? map[cc[i]] : -1;
-            v[i] = buf_ld4(rs, (rowok && pc >= 0) ? rowoff + pc * C * 4 : -1, 0);
-        }
-        const int pd = map[(cg == 0) ? b : a];  // (one unconditional read: pi_a(b) for c-group 0, pi_a(a) for the others)
-        dg = buf_ld4(rs, (rowok && cg < 2 && pd >= 0) ? rowoff + pd * C * 4 : -1, 0);
+        for (int i = 0; i < NI; ++i) oc[i] = orow[cg + PPW * i];
+        const int od = orow[(cg == 0) ? b : a];  // pi_a(b) for c-group 0, pi_a(a) for the others
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ri.x), hi = __builtin_amdgcn_readfirstlane((unsigned)ri.y);
+        const int bytes = __builtin_amdgcn_readfirstlane(ri.z), sw = __builtin_amdgcn_readfirstlane(ri.w);
+        const float *src = reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (size_t)(unsigned)bytes);
+        const int rowoff = __builtin_amdgcn_readfirstlane(ob) * sw;  // row pi_a(b) of the source: pi_a(b) C 4 bytes x s_w
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[i] = buf_ld4(rs, oc[i] + lane_off, rowoff);
+        dg = buf_ld4(rs, od + diag_off, rowoff);
     };
 
     // two row buffers used alternately (the loop is unrolled by two: no register copies between rows)
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
     // Rows (a, b) whose source does not contain vertex b (pi_a(b) < 0) are structurally zero -- about 40 % of them at QM9
     // sizes: they are never loaded or summed, only their two table entries are written as zeros.  `present` is wave-uniform
     // (b is the wave's, a the loop's): bit a = row a has data.  The row of the node's own vertex (a == b) always has.
-    unsigned present = (unsigned)__ballot(lane < N && sPi[lane * N + b] >= 0);
+    unsigned present = (unsigned)__ballot(lane < N && sOff[(lane < N ? lane : 0) * ST + b] != kAbsent);
     present = __builtin_amdgcn_readfirstlane(present);
     if (allok) {
         if (!zeros_kept)  // (the zeros of these rows are already in the buffer, written once for this batch: DevLevel::t_zeros)
@@ -240,6 +258,27 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
             // requests and one store): the compiler counts the queue (vmcnt(N)) instead of draining it -- stores included --
             // at the top of every pair of rows.  (Row order changes the order of the sums over a, not their terms.)
             present &= ~(1u << b);
+            if constexpr (GF_TF_DEPTH2 && NI <= GF_TF_D2NI) {
+                // TWO rows requested ahead (three buffers in rotation; round 3 -- the offset maps above freed the registers): a wave
+                // spent ~2 us per row, the round trip of a gather under load, with one row in flight
+                f4 bufC[NI], dC;
+                int a1 = pop(), a2 = pop();
+                load_row(b, bufA, dA);
+                load_row(a1 >= 0 ? a1 : b, bufB, dB);
+                row_step(b, a2, bufA, dA, bufC, dC, std::true_type{});
+                while (a1 >= 0) {  // (a1 waits in B, a2 in C)
+                    const int a3 = pop();
+                    row_step(a1, a3, bufB, dB, bufA, dA, std::false_type{});
+                    if (a2 < 0) break;
+                    const int a4 = pop();
+                    row_step(a2, a4, bufC, dC, bufB, dB, std::false_type{});
+                    if (a3 < 0) break;
+                    const int a5 = pop();
+                    row_step(a3, a5, bufA, dA, bufC, dC, std::false_type{});
+                    a1 = a4;
+                    a2 = a5;
+                }
+            } else {
             int a = b, an = pop();
             load_row(a, bufA, dA);
             row_step(a, an, bufA, dA, bufB, dB, std::true_type{});
@@ -251,6 +290,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? 4 : 2) void smp_tables_fwd_w(  
                 a = an;
                 an = pop();
                 row_step(a, an, bufA, dA, bufB, dB, std::false_type{});
+            }
             }
         } else {
             int a = pop();
@@ -943,8 +983,7 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     q_lo = (int)(std::lower_bound(h.quad_node.begin(), h.quad_node.end(), n_lo) - h.quad_node.begin());
     q_hi = (int)(std::lower_bound(h.quad_node.begin(), h.quad_node.end(), n_hi) - h.quad_node.begin());
     if (q_hi <= q_lo) return GF_OK;
-    const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + sizeof(long long) * c.smax + sizeof(int) * ((c.smax + 3) & ~3) +
-                       sizeof(short) * (size_t)c.smax * c.smax + 16;
+    const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + 16 * (size_t)c.smax + sizeof(int) * (size_t)c.smax * 4 * NI + 16;
     unsigned *bm = s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr;
     if ((C & 63) == 0)
         GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
@@ -1506,7 +1545,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             return smp_level_fwd_fused_c64(s, l, T, bl, cus < 1 ? 256 : cus);
         }
         if (C == 64 && panels) {
-            st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, ocols == 2 ? d.trow : nullptr);  // weights in LDS
+            st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, ocols == 2 ? d.trow : nullptr, d.trowf);  // weights in LDS
             if (st != GF_OK) return st;
         } else if (gemm_grouped_supported(sp, 3, false, false)) {
             st = gemm_grouped_rows(ctx, false, false, sp, 3, rows);

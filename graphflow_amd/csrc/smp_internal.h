@@ -38,12 +38,13 @@ bool gemm_grouped_supported(const GemmSpec *specs, int n, bool ta, bool tb);
 gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows);
 gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int rows, float *dest, int accumulate);
 // trow != nullptr: compact O / dO layout ([O_loc | U], 2C wide) with the transposed-row gather inside the product (see kernel)
+// trowf (optional): the level's packed table with the presence bits of the S_ab / T6 blocks (DevLevel::trowf)
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                    int rows, const int *trow);
+                                    int rows, const int *trow, const int *trowf = nullptr);
 // the compact-layout products on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip; GF_SMP_SPLIT=0: fp32 MFMA)
 bool smp_split_products(const gf_ctx *ctx);
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                 int rows, const int *trow, int cus);
+                                 int rows, const int *trow, int cus, const int *trowf = nullptr);
 // blkmax: the level's block maxima (gf_smp::blkmax), kept by the producers of T and dO; max_tot / max_tr: of the level's row factors
 gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
                                        int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr);
@@ -101,6 +102,7 @@ struct gf_smp {
         bool t_zeros = false;
         unsigned char *rowflag = nullptr;
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
+        int *trowf = nullptr;  // [rows] trow | bit 31: rowflag of the row | bit 30: rowflag of the transposed row (smp_rowpanel_split)
         float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients)
         long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
         int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr, *gather_items = nullptr;

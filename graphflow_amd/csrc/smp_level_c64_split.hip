@@ -49,11 +49,19 @@ __device__ __forceinline__ void split_pair(float a, float b, float s, h2 *h, h2 
     *l = __builtin_convertvector(r, h2);
 }
 
-template <bool FWD>
+// MASK: `trow` is the level's PACKED table (DevLevel::trowf) -- bits 0..29 the transposed row, bit 31 = the row's S_ab / T6 blocks
+// hold data, bit 30 = those of the transposed row do.  Half of the rows at QM9 sizes are structurally zero in those two blocks
+// (row (a, b) with b outside the field of a's source); the forward kernel then reads such a block from one 128-byte page of zeros
+// that never leaves the caches instead: 1.1 of the 3.3 GB the kernel read per cfg3 step are not fetched.
+__device__ __attribute__((aligned(256))) const float sp_zero_page[64] = {};
+template <bool FWD, bool MASK>
 __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float *__restrict__ A, const float *__restrict__ rs,
                                                                      const float *__restrict__ Wst, float *__restrict__ Out, int rows,
                                                                      const int *__restrict__ trow) {
     constexpr int LDA = FWD ? 256 : 128, LDOUT = FWD ? 128 : 256;
+    auto t_row = [](int t) { return MASK ? (t & 0x3fffffff) : t; };
+    auto t_own = [](int t) { return MASK ? t < 0 : true; };
+    auto t_tr = [](int t) { return MASK ? ((t >> 30) & 1) != 0 : true; };
     extern __shared__ __attribute__((aligned(16))) uint4 sp_smem[];
     uint4 *imgH = sp_smem, *imgL = sp_smem + kSpImg;
     float *winv = reinterpret_cast<float *>(sp_smem + 2 * kSpImg);  // [8] 2^-k of the weight blocks
@@ -112,18 +120,19 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
     };
     // columns [64 blk + 32 lh, +32) of row `li` of panel p, or of the given row (the transposed one).  Rows past the end read the
     // last row instead (unconditional loads: no branch per request); what is computed from them is never stored.
-    auto load_raw_at = [&](Raw &R, int src_row, int blk) {
+    auto load_raw_at = [&](Raw &R, int src_row, int blk, bool present) {
         __builtin_amdgcn_sched_barrier(0);  // (requests stay where the schedule below puts them: hoisted to the top of the panel
                                             //  they would all be live at once)
         asm volatile("" : "+v"(src_row));   // (nor is the address arithmetic on a prefetched row index moved up to its load)
         const float *src = A + (size_t)src_row * LDA + blk * 64 + 32 * lh;
+        if constexpr (MASK && FWD) src = present ? src : sp_zero_page;  // (a select on the address: same requests, same registers)
 #pragma unroll
         for (int q = 0; q < 8; ++q) R.a[q] = *reinterpret_cast<const f4v *>(src + 4 * q);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto load_raw = [&](Raw &R, int p, int blk) {
+    auto load_raw = [&](Raw &R, int p, int blk, bool present) {
         const int row = p * 32 + li;
-        load_raw_at(R, row < rows ? row : rows - 1, blk);
+        load_raw_at(R, row < rows ? row : rows - 1, blk, present);
     };
     // The transposed row of the lane's row of panel p.  Requested a panel ahead of the block request that uses it: a request
     // that waits for its own index waits for everything the wave has in flight before it (loads and stores return in order).
@@ -239,16 +248,15 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         const int pn = p + nwaves;
         const int tcur = tnext;   // the transposed rows of this panel's rows (requested during the previous panel)
         tnext = fetch_trow(pn);
-        (void)tcur;
         const float2 sc = load_scale(p);  // (used after the panel's first products)
         f16v acc0, acc1;
         Spl X, Y, Z;
         float iX, iY, iZ;
         if (FWD) {  // T blocks: 0 S_ab, 1 S_bc, 2 T6, 3 T10; outputs: 0 O_loc, 1 U.  Entry: Ra = S_ab, Rb = S_ab at the transposed rows
             split_blk(Ra, X, iX);
-            load_raw(Ra, p, 1);                      // S_bc
+            load_raw(Ra, p, 1, true);                // S_bc
             split_blk(Rb, Z, iZ);
-            load_raw(Rb, p, 2);                      // T6
+            load_raw(Rb, p, 2, t_own(tcur));         // T6
             clear(acc0, acc1);
             prod(X, iX, 5, acc0, acc1);
             prod(Z, iZ, 7, acc0, acc1);
@@ -259,20 +267,20 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             prod(X, iX * sc.x, 0, acc0, acc1);
             prod(X, iX * sc.y, 2, acc0, acc1);
             prod(Y, iY * sc.x, 1, acc0, acc1);
-            load_raw(Ra, p, 3);                      // T10, once X and Y are dead: with two requests beside them the panel spills,
+            load_raw(Ra, p, 3, true);                // T10, once X and Y are dead: with two requests beside them the panel spills,
                                                      // and a scratch reload waits for the whole memory queue
             split_blk(Rb, Z, iZ);
-            load_raw_at(Rb, tnext, 0);               // S_ab of the next panel at its transposed rows
+            load_raw_at(Rb, t_row(tnext), 0, t_tr(tnext));   // S_ab of the next panel at its transposed rows
             prod(Z, iZ, 3, acc0, acc1);
             split_blk(Ra, Z, iZ);
-            load_raw(Ra, pn, 0);                     // S_ab of the next panel
+            load_raw(Ra, pn, 0, t_own(tnext));       // S_ab of the next panel
             prod(Z, iZ, 4, acc0, acc1);
             store_out(p, 0, acc0, acc1, full);
         } else {    // dO blocks: 0 L, 1 dU; outputs: 0 dS_ab, 1 dS_bc, 2 dT6, 3 dT10.  Entry: Ra = L, Rb = dU
             split_blk(Ra, X, iX);
-            load_raw_at(Ra, tcur, 1);                // dU at the transposed rows
+            load_raw_at(Ra, t_row(tcur), 1, true);    // dU at the transposed rows
             split_blk(Rb, Y, iY);
-            load_raw(Rb, pn, 1);                     // dU of the next panel
+            load_raw(Rb, pn, 1, true);               // dU of the next panel
             clear(acc0, acc1);
             prod(X, iX, 3, acc0, acc1);
             store_out(p, 2, acc0, acc1, full);
@@ -288,16 +296,16 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             prod(X, iX * sc.y, 2, acc0, acc1);
             prod(Y, iY, 5, acc0, acc1);
             split_blk(Ra, Z, iZ);
-            load_raw(Ra, pn, 0);                     // L of the next panel
+            load_raw(Ra, pn, 0, true);               // L of the next panel
             prod(Z, iZ, 7, acc0, acc1);
             store_out(p, 0, acc0, acc1, full);
         }
     };
     Raw R0, R1;
     int p = blockIdx.x * (kSpThreads / 64) + wave;
-    load_raw(R0, p, 0);
-    if (FWD) load_raw_at(R1, tnext, 0);
-    else load_raw(R1, p, 1);
+    load_raw(R0, p, 0, FWD ? t_own(tnext) : true);
+    if (FWD) load_raw_at(R1, t_row(tnext), 0, t_tr(tnext));
+    else load_raw(R1, p, 1, true);
     const int nfull = rows / 32;
     for (; p < nfull; p += nwaves) panel(p, R0, R1, std::true_type{});
     if (p < npanels) panel(p, R0, R1, std::false_type{});  // (the matrix's partial last panel: one wave of the grid)
@@ -551,22 +559,28 @@ bool smp_split_products(const gf_ctx *ctx) {  // (read per call: the parity test
 // level): forward O from T = [S_ab|S_bc|T6|T10], or backward dT from dO.  Every output element is produced by one wave in a
 // fixed order: results do not depend on the grid size.
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                 int rows, const int *trow, int cus) {
+                                 int rows, const int *trow, int cus, const int *trowf) {
     const int per = kSpThreads / 64;
     const int npanels = (rows + 31) / 32;
     const int want = (npanels + per - 1) / per;
     const int grid = want < cus ? want : cus;  // one persistent workgroup per CU (the weight images take 128 KB of LDS)
+    // packed table with the presence bits (see the kernel)
+    const bool mask = trowf && rows < (1 << 30) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
+#define GF_SP_LAUNCH(F, M, name)                                                                                                   \
+    do {                                                                                                                           \
+        gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M>, kSpLds);                                                          \
+        if (st != GF_OK) return st;                                                                                                \
+        GF_LAUNCH(ctx, name, (smp_rowpanel_split<F, M>), dim3((unsigned)grid), dim3(kSpThreads), kSpLds, A, rowscale, Wst, Out, rows, \
+                  M ? trowf : trow);                                                                                               \
+    } while (0)
     if (forward) {
-        gf_status st = opt_in_lds(ctx, smp_rowpanel_split<true>, kSpLds);
-        if (st != GF_OK) return st;
-        GF_LAUNCH(ctx, "smpf_products_fwd", (smp_rowpanel_split<true>), dim3((unsigned)grid), dim3(kSpThreads), kSpLds, A, rowscale, Wst,
-                  Out, rows, trow);
+        if (mask) GF_SP_LAUNCH(true, true, "smpf_products_fwd");
+        else GF_SP_LAUNCH(true, false, "smpf_products_fwd");
     } else {
-        gf_status st = opt_in_lds(ctx, smp_rowpanel_split<false>, kSpLds);
-        if (st != GF_OK) return st;
-        GF_LAUNCH(ctx, "smpf_products_bwd", (smp_rowpanel_split<false>), dim3((unsigned)grid), dim3(kSpThreads), kSpLds, A, rowscale, Wst,
-                  Out, rows, trow);
+        if (mask) GF_SP_LAUNCH(false, true, "smpf_products_bwd");
+        else GF_SP_LAUNCH(false, false, "smpf_products_bwd");
     }
+#undef GF_SP_LAUNCH
     return GF_OK;
 }
 
