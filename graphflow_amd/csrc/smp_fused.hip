@@ -367,25 +367,25 @@ __global__ __launch_bounds__(256) void smp_vectors(const float *__restrict__ T, 
     const auto one = [](int) { return 1.f; };
     for (int i = threadIdx.x; i < s * nl; i += blockDim.x) {
         const int fl = i % nl, x = i / nl;
-        const float *t = T + (rowbase + (size_t)x * s) * (size_t)(T_COLS * C) + 4 * fl;
-        const f4 rs = batched_sum(t + T_SAB * C, (size_t)T_COLS * C, 0, s, one);
-        f4 d8;
-        {  // D8[x] = sum_b P[x,b,b] = sum over the images pi_x(b) of f_{l-1}[w_x][p,p]  (compact table Fdc)
+        const float *t = T + (rowbase + (size_t)x * s) * (size_t)(T_COLS * C) + T_SAB * C + 4 * fl;
+        f4 rs = splat(0.f), d8 = splat(0.f);
+        {  // D8[x] = sum_b P[x,b,b] = sum over the images pi_x(b) of f_{l-1}[w_x][p,p]  (compact table Fdc); the rows (x, b) with
+           // pi_x(b) < 0 are structurally zero in S_ab as well: only the others are read (half of the 0.73 GB block at QM9 sizes)
             const float *fd = Fdc + (size_t)pair_src_pair[pairbase + x] * 2 * C + 4 * fl;
             const short *map = pi + rowbase + (size_t)x * s;
-            d8 = splat(0.f);
             for (int b0 = 0; b0 < s; b0 += 8) {
-                f4 v[8];
+                f4 v[8], u[8];
                 bool ok[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int p = (b0 + j < s) ? map[b0 + j] : -1;
                     ok[j] = p >= 0;
                     v[j] = ld4(fd + (size_t)(ok[j] ? p : 0) * 2 * C);
+                    u[j] = ld4(ok[j] ? t + (size_t)(b0 + j) * (T_COLS * C) : fd);  // (absent: a line the lane has just read)
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (ok[j]) d8 += v[j];
+                    if (ok[j]) d8 += v[j], rs += u[j];
             }
         }
         st4(Vt + (pairbase + x) * 4 * (size_t)C + 0 * C + 4 * fl, rs);
@@ -1653,7 +1653,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     const bool stationary = C == 64 && !env_is("GF_SMP_WGRAD", '0');
     if (stationary) {
         st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg, ocols == 2 ? d.trow : nullptr,
-                                    s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr, d.max_tot, d.max_tr);
+                                    s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr, d.max_tot, d.max_tr, d.trowf);
         if (st != GF_OK) return st;
         used = (size_t)rowg.splits * rowg.n;
     } else {  // other channel counts: the grouped split-K launch (its own ordered reduction) into the stacked image, one "image"
@@ -1720,7 +1720,9 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     }
     // table gradients dT from dO
     if (C == 64 && !env_is("GF_SMP_ROWPANEL", '0')) {
-        st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows, ocols == 2 ? d.trow : nullptr);
+        // (with the consumer gather reading dT, the gradients of the structurally-zero S_ab / T6 rows have no reader: not written)
+        st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows, ocols == 2 ? d.trow : nullptr, d.trowf,
+                                       smp_fused_gather_enabled(s, l));
         if (st != GF_OK) return st;
     } else {
         const long long oC = C, wCC = (long long)CC;

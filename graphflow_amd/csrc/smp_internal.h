@@ -40,20 +40,21 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
 // trow != nullptr: compact O / dO layout ([O_loc | U], 2C wide) with the transposed-row gather inside the product (see kernel)
 // trowf (optional): the level's packed table with the presence bits of the S_ab / T6 blocks (DevLevel::trowf)
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                    int rows, const int *trow, const int *trowf = nullptr);
+                                    int rows, const int *trow, const int *trowf = nullptr, bool skip_zero_grads = false);
 // the compact-layout products on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip; GF_SMP_SPLIT=0: fp32 MFMA)
 bool smp_split_products(const gf_ctx *ctx);
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                 int rows, const int *trow, int cus, const int *trowf = nullptr);
+                                 int rows, const int *trow, int cus, const int *trowf = nullptr, bool skip_zero_grads = false);
 // blkmax: the level's block maxima (gf_smp::blkmax), kept by the producers of T and dO; max_tot / max_tr: of the level's row factors
 gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
-                                       int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr);
+                                       int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr,
+                                       const int *trowf = nullptr);
 gf_status splitk_fold(gf_ctx *ctx, const float *part, float *dest, size_t total, int splits, int accumulate);
 gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst);
 // the same product, partial images only (fold == caller's): `part` receives out->splits images of 8 * 64 * 64 floats
 gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
                                  size_t part_floats, FoldGroup *out, const int *trow, const unsigned *blkmax = nullptr,
-                                 float max_tot = 0.f, float max_tr = 0.f);
+                                 float max_tot = 0.f, float max_tr = 0.f, const int *trowf = nullptr);
 }
 
 namespace gf {

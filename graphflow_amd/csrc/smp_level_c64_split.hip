@@ -54,10 +54,16 @@ __device__ __forceinline__ void split_pair(float a, float b, float s, h2 *h, h2 
 // (row (a, b) with b outside the field of a's source); the forward kernel then reads such a block from one 128-byte page of zeros
 // that never leaves the caches instead: 1.1 of the 3.3 GB the kernel read per cfg3 step are not fetched.
 __device__ __attribute__((aligned(256))) const float sp_zero_page[64] = {};
+// ... and the backward kernel sends the dS_ab / dT6 blocks of such rows -- gradients of structural zeros, which no consumer reads
+// (the gather of df_{l-1} only visits rows (a, b) with b inside the field of a's source) -- to a scratch area that stays in L2:
+// 0.73 of the 2.9 GB of dT are not written.  288 rows of 64 floats: a panel row r lands on scratch row (r & 255) + its offset
+// inside the panel, spread over the cache channels.
+constexpr int kSpDumpRows = 256 + 32;
+__device__ __attribute__((aligned(256))) float sp_dump[kSpDumpRows * 64];
 template <bool FWD, bool MASK>
 __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float *__restrict__ A, const float *__restrict__ rs,
                                                                      const float *__restrict__ Wst, float *__restrict__ Out, int rows,
-                                                                     const int *__restrict__ trow) {
+                                                                     const int *__restrict__ trow, int store_mask) {
     constexpr int LDA = FWD ? 256 : 128, LDOUT = FWD ? 128 : 256;
     auto t_row = [](int t) { return MASK ? (t & 0x3fffffff) : t; };
     auto t_own = [](int t) { return MASK ? t < 0 : true; };
@@ -218,9 +224,24 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
     // (FULL: a panel wholly inside the matrix -- unconditional stores.  A conditional store or load anywhere in the panel loop
     //  makes the compiler give up counting the memory queue at the join: it then waits for vmcnt(0), requests just issued included,
     //  before every split.  The one partial panel of the matrix runs a second copy of the panel code.)
-    auto store_out = [&](int p, int o, const f16v &acc0, const f16v &acc1, auto full) {
+    auto store_out = [&](int p, int o, const f16v &acc0, const f16v &acc1, auto full, unsigned rowbits = 0xffffffffu) {
         const int r0 = p * 32;
         float *out = Out + (size_t)(r0 + 4 * lh) * LDOUT + o * 64 + li;
+        if constexpr (MASK && !FWD && decltype(full)::value) {
+            if (rowbits != 0xffffffffu) {  // (uniform; the blocks without structural zeros pass all ones)
+                // rows without data go to the scratch rows: a select on the address, every store is issued
+                const unsigned mine = rowbits >> (4 * lh);
+                float *dump = sp_dump + (size_t)((r0 & 255) + 4 * lh) * 64 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    float *dst = ((mine >> rr) & 1u) ? out + (size_t)rr * LDOUT : dump + rr * 64;
+                    dst[0] = acc0[r];
+                    dst[32] = acc1[r];
+                }
+                return;
+            }
+        }
         if constexpr (decltype(full)::value) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -281,9 +302,12 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             load_raw_at(Ra, t_row(tcur), 1, true);    // dU at the transposed rows
             split_blk(Rb, Y, iY);
             load_raw(Rb, pn, 1, true);               // dU of the next panel
+            // (rows whose S_ab / T6 blocks are structural zeros: bit i = row i of the panel has data; both lane halves hold the row's
+            //  entry, the low word of the ballot is the panel's)
+            const unsigned rowbits = (MASK && store_mask) ? (unsigned)__ballot(t_own(tcur)) : 0xffffffffu;
             clear(acc0, acc1);
             prod(X, iX, 3, acc0, acc1);
-            store_out(p, 2, acc0, acc1, full);
+            store_out(p, 2, acc0, acc1, full, rowbits);
             clear(acc0, acc1);
             prod(X, iX, 4, acc0, acc1);
             store_out(p, 3, acc0, acc1, full);
@@ -298,7 +322,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             split_blk(Ra, Z, iZ);
             load_raw(Ra, pn, 0, true);               // L of the next panel
             prod(Z, iZ, 7, acc0, acc1);
-            store_out(p, 0, acc0, acc1, full);
+            store_out(p, 0, acc0, acc1, full, rowbits);
         }
     };
     Raw R0, R1;
@@ -349,7 +373,8 @@ __constant__ int c_ws_bblk[8] = {1, 1, 2, 0, 0, 3, 3, 4};  // tot L, tot L, tr L
 __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__restrict__ T, const float *__restrict__ dO,
                                                                   const float *__restrict__ rs, int rows, int kchunk,
                                                                   float *__restrict__ part, const int *__restrict__ trow,
-                                                                  const unsigned *__restrict__ blkmax, float max_tot, float max_tr) {
+                                                                  const unsigned *__restrict__ blkmax, float max_tot, float max_tr,
+                                                                  int packed) {  // != 0: trow is the packed table (see smp_rowpanel_split)
     extern __shared__ __attribute__((aligned(16))) unsigned ws_smem[];  // stage s: A h | A l | B h | B l
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -402,6 +427,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
         float f0[NB], f1[NB];  // the two rows' factor (tot for the tot L copy, tr for the tr L copy, else unused)
     };
     const bool has_b1 = wave < 2;
+    const bool zblk = ((wave >> 1) & 1) == 0;  // the wave stages S_ab (waves 0, 1) or T6 (4, 5)
     const int a_quad = 8 * wave + q_lo;
     auto b_blk = [&](int e) { return (wave + 8 * e) >> 1; };
     auto b_quad = [&](int e) { return 8 * ((wave + 8 * e) & 1) + q_lo; };
@@ -424,13 +450,17 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
     // anywhere in the loop the compiler cannot count what is in flight at the join and waits for vmcnt(0) before every split --
     // the whole queue, the requests just issued included (the interval was one HBM round trip for that reason, too).
     auto load_slice = [&](Set &S, int m) {  // the workgroup's m-th slice; calls come with consecutive m
-        const int g0 = ia0, g1 = ia1;
+        // (packed table: bit 31 of a row's entry = its S_ab / T6 blocks hold data; the waves that stage those blocks read the rows
+        //  without from the page of zeros -- 0.73 GB a cfg3 step that is not fetched)
+        const int g0 = packed ? (ia0 & 0x3fffffff) : ia0, g1 = packed ? (ia1 & 0x3fffffff) : ia1;
+        const bool z0 = packed && zblk && ia0 >= 0, z1 = packed && zblk && ia1 >= 0;
         ia0 = ib0, ia1 = ib1;
         fetch_trow(m + 2, ib0, ib1);
         const long long last = kend - 1, kk = K(m) + 2 * pair;
         const int c0 = (int)(kk < last ? kk : last), c1 = (int)(kk + 1 < last ? kk + 1 : last);
-        S.ta.v0 = *reinterpret_cast<const f4v *>(T + (size_t)c0 * 256 + 4 * a_quad);
-        S.ta.v1 = *reinterpret_cast<const f4v *>(T + (size_t)c1 * 256 + 4 * a_quad);
+        const float *t0 = T + (size_t)c0 * 256 + 4 * a_quad, *t1 = T + (size_t)c1 * 256 + 4 * a_quad;
+        S.ta.v0 = *reinterpret_cast<const f4v *>(z0 ? sp_zero_page + 4 * q_lo : t0);
+        S.ta.v1 = *reinterpret_cast<const f4v *>(z1 ? sp_zero_page + 4 * q_lo : t1);
 #pragma unroll
         for (int e = 0; e < NB; ++e) {
             const int blk = b_blk(e);  // (e == 1: 4 on waves 0 and 1, no block on the others)
@@ -559,7 +589,7 @@ bool smp_split_products(const gf_ctx *ctx) {  // (read per call: the parity test
 // level): forward O from T = [S_ab|S_bc|T6|T10], or backward dT from dO.  Every output element is produced by one wave in a
 // fixed order: results do not depend on the grid size.
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                 int rows, const int *trow, int cus, const int *trowf) {
+                                 int rows, const int *trow, int cus, const int *trowf, bool skip_zero_grads) {
     const int per = kSpThreads / 64;
     const int npanels = (rows + 31) / 32;
     const int want = (npanels + per - 1) / per;
@@ -571,7 +601,7 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
         gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M>, kSpLds);                                                          \
         if (st != GF_OK) return st;                                                                                                \
         GF_LAUNCH(ctx, name, (smp_rowpanel_split<F, M>), dim3((unsigned)grid), dim3(kSpThreads), kSpLds, A, rowscale, Wst, Out, rows, \
-                  M ? trowf : trow);                                                                                               \
+                  M ? trowf : trow, skip_zero_grads ? 1 : 0);                                                                      \
     } while (0)
     if (forward) {
         if (mask) GF_SP_LAUNCH(true, true, "smpf_products_fwd");
@@ -587,11 +617,13 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
 // The eight row block products of a fused level at C = 64 (compact layout) as partial images, split operands: the contract of
 // smp_wgrad_partials_c64 (same row ranges, same image layout, folded by the caller).
 gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
-                                       int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr) {
+                                       int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr,
+                                       const int *trowf) {
     gf_status st = opt_in_lds(ctx, smp_wgrad_split, kWsLds);
     if (st != GF_OK) return st;
+    const bool mask = trowf && rows < (1 << 30) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
     GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_split, dim3((unsigned)splits), dim3(kWsThreads), kWsLds, T, dO, rowscale, rows, kchunk, part,
-              trow, blkmax, max_tot, max_tr);
+              mask ? trowf : trow, blkmax, max_tot, max_tr, mask ? 1 : 0);
     return GF_OK;
 }
 
