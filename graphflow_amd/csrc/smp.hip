@@ -993,6 +993,10 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         UP(d.node_center, h.node_center);
         UP(d.mol_order, h.mol_order);
         UP(d.gather_items, h.gather_items);
+        if (l >= 1 && !s->cfg.physics) {
+            st = gf::upload(s, &d.tf_recs, nullptr, (size_t)h.nNodes * 2);
+            if (st != GF_OK) return st;
+        }
         st = gf::upload(s, &d.node_row, &h.node_row[0], h.node_row.size());
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.node_pair, &h.node_pair[0], h.node_pair.size());
@@ -1115,6 +1119,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         hipLaunchKernelGGL(gf::expand_rowscale, dim3(B.level[l].nNodes), dim3(64), 0, up, reinterpret_cast<float2 *>(s->lv[l].rowscale),
                            reinterpret_cast<const float2 *>(s->lv[l].node_scale), s->lv[l].node_s, s->lv[l].node_row);
         st = gf::smp_build_gather_records(s, l, up);
+        if (st != GF_OK) return st;
+        st = gf::smp_build_tf_records(s, l, up);
         if (st != GF_OK) return st;
         st = gf::smp_fwd_fused_build_tables(s, l, up);
         if (st != GF_OK) return st;

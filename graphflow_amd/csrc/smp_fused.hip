@@ -103,10 +103,8 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_
                                                              float *__restrict__ T, float *__restrict__ Vt,
                                                              float *__restrict__ scal, const long long *__restrict__ pair_src_row,
                                                              const int *__restrict__ pair_src_s, const short *__restrict__ pi,
-                                                             const int *__restrict__ quad_node, const int *__restrict__ quad_b0,
-                                                             const int *__restrict__ node_s, const long long *__restrict__ node_row,
-                                                             const long long *__restrict__ node_pair, int quad_base, int C, int nwin,
-                                                             const int *__restrict__ quad_order,
+                                                             const int4 *__restrict__ recs,  // two per node, in launch order (build_tf_records)
+                                                             int C, int nwin,
                                                              unsigned *__restrict__ blkmax,    // [4] maxima of T's blocks, or null
                                                              int zeros_kept) {  // != 0: the structurally-zero rows (a, b) hold their zeros
     constexpr int LPC = 16, PPW = 4;
@@ -120,10 +118,14 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_
         const unsigned nb = gridDim.x, qq = nb / 8, r = nb % 8, x = blockIdx.x % 8;
         tile = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + blockIdx.x / 8;
     }
-    const int q = quad_order[quad_base + (int)(tile / nwin)], win = (int)(tile % nwin);
-    const int n = quad_node[q];
-    const int N = node_s[n], b = quad_b0[q] + wave;
-    const size_t rowbase = (size_t)node_row[n], pairbase = (size_t)node_pair[n];
+    // ONE workgroup per node (round 3; it was one per four b): measured with every row but a wave's own skipped, two thirds of the
+    // kernel's time were the workgroup's fixed costs -- three dependent table reads to find the node, the staging of its maps, the
+    // barrier -- paid s / 4 times per node.  The node's record is one 32-byte read, the maps are staged once, and each wave walks
+    // b = wave, wave + 4, ... on its own.
+    const int win = (int)(tile % nwin);
+    const int4 r0 = recs[2 * (tile / nwin)], r1 = recs[2 * (tile / nwin) + 1];
+    const int N = r0.y;
+    const size_t rowbase = ((size_t)(unsigned)r1.y << 32) | (unsigned)r1.x, pairbase = ((size_t)(unsigned)r1.w << 32) | (unsigned)r1.z;
     const int f = win * 64 + 4 * fl;
     const bool fok = f < C;
     const int fld = fok ? f : 0;
@@ -152,7 +154,6 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_
         sOff[i] = p >= 0 ? p * C * 4 : kAbsent;
     }
     __syncthreads();
-    if (b >= N) return;
 
     float rc[NI];
     int cc[NI];
@@ -162,11 +163,13 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_
         cc[i] = (c < N) ? c : -1;
         rc[i] = (c < N && fok) ? sR[c] : 0.f;
     }
+    float mx_both = 0.f;  // largest |S_ab| (even c-groups) / |T6| (odd c-groups) this lane has produced
+    float mx_sbc = 0.f, mx_t10 = 0.f;
+    for (int b = wave; b < N; b += kThreads / 64) {
     f4 sbc[NI], t10[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) sbc[i] = t10[i] = splat(0.f);
     f4 dgsum = splat(0.f);
-    float mx_both = 0.f;  // largest |S_ab| (even c-groups) / |T6| (odd c-groups) this lane has produced
 
     // Row a of the slab through a buffer descriptor of the source tensor f_{l-1}[src(n, a)] (wave-uniform base and row offset,
     // 32-bit lane offsets): a structurally-zero position gets an out-of-range offset and the hardware returns 0 -- no 64-bit
@@ -330,13 +333,13 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_
         st4(sc + 0 * C, cs);
         st4(sc + 2 * C, dgsum);
     }
-    if (blkmax) {  // (uniform)
-        float mx_sbc = 0.f, mx_t10 = 0.f;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            mx_sbc = amax4(sbc[i], mx_sbc);  // (positions past the node hold zeros)
-            mx_t10 = amax4(t10[i], mx_t10);
-        }
+    for (int i = 0; i < NI; ++i) {
+        mx_sbc = amax4(sbc[i], mx_sbc);  // (positions past the node hold zeros)
+        mx_t10 = amax4(t10[i], mx_t10);
+    }
+    }  // b
+    if (blkmax) {  // (uniform; once per wave, over all its b)
         const unsigned rb = row16_max(__float_as_uint(mx_both)), rsb = row16_max(__float_as_uint(mx_sbc)), rt = row16_max(__float_as_uint(mx_t10));
         auto at = [](unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); };
         auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
@@ -977,22 +980,21 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     const gf_smp::DevLevel &d = s->lv[l];
     const gfsmp::LevelLayout &h = s->lay.level[l];
     const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
-    // quads of the class: nodes are sorted by size, so the class is a contiguous quad range
+    // nodes of the class: nodes are sorted by size, so the class is a contiguous node range -- and the same range of positions in
+    // the level's (class, molecule) order, which is the order of the records (build_tf_records)
     const int n_lo = h.pair_node[(size_t)c.lo], n_hi = (c.hi < (long long)h.pairs) ? h.pair_node[(size_t)c.hi] : h.nNodes;
-    int q_lo = 0, q_hi = (int)h.quad_node.size();
-    q_lo = (int)(std::lower_bound(h.quad_node.begin(), h.quad_node.end(), n_lo) - h.quad_node.begin());
-    q_hi = (int)(std::lower_bound(h.quad_node.begin(), h.quad_node.end(), n_hi) - h.quad_node.begin());
-    if (q_hi <= q_lo) return GF_OK;
+    if (n_hi <= n_lo) return GF_OK;
     const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + 16 * (size_t)c.smax + sizeof(int) * (size_t)c.smax * 4 * NI + 16;
     unsigned *bm = s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr;
+    const int flags = ((d.t_zeros && (C & 63) == 0) ? 1 : 0);
     if ((C & 63) == 0)
-        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
-                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
-                  d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order, bm, (d.t_zeros && (C & 63) == 0) ? 1 : 0);
+        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3(kThreads), lds,
+                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin, bm,
+                  flags);
     else
-        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, false>), dim3((unsigned)((q_hi - q_lo) * nwin)), dim3(kThreads), lds,
-                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.quad_node, d.quad_b0, d.node_s,
-                  d.node_row, d.node_pair, q_lo, C, nwin, d.quad_order, bm, (d.t_zeros && (C & 63) == 0) ? 1 : 0);
+        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, false>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3(kThreads), lds,
+                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin, bm,
+                  flags);
     return GF_OK;
 }
 
@@ -1937,6 +1939,28 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
 
 // per-batch tables of smp_bwd_gather_v2, built on the device at prepare time on the handle's upload stream (behind the uploads
 // of the consumer lists they are derived from)
+// records of tables-forward: two int4 per node, in the level's (size class, molecule) order (mol_order):
+//   {node, s, 0, 0}  {first row lo, hi, first pair lo, hi}
+__global__ void build_tf_records(const int *__restrict__ mol_order, const int *__restrict__ node_s, const long long *__restrict__ node_row,
+                                 const long long *__restrict__ node_pair, int4 *__restrict__ recs, int nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nodes) return;
+    const int n = mol_order[i];
+    const long long r = node_row[n], p = node_pair[n];
+    recs[2 * i] = make_int4(n, node_s[n], 0, 0);
+    recs[2 * i + 1] = make_int4((int)(unsigned)(r & 0xffffffffll), (int)(r >> 32), (int)(unsigned)(p & 0xffffffffll), (int)(p >> 32));
+}
+
+gf_status smp_build_tf_records(gf_smp *s, int l, hipStream_t stream) {
+    gf_smp::DevLevel &d = s->lv[l];
+    const int nodes = s->lay.level[l].nNodes;
+    if (!d.tf_recs || nodes == 0) return GF_OK;
+    hipLaunchKernelGGL(build_tf_records, dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0, stream, d.mol_order, d.node_s, d.node_row,
+                       d.node_pair, d.tf_recs, nodes);
+    GF_LAUNCH_CHECK(s->ctx, "build_tf_records");
+    return GF_OK;
+}
+
 gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream) {
     gf_smp::DevLevel &d = s->lv[l];
     const gf_smp::DevLevel &pv = s->lv[l - 1];

@@ -103,6 +103,7 @@ struct gf_smp {
         bool t_zeros = false;
         unsigned char *rowflag = nullptr;
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
+        int4 *tf_recs = nullptr;  // [2 nNodes] records of tables-forward in launch order (build_tf_records)
         int *trowf = nullptr;  // [rows] trow | bit 31: rowflag of the row | bit 30: rowflag of the transposed row (smp_rowpanel_split)
         float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients)
         long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
@@ -175,6 +176,7 @@ gf_status smp_fused_gather_backward(gf_smp *s, int l);
 bool smp_fused_gather_enabled(const gf_smp *s, int l);
 gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
+gf_status smp_build_tf_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_level_fwd_fused_c64(gf_smp *s, int l, const float *T, const float *bias, int cus);
 gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias);
