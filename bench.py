@@ -235,16 +235,22 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
     # ... and then the three product kernels run on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip): 3 MFMA
     # flops of a 16x faster pipe per algorithmic flop -- they are HBM streams, priced against the HBM roofline
     split = oc == 2 and os.environ.get("GF_SMP_SPLIT", "1") != "0"
+    # rows (a, b) whose S_ab / T6 table blocks are not structural zeros (b inside the field of a's source): at C = 64 the other rows'
+    # blocks are neither written (tables-forward), read (forward products, weight gradients) nor back-propagated (backward products,
+    # gather) -- bytes that need not move are not counted as moved
+    masked = split and fused and os.environ.get("GF_SMP_MASK_ZEROS", "1") != "0" and os.environ.get("GF_SMP_KEEP_ZEROS", "1") != "0"
+    present = [net.level_present_rows(l) for l in range(L + 1)]
     for l in range(1, L + 1):
         _, R, S = sizes[l]
         _, Rp, _ = sizes[l - 1]
         unit = 2 * R * C * C                                     # one C x C block product over all rows
+        Tb = (2 * R + 2 * present[l]) * C if masked else 4 * R * C   # floats of T (or dT) that move
         if fused:
-            add(kb, "smpf_tables_fwd", 4 * (Rp * C + 4 * R * C))        # gather f_{l-1} (cached), write 4 tables
+            add(kb, "smpf_tables_fwd", 4 * (Rp * C + Tb))               # gather f_{l-1} (cached), write 4 tables
             add(kb, "smpf_combine_fwd", 4 * (oc * R * C + R * C))       # O in, f_l out
             add(kb, "smpf_combine_bwd", 4 * (2 * R * C + oc * R * C))
             if os.environ.get("GF_SMP_BWD_GATHER", "1") != "0":           # dP evaluated inside the consumer gather
-                add(kb, "smpf_bwd_gather", 4 * (4 * R * C + Rp * C))    # table gradients in (once), df_{l-1} out
+                add(kb, "smpf_bwd_gather", 4 * (Tb + Rp * C))           # table gradients in (once), df_{l-1} out
             else:
                 add(kb, "smpf_tables_bwd", 4 * (4 * R * C + S * C))
                 add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
@@ -253,7 +259,7 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
                      ("smpf_wgrad" if c64 and os.environ.get("GF_SMP_WGRAD", "1") != "0" else "gemm_tn"))
             for k in names:
                 add(kf, k, 8 * unit)
-                add(kb, k, 4 * (4 * R * C + oc * R * C))                 # T (4C) and O / dO per row, each once
+                add(kb, k, 4 * (Tb + oc * R * C))                        # T (4C) and O / dO per row, each once
         else:
             add(kb, "smp_promote_fwd", 4 * (Rp * C + S * C))
             add(kb, "r18_fwd_slab", 4 * (S * C + 10 * R * C))
@@ -266,7 +272,7 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
                 add(kb, k, 4 * (18 * R * C + R * C))
     step_bytes = sum(kb.values())
     step_flops = sum(kf.values())
-    work = {"levels": [{"nodes": n, "rows_sum_s2": r, "ppos_sum_s3": s} for (n, r, s) in sizes],
+    work = {"levels": [{"nodes": n, "rows_sum_s2": r, "ppos_sum_s3": s, "rows_with_data": p} for (n, r, s), p in zip(sizes, present)],
             "algorithmic_GB_per_step": round(step_bytes / 1e9, 2), "gemm_GFLOP_per_step": round(step_flops / 1e9, 1)}
 
     def finish(timers, ms_per_step, steps):

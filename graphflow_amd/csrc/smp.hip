@@ -1567,5 +1567,13 @@ gf_status gf_smp_level_sizes(const gf_smp *s, int level, long long *nodes, long 
     if (ppos) *ppos = h.ppos;
     return GF_OK;
 }
+long long gf_smp_level_present_rows(const gf_smp *s, int level) {
+    if (!s || !s->prepared || level < 0 || level > s->cfg.nLevels) return -1;
+    const gfsmp::LevelLayout &h = s->lay.level[level];
+    if (level == 0 || h.pi.size() != (size_t)h.rows) return h.rows;
+    long long n = 0;
+    for (size_t i = 0; i < h.pi.size(); ++i) n += h.pi[i] >= 0;
+    return n;
+}
 
 }  // extern "C"

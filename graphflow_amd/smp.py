@@ -185,6 +185,10 @@ class SMPOmega:
         self.ctx.check(self.lib.gf_smp_level_sizes(self.handle, level, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def level_present_rows(self, level):
+        """rows (a, b) of the level whose slab row is not structurally zero (gf_smp_level_present_rows)"""
+        return int(self.lib.gf_smp_level_present_rows(self.handle, level))
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.gf_smp_destroy(self.handle)

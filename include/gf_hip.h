@@ -319,6 +319,10 @@ int       gf_smp_receptive_field(const gf_smp *smp, int mol, int level, int v, i
 long long gf_smp_read_activation(gf_smp *smp, int mol, int level, int v, float *host_out, size_t capacity);
 long long gf_smp_read_reduced_adjacency(gf_smp *smp, int mol, int level, int v, float *host_out, size_t capacity);
 gf_status gf_smp_level_sizes(const gf_smp *smp, int level, long long *nodes, long long *rows, long long *ppos);
+/* Rows (a, b) of the level whose promoted slab row is not structurally zero -- vertex b lies inside the receptive field of a's
+ * source (the selection matrices of SMP_omega.h:461-474 have a 1 in that column) -- out of gf_smp_level_sizes' `rows`.  The fused
+ * level neither writes, reads nor back-propagates the other rows' S_ab / T6 table blocks; the bench prices its kernels with it. */
+long long gf_smp_level_present_rows(const gf_smp *smp, int level);
 
 /* RisiContraction_18_dropout inside a physics tower (SMP_sigma_pairgraphs.h:248-265, :632-651): masks[(l-1) * nVertices + gv] =
  * kept-slice bits of the contraction of global vertex gv (molecules back to back) at level l, drawn by the caller in the
