@@ -58,7 +58,12 @@ static gf_status grow(gf_ctx *ctx, void **buf, size_t *have, size_t want, bool p
                     pinned_host ? "pinned host memory" : "device memory", hipGetErrorString(e));
     }
     *have = want;
-    if (!pinned_host && poison_buffers()) GF_HIP_TRY(ctx, hipMemset(*buf, 0xff, want));  // GF_POISON=1 (debug): see poison_buffers()
+    // GF_POISON=1 (debug): see poison_buffers().  On the context's stream: a null-stream hipMemset is not ordered against a
+    // non-blocking stream and landed on top of results now and then
+    if (!pinned_host && poison_buffers()) {
+        GF_HIP_TRY(ctx, hipMemsetAsync(*buf, 0xff, want, ctx->stream));
+        GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return GF_OK;
 }
 

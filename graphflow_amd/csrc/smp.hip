@@ -523,8 +523,13 @@ gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
     }
     if (src && count)
         GF_HIP_TRY(s->ctx, hipMemcpyAsync(p, src, sizeof(T) * count, hipMemcpyHostToDevice, s->upload ? s->upload : s->ctx->stream));
-    else if (gf::poison_buffers())  // GF_POISON=1 (debug): a buffer handed out without contents is filled with NaN bit patterns, so a
-        GF_HIP_TRY(s->ctx, hipMemsetAsync(p, 0xff, bytes, s->upload ? s->upload : s->ctx->stream));  // read-before-write shows
+    else if (gf::poison_buffers()) {  // GF_POISON=1 (debug): a buffer handed out without contents is filled with NaN bit patterns, so a
+        hipStream_t st = s->upload ? s->upload : s->ctx->stream;                    // read-before-write shows
+        GF_HIP_TRY(s->ctx, hipMemsetAsync(p, 0xff, bytes, st));
+        // (finished before anything else is launched: buffers are also taken from the pool in the middle of a pass -- the promoted
+        //  stack of the op-by-op levels -- where the upload stream is not ordered against the pass)
+        GF_HIP_TRY(s->ctx, hipStreamSynchronize(st));
+    }
     *dst = static_cast<T *>(p);
     return GF_OK;
 }

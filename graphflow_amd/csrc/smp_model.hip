@@ -237,7 +237,7 @@ gf_status gf_smp_model_prepare(gf_smp_model *m, int nMol, const int *nVertices1,
             float *bufs[] = {m->feat[0], m->feat[1], m->dfeat[0], m->dfeat[1], m->x, m->dx, m->work};
             const size_t n[] = {fw, fw, fw, fw, xw, xw, gf_head_work_floats(m->nLayers, m->widths.data(), nMol)};
             for (int i = 0; i < 7; ++i)
-                if (bufs[i]) GF_HIP_TRY(ctx, hipMemset(bufs[i], 0xff, n[i] * sizeof(float)));
+                if (bufs[i]) GF_HIP_TRY(ctx, hipMemsetAsync(bufs[i], 0xff, n[i] * sizeof(float), ctx->stream));  // (ordered with the kernels)
         }
         m->cap_mol = nMol;
     }
