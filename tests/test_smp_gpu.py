@@ -1,4 +1,6 @@
 """GPU parity suite for the batched SMP_omega driver (gf_smp_*) vs reference goldens and the fp64 oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -825,6 +827,24 @@ def test_smp_2d_ver6_batchlearn_matches_the_reference(gf):
     scale = np.abs(z["train2d6__params"] - z["train2d6__params0"]).max()
     print("max |param - reference| %.3e, largest parameter change %.3e" % (err.max(), scale))
     assert err.max() <= 1e-3 * scale
+
+
+def test_no_kernel_reads_what_nobody_wrote():
+    """GF_POISON=1 fills every buffer the library hands out without contents (workspace, pooled level buffers, model buffers) with
+    NaN patterns before anything is launched.  The golden, headline, gather and physics parity tests must pass unchanged in such a
+    process: no kernel may read memory nobody wrote -- in particular the dS_ab / dT6 rows of structurally-zero slab rows, which
+    the backward block products no longer write (smp_level_c64_split.hip), must have no reader."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GF_POISON="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "reference_goldens or headline_shape or gather_kernels_agree or folded_backward or batch_equals_sum or physics_and_pairgraphs"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_smp_gpu.py"), os.path.join(here, "test_physics_gpu.py"),
+                        "-q", "-x", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    tail = (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
 
 
 def test_zz_print_margins(gf):
