@@ -411,6 +411,140 @@ __global__ void expand_rowscale(float2 *__restrict__ rowscale, const float2 *__r
     for (int i = threadIdx.x; i < s * s; i += blockDim.x) rowscale[r0 + i] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Level tables on the device (round 3; BatchLayout::device_tables).  What gfsmp::build_batch writes per node in its phase B --
+// the reduced adjacency (SMP_omega.h:556-581: 1 on the diagonal and adj[v1][v2] elsewhere, or the Coulomb entries), its gated row
+// sums and (tot, tr), the selection maps pi (:461-474) -- and per consumer entry in phase D (the inverse maps) are rows-sized:
+// 2.2 of the 6.2 ms of host graph preparation on 32 threads (8 of 14 ms on 8) and 17 MB of the upload per 1024 molecules.  The
+// kernels below build them from the receptive fields (sum-s ints per level), the pair tables and the molecules' adjacency
+// matrices, with the host's summation orders (bit-identical tables: tests/test_smp_gpu.py::test_device_level_tables...).
+// Workgroup per node; wave w builds the maps of the neighbours a = w, w + 4, ...
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_level_rows(const int *__restrict__ node_s, const int *__restrict__ node_mol,
+                                                        const long long *__restrict__ node_row, const long long *__restrict__ node_pair,
+                                                        const int *__restrict__ field, const int *__restrict__ prev_field,
+                                                        const long long *__restrict__ pair_src_pair, const int *__restrict__ pair_src_s,
+                                                        const int *__restrict__ mol_nv, const long long *__restrict__ mol_adj_off,
+                                                        const int *__restrict__ mol_adj, const double *__restrict__ mol_coul,
+                                                        float *__restrict__ adj, float *__restrict__ rsum, float *__restrict__ node_scale,
+                                                        short *__restrict__ pi, int *__restrict__ node_present, int vmax) {
+    extern __shared__ int lr_smem[];
+    const int n = blockIdx.x, s = node_s[n], m = node_mol[n], V = mol_nv[m];
+    const long long r0 = node_row[n], p0 = node_pair[n];
+    int *f = lr_smem;                                             // [s] the node's field
+    float *rs = reinterpret_cast<float *>(lr_smem + s);           // [s] gated row sums
+    float *dg = rs + s;                                           // [s] gated diagonal
+    short *pos = reinterpret_cast<short *>(dg + s);               // [4][vmax] position inside the source's field, -1 outside
+    const int *madj = mol_adj + mol_adj_off[m];
+    const double *mc = mol_coul ? mol_coul + mol_adj_off[m] : nullptr;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < s; i += blockDim.x) f[i] = field[p0 + i];
+    for (int i = tid; i < 4 * vmax; i += blockDim.x) pos[i] = -1;
+    __syncthreads();
+    auto entry = [&](int i, int j) {
+        return mc ? (float)mc[(size_t)f[i] * V + f[j]] : ((f[i] == f[j]) ? 1.f : (float)madj[(size_t)f[i] * V + f[j]]);
+    };
+    for (int idx = tid; idx < s * s; idx += blockDim.x) adj[r0 + idx] = entry(idx / s, idx % s);
+    for (int i = tid; i < s; i += blockDim.x) {  // (entries with A <= 0 are skipped: RisiContraction_18.h:90; j in order, as the host sums)
+        float acc = 0.f;
+        for (int j = 0; j < s; ++j) {
+            const float av = entry(i, j);
+            if (av > 0.f) acc += av;
+        }
+        rs[i] = acc;
+        rsum[p0 + i] = acc;
+        const float d = entry(i, i);
+        dg[i] = d > 0.f ? d : 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f, tr = 0.f;
+        for (int i = 0; i < s; ++i) {
+            tot += rs[i];
+            tr += dg[i];
+        }
+        node_scale[2 * (size_t)n] = tot;
+        node_scale[2 * (size_t)n + 1] = tr;
+    }
+    short *mypos = pos + wave * vmax;
+    unsigned cnt = 0;
+    for (int a0 = 0; a0 < s; a0 += 4) {
+        const int a = a0 + wave;
+        const int *wf = nullptr;
+        int sw = 0;
+        if (a < s) {
+            wf = prev_field + pair_src_pair[p0 + a];
+            sw = pair_src_s[p0 + a];
+            for (int k = lane; k < sw; k += 64) mypos[wf[k]] = (short)k;
+        }
+        __syncthreads();
+        if (a < s)
+            for (int p = lane; p < s; p += 64) {
+                const short k = mypos[f[p]];
+                pi[r0 + (long long)a * s + p] = k;
+                cnt += k >= 0;
+            }
+        __syncthreads();
+        if (a < s)
+            for (int k = lane; k < sw; k += 64) mypos[wf[k]] = -1;
+    }
+    // rows with data of the node (level_table_stats sums them: one hot word for 17,000 workgroups' atomics cost 1 ms per level)
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    __syncthreads();
+    int *wcnt = reinterpret_cast<int *>(pos);
+    if (lane == 0) wcnt[wave] = (int)cnt;
+    __syncthreads();
+    if (tid == 0) node_present[n] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// stats = {max |tot| (float bits), max |tr|, rows with data (two words)} of a level; one workgroup, fixed order
+__global__ __launch_bounds__(1024) void level_table_stats(const float *__restrict__ node_scale, const int *__restrict__ node_present,
+                                                          int nodes, unsigned *__restrict__ stats) {
+    __shared__ float mt[1024], mr[1024];
+    __shared__ unsigned long long sc[1024];
+    float a = 0.f, b = 0.f;
+    unsigned long long c = 0;
+    for (int n = threadIdx.x; n < nodes; n += 1024) {
+        a = fmaxf(a, fabsf(node_scale[2 * (size_t)n]));
+        b = fmaxf(b, fabsf(node_scale[2 * (size_t)n + 1]));
+        c += (unsigned long long)node_present[n];
+    }
+    mt[threadIdx.x] = a, mr[threadIdx.x] = b, sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            mt[threadIdx.x] = fmaxf(mt[threadIdx.x], mt[threadIdx.x + o]);
+            mr[threadIdx.x] = fmaxf(mr[threadIdx.x], mr[threadIdx.x + o]);
+            sc[threadIdx.x] += sc[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[0] = __float_as_uint(mt[0]);
+        stats[1] = __float_as_uint(mr[0]);
+        stats[2] = (unsigned)(sc[0] & 0xffffffffull);
+        stats[3] = (unsigned)(sc[0] >> 32);
+    }
+}
+
+// inv[cons_inv_off[c] + k] = p  where source position k is the image of the consumer's position p (inv prefilled with -1)
+__global__ __launch_bounds__(256) void build_level_inv(const long long *__restrict__ cons_pair, const int *__restrict__ pair_node,
+                                                       const int *__restrict__ node_s, const long long *__restrict__ node_row,
+                                                       const long long *__restrict__ node_pair, const long long *__restrict__ cons_inv_off,
+                                                       const short *__restrict__ pi, short *__restrict__ inv, long long pairs) {
+    const long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= pairs) return;
+    const int lane = threadIdx.x & 63;
+    const long long e = cons_pair[c];
+    const int n = pair_node[e], s = node_s[n], a = (int)(e - node_pair[n]);
+    const short *row = pi + node_row[n] + (long long)a * s;
+    short *iv = inv + cons_inv_off[c];
+    for (int p = lane; p < s; p += 64) {
+        const short k = row[p];
+        if (k >= 0) iv[k] = (short)p;
+    }
+}
+
 // trow[row of (x, e)] = row of (e, x) inside the same node (compact O layout of the fused C = 64 level, smp_level_c64.hip)
 __global__ void build_trow(int *__restrict__ trow, const int *__restrict__ node_s, const long long *__restrict__ node_row,
                            const short *__restrict__ pi, unsigned char *__restrict__ rowflag, int *__restrict__ trowf) {
@@ -979,6 +1113,14 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     }
     gf::release(s);
     const auto tp1 = std::chrono::steady_clock::now();
+    // rows-sized level tables on the device (GF_PREP_DEVICE_TABLES=0: on the host, as rounds 1-2 built them; the parity tests hold
+    // the two against each other bit for bit)
+    {
+        const char *e = std::getenv("GF_PREP_DEVICE_TABLES");
+        s->lay.device_tables = !(e && e[0] == '0');
+    }
+    s->tab_stats = nullptr;
+    s->h_tab_stats.clear();
     gfsmp::build_batch(s->cfg, nMol, nVertices, adj, feature, coulomb, &s->lay);
     const auto tp2 = std::chrono::steady_clock::now();
     const gfsmp::BatchLayout &B = s->lay;
@@ -998,6 +1140,10 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         UP(d.node_center, h.node_center);
         UP(d.mol_order, h.mol_order);
         UP(d.gather_items, h.gather_items);
+        if (B.device_tables) {
+            UP(d.field, h.field);
+            if (!s->cfg.physics) UP(d.node_mol, h.node_mol);   // (the towers upload it below)
+        }
         if (l >= 1 && !s->cfg.physics) {
             st = gf::upload(s, &d.tf_recs, nullptr, (size_t)h.nNodes * 2);
             if (st != GF_OK) return st;
@@ -1025,13 +1171,21 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (l == 0) continue;
         st = gf::upload(s, &d.node_p, &h.node_p[0], h.node_p.size());
         if (st != GF_OK) return st;
+        d.max_tot = d.max_tr = 0.f;
+        if (B.device_tables) {  // built by build_level_rows below
+            st = gf::upload(s, &d.adj, nullptr, (size_t)h.rows);
+            if (st == GF_OK) st = gf::upload(s, &d.rsum, nullptr, (size_t)h.pairs);
+            if (st == GF_OK) st = gf::upload(s, &d.node_scale, nullptr, (size_t)h.nNodes * 2);
+            if (st == GF_OK) st = gf::upload(s, &d.node_present, nullptr, (size_t)h.nNodes);
+            if (st != GF_OK) return st;
+        } else {
         UP(d.adj, h.adj);
         UP(d.rsum, h.rsum);
         UP(d.node_scale, h.rowscale);
-        d.max_tot = d.max_tr = 0.f;
         for (size_t i = 0; i + 1 < h.rowscale.size(); i += 2) {
             d.max_tot = std::max(d.max_tot, std::fabs(h.rowscale[i]));
             d.max_tr = std::max(d.max_tr, std::fabs(h.rowscale[i + 1]));
+        }
         }
         st = gf::upload(s, &d.rowscale, nullptr, (size_t)h.rows * 2);
         if (st != GF_OK) return st;
@@ -1063,8 +1217,14 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.cons_inv_off, h.cons_inv_off.empty() ? nullptr : &h.cons_inv_off[0], h.cons_inv_off.size());
         if (st != GF_OK) return st;
-        UP(d.pi, h.pi);
-        UP(d.inv, h.inv);
+        if (B.device_tables) {
+            st = gf::upload(s, &d.pi, nullptr, (size_t)h.rows);
+            if (st == GF_OK) st = gf::upload(s, &d.inv, nullptr, (size_t)h.inv_count);
+            if (st != GF_OK) return st;
+        } else {
+            UP(d.pi, h.pi);
+            UP(d.inv, h.inv);
+        }
         if (!s->cfg.physics && s->cfg.nContractions == 18 && C % 4 == 0 && s->bwd_gather) {  // fused levels: tables of the gather
             st = gf::upload(s, &d.cons_hdr, nullptr, (size_t)h.pairs * 2);
             if (st != GF_OK) return st;
@@ -1117,6 +1277,43 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             if (w > contract_ws) contract_ws = w;
         }
         contract_ws = std::max(contract_ws, gf::r18_ragged_workspace_bytes((long long)h.rows, (long long)h.pairs, Cp));
+    }
+    if (B.device_tables) {  // the molecules' adjacency matrices, then the rows-sized tables of every level (kernels above)
+        hipStream_t up = s->upload ? s->upload : ctx->stream;
+        const int vmax = B.max_vertices;
+        UP(s->mol_nv, B.mol_nv);
+        UP(s->mol_adj, B.mol_adj);
+        st = gf::upload(s, &s->mol_adj_off, &B.mol_adj_off[0], B.mol_adj_off.size());
+        s->mol_coul = nullptr;
+        if (st == GF_OK && coulomb) st = gf::upload(s, &s->mol_coul, &B.mol_coul[0], B.mol_coul.size());
+        if (st == GF_OK) st = gf::upload(s, &s->tab_stats, nullptr, (size_t)4 * (L + 1));  // per level: max |tot|, max |tr| (float bits), rows with data (64 bit)
+        if (st != GF_OK) return st;
+        GF_HIP_TRY(ctx, hipMemsetAsync(s->tab_stats, 0, sizeof(unsigned) * 4 * (L + 1), up));
+        for (int l = 1; l <= L; ++l) {
+            const gfsmp::LevelLayout &h = B.level[l];
+            gf_smp::DevLevel &d = s->lv[l];
+            const int smax = h.buckets.empty() ? 1 : h.buckets.back().s;
+            const size_t lds = sizeof(int) * (size_t)smax * 3 + sizeof(short) * 4 * (size_t)vmax + 16;
+            if (lds > 64 * 1024) return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare: a receptive field of %d vertices in a molecule of %d "
+                                             "(set GF_PREP_DEVICE_TABLES=0)", smax, vmax);
+            unsigned *stats = s->tab_stats + 4 * l;
+            hipLaunchKernelGGL(gf::build_level_rows, dim3(h.nNodes), dim3(256), lds, up, d.node_s, d.node_mol, d.node_row, d.node_pair, d.field,
+                               s->lv[l - 1].field, d.pair_src_pair, d.pair_src_s, s->mol_nv, s->mol_adj_off, s->mol_adj, s->mol_coul, d.adj,
+                               d.rsum, d.node_scale, d.pi, d.node_present, vmax);
+            GF_LAUNCH_CHECK(ctx, "build_level_rows");
+            hipLaunchKernelGGL(gf::level_table_stats, dim3(1), dim3(1024), 0, up, d.node_scale, d.node_present, h.nNodes, stats);
+            GF_LAUNCH_CHECK(ctx, "level_table_stats");
+            if (h.inv_count) GF_HIP_TRY(ctx, hipMemsetAsync(d.inv, 0xff, sizeof(short) * (size_t)h.inv_count, up));
+            if (h.pairs) {
+                hipLaunchKernelGGL(gf::build_level_inv, dim3((unsigned)((h.pairs + 3) / 4)), dim3(256), 0, up, d.cons_pair, d.pair_node, d.node_s,
+                                   d.node_row, d.node_pair, d.cons_inv_off, d.pi, d.inv, (long long)h.pairs);
+                GF_LAUNCH_CHECK(ctx, "build_level_inv");
+            }
+        }
+        // (the split-operand weight gradients read a level's largest |tot|, |tr| from the statistics words: no read-back, the
+        //  preparing thread does not wait for its uploads)
+        for (int l = 1; l <= L; ++l) s->lv[l].row_max = s->tab_stats + 4 * l;
+        s->h_tab_stats.clear();
     }
     // (the node tables went up on the handle's upload stream: build the transposed-row tables there too, behind them)
     for (int l = 1; l <= L; ++l) {
@@ -1575,6 +1772,21 @@ gf_status gf_smp_level_sizes(const gf_smp *s, int level, long long *nodes, long 
 long long gf_smp_level_present_rows(const gf_smp *s, int level) {
     if (!s || !s->prepared || level < 0 || level > s->cfg.nLevels) return -1;
     const gfsmp::LevelLayout &h = s->lay.level[level];
+    if (level >= 1 && s->lay.device_tables && s->tab_stats) {
+        gf_smp *ms = const_cast<gf_smp *>(s);   // (lazily: the statistics words the table kernels left on the device)
+        if (ms->h_tab_stats.empty()) {
+            ms->h_tab_stats.assign((size_t)4 * (s->cfg.nLevels + 1), 0u);
+            hipStream_t up = s->upload ? s->upload : s->ctx->stream;
+            if (hipMemcpyAsync(&ms->h_tab_stats[0], s->tab_stats, sizeof(unsigned) * ms->h_tab_stats.size(), hipMemcpyDeviceToHost, up) != hipSuccess ||
+                hipStreamSynchronize(up) != hipSuccess) {
+                ms->h_tab_stats.clear();
+                return -1;
+            }
+        }
+        unsigned long long n = 0;
+        std::memcpy(&n, &s->h_tab_stats[(size_t)4 * level + 2], sizeof(n));
+        return (long long)n;
+    }
     if (level == 0 || h.pi.size() != (size_t)h.rows) return h.rows;
     long long n = 0;
     for (size_t i = 0; i < h.pi.size(); ++i) n += h.pi[i] >= 0;

@@ -1655,7 +1655,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     const bool stationary = C == 64 && !env_is("GF_SMP_WGRAD", '0');
     if (stationary) {
         st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg, ocols == 2 ? d.trow : nullptr,
-                                    s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr, d.max_tot, d.max_tr, d.trowf);
+                                    s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr, d.max_tot, d.max_tr, d.trowf, d.row_max);
         if (st != GF_OK) return st;
         used = (size_t)rowg.splits * rowg.n;
     } else {  // other channel counts: the grouped split-K launch (its own ordered reduction) into the stacked image, one "image"

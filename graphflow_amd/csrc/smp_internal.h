@@ -48,13 +48,13 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
 // blkmax: the level's block maxima (gf_smp::blkmax), kept by the producers of T and dO; max_tot / max_tr: of the level's row factors
 gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
                                        int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr,
-                                       const int *trowf = nullptr);
+                                       const int *trowf = nullptr, const unsigned *row_max = nullptr);
 gf_status splitk_fold(gf_ctx *ctx, const float *part, float *dest, size_t total, int splits, int accumulate);
 gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst);
 // the same product, partial images only (fold == caller's): `part` receives out->splits images of 8 * 64 * 64 floats
 gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
                                  size_t part_floats, FoldGroup *out, const int *trow, const unsigned *blkmax = nullptr,
-                                 float max_tot = 0.f, float max_tr = 0.f, const int *trowf = nullptr);
+                                 float max_tot = 0.f, float max_tr = 0.f, const int *trowf = nullptr, const unsigned *row_max = nullptr);
 }
 
 namespace gf {
@@ -106,6 +106,7 @@ struct gf_smp {
         int4 *tf_recs = nullptr;  // [2 nNodes] records of tables-forward in launch order (build_tf_records)
         int *trowf = nullptr;  // [rows] trow | bit 31: rowflag of the row | bit 30: rowflag of the transposed row (smp_rowpanel_split)
         float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients)
+        const unsigned *row_max = nullptr;  // the same two as float bits in device memory when the tables are built there
         long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
         int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr, *gather_items = nullptr;
         float *Fdc = nullptr, *Gc = nullptr, *dGc = nullptr, *dFdc = nullptr;  // [pairs of level l-1][2C] each
@@ -113,6 +114,8 @@ struct gf_smp {
         // physics towers (every level is read out): per-node sums of f, their LeakyReLU, vertex -> node and node -> molecule maps
         float *sh = nullptr, *vf = nullptr;
         int *node_of_vertex = nullptr, *node_mol = nullptr;
+        int *node_present = nullptr;  // [nodes] rows with data of the node (device-built tables)
+        int *field = nullptr;  // [pairs] receptive fields back to back (device-built level tables: smp.hip build_level_rows)
         unsigned *keep_mask = nullptr;  // [nodes] slice masks of RisiContraction_18_dropout for this forward (gf_smp_dropout_masks)
         // fused level (smp_fused.hip): small per-(node,x) / per-node tables and stacked weights
         float *Vt = nullptr, *dVt = nullptr;        // [pairs][4C]  rowsum_a | colsum_b | D8 | D11
@@ -124,6 +127,12 @@ struct gf_smp {
         float *Wst = nullptr, *dWst = nullptr;      // [18][C][C] block-permuted K_l and its gradient
     };
     std::vector<DevLevel> lv;
+    // device-built level tables: the batch's adjacency matrices and the per-level statistics the kernels leave behind
+    int *mol_nv = nullptr, *mol_adj = nullptr;
+    long long *mol_adj_off = nullptr;
+    double *mol_coul = nullptr;
+    unsigned *tab_stats = nullptr;          // [levels + 1][4]: max |tot|, max |tr| (float bits), rows with data (two words)
+    std::vector<unsigned> h_tab_stats;
     // [levels + 1][kBlkCopies][kBlkStride] largest magnitudes (float bits) written this step into T's four blocks (words [0..4) of a
     // copy) and dO's two ([4..6)) of a level, kept by the producing kernels for the split-operand weight gradients
     // (smp_level_c64_split.hip); C = 64 only

@@ -374,7 +374,13 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
                                                                   const float *__restrict__ rs, int rows, int kchunk,
                                                                   float *__restrict__ part, const int *__restrict__ trow,
                                                                   const unsigned *__restrict__ blkmax, float max_tot, float max_tr,
-                                                                  int packed) {  // != 0: trow is the packed table (see smp_rowpanel_split)
+                                                                  int packed,    // != 0: trow is the packed table (see smp_rowpanel_split)
+                                                                  const unsigned *__restrict__ row_max) {  // or null: {max |tot|, max |tr|} as float
+                                                                  // bits, left by the device-side table builder (they replace max_tot / max_tr)
+    if (row_max) {
+        max_tot = __uint_as_float(row_max[0]);
+        max_tr = __uint_as_float(row_max[1]);
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned ws_smem[];  // stage s: A h | A l | B h | B l
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -618,12 +624,12 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
 // smp_wgrad_partials_c64 (same row ranges, same image layout, folded by the caller).
 gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
                                        int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr,
-                                       const int *trowf) {
+                                       const int *trowf, const unsigned *row_max) {
     gf_status st = opt_in_lds(ctx, smp_wgrad_split, kWsLds);
     if (st != GF_OK) return st;
     const bool mask = trowf && rows < (1 << 30) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
     GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_split, dim3((unsigned)splits), dim3(kWsThreads), kWsLds, T, dO, rowscale, rows, kchunk, part,
-              mask ? trowf : trow, blkmax, max_tot, max_tr, mask ? 1 : 0);
+              mask ? trowf : trow, blkmax, max_tot, max_tr, mask ? 1 : 0, row_max);
     return GF_OK;
 }
 

@@ -249,6 +249,18 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
     }
     const int totalV = out->mol_first_vertex[nMol];
     out->x.assign((size_t)totalV * FD, 0.f);
+    if (out->device_tables) {
+        out->mol_nv.assign(nVertices, nVertices + nMol);
+        out->mol_adj_off.resize((size_t)nMol + 1);
+        out->max_vertices = 1;
+        for (int m = 0; m <= nMol; ++m) out->mol_adj_off[(size_t)m] = (int64_t)adj_off[m];
+        for (int m = 0; m < nMol; ++m) out->max_vertices = std::max(out->max_vertices, nVertices[m]);
+        out->mol_adj.assign(adj, adj + adj_off[nMol]);
+        if (coulomb)
+            out->mol_coul.assign(coulomb, coulomb + adj_off[nMol]);
+        else
+            out->mol_coul.clear();
+    }
     parallel_for(nMol, [&](int m) {
         const int V = nVertices[m], v0 = out->mol_first_vertex[m];
         prepare_molecule(cfg, V, adj + adj_off[m], feature + (size_t)v0 * F, &out->mols[m]);
@@ -302,6 +314,10 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         lv.rows = row;
         lv.ppos = pp;
         lv.pairs = pair;
+        if (l == 0) {  // (a level-0 field is the vertex itself: the sources of level 1)
+            lv.field.resize((size_t)totalV);
+            for (int n = 0; n < totalV; ++n) lv.field[(size_t)n] = lv.node_vertex[n];
+        }
         lv.node_center.assign(totalV, 0);
         {  // counting sort of the nodes by (register class of s, molecule); stable, so size-major order survives inside a key
             auto cls = [](int s) { return s <= 1 ? 0 : s <= 4 ? 1 : s <= 8 ? 2 : s <= 16 ? 3 : 4; };
@@ -365,16 +381,18 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         (void)prev;
         (void)pair_src_node;
         // every element of these is written by the node loop below: resize only (no fill pass over ~50 MB per batch)
-        lv.adj.resize((size_t)lv.rows);
-        lv.rsum.resize((size_t)lv.pairs);
-        lv.rowscale.resize((size_t)lv.nNodes * 2);
+        const bool dev = out->device_tables;
+        lv.adj.resize(dev ? 0 : (size_t)lv.rows);
+        lv.rsum.resize(dev ? 0 : (size_t)lv.pairs);
+        lv.rowscale.resize(dev ? 0 : (size_t)lv.nNodes * 2);
+        lv.field.resize((size_t)lv.pairs);
         lv.quad_node.clear();
         lv.quad_b0.clear();
         lv.pair_node.resize((size_t)lv.pairs);
         lv.pair_src_row.resize((size_t)lv.pairs);
         lv.pair_src_pair.resize((size_t)lv.pairs);
         lv.pair_src_s.resize((size_t)lv.pairs);
-        lv.pi.resize((size_t)lv.rows);
+        lv.pi.resize(dev ? 0 : (size_t)lv.rows);
         pair_src_node.assign((size_t)lv.pairs, 0);
         for (int n = 0; n < lv.nNodes; ++n)
             for (int b0 = 0; b0 < lv.node_s[n]; b0 += 4) {
@@ -397,6 +415,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
             }
         }
     });
+    const std::chrono::steady_clock::time_point t_A = std::chrono::steady_clock::now();
     parallel_for(L * totalV, [&](int k) {   // phase B: per node -- reduced adjacency, row sums, selection maps
         const int l = 1 + k / totalV, n = k % totalV;
         LevelLayout &lv = out->level[l];
@@ -408,8 +427,11 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
             const int V = nVertices[m], v0 = out->mol_first_vertex[m];
             const int *madj = adj + adj_off[m];
             const std::vector<int> &field = out->mols[m].phi[l][v];
+            for (int i = 0; i < s; ++i) lv.field[(size_t)lv.node_pair[n] + i] = field[i];
+            const bool dev = out->device_tables;
             // reduced adjacency (:556-581): 1 on the diagonal and adj[v1][v2] elsewhere, or the Coulomb entries
             const double *mcoul = coulomb ? coulomb + adj_off[m] : nullptr;
+            if (!dev) {
             for (int i = 0; i < s; ++i)
                 for (int j = 0; j < s; ++j)
                     lv.adj[(size_t)lv.node_row[n] + (size_t)i * s + j] =
@@ -433,6 +455,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 lv.rowscale[2 * (size_t)n] = tot;      // (expanded to one pair per row on the device: gf_smp_prepare)
                 lv.rowscale[2 * (size_t)n + 1] = tr;
             }
+            }
             int16_t pos[kMaxVertices];  // position of a vertex inside phi_{l-1}(w), -1 outside; reset after each neighbour
             if (V > kMaxVertices) std::abort();  // (gf_smp_prepare rejects such molecules before it gets here)
             for (int i = 0; i < V; ++i) pos[i] = -1;
@@ -446,12 +469,14 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 lv.pair_src_row[(size_t)e] = prev.node_row[src];
                 lv.pair_src_pair[(size_t)e] = prev.node_pair[src];
                 lv.pair_src_s[(size_t)e] = (int)wf.size();
+                if (dev) continue;
                 // selection map: X[i][k] = [phi_l(v)[i] == phi_{l-1}(w)[k]]   (:461-474)
                 for (size_t k = 0; k < wf.size(); ++k) pos[wf[k]] = (int16_t)k;
                 for (int p = 0; p < s; ++p) lv.pi[(size_t)lv.node_row[n] + (size_t)a * s + p] = pos[field[p]];
                 for (size_t k = 0; k < wf.size(); ++k) pos[wf[k]] = -1;
             }
             });
+    const std::chrono::steady_clock::time_point t_B = std::chrono::steady_clock::now();
     parallel_tasks(L, [&](int li) {   // phase C: consumer lists of the backward gather (prefix sums: serial per level)
         const int l = li + 1;
         LevelLayout &lv = out->level[l];
@@ -479,7 +504,11 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 lv.cons_inv_off[(size_t)c] = inv_total;
                 inv_total += prev.node_s[w];
             }
-        lv.inv.assign((size_t)inv_total, (int16_t)-1);
+        lv.inv_count = inv_total;
+        if (out->device_tables)
+            lv.inv.clear();
+        else
+            lv.inv.assign((size_t)inv_total, (int16_t)-1);
         lv.cons_qbase.assign((size_t)prev.nNodes, 0);
         int64_t q = 0;
         for (int w = 0; w < prev.nNodes; ++w) {
@@ -488,6 +517,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         }
         lv.qrec_total = q;
     });
+    const std::chrono::steady_clock::time_point t_C = std::chrono::steady_clock::now();
     parallel_for(L * totalV, [&](int k) {   // phase D: per source node -- its consumers' inverse maps
         const int l = 1 + k / totalV, w = k % totalV;
         LevelLayout &lv = out->level[l];
@@ -503,6 +533,7 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
                 lv.cons_s[(size_t)c] = s;
                 lv.cons_row[(size_t)c] = lv.node_row[n];
                 lv.cons_a[(size_t)c] = a;
+                if (out->device_tables) continue;
                 int16_t *iv = &lv.inv[(size_t)lv.cons_inv_off[(size_t)c]];
                 for (int p = 0; p < s; ++p) {
                     const int16_t k = lv.pi[(size_t)lv.node_row[n] + (size_t)a * s + p];
@@ -512,10 +543,12 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
             });
     if (timing) {
         const std::chrono::steady_clock::time_point t_end = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "build_batch: molecules %.1f ms, node order %.1f ms, level tables %.1f ms\n",
-                     std::chrono::duration<double, std::milli>(t_mol - t_begin).count(),
-                     std::chrono::duration<double, std::milli>(t_order - t_mol).count(),
-                     std::chrono::duration<double, std::milli>(t_end - t_order).count());
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        std::fprintf(stderr, "build_batch: molecules %.1f ms, node order %.1f ms, level tables %.1f ms (sizes / quads %.1f, per node %.1f, "
+                             "consumer lists %.1f, inverse maps %.1f)\n",
+                     ms(t_begin, t_mol), ms(t_mol, t_order), ms(t_order, t_end), ms(t_order, t_A), ms(t_A, t_B), ms(t_B, t_C), ms(t_C, t_end));
     }
 }
 

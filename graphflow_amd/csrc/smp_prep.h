@@ -80,6 +80,11 @@ struct LevelLayout {
     std::vector<Bucket> buckets;
     tvec<int> node_s, node_mol, node_vertex;
     tvec<int64_t> node_row, node_p, node_pair;
+    // The rows-sized tables (adj, pi, inv) and what is summed from adj (rsum, rowscale) are built on the DEVICE when
+    // BatchLayout::device_tables is set (smp.hip: build_level_rows / build_level_inv, from `field`, the pair tables and the
+    // molecules' adjacency matrices); the host then leaves them empty.
+    tvec<int> field;  // [pairs] the receptive fields back to back: field[node_pair[n] + i] = i-th vertex (index inside its molecule)
+    int64_t inv_count = 0;  // elements of inv
     tvec<float> adj;  // [rows] reduced adjacency, node-major [s][s]
     tvec<float> rsum; // [pairs] r[d] = sum_e A+[d][e] (A+ = A where A > 0), pair = node_pair[n] + d
     tvec<float> rowscale;  // [nNodes][2] (tot, tr) of the node's gated adjacency: per-row factors of the level's block GEMMs
@@ -128,6 +133,13 @@ GF_PREP_HD inline int gather_pad(int s) {
 }
 
 struct BatchLayout {
+    bool device_tables = false;  // in: see LevelLayout::field
+    // (device_tables) the batch's inputs in page-locked tables, for the device-side builder: vertex counts, V x V adjacency
+    // (and Coulomb) matrices back to back, their offsets
+    tvec<int> mol_nv, mol_adj;
+    tvec<int64_t> mol_adj_off;
+    tvec<double> mol_coul;
+    int max_vertices = 1;
     int nMol = 0;
     std::vector<int> mol_first_vertex;  // [nMol+1] prefix sum of vertex counts (level-0 node = global vertex id)
     tvec<float> x;                      // [nVertices][F(D+1)] WL features, level-0 input

@@ -829,6 +829,45 @@ def test_smp_2d_ver6_batchlearn_matches_the_reference(gf):
     assert err.max() <= 1e-3 * scale
 
 
+@pytest.mark.parametrize("C,fused,cap,coul", [(64, True, 29, False), (8, False, 6, False), (16, True, 12, True)])
+def test_device_level_tables_equal_the_host_built_ones(gf, monkeypatch, C, fused, cap, coul):
+    """The rows-sized level tables (reduced adjacency, gated row sums, (tot, tr), selection maps, inverse maps) are built on the
+    device from the receptive fields (smp.hip: build_level_rows / build_level_inv; GF_PREP_DEVICE_TABLES=0: by the host, as
+    gfsmp::build_batch's phases B and D write them, SMP_omega.h:461-474, 556-581).  Same batch both ways: reduced adjacencies of
+    every node, the count of rows with data, and -- every kernel being deterministic -- predictions, losses and gradients must
+    be IDENTICAL bit for bit."""
+    from graphflow_amd.smp import SMPOmega
+    L, F, D = 3, 5, 2
+    rng = np.random.default_rng(C)
+    mols = [synthetic_molecule(200 + i)[:2] for i in range(12)]
+    cm = None
+    if coul:   # the use_coulomb variant: dense signed "adjacency" (SMP_omega.h:568-579)
+        cm = [rng.uniform(-1, 2, (len(a), len(a))) for a, _ in mols]
+        cm = [0.5 * (c + c.T) for c in cm]
+    tg = np.array([synthetic_molecule(200 + i)[2] for i in range(12)], dtype=np.float32)
+    params = smp_params(C, F, D, L, 3).astype(np.float32)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GF_PREP_DEVICE_TABLES", mode)
+        net = SMPOmega(L, C, F, D, cap, True)
+        net.set_fused(fused)
+        net.prepare(mols, coulomb=cm)
+        p = dev(params)
+        pred, loss, feat = net.forward(p, dev(tg))
+        g = torch.empty(net.n_params, device="cuda")
+        net.backward(p, g)
+        adjs = [net.reduced_adjacency(m, l, v) for m in (0, 5, 11) for l in range(1, L + 1) for v in range(len(mols[m][0]))]
+        got[mode] = (pred.cpu().numpy().copy(), loss.cpu().numpy().copy(), g.cpu().numpy().copy(), adjs,
+                     [net.level_present_rows(l) for l in range(L + 1)], [net.level_sizes(l) for l in range(L + 1)])
+        net.close()
+    a, b = got["0"], got["1"]
+    assert a[5] == b[5] and a[4] == b[4], (a[4], b[4])
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2]), float(np.abs(a[2] - b[2]).max())
+    assert np.isfinite(a[2]).all() and np.abs(a[2]).max() > 0
+
+
 def test_no_kernel_reads_what_nobody_wrote():
     """GF_POISON=1 fills every buffer the library hands out without contents (workspace, pooled level buffers, model buffers) with
     NaN patterns before anything is launched.  The golden, headline, gather and physics parity tests must pass unchanged in such a
