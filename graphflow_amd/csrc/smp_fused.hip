@@ -92,13 +92,16 @@ __constant__ int c_kperm[18] = {0, 2, 6, 5, 9, 8, 12, 11, 15, 16, 1, 3, 7, 10, 4
 #define GF_TF_DEPTH2 0
 #endif
 #ifndef GF_TF_OCC
-#define GF_TF_OCC 4
+#define GF_TF_OCC 4   // waves per SIMD of the classes s <= 16 (five: the per-node kernel spills, 0.94 -> 1.08 ms)
+#endif
+#ifndef GF_TF_WIDE
+#define GF_TF_WIDE 16   // classes NI >= this run eight waves per node (16: none)
 #endif
 #ifndef GF_TF_D2NI
 #define GF_TF_D2NI 4
 #endif
 template <int NI, bool ALLOK>  // ALLOK: C is a multiple of 64 -- every lane of every window has channels
-__global__ __launch_bounds__(kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_fwd_w(  // (NI = 4 sat at 130 VGPRs: capped to 128 -> 4 waves per SIMD)
+__global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_fwd_w(  // (NI = 4 sat at 130 VGPRs: capped to 128 -> 4 waves per SIMD)
     const float *__restrict__ fprev, const float *__restrict__ rsum,
                                                              float *__restrict__ T, float *__restrict__ Vt,
                                                              float *__restrict__ scal, const long long *__restrict__ pair_src_row,
@@ -142,13 +145,14 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_
     float *sR = smem;                                               // [N]
     int4 *sRow = reinterpret_cast<int4 *>(smem + ((N + 3) & ~3));   // [N] {address lo, hi, bytes, s_w} of f_{l-1}[src(n, a)]
     int *sOff = reinterpret_cast<int *>(sRow + N);                  // [N][ST]
-    for (int i = tid; i < N; i += kThreads) {
+    const int nthreads = (NI >= GF_TF_WIDE ? 2 : 1) * kThreads;   // (eight waves per node in the wide classes)
+    for (int i = tid; i < N; i += nthreads) {
         sR[i] = rsum[pairbase + i];
         const int sw = pair_src_s[pairbase + i];
         const unsigned long long addr = reinterpret_cast<unsigned long long>(fprev + pair_src_row[pairbase + i] * C);
         sRow[i] = make_int4((int)(unsigned)addr, (int)(unsigned)(addr >> 32), sw * sw * C * 4, sw);
     }
-    for (int i = tid; i < N * ST; i += kThreads) {
+    for (int i = tid; i < N * ST; i += nthreads) {
         const int a = i / ST, c = i % ST;
         const int p = (c < N) ? pi[rowbase + a * N + c] : -1;
         sOff[i] = p >= 0 ? p * C * 4 : kAbsent;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_
     }
     float mx_both = 0.f;  // largest |S_ab| (even c-groups) / |T6| (odd c-groups) this lane has produced
     float mx_sbc = 0.f, mx_t10 = 0.f;
-    for (int b = wave; b < N; b += kThreads / 64) {
+    for (int b = wave; b < N; b += nthreads / 64) {
     f4 sbc[NI], t10[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) sbc[i] = t10[i] = splat(0.f);
@@ -988,11 +992,11 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     unsigned *bm = s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr;
     const int flags = ((d.t_zeros && (C & 63) == 0) ? 1 : 0);
     if ((C & 63) == 0)
-        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3(kThreads), lds,
+        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin, bm,
                   flags);
     else
-        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, false>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3(kThreads), lds,
+        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, false>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin, bm,
                   flags);
     return GF_OK;
