@@ -1236,6 +1236,11 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (!s->cfg.physics && C == 64 && h.rows < 0x7fffffffll) {
             st = gf::upload(s, &d.trow, nullptr, (size_t)h.rows);
             if (st == GF_OK) st = gf::upload(s, &d.trowf, nullptr, (size_t)h.rows);
+            if (st == GF_OK) {
+                unsigned char *img = nullptr;
+                st = gf::upload(s, &img, nullptr, gf::smp_split_image_bytes());
+                d.wimg = img;
+            }
             if (st != GF_OK) return st;
             st = gf::upload(s, &d.rowflag, nullptr, (size_t)h.rows);
             if (st != GF_OK) return st;

@@ -1425,6 +1425,22 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K) {
         if (a.n > 0)
             GF_LAUNCH(s->ctx, "smpf_stack_w", stack_weights_all, dim3(64, a.n), dim3(256), 0, a, C, s->cfg.custom_matmul);
     }
+    // ... and the split product kernels' weight images of every level, both directions (the backward pass reuses them)
+    for (int l = 1; l <= L; ++l) s->lv[l].wimg_ready = false;
+    if (C == 64 && smp_compact_o(s) && smp_split_products(s->ctx) && !env_is("GF_SMP_PREBUILT_IMAGES", '0')) {
+        std::vector<const float *> w;
+        std::vector<void *> im;
+        for (int l = 1; l <= L; ++l)
+            if (s->fused && smp_fused_supported(s, l) && s->lv[l].wimg) {
+                w.push_back(s->lv[l].Wst);
+                im.push_back(s->lv[l].wimg);
+                s->lv[l].wimg_ready = true;
+            }
+        if (!w.empty()) {
+            gf_status st = smp_split_build_images(s->ctx, w.data(), im.data(), (int)w.size());
+            if (st != GF_OK) return st;
+        }
+    }
     return GF_OK;
 }
 
@@ -1551,7 +1567,8 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             return smp_level_fwd_fused_c64(s, l, T, bl, cus < 1 ? 256 : cus);
         }
         if (C == 64 && panels) {
-            st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, ocols == 2 ? d.trow : nullptr, d.trowf);  // weights in LDS
+            st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, ocols == 2 ? d.trow : nullptr, d.trowf, false,
+                                           d.wimg_ready ? d.wimg : nullptr);  // weights in LDS
             if (st != GF_OK) return st;
         } else if (gemm_grouped_supported(sp, 3, false, false)) {
             st = gemm_grouped_rows(ctx, false, false, sp, 3, rows);
@@ -1728,7 +1745,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     if (C == 64 && !env_is("GF_SMP_ROWPANEL", '0')) {
         // (with the consumer gather reading dT, the gradients of the structurally-zero S_ab / T6 rows have no reader: not written)
         st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows, ocols == 2 ? d.trow : nullptr, d.trowf,
-                                       smp_fused_gather_enabled(s, l));
+                                       smp_fused_gather_enabled(s, l), d.wimg_ready ? d.wimg : nullptr);
         if (st != GF_OK) return st;
     } else {
         const long long oC = C, wCC = (long long)CC;

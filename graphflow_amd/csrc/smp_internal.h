@@ -40,11 +40,16 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
 // trow != nullptr: compact O / dO layout ([O_loc | U], 2C wide) with the transposed-row gather inside the product (see kernel)
 // trowf (optional): the level's packed table with the presence bits of the S_ab / T6 blocks (DevLevel::trowf)
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                    int rows, const int *trow, const int *trowf = nullptr, bool skip_zero_grads = false);
+                                    int rows, const int *trow, const int *trowf = nullptr, bool skip_zero_grads = false,
+                                    const void *wimg = nullptr);
 // the compact-layout products on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip; GF_SMP_SPLIT=0: fp32 MFMA)
 bool smp_split_products(const gf_ctx *ctx);
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                 int rows, const int *trow, int cus, const int *trowf = nullptr, bool skip_zero_grads = false);
+                                 int rows, const int *trow, int cus, const int *trowf = nullptr, bool skip_zero_grads = false,
+                                 const void *wimg = nullptr);
+// the split kernels' weight images of a level (both directions), built once per forward pass (smp_level_c64_split.hip)
+size_t smp_split_image_bytes();
+gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n);
 // blkmax: the level's block maxima (gf_smp::blkmax), kept by the producers of T and dO; max_tot / max_tr: of the level's row factors
 gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
                                        int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr,
@@ -104,6 +109,8 @@ struct gf_smp {
         unsigned char *rowflag = nullptr;
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
         int4 *tf_recs = nullptr;  // [2 nNodes] records of tables-forward in launch order (build_tf_records)
+        void *wimg = nullptr;  // the split product kernels' weight images of this pass (smp_split_build_images), C = 64
+        bool wimg_ready = false;
         int *trowf = nullptr;  // [rows] trow | bit 31: rowflag of the row | bit 30: rowflag of the transposed row (smp_rowpanel_split)
         float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients)
         const unsigned *row_max = nullptr;  // the same two as float bits in device memory when the tables are built there

@@ -60,24 +60,14 @@ __device__ __attribute__((aligned(256))) const float sp_zero_page[64] = {};
 // inside the panel, spread over the cache channels.
 constexpr int kSpDumpRows = 256 + 32;
 __device__ __attribute__((aligned(256))) float sp_dump[kSpDumpRows * 64];
-template <bool FWD, bool MASK>
-__global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float *__restrict__ A, const float *__restrict__ rs,
-                                                                     const float *__restrict__ Wst, float *__restrict__ Out, int rows,
-                                                                     const int *__restrict__ trow, int store_mask) {
-    constexpr int LDA = FWD ? 256 : 128, LDOUT = FWD ? 128 : 256;
-    auto t_row = [](int t) { return MASK ? (t & 0x3fffffff) : t; };
-    auto t_own = [](int t) { return MASK ? t < 0 : true; };
-    auto t_tr = [](int t) { return MASK ? ((t >> 30) & 1) != 0 : true; };
-    extern __shared__ __attribute__((aligned(16))) uint4 sp_smem[];
-    uint4 *imgH = sp_smem, *imgL = sp_smem + kSpImg;
-    float *winv = reinterpret_cast<float *>(sp_smem + 2 * kSpImg);  // [8] 2^-k of the weight blocks
-    unsigned *wmax = reinterpret_cast<unsigned *>(winv + 8);        // [8]
-    float *facs = winv + 16;                                        // [waves][32]: row factors on their way to the C layout
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6;
-
-    // ---- weight images: B fragment (pos, nh, c) gives lane (n, g) the eight values B[k = 32 g + 8 c + j][32 nh + n], j < 8, where
-    // B = W_pos (forward) or W_pos^T (backward) -- the k order a lane's half row of A supplies (see split_blk)
+// The weight images of one direction: B fragment (pos, nh, c) gives lane (n, g) the eight values B[k = 32 g + 8 c + j][32 nh + n],
+// j < 8, where B = W_pos (forward) or W_pos^T (backward) -- the k order a lane's half row of A supplies (see split_blk) -- as two f16
+// halves at the block's exponent.  imgH / imgL / winv may be LDS (built by the product kernel itself) or global memory (built once
+// per forward pass by smp_split_weight_images and copied by the product kernels: the build is ~30 us of strided reads per
+// workgroup, and six launches per step paid it).  wmax: 8 words of LDS.
+template <bool FWD>
+__device__ __forceinline__ void build_weight_images(const float *__restrict__ Wst, uint4 *imgH, uint4 *imgL, float *winv, unsigned *wmax,
+                                                    int tid) {
     if (tid < 8) wmax[tid] = 0u;
     __syncthreads();
 #pragma unroll
@@ -111,6 +101,51 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         }
         imgH[t] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
         imgL[t] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+}
+
+// images of both directions of up to kSpImgLevels levels in one launch: workgroup (direction, level); layout per (level, direction):
+// imgH [kSpImg] | imgL [kSpImg] | winv (one uint4 pair = 8 floats)
+constexpr int kSpImgLevels = 8;
+constexpr int kSpImgStride = 2 * kSpImg + 2;   // uint4 per (level, direction)
+struct SplitImages {
+    const float *Wst[kSpImgLevels];
+    uint4 *img[kSpImgLevels];   // [2 directions][kSpImgStride]
+};
+__global__ __launch_bounds__(kSpThreads) void smp_split_weight_images(SplitImages a) {
+    __shared__ unsigned wmax[8];
+    uint4 *out = a.img[blockIdx.y] + (size_t)blockIdx.x * kSpImgStride;
+    float *winv = reinterpret_cast<float *>(out + 2 * kSpImg);
+    if (blockIdx.x == 0)
+        build_weight_images<true>(a.Wst[blockIdx.y], out, out + kSpImg, winv, wmax, threadIdx.x);
+    else
+        build_weight_images<false>(a.Wst[blockIdx.y], out, out + kSpImg, winv, wmax, threadIdx.x);
+}
+
+template <bool FWD, bool MASK>
+__global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float *__restrict__ A, const float *__restrict__ rs,
+                                                                     const float *__restrict__ Wst, float *__restrict__ Out, int rows,
+                                                                     const int *__restrict__ trow, int store_mask,
+                                                                     const uint4 *__restrict__ wimg) {  // or null: this direction's
+                                                                     // images, built by smp_split_weight_images
+    constexpr int LDA = FWD ? 256 : 128, LDOUT = FWD ? 128 : 256;
+    auto t_row = [](int t) { return MASK ? (t & 0x3fffffff) : t; };
+    auto t_own = [](int t) { return MASK ? t < 0 : true; };
+    auto t_tr = [](int t) { return MASK ? ((t >> 30) & 1) != 0 : true; };
+    extern __shared__ __attribute__((aligned(16))) uint4 sp_smem[];
+    uint4 *imgH = sp_smem, *imgL = sp_smem + kSpImg;
+    float *winv = reinterpret_cast<float *>(sp_smem + 2 * kSpImg);  // [8] 2^-k of the weight blocks
+    unsigned *wmax = reinterpret_cast<unsigned *>(winv + 8);        // [8]
+    float *facs = winv + 16;                                        // [waves][32]: row factors on their way to the C layout
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6;
+
+    // ---- weight images (see build_weight_images): copied from the pass's prebuilt ones, or built here
+    if (wimg) {
+        for (int t = tid; t < 2 * kSpImg; t += kSpThreads) sp_smem[t] = wimg[t];
+        if (tid < 2) reinterpret_cast<uint4 *>(winv)[tid] = wimg[2 * kSpImg + tid];
+    } else {
+        build_weight_images<FWD>(Wst, imgH, imgL, winv, wmax, tid);
     }
     __syncthreads();
 
@@ -591,11 +626,26 @@ bool smp_split_products(const gf_ctx *ctx) {  // (read per call: the parity test
     return !(e && e[0] == '0');
 }
 
+size_t smp_split_image_bytes() { return 2 * (size_t)kSpImgStride * sizeof(uint4); }
+// the split weight images (both directions) of n levels' stacked weights in one launch; img[i]: smp_split_image_bytes() each
+gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n) {
+    for (int i0 = 0; i0 < n; i0 += kSpImgLevels) {
+        SplitImages a;
+        const int m = n - i0 < kSpImgLevels ? n - i0 : kSpImgLevels;
+        for (int i = 0; i < m; ++i) {
+            a.Wst[i] = Wst[i0 + i];
+            a.img[i] = static_cast<uint4 *>(img[i0 + i]);
+        }
+        GF_LAUNCH(ctx, "smpf_stack_w", smp_split_weight_images, dim3(2, m), dim3(kSpThreads), 0, a);
+    }
+    return GF_OK;
+}
+
 // Row-panel products of a fused SMP level at C = 64, compact layout (O = [O_loc | U]; trow = the transposed-row table of the
 // level): forward O from T = [S_ab|S_bc|T6|T10], or backward dT from dO.  Every output element is produced by one wave in a
 // fixed order: results do not depend on the grid size.
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                 int rows, const int *trow, int cus, const int *trowf, bool skip_zero_grads) {
+                                 int rows, const int *trow, int cus, const int *trowf, bool skip_zero_grads, const void *wimg) {
     const int per = kSpThreads / 64;
     const int npanels = (rows + 31) / 32;
     const int want = (npanels + per - 1) / per;
@@ -607,7 +657,8 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
         gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M>, kSpLds);                                                          \
         if (st != GF_OK) return st;                                                                                                \
         GF_LAUNCH(ctx, name, (smp_rowpanel_split<F, M>), dim3((unsigned)grid), dim3(kSpThreads), kSpLds, A, rowscale, Wst, Out, rows, \
-                  M ? trowf : trow, skip_zero_grads ? 1 : 0);                                                                      \
+                  M ? trowf : trow, skip_zero_grads ? 1 : 0,                                                                       \
+                  wimg ? static_cast<const uint4 *>(wimg) + (F ? 0 : kSpImgStride) : (const uint4 *)nullptr);                      \
     } while (0)
     if (forward) {
         if (mask) GF_SP_LAUNCH(true, true, "smpf_products_fwd");
