@@ -293,6 +293,19 @@ __global__ __launch_bounds__(256) void readout_nodes_v(const float *__restrict__
     }
 }
 
+// the same sums from the row-panel partials the top level's combine-forward left behind (C = 64): thread per (node, channel),
+// the node's panels in order
+__global__ __launch_bounds__(256) void readout_nodes_panels(const float *__restrict__ psum, const int *__restrict__ node_panel, int nodes,
+                                                            int npanels, float *__restrict__ sh, float *__restrict__ vf) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+    if (n >= nodes) return;
+    const int p0 = node_panel[n], p1 = (n + 1 < nodes) ? node_panel[n + 1] : npanels;
+    float t = 0.f;
+    for (int p = p0; p < p1; ++p) t += psum[(size_t)p * 64 + c];
+    sh[(size_t)n * 64 + c] = t;
+    vf[(size_t)n * 64 + c] = lrelu(t);
+}
+
 // one workgroup per molecule: g = sum_v vf (SumVectors), y = <g, W> (InnerProduct.h:39-46), loss (SquaredLoss.h:45-53)
 __global__ void readout_molecules(const float *__restrict__ vf, const int *__restrict__ mol_ptr,
                                   const int *__restrict__ mol_nodes, const float *__restrict__ W,
@@ -1246,18 +1259,15 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             if (st != GF_OK) return st;
             if (s->cfg.nContractions == 18 && h.rows * 256 < 0x3fffffffll && !h.buckets.empty() && h.buckets.back().s <= 32) {
                 // row panels of the fused forward level (smp_level_c64_fwd.hip): a node of size s has ceil(s / max(1, 32 / s)) panels
-                std::vector<int> node_panel((size_t)h.nNodes);
-                int np = 0;
-                for (int n = 0; n < h.nNodes; ++n) {
-                    node_panel[(size_t)n] = np;
-                    const int sz = h.node_s[n], gpp = sz >= 32 ? 1 : std::min(8, 32 / sz);
-                    np += (sz + gpp - 1) / gpp;
-                }
+                const int np = h.npanels;   // (page-locked table of the layout: no wait for the copy)
                 d.fwd_npanels = np;
-                UP(d.node_panel, node_panel);
-                GF_HIP_TRY(ctx, hipStreamSynchronize(s->upload ? s->upload : ctx->stream));  // (node_panel is a local)
+                UP(d.node_panel, h.node_panel);
                 st = gf::upload(s, &d.fwd_pan, nullptr, (size_t)np);
                 if (st != GF_OK) return st;
+                if (l == L) {
+                    st = gf::upload(s, &d.psum, nullptr, (size_t)np * 64);
+                    if (st != GF_OK) return st;
+                }
                 st = gf::upload(s, &d.fwd_pan_node, nullptr, (size_t)np);
                 if (st != GF_OK) return st;
                 st = gf::upload(s, &d.fwd_goff, nullptr, (size_t)h.rows);
@@ -1415,6 +1425,7 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)nV * C)), dim3(256), 0, s->lv[0].f,
               (const float *)nullptr, C, (size_t)nV * C);
+    s->lv[L].psum_ready = false;
     if (s->fused) {
         if (s->blkmax) GF_HIP_TRY(ctx, hipMemsetAsync(s->blkmax, 0, sizeof(unsigned) * gf::kBlkCopies * gf::kBlkStride * (size_t)(L + 1), ctx->stream));
         st = gf::smp_fused_stack_all(s, K);
@@ -1467,7 +1478,10 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
         return GF_OK;
     }
     const gfsmp::LevelLayout &top = B.level[L];
-    if (C % 4 == 0 && C <= 1024) {
+    if (C == 64 && s->lv[L].psum_ready) {
+        GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels, dim3((unsigned)((top.nNodes + 3) / 4)), dim3(256), 0, s->lv[L].psum,
+                  s->lv[L].node_panel, top.nNodes, s->lv[L].fwd_npanels, s->sh, s->vf);
+    } else if (C % 4 == 0 && C <= 1024) {
         GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(top.nNodes), dim3(256), 0, s->lv[L].f, s->lv[L].node_s,
                   s->lv[L].node_row, s->sh, s->vf, C);
     } else {

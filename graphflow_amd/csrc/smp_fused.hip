@@ -1592,7 +1592,12 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     }
     if (s->side && !grouped) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
     if (C == 64 && ocols == 2 && d.fwd_pan && (long long)rows * 512 < 0x3fffffffll && !env_is("GF_SMP_COMBINE_PANELS", '0'))
-        return smp_combine_fwd_panels_c64(s, l, O, bl);  // wave per row panel, the adjacency product on the matrix pipe
+    {   // wave per row panel, the adjacency product on the matrix pipe; the top level leaves the readout's partial sums behind
+        float *psum = (l == s->cfg.nLevels && !env_is("GF_SMP_READOUT_PARTIALS", '0')) ? d.psum : nullptr;
+        st = smp_combine_fwd_panels_c64(s, l, O, bl, psum);
+        if (st == GF_OK && psum) s->lv[l].psum_ready = true;
+        return st;
+    }
     {
         const size_t lds = combine_lds<16>(h.buckets.back().s);
         st = opt_in_lds(ctx, smp_combine_fwd<16>, lds);

@@ -109,6 +109,8 @@ struct gf_smp {
         unsigned char *rowflag = nullptr;
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
         int4 *tf_recs = nullptr;  // [2 nNodes] records of tables-forward in launch order (build_tf_records)
+        float *psum = nullptr;     // top level, C = 64: [fwd_npanels][64] column sums of the row panels of f_L (readout)
+        bool psum_ready = false;   // ... written by this forward pass
         void *wimg = nullptr;  // the split product kernels' weight images of this pass (smp_split_build_images), C = 64
         bool wimg_ready = false;
         int *trowf = nullptr;  // [rows] trow | bit 31: rowflag of the row | bit 30: rowflag of the transposed row (smp_rowpanel_split)
@@ -195,7 +197,7 @@ gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_build_tf_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_level_fwd_fused_c64(gf_smp *s, int l, const float *T, const float *bias, int cus);
-gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias);
+gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce

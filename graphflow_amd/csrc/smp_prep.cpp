@@ -394,6 +394,16 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         lv.pair_src_s.resize((size_t)lv.pairs);
         lv.pi.resize(dev ? 0 : (size_t)lv.rows);
         pair_src_node.assign((size_t)lv.pairs, 0);
+        {
+            lv.node_panel.resize((size_t)lv.nNodes);
+            int np = 0;
+            for (int n = 0; n < lv.nNodes; ++n) {
+                lv.node_panel[(size_t)n] = np;
+                const int sz = lv.node_s[n], gpp = sz >= 32 ? 1 : std::min(8, 32 / (sz < 1 ? 1 : sz));
+                np += (sz + gpp - 1) / gpp;
+            }
+            lv.npanels = np;
+        }
         for (int n = 0; n < lv.nNodes; ++n)
             for (int b0 = 0; b0 < lv.node_s[n]; b0 += 4) {
                 lv.quad_node.push_back(n);

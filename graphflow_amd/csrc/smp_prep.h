@@ -83,6 +83,8 @@ struct LevelLayout {
     // The rows-sized tables (adj, pi, inv) and what is summed from adj (rsum, rowscale) are built on the DEVICE when
     // BatchLayout::device_tables is set (smp.hip: build_level_rows / build_level_inv, from `field`, the pair tables and the
     // molecules' adjacency matrices); the host then leaves them empty.
+    tvec<int> node_panel;  // [nNodes] first row panel of the node (combine-forward on row panels, smp_level_c64_fwd.hip)
+    int npanels = 0;       //   a node of size s has ceil(s / gpp) panels of gpp = max(1, min(8, 32 / s)) row groups
     tvec<int> field;  // [pairs] the receptive fields back to back: field[node_pair[n] + i] = i-th vertex (index inside its molecule)
     int64_t inv_count = 0;  // elements of inv
     tvec<float> adj;  // [rows] reduced adjacency, node-major [s][s]
