@@ -50,6 +50,8 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
 // the split kernels' weight images of a level (both directions), built once per forward pass (smp_level_c64_split.hip)
 size_t smp_split_image_bytes();
 gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n);
+gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *prog, const float *const *In, float *const *Out, const int *rows,
+                              const int *pos0, const void *wimg, const char *name);
 // blkmax: the level's block maxima (gf_smp::blkmax), kept by the producers of T and dO; max_tot / max_tr: of the level's row factors
 gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
                                        int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr,

@@ -65,13 +65,13 @@ __device__ __attribute__((aligned(256))) float sp_dump[kSpDumpRows * 64];
 // halves at the block's exponent.  imgH / imgL / winv may be LDS (built by the product kernel itself) or global memory (built once
 // per forward pass by smp_split_weight_images and copied by the product kernels: the build is ~30 us of strided reads per
 // workgroup, and six launches per step paid it).  wmax: 8 words of LDS.
-template <bool FWD>
+template <bool FWD, int NPOS>
 __device__ __forceinline__ void build_weight_images(const float *__restrict__ Wst, uint4 *imgH, uint4 *imgL, float *winv, unsigned *wmax,
                                                     int tid) {
-    if (tid < 8) wmax[tid] = 0u;
+    if (tid < NPOS) wmax[tid] = 0u;
     __syncthreads();
-#pragma unroll
-    for (int pos = 0; pos < 8; ++pos) {
+#pragma unroll 1
+    for (int pos = 0; pos < NPOS; ++pos) {
         unsigned m = 0u;
 #pragma unroll
         for (int i = 0; i < 4096 / kSpThreads; ++i) {
@@ -81,7 +81,7 @@ __device__ __forceinline__ void build_weight_images(const float *__restrict__ Ws
         atomicMax(&wmax[pos], m);
     }
     __syncthreads();
-    for (int t = tid; t < kSpImg; t += kSpThreads) {
+    for (int t = tid; t < NPOS * 512; t += kSpThreads) {
         const int ln = t & 63, c = (t >> 6) & 3, nh = (t >> 8) & 1, pos = t >> 9;
         const int n = 32 * nh + (ln & 31), k0 = 32 * (ln >> 5) + 8 * c;
         float s, inv;
@@ -105,21 +105,25 @@ __device__ __forceinline__ void build_weight_images(const float *__restrict__ Ws
 }
 
 // images of both directions of up to kSpImgLevels levels in one launch: workgroup (direction, level); layout per (level, direction):
-// imgH [kSpImg] | imgL [kSpImg] | winv (one uint4 pair = 8 floats)
+// imgH [kSpAll] | imgL [kSpAll] | winv (kSpPos floats in five uint4) -- ALL eighteen stacked blocks: positions 0..7 are the row products'
+// (smp_rowpanel_split), 8..17 the per-(node,x) / per-node / compact products' (smp_small_split)
 constexpr int kSpImgLevels = 8;
-constexpr int kSpImgStride = 2 * kSpImg + 2;   // uint4 per (level, direction)
+constexpr int kSpPos = 18, kSpAll = kSpPos * 512;
+constexpr int kSpImgStride = 2 * kSpAll + 5;   // uint4 per (level, direction)
 struct SplitImages {
     const float *Wst[kSpImgLevels];
     uint4 *img[kSpImgLevels];   // [2 directions][kSpImgStride]
 };
-__global__ __launch_bounds__(kSpThreads) void smp_split_weight_images(SplitImages a) {
-    __shared__ unsigned wmax[8];
+__global__ __launch_bounds__(kSpThreads) void smp_split_weight_images(SplitImages a) {  // workgroup (direction, level, position)
+    __shared__ unsigned wmax[1];
     uint4 *out = a.img[blockIdx.y] + (size_t)blockIdx.x * kSpImgStride;
-    float *winv = reinterpret_cast<float *>(out + 2 * kSpImg);
+    float *winv = reinterpret_cast<float *>(out + 2 * kSpAll) + blockIdx.z;
+    const float *w = a.Wst[blockIdx.y] + (size_t)blockIdx.z * 4096;
+    uint4 *H = out + blockIdx.z * 512, *L = out + kSpAll + blockIdx.z * 512;
     if (blockIdx.x == 0)
-        build_weight_images<true>(a.Wst[blockIdx.y], out, out + kSpImg, winv, wmax, threadIdx.x);
+        build_weight_images<true, 1>(w, H, L, winv, wmax, threadIdx.x);
     else
-        build_weight_images<false>(a.Wst[blockIdx.y], out, out + kSpImg, winv, wmax, threadIdx.x);
+        build_weight_images<false, 1>(w, H, L, winv, wmax, threadIdx.x);
 }
 
 template <bool FWD, bool MASK>
@@ -142,10 +146,13 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
 
     // ---- weight images (see build_weight_images): copied from the pass's prebuilt ones, or built here
     if (wimg) {
-        for (int t = tid; t < 2 * kSpImg; t += kSpThreads) sp_smem[t] = wimg[t];
-        if (tid < 2) reinterpret_cast<uint4 *>(winv)[tid] = wimg[2 * kSpImg + tid];
+        for (int t = tid; t < kSpImg; t += kSpThreads) {
+            imgH[t] = wimg[t];
+            imgL[t] = wimg[kSpAll + t];
+        }
+        if (tid < 2) reinterpret_cast<uint4 *>(winv)[tid] = wimg[2 * kSpAll + tid];
     } else {
-        build_weight_images<FWD>(Wst, imgH, imgL, winv, wmax, tid);
+        build_weight_images<FWD, 8>(Wst, imgH, imgL, winv, wmax, tid);
     }
     __syncthreads();
 
@@ -370,6 +377,174 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
     if (p < npanels) panel(p, R0, R1, std::false_type{});  // (the matrix's partial last panel: one wave of the grid)
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The small products of a level on the same machinery (round 3): per-(node,x) vectors, per-node scalars and the compact
+// diagonal rows are [pairs | nodes | pairs of the level below] x 64..256 operands -- as 128-row tiles of the fp32 tile GEMM they
+// were one latency chain of K / 32 steps per workgroup (40 us per launch at level 1 for 10 us of bytes).  Here a wave takes a
+// 32-row panel, requests its whole operand at once, and multiplies from registers against weight images copied from the pass's
+// prebuilt set (positions pos0.. of this direction).
+//   PROG 0  Out[rows][64]          = sum_k In[rows][64 k ..] W_k      (k < 4)   Vout = Vt [K1;K3;K7;K10],  Sout = St [K4;K13;K14;K17]
+//   PROG 1  Out[rows][64 k ..]     = In[rows][64] W_k^T               (k < 4)   dVt = dVout W^T,  dSt = dSout W^T   (transposed images)
+//   PROG 2  Out[rows][64 k ..]     = In[rows][64 k ..] W_k            (k < 2)   Gc = [Fd K15 | Fc K16];  dFdc with the transposed images
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSmThreads = 256;
+// up to three products in ONE launch (a level's V, S and compact products: 17,000-row jobs are one round of latencies each, and
+// three launches paid it three times): workgroups [wg0, wg0 + nwg) run job j
+struct SmallJobs {
+    const float *In[3];
+    float *Out[3];
+    int rows[3], pos0[3], prog[3], wg0[3], nwg[3];
+    int n;
+};
+template <int PROG>
+__device__ __forceinline__ void small_split_body(const float *__restrict__ In, float *__restrict__ Out, int rows,
+                                                 const uint4 *__restrict__ wimg, int pos0, int wg, int nwg) {
+    constexpr int NPOS = PROG == 2 ? 2 : 4;
+    constexpr int LDA = PROG == 0 ? 256 : PROG == 1 ? 64 : 128, LDOUT = PROG == 0 ? 64 : PROG == 1 ? 256 : 128;
+    constexpr int NIN = PROG == 1 ? 1 : NPOS;
+    extern __shared__ __attribute__((aligned(16))) uint4 sm_smem[];
+    uint4 *imgH = sm_smem, *imgL = sm_smem + NPOS * 512;
+    float *winv = reinterpret_cast<float *>(sm_smem + 2 * NPOS * 512);  // [NPOS] (room for 16)
+    float *facs = winv + 16;                                             // [waves][32]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
+    for (int t = tid; t < NPOS * 512; t += kSmThreads) {
+        imgH[t] = wimg[pos0 * 512 + t];
+        imgL[t] = wimg[kSpAll + pos0 * 512 + t];
+    }
+    if (tid < NPOS) winv[tid] = reinterpret_cast<const float *>(wimg + 2 * kSpAll)[pos0 + tid];
+    __syncthreads();
+    float *myfac = facs + wave * 32;
+    struct Raw {
+        f4v a[8];
+    };
+    struct Spl {
+        uint4 h[4], l[4];
+    };
+    auto split_blk = [&](const Raw &R, Spl &S, float &inv) {
+        unsigned m = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned b = __float_as_uint(R.a[q][j]) & 0x7fffffffu;
+                m = b > m ? b : m;
+            }
+        const unsigned mo = (unsigned)__shfl_xor((int)m, 32);
+        m = mo > m ? mo : m;
+        float sc;
+        pow2_scale(m, &sc, &inv);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h2 h, l;
+                const f4v v = R.a[2 * c + (j >> 1)];
+                split_pair(v[2 * (j & 1)], v[2 * (j & 1) + 1], sc, &h, &l);
+                hw[j] = __builtin_bit_cast(unsigned, h);
+                lw[j] = __builtin_bit_cast(unsigned, l);
+            }
+            S.h[c] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            S.l[c] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        }
+    };
+    auto prod = [&](const Spl &S, float rowfac, int wpos, f16v &acc0, f16v &acc1) {
+        __builtin_amdgcn_wave_barrier();
+        myfac[li] = rowfac * winv[wpos];
+        __builtin_amdgcn_wave_barrier();
+        const uint4 *bh = imgH + (size_t)(wpos * 8) * 64 + lane, *bl = imgL + (size_t)(wpos * 8) * 64 + lane;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            f16v t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const h8 bhc = __builtin_bit_cast(h8, bh[(4 * nh + c) * 64]), blc = __builtin_bit_cast(h8, bl[(4 * nh + c) * 64]);
+                const h8 ah = __builtin_bit_cast(h8, S.h[c]), al = __builtin_bit_cast(h8, S.l[c]);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhc, t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blc, t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhc, t, 0, 0, 0);
+            }
+            f16v &acc = nh ? acc1 : acc0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f4v fac = *reinterpret_cast<const f4v *>(myfac + 8 * g + 4 * lh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * g + j] += t[4 * g + j] * fac[j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int npanels = (rows + 31) / 32;
+    for (int p = wg * (kSmThreads / 64) + wave; p < npanels; p += nwg * (kSmThreads / 64)) {
+        const int r0 = p * 32;
+        const int row = r0 + li < rows ? r0 + li : rows - 1;   // (rows past the end re-read the last row; never stored)
+        Raw R[NIN];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const float *src = In + (size_t)row * LDA + k * 64 + 32 * lh;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) R[k].a[q] = *reinterpret_cast<const f4v *>(src + 4 * q);
+        }
+        (void)NIN;
+        auto store_out = [&](int o, const f16v &acc0, const f16v &acc1) {
+            float *out = Out + (size_t)(r0 + 4 * lh) * LDOUT + o * 64 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                if (r0 + 4 * lh + rr < rows) {
+                    out[(size_t)rr * LDOUT] = acc0[r];
+                    out[(size_t)rr * LDOUT + 32] = acc1[r];
+                }
+            }
+        };
+        f16v acc0, acc1;
+        Spl X;
+        float iX;
+        if constexpr (PROG == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NPOS; ++k) {
+                split_blk(R[k], X, iX);
+                prod(X, iX, k, acc0, acc1);
+            }
+            store_out(0, acc0, acc1);
+        } else if constexpr (PROG == 1) {
+            split_blk(R[0], X, iX);
+#pragma unroll
+            for (int k = 0; k < NPOS; ++k) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+                prod(X, iX, k, acc0, acc1);
+                store_out(k, acc0, acc1);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPOS; ++k) {
+                split_blk(R[k], X, iX);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+                prod(X, iX, k, acc0, acc1);
+                store_out(k, acc0, acc1);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kSmThreads, 2) void smp_small_split(SmallJobs jobs, const uint4 *__restrict__ wimg) {
+    int j = 0;
+    if (jobs.n > 1 && (int)blockIdx.x >= jobs.wg0[1]) j = 1;
+    if (jobs.n > 2 && (int)blockIdx.x >= jobs.wg0[2]) j = 2;
+    const int wg = (int)blockIdx.x - jobs.wg0[j];
+    switch (jobs.prog[j]) {  // (uniform per workgroup)
+        case 0: small_split_body<0>(jobs.In[j], jobs.Out[j], jobs.rows[j], wimg, jobs.pos0[j], wg, jobs.nwg[j]); break;
+        case 1: small_split_body<1>(jobs.In[j], jobs.Out[j], jobs.rows[j], wimg, jobs.pos0[j], wg, jobs.nwg[j]); break;
+        default: small_split_body<2>(jobs.In[j], jobs.Out[j], jobs.rows[j], wimg, jobs.pos0[j], wg, jobs.nwg[j]); break;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients of the fused level (compact layout), same split operands.  The eight row block products
@@ -627,6 +802,31 @@ bool smp_split_products(const gf_ctx *ctx) {  // (read per call: the parity test
 }
 
 size_t smp_split_image_bytes() { return 2 * (size_t)kSpImgStride * sizeof(uint4); }
+// the small products of a level in one launch (see smp_small_split): n <= 3 jobs of prog 0 / 1 / 2 on `rows[j]` rows with the weight
+// images from stacked position pos0[j] on; `transposed` picks the backward images; wimg = the level's prebuilt images
+gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *prog, const float *const *In, float *const *Out, const int *rows,
+                              const int *pos0, const void *wimg, const char *name) {
+    const uint4 *img = static_cast<const uint4 *>(wimg) + (transposed ? kSpImgStride : 0);
+    SmallJobs jb;
+    jb.n = 0;
+    int total = 0;
+    for (int j = 0; j < n && jb.n < 3; ++j) {
+        if (rows[j] < 1) continue;
+        const int npanels = (rows[j] + 31) / 32, per = kSmThreads / 64, want = (npanels + per - 1) / per;
+        const int k = jb.n++;
+        jb.In[k] = In[j], jb.Out[k] = Out[j], jb.rows[k] = rows[j], jb.pos0[k] = pos0[j], jb.prog[k] = prog[j];
+        jb.wg0[k] = total;
+        jb.nwg[k] = want < 512 ? want : 512;   // (persistent: a workgroup copies 32 - 64 KB of weight images before its first panel)
+        total += jb.nwg[k];
+    }
+    if (total == 0) return GF_OK;
+    const size_t lds = 2 * (size_t)4 * 512 * 16 + 16 * sizeof(float) + (kSmThreads / 64) * 32 * sizeof(float);
+    gf_status st = opt_in_lds(ctx, smp_small_split, lds);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, name, smp_small_split, dim3((unsigned)total), dim3(kSmThreads), lds, jb, img);
+    return GF_OK;
+}
+
 // the split weight images (both directions) of n levels' stacked weights in one launch; img[i]: smp_split_image_bytes() each
 gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n) {
     for (int i0 = 0; i0 < n; i0 += kSpImgLevels) {
@@ -636,7 +836,7 @@ gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *con
             a.Wst[i] = Wst[i0 + i];
             a.img[i] = static_cast<uint4 *>(img[i0 + i]);
         }
-        GF_LAUNCH(ctx, "smpf_stack_w", smp_split_weight_images, dim3(2, m), dim3(kSpThreads), 0, a);
+        GF_LAUNCH(ctx, "smpf_stack_w", smp_split_weight_images, dim3(2, m, kSpPos), dim3(kSpThreads), 0, a);
     }
     return GF_OK;
 }
