@@ -949,6 +949,15 @@ size_t combine_lds(int N) {
     return sizeof(float) * ((size_t)adj_lds_floats(N) + (size_t)kCombX * (N + 1) * CW);  // + the forward's Vout rows
 }
 
+// threads of a workgroup-per-node kernel whose items are (position, channel quad): the level's largest node decides (a level of
+// 3-vertex fields left 200 of 256 threads idle, and a quarter of the workgroups a CU could hold)
+static int node_block(const gfsmp::LevelLayout &h, int C) {
+    const int smax = h.buckets.empty() ? 1 : h.buckets.back().s;
+    int t = (smax * (C / 4) + 63) / 64 * 64;
+    if (const char *e = std::getenv("GF_SMP_NODE_BLOCK")) t = std::atoi(e);
+    return t < 64 ? 64 : t > 256 ? 256 : t;
+}
+
 struct SizeClass {
     long long lo, hi;  // pair range
     int smax, ni;
@@ -1488,7 +1497,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     if (!grouped) GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C, s->cfg.custom_matmul);
     {  // Fdc = [f[w][p,p] | f[w][p,c_w]] of the level below (read by smp_vectors and by the compact products)
         const gf_smp::DevLevel &pv = s->lv[l - 1];
-        GF_LAUNCH(ctx, "smpf_diag_gather", diag_gather_fwd, dim3(s->lay.level[l - 1].nNodes), dim3(256), 0, pv.f, d.Fdc, pv.node_s,
+        GF_LAUNCH(ctx, "smpf_diag_gather", diag_gather_fwd, dim3(s->lay.level[l - 1].nNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, pv.f, d.Fdc, pv.node_s,
                   pv.node_row, pv.node_pair, pv.node_center, C);
     }
     // The per-(node,x) vectors and per-node scalars (smp_vectors + two small GEMMs) only need T and the stacked weights:
@@ -1507,7 +1516,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         ctx->stream = s->side;
         swap.on = true;
     }
-    GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(256), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
+    GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(node_block(h, C)), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
               d.node_pair, C, d.Fdc, d.pair_src_pair, d.pi);
     const size_t CC = (size_t)C * C;
     if (grouped) {
@@ -1652,7 +1661,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     GF_LAUNCH(ctx, "smpf_reduce_pairs", smp_reduce_pairs, dim3(nb), dim3(256), 0, d.dSpart, d.dbpart, d.dSout, colpart, d.node_s,
               d.node_pair, C, nodes, npb);
     const int ocols = smp_compact_o(s) ? 2 : O_COLS;
-    GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(256), 0, dO, d.dGc, pv.node_s, pv.node_pair,
+    GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, dO, d.dGc, pv.node_s, pv.node_pair,
               d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C, ocols);
     {
         const GemmSpec nt[4] = {spec(d.dGc, d.Wst + 8 * CC, d.dFdc, prevPairs, C, C, 2 * C, C, 2 * C),
@@ -1838,7 +1847,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         // caller), dK15 = Fd^T dG15, dK16 = Fc^T dG16 (stack positions 8, 9)
         const gf_smp::DevLevel &pv = s->lv[l - 1];
         const int prevNodes = s->lay.level[l - 1].nNodes, prevPairs = (int)s->lay.level[l - 1].pairs;
-        GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(256), 0, dO, d.dGc, pv.node_s, pv.node_pair,
+        GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, dO, d.dGc, pv.node_s, pv.node_pair,
                   d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C, (int)O_COLS);
         if (s->side_pending) {  // GF_SMP_OVERLAP: the level above may still be folding split-K partials in the context's ONE
             GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));  // workspace, which the products below use too
