@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
                                             //  they would all be live at once)
         asm volatile("" : "+v"(src_row));   // (nor is the address arithmetic on a prefetched row index moved up to its load)
         const float *src = A + (size_t)src_row * LDA + blk * 64 + 32 * lh;
-        if constexpr (MASK && FWD) src = present ? src : sp_zero_page;  // (a select on the address: same requests, same registers)
+        if constexpr (MASK) src = present ? src : sp_zero_page;  // (a select on the address: same requests, same registers)
 #pragma unroll
         for (int q = 0; q < 8; ++q) R.a[q] = *reinterpret_cast<const f4v *>(src + 4 * q);
         __builtin_amdgcn_sched_barrier(0);
@@ -341,7 +341,8 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             store_out(p, 0, acc0, acc1, full);
         } else {    // dO blocks: 0 L, 1 dU; outputs: 0 dS_ab, 1 dS_bc, 2 dT6, 3 dT10.  Entry: Ra = L, Rb = dU
             split_blk(Ra, X, iX);
-            load_raw_at(Ra, t_row(tcur), 1, true);    // dU at the transposed rows
+            // dU at the transposed rows: it only feeds dS_ab of this row, which is not stored where the row has no data
+            load_raw_at(Ra, t_row(tcur), 1, !(MASK && store_mask) || t_own(tcur));
             split_blk(Rb, Y, iY);
             load_raw(Rb, pn, 1, true);               // dU of the next panel
             // (rows whose S_ab / T6 blocks are structural zeros: bit i = row i of the panel has data; both lane halves hold the row's
@@ -685,8 +686,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
             const bool gathered = blk == 4;
             const float *src = blk < 5 ? dO + (blk >= 3 ? 64 : 0) + 4 * b_quad(e) : T + 4 * a_quad;
             const int ld = blk < 5 ? 128 : 256;
-            S.tb[e].v0 = *reinterpret_cast<const f4v *>(src + (size_t)(gathered ? g0 : c0) * ld);
-            S.tb[e].v1 = *reinterpret_cast<const f4v *>(src + (size_t)(gathered ? g1 : c1) * ld);
+            // (the gathered dU row only meets S_ab of ITS row in product 7: a row without data skips the gather as well)
+            const float *s0 = src + (size_t)(gathered ? g0 : c0) * ld, *s1 = src + (size_t)(gathered ? g1 : c1) * ld;
+            S.tb[e].v0 = *reinterpret_cast<const f4v *>((gathered && z0) ? sp_zero_page + 4 * q_lo : s0);
+            S.tb[e].v1 = *reinterpret_cast<const f4v *>((gathered && z1) ? sp_zero_page + 4 * q_lo : s1);
         }
     };
     // word (column col0 + j, pair) of the images <- halves of (row k, row k + 1) at column col0 + j
