@@ -240,11 +240,13 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
     # gather) -- bytes that need not move are not counted as moved
     masked = split and fused and os.environ.get("GF_SMP_MASK_ZEROS", "1") != "0" and os.environ.get("GF_SMP_KEEP_ZEROS", "1") != "0"
     present = [net.level_present_rows(l) for l in range(L + 1)]
+    covered = [net.level_covered_rows(l) for l in range(L + 1)]   # rows (b, c) some source covers: the S_bc / T10 blocks with data
     for l in range(1, L + 1):
         _, R, S = sizes[l]
         _, Rp, _ = sizes[l - 1]
         unit = 2 * R * C * C                                     # one C x C block product over all rows
-        Tb = (2 * R + 2 * present[l]) * C if masked else 4 * R * C   # floats of T (or dT) that move
+        Tb = (2 * covered[l] + 2 * present[l]) * C if masked else 4 * R * C   # floats of T that move (written once, read twice)
+        dTw = (2 * R + 2 * present[l]) * C if masked else 4 * R * C              # floats of dT written (its S_bc / T10 half: every row)
         if fused:
             add(kb, "smpf_tables_fwd", 4 * (Rp * C + Tb))               # gather f_{l-1} (cached), write 4 tables
             add(kb, "smpf_combine_fwd", 4 * (oc * R * C + R * C))       # O in, f_l out
@@ -259,7 +261,7 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
                      ("smpf_wgrad" if c64 and os.environ.get("GF_SMP_WGRAD", "1") != "0" else "gemm_tn"))
             for k in names:
                 add(kf, k, 8 * unit)
-                add(kb, k, 4 * (Tb + oc * R * C))                        # T (4C) and O / dO per row, each once
+                add(kb, k, 4 * ((dTw if k == "smpf_products_bwd" else Tb) + oc * R * C))   # T (4C) and O / dO per row, each once
         else:
             add(kb, "smp_promote_fwd", 4 * (Rp * C + S * C))
             add(kb, "r18_fwd_slab", 4 * (S * C + 10 * R * C))
@@ -272,7 +274,7 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
                 add(kb, k, 4 * (18 * R * C + R * C))
     step_bytes = sum(kb.values())
     step_flops = sum(kf.values())
-    work = {"levels": [{"nodes": n, "rows_sum_s2": r, "ppos_sum_s3": s, "rows_with_data": p} for (n, r, s), p in zip(sizes, present)],
+    work = {"levels": [{"nodes": n, "rows_sum_s2": r, "ppos_sum_s3": s, "rows_with_data": p, "rows_covered": q} for (n, r, s), p, q in zip(sizes, present, covered)],
             "algorithmic_GB_per_step": round(step_bytes / 1e9, 2), "gemm_GFLOP_per_step": round(step_flops / 1e9, 1)}
 
     def finish(timers, ms_per_step, steps):

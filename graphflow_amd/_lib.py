@@ -112,6 +112,7 @@ PROTOTYPES.update({
     "gf_smp_read_reduced_adjacency": (C.c_longlong, [_vp, _i, _i, _i, _vp, C.c_size_t]),
     "gf_smp_level_sizes": (_i, [_vp, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "gf_smp_level_present_rows": (C.c_longlong, [_vp, _i]),
+    "gf_smp_level_covered_rows": (C.c_longlong, [_vp, _i]),
     "gf_stack_forward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
     "gf_stack_backward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
 })

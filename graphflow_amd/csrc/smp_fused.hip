@@ -109,7 +109,9 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
                                                              const int4 *__restrict__ recs,  // two per node, in launch order (build_tf_records)
                                                              int C, int nwin,
                                                              unsigned *__restrict__ blkmax,    // [4] maxima of T's blocks, or null
-                                                             int zeros_kept) {  // != 0: the structurally-zero rows (a, b) hold their zeros
+                                                             int zeros_kept,  // != 0: the structurally-zero rows (a, b) hold their zeros
+                                                             const unsigned char *__restrict__ rowflag) {  // with zeros_kept: bit 1 =
+                                                             // row (b, c) has data in S_bc / T10 (the others are not stored either)
     constexpr int LPC = 16, PPW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,6 +159,10 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
         const int p = (c < N) ? pi[rowbase + a * N + c] : -1;
         sOff[i] = p >= 0 ? p * C * 4 : kAbsent;
     }
+    unsigned char *sFlag = reinterpret_cast<unsigned char *>(sOff + N * ST);  // [N][N] the node's row flags
+    const bool skip_bc = zeros_kept && rowflag;
+    if (skip_bc)
+        for (int i = tid; i < N * N; i += nthreads) sFlag[i] = rowflag[rowbase + i];
     __syncthreads();
 
     float rc[NI];
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
     for (int i = 0; i < NI; ++i) {
         if (cc[i] >= 0) {
             cs += sbc[i];
-            if (fok) {
+            if (fok && (!skip_bc || (sFlag[b * N + cc[i]] & 2))) {
                 float *trow = T + (rowbase + (size_t)b * N + cc[i]) * (size_t)(T_COLS * C) + f;  // table row (b, c)
                 st4(trow + T_SBC * C, sbc[i]);
                 st4(trow + T_T10 * C, t10[i]);
@@ -464,13 +470,15 @@ __global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict_
     }
 }
 
-// zeros into the S_ab and T6 blocks of the rows (a, b) tables-forward never writes: once per prepared batch (DevLevel::t_zeros)
+// zeros into the S_ab / T6 blocks of the rows (a, b), and the S_bc / T10 blocks of the rows (b, c), that tables-forward never
+// writes: once per prepared batch (DevLevel::t_zeros; rowflag bits 0 / 1 = the row has data in the first / second pair of blocks)
 __global__ void tables_zero_fill(float *__restrict__ T, const unsigned char *__restrict__ rowflag, long long rows) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long row = i >> 5;
-    if (row >= rows || rowflag[row]) return;
-    const int q = (int)(i & 31);  // 32 float4 = the two 64-column blocks
-    st4(T + row * (T_COLS * 64) + (q < 16 ? T_SAB * 64 + 4 * q : T_T6 * 64 + 4 * (q - 16)), splat(0.f));
+    if (row >= rows) return;
+    const int fl = rowflag[row], q = (int)(i & 31);  // 32 float4 = two 64-column blocks
+    if (!(fl & 1)) st4(T + row * (T_COLS * 64) + (q < 16 ? T_SAB * 64 + 4 * q : T_T6 * 64 + 4 * (q - 16)), splat(0.f));
+    if (!(fl & 2)) st4(T + row * (T_COLS * 64) + (q < 16 ? T_SBC * 64 + 4 * q : T_T10 * 64 + 4 * (q - 16)), splat(0.f));
 }
 
 // stacked[p] = K^(kperm[p])  (gather), or  dK^(kperm[p]) += dstacked[p]  (scatter-add).  Block k of the level weight is
@@ -997,17 +1005,18 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     // the level's (class, molecule) order, which is the order of the records (build_tf_records)
     const int n_lo = h.pair_node[(size_t)c.lo], n_hi = (c.hi < (long long)h.pairs) ? h.pair_node[(size_t)c.hi] : h.nNodes;
     if (n_hi <= n_lo) return GF_OK;
-    const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + 16 * (size_t)c.smax + sizeof(int) * (size_t)c.smax * 4 * NI + 16;
+    const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + 16 * (size_t)c.smax + sizeof(int) * (size_t)c.smax * 4 * NI + 16 +
+                       (size_t)c.smax * c.smax + 16;
     unsigned *bm = s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr;
     const int flags = ((d.t_zeros && (C & 63) == 0) ? 1 : 0);
     if ((C & 63) == 0)
         GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin, bm,
-                  flags);
+                  flags, flags ? d.rowflag : (const unsigned char *)nullptr);
     else
         GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, false>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin, bm,
-                  flags);
+                  flags, (const unsigned char *)nullptr);
     return GF_OK;
 }
 
@@ -1215,8 +1224,19 @@ __global__ __launch_bounds__(64) void build_gather_records(const int *__restrict
         const int q = (int)(i % pad);
         const long long pe = cons_pair[ce], pb = pe - cons_a[ce];
         const int c = q < sw ? (int)inv[cons_inv_off[ce] + q] : -1;
+        // A position q without an image (or padding) multiplies what it loads by m = 0 -- but it still loads: from the row of the
+        // FIRST position that has an image, a row (b, c') every b of this entry shares a source with (the entry's own), i.e. one that
+        // is written every step (the backward products do not store the S_bc / T10 gradients of rows no source covers).
+        int cfirst = 0;
+        for (int k = 0; k < sw; ++k) {
+            const int ck = (int)inv[cons_inv_off[ce] + k];
+            if (ck >= 0) {
+                cfirst = ck;
+                break;
+            }
+        }
         const float ra = rsum[pe], rho = c >= 0 ? rsum[pb + c] : 0.f, m = c >= 0 ? 1.f : 0.f;
-        qrec[qb + i] = make_int4(c >= 0 ? c * ldt_bytes : 0, __float_as_int(rho), __float_as_int(m), __float_as_int(m * ra));
+        qrec[qb + i] = make_int4((c >= 0 ? c : cfirst) * ldt_bytes, __float_as_int(rho), __float_as_int(m), __float_as_int(m * ra));
     }
 }
 

@@ -133,9 +133,10 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
                                                                      const uint4 *__restrict__ wimg) {  // or null: this direction's
                                                                      // images, built by smp_split_weight_images
     constexpr int LDA = FWD ? 256 : 128, LDOUT = FWD ? 128 : 256;
-    auto t_row = [](int t) { return MASK ? (t & 0x3fffffff) : t; };
+    auto t_row = [](int t) { return MASK ? (t & 0x1fffffff) : t; };
     auto t_own = [](int t) { return MASK ? t < 0 : true; };
     auto t_tr = [](int t) { return MASK ? ((t >> 30) & 1) != 0 : true; };
+    auto t_bc = [](int t) { return MASK ? ((t >> 29) & 1) != 0 : true; };   // the row's S_bc / T10 blocks hold data
     extern __shared__ __attribute__((aligned(16))) uint4 sp_smem[];
     uint4 *imgH = sp_smem, *imgL = sp_smem + kSpImg;
     float *winv = reinterpret_cast<float *>(sp_smem + 2 * kSpImg);  // [8] 2^-k of the weight blocks
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         float iX, iY, iZ;
         if (FWD) {  // T blocks: 0 S_ab, 1 S_bc, 2 T6, 3 T10; outputs: 0 O_loc, 1 U.  Entry: Ra = S_ab, Rb = S_ab at the transposed rows
             split_blk(Ra, X, iX);
-            load_raw(Ra, p, 1, true);                // S_bc
+            load_raw(Ra, p, 1, t_bc(tcur));          // S_bc
             split_blk(Rb, Z, iZ);
             load_raw(Rb, p, 2, t_own(tcur));         // T6
             clear(acc0, acc1);
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             prod(X, iX * sc.x, 0, acc0, acc1);
             prod(X, iX * sc.y, 2, acc0, acc1);
             prod(Y, iY * sc.x, 1, acc0, acc1);
-            load_raw(Ra, p, 3, true);                // T10, once X and Y are dead: with two requests beside them the panel spills,
+            load_raw(Ra, p, 3, t_bc(tcur));          // T10, once X and Y are dead: with two requests beside them the panel spills,
                                                      // and a scratch reload waits for the whole memory queue
             split_blk(Rb, Z, iZ);
             load_raw_at(Rb, t_row(tnext), 0, t_tr(tnext));   // S_ab of the next panel at its transposed rows
@@ -347,6 +348,8 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             load_raw(Rb, pn, 1, true);               // dU of the next panel
             // (rows whose S_ab / T6 blocks are structural zeros: bit i = row i of the panel has data; both lane halves hold the row's
             //  entry, the low word of the ballot is the panel's)
+            // (the dS_bc / dT10 blocks of rows no source covers are stored all the same -- 8 % of the rows at level 3: masking them as
+            //  well cost the kernel fifteen spills and more than it saved, 0.84 -> 0.91 ms)
             const unsigned rowbits = (MASK && store_mask) ? (unsigned)__ballot(t_own(tcur)) : 0xffffffffu;
             clear(acc0, acc1);
             prod(X, iX, 3, acc0, acc1);
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
         float f0[NB], f1[NB];  // the two rows' factor (tot for the tot L copy, tr for the tr L copy, else unused)
     };
     const bool has_b1 = wave < 2;
-    const bool zblk = ((wave >> 1) & 1) == 0;  // the wave stages S_ab (waves 0, 1) or T6 (4, 5)
+    const int zbit = ((wave >> 1) & 1) == 0 ? 31 : 29;  // the wave stages S_ab / T6 (waves 0, 1, 4, 5) or S_bc / T10 (2, 3, 6, 7)
     const int a_quad = 8 * wave + q_lo;
     auto b_blk = [&](int e) { return (wave + 8 * e) >> 1; };
     auto b_quad = [&](int e) { return 8 * ((wave + 8 * e) & 1) + q_lo; };
@@ -669,8 +672,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
     auto load_slice = [&](Set &S, int m) {  // the workgroup's m-th slice; calls come with consecutive m
         // (packed table: bit 31 of a row's entry = its S_ab / T6 blocks hold data; the waves that stage those blocks read the rows
         //  without from the page of zeros -- 0.73 GB a cfg3 step that is not fetched)
-        const int g0 = packed ? (ia0 & 0x3fffffff) : ia0, g1 = packed ? (ia1 & 0x3fffffff) : ia1;
-        const bool z0 = packed && zblk && ia0 >= 0, z1 = packed && zblk && ia1 >= 0;
+        const int g0 = packed ? (ia0 & 0x1fffffff) : ia0, g1 = packed ? (ia1 & 0x1fffffff) : ia1;
+        // (absent: bit 31 clear for the S_ab / T6 waves, bit 29 clear for the S_bc / T10 waves)
+        const bool z0 = packed && !((ia0 >> zbit) & 1), z1 = packed && !((ia1 >> zbit) & 1);
+        const bool zg0 = packed && ia0 >= 0, zg1 = packed && ia1 >= 0;   // the gathered dU row meets S_ab of its row only
         ia0 = ib0, ia1 = ib1;
         fetch_trow(m + 2, ib0, ib1);
         const long long last = kend - 1, kk = K(m) + 2 * pair;
@@ -688,8 +693,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
             const int ld = blk < 5 ? 128 : 256;
             // (the gathered dU row only meets S_ab of ITS row in product 7: a row without data skips the gather as well)
             const float *s0 = src + (size_t)(gathered ? g0 : c0) * ld, *s1 = src + (size_t)(gathered ? g1 : c1) * ld;
-            S.tb[e].v0 = *reinterpret_cast<const f4v *>((gathered && z0) ? sp_zero_page + 4 * q_lo : s0);
-            S.tb[e].v1 = *reinterpret_cast<const f4v *>((gathered && z1) ? sp_zero_page + 4 * q_lo : s1);
+            S.tb[e].v0 = *reinterpret_cast<const f4v *>((gathered && zg0) ? sp_zero_page + 4 * q_lo : s0);
+            S.tb[e].v1 = *reinterpret_cast<const f4v *>((gathered && zg1) ? sp_zero_page + 4 * q_lo : s1);
         }
     };
     // word (column col0 + j, pair) of the images <- halves of (row k, row k + 1) at column col0 + j
@@ -854,7 +859,7 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
     const int want = (npanels + per - 1) / per;
     const int grid = want < cus ? want : cus;  // one persistent workgroup per CU (the weight images take 128 KB of LDS)
     // packed table with the presence bits (see the kernel)
-    const bool mask = trowf && rows < (1 << 30) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
+    const bool mask = trowf && rows < (1 << 29) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
 #define GF_SP_LAUNCH(F, M, name)                                                                                                   \
     do {                                                                                                                           \
         gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M>, kSpLds);                                                          \
@@ -881,7 +886,7 @@ gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float 
                                        const int *trowf, const unsigned *row_max) {
     gf_status st = opt_in_lds(ctx, smp_wgrad_split, kWsLds);
     if (st != GF_OK) return st;
-    const bool mask = trowf && rows < (1 << 30) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
+    const bool mask = trowf && rows < (1 << 29) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
     GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_split, dim3((unsigned)splits), dim3(kWsThreads), kWsLds, T, dO, rowscale, rows, kchunk, part,
               mask ? trowf : trow, blkmax, max_tot, max_tr, mask ? 1 : 0, row_max);
     return GF_OK;

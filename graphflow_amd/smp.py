@@ -189,6 +189,10 @@ class SMPOmega:
         """rows (a, b) of the level whose slab row is not structurally zero (gf_smp_level_present_rows)"""
         return int(self.lib.gf_smp_level_present_rows(self.handle, level))
 
+    def level_covered_rows(self, level):
+        """rows (b, c) of the level that some source covers (gf_smp_level_covered_rows)"""
+        return int(self.lib.gf_smp_level_covered_rows(self.handle, level))
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.gf_smp_destroy(self.handle)

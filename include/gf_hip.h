@@ -323,6 +323,9 @@ gf_status gf_smp_level_sizes(const gf_smp *smp, int level, long long *nodes, lon
  * source (the selection matrices of SMP_omega.h:461-474 have a 1 in that column) -- out of gf_smp_level_sizes' `rows`.  The fused
  * level neither writes, reads nor back-propagates the other rows' S_ab / T6 table blocks; the bench prices its kernels with it. */
 long long gf_smp_level_present_rows(const gf_smp *smp, int level);
+/* ... and the rows (b, c) that SOME source covers (both vertices inside one source's field): the others' S_bc / T10 blocks are
+ * structural zeros as well.  Equal to `rows` where the handle keeps no row flags (channel counts other than 64).  Blocking. */
+long long gf_smp_level_covered_rows(const gf_smp *smp, int level);
 
 /* RisiContraction_18_dropout inside a physics tower (SMP_sigma_pairgraphs.h:248-265, :632-651): masks[(l-1) * nVertices + gv] =
  * kept-slice bits of the contraction of global vertex gv (molecules back to back) at level l, drawn by the caller in the

@@ -868,6 +868,37 @@ def test_device_level_tables_equal_the_host_built_ones(gf, monkeypatch, C, fused
     assert np.isfinite(a[2]).all() and np.abs(a[2]).max() > 0
 
 
+def test_row_flags_count_the_rows_with_data(gf):
+    """The structural zeros the C = 64 level skips, counted from the receptive fields: row (a, b) of the S_ab / T6 blocks has data when
+    b lies in the field of a's source; row (b, c) of the S_bc / T10 blocks when some source holds both (SMP_omega.h:461-474: the
+    selection matrices of MatTensorMul / TensorMatMul have a 1 in those columns).  gf_smp_level_present_rows / _covered_rows report the
+    device's flags (build_trow), which the kernels mask with."""
+    from graphflow_amd.smp import SMPOmega
+    L, C, F, D, cap = 3, 64, 5, 2, 29
+    mols = [synthetic_molecule(300 + i)[:2] for i in range(5)]
+    net = SMPOmega(L, C, F, D, cap, True)
+    net.prepare(mols)
+    present, covered, rows = [0] * (L + 1), [0] * (L + 1), [0] * (L + 1)
+    for m, (adj, _) in enumerate(mols):
+        V = len(adj)
+        f = [[net.receptive_field(m, l, v) for v in range(V)] for l in range(L + 1)]
+        for l in range(1, L + 1):
+            for v in range(V):
+                fld = f[l][v]
+                srcs = [set(f[l - 1][a]) for a in fld]
+                rows[l] += len(fld) ** 2
+                present[l] += sum(1 for sa in srcs for b in fld if b in sa)
+                for b in fld:
+                    u = set().union(*[sa for sa in srcs if b in sa])
+                    covered[l] += sum(1 for c in fld if c in u)
+    for l in range(1, L + 1):
+        assert net.level_sizes(l)[1] == rows[l]
+        assert net.level_present_rows(l) == present[l], (l, net.level_present_rows(l), present[l])
+        assert net.level_covered_rows(l) == covered[l], (l, net.level_covered_rows(l), covered[l])
+        assert present[l] <= covered[l] <= rows[l]
+    net.close()
+
+
 def test_no_kernel_reads_what_nobody_wrote():
     """GF_POISON=1 fills every buffer the library hands out without contents (workspace, pooled level buffers, model buffers) with
     NaN patterns before anything is launched.  The golden, headline, gather and physics parity tests must pass unchanged in such a
