@@ -345,7 +345,8 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             // dU at the transposed rows: it only feeds dS_ab of this row, which is not stored where the row has no data
             load_raw_at(Ra, t_row(tcur), 1, !(MASK && store_mask) || t_own(tcur));
             split_blk(Rb, Y, iY);
-            load_raw(Rb, pn, 1, true);               // dU of the next panel
+            load_raw(Rb, pn, 1, !(MASK && store_mask) || t_bc(tnext));   // dU of the next panel (a row no source covers has nothing to
+                                                                         // back-propagate: its whole dT row is a gradient of structural zeros)
             // (rows whose S_ab / T6 blocks are structural zeros: bit i = row i of the panel has data; both lane halves hold the row's
             //  entry, the low word of the ballot is the panel's)
             // (the dS_bc / dT10 blocks of rows no source covers are stored all the same -- 8 % of the rows at level 3: masking them as
@@ -366,16 +367,16 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             prod(X, iX * sc.y, 2, acc0, acc1);
             prod(Y, iY, 5, acc0, acc1);
             split_blk(Ra, Z, iZ);
-            load_raw(Ra, pn, 0, true);               // L of the next panel
+            load_raw(Ra, pn, 0, !(MASK && store_mask) || t_bc(tnext));   // L of the next panel
             prod(Z, iZ, 7, acc0, acc1);
             store_out(p, 0, acc0, acc1, full, rowbits);
         }
     };
     Raw R0, R1;
     int p = blockIdx.x * (kSpThreads / 64) + wave;
-    load_raw(R0, p, 0, FWD ? t_own(tnext) : true);
+    load_raw(R0, p, 0, FWD ? t_own(tnext) : (!(MASK && store_mask) || t_bc(tnext)));
     if (FWD) load_raw_at(R1, t_row(tnext), 0, t_tr(tnext));
-    else load_raw(R1, p, 1, true);
+    else load_raw(R1, p, 1, !(MASK && store_mask) || t_bc(tnext));
     const int nfull = rows / 32;
     for (; p < nfull; p += nwaves) panel(p, R0, R1, std::true_type{});
     if (p < npanels) panel(p, R0, R1, std::false_type{});  // (the matrix's partial last panel: one wave of the grid)
