@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "gf_internal.h"
+#include "r18_device.h"
 
 namespace gf {
 namespace {
@@ -461,6 +462,126 @@ __global__ __launch_bounds__(256) void fam_products_lds(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// RisiContraction_50 forward outputs on the matrix pipe (C % 32 == 0, N <= 32): ONE kernel writes all fifty slices of a row
+// (fam_forward + fam_products_lds wrote them in two launches, 32 + 18 slices).  One WAVE owns (graph g, row x, window of 32
+// channels).  The eighteen adjacency products  Out_k[x, y, f] = sum_z op[z, f] M[z, y]  (M = A[y, z] or A[z, y]) are
+// v_mfma_f32_32x32x2_f32 with the nine operands -- rows / columns x of S_ab, S_ac, S_bc and the three diagonals of P -- loaded
+// straight from global memory in the B-operand layout (z = 2 step + lane / 32, f = lane % 32: two coalesced 128-byte rows per
+// load, each operand read once and used by two products) and the adjacency in registers in the A-operand layout.  The result
+// leaves the pipe as (row y = 8 (v / 4) + 4 (lane / 32) + v % 4, column f = lane % 32), the layout the thirty-two plain slices
+// are evaluated in as well: every store is two 128-byte rows of Out.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f16acc __attribute__((ext_vector_type(16)));
+
+// Buffer addressing for the two matrix-pipe kernels: wave-uniform descriptor + per-lane byte offset + scalar byte offset.  A lane
+// that has no row / no z gets the offset kOob: its loads return 0 and its stores are dropped by the bounds check, so the kernels
+// are free of branches and of 64-bit address arithmetic.
+constexpr unsigned kOob = 0x80000000u;
+__device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
+template <int NS>  // N <= 2 NS
+__global__ __launch_bounds__(256, 2) void fam50_forward_mfma(const float *__restrict__ P, const float *__restrict__ A,
+                                                             const float *__restrict__ adjs, const float *__restrict__ tab,
+                                                             const float *__restrict__ vec, const float *__restrict__ sc,
+                                                             float *__restrict__ Out, int N, int C, unsigned nwaves) {
+    constexpr int K = 50;
+    const int lane = threadIdx.x & 63, hi = lane >> 5, m = lane & 31;
+    const unsigned wid = (unsigned)xcd_block() * 4 + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wid >= nwaves) return;
+    const unsigned nwin = (unsigned)C >> 5;
+    const int win = (int)(wid % nwin), x = (int)((wid / nwin) % (unsigned)N);
+    const size_t g = wid / nwin / (unsigned)N;
+    const int f = win * 32 + m;
+    const unsigned uN = (unsigned)N, uC = (unsigned)C, NC = uN * uC, NNC = uN * NC;
+    const float *Ag = A + g * N * N;
+    const float *r = adjs + g * adjs_stride(N), *q = r + N, *st = q + 2 * N;
+    const __amdgpu_buffer_rsrc_t rT = dev::make_rsrc(tab + g * kNTab * (size_t)NNC, (size_t)kNTab * NNC * 4);
+    const __amdgpu_buffer_rsrc_t rP = dev::make_rsrc(P + g * (size_t)NNC * N, (size_t)NNC * N * 4);
+    const __amdgpu_buffer_rsrc_t rO = dev::make_rsrc(Out + (g * N + x) * (size_t)N * K * C, (size_t)N * K * C * 4);
+    auto row_of = [&](int v) { return 8 * (v >> 2) + 4 * hi + (v & 3); };
+    unsigned oY[16];   // byte offset of (column y, channel f) in the row of Out; slice cs adds (cs - 1) C floats
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const unsigned y = (unsigned)row_of(v);
+        oY[v] = y < uN ? (y * (unsigned)K * uC + (unsigned)f) * 4u : kOob;
+    }
+    {   // the thirty-two plain slices
+        const float *vv = vec + g * kNVec * (size_t)NC + (size_t)x * C + f;
+        const float *ss = sc + g * kNSc * (size_t)C + f;
+        const float va = vv[0 * NC], vb = vv[1 * NC], vc = vv[2 * NC], vbb = vv[3 * NC], vaba = vv[4 * NC], vaac = vv[5 * NC];
+        const float s0 = ss[0 * C], s1 = ss[1 * C], s2 = ss[2 * C], s3 = ss[3 * C], s4 = ss[4 * C];
+        const float tot = st[0], tr = st[1];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned y = (unsigned)row_of(v);
+            const unsigned yc = y < uN ? y : 0u;
+            const unsigned tY = y < uN ? (((unsigned)x * uN + y) * uC + (unsigned)f) * 4u : kOob;
+            const float ry = r[yc], qy = q[yc], axy = Ag[x * N + (int)yc];
+            float t[kNTab];
+#pragma unroll
+            for (int k = 0; k < kNTab; ++k) t[k] = bld(rT, tY, (unsigned)k * NNC * 4u);
+#define OUTS(c, expr) bst(rO, oY[v], (unsigned)((c) - 1) * uC * 4u, (expr))
+            OUTS(1, t[0] * tot);  OUTS(2, t[1] * tot);  OUTS(3, va * ry);   OUTS(4, va * qy);   OUTS(5, t[2] * tot);
+            OUTS(6, vb * ry);     OUTS(7, vb * qy);     OUTS(8, vc * ry);   OUTS(9, vc * qy);   OUTS(10, s0 * axy);
+            OUTS(11, t[3]);       OUTS(12, t[4]);       OUTS(13, t[0] * tr); OUTS(14, t[6]);    OUTS(15, t[7]);
+            OUTS(16, t[1] * tr);  OUTS(17, vbb * ry);   OUTS(20, vbb * qy); OUTS(23, t[9]);     OUTS(24, t[10]);
+            OUTS(25, t[2] * tr);  OUTS(26, vaba * ry);  OUTS(29, vaba * qy); OUTS(32, vaac * ry); OUTS(35, vaac * qy);
+            OUTS(38, s1 * axy);   OUTS(39, s2 * axy);   OUTS(40, s3 * axy); OUTS(41, t[5]);     OUTS(42, t[8]);
+            OUTS(45, t[11]);      OUTS(50, s4 * axy);
+#undef OUTS
+            if ((v & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four rows of loads in flight, not sixteen)
+        }
+    }
+    float ma[NS], mt[NS];
+    bool zok[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int z = 2 * t + hi;
+        zok[t] = z < N;
+        const bool v = zok[t] && m < N;
+        const int zc = zok[t] ? z : 0, mc = m < N ? m : 0;
+        const float a0 = Ag[zc * N + mc], a1 = Ag[mc * N + zc];
+        ma[t] = v ? a0 : 0.f;   // A[z, y]
+        mt[t] = v ? a1 : 0.f;   // A[y, z]
+    }
+    // operand (z, f) at  base + z zstr  floats of descriptor rs, in the B layout; slices c_yz = sum_z op A[y, z], c_zy = sum_z op A[z, y]
+    auto product = [&](__amdgpu_buffer_rsrc_t rs, unsigned base, unsigned zstr, int c_yz, int c_zy) {
+        const unsigned lo = ((unsigned)hi * zstr + (unsigned)f) * 4u;
+        float b[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) b[t] = bld(rs, zok[t] ? lo : kOob, (base + 2u * t * zstr) * 4u);
+        f16acc d0, d1;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) d0[v] = d1[v] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(mt[t], b[t], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ma[t], b[t], d1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            bst(rO, oY[v], (unsigned)(c_yz - 1) * uC * 4u, d0[v]);
+            bst(rO, oY[v], (unsigned)(c_zy - 1) * uC * 4u, d1[v]);
+        }
+    };
+    const unsigned xr = (unsigned)x * NC, xc = (unsigned)x * uC;
+    product(rT, 0 * NNC + xr, uC, 18, 21);          // S_ab[x, z]
+    product(rT, 1 * NNC + xr, uC, 19, 22);          // S_ac[x, z]
+    product(rT, 0 * NNC + xc, NC, 27, 30);          // S_ab[z, x]
+    product(rT, 2 * NNC + xr, uC, 28, 31);          // S_bc[x, z]
+    product(rT, 1 * NNC + xc, NC, 33, 36);          // S_ac[z, x]
+    product(rT, 2 * NNC + xc, NC, 34, 37);          // S_bc[z, x]
+    product(rP, (unsigned)x * NNC, NC + uC, 43, 44);   // P[x, z, z]
+    product(rP, xr, NNC + uC, 46, 47);              // P[z, x, z]
+    product(rP, xc, NNC + NC, 48, 49);              // P[z, z, x]
+}
+
 // backward scalars, bsc[g][5][C]: u10, u38, u39, u40, u50 = sum_{d,e} G_c[d,e] A[d,e].
 // Workgroup per (graph, slice): 256 threads = row groups x channel lanes; a group walks (d,e) = grp, grp + ngrp, ...,
 // the groups are folded through LDS in a fixed order (deterministic).
@@ -743,6 +864,135 @@ __global__ __launch_bounds__(256) void fam_bwd_tables_lds(const float *__restric
 #undef GD
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// RisiContraction_50 backward tables on the matrix pipe (C % 32 == 0, N <= 32): every G row is read ONCE, straight from global
+// memory into the operand registers of v_mfma_f32_32x32x2_f32 -- no LDS, no re-reads through L1.
+//
+// All six tables are sums of  out[t, f] += sum_z G_s[x, z, f] M[z, t]  with M one of A[z, t], A[t, z] (per graph) or a weight
+// vector r[z], q[z] that does not depend on t.  One WAVE owns (graph g, row x, window of 32 channels).  The G operand of a step
+// is the 2 x 32 block (z = 2 step + lane / 32, f = lane % 32) -- exactly the B-operand layout of the instruction, and two fully
+// coalesced 128-byte rows of the slice per load.  The adjacency operand (A-operand layout: t = lane % 32, z likewise) is loaded
+// once per wave and stays in registers for all eighteen products.  The weighted sums (r, q) run on the VALU and are added to
+// every row of the accumulator.  D leaves the pipe as (row t = 8 (v / 4) + 4 (lane / 32) + v % 4, column f = lane % 32): stores
+// are 128-byte rows again.  Twelve MFMAs per product at N = 24 (216 per wave): a twentieth of the kernel's memory time.
+//   ROLE 0 (column role, first launch): the slices indexed (j = x, z) give COLUMN x of X_ab, X_ac, X_bc: stored at [t][x].
+//   ROLE 1 (row role, second launch): the slices indexed (i = x, z) give ROW x of all six tables; X_* start from what the
+//   first launch left at [x][t], the direct (x, t)-indexed slices and the per-graph scalars.
+// fam_bwd_tables (thread per (i, columns j, f)) re-read the (i, z) slices once per column block and the (j, z) slices once per
+// row pair through L1: 0.35 ms at cfg5, the longest kernel of that step.
+// ---------------------------------------------------------------------------------------------------------------
+
+template <int NS, int ROLE>  // N <= 2 NS
+__global__ __launch_bounds__(256, 3) void fam50_bwd_tables_mfma(const float *__restrict__ G, const float *__restrict__ A,
+                                                                const float *__restrict__ adjs, const float *__restrict__ bsc,
+                                                                float *__restrict__ btab, int N, int C, unsigned nwaves) {
+    constexpr int K = 50;
+    const int lane = threadIdx.x & 63, hi = lane >> 5, m = lane & 31;
+    const unsigned wid = (unsigned)xcd_block() * 4 + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wid >= nwaves) return;
+    const unsigned nwin = (unsigned)C >> 5;
+    const int win = (int)(wid % nwin), x = (int)((wid / nwin) % (unsigned)N);
+    const size_t g = wid / nwin / (unsigned)N;
+    const int f = win * 32 + m;
+    const unsigned uN = (unsigned)N, uC = (unsigned)C, NC = uN * uC, NNC = uN * NC, zs = (unsigned)K * uC;
+    const float *Ag = A + g * N * N;
+    const float *r = adjs + g * adjs_stride(N), *q = r + N, *st = q + 2 * N;
+    // row x of G: slice cs of (x, z) at  z zs + (cs - 1) C  floats
+    const __amdgpu_buffer_rsrc_t rG = dev::make_rsrc(G + (g * N + x) * (size_t)N * zs, (size_t)N * zs * 4);
+    const __amdgpu_buffer_rsrc_t rB = dev::make_rsrc(btab + g * kNBTab * (size_t)NNC, (size_t)kNBTab * NNC * 4);
+    float ma[NS], mt[NS], rz[NS], qz[NS];
+    unsigned lo[NS];   // this lane's (z, f) of step t inside a G row, or kOob
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int z = 2 * t + hi;
+        const bool zv = z < N, v = zv && m < N;
+        const int zc = zv ? z : 0, mc = m < N ? m : 0;
+        const float a0 = Ag[zc * N + mc], a1 = Ag[mc * N + zc], r0 = r[zc], q0 = q[zc];
+        ma[t] = v ? a0 : 0.f;   // A[z, t]
+        mt[t] = v ? a1 : 0.f;   // A[t, z]
+        rz[t] = zv ? r0 : 0.f;
+        qz[t] = zv ? q0 : 0.f;
+        lo[t] = zv ? ((unsigned)hi * zs + (unsigned)f) * 4u : kOob;
+    }
+    auto ld = [&](int cs, int t) -> float { return bld(rG, lo[t], (2u * t * zs + (unsigned)(cs - 1) * uC) * 4u); };
+    // acc += G_ca . A[z, t] + G_ct . A[t, z]
+    auto prod = [&](f16acc &acc, int ca, int ct) {
+        float ga[NS], gt[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) ga[t] = ld(ca, t), gt[t] = ld(ct, t);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ma[t], ga[t], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mt[t], gt[t], acc, 0, 0, 0);
+        }
+    };
+    // sum_z G_cr[x, z] r[z] + G_cq[x, z] q[z]   (the same value in both halves of the wave)
+    auto wsum = [&](int cr, int cq) -> float {
+        float w = 0.f;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) w += ld(cr, t) * rz[t] + ld(cq, t) * qz[t];
+        return dev::xor32_sum(w);
+    };
+    auto row_of = [&](int v) { return 8 * (v >> 2) + 4 * hi + (v & 3); };
+    if (ROLE == 0) {
+        unsigned cY[16];   // (t, x, f) of a table
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned t = (unsigned)row_of(v);
+            cY[v] = t < uN ? ((t * uN + (unsigned)x) * uC + (unsigned)f) * 4u : kOob;
+        }
+        auto col_table = [&](int tbl, float w, int ca, int ct) {
+            f16acc acc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] = w;
+            prod(acc, ca, ct);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) bst(rB, cY[v], (unsigned)tbl * NNC * 4u, acc[v]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        col_table(0, wsum(6, 7), 27, 30);
+        col_table(1, wsum(8, 9), 33, 36);
+        col_table(2, 0.f, 34, 37);
+    } else {
+        const float tot = st[0], tr = st[1];
+        const float *u = bsc + g * 5 * (size_t)C + f;
+        unsigned rY[16], gY[16];   // (x, t, f) of a table; (t, f) of a G row
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned t = (unsigned)row_of(v);
+            rY[v] = t < uN ? (((unsigned)x * uN + t) * uC + (unsigned)f) * 4u : kOob;
+            gY[v] = t < uN ? (t * zs + (unsigned)f) * 4u : kOob;
+        }
+        // X tables: tot G_c1[x, t] + tr G_c2[x, t] + what the column launch left + u + weighted sums + the two products
+        auto xtable = [&](int tbl, int c1, int c2, float add, int ca, int ct) {
+            f16acc acc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                acc[v] = tot * bld(rG, gY[v], (unsigned)(c1 - 1) * uC * 4u) + tr * bld(rG, gY[v], (unsigned)(c2 - 1) * uC * 4u) +
+                         bld(rB, rY[v], (unsigned)tbl * NNC * 4u) + add;
+            prod(acc, ca, ct);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) bst(rB, rY[v], (unsigned)tbl * NNC * 4u, acc[v]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto ztable = [&](int tbl, float add, int ca, int ct) {
+            f16acc acc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] = add;
+            prod(acc, ca, ct);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) bst(rB, rY[v], (unsigned)tbl * NNC * 4u, acc[v]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        xtable(0, 1, 13, u[0] + wsum(3, 4), 18, 21);
+        xtable(1, 2, 16, 0.f, 19, 22);
+        xtable(2, 5, 25, 0.f, 28, 31);
+        ztable(3, u[3 * C] + wsum(17, 20), 43, 44);
+        ztable(4, u[2 * C] + wsum(26, 29), 46, 47);
+        ztable(5, u[1 * C] + wsum(32, 35), 48, 49);
+    }
+}
+
 template <int K>
 __global__ void fam_backward(const float *__restrict__ G, const float *__restrict__ A, const float *__restrict__ adjs,
                              const float *__restrict__ bsc, const float *__restrict__ btab, float *__restrict__ dP, int N,
@@ -906,7 +1156,24 @@ gf_status fam_forward_launch(gf_ctx *ctx, const float *P, const float *A, float 
     GF_LAUNCH(ctx, "fam_vectors", fam_vectors, dim3(grid_for(nv)), dim3(256), 0, P, w.tab, w.vec, w.sc, N, C, nv);
     GF_LAUNCH(ctx, "fam_scalars", fam_scalars, dim3(grid_for(ns)), dim3(256), 0, P, w.vec, w.sc, N, C, ns);
     const size_t prod_lds = sizeof(float) * ((size_t)9 * N * C + (size_t)N * N);
-    if (vec && K == 50 && prod_lds <= 150 * 1024 && C / 4 <= 256) {
+    bool mfma_out = false;
+    if constexpr (K == 50) {
+        // all fifty slices of a row from one wave, the adjacency products on the matrix pipe (GF_FAM_FWD_MFMA=0: the two kernels below)
+        const char *e = std::getenv("GF_FAM_FWD_MFMA");
+        mfma_out = C % 32 == 0 && N <= 32 && (size_t)batch * N * (C / 32) < 0x7fffffffu && (size_t)N * N * N * C < (1u << 29) && !(e && e[0] == '0');   // (buffer descriptors of a graph's P and tables stay under 2 GB)
+        if (mfma_out) {
+            const unsigned nw = (unsigned)((size_t)batch * N * (C / 32));
+            const dim3 grid((nw + 3) / 4), block(256);
+            if (N <= 16)
+                GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<8>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);
+            else if (N <= 24)
+                GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<12>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);
+            else
+                GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<16>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);
+        }
+    }
+    if (mfma_out) {
+    } else if (vec && K == 50 && prod_lds <= 150 * 1024 && C / 4 <= 256) {
         // the plain slices by the element kernel, the eighteen adjacency products from LDS-staged operands
         const size_t nf = (size_t)batch * N * N * (C / 4);
         GF_LAUNCH(ctx, "fam_forward", (fam_forward<K, 4, false>), dim3(grid_for(nf)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec,
@@ -956,7 +1223,26 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
         //  slices per z -- 0.56 ms against 0.40 ms for fam_bwd_tables, and fam_backward_rows pays 0.11 ms for the transposed halves)
         if (sizeof(float) * 4 * (size_t)N * C > 48 * 1024 || (size_t)batch * N >= 0x7fffffffu) cwin = 0;  // (only fam_backward_rows adds the halves)
     }
-    if (cwin > 0) {
+    bool mfma_tables = false;
+    if constexpr (K == 50) {
+        // matrix-pipe tables (every G row read once, no LDS): C in whole 32-channel windows, N <= 32.  GF_FAM_BWD_MFMA=0: the
+        // thread-per-(i, columns, f) kernel below
+        const char *e = std::getenv("GF_FAM_BWD_MFMA");
+        mfma_tables = C % 32 == 0 && N <= 32 && (size_t)batch * N * (C / 32) < 0x7fffffffu && (size_t)N * N * K * C < (1u << 28) && !(e && e[0] == '0') && cwin == 0;
+        if (mfma_tables) {
+            const unsigned nw = (unsigned)((size_t)batch * N * (C / 32));
+            const dim3 grid((nw + 3) / 4), block(256);
+#define GF_FAM_MFMA(NS)                                                                                                            \
+    do {                                                                                                                           \
+        GF_LAUNCH(ctx, "fam_bwd_tables", (fam50_bwd_tables_mfma<NS, 0>), grid, block, 0, G, A, w.adjs, w.sc, w.tab, N, C, nw);     \
+        GF_LAUNCH(ctx, "fam_bwd_tables", (fam50_bwd_tables_mfma<NS, 1>), grid, block, 0, G, A, w.adjs, w.sc, w.tab, N, C, nw);     \
+    } while (0)
+            if (N <= 16) GF_FAM_MFMA(8); else if (N <= 24) GF_FAM_MFMA(12); else GF_FAM_MFMA(16);
+#undef GF_FAM_MFMA
+        }
+    }
+    if (mfma_tables) {
+    } else if (cwin > 0) {
         const int nwin = (C + cwin - 1) / cwin;
         const size_t lds = sizeof(float) * ((size_t)((K == 50) ? kBtI + kBtJ : 6) * N * cwin + (size_t)N * N);
         st = opt_in_lds(ctx, fam_bwd_tables_lds<K>, lds);

@@ -91,14 +91,20 @@ def test_r18_is_the_gated_subset_of_r50(gf):
     assert rel_err_slices(o18, o50[:, :, :, sel, :]) <= REL_TOL_F32
 
 
-@pytest.mark.parametrize("lds", ["0", "1"])
+@pytest.mark.parametrize("lds", ["0", "1", "threads"])
 @pytest.mark.parametrize("K", [50, 10])
 def test_cfg5_shape_one_graph_vs_oracle_spec_form(gf, oracle, monkeypatch, K, lds):
     """BASELINE configs[4]'s shape (N = 24, C = 32): the lane mapping of fam_tables<50,4> / fam_products_lds<50> /
     fam_bwd_tables<50,1> is only reached at C % 4 == 0 and this size.  Graph 0 of a 3-graph batch (weighted adjacency, so the
     no-gate rule of _50 / _10 matters) against the oracle's table-driven spec form (RisiContraction_50.h:94-430) on two
     channels -- channels are independent, so the oracle runs the O(N^5) form on a 2-channel copy."""
-    monkeypatch.setenv("GF_FAM_BWD_LDS", lds)   # 1: the LDS-staged backward tables (fam_bwd_tables_lds, opt-in: DESIGN.md 6)
+    # "0": the default kernels (K = 50: fam50_forward_mfma / fam50_bwd_tables_mfma, the matrix-pipe forms); "1": the LDS-staged
+    # backward tables (fam_bwd_tables_lds, opt-in: DESIGN.md 4.2); "threads": the thread-per-element kernels the matrix-pipe
+    # forms replaced (fam_forward + fam_products_lds, fam_bwd_tables)
+    monkeypatch.setenv("GF_FAM_BWD_LDS", "1" if lds == "1" else "0")
+    if lds == "threads":
+        monkeypatch.setenv("GF_FAM_FWD_MFMA", "0")
+        monkeypatch.setenv("GF_FAM_BWD_MFMA", "0")
     rng = np.random.default_rng(5050 + K)
     B, N, C = 3, 24, 32
     P = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
@@ -108,6 +114,37 @@ def test_cfg5_shape_one_graph_vs_oracle_spec_form(gf, oracle, monkeypatch, K, ld
     dP = host(gf.contract_backward(dev(G), dev(A), K))
     sub = [3, 30]
     for g in range(2):
+        ref_out = oracle.contract_forward(K, np.ascontiguousarray(P[g][..., sub]), A[g])
+        assert rel_err_slices(out[g][..., sub], ref_out) <= REL_TOL_F32, g
+        ref_dp = oracle.contract_backward(K, np.ascontiguousarray(G[g][..., sub]), A[g])
+        assert rel_err(dP[g][..., sub], ref_dp) <= REL_TOL_F32, g
+
+
+@pytest.mark.parametrize("N,C", [(1, 32), (2, 32), (7, 32), (15, 64), (16, 32), (17, 96), (23, 32), (25, 64), (31, 32), (32, 64)])
+def test_r50_matrix_pipe_kernels_vs_thread_kernels_and_oracle(gf, oracle, monkeypatch, N, C):
+    """fam50_forward_mfma / fam50_bwd_tables_mfma (C % 32 == 0, N <= 32; wave per (graph, row, 32-channel window), z steps of two
+    with odd and even N, padded accumulator rows, all three z-step instantiations) against the thread-per-element kernels on
+    the whole batch and against the oracle's spec form (RisiContraction_50.h:94-430) on two channels of every graph."""
+    K, B = 50, 3
+    rng = np.random.default_rng(50000 + 100 * N + C)
+    P = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
+    A = np.stack([adjacency(k, N, rng) for k in ("signed", "weighted", "sym01")])
+    G = f32exact(rng.uniform(-1, 1, (B, N, N, K, C)))
+    d0 = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
+    out = host(gf.contract_forward(dev(P), dev(A), K))
+    dP = host(gf.contract_backward(dev(G), dev(A), K))
+    da = dev(d0)
+    gf.contract_backward(dev(G), dev(A), K, dP=da, accumulate=True)
+    monkeypatch.setenv("GF_FAM_FWD_MFMA", "0")
+    monkeypatch.setenv("GF_FAM_BWD_MFMA", "0")
+    out_t = host(gf.contract_forward(dev(P), dev(A), K))
+    dP_t = host(gf.contract_backward(dev(G), dev(A), K))
+    for g in range(B):
+        assert rel_err_slices(out[g], out_t[g]) <= REL_TOL_F32, g
+        assert rel_err(dP[g], dP_t[g]) <= REL_TOL_F32, g
+        assert rel_err(host(da)[g], dP_t[g] + d0[g]) <= REL_TOL_F32, g
+    sub = [0, C - 1] if N > 12 else list(range(0, C, max(1, C // 8)))
+    for g in range(B if N <= 17 else 1):
         ref_out = oracle.contract_forward(K, np.ascontiguousarray(P[g][..., sub]), A[g])
         assert rel_err_slices(out[g][..., sub], ref_out) <= REL_TOL_F32, g
         ref_dp = oracle.contract_backward(K, np.ascontiguousarray(G[g][..., sub]), A[g])
