@@ -196,6 +196,76 @@ __global__ void fam_tables(const float *__restrict__ P, const float *__restrict_
     }
 }
 
+// RisiContraction_50, C % 4 == 0, with fam50_forward_mfma<.., true>: the same pass over P, but
+//   * only the three plain marginals go to the workspace (the adjacency products read their rows and columns); the nine weighted
+//     tables ARE output slices (11, 12, 41 | 14, 15, 42 | 23, 24, 45) and the six slices S tot, S tr (1, 13 | 2, 16 | 5, 25) are one
+//     multiply away: all fifteen are written straight into Out -- the workspace round trip of nine tables (0.34 GB per cfg5 step)
+//     is gone and the output kernel has no table to load for its plain slices;
+//   * UNR steps of the walk are loaded before any is used (3 UNR loads of 16 bytes in flight per thread), so the kernel keeps the
+//     memory system busy at a LOW occupancy -- the launch asks for enough LDS to hold it to a few workgroups per CU: the three
+//     roles of a graph's P (1.8 MB at cfg5) are read by consecutive workgroups of one XCD, and with about two graphs in flight
+//     per XCD instead of fourteen the second and third reads are L2 hits (P was fetched 2.25 x).
+template <int UNR>
+__global__ __launch_bounds__(256) void fam50_tables_out(const float *__restrict__ P, const float *__restrict__ adjs,
+                                                        float *__restrict__ tab, float *__restrict__ Out, int N, int C,
+                                                        size_t total) {
+    constexpr int K = 50;
+    const size_t NNC = (size_t)N * N * C;
+    const int CV = C / 4;
+    GRID_STRIDE(idx, total) {
+        const int f = (int)(idx % CV) * 4;
+        size_t t = idx / CV;
+        const int j = t % N;
+        t /= N;
+        const int i = t % N;
+        const size_t g = t / N;
+        const float *Pg = P + g * NNC * N + f;
+        const float *r = adjs + g * adjs_stride(N), *q = r + N, *dg = q + N, *st = dg + N;
+        vf4 acc[kNTab];
+#pragma unroll
+        for (int k = 0; k < kNTab; ++k) acc[k] = vf4{0.f, 0.f, 0.f, 0.f};
+        const float *pab0 = Pg + ((size_t)i * N + j) * N * C;   // + s C
+        const float *pac0 = Pg + (size_t)i * NNC + (size_t)j * C;   // + s N C
+        const float *pbc0 = Pg + ((size_t)i * N + j) * C;       // + s N N C
+        for (int s0 = 0; s0 < N; s0 += UNR) {
+            vf4 pab[UNR], pac[UNR], pbc[UNR];
+            float ok[UNR], rs[UNR], qs[UNR], ds[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const bool in = s0 + u < N;
+                const int sc = in ? s0 + u : N - 1;   // (clamped re-read, weights 0)
+                pab[u] = Vec<4>::ld(pab0 + (size_t)sc * C);
+                pac[u] = Vec<4>::ld(pac0 + (size_t)sc * N * C);
+                pbc[u] = Vec<4>::ld(pbc0 + (size_t)sc * NNC);
+                ok[u] = in ? 1.f : 0.f;
+                rs[u] = in ? r[sc] : 0.f;
+                qs[u] = in ? q[sc] : 0.f;
+                ds[u] = in ? dg[sc] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                acc[0] += pab[u] * ok[u];  acc[1] += pac[u] * ok[u];  acc[2] += pbc[u] * ok[u];
+                acc[3] += pab[u] * rs[u];  acc[4] += pab[u] * qs[u];  acc[5] += pab[u] * ds[u];
+                acc[6] += pac[u] * rs[u];  acc[7] += pac[u] * qs[u];  acc[8] += pac[u] * ds[u];
+                acc[9] += pbc[u] * rs[u];  acc[10] += pbc[u] * qs[u]; acc[11] += pbc[u] * ds[u];
+            }
+        }
+        const float tot = st[0], tr = st[1];
+        float *tg = tab + g * kNTab * NNC + ((size_t)i * N + j) * C + f;
+        Vec<4>::st(tg + 0 * NNC, acc[0]);
+        Vec<4>::st(tg + 1 * NNC, acc[1]);
+        Vec<4>::st(tg + 2 * NNC, acc[2]);
+        float *o = Out + (((size_t)g * N + i) * N + j) * (size_t)(K * C) + f;
+#define OUTS(c, expr) Vec<4>::st(o + (size_t)((c) - 1) * C, (expr))
+        OUTS(1, acc[0] * tot);  OUTS(2, acc[1] * tot);  OUTS(5, acc[2] * tot);
+        OUTS(11, acc[3]);       OUTS(12, acc[4]);       OUTS(13, acc[0] * tr);
+        OUTS(14, acc[6]);       OUTS(15, acc[7]);       OUTS(16, acc[1] * tr);
+        OUTS(23, acc[9]);       OUTS(24, acc[10]);      OUTS(25, acc[2] * tr);
+        OUTS(41, acc[5]);       OUTS(42, acc[8]);       OUTS(45, acc[11]);
+#undef OUTS
+    }
+}
+
 // single-index vectors and scalars, vec[g][6][N][C] then sc[g][5][C] (written by the threads with i == 0):
 //   vec 0 s_a[i] = sum_b S_ab[i,b]   1 s_b[i] = sum_a S_ab[a,i]   2 s_c[i] = sum_b S_bc[b,i]
 //       3 v_bb[i] = sum_b P[i,b,b]   4 v_aba[i] = sum_a P[a,i,a]  5 v_aac[i] = sum_a P[a,a,i]
@@ -485,7 +555,7 @@ __device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, unsigned voff, uns
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
 
-template <int NS>  // N <= 2 NS
+template <int NS, bool SLIM>  // N <= 2 NS; SLIM: fam50_tables_out has written the fifteen slices that are tables already
 __global__ __launch_bounds__(256, 2) void fam50_forward_mfma(const float *__restrict__ P, const float *__restrict__ A,
                                                              const float *__restrict__ adjs, const float *__restrict__ tab,
                                                              const float *__restrict__ vec, const float *__restrict__ sc,
@@ -522,18 +592,22 @@ __global__ __launch_bounds__(256, 2) void fam50_forward_mfma(const float *__rest
             const unsigned y = (unsigned)row_of(v);
             const unsigned yc = y < uN ? y : 0u;
             const unsigned tY = y < uN ? (((unsigned)x * uN + y) * uC + (unsigned)f) * 4u : kOob;
+            (void)tY;
             const float ry = r[yc], qy = q[yc], axy = Ag[x * N + (int)yc];
-            float t[kNTab];
-#pragma unroll
-            for (int k = 0; k < kNTab; ++k) t[k] = bld(rT, tY, (unsigned)k * NNC * 4u);
 #define OUTS(c, expr) bst(rO, oY[v], (unsigned)((c) - 1) * uC * 4u, (expr))
-            OUTS(1, t[0] * tot);  OUTS(2, t[1] * tot);  OUTS(3, va * ry);   OUTS(4, va * qy);   OUTS(5, t[2] * tot);
-            OUTS(6, vb * ry);     OUTS(7, vb * qy);     OUTS(8, vc * ry);   OUTS(9, vc * qy);   OUTS(10, s0 * axy);
-            OUTS(11, t[3]);       OUTS(12, t[4]);       OUTS(13, t[0] * tr); OUTS(14, t[6]);    OUTS(15, t[7]);
-            OUTS(16, t[1] * tr);  OUTS(17, vbb * ry);   OUTS(20, vbb * qy); OUTS(23, t[9]);     OUTS(24, t[10]);
-            OUTS(25, t[2] * tr);  OUTS(26, vaba * ry);  OUTS(29, vaba * qy); OUTS(32, vaac * ry); OUTS(35, vaac * qy);
-            OUTS(38, s1 * axy);   OUTS(39, s2 * axy);   OUTS(40, s3 * axy); OUTS(41, t[5]);     OUTS(42, t[8]);
-            OUTS(45, t[11]);      OUTS(50, s4 * axy);
+            if (!SLIM) {
+                float t[kNTab];
+#pragma unroll
+                for (int k = 0; k < kNTab; ++k) t[k] = bld(rT, tY, (unsigned)k * NNC * 4u);
+                OUTS(1, t[0] * tot);  OUTS(2, t[1] * tot);  OUTS(5, t[2] * tot);
+                OUTS(11, t[3]);       OUTS(12, t[4]);       OUTS(13, t[0] * tr); OUTS(14, t[6]);    OUTS(15, t[7]);
+                OUTS(16, t[1] * tr);  OUTS(23, t[9]);       OUTS(24, t[10]);     OUTS(25, t[2] * tr);
+                OUTS(41, t[5]);       OUTS(42, t[8]);       OUTS(45, t[11]);
+            }
+            OUTS(3, va * ry);     OUTS(4, va * qy);     OUTS(6, vb * ry);     OUTS(7, vb * qy);     OUTS(8, vc * ry);
+            OUTS(9, vc * qy);     OUTS(10, s0 * axy);   OUTS(17, vbb * ry);   OUTS(20, vbb * qy);   OUTS(26, vaba * ry);
+            OUTS(29, vaba * qy);  OUTS(32, vaac * ry);  OUTS(35, vaac * qy);  OUTS(38, s1 * axy);   OUTS(39, s2 * axy);
+            OUTS(40, s3 * axy);   OUTS(50, s4 * axy);
 #undef OUTS
             if ((v & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four rows of loads in flight, not sixteen)
         }
@@ -885,7 +959,8 @@ __global__ __launch_bounds__(256) void fam_bwd_tables_lds(const float *__restric
 template <int NS, int ROLE>  // N <= 2 NS
 __global__ __launch_bounds__(256, 3) void fam50_bwd_tables_mfma(const float *__restrict__ G, const float *__restrict__ A,
                                                                 const float *__restrict__ adjs, const float *__restrict__ bsc,
-                                                                float *__restrict__ btab, int N, int C, unsigned nwaves) {
+                                                                float *__restrict__ btab, float *__restrict__ bpart, int N, int C,
+                                                                unsigned nwaves) {
     constexpr int K = 50;
     const int lane = threadIdx.x & 63, hi = lane >> 5, m = lane & 31;
     const unsigned wid = (unsigned)xcd_block() * 4 + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -953,6 +1028,24 @@ __global__ __launch_bounds__(256, 3) void fam50_bwd_tables_mfma(const float *__r
         col_table(0, wsum(6, 7), 27, 30);
         col_table(1, wsum(8, 9), 33, 36);
         col_table(2, 0.f, 34, 37);
+        // row x of the five per-graph scalars u_c = sum_{d,e} G_c[d, e] A[d, e] (cases 10, 38, 39, 40, 50): bpart[g][x][5][C], folded
+        // over x by fam50_bwd_scalars_fold before the row launch (fam_bwd_scalars read these slices in a launch of its own)
+        float ax[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int z = 2 * t + hi;
+            const float a = Ag[x * N + (z < N ? z : 0)];
+            ax[t] = z < N ? a : 0.f;
+        }
+        constexpr int ucase[5] = {10, 38, 39, 40, 50};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float w = 0.f;
+#pragma unroll
+            for (int t = 0; t < NS; ++t) w += ld(ucase[j], t) * ax[t];
+            w = dev::xor32_sum(w);
+            if (hi == 0) bpart[((g * N + x) * 5 + j) * (size_t)C + f] = w;
+        }
     } else {
         const float tot = st[0], tr = st[1];
         const float *u = bsc + g * 5 * (size_t)C + f;
@@ -1036,7 +1129,7 @@ __global__ void fam_backward(const float *__restrict__ G, const float *__restric
 // registers and walks c.  The (b,c)-indexed terms (X_bc and the slices of cases 23, 24, 45: four global loads per output with one
 // a per workgroup, N x the bytes of those tables through L2 -- the kernel's bound at cfg5) are loaded once per c and serve the AB
 // rows a of the workgroup.
-template <int K, int VW, int AB>
+template <int K, int VW, int AB, int CU = 1>   // CU: iterations of the walk over c unrolled (their loads are issued together)
 __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict__ G, const float *__restrict__ adjs,
                                                          const float *__restrict__ bsc, const float *__restrict__ btab,
                                                          float *__restrict__ dP, int N, int C, int accumulate,
@@ -1089,6 +1182,7 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
                 zac[m] = Vec<VW>::ld(bt + 4 * NNC + ((size_t)b * N + a) * C + f);   // applies at c == a
             }
         }
+#pragma unroll CU
         for (int c = 0; c < N; ++c) {
             V xbc = Vec<VW>::ld(bt + 2 * NNC + ((size_t)b * N + c) * C + f);
             if (jt && K == 50) xbc += Vec<VW>::ld(bt + 8 * NNC + ((size_t)c * N + b) * C + f);
@@ -1123,6 +1217,85 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
 #undef GCF
 }
 
+// The same combination with the roles of b and c exchanged (round 3): a thread owns (c, channel quad) and walks b.  Everything
+// indexed (a, c) -- X_ac, the slices of cases 14, 15, 42, and the diagonal tables Z_bc[a, c], Z_ab[c, a] -- is then a per-thread
+// constant and lives in REGISTERS for the AB rows a of the workgroup: no LDS image, no barrier, no idle wave (fam_backward_rows
+// stages those rows in 24 KB of LDS per a and leaves a quarter of its threads without a column at cfg5), and the occupancy is
+// bounded by registers alone.  Per b a thread loads the four (b, c)-indexed values (coalesced: row b of X_bc and of the slices of
+// cases 23, 24, 45, shared by the AB rows) and the (a, b)-indexed ones (one 128-byte line per table for the whole wave).
+template <int K, int AB>
+__global__ __launch_bounds__(256) void fam_backward_cols(const float *__restrict__ G, const float *__restrict__ adjs,
+                                                         const float *__restrict__ bsc, const float *__restrict__ btab,
+                                                         float *__restrict__ dP, int N, int C, int accumulate) {
+    using V = vf4;
+    const size_t NNC = (size_t)N * N * C;
+    const size_t blk = xcd_block();
+    const int na = (N + AB - 1) / AB;
+    const size_t g = blk / na;
+    const int a0 = (int)(blk % na) * AB;
+    const float *bt = btab + g * kNBTab * NNC;
+    const float *Gg = G + g * (size_t)N * N * K * C;
+    const float *r = adjs + g * adjs_stride(N), *q = r + N, *dg = q + N;
+    const int CV = C / 4, items = N * CV;
+#define GCF(cs, x, y, f) Vec<4>::ld(Gg + (((size_t)(x) * N + (y)) * K + slot<K>(cs)) * C + (f))
+#define BTF(k, x, y, f) Vec<4>::ld(bt + (k) * NNC + ((size_t)(x) * N + (y)) * C + (f))
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int c = it / CV, f = (it % CV) * 4;
+        const V z4 = {0.f, 0.f, 0.f, 0.f};
+        V xac[AB], g14[AB], g15[AB], g42[AB], zbc[AB], zab[AB];
+        float ra[AB], qa[AB], dga[AB];
+        int aa[AB];
+        const float rc = r[c], qc = q[c], dgc = dg[c];
+        V u50 = z4;
+        if (K == 50) u50 = Vec<4>::ld(bsc + g * 5 * (size_t)C + 4 * C + f);
+#pragma unroll
+        for (int m = 0; m < AB; ++m) {
+            const int a = aa[m] = (a0 + m < N) ? a0 + m : N - 1;   // (rows past the end: a clamped copy, never stored)
+            xac[m] = BTF(1, a, c, f);
+            g14[m] = g15[m] = g42[m] = zbc[m] = zab[m] = z4;
+            ra[m] = r[a], qa[m] = q[a], dga[m] = dg[a];
+            if (K == 50) {
+                g14[m] = GCF(14, a, c, f);
+                g15[m] = GCF(15, a, c, f);
+                g42[m] = GCF(42, a, c, f);
+                zbc[m] = BTF(3, a, c, f);   // Z_bc[a, b]: applies at b == c
+                zab[m] = BTF(5, c, a, f);   // Z_ab[c, a]: applies at a == b
+            }
+        }
+        for (int b = 0; b < N; ++b) {
+            const V xbc = BTF(2, b, c, f);
+            V g23 = z4, g24 = z4, g45 = z4;
+            float rb = 0.f, qb = 0.f, dgb = 0.f;
+            if (K == 50) {
+                g23 = GCF(23, b, c, f), g24 = GCF(24, b, c, f), g45 = GCF(45, b, c, f);
+                rb = r[b], qb = q[b], dgb = dg[b];
+            }
+#pragma unroll
+            for (int m = 0; m < AB; ++m) {
+                const int a = aa[m];
+                V v = BTF(0, a, b, f) + xac[m] + xbc;
+                if (K == 50) {
+                    v += GCF(11, a, b, f) * rc + GCF(12, a, b, f) * qc + GCF(41, a, b, f) * dgc;
+                    v += g14[m] * rb + g15[m] * qb + g42[m] * dgb;
+                    v += g23 * ra[m] + g24 * qa[m] + g45 * dga[m];
+                    const V zac = BTF(4, b, a, f);   // Z_ac[b, a]: applies at a == c
+                    if (b == c) v += zbc[m];
+                    if (a == c) v += zac;
+                    if (a == b) v += zab[m];
+                    if (a == b && b == c) v += u50;
+                }
+                if (a0 + m < N) {
+                    float *out = dP + ((g * N + a) * N + b) * (size_t)N * C + (size_t)c * C + f;
+                    if (accumulate) v += Vec<4>::ld(out);
+                    Vec<4>::st(out, v);
+                }
+            }
+        }
+    }
+#undef GCF
+#undef BTF
+}
+
 struct FamWs {
     float *adjs, *tab, *vec, *sc;
 };
@@ -1149,27 +1322,50 @@ gf_status fam_forward_launch(gf_ctx *ctx, const float *P, const float *A, float 
     const size_t nn = (size_t)batch * N * N * C, nv = (size_t)batch * N * C, ns = (size_t)batch * C;
     GF_LAUNCH(ctx, "fam_adj", fam_adj, dim3(batch), dim3(64), 0, A, w.adjs, N);
     const bool vec = C % 4 == 0 && (((uintptr_t)P | (uintptr_t)Out | (uintptr_t)w.tab) & 15) == 0;
-    if (vec)
+    bool mfma_out = false, slim = false;
+    if constexpr (K == 50) {
+        // all fifty slices of a row from one wave, the adjacency products on the matrix pipe (GF_FAM_FWD_MFMA=0: the two kernels below);
+        // GF_FAM_FWD_SLIM=0: the twelve tables go through the workspace and the output kernel writes all fifty slices
+        const char *e = std::getenv("GF_FAM_FWD_MFMA"), *e2 = std::getenv("GF_FAM_FWD_SLIM");
+        mfma_out = C % 32 == 0 && N <= 32 && (size_t)batch * N * (C / 32) < 0x7fffffffu && (size_t)N * N * N * C < (1u << 29) && !(e && e[0] == '0');   // (buffer descriptors of a graph's P and tables stay under 2 GB)
+        slim = mfma_out && vec && !(e2 && e2[0] == '0');
+    }
+    if (slim) {
+        if constexpr (K == 50) {
+            // occupancy held down by an LDS request (GF_FAM_TAB_LDS_KB per workgroup, default 40: four workgroups per CU)
+            const char *e = std::getenv("GF_FAM_TAB_LDS_KB"), *eu = std::getenv("GF_FAM_TAB_UNR");
+            const size_t lds = (size_t)(e ? std::atoi(e) : 40) * 1024;
+            const int unr = eu ? std::atoi(eu) : 8;
+            if (unr == 4) {
+                st = opt_in_lds(ctx, fam50_tables_out<4>, lds);
+                if (st != GF_OK) return st;
+                GF_LAUNCH(ctx, "fam_tables", (fam50_tables_out<4>), dim3(grid_for(nn / 4)), dim3(256), lds, P, w.adjs, w.tab, Out, N, C, nn / 4);
+            } else {
+                st = opt_in_lds(ctx, fam50_tables_out<8>, lds);
+                if (st != GF_OK) return st;
+                GF_LAUNCH(ctx, "fam_tables", (fam50_tables_out<8>), dim3(grid_for(nn / 4)), dim3(256), lds, P, w.adjs, w.tab, Out, N, C, nn / 4);
+            }
+        }
+    } else if (vec)
         GF_LAUNCH(ctx, "fam_tables", (fam_tables<K, 4>), dim3(grid_for(nn / 4)), dim3(256), 0, P, w.adjs, w.tab, N, C, nn / 4);
     else
         GF_LAUNCH(ctx, "fam_tables", (fam_tables<K, 1>), dim3(grid_for(nn)), dim3(256), 0, P, w.adjs, w.tab, N, C, nn);
     GF_LAUNCH(ctx, "fam_vectors", fam_vectors, dim3(grid_for(nv)), dim3(256), 0, P, w.tab, w.vec, w.sc, N, C, nv);
     GF_LAUNCH(ctx, "fam_scalars", fam_scalars, dim3(grid_for(ns)), dim3(256), 0, P, w.vec, w.sc, N, C, ns);
     const size_t prod_lds = sizeof(float) * ((size_t)9 * N * C + (size_t)N * N);
-    bool mfma_out = false;
     if constexpr (K == 50) {
-        // all fifty slices of a row from one wave, the adjacency products on the matrix pipe (GF_FAM_FWD_MFMA=0: the two kernels below)
-        const char *e = std::getenv("GF_FAM_FWD_MFMA");
-        mfma_out = C % 32 == 0 && N <= 32 && (size_t)batch * N * (C / 32) < 0x7fffffffu && (size_t)N * N * N * C < (1u << 29) && !(e && e[0] == '0');   // (buffer descriptors of a graph's P and tables stay under 2 GB)
         if (mfma_out) {
             const unsigned nw = (unsigned)((size_t)batch * N * (C / 32));
             const dim3 grid((nw + 3) / 4), block(256);
-            if (N <= 16)
-                GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<8>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);
-            else if (N <= 24)
-                GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<12>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);
-            else
-                GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<16>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);
+#define GF_FAM_OUT(NS)                                                                                                                    \
+    do {                                                                                                                                  \
+        if (slim)                                                                                                                         \
+            GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<NS, true>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);  \
+        else                                                                                                                              \
+            GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<NS, false>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw); \
+    } while (0)
+            if (N <= 16) GF_FAM_OUT(8); else if (N <= 24) GF_FAM_OUT(12); else GF_FAM_OUT(16);
+#undef GF_FAM_OUT
         }
     }
     if (mfma_out) {
@@ -1196,6 +1392,18 @@ gf_status fam_forward_launch(gf_ctx *ctx, const float *P, const float *A, float 
     return GF_OK;
 }
 
+// bsc[g][5][C] = sum_x bpart[g][x][5][C], in the order of x
+__global__ void fam50_bwd_scalars_fold(const float *__restrict__ bpart, float *__restrict__ bsc, int N, int C, size_t total) {
+    GRID_STRIDE(idx, total) {
+        const size_t g = idx / (5 * (size_t)C), jf = idx % (5 * (size_t)C);
+        float sum = 0.f;
+        for (int x = 0; x < N; ++x) sum += bpart[(g * N + x) * 5 * (size_t)C + jf];
+        bsc[idx] = sum;
+    }
+}
+
+static inline bool mfma_tables_jt(int cwin) { return cwin > 0; }   // the LDS-staged tables kernel leaves transposed partials only fam_backward_rows adds
+
 template <int K>
 gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float *dP, int N, int C, int batch,
                               int accumulate) {
@@ -1205,7 +1413,16 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     const size_t nn = (size_t)batch * N * N * C, np = nn * N;
     const bool vec = C % 4 == 0 && (((uintptr_t)G | (uintptr_t)dP | (uintptr_t)w.tab | (uintptr_t)w.sc) & 15) == 0;
     GF_LAUNCH(ctx, "fam_adj", fam_adj, dim3(batch), dim3(64), 0, A, w.adjs, N);
-    GF_LAUNCH(ctx, "fam_bwd_scalars", fam_bwd_scalars<K>, dim3(batch * 5), dim3(256), 0, G, A, w.sc, N, C);
+    bool mfma_tables = false;
+    if constexpr (K == 50) {
+        // matrix-pipe tables (every G row read once, no LDS): C in whole 32-channel windows, N <= 32.  GF_FAM_BWD_MFMA=0: the
+        // thread-per-(i, columns, f) kernel below
+        const char *e = std::getenv("GF_FAM_BWD_MFMA"), *el = std::getenv("GF_FAM_BWD_LDS");
+        mfma_tables = C % 32 == 0 && N <= 32 && (size_t)batch * N * (C / 32) < 0x7fffffffu && (size_t)N * N * K * C < (1u << 28) &&
+                      !(e && e[0] == '0') && !(el && el[0] == '1');
+    }
+    if (!mfma_tables)   // (the matrix-pipe column launch leaves per-row partials of these scalars instead)
+        GF_LAUNCH(ctx, "fam_bwd_scalars", fam_bwd_scalars<K>, dim3(batch * 5), dim3(256), 0, G, A, w.sc, N, C);
     // (measured at cfg5: the 16-byte variant of the TABLES kernel is slower -- with four channels per thread only two columns fit
     //  in registers and the shared (i,z) operands are re-read three times as often -- so it keeps one channel per thread, two rows
     //  x six columns; the rows kernel below takes 16-byte lanes)
@@ -1223,19 +1440,16 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
         //  slices per z -- 0.56 ms against 0.40 ms for fam_bwd_tables, and fam_backward_rows pays 0.11 ms for the transposed halves)
         if (sizeof(float) * 4 * (size_t)N * C > 48 * 1024 || (size_t)batch * N >= 0x7fffffffu) cwin = 0;  // (only fam_backward_rows adds the halves)
     }
-    bool mfma_tables = false;
     if constexpr (K == 50) {
-        // matrix-pipe tables (every G row read once, no LDS): C in whole 32-channel windows, N <= 32.  GF_FAM_BWD_MFMA=0: the
-        // thread-per-(i, columns, f) kernel below
-        const char *e = std::getenv("GF_FAM_BWD_MFMA");
-        mfma_tables = C % 32 == 0 && N <= 32 && (size_t)batch * N * (C / 32) < 0x7fffffffu && (size_t)N * N * K * C < (1u << 28) && !(e && e[0] == '0') && cwin == 0;
         if (mfma_tables) {
             const unsigned nw = (unsigned)((size_t)batch * N * (C / 32));
             const dim3 grid((nw + 3) / 4), block(256);
+            const size_t nsc = (size_t)batch * 5 * C;
 #define GF_FAM_MFMA(NS)                                                                                                            \
     do {                                                                                                                           \
-        GF_LAUNCH(ctx, "fam_bwd_tables", (fam50_bwd_tables_mfma<NS, 0>), grid, block, 0, G, A, w.adjs, w.sc, w.tab, N, C, nw);     \
-        GF_LAUNCH(ctx, "fam_bwd_tables", (fam50_bwd_tables_mfma<NS, 1>), grid, block, 0, G, A, w.adjs, w.sc, w.tab, N, C, nw);     \
+        GF_LAUNCH(ctx, "fam_bwd_tables", (fam50_bwd_tables_mfma<NS, 0>), grid, block, 0, G, A, w.adjs, w.sc, w.tab, w.vec, N, C, nw); \
+        GF_LAUNCH(ctx, "fam_bwd_scalars", fam50_bwd_scalars_fold, dim3(grid_for(nsc)), dim3(256), 0, w.vec, w.sc, N, C, nsc);      \
+        GF_LAUNCH(ctx, "fam_bwd_tables", (fam50_bwd_tables_mfma<NS, 1>), grid, block, 0, G, A, w.adjs, w.sc, w.tab, w.vec, N, C, nw); \
     } while (0)
             if (N <= 16) GF_FAM_MFMA(8); else if (N <= 24) GF_FAM_MFMA(12); else GF_FAM_MFMA(16);
 #undef GF_FAM_MFMA
@@ -1273,7 +1487,26 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
         }
     }
     const size_t row_lds = sizeof(float) * 4 * (size_t)N * C;
-    if (row_lds <= 48 * 1024 && (size_t)batch * N < 0x7fffffffu) {
+    // opt-in (GF_FAM_BWD_COLS=1; GF_FAM_COLS_AB: rows a per workgroup, 1 / 2 / 4): thread per (c, channel quad) walking b, the
+    // (a, c)-indexed terms in registers.  Measured at cfg5: 0.228 ms against 0.215 ms for the LDS-staged rows kernel below (four rows
+    // per workgroup: 0.45 ms) -- neither the LDS image nor the occupancy bounds this combination
+    const char *ecols = std::getenv("GF_FAM_BWD_COLS");
+    if (vec && !mfma_tables_jt(cwin) && (size_t)batch * N < 0x7fffffffu && ecols && ecols[0] == '1') {
+        const char *eab = std::getenv("GF_FAM_COLS_AB");
+        const int ab = eab ? std::atoi(eab) : 2;
+        const unsigned items = (unsigned)(N * (C / 4));
+        const unsigned threads = items >= 256 ? 256u : (items + 63) / 64 * 64;
+        if (ab == 4) {
+            const unsigned nb = (unsigned)((size_t)batch * ((N + 3) / 4));
+            GF_LAUNCH(ctx, "fam_backward", (fam_backward_cols<K, 4>), dim3(nb), dim3(threads), 0, G, w.adjs, w.sc, w.tab, dP, N, C, accumulate);
+        } else if (ab == 1) {
+            const unsigned nb = (unsigned)((size_t)batch * N);
+            GF_LAUNCH(ctx, "fam_backward", (fam_backward_cols<K, 1>), dim3(nb), dim3(threads), 0, G, w.adjs, w.sc, w.tab, dP, N, C, accumulate);
+        } else {
+            const unsigned nb = (unsigned)((size_t)batch * ((N + 1) / 2));
+            GF_LAUNCH(ctx, "fam_backward", (fam_backward_cols<K, 2>), dim3(nb), dim3(threads), 0, G, w.adjs, w.sc, w.tab, dP, N, C, accumulate);
+        }
+    } else if (row_lds <= 48 * 1024 && (size_t)batch * N < 0x7fffffffu) {
         // rows a per workgroup (GF_FAM_BWD_AB overrides): two while their staged rows fit 64 KB and the grid still fills the part
         // (cfg5: 0.30 / 0.25 / 0.28 ms at one / two / four)
         int ab = (2 * row_lds <= 64 * 1024 && (size_t)batch * ((N + 1) / 2) >= 1024) ? 2 : 1;
@@ -1291,7 +1524,19 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     } while (0)
         const char *ev = std::getenv("GF_FAM_ROWS_VW");
         if (vec && !(ev && ev[0] == '1')) {  // (16-byte lanes: 0.26 -> 0.23 ms at cfg5; GF_FAM_ROWS_VW=1 keeps one channel per thread)
-            if (ab == 4) GF_FAM_ROWS(4, 4); else if (ab == 2) GF_FAM_ROWS(4, 2); else GF_FAM_ROWS(4, 1);
+            const char *ecu = std::getenv("GF_FAM_ROWS_CU");
+            const int cu = ecu ? std::atoi(ecu) : 1;
+            if (ab == 2 && (cu == 2 || cu == 4)) {
+                if (cu == 2) {
+                    st = opt_in_lds(ctx, (fam_backward_rows<K, 4, 2, 2>), 2 * row_lds);
+                    if (st != GF_OK) return st;
+                    GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, 4, 2, 2>), dim3(nb), dim3(256), 2 * row_lds, G, w.adjs, w.sc, w.tab, dP, N, C, accumulate, jt);
+                } else {
+                    st = opt_in_lds(ctx, (fam_backward_rows<K, 4, 2, 4>), 2 * row_lds);
+                    if (st != GF_OK) return st;
+                    GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, 4, 2, 4>), dim3(nb), dim3(256), 2 * row_lds, G, w.adjs, w.sc, w.tab, dP, N, C, accumulate, jt);
+                }
+            } else if (ab == 4) GF_FAM_ROWS(4, 4); else if (ab == 2) GF_FAM_ROWS(4, 2); else GF_FAM_ROWS(4, 1);
         } else {
             if (ab == 4) GF_FAM_ROWS(1, 4); else if (ab == 2) GF_FAM_ROWS(1, 2); else GF_FAM_ROWS(1, 1);
         }
