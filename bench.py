@@ -135,7 +135,7 @@ def setup_contraction(workload, args, torch, gf, dev, world, rank, ctx):
         fwd_b, bwd_b = contraction_bytes(K, N, C)
         if not timers:
             return {"note": "per-kernel timing disabled"}
-        per = {k: v[0] / max(v[1], 1) for k, v in timers.items()}
+        per = {k: v[0] / max(steps, 1) for k, v in timers.items()}   # ms per STEP under that launch name (fam_adj runs in both calls)
         dom = max(timers, key=lambda k: timers[k][0])
         is_bwd = ("bwd" in dom) or ("backward" in dom)
         fwd_ms = sum(v for k, v in per.items() if not (("bwd" in k) or ("backward" in k)))

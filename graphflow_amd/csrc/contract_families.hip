@@ -1028,6 +1028,9 @@ __global__ __launch_bounds__(256, 3) void fam50_bwd_tables_mfma(const float *__r
         col_table(0, wsum(6, 7), 27, 30);
         col_table(1, wsum(8, 9), 33, 36);
         col_table(2, 0.f, 34, 37);
+        // (measured: the three diagonal tables in THIS launch, their scalars added by the combination kernel -- 27 slices here, 14 in
+        //  the row launch -- 0.165 + 0.098 ms against 0.108 + 0.127; this launch is the first reader after the forward's 0.9 GB of
+        //  writes and runs 0.03 ms slower than its own repeat)
         // row x of the five per-graph scalars u_c = sum_{d,e} G_c[d, e] A[d, e] (cases 10, 38, 39, 40, 50): bpart[g][x][5][C], folded
         // over x by fam50_bwd_scalars_fold before the row launch (fam_bwd_scalars read these slices in a launch of its own)
         float ax[NS];
@@ -1447,9 +1450,9 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
             const size_t nsc = (size_t)batch * 5 * C;
 #define GF_FAM_MFMA(NS)                                                                                                            \
     do {                                                                                                                           \
-        GF_LAUNCH(ctx, "fam_bwd_tables", (fam50_bwd_tables_mfma<NS, 0>), grid, block, 0, G, A, w.adjs, w.sc, w.tab, w.vec, N, C, nw); \
+        GF_LAUNCH(ctx, "fam_bwd_tables_col", (fam50_bwd_tables_mfma<NS, 0>), grid, block, 0, G, A, w.adjs, w.sc, w.tab, w.vec, N, C, nw); \
         GF_LAUNCH(ctx, "fam_bwd_scalars", fam50_bwd_scalars_fold, dim3(grid_for(nsc)), dim3(256), 0, w.vec, w.sc, N, C, nsc);      \
-        GF_LAUNCH(ctx, "fam_bwd_tables", (fam50_bwd_tables_mfma<NS, 1>), grid, block, 0, G, A, w.adjs, w.sc, w.tab, w.vec, N, C, nw); \
+        GF_LAUNCH(ctx, "fam_bwd_tables_row", (fam50_bwd_tables_mfma<NS, 1>), grid, block, 0, G, A, w.adjs, w.sc, w.tab, w.vec, N, C, nw); \
     } while (0)
             if (N <= 16) GF_FAM_MFMA(8); else if (N <= 24) GF_FAM_MFMA(12); else GF_FAM_MFMA(16);
 #undef GF_FAM_MFMA

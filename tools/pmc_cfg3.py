@@ -15,13 +15,17 @@ def launch_name(k):
     m = re.match(r"gf::smp_rowpanel_(?:c64|split)<(true|false)", k)
     if m:
         return "smpf_products_fwd" if m.group(1) == "true" else "smpf_products_bwd"
+    m = re.match(r"gf::fam50_bwd_tables_mfma<\d+, (\d)", k)
+    if m:
+        return "fam_bwd_tables_col" if m.group(1) == "0" else "fam_bwd_tables_row"
     base = re.sub(r"[<(].*", "", k).split("::")[-1]
     table = {"smp_tables_fwd": "smpf_tables_fwd", "smp_tables_fwd_w": "smpf_tables_fwd", "smp_tables_bwd": "smpf_tables_bwd",
              "smp_combine_fwd": "smpf_combine_fwd", "smp_combine_bwd": "smpf_combine_bwd", "promote_backward": "smp_promote_bwd",
              "smp_vectors": "smpf_vectors", "smp_bwd_gather": "smpf_bwd_gather", "smp_wgrad_c64": "smpf_wgrad", "smp_wgrad_split": "smpf_wgrad",
              "smp_reduce_pairs": "smpf_reduce_pairs", "smp_fold_level": "smpf_fold", "diag_gather_bwd": "smpf_diag_gather_bwd",
              "diag_gather_fwd": "smpf_diag_gather", "stack_weights_all": "smpf_stack_w", "readout_nodes_v": "smp_readout_nodes",
-             "fam_backward_rows": "fam_backward", "fam_products_lds": "fam_products"}
+             "fam_backward_rows": "fam_backward", "fam_backward_cols": "fam_backward", "fam_products_lds": "fam_products",
+             "fam50_tables_out": "fam_tables", "fam50_forward_mfma": "fam_forward", "fam50_bwd_scalars_fold": "fam_bwd_scalars"}
     return table.get(base, base)
 
 
