@@ -59,6 +59,28 @@ def contraction_fixtures(ref):
     return out
 
 
+def wide_contraction_fixtures(ref):
+    """RisiContraction_50 at channel counts that are multiples of 32: the shapes at which the HIP library runs its matrix-pipe
+    kernels (fam50_forward_mfma / fam50_bwd_tables_mfma: one wave per (graph, row, 32-channel window)); odd and even N, one and two
+    channel windows.  Same recipe as contraction_fixtures."""
+    out = {}
+    K = 50
+    for (N, C, kind) in [(5, 32, "signed"), (6, 32, "weighted"), (3, 64, "signed")]:
+        rng = np.random.default_rng(1000 * K + 10 * N + C)
+        P = f32exact(rng.uniform(-1, 1, (N, N, N, C)))
+        G = f32exact(rng.uniform(0, 1, (N, N, K, C)))
+        dP0 = f32exact(rng.uniform(-1, 1, (N, N, N, C)))
+        A = adjacency(kind, N, rng)
+        tag = "r%d_N%d_C%d_%s" % (K, N, C, kind)
+        out[tag + "__P"] = P.astype(np.float32)
+        out[tag + "__G"] = G.astype(np.float32)
+        out[tag + "__dP0"] = dP0.astype(np.float32)
+        out[tag + "__A"] = A.astype(np.float32)
+        out[tag + "__Out"] = ref.contract_forward(K, P, A)
+        out[tag + "__dP"] = ref.contract_backward(K, G, A, dP0)
+    return out
+
+
 def dropout_fixtures(ref):
     """RisiContraction_18_dropout: the reference draws the kept slices itself after srand(seed); the fixture keeps the mask."""
     out = {}
@@ -402,6 +424,7 @@ def main():
     if ref is None:
         sys.exit("oracle/_ref/libgf_ref.so missing: needs /root/reference (build container only)")
     np.savez_compressed(os.path.join(HERE, "contractions.npz"), **contraction_fixtures(ref))
+    np.savez_compressed(os.path.join(HERE, "contractions_wide.npz"), **wide_contraction_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "mixers.npz"), **mixer_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "dropout.npz"), **dropout_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "smp.npz"), **smp_fixtures())
@@ -411,7 +434,7 @@ def main():
     headline_fixture()
     with open(os.path.join(HERE, "structural_50.json"), "w") as fh:
         json.dump(structural_50(), fh, indent=1)
-    for f in ("contractions.npz", "mixers.npz", "smp.npz", "structural_50.json", "smp_syn12_checkpoint.txt", "dropout.npz", "smp_train.npz", "smp_headline.npz", "smp_physics.npz"):
+    for f in ("contractions.npz", "contractions_wide.npz", "mixers.npz", "smp.npz", "structural_50.json", "smp_syn12_checkpoint.txt", "dropout.npz", "smp_train.npz", "smp_headline.npz", "smp_physics.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
@@ -420,6 +443,10 @@ if __name__ == "__main__":
         pyoracle.build()
         physics_fixtures()
         print("smp_physics.npz", os.path.getsize(os.path.join(HERE, "smp_physics.npz")), "bytes")
+    elif len(sys.argv) > 1 and sys.argv[1] == "wide":   # only the RisiContraction_50 fixtures at C % 32 == 0
+        pyoracle.build()
+        np.savez_compressed(os.path.join(HERE, "contractions_wide.npz"), **wide_contraction_fixtures(pyoracle.reference()))
+        print("contractions_wide.npz", os.path.getsize(os.path.join(HERE, "contractions_wide.npz")), "bytes")
     elif len(sys.argv) > 1 and sys.argv[1] == "headline":   # only the (slow) headline fixture
         pyoracle.build()
         headline_fixture()
