@@ -915,6 +915,14 @@ def test_no_kernel_reads_what_nobody_wrote():
     tail = (r.stdout + r.stderr)[-2000:]
     assert r.returncode == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
+    # the contraction families' workspace (pair tables, per-row partials of the scalars, the column launch's tables the row launch
+    # starts from): every word a kernel reads there must have been written by an earlier kernel of the same call
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_families_gpu.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "golden_vectors or matrix_pipe or cfg5_shape", "-p", "no:cacheprovider"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
 
 
 def test_zz_print_margins(gf):
