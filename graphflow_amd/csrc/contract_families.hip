@@ -1132,7 +1132,7 @@ __global__ void fam_backward(const float *__restrict__ G, const float *__restric
 // registers and walks c.  The (b,c)-indexed terms (X_bc and the slices of cases 23, 24, 45: four global loads per output with one
 // a per workgroup, N x the bytes of those tables through L2 -- the kernel's bound at cfg5) are loaded once per c and serve the AB
 // rows a of the workgroup.
-template <int K, int VW, int AB, int CU = 1>   // CU: iterations of the walk over c unrolled (their loads are issued together)
+template <int K, int VW, int AB>
 __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict__ G, const float *__restrict__ adjs,
                                                          const float *__restrict__ bsc, const float *__restrict__ btab,
                                                          float *__restrict__ dP, int N, int C, int accumulate,
@@ -1185,8 +1185,7 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
                 zac[m] = Vec<VW>::ld(bt + 4 * NNC + ((size_t)b * N + a) * C + f);   // applies at c == a
             }
         }
-#pragma unroll CU
-        for (int c = 0; c < N; ++c) {
+        for (int c = 0; c < N; ++c) {   // (measured: this walk unrolled by two / four, 0.221 / 0.250 ms against 0.217)
             V xbc = Vec<VW>::ld(bt + 2 * NNC + ((size_t)b * N + c) * C + f);
             if (jt && K == 50) xbc += Vec<VW>::ld(bt + 8 * NNC + ((size_t)c * N + b) * C + f);
             V g23 = Vec<VW>::zero(), g24 = g23, g45 = g23;
@@ -1527,19 +1526,7 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     } while (0)
         const char *ev = std::getenv("GF_FAM_ROWS_VW");
         if (vec && !(ev && ev[0] == '1')) {  // (16-byte lanes: 0.26 -> 0.23 ms at cfg5; GF_FAM_ROWS_VW=1 keeps one channel per thread)
-            const char *ecu = std::getenv("GF_FAM_ROWS_CU");
-            const int cu = ecu ? std::atoi(ecu) : 1;
-            if (ab == 2 && (cu == 2 || cu == 4)) {
-                if (cu == 2) {
-                    st = opt_in_lds(ctx, (fam_backward_rows<K, 4, 2, 2>), 2 * row_lds);
-                    if (st != GF_OK) return st;
-                    GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, 4, 2, 2>), dim3(nb), dim3(256), 2 * row_lds, G, w.adjs, w.sc, w.tab, dP, N, C, accumulate, jt);
-                } else {
-                    st = opt_in_lds(ctx, (fam_backward_rows<K, 4, 2, 4>), 2 * row_lds);
-                    if (st != GF_OK) return st;
-                    GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, 4, 2, 4>), dim3(nb), dim3(256), 2 * row_lds, G, w.adjs, w.sc, w.tab, dP, N, C, accumulate, jt);
-                }
-            } else if (ab == 4) GF_FAM_ROWS(4, 4); else if (ab == 2) GF_FAM_ROWS(4, 2); else GF_FAM_ROWS(4, 1);
+            if (ab == 4) GF_FAM_ROWS(4, 4); else if (ab == 2) GF_FAM_ROWS(4, 2); else GF_FAM_ROWS(4, 1);
         } else {
             if (ab == 4) GF_FAM_ROWS(1, 4); else if (ab == 2) GF_FAM_ROWS(1, 2); else GF_FAM_ROWS(1, 1);
         }
