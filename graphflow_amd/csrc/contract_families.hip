@@ -956,8 +956,14 @@ __global__ __launch_bounds__(256) void fam_bwd_tables_lds(const float *__restric
 // row pair through L1: 0.35 ms at cfg5, the longest kernel of that step.
 // ---------------------------------------------------------------------------------------------------------------
 
+#ifndef GF_FAM_BWD_OCC
+#define GF_FAM_BWD_OCC 3   // (4: 128 registers, six spills, 0.118 + 0.151 ms against 0.109 + 0.136)
+#endif
+#ifndef GF_FAM_BWD_SCHED_BARRIER
+#define GF_FAM_BWD_SCHED_BARRIER 1   // (0: the tables of a launch interleave -- measured 0.167 ms against 0.13 ms for the row launch)
+#endif
 template <int NS, int ROLE>  // N <= 2 NS
-__global__ __launch_bounds__(256, 3) void fam50_bwd_tables_mfma(const float *__restrict__ G, const float *__restrict__ A,
+__global__ __launch_bounds__(256, GF_FAM_BWD_OCC) void fam50_bwd_tables_mfma(const float *__restrict__ G, const float *__restrict__ A,
                                                                 const float *__restrict__ adjs, const float *__restrict__ bsc,
                                                                 float *__restrict__ btab, float *__restrict__ bpart, int N, int C,
                                                                 unsigned nwaves) {
@@ -1023,7 +1029,9 @@ __global__ __launch_bounds__(256, 3) void fam50_bwd_tables_mfma(const float *__r
             prod(acc, ca, ct);
 #pragma unroll
             for (int v = 0; v < 16; ++v) bst(rB, cY[v], (unsigned)tbl * NNC * 4u, acc[v]);
+#if GF_FAM_BWD_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);
+#endif
         };
         col_table(0, wsum(6, 7), 27, 30);
         col_table(1, wsum(8, 9), 33, 36);
@@ -1069,7 +1077,9 @@ __global__ __launch_bounds__(256, 3) void fam50_bwd_tables_mfma(const float *__r
             prod(acc, ca, ct);
 #pragma unroll
             for (int v = 0; v < 16; ++v) bst(rB, rY[v], (unsigned)tbl * NNC * 4u, acc[v]);
+#if GF_FAM_BWD_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);
+#endif
         };
         auto ztable = [&](int tbl, float add, int ca, int ct) {
             f16acc acc;
@@ -1078,7 +1088,9 @@ __global__ __launch_bounds__(256, 3) void fam50_bwd_tables_mfma(const float *__r
             prod(acc, ca, ct);
 #pragma unroll
             for (int v = 0; v < 16; ++v) bst(rB, rY[v], (unsigned)tbl * NNC * 4u, acc[v]);
+#if GF_FAM_BWD_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);
+#endif
         };
         xtable(0, 1, 13, u[0] + wsum(3, 4), 18, 21);
         xtable(1, 2, 16, 0.f, 19, 22);
@@ -1132,13 +1144,15 @@ __global__ void fam_backward(const float *__restrict__ G, const float *__restric
 // registers and walks c.  The (b,c)-indexed terms (X_bc and the slices of cases 23, 24, 45: four global loads per output with one
 // a per workgroup, N x the bytes of those tables through L2 -- the kernel's bound at cfg5) are loaded once per c and serve the AB
 // rows a of the workgroup.
-template <int K, int VW, int AB>
+template <int K, int VW, int AB, bool ACC>
 __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict__ G, const float *__restrict__ adjs,
                                                          const float *__restrict__ bsc, const float *__restrict__ btab,
-                                                         float *__restrict__ dP, int N, int C, int accumulate,
+                                                         float *__restrict__ dP, int N, int C,
                                                          int jt) {  // != 0: tables of fam_bwd_tables_lds (column-role partials 6..8)
     using V = typename Vec<VW>::T;
-    extern __shared__ __attribute__((aligned(16))) float srow[];  // [AB][4][N][C]: X_ac(a,c) | G14(a,c) | G15(a,c) | G42(a,c)
+    // [AB][5][N][C]: X_ac(a,c) | G14(a,c) | G15(a,c) | G42(a,c) | Z_ab(c,a)
+    extern __shared__ __attribute__((aligned(16))) float srow[];
+    constexpr int NT = 5;
     const size_t NNC = (size_t)N * N * C, NC = (size_t)N * C;
     const size_t blk = xcd_block();
     const int na = (N + AB - 1) / AB;
@@ -1152,7 +1166,7 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
     for (int it = threadIdx.x; it < AB * items; it += blockDim.x) {
         const int m = it / items, c = (it % items) / CV, f = (it % CV) * VW;
         const int a = (a0 + m < N) ? a0 + m : N - 1;  // (rows past the end: a clamped copy, never stored)
-        float *sr = srow + (size_t)m * 4 * NC + (size_t)c * C + f;
+        float *sr = srow + (size_t)m * NT * NC + (size_t)c * C + f;
         V xac = Vec<VW>::ld(bt + 1 * NNC + ((size_t)a * N + c) * C + f);
         if (jt) xac += Vec<VW>::ld(bt + 7 * NNC + ((size_t)c * N + a) * C + f);
         Vec<VW>::st(sr + 0 * NC, xac);
@@ -1160,6 +1174,7 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
             Vec<VW>::st(sr + 1 * NC, GCF(14, a, c, f));
             Vec<VW>::st(sr + 2 * NC, GCF(15, a, c, f));
             Vec<VW>::st(sr + 3 * NC, GCF(42, a, c, f));
+            Vec<VW>::st(sr + 4 * NC, Vec<VW>::ld(bt + 5 * NNC + ((size_t)c * N + a) * C + f));   // Z_ab[c, a]: applies at a == b
         }
     }
     __syncthreads();
@@ -1185,35 +1200,58 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
                 zac[m] = Vec<VW>::ld(bt + 4 * NNC + ((size_t)b * N + a) * C + f);   // applies at c == a
             }
         }
-        for (int c = 0; c < N; ++c) {   // (measured: this walk unrolled by two / four, 0.221 / 0.250 ms against 0.217)
-            V xbc = Vec<VW>::ld(bt + 2 * NNC + ((size_t)b * N + c) * C + f);
-            if (jt && K == 50) xbc += Vec<VW>::ld(bt + 8 * NNC + ((size_t)c * N + b) * C + f);
-            V g23 = Vec<VW>::zero(), g24 = g23, g45 = g23;
+        // The (b, c)-indexed operands of step c + 1 are requested BEFORE step c is combined and stored: the walk used to be one
+        // round trip per step (four requests, wait for all, two stores) on 2.4 waves per SIMD -- two thirds of the waves' cycles
+        // were waits (SQ_WAIT_ANY).  No conditional request inside the walk (the diagonal table Z_ab rides in the LDS image, the
+        // read of the old dP is a template parameter): the compiler counts the queue instead of draining it.
+        struct BC {
+            V xbc, g23, g24, g45;
+        };
+        auto load_bc = [&](int c) {
+            BC o;
+            o.xbc = Vec<VW>::ld(bt + 2 * NNC + ((size_t)b * N + c) * C + f);
+            if (jt && K == 50) o.xbc += Vec<VW>::ld(bt + 8 * NNC + ((size_t)c * N + b) * C + f);
+            o.g23 = o.g24 = o.g45 = Vec<VW>::zero();
+            if (K == 50) o.g23 = GCF(23, b, c, f), o.g24 = GCF(24, b, c, f), o.g45 = GCF(45, b, c, f);
+            return o;
+        };
+#ifndef GF_FAM_ROWS_PF2
+#define GF_FAM_ROWS_PF2 0
+#endif
+        BC cur = load_bc(0);
+#if GF_FAM_ROWS_PF2
+        BC nx1 = load_bc(1 < N ? 1 : 0);
+#endif
+        for (int c = 0; c < N; ++c) {
+#if GF_FAM_ROWS_PF2
+            const BC nxt = nx1;
+            nx1 = load_bc(c + 2 < N ? c + 2 : N - 1);
+#else
+            const BC nxt = load_bc(c + 1 < N ? c + 1 : c);   // (the last step re-requests its own row)
+#endif
             float rc = 0.f, qc = 0.f, dgc = 0.f;
-            if (K == 50) {
-                g23 = GCF(23, b, c, f), g24 = GCF(24, b, c, f), g45 = GCF(45, b, c, f);
-                rc = r[c], qc = q[c], dgc = dg[c];
-            }
+            if (K == 50) rc = r[c], qc = q[c], dgc = dg[c];
 #pragma unroll
             for (int m = 0; m < AB; ++m) {
                 const int a = a0 + m;
-                const float *sr = srow + (size_t)m * 4 * NC + (size_t)c * C + f;
-                V v = xab[m] + Vec<VW>::ld(sr + 0 * NC) + xbc;
+                const float *sr = srow + (size_t)m * NT * NC + (size_t)c * C + f;
+                V v = xab[m] + Vec<VW>::ld(sr + 0 * NC) + cur.xbc;
                 if (K == 50) {
                     v += g11[m] * rc + g12[m] * qc + g41[m] * dgc;
                     v += Vec<VW>::ld(sr + 1 * NC) * rb + Vec<VW>::ld(sr + 2 * NC) * qb + Vec<VW>::ld(sr + 3 * NC) * dgb;
-                    v += g23 * ra[m] + g24 * qa[m] + g45 * dga[m];
+                    v += cur.g23 * ra[m] + cur.g24 * qa[m] + cur.g45 * dga[m];
                     if (b == c) v += zbc[m];
                     if (a == c) v += zac[m];
-                    if (a == b) v += Vec<VW>::ld(bt + 5 * NNC + ((size_t)c * N + (a < N ? a : N - 1)) * C + f);
+                    if (a == b) v += Vec<VW>::ld(sr + 4 * NC);
                     if (a == b && b == c) v += u50;
                 }
                 if (a < N) {
                     float *out = dP + ((g * N + a) * N + b) * (size_t)N * C + (size_t)c * C + f;
-                    if (accumulate) v += Vec<VW>::ld(out);
+                    if (ACC) v += Vec<VW>::ld(out);
                     Vec<VW>::st(out, v);
                 }
             }
+            cur = nxt;
         }
     }
 #undef GCF
@@ -1440,7 +1478,7 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
         if (cwin < 4 || N * (cwin / 4) > 1024 || !(std::getenv("GF_FAM_BWD_LDS") && std::getenv("GF_FAM_BWD_LDS")[0] == '1')) cwin = 0;
         // (opt-in: measured at cfg5 the LDS-staged tables are LDS-bandwidth bound -- every thread of a row reads all 30 staged
         //  slices per z -- 0.56 ms against 0.40 ms for fam_bwd_tables, and fam_backward_rows pays 0.11 ms for the transposed halves)
-        if (sizeof(float) * 4 * (size_t)N * C > 48 * 1024 || (size_t)batch * N >= 0x7fffffffu) cwin = 0;  // (only fam_backward_rows adds the halves)
+        if (sizeof(float) * 5 * (size_t)N * C > 48 * 1024 || (size_t)batch * N >= 0x7fffffffu) cwin = 0;  // (only fam_backward_rows adds the halves)
     }
     if constexpr (K == 50) {
         if (mfma_tables) {
@@ -1488,7 +1526,7 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
                       C, njb, nt);
         }
     }
-    const size_t row_lds = sizeof(float) * 4 * (size_t)N * C;
+    const size_t row_lds = sizeof(float) * 5 * (size_t)N * C;
     // opt-in (GF_FAM_BWD_COLS=1; GF_FAM_COLS_AB: rows a per workgroup, 1 / 2 / 4): thread per (c, channel quad) walking b, the
     // (a, c)-indexed terms in registers.  Measured at cfg5: 0.228 ms against 0.215 ms for the LDS-staged rows kernel below (four rows
     // per workgroup: 0.45 ms) -- neither the LDS image nor the occupancy bounds this combination
@@ -1512,23 +1550,32 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
         // rows a per workgroup (GF_FAM_BWD_AB overrides): two while their staged rows fit 64 KB and the grid still fills the part
         // (cfg5: 0.30 / 0.25 / 0.28 ms at one / two / four)
         int ab = (2 * row_lds <= 64 * 1024 && (size_t)batch * ((N + 1) / 2) >= 1024) ? 2 : 1;
+        // (with the walk's requests a step ahead, cfg5: 0.197 / 0.171 / 0.178 ms at two / three / four rows; two steps ahead no better)
+        if (3 * row_lds <= 64 * 1024 && (size_t)batch * ((N + 2) / 3) >= 1024) ab = 3;
         if (const char *e = std::getenv("GF_FAM_BWD_AB")) ab = std::atoi(e);
-        if (ab != 4 && ab != 2) ab = 1;
+        if (ab != 4 && ab != 3 && ab != 2) ab = 1;
         if ((size_t)ab * row_lds > 64 * 1024) ab = 1;
         const int jt = cwin > 0 ? 1 : 0;
         const unsigned nb = (unsigned)((size_t)batch * ((N + ab - 1) / ab));
 #define GF_FAM_ROWS(VW, AB)                                                                                                        \
     do {                                                                                                                           \
-        st = opt_in_lds(ctx, fam_backward_rows<K, VW, AB>, AB * row_lds);                                                          \
-        if (st != GF_OK) return st;                                                                                                \
-        GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, VW, AB>), dim3(nb), dim3(256), AB * row_lds, G, w.adjs, w.sc, w.tab, dP, N, \
-                  C, accumulate, jt);                                                                                              \
+        if (accumulate) {                                                                                                          \
+            st = opt_in_lds(ctx, fam_backward_rows<K, VW, AB, true>, AB * row_lds);                                                \
+            if (st != GF_OK) return st;                                                                                            \
+            GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, VW, AB, true>), dim3(nb), dim3(256), AB * row_lds, G, w.adjs, w.sc, w.tab, \
+                      dP, N, C, jt);                                                                                               \
+        } else {                                                                                                                   \
+            st = opt_in_lds(ctx, fam_backward_rows<K, VW, AB, false>, AB * row_lds);                                               \
+            if (st != GF_OK) return st;                                                                                            \
+            GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, VW, AB, false>), dim3(nb), dim3(256), AB * row_lds, G, w.adjs, w.sc, w.tab, \
+                      dP, N, C, jt);                                                                                               \
+        }                                                                                                                          \
     } while (0)
         const char *ev = std::getenv("GF_FAM_ROWS_VW");
         if (vec && !(ev && ev[0] == '1')) {  // (16-byte lanes: 0.26 -> 0.23 ms at cfg5; GF_FAM_ROWS_VW=1 keeps one channel per thread)
-            if (ab == 4) GF_FAM_ROWS(4, 4); else if (ab == 2) GF_FAM_ROWS(4, 2); else GF_FAM_ROWS(4, 1);
+            if (ab == 4) GF_FAM_ROWS(4, 4); else if (ab == 3) GF_FAM_ROWS(4, 3); else if (ab == 2) GF_FAM_ROWS(4, 2); else GF_FAM_ROWS(4, 1);
         } else {
-            if (ab == 4) GF_FAM_ROWS(1, 4); else if (ab == 2) GF_FAM_ROWS(1, 2); else GF_FAM_ROWS(1, 1);
+            if (ab == 4) GF_FAM_ROWS(1, 4); else if (ab == 3) GF_FAM_ROWS(1, 3); else if (ab == 2) GF_FAM_ROWS(1, 2); else GF_FAM_ROWS(1, 1);
         }
 #undef GF_FAM_ROWS
     } else {
