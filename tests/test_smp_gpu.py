@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from inputs import smp_params, synthetic_molecule, toy_molecules
+from inputs import f32exact, smp_params, synthetic_molecule, toy_molecules
 from util import golden_cases, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -827,6 +827,42 @@ def test_smp_2d_ver6_batchlearn_matches_the_reference(gf):
     scale = np.abs(z["train2d6__params"] - z["train2d6__params0"]).max()
     print("max |param - reference| %.3e, largest parameter change %.3e" % (err.max(), scale))
     assert err.max() <= 1e-3 * scale
+
+
+def test_smp_2d_ver7_wiring_at_32_channels_runs_the_matrix_pipe_contractions(gf, monkeypatch):
+    """The SMP_2D_ver7 wiring (RisiContraction_50 per node, op by op) at 32 channels: the driver hands gf_contract_*_f32 one uniform
+    batch per receptive-field size, which at C % 32 == 0 runs fam50_forward_mfma / fam50_bwd_tables_mfma.  Predictions, features
+    and every parameter gradient against the same step on the thread-per-element kernels (GF_FAM_*_MFMA=0), which the goldens of
+    tests/golden/smp.npz pin to the real SMP_2D_ver7 at small channel counts."""
+    from graphflow_amd.smp import SMPOmega
+    L, C, F, D, cap = 2, 32, 5, 2, 10
+    mols, tg = [], []
+    for seed in range(8):
+        adj, feat, t = synthetic_molecule(300 + seed, nV=3 + 2 * seed)
+        mols.append((adj, feat))
+        tg.append(t)
+
+    def step():
+        net = SMPOmega(L, C, F, D, cap, True, nContractions=50, custom_matmul=False)
+        rng = np.random.default_rng(7)
+        params = f32exact(rng.uniform(-1, 1, net.n_params) / np.sqrt(50 * C))
+        net.prepare(mols)
+        p = dev(params)
+        pred, loss, feat = net.forward(p, dev(np.array(tg)))
+        grads = torch.empty(net.n_params, device="cuda")
+        net.backward(p, grads)
+        out = [x.cpu().numpy().astype(np.float64) for x in (pred, feat, grads)]
+        net.close()
+        return out
+
+    a = step()
+    monkeypatch.setenv("GF_FAM_FWD_MFMA", "0")
+    monkeypatch.setenv("GF_FAM_BWD_MFMA", "0")
+    b = step()
+    note("ver7_c32_mfma_vs_threads", pred=rel_err(a[0], b[0]), feat=rel_err(a[1], b[1]), grads=rel_err(a[2], b[2]))
+    assert np.isfinite(a[2]).all() and np.abs(a[2]).max() > 0
+    assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[1], b[1]) <= TOL_FWD
+    assert rel_err(a[2], b[2]) <= TOL_GRAD
 
 
 @pytest.mark.parametrize("C,fused,cap,coul", [(64, True, 29, False), (8, False, 6, False), (16, True, 12, True)])
