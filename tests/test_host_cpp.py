@@ -39,7 +39,7 @@ def test_host_op_fails_loudly_without_a_gpu(bins):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,C,K", [(16, 8, 18), (10, 5, 18), (8, 64, 18), (5, 3, 18), (12, 16, 18), (10, 5, 50), (8, 4, 10), (10, 5, 4)])
+@pytest.mark.parametrize("N,C,K", [(16, 8, 18), (10, 5, 18), (8, 64, 18), (5, 3, 18), (12, 16, 18), (10, 5, 50), (7, 32, 50), (8, 4, 10), (10, 5, 4)])
 def test_entity_style_op_parity_f64(bins, N, C, K):
     r = subprocess.run([os.path.join(bins, "test_RisiContraction_hip"), str(N), str(C), str(K)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
