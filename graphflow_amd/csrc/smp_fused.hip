@@ -472,13 +472,22 @@ __global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict_
 
 // zeros into the S_ab / T6 blocks of the rows (a, b), and the S_bc / T10 blocks of the rows (b, c), that tables-forward never
 // writes: once per prepared batch (DevLevel::t_zeros; rowflag bits 0 / 1 = the row has data in the first / second pair of blocks)
-__global__ void tables_zero_fill(float *__restrict__ T, const unsigned char *__restrict__ rowflag, long long rows) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long row = i >> 5;
-    if (row >= rows) return;
-    const int fl = rowflag[row], q = (int)(i & 31);  // 32 float4 = two 64-column blocks
-    if (!(fl & 1)) st4(T + row * (T_COLS * 64) + (q < 16 ? T_SAB * 64 + 4 * q : T_T6 * 64 + 4 * (q - 16)), splat(0.f));
-    if (!(fl & 2)) st4(T + row * (T_COLS * 64) + (q < 16 ? T_SBC * 64 + 4 * q : T_T10 * 64 + 4 * (q - 16)), splat(0.f));
+constexpr int kZeroFillRows = 64;   // rows per workgroup: eight per pass (a thread was launched per (row, float4): 62 M threads at cfg3's level 3)
+__global__ __launch_bounds__(256) void tables_zero_fill(float *__restrict__ T, const unsigned char *__restrict__ rowflag, long long rows) {
+    const int q = threadIdx.x & 31;  // 32 float4 = two 64-column blocks
+    const long long row0 = (long long)blockIdx.x * kZeroFillRows + (threadIdx.x >> 5);
+    int fl[kZeroFillRows / 8];
+#pragma unroll
+    for (int p = 0; p < kZeroFillRows / 8; ++p) {   // (all flags first: one round trip)
+        const long long row = row0 + 8 * p;
+        fl[p] = row < rows ? rowflag[row] : 3;
+    }
+#pragma unroll
+    for (int p = 0; p < kZeroFillRows / 8; ++p) {
+        const long long row = row0 + 8 * p;
+        if (!(fl[p] & 1)) st4(T + row * (T_COLS * 64) + (q < 16 ? T_SAB * 64 + 4 * q : T_T6 * 64 + 4 * (q - 16)), splat(0.f));
+        if (!(fl[p] & 2)) st4(T + row * (T_COLS * 64) + (q < 16 ? T_SBC * 64 + 4 * q : T_T10 * 64 + 4 * (q - 16)), splat(0.f));
+    }
 }
 
 // stacked[p] = K^(kperm[p])  (gather), or  dK^(kperm[p]) += dstacked[p]  (scatter-add).  Block k of the level weight is
@@ -1496,8 +1505,8 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     // same rows every step of a prepared batch and nothing else writes there: their zeros go in once, tables-forward skips them.
     if (C == 64 && d.rowflag && !env_is("GF_SMP_KEEP_ZEROS", '0')) {
         if (!d.t_zeros) {
-            GF_LAUNCH(ctx, "smpf_tables_fill", tables_zero_fill, dim3((unsigned)(((long long)rows * 32 + 255) / 256)), dim3(256), 0, T, d.rowflag,
-                      (long long)rows);
+            GF_LAUNCH(ctx, "smpf_tables_fill", tables_zero_fill, dim3((unsigned)(((long long)rows + kZeroFillRows - 1) / kZeroFillRows)), dim3(256), 0, T,
+                      d.rowflag, (long long)rows);
             s->lv[l].t_zeros = true;
         }
     } else {
