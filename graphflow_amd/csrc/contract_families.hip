@@ -11,7 +11,6 @@
 //             fam_tables  thread per (i,j,f): 12 pair tables in one pass over the third index
 //             fam_vectors thread per (i,f) / per f: single-index marginals and scalars
 //             fam_forward thread per (x,y,f): all K outputs, one loop over the contracted index
-//             fam_products_lds (_50, C % 4 = 0): workgroup per (graph, x), the eighteen adjacency products from LDS
 //   backward  fam_bwd_scalars, fam_bwd_tables (thread per (i,j,f): X_ab, X_ac, X_bc, Z_bc, Z_ac, Z_ab),
 //             fam_backward thread per (a,b,c,f): O(1) combination.
 // These are "table" kernels (coalesced over the channel axis, tables re-read through L2), not the LDS-staged slab
@@ -467,74 +466,9 @@ __global__ __launch_bounds__(256) void fam_forward(const float *__restrict__ P, 
 }
 #undef OUTC
 
-// The eighteen N x N products of RisiContraction_50 with the adjacency (cases 18,19,21,22,27,28,30,31,33,34,36,37,43,44,
-// 46-49), LDS-staged.  Workgroup per (graph, x): the nine operand rows indexed by (x, z) / (z, x) -- three pair tables in
-// both orientations and three diagonals of P, N rows of C floats each -- are read from global memory ONCE and shared by all
-// columns y (fam_forward re-reads them per column through L1: 24 x at cfg5); the adjacency of the graph sits beside them.
-// Thread = (column y, channel quad); 18 accumulators of four channels.
-template <int K>
-__global__ __launch_bounds__(256) void fam_products_lds(const float *__restrict__ P, const float *__restrict__ A,
-                                                        const float *__restrict__ tab, float *__restrict__ Out, int N, int C) {
-    static_assert(K == 50, "only RisiContraction_50 has these slices");
-    extern __shared__ __attribute__((aligned(16))) float fp_smem[];
-    const unsigned blk = (unsigned)xcd_block();
-    const int g = blk / N, x = blk % N;
-    const int CV = C / 4, tid = threadIdx.x;
-    const size_t NNC = (size_t)N * N * C;
-    const float *Pg = P + (size_t)g * NNC * N, *T = tab + (size_t)g * kNTab * NNC, *Ag = A + (size_t)g * N * N;
-    float *ops = fp_smem;                   // [9][N][C]
-    float *As = fp_smem + (size_t)9 * N * C;  // [N][N]
-    for (int i = tid; i < 9 * N * CV; i += blockDim.x) {
-        const int fl = i % CV, z = (i / CV) % N, k = i / (CV * N);
-        const float *src;
-        switch (k) {
-            case 0: src = T + 0 * NNC + ((size_t)x * N + z) * C; break;   // S_ab[x,z]
-            case 1: src = T + 0 * NNC + ((size_t)z * N + x) * C; break;   // S_ab[z,x]
-            case 2: src = T + 1 * NNC + ((size_t)x * N + z) * C; break;   // S_ac[x,z]
-            case 3: src = T + 1 * NNC + ((size_t)z * N + x) * C; break;   // S_ac[z,x]
-            case 4: src = T + 2 * NNC + ((size_t)x * N + z) * C; break;   // S_bc[x,z]
-            case 5: src = T + 2 * NNC + ((size_t)z * N + x) * C; break;   // S_bc[z,x]
-            case 6: src = Pg + (((size_t)x * N + z) * N + z) * C; break;  // P[x,z,z]
-            case 7: src = Pg + (((size_t)z * N + x) * N + z) * C; break;  // P[z,x,z]
-            default: src = Pg + (((size_t)z * N + z) * N + x) * C; break;  // P[z,z,x]
-        }
-        *reinterpret_cast<float4 *>(ops + ((size_t)k * N + z) * C + 4 * fl) = *reinterpret_cast<const float4 *>(src + 4 * fl);
-    }
-    for (int i = tid; i < N * N; i += blockDim.x) As[i] = Ag[i];
-    __syncthreads();
-    const int fl = tid % CV, ypp = blockDim.x / CV;
-    constexpr int cases[18] = {18, 19, 21, 22, 27, 28, 30, 31, 33, 34, 36, 37, 43, 44, 46, 47, 48, 49};
-    // which operand (row block of `ops`) and which adjacency orientation (0: A[y,z], 1: A[z,y]) each product uses
-    constexpr int opnd[18] = {0, 2, 0, 2, 1, 4, 1, 4, 3, 5, 3, 5, 6, 6, 7, 7, 8, 8};
-    constexpr int ori[18] = {0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1, 0, 1};
-    for (int y = tid / CV; y < N; y += ypp) {
-        float4 mm[18];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) mm[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < N; ++z) {
-            const float ayz = As[y * N + z], azy = As[z * N + y];
-            float4 o[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) o[k] = *reinterpret_cast<const float4 *>(ops + ((size_t)k * N + z) * C + 4 * fl);
-#pragma unroll
-            for (int k = 0; k < 18; ++k) {
-                const float a = ori[k] == 0 ? ayz : azy;
-                const float4 v = o[opnd[k]];
-                mm[k].x += v.x * a;
-                mm[k].y += v.y * a;
-                mm[k].z += v.z * a;
-                mm[k].w += v.w * a;
-            }
-        }
-        float *o = Out + (((size_t)g * N + x) * N + y) * (size_t)(K * C) + 4 * fl;
-#pragma unroll
-        for (int k = 0; k < 18; ++k) *reinterpret_cast<float4 *>(o + (size_t)(cases[k] - 1) * C) = mm[k];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // RisiContraction_50 forward outputs on the matrix pipe (C % 32 == 0, N <= 32): ONE kernel writes all fifty slices of a row
-// (fam_forward + fam_products_lds wrote them in two launches, 32 + 18 slices).  One WAVE owns (graph g, row x, window of 32
+// (the table kernels write them in one launch of a thread per (x, y, channel quad)).  One WAVE owns (graph g, row x, window of 32
 // channels).  The eighteen adjacency products  Out_k[x, y, f] = sum_z op[z, f] M[z, y]  (M = A[y, z] or A[z, y]) are
 // v_mfma_f32_32x32x2_f32 with the nine operands -- rows / columns x of S_ab, S_ac, S_bc and the three diagonals of P -- loaded
 // straight from global memory in the B-operand layout (z = 2 step + lane / 32, f = lane % 32: two coalesced 128-byte rows per
@@ -831,113 +765,6 @@ __global__ __launch_bounds__(256) void fam_bwd_tables(const float *__restrict__ 
     }
 }
 
-// The same tables with every G row read ONCE (round 3).  Workgroup per (graph g, row x, channel window): the slices of row x
-// that are contracted over their second index z are staged in LDS -- the twenty indexed (i, z) (they feed row i = x of the six
-// tables above) and the ten indexed (j, z) (cases 6..9, 27, 30, 33, 36, 34, 37: they feed COLUMN j = x) -- together with the
-// graph's adjacency; a thread owns (t, four channels) and walks z once.  The column role cannot add into rows other workgroups
-// own, so its three sums go to tables of their own, stored transposed:
-//   btab[6] J_ab[j, i]   btab[7] J_ac[j, i]   btab[8] J_bc[j, i]      X_ab[i, j] = btab[0][i, j] + btab[6][j, i]  (etc.)
-// fam_backward_rows adds the two halves where it reads them.  The thread-per-(i, columns, f) kernel above re-read the (i, z)
-// slices once per column block and the (j, z) slices once per row: 11x the bytes of G through L1 / L2.
-constexpr int kNBTabJ = 9;  // six tables + the three column-role partials
-constexpr int kBtI = 20, kBtJ = 10;
-__constant__ int c_bt_islices[kBtI] = {3, 4, 18, 21, 19, 22, 28, 31, 43, 44, 46, 47, 48, 49, 17, 20, 26, 29, 32, 35};
-__constant__ int c_bt_jslices[kBtJ] = {6, 7, 27, 30, 8, 9, 33, 36, 34, 37};
-
-template <int K>
-__global__ __launch_bounds__(256) void fam_bwd_tables_lds(const float *__restrict__ G, const float *__restrict__ A,
-                                                          const float *__restrict__ adjs, const float *__restrict__ bsc,
-                                                          float *__restrict__ btab, int N, int C, int CW, int nwin) {
-    extern __shared__ __attribute__((aligned(16))) float bt_smem[];
-    constexpr int NS = (K == 50) ? kBtI + kBtJ : 6;  // K = 10: slices 3, 4 (row role) and 6, 7, 8, 9 (column role)
-    const size_t blk = xcd_block();
-    const int win = (int)(blk % nwin);
-    const int x = (int)((blk / nwin) % N);
-    const size_t g = blk / nwin / N;
-    const int f0 = win * CW, cw = (C - f0 < CW) ? C - f0 : CW, cv = cw / 4;
-    const size_t NNC = (size_t)N * N * C;
-    float *sl = bt_smem;                         // [NS][N][CW]
-    float *As = bt_smem + (size_t)NS * N * CW;   // [N][N]
-    const float *Gx = G + (g * N + x) * (size_t)N * K * C;  // row x: [z][K][C]
-    const float *Ag = A + g * N * N;
-    // (eight requests per thread in flight: one at a time, the staging of a row was 45 us of round trips per workgroup)
-    const int nst = NS * N * cv;
-    for (int i0 = threadIdx.x; i0 < nst; i0 += 8 * blockDim.x) {
-        vf4 v[8];
-        int dst[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i = i0 + j * blockDim.x, ic = i < nst ? i : nst - 1;
-            const int fl = ic % cv, z = (ic / cv) % N, k = ic / (cv * N);
-            int cs;
-            if (K == 50) cs = k < kBtI ? c_bt_islices[k] : c_bt_jslices[k - kBtI];
-            else cs = (k < 2) ? 3 + k : 4 + k;  // 3, 4 | 6, 7, 8, 9
-            dst[j] = i < nst ? (k * N + z) * CW + 4 * fl : -1;
-            v[j] = *reinterpret_cast<const vf4 *>(Gx + ((size_t)z * K + slot<K>(cs)) * C + f0 + 4 * fl);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (dst[j] >= 0) *reinterpret_cast<vf4 *>(sl + dst[j]) = v[j];
-    }
-    for (int i = threadIdx.x; i < N * N; i += blockDim.x) As[i] = Ag[i];
-    __syncthreads();
-    const float *r = adjs + g * adjs_stride(N), *q = r + N, *st = q + 2 * N;
-    const float tot = st[0], tr = st[1];
-    const float *u = bsc + g * 5 * (size_t)C;
-#define SL(k, z) (*reinterpret_cast<const vf4 *>(sl + ((size_t)(k) * N + (z)) * CW + 4 * fl))
-#define GD(c, xx, yy) (slot<K>(c) >= 0 ? *reinterpret_cast<const vf4 *>(G + (((g * N + (xx)) * (size_t)N + (yy)) * K + slot<K>(c)) * C + f) : vf4{0.f, 0.f, 0.f, 0.f})
-    for (int it = threadIdx.x; it < N * cv; it += blockDim.x) {
-        const int fl = it % cv, t = it / cv, f = f0 + 4 * fl;
-        const vf4 z4 = {0.f, 0.f, 0.f, 0.f};
-        // row role: i = x, j = t
-        vf4 xab = tot * GD(1, x, t) + *reinterpret_cast<const vf4 *>(u + 0 * C + f);
-        vf4 xac = tot * GD(2, x, t), xbc = tot * GD(5, x, t);
-        vf4 zbc = z4, zac = z4, zab = z4, jab = z4, jac = z4, jbc = z4;
-        if (K == 50) {
-            xab += tr * GD(13, x, t);
-            xac += tr * GD(16, x, t);
-            xbc += tr * GD(25, x, t);
-            zbc = *reinterpret_cast<const vf4 *>(u + 3 * C + f);
-            zac = *reinterpret_cast<const vf4 *>(u + 2 * C + f);
-            zab = *reinterpret_cast<const vf4 *>(u + 1 * C + f);
-        }
-        for (int z = 0; z < N; ++z) {
-            const float rz = r[z], qz = q[z];
-            if (K == 50) {
-                const float azt = As[z * N + t], atz = As[t * N + z];
-                xab += SL(0, z) * rz + SL(1, z) * qz + SL(2, z) * azt + SL(3, z) * atz;       // 3 r + 4 q + 18 A[z,j] + 21 A[j,z]
-                xac += SL(4, z) * azt + SL(5, z) * atz;                                        // 19, 22
-                xbc += SL(6, z) * azt + SL(7, z) * atz;                                        // 28, 31
-                zbc += SL(14, z) * rz + SL(15, z) * qz + SL(8, z) * azt + SL(9, z) * atz;      // 17 r + 20 q + 43, 44
-                zac += SL(16, z) * rz + SL(17, z) * qz + SL(10, z) * azt + SL(11, z) * atz;    // 26 r + 29 q + 46, 47
-                zab += SL(18, z) * rz + SL(19, z) * qz + SL(12, z) * azt + SL(13, z) * atz;    // 32 r + 35 q + 48, 49
-                // column role: j = x, i = t
-                jab += SL(20, z) * rz + SL(21, z) * qz + SL(22, z) * azt + SL(23, z) * atz;    // 6 r + 7 q + 27 A[z,i] + 30 A[i,z]
-                jac += SL(24, z) * rz + SL(25, z) * qz + SL(26, z) * azt + SL(27, z) * atz;    // 8 r + 9 q + 33, 36
-                jbc += SL(28, z) * azt + SL(29, z) * atz;                                      // 34, 37
-            } else {
-                xab += SL(0, z) * rz + SL(1, z) * qz;
-                jab += SL(2, z) * rz + SL(3, z) * qz;
-                jac += SL(4, z) * rz + SL(5, z) * qz;
-            }
-        }
-        float *bt = btab + g * kNBTabJ * NNC + ((size_t)x * N + t) * C + f;
-        *reinterpret_cast<vf4 *>(bt + 0 * NNC) = xab;
-        *reinterpret_cast<vf4 *>(bt + 1 * NNC) = xac;
-        *reinterpret_cast<vf4 *>(bt + 2 * NNC) = xbc;
-        if (K == 50) {
-            *reinterpret_cast<vf4 *>(bt + 3 * NNC) = zbc;
-            *reinterpret_cast<vf4 *>(bt + 4 * NNC) = zac;
-            *reinterpret_cast<vf4 *>(bt + 5 * NNC) = zab;
-        }
-        *reinterpret_cast<vf4 *>(bt + 6 * NNC) = jab;
-        *reinterpret_cast<vf4 *>(bt + 7 * NNC) = jac;
-        if (K == 50) *reinterpret_cast<vf4 *>(bt + 8 * NNC) = jbc;
-    }
-#undef SL
-#undef GD
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // RisiContraction_50 backward tables on the matrix pipe (C % 32 == 0, N <= 32): every G row is read ONCE, straight from global
 // memory into the operand registers of v_mfma_f32_32x32x2_f32 -- no LDS, no re-reads through L1.
@@ -1148,7 +975,7 @@ template <int K, int VW, int AB, bool ACC>
 __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict__ G, const float *__restrict__ adjs,
                                                          const float *__restrict__ bsc, const float *__restrict__ btab,
                                                          float *__restrict__ dP, int N, int C,
-                                                         int jt) {  // != 0: tables of fam_bwd_tables_lds (column-role partials 6..8)
+                                                         int) {
     using V = typename Vec<VW>::T;
     // [AB][5][N][C]: X_ac(a,c) | G14(a,c) | G15(a,c) | G42(a,c) | Z_ab(c,a)
     extern __shared__ __attribute__((aligned(16))) float srow[];
@@ -1158,7 +985,7 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
     const int na = (N + AB - 1) / AB;
     const size_t g = blk / na;
     const int a0 = (int)(blk % na) * AB;
-    const float *bt = btab + g * (jt ? kNBTabJ : kNBTab) * NNC;
+    const float *bt = btab + g * kNBTab * NNC;
     const float *Gg = G + g * (size_t)N * N * K * C;
     const float *r = adjs + g * adjs_stride(N), *q = r + N, *dg = q + N;
 #define GCF(cs, x, y, f) Vec<VW>::ld(Gg + (((size_t)(x) * N + (y)) * K + slot<K>(cs)) * C + (f))
@@ -1168,7 +995,6 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
         const int a = (a0 + m < N) ? a0 + m : N - 1;  // (rows past the end: a clamped copy, never stored)
         float *sr = srow + (size_t)m * NT * NC + (size_t)c * C + f;
         V xac = Vec<VW>::ld(bt + 1 * NNC + ((size_t)a * N + c) * C + f);
-        if (jt) xac += Vec<VW>::ld(bt + 7 * NNC + ((size_t)c * N + a) * C + f);
         Vec<VW>::st(sr + 0 * NC, xac);
         if (K == 50) {
             Vec<VW>::st(sr + 1 * NC, GCF(14, a, c, f));
@@ -1189,7 +1015,6 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
         for (int m = 0; m < AB; ++m) {
             const int a = (a0 + m < N) ? a0 + m : N - 1;
             xab[m] = Vec<VW>::ld(bt + 0 * NNC + ((size_t)a * N + b) * C + f);
-            if (jt) xab[m] += Vec<VW>::ld(bt + 6 * NNC + ((size_t)b * N + a) * C + f);
             g11[m] = g12[m] = g41[m] = zbc[m] = zac[m] = Vec<VW>::zero();
             ra[m] = r[a], qa[m] = q[a], dga[m] = dg[a];
             if (K == 50) {
@@ -1210,7 +1035,6 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
         auto load_bc = [&](int c) {
             BC o;
             o.xbc = Vec<VW>::ld(bt + 2 * NNC + ((size_t)b * N + c) * C + f);
-            if (jt && K == 50) o.xbc += Vec<VW>::ld(bt + 8 * NNC + ((size_t)c * N + b) * C + f);
             o.g23 = o.g24 = o.g45 = Vec<VW>::zero();
             if (K == 50) o.g23 = GCF(23, b, c, f), o.g24 = GCF(24, b, c, f), o.g45 = GCF(45, b, c, f);
             return o;
@@ -1257,85 +1081,6 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
 #undef GCF
 }
 
-// The same combination with the roles of b and c exchanged (round 3): a thread owns (c, channel quad) and walks b.  Everything
-// indexed (a, c) -- X_ac, the slices of cases 14, 15, 42, and the diagonal tables Z_bc[a, c], Z_ab[c, a] -- is then a per-thread
-// constant and lives in REGISTERS for the AB rows a of the workgroup: no LDS image, no barrier, no idle wave (fam_backward_rows
-// stages those rows in 24 KB of LDS per a and leaves a quarter of its threads without a column at cfg5), and the occupancy is
-// bounded by registers alone.  Per b a thread loads the four (b, c)-indexed values (coalesced: row b of X_bc and of the slices of
-// cases 23, 24, 45, shared by the AB rows) and the (a, b)-indexed ones (one 128-byte line per table for the whole wave).
-template <int K, int AB>
-__global__ __launch_bounds__(256) void fam_backward_cols(const float *__restrict__ G, const float *__restrict__ adjs,
-                                                         const float *__restrict__ bsc, const float *__restrict__ btab,
-                                                         float *__restrict__ dP, int N, int C, int accumulate) {
-    using V = vf4;
-    const size_t NNC = (size_t)N * N * C;
-    const size_t blk = xcd_block();
-    const int na = (N + AB - 1) / AB;
-    const size_t g = blk / na;
-    const int a0 = (int)(blk % na) * AB;
-    const float *bt = btab + g * kNBTab * NNC;
-    const float *Gg = G + g * (size_t)N * N * K * C;
-    const float *r = adjs + g * adjs_stride(N), *q = r + N, *dg = q + N;
-    const int CV = C / 4, items = N * CV;
-#define GCF(cs, x, y, f) Vec<4>::ld(Gg + (((size_t)(x) * N + (y)) * K + slot<K>(cs)) * C + (f))
-#define BTF(k, x, y, f) Vec<4>::ld(bt + (k) * NNC + ((size_t)(x) * N + (y)) * C + (f))
-    for (int it = threadIdx.x; it < items; it += blockDim.x) {
-        const int c = it / CV, f = (it % CV) * 4;
-        const V z4 = {0.f, 0.f, 0.f, 0.f};
-        V xac[AB], g14[AB], g15[AB], g42[AB], zbc[AB], zab[AB];
-        float ra[AB], qa[AB], dga[AB];
-        int aa[AB];
-        const float rc = r[c], qc = q[c], dgc = dg[c];
-        V u50 = z4;
-        if (K == 50) u50 = Vec<4>::ld(bsc + g * 5 * (size_t)C + 4 * C + f);
-#pragma unroll
-        for (int m = 0; m < AB; ++m) {
-            const int a = aa[m] = (a0 + m < N) ? a0 + m : N - 1;   // (rows past the end: a clamped copy, never stored)
-            xac[m] = BTF(1, a, c, f);
-            g14[m] = g15[m] = g42[m] = zbc[m] = zab[m] = z4;
-            ra[m] = r[a], qa[m] = q[a], dga[m] = dg[a];
-            if (K == 50) {
-                g14[m] = GCF(14, a, c, f);
-                g15[m] = GCF(15, a, c, f);
-                g42[m] = GCF(42, a, c, f);
-                zbc[m] = BTF(3, a, c, f);   // Z_bc[a, b]: applies at b == c
-                zab[m] = BTF(5, c, a, f);   // Z_ab[c, a]: applies at a == b
-            }
-        }
-        for (int b = 0; b < N; ++b) {
-            const V xbc = BTF(2, b, c, f);
-            V g23 = z4, g24 = z4, g45 = z4;
-            float rb = 0.f, qb = 0.f, dgb = 0.f;
-            if (K == 50) {
-                g23 = GCF(23, b, c, f), g24 = GCF(24, b, c, f), g45 = GCF(45, b, c, f);
-                rb = r[b], qb = q[b], dgb = dg[b];
-            }
-#pragma unroll
-            for (int m = 0; m < AB; ++m) {
-                const int a = aa[m];
-                V v = BTF(0, a, b, f) + xac[m] + xbc;
-                if (K == 50) {
-                    v += GCF(11, a, b, f) * rc + GCF(12, a, b, f) * qc + GCF(41, a, b, f) * dgc;
-                    v += g14[m] * rb + g15[m] * qb + g42[m] * dgb;
-                    v += g23 * ra[m] + g24 * qa[m] + g45 * dga[m];
-                    const V zac = BTF(4, b, a, f);   // Z_ac[b, a]: applies at a == c
-                    if (b == c) v += zbc[m];
-                    if (a == c) v += zac;
-                    if (a == b) v += zab[m];
-                    if (a == b && b == c) v += u50;
-                }
-                if (a0 + m < N) {
-                    float *out = dP + ((g * N + a) * N + b) * (size_t)N * C + (size_t)c * C + f;
-                    if (accumulate) v += Vec<4>::ld(out);
-                    Vec<4>::st(out, v);
-                }
-            }
-        }
-    }
-#undef GCF
-#undef BTF
-}
-
 struct FamWs {
     float *adjs, *tab, *vec, *sc;
 };
@@ -1362,29 +1107,22 @@ gf_status fam_forward_launch(gf_ctx *ctx, const float *P, const float *A, float 
     const size_t nn = (size_t)batch * N * N * C, nv = (size_t)batch * N * C, ns = (size_t)batch * C;
     GF_LAUNCH(ctx, "fam_adj", fam_adj, dim3(batch), dim3(64), 0, A, w.adjs, N);
     const bool vec = C % 4 == 0 && (((uintptr_t)P | (uintptr_t)Out | (uintptr_t)w.tab) & 15) == 0;
-    bool mfma_out = false, slim = false;
+    bool mfma_out = false;
     if constexpr (K == 50) {
-        // all fifty slices of a row from one wave, the adjacency products on the matrix pipe (GF_FAM_FWD_MFMA=0: the two kernels below);
-        // GF_FAM_FWD_SLIM=0: the twelve tables go through the workspace and the output kernel writes all fifty slices
-        const char *e = std::getenv("GF_FAM_FWD_MFMA"), *e2 = std::getenv("GF_FAM_FWD_SLIM");
-        mfma_out = C % 32 == 0 && N <= 32 && (size_t)batch * N * (C / 32) < 0x7fffffffu && (size_t)N * N * N * C < (1u << 29) && !(e && e[0] == '0');   // (buffer descriptors of a graph's P and tables stay under 2 GB)
-        slim = mfma_out && vec && !(e2 && e2[0] == '0');
+        // all fifty slices of a row from one wave, the adjacency products on the matrix pipe (GF_FAM_FWD_MFMA=0: the table kernels below,
+        // which serve every other shape and _10 -- the parity tests hold the two against each other)
+        const char *e = std::getenv("GF_FAM_FWD_MFMA");
+        mfma_out = vec && C % 32 == 0 && N <= 32 && (size_t)batch * N * (C / 32) < 0x7fffffffu && (size_t)N * N * N * C < (1u << 29) &&
+                   !(e && e[0] == '0');   // (buffer descriptors of a graph's P and tables stay under 2 GB)
     }
-    if (slim) {
+    if (mfma_out) {
         if constexpr (K == 50) {
-            // occupancy held down by an LDS request (GF_FAM_TAB_LDS_KB per workgroup, default 40: four workgroups per CU)
-            const char *e = std::getenv("GF_FAM_TAB_LDS_KB"), *eu = std::getenv("GF_FAM_TAB_UNR");
-            const size_t lds = (size_t)(e ? std::atoi(e) : 40) * 1024;
-            const int unr = eu ? std::atoi(eu) : 8;
-            if (unr == 4) {
-                st = opt_in_lds(ctx, fam50_tables_out<4>, lds);
-                if (st != GF_OK) return st;
-                GF_LAUNCH(ctx, "fam_tables", (fam50_tables_out<4>), dim3(grid_for(nn / 4)), dim3(256), lds, P, w.adjs, w.tab, Out, N, C, nn / 4);
-            } else {
-                st = opt_in_lds(ctx, fam50_tables_out<8>, lds);
-                if (st != GF_OK) return st;
-                GF_LAUNCH(ctx, "fam_tables", (fam50_tables_out<8>), dim3(grid_for(nn / 4)), dim3(256), lds, P, w.adjs, w.tab, Out, N, C, nn / 4);
-            }
+            // the pass over P writes the fifteen slices that ARE tables straight into Out; occupancy held at four workgroups per CU by
+            // a 40 KB LDS request (measured: 0.170 - 0.182 ms from 0 to 160 KB)
+            const size_t lds = (size_t)40 * 1024;
+            st = opt_in_lds(ctx, fam50_tables_out<8>, lds);
+            if (st != GF_OK) return st;
+            GF_LAUNCH(ctx, "fam_tables", (fam50_tables_out<8>), dim3(grid_for(nn / 4)), dim3(256), lds, P, w.adjs, w.tab, Out, N, C, nn / 4);
         }
     } else if (vec)
         GF_LAUNCH(ctx, "fam_tables", (fam_tables<K, 4>), dim3(grid_for(nn / 4)), dim3(256), 0, P, w.adjs, w.tab, N, C, nn / 4);
@@ -1392,34 +1130,20 @@ gf_status fam_forward_launch(gf_ctx *ctx, const float *P, const float *A, float 
         GF_LAUNCH(ctx, "fam_tables", (fam_tables<K, 1>), dim3(grid_for(nn)), dim3(256), 0, P, w.adjs, w.tab, N, C, nn);
     GF_LAUNCH(ctx, "fam_vectors", fam_vectors, dim3(grid_for(nv)), dim3(256), 0, P, w.tab, w.vec, w.sc, N, C, nv);
     GF_LAUNCH(ctx, "fam_scalars", fam_scalars, dim3(grid_for(ns)), dim3(256), 0, P, w.vec, w.sc, N, C, ns);
-    const size_t prod_lds = sizeof(float) * ((size_t)9 * N * C + (size_t)N * N);
     if constexpr (K == 50) {
         if (mfma_out) {
             const unsigned nw = (unsigned)((size_t)batch * N * (C / 32));
             const dim3 grid((nw + 3) / 4), block(256);
-#define GF_FAM_OUT(NS)                                                                                                                    \
-    do {                                                                                                                                  \
-        if (slim)                                                                                                                         \
-            GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<NS, true>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);  \
-        else                                                                                                                              \
-            GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<NS, false>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw); \
-    } while (0)
-            if (N <= 16) GF_FAM_OUT(8); else if (N <= 24) GF_FAM_OUT(12); else GF_FAM_OUT(16);
-#undef GF_FAM_OUT
+            if (N <= 16)
+                GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<8, true>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);
+            else if (N <= 24)
+                GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<12, true>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);
+            else
+                GF_LAUNCH(ctx, "fam_forward", (fam50_forward_mfma<16, true>), grid, block, 0, P, A, w.adjs, w.tab, w.vec, w.sc, Out, N, C, nw);
+            return GF_OK;
         }
     }
-    if (mfma_out) {
-    } else if (vec && K == 50 && prod_lds <= 150 * 1024 && C / 4 <= 256) {
-        // the plain slices by the element kernel, the eighteen adjacency products from LDS-staged operands
-        const size_t nf = (size_t)batch * N * N * (C / 4);
-        GF_LAUNCH(ctx, "fam_forward", (fam_forward<K, 4, false>), dim3(grid_for(nf)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec,
-                  w.sc, Out, N, C, N, nf);
-        {
-            gf_status st = opt_in_lds(ctx, fam_products_lds<50>, prod_lds);
-            if (st != GF_OK) return st;
-        }
-        GF_LAUNCH(ctx, "fam_products", (fam_products_lds<50>), dim3((unsigned)(batch * N)), dim3(256), prod_lds, P, A, w.tab, Out, N, C);
-    } else if (vec) {
+    if (vec) {
         const size_t nf = (size_t)batch * N * N * (C / 4);
         GF_LAUNCH(ctx, "fam_forward", (fam_forward<K, 4>), dim3(grid_for(nf)), dim3(256), 0, P, A, w.adjs, w.tab, w.vec, w.sc,
                   Out, N, C, N, nf);
@@ -1442,8 +1166,6 @@ __global__ void fam50_bwd_scalars_fold(const float *__restrict__ bpart, float *_
     }
 }
 
-static inline bool mfma_tables_jt(int cwin) { return cwin > 0; }   // the LDS-staged tables kernel leaves transposed partials only fam_backward_rows adds
-
 template <int K>
 gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float *dP, int N, int C, int batch,
                               int accumulate) {
@@ -1456,29 +1178,10 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
     bool mfma_tables = false;
     if constexpr (K == 50) {
         // matrix-pipe tables (every G row read once, no LDS): C in whole 32-channel windows, N <= 32.  GF_FAM_BWD_MFMA=0: the
-        // thread-per-(i, columns, f) kernel below
-        const char *e = std::getenv("GF_FAM_BWD_MFMA"), *el = std::getenv("GF_FAM_BWD_LDS");
+        // thread-per-(i, columns, f) kernel below (every other shape, _10; the parity tests hold the two against each other)
+        const char *e = std::getenv("GF_FAM_BWD_MFMA");
         mfma_tables = C % 32 == 0 && N <= 32 && (size_t)batch * N * (C / 32) < 0x7fffffffu && (size_t)N * N * K * C < (1u << 28) &&
-                      !(e && e[0] == '0') && !(el && el[0] == '1');
-    }
-    if (!mfma_tables)   // (the matrix-pipe column launch leaves per-row partials of these scalars instead)
-        GF_LAUNCH(ctx, "fam_bwd_scalars", fam_bwd_scalars<K>, dim3(batch * 5), dim3(256), 0, G, A, w.sc, N, C);
-    // (measured at cfg5: the 16-byte variant of the TABLES kernel is slower -- with four channels per thread only two columns fit
-    //  in registers and the shared (i,z) operands are re-read three times as often -- so it keeps one channel per thread, two rows
-    //  x six columns; the rows kernel below takes 16-byte lanes)
-    const bool vec_bt = false;
-    // LDS-staged tables (every G row read once): C % 4 == 0, the staged slices of a row fit 96 KB per channel window
-    int cwin = 0;
-    if (vec && N <= 64) {
-        const int ns = (K == 50) ? kBtI + kBtJ : 6;
-        const char *lim = std::getenv("GF_FAM_BWD_KB");  // LDS budget per workgroup (default 48 KB: three workgroups per CU)
-        const size_t budget = (size_t)(lim ? std::atoi(lim) : 48) * 1024;
-        cwin = (int)((budget - sizeof(float) * (size_t)N * N) / (sizeof(float) * (size_t)ns * N)) / 4 * 4;
-        if (cwin > C) cwin = C;
-        if (cwin < 4 || N * (cwin / 4) > 1024 || !(std::getenv("GF_FAM_BWD_LDS") && std::getenv("GF_FAM_BWD_LDS")[0] == '1')) cwin = 0;
-        // (opt-in: measured at cfg5 the LDS-staged tables are LDS-bandwidth bound -- every thread of a row reads all 30 staged
-        //  slices per z -- 0.56 ms against 0.40 ms for fam_bwd_tables, and fam_backward_rows pays 0.11 ms for the transposed halves)
-        if (sizeof(float) * 5 * (size_t)N * C > 48 * 1024 || (size_t)batch * N >= 0x7fffffffu) cwin = 0;  // (only fam_backward_rows adds the halves)
+                      !(e && e[0] == '0');
     }
     if constexpr (K == 50) {
         if (mfma_tables) {
@@ -1495,30 +1198,14 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
 #undef GF_FAM_MFMA
         }
     }
-    if (mfma_tables) {
-    } else if (cwin > 0) {
-        const int nwin = (C + cwin - 1) / cwin;
-        const size_t lds = sizeof(float) * ((size_t)((K == 50) ? kBtI + kBtJ : 6) * N * cwin + (size_t)N * N);
-        st = opt_in_lds(ctx, fam_bwd_tables_lds<K>, lds);
-        if (st != GF_OK) return st;
-        GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables_lds<K>), dim3((unsigned)((size_t)batch * N * nwin)), dim3(256), lds, G, A, w.adjs,
-                  w.sc, w.tab, N, C, cwin, nwin);
-    } else if (vec && vec_bt) {
-        const int njb = (N + 1) / 2;
-        const size_t nt = (size_t)batch * N * njb * (C / 4);
-        GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 4, 1>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
-                  C, njb, nt);
-    } else {
+    if (!mfma_tables) {   // (the matrix-pipe column launch leaves per-row partials of the scalars instead)
+        GF_LAUNCH(ctx, "fam_bwd_scalars", fam_bwd_scalars<K>, dim3(batch * 5), dim3(256), 0, G, A, w.sc, N, C);
+        // one channel per thread, six columns x one or two rows (two once the grid fills the part): with four channels per thread only
+        // two columns fit in registers and the shared (i, z) operands are re-read three times as often (measured at cfg5)
         const int njb = (N + 5) / 6;
-        const char *e = std::getenv("GF_FAM_BWD_IB");
-        const int ib = e ? std::atoi(e) : ((size_t)batch * ((N + 1) / 2) * njb * C >= 256 * 1024 ? 2 : 1);  // (two rows per thread once the grid fills the part)
-        if (ib == 2) {
+        if ((size_t)batch * ((N + 1) / 2) * njb * C >= 256 * 1024) {
             const size_t nt = (size_t)batch * ((N + 1) / 2) * njb * C;
             GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 1, 2>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
-                      C, njb, nt);
-        } else if (ib == 4) {
-            const size_t nt = (size_t)batch * ((N + 3) / 4) * njb * C;
-            GF_LAUNCH(ctx, "fam_bwd_tables", (fam_bwd_tables<K, 1, 4>), dim3(grid_for(nt)), dim3(256), 0, G, A, w.adjs, w.sc, w.tab, N,
                       C, njb, nt);
         } else {
             const size_t nt = (size_t)batch * N * njb * C;
@@ -1527,35 +1214,11 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
         }
     }
     const size_t row_lds = sizeof(float) * 5 * (size_t)N * C;
-    // opt-in (GF_FAM_BWD_COLS=1; GF_FAM_COLS_AB: rows a per workgroup, 1 / 2 / 4): thread per (c, channel quad) walking b, the
-    // (a, c)-indexed terms in registers.  Measured at cfg5: 0.228 ms against 0.215 ms for the LDS-staged rows kernel below (four rows
-    // per workgroup: 0.45 ms) -- neither the LDS image nor the occupancy bounds this combination
-    const char *ecols = std::getenv("GF_FAM_BWD_COLS");
-    if (vec && !mfma_tables_jt(cwin) && (size_t)batch * N < 0x7fffffffu && ecols && ecols[0] == '1') {
-        const char *eab = std::getenv("GF_FAM_COLS_AB");
-        const int ab = eab ? std::atoi(eab) : 2;
-        const unsigned items = (unsigned)(N * (C / 4));
-        const unsigned threads = items >= 256 ? 256u : (items + 63) / 64 * 64;
-        if (ab == 4) {
-            const unsigned nb = (unsigned)((size_t)batch * ((N + 3) / 4));
-            GF_LAUNCH(ctx, "fam_backward", (fam_backward_cols<K, 4>), dim3(nb), dim3(threads), 0, G, w.adjs, w.sc, w.tab, dP, N, C, accumulate);
-        } else if (ab == 1) {
-            const unsigned nb = (unsigned)((size_t)batch * N);
-            GF_LAUNCH(ctx, "fam_backward", (fam_backward_cols<K, 1>), dim3(nb), dim3(threads), 0, G, w.adjs, w.sc, w.tab, dP, N, C, accumulate);
-        } else {
-            const unsigned nb = (unsigned)((size_t)batch * ((N + 1) / 2));
-            GF_LAUNCH(ctx, "fam_backward", (fam_backward_cols<K, 2>), dim3(nb), dim3(threads), 0, G, w.adjs, w.sc, w.tab, dP, N, C, accumulate);
-        }
-    } else if (row_lds <= 48 * 1024 && (size_t)batch * N < 0x7fffffffu) {
-        // rows a per workgroup (GF_FAM_BWD_AB overrides): two while their staged rows fit 64 KB and the grid still fills the part
-        // (cfg5: 0.30 / 0.25 / 0.28 ms at one / two / four)
+    if (row_lds <= 48 * 1024 && (size_t)batch * N < 0x7fffffffu) {
+        // rows a per workgroup: as many of one / two / three as fit 64 KB of staged rows while the grid still fills the part
+        // (cfg5, with the walk's requests a step ahead: 0.197 / 0.171 / 0.178 ms at two / three / four rows)
         int ab = (2 * row_lds <= 64 * 1024 && (size_t)batch * ((N + 1) / 2) >= 1024) ? 2 : 1;
-        // (with the walk's requests a step ahead, cfg5: 0.197 / 0.171 / 0.178 ms at two / three / four rows; two steps ahead no better)
         if (3 * row_lds <= 64 * 1024 && (size_t)batch * ((N + 2) / 3) >= 1024) ab = 3;
-        if (const char *e = std::getenv("GF_FAM_BWD_AB")) ab = std::atoi(e);
-        if (ab != 4 && ab != 3 && ab != 2) ab = 1;
-        if ((size_t)ab * row_lds > 64 * 1024) ab = 1;
-        const int jt = cwin > 0 ? 1 : 0;
         const unsigned nb = (unsigned)((size_t)batch * ((N + ab - 1) / ab));
 #define GF_FAM_ROWS(VW, AB)                                                                                                        \
     do {                                                                                                                           \
@@ -1563,19 +1226,18 @@ gf_status fam_backward_launch(gf_ctx *ctx, const float *G, const float *A, float
             st = opt_in_lds(ctx, fam_backward_rows<K, VW, AB, true>, AB * row_lds);                                                \
             if (st != GF_OK) return st;                                                                                            \
             GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, VW, AB, true>), dim3(nb), dim3(256), AB * row_lds, G, w.adjs, w.sc, w.tab, \
-                      dP, N, C, jt);                                                                                               \
+                      dP, N, C, 0);                                                                                                \
         } else {                                                                                                                   \
             st = opt_in_lds(ctx, fam_backward_rows<K, VW, AB, false>, AB * row_lds);                                               \
             if (st != GF_OK) return st;                                                                                            \
             GF_LAUNCH(ctx, "fam_backward", (fam_backward_rows<K, VW, AB, false>), dim3(nb), dim3(256), AB * row_lds, G, w.adjs, w.sc, w.tab, \
-                      dP, N, C, jt);                                                                                               \
+                      dP, N, C, 0);                                                                                                \
         }                                                                                                                          \
     } while (0)
-        const char *ev = std::getenv("GF_FAM_ROWS_VW");
-        if (vec && !(ev && ev[0] == '1')) {  // (16-byte lanes: 0.26 -> 0.23 ms at cfg5; GF_FAM_ROWS_VW=1 keeps one channel per thread)
-            if (ab == 4) GF_FAM_ROWS(4, 4); else if (ab == 3) GF_FAM_ROWS(4, 3); else if (ab == 2) GF_FAM_ROWS(4, 2); else GF_FAM_ROWS(4, 1);
+        if (vec) {  // (16-byte lanes: 0.26 -> 0.23 ms at cfg5)
+            if (ab == 3) GF_FAM_ROWS(4, 3); else if (ab == 2) GF_FAM_ROWS(4, 2); else GF_FAM_ROWS(4, 1);
         } else {
-            if (ab == 4) GF_FAM_ROWS(1, 4); else if (ab == 3) GF_FAM_ROWS(1, 3); else if (ab == 2) GF_FAM_ROWS(1, 2); else GF_FAM_ROWS(1, 1);
+            if (ab == 3) GF_FAM_ROWS(1, 3); else if (ab == 2) GF_FAM_ROWS(1, 2); else GF_FAM_ROWS(1, 1);
         }
 #undef GF_FAM_ROWS
     } else {

@@ -15,15 +15,26 @@ static thread_local char g_create_err[512] = {0};
 //  same context: one process-wide lock keeps the two messages from interleaving)
 static std::mutex g_err_mutex;
 gf_status fail(gf_ctx *ctx, gf_status st, const char *fmt, ...) {
-    char *dst = ctx ? ctx->err : g_create_err;
     va_list ap;
     va_start(ap, fmt);
-    {
+    if (ctx) {
         std::lock_guard<std::mutex> lock(g_err_mutex);
-        vsnprintf(dst, 512, fmt, ap);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+    } else {
+        vsnprintf(g_create_err, sizeof g_create_err, fmt, ap);   // (thread-local: nobody else writes it)
     }
     va_end(ap);
     return st;
+}
+// what gf_last_error hands out: a per-thread copy taken under the writers' lock, so a message a loader thread is writing into the
+// context is never read half-way (round-3 advice)
+static thread_local char g_err_snapshot[512] = {0};
+static const char *error_snapshot(gf_ctx *ctx) {
+    if (!ctx) return g_create_err;
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    std::memcpy(g_err_snapshot, ctx->err, sizeof g_err_snapshot);
+    g_err_snapshot[sizeof g_err_snapshot - 1] = 0;
+    return g_err_snapshot;
 }
 
 // GF_POISON=1: every device buffer the library hands out WITHOUT contents (workspace, staging, the SMP handle's pool blocks) is
@@ -605,7 +616,7 @@ gf_status gf_ctx_timing_get(gf_ctx *ctx, int index, const char **name, double *t
     return GF_OK;
 }
 
-const char *gf_last_error(gf_ctx *ctx) { return ctx ? ctx->err : gf::g_create_err; }
+const char *gf_last_error(gf_ctx *ctx) { return gf::error_snapshot(ctx); }
 
 size_t gf_contract_workspace_bytes(int K, int N, int C, int batch) {
     if (N <= 0 || C <= 0 || batch <= 0) return 0;

@@ -650,11 +650,7 @@ gf_status gemm_grouped_free_tn(gf_ctx *ctx, const GemmSpec *specs, int n, float 
             return fail(ctx, GF_ERR_UNSUPPORTED, "gemm_grouped_free_tn: group %d is not 16-byte aligned / a multiple of 4", i);
         // at least four k-steps per workgroup, at most `cap` partial images.  (64 until round 3: the per-(node,x) products of level 3
         // -- 168,000 rows -- then ran as 128 workgroups of 82 k-steps each on 256 CUs, one latency chain 140 us long)
-        static const int cap = [] {
-            const char *e = std::getenv("GF_TN_MAX_SPLITS");
-            const int v = e ? std::atoi(e) : 256;   // (cfg3: 0.30 ms at 64, 0.23 at 128, 0.22 at 256, 0.23 at 384 + a slower fold)
-            return v < 1 ? 1 : v;
-        }();
+        constexpr int cap = 256;   // (cfg3: 0.30 ms at 64, 0.23 at 128, 0.22 at 256, 0.23 at 384 + a slower fold)
         int splits = sp.K / (4 * BK);
         if (splits > cap) splits = cap;
         if (splits < 1) splits = 1;

@@ -1140,9 +1140,17 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     {
         const char *e = std::getenv("GF_PREP_DEVICE_TABLES");
         s->lay.device_tables = !(e && e[0] == '0');
+        // build_level_rows keeps three ints per field position and four shorts per vertex of its molecule in LDS: beyond the
+        // default 32 KiB window (a molecule of ~4,000 vertices) the tables are built on the host, as rounds 1-2 built all of them
+        // (decided BEFORE build_batch lays the batch out for one builder or the other; round-3 advice)
+        int vmax = 0;
+        for (int m = 0; m < nMol; ++m) vmax = nVertices[m] > vmax ? nVertices[m] : vmax;
+        const int smax = s->cfg.max_receptive_field > 0 && s->cfg.max_receptive_field < vmax ? s->cfg.max_receptive_field : vmax;
+        if (sizeof(int) * (size_t)smax * 3 + sizeof(short) * 4 * (size_t)vmax + 16 > 32 * 1024) s->lay.device_tables = false;
     }
     s->tab_stats = nullptr;
     s->h_tab_stats.clear();
+    s->h_covered.clear();
     gfsmp::build_batch(s->cfg, nMol, nVertices, adj, feature, coulomb, &s->lay);
     const auto tp2 = std::chrono::steady_clock::now();
     const gfsmp::BatchLayout &B = s->lay;
@@ -1318,8 +1326,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             gf_smp::DevLevel &d = s->lv[l];
             const int smax = h.buckets.empty() ? 1 : h.buckets.back().s;
             const size_t lds = sizeof(int) * (size_t)smax * 3 + sizeof(short) * 4 * (size_t)vmax + 16;
-            if (lds > 64 * 1024) return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare: a receptive field of %d vertices in a molecule of %d "
-                                             "(set GF_PREP_DEVICE_TABLES=0)", smax, vmax);
+            if (lds > 32 * 1024)   // (cannot happen: gf_smp_prepare chose the host builder for such a batch)
+                return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare: a receptive field of %d vertices in a molecule of %d", smax, vmax);
             unsigned *stats = s->tab_stats + 4 * l;
             hipLaunchKernelGGL(gf::build_level_rows, dim3(h.nNodes), dim3(256), lds, up, d.node_s, d.node_mol, d.node_row, d.node_pair, d.field,
                                s->lv[l - 1].field, d.pair_src_pair, d.pair_src_s, s->mol_nv, s->mol_adj_off, s->mol_adj, s->mol_coul, d.adj,
@@ -1338,6 +1346,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         //  preparing thread does not wait for its uploads)
         for (int l = 1; l <= L; ++l) s->lv[l].row_max = s->tab_stats + 4 * l;
         s->h_tab_stats.clear();
+        s->h_covered.clear();
     }
     // (the node tables went up on the handle's upload stream: build the transposed-row tables there too, behind them)
     for (int l = 1; l <= L; ++l) {
@@ -1358,9 +1367,9 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     s->P = nullptr;  // [max ppos][C]: by far the largest buffer of the op-by-op path, taken from the pool only when a level needs it
     s->P_count = (size_t)maxp;  // (positions x channels of the level below, maximised over the levels)
     const gfsmp::LevelLayout &top = B.level[L];
-    s->blkmax = nullptr;
+    s->wbound = nullptr;
     if (!s->cfg.physics && C == 64) {
-        st = gf::upload(s, &s->blkmax, nullptr, (size_t)gf::kBlkCopies * gf::kBlkStride * (L + 1));
+        st = gf::upload(s, &s->wbound, nullptr, gf::smp_wgrad_bound_words() * (size_t)(L + 1));
         if (st != GF_OK) return st;
     }
     st = gf::upload(s, &s->sh, nullptr, (size_t)top.nNodes * C);
@@ -1436,7 +1445,7 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
               (const float *)nullptr, C, (size_t)nV * C);
     s->lv[L].psum_ready = false;
     if (s->fused) {
-        if (s->blkmax) GF_HIP_TRY(ctx, hipMemsetAsync(s->blkmax, 0, sizeof(unsigned) * gf::kBlkCopies * gf::kBlkStride * (size_t)(L + 1), ctx->stream));
+        if (s->wbound) GF_HIP_TRY(ctx, hipMemsetAsync(s->wbound, 0, sizeof(unsigned) * gf::smp_wgrad_bound_words() * (size_t)(L + 1), ctx->stream));
         st = gf::smp_fused_stack_all(s, K);
         if (st != GF_OK) return st;
     }
@@ -1555,6 +1564,10 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
     }
     if (!params || !grads) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: null argument");
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {   // (a no-op after this batch's forward; it makes the reverse sweep independent of who grew the context's workspace last)
+        gf_status st = gf::ensure_ws(ctx, s->ws_need);
+        if (st != GF_OK) return st;
+    }
     const gfsmp::BatchLayout &B = s->lay;
     const int L = s->cfg.nLevels, C = s->cfg.nChanels, FD = s->cfg.fdim();
     const float *H, *W;
@@ -1801,12 +1814,16 @@ long long gf_smp_level_covered_rows(const gf_smp *s, int level) {
     if (!s || !s->prepared || level < 0 || level > s->cfg.nLevels) return -1;
     const gfsmp::LevelLayout &h = s->lay.level[level];
     if (level == 0 || !s->lv[level].rowflag || h.rows == 0) return h.rows;
+    gf_smp *ms = const_cast<gf_smp *>(s);   // (cached per prepared batch; see the header for the threading contract)
+    if (ms->h_covered.size() != (size_t)s->cfg.nLevels + 1) ms->h_covered.assign((size_t)s->cfg.nLevels + 1, -1);
+    if (ms->h_covered[level] >= 0) return ms->h_covered[level];
     std::vector<unsigned char> fl((size_t)h.rows);
     hipStream_t up = s->upload ? s->upload : s->ctx->stream;
     if (hipMemcpyAsync(&fl[0], s->lv[level].rowflag, fl.size(), hipMemcpyDeviceToHost, up) != hipSuccess || hipStreamSynchronize(up) != hipSuccess)
         return -1;
     long long n = 0;
     for (size_t i = 0; i < fl.size(); ++i) n += (fl[i] >> 1) & 1;
+    ms->h_covered[level] = n;
     return n;
 }
 long long gf_smp_level_present_rows(const gf_smp *s, int level) {

@@ -50,25 +50,6 @@ __device__ __forceinline__ f4 fold_two_tables(f4 u, f4 v) {
 constexpr float kAlphaF = 0.01f;
 __device__ __forceinline__ float lreluf(float z) { return z > 0.f ? z : kAlphaF * z; }
 
-// ---- block maxima for the split-operand weight gradients (smp_level_c64_split.hip): the producers of T and dO keep the largest
-// magnitude they write per 64-column block of the level (as float bits: non-negative floats order like integers).  Only the
-// exponent is used.
-__device__ __forceinline__ float amax4(f4 v, float m) {
-    m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), m);
-    return fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), m);
-}
-__device__ __forceinline__ unsigned row16_max(unsigned v) {  // maximum over each row of 16 lanes (DPP)
-    auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
-    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));  // row_half_mirror
-    return mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));  // row_mirror
-}
-// The maxima are kept in kBlkCopies copies, 128 B apart, chosen by the workgroup's index: unconditional atomics whose results
-// nobody waits for, spread over that many cache lines (one hot word per block would serialise ~10^5 atomics a step in one L2
-// channel).  The consumer takes the maximum over the copies.
-__device__ __forceinline__ unsigned *blkmax_copy(unsigned *blkmax) { return blkmax + (blockIdx.x % kBlkCopies) * kBlkStride; }
-
 // column blocks of the table matrix T [rows][4C]
 enum { T_SAB = 0, T_SBC = 1, T_T6 = 2, T_T10 = 3, T_COLS = 4 };
 // column blocks of the projected matrix O [rows][3C].  O_LOC = tot O_tot + tr O_tr + O_dir: the per-node factors tot and
@@ -108,7 +89,6 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
                                                              const int *__restrict__ pair_src_s, const short *__restrict__ pi,
                                                              const int4 *__restrict__ recs,  // two per node, in launch order (build_tf_records)
                                                              int C, int nwin,
-                                                             unsigned *__restrict__ blkmax,    // [4] maxima of T's blocks, or null
                                                              int zeros_kept,  // != 0: the structurally-zero rows (a, b) hold their zeros
                                                              const unsigned char *__restrict__ rowflag) {  // with zeros_kept: bit 1 =
                                                              // row (b, c) has data in S_bc / T10 (the others are not stored either)
@@ -173,8 +153,6 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
         cc[i] = (c < N) ? c : -1;
         rc[i] = (c < N && fok) ? sR[c] : 0.f;
     }
-    float mx_both = 0.f;  // largest |S_ab| (even c-groups) / |T6| (odd c-groups) this lane has produced
-    float mx_sbc = 0.f, mx_t10 = 0.f;
     for (int b = wave; b < N; b += nthreads / 64) {
     f4 sbc[NI], t10[NI];
 #pragma unroll
@@ -235,7 +213,6 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
             t6 += rc[i] * v;
         }
         const f4 both = fold_two_tables(sab, t6);  // even c-groups: S_ab[a,b], odd c-groups: T6[a,b]
-        mx_both = amax4(both, mx_both);
         dgsum += dcur;
         if (allok) {
             // every lane stores (c-groups 0/2 the S_ab block, 1/3 the T6 block; the pairs write identical values to the same
@@ -343,27 +320,7 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
         st4(sc + 0 * C, cs);
         st4(sc + 2 * C, dgsum);
     }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        mx_sbc = amax4(sbc[i], mx_sbc);  // (positions past the node hold zeros)
-        mx_t10 = amax4(t10[i], mx_t10);
-    }
     }  // b
-    if (blkmax) {  // (uniform; once per wave, over all its b)
-        const unsigned rb = row16_max(__float_as_uint(mx_both)), rsb = row16_max(__float_as_uint(mx_sbc)), rt = row16_max(__float_as_uint(mx_t10));
-        auto at = [](unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); };
-        auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
-        const unsigned m_sab = mx(at(rb, 0), at(rb, 32)), m_t6 = mx(at(rb, 16), at(rb, 48));
-        const unsigned m_sbc = mx(mx(at(rsb, 0), at(rsb, 16)), mx(at(rsb, 32), at(rsb, 48)));
-        const unsigned m_t10 = mx(mx(at(rt, 0), at(rt, 16)), mx(at(rt, 32), at(rt, 48)));
-        if (lane == 0) {
-            unsigned *slot = blkmax_copy(blkmax);
-            atomicMax(slot + T_SAB, m_sab);
-            atomicMax(slot + T_SBC, m_sbc);
-            atomicMax(slot + T_T6, m_t6);
-            atomicMax(slot + T_T10, m_t10);
-        }
-    }
 }
 
 // rowsum_a[x] = sum_b S_ab[x,b], D8[x] = sum_b Dbb[x,b] per (node, x); scalars per node = sum over b of the partials.
@@ -716,11 +673,9 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                                                             const int *__restrict__ quad_b0, const int *__restrict__ node_s,
                                                             const long long *__restrict__ node_row,
                                                             const long long *__restrict__ node_pair, int C, int nwin,
-                                                            const float *__restrict__ rsum, int ocols,
-                                                            unsigned *__restrict__ blkmax) {  // [2] maxima of dO's blocks L | dU, or null
+                                                            const float *__restrict__ rsum, int ocols) {
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
-    float mx_l = 0.f, mx_u = 0.f;
     const int tid = threadIdx.x;
     const int grp = tid / LPC, fl = tid % LPC;
     const QuadWhere W = locate_quad(quad_node, quad_b0, node_s, node_row, node_pair, nwin);
@@ -757,7 +712,6 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                 f4 dz;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dz[j] = fok ? g[u][j] * (fv[u][j] > 0.f ? 1.f : kAlphaF) : 0.f;
-                mx_l = amax4(dz, mx_l);
                 st4(sDz + (size_t)it * CW + 4 * fl, dz);
                 if (fok) st4(dO + row * ldo + O_LOC * C + f, dz);
             }
@@ -769,7 +723,6 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
         const float *const Tt[1] = {sDz + (size_t)xi * N * CW};
         f4 m[1];
         small_matvec<1, CW>(L, N, e, fl, Tt, m);  // dU[e] = sum_y A+[y][e] dz[y]
-        mx_u = amax4(m[0], mx_u);
         if (fok) {
             st4(dO + (rowbase + (size_t)x * N + e) * ldo + O_Z * C + f, m[0]);
             if (ocols == 3) st4(dO + (rowbase + (size_t)e * N + x) * ldo + O_ZP * C + f, m[0]);
@@ -786,18 +739,6 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
             }
             float *dst = (k == 0) ? dVout : (k == 1) ? dSpart : dbpart;
             st4(dst + (pairbase + x) * (size_t)C + f, acc);
-        }
-    }
-    if (blkmax) {  // (uniform)
-        const unsigned rl = row16_max(__float_as_uint(mx_l)), ru = row16_max(__float_as_uint(mx_u));
-        auto at = [](unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); };
-        auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
-        const unsigned m_l = mx(mx(at(rl, 0), at(rl, 16)), mx(at(rl, 32), at(rl, 48)));
-        const unsigned m_u = mx(mx(at(ru, 0), at(ru, 16)), mx(at(ru, 32), at(ru, 48)));
-        if ((tid & 63) == 0) {
-            unsigned *slot = blkmax_copy(blkmax);
-            atomicMax(slot, m_l);
-            atomicMax(slot + 1, m_u);
         }
     }
 }
@@ -1016,15 +957,14 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     if (n_hi <= n_lo) return GF_OK;
     const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + 16 * (size_t)c.smax + sizeof(int) * (size_t)c.smax * 4 * NI + 16 +
                        (size_t)c.smax * c.smax + 16;
-    unsigned *bm = s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr;
     const int flags = ((d.t_zeros && (C & 63) == 0) ? 1 : 0);
     if ((C & 63) == 0)
         GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
-                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin, bm,
+                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
                   flags, flags ? d.rowflag : (const unsigned char *)nullptr);
     else
         GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, false>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
-                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin, bm,
+                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
                   flags, (const unsigned char *)nullptr);
     return GF_OK;
 }
@@ -1594,23 +1534,6 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
              {-1, -1, -1, -1}},
         };
         const bool panels = !env_is("GF_SMP_ROWPANEL", '0');  // (read per call: the parity tests switch it)
-        // products + combine in one kernel, O never written (smp_level_c64_fwd.hip): the split-operand compact layout only
-        // (opt-in, GF_SMP_FUSE_FWD=1: correct -- tests/test_smp_gpu.py::test_fused_forward_level... -- but at 3.6 ms against 1.0 + 0.73 ms
-        //  for the two kernels it replaces: U and M together with a panel's operands do not fit 256 registers at two waves per SIMD,
-        //  and at one wave per SIMD the compiler's remaining spills sit in the panel loop, where every scratch reload drains the
-        //  in-order memory queue -- prefetch included.  DESIGN.md section 9.)
-        const bool fuse_fwd = C == 64 && panels && ocols == 2 && d.fwd_pan && smp_split_products(ctx) && env_is("GF_SMP_FUSE_FWD", '1');
-        if (fuse_fwd) {
-            if (!grouped) {  // (the compact products Gc are read by the fused kernel: they must be there before it)
-                const int prevPairs = (int)s->lay.level[l - 1].pairs;
-                st = gemm(ctx, false, false, prevPairs, C, C, d.Fdc, 2 * C, C, d.Wst + 8 * CC, C, (long long)CC, d.Gc, 2 * C, C, 2, 0);
-                if (st != GF_OK) return st;
-            }
-            if (s->side && !grouped) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
-            int cus = 256;
-            GF_HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-            return smp_level_fwd_fused_c64(s, l, T, bl, cus < 1 ? 256 : cus);
-        }
         if (C == 64 && panels) {
             st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, ocols == 2 ? d.trow : nullptr, d.trowf, false,
                                            d.wimg_ready ? d.wimg : nullptr);  // weights in LDS
@@ -1731,8 +1654,14 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     FoldGroup rowg;
     const bool stationary = C == 64 && !env_is("GF_SMP_WGRAD", '0');
     if (stationary) {
-        st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg, ocols == 2 ? d.trow : nullptr,
-                                    s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride : nullptr, d.max_tot, d.max_tr, d.trowf, d.row_max);
+        unsigned *wb = (s->wbound && ocols == 2 && smp_split_products(ctx)) ? s->wbound + (size_t)l * smp_wgrad_bound_words() : nullptr;
+        if (wb) {   // the column bounds of this level's operand blocks, from the largest |f_{l-1}| and |df_l| of every channel
+            const bool top = l == s->cfg.nLevels;   // (top level: df_L is the per-node readout gradient, broadcast over the node's rows)
+            st = smp_wgrad_column_bounds(ctx, pv.f, (long long)s->lay.level[l - 1].rows, top ? s->dsh : d.df, top ? (long long)nodes : (long long)rows,
+                                         h.buckets.back().s, d.max_tot, d.max_tr, d.row_max, wb);
+            if (st != GF_OK) return st;
+        }
+        st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg, ocols == 2 ? d.trow : nullptr, wb ? wb + 128 : nullptr, d.trowf);
         if (st != GF_OK) return st;
         used = (size_t)rowg.splits * rowg.n;
     } else {  // other channel counts: the grouped split-K launch (its own ordered reduction) into the stacked image, one "image"
@@ -1860,7 +1789,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
                   d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
-                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS, s->blkmax ? s->blkmax + (size_t)l * kBlkCopies * kBlkStride + 4 : nullptr);
+                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS);
     }
     if (smp_grouped_small(s)) return smp_fused_backward_level_grouped(s, l, dKl, dbl);
     GF_LAUNCH(ctx, "smpf_node_sum", smp_node_sum, dim3(nodes), dim3(64), 0, d.dSpart, d.dSout, d.node_s, d.node_pair, C);

@@ -52,21 +52,22 @@ size_t smp_split_image_bytes();
 gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n);
 gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *prog, const float *const *In, float *const *Out, const int *rows,
                               const int *pos0, const void *wimg, const char *name);
-// blkmax: the level's block maxima (gf_smp::blkmax), kept by the producers of T and dO; max_tot / max_tr: of the level's row factors
+// cmax: the level's per-column magnitude bounds of the nine operand blocks (smp_level_c64_split.hip: smp_wgrad_split)
 gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
-                                       int splits, float *part, const int *trow, const unsigned *blkmax, float max_tot, float max_tr,
-                                       const int *trowf = nullptr, const unsigned *row_max = nullptr);
+                                       int splits, float *part, const int *trow, const unsigned *cmax, const int *trowf = nullptr);
+size_t smp_wgrad_bound_words();
+gf_status smp_wgrad_column_bounds(gf_ctx *ctx, const float *fprev, long long prev_rows, const float *dsrc, long long drows, int smax,
+                                  float max_tot, float max_tr, const unsigned *row_max, unsigned *words);
+size_t smp_wgrad_bound_words_exact();
+gf_status smp_wgrad_column_bounds_exact(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, unsigned *words);
 gf_status splitk_fold(gf_ctx *ctx, const float *part, float *dest, size_t total, int splits, int accumulate);
 gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst);
 // the same product, partial images only (fold == caller's): `part` receives out->splits images of 8 * 64 * 64 floats
 gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
-                                 size_t part_floats, FoldGroup *out, const int *trow, const unsigned *blkmax = nullptr,
-                                 float max_tot = 0.f, float max_tr = 0.f, const int *trowf = nullptr, const unsigned *row_max = nullptr);
+                                 size_t part_floats, FoldGroup *out, const int *trow, const unsigned *cmax = nullptr,
+                                 const int *trowf = nullptr);
 }
 
-namespace gf {
-constexpr int kBlkCopies = 64, kBlkStride = 32;  // copies of a level's block maxima, words between them (128 B)
-}
 
 struct gf_smp {
     gf_ctx *ctx = nullptr;
@@ -116,7 +117,7 @@ struct gf_smp {
         void *wimg = nullptr;  // the split product kernels' weight images of this pass (smp_split_build_images), C = 64
         bool wimg_ready = false;
         int *trowf = nullptr;  // [rows] trow | bit 31: rowflag of the row | bit 30: rowflag of the transposed row (smp_rowpanel_split)
-        float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients)
+        float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients' column bounds)
         const unsigned *row_max = nullptr;  // the same two as float bits in device memory when the tables are built there
         long long *pair_src_pair = nullptr, *cons_row = nullptr, *cons_pair = nullptr;  // compact diagonal path (smp_prep.h)
         int *node_center = nullptr, *cons_a = nullptr, *mol_order = nullptr, *gather_items = nullptr;
@@ -144,10 +145,10 @@ struct gf_smp {
     double *mol_coul = nullptr;
     unsigned *tab_stats = nullptr;          // [levels + 1][4]: max |tot|, max |tr| (float bits), rows with data (two words)
     std::vector<unsigned> h_tab_stats;
-    // [levels + 1][kBlkCopies][kBlkStride] largest magnitudes (float bits) written this step into T's four blocks (words [0..4) of a
-    // copy) and dO's two ([4..6)) of a level, kept by the producing kernels for the split-operand weight gradients
-    // (smp_level_c64_split.hip); C = 64 only
-    unsigned *blkmax = nullptr;
+    std::vector<long long> h_covered;       // [levels + 1] cache of gf_smp_level_covered_rows (-1 = not read yet), cleared by prepare
+    // [levels + 1][smp_wgrad_bound_words()] per-channel maxima of f_{l-1} and of df_l and the column bounds the split-operand weight
+    // gradients derive from them (smp_level_c64_split.hip: smp_wgrad_column_bounds); C = 64 only, zeroed at the start of every forward
+    unsigned *wbound = nullptr;
     float *x = nullptr;      // [nVertices][FD]
     float *P = nullptr;      // shared promotion / dP buffer, max over levels of ppos*C; allocated on first use (ensure_P):
     size_t P_count = 0;      // the fused levels with the folded backward gather never materialise it
@@ -198,7 +199,6 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_build_tf_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream);
-gf_status smp_level_fwd_fused_c64(gf_smp *s, int l, const float *T, const float *bias, int cus);
 gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts

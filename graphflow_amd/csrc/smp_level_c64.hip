@@ -429,8 +429,7 @@ __global__ __launch_bounds__(TH, 1) void smp_rowpanel_c64(const float *__restric
 // 8 x 64 x 64 floats per row range.  T = [rows][256], dO = [rows][192], rowscale = [rows][2].  The row range per workgroup
 // depends on `rows` only: results are reproducible.  The caller folds the images in order.
 gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
-                                 size_t part_floats, FoldGroup *out, const int *trow, const unsigned *blkmax, float max_tot,
-                                 float max_tr, const int *trowf, const unsigned *row_max) {
+                                 size_t part_floats, FoldGroup *out, const int *trow, const unsigned *cmax, const int *trowf) {
     const size_t total = 8 * 4096;
     out->part = part;
     out->n = total;
@@ -445,8 +444,8 @@ gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, c
     if ((size_t)splits * total > part_floats)
         return fail(ctx, GF_ERR_NOMEM, "smp_wgrad_partials_c64: %d partial images, room for %zu", splits, part_floats / total);
     out->splits = splits;
-    if (trow && blkmax && smp_split_products(ctx))
-        return smp_wgrad_partials_split_c64(ctx, T, dO, rowscale, rows, kchunk, splits, part, trow, blkmax, max_tot, max_tr, trowf, row_max);
+    if (trow && cmax && smp_split_products(ctx))
+        return smp_wgrad_partials_split_c64(ctx, T, dO, rowscale, rows, kchunk, splits, part, trow, cmax, trowf);
     const size_t lds = sizeof(float) * 2 * (size_t)kWgStage;
     gf_status st = opt_in_lds(ctx, smp_wgrad_c64, lds);
     if (st != GF_OK) return st;

@@ -62,7 +62,7 @@ gf_status gf_ctx_set_timing(gf_ctx *ctx, int enable);
 gf_status gf_ctx_set_timing_filter(gf_ctx *ctx, const char *kernel_name);
 int       gf_ctx_timing_count(gf_ctx *ctx);
 gf_status gf_ctx_timing_get(gf_ctx *ctx, int index, const char **name, double *total_ms, long long *launches);
-const char *gf_last_error(gf_ctx *ctx);                     /* valid until the next call on ctx; ctx may be NULL for create errors */
+const char *gf_last_error(gf_ctx *ctx);                     /* a per-thread copy: valid until this thread's next gf_last_error; ctx may be NULL for create errors */
 const char *gf_version(void);
 /* Per-context options.  GF_OPT_R18_GENERIC_KERNELS != 0 routes RisiContraction_18 through the layout-agnostic generic
  * kernels (any N, any C, one thread per table / output element) instead of the slab kernels: the independent second
@@ -324,7 +324,10 @@ gf_status gf_smp_level_sizes(const gf_smp *smp, int level, long long *nodes, lon
  * level neither writes, reads nor back-propagates the other rows' S_ab / T6 table blocks; the bench prices its kernels with it. */
 long long gf_smp_level_present_rows(const gf_smp *smp, int level);
 /* ... and the rows (b, c) that SOME source covers (both vertices inside one source's field): the others' S_bc / T10 blocks are
- * structural zeros as well.  Equal to `rows` where the handle keeps no row flags (channel counts other than 64).  Blocking. */
+ * structural zeros as well.  Equal to `rows` where the handle keeps no row flags (channel counts other than 64).
+ * Both calls are introspection for tests and the bench: the first call after a prepare blocks on a device-to-host copy (the
+ * result is then cached until the next prepare), and neither may run concurrently with gf_smp_prepare / gf_smp_destroy on the
+ * SAME handle (they read the tables prepare replaces).  Other handles of the context are unaffected. */
 long long gf_smp_level_covered_rows(const gf_smp *smp, int level);
 
 /* RisiContraction_18_dropout inside a physics tower (SMP_sigma_pairgraphs.h:248-265, :632-651): masks[(l-1) * nVertices + gv] =

@@ -5,20 +5,21 @@ every weight-gradient block, not by one global maximum (round-2 review, weak #2)
 confined to the small entries of a row whose largest entry is 10^5 .. 10^6 times bigger.
 
 What the split arithmetic is: x 2^k = h + l with f16 halves, k chosen per (row, 64-column block) (products) or per (level,
-64-column block) (weight gradients) so that the block's largest magnitude lands in [2^13, 2^14).  f16 is a floating-point format,
-so an element keeps 22 significant bits OF ITS OWN as long as its l half stays normal -- down to 2^-17 (1.3e5) of the block
-maximum -- and loses one bit per binary order below that (l goes subnormal, quantum 2^-24 at the scaled magnitude).  Measured
-here, with weights that IGNORE the loud channel in half of the output columns (so those outputs are made of the small entries
-alone):
+64-column block) (weight gradients) so that the block's largest magnitude lands in [2^13, 2^14).  Round 4: the LOW half is carried
+at 2^11 times its value (l' = rn_f16((x 2^k - h) 2^11)), the two cross products are accumulated on their own and multiplied by
+2^-11 before the main product is added.  Unscaled (rounds 2-3), l went subnormal for every element more than 2^17 below the block
+maximum, which then lost one bit per binary order (~15 bits at 2^24 : 1: the round-3 review's weak #1); scaled, an element keeps
+its 22 significant bits down to 2^-27 of the block maximum -- more range than an fp32 sum of the same terms resolves -- so there
+is no window to detect and nothing to fall back from.  Measured here, with weights that IGNORE the loud channel in half of the
+output columns (so those outputs are made of the small entries alone), all with DEFAULT settings:
 
     in-block range     products, per (row, half)      weight gradients, per (block, row, column class)
     1e5 : 1            <= 1e-5  (asserted)            <= 1e-5  (asserted)
-    1e6 : 1            ~1e-5    (asserted <= 3e-5)    ~2e-5    (asserted <= 5e-5)
-    2^24 : 1           ~1e-4    (shown, <= 1e-3)
+    1e6 : 1            <= 1e-5  (asserted)            <= 1e-5  (asserted)
+    2^24 : 1           <= 1e-5  (asserted)            <= 1e-5  (asserted)
 
-i.e. the split path is component-wise fp32-grade inside a 2^17 window per block and degrades one bit per octave beyond it; the
-fp32 pipe (GF_SMP_SPLIT=0 / gf_ctx_set_option(GF_OPT_SMP_FP32_PRODUCTS), same entry points, held to 1e-5 at every range below and
-timed beside the split step by bench.py) has no window.  DESIGN.md section 5 states the same."""
+The fp32 pipe (GF_SMP_SPLIT=0 / gf_ctx_set_option(GF_OPT_SMP_FP32_PRODUCTS), same entry points, timed beside the split step by
+bench.py) is held to the same bounds.  DESIGN.md section 5 states the same."""
 import ctypes as C
 
 import numpy as np
@@ -115,8 +116,8 @@ def make_case(rng, rows, width, big=1e6):
     return A.astype(np.float32), hot
 
 
-# (pipe, in-block range, bound): the window of the split operands (module docstring); the fp32 pipe has none
-CASES = [("split", 1e5, TOL), ("split", 1e6, 3e-5), ("fp32", 1e5, TOL), ("fp32", 1e6, TOL)]
+# (pipe, in-block range, bound): one bound for every range and both pipes (module docstring)
+CASES = [("split", 1e5, TOL), ("split", 1e6, TOL), ("split", 2.0 ** 24, TOL), ("fp32", 1e5, TOL), ("fp32", 1e6, TOL), ("fp32", 2.0 ** 24, TOL)]
 
 
 @pytest.mark.parametrize("pipe,big,bound", CASES)
@@ -146,7 +147,7 @@ def test_products_per_row_with_a_loud_channel_inside_a_block(gf, monkeypatch, pi
     assert e_f <= bound and e_b <= bound, (e_f, e_b)
 
 
-@pytest.mark.parametrize("pipe,big,bound", [("split", 1e5, TOL), ("split", 1e6, 5e-5), ("fp32", 1e5, TOL), ("fp32", 1e6, TOL)])
+@pytest.mark.parametrize("pipe,big,bound", [("split", 1e5, TOL), ("split", 1e6, TOL), ("split", 2.0 ** 24, TOL), ("fp32", 1e5, TOL), ("fp32", 1e6, TOL)])
 def test_wgrad_per_row_when_one_molecule_dominates_the_level(gf, monkeypatch, pipe, big, bound):
     """Weight gradients reduce over the rows, so the split path carries ONE exponent per operand block per level.  200 rows of one
     'molecule' are `big` times larger than the other 5000 -- but only in half of the channels: the rows of dW that belong to the
@@ -177,17 +178,19 @@ def test_wgrad_per_row_when_one_molecule_dominates_the_level(gf, monkeypatch, pi
     assert worst <= bound, worst
 
 
-def test_products_scale_window_is_documented(gf):
-    """The edge of the window: at 2^24 : 1 inside one row block the small entries keep ~15 bits on the split path --
-    this is the documented limit, shown, not hidden: the per-row error is above 1e-5 there and well below 1e-3."""
+def test_products_far_beyond_fp32_range_inside_a_block(gf):
+    """2^27 : 1 and 2^30 : 1 inside one row block -- more than the 24 bits an fp32 sum of the same terms resolves: the small entries
+    still come out at 1e-5 of their own outputs (h keeps its bits down to 2^-27 of the block maximum; beyond that the error is
+    2^-28 of the block maximum, absolute)."""
     rng = np.random.default_rng(3)
     rows = 512
     trow = involution(rows, rng)
     rs = np.ones((rows, 2), dtype=np.float32)
-    T, hot = make_case(rng, rows, 256, big=2.0 ** 24)
-    W = rng.uniform(-1, 1, (8, 64, 64)).astype(np.float32)
-    for h in hot:
-        W[:, h % 64, :32] = 0.0
-    e = row_half_err(run_products(gf, False, T, rs, W, trow), forward_ref(T, rs, W, trow))
-    print("block products (split pipe) at 2^24 : 1 inside a row block: per-(row, half) rel err %.2e" % e)
-    assert e <= 1e-3
+    for big in (2.0 ** 27, 2.0 ** 30):
+        T, hot = make_case(rng, rows, 256, big=big)
+        W = rng.uniform(-1, 1, (8, 64, 64)).astype(np.float32)
+        for h in hot:
+            W[:, h % 64, :32] = 0.0
+        e = row_half_err(run_products(gf, False, T, rs, W, trow), forward_ref(T, rs, W, trow))
+        print("block products (split pipe) at 2^%d : 1 inside a row block: per-(row, half) rel err %.2e" % (int(np.log2(big)), e))
+        assert e <= TOL, (big, e)
