@@ -37,6 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable with a float4 copy)
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
+MFMA_F16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (the vendor's 5 PF figure includes 2:1 sparsity)
 
 
 def copy_ceiling_gbps(torch, dev):
@@ -231,14 +232,14 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
 
     c64 = C == 64
     # projected matrix O / dO: [O_loc | U] (2C) when the three dedicated C = 64 product kernels run, else [O_loc | Z | Z'] (3C)
-    oc = 2 if (c64 and all(os.environ.get(k, "1") != "0" for k in ("GF_SMP_ROWPANEL", "GF_SMP_WGRAD", "GF_SMP_GROUPED", "GF_SMP_COMPACT_O"))) else 3
+    oc = 2 if (c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0") else 3
     # ... and then the three product kernels run on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip): 3 MFMA
     # flops of a 16x faster pipe per algorithmic flop -- they are HBM streams, priced against the HBM roofline
     split = oc == 2 and os.environ.get("GF_SMP_SPLIT", "1") != "0"
     # rows (a, b) whose S_ab / T6 table blocks are not structural zeros (b inside the field of a's source): at C = 64 the other rows'
     # blocks are neither written (tables-forward), read (forward products, weight gradients) nor back-propagated (backward products,
     # gather) -- bytes that need not move are not counted as moved
-    masked = split and fused and os.environ.get("GF_SMP_MASK_ZEROS", "1") != "0" and os.environ.get("GF_SMP_KEEP_ZEROS", "1") != "0"
+    masked = split and fused and os.environ.get("GF_SMP_MASK_ZEROS", "1") != "0"
     present = [net.level_present_rows(l) for l in range(L + 1)]
     covered = [net.level_covered_rows(l) for l in range(L + 1)]   # rows (b, c) some source covers: the S_bc / T10 blocks with data
     for l in range(1, L + 1):
@@ -258,7 +259,7 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
                 add(kb, "smp_promote_bwd", 4 * (S * C + Rp * C))
             names = (("smpf_products_fwd" if c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0" else "gemm_nn"),
                      ("smpf_products_bwd" if c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0" else "gemm_nt"),
-                     ("smpf_wgrad" if c64 and os.environ.get("GF_SMP_WGRAD", "1") != "0" else "gemm_tn"))
+                     ("smpf_wgrad" if c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0" else "gemm_tn"))
             for k in names:
                 add(kf, k, 8 * unit)
                 add(kb, k, 4 * ((dTw if k == "smpf_products_bwd" else Tb) + oc * R * C))   # T (4C) and O / dO per row, each once
@@ -321,6 +322,27 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
         roof["step_composite_frac"] = round(ideal_ms / ms_per_step, 4)
         roof["step_GBps"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
         roof["step_gemm_TFLOPs"] = round(step_flops / (ms_per_step * 1e-3) / 1e12, 2)
+        # north_star: "MFMA utilisation reported against gfx950 peak".  Split path: every algorithmic product term is three
+        # v_mfma_f32_32x32x16_f16 (ah bh + ah bl + al bh), so the matrix pipe executes 3x the algorithmic flops, at the f16 rate; the
+        # fp32 pipe (GF_SMP_SPLIT=0) executes them once at the fp32-input rate.  Per product kernel: executed flops / its device time
+        # / the dense peak of the instruction it issues; `busy_pmc`: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of the committed
+        # counter pass (profiles/*_cfg3_mfma_busy.txt), when there is one for the kernels that ran.
+        peak, mult = (MFMA_F16_PEAK_TF, 3.0) if split else (MFMA_F32_PEAK_TF, 1.0)
+        mu = {"instruction": "v_mfma_f32_32x32x16_f16 (3 per product term)" if split else "v_mfma_f32_32x32x2_f32", "peak_TFLOPs": peak,
+              "per_kernel": {k: round(mult * kf[k] / (tot[k] * 1e-3) / 1e12 / peak, 4) for k in kf if k in tot and tot[k] > 0},
+              "step": round(mult * step_flops / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
+        if busy and fused and (B, C) == (1024, 64):
+            names = {"smpf_products_fwd": ("smp_rowpanel_split<true", "smp_rowpanel_c64<true"), "smpf_products_bwd": ("smp_rowpanel_split<false", "smp_rowpanel_c64<false"),
+                     "smpf_wgrad": ("smp_wgrad_split", "smp_wgrad_c64")}
+            pm = {}
+            for line in open(busy):
+                for k, (a, b) in names.items():
+                    if line.startswith(a if split else b) and "MFMA busy" in line:
+                        pm[k] = float(line.rsplit("MFMA busy", 1)[1])
+            if pm:
+                mu["busy_pmc"] = pm
+                mu["busy_pmc_source"] = os.path.basename(busy)
+        roof["mfma_util"] = mu
         return roof
 
     def cpu():

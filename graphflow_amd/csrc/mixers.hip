@@ -526,7 +526,6 @@ gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs
     ga.panel_is_split = 0;
     ga.npanels = (rows + BM - 1) / BM;
     ga.window = 8;
-    if (const char *e = std::getenv("GF_GEMM_WINDOW")) ga.window = std::max(1, std::atoi(e));
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         if (specs[i].M != rows) return fail(ctx, GF_ERR_INVALID, "gemm_grouped_rows: group %d has M=%d, expected %d", i, specs[i].M, rows);
@@ -548,7 +547,6 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
     ga.panel_is_split = 1;
     ga.npanels = 0;   // (set to the split count below)
     ga.window = 1;
-    if (const char *e = std::getenv("GF_GEMM_WINDOW_TN")) ga.window = std::max(1, std::atoi(e));
     int tiles = 0;
     size_t total = 0;
     for (int i = 0; i < n; ++i) {

@@ -633,10 +633,9 @@ void *pinned_table_alloc(size_t bytes) {
     void *p = nullptr;
     const size_t total = bytes + 16;
     unsigned kind = 1;
-    if (std::getenv("GF_PINNED_TABLES") && std::getenv("GF_PINNED_TABLES")[0] == '0') p = nullptr;
     // (portable: the preparation's worker threads never call hipSetDevice, and a table pinned against device 0 only would be
     //  pageable memory to the uploads of every other rank's device)
-    else if (hipHostMalloc(&p, total, hipHostMallocPortable) != hipSuccess) p = nullptr;
+    if (hipHostMalloc(&p, total, hipHostMallocPortable) != hipSuccess) p = nullptr;
     if (!p) {
         (void)hipGetLastError();
         p = std::malloc(total);
@@ -693,20 +692,6 @@ gf_status upload(gf_smp *s, T **dst, const void *src, size_t count) {
 gf_status ensure_P_impl(gf_smp *s) {
     if (s->P) return GF_OK;
     return upload(s, &s->P, nullptr, s->P_count);
-}
-
-// the second stream of the fused levels (smp_internal.h), created on first use
-void ensure_side_stream(gf_smp *s) {
-    if (s->side_tried) return;
-    s->side_tried = true;
-    // Off unless GF_SMP_OVERLAP=1: worth -0.3 ms of a 16.5 ms cfg3 step, but two GEMMs sharing the machine make per-kernel
-    // durations (and the roofline fraction computed from them) meaningless, so the measured default keeps one stream.
-    const char *e = std::getenv("GF_SMP_OVERLAP");
-    if (!(e && e[0] == '1')) return;
-    if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)
-        s->side = nullptr;
 }
 
 // End of a batch: its buffers go back to the pool (blocks idle for three batches in a row are returned to the device).
@@ -899,12 +884,6 @@ gf_status gf_smp_destroy(gf_smp *s) {
     if (s->ev_last) (void)hipEventDestroy(s->ev_last);
     if (s->ev_grad) (void)hipEventDestroy(s->ev_grad);
     if (s->ev_comm) (void)hipEventDestroy(s->ev_comm);
-    if (s->side) {
-        (void)hipStreamSynchronize(s->side);
-        (void)hipStreamDestroy(s->side);
-        (void)hipEventDestroy(s->ev_fork);
-        (void)hipEventDestroy(s->ev_join);
-    }
     if (s->adam_m) (void)hipFree(s->adam_m);
     if (s->adam_v) (void)hipFree(s->adam_v);
     if (s->own_p) (void)hipFree(s->own_p);
@@ -1284,7 +1263,12 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                 if (l == L) {
                     st = gf::upload(s, &d.psum, nullptr, (size_t)np * 64);
                     if (st != GF_OK) return st;
+                } else {
+                    st = gf::upload(s, &d.pmax, nullptr, (size_t)np * 64);
+                    if (st != GF_OK) return st;
                 }
+                st = gf::upload(s, &d.dzmax, nullptr, h.quad_node.size() * 64);
+                if (st != GF_OK) return st;
                 st = gf::upload(s, &d.fwd_pan_node, nullptr, (size_t)np);
                 if (st != GF_OK) return st;
                 st = gf::upload(s, &d.fwd_goff, nullptr, (size_t)h.rows);
@@ -1436,7 +1420,6 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     const float *H, *W;
     std::vector<const float *> K, b;
     gf::view_params<const float>(s->cfg, params, &H, &K, &b, &W);
-    gf::ensure_side_stream(s);
     // level 0: f_0 = LeakyReLU(X H^T)   (MatMul(H, x_v) per vertex, SMP_omega.h:618)
     const int nV = B.level[0].nNodes;
     st = gf::gemm(ctx, false, true, nV, C, FD, s->x, FD, 0, H, FD, 0, s->lv[0].f, C, 0, 1, 0);
@@ -1444,6 +1427,7 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)nV * C)), dim3(256), 0, s->lv[0].f,
               (const float *)nullptr, C, (size_t)nV * C);
     s->lv[L].psum_ready = false;
+    for (int l = 0; l <= L; ++l) s->lv[l].pmax_ready = false;
     if (s->fused) {
         if (s->wbound) GF_HIP_TRY(ctx, hipMemsetAsync(s->wbound, 0, sizeof(unsigned) * gf::smp_wgrad_bound_words() * (size_t)(L + 1), ctx->stream));
         st = gf::smp_fused_stack_all(s, K);
@@ -1616,7 +1600,6 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
         GF_LAUNCH(ctx, "smp_readout_bwd", gf::readout_backward_nodes, dim3(top.nNodes), dim3(256), 0, s->dy, W, s->sh,
                   s->top_node_mol, s->lv[L].node_s, s->lv[L].node_row, s->lv[L].df, C);
     }
-    gf::ensure_side_stream(s);
     for (int l = L; l >= 1; --l) {
         const gfsmp::LevelLayout &h = B.level[l];
         const gf_smp::DevLevel &d = s->lv[l];
@@ -1665,10 +1648,6 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
             st = feature_backward(l - 1, 1);
             if (st != GF_OK) return st;
         }
-    }
-    if (s->side_pending) {  // join: the weight gradients (and their use of the split-K workspace) are complete
-        GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
-        s->side_pending = false;
     }
     // level 0: dZ0 = dF0 * lrelu'; dH += dZ0^T X
     {

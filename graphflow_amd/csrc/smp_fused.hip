@@ -447,24 +447,13 @@ __global__ __launch_bounds__(256) void tables_zero_fill(float *__restrict__ T, c
     }
 }
 
-// stacked[p] = K^(kperm[p])  (gather), or  dK^(kperm[p]) += dstacked[p]  (scatter-add).  Block k of the level weight is
+// stacked[p] = K^(kperm[p])  (gather; the gradients take the inverse permutation in smp_fold_level).  Block k of the level weight is
 // K[(k C + ci) C + co] in the SMP_omega layout [18C][C] and K[co 18C + k C + ci] in the CustomMatMulTensor layout [C][18C]
 // (custom != 0, SMP_2D_ver8): the stacked copy is [ci][co] either way, so the block GEMMs do not care.
 __device__ __forceinline__ size_t weight_index(int k, int r, int C, int custom) {
     const int ci = r / C, co = r % C;
     return custom ? (size_t)co * 18 * C + (size_t)k * C + ci : ((size_t)k * C + ci) * C + co;
 }
-__global__ void stack_weights(const float *__restrict__ K, float *__restrict__ stacked, int C, int custom) {
-    const int CC = C * C;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 18 * CC; i += gridDim.x * blockDim.x)
-        stacked[i] = K[weight_index(c_kperm[i / CC], i % CC, C, custom)];
-}
-__global__ void unstack_weight_grads(const float *__restrict__ dstacked, float *__restrict__ dK, int C, int custom) {
-    const int CC = C * C;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 18 * CC; i += gridDim.x * blockDim.x)
-        dK[weight_index(c_kperm[i / CC], i % CC, C, custom)] += dstacked[i];
-}
-
 // every level's stacked copy in one launch (the parameters are fixed for the whole forward pass)
 constexpr int kStackLevels = 8;
 struct StackAll {
@@ -481,8 +470,8 @@ __global__ void stack_weights_all(StackAll a, int C, int custom) {
 }
 
 // One pass over the per-(node,x) partials of combine-backward for a block of nodes [n0, n1):
-//   dSout[n] = sum_x dSpart[(n,x)]                       (was smp_node_sum)
-//   colpart[block] = sum over the block's pairs of dbpart    (was colsum_chunks; folded in order by smp_fold_level)
+//   dSout[n] = sum_x dSpart[(n,x)]
+//   colpart[block] = sum over the block's pairs of dbpart    (folded in order by smp_fold_level)
 // 256 threads = row groups x C/4 float4 lanes (C % 4 == 0, C <= 1024); the groups are folded through LDS in a fixed order.
 __global__ __launch_bounds__(256) void smp_reduce_pairs(const float *__restrict__ dSpart, const float *__restrict__ dbpart,
                                                         float *__restrict__ dSout, float *__restrict__ colpart,
@@ -514,7 +503,7 @@ __global__ __launch_bounds__(256) void smp_reduce_pairs(const float *__restrict_
 //   [8,9), [9,10)            <- dK15, dK16 on the compact rows                  (n = C^2 each)
 //   [10,14), [14,18)         <- the per-(node,x) and per-node products          (n = 4 C^2 each)
 //   bias                     <- the column partials of smp_reduce_pairs         (n = C)
-// dK_l[weight_index(kperm[p], .)] += sum (the un-stacking permutation of unstack_weight_grads), db_l += sum.
+// dK_l[weight_index(kperm[p], .)] += sum (the inverse of stack_weights_all's permutation), db_l += sum.
 // 256 threads = 64 outputs x 4 split quarters: a quarter sums its run of images in order (8 loads in flight), the four
 // quarters are then added in order through LDS -- the summation tree depends on the image count only.
 constexpr int kFoldGroups = 6;
@@ -673,7 +662,9 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                                                             const int *__restrict__ quad_b0, const int *__restrict__ node_s,
                                                             const long long *__restrict__ node_row,
                                                             const long long *__restrict__ node_pair, int C, int nwin,
-                                                            const float *__restrict__ rsum, int ocols) {
+                                                            const float *__restrict__ rsum, int ocols,
+                                                            float *__restrict__ dzmax) {  // or null: [workgroups][CW] largest |dz| per column
+    // of this workgroup's rows (C = 64: the weight gradients' column exponents, smp_wgrad_column_bounds)
     constexpr int CW = 4 * LPC;
     constexpr int NGRP = kThreads / LPC;
     const int tid = threadIdx.x;
@@ -685,6 +676,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
     const bool fok = f < C;
     const int fc = fok ? f : 0;
     const size_t ldo = (size_t)ocols * C;
+    f4 dzm = splat(0.f);
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AdjLds L = load_adjacency_lite<true>(smem, A + rowbase, rsum + pairbase, N);  // L.A[e][y] = A+[y][e]; see the barrier below
@@ -712,6 +704,8 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                 f4 dz;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dz[j] = fok ? g[u][j] * (fv[u][j] > 0.f ? 1.f : kAlphaF) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dzm[j] = fmaxf(dzm[j], fabsf(dz[j]));
                 st4(sDz + (size_t)it * CW + 4 * fl, dz);
                 if (fok) st4(dO + row * ldo + O_LOC * C + f, dz);
             }
@@ -741,59 +735,19 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
             st4(dst + (pairbase + x) * (size_t)C + f, acc);
         }
     }
-}
-
-// out[f] += sum_r part[r][f] over `rows` rows: chunked partial sums, then a fixed-order fold (deterministic).
-// 256 threads = row groups x C/4 float4 lanes (C % 4 == 0, C <= 1024), batched loads, ordered LDS fold of the groups.
-__global__ __launch_bounds__(256) void colsum_chunks(const float *__restrict__ part, float *__restrict__ tmp, int C, long long rows,
-                                                     int rows_per_block) {
-    __shared__ __attribute__((aligned(16))) float red[1024];
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
-    const int nr = (int)((r0 + rows_per_block < rows ? r0 + rows_per_block : rows) - r0);
-    const int nl = C / 4, ng = 256 / nl;
-    const int g = threadIdx.x / nl, fl = threadIdx.x % nl;
-    if (g < ng) {
-        const int cnt = (nr - g + ng - 1) / ng;
-        st4(red + g * C + 4 * fl, batched_sum(part + ((size_t)r0 + g) * C + 4 * fl, (size_t)ng * C, 0, cnt > 0 ? cnt : 0,
-                                              [](int) { return 1.f; }));
-    }
-    __syncthreads();
-    if (g == 0) {
-        f4 t = ld4(red + 4 * fl);
-        for (int k = 1; k < ng; ++k) t += ld4(red + k * C + 4 * fl);
-        st4(tmp + (size_t)blockIdx.x * C + 4 * fl, t);
-    }
-}
-__global__ __launch_bounds__(1024) void colsum_fold(const float *__restrict__ tmp, float *__restrict__ out, int C, int nblocks) {
-    __shared__ float red[1024];
-    const int nt = (int)blockDim.x;  // 1024: sixteen row groups at C = 64 (a single workgroup keeps the fold ordered)
-    const int lanes = (C < nt) ? C : nt, rl = nt / lanes;
-    const int f0 = threadIdx.x % lanes, rr = threadIdx.x / lanes;
-    for (int fb = 0; fb < C; fb += lanes) {
-        const int f = fb + f0;
-        float s = 0.f;
-        if (f < C && rr < rl)
-            for (int b = rr; b < nblocks; b += rl) s += tmp[(size_t)b * C + f];
-        red[threadIdx.x] = s;
+    if (dzmax) {  // (uniform) the sixteen row groups' maxima through the image of dz, which nobody reads any more
         __syncthreads();
-        if (rr == 0 && f < C) {
-            float t = 0.f;
-            for (int k = 0; k < rl; ++k) t += red[k * lanes + f0];
-            out[f] += t;
+        st4(sDz + (size_t)grp * CW + 4 * fl, dzm);
+        __syncthreads();
+        if (grp == 0) {
+            f4 m = dzm;
+            for (int g = 1; g < NGRP; ++g) {
+                const f4 v = ld4(sDz + (size_t)g * CW + 4 * fl);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+            }
+            st4(dzmax + (size_t)blockIdx.x * CW + 4 * fl, m);
         }
-        __syncthreads();
-    }
-}
-
-// dSout[n] = sum_x dSpart[(n,x)]
-__global__ void smp_node_sum(const float *__restrict__ part, float *__restrict__ out, const int *__restrict__ node_s,
-                             const long long *__restrict__ node_pair, int C) {
-    const int n = blockIdx.x;
-    const int s = node_s[n];
-    for (int f = threadIdx.x; f < C; f += blockDim.x) {
-        float acc = 0.f;
-        for (int x = 0; x < s; ++x) acc += part[((size_t)node_pair[n] + x) * C + f];
-        out[(size_t)n * C + f] = acc;
     }
 }
 
@@ -912,7 +866,6 @@ size_t combine_lds(int N) {
 static int node_block(const gfsmp::LevelLayout &h, int C) {
     const int smax = h.buckets.empty() ? 1 : h.buckets.back().s;
     int t = (smax * (C / 4) + 63) / 64 * 64;
-    if (const char *e = std::getenv("GF_SMP_NODE_BLOCK")) t = std::atoi(e);
     return t < 64 ? 64 : t > 256 ? 256 : t;
 }
 
@@ -984,156 +937,21 @@ gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *d
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// consumer gather with tables-backward folded in (GF_SMP_BWD_GATHER).  Workgroup per SOURCE node w of level l-1:
+// consumer gather with tables-backward folded in.  Per SOURCE node w of level l-1:
 //   df_{l-1}[w][p,q] = [p==q] dFd[p] + [q==c_w] dFc[p] + sum over consumers (n,a), in consumer order, of dP_n[a, b, c]
 // with b = inv(p), c = inv(q) both present, and dP_n[a,b,c] EVALUATED from the table gradients by the formula above
 // smp_tables_bwd (same expression; only the two diagonal terms are summed separately) instead of being written by one
-// kernel and read back by the next.  A thread owns (p, 4 channels) and keeps the sw accumulators of its row in registers.
+// kernel and read back by the next.  A lane owns (p, 4 channels) and keeps the accumulators of its row in registers.
+// The [c == b] and [c == a] terms of dP land on fixed positions of the row: c == b means q == p (inv is injective), and c == a means
+// q == c_w (the source's own vertex sits at position a of the consumer): they are summed over the consumers in two extra
+// accumulators, which start from the compact-path gradients of the same two positions, and join the row at the end.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kGatherChunk = 64, kGatherMaxS = 32;
-#ifndef GF_GATHER_QB
-#define GF_GATHER_QB 4
-#endif
-
-template <int SW>
-__global__ __launch_bounds__(256) void smp_bwd_gather(
-    const float *__restrict__ dT, const float *__restrict__ dVt, const float *__restrict__ dSt, const float *__restrict__ rsum,
-    float *__restrict__ dfprev, const float *__restrict__ dFdc, const int *__restrict__ prev_s, const long long *__restrict__ prev_row,
-    const long long *__restrict__ prev_pair, const int *__restrict__ prev_center, const long long *__restrict__ cons_ptr,
-    const long long *__restrict__ cons_row, const int *__restrict__ cons_s, const int *__restrict__ cons_a,
-    const long long *__restrict__ cons_pair, const int *__restrict__ pair_node, const long long *__restrict__ cons_inv_off,
-    const short *__restrict__ inv, int C, const int *__restrict__ order) {
-    constexpr int QB = (SW < GF_GATHER_QB) ? SW : GF_GATHER_QB;  // positions q whose loads are in flight together
-    __shared__ long long sRow[kGatherChunk], sPb[kGatherChunk];
-    __shared__ int sS[kGatherChunk], sA[kGatherChunk], sNode[kGatherChunk];
-    __shared__ short sInv[kGatherChunk][SW];
-    __shared__ float sR[kGatherChunk][kGatherMaxS];
-    // launch order: molecule-major, and every XCD (blockIdx % 8) gets a contiguous run of it -- the rows (b, c) of one
-    // consumer node are re-read by each of its sources, which then share an L2
-    int w;
-    {
-        const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8;
-        w = order[(x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8];
-    }
-    const int sw = prev_s[w], cw = prev_center[w];
-    const int nl = C >> 2, items = sw * nl;
-    const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
-    const size_t ldt = (size_t)T_COLS * C;
-    float *dst = dfprev + prev_row[w] * C;
-    const float *dfd = dFdc + (size_t)prev_pair[w] * 2 * C;
-    for (int base = 0; base < items; base += (int)blockDim.x) {
-        const int it = base + (int)threadIdx.x;
-        const bool live = it < items;
-        const int p = live ? it / nl : 0, f = 4 * (live ? it % nl : 0);
-        // The [c == b] and [c == a] terms of dP land on fixed positions of the row: c == b means q == p (inv is injective), and
-        // c == a means q == c_w (the source's own vertex sits at position a of the consumer).  They are summed over the
-        // consumers in two extra accumulators, which start from the compact-path gradients of the same two positions, and
-        // join the row at the end -- not one compare-and-select pair per element of the inner loop.
-        f4 acc[SW], accd = splat(0.f), accc = splat(0.f);
-#pragma unroll
-        for (int q = 0; q < SW; ++q) acc[q] = splat(0.f);
-        if (live) {
-            accd = ld4(dfd + (size_t)p * 2 * C + f);
-            accc = ld4(dfd + (size_t)p * 2 * C + C + f);
-        }
-        for (long long cb = c0; cb < c1; cb += kGatherChunk) {
-            const int nc = (int)((c1 - cb < kGatherChunk) ? c1 - cb : kGatherChunk);
-            __syncthreads();
-            for (int i = threadIdx.x; i < nc; i += blockDim.x) {
-                const long long e = cons_pair[cb + i];
-                const int a = cons_a[cb + i];
-                sRow[i] = cons_row[cb + i];
-                sS[i] = cons_s[cb + i];
-                sA[i] = a;
-                sPb[i] = e - a;
-                sNode[i] = pair_node[e];
-            }
-            for (int i = threadIdx.x; i < nc * sw; i += blockDim.x) sInv[i / sw][i % sw] = inv[cons_inv_off[cb + i / sw] + i % sw];
-            __syncthreads();
-            for (int i = threadIdx.x; i < nc * kGatherMaxS; i += blockDim.x) {
-                const int e = i / kGatherMaxS, x = i % kGatherMaxS;
-                sR[e][x] = (x < sS[e]) ? rsum[sPb[e] + x] : 0.f;
-            }
-            __syncthreads();
-            if (!live) continue;
-            for (int e = 0; e < nc; ++e) {
-                const int b = sInv[e][p];
-                if (b < 0) continue;
-                // the consumer's tables through buffer descriptors (wave-uniform bases, 32-bit lane offsets: no 64-bit address
-                // arithmetic per load; the kernel is instruction-bound)
-                const int s = __builtin_amdgcn_readfirstlane(sS[e]), a = __builtin_amdgcn_readfirstlane(sA[e]);
-                const long long row0 = sRow[e], pb0 = sPb[e];
-                const long long urow = ((long long)__builtin_amdgcn_readfirstlane((int)(row0 >> 32)) << 32) |
-                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(row0 & 0xffffffffll));
-                const long long upb = ((long long)__builtin_amdgcn_readfirstlane((int)(pb0 >> 32)) << 32) |
-                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(pb0 & 0xffffffffll));
-                const int unode = __builtin_amdgcn_readfirstlane(sNode[e]);
-                const __amdgpu_buffer_rsrc_t rT = make_rsrc(dT + (size_t)urow * ldt, (size_t)s * s * ldt * sizeof(float));
-                const __amdgpu_buffer_rsrc_t rV = make_rsrc(dVt + (size_t)upb * 4 * C, (size_t)s * 4 * C * sizeof(float));
-                const __amdgpu_buffer_rsrc_t rS = make_rsrc(dSt + (size_t)unode * 4 * C, (size_t)4 * C * sizeof(float));
-                const int C4 = C * 4, f4b = f * 4;
-                const int tab = ((a * s + b) * (int)ldt) * 4 + f4b, va = a * 4 * C4 + f4b, vb = b * 4 * C4 + f4b;
-                // all of a consumer's row terms AND its first batch of (b, c) rows are requested before anything is summed: one
-                // memory latency for both instead of two in a row (a workgroup's time is the sum of its consumers' latencies)
-                const f4 l0 = buf_ld4(rT, tab, T_SAB * C4), l1 = buf_ld4(rV, va, 0), l2 = buf_ld4(rV, vb, C4), l3 = buf_ld4(rS, f4b, 0);
-                const f4 l4 = buf_ld4(rV, va, 2 * C4), l5 = buf_ld4(rS, f4b, 2 * C4);
-                const f4 l6 = buf_ld4(rS, f4b, C4), l7 = buf_ld4(rS, f4b, 3 * C4);
-                const f4 g5 = buf_ld4(rT, tab, T_T6 * C4), z2 = buf_ld4(rV, vb, 3 * C4);
-                const float ra = sR[e][a];
-                const int tb = (b * s * (int)ldt) * 4 + f4b;
-                auto load_batch = [&](int q0, f4(&y)[QB], f4(&g9)[QB], int(&cc)[QB]) {
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) {
-                        const int q = q0 + j;
-                        const int c = (q < sw) ? sInv[e][q] : -1;
-                        cc[j] = c;
-                        const int t = c < 0 ? -1 : tb + c * (int)ldt * 4;  // (out of range: the load returns 0 and is not used)
-                        y[j] = buf_ld4(rT, t, T_SBC * C4);
-                        g9[j] = buf_ld4(rT, t, T_T10 * C4);
-                    }
-                };
-                f4 y[QB], g9[QB];
-                int cc[QB];
-                load_batch(0, y, g9, cc);
-                f4 x = l0 + l1 + l2 + l3;
-                f4 z1 = l4 + l5;
-                if (a == b) {
-                    x += l6;
-                    z1 += l7;
-                }
-#pragma unroll
-                for (int q0 = 0; q0 < SW; q0 += QB) {
-                    if (q0 >= sw) break;
-                    if (q0 > 0) load_batch(q0, y, g9, cc);
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) {
-                        const int c = cc[j];
-                        if (c < 0) continue;
-                        acc[q0 + j] += x + y[j] + g5 * sR[e][c] + g9[j] * ra;
-                    }
-                }
-                accd += z1;
-                accc += z2;
-            }
-        }
-        if (live) {
-#pragma unroll
-            for (int q = 0; q < SW; ++q)
-                if (q < sw) {
-                    f4 o = acc[q];
-                    if (q == p) o += accd;
-                    if (q == cw) o += accc;
-                    st4(dst + ((size_t)p * sw + q) * C + f, o);
-                }
-        }
-    }
-}
+constexpr int kGatherMaxS = 32;
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same gather with nothing but memory requests and sums inside the consumer loop (round 3; GF_SMP_GATHER=1 keeps the kernel
-// above).  What the kernel above spends per consumer is three dependent round trips -- LDS staging behind barriers, the row terms
-// with the first four positions, the next four positions -- at three waves per SIMD: it is latency-bound (rocprof: the loop's
-// instructions account for a tenth of its time), not issue-bound.  Here:
+// Nothing but memory requests and sums inside the consumer loop (round 3).  Round 2's kernel (a workgroup per source, consumer lists
+// staged in LDS behind barriers, one launch per size class) spent three dependent round trips per consumer at three waves per SIMD: it
+// was latency-bound (rocprof: the loop's instructions accounted for a tenth of its time), not issue-bound.  Here:
 //   * everything wave-uniform about a consumer comes from two per-batch tables built on the device at prepare time
 //     (build_gather_records): an 8-dword header per consumer entry (size, index, row / pair bases, node, r[a]) and a 4-dword record
 //     per (entry, source position q): byte offset of the consumer's row (b = 0, c = inv(q)), r[c], presence m, m r[a].  They are
@@ -1144,8 +962,8 @@ __global__ __launch_bounds__(256) void smp_bwd_gather(
 //     the first sum: one round trip per consumer, 26 - 42 KB in flight per wave;
 //   * absent positions (uniform) read the consumer's row c = 0 and are multiplied by m = 0; absent b (per lane) sends every
 //     request of the lane out of range (zeros): no branch anywhere in the loop, so the memory queue is counted, not drained.
-// Same expression, same consumer order as the kernel above: results agree to the last bit of the fp32 sums' rounding order
-// (x + y first, then the two products), tests/test_smp_gpu.py::test_gather_kernels_agree.
+// Held against the two-kernel form (tables-backward writes dP, promote_backward gathers it: GF_SMP_BWD_GATHER=0) by
+// tests/test_smp_gpu.py::test_folded_backward_gather_equals_the_two_kernel_path.
 // ---------------------------------------------------------------------------------------------------------------
 struct GatherTables {
     const int4 *hdr;   // [entries][2]: {s, a, row lo, row hi} {pair base lo, hi, node, r[a] bits}
@@ -1364,32 +1182,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
-template <int SW>
-gf_status launch_bwd_gather(gf_smp *s, int l, int w0, int w1, const float *dT) {
-    gf_ctx *ctx = s->ctx;
-    const gf_smp::DevLevel &d = s->lv[l], &pv = s->lv[l - 1];
-    const int C = s->cfg.nChanels;
-    int threads = SW * (C / 4);
-    threads = threads > 256 ? 256 : (threads + 63) / 64 * 64;
-    GF_LAUNCH(ctx, "smpf_bwd_gather", (smp_bwd_gather<SW>), dim3((unsigned)(w1 - w0)), dim3(threads), 0, dT, d.dVt, d.dSt, d.rsum, pv.df,
-              d.dFdc, pv.node_s, pv.node_row, pv.node_pair, pv.node_center, d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_pair,
-              d.pair_node, d.cons_inv_off, d.inv, C, pv.mol_order + w0);
-    return GF_OK;
-}
 }  // namespace
 
-bool smp_grouped_small(const gf_smp *s);
-// compact projected matrix O = [O_loc | U] (2C) instead of [O_loc | Z | Z'] (3C): needs the three dedicated C = 64 product kernels
-// (they gather the transposed rows themselves) and the batched reverse sweep; GF_SMP_COMPACT_O=0 keeps the three-block layout
-bool smp_compact_o(const gf_smp *s) {
-    return s->cfg.nChanels == 64 && smp_grouped_small(s) && !env_is("GF_SMP_ROWPANEL", '0') && !env_is("GF_SMP_WGRAD", '0') &&
-           !env_is("GF_SMP_COMPACT_O", '0');
-}
+// the dedicated C = 64 kernels of the block products (weights resident in LDS, rows in registers; output-stationary weight gradients).
+// GF_SMP_ROWPANEL=0 (read per call: the parity tests switch it) selects the grouped tiled GEMM launches every other channel count uses.
+static bool smp_c64_kernels(const gf_smp *s) { return s->cfg.nChanels == 64 && !env_is("GF_SMP_ROWPANEL", '0'); }
+// compact projected matrix O = [O_loc | U] (2C) instead of [O_loc | Z | Z'] (3C): the dedicated C = 64 product kernels gather the
+// transposed rows themselves; the tiled launches keep the three-block layout
+bool smp_compact_o(const gf_smp *s) { return smp_c64_kernels(s); }
 gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *dbl);
 
 // every level's block-permuted weight copy in one launch (gf_smp_forward, before the first level)
 gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K) {
-    if (!smp_grouped_small(s)) return GF_OK;
     const int L = s->cfg.nLevels, C = s->cfg.nChanels;
     for (int l0 = 1; l0 <= L; l0 += kStackLevels) {
         StackAll a;
@@ -1405,7 +1209,7 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K) {
     }
     // ... and the split product kernels' weight images of every level, both directions (the backward pass reuses them)
     for (int l = 1; l <= L; ++l) s->lv[l].wimg_ready = false;
-    if (C == 64 && smp_compact_o(s) && smp_split_products(s->ctx) && !env_is("GF_SMP_PREBUILT_IMAGES", '0')) {
+    if (C == 64 && smp_compact_o(s) && smp_split_products(s->ctx)) {
         std::vector<const float *> w;
         std::vector<void *> im;
         for (int l = 1; l <= L; ++l)
@@ -1443,7 +1247,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     gf_status st;
     // The structurally-zero rows of the S_ab / T6 blocks (half of the rows at QM9 sizes, 0.73 GB of zeros a step at cfg3) are the
     // same rows every step of a prepared batch and nothing else writes there: their zeros go in once, tables-forward skips them.
-    if (C == 64 && d.rowflag && !env_is("GF_SMP_KEEP_ZEROS", '0')) {
+    if (C == 64 && d.rowflag && !env_is("GF_SMP_MASK_ZEROS", '0')) {
         if (!d.t_zeros) {
             GF_LAUNCH(ctx, "smpf_tables_fill", tables_zero_fill, dim3((unsigned)(((long long)rows + kZeroFillRows - 1) / kZeroFillRows)), dim3(256), 0, T,
                       d.rowflag, (long long)rows);
@@ -1462,34 +1266,16 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         }
         if (st != GF_OK) return st;
     }
-    const bool grouped = smp_grouped_small(s);
-    if (!grouped) GF_LAUNCH(ctx, "smpf_stack_w", stack_weights, dim3(64), dim3(256), 0, Kl, d.Wst, C, s->cfg.custom_matmul);
     {  // Fdc = [f[w][p,p] | f[w][p,c_w]] of the level below (read by smp_vectors and by the compact products)
         const gf_smp::DevLevel &pv = s->lv[l - 1];
         GF_LAUNCH(ctx, "smpf_diag_gather", diag_gather_fwd, dim3(s->lay.level[l - 1].nNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, pv.f, d.Fdc, pv.node_s,
                   pv.node_row, pv.node_pair, pv.node_center, C);
     }
-    // The per-(node,x) vectors and per-node scalars (smp_vectors + two small GEMMs) only need T and the stacked weights:
-    // they run on the handle's second stream beside the big row GEMM and are joined before combine-forward.
-    struct StreamSwap {
-        gf_ctx *c;
-        hipStream_t saved;
-        bool on;
-        ~StreamSwap() {
-            if (on) c->stream = saved;
-        }
-    } swap = {ctx, ctx->stream, false};
-    if (s->side && !grouped) {
-        GF_HIP_TRY(ctx, hipEventRecord(s->ev_fork, ctx->stream));
-        GF_HIP_TRY(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
-        ctx->stream = s->side;
-        swap.on = true;
-    }
     GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(node_block(h, C)), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
               d.node_pair, C, d.Fdc, d.pair_src_pair, d.pi);
     const size_t CC = (size_t)C * C;
-    if (grouped) {
-        // V = Vt [K1;K3;K7;K10], S = St [K4;K13;K14;K17], Gc = [Fd K15 | Fc K16]: four small products, ONE launch
+    {
+        // V = Vt [K1;K3;K7;K10], S = St [K4;K13;K14;K17], Gc = [Fd K15 | Fc K16]: the small products of the level, ONE launch
         const int prevPairs = (int)s->lay.level[l - 1].pairs;
         const GemmSpec sm[4] = {
             {d.Vt, d.Wst + 10 * CC, d.Vout, pairs, C, 4 * C, 4 * C, C, C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
@@ -1497,7 +1283,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             {d.Fdc, d.Wst + 8 * CC, d.Gc, prevPairs, C, C, 2 * C, C, 2 * C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
             {d.Fdc + C, d.Wst + 9 * CC, d.Gc + C, prevPairs, C, C, 2 * C, C, 2 * C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
         };
-        if (C == 64 && d.wimg_ready && !env_is("GF_SMP_SMALL_SPLIT", '0')) {   // wave per 32-row panel on the f16 pipe (smp_small_split)
+        if (C == 64 && d.wimg_ready) {   // wave per 32-row panel on the f16 pipe (smp_small_split)
             const int prog[3] = {0, 2, 0}, nrows[3] = {pairs, prevPairs, nodes}, pos0[3] = {10, 8, 14};
             const float *in[3] = {d.Vt, d.Fdc, d.St};
             float *out[3] = {d.Vout, d.Gc, d.Sout};
@@ -1506,16 +1292,6 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             st = gemm_grouped_free(ctx, false, sm, 4, "smpf_small_nn");
         }
         if (st != GF_OK) return st;
-    } else {
-    st = gemm(ctx, false, false, pairs, C, 4 * C, d.Vt, 4 * C, 0, d.Wst + 10 * CC, C, 0, d.Vout, C, 0, 1, 0);
-    if (st != GF_OK) return st;
-    st = gemm(ctx, false, false, nodes, C, 4 * C, d.St, 4 * C, 0, d.Wst + 14 * CC, C, 0, d.Sout, C, 0, 1, 0);
-    if (st != GF_OK) return st;
-    }
-    if (swap.on) {
-        GF_HIP_TRY(ctx, hipEventRecord(s->ev_join, s->side));
-        ctx->stream = swap.saved;
-        swap.on = false;
     }
     const int ocols = smp_compact_o(s) ? 2 : O_COLS;
     const int ldt = T_COLS * C, ldo = O_COLS * C;   // (the tiled launches below always use the three-block layout)
@@ -1533,9 +1309,8 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             {T + T_SAB * C, d.Wst + 7 * CC, O + O_ZP * C, rows, C, C, ldt, C, ldo, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0,
              {-1, -1, -1, -1}},
         };
-        const bool panels = !env_is("GF_SMP_ROWPANEL", '0');  // (read per call: the parity tests switch it)
-        if (C == 64 && panels) {
-            st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, ocols == 2 ? d.trow : nullptr, d.trowf, false,
+        if (smp_c64_kernels(s)) {
+            st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, d.trow, d.trowf, false,
                                            d.wimg_ready ? d.wimg : nullptr);  // weights in LDS
             if (st != GF_OK) return st;
         } else if (gemm_grouped_supported(sp, 3, false, false)) {
@@ -1552,18 +1327,13 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             }
         }
     }
-    if (!grouped) {  // Gc = [Fd K15 | Fc K16] on the compact rows of the level below
-        const int prevPairs = (int)s->lay.level[l - 1].pairs;
-        // (one launch, batch of two: operand / weight / output of the second product sit C, C*C, C elements further on)
-        st = gemm(ctx, false, false, prevPairs, C, C, d.Fdc, 2 * C, C, d.Wst + 8 * CC, C, (long long)CC, d.Gc, 2 * C, C, 2, 0);
-        if (st != GF_OK) return st;
-    }
-    if (s->side && !grouped) GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));
-    if (C == 64 && ocols == 2 && d.fwd_pan && (long long)rows * 512 < 0x3fffffffll && !env_is("GF_SMP_COMBINE_PANELS", '0'))
-    {   // wave per row panel, the adjacency product on the matrix pipe; the top level leaves the readout's partial sums behind
-        float *psum = (l == s->cfg.nLevels && !env_is("GF_SMP_READOUT_PARTIALS", '0')) ? d.psum : nullptr;
-        st = smp_combine_fwd_panels_c64(s, l, O, bl, psum);
+    if (C == 64 && ocols == 2 && d.fwd_pan && (long long)rows * 512 < 0x3fffffffll)
+    {   // wave per row panel, the adjacency product on the matrix pipe; the top level leaves the readout's partial sums behind, the
+        // others the per-channel maxima the level above scales its weight-gradient operands with
+        float *psum = l == s->cfg.nLevels ? d.psum : nullptr;
+        st = smp_combine_fwd_panels_c64(s, l, O, bl, psum, d.pmax);
         if (st == GF_OK && psum) s->lv[l].psum_ready = true;
+        if (st == GF_OK && d.pmax) s->lv[l].pmax_ready = true;
         return st;
     }
     {
@@ -1575,12 +1345,6 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
                   d.pair_src_pair, d.pi, d.rsum, ocols);
     }
     return GF_OK;
-}
-
-// GF_SMP_GROUPED=0 keeps one launch per small product / reduction (the round-1 schedule); read per call for the parity tests
-bool smp_grouped_small(const gf_smp *s) {
-    (void)s;
-    return !env_is("GF_SMP_GROUPED", '0');
 }
 
 // Remainder of a level's reverse sweep after combine-backward, with the small work batched:
@@ -1620,7 +1384,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
                                 spec(d.dGc + C, d.Wst + 9 * CC, d.dFdc + C, prevPairs, C, C, 2 * C, C, 2 * C),
                                 spec(d.dVout, d.Wst + 10 * CC, d.dVt, pairs, 4 * C, C, C, C, 4 * C),
                                 spec(d.dSout, d.Wst + 14 * CC, d.dSt, nodes, 4 * C, C, C, C, 4 * C)};
-        if (C == 64 && d.wimg_ready && !env_is("GF_SMP_SMALL_SPLIT", '0')) {
+        if (C == 64 && d.wimg_ready) {
             const int prog[3] = {1, 2, 1}, nrows[3] = {pairs, prevPairs, nodes}, pos0[3] = {10, 8, 14};
             const float *in[3] = {d.dVout, d.dGc, d.dSout};
             float *out[3] = {d.dVt, d.dFdc, d.dSt};
@@ -1629,39 +1393,28 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
         st = gemm_grouped_free(ctx, true, nt, 4, "smpf_small_nt");
         if (st != GF_OK) return st;
     }
-    // weight gradients on the handle's second stream when GF_SMP_OVERLAP=1 (they only share inputs with what follows)
-    struct StreamSwap {
-        gf_ctx *c;
-        hipStream_t saved;
-        bool on;
-        ~StreamSwap() {
-            if (on) c->stream = saved;
-        }
-    } swap = {ctx, ctx->stream, false};
-    if (s->side) {
-        if (s->side_pending) {  // the level above still owns the context's one workspace on the second stream: same stream, ordered
-            s->side_pending = false;
-        }
-        GF_HIP_TRY(ctx, hipEventRecord(s->ev_fork, ctx->stream));
-        GF_HIP_TRY(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
-        ctx->stream = s->side;
-        swap.on = true;
-    }
     FoldArgs fa;
     fa.ngroups = 6;
     float *ws = static_cast<float *>(ctx->ws);
     size_t ws_floats = ctx->ws_bytes / sizeof(float), used = 0;
     FoldGroup rowg;
-    const bool stationary = C == 64 && !env_is("GF_SMP_WGRAD", '0');
+    const bool stationary = smp_c64_kernels(s);
     if (stationary) {
         unsigned *wb = (s->wbound && ocols == 2 && smp_split_products(ctx)) ? s->wbound + (size_t)l * smp_wgrad_bound_words() : nullptr;
-        if (wb) {   // the column bounds of this level's operand blocks, from the largest |f_{l-1}| and |df_l| of every channel
-            const bool top = l == s->cfg.nLevels;   // (top level: df_L is the per-node readout gradient, broadcast over the node's rows)
-            st = smp_wgrad_column_bounds(ctx, pv.f, (long long)s->lay.level[l - 1].rows, top ? s->dsh : d.df, top ? (long long)nodes : (long long)rows,
-                                         h.buckets.back().s, d.max_tot, d.max_tr, d.row_max, wb);
+        if (wb && !d.dzmax) wb = nullptr;
+        WgradScales sc;
+        if (wb) {   // the operand columns' exponents come from the largest |f_{l-1}| and |dz_l| of every channel: the per-panel maxima
+            // combine-forward of the level below left behind (or f_0 itself) and the per-workgroup maxima of this level's
+            // combine-backward -- 17 - 19 MB of partials at cfg3's level 3, reduced by one small launch
+            const bool pm = pv.pmax && pv.pmax_ready;
+            st = smp_wgrad_channel_maxima(ctx, pm ? pv.pmax : pv.f, pm ? (long long)pv.fwd_npanels : (long long)s->lay.level[l - 1].rows, d.dzmax,
+                                          (long long)h.quad_node.size(), wb);
             if (st != GF_OK) return st;
+            sc.chan = wb;
+            sc.smax = (float)h.buckets.back().s;
+            sc.max_tot = d.max_tot, sc.max_tr = d.max_tr, sc.row_max = d.row_max;
         }
-        st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg, ocols == 2 ? d.trow : nullptr, wb ? wb + 128 : nullptr, d.trowf);
+        st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg, ocols == 2 ? d.trow : nullptr, sc, d.trowf);
         if (st != GF_OK) return st;
         used = (size_t)rowg.splits * rowg.n;
     } else {  // other channel counts: the grouped split-K launch (its own ordered reduction) into the stacked image, one "image"
@@ -1720,14 +1473,8 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     GF_LAUNCH(ctx, "smpf_fold", smp_fold_level, dim3((total + 63) / 64), dim3(256), 0, fa, dKl, dbl, C, s->cfg.custom_matmul, total);
     st = smp_dp_level_done(s, l);  // data-parallel: dK_l and db_l are final -- their all-reduce runs beside what follows
     if (st != GF_OK) return st;
-    if (swap.on) {
-        GF_HIP_TRY(ctx, hipEventRecord(s->ev_join, s->side));
-        ctx->stream = swap.saved;
-        swap.on = false;
-        s->side_pending = true;
-    }
     // table gradients dT from dO
-    if (C == 64 && !env_is("GF_SMP_ROWPANEL", '0')) {
+    if (smp_c64_kernels(s)) {
         // (with the consumer gather reading dT, the gradients of the structurally-zero S_ab / T6 rows have no reader: not written)
         st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows, ocols == 2 ? d.trow : nullptr, d.trowf,
                                        smp_fused_gather_enabled(s, l), d.wimg_ready ? d.wimg : nullptr);
@@ -1778,10 +1525,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     const gfsmp::LevelLayout &h = s->lay.level[l];
     const gf_smp::DevLevel &d = s->lv[l];
     const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
-    const int rows = (int)h.rows, pairs = (int)h.pairs, nodes = h.nNodes;
-    float *T = d.Q, *dO = d.Q + (size_t)h.rows * T_COLS * C, *dT = dO + (size_t)h.rows * O_COLS * C;
-    const size_t CC = (size_t)C * C;
-    const int ldt = T_COLS * C, ldo = O_COLS * C;
+    float *dO = d.Q + (size_t)h.rows * T_COLS * C;
     gf_status st;
     {
         const size_t lds = combine_lds<16>(h.buckets.back().s);
@@ -1789,158 +1533,10 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
                   d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
-                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS);
-    }
-    if (smp_grouped_small(s)) return smp_fused_backward_level_grouped(s, l, dKl, dbl);
-    GF_LAUNCH(ctx, "smpf_node_sum", smp_node_sum, dim3(nodes), dim3(64), 0, d.dSpart, d.dSout, d.node_s, d.node_pair, C);
-    // bias gradient: column sums of the per-(node,x) partials
-    {
-        const int rpb = 256, nb = (pairs + rpb - 1) / rpb;  // s->colpart holds (max rows / 1024 + 1) x C floats >= nb x C
-        GF_LAUNCH(ctx, "smpf_colsum", colsum_chunks, dim3(nb), dim3(256), 0, d.dbpart, s->colpart, C, (long long)pairs, rpb);
-        GF_LAUNCH(ctx, "smpf_colsum_fold", colsum_fold, dim3(1), dim3(1024), 0, s->colpart, dbl, C, nb);
-    }
-    {
-        // compact diagonal path: gradients of Gc by a consumer gather over dU (the Z block of dO), then the two C x C
-        // products on the compact rows: dFdc = [dG15 K15^T | dG16 K16^T] (added to df_{l-1} by the consumer gather of the
-        // caller), dK15 = Fd^T dG15, dK16 = Fc^T dG16 (stack positions 8, 9)
-        const gf_smp::DevLevel &pv = s->lv[l - 1];
-        const int prevNodes = s->lay.level[l - 1].nNodes, prevPairs = (int)s->lay.level[l - 1].pairs;
-        GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, dO, d.dGc, pv.node_s, pv.node_pair,
-                  d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C, (int)O_COLS);
-        if (s->side_pending) {  // GF_SMP_OVERLAP: the level above may still be folding split-K partials in the context's ONE
-            GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_join, 0));  // workspace, which the products below use too
-            s->side_pending = false;
-        }
-        // dFdc: one launch, batch of two; dK15 | dK16: one grouped split-K launch (both reduce over the compact rows)
-        st = gemm(ctx, false, true, prevPairs, C, C, d.dGc, 2 * C, C, d.Wst + 8 * CC, C, (long long)CC, d.dFdc, 2 * C, C, 2, 0);
-        if (st != GF_OK) return st;
-        GemmSpec ck[2];
-        for (int half = 0; half < 2; ++half) {
-            GemmSpec z = {d.Fdc + half * C, d.dGc + half * C, d.dWst + (8 + half) * CC, C, C, prevPairs, 2 * C, 2 * C, C, 0,
-                          {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}};
-            ck[half] = z;
-        }
-        if (C <= 64 && gemm_grouped_supported(ck, 2, true, false)) {  // (the grouped split-K tiles are one BN = 64 wide)
-            st = gemm_grouped_splitk(ctx, ck, 2, prevPairs, d.dWst + 8 * CC, 0);
-            if (st != GF_OK) return st;
-        } else {
-            for (int half = 0; half < 2; ++half) {
-                st = gemm(ctx, true, false, C, C, prevPairs, d.Fdc + half * C, 2 * C, 0, d.dGc + half * C, 2 * C, 0,
-                          d.dWst + (8 + half) * CC, C, 0, 1, 0);
-                if (st != GF_OK) return st;
-            }
-        }
-    }
-    // The weight-gradient products below read T and dO and write only dWst / dK_l: they run on the handle's second stream
-    // while this stream continues with the table-gradient chain (dT GEMM -> tables-backward -> consumer gather).
-    struct StreamSwap {
-        gf_ctx *c;
-        hipStream_t saved;
-        bool on;
-        ~StreamSwap() {
-            if (on) c->stream = saved;
-        }
-    } swap = {ctx, ctx->stream, false};
-    if (s->side) {
-        GF_HIP_TRY(ctx, hipEventRecord(s->ev_fork, ctx->stream));
-        GF_HIP_TRY(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
-        ctx->stream = s->side;
-        swap.on = true;
-    }
-    // weight gradients (stacked), then scatter-add into dK_l:  dW = T_blk^T dO_blk   (split-K over rows).  Grouped: the
-    // five products share each split's row range of T and dO, and their partial images are folded by ONE ordered
-    // reduction straight into the first ten stacked blocks.
-    struct G { int tcol, kb, wpos, ocol, scol; };  // scol: T rows scaled by tot (0) / tr (1) for the row-local products
-    // Z: [S_ab|S_bc] -> stack 5,6;  Z': S_ab -> stack 7;  positions 0..7 are contiguous for the ordered reduction
-    const G gs[5] = {{T_SAB, 2, 0, O_LOC, 0}, {T_SAB, 1, 2, O_LOC, 1}, {T_T6, 2, 3, O_LOC, -1}, {T_SAB, 2, 5, O_Z, -1}, {T_SAB, 1, 7, O_ZP, -1}};
-    {
-        GemmSpec sp[5];
-        for (int i = 0; i < 5; ++i) {
-            GemmSpec z = {T + gs[i].tcol * C, dO + gs[i].ocol * C, d.dWst + gs[i].wpos * CC, gs[i].kb * C, C, rows, ldt, ldo, C, 0,
-                          {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, gs[i].scol >= 0 ? d.rowscale : nullptr, 2, {gs[i].scol, -1, -1, -1}};
-            sp[i] = z;
-        }
-        const bool stationary = !env_is("GF_SMP_WGRAD", '0');
-        if (C == 64 && stationary) {
-            st = smp_wgrad_stationary_c64(ctx, T, dO, d.rowscale, rows, d.dWst);  // every operand byte fetched once
-            if (st != GF_OK) return st;
-        } else if (C <= 64 && gemm_grouped_supported(sp, 5, true, false)) {
-            st = gemm_grouped_splitk(ctx, sp, 5, rows, d.dWst, 0);  // stack positions 0..7 are contiguous in dWst
-            if (st != GF_OK) return st;
-        } else {
-            for (const G &g : gs) {
-                st = gemm_rs(ctx, true, false, g.kb * C, C, rows, T + g.tcol * C, ldt, 0, dO + g.ocol * C, ldo, 0, d.dWst + g.wpos * CC, C,
-                             0, 1, 0, d.rowscale, 2, g.scol);
-                if (st != GF_OK) return st;
-            }
-        }
-    }
-    st = gemm(ctx, true, false, 4 * C, C, pairs, d.Vt, 4 * C, 0, d.dVout, C, 0, d.dWst + 10 * CC, C, 0, 1, 0);
-    if (st != GF_OK) return st;
-    st = gemm(ctx, true, false, 4 * C, C, nodes, d.St, 4 * C, 0, d.dSout, C, 0, d.dWst + 14 * CC, C, 0, 1, 0);
-    if (st != GF_OK) return st;
-    GF_LAUNCH(ctx, "smpf_unstack_dw", unstack_weight_grads, dim3(64), dim3(256), 0, d.dWst, dKl, C, s->cfg.custom_matmul);
-    st = smp_dp_level_done(s, l);  // data-parallel: dK_l and db_l are final -- their all-reduce runs beside what follows
-    if (st != GF_OK) return st;
-    if (swap.on) {
-        GF_HIP_TRY(ctx, hipEventRecord(s->ev_join, s->side));
-        ctx->stream = swap.saved;
-        swap.on = false;
-        s->side_pending = true;
-    }
-    // table gradients: dT_blk = sum over the dO blocks that feed it of  dO_blk W_blk^T
-    //   S_ab <- tot dO_loc K0^T + tr dO_loc K6^T + dZ K8^T + dZ' K11^T      S_bc <- tot dO_loc K2^T + dZ K12^T
-    //   [T6|T10] <- dO_loc [K5;K9]^T
-    {
-        // grouped: one group per output column block of dT, K segmented over the dO blocks that feed it (no read-modify-
-        // write of dT, dO read once per panel); fallback: six launches that accumulate in a fixed order
-        const long long oC = C, wCC = (long long)CC;
-        GemmSpec dg[3] = {
-            {dO, d.Wst, dT + T_SAB * C, rows, C, 4 * C, ldo, C, ldt, 4, {O_LOC * oC, O_LOC * oC, O_Z * oC, O_ZP * oC},
-             {0 * wCC, 2 * wCC, 5 * wCC, 7 * wCC}, {C, C, C, C}, d.rowscale, 2, {0, 1, -1, -1}},
-            {dO, d.Wst, dT + T_SBC * C, rows, C, 2 * C, ldo, C, ldt, 2, {O_LOC * oC, O_Z * oC, 0, 0}, {1 * wCC, 6 * wCC, 0, 0}, {C, C, 0, 0},
-             d.rowscale, 2, {0, -1, -1, -1}},
-            {dO, d.Wst, dT + T_T6 * C, rows, 2 * C, C, ldo, C, ldt, 1, {O_LOC * oC, 0, 0, 0}, {3 * wCC, 0, 0, 0}, {C, 0, 0, 0}, nullptr, 0,
-             {-1, -1, -1, -1}},
-        };
-        const bool panels = !env_is("GF_SMP_ROWPANEL", '0');  // (read per call: the parity tests switch it)
-        if (C == 64 && panels) {
-            st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows, nullptr);  // weights in LDS, rows in registers
-            if (st != GF_OK) return st;
-        } else if (gemm_grouped_supported(dg, 3, false, true)) {
-            st = gemm_grouped_rows(ctx, false, true, dg, 3, rows);
-            if (st != GF_OK) return st;
-        } else {
-            struct H { int ocol, wpos, kb, tcol, acc, scol; };
-            const H hs[6] = {{O_Z, 5, 2, T_SAB, 0, -1}, {O_LOC, 0, 1, T_SAB, 1, 0}, {O_LOC, 1, 1, T_SBC, 1, 0}, {O_LOC, 2, 1, T_SAB, 1, 1},
-                             {O_ZP, 7, 1, T_SAB, 1, -1}, {O_LOC, 3, 2, T_T6, 0, -1}};
-            for (const H &g : hs) {
-                st = gemm_rs(ctx, false, true, rows, g.kb * C, C, dO + g.ocol * C, ldo, 0, d.Wst + g.wpos * CC, C, 0, dT + g.tcol * C, ldt, 0,
-                             1, g.acc, d.rowscale, 2, g.scol);
-                if (st != GF_OK) return st;
-            }
-        }
-    }
-    st = gemm(ctx, false, true, pairs, 4 * C, C, d.dVout, C, 0, d.Wst + 10 * CC, C, 0, d.dVt, 4 * C, 0, 1, 0);
-    if (st != GF_OK) return st;
-    st = gemm(ctx, false, true, nodes, 4 * C, C, d.dSout, C, 0, d.Wst + 14 * CC, C, 0, d.dSt, 4 * C, 0, 1, 0);
-    if (st != GF_OK) return st;
-    // rowsum_a / D8 were sums over b of S_ab / Dbb: their gradients broadcast back (handled inside tables-backward via dVt)
-    if (smp_fused_gather_enabled(s, l)) return GF_OK;  // dP is evaluated inside the consumer gather (smp_fused_gather_backward)
-    st = ensure_P(s);
-    if (st != GF_OK) return st;
-    const std::vector<SizeClass> cls = classes_of(h, 4);
-    for (const SizeClass &c : cls) {
-        switch (c.ni) {
-            case 1: st = launch_tables_bwd<1>(s, l, c, dT); break;
-            case 2: st = launch_tables_bwd<2>(s, l, c, dT); break;
-            case 4: st = launch_tables_bwd<4>(s, l, c, dT); break;
-            default: st = launch_tables_bwd<8>(s, l, c, dT); break;
-        }
-        if (st != GF_OK) return st;
+                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS, (C == 64 && s->wbound) ? d.dzmax : (float *)nullptr);
     }
     (void)Kl;
-    return GF_OK;
+    return smp_fused_backward_level_grouped(s, l, dKl, dbl);
 }
 
 // per-batch tables of smp_bwd_gather_v2, built on the device at prepare time on the handle's upload stream (behind the uploads
@@ -1992,38 +1588,16 @@ gf_status smp_fused_gather_backward(gf_smp *s, int l) {
     const gf_smp::DevLevel &d = s->lv[l];
     const int C = s->cfg.nChanels;
     const float *dT = d.Q + (size_t)h.rows * T_COLS * C + (size_t)h.rows * O_COLS * C;
-    // source nodes are sorted by receptive-field size: one launch per register class of sw (the classes of mol_order)
-    size_t k = 0;
-    if (d.cons_hdr && !env_is("GF_SMP_GATHER", '1')) {
-        const gf_smp::DevLevel &pv = s->lv[l - 1];
-        gf_ctx *ctx = s->ctx;
-        const GatherTables G = {d.cons_hdr, d.cons_qrec};
-        const int n_items = (int)(hp.gather_items.size() / 2);
-        if (n_items > 0)
-            GF_LAUNCH(ctx, "smpf_bwd_gather", smp_bwd_gather_all, dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, dT, d.dVt, d.dSt, pv.df,
-                      d.dFdc, pv.node_s, pv.node_row, pv.node_pair, pv.node_center, d.cons_ptr, d.cons_inv_off, d.cons_qbase, d.inv, G, C,
-                      reinterpret_cast<const int2 *>(pv.gather_items), n_items);
-        k = hp.buckets.size();
-        if (!hp.buckets.empty() && hp.buckets.back().s > 32) return fail(s->ctx, GF_ERR_UNSUPPORTED, "smp_fused_gather_backward: receptive field > 32");
-    } else {
-    const int cls[5] = {1, 4, 8, 16, 32};
-    for (int ci = 0; ci < 5 && k < hp.buckets.size(); ++ci) {
-        const size_t k0 = k;
-        while (k < hp.buckets.size() && hp.buckets[k].s <= cls[ci]) ++k;
-        if (k == k0) continue;
-        const int w0 = hp.buckets[k0].first_node, w1 = (k < hp.buckets.size()) ? hp.buckets[k].first_node : hp.nNodes;
-        gf_status st;
-        switch (cls[ci]) {
-            case 1: st = launch_bwd_gather<1>(s, l, w0, w1, dT); break;
-            case 4: st = launch_bwd_gather<4>(s, l, w0, w1, dT); break;
-            case 8: st = launch_bwd_gather<8>(s, l, w0, w1, dT); break;
-            case 16: st = launch_bwd_gather<16>(s, l, w0, w1, dT); break;
-            default: st = launch_bwd_gather<32>(s, l, w0, w1, dT); break;
-        }
-        if (st != GF_OK) return st;
-    }
-    }
-    if (k < hp.buckets.size()) return fail(s->ctx, GF_ERR_UNSUPPORTED, "smp_fused_gather_backward: receptive field > 32");
+    if (!d.cons_hdr) return fail(s->ctx, GF_ERR_INVALID, "smp_fused_gather_backward: level %d has no gather records", l);
+    if (!hp.buckets.empty() && hp.buckets.back().s > kGatherMaxS) return fail(s->ctx, GF_ERR_UNSUPPORTED, "smp_fused_gather_backward: receptive field > 32");
+    const gf_smp::DevLevel &pv = s->lv[l - 1];
+    gf_ctx *ctx = s->ctx;
+    const GatherTables G = {d.cons_hdr, d.cons_qrec};
+    const int n_items = (int)(hp.gather_items.size() / 2);
+    if (n_items > 0)
+        GF_LAUNCH(ctx, "smpf_bwd_gather", smp_bwd_gather_all, dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, dT, d.dVt, d.dSt, pv.df,
+                  d.dFdc, pv.node_s, pv.node_row, pv.node_pair, pv.node_center, d.cons_ptr, d.cons_inv_off, d.cons_qbase, d.inv, G, C,
+                  reinterpret_cast<const int2 *>(pv.gather_items), n_items);
     return GF_OK;
 }
 

@@ -52,19 +52,25 @@ size_t smp_split_image_bytes();
 gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n);
 gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *prog, const float *const *In, float *const *Out, const int *rows,
                               const int *pos0, const void *wimg, const char *name);
-// cmax: the level's per-column magnitude bounds of the nine operand blocks (smp_level_c64_split.hip: smp_wgrad_split)
+// where the split-operand weight gradients take their per-column exponents from (smp_level_c64_split.hip: smp_wgrad_split): either
+// `cmax`, explicit per-column bounds of the nine operand blocks (576 float bits, device), or `chan`, the level's per-channel maxima
+// (128 float bits: max |f_{l-1}| then max |dz_l|) with the largest receptive field and row factors of the level
+struct WgradScales {
+    const unsigned *cmax = nullptr, *chan = nullptr;
+    float smax = 0.f, max_tot = 0.f, max_tr = 0.f;
+    const unsigned *row_max = nullptr;   // or: {max |tot|, max |tr|} as float bits in device memory
+    bool any() const { return cmax || chan; }
+};
 gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
-                                       int splits, float *part, const int *trow, const unsigned *cmax, const int *trowf = nullptr);
+                                       int splits, float *part, const int *trow, const WgradScales &ws, const int *trowf = nullptr);
 size_t smp_wgrad_bound_words();
-gf_status smp_wgrad_column_bounds(gf_ctx *ctx, const float *fprev, long long prev_rows, const float *dsrc, long long drows, int smax,
-                                  float max_tot, float max_tr, const unsigned *row_max, unsigned *words);
+gf_status smp_wgrad_channel_maxima(gf_ctx *ctx, const float *fprev, long long prev_rows, const float *dsrc, long long drows, unsigned *words);
 size_t smp_wgrad_bound_words_exact();
 gf_status smp_wgrad_column_bounds_exact(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, unsigned *words);
 gf_status splitk_fold(gf_ctx *ctx, const float *part, float *dest, size_t total, int splits, int accumulate);
-gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst);
 // the same product, partial images only (fold == caller's): `part` receives out->splits images of 8 * 64 * 64 floats
 gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
-                                 size_t part_floats, FoldGroup *out, const int *trow, const unsigned *cmax = nullptr,
+                                 size_t part_floats, FoldGroup *out, const int *trow, const WgradScales &ws = WgradScales(),
                                  const int *trowf = nullptr);
 }
 
@@ -114,6 +120,10 @@ struct gf_smp {
         int4 *tf_recs = nullptr;  // [2 nNodes] records of tables-forward in launch order (build_tf_records)
         float *psum = nullptr;     // top level, C = 64: [fwd_npanels][64] column sums of the row panels of f_L (readout)
         bool psum_ready = false;   // ... written by this forward pass
+        // per-channel maxima for the weight gradients' column exponents (smp_level_c64_split.hip: smp_wgrad_column_bounds), C = 64:
+        float *pmax = nullptr;     // [fwd_npanels][64] largest |f_l| of every row panel, left by combine-forward (levels below the top)
+        float *dzmax = nullptr;    // [quads][64] largest |dz| of every workgroup of combine-backward
+        bool pmax_ready = false;
         void *wimg = nullptr;  // the split product kernels' weight images of this pass (smp_split_build_images), C = 64
         bool wimg_ready = false;
         int *trowf = nullptr;  // [rows] trow | bit 31: rowflag of the row | bit 30: rowflag of the transposed row (smp_rowpanel_split)
@@ -168,18 +178,11 @@ struct gf_smp {
         int idle;  // consecutive prepares that did not use the block
     };
     std::vector<Block> pool;
-    // second stream of the fused levels.  Backward: the weight-gradient GEMMs (they only share inputs with the
-    // table-gradient chain), forked after combine-backward of a level, joined before gf_smp_backward returns.  Forward:
-    // the per-(node,x) vectors / per-node scalars and their two small GEMMs, beside the big row GEMM, joined before
-    // combine-forward.  Opt-in: GF_SMP_OVERLAP=1.
     // Two handles on one context can alternate (prepare of one while the device runs the step of the other): uploads go
     // through the handle's own stream, and recycling the handle's buffers waits for ITS last launch only, not for the stream.
     hipStream_t upload = nullptr;
     hipEvent_t ev_last = nullptr;
     bool used = false;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool side_tried = false, side_pending = false;
     // Adam state (gf_smp_adam_step); survives gf_smp_prepare, freed by gf_smp_destroy
     float *adam_m = nullptr, *adam_v = nullptr;
     // handle-owned model (host-pointer mode of the driver): parameters and their gradient, [param_count] each
@@ -199,7 +202,7 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_build_tf_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream);
-gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr);
+gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr, float *pmax = nullptr);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce

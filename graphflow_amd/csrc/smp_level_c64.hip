@@ -429,46 +429,27 @@ __global__ __launch_bounds__(TH, 1) void smp_rowpanel_c64(const float *__restric
 // 8 x 64 x 64 floats per row range.  T = [rows][256], dO = [rows][192], rowscale = [rows][2].  The row range per workgroup
 // depends on `rows` only: results are reproducible.  The caller folds the images in order.
 gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *part,
-                                 size_t part_floats, FoldGroup *out, const int *trow, const unsigned *cmax, const int *trowf) {
+                                 size_t part_floats, FoldGroup *out, const int *trow, const WgradScales &ws, const int *trowf) {
     const size_t total = 8 * 4096;
     out->part = part;
     out->n = total;
     out->splits = 0;
     if (rows < 1) return GF_OK;
     // one workgroup fits a CU (two LDS stages): aim at `target` row ranges, at least 8 slices each
-    int target = 256;
-    if (const char *e = std::getenv("GF_WGRAD_SPLITS")) target = std::max(1, std::atoi(e));
+    const int target = 256;
     int kchunk = ((rows + target - 1) / target + BK - 1) / BK * BK;
     if (kchunk < 8 * BK) kchunk = 8 * BK;
     const int splits = (rows + kchunk - 1) / kchunk;
     if ((size_t)splits * total > part_floats)
         return fail(ctx, GF_ERR_NOMEM, "smp_wgrad_partials_c64: %d partial images, room for %zu", splits, part_floats / total);
     out->splits = splits;
-    if (trow && cmax && smp_split_products(ctx))
-        return smp_wgrad_partials_split_c64(ctx, T, dO, rowscale, rows, kchunk, splits, part, trow, cmax, trowf);
+    if (trow && ws.any() && smp_split_products(ctx))
+        return smp_wgrad_partials_split_c64(ctx, T, dO, rowscale, rows, kchunk, splits, part, trow, ws, trowf);
     const size_t lds = sizeof(float) * 2 * (size_t)kWgStage;
     gf_status st = opt_in_lds(ctx, smp_wgrad_c64, lds);
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_c64, dim3((unsigned)splits), dim3(kWgThreads), lds, T, dO, rowscale, rows, kchunk, part, trow);
     return GF_OK;
-}
-
-// the same, folded into dWst[0..8) by the two-pass ordered reduction (kept for GF_SMP_GROUPED=0)
-gf_status smp_wgrad_stationary_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, float *dWst) {
-    if (rows < 1) return GF_OK;
-    const size_t total = 8 * 4096;
-    int target = 256;
-    if (const char *e = std::getenv("GF_WGRAD_SPLITS")) target = std::max(1, std::atoi(e));
-    int kchunk = ((rows + target - 1) / target + BK - 1) / BK * BK;
-    if (kchunk < 8 * BK) kchunk = 8 * BK;
-    const int splits = (rows + kchunk - 1) / kchunk;
-    const int nchunks = (splits + 31) / 32;
-    gf_status st = ensure_ws(ctx, sizeof(float) * ((size_t)splits + nchunks) * total + 256);
-    if (st != GF_OK) return st;
-    FoldGroup fg;
-    st = smp_wgrad_partials_c64(ctx, T, dO, rowscale, rows, static_cast<float *>(ctx->ws), (size_t)splits * total, &fg, nullptr);
-    if (st != GF_OK) return st;
-    return splitk_fold(ctx, fg.part, dWst, total, fg.splits, 0);
 }
 
 // Row-panel products of a fused SMP level at C = 64 (see smp_rowpanel_c64): forward O from T, or backward dT from dO.
@@ -488,9 +469,7 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
     // forward: four waves per SIMD (measured equal to two); backward: two waves per SIMD with 256 registers -- the 128-register
     // build of the backward panel spills 100 B per lane and waits for one block request per panel (1.84 -> 1.66 ms at cfg3).
     // The compact layout (trow given) keeps four operand blocks in registers: two waves per SIMD in both directions.
-    int th = (forward && !trow) ? 1024 : 512;
-    if (!trow)
-        if (const char *e = std::getenv(forward ? "GF_RP_THREADS_FWD" : "GF_RP_THREADS_BWD")) th = std::atoi(e) == 512 ? 512 : 1024;
+    const int th = (forward && !trow) ? 1024 : 512;
     const int npanels = (rows + 31) / 32, per = th / 64;
     const int want = (npanels + per - 1) / per;
     const int grid = want < cus ? want : cus;  // one persistent workgroup per CU (the weight image takes 144 KB of LDS)
@@ -505,11 +484,9 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
         if (forward) GF_RP_LAUNCH(true, 512, true);
         else GF_RP_LAUNCH(false, 512, true);
     } else if (forward) {
-        if (th == 512) GF_RP_LAUNCH(true, 512, false);
-        else GF_RP_LAUNCH(true, 1024, false);
+        GF_RP_LAUNCH(true, 1024, false);
     } else {
-        if (th == 512) GF_RP_LAUNCH(false, 512, false);
-        else GF_RP_LAUNCH(false, 1024, false);
+        GF_RP_LAUNCH(false, 512, false);
     }
 #undef GF_RP_LAUNCH
     return GF_OK;

@@ -55,8 +55,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     const float *__restrict__ O, float *__restrict__ F, const int4 *__restrict__ pan, const int *__restrict__ pan_node, int npanels,
     int rows, const int2 *__restrict__ goff, const float *__restrict__ Gc, long long gc_rows, const float *__restrict__ adj,
     const float *__restrict__ rsum, const float *__restrict__ Vout, long long pairs, const float *__restrict__ Sout,
-    const float *__restrict__ bias, float *__restrict__ psum) {  // psum (top level, or null): [npanels][64] column sums of the panel's
+    const float *__restrict__ bias, float *__restrict__ psum,   // psum (top level, or null): [npanels][64] column sums of the panel's
     // rows of f -- the readout's per-node sums (ShrinkTensor, SMP_omega.h:671-676) then read 22 MB of partials instead of f_L again
+    float *__restrict__ pmax) {  // pmax (or null): [npanels][64] largest |f| per column of the panel's rows (the level above scales the
+    // columns of its weight-gradient operands with the level's per-channel maxima: smp_wgrad_column_bounds)
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     unsigned blk;
     {
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
             }
         }
     }
-    float c0 = 0.f, c1 = 0.f;
+    float c0 = 0.f, c1 = 0.f, x0m = 0.f, x1m = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -160,12 +162,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         const float f0 = z0 > 0.f ? z0 : kAlphaFf * z0, f1 = z1 > 0.f ? z1 : kAlphaFf * z1;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f0), rF, vo, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f1), rF, vo + 128, 0, 0);
-        if (rr < nrows) c0 += f0, c1 += f1;   // (rows in register order: a fixed order)
+        if (rr < nrows) {   // (rows in register order: a fixed order)
+            c0 += f0, c1 += f1;
+            x0m = fmaxf(x0m, fabsf(f0)), x1m = fmaxf(x1m, fabsf(f1));
+        }
     }
     if (psum) {  // (uniform)
         c0 += __shfl_xor(c0, 32);
         c1 += __shfl_xor(c1, 32);
         psum[(size_t)p * 64 + lane] = lh ? c1 : c0;   // lane = 32 lh + li: columns li | 32 + li
+    }
+    if (pmax) {  // (uniform)
+        x0m = fmaxf(x0m, __shfl_xor(x0m, 32));
+        x1m = fmaxf(x1m, __shfl_xor(x1m, 32));
+        pmax[(size_t)p * 64 + lane] = lh ? x1m : x0m;
     }
 }
 
@@ -210,7 +220,7 @@ gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream) {
 }
 
 // f_l from the projected matrix O = [O_loc | U] (compact layout) of a fused level at C = 64: smp_combine_fwd_panels
-gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum) {
+gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum, float *pmax) {
     gf_ctx *ctx = s->ctx;
     const gf_smp::DevLevel &d = s->lv[l];
     const gfsmp::LevelLayout &h = s->lay.level[l];
@@ -218,7 +228,7 @@ gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const flo
     if (npanels < 1) return GF_OK;
     GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
               d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
-              (long long)h.pairs, d.Sout, bias, psum);
+              (long long)h.pairs, d.Sout, bias, psum, pmax);
     return GF_OK;
 }
 

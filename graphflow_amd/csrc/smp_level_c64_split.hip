@@ -611,7 +611,12 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
                                                                   const float *__restrict__ rs, int rows, int kchunk,
                                                                   float *__restrict__ part, const int *__restrict__ trow,
                                                                   const unsigned *__restrict__ cmax,   // [kWsACols + kWsBCols] per-COLUMN magnitude
-                                                                  // bounds (float bits) of the nine operand blocks over the level, see below
+                                                                  // bounds (float bits) of the nine operand blocks over the level, see below; or
+                                                                  // null: built here from the level's per-channel maxima
+                                                                  const unsigned *__restrict__ chan,   // [128] max |f_{l-1}| | max |dz_l| per channel
+                                                                  float smax, float max_tot, float max_tr,
+                                                                  const unsigned *__restrict__ row_max,   // or null: {max |tot|, max |tr|} as float bits in
+                                                                  // device memory (they replace max_tot / max_tr: the device-side table builder's)
                                                                   int packed) {  // != 0: trow is the packed table (see smp_rowpanel_split)
     extern __shared__ __attribute__((aligned(16))) unsigned ws_smem[];  // stage s: A h | A l | B h | B l; then the column scales
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
@@ -631,7 +636,27 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
     // largest |f_{l-1}| of the channel, etc.: smp_wgrad_column_bounds); a bound 2^10 above the true maximum still leaves the floor
     // at 2^-28 of it.
     float *sScale = reinterpret_cast<float *>(ws_smem + 2 * kWsStageWords), *sInv = sScale + kWsACols + kWsBCols;
-    for (int c = tid; c < kWsACols + kWsBCols; c += kWsThreads) pow2_scale(cmax[c], &sScale[c], &sInv[c]);
+    if (cmax) {
+        for (int c = tid; c < kWsACols + kWsBCols; c += kWsThreads) pow2_scale(cmax[c], &sScale[c], &sInv[c]);
+    } else {
+        // from the per-channel maxima mf = max |f_{l-1}| and mdz = max |dz_l| (left by combine-forward of the level below and by this
+        // level's combine-backward, reduced by level_channel_maxima):
+        //   S_ab, S_bc = sums over <= smax positions of f_{l-1}          <= smax mf       T6, T10 = the same sums weighted by row sums
+        //   of the gated adjacency (>= 0, they add up to tot)            <= max_tot mf
+        //   L = dz <= mdz     tot L, tr L <= max_tot mdz, max_tr mdz     dU[e] = sum_y A+[y, e] dz[y] <= max_tot mdz   (and its gathered copy)
+        if (row_max) {
+            max_tot = __uint_as_float(row_max[0]);
+            max_tr = __uint_as_float(row_max[1]);
+        }
+        for (int c = tid; c < kWsACols + kWsBCols; c += kWsThreads) {
+            const bool isa = c < kWsACols;
+            const int blk = (isa ? c : c - kWsACols) >> 6, ch = c & 63;
+            const float m = __uint_as_float(chan[(isa ? 0 : 64) + ch]);
+            const float fa = blk < 2 ? smax : max_tot;                                   // S_ab, S_bc | T6, T10
+            const float fb = blk == 0 ? 1.f : blk == 2 ? max_tr : max_tot;               // L | tot L | tr L | dU | dU[trow]
+            pow2_scale(__float_as_uint(m * (isa ? fa : fb)), &sScale[c], &sInv[c]);
+        }
+    }
     __syncthreads();
 
     // ---- staging tasks: one task = rows (k, k + 1) x 4 columns; a wave's task group = 8 column quads (128 B of a row) x the 8
@@ -823,34 +848,51 @@ __global__ __launch_bounds__(256) void col_absmax64(const float *__restrict__ X,
     __syncthreads();
     const int q = threadIdx.x & 15;   // channel quad
     f4v m = {0.f, 0.f, 0.f, 0.f};
-    for (long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); r < rows; r += (long long)gridDim.x * 16) {
-        const f4v v = *reinterpret_cast<const f4v *>(X + (size_t)r * ld + 4 * q);
+    const long long step = (long long)gridDim.x * 16;
+    for (long long r0 = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); r0 < rows; r0 += 4 * step) {   // four rows in flight per thread
+        f4v v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], fabsf(v[j]));
+        for (int u = 0; u < 4; ++u) {
+            const long long r = r0 + u * step;
+            v[u] = *reinterpret_cast<const f4v *>(X + (size_t)(r < rows ? r : r0) * ld + 4 * q);   // (past the end: row r0 again)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], fabsf(v[u][j]));
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) atomicMax(&red[4 * q + j], __float_as_uint(m[j]));
     __syncthreads();
     if (threadIdx.x < 64 && red[threadIdx.x]) atomicMax(&out[threadIdx.x], red[threadIdx.x]);
 }
-// cmax[kWsACols + kWsBCols] from the per-channel maxima mf = max |f_{l-1}| and mdz >= max |dz| (dz = df_l x LeakyReLU slope):
-//   S_ab, S_bc = sums over <= smax positions of f_{l-1}             <= smax mf        T6, T10 = the same sums weighted by row sums of
-//   the gated adjacency (>= 0, they add up to tot)                  <= max_tot mf
-//   L = dz <= mdz      tot L, tr L <= max_tot mdz, max_tr mdz       dU[e] = sum_y A+[y, e] dz[y] <= max_tot mdz     (and its gathered copy)
-__global__ void wgrad_bounds(const unsigned *__restrict__ mf, const unsigned *__restrict__ mdz, float smax, float max_tot, float max_tr,
-                             const unsigned *__restrict__ row_max, unsigned *__restrict__ cmax) {
-    if (row_max) {
-        max_tot = __uint_as_float(row_max[0]);
-        max_tr = __uint_as_float(row_max[1]);
+// both per-channel maxima of a level in ONE launch: blockIdx.y = 0: X0 [rows0][64] -> out[0, 64), 1: X1 [rows1][64] -> out[64, 128)
+__global__ __launch_bounds__(256) void level_channel_maxima(const float *__restrict__ X0, long long rows0, const float *__restrict__ X1,
+                                                            long long rows1, unsigned *__restrict__ out) {
+    __shared__ unsigned red[64];
+    const float *X = blockIdx.y ? X1 : X0;
+    const long long rows = blockIdx.y ? rows1 : rows0;
+    if (threadIdx.x < 64) red[threadIdx.x] = 0u;
+    __syncthreads();
+    const int q = threadIdx.x & 15;
+    f4v m = {0.f, 0.f, 0.f, 0.f};
+    const long long step = (long long)gridDim.x * 16;
+    for (long long r0 = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); r0 < rows; r0 += 4 * step) {
+        f4v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long r = r0 + u * step;
+            v[u] = *reinterpret_cast<const f4v *>(X + (size_t)(r < rows ? r : r0) * 64 + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], fabsf(v[u][j]));
     }
-    const int c = threadIdx.x;   // 64 threads
-    const float f = __uint_as_float(mf[c]), d = __uint_as_float(mdz[c]);
-    const float a[4] = {smax * f, smax * f, max_tot * f, max_tot * f};
-    const float b[5] = {d, max_tot * d, max_tr * d, max_tot * d, max_tot * d};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cmax[64 * k + c] = __float_as_uint(a[k]);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) cmax[kWsACols + 64 * k + c] = __float_as_uint(b[k]);
+    for (int j = 0; j < 4; ++j) atomicMax(&red[4 * q + j], __float_as_uint(m[j]));
+    __syncthreads();
+    if (threadIdx.x < 64 && red[threadIdx.x]) atomicMax(&out[64 * blockIdx.y + threadIdx.x], red[threadIdx.x]);
 }
 __global__ void rowscale_absmax(const float *__restrict__ rs, int rows, unsigned *__restrict__ out) {   // out[0..1] = max |tot|, |tr|
     float a = 0.f, b = 0.f;
@@ -955,28 +997,26 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
 }
 
 // The eight row block products of a fused level at C = 64 (compact layout) as partial images, split operands: the contract of
-// smp_wgrad_partials_c64 (same row ranges, same image layout, folded by the caller).  cmax: the level's column bounds (device, kWsACols
-// + kWsBCols float bits: smp_wgrad_column_bounds / smp_wgrad_column_bounds_exact).
+// smp_wgrad_partials_c64 (same row ranges, same image layout, folded by the caller).  ws: where the operand columns' exponents come
+// from (smp_internal.h: WgradScales).
 gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int kchunk,
-                                       int splits, float *part, const int *trow, const unsigned *cmax, const int *trowf) {
+                                       int splits, float *part, const int *trow, const WgradScales &ws, const int *trowf) {
     gf_status st = opt_in_lds(ctx, smp_wgrad_split, kWsLds);
     if (st != GF_OK) return st;
     const bool mask = trowf && rows < (1 << 29) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
     GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_split, dim3((unsigned)splits), dim3(kWsThreads), kWsLds, T, dO, rowscale, rows, kchunk, part,
-              mask ? trowf : trow, cmax, mask ? 1 : 0);
+              mask ? trowf : trow, ws.cmax, ws.chan, ws.smax, ws.max_tot, ws.max_tr, ws.row_max, mask ? 1 : 0);
     return GF_OK;
 }
 
-size_t smp_wgrad_bound_words() { return 128 + kWsACols + kWsBCols; }
-// words: [0, 64) largest |f_{l-1}| per channel, [64, 128) largest |dz-bound| per channel (both accumulated here with atomicMax: the
-// caller zeroes them once per pass), [128, 128 + 576) the column bounds.  fprev [prev_rows][64]; dsrc [drows][64] bounds dz = df_l x
-// slope from above: df_l itself, or the per-node readout gradient at the top level.
-gf_status smp_wgrad_column_bounds(gf_ctx *ctx, const float *fprev, long long prev_rows, const float *dsrc, long long drows, int smax,
-                                  float max_tot, float max_tr, const unsigned *row_max, unsigned *words) {
-    auto grid = [](long long rows) { const long long g = (rows + 15) / 16; return (unsigned)(g < 1 ? 1 : g > 1024 ? 1024 : g); };
-    GF_LAUNCH(ctx, "smpf_colmax", col_absmax64, dim3(grid(prev_rows)), dim3(256), 0, fprev, prev_rows, 64, words);
-    GF_LAUNCH(ctx, "smpf_colmax", col_absmax64, dim3(grid(drows)), dim3(256), 0, dsrc, drows, 64, words + 64);
-    GF_LAUNCH(ctx, "smpf_colmax", wgrad_bounds, dim3(1), dim3(64), 0, words, words + 64, (float)smax, max_tot, max_tr, row_max, words + 128);
+size_t smp_wgrad_bound_words() { return 128; }
+// words: [0, 64) largest |f_{l-1}| per channel, [64, 128) largest |dz_l| per channel, accumulated here with atomicMax (the caller zeroes
+// them once per pass).  fprev [prev_rows][64]: f_{l-1} or the per-panel maxima its combine-forward left; dsrc [drows][64]: the
+// per-workgroup maxima of this level's combine-backward.  One launch.
+gf_status smp_wgrad_channel_maxima(gf_ctx *ctx, const float *fprev, long long prev_rows, const float *dsrc, long long drows, unsigned *words) {
+    const long long big = prev_rows > drows ? prev_rows : drows, g0 = (big + 63) / 64;
+    const unsigned g = (unsigned)(g0 < 1 ? 1 : g0 > 256 ? 256 : g0);
+    GF_LAUNCH(ctx, "smpf_colmax", level_channel_maxima, dim3(g, 2), dim3(256), 0, fprev, prev_rows, dsrc, drows, words);
     return GF_OK;
 }
 // the same from the operands themselves (gf_smp_level_wgrad_f32): words = 256 + 128 + 2 scratch words (zeroed here) + the bounds

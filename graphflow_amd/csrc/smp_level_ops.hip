@@ -37,7 +37,9 @@ gf_status gf_smp_level_wgrad_f32(gf_ctx *ctx, int rows, const float *T, const fl
     st = gf::smp_wgrad_column_bounds_exact(ctx, T, dO, rowscale, rows, bw);
     if (st != GF_OK) return st;
     gf::FoldGroup fg;
-    st = gf::smp_wgrad_partials_c64(ctx, T, dO, rowscale, rows, ws, (size_t)264 * total, &fg, trow, bw + 512);
+    gf::WgradScales sc;
+    sc.cmax = bw + 512;
+    st = gf::smp_wgrad_partials_c64(ctx, T, dO, rowscale, rows, ws, (size_t)264 * total, &fg, trow, sc);
     if (st != GF_OK) return st;
     return gf::splitk_fold(ctx, fg.part, dWst, total, fg.splits, 0);
 }

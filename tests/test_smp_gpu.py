@@ -216,7 +216,7 @@ def test_headline_shape_against_the_real_reference(gf, fused):
 VARIANTS = {
     "split": {},                                                   # default: f16 matrix pipe, two-half operands
     "fp32_pipe": {"GF_SMP_SPLIT": "0"},                            # row-panel kernels on the fp32 matrix pipe
-    "tiled_gemm": {"GF_SMP_ROWPANEL": "0", "GF_SMP_WGRAD": "0"},   # grouped tiled fp32 GEMMs (what every other channel count runs)
+    "tiled_gemm": {"GF_SMP_ROWPANEL": "0"},                        # grouped tiled fp32 GEMMs, three-block projection (what every other channel count runs)
     "op_by_op": None,                                              # the unfused pipeline
 }
 # measured on the fixture (profiles/r04_parity_margins.txt; r03: the same): NO variant flips a slope -- split operands, fp32-pipe row
@@ -361,13 +361,14 @@ def test_fused_and_op_by_op_levels_agree_at_scale(gf):
 
 
 def test_folded_backward_gather_equals_the_two_kernel_path(gf, monkeypatch):
-    """Fused levels evaluate dP inside the consumer gather (default) or write it with tables-backward and gather it
-    afterwards (GF_SMP_BWD_GATHER=0, also the route for receptive fields > 32): same expression (the gather adds the two
-    diagonal terms of a row after the consumers instead of per consumer)."""
+    """Fused levels evaluate dP inside the consumer gather (default: one launch per level, a wave per (source, 64-lane chunk) with
+    scalar-loaded per-consumer records) or write it with tables-backward and gather it afterwards (GF_SMP_BWD_GATHER=0, also the
+    route for receptive fields > 32): same expression (the gather adds the two diagonal terms of a row after the consumers instead
+    of per consumer).  29-atom molecules reach the 12- and 16-accumulator paths and the two-half items of sources above 16."""
     F, D, C, L, cap = 5, 5, 64, 3, 29
     mols, tg = [], []
     for seed in range(24):
-        adj, feat, t = synthetic_molecule(900 + seed)
+        adj, feat, t = synthetic_molecule(900 + seed, nV=29 if seed % 3 == 0 else None)
         mols.append((adj, feat))
         tg.append(t)
     params = smp_params(C, F, D, L, 5)
@@ -377,66 +378,30 @@ def test_folded_backward_gather_equals_the_two_kernel_path(gf, monkeypatch):
     assert rel_err(g1, g0) <= 1e-6
 
 
-@pytest.mark.parametrize("C", [64, 32, 16])
-def test_gather_kernels_agree(gf, monkeypatch, C):
-    """The one-launch backward gather (scalar-loaded per-consumer records, every request of a consumer in flight at once; default)
-    against the round-2 kernel (GF_SMP_GATHER=1: LDS-staged consumer lists, one launch per size class): same expression, same
-    consumer order; 29-atom molecules reach the 12- and 16-accumulator paths and the > 16 launch."""
-    F, D, L, cap = 5, 5, 3, 29
-    mols, tg = [], []
-    for seed in range(24):
-        adj, feat, t = synthetic_molecule(900 + seed, nV=29 if seed % 3 == 0 else None)
-        mols.append((adj, feat))
-        tg.append(t)
-    params = smp_params(C, F, D, L, 5)
-    g1 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)[3]
-    monkeypatch.setenv("GF_SMP_GATHER", "1")   # read per call
-    g0 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)[3]
-    assert not np.array_equal(g1, g0)   # (the switch switches something: the sums associate differently)
-    assert rel_err(g1, g0) <= 1e-6
-
-
-def test_panel_combine_forward_equals_the_quad_kernel(gf, monkeypatch):
-    """combine-forward at C = 64: one wave per row panel with the adjacency product and the rank-one terms as fp32 MFMAs on registers
-    (smp_combine_fwd_panels, default) against the round-2 kernel (GF_SMP_COMBINE_PANELS=0: workgroup per (node, four x), adjacency
-    image in LDS): same sums, different association."""
+def test_c64_level_kernels_equal_the_tiled_gemm_path(gf, monkeypatch):
+    """At C = 64 the block products of a fused level run as dedicated kernels (weights resident in LDS with the rows in registers,
+    compact two-block projection U = Z + Z'^T, combine-forward on row panels; output-stationary weight gradients).  GF_SMP_ROWPANEL=0
+    selects what every other channel count runs: the grouped tiled GEMM launches, the three-block projection and the workgroup-per-
+    (node, four x) combine -- same products, different summation order.  29-atom molecules: one-group panels (s >= 17), ragged last
+    panels, up to eight groups per panel."""
     F, D, C, L, cap = 5, 5, 64, 3, 29
     mols, tg = [], []
-    for seed in range(40):   # 29-atom molecules: one-group panels (s >= 17), ragged last panels, up to eight groups per panel
-        adj, feat, t = synthetic_molecule(1500 + seed, nV=29 if seed % 4 == 0 else None)
+    for seed in range(40):   # 40 molecules: the row counts are not multiples of the 32-row panels / 32-row slices
+        adj, feat, t = synthetic_molecule(1300 + seed, nV=29 if seed % 4 == 0 else None)
         mols.append((adj, feat))
         tg.append(t)
     params = smp_params(C, F, D, L, 6)
     p1, _, f1, g1, n1 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
     a1 = [n1.activation(0, l, 0) for l in (1, 2, 3)]
-    monkeypatch.setenv("GF_SMP_COMBINE_PANELS", "0")
+    monkeypatch.setenv("GF_SMP_ROWPANEL", "0")
     p0, _, f0, g0, n0 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
     a0 = [n0.activation(0, l, 0) for l in (1, 2, 3)]
     assert not np.array_equal(f1, f0)   # (the switch switches something)
     for x, y in zip(a1, a0):
         assert rel_err(x.astype(np.float64), y.astype(np.float64)) <= 2e-6
-    note("panel_combine_vs_quad_combine", pred=rel_err(p1, p0), feat=rel_err(f1, f0))
+    note("c64_kernels_vs_tiled_gemms", pred=rel_err(p1, p0), feat=rel_err(f1, f0))
     assert rel_err(p1, p0) <= 2e-6 and rel_err(f1, f0) <= 2e-6
-    assert_grads_agree_kink_aware("panel_combine_vs_quad_combine", g1, g0, n1, n0, mols, L)
-
-
-def test_c64_level_kernels_equal_the_tiled_gemm_path(gf, monkeypatch):
-    """At C = 64 the block products of a fused level run as dedicated kernels (weights resident in LDS with the rows in
-    registers; output-stationary weight gradients).  GF_SMP_ROWPANEL=0 / GF_SMP_WGRAD=0 select the grouped tiled GEMM
-    launches that every other channel count uses: same products, different summation order."""
-    F, D, C, L, cap = 5, 5, 64, 3, 29
-    mols, tg = [], []
-    for seed in range(40):   # 40 molecules: the row counts are not multiples of the 32-row panels / 32-row slices
-        adj, feat, t = synthetic_molecule(1300 + seed)
-        mols.append((adj, feat))
-        tg.append(t)
-    params = smp_params(C, F, D, L, 6)
-    p1, _, f1, g1, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
-    monkeypatch.setenv("GF_SMP_ROWPANEL", "0")
-    monkeypatch.setenv("GF_SMP_WGRAD", "0")
-    p0, _, f0, g0, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
-    assert rel_err(p1, p0) <= 1e-5 and rel_err(f1, f0) <= 1e-5
-    assert rel_err(g1, g0) <= 2e-5
+    assert_grads_agree_kink_aware("c64_kernels_vs_tiled_gemms", g1, g0, n1, n0, mols, L)
 
 
 def test_split_operand_products_equal_the_fp32_products(gf, monkeypatch):
@@ -491,32 +456,6 @@ def test_split_operand_products_over_input_scales(gf, scales):
     if len(scales) > 1:   # ... and against the op-by-op fp32 pipeline of the same batch, slope for slope
         _, _, _, g_ob, n_ob = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap, fused=False)
         assert_grads_agree_kink_aware("mixed_scales_fused_vs_op_by_op", grads, g_ob, net_fused, n_ob, mols, L)
-
-
-@pytest.mark.parametrize("C", [64, 16])
-def test_batched_small_launches_equal_one_launch_per_product(gf, monkeypatch, C):
-    """The per-(node,x) / per-node / compact products, their split-K folds, the bias and node sums and the weight un-stacking
-    run as a few batched launches per level (default) or one launch each (GF_SMP_GROUPED=0, the round-1 schedule): same
-    products, the reductions over rows split differently."""
-    F, D, L, cap = 5, 3, 3, 29
-    mols, tg = [], []
-    for seed in range(33):
-        adj, feat, t = synthetic_molecule(1700 + seed)
-        mols.append((adj, feat))
-        tg.append(t)
-    params = smp_params(C, F, D, L, 6)
-    p1, _, f1, g1, n1 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
-    monkeypatch.setenv("GF_SMP_COMPACT_O", "0")   # (C = 64: the two-block projected matrix U = Z + Z'^T vs the three-block one)
-    p2, _, f2, g2, n2 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
-    # the forward sums U in a different order, so a few pre-activations land on the other side of LeakyReLU's kink (KINK_TOL
-    # above): the gradients of the two layouts agree to the kink-limited bound only; the compact layout's own gradient is held
-    # to 1e-5 against the fp64 port by the headline tests
-    assert rel_err(p1, p2) <= 1e-6 and rel_err(f1, f2) <= 1e-6
-    assert_grads_agree_kink_aware("compact_vs_three_block_projection_C%d" % C, g1, g2, n1, n2, mols, L)
-    monkeypatch.setenv("GF_SMP_GROUPED", "0")
-    p0, _, f0, g0, _ = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
-    assert np.array_equal(p2, p0) and np.array_equal(f2, f0)   # forward: the same tiles, launched together
-    assert rel_err(g2, g0) <= 2e-6
 
 
 def test_two_handles_alternate_without_waiting_for_each_other(gf):
