@@ -1105,7 +1105,15 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     const bool prep_timing = std::getenv("GF_PREP_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     if (!s->upload) {
-        if (hipStreamCreateWithFlags(&s->upload, hipStreamNonBlocking) != hipSuccess) s->upload = nullptr;
+        // the batch's uploads and table-building kernels run at the LOWEST stream priority: in the loop with a new batch every step they
+        // share the device with the running step of another handle, which is what the loop waits for (GF_PREP_PRIORITY=0: default priority)
+        int least = 0, greatest = 0;
+        const char *pe = std::getenv("GF_PREP_PRIORITY");
+        if (!(pe && pe[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+            if (hipStreamCreateWithPriority(&s->upload, hipStreamNonBlocking, least) != hipSuccess) s->upload = nullptr;
+        } else if (hipStreamCreateWithFlags(&s->upload, hipStreamNonBlocking) != hipSuccess) {
+            s->upload = nullptr;
+        }
         if (s->upload && hipEventCreateWithFlags(&s->ev_last, hipEventDisableTiming) != hipSuccess) {
             (void)hipStreamDestroy(s->upload);
             s->upload = nullptr;
@@ -1441,7 +1449,7 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
             if (st != GF_OK) return st;
             continue;
         }
-        s->lv[l].t_zeros = false;  // (the op-by-op level uses all of Q: the zeros kept in the fused level's T region are gone)
+        s->lv[l].t_zeros = s->lv[l].t_filled = false;  // (the op-by-op level uses all of Q: the zeros kept in the fused level's T region are gone)
         st = gf::ensure_P(s);
         if (st != GF_OK) return st;
         const int Cp = s->cfg.level_channels(l - 1), Cc = s->cfg.level_channels(l);  // (equal unless a physics tower)

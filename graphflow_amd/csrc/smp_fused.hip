@@ -81,7 +81,14 @@ __constant__ int c_kperm[18] = {0, 2, 6, 5, 9, 8, 12, 11, 15, 16, 1, 3, 7, 10, 4
 #ifndef GF_TF_D2NI
 #define GF_TF_D2NI 4
 #endif
-template <int NI, bool ALLOK>  // ALLOK: C is a multiple of 64 -- every lane of every window has channels
+// VEC (round 4, ALLOK only): the sums over b that smp_vectors used to collect in a pass of its own -- rowsum_a[x] = sum_b S_ab[x, b],
+// D8[x] = sum_b P[x, b, b] and the per-node scalars -- are kept as the rows go by: every wave adds its (a, b) terms to LDS accumulators
+// of its OWN (two 16-byte read-modify-writes per row, plain DS operations in wave order: no atomics; the lanes outside c-group 0 work
+// on a slot nobody reads, so the row loop stays branch-free), the four waves' partials are folded in a fixed order after one barrier.
+// tables-forward 0.90 -> 1.04 ms, smp_vectors (0.38 ms a cfg3 step, 1 GB of traffic) gone.  Measured and not kept: one read-modify-write
+// per row with c-group 2 taking the diagonal element over lane ^ 32 (1.19 ms: the exchange sits on the row's critical path); the
+// row sums only, D8 gathered from the compact diagonal table in the epilogue as smp_vectors did (1.10 ms).
+template <int NI, bool ALLOK, bool VEC = false>  // ALLOK: C is a multiple of 64 -- every lane of every window has channels
 __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_fwd_w(  // (NI = 4 sat at 130 VGPRs: capped to 128 -> 4 waves per SIMD)
     const float *__restrict__ fprev, const float *__restrict__ rsum,
                                                              float *__restrict__ T, float *__restrict__ Vt,
@@ -90,8 +97,10 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
                                                              const int4 *__restrict__ recs,  // two per node, in launch order (build_tf_records)
                                                              int C, int nwin,
                                                              int zeros_kept,  // != 0: the structurally-zero rows (a, b) hold their zeros
-                                                             const unsigned char *__restrict__ rowflag) {  // with zeros_kept: bit 1 =
+                                                             const unsigned char *__restrict__ rowflag,  // with zeros_kept: bit 1 =
                                                              // row (b, c) has data in S_bc / T10 (the others are not stored either)
+                                                             float *__restrict__ St) {  // VEC: [nodes][4C] per-node scalars
+    static_assert(!VEC || ALLOK, "the folded vector sums need every lane to have channels");
     constexpr int LPC = 16, PPW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,6 +152,12 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
     const bool skip_bc = zeros_kept && rowflag;
     if (skip_bc)
         for (int i = tid; i < N * N; i += nthreads) sFlag[i] = rowflag[rowbase + i];
+    // VEC: per wave, [N][rowsum | D8][64 floats] accumulators and a 64-float slot the lanes outside c-group 0 read and write instead
+    f4 *sAcc = reinterpret_cast<f4 *>(smem + ((((N + 3) & ~3) + 4 * N + N * ST + ((N * N + 3) >> 2) + 3) & ~3));
+    const int nwv = nthreads / 64;
+    f4 *wacc = sAcc + (size_t)wave * N * 32, *wdummy = sAcc + (size_t)nwv * N * 32 + wave * 32;
+    if constexpr (VEC)
+        for (int i = lane; i < N * 32; i += 64) wacc[i] = splat(0.f);
     __syncthreads();
 
     float rc[NI];
@@ -219,6 +234,12 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
             // address): a store that all paths issue can be COUNTED by the compiler, so waiting for the next row's loads
             // (vmcnt is in order over loads and stores) need not include it; lane-conditional stores cannot (-5 %)
             st4(tcol + a * tstep, both);  // table row (a, b)
+            if constexpr (VEC) {   // c-group 0 holds S_ab[a, b] and P[a, b, b]: into the wave's accumulators of row a
+                f4 *slot = (cg == 0) ? wacc + a * 32 + fl : wdummy + fl;
+                const f4 r = slot[0] + both, d8 = slot[16] + dcur;
+                slot[0] = r;
+                slot[16] = d8;
+            }
             if constexpr (decltype(own_row)::value) {  // a == b: the peeled first row
                 if (cg == 0) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);
                 if (cg == 2) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, both);
@@ -321,6 +342,22 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
         st4(sc + 2 * C, dgsum);
     }
     }  // b
+    if constexpr (VEC) {
+        __syncthreads();   // (every wave's accumulators and partial scalars are complete and visible to the workgroup)
+        const int node = r0.x;
+        for (int i = tid; i < N * 32; i += nthreads) {   // (row a, rowsum | D8, float4 q): the waves' partials in wave order
+            const int a = i >> 5, rem = i & 31;
+            f4 v = sAcc[(size_t)a * 32 + rem];
+            for (int w = 1; w < nwv; ++w) v += sAcc[((size_t)w * N + a) * 32 + rem];
+            st4(Vt + (pairbase + a) * 4 * (size_t)C + (rem >> 4) * 2 * C + win * 64 + 4 * (rem & 15), v);
+        }
+        if (tid < 64) {   // per-node scalars: the sum over b of the partials, in the order of b (as smp_vectors formed it)
+            const int k = tid >> 4, q = tid & 15;
+            const auto one = [](int) { return 1.f; };
+            st4(St + (size_t)node * 4 * C + k * C + win * 64 + 4 * q,
+                batched_sum(scal + pairbase * 4 * (size_t)C + k * C + win * 64 + 4 * q, (size_t)4 * C, 0, N, one));
+        }
+    }
 }
 
 // rowsum_a[x] = sum_b S_ab[x,b], D8[x] = sum_b Dbb[x,b] per (node, x); scalars per node = sum over b of the partials.
@@ -898,6 +935,9 @@ Ragged ragged_for(const gf_smp::DevLevel &d, long long lo, int smax) {
     return R;
 }
 
+// tables-forward keeps smp_vectors' sums itself (C % 64 == 0; GF_SMP_TF_VEC=0: the separate pass)
+static bool smp_tables_fold_vectors(const gf_smp *s) { return (s->cfg.nChanels & 63) == 0 && !env_is("GF_SMP_TF_VEC", '0'); }
+
 template <int NI>
 gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     gf_ctx *ctx = s->ctx;
@@ -911,14 +951,22 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
     const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + 16 * (size_t)c.smax + sizeof(int) * (size_t)c.smax * 4 * NI + 16 +
                        (size_t)c.smax * c.smax + 16;
     const int flags = ((d.t_zeros && (C & 63) == 0) ? 1 : 0);
-    if ((C & 63) == 0)
+    if (smp_tables_fold_vectors(s)) {   // the sums over b of smp_vectors kept by the kernel itself (VEC)
+        const int nwv = (NI >= GF_TF_WIDE ? 2 : 1) * kThreads / 64;
+        const size_t lds_v = ((lds + 15) & ~(size_t)15) + 16 + (size_t)nwv * ((size_t)c.smax * 512 + 512);
+        gf_status st = opt_in_lds(ctx, smp_tables_fwd_w<NI, true, true>, lds_v);
+        if (st != GF_OK) return st;
+        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds_v,
+                  s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
+                  flags, flags ? d.rowflag : (const unsigned char *)nullptr, d.St);
+    } else if ((C & 63) == 0)
         GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
-                  flags, flags ? d.rowflag : (const unsigned char *)nullptr);
+                  flags, flags ? d.rowflag : (const unsigned char *)nullptr, (float *)nullptr);
     else
         GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, false>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
-                  flags, (const unsigned char *)nullptr);
+                  flags, (const unsigned char *)nullptr, (float *)nullptr);
     return GF_OK;
 }
 
@@ -1226,6 +1274,17 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K) {
     return GF_OK;
 }
 
+// zeros into the blocks of T that tables-forward skips (DevLevel::t_zeros), unless they are there already
+gf_status smp_fused_ensure_zero_fill(gf_smp *s, int l) {
+    gf_smp::DevLevel &d = s->lv[l];
+    if (!d.t_zeros || d.t_filled || !d.rowflag) return GF_OK;
+    const long long rows = s->lay.level[l].rows;
+    GF_LAUNCH(s->ctx, "smpf_tables_fill", tables_zero_fill, dim3((unsigned)((rows + kZeroFillRows - 1) / kZeroFillRows)), dim3(256), 0, d.Q,
+              d.rowflag, rows);
+    d.t_filled = true;
+    return GF_OK;
+}
+
 bool smp_fused_supported(const gf_smp *s, int l) {
     const int C = s->cfg.nChanels;
     if (C % 4 != 0 || C > 1024) return false;
@@ -1247,11 +1306,15 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     gf_status st;
     // The structurally-zero rows of the S_ab / T6 blocks (half of the rows at QM9 sizes, 0.73 GB of zeros a step at cfg3) are the
     // same rows every step of a prepared batch and nothing else writes there: their zeros go in once, tables-forward skips them.
+    // Round 4: and they are not even written that once while every reader of T skips them -- the split product kernels and the packed
+    // weight-gradient kernel read an absent block from a page of zeros, the sums over b never visit one -- which is the default path; a
+    // reader that does not mask (fp32 pipe, tiled GEMMs) gets the fill before it runs (here, or ensure_zero_fill in the reverse sweep).
     if (C == 64 && d.rowflag && !env_is("GF_SMP_MASK_ZEROS", '0')) {
-        if (!d.t_zeros) {
-            GF_LAUNCH(ctx, "smpf_tables_fill", tables_zero_fill, dim3((unsigned)(((long long)rows + kZeroFillRows - 1) / kZeroFillRows)), dim3(256), 0, T,
-                      d.rowflag, (long long)rows);
-            s->lv[l].t_zeros = true;
+        s->lv[l].t_zeros = true;
+        const bool readers_mask = smp_c64_kernels(s) && smp_split_products(ctx) && d.trowf && d.trow && (long long)rows < (1ll << 29);
+        if (!readers_mask) {
+            st = smp_fused_ensure_zero_fill(s, l);
+            if (st != GF_OK) return st;
         }
     } else {
         s->lv[l].t_zeros = false;
@@ -1271,8 +1334,9 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         GF_LAUNCH(ctx, "smpf_diag_gather", diag_gather_fwd, dim3(s->lay.level[l - 1].nNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, pv.f, d.Fdc, pv.node_s,
                   pv.node_row, pv.node_pair, pv.node_center, C);
     }
-    GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(node_block(h, C)), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
-              d.node_pair, C, d.Fdc, d.pair_src_pair, d.pi);
+    if (!smp_tables_fold_vectors(s))
+        GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(node_block(h, C)), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
+                  d.node_pair, C, d.Fdc, d.pair_src_pair, d.pi);
     const size_t CC = (size_t)C * C;
     {
         // V = Vt [K1;K3;K7;K10], S = St [K4;K13;K14;K17], Gc = [Fd K15 | Fc K16]: the small products of the level, ONE launch
@@ -1413,6 +1477,14 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
             sc.chan = wb;
             sc.smax = (float)h.buckets.back().s;
             sc.max_tot = d.max_tot, sc.max_tr = d.max_tr, sc.row_max = d.row_max;
+        }
+        {   // (a weight-gradient kernel that reads the absent blocks of T needs their zeros: see smp_fused_forward_level)
+            const bool packed = ocols == 2 && sc.any() && smp_split_products(ctx) && d.trowf && (long long)rows < (1ll << 29) &&
+                                !env_is("GF_SMP_MASK_ZEROS", '0');
+            if (!packed) {
+                st = smp_fused_ensure_zero_fill(s, l);
+                if (st != GF_OK) return st;
+            }
         }
         st = smp_wgrad_partials_c64(ctx, T, dO, d.rowscale, rows, ws, ws_floats, &rowg, ocols == 2 ? d.trow : nullptr, sc, d.trowf);
         if (st != GF_OK) return st;

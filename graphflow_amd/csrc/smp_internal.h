@@ -115,6 +115,7 @@ struct gf_smp {
         // tables-forward then skips them; rowflag[row] = 1 where the row is written every step.  t_zeros goes false whenever
         // something else may have overwritten the T region of Q (an op-by-op forward of the level).
         bool t_zeros = false;
+        bool t_filled = false;   // ... and the zeros are physically there (tables_zero_fill ran: some reader of T does not mask them)
         unsigned char *rowflag = nullptr;
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
         int4 *tf_recs = nullptr;  // [2 nNodes] records of tables-forward in launch order (build_tf_records)
@@ -194,6 +195,7 @@ struct gf_smp {
 namespace gf {
 bool smp_fused_supported(const gf_smp *s, int l);
 gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float *bl);
+gf_status smp_fused_ensure_zero_fill(gf_smp *s, int l);
 // node_df != nullptr (top level): df_l is the same C-vector at every position of a node, given as [nodes][C]
 gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl, const float *node_df);
 gf_status smp_fused_gather_backward(gf_smp *s, int l);
