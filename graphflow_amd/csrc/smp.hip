@@ -510,6 +510,112 @@ __global__ __launch_bounds__(256) void build_level_rows(const int *__restrict__ 
     if (tid == 0) node_present[n] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
 
+// Round 4: ONE workgroup per node builds every rows-sized table of the node (receptive fields of at most 32 vertices): what
+// build_level_rows, build_level_inv, expand_rowscale, build_trow and build_fwd_goff built in five launches that each re-read the
+// selection maps -- 1.0 of the 1.45 ms of table-building kernels per prepared 1024-molecule batch, which run beside the step of
+// another handle in the loop with a new batch every step.  The source fields of the node's neighbours are staged in LDS once and the
+// map of a (neighbour, position) pair is a scan of at most 32 entries by its own thread (no per-neighbour barriers); the maps stay
+// in LDS for the presence masks, the transposed-row table and the gather offsets of combine-forward.
+// cons_of_pair[e] = index of pair e in its source's consumer list (the inverse of cons_pair: invert_cons_pair).
+__global__ void invert_cons_pair(const long long *__restrict__ cons_pair, int *__restrict__ cons_of_pair, long long pairs) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < pairs) cons_of_pair[cons_pair[c]] = (int)c;
+}
+__global__ __launch_bounds__(128) void build_node_tables(
+    const int *__restrict__ node_s, const int *__restrict__ node_mol, const long long *__restrict__ node_row,
+    const long long *__restrict__ node_pair, const int *__restrict__ field, const int *__restrict__ prev_field,
+    const long long *__restrict__ pair_src_pair, const int *__restrict__ pair_src_s, const int *__restrict__ mol_nv,
+    const long long *__restrict__ mol_adj_off, const int *__restrict__ mol_adj, const double *__restrict__ mol_coul,
+    float *__restrict__ adj, float *__restrict__ rsum, float *__restrict__ node_scale, short *__restrict__ pi,
+    int *__restrict__ node_present, int swp,                                     // swp: largest field of the level below
+    const int *__restrict__ cons_of_pair, const long long *__restrict__ cons_inv_off, short *__restrict__ inv,   // or null (no consumers' maps)
+    float2 *__restrict__ rowscale,                                               // or null
+    int *__restrict__ trow, unsigned char *__restrict__ rowflag, int *__restrict__ trowf,   // trow null: none of the three
+    int2 *__restrict__ goff) {                                                   // or null
+    extern __shared__ int nt_smem[];
+    const int n = blockIdx.x, s = node_s[n], m = node_mol[n], V = mol_nv[m];
+    const long long r0 = node_row[n], p0 = node_pair[n];
+    int *f = nt_smem;                                             // [s] the node's field
+    float *rs = reinterpret_cast<float *>(f + s);                 // [s] gated row sums
+    float *dg = rs + s;                                           // [s] gated diagonal
+    unsigned *mask = reinterpret_cast<unsigned *>(dg + s);        // [s] bit p: neighbour a's source holds the vertex of position p
+    int *sf = reinterpret_cast<int *>(mask + s);                  // [s][swp] the neighbours' source fields, -1 padded
+    short *spi = reinterpret_cast<short *>(sf + s * swp);         // [s][s] the maps
+    const int *madj = mol_adj + mol_adj_off[m];
+    const double *mc = mol_coul ? mol_coul + mol_adj_off[m] : nullptr;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < s; i += nt) f[i] = field[p0 + i];
+    for (int i = tid; i < s * swp; i += nt) {
+        const int a = i / swp, k = i - a * swp;
+        sf[i] = k < pair_src_s[p0 + a] ? prev_field[pair_src_pair[p0 + a] + k] : -1;
+    }
+    __syncthreads();
+    auto entry = [&](int i, int j) {
+        return mc ? (float)mc[(size_t)f[i] * V + f[j]] : ((f[i] == f[j]) ? 1.f : (float)madj[(size_t)f[i] * V + f[j]]);
+    };
+    for (int idx = tid; idx < s * s; idx += nt) adj[r0 + idx] = entry(idx / s, idx % s);
+    for (int i = tid; i < s; i += nt) {  // (entries with A <= 0 are skipped: RisiContraction_18.h:90; j in order, as the host sums)
+        float acc = 0.f;
+        for (int j = 0; j < s; ++j) {
+            const float av = entry(i, j);
+            if (av > 0.f) acc += av;
+        }
+        rs[i] = acc;
+        rsum[p0 + i] = acc;
+        const float d = entry(i, i);
+        dg[i] = d > 0.f ? d : 0.f;
+    }
+    // the maps: pi[a][p] = position of the vertex of position p inside the field of neighbour a's source, -1 outside (:461-474)
+    for (int i = tid; i < s * s; i += nt) {
+        const int a = i / s, p = i - a * s, v = f[p];
+        const int *row = sf + a * swp;
+        int k = -1;
+        for (int kk = 0; kk < swp; ++kk) k = row[kk] == v ? kk : k;   // (a field holds a vertex once)
+        pi[r0 + i] = (short)k;
+        spi[i] = (short)k;
+        if (inv && k >= 0) inv[cons_inv_off[cons_of_pair[p0 + a]] + k] = (short)p;
+    }
+    __syncthreads();
+    float tot = 0.f, tr = 0.f;   // (every thread forms them, in the host's order: the row factors below need them)
+    for (int i = 0; i < s; ++i) {
+        tot += rs[i];
+        tr += dg[i];
+    }
+    if (tid == 0) {
+        node_scale[2 * (size_t)n] = tot;
+        node_scale[2 * (size_t)n + 1] = tr;
+    }
+    for (int a = tid; a < s; a += nt) {
+        unsigned mk = 0u;
+        for (int p = 0; p < s; ++p) mk |= (spi[a * s + p] >= 0 ? 1u : 0u) << p;
+        mask[a] = mk;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int cnt = 0;
+        for (int a = 0; a < s; ++a) cnt += __popc(mask[a]);
+        node_present[n] = cnt;
+    }
+    for (int i = tid; i < s * s; i += nt) {
+        const int x = i / s, e = i - x * s, it = e * s + x;
+        if (rowscale) rowscale[r0 + i] = make_float2(tot, tr);
+        const short pxe = spi[i], pex = spi[it];
+        if (goff) goff[r0 + i] = make_int2(pxe >= 0 ? (int)(pair_src_pair[p0 + x] + pxe) : -1, pex >= 0 ? (int)(pair_src_pair[p0 + e] + pex) : -1);
+        if (trow) {
+            const long long t = r0 + it;
+            trow[r0 + i] = (int)t;
+            const bool own = pxe >= 0, trp = pex >= 0;
+            // row (b, c) = (x, e) of the S_bc / T10 blocks has data when SOME neighbour's source holds both b and c
+            unsigned both = 0u;
+            for (int a = 0; a < s; ++a) both |= (mask[a] >> x) & (mask[a] >> e);
+            const bool bc = (both & 1u) != 0;
+            rowflag[r0 + i] = (own ? 1 : 0) | (bc ? 2 : 0);
+            if (trowf)
+                trowf[r0 + i] = (t < (1ll << 29)) ? (int)((unsigned)t | (own ? 0x80000000u : 0u) | (trp ? 0x40000000u : 0u) | (bc ? 0x20000000u : 0u)) : -1;
+        }
+    }
+}
+
 // stats = {max |tot| (float bits), max |tr|, rows with data (two words)} of a level; one workgroup, fixed order
 __global__ __launch_bounds__(1024) void level_table_stats(const float *__restrict__ node_scale, const int *__restrict__ node_present,
                                                           int nodes, unsigned *__restrict__ stats) {
@@ -1321,18 +1427,34 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             if (lds > 32 * 1024)   // (cannot happen: gf_smp_prepare chose the host builder for such a batch)
                 return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare: a receptive field of %d vertices in a molecule of %d", smax, vmax);
             unsigned *stats = s->tab_stats + 4 * l;
-            hipLaunchKernelGGL(gf::build_level_rows, dim3(h.nNodes), dim3(256), lds, up, d.node_s, d.node_mol, d.node_row, d.node_pair, d.field,
-                               s->lv[l - 1].field, d.pair_src_pair, d.pair_src_s, s->mol_nv, s->mol_adj_off, s->mol_adj, s->mol_coul, d.adj,
-                               d.rsum, d.node_scale, d.pi, d.node_present, vmax);
-            GF_LAUNCH_CHECK(ctx, "build_level_rows");
+            if (h.inv_count) GF_HIP_TRY(ctx, hipMemsetAsync(d.inv, 0xff, sizeof(short) * (size_t)h.inv_count, up));
+            // one kernel for all the node's tables where the fields fit its LDS image and its 32-bit presence masks (build_node_tables)
+            const int swp = B.level[l - 1].buckets.empty() ? 1 : B.level[l - 1].buckets.back().s;
+            const size_t lds_nt = sizeof(int) * (size_t)smax * (4 + (size_t)swp) + sizeof(short) * (size_t)smax * smax + 16;
+            d.node_tables_merged = smax <= 32 && lds_nt <= 32 * 1024 && h.pairs > 0 && h.pairs < 0x7fffffffll;
+            if (d.node_tables_merged) {
+                st = gf::upload(s, &d.cons_of_pair, nullptr, (size_t)h.pairs);
+                if (st != GF_OK) return st;
+                hipLaunchKernelGGL(gf::invert_cons_pair, dim3((unsigned)((h.pairs + 255) / 256)), dim3(256), 0, up, d.cons_pair, d.cons_of_pair,
+                                   (long long)h.pairs);
+                hipLaunchKernelGGL(gf::build_node_tables, dim3(h.nNodes), dim3(128), lds_nt, up, d.node_s, d.node_mol, d.node_row, d.node_pair,
+                                   d.field, s->lv[l - 1].field, d.pair_src_pair, d.pair_src_s, s->mol_nv, s->mol_adj_off, s->mol_adj, s->mol_coul,
+                                   d.adj, d.rsum, d.node_scale, d.pi, d.node_present, swp, d.cons_of_pair, d.cons_inv_off, d.inv,
+                                   reinterpret_cast<float2 *>(d.rowscale), d.trow, d.rowflag, d.trowf, d.fwd_goff);
+                GF_LAUNCH_CHECK(ctx, "build_node_tables");
+            } else {
+                hipLaunchKernelGGL(gf::build_level_rows, dim3(h.nNodes), dim3(256), lds, up, d.node_s, d.node_mol, d.node_row, d.node_pair, d.field,
+                                   s->lv[l - 1].field, d.pair_src_pair, d.pair_src_s, s->mol_nv, s->mol_adj_off, s->mol_adj, s->mol_coul, d.adj,
+                                   d.rsum, d.node_scale, d.pi, d.node_present, vmax);
+                GF_LAUNCH_CHECK(ctx, "build_level_rows");
+                if (h.pairs) {
+                    hipLaunchKernelGGL(gf::build_level_inv, dim3((unsigned)((h.pairs + 3) / 4)), dim3(256), 0, up, d.cons_pair, d.pair_node, d.node_s,
+                                       d.node_row, d.node_pair, d.cons_inv_off, d.pi, d.inv, (long long)h.pairs);
+                    GF_LAUNCH_CHECK(ctx, "build_level_inv");
+                }
+            }
             hipLaunchKernelGGL(gf::level_table_stats, dim3(1), dim3(1024), 0, up, d.node_scale, d.node_present, h.nNodes, stats);
             GF_LAUNCH_CHECK(ctx, "level_table_stats");
-            if (h.inv_count) GF_HIP_TRY(ctx, hipMemsetAsync(d.inv, 0xff, sizeof(short) * (size_t)h.inv_count, up));
-            if (h.pairs) {
-                hipLaunchKernelGGL(gf::build_level_inv, dim3((unsigned)((h.pairs + 3) / 4)), dim3(256), 0, up, d.cons_pair, d.pair_node, d.node_s,
-                                   d.node_row, d.node_pair, d.cons_inv_off, d.pi, d.inv, (long long)h.pairs);
-                GF_LAUNCH_CHECK(ctx, "build_level_inv");
-            }
         }
         // (the split-operand weight gradients read a level's largest |tot|, |tr| from the statistics words: no read-back, the
         //  preparing thread does not wait for its uploads)
@@ -1343,15 +1465,17 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     // (the node tables went up on the handle's upload stream: build the transposed-row tables there too, behind them)
     for (int l = 1; l <= L; ++l) {
         hipStream_t up = s->upload ? s->upload : ctx->stream;
-        hipLaunchKernelGGL(gf::expand_rowscale, dim3(B.level[l].nNodes), dim3(64), 0, up, reinterpret_cast<float2 *>(s->lv[l].rowscale),
-                           reinterpret_cast<const float2 *>(s->lv[l].node_scale), s->lv[l].node_s, s->lv[l].node_row);
+        const bool merged = s->lv[l].node_tables_merged;   // (row factors, transposed-row tables and gather offsets are in place)
+        if (!merged)
+            hipLaunchKernelGGL(gf::expand_rowscale, dim3(B.level[l].nNodes), dim3(64), 0, up, reinterpret_cast<float2 *>(s->lv[l].rowscale),
+                               reinterpret_cast<const float2 *>(s->lv[l].node_scale), s->lv[l].node_s, s->lv[l].node_row);
         st = gf::smp_build_gather_records(s, l, up);
         if (st != GF_OK) return st;
         st = gf::smp_build_tf_records(s, l, up);
         if (st != GF_OK) return st;
-        st = gf::smp_fwd_fused_build_tables(s, l, up);
+        st = gf::smp_fwd_fused_build_tables(s, l, up, !merged);
         if (st != GF_OK) return st;
-        if (s->lv[l].trow)
+        if (s->lv[l].trow && !merged)
             hipLaunchKernelGGL(gf::build_trow, dim3(B.level[l].nNodes), dim3(64), 0, up, s->lv[l].trow, s->lv[l].node_s, s->lv[l].node_row,
                                s->lv[l].pi, s->lv[l].rowflag, s->lv[l].trowf);
     }

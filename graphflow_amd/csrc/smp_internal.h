@@ -107,6 +107,8 @@ struct gf_smp {
         long long *cons_qbase = nullptr;                 // [nodes of level l-1] first record of the source's consumer entries
         // fused forward level at C = 64 (smp_level_c64_fwd.hip): row panels of whole (node, x) groups, per-row gather indices
         int4 *fwd_pan = nullptr;
+        int *cons_of_pair = nullptr;       // [pairs] index of a pair in its source's consumer list (build_node_tables)
+        bool node_tables_merged = false;   // this batch's rows-sized tables of the level came from build_node_tables (smp.hip)
         int *fwd_pan_node = nullptr, *node_panel = nullptr;
         int2 *fwd_goff = nullptr;
         int fwd_npanels = 0;
@@ -203,7 +205,7 @@ bool smp_fused_gather_enabled(const gf_smp *s, int l);
 gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_build_tf_records(gf_smp *s, int l, hipStream_t stream);
-gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream);
+gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream, bool gather_offsets = true);
 gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr, float *pmax = nullptr);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts

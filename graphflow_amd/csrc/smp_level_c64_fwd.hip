@@ -207,14 +207,16 @@ __global__ void build_fwd_goff(const int *__restrict__ node_s, const long long *
 
 }  // namespace
 
-gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream) {
+// gather_offsets = false: goff is in place already (build_node_tables, smp.hip)
+gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream, bool gather_offsets) {
     gf_smp::DevLevel &d = s->lv[l];
     const gfsmp::LevelLayout &h = s->lay.level[l];
     if (!d.fwd_pan || h.nNodes == 0) return GF_OK;
     hipLaunchKernelGGL(build_fwd_panels, dim3((unsigned)h.nNodes), dim3(64), 0, stream, d.node_s, d.node_row, d.node_pair, d.node_panel,
                        d.fwd_pan, d.fwd_pan_node);
-    hipLaunchKernelGGL(build_fwd_goff, dim3((unsigned)h.nNodes), dim3(64), 0, stream, d.node_s, d.node_row, d.node_pair, d.pair_src_pair,
-                       d.pi, d.fwd_goff);
+    if (gather_offsets)
+        hipLaunchKernelGGL(build_fwd_goff, dim3((unsigned)h.nNodes), dim3(64), 0, stream, d.node_s, d.node_row, d.node_pair, d.pair_src_pair,
+                           d.pi, d.fwd_goff);
     GF_LAUNCH_CHECK(s->ctx, "build_fwd_panels");
     return GF_OK;
 }
