@@ -1356,7 +1356,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             st = gf::upload(s, &d.cons_qbase, h.cons_qbase.empty() ? nullptr : &h.cons_qbase[0], h.cons_qbase.size());
             if (st != GF_OK) return st;
         }
-        if (!s->cfg.physics && C == 64 && h.rows < 0x7fffffffll) {
+        if (!s->cfg.physics && (C == 64 || C == 32) && h.rows < 0x7fffffffll) {   // (C = 32: the split row-panel products, round 4)
             st = gf::upload(s, &d.trow, nullptr, (size_t)h.rows);
             if (st == GF_OK) st = gf::upload(s, &d.trowf, nullptr, (size_t)h.rows);
             if (st == GF_OK) {
@@ -1367,7 +1367,11 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             if (st != GF_OK) return st;
             st = gf::upload(s, &d.rowflag, nullptr, (size_t)h.rows);
             if (st != GF_OK) return st;
-            if (s->cfg.nContractions == 18 && h.rows * 256 < 0x3fffffffll && !h.buckets.empty() && h.buckets.back().s <= 32) {
+            if (C == 32) {   // per-workgroup column maxima of dz (combine-backward): the weight gradients' column exponents
+                st = gf::upload(s, &d.dzmax, nullptr, h.quad_node.size() * 64);
+                if (st != GF_OK) return st;
+            }
+            if (C == 64 && s->cfg.nContractions == 18 && h.rows * 256 < 0x3fffffffll && !h.buckets.empty() && h.buckets.back().s <= 32) {
                 // row panels of the fused forward level (smp_level_c64_fwd.hip): a node of size s has ceil(s / max(1, 32 / s)) panels
                 const int np = h.npanels;   // (page-locked table of the layout: no wait for the copy)
                 d.fwd_npanels = np;
@@ -1487,6 +1491,9 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     if (!s->cfg.physics && C == 64) {
         st = gf::upload(s, &s->wbound, nullptr, gf::smp_wgrad_bound_words() * (size_t)(L + 1));
         if (st != GF_OK) return st;
+    } else if (!s->cfg.physics && C == 32) {   // scratch words of the C = 32 weight-gradient kernel's exact column bounds
+        st = gf::upload(s, &s->wbound, nullptr, gf::smp_wgrad_direct_words_c32() * (size_t)(L + 1));
+        if (st != GF_OK) return st;
     }
     st = gf::upload(s, &s->sh, nullptr, (size_t)top.nNodes * C);
     if (st != GF_OK) return st;
@@ -1561,7 +1568,7 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     s->lv[L].psum_ready = false;
     for (int l = 0; l <= L; ++l) s->lv[l].pmax_ready = false;
     if (s->fused) {
-        if (s->wbound) GF_HIP_TRY(ctx, hipMemsetAsync(s->wbound, 0, sizeof(unsigned) * gf::smp_wgrad_bound_words() * (size_t)(L + 1), ctx->stream));
+        if (s->wbound && C == 64) GF_HIP_TRY(ctx, hipMemsetAsync(s->wbound, 0, sizeof(unsigned) * gf::smp_wgrad_bound_words() * (size_t)(L + 1), ctx->stream));
         st = gf::smp_fused_stack_all(s, K);
         if (st != GF_OK) return st;
     }

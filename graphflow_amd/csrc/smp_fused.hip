@@ -1234,7 +1234,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 // the dedicated C = 64 kernels of the block products (weights resident in LDS, rows in registers; output-stationary weight gradients).
 // GF_SMP_ROWPANEL=0 (read per call: the parity tests switch it) selects the grouped tiled GEMM launches every other channel count uses.
-static bool smp_c64_kernels(const gf_smp *s) { return s->cfg.nChanels == 64 && !env_is("GF_SMP_ROWPANEL", '0'); }
+// Round 4: the split-operand row-panel products also run at C = 32 (32 x 32 blocks: one column half, two k-chunks per lane; weight
+// gradients on smp_wgrad_direct<32>); the fp32-pipe variants, the panel combine and the small-product kernels stay C = 64 only.
+static bool smp_c64_kernels(const gf_smp *s) {
+    if (env_is("GF_SMP_ROWPANEL", '0')) return false;
+    return s->cfg.nChanels == 64 || (s->cfg.nChanels == 32 && smp_split_products(s->ctx) && s->wbound != nullptr);
+}
 // compact projected matrix O = [O_loc | U] (2C) instead of [O_loc | Z | Z'] (3C): the dedicated C = 64 product kernels gather the
 // transposed rows themselves; the tiled launches keep the three-block layout
 bool smp_compact_o(const gf_smp *s) { return smp_c64_kernels(s); }
@@ -1257,7 +1262,7 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K) {
     }
     // ... and the split product kernels' weight images of every level, both directions (the backward pass reuses them)
     for (int l = 1; l <= L; ++l) s->lv[l].wimg_ready = false;
-    if (C == 64 && smp_compact_o(s) && smp_split_products(s->ctx)) {
+    if ((C == 64 || C == 32) && smp_compact_o(s) && smp_split_products(s->ctx)) {
         std::vector<const float *> w;
         std::vector<void *> im;
         for (int l = 1; l <= L; ++l)
@@ -1267,7 +1272,7 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K) {
                 s->lv[l].wimg_ready = true;
             }
         if (!w.empty()) {
-            gf_status st = smp_split_build_images(s->ctx, w.data(), im.data(), (int)w.size());
+            gf_status st = smp_split_build_images(s->ctx, w.data(), im.data(), (int)w.size(), C);
             if (st != GF_OK) return st;
         }
     }
@@ -1375,7 +1380,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         };
         if (smp_c64_kernels(s)) {
             st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, d.trow, d.trowf, false,
-                                           d.wimg_ready ? d.wimg : nullptr);  // weights in LDS
+                                           d.wimg_ready ? d.wimg : nullptr, C);  // weights in LDS
             if (st != GF_OK) return st;
         } else if (gemm_grouped_supported(sp, 3, false, false)) {
             st = gemm_grouped_rows(ctx, false, false, sp, 3, rows);
@@ -1463,7 +1468,26 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     size_t ws_floats = ctx->ws_bytes / sizeof(float), used = 0;
     FoldGroup rowg;
     const bool stationary = smp_c64_kernels(s);
-    if (stationary) {
+    if (stationary && C == 32) {   // smp_wgrad_direct<32>: one partial image of the eight products per workgroup
+        const long long slices = ((long long)rows + 15) / 16;
+        int splits = (int)(slices / 8 < 1 ? 1 : slices / 8 > 256 ? 256 : slices / 8);
+        if ((size_t)splits * 8 * CC > ws_floats) return fail(ctx, GF_ERR_NOMEM, "fused level: workspace too small for %d weight-gradient images", splits);
+        unsigned *words = s->wbound + (size_t)l * smp_wgrad_direct_words_c32();
+        const unsigned *chan = nullptr;
+        if (d.dzmax && d.row_max) {   // per-channel maxima of f_{l-1} and of this level's dz (combine-backward's per-workgroup maxima)
+            GF_HIP_TRY(ctx, hipMemsetAsync(words, 0, sizeof(unsigned) * 64, ctx->stream));
+            st = smp_wgrad_channel_maxima_ld(ctx, pv.f, (long long)s->lay.level[l - 1].rows, C, d.dzmax, (long long)h.quad_node.size(), 64, C, words);
+            if (st != GF_OK) return st;
+            chan = words;
+        }
+        st = smp_wgrad_partials_direct_c32(ctx, T, dO, d.rowscale, rows, splits, ws, d.trow, d.trowf, words, chan, (float)h.buckets.back().s,
+                                           d.row_max);
+        if (st != GF_OK) return st;
+        rowg.part = ws;
+        rowg.splits = splits;
+        rowg.n = 8 * CC;
+        used = (size_t)splits * 8 * CC;
+    } else if (stationary) {
         unsigned *wb = (s->wbound && ocols == 2 && smp_split_products(ctx)) ? s->wbound + (size_t)l * smp_wgrad_bound_words() : nullptr;
         if (wb && !d.dzmax) wb = nullptr;
         WgradScales sc;
@@ -1549,7 +1573,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     if (smp_c64_kernels(s)) {
         // (with the consumer gather reading dT, the gradients of the structurally-zero S_ab / T6 rows have no reader: not written)
         st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows, ocols == 2 ? d.trow : nullptr, d.trowf,
-                                       smp_fused_gather_enabled(s, l), d.wimg_ready ? d.wimg : nullptr);
+                                       smp_fused_gather_enabled(s, l), d.wimg_ready ? d.wimg : nullptr, C);
         if (st != GF_OK) return st;
     } else {
         const long long oC = C, wCC = (long long)CC;
@@ -1605,7 +1629,7 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
                   d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
-                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS, (C == 64 && s->wbound) ? d.dzmax : (float *)nullptr);
+                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS, (s->wbound && d.dzmax && smp_compact_o(s)) ? d.dzmax : (float *)nullptr);
     }
     (void)Kl;
     return smp_fused_backward_level_grouped(s, l, dKl, dbl);

@@ -30,8 +30,6 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 
 constexpr int kSpThreads = 512;            // two waves per SIMD, 256 registers each
-constexpr int kSpImg = 8 * 2 * 4 * 64;     // 16-byte fragment entries per image: [pos][column half][k chunk][lane]
-constexpr size_t kSpLds = 2 * (size_t)kSpImg * 16 + 16 * sizeof(float) + (kSpThreads / 64) * 32 * sizeof(float);
 
 // power-of-two scale that puts a magnitude with biased exponent e into [2^13, 2^14), and its inverse (e clamped: magnitudes below
 // 2^-113 are flushed by the f16 conversion, which is what the fp32 product of such operands underflows to as well)
@@ -78,32 +76,37 @@ __device__ __attribute__((aligned(256))) float sp_dump[kSpDumpRows * 64];
 // halves at the block's exponent.  imgH / imgL / winv may be LDS (built by the product kernel itself) or global memory (built once
 // per forward pass by smp_split_weight_images and copied by the product kernels: the build is ~30 us of strided reads per
 // workgroup, and six launches per step paid it).  wmax: 8 words of LDS.
-template <bool FWD, int NPOS>
+// CB = channels (64, or 32 since round 4): a block is CB x CB, a lane (row, half lh) of the A operand holds CB / 2 columns of its row,
+// i.e. NC = CB / 16 k-chunks of eight, and the output has NH = CB / 32 column halves: NH NC 64 fragment entries per block, stored at
+// a stride of 512 entries per position whatever CB is.
+template <bool FWD, int NPOS, int CB = 64>
 __device__ __forceinline__ void build_weight_images(const float *__restrict__ Wst, uint4 *imgH, uint4 *imgL, float *winv, unsigned *wmax,
                                                     int tid) {
+    constexpr int NC = CB / 16, NH = CB / 32, E = NH * NC * 64;
     if (tid < NPOS) wmax[tid] = 0u;
     __syncthreads();
 #pragma unroll 1
     for (int pos = 0; pos < NPOS; ++pos) {
         unsigned m = 0u;
-#pragma unroll
-        for (int i = 0; i < 4096 / kSpThreads; ++i) {
-            const unsigned b = __float_as_uint(Wst[pos * 4096 + i * kSpThreads + tid]) & 0x7fffffffu;
+        for (int i = tid; i < CB * CB; i += kSpThreads) {
+            const unsigned b = __float_as_uint(Wst[pos * CB * CB + i]) & 0x7fffffffu;
             m = b > m ? b : m;
         }
         atomicMax(&wmax[pos], m);
     }
     __syncthreads();
-    for (int t = tid; t < NPOS * 512; t += kSpThreads) {
-        const int ln = t & 63, c = (t >> 6) & 3, nh = (t >> 8) & 1, pos = t >> 9;
-        const int n = 32 * nh + (ln & 31), k0 = 32 * (ln >> 5) + 8 * c;
+    for (int t0 = tid; t0 < NPOS * E; t0 += kSpThreads) {
+        const int pos = t0 / E, e = t0 % E;
+        const int ln = e & 63, c = (e >> 6) % NC, nh = (e >> 6) / NC;
+        const int t = pos * 512 + e;
+        const int n = 32 * nh + (ln & 31), k0 = (CB / 2) * (ln >> 5) + 8 * c;
         float s, inv;
         pow2_scale(wmax[pos], &s, &inv);
-        if (ln == 0 && c == 0 && nh == 0) winv[pos] = inv;
-        const float *w = Wst + pos * 4096;
+        if (e == 0) winv[pos] = inv;
+        const float *w = Wst + pos * CB * CB;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = FWD ? w[(k0 + j) * 64 + n] : w[n * 64 + k0 + j];
+        for (int j = 0; j < 8; ++j) v[j] = FWD ? w[(k0 + j) * CB + n] : w[n * CB + k0 + j];
         unsigned hw[4], lw[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -127,32 +130,40 @@ struct SplitImages {
     const float *Wst[kSpImgLevels];
     uint4 *img[kSpImgLevels];   // [2 directions][kSpImgStride]
 };
-__global__ __launch_bounds__(kSpThreads) void smp_split_weight_images(SplitImages a) {  // workgroup (direction, level, position)
+__global__ __launch_bounds__(kSpThreads) void smp_split_weight_images(SplitImages a, int C) {  // workgroup (direction, level, position)
     __shared__ unsigned wmax[1];
     uint4 *out = a.img[blockIdx.y] + (size_t)blockIdx.x * kSpImgStride;
     float *winv = reinterpret_cast<float *>(out + 2 * kSpAll) + blockIdx.z;
-    const float *w = a.Wst[blockIdx.y] + (size_t)blockIdx.z * 4096;
+    const float *w = a.Wst[blockIdx.y] + (size_t)blockIdx.z * C * C;
     uint4 *H = out + blockIdx.z * 512, *L = out + kSpAll + blockIdx.z * 512;
-    if (blockIdx.x == 0)
-        build_weight_images<true, 1>(w, H, L, winv, wmax, threadIdx.x);
-    else
-        build_weight_images<false, 1>(w, H, L, winv, wmax, threadIdx.x);
+    if (C == 64) {
+        if (blockIdx.x == 0)
+            build_weight_images<true, 1, 64>(w, H, L, winv, wmax, threadIdx.x);
+        else
+            build_weight_images<false, 1, 64>(w, H, L, winv, wmax, threadIdx.x);
+    } else {
+        if (blockIdx.x == 0)
+            build_weight_images<true, 1, 32>(w, H, L, winv, wmax, threadIdx.x);
+        else
+            build_weight_images<false, 1, 32>(w, H, L, winv, wmax, threadIdx.x);
+    }
 }
 
-template <bool FWD, bool MASK>
+template <bool FWD, bool MASK, int CB = 64>
 __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float *__restrict__ A, const float *__restrict__ rs,
                                                                      const float *__restrict__ Wst, float *__restrict__ Out, int rows,
                                                                      const int *__restrict__ trow, int store_mask,
                                                                      const uint4 *__restrict__ wimg) {  // or null: this direction's
                                                                      // images, built by smp_split_weight_images
-    constexpr int LDA = FWD ? 256 : 128, LDOUT = FWD ? 128 : 256;
+    constexpr int LDA = FWD ? 4 * CB : 2 * CB, LDOUT = FWD ? 2 * CB : 4 * CB;
+    constexpr int VPL = CB / 2, NC = CB / 16, NH = CB / 32, E = NH * NC * 64;   // values per lane and block, k-chunks, column halves, fragment entries per block
     auto t_row = [](int t) { return MASK ? (t & 0x1fffffff) : t; };
     auto t_own = [](int t) { return MASK ? t < 0 : true; };
     auto t_tr = [](int t) { return MASK ? ((t >> 30) & 1) != 0 : true; };
     auto t_bc = [](int t) { return MASK ? ((t >> 29) & 1) != 0 : true; };   // the row's S_bc / T10 blocks hold data
     extern __shared__ __attribute__((aligned(16))) uint4 sp_smem[];
-    uint4 *imgH = sp_smem, *imgL = sp_smem + kSpImg;
-    float *winv = reinterpret_cast<float *>(sp_smem + 2 * kSpImg);  // [8] 2^-k of the weight blocks
+    uint4 *imgH = sp_smem, *imgL = sp_smem + 8 * E;
+    float *winv = reinterpret_cast<float *>(sp_smem + 2 * 8 * E);  // [8] 2^-k of the weight blocks
     unsigned *wmax = reinterpret_cast<unsigned *>(winv + 8);        // [8]
     float *facs = winv + 16;                                        // [waves][32]: row factors on their way to the C layout
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -160,13 +171,15 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
 
     // ---- weight images (see build_weight_images): copied from the pass's prebuilt ones, or built here
     if (wimg) {
-        for (int t = tid; t < kSpImg; t += kSpThreads) {
-            imgH[t] = wimg[t];
-            imgL[t] = wimg[kSpAll + t];
+        for (int t = tid; t < 8 * E; t += kSpThreads) {   // (512 entries apart per position in the prebuilt set, whatever CB is)
+            const int g = (t / E) * 512 + t % E;
+            imgH[t] = wimg[g];
+            imgL[t] = wimg[kSpAll + g];
         }
         if (tid < 2) reinterpret_cast<uint4 *>(winv)[tid] = wimg[2 * kSpAll + tid];
     } else {
-        build_weight_images<FWD, 8>(Wst, imgH, imgL, winv, wmax, tid);
+        static_assert(E == 512 || true, "");
+        if constexpr (CB == 64) build_weight_images<FWD, 8>(Wst, imgH, imgL, winv, wmax, tid);   // (other channel counts: prebuilt images only)
     }
     __syncthreads();
 
@@ -175,10 +188,10 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
     float *myfac = facs + wave * 32;
 
     struct Raw {
-        f4v a[8];
+        f4v a[VPL / 4];
     };
     struct Spl {
-        uint4 h[4], l[4];  // eight f16 each
+        uint4 h[NC], l[NC];  // eight f16 each
     };
     // columns [64 blk + 32 lh, +32) of row `li` of panel p, or of the given row (the transposed one).  Rows past the end read the
     // last row instead (unconditional loads: no branch per request); what is computed from them is never stored.
@@ -186,10 +199,10 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         __builtin_amdgcn_sched_barrier(0);  // (requests stay where the schedule below puts them: hoisted to the top of the panel
                                             //  they would all be live at once)
         asm volatile("" : "+v"(src_row));   // (nor is the address arithmetic on a prefetched row index moved up to its load)
-        const float *src = A + (size_t)src_row * LDA + blk * 64 + 32 * lh;
+        const float *src = A + (size_t)src_row * LDA + blk * CB + VPL * lh;
         if constexpr (MASK) src = present ? src : sp_zero_page;  // (a select on the address: same requests, same registers)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) R.a[q] = *reinterpret_cast<const f4v *>(src + 4 * q);
+        for (int q = 0; q < VPL / 4; ++q) R.a[q] = *reinterpret_cast<const f4v *>(src + 4 * q);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto load_raw = [&](Raw &R, int p, int blk, bool present) {
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         __builtin_amdgcn_sched_barrier(0);  // (not earlier than written: a block split ahead of time is 32 more live registers)
         unsigned m = 0u;
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < VPL / 4; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned b = __float_as_uint(R.a[q][j]) & 0x7fffffffu;
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         float s;
         pow2_scale(m, &s, &inv);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
             unsigned hw[4], lw[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -246,18 +259,18 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         __builtin_amdgcn_wave_barrier();
         myfac[li] = rowfac * winv[wpos];  // (both lane halves hold the row's factor: same value, same address, no branch)
         __builtin_amdgcn_wave_barrier();
-        const uint4 *bh = imgH + (size_t)(wpos * 8) * 64 + lane, *bl = imgL + (size_t)(wpos * 8) * 64 + lane;
+        const uint4 *bh = imgH + (size_t)wpos * E + lane, *bl = imgL + (size_t)wpos * E + lane;
         // one column half at a time (sixteen registers of products in flight, not thirty-two: the panel's operand blocks and the
         // requests behind them take the rest of the wave's 256)
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
+        for (int nh = 0; nh < NH; ++nh) {
             f16v t;
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[r] = 0.f;
             // the cross products (low halves at 2^11, see split_pair) ...
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const h8 bhc = __builtin_bit_cast(h8, bh[(4 * nh + c) * 64]), blc = __builtin_bit_cast(h8, bl[(4 * nh + c) * 64]);
+            for (int c = 0; c < NC; ++c) {
+                const h8 bhc = __builtin_bit_cast(h8, bh[(NC * nh + c) * 64]), blc = __builtin_bit_cast(h8, bl[(NC * nh + c) * 64]);
                 const h8 ah = __builtin_bit_cast(h8, S.h[c]), al = __builtin_bit_cast(h8, S.l[c]);
                 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhc, t, 0, 0, 0);
                 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blc, t, 0, 0, 0);
@@ -267,8 +280,8 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             // ... and the main product on top, one dependent chain (its B fragments are read again: four more ds_read_b128, no
             // registers held; as two independent chains the compiler interleaved them and spilled hundreds of registers)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const h8 bhc = __builtin_bit_cast(h8, bh[(4 * nh + c) * 64]);
+            for (int c = 0; c < NC; ++c) {
+                const h8 bhc = __builtin_bit_cast(h8, bh[(NC * nh + c) * 64]);
                 const h8 ah = __builtin_bit_cast(h8, S.h[c]);
                 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhc, t, 0, 0, 0);
             }
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
     //  before every split.  The one partial panel of the matrix runs a second copy of the panel code.)
     auto store_out = [&](int p, int o, const f16v &acc0, const f16v &acc1, auto full, unsigned rowbits = 0xffffffffu) {
         const int r0 = p * 32;
-        float *out = Out + (size_t)(r0 + 4 * lh) * LDOUT + o * 64 + li;
+        float *out = Out + (size_t)(r0 + 4 * lh) * LDOUT + o * CB + li;
         if constexpr (MASK && !FWD && decltype(full)::value) {
             if (rowbits != 0xffffffffu) {  // (uniform; the blocks without structural zeros pass all ones)
                 // rows without data go to the scratch rows: a select on the address, every store is issued
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
                     const int rr = (r & 3) + 8 * (r >> 2);
                     float *dst = ((mine >> rr) & 1u) ? out + (size_t)rr * LDOUT : dump + rr * 64;
                     dst[0] = acc0[r];
-                    dst[32] = acc1[r];
+                    if constexpr (NH == 2) dst[32] = acc1[r];
                 }
                 return;
             }
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
                 out[(size_t)rr * LDOUT] = acc0[r];
-                out[(size_t)rr * LDOUT + 32] = acc1[r];
+                if constexpr (NH == 2) out[(size_t)rr * LDOUT + 32] = acc1[r];
             }
         } else {
 #pragma unroll
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
                 const int rr = (r & 3) + 8 * (r >> 2);
                 if (r0 + 4 * lh + rr < rows) {
                     out[(size_t)rr * LDOUT] = acc0[r];
-                    out[(size_t)rr * LDOUT + 32] = acc1[r];
+                    if constexpr (NH == 2) out[(size_t)rr * LDOUT + 32] = acc1[r];
                 }
             }
         }
@@ -840,6 +853,233 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same eight products with the operands loaded STRAIGHT into MFMA layout (round 4): the weight gradients of the OTHER channel
+// count the row-panel kernels serve (CB = 32; at CB = 64 the staged kernel above is faster: 0.92 against 1.13 ms per cfg3 step --
+// every wave re-reads and re-splits the operands it shares with other products, 2.5 x the staged kernel's L1 / L2 traffic).
+// Both operands of  dW = A^T B  reduce over the ROWS, and v_mfma_f32_32x32x16_f16 wants from lane (c = lane & 31, g = lane >> 5)
+// the eight reduction indices k = 8 g .. 8 g + 7 of column c -- eight ROWS of one column.  One dword load per row hands the wave two
+// fully used 128-byte row segments, the lane splits its eight values in registers (a column's power-of-two scale is one register per
+// lane and tile), and the fragments go to the pipe: no transposed LDS image, no barrier per 16-row slice.  Wave w keeps product w.
+//   * Buffer addressing with the descriptor REBASED per slice (wave-uniform scalar arithmetic): lane offsets are constants, the row
+//     of a request rides in its scalar offset, rows past the end of the level are out of range (they load zeros), and a row whose
+//     block is structurally zero (packed table, see smp_rowpanel_split) gets an out-of-range offset.  The gathered rows dU[trow] lie
+//     inside the row's own node (< 1024 rows away): their descriptor starts 1024 rows below the slice.  Any level size.
+//   * Two slices in flight per wave behind the one being multiplied; the slice's packed table entries and row factors are
+//     requested a slice earlier than its operands, BEFORE the previous slice's operand requests, so that waiting for them does not
+//     wait for those (loads return in order).  The fragments are pinned (an empty asm) ahead of the requests: left alone the split
+//     drifts below them, the raw registers are still live when the next requests want them, and every value loaded in the loop is
+//     copied into place behind a drained queue at the loop's end.
+//   * Same partial images (8 x CB x CB floats per workgroup), same fold as the staged kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWdThreads = 512;
+template <int CB>
+__global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *__restrict__ T, const float *__restrict__ dO,
+                                                                   const float *__restrict__ rs, int rows, float *__restrict__ part,
+                                                                   const int *__restrict__ trow, const unsigned *__restrict__ cmax,   // [9 CB] column bounds, or null:
+                                                                   const unsigned *__restrict__ chan,   // [2 CB] max |f_{l-1}| | max |dz_l| per channel (see smp_wgrad_split)
+                                                                   float smax, const unsigned *__restrict__ row_max,   // {max |tot|, max |tr|} (float bits)
+                                                                   int packed) {
+    constexpr int NT = CB / 32, ACOLS = 4 * CB, BCOLS = 5 * CB;
+    constexpr int TROW = 16 * CB, DROW = 8 * CB;   // bytes of a row of T, of dO
+    __shared__ float sScale[ACOLS + BCOLS], sInv[ACOLS + BCOLS];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (cmax) {
+        for (int c = tid; c < ACOLS + BCOLS; c += kWdThreads) pow2_scale(cmax[c], &sScale[c], &sInv[c]);
+    } else {   // (the bounds of smp_wgrad_split, from the level's per-channel maxima)
+        const float max_tot = __uint_as_float(row_max[0]), max_tr = __uint_as_float(row_max[1]);
+        for (int c = tid; c < ACOLS + BCOLS; c += kWdThreads) {
+            const bool isa = c < ACOLS;
+            const int blk = (isa ? c : c - ACOLS) / CB, ch = c % CB;
+            const float m = __uint_as_float(chan[(isa ? 0 : CB) + ch]);
+            const float fa = blk < 2 ? smax : max_tot;
+            const float fb = blk == 0 ? 1.f : blk == 2 ? max_tr : max_tot;
+            pow2_scale(__float_as_uint(m * (isa ? fa : fb)), &sScale[c], &sInv[c]);
+        }
+    }
+    __syncthreads();
+
+    const int ablk = c_ws_ablk[wave], bblk = c_ws_bblk[wave];   // (uniform)
+    const bool gathered = bblk == 4;
+    const int fsel = bblk == 2 ? 1 : 0;                         // the row factor a scaled copy of L takes: tot | tr
+    const bool scaled = bblk == 1 || bblk == 2;
+    const int abit = (ablk == 0 || ablk == 2) ? 31 : 29;        // presence bit of the wave's T block: S_ab / T6 | S_bc / T10
+    float sa[NT], sb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        sa[t] = sScale[CB * ablk + 32 * t + li];
+        sb[t] = sScale[ACOLS + CB * bblk + 32 * t + li];
+    }
+    constexpr int kOut = 0x40000000;   // an offset no descriptor of this kernel reaches
+    const int offA = (8 * lg) * TROW + (CB * ablk + li) * 4;
+    const int offB = (8 * lg) * DROW + ((bblk >= 3 ? CB : 0) + li) * 4;
+    const int offG = (CB + li) * 4;   // (gathered: the row comes from the table)
+    const long long nsl = ((long long)rows + kWsSlice - 1) / kWsSlice;
+    auto slice_of = [&](int n) { return (long long)blockIdx.x + (long long)n * gridDim.x; };
+
+    struct Idx {      // a slice's table entries for the lane's eight rows
+        int t[8];
+    };
+    struct Fac {      // ... and its row factors
+        float f[8];
+    };
+    struct Raw {
+        float a[NT][8], b[NT][8];
+    };
+    // (entries of rows past the end of the level read as 0 through the descriptors: no flag, factor 0 -- their operand rows are
+    //  out of range anyway)
+    const __amdgpu_buffer_rsrc_t rTr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(trow), 0, (unsigned)rows * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rRs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rs), 0, (unsigned)rows * 8u, 0x00020000);
+    const int offF = scaled ? 64 * lg + 4 * fsel : kOut;   // (the other waves' requests return at once)
+    auto ld1 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    };
+    auto load_idx = [&](Idx &I, int n) {
+        const long long k0 = slice_of(n) * kWsSlice;
+        const int ks = k0 < rows ? (int)k0 : rows;   // (past the end: every entry out of range)
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        const i4v t0 = __builtin_bit_cast(i4v, __builtin_amdgcn_raw_buffer_load_b128(rTr, 32 * lg, ks * 4, 0));
+        const i4v t1 = __builtin_bit_cast(i4v, __builtin_amdgcn_raw_buffer_load_b128(rTr, 32 * lg + 16, ks * 4, 0));
+        I.t[0] = t0[0], I.t[1] = t0[1], I.t[2] = t0[2], I.t[3] = t0[3], I.t[4] = t1[0], I.t[5] = t1[1], I.t[6] = t1[2], I.t[7] = t1[3];
+    };
+    auto load_fac = [&](Fac &F, int n) {
+        const long long k0 = slice_of(n) * kWsSlice;
+        const int ks = k0 < rows ? (int)k0 : rows;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) F.f[j] = ld1(rRs, offF, ks * 8 + 8 * j);   // (the row in the scalar offset: one lane constant)
+    };
+    auto load_raw = [&](Raw &R, const Idx &I, int n) {
+        const long long k0 = slice_of(n) * kWsSlice;
+        const bool live = k0 < rows;
+        // descriptors of this slice: T rows [k0, k0 + 16); dO rows [g0, min(rows, k0 + 16 + 1024)) with g0 = max(0, k0 - 1024)
+        long long left = (long long)rows - k0;
+        left = left < 0 ? 0 : left > kWsSlice ? kWsSlice : left;
+        const long long k0c = live ? k0 : 0;
+        const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(T + (size_t)k0c * ACOLS), 0, (unsigned)(left * TROW), 0x00020000);
+        const long long g0 = k0c > 1024 ? k0c - 1024 : 0;
+        long long g1 = k0c + kWsSlice + 1024;
+        g1 = g1 > rows ? rows : g1;
+        const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dO + (size_t)g0 * 2 * CB), 0, live ? (unsigned)((g1 - g0) * DROW) : 0u, 0x00020000);
+        const int own = (int)(k0c - g0) * DROW;   // the slice's first row inside the dO window
+        const int ig0 = (int)g0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = I.t[j];
+            const bool pa = !packed || ((t >> abit) & 1);
+            const int va = pa ? offA : kOut;
+            // B: the slice's own rows, or (product 7) row trow of dU -- which only meets S_ab of ITS row: skipped where that is absent
+            const int tr = packed ? (t & 0x1fffffff) : t;
+            const bool pg = !packed || t < 0;
+            const int vg = pg ? (tr - ig0) * DROW + offG : kOut;
+            const int vb = gathered ? vg : offB;
+            const int sbo = gathered ? 0 : own + j * DROW;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                R.a[u][j] = ld1(rT, va + 128 * u, j * TROW);
+                R.b[u][j] = ld1(rD, vb + 128 * u, sbo);
+            }
+        }
+    };
+    f16v acc[NT][NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    auto frag = [&](const float (&v)[8], float sc, const float *f, h8 *H, h8 *L) {
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h2 h, l;
+            split_plain2(v[2 * i], v[2 * i + 1], f ? sc * f[2 * i] : sc, f ? sc * f[2 * i + 1] : sc, &h, &l);
+            hw[i] = __builtin_bit_cast(unsigned, h);
+            lw[i] = __builtin_bit_cast(unsigned, l);
+        }
+        *H = __builtin_bit_cast(h8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+        *L = __builtin_bit_cast(h8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+    };
+    if (slice_of(0) < nsl) {
+        const int mine = (int)((nsl - slice_of(0) + gridDim.x - 1) / gridDim.x);   // slices of this workgroup
+        Idx I0, I1;
+        Fac F0, F1;
+        Raw R0, R1;
+        load_idx(I0, 0);
+        load_idx(I1, 1);
+        load_fac(F0, 0);
+        load_raw(R0, I0, 0);
+        load_idx(I0, 2);
+        load_fac(F1, 1);
+        load_raw(R1, I1, 1);
+        // Step n: slice n's operands are in R and its factors in Fcur; slice n + 1's operands are in flight; slice n + 2's table
+        // entries (Inext2) and slice n + 1's factors were requested BEFORE those.  Nothing in the loop is conditional: slices past the
+        // end load zeros (descriptors of zero bytes) and add nothing, so an odd tail runs a whole pair of steps as well.
+        auto step = [&](Raw &R, Fac &Fcur, Idx &Inext2, Idx &Inext3, int n) {
+            h8 ah[NT], al[NT], bh[NT], bl[NT];
+            float fac[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fac[j] = scaled ? Fcur.f[j] : 1.f;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                frag(R.a[u], sa[u], nullptr, &ah[u], &al[u]);
+                frag(R.b[u], sb[u], fac, &bh[u], &bl[u]);
+            }
+            if constexpr (NT == 1)
+                asm volatile("" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
+            else
+                asm volatile("" : "+v"(ah[0]), "+v"(al[0]), "+v"(ah[1]), "+v"(al[1]), "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
+            __builtin_amdgcn_sched_barrier(0);
+            load_idx(Inext3, n + 3);
+            load_fac(Fcur, n + 2);
+            load_raw(R, Inext2, n + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
+        };
+        for (int n = 0; n < mine; n += 2) {
+            step(R0, F0, I0, I1, n);       // (I0 = entries of slice n + 2, I1 <- slice n + 3)
+            step(R1, F1, I1, I0, n + 1);   // (I1 = entries of slice n + 3, I0 <- slice n + 4)
+        }
+    }
+    // back to fp32 units: row k of the product is column k of its A block, column n column n of its B block
+    float *out = part + ((size_t)blockIdx.x * 8 + wave) * (CB * CB) + li;
+    const float *ia = sInv + ablk * CB, *ib = sInv + ACOLS + bblk * CB;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float ub = ib[32 * nt + li];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                out[row * CB + 32 * nt] = acc[mt][nt][r] * (ia[row] * ub);
+            }
+        }
+}
+
+// exact column bounds of the nine operand blocks of smp_wgrad_direct<CB> from the column maxima of T [rows][4 CB] (mt) and of
+// dO [rows][2 CB] (mo) and the largest |tot|, |tr| (mx): cmax [9 CB]
+__global__ void wgrad_bounds_exact_cb(const unsigned *__restrict__ mt, const unsigned *__restrict__ mo, const unsigned *__restrict__ mx,
+                                      unsigned *__restrict__ cmax, int CB) {
+    const int c = threadIdx.x;   // CB threads
+    if (c >= CB) return;
+    const float tot = __uint_as_float(mx[0]), tr = __uint_as_float(mx[1]);
+    for (int k = 0; k < 4; ++k) cmax[CB * k + c] = mt[CB * k + c];
+    const float l = __uint_as_float(mo[c]), u = __uint_as_float(mo[CB + c]);
+    cmax[4 * CB + c] = __float_as_uint(l);
+    cmax[5 * CB + c] = __float_as_uint(tot * l);
+    cmax[6 * CB + c] = __float_as_uint(tr * l);
+    cmax[7 * CB + c] = cmax[8 * CB + c] = __float_as_uint(u);
+}
+
 // ---- the column bounds of a level's operand blocks (cmax of smp_wgrad_split) -------------------------------------------------
 // largest |x| of every column of X [rows][ld] (columns [0, 64)) into out[64] (float bits, atomicMax: out starts at 0)
 __global__ __launch_bounds__(256) void col_absmax64(const float *__restrict__ X, long long rows, int ld, unsigned *__restrict__ out) {
@@ -893,6 +1133,28 @@ __global__ __launch_bounds__(256) void level_channel_maxima(const float *__restr
     for (int j = 0; j < 4; ++j) atomicMax(&red[4 * q + j], __float_as_uint(m[j]));
     __syncthreads();
     if (threadIdx.x < 64 && red[threadIdx.x]) atomicMax(&out[64 * blockIdx.y + threadIdx.x], red[threadIdx.x]);
+}
+// the same for other row widths: X0 [rows0][ld0], X1 [rows1][ld1], columns [0, C) of each -> out[0, C) | out[C, 2 C)  (C % 4 == 0, C <= 64)
+__global__ __launch_bounds__(256) void level_channel_maxima_ld(const float *__restrict__ X0, long long rows0, int ld0, const float *__restrict__ X1,
+                                                               long long rows1, int ld1, int C, unsigned *__restrict__ out) {
+    __shared__ unsigned red[64];
+    const float *X = blockIdx.y ? X1 : X0;
+    const long long rows = blockIdx.y ? rows1 : rows0;
+    const int ld = blockIdx.y ? ld1 : ld0, nq = C / 4, rpb = 256 / nq;   // rows per block pass
+    if (threadIdx.x < 64) red[threadIdx.x] = 0u;
+    __syncthreads();
+    const int q = threadIdx.x % nq, rr = threadIdx.x / nq;
+    f4v m = {0.f, 0.f, 0.f, 0.f};
+    if (rr < rpb)
+        for (long long r = (long long)blockIdx.x * rpb + rr; r < rows; r += (long long)gridDim.x * rpb) {
+            const f4v v = *reinterpret_cast<const f4v *>(X + (size_t)r * ld + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], fabsf(v[j]));
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicMax(&red[4 * q + j], __float_as_uint(m[j]));
+    __syncthreads();
+    if ((int)threadIdx.x < C && red[threadIdx.x]) atomicMax(&out[C * blockIdx.y + threadIdx.x], red[threadIdx.x]);
 }
 __global__ void rowscale_absmax(const float *__restrict__ rs, int rows, unsigned *__restrict__ out) {   // out[0..1] = max |tot|, |tr|
     float a = 0.f, b = 0.f;
@@ -953,7 +1215,7 @@ gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *pr
 }
 
 // the split weight images (both directions) of n levels' stacked weights in one launch; img[i]: smp_split_image_bytes() each
-gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n) {
+gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n, int C) {
     for (int i0 = 0; i0 < n; i0 += kSpImgLevels) {
         SplitImages a;
         const int m = n - i0 < kSpImgLevels ? n - i0 : kSpImgLevels;
@@ -961,7 +1223,7 @@ gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *con
             a.Wst[i] = Wst[i0 + i];
             a.img[i] = static_cast<uint4 *>(img[i0 + i]);
         }
-        GF_LAUNCH(ctx, "smpf_stack_w", smp_split_weight_images, dim3(2, m, kSpPos), dim3(kSpThreads), 0, a);
+        GF_LAUNCH(ctx, "smpf_stack_w", smp_split_weight_images, dim3(2, m, kSpPos), dim3(kSpThreads), 0, a, C);
     }
     return GF_OK;
 }
@@ -970,27 +1232,43 @@ gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *con
 // level): forward O from T = [S_ab|S_bc|T6|T10], or backward dT from dO.  Every output element is produced by one wave in a
 // fixed order: results do not depend on the grid size.
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                 int rows, const int *trow, int cus, const int *trowf, bool skip_zero_grads, const void *wimg) {
+                                 int rows, const int *trow, int cus, const int *trowf, bool skip_zero_grads, const void *wimg, int C) {
     const int per = kSpThreads / 64;
     const int npanels = (rows + 31) / 32;
     const int want = (npanels + per - 1) / per;
-    const int grid = want < cus ? want : cus;  // one persistent workgroup per CU (the weight images take 128 KB of LDS)
+    // C = 64: one persistent workgroup per CU (the weight images take 128 KB of LDS); C = 32 (32 KB of images): two
+    const int slots = C == 64 ? cus : 2 * cus;
+    const int grid = want < slots ? want : slots;
+    if (C != 64 && !wimg) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d channels need the level's prebuilt weight images", C);
     // packed table with the presence bits (see the kernel)
     const bool mask = trowf && rows < (1 << 29) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
-#define GF_SP_LAUNCH(F, M, name)                                                                                                   \
+#define GF_SP_LAUNCH(F, M, CBv, name)                                                                                              \
     do {                                                                                                                           \
-        gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M>, kSpLds);                                                          \
+        const size_t lds__ = 2 * (size_t)8 * (CBv / 32) * (CBv / 16) * 64 * 16 + 16 * sizeof(float) + (kSpThreads / 64) * 32 * sizeof(float); \
+        gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M, CBv>, lds__);                                                      \
         if (st != GF_OK) return st;                                                                                                \
-        GF_LAUNCH(ctx, name, (smp_rowpanel_split<F, M>), dim3((unsigned)grid), dim3(kSpThreads), kSpLds, A, rowscale, Wst, Out, rows, \
+        GF_LAUNCH(ctx, name, (smp_rowpanel_split<F, M, CBv>), dim3((unsigned)grid), dim3(kSpThreads), lds__, A, rowscale, Wst, Out, rows, \
                   M ? trowf : trow, skip_zero_grads ? 1 : 0,                                                                       \
                   wimg ? static_cast<const uint4 *>(wimg) + (F ? 0 : kSpImgStride) : (const uint4 *)nullptr);                      \
     } while (0)
-    if (forward) {
-        if (mask) GF_SP_LAUNCH(true, true, "smpf_products_fwd");
-        else GF_SP_LAUNCH(true, false, "smpf_products_fwd");
+    if (C == 64) {
+        if (forward) {
+            if (mask) GF_SP_LAUNCH(true, true, 64, "smpf_products_fwd");
+            else GF_SP_LAUNCH(true, false, 64, "smpf_products_fwd");
+        } else {
+            if (mask) GF_SP_LAUNCH(false, true, 64, "smpf_products_bwd");
+            else GF_SP_LAUNCH(false, false, 64, "smpf_products_bwd");
+        }
+    } else if (C == 32) {
+        if (forward) {
+            if (mask) GF_SP_LAUNCH(true, true, 32, "smpf_products_fwd");
+            else GF_SP_LAUNCH(true, false, 32, "smpf_products_fwd");
+        } else {
+            if (mask) GF_SP_LAUNCH(false, true, 32, "smpf_products_bwd");
+            else GF_SP_LAUNCH(false, false, 32, "smpf_products_bwd");
+        }
     } else {
-        if (mask) GF_SP_LAUNCH(false, true, "smpf_products_bwd");
-        else GF_SP_LAUNCH(false, false, "smpf_products_bwd");
+        return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d channels", C);
     }
 #undef GF_SP_LAUNCH
     return GF_OK;
@@ -1009,6 +1287,34 @@ gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float 
     return GF_OK;
 }
 
+
+// The eight row block products of a fused level at C = 32 (compact layout) as partial images of 8 x 32 x 32 floats: smp_wgrad_direct<32>.
+// Column exponents from the level's per-channel maxima (chan: [64] words, smax, row_max: see smp_wgrad_split), or -- chan null -- exact
+// column bounds taken from the operands themselves (one extra pass over T and dO; `words`: 512 + 9 * 32 scratch words).
+gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int splits, float *part,
+                                        const int *trow, const int *trowf, unsigned *words, const unsigned *chan, float smax,
+                                        const unsigned *row_max) {
+    constexpr int CB = 32;
+    const bool mask = trowf && rows < (1 << 28) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
+    if (chan && row_max) {
+        GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<CB>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
+                  mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0);
+        return GF_OK;
+    }
+    GF_HIP_TRY(ctx, hipMemsetAsync(words, 0, sizeof(unsigned) * 512, ctx->stream));
+    const long long g0 = ((long long)rows + 15) / 16;
+    const unsigned g = (unsigned)(g0 < 1 ? 1 : g0 > 1024 ? 1024 : g0);
+    // column maxima in chunks of 64 columns: T [rows][128] -> words [0, 128), dO [rows][64] -> words [256, 320)
+    for (int k = 0; k < 4 * CB / 64; ++k) GF_LAUNCH(ctx, "smpf_colmax", col_absmax64, dim3(g), dim3(256), 0, T + 64 * k, (long long)rows, 4 * CB, words + 64 * k);
+    for (int k = 0; k < 2 * CB / 64; ++k) GF_LAUNCH(ctx, "smpf_colmax", col_absmax64, dim3(g), dim3(256), 0, dO + 64 * k, (long long)rows, 2 * CB, words + 256 + 64 * k);
+    GF_LAUNCH(ctx, "smpf_colmax", rowscale_absmax, dim3(64), dim3(256), 0, rowscale, rows, words + 384);
+    GF_LAUNCH(ctx, "smpf_colmax", wgrad_bounds_exact_cb, dim3(1), dim3(64), 0, words, words + 256, words + 384, words + 512, CB);
+    GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<CB>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
+              mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0);
+    return GF_OK;
+}
+size_t smp_wgrad_direct_words_c32() { return 512 + 9 * 32; }
+
 size_t smp_wgrad_bound_words() { return 128; }
 // words: [0, 64) largest |f_{l-1}| per channel, [64, 128) largest |dz_l| per channel, accumulated here with atomicMax (the caller zeroes
 // them once per pass).  fprev [prev_rows][64]: f_{l-1} or the per-panel maxima its combine-forward left; dsrc [drows][64]: the
@@ -1017,6 +1323,13 @@ gf_status smp_wgrad_channel_maxima(gf_ctx *ctx, const float *fprev, long long pr
     const long long big = prev_rows > drows ? prev_rows : drows, g0 = (big + 63) / 64;
     const unsigned g = (unsigned)(g0 < 1 ? 1 : g0 > 256 ? 256 : g0);
     GF_LAUNCH(ctx, "smpf_colmax", level_channel_maxima, dim3(g, 2), dim3(256), 0, fprev, prev_rows, dsrc, drows, words);
+    return GF_OK;
+}
+gf_status smp_wgrad_channel_maxima_ld(gf_ctx *ctx, const float *fprev, long long prev_rows, int ld0, const float *dsrc, long long drows, int ld1, int C,
+                                      unsigned *words) {
+    const long long big = prev_rows > drows ? prev_rows : drows, g0 = (big + 63) / 64;
+    const unsigned g = (unsigned)(g0 < 1 ? 1 : g0 > 256 ? 256 : g0);
+    GF_LAUNCH(ctx, "smpf_colmax", level_channel_maxima_ld, dim3(g, 2), dim3(256), 0, fprev, prev_rows, ld0, dsrc, drows, ld1, C, words);
     return GF_OK;
 }
 // the same from the operands themselves (gf_smp_level_wgrad_f32): words = 256 + 128 + 2 scratch words (zeroed here) + the bounds

@@ -85,7 +85,7 @@ def test_batch_equals_sum_of_molecules(gf, golden):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("C,L,cap", [(8, 2, 6), (16, 3, 8), (20, 2, 8), (64, 2, 12), (128, 2, 8)])
+@pytest.mark.parametrize("C,L,cap", [(8, 2, 6), (16, 3, 8), (20, 2, 8), (32, 3, 10), (64, 2, 12), (128, 2, 8)])
 def test_synthetic_batch_vs_oracle(gf, C, L, cap, fused):
     from oracle import smp_oracle
     F, D = 5, 2
@@ -402,6 +402,38 @@ def test_c64_level_kernels_equal_the_tiled_gemm_path(gf, monkeypatch):
     note("c64_kernels_vs_tiled_gemms", pred=rel_err(p1, p0), feat=rel_err(f1, f0))
     assert rel_err(p1, p0) <= 2e-6 and rel_err(f1, f0) <= 2e-6
     assert_grads_agree_kink_aware("c64_kernels_vs_tiled_gemms", g1, g0, n1, n0, mols, L)
+
+
+def test_c32_row_panel_kernels_equal_the_tiled_gemm_path(gf, monkeypatch):
+    """Round 4: at C = 32 the block products of a fused level run on the same split-operand row-panel kernels as at C = 64 (32 x 32
+    blocks: one column half, two k-chunks per lane; compact two-block projection with the transposed-row gather; structural zeros
+    read from the zero page) and the weight gradients on smp_wgrad_direct<32> (operands loaded straight into MFMA layout, exact
+    column bounds).  GF_SMP_ROWPANEL=0 selects the grouped tiled fp32 GEMMs with the three-block projection that the other channel
+    counts run.  29-atom molecules: ragged last panels and slices, rows without data in every block."""
+    F, D, C, L, cap = 5, 5, 32, 3, 29
+    mols, tg = [], []
+    for seed in range(40):
+        adj, feat, t = synthetic_molecule(1700 + seed, nV=29 if seed % 4 == 0 else None)
+        mols.append((adj, feat))
+        tg.append(t)
+    params = smp_params(C, F, D, L, 6)
+    p1, _, f1, g1, n1 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    a1 = [n1.activation(0, l, 0) for l in (1, 2, 3)]
+    monkeypatch.setenv("GF_SMP_ROWPANEL", "0")
+    p0, _, f0, g0, n0 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    a0 = [n0.activation(0, l, 0) for l in (1, 2, 3)]
+    assert not np.array_equal(f1, f0)   # (the switch switches something)
+    for x, y in zip(a1, a0):
+        assert rel_err(x.astype(np.float64), y.astype(np.float64)) <= 2e-6
+    note("c32_kernels_vs_tiled_gemms", pred=rel_err(p1, p0), feat=rel_err(f1, f0))
+    assert rel_err(p1, p0) <= 2e-6 and rel_err(f1, f0) <= 2e-6
+    assert_grads_agree_kink_aware("c32_kernels_vs_tiled_gemms", g1, g0, n1, n0, mols, L)
+    # ... and with the structural-zero masking off (dense reads of the same tables)
+    monkeypatch.delenv("GF_SMP_ROWPANEL")
+    monkeypatch.setenv("GF_SMP_MASK_ZEROS", "0")
+    p2, _, f2, g2, n2 = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    assert rel_err(p2, p1) <= 2e-6 and rel_err(f2, f1) <= 2e-6
+    assert_grads_agree_kink_aware("c32_masked_vs_dense", g2, g1, n2, n1, mols, L)
 
 
 def test_split_operand_products_equal_the_fp32_products(gf, monkeypatch):
