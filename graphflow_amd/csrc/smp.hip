@@ -1367,21 +1367,17 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             if (st != GF_OK) return st;
             st = gf::upload(s, &d.rowflag, nullptr, (size_t)h.rows);
             if (st != GF_OK) return st;
-            if (C == 32) {   // per-workgroup column maxima of dz (combine-backward): the weight gradients' column exponents
-                st = gf::upload(s, &d.dzmax, nullptr, h.quad_node.size() * 64);
-                if (st != GF_OK) return st;
-            }
-            if (C == 64 && s->cfg.nContractions == 18 && h.rows * 256 < 0x3fffffffll && !h.buckets.empty() && h.buckets.back().s <= 32) {
+            if (s->cfg.nContractions == 18 && h.rows * 256 < 0x3fffffffll && !h.buckets.empty() && h.buckets.back().s <= 32) {
                 // row panels of the fused forward level (smp_level_c64_fwd.hip): a node of size s has ceil(s / max(1, 32 / s)) panels
                 const int np = h.npanels;   // (page-locked table of the layout: no wait for the copy)
                 d.fwd_npanels = np;
                 UP(d.node_panel, h.node_panel);
                 st = gf::upload(s, &d.fwd_pan, nullptr, (size_t)np);
                 if (st != GF_OK) return st;
-                if (l == L) {
+                if (C == 64 && l == L) {   // (the readout from panel partials and the per-panel channel maxima are C = 64 only)
                     st = gf::upload(s, &d.psum, nullptr, (size_t)np * 64);
                     if (st != GF_OK) return st;
-                } else {
+                } else if (C == 64) {
                     st = gf::upload(s, &d.pmax, nullptr, (size_t)np * 64);
                     if (st != GF_OK) return st;
                 }

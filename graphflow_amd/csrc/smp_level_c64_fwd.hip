@@ -51,6 +51,8 @@ __device__ __forceinline__ float ff_ld1(__amdgpu_buffer_rsrc_t r, int voff) {
 // registers laid out as the MFMA's C/D tile, f_l leaves as 128-byte row segments.  Replaces smp_combine_fwd<16> (workgroup per
 // (node, four x): adjacency image in LDS, a barrier between its two phases, a quarter of its waves idle on ragged quads).
 // ---------------------------------------------------------------------------------------------------------------
+// CB = channels: 64 (two 32-column halves per row) or 32 (one; round 4)
+template <int CB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void smp_combine_fwd_panels(
     const float *__restrict__ O, float *__restrict__ F, const int4 *__restrict__ pan, const int *__restrict__ pan_node, int npanels,
     int rows, const int2 *__restrict__ goff, const float *__restrict__ Gc, long long gc_rows, const float *__restrict__ adj,
@@ -75,11 +77,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     const bool rowok = li < nrows;
     const int row = P.x + (rowok ? li : nrows - 1);
     const int2 go = goff[row];
-    const __amdgpu_buffer_rsrc_t rO = ff_rsrc(O, (size_t)rows * 128 * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rGc = ff_rsrc(Gc, (size_t)gc_rows * 128 * sizeof(float));
+    constexpr bool TWO = CB == 64;   // a second column half
+    constexpr int OB = 2 * CB * 4, FB = CB * 4;   // bytes of a row of O = [O_loc | U] and of Gc = [G15 | G16], of f and of Vout
+    const __amdgpu_buffer_rsrc_t rO = ff_rsrc(O, (size_t)rows * 2 * CB * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rGc = ff_rsrc(Gc, (size_t)gc_rows * 2 * CB * sizeof(float));
     const __amdgpu_buffer_rsrc_t rAdj = ff_rsrc(adj, (size_t)rows * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rV = ff_rsrc(Vout, (size_t)pairs * 64 * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rF = ff_rsrc(F, (size_t)rows * 64 * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rV = ff_rsrc(Vout, (size_t)pairs * CB * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rF = ff_rsrc(F, (size_t)rows * CB * sizeof(float));
     const int gs = (int)((li + 0.5f) * __builtin_amdgcn_rcpf((float)s));
     const int y_li = li - gs * s;
     // operands that do not depend on the gather indices first
@@ -87,11 +91,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int vo = rr < nrows ? (P.x + rr) * 512 + li * 4 : kFfOor;
+        const int vo = rr < nrows ? (P.x + rr) * OB + li * 4 : kFfOor;
         m0[r] = ff_ld1(rO, vo);
-        m1[r] = ff_ld1(rO, vo + 128);
-        u0[r] = ff_ld1(rO, vo + 256);
-        u1[r] = ff_ld1(rO, vo + 384);
+        u0[r] = ff_ld1(rO, vo + FB);
+        if constexpr (TWO) {
+            m1[r] = ff_ld1(rO, vo + 128);
+            u1[r] = ff_ld1(rO, vo + FB + 128);
+        } else {
+            m1[r] = u1[r] = 0.f;
+        }
     }
     float aval[16], vb0[5], vb1[5];
 #pragma unroll
@@ -102,15 +110,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         aval[r] = ff_ld1(rAdj, in ? (P.z + y_li * s + e) * 4 : kFfOor);
     }
     {
-        const float *p0 = lh ? bias : Sout + (size_t)node * 64;
+        const float *p0 = lh ? bias : Sout + (size_t)node * CB;
         vb0[0] = p0[li];
-        vb1[0] = p0[32 + li];
+        vb1[0] = TWO ? p0[(TWO ? 32 : 0) + li] : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int g = 2 * t + lh;
-            const int vo = g < G ? (int)(((long long)P.w + x0 + g) * 256) + li * 4 : kFfOor;
+            const int vo = g < G ? (int)(((long long)P.w + x0 + g) * FB) + li * 4 : kFfOor;
             vb0[t + 1] = ff_ld1(rV, vo);
-            vb1[t + 1] = ff_ld1(rV, vo + 128);
+            vb1[t + 1] = TWO ? ff_ld1(rV, vo + 128) : 0.f;
         }
     }
     const float axy = rowok ? adj[row] : 0.f;
@@ -123,11 +131,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         const int a15 = __builtin_amdgcn_readlane(go.x, rr), b15 = __builtin_amdgcn_readlane(go.x, rr + 4);
         const int a16 = __builtin_amdgcn_readlane(go.y, rr), b16 = __builtin_amdgcn_readlane(go.y, rr + 4);
         const int i15 = lh ? b15 : a15, i16 = lh ? b16 : a16;
-        const int v15 = i15 < 0 ? kFfOor : i15 * 512 + li * 4, v16 = i16 < 0 ? kFfOor : i16 * 512 + 256 + li * 4;
+        const int v15 = i15 < 0 ? kFfOor : i15 * OB + li * 4, v16 = i16 < 0 ? kFfOor : i16 * OB + FB + li * 4;
         g0[r] = ff_ld1(rGc, v15);
         g1[r] = ff_ld1(rGc, v16);
-        g2[r] = ff_ld1(rGc, v15 + 128);
-        g3[r] = ff_ld1(rGc, v16 + 128);
+        g2[r] = TWO ? ff_ld1(rGc, v15 + 128) : 0.f;
+        g3[r] = TWO ? ff_ld1(rGc, v16 + 128) : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -138,18 +146,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     for (int r = 0; r < 16; ++r) {
         const float a = aval[r] > 0.f ? aval[r] : 0.f;  // the gate of RisiContraction_18 (RisiContraction_18.h:90)
         m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u0[r], m0, 0, 0, 0);
-        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u1[r], m1, 0, 0, 0);
+        if constexpr (TWO) m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u1[r], m1, 0, 0, 0);
     }
     {
         const float a0 = lh ? 1.f : (axy > 0.f ? axy : 0.f);
         m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, vb0[0], m0, 0, 0, 0);
-        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, vb1[0], m1, 0, 0, 0);
+        if constexpr (TWO) m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, vb1[0], m1, 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (2 * t < G) {  // (uniform; nothing is requested in here)
                 const float a = (2 * t + lh) == gs ? r_y : 0.f;
                 m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vb0[t + 1], m0, 0, 0, 0);
-                m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vb1[t + 1], m1, 0, 0, 0);
+                if constexpr (TWO) m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vb1[t + 1], m1, 0, 0, 0);
             }
         }
     }
@@ -157,11 +165,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int vo = rr < nrows ? (P.x + rr) * 256 + li * 4 : kFfOor;
+        const int vo = rr < nrows ? (P.x + rr) * FB + li * 4 : kFfOor;
         const float z0 = m0[r], z1 = m1[r];
         const float f0 = z0 > 0.f ? z0 : kAlphaFf * z0, f1 = z1 > 0.f ? z1 : kAlphaFf * z1;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f0), rF, vo, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f1), rF, vo + 128, 0, 0);
+        if constexpr (TWO) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f1), rF, vo + 128, 0, 0);
         if (rr < nrows) {   // (rows in register order: a fixed order)
             c0 += f0, c1 += f1;
             x0m = fmaxf(x0m, fabsf(f0)), x1m = fmaxf(x1m, fabsf(f1));
@@ -170,12 +178,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     if (psum) {  // (uniform)
         c0 += __shfl_xor(c0, 32);
         c1 += __shfl_xor(c1, 32);
-        psum[(size_t)p * 64 + lane] = lh ? c1 : c0;   // lane = 32 lh + li: columns li | 32 + li
+        if (TWO || lh == 0) psum[(size_t)p * CB + lane] = lh ? c1 : c0;   // lane = 32 lh + li: columns li | 32 + li
     }
     if (pmax) {  // (uniform)
         x0m = fmaxf(x0m, __shfl_xor(x0m, 32));
         x1m = fmaxf(x1m, __shfl_xor(x1m, 32));
-        pmax[(size_t)p * 64 + lane] = lh ? x1m : x0m;
+        if (TWO || lh == 0) pmax[(size_t)p * CB + lane] = lh ? x1m : x0m;
     }
 }
 
@@ -228,9 +236,14 @@ gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const flo
     const gfsmp::LevelLayout &h = s->lay.level[l];
     const int npanels = d.fwd_npanels;
     if (npanels < 1) return GF_OK;
-    GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
-              d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
-              (long long)h.pairs, d.Sout, bias, psum, pmax);
+    if (s->cfg.nChanels == 64)
+        GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels<64>, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
+                  d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
+                  (long long)h.pairs, d.Sout, bias, psum, pmax);
+    else
+        GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels<32>, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
+                  d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
+                  (long long)h.pairs, d.Sout, bias, psum, pmax);
     return GF_OK;
 }
 
