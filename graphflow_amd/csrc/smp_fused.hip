@@ -47,6 +47,15 @@ __device__ __forceinline__ f4 fold_two_tables(f4 u, f4 v) {
     return z;
 }
 
+// x of lane ^ 8 (a rotation by eight inside each 16-lane row: one DPP move per dword)
+__device__ __forceinline__ f4 dpp_xor8(f4 v) {
+    f4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), 0x128 /* row_ror:8 */, 0xf, 0xf, true));
+    return r;
+}
+
 constexpr float kAlphaF = 0.01f;
 __device__ __forceinline__ float lreluf(float z) { return z > 0.f ? z : kAlphaF * z; }
 
@@ -88,7 +97,9 @@ __constant__ int c_kperm[18] = {0, 2, 6, 5, 9, 8, 12, 11, 15, 16, 1, 3, 7, 10, 4
 // tables-forward 0.90 -> 1.04 ms, smp_vectors (0.38 ms a cfg3 step, 1 GB of traffic) gone.  Measured and not kept: one read-modify-write
 // per row with c-group 2 taking the diagonal element over lane ^ 32 (1.19 ms: the exchange sits on the row's critical path); the
 // row sums only, D8 gathered from the compact diagonal table in the epilogue as smp_vectors did (1.10 ms).
-template <int NI, bool ALLOK, bool VEC = false>  // ALLOK: C is a multiple of 64 -- every lane of every window has channels
+// LPC (round 4): lanes per position -- 16 (64-channel windows) or 8 (32-channel windows: at C = 32 every lane has channels and a wave
+// load covers eight positions; the sixteen-lane mapping left half of the lanes idle there).
+template <int NI, bool ALLOK, bool VEC = false, int LPC = 16>  // ALLOK: C is a multiple of the window (4 LPC channels) -- every lane has channels
 __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4 ? GF_TF_OCC : 2) void smp_tables_fwd_w(  // (NI = 4 sat at 130 VGPRs: capped to 128 -> 4 waves per SIMD)
     const float *__restrict__ fprev, const float *__restrict__ rsum,
                                                              float *__restrict__ T, float *__restrict__ Vt,
@@ -101,7 +112,8 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
                                                              // row (b, c) has data in S_bc / T10 (the others are not stored either)
                                                              float *__restrict__ St) {  // VEC: [nodes][4C] per-node scalars
     static_assert(!VEC || ALLOK, "the folded vector sums need every lane to have channels");
-    constexpr int LPC = 16, PPW = 4;
+    constexpr int PPW = 64 / LPC, CWIN = 4 * LPC;   // positions per wave load, channels per window
+    static_assert(LPC == 16 || (LPC == 8 && ALLOK), "eight lanes per position: whole 32-channel windows only");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = lane / LPC, fl = lane % LPC;
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
     const int4 r0 = recs[2 * (tile / nwin)], r1 = recs[2 * (tile / nwin) + 1];
     const int N = r0.y;
     const size_t rowbase = ((size_t)(unsigned)r1.y << 32) | (unsigned)r1.x, pairbase = ((size_t)(unsigned)r1.w << 32) | (unsigned)r1.z;
-    const int f = win * 64 + 4 * fl;
+    const int f = win * CWIN + 4 * fl;
     const bool fok = f < C;
     const int fld = fok ? f : 0;
     constexpr bool allok = ALLOK;
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
     // where pi_a(c) < 0 and in the padding c >= N), rows padded to the class's 4 NI positions so that a lane's NI reads are
     // unconditional and a constant 16 bytes apart.  (Round 3: the maps were shorts read one at a time behind a lane mask, each waited
     // for, multiplied and selected before its request went out: ~45 VALU and five LDS round trips per row in front of the loads.)
-    constexpr int ST = 4 * NI;
+    constexpr int ST = PPW * NI;
     constexpr int kAbsent = 0x40000000;
     float *sR = smem;                                               // [N]
     int4 *sRow = reinterpret_cast<int4 *>(smem + ((N + 3) & ~3));   // [N] {address lo, hi, bytes, s_w} of f_{l-1}[src(n, a)]
@@ -155,9 +167,9 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
     // VEC: per wave, [N][rowsum | D8][64 floats] accumulators and a 64-float slot the lanes outside c-group 0 read and write instead
     f4 *sAcc = reinterpret_cast<f4 *>(smem + ((((N + 3) & ~3) + 4 * N + N * ST + ((N * N + 3) >> 2) + 3) & ~3));
     const int nwv = nthreads / 64;
-    f4 *wacc = sAcc + (size_t)wave * N * 32, *wdummy = sAcc + (size_t)nwv * N * 32 + wave * 32;
+    f4 *wacc = sAcc + (size_t)wave * N * (2 * LPC), *wdummy = sAcc + (size_t)nwv * N * (2 * LPC) + wave * (2 * LPC);
     if constexpr (VEC)
-        for (int i = lane; i < N * 32; i += 64) wacc[i] = splat(0.f);
+        for (int i = lane; i < N * (2 * LPC); i += 64) wacc[i] = splat(0.f);
     __syncthreads();
 
     float rc[NI];
@@ -200,7 +212,8 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
 
     // two row buffers used alternately (the loop is unrolled by two: no register copies between rows)
     f4 bufA[NI], bufB[NI], dA, dB;
-    float *const tcol = T + (rowbase + b) * (size_t)(T_COLS * C) + f + ((cg & 1) ? T_T6 : T_SAB) * C;  // (+ a N ldt per row)
+    // (after fold_two_tables the EVEN 16-lane rows of the wave hold the S_ab total, the odd rows the T6 total)
+    float *const tcol = T + (rowbase + b) * (size_t)(T_COLS * C) + f + (((lane >> 4) & 1) ? T_T6 : T_SAB) * C;  // (+ a N ldt per row)
     const size_t tstep = (size_t)N * (T_COLS * C);
     // Rows (a, b) whose source does not contain vertex b (pi_a(b) < 0) are structurally zero -- about 40 % of them at QM9
     // sizes: they are never loaded or summed, only their two table entries are written as zeros.  `present` is wave-uniform
@@ -227,7 +240,11 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
             sab += v;
             t6 += rc[i] * v;
         }
-        const f4 both = fold_two_tables(sab, t6);  // even c-groups: S_ab[a,b], odd c-groups: T6[a,b]
+        if constexpr (LPC == 8) {   // the two c-groups of a 16-lane row first (lane ^ 8: a rotation by eight inside the row, on the VALU)
+            sab += dpp_xor8(sab);
+            t6 += dpp_xor8(t6);
+        }
+        const f4 both = fold_two_tables(sab, t6);  // even 16-lane rows: S_ab[a,b], odd rows: T6[a,b]
         dgsum += dcur;
         if (allok) {
             // every lane stores (c-groups 0/2 the S_ab block, 1/3 the T6 block; the pairs write identical values to the same
@@ -235,14 +252,14 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
             // (vmcnt is in order over loads and stores) need not include it; lane-conditional stores cannot (-5 %)
             st4(tcol + a * tstep, both);  // table row (a, b)
             if constexpr (VEC) {   // c-group 0 holds S_ab[a, b] and P[a, b, b]: into the wave's accumulators of row a
-                f4 *slot = (cg == 0) ? wacc + a * 32 + fl : wdummy + fl;
-                const f4 r = slot[0] + both, d8 = slot[16] + dcur;
+                f4 *slot = (cg == 0) ? wacc + a * (2 * LPC) + fl : wdummy + fl;
+                const f4 r = slot[0] + both, d8 = slot[LPC] + dcur;
                 slot[0] = r;
-                slot[16] = d8;
+                slot[LPC] = d8;
             }
             if constexpr (decltype(own_row)::value) {  // a == b: the peeled first row
                 if (cg == 0) st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dcur);
-                if (cg == 2) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, both);
+                if (cg == 2 * (16 / LPC)) st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, both);   // (a c-group of an even row other than 0)
             }
         } else if (fok) {
             float *trow = T + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + f;  // table row (a, b)
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
     }
     cs = reduce_cgroups<LPC>(cs);
     // diagonal sums: lanes of c-group 0 hold sum_a P[a,b,b], c-group 1 holds sum_a P[a,b,a]
-    const f4 dactot = shfl_xor4(dgsum, 16);  // c-group 0 lanes receive c-group 1's sum
+    const f4 dactot = shfl_xor4(dgsum, LPC);  // c-group 0 lanes receive c-group 1's sum
     if (cg == 0 && fok) {
         float *v = Vt + (pairbase + b) * 4 * (size_t)C + f;
         st4(v + 1 * C, cs);
@@ -345,17 +362,17 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
     if constexpr (VEC) {
         __syncthreads();   // (every wave's accumulators and partial scalars are complete and visible to the workgroup)
         const int node = r0.x;
-        for (int i = tid; i < N * 32; i += nthreads) {   // (row a, rowsum | D8, float4 q): the waves' partials in wave order
-            const int a = i >> 5, rem = i & 31;
-            f4 v = sAcc[(size_t)a * 32 + rem];
-            for (int w = 1; w < nwv; ++w) v += sAcc[((size_t)w * N + a) * 32 + rem];
-            st4(Vt + (pairbase + a) * 4 * (size_t)C + (rem >> 4) * 2 * C + win * 64 + 4 * (rem & 15), v);
+        for (int i = tid; i < N * (2 * LPC); i += nthreads) {   // (row a, rowsum | D8, float4 q): the waves' partials in wave order
+            const int a = i / (2 * LPC), rem = i % (2 * LPC);
+            f4 v = sAcc[(size_t)a * (2 * LPC) + rem];
+            for (int w = 1; w < nwv; ++w) v += sAcc[((size_t)w * N + a) * (2 * LPC) + rem];
+            st4(Vt + (pairbase + a) * 4 * (size_t)C + (rem / LPC) * 2 * C + win * CWIN + 4 * (rem % LPC), v);
         }
-        if (tid < 64) {   // per-node scalars: the sum over b of the partials, in the order of b (as smp_vectors formed it)
-            const int k = tid >> 4, q = tid & 15;
+        if (tid < 4 * LPC) {   // per-node scalars: the sum over b of the partials, in the order of b (as smp_vectors formed it)
+            const int k = tid / LPC, q = tid % LPC;
             const auto one = [](int) { return 1.f; };
-            st4(St + (size_t)node * 4 * C + k * C + win * 64 + 4 * q,
-                batched_sum(scal + pairbase * 4 * (size_t)C + k * C + win * 64 + 4 * q, (size_t)4 * C, 0, N, one));
+            st4(St + (size_t)node * 4 * C + k * C + win * CWIN + 4 * q,
+                batched_sum(scal + pairbase * 4 * (size_t)C + k * C + win * CWIN + 4 * q, (size_t)4 * C, 0, N, one));
         }
     }
 }
@@ -467,20 +484,22 @@ __global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict_
 // zeros into the S_ab / T6 blocks of the rows (a, b), and the S_bc / T10 blocks of the rows (b, c), that tables-forward never
 // writes: once per prepared batch (DevLevel::t_zeros; rowflag bits 0 / 1 = the row has data in the first / second pair of blocks)
 constexpr int kZeroFillRows = 64;   // rows per workgroup: eight per pass (a thread was launched per (row, float4): 62 M threads at cfg3's level 3)
+template <int CB>   // channels: 64 or 32
 __global__ __launch_bounds__(256) void tables_zero_fill(float *__restrict__ T, const unsigned char *__restrict__ rowflag, long long rows) {
-    const int q = threadIdx.x & 31;  // 32 float4 = two 64-column blocks
-    const long long row0 = (long long)blockIdx.x * kZeroFillRows + (threadIdx.x >> 5);
-    int fl[kZeroFillRows / 8];
+    constexpr int NQ = CB / 4, RPP = 256 / (2 * NQ), NP = kZeroFillRows / RPP;   // float4 per block, rows per pass, passes
+    const int q = threadIdx.x % (2 * NQ);  // 2 NQ float4 = two CB-column blocks
+    const long long row0 = (long long)blockIdx.x * kZeroFillRows + threadIdx.x / (2 * NQ);
+    int fl[NP];
 #pragma unroll
-    for (int p = 0; p < kZeroFillRows / 8; ++p) {   // (all flags first: one round trip)
-        const long long row = row0 + 8 * p;
+    for (int p = 0; p < NP; ++p) {   // (all flags first: one round trip)
+        const long long row = row0 + RPP * p;
         fl[p] = row < rows ? rowflag[row] : 3;
     }
 #pragma unroll
-    for (int p = 0; p < kZeroFillRows / 8; ++p) {
-        const long long row = row0 + 8 * p;
-        if (!(fl[p] & 1)) st4(T + row * (T_COLS * 64) + (q < 16 ? T_SAB * 64 + 4 * q : T_T6 * 64 + 4 * (q - 16)), splat(0.f));
-        if (!(fl[p] & 2)) st4(T + row * (T_COLS * 64) + (q < 16 ? T_SBC * 64 + 4 * q : T_T10 * 64 + 4 * (q - 16)), splat(0.f));
+    for (int p = 0; p < NP; ++p) {
+        const long long row = row0 + RPP * p;
+        if (!(fl[p] & 1)) st4(T + row * (T_COLS * CB) + (q < NQ ? T_SAB * CB + 4 * q : T_T6 * CB + 4 * (q - NQ)), splat(0.f));
+        if (!(fl[p] & 2)) st4(T + row * (T_COLS * CB) + (q < NQ ? T_SBC * CB + 4 * q : T_T10 * CB + 4 * (q - NQ)), splat(0.f));
     }
 }
 
@@ -935,8 +954,36 @@ Ragged ragged_for(const gf_smp::DevLevel &d, long long lo, int smax) {
     return R;
 }
 
+// channel counts that are whole 32-channel windows but not whole 64-channel ones (C = 32, 96): the workgroup-per-(node, x) kernels run
+// with eight lanes per row instead of sixteen half-idle ones
+static bool smp_half_window(int C) { return C % 32 == 0 && C % 64 != 0; }
+
 // tables-forward keeps smp_vectors' sums itself (C % 64 == 0; GF_SMP_TF_VEC=0: the separate pass)
-static bool smp_tables_fold_vectors(const gf_smp *s) { return (s->cfg.nChanels & 63) == 0 && !env_is("GF_SMP_TF_VEC", '0'); }
+static bool smp_tables_fold_vectors(const gf_smp *s) {
+    return ((s->cfg.nChanels & 63) == 0 || smp_half_window(s->cfg.nChanels)) && !env_is("GF_SMP_TF_VEC", '0');
+}
+
+// the eight-lanes-per-position classes (C % 32 == 0, C % 64 != 0): a wave load covers eight positions, NI = 1, 2, 4 for s <= 8, 16, 32
+template <int NI>
+gf_status launch_tables_fwd_w8(gf_smp *s, int l, const SizeClass &c) {
+    gf_ctx *ctx = s->ctx;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const gfsmp::LevelLayout &h = s->lay.level[l];
+    const int C = s->cfg.nChanels, nwin = C / 32;
+    const int n_lo = h.pair_node[(size_t)c.lo], n_hi = (c.hi < (long long)h.pairs) ? h.pair_node[(size_t)c.hi] : h.nNodes;
+    if (n_hi <= n_lo) return GF_OK;
+    const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + 16 * (size_t)c.smax + sizeof(int) * (size_t)c.smax * 8 * NI + 16 +
+                       (size_t)c.smax * c.smax + 16;
+    const int nwv = kThreads / 64;
+    const size_t lds_v = ((lds + 15) & ~(size_t)15) + 16 + (size_t)nwv * ((size_t)c.smax * 256 + 256);
+    gf_status st = opt_in_lds(ctx, smp_tables_fwd_w<NI, true, true, 8>, lds_v);
+    if (st != GF_OK) return st;
+    const int flags = d.t_zeros ? 1 : 0;
+    GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true, true, 8>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3(kThreads), lds_v,
+              s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
+              flags, flags ? d.rowflag : (const unsigned char *)nullptr, d.St);
+    return GF_OK;
+}
 
 template <int NI>
 gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
@@ -1284,8 +1331,12 @@ gf_status smp_fused_ensure_zero_fill(gf_smp *s, int l) {
     gf_smp::DevLevel &d = s->lv[l];
     if (!d.t_zeros || d.t_filled || !d.rowflag) return GF_OK;
     const long long rows = s->lay.level[l].rows;
-    GF_LAUNCH(s->ctx, "smpf_tables_fill", tables_zero_fill, dim3((unsigned)((rows + kZeroFillRows - 1) / kZeroFillRows)), dim3(256), 0, d.Q,
-              d.rowflag, rows);
+    if (s->cfg.nChanels == 64)
+        GF_LAUNCH(s->ctx, "smpf_tables_fill", tables_zero_fill<64>, dim3((unsigned)((rows + kZeroFillRows - 1) / kZeroFillRows)), dim3(256), 0, d.Q,
+                  d.rowflag, rows);
+    else
+        GF_LAUNCH(s->ctx, "smpf_tables_fill", tables_zero_fill<32>, dim3((unsigned)((rows + kZeroFillRows - 1) / kZeroFillRows)), dim3(256), 0, d.Q,
+                  d.rowflag, rows);
     d.t_filled = true;
     return GF_OK;
 }
@@ -1314,7 +1365,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     // Round 4: and they are not even written that once while every reader of T skips them -- the split product kernels and the packed
     // weight-gradient kernel read an absent block from a page of zeros, the sums over b never visit one -- which is the default path; a
     // reader that does not mask (fp32 pipe, tiled GEMMs) gets the fill before it runs (here, or ensure_zero_fill in the reverse sweep).
-    if (C == 64 && d.rowflag && !env_is("GF_SMP_MASK_ZEROS", '0')) {
+    if ((C == 64 || (C == 32 && smp_tables_fold_vectors(s))) && d.rowflag && !env_is("GF_SMP_MASK_ZEROS", '0')) {
         s->lv[l].t_zeros = true;
         const bool readers_mask = smp_c64_kernels(s) && smp_split_products(ctx) && d.trowf && d.trow && (long long)rows < (1ll << 29);
         if (!readers_mask) {
@@ -1324,13 +1375,22 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     } else {
         s->lv[l].t_zeros = false;
     }
-    const std::vector<SizeClass> cls = classes_of(h, 4);
+    const bool lanes8 = smp_half_window(C) && smp_tables_fold_vectors(s);   // eight lanes per position (C = 32): classes of 8 NI positions
+    const std::vector<SizeClass> cls = classes_of(h, lanes8 ? 8 : 4);
     for (const SizeClass &c : cls) {
-        switch (c.ni) {
-            case 1: st = launch_tables_fwd_w<1>(s, l, c); break;
-            case 2: st = launch_tables_fwd_w<2>(s, l, c); break;
-            case 4: st = launch_tables_fwd_w<4>(s, l, c); break;
-            default: st = launch_tables_fwd_w<8>(s, l, c); break;
+        if (lanes8) {
+            switch (c.ni) {
+                case 1: st = launch_tables_fwd_w8<1>(s, l, c); break;
+                case 2: st = launch_tables_fwd_w8<2>(s, l, c); break;
+                default: st = launch_tables_fwd_w8<4>(s, l, c); break;
+            }
+        } else {
+            switch (c.ni) {
+                case 1: st = launch_tables_fwd_w<1>(s, l, c); break;
+                case 2: st = launch_tables_fwd_w<2>(s, l, c); break;
+                case 4: st = launch_tables_fwd_w<4>(s, l, c); break;
+                default: st = launch_tables_fwd_w<8>(s, l, c); break;
+            }
         }
         if (st != GF_OK) return st;
     }
@@ -1470,13 +1530,15 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     const bool stationary = smp_c64_kernels(s);
     if (stationary && C == 32) {   // smp_wgrad_direct<32>: one partial image of the eight products per workgroup
         const long long slices = ((long long)rows + 15) / 16;
-        int splits = (int)(slices / 8 < 1 ? 1 : slices / 8 > 256 ? 256 : slices / 8);
+        int splits = (int)(slices / 8 < 1 ? 1 : slices / 8 > 512 ? 512 : slices / 8);   // (116 registers: two workgroups per CU)
         if ((size_t)splits * 8 * CC > ws_floats) return fail(ctx, GF_ERR_NOMEM, "fused level: workspace too small for %d weight-gradient images", splits);
         unsigned *words = s->wbound + (size_t)l * smp_wgrad_direct_words_c32();
         const unsigned *chan = nullptr;
         if (d.dzmax && d.row_max) {   // per-channel maxima of f_{l-1} and of this level's dz (combine-backward's per-workgroup maxima)
             GF_HIP_TRY(ctx, hipMemsetAsync(words, 0, sizeof(unsigned) * 64, ctx->stream));
-            st = smp_wgrad_channel_maxima_ld(ctx, pv.f, (long long)s->lay.level[l - 1].rows, C, d.dzmax, (long long)h.quad_node.size(), 64, C, words);
+            // (combine-backward's maxima: one row of a window's width per workgroup -- 32-channel windows at C = 32)
+            st = smp_wgrad_channel_maxima_ld(ctx, pv.f, (long long)s->lay.level[l - 1].rows, C, d.dzmax, (long long)h.quad_node.size(),
+                                             smp_half_window(C) ? 32 : 64, C, words);
             if (st != GF_OK) return st;
             chan = words;
         }
@@ -1623,13 +1685,23 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
     float *dO = d.Q + (size_t)h.rows * T_COLS * C;
     gf_status st;
-    {
-        const size_t lds = combine_lds<16>(h.buckets.back().s);
+    float *dzmax = (s->wbound && d.dzmax && smp_compact_o(s)) ? d.dzmax : (float *)nullptr;
+    if (smp_half_window(C)) {   // eight lanes per row (32-channel windows): at C = 32 every lane has channels
+        const int nw8 = C / 32, N = h.buckets.back().s;
+        // (the column maxima go through kThreads / 8 x 32 floats of the dz image: room for them whatever the field size)
+        const size_t lds = std::max(combine_lds<8>(N), sizeof(float) * ((size_t)adj_lds_floats(N) + 1024));
+        st = opt_in_lds(ctx, smp_combine_bwd<8>, lds);
+        if (st != GF_OK) return st;
+        GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<8>), dim3((unsigned)(h.quad_node.size() * nw8)), dim3(kThreads), lds, d.f,
+                  d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
+                  nw8, d.rsum, smp_compact_o(s) ? 2 : O_COLS, dzmax);
+    } else {
+        const size_t lds = std::max(combine_lds<16>(h.buckets.back().s), sizeof(float) * ((size_t)adj_lds_floats(h.buckets.back().s) + 1024));
         st = opt_in_lds(ctx, smp_combine_bwd<16>, lds);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
                   d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
-                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS, (s->wbound && d.dzmax && smp_compact_o(s)) ? d.dzmax : (float *)nullptr);
+                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS, dzmax);
     }
     (void)Kl;
     return smp_fused_backward_level_grouped(s, l, dKl, dbl);
