@@ -1412,11 +1412,11 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             {d.Fdc, d.Wst + 8 * CC, d.Gc, prevPairs, C, C, 2 * C, C, 2 * C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
             {d.Fdc + C, d.Wst + 9 * CC, d.Gc + C, prevPairs, C, C, 2 * C, C, 2 * C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
         };
-        if (C == 64 && d.wimg_ready) {   // wave per 32-row panel on the f16 pipe (smp_small_split)
+        if ((C == 64 || C == 32) && d.wimg_ready) {   // wave per 32-row panel on the f16 pipe (smp_small_split)
             const int prog[3] = {0, 2, 0}, nrows[3] = {pairs, prevPairs, nodes}, pos0[3] = {10, 8, 14};
             const float *in[3] = {d.Vt, d.Fdc, d.St};
             float *out[3] = {d.Vout, d.Gc, d.Sout};
-            st = smp_small_split_c64(ctx, false, 3, prog, in, out, nrows, pos0, d.wimg, "smpf_small_nn");
+            st = smp_small_split_c64(ctx, false, 3, prog, in, out, nrows, pos0, d.wimg, "smpf_small_nn", C);
         } else {
             st = gemm_grouped_free(ctx, false, sm, 4, "smpf_small_nn");
         }
@@ -1513,11 +1513,11 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
                                 spec(d.dGc + C, d.Wst + 9 * CC, d.dFdc + C, prevPairs, C, C, 2 * C, C, 2 * C),
                                 spec(d.dVout, d.Wst + 10 * CC, d.dVt, pairs, 4 * C, C, C, C, 4 * C),
                                 spec(d.dSout, d.Wst + 14 * CC, d.dSt, nodes, 4 * C, C, C, C, 4 * C)};
-        if (C == 64 && d.wimg_ready) {
+        if ((C == 64 || C == 32) && d.wimg_ready) {
             const int prog[3] = {1, 2, 1}, nrows[3] = {pairs, prevPairs, nodes}, pos0[3] = {10, 8, 14};
             const float *in[3] = {d.dVout, d.dGc, d.dSout};
             float *out[3] = {d.dVt, d.dFdc, d.dSt};
-            st = smp_small_split_c64(ctx, true, 3, prog, in, out, nrows, pos0, d.wimg, "smpf_small_nt");
+            st = smp_small_split_c64(ctx, true, 3, prog, in, out, nrows, pos0, d.wimg, "smpf_small_nt", C);
         } else
         st = gemm_grouped_free(ctx, true, nt, 4, "smpf_small_nt");
         if (st != GF_OK) return st;

@@ -58,7 +58,7 @@ gf_status smp_wgrad_channel_maxima_ld(gf_ctx *ctx, const float *fprev, long long
                                       unsigned *words);
 size_t smp_wgrad_direct_words_c32();
 gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *prog, const float *const *In, float *const *Out, const int *rows,
-                              const int *pos0, const void *wimg, const char *name);
+                              const int *pos0, const void *wimg, const char *name, int C = 64);
 // where the split-operand weight gradients take their per-column exponents from (smp_level_c64_split.hip: smp_wgrad_split): either
 // `cmax`, explicit per-column bounds of the nine operand blocks (576 float bits, device), or `chan`, the level's per-channel maxima
 // (128 float bits: max |f_{l-1}| then max |dz_l|) with the largest receptive field and row factors of the level

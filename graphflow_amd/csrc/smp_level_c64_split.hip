@@ -440,34 +440,36 @@ struct SmallJobs {
     int rows[3], pos0[3], prog[3], wg0[3], nwg[3];
     int n;
 };
-template <int PROG>
+template <int PROG, int CB = 64>
 __device__ __forceinline__ void small_split_body(const float *__restrict__ In, float *__restrict__ Out, int rows,
                                                  const uint4 *__restrict__ wimg, int pos0, int wg, int nwg) {
     constexpr int NPOS = PROG == 2 ? 2 : 4;
-    constexpr int LDA = PROG == 0 ? 256 : PROG == 1 ? 64 : 128, LDOUT = PROG == 0 ? 64 : PROG == 1 ? 256 : 128;
+    constexpr int LDA = PROG == 0 ? 4 * CB : PROG == 1 ? CB : 2 * CB, LDOUT = PROG == 0 ? CB : PROG == 1 ? 4 * CB : 2 * CB;
+    constexpr int VPL = CB / 2, NC = CB / 16, NH = CB / 32, E = NH * NC * 64;   // (see smp_rowpanel_split)
     constexpr int NIN = PROG == 1 ? 1 : NPOS;
     extern __shared__ __attribute__((aligned(16))) uint4 sm_smem[];
-    uint4 *imgH = sm_smem, *imgL = sm_smem + NPOS * 512;
-    float *winv = reinterpret_cast<float *>(sm_smem + 2 * NPOS * 512);  // [NPOS] (room for 16)
+    uint4 *imgH = sm_smem, *imgL = sm_smem + NPOS * E;
+    float *winv = reinterpret_cast<float *>(sm_smem + 2 * NPOS * E);  // [NPOS] (room for 16)
     float *facs = winv + 16;                                             // [waves][32]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
-    for (int t = tid; t < NPOS * 512; t += kSmThreads) {
-        imgH[t] = wimg[pos0 * 512 + t];
-        imgL[t] = wimg[kSpAll + pos0 * 512 + t];
+    for (int t = tid; t < NPOS * E; t += kSmThreads) {   // (512 entries apart per position in the prebuilt set)
+        const int g = (pos0 + t / E) * 512 + t % E;
+        imgH[t] = wimg[g];
+        imgL[t] = wimg[kSpAll + g];
     }
     if (tid < NPOS) winv[tid] = reinterpret_cast<const float *>(wimg + 2 * kSpAll)[pos0 + tid];
     __syncthreads();
     float *myfac = facs + wave * 32;
     struct Raw {
-        f4v a[8];
+        f4v a[VPL / 4];
     };
     struct Spl {
-        uint4 h[4], l[4];
+        uint4 h[NC], l[NC];
     };
     auto split_blk = [&](const Raw &R, Spl &S, float &inv) {
         unsigned m = 0u;
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < VPL / 4; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned b = __float_as_uint(R.a[q][j]) & 0x7fffffffu;
@@ -478,7 +480,7 @@ __device__ __forceinline__ void small_split_body(const float *__restrict__ In, f
         float sc;
         pow2_scale(m, &sc, &inv);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
             unsigned hw[4], lw[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -496,16 +498,16 @@ __device__ __forceinline__ void small_split_body(const float *__restrict__ In, f
         __builtin_amdgcn_wave_barrier();
         myfac[li] = rowfac * winv[wpos];
         __builtin_amdgcn_wave_barrier();
-        const uint4 *bh = imgH + (size_t)(wpos * 8) * 64 + lane, *bl = imgL + (size_t)(wpos * 8) * 64 + lane;
+        const uint4 *bh = imgH + (size_t)wpos * E + lane, *bl = imgL + (size_t)wpos * E + lane;
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
+        for (int nh = 0; nh < NH; ++nh) {
             f16v t;
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[r] = 0.f;
             // the cross products (low halves at 2^11, see split_pair) ...
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const h8 bhc = __builtin_bit_cast(h8, bh[(4 * nh + c) * 64]), blc = __builtin_bit_cast(h8, bl[(4 * nh + c) * 64]);
+            for (int c = 0; c < NC; ++c) {
+                const h8 bhc = __builtin_bit_cast(h8, bh[(NC * nh + c) * 64]), blc = __builtin_bit_cast(h8, bl[(NC * nh + c) * 64]);
                 const h8 ah = __builtin_bit_cast(h8, S.h[c]), al = __builtin_bit_cast(h8, S.l[c]);
                 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhc, t, 0, 0, 0);
                 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blc, t, 0, 0, 0);
@@ -515,8 +517,8 @@ __device__ __forceinline__ void small_split_body(const float *__restrict__ In, f
             // ... and the main product on top, one dependent chain (its B fragments are read again: four more ds_read_b128, no
             // registers held; as two independent chains the compiler interleaved them and spilled hundreds of registers)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const h8 bhc = __builtin_bit_cast(h8, bh[(4 * nh + c) * 64]);
+            for (int c = 0; c < NC; ++c) {
+                const h8 bhc = __builtin_bit_cast(h8, bh[(NC * nh + c) * 64]);
                 const h8 ah = __builtin_bit_cast(h8, S.h[c]);
                 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhc, t, 0, 0, 0);
             }
@@ -537,19 +539,19 @@ __device__ __forceinline__ void small_split_body(const float *__restrict__ In, f
         Raw R[NIN];
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
-            const float *src = In + (size_t)row * LDA + k * 64 + 32 * lh;
+            const float *src = In + (size_t)row * LDA + k * CB + VPL * lh;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) R[k].a[q] = *reinterpret_cast<const f4v *>(src + 4 * q);
+            for (int q = 0; q < VPL / 4; ++q) R[k].a[q] = *reinterpret_cast<const f4v *>(src + 4 * q);
         }
         (void)NIN;
         auto store_out = [&](int o, const f16v &acc0, const f16v &acc1) {
-            float *out = Out + (size_t)(r0 + 4 * lh) * LDOUT + o * 64 + li;
+            float *out = Out + (size_t)(r0 + 4 * lh) * LDOUT + o * CB + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
                 if (r0 + 4 * lh + rr < rows) {
                     out[(size_t)rr * LDOUT] = acc0[r];
-                    out[(size_t)rr * LDOUT + 32] = acc1[r];
+                    if constexpr (NH == 2) out[(size_t)rr * LDOUT + 32] = acc1[r];
                 }
             }
         };
@@ -587,15 +589,16 @@ __device__ __forceinline__ void small_split_body(const float *__restrict__ In, f
     }
 }
 
+template <int CB>
 __global__ __launch_bounds__(kSmThreads, 2) void smp_small_split(SmallJobs jobs, const uint4 *__restrict__ wimg) {
     int j = 0;
     if (jobs.n > 1 && (int)blockIdx.x >= jobs.wg0[1]) j = 1;
     if (jobs.n > 2 && (int)blockIdx.x >= jobs.wg0[2]) j = 2;
     const int wg = (int)blockIdx.x - jobs.wg0[j];
     switch (jobs.prog[j]) {  // (uniform per workgroup)
-        case 0: small_split_body<0>(jobs.In[j], jobs.Out[j], jobs.rows[j], wimg, jobs.pos0[j], wg, jobs.nwg[j]); break;
-        case 1: small_split_body<1>(jobs.In[j], jobs.Out[j], jobs.rows[j], wimg, jobs.pos0[j], wg, jobs.nwg[j]); break;
-        default: small_split_body<2>(jobs.In[j], jobs.Out[j], jobs.rows[j], wimg, jobs.pos0[j], wg, jobs.nwg[j]); break;
+        case 0: small_split_body<0, CB>(jobs.In[j], jobs.Out[j], jobs.rows[j], wimg, jobs.pos0[j], wg, jobs.nwg[j]); break;
+        case 1: small_split_body<1, CB>(jobs.In[j], jobs.Out[j], jobs.rows[j], wimg, jobs.pos0[j], wg, jobs.nwg[j]); break;
+        default: small_split_body<2, CB>(jobs.In[j], jobs.Out[j], jobs.rows[j], wimg, jobs.pos0[j], wg, jobs.nwg[j]); break;
     }
 }
 
@@ -1192,7 +1195,7 @@ size_t smp_split_image_bytes() { return 2 * (size_t)kSpImgStride * sizeof(uint4)
 // the small products of a level in one launch (see smp_small_split): n <= 3 jobs of prog 0 / 1 / 2 on `rows[j]` rows with the weight
 // images from stacked position pos0[j] on; `transposed` picks the backward images; wimg = the level's prebuilt images
 gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *prog, const float *const *In, float *const *Out, const int *rows,
-                              const int *pos0, const void *wimg, const char *name) {
+                              const int *pos0, const void *wimg, const char *name, int C) {
     const uint4 *img = static_cast<const uint4 *>(wimg) + (transposed ? kSpImgStride : 0);
     SmallJobs jb;
     jb.n = 0;
@@ -1207,10 +1210,18 @@ gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *pr
         total += jb.nwg[k];
     }
     if (total == 0) return GF_OK;
-    const size_t lds = 2 * (size_t)4 * 512 * 16 + 16 * sizeof(float) + (kSmThreads / 64) * 32 * sizeof(float);
-    gf_status st = opt_in_lds(ctx, smp_small_split, lds);
-    if (st != GF_OK) return st;
-    GF_LAUNCH(ctx, name, smp_small_split, dim3((unsigned)total), dim3(kSmThreads), lds, jb, img);
+    const size_t lds = 2 * (size_t)4 * (C / 32) * (C / 16) * 64 * 16 + 16 * sizeof(float) + (kSmThreads / 64) * 32 * sizeof(float);
+    if (C == 64) {
+        gf_status st = opt_in_lds(ctx, smp_small_split<64>, lds);
+        if (st != GF_OK) return st;
+        GF_LAUNCH(ctx, name, smp_small_split<64>, dim3((unsigned)total), dim3(kSmThreads), lds, jb, img);
+    } else if (C == 32) {
+        gf_status st = opt_in_lds(ctx, smp_small_split<32>, lds);
+        if (st != GF_OK) return st;
+        GF_LAUNCH(ctx, name, smp_small_split<32>, dim3((unsigned)total), dim3(kSmThreads), lds, jb, img);
+    } else {
+        return fail(ctx, GF_ERR_UNSUPPORTED, "smp_small_split: %d channels", C);
+    }
     return GF_OK;
 }
 
