@@ -1246,7 +1246,7 @@ __device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w, int chunk
 // then every other source molecule by molecule).  Waves are independent (no LDS, no barrier): a workgroup is just four
 // consecutive items, whatever their sources' sizes; nothing is launched for rows a source does not have (idle waves of a
 // workgroup-per-source grid cost 0.15 - 0.3 ms of wave launches per step).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void smp_bwd_gather_all(GF_GATHER_PARAMS,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void smp_bwd_gather_all(GF_GATHER_PARAMS,
                                                                                                       const int2 *__restrict__ items,
                                                                                                       int n_items) {
     // launch order: each XCD (blockIdx % 8) takes a contiguous run of the list
@@ -1259,11 +1259,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (i >= n_items) return;
     const int2 item = items[i];
     const int w = __builtin_amdgcn_readfirstlane(item.x), chunk = __builtin_amdgcn_readfirstlane(item.y & 0xffff);
+    const int qc = __builtin_amdgcn_readfirstlane(item.y >> 16);   // which eight positions q of the source (sources above eight positions)
     const int sw = prev_s[w];
-    if (sw > 16) {
-        gather_source<16, 4, 32>(GF_GATHER_ARGS, w, chunk, 16 * __builtin_amdgcn_readfirstlane(item.y >> 16));
-        return;
-    }
+    // Round 4: at most EIGHT accumulators per item -- a source of more positions runs as ceil(s_w / 8) items of eight positions q each
+    // (the row terms of a consumer are requested by each of them: L1 hits).  128 registers, four waves per SIMD instead of three: the
+    // kernel waits on its gathers (holding it to two waves per SIMD costs 20 %), and the sixteen-accumulator path set its budget.
     switch (gfsmp::gather_pad(sw)) {
         case 1: gather_source<1, 1>(GF_GATHER_ARGS, w, chunk); break;
         case 2: gather_source<2, 2>(GF_GATHER_ARGS, w, chunk); break;
@@ -1271,9 +1271,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         case 5: gather_source<5, 5>(GF_GATHER_ARGS, w, chunk); break;
         case 6: gather_source<6, 6>(GF_GATHER_ARGS, w, chunk); break;
         case 8: gather_source<8, 8>(GF_GATHER_ARGS, w, chunk); break;
-        case 10: gather_source<10, 5>(GF_GATHER_ARGS, w, chunk); break;
-        case 12: gather_source<12, 6>(GF_GATHER_ARGS, w, chunk); break;
-        default: gather_source<16, 4>(GF_GATHER_ARGS, w, chunk); break;
+        case 10:
+            if (qc == 0) gather_source<8, 8, 10>(GF_GATHER_ARGS, w, chunk, 0);
+            else gather_source<2, 2, 10>(GF_GATHER_ARGS, w, chunk, 8);
+            break;
+        case 12:
+            if (qc == 0) gather_source<8, 8, 12>(GF_GATHER_ARGS, w, chunk, 0);
+            else gather_source<4, 4, 12>(GF_GATHER_ARGS, w, chunk, 8);
+            break;
+        case 16: gather_source<8, 8, 16>(GF_GATHER_ARGS, w, chunk, 8 * qc); break;
+        default: gather_source<8, 8, 32>(GF_GATHER_ARGS, w, chunk, 8 * qc); break;
     }
 }
 

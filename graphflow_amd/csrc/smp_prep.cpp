@@ -327,33 +327,23 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
             lv.mol_order.assign(totalV, 0);
             for (int n = 0; n < totalV; ++n) lv.mol_order[(size_t)start[(size_t)cls(lv.node_s[n]) * nMol + lv.node_mol[n]]++] = n;
         }
-        {  // work items of the one-launch gather (smp_prep.h): large sources first, the others molecule-major
+        {  // work items of the one-launch gather (smp_prep.h), molecule-major: (source, 64-lane chunk of its (p, channel quad) rows,
+           // eight positions q) -- a source of more than eight positions is several items (round 4: eight accumulators per item)
             const int nl = std::max(1, cfg.nChanels / 4);
             std::vector<int> start((size_t)nMol + 1, 0);
-            for (int n = 0; n < totalV; ++n)
-                if (lv.node_s[n] <= 16) start[(size_t)lv.node_mol[n] + 1] += 1;
+            for (int n = 0; n < totalV; ++n) start[(size_t)lv.node_mol[n] + 1] += 1;
             for (size_t k = 0; k + 1 < start.size(); ++k) start[k + 1] += start[k];
-            std::vector<int> small((size_t)start.back());
+            std::vector<int> order((size_t)totalV);
+            for (int n = 0; n < totalV; ++n) order[(size_t)start[(size_t)lv.node_mol[n]]++] = n;
             lv.gather_items.clear();
-            for (int n = 0; n < totalV; ++n) {
-                const int s = lv.node_s[n];
-                if (s <= 16) {
-                    small[(size_t)start[(size_t)lv.node_mol[n]]++] = n;
-                    continue;
-                }
-                const int chunks = (s * nl + 63) / 64;
-                for (int h = 0; h < 2; ++h)
+            for (size_t i = 0; i < order.size(); ++i) {
+                const int n = order[i], s = lv.node_s[n], chunks = (s * nl + 63) / 64;
+                const int qchunks = s <= 8 ? 1 : (gather_pad(s) + 7) / 8;
+                for (int h = 0; h < qchunks; ++h)
                     for (int c = 0; c < chunks; ++c) {
                         lv.gather_items.push_back(n);
                         lv.gather_items.push_back(c | (h << 16));
                     }
-            }
-            for (size_t i = 0; i < small.size(); ++i) {
-                const int n = small[i], chunks = (lv.node_s[n] * nl + 63) / 64;
-                for (int c = 0; c < chunks; ++c) {
-                    lv.gather_items.push_back(n);
-                    lv.gather_items.push_back(c);
-                }
             }
         }
         for (int n = 0; n < totalV; ++n) {
