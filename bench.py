@@ -230,7 +230,7 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
     def add(d, k, v):
         d[k] = d.get(k, 0) + v
 
-    c64 = C == 64
+    c64 = C in (64, 32)   # the dedicated product / weight-gradient kernels (row panels; C = 32 since round 4)
     # projected matrix O / dO: [O_loc | U] (2C) when the three dedicated C = 64 product kernels run, else [O_loc | Z | Z'] (3C)
     oc = 2 if (c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0") else 3
     # ... and then the three product kernels run on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip): 3 MFMA
