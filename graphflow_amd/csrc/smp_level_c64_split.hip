@@ -1,4 +1,5 @@
-// smp_level_c64_split.hip -- the row-panel block products of the fused SMP level at C = 64 (compact O layout) on the f16 matrix
+// smp_level_c64_split.hip -- the row-panel block products of the fused SMP level at C = 64 (and, templated on the channel count, C = 32:
+// round 4) in the compact O layout, on the f16 matrix
 // pipe with fp32-grade operands: every fp32 operand x is carried as TWO halves
 //     x 2^k = h + l,   h = rn_f16(x 2^k),  l = rn_f16(x 2^k - h)          (22 significant bits, k a per-row / per-block exponent)
 // and a product a b is evaluated as  ah bh + ah bl + al bh  (three v_mfma_f32_32x32x16_f16 with fp32 accumulation; products of
