@@ -109,6 +109,123 @@ struct Vec<4> {
     static __device__ __forceinline__ T zero() { return vf4{0.f, 0.f, 0.f, 0.f}; }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// RisiContraction_4 as slab streams (round 4; C % 4 == 0, 4 <= C / 4 <= 64 lanes per position dividing 64, 16-byte aligned buffers).
+// Every output of the family is owned by ONE middle index b: Out[a,b,0] = sum_c P[a,b,c] and Out[a,b,3] = P[a,b,b] for all a,
+// Out[b,c,1] = sum_a P[a,b,c] and Out[b,c,2] = P[b,b,c] for all c -- so a workgroup per (graph, b) streams the slab P[g][:, b, :, :]
+// ONCE (N rows of N C contiguous floats), with no workspace and no second pass: lane = (position group cg, channel quad fl), a wave
+// load covers PPW = 64 / (C / 4) positions x C channels as 16 bytes per lane, wave w owns rows a = w, w + 4, ...; the sums over c are
+// a register sum plus a butterfly over the position groups, the sums over a stay in registers per wave and meet in LDS in wave order.
+// The thread-per-output kernels above read P twice through 4-byte loads (0.62 ms at N = 24, C = 32, batch 256 forward + backward).
+// Backward: dP[a,b,c] = G0[a,b] + G1[b,c] + [a = b] G2[b,c] + [b = c] G3[a,b]: the (b, c)-indexed terms are lane-resident, a row costs two
+// broadcast loads and N C floats of stores.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SLOTS>   // position slots per lane: ceil(N / PPW)
+__global__ __launch_bounds__(256) void r4_fwd_slab(const float *__restrict__ P, float *__restrict__ Out, int N, int C) {
+    extern __shared__ __attribute__((aligned(16))) float r4_smem[];   // [4 waves][N][C] partial S_bc
+    const int lpc = C >> 2, ppw = 64 / lpc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = lane / lpc, fl = lane % lpc;
+    const size_t blk = xcd_block();
+    const int b = (int)(blk % N);
+    const size_t g = blk / N;
+    const size_t NC = (size_t)N * C;
+    const float *slab = P + g * NC * N * N + (size_t)b * NC + 4 * fl;   // row a at + a N NC
+    float *outg = Out + g * (size_t)N * N * 4 * C + 4 * fl;
+    vf4 sbc[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) sbc[i] = vf4{0.f, 0.f, 0.f, 0.f};
+    for (int a = wave; a < N; a += 4) {
+        const float *row = slab + (size_t)a * N * NC;
+        vf4 v[SLOTS];
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = i * ppw + cg;
+            v[i] = c < N ? Vec<4>::ld(row + (size_t)c * C) : vf4{0.f, 0.f, 0.f, 0.f};
+        }
+        vf4 sab = vf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            sab += v[i];
+            sbc[i] += v[i];
+        }
+        // sum over the position groups of the wave (lane bits >= log2(lpc))
+        for (int m = lpc; m < 64; m <<= 1) {
+            sab[0] += __shfl_xor(sab[0], m);
+            sab[1] += __shfl_xor(sab[1], m);
+            sab[2] += __shfl_xor(sab[2], m);
+            sab[3] += __shfl_xor(sab[3], m);
+        }
+        float *o = outg + ((size_t)a * N + b) * 4 * C;
+        if (cg == 0) Vec<4>::st(o + 0 * C, sab);                       // Out[a,b,0]
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = i * ppw + cg;
+            if (c == b) Vec<4>::st(o + 3 * C, v[i]);                    // Out[a,b,3] = P[a,b,b]
+            if (a == b && c < N) Vec<4>::st(outg + ((size_t)b * N + c) * 4 * C + 2 * C, v[i]);   // Out[b,c,2] = P[b,b,c]
+        }
+    }
+    // S_bc[b,c] = sum_a: the four waves' partials in wave order
+    vf4 *part = reinterpret_cast<vf4 *>(r4_smem);   // [4][N][lpc]
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int c = i * ppw + cg;
+        if (c < N) part[((size_t)wave * N + c) * lpc + fl] = sbc[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < N * lpc; i += 256) {
+        vf4 t = part[i];
+        for (int w = 1; w < 4; ++w) t += part[(size_t)w * N * lpc + i];
+        const int c = i / lpc, q = i % lpc;
+        Vec<4>::st(Out + g * (size_t)N * N * 4 * C + ((size_t)b * N + c) * 4 * C + 1 * C + 4 * q, t);   // Out[b,c,1]
+    }
+}
+
+template <int SLOTS, bool ACC>
+__global__ __launch_bounds__(256) void r4_bwd_slab(const float *__restrict__ G, float *__restrict__ dP, int N, int C) {
+    const int lpc = C >> 2, ppw = 64 / lpc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = lane / lpc, fl = lane % lpc;
+    const size_t blk = xcd_block();
+    const int b = (int)(blk % N);
+    const size_t g = blk / N;
+    const size_t NC = (size_t)N * C;
+    const float *Gg = G + g * (size_t)N * N * 4 * C + 4 * fl;
+    float *slab = dP + g * NC * N * N + (size_t)b * NC + 4 * fl;
+    vf4 y[SLOTS], y2[SLOTS];   // G1[b,c] and G1[b,c] + G2[b,c] (the row a = b)
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int c = i * ppw + cg;
+        const float *gc = Gg + ((size_t)b * N + (c < N ? c : 0)) * 4 * C;
+        y[i] = Vec<4>::ld(gc + 1 * C);
+        y2[i] = y[i] + Vec<4>::ld(gc + 2 * C);
+    }
+    for (int a = wave; a < N; a += 4) {
+        const float *ga = Gg + ((size_t)a * N + b) * 4 * C;
+        const vf4 g0 = Vec<4>::ld(ga), g3 = Vec<4>::ld(ga + 3 * C);
+        float *row = slab + (size_t)a * N * NC;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = i * ppw + cg;
+            if (c < N) {
+                vf4 v = g0 + (a == b ? y2[i] : y[i]);
+                if (c == b) v += g3;
+                if (ACC) v += Vec<4>::ld(row + (size_t)c * C);
+                Vec<4>::st(row + (size_t)c * C, v);
+            }
+        }
+    }
+}
+
+// the slab kernels serve: C % 4 == 0, C / 4 a power of two <= 64, N <= 16 positions slots per lane, aligned buffers
+static bool r4_slab_ok(int N, int C, const void *p0, const void *p1) {
+    if (C % 4 != 0 || C < 4) return false;
+    const int lpc = C / 4;
+    if (lpc > 64 || (lpc & (lpc - 1)) != 0) return false;
+    const int ppw = 64 / lpc, slots = (N + ppw - 1) / ppw;
+    return slots <= 16 && ((((uintptr_t)p0) | ((uintptr_t)p1)) & 15) == 0;
+}
+
 // Output slot (0-based) of "case c" (1-based numbering of RisiContraction_50.h) in family K, or -1 when absent.
 template <int K>
 __host__ __device__ constexpr int slot(int c) {
@@ -1256,6 +1373,24 @@ size_t family_workspace_bytes(int K, int N, int C, int batch) {
 
 gf_status family_forward(gf_ctx *ctx, int K, const float *P, const float *A, float *Out, int N, int C, int batch) {
     if (K == 4) {
+        if (r4_slab_ok(N, C, P, Out) && (size_t)batch * N < 0x7fffffffu) {
+            const int ppw = 64 / (C / 4), slots = (N + ppw - 1) / ppw;
+            const size_t lds = sizeof(float) * 4 * (size_t)N * C;
+            const dim3 grid((unsigned)((size_t)batch * N)), block(256);
+#define GF_R4F(S)                                                              \
+    do {                                                                       \
+        gf_status st = opt_in_lds(ctx, r4_fwd_slab<S>, lds);                   \
+        if (st != GF_OK) return st;                                            \
+        GF_LAUNCH(ctx, "r4_forward", r4_fwd_slab<S>, grid, block, lds, P, Out, N, C); \
+    } while (0)
+            if (slots <= 1) GF_R4F(1);
+            else if (slots <= 2) GF_R4F(2);
+            else if (slots <= 4) GF_R4F(4);
+            else if (slots <= 8) GF_R4F(8);
+            else GF_R4F(16);
+#undef GF_R4F
+            return GF_OK;
+        }
         const size_t total = (size_t)batch * N * N * C;
         GF_LAUNCH(ctx, "r4_forward", r4_forward, dim3(grid_for(total)), dim3(256), 0, P, Out, N, C, total);
         return GF_OK;
@@ -1268,6 +1403,22 @@ gf_status family_forward(gf_ctx *ctx, int K, const float *P, const float *A, flo
 gf_status family_backward(gf_ctx *ctx, int K, const float *G, const float *A, float *dP, int N, int C, int batch,
                           int accumulate) {
     if (K == 4) {
+        if (r4_slab_ok(N, C, G, dP) && (size_t)batch * N < 0x7fffffffu) {
+            const int ppw = 64 / (C / 4), slots = (N + ppw - 1) / ppw;
+            const dim3 grid((unsigned)((size_t)batch * N)), block(256);
+#define GF_R4B(S)                                                                                 \
+    do {                                                                                          \
+        if (accumulate) GF_LAUNCH(ctx, "r4_backward", (r4_bwd_slab<S, true>), grid, block, 0, G, dP, N, C); \
+        else GF_LAUNCH(ctx, "r4_backward", (r4_bwd_slab<S, false>), grid, block, 0, G, dP, N, C);           \
+    } while (0)
+            if (slots <= 1) GF_R4B(1);
+            else if (slots <= 2) GF_R4B(2);
+            else if (slots <= 4) GF_R4B(4);
+            else if (slots <= 8) GF_R4B(8);
+            else GF_R4B(16);
+#undef GF_R4B
+            return GF_OK;
+        }
         const size_t total = (size_t)batch * N * N * N * C;
         GF_LAUNCH(ctx, "r4_backward", r4_backward, dim3(grid_for(total)), dim3(256), 0, G, dP, N, C, total, accumulate);
         return GF_OK;

@@ -55,6 +55,29 @@ def test_forward_backward_vs_oracle(gf, oracle, K, N, C):
         assert rel_err(da[g], ref + d0[g]) <= REL_TOL_F32
 
 
+@pytest.mark.parametrize("N,C", [(1, 4), (3, 8), (5, 16), (7, 12), (17, 32), (24, 32), (32, 64), (33, 64), (20, 128), (70, 256)])
+def test_r4_slab_kernels_vs_oracle(gf, oracle, N, C):
+    """RisiContraction_4 on the slab-streaming kernels of round 4 (C % 4 == 0 and C / 4 a power of two; (7, 12) takes the thread kernels):
+    one to sixteen position slots per lane, ragged last slots, fewer rows than waves, write-only and accumulating backward -- against
+    the fp64 oracle's spec form (RisiContraction_4.h:79-120), slice by slice."""
+    rng = np.random.default_rng(4000 + 10 * N + C)
+    B = 2
+    P = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
+    G = f32exact(rng.uniform(-1, 1, (B, N, N, 4, C)))
+    d0 = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
+    out = host(gf.contract_forward(dev(P), None, 4))
+    dw = host(gf.contract_backward(dev(G), None, 4))
+    da = dev(d0)
+    gf.contract_backward(dev(G), None, 4, dP=da, accumulate=True)
+    da = host(da)
+    A = np.zeros((N, N))
+    for g in range(B):
+        assert rel_err_slices(out[g], oracle.contract_forward(4, P[g], A)) <= REL_TOL_F32
+        ref = oracle.contract_backward(4, G[g], A)
+        assert rel_err(dw[g], ref) <= REL_TOL_F32
+        assert rel_err(da[g], ref + d0[g]) <= REL_TOL_F32
+
+
 def test_structural_50_collapse_on_gpu(gf):
     """The reference's own known-answer (tests/test_RisiContraction_50.cpp): 50 slices -> the 18 recorded groups,
     bit-identical, for integer tensors symmetric in (b,c) and a symmetric zero-diagonal 0/1 adjacency."""
