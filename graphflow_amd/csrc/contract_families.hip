@@ -321,11 +321,12 @@ __global__ void fam_tables(const float *__restrict__ P, const float *__restrict_
 //     memory system busy at a LOW occupancy -- the launch asks for enough LDS to hold it to a few workgroups per CU: the three
 //     roles of a graph's P (1.8 MB at cfg5) are read by consecutive workgroups of one XCD, and with about two graphs in flight
 //     per XCD instead of fourteen the second and third reads are L2 hits (P was fetched 2.25 x).
-template <int UNR>
+// K = 10 (round 4): the same walk with the three plain marginals only -- S_ab, S_ac, S_bc into the workspace and S tot straight into
+// slices 1, 2, 5 -- eight steps requested ahead, instead of fam_tables<10>'s one step at a time (0.185 -> 0.11 ms at the cfg5 shape).
+template <int UNR, int K = 50>
 __global__ __launch_bounds__(256) void fam50_tables_out(const float *__restrict__ P, const float *__restrict__ adjs,
                                                         float *__restrict__ tab, float *__restrict__ Out, int N, int C,
                                                         size_t total) {
-    constexpr int K = 50;
     const size_t NNC = (size_t)N * N * C;
     const int CV = C / 4;
     GRID_STRIDE(idx, total) {
@@ -354,16 +355,18 @@ __global__ __launch_bounds__(256) void fam50_tables_out(const float *__restrict_
                 pac[u] = Vec<4>::ld(pac0 + (size_t)sc * N * C);
                 pbc[u] = Vec<4>::ld(pbc0 + (size_t)sc * NNC);
                 ok[u] = in ? 1.f : 0.f;
-                rs[u] = in ? r[sc] : 0.f;
-                qs[u] = in ? q[sc] : 0.f;
-                ds[u] = in ? dg[sc] : 0.f;
+                rs[u] = (K == 50 && in) ? r[sc] : 0.f;
+                qs[u] = (K == 50 && in) ? q[sc] : 0.f;
+                ds[u] = (K == 50 && in) ? dg[sc] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 acc[0] += pab[u] * ok[u];  acc[1] += pac[u] * ok[u];  acc[2] += pbc[u] * ok[u];
-                acc[3] += pab[u] * rs[u];  acc[4] += pab[u] * qs[u];  acc[5] += pab[u] * ds[u];
-                acc[6] += pac[u] * rs[u];  acc[7] += pac[u] * qs[u];  acc[8] += pac[u] * ds[u];
-                acc[9] += pbc[u] * rs[u];  acc[10] += pbc[u] * qs[u]; acc[11] += pbc[u] * ds[u];
+                if constexpr (K == 50) {
+                    acc[3] += pab[u] * rs[u];  acc[4] += pab[u] * qs[u];  acc[5] += pab[u] * ds[u];
+                    acc[6] += pac[u] * rs[u];  acc[7] += pac[u] * qs[u];  acc[8] += pac[u] * ds[u];
+                    acc[9] += pbc[u] * rs[u];  acc[10] += pbc[u] * qs[u]; acc[11] += pbc[u] * ds[u];
+                }
             }
         }
         const float tot = st[0], tr = st[1];
@@ -374,10 +377,13 @@ __global__ __launch_bounds__(256) void fam50_tables_out(const float *__restrict_
         float *o = Out + (((size_t)g * N + i) * N + j) * (size_t)(K * C) + f;
 #define OUTS(c, expr) Vec<4>::st(o + (size_t)((c) - 1) * C, (expr))
         OUTS(1, acc[0] * tot);  OUTS(2, acc[1] * tot);  OUTS(5, acc[2] * tot);
-        OUTS(11, acc[3]);       OUTS(12, acc[4]);       OUTS(13, acc[0] * tr);
-        OUTS(14, acc[6]);       OUTS(15, acc[7]);       OUTS(16, acc[1] * tr);
-        OUTS(23, acc[9]);       OUTS(24, acc[10]);      OUTS(25, acc[2] * tr);
-        OUTS(41, acc[5]);       OUTS(42, acc[8]);       OUTS(45, acc[11]);
+        if constexpr (K == 50) {
+            OUTS(11, acc[3]);       OUTS(12, acc[4]);       OUTS(13, acc[0] * tr);
+            OUTS(14, acc[6]);       OUTS(15, acc[7]);       OUTS(16, acc[1] * tr);
+            OUTS(23, acc[9]);       OUTS(24, acc[10]);      OUTS(25, acc[2] * tr);
+            OUTS(41, acc[5]);       OUTS(42, acc[8]);       OUTS(45, acc[11]);
+        }
+        (void)tr;
 #undef OUTS
     }
 }
@@ -1241,6 +1247,9 @@ gf_status fam_forward_launch(gf_ctx *ctx, const float *P, const float *A, float 
             if (st != GF_OK) return st;
             GF_LAUNCH(ctx, "fam_tables", (fam50_tables_out<8>), dim3(grid_for(nn / 4)), dim3(256), lds, P, w.adjs, w.tab, Out, N, C, nn / 4);
         }
+    } else if (vec && K == 10 && (((uintptr_t)Out) & 15) == 0) {
+        // the three plain marginals with eight steps of the walk in flight (fam50_tables_out<8, 10>); S tot also goes straight into slices 1, 2, 5
+        GF_LAUNCH(ctx, "fam_tables", (fam50_tables_out<8, 10>), dim3(grid_for(nn / 4)), dim3(256), 0, P, w.adjs, w.tab, Out, N, C, nn / 4);
     } else if (vec)
         GF_LAUNCH(ctx, "fam_tables", (fam_tables<K, 4>), dim3(grid_for(nn / 4)), dim3(256), 0, P, w.adjs, w.tab, N, C, nn / 4);
     else
