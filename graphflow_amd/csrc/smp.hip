@@ -731,7 +731,7 @@ __global__ void level_feature_backward(const float *__restrict__ dfeat, const fl
 }
 
 size_t param_count(const gfsmp::Config &c);
-static size_t param_count_of(const gf_smp *s) { return param_count(s->cfg); }
+static size_t param_count_of(const gf_smp *s) { return param_count(s->ucfg); }   // (the caller's layout)
 
 // page-locked host memory for the per-batch tables (smp_prep.h: table_alloc): their uploads then run on the DMA engines beside
 // the step that is executing, instead of blit kernels queued behind its compute kernels.  16-byte header: how it was obtained.
@@ -965,6 +965,25 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
     s->cfg.nContractions = cfg->nContractions ? cfg->nContractions : 18;
     s->cfg.custom_matmul = cfg->custom_matmul ? 1 : 0;
     s->cfg.physics = cfg->physics ? 1 : 0;
+    // Round 4: the channel count the DEVICE computes with.  The dedicated kernels of the fused level exist at 32 and 64 channels, the
+    // generic fused level needs C % 4 == 0, and anything else ran the op-by-op level on the one-thread-per-element contraction kernels
+    // (the reference's own tests use nChanels = 10: 35.8 ms per 1024-molecule step, against 8.0 ms at 12 channels and 4.1 ms at 32).
+    // A model is therefore computed with its channels PADDED to 32 / 64 (above 64: to a multiple of 4): padded weights, biases and
+    // features are zero, LeakyReLU(0) = 0 keeps them zero through every level, so the real channels see exactly the sums they saw
+    // before (plus zero terms).  ucfg keeps the caller's layout: parameters, gradients, features and activations cross the C ABI in
+    // it and are padded / cropped at the boundary (gf_smp_forward / gf_smp_backward).  GF_SMP_PAD_CHANNELS=0: compute at nChanels.
+    s->ucfg = s->cfg;
+    {
+        const char *e = std::getenv("GF_SMP_PAD_CHANNELS");
+        const int C = s->cfg.nChanels;
+        int Cc = C;
+        if (!(e && e[0] == '0') && !s->cfg.physics && s->cfg.nContractions == 18) {
+            if (C <= 32) Cc = 32;
+            else if (C <= 64) Cc = 64;
+            else Cc = (C + 3) & ~3;
+        }
+        s->cfg.nChanels = Cc;
+    }
     if (s->cfg.physics && (s->cfg.nDepth != 0 || s->cfg.nContractions != 18 || s->cfg.custom_matmul)) {
         delete s;
         return fail(ctx, GF_ERR_INVALID, "gf_smp_create: a physics tower has nDepth 0 (raw features), RisiContraction_18 and [18 C', C] weights");
@@ -994,11 +1013,14 @@ gf_status gf_smp_destroy(gf_smp *s) {
     if (s->adam_v) (void)hipFree(s->adam_v);
     if (s->own_p) (void)hipFree(s->own_p);
     if (s->own_g) (void)hipFree(s->own_g);
+    if (s->pad_p) (void)hipFree(s->pad_p);
+    if (s->pad_g) (void)hipFree(s->pad_g);
+    if (s->pad_feat) (void)hipFree(s->pad_feat);
     delete s;
     return GF_OK;
 }
 
-size_t gf_smp_param_count(const gf_smp *s) { return s ? gf::param_count(s->cfg) : 0; }
+size_t gf_smp_param_count(const gf_smp *s) { return s ? gf::param_count(s->ucfg) : 0; }
 
 // ---- host-pointer mode of the driver: the handle owns the model, batches and results cross as host arrays -------------
 gf_status gf_smp_parameters_upload(gf_smp *s, const float *host) {
@@ -1006,7 +1028,7 @@ gf_status gf_smp_parameters_upload(gf_smp *s, const float *host) {
     if (!host) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_parameters_upload: null argument");
     gf_status st = gf::own_model(s);
     if (st != GF_OK) return st;
-    GF_HIP_TRY(s->ctx, hipMemcpyAsync(s->own_p, host, gf::param_count(s->cfg) * sizeof(float), hipMemcpyHostToDevice, s->ctx->stream));
+    GF_HIP_TRY(s->ctx, hipMemcpyAsync(s->own_p, host, gf::param_count(s->ucfg) * sizeof(float), hipMemcpyHostToDevice, s->ctx->stream));
     GF_HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
     return GF_OK;
 }
@@ -1014,7 +1036,7 @@ gf_status gf_smp_parameters_upload(gf_smp *s, const float *host) {
 gf_status gf_smp_parameters_download(gf_smp *s, float *host_params, float *host_grads) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     if (!s->own_p) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_parameters_download: no handle-owned model");
-    const size_t bytes = gf::param_count(s->cfg) * sizeof(float);
+    const size_t bytes = gf::param_count(s->ucfg) * sizeof(float);
     if (host_params) GF_HIP_TRY(s->ctx, hipMemcpyAsync(host_params, s->own_p, bytes, hipMemcpyDeviceToHost, s->ctx->stream));
     if (host_grads) GF_HIP_TRY(s->ctx, hipMemcpyAsync(host_grads, s->own_g, bytes, hipMemcpyDeviceToHost, s->ctx->stream));
     GF_HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
@@ -1026,7 +1048,7 @@ gf_status gf_smp_forward_host(gf_smp *s, const double *targets, double *predict,
     gf_ctx *ctx = s->ctx;
     if (!s->prepared) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward_host before gf_smp_prepare");
     if (!s->own_p) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward_host: no handle-owned model (gf_smp_parameters_upload)");
-    const int nMol = s->lay.nMol, C = s->cfg.nChanels;
+    const int nMol = s->lay.nMol, C = s->ucfg.nChanels;
     gf_status st;
     if (!s->own_y) {
         st = gf::upload(s, &s->own_t, nullptr, (size_t)nMol);
@@ -1068,7 +1090,7 @@ gf_status gf_smp_adam_step(gf_smp *s, float *params, const float *grads, double 
     }
     if (!params || !grads || nBatch <= 0) return fail(ctx, GF_ERR_INVALID, "gf_smp_adam_step: bad argument");
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t n = gf::param_count(s->cfg);
+    const size_t n = gf::param_count(s->ucfg);
     if (!s->adam_m) {
         GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->adam_m), n * sizeof(float)));
         GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->adam_v), n * sizeof(float)));
@@ -1093,7 +1115,7 @@ gf_status gf_smp_momentum_step(gf_smp *s, float *params, const float *grads, dou
     }
     if (!params || !grads || nBatch <= 0) return fail(ctx, GF_ERR_INVALID, "gf_smp_momentum_step: bad argument");
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t n = gf::param_count(s->cfg);
+    const size_t n = gf::param_count(s->ucfg);
     if (!s->adam_m) {
         GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->adam_m), n * sizeof(float)));
         GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->adam_v), n * sizeof(float)));
@@ -1121,7 +1143,7 @@ gf_status gf_adam_step_f32(gf_ctx *ctx, float *params, const float *grads, float
 gf_status gf_smp_adam_reset(gf_smp *s) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     if (s->adam_m) {
-        const size_t n = gf::param_count(s->cfg);
+        const size_t n = gf::param_count(s->ucfg);
         GF_HIP_TRY(s->ctx, hipMemsetAsync(s->adam_m, 0, n * sizeof(float), s->ctx->stream));
         GF_HIP_TRY(s->ctx, hipMemsetAsync(s->adam_v, 0, n * sizeof(float), s->ctx->stream));
     }
@@ -1161,7 +1183,7 @@ gf_status gf_smp_save_model(const gf_smp *s, const float *params, const char *pa
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp");
     if (!params) params = s->own_p;
     if (!params || !path) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_save_model: null argument");
-    const size_t n = gf::param_count(s->cfg);
+    const size_t n = gf::param_count(s->ucfg);
     std::vector<float> host(n);
     GF_HIP_TRY(s->ctx, hipMemcpyAsync(host.data(), params, n * sizeof(float), hipMemcpyDeviceToHost, s->ctx->stream));
     GF_HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
@@ -1181,7 +1203,7 @@ gf_status gf_smp_load_model(gf_smp *s, float *params, const char *path) {
         params = s->own_p;
     }
     if (!params || !path) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_load_model: null argument");
-    const size_t n = gf::param_count(s->cfg);
+    const size_t n = gf::param_count(s->ucfg);
     FILE *f = std::fopen(path, "r");
     if (!f) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_load_model: cannot open %s", path);
     std::vector<float> host(n);
@@ -1536,8 +1558,110 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     return GF_OK;
 }
 
+// ---- channel padding at the C ABI (gf_smp_create: cfg = what the device computes with, ucfg = the caller's layout) ----------------
+namespace gf {
+// element i of the parameter vector in the PADDED layout (Cc channels) <-> its place in the caller's layout (C channels), or -1 (a padded
+// weight: zero).  Order H [C][FD], (K_l, b_l)..., W [C]; K_l is [18][C][C] as (k, ci, co) (SMP_omega.h:289-295) or, custom_matmul,
+// [C][18 C] as (co, k, ci) (CustomMatMulTensor, SMP_2D_ver8).
+__device__ __forceinline__ long long padded_to_user(long long i, int C, int Cc, int FD, int L, int nK, int custom) {
+    const long long hpad = (long long)Cc * FD;
+    if (i < hpad) {
+        const int c = (int)(i / FD);
+        return c < C ? i : -1;   // (same index: rows c < C come first in both layouts)
+    }
+    i -= hpad;
+    const long long lvl_pad = (long long)nK * Cc * Cc + Cc, lvl_usr = (long long)nK * C * C + C;
+    const long long l = i / lvl_pad;
+    if (l < L) {
+        const long long j = i - l * lvl_pad, base = (long long)C * FD + l * lvl_usr;
+        if (j >= (long long)nK * Cc * Cc) {   // bias
+            const long long c = j - (long long)nK * Cc * Cc;
+            return c < C ? base + (long long)nK * C * C + c : -1;
+        }
+        int k, ci, co;
+        if (custom) {
+            co = (int)(j / ((long long)nK * Cc));
+            const long long r = j % ((long long)nK * Cc);
+            k = (int)(r / Cc), ci = (int)(r % Cc);
+            return (co < C && ci < C) ? base + (long long)co * nK * C + (long long)k * C + ci : -1;
+        }
+        k = (int)(j / ((long long)Cc * Cc));
+        const long long r = j % ((long long)Cc * Cc);
+        ci = (int)(r / Cc), co = (int)(r % Cc);
+        return (ci < C && co < C) ? base + ((long long)k * C + ci) * C + co : -1;
+    }
+    const long long c = i - (long long)L * lvl_pad;   // W
+    return c < C ? (long long)C * FD + (long long)L * lvl_usr + c : -1;
+}
+__global__ void pad_parameters(const float *__restrict__ user, float *__restrict__ padded, long long n_padded, int C, int Cc, int FD, int L, int nK,
+                               int custom) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_padded) return;
+    const long long u = padded_to_user(i, C, Cc, FD, L, nK, custom);
+    padded[i] = u >= 0 ? user[u] : 0.f;
+}
+__global__ void crop_gradients(const float *__restrict__ padded, float *__restrict__ user, long long n_padded, int C, int Cc, int FD, int L, int nK,
+                               int custom, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_padded) return;
+    const long long u = padded_to_user(i, C, Cc, FD, L, nK, custom);
+    if (u >= 0) user[u] = accumulate ? user[u] + padded[i] : padded[i];
+}
+static bool padded_channels(const gf_smp *s) { return s->cfg.nChanels != s->ucfg.nChanels; }
+// the handle's padded copies of the caller's parameters / of the gradients of the running step
+static gf_status pad_buffers(gf_smp *s) {
+    if (s->pad_p) return GF_OK;
+    const size_t n = param_count(s->cfg);
+    GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->pad_p), n * sizeof(float)));
+    GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->pad_g), n * sizeof(float)));
+    return GF_OK;
+}
+static gf_status pad_params_now(gf_smp *s, const float *params) {
+    gf_status st = pad_buffers(s);
+    if (st != GF_OK) return st;
+    const long long n = (long long)param_count(s->cfg);
+    GF_LAUNCH(s->ctx, "smp_pad_params", pad_parameters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, params, s->pad_p, n, s->ucfg.nChanels,
+              s->cfg.nChanels, s->cfg.fdim(), s->cfg.nLevels, s->cfg.nContractions, s->cfg.custom_matmul);
+    return GF_OK;
+}
+}  // namespace gf
+
+static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *targets, float *predict, float *loss, float *graph_feature);
+
 gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, float *predict, float *loss,
                          float *graph_feature) {
+    if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
+    if (!gf::padded_channels(s)) return smp_forward_impl(s, params, targets, predict, loss, graph_feature);
+    gf_ctx *ctx = s->ctx;
+    if (!s->prepared) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward before gf_smp_prepare");
+    if (!params) {
+        if (!s->own_p) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward: null params and no handle-owned model");
+        params = s->own_p;
+    }
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gf_status st = gf::pad_params_now(s, params);
+    if (st != GF_OK) return st;
+    const int C = s->ucfg.nChanels, Cc = s->cfg.nChanels, nMol = s->lay.nMol;
+    float *feat = nullptr;
+    if (graph_feature) {
+        if (s->pad_feat_n < (size_t)nMol * Cc) {
+            if (s->pad_feat) (void)hipFree(s->pad_feat);
+            s->pad_feat = nullptr;
+            GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->pad_feat), (size_t)nMol * Cc * sizeof(float)));
+            s->pad_feat_n = (size_t)nMol * Cc;
+        }
+        feat = s->pad_feat;
+    }
+    st = smp_forward_impl(s, s->pad_p, targets, predict, loss, feat);
+    if (st != GF_OK) return st;
+    if (graph_feature)   // crop the padded columns of the graph features
+        GF_HIP_TRY(ctx, hipMemcpy2DAsync(graph_feature, (size_t)C * sizeof(float), feat, (size_t)Cc * sizeof(float), (size_t)C * sizeof(float), (size_t)nMol,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+    return GF_OK;
+}
+
+static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *targets, float *predict, float *loss,
+                                  float *graph_feature) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     gf_ctx *ctx = s->ctx;
     if (!s->prepared) return fail(ctx, GF_ERR_INVALID, "gf_smp_forward before gf_smp_prepare");
@@ -1809,7 +1933,25 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
 
 gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accumulate) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
-    return smp_backward_impl(s, params, grads, accumulate, nullptr);
+    if (!gf::padded_channels(s)) return smp_backward_impl(s, params, grads, accumulate, nullptr);
+    gf_ctx *ctx = s->ctx;
+    if (!params && !grads && s->own_p) {
+        params = s->own_p;
+        grads = s->own_g;
+    }
+    if (!params || !grads) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: null argument");
+    if (accumulate && gf::dist_active(ctx) && s->grad_allreduce)
+        return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: accumulate with a communicator would re-sum earlier global sums "
+                                         "(gf_smp_set_grad_allreduce(smp, 0) and reduce once at the end instead)");
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gf_status st = gf::pad_params_now(s, params);   // (the caller may have stepped the parameters since the forward pass: same values then)
+    if (st != GF_OK) return st;
+    st = smp_backward_impl(s, s->pad_p, s->pad_g, 0, nullptr);   // (with a communicator: the padded segments are all-reduced)
+    if (st != GF_OK) return st;
+    const long long n = (long long)gf::param_count(s->cfg);
+    GF_LAUNCH(ctx, "smp_crop_grads", gf::crop_gradients, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->pad_g, grads, n, s->ucfg.nChanels,
+              s->cfg.nChanels, s->cfg.fdim(), s->cfg.nLevels, s->cfg.nContractions, s->cfg.custom_matmul, accumulate ? 1 : 0);
+    return GF_OK;
 }
 
 gf_status gf_smp_backward_features(gf_smp *s, const float *params, float *grads, const float *d_feature, int accumulate) {
@@ -1820,7 +1962,7 @@ gf_status gf_smp_backward_features(gf_smp *s, const float *params, float *grads,
 
 size_t gf_smp_feature_width(const gf_smp *s) {
     if (!s) return 0;
-    return s->cfg.physics ? gf::feature_width(s->cfg) : (size_t)s->cfg.nChanels;
+    return s->cfg.physics ? gf::feature_width(s->cfg) : (size_t)s->ucfg.nChanels;
 }
 
 /* Host-only graph preparation of ONE molecule (no device needed): receptive fields phi[l][v] as
@@ -1900,10 +2042,14 @@ static long long smp_read_node(gf_smp *s, int mol, int level, int v, float *out,
     }
     if (n < 0) return -1;
     const size_t sz = (size_t)h.node_s[n], C = (size_t)s->cfg.level_channels(level);  // (physics towers halve per level)
-    const size_t count = adjacency ? sz * sz : sz * sz * C;
+    const size_t Cu = (size_t)s->ucfg.level_channels(level);                              // (the caller's channels: the padded ones are cropped)
+    const size_t count = adjacency ? sz * sz : sz * sz * Cu;
     if (count > capacity) return -1;
     const float *src = adjacency ? s->lv[level].adj + h.node_row[n] : s->lv[level].f + (size_t)h.node_row[n] * C;
-    if (hipMemcpyAsync(out, src, count * sizeof(float), hipMemcpyDeviceToHost, s->ctx->stream) != hipSuccess) return -1;
+    if (!adjacency && Cu != C) {
+        if (hipMemcpy2DAsync(out, Cu * sizeof(float), src, C * sizeof(float), Cu * sizeof(float), sz * sz, hipMemcpyDeviceToHost, s->ctx->stream) != hipSuccess)
+            return -1;
+    } else if (hipMemcpyAsync(out, src, count * sizeof(float), hipMemcpyDeviceToHost, s->ctx->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) return -1;
     return (long long)count;
 }

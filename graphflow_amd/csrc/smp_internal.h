@@ -84,7 +84,10 @@ gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, c
 
 struct gf_smp {
     gf_ctx *ctx = nullptr;
-    gfsmp::Config cfg;
+    gfsmp::Config cfg;    // what the device computes with: nChanels padded to 32 / 64 / a multiple of 4 (gf_smp_create, round 4)
+    gfsmp::Config ucfg;   // the caller's configuration: the layout of parameters, gradients, features and activations at the C ABI
+    float *pad_p = nullptr, *pad_g = nullptr, *pad_feat = nullptr;   // padded copies (cfg.nChanels != ucfg.nChanels)
+    size_t pad_feat_n = 0;
     gfsmp::BatchLayout lay;
     bool prepared = false, forwarded = false;
     // context workspace this batch needs.  gf_smp_prepare only RECORDS it (prepare may run on a loader thread while another

@@ -34,12 +34,17 @@ constexpr int kSpThreads = 512;            // two waves per SIMD, 256 registers 
 
 // power-of-two scale that puts a magnitude with biased exponent e into [2^13, 2^14), and its inverse (e clamped: magnitudes below
 // 2^-113 are flushed by the f16 conversion, which is what the fp32 product of such operands underflows to as well)
+template <unsigned EMIN = 14u>
 __device__ __forceinline__ void pow2_scale(unsigned maxbits, float *s, float *inv) {
     unsigned e = maxbits >> 23;
-    e = e < 14u ? 14u : e;
+    e = e < EMIN ? EMIN : e;
     *s = __uint_as_float((267u - e) << 23);
     *inv = __uint_as_float((e - 13u) << 23);
 }
+// The weight-gradient kernels fold a row's fp32 factor (tot, tr: up to ~2^10) into the column's scale BEFORE the multiply, so the
+// scale of an all-zero column (a dead channel; every padded channel of gf_smp_create) must leave room for it: 2^126 x 30 = inf and
+// inf x 0 = NaN.  Exponent floor 64: scale <= 2^76, a column whose largest magnitude is below 2^-63 keeps fewer than 22 bits.
+__device__ __forceinline__ void pow2_scale_col(unsigned maxbits, float *s, float *inv) { pow2_scale<64u>(maxbits, s, inv); }
 // (a, b) 2^k -> halves.  The LOW half is carried at 2^11 times its value (round 4): unscaled it goes subnormal for every element
 // more than 2^17 below the block's largest (f16's smallest normal is 2^-14), which then kept one bit less per binary order -- ~15 bits
 // at 2^24 : 1 inside a block.  Scaled, an element keeps its 22 bits down to 2^-27 of the block maximum (where h itself goes
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
     // at 2^-28 of it.
     float *sScale = reinterpret_cast<float *>(ws_smem + 2 * kWsStageWords), *sInv = sScale + kWsACols + kWsBCols;
     if (cmax) {
-        for (int c = tid; c < kWsACols + kWsBCols; c += kWsThreads) pow2_scale(cmax[c], &sScale[c], &sInv[c]);
+        for (int c = tid; c < kWsACols + kWsBCols; c += kWsThreads) pow2_scale_col(cmax[c], &sScale[c], &sInv[c]);
     } else {
         // from the per-channel maxima mf = max |f_{l-1}| and mdz = max |dz_l| (left by combine-forward of the level below and by this
         // level's combine-backward, reduced by level_channel_maxima):
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
             const float m = __uint_as_float(chan[(isa ? 0 : 64) + ch]);
             const float fa = blk < 2 ? smax : max_tot;                                   // S_ab, S_bc | T6, T10
             const float fb = blk == 0 ? 1.f : blk == 2 ? max_tr : max_tot;               // L | tot L | tr L | dU | dU[trow]
-            pow2_scale(__float_as_uint(m * (isa ? fa : fb)), &sScale[c], &sInv[c]);
+            pow2_scale_col(__float_as_uint(m * (isa ? fa : fb)), &sScale[c], &sInv[c]);
         }
     }
     __syncthreads();
@@ -891,7 +896,7 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (cmax) {
-        for (int c = tid; c < ACOLS + BCOLS; c += kWdThreads) pow2_scale(cmax[c], &sScale[c], &sInv[c]);
+        for (int c = tid; c < ACOLS + BCOLS; c += kWdThreads) pow2_scale_col(cmax[c], &sScale[c], &sInv[c]);
     } else {   // (the bounds of smp_wgrad_split, from the level's per-channel maxima)
         const float max_tot = __uint_as_float(row_max[0]), max_tr = __uint_as_float(row_max[1]);
         for (int c = tid; c < ACOLS + BCOLS; c += kWdThreads) {
@@ -900,7 +905,7 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
             const float m = __uint_as_float(chan[(isa ? 0 : CB) + ch]);
             const float fa = blk < 2 ? smax : max_tot;
             const float fb = blk == 0 ? 1.f : blk == 2 ? max_tr : max_tot;
-            pow2_scale(__float_as_uint(m * (isa ? fa : fb)), &sScale[c], &sInv[c]);
+            pow2_scale_col(__float_as_uint(m * (isa ? fa : fb)), &sScale[c], &sInv[c]);
         }
     }
     __syncthreads();
