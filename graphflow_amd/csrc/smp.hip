@@ -947,7 +947,13 @@ using gf::fail;
 
 extern "C" {
 
-gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
+gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) { return gf::smp_create(ctx, cfg, /*pad_channels=*/true, out); }
+
+}  // extern "C"
+
+// pad_channels = false: compute at the configuration's own channel counts (the towers of a model with RisiContraction_18_dropout --
+// SMP_sigma_pairgraphs -- whose levels run op by op, where a padded width only costs)
+gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channels, gf_smp **out) {
     if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
     if (!cfg || !out) return fail(ctx, GF_ERR_INVALID, "gf_smp_create: null argument");
     if (cfg->nLevels < 1 || cfg->nChanels < 1 || cfg->nFeatures < 1 || cfg->nDepth < 0 || cfg->max_receptive_field < 1)
@@ -977,10 +983,13 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
         const char *e = std::getenv("GF_SMP_PAD_CHANNELS");
         const int C = s->cfg.nChanels;
         int Cc = C;
-        if (!(e && e[0] == '0') && !s->cfg.physics && s->cfg.nContractions == 18) {
+        if ((pad_channels || (e && e[0] == '2')) && !(e && e[0] == '0') && s->cfg.nContractions == 18 && s->cfg.nLevels < gf::kPadMaxLevels) {   // (2: tests)
             if (C <= 32) Cc = 32;
             else if (C <= 64) Cc = 64;
             else Cc = (C + 3) & ~3;
+            // a physics tower (channels halve per level, SMP_omega_physics.h:141-151) is computed at ONE width: K_l [18 C_{l-1}][C_l]
+            // sits in the corner of a square [18 Cc][Cc] block, the level features are cropped level by level
+            if (s->cfg.physics) s->cfg.uniform = 1;
         }
         s->cfg.nChanels = Cc;
     }
@@ -1000,6 +1009,8 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) {
     *out = s;
     return GF_OK;
 }
+
+extern "C" {
 
 gf_status gf_smp_destroy(gf_smp *s) {
     if (!s) return GF_OK;
@@ -1289,7 +1300,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             UP(d.field, h.field);
             if (!s->cfg.physics) UP(d.node_mol, h.node_mol);   // (the towers upload it below)
         }
-        if (l >= 1 && !s->cfg.physics) {
+        if (l >= 1 && s->cfg.square()) {
             st = gf::upload(s, &d.tf_recs, nullptr, (size_t)h.nNodes * 2);
             if (st != GF_OK) return st;
         }
@@ -1370,7 +1381,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             UP(d.pi, h.pi);
             UP(d.inv, h.inv);
         }
-        if (!s->cfg.physics && s->cfg.nContractions == 18 && C % 4 == 0 && s->bwd_gather) {  // fused levels: tables of the gather
+        if (s->cfg.square() && s->cfg.nContractions == 18 && C % 4 == 0 && s->bwd_gather) {  // fused levels: tables of the gather
             st = gf::upload(s, &d.cons_hdr, nullptr, (size_t)h.pairs * 2);
             if (st != GF_OK) return st;
             st = gf::upload(s, &d.cons_qrec, nullptr, (size_t)h.qrec_total);
@@ -1378,7 +1389,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             st = gf::upload(s, &d.cons_qbase, h.cons_qbase.empty() ? nullptr : &h.cons_qbase[0], h.cons_qbase.size());
             if (st != GF_OK) return st;
         }
-        if (!s->cfg.physics && (C == 64 || C == 32) && h.rows < 0x7fffffffll) {   // (C = 32: the split row-panel products, round 4)
+        if (s->cfg.square() && (C == 64 || C == 32) && h.rows < 0x7fffffffll) {   // (C = 32: the split row-panel products, round 4)
             st = gf::upload(s, &d.trow, nullptr, (size_t)h.rows);
             if (st == GF_OK) st = gf::upload(s, &d.trowf, nullptr, (size_t)h.rows);
             if (st == GF_OK) {
@@ -1413,7 +1424,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         }
         st = gf::upload(s, &d.Q, nullptr, (size_t)h.rows * std::max(18, s->cfg.nContractions) * Cp);
         if (st != GF_OK) return st;
-        if (!s->cfg.physics) {
+        if (s->cfg.square()) {
             float **bufs[] = {&d.Vt, &d.dVt, &d.St, &d.dSt, &d.scal, &d.Vout, &d.dVout, &d.Sout, &d.dSout, &d.dSpart, &d.dbpart, &d.Wst, &d.dWst};
             const size_t sizes[] = {(size_t)h.pairs * 4 * C, (size_t)h.pairs * 4 * C, (size_t)h.nNodes * 4 * C, (size_t)h.nNodes * 4 * C,
                                     (size_t)h.pairs * 4 * C, (size_t)h.pairs * C, (size_t)h.pairs * C, (size_t)h.nNodes * C,
@@ -1506,10 +1517,10 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     s->P_count = (size_t)maxp;  // (positions x channels of the level below, maximised over the levels)
     const gfsmp::LevelLayout &top = B.level[L];
     s->wbound = nullptr;
-    if (!s->cfg.physics && C == 64) {
+    if (s->cfg.square() && C == 64) {
         st = gf::upload(s, &s->wbound, nullptr, gf::smp_wgrad_bound_words() * (size_t)(L + 1));
         if (st != GF_OK) return st;
-    } else if (!s->cfg.physics && C == 32) {   // scratch words of the C = 32 weight-gradient kernel's exact column bounds
+    } else if (s->cfg.square() && C == 32) {   // scratch words of the C = 32 weight-gradient kernel's exact column bounds
         st = gf::upload(s, &s->wbound, nullptr, gf::smp_wgrad_direct_words_c32() * (size_t)(L + 1));
         if (st != GF_OK) return st;
     }
@@ -1560,54 +1571,69 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
 
 // ---- channel padding at the C ABI (gf_smp_create: cfg = what the device computes with, ucfg = the caller's layout) ----------------
 namespace gf {
-// element i of the parameter vector in the PADDED layout (Cc channels) <-> its place in the caller's layout (C channels), or -1 (a padded
-// weight: zero).  Order H [C][FD], (K_l, b_l)..., W [C]; K_l is [18][C][C] as (k, ci, co) (SMP_omega.h:289-295) or, custom_matmul,
-// [C][18 C] as (co, k, ci) (CustomMatMulTensor, SMP_2D_ver8).
-__device__ __forceinline__ long long padded_to_user(long long i, int C, int Cc, int FD, int L, int nK, int custom) {
-    const long long hpad = (long long)Cc * FD;
+// The two parameter layouts.  Order H [C_0][FD], (K_l, b_l)..., W [C] (no W in a physics tower); K_l is [18][C_{l-1}][C_l] as (k, ci, co)
+// (SMP_omega.h:289-295; C_l = C, or halving per level in a tower) or, custom_matmul, [C][18 C] as (co, k, ci) (CustomMatMulTensor,
+// SMP_2D_ver8).  The padded layout has Cc channels at every level.
+struct PadMap {
+    int L, nK, custom, FD, Cc, hasW;
+    int cu[kPadMaxLevels + 1];          // the caller's channels of level l
+    long long uoff[kPadMaxLevels + 2];  // the caller's offset of H (0), K_1, ..., K_L, W
+};
+static PadMap pad_map(const gfsmp::Config &u, const gfsmp::Config &c) {
+    PadMap m = {};
+    m.L = u.nLevels, m.nK = u.nContractions, m.custom = u.custom_matmul, m.FD = u.fdim(), m.Cc = c.nChanels, m.hasW = u.physics ? 0 : 1;
+    for (int l = 0; l <= m.L; ++l) m.cu[l] = u.level_channels(l);
+    m.uoff[0] = 0;
+    m.uoff[1] = (long long)m.cu[0] * m.FD;
+    for (int l = 1; l <= m.L; ++l) m.uoff[l + 1] = m.uoff[l] + (long long)m.nK * m.cu[l - 1] * m.cu[l] + m.cu[l];
+    return m;
+}
+// element i of the PADDED parameter vector -> its place in the caller's, or -1 (a padded weight: zero)
+__device__ __forceinline__ long long padded_to_user(long long i, const PadMap &m) {
+    const int Cc = m.Cc;
+    const long long hpad = (long long)Cc * m.FD;
     if (i < hpad) {
-        const int c = (int)(i / FD);
-        return c < C ? i : -1;   // (same index: rows c < C come first in both layouts)
+        const int c = (int)(i / m.FD);
+        return c < m.cu[0] ? i : -1;   // (same index: rows c < C_0 come first in both layouts)
     }
     i -= hpad;
-    const long long lvl_pad = (long long)nK * Cc * Cc + Cc, lvl_usr = (long long)nK * C * C + C;
-    const long long l = i / lvl_pad;
-    if (l < L) {
-        const long long j = i - l * lvl_pad, base = (long long)C * FD + l * lvl_usr;
-        if (j >= (long long)nK * Cc * Cc) {   // bias
-            const long long c = j - (long long)nK * Cc * Cc;
-            return c < C ? base + (long long)nK * C * C + c : -1;
+    const long long lvl_pad = (long long)m.nK * Cc * Cc + Cc;
+    const long long lq = i / lvl_pad;
+    if (lq < m.L) {
+        const int l = (int)lq + 1, Ci = m.cu[l - 1], Co = m.cu[l];
+        const long long j = i - lq * lvl_pad, base = m.uoff[l];
+        if (j >= (long long)m.nK * Cc * Cc) {   // bias
+            const long long c = j - (long long)m.nK * Cc * Cc;
+            return c < Co ? base + (long long)m.nK * Ci * Co + c : -1;
         }
         int k, ci, co;
-        if (custom) {
-            co = (int)(j / ((long long)nK * Cc));
-            const long long r = j % ((long long)nK * Cc);
+        if (m.custom) {
+            co = (int)(j / ((long long)m.nK * Cc));
+            const long long r = j % ((long long)m.nK * Cc);
             k = (int)(r / Cc), ci = (int)(r % Cc);
-            return (co < C && ci < C) ? base + (long long)co * nK * C + (long long)k * C + ci : -1;
+            return (co < Co && ci < Ci) ? base + (long long)co * m.nK * Ci + (long long)k * Ci + ci : -1;
         }
         k = (int)(j / ((long long)Cc * Cc));
         const long long r = j % ((long long)Cc * Cc);
         ci = (int)(r / Cc), co = (int)(r % Cc);
-        return (ci < C && co < C) ? base + ((long long)k * C + ci) * C + co : -1;
+        return (ci < Ci && co < Co) ? base + ((long long)k * Ci + ci) * Co + co : -1;
     }
-    const long long c = i - (long long)L * lvl_pad;   // W
-    return c < C ? (long long)C * FD + (long long)L * lvl_usr + c : -1;
+    const long long c = i - (long long)m.L * lvl_pad;   // W
+    return (m.hasW && c < m.cu[m.L]) ? m.uoff[m.L + 1] + c : -1;
 }
-__global__ void pad_parameters(const float *__restrict__ user, float *__restrict__ padded, long long n_padded, int C, int Cc, int FD, int L, int nK,
-                               int custom) {
+__global__ void pad_parameters(const float *__restrict__ user, float *__restrict__ padded, long long n_padded, PadMap m) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_padded) return;
-    const long long u = padded_to_user(i, C, Cc, FD, L, nK, custom);
+    const long long u = padded_to_user(i, m);
     padded[i] = u >= 0 ? user[u] : 0.f;
 }
-__global__ void crop_gradients(const float *__restrict__ padded, float *__restrict__ user, long long n_padded, int C, int Cc, int FD, int L, int nK,
-                               int custom, int accumulate) {
+__global__ void crop_gradients(const float *__restrict__ padded, float *__restrict__ user, long long n_padded, PadMap m, int accumulate) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_padded) return;
-    const long long u = padded_to_user(i, C, Cc, FD, L, nK, custom);
+    const long long u = padded_to_user(i, m);
     if (u >= 0) user[u] = accumulate ? user[u] + padded[i] : padded[i];
 }
-static bool padded_channels(const gf_smp *s) { return s->cfg.nChanels != s->ucfg.nChanels; }
+static bool padded_channels(const gf_smp *s) { return s->cfg.nChanels != s->ucfg.nChanels || s->cfg.uniform != s->ucfg.uniform; }
 // the handle's padded copies of the caller's parameters / of the gradients of the running step
 static gf_status pad_buffers(gf_smp *s) {
     if (s->pad_p) return GF_OK;
@@ -1620,8 +1646,46 @@ static gf_status pad_params_now(gf_smp *s, const float *params) {
     gf_status st = pad_buffers(s);
     if (st != GF_OK) return st;
     const long long n = (long long)param_count(s->cfg);
-    GF_LAUNCH(s->ctx, "smp_pad_params", pad_parameters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, params, s->pad_p, n, s->ucfg.nChanels,
-              s->cfg.nChanels, s->cfg.fdim(), s->cfg.nLevels, s->cfg.nContractions, s->cfg.custom_matmul);
+    GF_LAUNCH(s->ctx, "smp_pad_params", pad_parameters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, params, s->pad_p, n, pad_map(s->ucfg, s->cfg));
+    return GF_OK;
+}
+static gf_status crop_grads_now(gf_smp *s, float *grads, int accumulate) {
+    const long long n = (long long)param_count(s->cfg);
+    GF_LAUNCH(s->ctx, "smp_crop_grads", crop_gradients, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->pad_g, grads, n, pad_map(s->ucfg, s->cfg),
+              accumulate ? 1 : 0);
+    return GF_OK;
+}
+// the handle's padded feature rows ([nMol][feature width of cfg]): the device's graph features, or the caller's feature gradient padded
+static gf_status pad_feature_buffer(gf_smp *s) {
+    const size_t n = (size_t)s->lay.nMol * (s->cfg.physics ? feature_width(s->cfg) : (size_t)s->cfg.nChanels);
+    if (s->pad_feat_n >= n) return GF_OK;
+    if (s->pad_feat) (void)hipFree(s->pad_feat);
+    s->pad_feat = nullptr;
+    s->pad_feat_n = 0;
+    GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->pad_feat), n * sizeof(float)));
+    s->pad_feat_n = n;
+    return GF_OK;
+}
+// feature rows between the two layouts, level block by level block (one block outside the towers): to_user crops, else pads (the
+// caller's columns into a zeroed padded row)
+static gf_status copy_feature_blocks(gf_smp *s, float *user, float *padded, bool to_user) {
+    gf_ctx *ctx = s->ctx;
+    const int nMol = s->lay.nMol, Cc = s->cfg.nChanels;
+    const int nblk = s->cfg.physics ? s->cfg.nLevels + 1 : 1;
+    const size_t wu = s->cfg.physics ? feature_width(s->ucfg) : (size_t)s->ucfg.nChanels, wp = (size_t)nblk * Cc;
+    if (!to_user) GF_HIP_TRY(ctx, hipMemsetAsync(padded, 0, (size_t)nMol * wp * sizeof(float), ctx->stream));
+    size_t uo = 0;
+    for (int l = 0; l < nblk; ++l) {
+        const size_t cu = s->cfg.physics ? (size_t)s->ucfg.level_channels(l) : (size_t)s->ucfg.nChanels;
+        float *pu = user + uo, *pp = padded + (size_t)l * Cc;
+        if (to_user)
+            GF_HIP_TRY(ctx, hipMemcpy2DAsync(pu, wu * sizeof(float), pp, wp * sizeof(float), cu * sizeof(float), (size_t)nMol, hipMemcpyDeviceToDevice,
+                                             ctx->stream));
+        else
+            GF_HIP_TRY(ctx, hipMemcpy2DAsync(pp, wp * sizeof(float), pu, wu * sizeof(float), cu * sizeof(float), (size_t)nMol, hipMemcpyDeviceToDevice,
+                                             ctx->stream));
+        uo += cu;
+    }
     return GF_OK;
 }
 }  // namespace gf
@@ -1641,22 +1705,15 @@ gf_status gf_smp_forward(gf_smp *s, const float *params, const float *targets, f
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     gf_status st = gf::pad_params_now(s, params);
     if (st != GF_OK) return st;
-    const int C = s->ucfg.nChanels, Cc = s->cfg.nChanels, nMol = s->lay.nMol;
     float *feat = nullptr;
     if (graph_feature) {
-        if (s->pad_feat_n < (size_t)nMol * Cc) {
-            if (s->pad_feat) (void)hipFree(s->pad_feat);
-            s->pad_feat = nullptr;
-            GF_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->pad_feat), (size_t)nMol * Cc * sizeof(float)));
-            s->pad_feat_n = (size_t)nMol * Cc;
-        }
+        st = gf::pad_feature_buffer(s);
+        if (st != GF_OK) return st;
         feat = s->pad_feat;
     }
     st = smp_forward_impl(s, s->pad_p, targets, predict, loss, feat);
     if (st != GF_OK) return st;
-    if (graph_feature)   // crop the padded columns of the graph features
-        GF_HIP_TRY(ctx, hipMemcpy2DAsync(graph_feature, (size_t)C * sizeof(float), feat, (size_t)Cc * sizeof(float), (size_t)C * sizeof(float), (size_t)nMol,
-                                         hipMemcpyDeviceToDevice, ctx->stream));
+    if (graph_feature) return gf::copy_feature_blocks(s, graph_feature, feat, /*to_user=*/true);   // (the padded columns are cropped)
     return GF_OK;
 }
 
@@ -1898,6 +1955,10 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
         if (diag_level && gf::smp_fused_gather_enabled(s, l)) {
             st = gf::smp_fused_gather_backward(s, l);
             if (st != GF_OK) return st;
+            if (dfeat) {  // (a tower: level l-1 is read out too)
+                st = feature_backward(l - 1, 1);
+                if (st != GF_OK) return st;
+            }
             continue;
         }
         GF_LAUNCH(ctx, "smp_promote_bwd", gf::promote_backward, dim3(B.level[l - 1].nNodes), dim3(256), 0, s->P, pv.df,
@@ -1948,21 +2009,30 @@ gf_status gf_smp_backward(gf_smp *s, const float *params, float *grads, int accu
     if (st != GF_OK) return st;
     st = smp_backward_impl(s, s->pad_p, s->pad_g, 0, nullptr);   // (with a communicator: the padded segments are all-reduced)
     if (st != GF_OK) return st;
-    const long long n = (long long)gf::param_count(s->cfg);
-    GF_LAUNCH(ctx, "smp_crop_grads", gf::crop_gradients, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->pad_g, grads, n, s->ucfg.nChanels,
-              s->cfg.nChanels, s->cfg.fdim(), s->cfg.nLevels, s->cfg.nContractions, s->cfg.custom_matmul, accumulate ? 1 : 0);
-    return GF_OK;
+    return gf::crop_grads_now(s, grads, accumulate);
 }
 
 gf_status gf_smp_backward_features(gf_smp *s, const float *params, float *grads, const float *d_feature, int accumulate) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     if (!d_feature) return fail(s->ctx, GF_ERR_INVALID, "gf_smp_backward_features: null feature gradient");
-    return smp_backward_impl(s, params, grads, accumulate, d_feature);
+    if (!gf::padded_channels(s)) return smp_backward_impl(s, params, grads, accumulate, d_feature);
+    gf_ctx *ctx = s->ctx;
+    if (!s->cfg.physics) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward_features needs a physics tower");
+    if (!s->forwarded) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward before gf_smp_forward");
+    if (!params || !grads) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: null argument");
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gf_status st = gf::pad_params_now(s, params);
+    if (st == GF_OK) st = gf::pad_feature_buffer(s);
+    if (st == GF_OK) st = gf::copy_feature_blocks(s, const_cast<float *>(d_feature), s->pad_feat, /*to_user=*/false);
+    if (st != GF_OK) return st;
+    st = smp_backward_impl(s, s->pad_p, s->pad_g, 0, s->pad_feat);
+    if (st != GF_OK) return st;
+    return gf::crop_grads_now(s, grads, accumulate);
 }
 
 size_t gf_smp_feature_width(const gf_smp *s) {
     if (!s) return 0;
-    return s->cfg.physics ? gf::feature_width(s->cfg) : (size_t)s->ucfg.nChanels;
+    return s->cfg.physics ? gf::feature_width(s->ucfg) : (size_t)s->ucfg.nChanels;
 }
 
 /* Host-only graph preparation of ONE molecule (no device needed): receptive fields phi[l][v] as

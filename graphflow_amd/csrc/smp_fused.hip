@@ -1352,7 +1352,8 @@ bool smp_fused_supported(const gf_smp *s, int l) {
     const int C = s->cfg.nChanels;
     if (C % 4 != 0 || C > 1024) return false;
     if (s->cfg.nContractions != 18) return false;  // SMP_2D_ver6 / ver7 (_10 / _50): op-by-op levels
-    if (s->cfg.physics) return false;              // channel counts change from level to level: op-by-op levels
+    if (!s->cfg.square()) return false;            // a tower at its own halving channel counts (GF_SMP_PAD_CHANNELS=0): op-by-op levels
+    if (s->drop_on) return false;                  // RisiContraction_18_dropout masks single slices of Q: op-by-op levels
     const gfsmp::LevelLayout &h = s->lay.level[l];
     if (h.buckets.empty()) return false;
     return h.buckets.back().s <= 32;  // 8 * PPW at LPC = 16

@@ -82,6 +82,10 @@ gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, c
 }
 
 
+namespace gf {
+gf_status smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channels, gf_smp **out);   // gf_smp_create = (.., true, ..)
+constexpr int kPadMaxLevels = 15;   // levels a padded model's layout map holds (gf_smp_create: deeper models compute at nChanels)
+}
 struct gf_smp {
     gf_ctx *ctx = nullptr;
     gfsmp::Config cfg;    // what the device computes with: nChanels padded to 32 / 64 / a multiple of 4 (gf_smp_create, round 4)

@@ -123,7 +123,8 @@ gf_status gf_smp_model_create(gf_ctx *ctx, const gf_smp_model_config *cfg, gf_sm
     size_t toff[2] = {0, 0};
     for (int t = 0; t < m->nTowers; ++t) {
         gf_smp_config tc = {cfg->nLevels, cfg->nChanels, cfg->nFeatures[t], 0, cfg->max_receptive_field, 0, 18, 0, 1};
-        gf_status st = gf_smp_create(ctx, &tc, &m->tower[t]);
+        // (nKept > 0: RisiContraction_18_dropout keeps the levels op by op -- the towers then stay at their own halving widths)
+        gf_status st = gf::smp_create(ctx, &tc, /*pad_channels=*/cfg->nKept <= 0, &m->tower[t]);
         if (st != GF_OK) {
             gf_smp_model_destroy(m);
             return st;

@@ -44,8 +44,12 @@ struct Config {
     // WL ordering, and the cap orders by hop distance only, :436-450), channels halve from level to level (:141-151), every
     // level is read out (:572-590).  One such model body is a "tower": its output is the concatenated level features.
     int physics = 0;
+    // 1 (a physics tower's DEVICE configuration, gf_smp_create): every level is computed at nChanels -- the halving channel counts
+    // zero-padded to one width -- so the tower's levels run the fused level kernels
+    int uniform = 0;
+    bool square() const { return !physics || uniform; }   // K_l is [nContractions C][C] at every level
     int level_channels(int l) const {
-        if (!physics) return nChanels;
+        if (square()) return nChanels;
         int c = nChanels >> l;
         return c < 1 ? 1 : c;
     }

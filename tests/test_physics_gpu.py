@@ -80,3 +80,37 @@ def test_batch_is_the_sum_of_its_samples(gf):
     with pytest.raises(Exception):
         net.forward(p)
         net.backward(p, g)   # no targets in the last forward
+
+
+@pytest.mark.parametrize("towers,Cn,nKept", [(1, 16, 0), (2, 8, 0), (1, 48, 0), (2, 16, 9)])
+def test_padded_towers_equal_the_towers_at_their_own_widths(gf, monkeypatch, towers, Cn, nKept):
+    """Round 4: a tower (channels C, C/2, C/4, ... per level, SMP_omega_physics.h:141-151) is COMPUTED at one padded width (32 / 64) so
+    that its levels run the fused level kernels; K_l [18 C_{l-1}][C_l] sits in the corner of a square block, the level features are
+    cropped level by level, the feature gradient is padded with zeros (gf_smp_create / gf_smp_backward_features).  Same batch with
+    GF_SMP_PAD_CHANNELS=0 (op-by-op levels at the halving widths).  nKept > 0 (SMP_sigma_pairgraphs: RisiContraction_18_dropout masks single
+    slices of Q) keeps the levels op by op, so gf_smp_model_create leaves such towers at their own widths (padded: 55 against 34 ms per
+    1024-sample step); GF_SMP_PAD_CHANNELS=2 pads them all the same -- the path of a caller who sets dropout masks on a padded tower."""
+    from graphflow_amd.smp import SMPModel
+    from inputs import synthetic_molecule
+    L, cap, F = 3, 10, 5
+    mols = [synthetic_molecule(3100 + i, nV=4 + i % 8)[:2] for i in range(20)]
+    mols2 = [synthetic_molecule(3200 + i, nV=3 + i % 7)[:2] for i in range(20)]
+    tg = dev(np.array([synthetic_molecule(3100 + i)[2] for i in range(20)]))
+    got = []
+    for mode in ("2" if nKept else "1", "0"):
+        monkeypatch.setenv("GF_SMP_PAD_CHANNELS", mode)
+        net = SMPModel(L, Cn, cap, [F] * towers, nKept=nKept)
+        p = dev(np.random.default_rng(11).uniform(-0.3, 0.3, net.n_params))
+        net.prepare(mols, mols2 if towers == 2 else None)
+        net.set_mode(True)
+        C.CDLL(None).srand(5)
+        pred, loss = net.forward(p, tg)
+        g = torch.full((net.n_params,), float("nan"), device="cuda")
+        net.backward(p, g)
+        got.append((pred.cpu().numpy().astype(np.float64), loss.cpu().numpy().astype(np.float64), g.cpu().numpy().astype(np.float64)))
+        net.close()
+    (p1, l1, g1), (p0, l0, g0) = got
+    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
+    print("towers %d C %d nKept %d: predict %.2e loss %.2e grads %.2e" % (towers, Cn, nKept, rel_err(p1, p0), rel_err(l1, l0), rel_err(g1, g0)))
+    assert rel_err(p1, p0) <= 2e-6 and rel_err(l1, l0) <= 4e-6
+    assert rel_err(g1, g0) <= TOL
