@@ -226,6 +226,298 @@ static bool r4_slab_ok(int N, int C, const void *p0, const void *p1) {
     return slots <= 16 && ((((uintptr_t)p0) | ((uintptr_t)p1)) & 15) == 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// RisiContraction_10 as ONE stream per graph (round 4, second session; C % 4 == 0 with C / 4 <= 32 lanes per position, N <= 32, at most
+// four position slots per lane, 16-byte aligned buffers, batches that fill the chip).  The ten slices are the "1+1+1" cases
+// (RisiContraction_10.h:94-142): with S_ab, S_ac, S_bc the pair marginals of P, Va / Vb / Vc their vector marginals, s the total, r / q
+// the row / column sums of A and tot their total,
+//   Out[.,.,0..9] = S_ab tot | S_ac tot | Va[x] r[y] | Va[x] q[y] | S_bc tot | Vb[x] r[y] | Vb[x] q[y] | Vc[x] r[y] | Vc[x] q[y] | s A[x,y].
+// No 1-D slab owns all three pair marginals, but a whole graph's do fit ONE workgroup: P[g] (N^3 C floats, 1.8 MB at N = 24, C = 32) is
+// streamed once by a workgroup of ceil(N / 2) waves, wave w owning the rows b = w and w + nw of every slab P[g][a]: S_ab[a,b] is a
+// register sum plus a butterfly over the wave's position groups, S_bc[b,c] accumulates in the owner's registers over a, and S_ac[a,:]
+// = sum_b meets in LDS once per a (the waves' partials in wave order behind ONE barrier: double-buffered) -- where it is written out,
+// folded into Vc, and forgotten.  The rows of a + 1 are requested before the sums of a.  The vector slices are written from LDS at the
+// end.  The table kernels read P three times through L2 (1.48 x fetched) and wrote / re-read the marginals: 0.25 -> see DESIGN 4.2.
+// Backward: dP[a,b,c] = tot (G0[a,b] + G1[a,c] + G4[b,c]) + xa[a] + xb[b] + xc[c] + s with xa[x] = sum_y G2[x,y] r[y] + G3[x,y] q[y]
+// (xb from G5, G6; xc from G7, G8) and s = sum G9[x,y] A[x,y]: one pass over seven slices of G for the vectors, then dP streamed out
+// with the (b, c)-indexed terms lane-resident.
+// ---------------------------------------------------------------------------------------------------------------
+struct R10Lds {   // float offsets into the workgroup's LDS
+    int A, r, q, tot, Va, Vb, Vc, S, pva, pac, total;
+};
+__host__ __device__ inline R10Lds r10_lds(int N, int lpc, int nw) {
+    R10Lds L;
+    L.A = 0;
+    L.r = N * N;
+    L.q = L.r + N;
+    L.tot = L.q + N;
+    L.Va = (L.tot + 4 + 3) & ~3;
+    L.Vb = L.Va + 4 * N * lpc;
+    L.Vc = L.Vb + 4 * N * lpc;
+    L.S = L.Vc + 4 * N * lpc;
+    L.pva = L.S + 4 * lpc;
+    L.pac = L.pva + 4 * 2 * nw * lpc;
+    L.total = L.pac + 4 * 2 * nw * N * lpc;
+    return L;
+}
+// the adjacency, its row / column sums and their total into LDS (every thread of the workgroup; ends behind a barrier)
+__device__ __forceinline__ float r10_adjacency(const float *__restrict__ Ag, float *sm, const R10Lds &L, int N) {
+    for (int i = threadIdx.x; i < N * N; i += blockDim.x) sm[L.A + i] = Ag[i];
+    __syncthreads();
+    if ((int)threadIdx.x < N) {
+        float rs = 0.f, qs = 0.f;
+        for (int j = 0; j < N; ++j) {
+            rs += sm[L.A + threadIdx.x * N + j];
+            qs += sm[L.A + j * N + threadIdx.x];
+        }
+        sm[L.r + threadIdx.x] = rs;
+        sm[L.q + threadIdx.x] = qs;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < N; ++i) t += sm[L.r + i];
+        sm[L.tot] = t;
+    }
+    __syncthreads();
+    return sm[L.tot];
+}
+__device__ __forceinline__ vf4 r10_butterfly(vf4 v, int lpc) {   // sum over the position groups of the wave (lane bits >= log2(lpc))
+    for (int m = lpc; m < 64; m <<= 1) {
+        v[0] += __shfl_xor(v[0], m);
+        v[1] += __shfl_xor(v[1], m);
+        v[2] += __shfl_xor(v[2], m);
+        v[3] += __shfl_xor(v[3], m);
+    }
+    return v;
+}
+
+template <int SLOTS, int MAXT>   // position slots per lane: ceil(N / PPW); threads: 768 (N <= 24: 168 registers) or 1024 (128)
+__global__ __launch_bounds__(MAXT) void r10_fwd_graph(const float *__restrict__ P, const float *__restrict__ A, float *__restrict__ Out, int N, int C,
+                                                      int nw) {
+    extern __shared__ __attribute__((aligned(16))) float r10_smem[];
+    const int lpc = C >> 2, ppw = 64 / lpc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = lane / lpc, fl = lane % lpc;
+    const size_t g = blockIdx.x;
+    const size_t NC = (size_t)N * C;
+    const R10Lds L = r10_lds(N, lpc, nw);
+    const float tot = r10_adjacency(A + g * N * N, r10_smem, L, N);
+    vf4 *sVa = reinterpret_cast<vf4 *>(r10_smem + L.Va), *sVb = reinterpret_cast<vf4 *>(r10_smem + L.Vb), *sVc = reinterpret_cast<vf4 *>(r10_smem + L.Vc);
+    vf4 *sS = reinterpret_cast<vf4 *>(r10_smem + L.S), *pva = reinterpret_cast<vf4 *>(r10_smem + L.pva), *pac = reinterpret_cast<vf4 *>(r10_smem + L.pac);
+    const float *sr = r10_smem + L.r, *sq = r10_smem + L.q, *sA = r10_smem + L.A;
+
+    const int brow[2] = {wave, wave + nw};
+    const bool okb[2] = {true, wave + nw < N};
+    const float *Pg = P + g * NC * N * N + 4 * fl;
+    float *Outg = Out + g * (size_t)N * N * 10 * C;
+    const vf4 zero = vf4{0.f, 0.f, 0.f, 0.f};
+    auto load_rows = [&](int a, vf4(&v)[2][SLOTS]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const float *row = Pg + ((size_t)a * N + (okb[rb] ? brow[rb] : brow[0])) * NC;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                const int c = i * ppw + cg;
+                v[rb][i] = (okb[rb] && c < N) ? Vec<4>::ld(row + (size_t)c * C) : zero;
+            }
+        }
+    };
+    vf4 sbc[2][SLOTS], vbacc[2] = {zero, zero}, vcacc = zero;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) sbc[rb][i] = zero;
+    vf4 cur[2][SLOTS], nxt[2][SLOTS];
+    load_rows(0, cur);
+    for (int a = 0; a < N; ++a) {
+        if (a + 1 < N) load_rows(a + 1, nxt);   // (in flight over the sums and the barrier of a)
+        vf4 sac[SLOTS], vap = zero;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) sac[i] = zero;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            vf4 sab = zero;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                sab += cur[rb][i];
+                sbc[rb][i] += cur[rb][i];
+                sac[i] += cur[rb][i];
+            }
+            sab = r10_butterfly(sab, lpc);
+            vbacc[rb] += sab;
+            vap += sab;
+            if (cg == 0 && okb[rb]) Vec<4>::st(Outg + (((size_t)a * N + brow[rb]) * 10 + 0) * C + 4 * fl, tot * sab);   // S_ab tot
+        }
+        const int buf = a & 1;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = i * ppw + cg;
+            if (c < N) pac[(((size_t)buf * nw + wave) * N + c) * lpc + fl] = sac[i];
+        }
+        if (cg == 0) pva[((size_t)buf * nw + wave) * lpc + fl] = vap;
+        __syncthreads();
+        if (tid < N * lpc) {   // S_ac[a, c] = sum_b: thread (c = tid / lpc, channel quad tid % lpc), the waves in order
+            vf4 t = pac[((size_t)buf * nw) * N * lpc + tid];
+            for (int w = 1; w < nw; ++w) t += pac[((size_t)buf * nw + w) * N * lpc + tid];
+            vcacc += t;
+            Vec<4>::st(Outg + (((size_t)a * N + tid / lpc) * 10 + 1) * C + 4 * (tid % lpc), tot * t);
+        }
+        if (wave == nw - 1 && lane < lpc) {   // Va[a] = sum_b S_ab[a, b]
+            vf4 t = pva[((size_t)buf * nw) * lpc + lane];
+            for (int w = 1; w < nw; ++w) t += pva[((size_t)buf * nw + w) * lpc + lane];
+            sVa[(size_t)a * lpc + lane] = t;
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) cur[rb][i] = nxt[rb][i];
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {   // S_bc tot, Vb
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = i * ppw + cg;
+            if (okb[rb] && c < N) Vec<4>::st(Outg + (((size_t)brow[rb] * N + c) * 10 + 4) * C + 4 * fl, tot * sbc[rb][i]);
+        }
+        if (cg == 0 && okb[rb]) sVb[(size_t)brow[rb] * lpc + fl] = vbacc[rb];
+    }
+    if (tid < N * lpc) sVc[tid] = vcacc;
+    __syncthreads();
+    if (tid < lpc) {
+        vf4 t = sVa[tid];
+        for (int a = 1; a < N; ++a) t += sVa[(size_t)a * lpc + tid];
+        sS[tid] = t;
+    }
+    __syncthreads();
+    // the seven vector / scalar slices of every row (x, y)
+    const int total = N * N * 7 * lpc;
+    for (int idx = tid; idx < total; idx += blockDim.x) {
+        const int q = idx % lpc, j = (idx / lpc) % 7, row = idx / (7 * lpc);
+        const int x = row / N, y = row - x * N;
+        const vf4 *vec = j < 2 ? sVa : j < 4 ? sVb : sVc;
+        const float w = j == 6 ? sA[x * N + y] : (j & 1) ? sq[y] : sr[y];
+        const vf4 v = (j == 6 ? sS[q] : vec[(size_t)x * lpc + q]) * w;
+        const int k = j < 2 ? 2 + j : 3 + j;   // 2, 3 | 5, 6, 7, 8, 9
+        Vec<4>::st(Outg + ((size_t)row * 10 + k) * C + 4 * q, v);
+    }
+}
+
+template <int SLOTS, bool ACC, int MAXT>
+__global__ __launch_bounds__(MAXT) void r10_bwd_graph(const float *__restrict__ G, const float *__restrict__ A, float *__restrict__ dP, int N, int C,
+                                                      int nw) {
+    extern __shared__ __attribute__((aligned(16))) float r10_smem[];
+    const int lpc = C >> 2, ppw = 64 / lpc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = lane / lpc, fl = lane % lpc;
+    const size_t g = blockIdx.x;
+    const size_t NC = (size_t)N * C;
+    const R10Lds L = r10_lds(N, lpc, nw);
+    const float tot = r10_adjacency(A + g * N * N, r10_smem, L, N);
+    vf4 *sxa = reinterpret_cast<vf4 *>(r10_smem + L.Va), *sxb = reinterpret_cast<vf4 *>(r10_smem + L.Vb), *sxc = reinterpret_cast<vf4 *>(r10_smem + L.Vc);
+    vf4 *sS = reinterpret_cast<vf4 *>(r10_smem + L.S), *ps = reinterpret_cast<vf4 *>(r10_smem + L.pva);
+    const float *sr = r10_smem + L.r, *sq = r10_smem + L.q, *sA = r10_smem + L.A;
+    const int brow[2] = {wave, wave + nw};
+    const bool okb[2] = {true, wave + nw < N};
+    const float *Gg = G + g * (size_t)N * N * 10 * C + 4 * fl;
+    const vf4 zero = vf4{0.f, 0.f, 0.f, 0.f};
+    {   // the vectors: rows x = the wave's two, sums over y
+        vf4 sw = zero;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            if (!okb[rb]) continue;   // (wave-uniform)
+            const int x = brow[rb];
+            vf4 xa = zero, xb = zero, xc = zero, xs = zero;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                const int y = i * ppw + cg;
+                if (y < N) {
+                    const float *row = Gg + ((size_t)x * N + y) * 10 * C;
+                    const float ry = sr[y], qy = sq[y], axy = sA[x * N + y];
+                    xa += Vec<4>::ld(row + 2 * C) * ry + Vec<4>::ld(row + 3 * C) * qy;
+                    xb += Vec<4>::ld(row + 5 * C) * ry + Vec<4>::ld(row + 6 * C) * qy;
+                    xc += Vec<4>::ld(row + 7 * C) * ry + Vec<4>::ld(row + 8 * C) * qy;
+                    xs += Vec<4>::ld(row + 9 * C) * axy;
+                }
+            }
+            xa = r10_butterfly(xa, lpc), xb = r10_butterfly(xb, lpc), xc = r10_butterfly(xc, lpc), xs = r10_butterfly(xs, lpc);
+            if (cg == 0) {
+                sxa[(size_t)x * lpc + fl] = xa;
+                sxb[(size_t)x * lpc + fl] = xb;
+                sxc[(size_t)x * lpc + fl] = xc;
+            }
+            sw += xs;
+        }
+        if (cg == 0) ps[(size_t)wave * lpc + fl] = sw;
+        __syncthreads();
+        if (tid < lpc) {
+            vf4 t = ps[tid];
+            for (int w = 1; w < nw; ++w) t += ps[(size_t)w * lpc + tid];
+            sS[tid] = t;
+        }
+        __syncthreads();
+    }
+    // dP streamed out: wave owns the rows b of every slab a; tot G4[b,c] + xb[b] + xc[c] + s stay in the lane
+    vf4 base[2][SLOTS];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = i * ppw + cg, b = okb[rb] ? brow[rb] : brow[0];
+            const int cc = c < N ? c : 0;
+            base[rb][i] = tot * Vec<4>::ld(Gg + (((size_t)b * N + cc) * 10 + 4) * C) + sxb[(size_t)b * lpc + fl] + sxc[(size_t)cc * lpc + fl] + sS[fl];
+        }
+    float *dPg = dP + g * NC * N * N + 4 * fl;
+    auto load_a = [&](int a, vf4(&ga)[2], vf4(&g1)[SLOTS]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) ga[rb] = Vec<4>::ld(Gg + (((size_t)a * N + (okb[rb] ? brow[rb] : brow[0])) * 10 + 0) * C);
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = i * ppw + cg;
+            g1[i] = Vec<4>::ld(Gg + (((size_t)a * N + (c < N ? c : 0)) * 10 + 1) * C);
+        }
+    };
+    vf4 ga[2], g1[SLOTS], gan[2], g1n[SLOTS];
+    load_a(0, ga, g1);
+    for (int a = 0; a < N; ++a) {
+        if (a + 1 < N) load_a(a + 1, gan, g1n);
+        const vf4 xa = sxa[(size_t)a * lpc + fl];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            if (!okb[rb]) continue;
+            float *row = dPg + ((size_t)a * N + brow[rb]) * NC;
+            const vf4 u = tot * ga[rb] + xa;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                const int c = i * ppw + cg;
+                if (c < N) {
+                    vf4 v = base[rb][i] + u + tot * g1[i];
+                    if (ACC) v += Vec<4>::ld(row + (size_t)c * C);
+                    Vec<4>::st(row + (size_t)c * C, v);
+                }
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) ga[rb] = gan[rb];
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) g1[i] = g1n[i];
+    }
+}
+
+// the per-graph kernels serve: C % 4 == 0 with C / 4 a power of two <= 32, N <= 32 with at most four position slots per lane, aligned
+// buffers, a workgroup's LDS within the CU's, and batches that give most CUs a graph (GF_FAM10_GRAPH=0: the table kernels)
+static bool r10_graph_ok(int N, int C, int batch, const void *p0, const void *p1, const void *p2) {
+    const char *e = std::getenv("GF_FAM10_GRAPH");   // 0: the table kernels; 2: any batch size (tests)
+    if (e && e[0] == '0') return false;
+    if (C % 4 != 0 || C < 4 || N < 1 || N > 32 || (batch < 96 && !(e && e[0] == '2'))) return false;
+    const int lpc = C / 4;
+    if (lpc > 32 || (lpc & (lpc - 1)) != 0) return false;
+    const int ppw = 64 / lpc, slots = (N + ppw - 1) / ppw, nw = (N + 1) / 2;
+    if (slots > 4) return false;
+    if ((size_t)r10_lds(N, lpc, nw).total * sizeof(float) > 160 * 1024) return false;
+    return ((((uintptr_t)p0) | ((uintptr_t)p1) | ((uintptr_t)p2)) & 15) == 0;
+}
+
 // Output slot (0-based) of "case c" (1-based numbering of RisiContraction_50.h) in family K, or -1 when absent.
 template <int K>
 __host__ __device__ constexpr int slot(int c) {
@@ -1404,6 +1696,29 @@ gf_status family_forward(gf_ctx *ctx, int K, const float *P, const float *A, flo
         GF_LAUNCH(ctx, "r4_forward", r4_forward, dim3(grid_for(total)), dim3(256), 0, P, Out, N, C, total);
         return GF_OK;
     }
+    if (K == 10 && r10_graph_ok(N, C, batch, P, Out, A)) {
+        const int lpc = C / 4, ppw = 64 / lpc, slots = (N + ppw - 1) / ppw, nw = (N + 1) / 2;
+        const size_t lds = sizeof(float) * (size_t)r10_lds(N, lpc, nw).total;
+        const dim3 grid((unsigned)batch), block(64 * nw);
+#define GF_R10F2(S, T)                                                                            \
+    do {                                                                                          \
+        gf_status st = opt_in_lds(ctx, r10_fwd_graph<S, T>, lds);                                 \
+        if (st != GF_OK) return st;                                                               \
+        GF_LAUNCH(ctx, "r10_forward", (r10_fwd_graph<S, T>), grid, block, lds, P, A, Out, N, C, nw); \
+    } while (0)
+#define GF_R10F(S)                   \
+    do {                             \
+        if (nw <= 12) GF_R10F2(S, 768); \
+        else GF_R10F2(S, 1024);      \
+    } while (0)
+        if (slots <= 1) GF_R10F(1);
+        else if (slots <= 2) GF_R10F(2);
+        else if (slots <= 3) GF_R10F(3);
+        else GF_R10F(4);
+#undef GF_R10F2
+#undef GF_R10F
+        return GF_OK;
+    }
     if (K == 10) return fam_forward_launch<10>(ctx, P, A, Out, N, C, batch);
     if (K == 50) return fam_forward_launch<50>(ctx, P, A, Out, N, C, batch);
     return fail(ctx, GF_ERR_INVALID, "family_forward: K=%d", K);
@@ -1430,6 +1745,31 @@ gf_status family_backward(gf_ctx *ctx, int K, const float *G, const float *A, fl
         }
         const size_t total = (size_t)batch * N * N * N * C;
         GF_LAUNCH(ctx, "r4_backward", r4_backward, dim3(grid_for(total)), dim3(256), 0, G, dP, N, C, total, accumulate);
+        return GF_OK;
+    }
+    if (K == 10 && r10_graph_ok(N, C, batch, G, dP, A)) {
+        const int lpc = C / 4, ppw = 64 / lpc, slots = (N + ppw - 1) / ppw, nw = (N + 1) / 2;
+        const size_t lds = sizeof(float) * (size_t)r10_lds(N, lpc, nw).total;
+        const dim3 grid((unsigned)batch), block(64 * nw);
+#define GF_R10B2(S, T)                                                                                                   \
+    do {                                                                                                                 \
+        gf_status st = opt_in_lds(ctx, r10_bwd_graph<S, true, T>, lds);                                                  \
+        if (st == GF_OK) st = opt_in_lds(ctx, r10_bwd_graph<S, false, T>, lds);                                          \
+        if (st != GF_OK) return st;                                                                                      \
+        if (accumulate) GF_LAUNCH(ctx, "r10_backward", (r10_bwd_graph<S, true, T>), grid, block, lds, G, A, dP, N, C, nw); \
+        else GF_LAUNCH(ctx, "r10_backward", (r10_bwd_graph<S, false, T>), grid, block, lds, G, A, dP, N, C, nw);          \
+    } while (0)
+#define GF_R10B(S)                   \
+    do {                             \
+        if (nw <= 12) GF_R10B2(S, 768); \
+        else GF_R10B2(S, 1024);      \
+    } while (0)
+        if (slots <= 1) GF_R10B(1);
+        else if (slots <= 2) GF_R10B(2);
+        else if (slots <= 3) GF_R10B(3);
+        else GF_R10B(4);
+#undef GF_R10B2
+#undef GF_R10B
         return GF_OK;
     }
     if (K == 10) return fam_backward_launch<10>(ctx, G, A, dP, N, C, batch, accumulate);

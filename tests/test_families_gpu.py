@@ -78,6 +78,37 @@ def test_r4_slab_kernels_vs_oracle(gf, oracle, N, C):
         assert rel_err(da[g], ref + d0[g]) <= REL_TOL_F32
 
 
+@pytest.mark.parametrize("N,C", [(1, 4), (2, 8), (3, 8), (5, 16), (8, 32), (17, 32), (24, 32), (32, 32), (16, 64), (15, 64), (7, 128), (9, 12), (24, 64)])
+def test_r10_graph_stream_kernels_vs_oracle_and_table_kernels(gf, oracle, monkeypatch, N, C):
+    """RisiContraction_10 on the one-stream-per-graph kernels of round 4 (r10_fwd_graph / r10_bwd_graph: P read once, the three pair
+    marginals never stored as tables): one to four position slots per lane, odd N (a last wave with one row), ragged last slots,
+    768- and 1024-thread builds, write-only and accumulating backward, symmetric / weighted / signed adjacencies -- against the fp64
+    oracle's spec form (RisiContraction_10.h:94-142) slice by slice, and against the table kernels (GF_FAM10_GRAPH=0).  (9, 12) and
+    (24, 64) are outside the kernels' shapes (C / 4 not a power of two; six slots): both legs run the table kernels."""
+    rng = np.random.default_rng(10000 + 10 * N + C)
+    B = 3
+    P = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
+    A = np.stack([adjacency(k, N, rng) for k in ("sym01", "weighted", "signed")])
+    G = f32exact(rng.uniform(-1, 1, (B, N, N, 10, C)))
+    d0 = f32exact(rng.uniform(-1, 1, (B, N, N, N, C)))
+    got = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("GF_FAM10_GRAPH", mode)
+        out = host(gf.contract_forward(dev(P), dev(A), 10))
+        dw = host(gf.contract_backward(dev(G), dev(A), 10))
+        da = dev(d0)
+        gf.contract_backward(dev(G), dev(A), 10, dP=da, accumulate=True)
+        got[mode] = (out, dw, host(da))
+    out, dw, da = got["2"]
+    for g in range(B):
+        assert rel_err_slices(out[g], oracle.contract_forward(10, P[g], A[g])) <= REL_TOL_F32
+        ref = oracle.contract_backward(10, G[g], A[g])
+        assert rel_err(dw[g], ref) <= REL_TOL_F32
+        assert rel_err(da[g], ref + d0[g]) <= REL_TOL_F32
+    for x, y in zip(got["2"], got["0"]):
+        assert rel_err(x, y) <= REL_TOL_F32
+
+
 def test_structural_50_collapse_on_gpu(gf):
     """The reference's own known-answer (tests/test_RisiContraction_50.cpp): 50 slices -> the 18 recorded groups,
     bit-identical, for integer tensors symmetric in (b,c) and a symmetric zero-diagonal 0/1 adjacency."""
