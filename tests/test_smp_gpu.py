@@ -973,6 +973,42 @@ def test_smp_2d_ver7_wiring_at_32_channels_runs_the_matrix_pipe_contractions(gf,
     assert rel_err(a[2], b[2]) <= TOL_GRAD
 
 
+def test_smp_2d_ver6_wiring_runs_the_graph_stream_contractions(gf, monkeypatch):
+    """The SMP_2D_ver6 wiring (RisiContraction_10 per node, op by op, [C][10 C] weights) on a batch whose size buckets hold hundreds of
+    nodes: the driver hands gf_contract_*_f32 one uniform batch per receptive-field size, which from 96 nodes on runs r10_fwd_graph /
+    r10_bwd_graph (round 4).  Predictions, features and every parameter gradient against the same step on the table kernels
+    (GF_FAM10_GRAPH=0), which the goldens of tests/golden/smp.npz pin to the real SMP_2D_ver6."""
+    from graphflow_amd.smp import SMPOmega
+    L, C, F, D, cap = 2, 32, 5, 2, 10
+    mols, tg = [], []
+    for seed in range(160):
+        adj, feat, t = synthetic_molecule(5000 + seed, nV=6 + seed % 5)
+        mols.append((adj, feat))
+        tg.append(t)
+
+    def step():
+        net = SMPOmega(L, C, F, D, cap, True, nContractions=10, custom_matmul=True)
+        rng = np.random.default_rng(8)
+        params = f32exact(rng.uniform(-1, 1, net.n_params) / np.sqrt(10 * C))
+        net.prepare(mols)
+        p = dev(params)
+        pred, loss, feat = net.forward(p, dev(np.array(tg)))
+        grads = torch.empty(net.n_params, device="cuda")
+        net.backward(p, grads)
+        out = [x.cpu().numpy().astype(np.float64) for x in (pred, feat, grads)]
+        net.close()
+        return out
+
+    a = step()
+    monkeypatch.setenv("GF_FAM10_GRAPH", "0")
+    b = step()
+    note("ver6_c32_graph_streams_vs_tables", pred=rel_err(a[0], b[0]), feat=rel_err(a[1], b[1]), grads=rel_err(a[2], b[2]))
+    assert np.isfinite(a[2]).all() and np.abs(a[2]).max() > 0
+    assert not np.array_equal(a[2], b[2])   # (the switch switches something)
+    assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[1], b[1]) <= TOL_FWD
+    assert rel_err(a[2], b[2]) <= TOL_GRAD
+
+
 @pytest.mark.parametrize("C,fused,cap,coul", [(64, True, 29, False), (8, False, 6, False), (16, True, 12, True)])
 def test_device_level_tables_equal_the_host_built_ones(gf, monkeypatch, C, fused, cap, coul):
     """The rows-sized level tables (reduced adjacency, gated row sums, (tot, tr), selection maps, inverse maps) are built on the
