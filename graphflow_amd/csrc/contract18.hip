@@ -771,7 +771,12 @@ struct FastShape {
 bool fast_shape(int N, int C, const void *p0, const void *p1, const void *p2, FastShape *fs) {
     if (C % 4 != 0) return false;
     if (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15u) return false;
-    const int lpc = (C <= 16) ? 4 : (C <= 32) ? 8 : 16;
+    // lanes per position = the channel window a workgroup works on (4 lpc channels).  Beyond eight wave loads per slab row the window is
+    // halved instead of leaving the slab kernels (round 4, second session): N <= 64 runs on 32-channel windows (128-byte pieces of a
+    // position's record: still whole cache lines), N <= 128 on 16-channel windows -- the thread-per-element kernels that used to take
+    // over at N > 32 (C = 64) moved 77 GB/s against 3.6 TB/s on the slabs (cfg2 shape at N = 40: 28 ms against 0.42 ms at N = 32).
+    int lpc = (C <= 16) ? 4 : (C <= 32) ? 8 : 16;
+    while (lpc > 4 && (N + 64 / lpc - 1) / (64 / lpc) > 8) lpc >>= 1;
     const int ppw = 64 / lpc;
     const int ni = (N + ppw - 1) / ppw;
     if (ni > 8) return false;

@@ -44,7 +44,9 @@ def test_golden_vectors(gf, golden, generic):
 
 
 SHAPES = [(1, 4), (2, 8), (3, 64), (4, 4), (5, 12), (7, 64), (8, 16), (9, 32), (13, 64), (16, 8), (17, 64), (24, 32),
-          (29, 64), (32, 64), (33, 8), (6, 128), (5, 48), (6, 3), (4, 10), (10, 5), (12, 1), (40, 4)]
+          (29, 64), (32, 64), (33, 8), (6, 128), (5, 48), (6, 3), (4, 10), (10, 5), (12, 1), (40, 4),
+          # round 4: beyond eight wave loads per row the channel window is halved (fast_shape): 32-channel windows to N = 64, 16 to N = 128
+          (33, 64), (40, 64), (50, 64), (64, 64), (45, 32), (70, 32), (100, 16), (128, 8), (129, 4)]
 
 
 @pytest.mark.parametrize("N,C", SHAPES)
@@ -64,7 +66,8 @@ def test_forward_backward_vs_oracle(gf, oracle, N, C):
     dP_acc = dev(d0)
     gf.contract_backward(dev(G), dev(A), 18, dP=dP_acc, accumulate=True)
     dP_acc = host(dP_acc)
-    for g in range(B):
+    # ... and big N to fewer graphs (N = 50: 18 s per graph and channel); beyond that the generic kernels below are the checker
+    for g in range(B if N <= 40 else 1 if N <= 50 else 0):
         ref_out = oracle.contract_forward(18, P[g][..., fs], A[g])
         assert rel_err_slices(out[g][..., fs], ref_out) <= REL_TOL_F32
         ref_dp = oracle.contract_backward(18, G[g][..., fs], A[g])
