@@ -83,6 +83,7 @@ void dist_teardown(gf_ctx *ctx);  // gf_dist.hip
 gf_status ensure_ws(gf_ctx *ctx, size_t bytes) { return grow(ctx, &ctx->ws, &ctx->ws_bytes, bytes, false); }
 gf_status ensure_stage(gf_ctx *ctx, size_t bytes) { return grow(ctx, &ctx->stage, &ctx->stage_bytes, bytes, false); }
 gf_status ensure_pinned(gf_ctx *ctx, size_t bytes) { return grow(ctx, &ctx->pinned, &ctx->pinned_bytes, bytes, true); }
+gf_status ensure_repack(gf_ctx *ctx, size_t bytes) { return grow(ctx, &ctx->repack, &ctx->repack_bytes, bytes, false); }
 
 gf_status opt_in_lds_fn(gf_ctx *ctx, const void *kernel, size_t bytes) {
     if (bytes > 160 * 1024) return fail(ctx, GF_ERR_UNSUPPORTED, "kernel needs %zu B of LDS (> 160 KiB)", bytes);
@@ -543,6 +544,7 @@ gf_status gf_ctx_destroy(gf_ctx *ctx) {
     gf::dist_teardown(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->repack) (void)hipFree(ctx->repack);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)gf::resolve_timers(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -627,11 +629,60 @@ size_t gf_contract_workspace_bytes(int K, int N, int C, int batch) {
     }
 }
 
+}  // extern "C"
+
+// ---- channel counts that are not a multiple of four (the reference's own tests run nChanels = 10) ---------------------------------
+// The slab / stream / matrix-pipe kernels of every family move 16 bytes per lane over the channel axis; at C % 4 != 0 the entry points
+// used to fall to the thread-per-element kernels (RisiContraction_18 at N = 32, C = 10, batch 256: 13.0 ms forward + backward, against
+// 0.57 ms at C = 12).  Now the operands are REPACKED: rows of C floats -> rows of C4 = 4 ceil(C / 4) floats with zero fill (the
+// contractions act channel by channel, a zero channel stays zero), the family's kernels run at C4 on the copies, and the result is cropped
+// back (+= for the accumulating backward).  Two extra passes over operand and result, in the context's own scratch.
+// GF_OPT_R18_GENERIC_KERNELS keeps RisiContraction_18 on the generic kernels at any C (the parity tests' second implementation).
+namespace gf {
+__global__ void repack_channels(const float *__restrict__ src, float *__restrict__ dst, size_t rows, int C, int C4) {   // dst[row][C4] <- src[row][C] | 0
+    const size_t total = rows * (size_t)C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / C4;
+        const int c = (int)(i - row * C4);
+        dst[i] = c < C ? src[row * C + c] : 0.f;
+    }
+}
+__global__ void crop_channels(const float *__restrict__ src, float *__restrict__ dst, size_t rows, int C, int C4, int accumulate) {   // dst[row][C] (+)= src[row][C4]
+    const size_t total = rows * (size_t)C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / C;
+        const int c = (int)(i - row * C);
+        const float v = src[row * C4 + c];
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+static bool repack_wanted(const gf_ctx *ctx, int K, int C) { return C % 4 != 0 && !(K == 18 && ctx->r18_generic); }
+// in: [rows_in][C] operand, out: [rows_out][C] result; run(in4, out4) computes at C4 on the repacked copies
+template <typename Run>
+static gf_status with_repacked_channels(gf_ctx *ctx, const float *in, size_t rows_in, float *out, size_t rows_out, int C, int accumulate, Run run) {
+    const int C4 = (C + 3) & ~3;
+    const size_t n_in = align_up(rows_in * (size_t)C4, 64), n_out = align_up(rows_out * (size_t)C4, 64);
+    gf_status st = ensure_repack(ctx, sizeof(float) * (n_in + n_out) + 256);
+    if (st != GF_OK) return st;
+    float *in4 = static_cast<float *>(ctx->repack), *out4 = in4 + n_in;
+    GF_LAUNCH(ctx, "repack_channels", repack_channels, dim3(cast_grid(rows_in * (size_t)C4)), dim3(256), 0, in, in4, rows_in, C, C4);
+    st = run(in4, out4, C4);
+    if (st != GF_OK) return st;
+    GF_LAUNCH(ctx, "crop_channels", crop_channels, dim3(cast_grid(rows_out * (size_t)C)), dim3(256), 0, out4, out, rows_out, C, C4, accumulate ? 1 : 0);
+    return GF_OK;
+}
+}  // namespace gf
+
+extern "C" {
+
 gf_status gf_contract_forward_f32(gf_ctx *ctx, int K, const float *P, const float *A, float *Out, int N, int C,
                                   int batch) {
     gf_status st = gf::check_contract_args(ctx, K, P, A, Out, N, C, batch);
     if (st != GF_OK || batch == 0) return st;
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (gf::repack_wanted(ctx, K, C))
+        return gf::with_repacked_channels(ctx, P, (size_t)batch * N * N * N, Out, (size_t)batch * N * N * K, C, 0,
+                                          [&](const float *P4, float *Out4, int C4) { return gf_contract_forward_f32(ctx, K, P4, A, Out4, N, C4, batch); });
     switch (K) {
         case 18: return gf::r18_forward(ctx, P, A, Out, N, C, batch);
         default: return gf::family_forward(ctx, K, P, A, Out, N, C, batch);
@@ -643,6 +694,9 @@ gf_status gf_contract_backward_f32(gf_ctx *ctx, int K, const float *G, const flo
     gf_status st = gf::check_contract_args(ctx, K, G, A, dP, N, C, batch);
     if (st != GF_OK || batch == 0) return st;
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (gf::repack_wanted(ctx, K, C))   // (write-only at C4, then dP (+)= the cropped result)
+        return gf::with_repacked_channels(ctx, G, (size_t)batch * N * N * K, dP, (size_t)batch * N * N * N, C, accumulate,
+                                          [&](const float *G4, float *dP4, int C4) { return gf_contract_backward_f32(ctx, K, G4, A, dP4, N, C4, batch, 0); });
     switch (K) {
         case 18: return gf::r18_backward(ctx, G, A, dP, N, C, batch, accumulate);
         default: return gf::family_backward(ctx, K, G, A, dP, N, C, batch, accumulate);

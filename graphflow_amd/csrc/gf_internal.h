@@ -25,6 +25,8 @@ struct gf_ctx {
     size_t ws_bytes = 0;
     void *stage = nullptr;  // device staging for the host-pointer (mode A) entry points
     size_t stage_bytes = 0;
+    void *repack = nullptr;  // device scratch of the contraction entry points: operands repacked to a multiple of four channels
+    size_t repack_bytes = 0;
     void *pinned = nullptr;  // pinned host staging for mode A
     size_t pinned_bytes = 0;
     char err[512] = {0};
@@ -51,6 +53,7 @@ gf_status fail(gf_ctx *ctx, gf_status st, const char *fmt, ...);
 bool poison_buffers();  // GF_POISON=1 (gf_capi.hip)
 gf_status ensure_ws(gf_ctx *ctx, size_t bytes);
 gf_status ensure_stage(gf_ctx *ctx, size_t bytes);
+gf_status ensure_repack(gf_ctx *ctx, size_t bytes);
 gf_status ensure_pinned(gf_ctx *ctx, size_t bytes);
 // kernels that want more than the default 32 KiB dynamic-LDS window opt in once per (device, kernel), process-wide, raise-only
 gf_status opt_in_lds_fn(gf_ctx *ctx, const void *kernel, size_t bytes);
