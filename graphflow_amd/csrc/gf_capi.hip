@@ -632,9 +632,8 @@ size_t gf_contract_workspace_bytes(int K, int N, int C, int batch) {
 }  // extern "C"
 
 // ---- channel counts that are not a multiple of four (the reference's own tests run nChanels = 10) ---------------------------------
-// The slab / stream / matrix-pipe kernels of every family move 16 bytes per lane over the channel axis; at C % 4 != 0 the entry points
-// used to fall to the thread-per-element kernels (RisiContraction_18 at N = 32, C = 10, batch 256: 13.0 ms forward + backward, against
-// 0.57 ms at C = 12).  Now the operands are REPACKED: rows of C floats -> rows of C4 = 4 ceil(C / 4) floats with zero fill (the
+// The slab kernels of RisiContraction_18 move 16 bytes per lane over the channel axis; at C % 4 != 0 the entry points used to fall to
+// the thread-per-element kernels (N = 32, C = 10, batch 256: 13.0 ms forward + backward, against 0.57 ms at C = 12).  Now the operands are REPACKED: rows of C floats -> rows of C4 = 4 ceil(C / 4) floats with zero fill (the
 // contractions act channel by channel, a zero channel stays zero), the family's kernels run at C4 on the copies, and the result is cropped
 // back (+= for the accumulating backward).  Two extra passes over operand and result, in the context's own scratch.
 // GF_OPT_R18_GENERIC_KERNELS keeps RisiContraction_18 on the generic kernels at any C (the parity tests' second implementation).
@@ -656,7 +655,9 @@ __global__ void crop_channels(const float *__restrict__ src, float *__restrict__
         dst[i] = accumulate ? dst[i] + v : v;
     }
 }
-static bool repack_wanted(const gf_ctx *ctx, int K, int C) { return C % 4 != 0 && !(K == 18 && ctx->r18_generic); }
+// (RisiContraction_18 only: the table kernels of _10 / _50 and the thread kernels of _4 lose less at scalar channel loads than the two
+//  extra passes cost -- SMP_2D_ver6 / ver7 steps at C = 10 measured 10.1 -> 12.0 and 24.3 -> 28.2 ms with their operands repacked)
+static bool repack_wanted(const gf_ctx *ctx, int K, int C) { return K == 18 && C % 4 != 0 && !ctx->r18_generic; }
 // in: [rows_in][C] operand, out: [rows_out][C] result; run(in4, out4) computes at C4 on the repacked copies
 template <typename Run>
 static gf_status with_repacked_channels(gf_ctx *ctx, const float *in, size_t rows_in, float *out, size_t rows_out, int C, int accumulate, Run run) {
