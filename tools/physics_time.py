@@ -34,3 +34,16 @@ for mode in ("1", "0"):
     print("towers %d C %d batch %d nKept %d GF_SMP_PAD_CHANNELS=%s: %.2f ms per forward + backward (%.0f samples/s), |g| max %.3e" %
           (towers, Cn, B, nKept, mode, ms, B / ms * 1e3, float(g.abs().max())), flush=True)
     net.close()
+if os.environ.get("GF_PHYS_KERNELS"):   # per-kernel times of one step of the last configuration's twin (default padding)
+    os.environ["GF_SMP_PAD_CHANNELS"] = "1"
+    net = SMPModel(L, Cn, cap, [F] * towers, nKept=nKept)
+    p = torch.tensor(np.random.default_rng(1).uniform(-0.2, 0.2, net.n_params).astype(np.float32), device="cuda")
+    g = torch.empty(net.n_params, device="cuda")
+    net.prepare(mols, mols if towers == 2 else None)
+    net.set_mode(True)
+    net.forward(p, tg); net.backward(p, g)
+    net.ctx.set_timing(True)
+    net.forward(p, tg); net.backward(p, g)
+    torch.cuda.synchronize()
+    for k, v in sorted(net.ctx.timings().items(), key=lambda kv: -kv[1][0])[:14]:
+        print("  %-28s %8.3f ms  %d launches" % (k, v[0], v[1]))
