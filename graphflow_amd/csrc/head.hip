@@ -38,16 +38,33 @@ __global__ void head_inner(const float *__restrict__ h, const float *__restrict_
         dy[m] = t - tg;
     }
 }
-// dw[f] += sum_m dy[m] h[m][f]  (one workgroup, molecules in order: deterministic);  dh[m][f] = dy[m] w[f]
-__global__ void head_inner_bwd(const float *__restrict__ dy, const float *__restrict__ h, const float *__restrict__ w,
-                               float *__restrict__ dw, float *__restrict__ dh, int width, int n) {
-    for (int f = threadIdx.x; f < width; f += blockDim.x) {
+// dw[f] += sum_m dy[m] h[m][f];  dh[m][f] = dy[m] w[f].  One workgroup (deterministic): thread = (column f, molecule group g), group g
+// takes the molecules g, g + ng, ... and the groups' partial sums are folded in group order through LDS.  (Round 4: with one thread per
+// column -- ~30 columns -- the 1024 dependent loads of a batch took 205 us of a 4.6 ms physics step.)
+__global__ __launch_bounds__(256) void head_inner_bwd(const float *__restrict__ dy, const float *__restrict__ h, const float *__restrict__ w,
+                                                      float *__restrict__ dw, float *__restrict__ dh, int width, int n) {
+    __shared__ float part[256];
+    for (int f0 = 0; f0 < width; f0 += 256) {   // (wider than 256 columns: in chunks)
+        const int wc = (width - f0 < 256) ? width - f0 : 256;   // columns of this chunk
+        const int ng = 256 / wc;                                // molecule groups
+        const int g = threadIdx.x / wc, f = f0 + threadIdx.x % wc;
         float acc = 0.f;
-        for (int m = 0; m < n; ++m) {
-            acc += dy[m] * h[(size_t)m * width + f];
-            dh[(size_t)m * width + f] = dy[m] * w[f];
+        if (g < ng) {
+            const float wf = w[f];
+            for (int m = g; m < n; m += ng) {
+                const float d = dy[m];
+                acc += d * h[(size_t)m * width + f];
+                dh[(size_t)m * width + f] = d * wf;
+            }
         }
-        dw[f] += acc;
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if (g == 0) {
+            float t = part[threadIdx.x];
+            for (int k = 1; k < ng; ++k) t += part[k * wc + threadIdx.x];
+            dw[f] += t;
+        }
+        __syncthreads();
     }
 }
 

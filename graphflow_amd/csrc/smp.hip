@@ -1808,8 +1808,11 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
         for (int l = 0; l <= L; ++l) {
             const gf_smp::DevLevel &d = s->lv[l];
             const int Cc = s->cfg.level_channels(l);
-            GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes, dim3(gf::grid_for((size_t)B.level[l].nNodes * Cc)), dim3(256), 0, d.f,
-                      d.node_s, d.node_row, d.sh, d.vf, Cc, (size_t)B.level[l].nNodes * Cc);
+            if (Cc % 4 == 0 && Cc <= 1024)   // (workgroup per node, float4 lanes: a padded tower's levels -- 105 -> see DESIGN 4.6)
+                GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(B.level[l].nNodes), dim3(256), 0, d.f, d.node_s, d.node_row, d.sh, d.vf, Cc);
+            else
+                GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes, dim3(gf::grid_for((size_t)B.level[l].nNodes * Cc)), dim3(256), 0, d.f,
+                          d.node_s, d.node_row, d.sh, d.vf, Cc, (size_t)B.level[l].nNodes * Cc);
             GF_LAUNCH(ctx, "smp_level_feature", gf::level_feature_sum, dim3(B.nMol), dim3(64), 0, d.vf, s->mol_ptr, d.node_of_vertex, s->g,
                       Cc, width, off);
             off += Cc;
