@@ -964,6 +964,12 @@ static bool smp_tables_fold_vectors(const gf_smp *s) {
 }
 
 // the eight-lanes-per-position classes (C % 32 == 0, C % 64 != 0): a wave load covers eight positions, NI = 1, 2, 4 for s <= 8, 16, 32
+// launch names of tables-forward: one per template instantiation, as rocprof lists kernels by symbol (the bench's "dominant kernel" is the
+// symbol with the largest time per step; it sums these four for the kernel's own roofline line)
+template <int NI>
+constexpr const char *tables_fwd_name() {
+    return NI == 1 ? "smpf_tables_fwd_ni1" : NI == 2 ? "smpf_tables_fwd_ni2" : NI == 4 ? "smpf_tables_fwd_ni4" : "smpf_tables_fwd_ni8";
+}
 template <int NI>
 gf_status launch_tables_fwd_w8(gf_smp *s, int l, const SizeClass &c) {
     gf_ctx *ctx = s->ctx;
@@ -979,7 +985,7 @@ gf_status launch_tables_fwd_w8(gf_smp *s, int l, const SizeClass &c) {
     gf_status st = opt_in_lds(ctx, smp_tables_fwd_w<NI, true, true, 8>, lds_v);
     if (st != GF_OK) return st;
     const int flags = d.t_zeros ? 1 : 0;
-    GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true, true, 8>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3(kThreads), lds_v,
+    GF_LAUNCH(ctx, tables_fwd_name<NI>(), (smp_tables_fwd_w<NI, true, true, 8>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3(kThreads), lds_v,
               s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
               flags, flags ? d.rowflag : (const unsigned char *)nullptr, d.St);
     return GF_OK;
@@ -1003,15 +1009,15 @@ gf_status launch_tables_fwd_w(gf_smp *s, int l, const SizeClass &c) {
         const size_t lds_v = ((lds + 15) & ~(size_t)15) + 16 + (size_t)nwv * ((size_t)c.smax * 512 + 512);
         gf_status st = opt_in_lds(ctx, smp_tables_fwd_w<NI, true, true>, lds_v);
         if (st != GF_OK) return st;
-        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds_v,
+        GF_LAUNCH(ctx, tables_fwd_name<NI>(), (smp_tables_fwd_w<NI, true, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds_v,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
                   flags, flags ? d.rowflag : (const unsigned char *)nullptr, d.St);
     } else if ((C & 63) == 0)
-        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
+        GF_LAUNCH(ctx, tables_fwd_name<NI>(), (smp_tables_fwd_w<NI, true>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
                   flags, flags ? d.rowflag : (const unsigned char *)nullptr, (float *)nullptr);
     else
-        GF_LAUNCH(ctx, "smpf_tables_fwd", (smp_tables_fwd_w<NI, false>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
+        GF_LAUNCH(ctx, tables_fwd_name<NI>(), (smp_tables_fwd_w<NI, false>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3((NI >= GF_TF_WIDE ? 2 : 1) * kThreads), lds,
                   s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
                   flags, (const unsigned char *)nullptr, (float *)nullptr);
     return GF_OK;
