@@ -517,6 +517,22 @@ __global__ __launch_bounds__(256) void build_level_rows(const int *__restrict__ 
 // map of a (neighbour, position) pair is a scan of at most 32 entries by its own thread (no per-neighbour barriers); the maps stay
 // in LDS for the presence masks, the transposed-row table and the gather offsets of combine-forward.
 // cons_of_pair[e] = index of pair e in its source's consumer list (the inverse of cons_pair: invert_cons_pair).
+// The per-consumer entries of a level's consumer lists from the list itself (round 4, second session; the host wrote them in a pass of
+// its own -- phase D of gfsmp::build_batch, 2 ms of a 1024-molecule prepare -- and uploaded 24 bytes per pair): consumer c is the pair
+// e = cons_pair[c] = (node n, index a); its slab of the promoted tensor, its size, its first row and a.
+__global__ void build_consumer_entries(const long long *__restrict__ cons_pair, const int *__restrict__ pair_node, const int *__restrict__ node_s,
+                                       const long long *__restrict__ node_pair, const long long *__restrict__ node_row,
+                                       const long long *__restrict__ node_p, long long *__restrict__ cons_slab, int *__restrict__ cons_s,
+                                       long long *__restrict__ cons_row, int *__restrict__ cons_a, long long pairs) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= pairs) return;
+    const long long e = cons_pair[c];
+    const int n = pair_node[e], sz = node_s[n], a = (int)(e - node_pair[n]);
+    cons_slab[c] = node_p[n] + (long long)a * sz * sz;
+    cons_s[c] = sz;
+    cons_row[c] = node_row[n];
+    cons_a[c] = a;
+}
 __global__ void invert_cons_pair(const long long *__restrict__ cons_pair, int *__restrict__ cons_of_pair, long long pairs) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < pairs) cons_of_pair[cons_pair[c]] = (int)c;
@@ -1373,11 +1389,18 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         UP(d.quad_order, h.quad_order);
         UP(d.pair_node, h.pair_node);
         UP(d.pair_src_s, h.pair_src_s);
-        UP(d.cons_s, h.cons_s);
-        UP(d.cons_a, h.cons_a);
+        if (B.device_tables) {   // (filled by build_consumer_entries below)
+            st = gf::upload(s, &d.cons_s, nullptr, (size_t)h.pairs);
+            if (st == GF_OK) st = gf::upload(s, &d.cons_a, nullptr, (size_t)h.pairs);
+            if (st != GF_OK) return st;
+        } else {
+            UP(d.cons_s, h.cons_s);
+            UP(d.cons_a, h.cons_a);
+        }
         st = gf::upload(s, &d.pair_src_pair, &h.pair_src_pair[0], h.pair_src_pair.size());
         if (st != GF_OK) return st;
-        st = gf::upload(s, &d.cons_row, h.cons_row.empty() ? nullptr : &h.cons_row[0], h.cons_row.size());
+        st = B.device_tables ? gf::upload(s, &d.cons_row, nullptr, (size_t)h.pairs)
+                             : gf::upload(s, &d.cons_row, h.cons_row.empty() ? nullptr : &h.cons_row[0], h.cons_row.size());
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.cons_pair, h.cons_pair.empty() ? nullptr : &h.cons_pair[0], h.cons_pair.size());
         if (st != GF_OK) return st;
@@ -1392,8 +1415,15 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         if (st != GF_OK) return st;
         st = gf::upload(s, &d.cons_ptr, &h.cons_ptr[0], h.cons_ptr.size());
         if (st != GF_OK) return st;
-        st = gf::upload(s, &d.cons_slab, h.cons_slab.empty() ? nullptr : &h.cons_slab[0], h.cons_slab.size());
+        st = B.device_tables ? gf::upload(s, &d.cons_slab, nullptr, (size_t)h.pairs)
+                             : gf::upload(s, &d.cons_slab, h.cons_slab.empty() ? nullptr : &h.cons_slab[0], h.cons_slab.size());
         if (st != GF_OK) return st;
+        if (B.device_tables && h.pairs) {
+            hipStream_t upst = s->upload ? s->upload : ctx->stream;
+            hipLaunchKernelGGL(gf::build_consumer_entries, dim3((unsigned)((h.pairs + 255) / 256)), dim3(256), 0, upst, d.cons_pair, d.pair_node, d.node_s,
+                               d.node_pair, d.node_row, d.node_p, d.cons_slab, d.cons_s, d.cons_row, d.cons_a, (long long)h.pairs);
+            GF_LAUNCH_CHECK(ctx, "build_consumer_entries");
+        }
         st = gf::upload(s, &d.cons_inv_off, h.cons_inv_off.empty() ? nullptr : &h.cons_inv_off[0], h.cons_inv_off.size());
         if (st != GF_OK) return st;
         if (B.device_tables) {

@@ -493,10 +493,17 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         tvec<int64_t> &cons_pair = lv.cons_pair;
         cons_pair.assign((size_t)lv.pairs, 0);
         for (int64_t e = 0; e < lv.pairs; ++e) cons_pair[(size_t)cursor[(size_t)pair_src_node[(size_t)e]]++] = e;
-        lv.cons_slab.assign((size_t)lv.pairs, 0);
-        lv.cons_s.assign((size_t)lv.pairs, 0);
-        lv.cons_row.assign((size_t)lv.pairs, 0);
-        lv.cons_a.assign((size_t)lv.pairs, 0);
+        if (out->device_tables) {   // (the device derives the per-consumer entries from cons_pair: smp.hip, build_consumer_entries)
+            lv.cons_slab.clear();
+            lv.cons_s.clear();
+            lv.cons_row.clear();
+            lv.cons_a.clear();
+        } else {
+            lv.cons_slab.assign((size_t)lv.pairs, 0);
+            lv.cons_s.assign((size_t)lv.pairs, 0);
+            lv.cons_row.assign((size_t)lv.pairs, 0);
+            lv.cons_a.assign((size_t)lv.pairs, 0);
+        }
         lv.cons_inv_off.assign((size_t)lv.pairs, 0);
         int64_t inv_total = 0;
         for (int w = 0; w < prev.nNodes; ++w)
@@ -518,7 +525,8 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         lv.qrec_total = q;
     });
     const std::chrono::steady_clock::time_point t_C = std::chrono::steady_clock::now();
-    parallel_for(L * totalV, [&](int k) {   // phase D: per source node -- its consumers' inverse maps
+    if (!out->device_tables)
+    parallel_for(L * totalV, [&](int k) {   // phase D: per source node -- its consumers' entries and inverse maps (host-built tables only)
         const int l = 1 + k / totalV, w = k % totalV;
         LevelLayout &lv = out->level[l];
         const LevelLayout &prev = out->level[l - 1];
