@@ -1463,8 +1463,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                 if (C == 64 && l == L) {   // (the readout from panel partials and the per-panel channel maxima are C = 64 only)
                     st = gf::upload(s, &d.psum, nullptr, (size_t)np * 64);
                     if (st != GF_OK) return st;
-                } else if (C == 64) {
-                    st = gf::upload(s, &d.pmax, nullptr, (size_t)np * 64);
+                } else if (C == 64 || l < L) {   // (C = 32, second session: [panels][32], below the top level)
+                    st = gf::upload(s, &d.pmax, nullptr, (size_t)np * C);
                     if (st != GF_OK) return st;
                 }
                 st = gf::upload(s, &d.dzmax, nullptr, h.quad_node.size() * 64);

@@ -1551,8 +1551,11 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
         if (d.dzmax && d.row_max) {   // per-channel maxima of f_{l-1} and of this level's dz (combine-backward's per-workgroup maxima)
             GF_HIP_TRY(ctx, hipMemsetAsync(words, 0, sizeof(unsigned) * 64, ctx->stream));
             // (combine-backward's maxima: one row of a window's width per workgroup -- 32-channel windows at C = 32)
-            st = smp_wgrad_channel_maxima_ld(ctx, pv.f, (long long)s->lay.level[l - 1].rows, C, d.dzmax, (long long)h.quad_node.size(),
-                                             smp_half_window(C) ? 32 : 64, C, words);
+            // (the largest |f_{l-1}| per channel from the per-panel maxima combine-forward of the level below left behind, as at C = 64 --
+            //  f_{l-1} itself was read for them: 94 MB at cfg3's level 3 -- or from f_0)
+            const bool pm = pv.pmax && pv.pmax_ready;
+            st = smp_wgrad_channel_maxima_ld(ctx, pm ? pv.pmax : pv.f, pm ? (long long)pv.fwd_npanels : (long long)s->lay.level[l - 1].rows, C, d.dzmax,
+                                             (long long)h.quad_node.size(), smp_half_window(C) ? 32 : 64, C, words);
             if (st != GF_OK) return st;
             chan = words;
         }
