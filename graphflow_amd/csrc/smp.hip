@@ -295,15 +295,16 @@ __global__ __launch_bounds__(256) void readout_nodes_v(const float *__restrict__
 
 // the same sums from the row-panel partials the top level's combine-forward left behind (C = 64): thread per (node, channel),
 // the node's panels in order
+template <int CB>   // channels: 64 or 32
 __global__ __launch_bounds__(256) void readout_nodes_panels(const float *__restrict__ psum, const int *__restrict__ node_panel, int nodes,
                                                             int npanels, float *__restrict__ sh, float *__restrict__ vf) {
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+    const int n = blockIdx.x * (256 / CB) + threadIdx.x / CB, c = threadIdx.x % CB;
     if (n >= nodes) return;
     const int p0 = node_panel[n], p1 = (n + 1 < nodes) ? node_panel[n + 1] : npanels;
     float t = 0.f;
-    for (int p = p0; p < p1; ++p) t += psum[(size_t)p * 64 + c];
-    sh[(size_t)n * 64 + c] = t;
-    vf[(size_t)n * 64 + c] = lrelu(t);
+    for (int p = p0; p < p1; ++p) t += psum[(size_t)p * CB + c];
+    sh[(size_t)n * CB + c] = t;
+    vf[(size_t)n * CB + c] = lrelu(t);
 }
 
 // one workgroup per molecule: g = sum_v vf (SumVectors), y = <g, W> (InnerProduct.h:39-46), loss (SquaredLoss.h:45-53)
@@ -1460,8 +1461,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                 UP(d.node_panel, h.node_panel);
                 st = gf::upload(s, &d.fwd_pan, nullptr, (size_t)np);
                 if (st != GF_OK) return st;
-                if (C == 64 && l == L) {   // (the readout from panel partials and the per-panel channel maxima are C = 64 only)
-                    st = gf::upload(s, &d.psum, nullptr, (size_t)np * 64);
+                if (l == L) {   // (the top level: the readout's partial sums)
+                    st = gf::upload(s, &d.psum, nullptr, (size_t)np * C);
                     if (st != GF_OK) return st;
                 } else if (C == 64 || l < L) {   // (C = 32, second session: [panels][32], below the top level)
                     st = gf::upload(s, &d.pmax, nullptr, (size_t)np * C);
@@ -1856,7 +1857,10 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
     }
     const gfsmp::LevelLayout &top = B.level[L];
     if (C == 64 && s->lv[L].psum_ready) {
-        GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels, dim3((unsigned)((top.nNodes + 3) / 4)), dim3(256), 0, s->lv[L].psum,
+        GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<64>, dim3((unsigned)((top.nNodes + 3) / 4)), dim3(256), 0, s->lv[L].psum,
+                  s->lv[L].node_panel, top.nNodes, s->lv[L].fwd_npanels, s->sh, s->vf);
+    } else if (C == 32 && s->lv[L].psum_ready) {
+        GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<32>, dim3((unsigned)((top.nNodes + 7) / 8)), dim3(256), 0, s->lv[L].psum,
                   s->lv[L].node_panel, top.nNodes, s->lv[L].fwd_npanels, s->sh, s->vf);
     } else if (C % 4 == 0 && C <= 1024) {
         GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(top.nNodes), dim3(256), 0, s->lv[L].f, s->lv[L].node_s,
