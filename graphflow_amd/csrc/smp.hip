@@ -1461,10 +1461,11 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                 UP(d.node_panel, h.node_panel);
                 st = gf::upload(s, &d.fwd_pan, nullptr, (size_t)np);
                 if (st != GF_OK) return st;
-                if (l == L) {   // (the top level: the readout's partial sums)
+                if (l == L || s->cfg.physics) {   // (the top level -- every level of a tower: the readout's partial sums)
                     st = gf::upload(s, &d.psum, nullptr, (size_t)np * C);
                     if (st != GF_OK) return st;
-                } else if (C == 64 || l < L) {   // (C = 32, second session: [panels][32], below the top level)
+                }
+                if (l < L) {   // (below the top level: the per-panel channel maxima the level above scales its weight-gradient operands with)
                     st = gf::upload(s, &d.pmax, nullptr, (size_t)np * C);
                     if (st != GF_OK) return st;
                 }
@@ -1796,8 +1797,7 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)nV * C)), dim3(256), 0, s->lv[0].f,
               (const float *)nullptr, C, (size_t)nV * C);
-    s->lv[L].psum_ready = false;
-    for (int l = 0; l <= L; ++l) s->lv[l].pmax_ready = false;
+    for (int l = 0; l <= L; ++l) s->lv[l].psum_ready = s->lv[l].pmax_ready = false;
     if (s->fused) {
         if (s->wbound && C == 64) GF_HIP_TRY(ctx, hipMemsetAsync(s->wbound, 0, sizeof(unsigned) * gf::smp_wgrad_bound_words() * (size_t)(L + 1), ctx->stream));
         st = gf::smp_fused_stack_all(s, K);
@@ -1839,7 +1839,13 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
         for (int l = 0; l <= L; ++l) {
             const gf_smp::DevLevel &d = s->lv[l];
             const int Cc = s->cfg.level_channels(l);
-            if (Cc % 4 == 0 && Cc <= 1024)   // (workgroup per node, float4 lanes: a padded tower's levels -- 105 -> see DESIGN 4.6)
+            if (l >= 1 && d.psum && d.psum_ready && Cc == 64)   // (a fused level left its row panels' column sums behind)
+                GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<64>, dim3((unsigned)((B.level[l].nNodes + 3) / 4)), dim3(256), 0, d.psum,
+                          d.node_panel, B.level[l].nNodes, d.fwd_npanels, d.sh, d.vf);
+            else if (l >= 1 && d.psum && d.psum_ready && Cc == 32)
+                GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<32>, dim3((unsigned)((B.level[l].nNodes + 7) / 8)), dim3(256), 0, d.psum,
+                          d.node_panel, B.level[l].nNodes, d.fwd_npanels, d.sh, d.vf);
+            else if (Cc % 4 == 0 && Cc <= 1024)   // (workgroup per node, float4 lanes: a padded tower's levels)
                 GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(B.level[l].nNodes), dim3(256), 0, d.f, d.node_s, d.node_row, d.sh, d.vf, Cc);
             else
                 GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes, dim3(gf::grid_for((size_t)B.level[l].nNodes * Cc)), dim3(256), 0, d.f,

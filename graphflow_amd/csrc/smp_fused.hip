@@ -1473,7 +1473,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     if ((C == 64 || C == 32) && ocols == 2 && d.fwd_pan && (long long)rows * 512 < 0x3fffffffll)
     {   // wave per row panel, the adjacency product on the matrix pipe; the top level leaves the readout's partial sums behind, the
         // others the per-channel maxima the level above scales its weight-gradient operands with
-        float *psum = l == s->cfg.nLevels ? d.psum : nullptr;
+        float *psum = (l == s->cfg.nLevels || s->cfg.physics) ? d.psum : nullptr;   // (a tower reads every level out)
         st = smp_combine_fwd_panels_c64(s, l, O, bl, psum, d.pmax);
         if (st == GF_OK && psum) s->lv[l].psum_ready = true;
         if (st == GF_OK && d.pmax) s->lv[l].pmax_ready = true;
