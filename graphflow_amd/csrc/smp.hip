@@ -754,6 +754,16 @@ __global__ void level_feature_sum(const float *__restrict__ vf, const int *__res
     }
 }
 
+// the same gradient as ONE vector per node (a fused level's combine-backward adds it to every row of the node itself)
+__global__ void level_feature_nodevec(const float *__restrict__ dfeat, const float *__restrict__ sh, const int *__restrict__ node_mol,
+                                      float *__restrict__ out, int C, int width, int off, size_t total) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const size_t n = i / C;
+        out[i] = dfeat[(size_t)node_mol[n] * width + off + c] * (sh[i] > 0.f ? 1.f : kAlpha);
+    }
+}
+
 // reverse: df_l[n][i][j][:] (+)= dfeat[mol(n)][off + :] * lrelu'(sh_l[n][:])   (SumVectors -> LeakyReLU -> ShrinkTensor::backward)
 __global__ void level_feature_backward(const float *__restrict__ dfeat, const float *__restrict__ sh, const int *__restrict__ node_mol,
                                        const int *__restrict__ node_s, const long long *__restrict__ node_row, float *__restrict__ df,
@@ -1357,6 +1367,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             st = gf::upload(s, &d.sh, nullptr, (size_t)h.nNodes * Cl);
             if (st != GF_OK) return st;
             st = gf::upload(s, &d.vf, nullptr, (size_t)h.nNodes * Cl);
+            if (st != GF_OK) return st;
+            st = gf::upload(s, &d.dshl, nullptr, (size_t)h.nNodes * Cl);
             if (st != GF_OK) return st;
             st = gf::upload(s, &d.node_of_vertex, &B.node_of_vertex[l][0], B.node_of_vertex[l].size());
             if (st != GF_OK) return st;
@@ -1975,9 +1987,21 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
     };
     if (!dfeat) GF_LAUNCH(ctx, "smp_readout_dW", gf::readout_dW, dim3(1), dim3(1024), 0, s->dy, s->g, dW, C, B.nMol);
     const bool top_fused = !dfeat && s->fused && gf::smp_fused_supported(s, L);
+    // a tower's FUSED level takes its read-out gradient as one vector per node (combine-backward adds it to the node's rows): the pass
+    // that broadcast it into df_l -- a read-modify-write of every row -- only runs for op-by-op levels and level 0
+    auto level_fused = [&](int l) { return l >= 1 && s->fused && gf::smp_fused_supported(s, l); };
+    auto feature_nodevec = [&](int l) -> gf_status {
+        const gf_smp::DevLevel &dl = s->lv[l];
+        const size_t n = (size_t)B.level[l].nNodes * s->cfg.level_channels(l);
+        GF_LAUNCH(ctx, "smp_level_feature_bwd", gf::level_feature_nodevec, dim3(gf::grid_for(n)), dim3(256), 0, dfeat, dl.sh, dl.node_mol, dl.dshl,
+                  s->cfg.level_channels(l), fwidth, foff[l], n);
+        return GF_OK;
+    };
     if (dfeat) {
-        st = feature_backward(L, 0);
-        if (st != GF_OK) return st;
+        if (!level_fused(L)) {
+            st = feature_backward(L, 0);
+            if (st != GF_OK) return st;
+        }
     } else if (top_fused) {
         GF_LAUNCH(ctx, "smp_readout_bwd", gf::readout_backward_nodevec, dim3(gf::grid_for((size_t)top.nNodes * C)), dim3(256), 0, s->dy,
                   W, s->sh, s->top_node_mol, s->dsh, C, (size_t)top.nNodes * C);
@@ -1989,7 +2013,12 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
         const gfsmp::LevelLayout &h = B.level[l];
         const gf_smp::DevLevel &d = s->lv[l];
         if (s->fused && gf::smp_fused_supported(s, l)) {
-            st = gf::smp_fused_backward_level(s, l, K[l], dK[l], db[l], (l == L && top_fused) ? s->dsh : nullptr);
+            if (dfeat) {
+                st = feature_nodevec(l);
+                if (st != GF_OK) return st;
+            }
+            st = gf::smp_fused_backward_level(s, l, K[l], dK[l], db[l], dfeat ? s->lv[l].dshl : (l == L && top_fused) ? s->dsh : nullptr,
+                                              /*rows_too=*/dfeat && l < L);
             if (st != GF_OK) return st;
         } else {
         // dZ = dF * lrelu'(z) in place; db_l += column sums
@@ -2027,7 +2056,7 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
         if (diag_level && gf::smp_fused_gather_enabled(s, l)) {
             st = gf::smp_fused_gather_backward(s, l);
             if (st != GF_OK) return st;
-            if (dfeat) {  // (a tower: level l-1 is read out too)
+            if (dfeat && !level_fused(l - 1)) {  // (a tower: level l-1 is read out too)
                 st = feature_backward(l - 1, 1);
                 if (st != GF_OK) return st;
             }
@@ -2036,7 +2065,7 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
         GF_LAUNCH(ctx, "smp_promote_bwd", gf::promote_backward, dim3(B.level[l - 1].nNodes), dim3(256), 0, s->P, pv.df,
                   pv.node_s, pv.node_row, d.cons_ptr, d.cons_slab, d.cons_s, d.cons_inv_off, d.inv, s->cfg.level_channels(l - 1),
                   diag_level ? d.dFdc : (const float *)nullptr, pv.node_pair, pv.node_center);
-        if (dfeat) {  // level l-1 is read out too: its own contribution joins what its consumers sent down
+        if (dfeat && !level_fused(l - 1)) {  // level l-1 is read out too: its own contribution joins what its consumers sent down
             st = feature_backward(l - 1, 1);
             if (st != GF_OK) return st;
         }

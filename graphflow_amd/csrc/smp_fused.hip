@@ -710,7 +710,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
 // ---------------------------------------------------------------------------------------------------------------
 template <int LPC>
 __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restrict__ F, const float *__restrict__ dF,
-                                                            const float *__restrict__ node_dF,  // [nodes][C] or null: dF is
+                                                            const float *__restrict__ node_dF,  // [nodes][C] or null: (dF null) dF is
                                                             // the same C-vector at every (x,y) of a node (readout broadcast)
                                                             const float *__restrict__ A, float *__restrict__ dO,
                                                             float *__restrict__ dVout, float *__restrict__ dSpart,
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                 const int xi = it / N, y = it - xi * N;
                 const size_t row = rowbase + (size_t)(W.x0 + xi) * N + y;
                 fv[u] = ld4(F + row * C + fc);
-                g[u] = node_dF ? gnode : ld4(dF + row * C + fc);
+                g[u] = !node_dF ? ld4(dF + row * C + fc) : dF ? gnode + ld4(dF + row * C + fc) : gnode;   // (a tower's level below the top: both)
             }
         }
 #pragma unroll
@@ -1695,10 +1695,12 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
 }
 
 // df_l is given in d.df; produces dP in s->P, accumulates dK_l and db_l; the caller then runs the promotion backward.
-gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl, const float *node_df) {
+gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl, const float *node_df, bool rows_too) {
     gf_ctx *ctx = s->ctx;
     const gfsmp::LevelLayout &h = s->lay.level[l];
     const gf_smp::DevLevel &d = s->lv[l];
+    // combine-backward reads dF rows, a per-node vector (the readout's broadcast), or -- a tower's level below the top -- both
+    const float *dfrows = (node_df && !rows_too) ? nullptr : d.df;
     const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
     float *dO = d.Q + (size_t)h.rows * T_COLS * C;
     gf_status st;
@@ -1710,14 +1712,14 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         st = opt_in_lds(ctx, smp_combine_bwd<8>, lds);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<8>), dim3((unsigned)(h.quad_node.size() * nw8)), dim3(kThreads), lds, d.f,
-                  d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
+                  dfrows, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
                   nw8, d.rsum, smp_compact_o(s) ? 2 : O_COLS, dzmax);
     } else {
         const size_t lds = std::max(combine_lds<16>(h.buckets.back().s), sizeof(float) * ((size_t)adj_lds_floats(h.buckets.back().s) + 1024));
         st = opt_in_lds(ctx, smp_combine_bwd<16>, lds);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
-                  d.df, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
+                  dfrows, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
                   nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS, dzmax);
     }
     (void)Kl;

@@ -136,6 +136,7 @@ struct gf_smp {
         int *trow = nullptr;  // [rows] row of (e, x) for row (x, e) of the same node (compact O layout of the fused C = 64 level)
         int4 *tf_recs = nullptr;  // [2 nNodes] records of tables-forward in launch order (build_tf_records)
         float *psum = nullptr;     // top level, C = 64: [fwd_npanels][64] column sums of the row panels of f_L (readout)
+        float *dshl = nullptr;     // towers: [nodes][C] gradient of the level's read-out per node (the fused level's combine-backward adds it)
         bool psum_ready = false;   // ... written by this forward pass
         // per-channel maxima for the weight gradients' column exponents (smp_level_c64_split.hip: smp_wgrad_column_bounds), C = 64:
         float *pmax = nullptr;     // [fwd_npanels][64] largest |f_l| of every row panel, left by combine-forward (levels below the top)
@@ -213,7 +214,7 @@ bool smp_fused_supported(const gf_smp *s, int l);
 gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float *bl);
 gf_status smp_fused_ensure_zero_fill(gf_smp *s, int l);
 // node_df != nullptr (top level): df_l is the same C-vector at every position of a node, given as [nodes][C]
-gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl, const float *node_df);
+gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl, float *dbl, const float *node_df, bool rows_too = false);
 gf_status smp_fused_gather_backward(gf_smp *s, int l);
 bool smp_fused_gather_enabled(const gf_smp *s, int l);
 gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
