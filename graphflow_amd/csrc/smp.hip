@@ -1810,6 +1810,7 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
     GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)nV * C)), dim3(256), 0, s->lv[0].f,
               (const float *)nullptr, C, (size_t)nV * C);
     for (int l = 0; l <= L; ++l) s->lv[l].psum_ready = s->lv[l].pmax_ready = false;
+    s->bwd_consumed = false;
     if (s->fused) {
         if (s->wbound && C == 64) GF_HIP_TRY(ctx, hipMemsetAsync(s->wbound, 0, sizeof(unsigned) * gf::smp_wgrad_bound_words() * (size_t)(L + 1), ctx->stream));
         st = gf::smp_fused_stack_all(s, K);
@@ -1962,6 +1963,8 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
     if (dp && accumulate)
         return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: accumulate with a communicator would re-sum earlier global sums "
                                          "(gf_smp_set_grad_allreduce(smp, 0) and reduce once at the end instead)");
+    if (s->bwd_consumed)   // (an op-by-op level's reverse sweep overwrites its Q with dQ: the forward state is gone)
+        return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: a second reverse sweep needs a new gf_smp_forward (op-by-op levels keep dQ in place of Q)");
     s->dp_grads = nullptr;
     if (dp) {
         if (!s->ev_grad) GF_HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_grad, hipEventDisableTiming));
@@ -2021,6 +2024,7 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
                                               /*rows_too=*/dfeat && l < L);
             if (st != GF_OK) return st;
         } else {
+            s->bwd_consumed = true;
         // dZ = dF * lrelu'(z) in place; db_l += column sums
             const int Cc = s->cfg.level_channels(l), Cq = s->cfg.level_channels(l - 1);  // (equal unless a physics tower)
             const int rpb = 1024;

@@ -1559,6 +1559,10 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
             if (st != GF_OK) return st;
             chan = words;
         }
+        if (!chan) {   // (host-built tables: the exact column bounds are maxima over ALL of T -- the absent blocks need their zeros)
+            st = smp_fused_ensure_zero_fill(s, l);
+            if (st != GF_OK) return st;
+        }
         st = smp_wgrad_partials_direct_c32(ctx, T, dO, d.rowscale, rows, splits, ws, d.trow, d.trowf, words, chan, (float)h.buckets.back().s,
                                            d.row_max);
         if (st != GF_OK) return st;

@@ -89,6 +89,7 @@ constexpr int kPadMaxLevels = 15;   // levels a padded model's layout map holds 
 struct gf_smp {
     gf_ctx *ctx = nullptr;
     gfsmp::Config cfg;    // what the device computes with: nChanels padded to 32 / 64 / a multiple of 4 (gf_smp_create, round 4)
+    bool bwd_consumed = false;   // an op-by-op level's reverse sweep has overwritten its Q since the last forward
     gfsmp::Config ucfg;   // the caller's configuration: the layout of parameters, gradients, features and activations at the C ABI
     float *pad_p = nullptr, *pad_g = nullptr, *pad_feat = nullptr;   // padded copies (cfg.nChanels != ucfg.nChanels)
     size_t pad_feat_n = 0;

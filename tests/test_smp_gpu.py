@@ -64,6 +64,15 @@ def test_reference_goldens_one_molecule_at_a_time(gf, golden, fused):
         assert rel_err(grads, c["grads"]) <= TOL_GRAD, tag
 
 
+def test_reference_goldens_with_host_built_level_tables(gf, golden, monkeypatch):
+    """The same goldens with the rows-sized level tables built by the host (GF_PREP_DEVICE_TABLES=0).  The C = 10 models are computed at
+    32 padded channels, whose weight-gradient kernel then takes its column exponents from exact column maxima over T and dO (the device
+    builder's statistics words are absent): maxima over ALL of T, so the structurally absent blocks -- which nobody writes while every
+    reader masks them -- must have their zeros first.  (Found in round 4's second session: gradients off by 0.5 on the toy molecules.)"""
+    monkeypatch.setenv("GF_PREP_DEVICE_TABLES", "0")
+    test_reference_goldens_one_molecule_at_a_time(gf, golden, True)
+
+
 def test_batch_equals_sum_of_molecules(gf, golden):
     """The four toy molecules of tests/test_SMP_omega.cpp as ONE batch: per-molecule outputs unchanged, gradient = sum
     (what sum_gradients accumulates in BatchLearn, SMP_omega.h:808-820)."""
@@ -312,6 +321,34 @@ def test_backward_needs_a_forward_with_targets(gf):
         net.backward(p, g[:-1])
     with pytest.raises(TypeError):
         net.forward(p.double())
+
+
+def test_a_second_backward_after_op_by_op_levels_is_refused(gf):
+    """An op-by-op level's reverse sweep overwrites its Q with dQ (MatMul::backward's first operand in place): a second gf_smp_backward
+    without a new forward would differentiate garbage.  It is an error, not a wrong gradient; the fused levels keep their forward state
+    and may be swept again (backward(accumulate) after backward)."""
+    from graphflow_amd.smp import SMPOmega
+    F, D, C, L, cap = 5, 2, 8, 2, 8
+    mols = [synthetic_molecule(s, nV=7)[:2] for s in range(3)]
+    p = dev(smp_params(C, F, D, L, 1))
+    t = dev(np.arange(3))
+    for fused in (False, True):
+        net = SMPOmega(L, C, F, D, cap)
+        net.set_fused(fused)
+        net.prepare(mols)
+        net.forward(p, t)
+        g = torch.empty(net.n_params, device="cuda")
+        net.backward(p, g)
+        if fused:
+            g2 = g.clone()
+            net.backward(p, g2, accumulate=True)
+            assert float((g2 - 2 * g).abs().max()) <= 1e-5 * float(g.abs().max())
+        else:
+            with pytest.raises(Exception, match="second reverse sweep"):
+                net.backward(p, g)
+            net.forward(p, t)
+            net.backward(p, g)   # (fine again after a forward)
+        net.close()
 
 
 def test_vertex_permutation_invariance(gf):
