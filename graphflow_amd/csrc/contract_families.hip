@@ -328,10 +328,17 @@ __global__ __launch_bounds__(MAXT) void r10_fwd_graph(const float *__restrict__ 
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) sbc[rb][i] = zero;
-    vf4 cur[2][SLOTS], nxt[2][SLOTS];
-    load_rows(0, cur);
+    // (the 1024-thread build -- N > 24 -- has 128 registers per lane: no second row set, its sixteen waves hide the latency instead;
+    //  with the prefetch it spilled 71 registers and ran no faster than the table kernels)
+    constexpr bool PREFETCH = MAXT <= 768 || SLOTS <= 2;
+    vf4 cur[2][SLOTS], nxt[PREFETCH ? 2 : 1][PREFETCH ? SLOTS : 1];
+    if constexpr (PREFETCH) load_rows(0, cur);
     for (int a = 0; a < N; ++a) {
-        if (a + 1 < N) load_rows(a + 1, nxt);   // (in flight over the sums and the barrier of a)
+        if constexpr (PREFETCH) {
+            if (a + 1 < N) load_rows(a + 1, nxt);   // (in flight over the sums and the barrier of a)
+        } else {
+            load_rows(a, cur);
+        }
         vf4 sac[SLOTS], vap = zero;
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) sac[i] = zero;
@@ -368,10 +375,12 @@ __global__ __launch_bounds__(MAXT) void r10_fwd_graph(const float *__restrict__ 
             for (int w = 1; w < nw; ++w) t += pva[((size_t)buf * nw + w) * lpc + lane];
             sVa[(size_t)a * lpc + lane] = t;
         }
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int i = 0; i < SLOTS; ++i) cur[rb][i] = nxt[rb][i];
+                for (int i = 0; i < SLOTS; ++i) cur[rb][i] = nxt[rb][i];
+        }
     }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {   // S_bc tot, Vb
