@@ -78,13 +78,23 @@ def latest_profile(name):
 
 
 # ---- the timed region (shared by the headline workload and the `extra` ones) ------------------------------------------
-def timed_run(torch, ctx, step, steps, warmup, fence, notiming=False):
+def timed_run(torch, ctx, step, steps, warmup, fence, notiming=False, repeats=1, quiesce=None):
     """warmup untimed steps, then an identical pass of `steps` steps with every launch bracketed by HIP events OUTSIDE the
     timed region (the per-kernel table: the events cost about 5 % of a 70-launch step, they keep neighbouring kernels from
     overlapping), then the timed region proper, in which only the dominant kernel is timed live -- its average duration is
-    what roofline.achieved is computed from.  Returns (elapsed seconds of this rank, {kernel: (total ms, launches)})."""
+    what roofline.achieved is computed from.  The timed region runs `repeats` times (exactly `steps` steps each, every one bracketed
+    by fence = barrier + synchronize on both sides): the caller reports the median and the spread.
+    quiesce: a data-parallel run's bounded wait for its collectives (gf_dist_quiesce) ahead of every blocking synchronize.
+    Returns ([elapsed seconds of this rank per repeat], {kernel: (total ms, launches)})."""
+    def sync():
+        if quiesce is not None:
+            quiesce()
+        torch.cuda.synchronize()
+
     for _ in range(warmup):
         step()
+    if quiesce is not None:
+        quiesce()
     fence()
     timers, dominant = {}, None
     if not notiming:
@@ -92,25 +102,35 @@ def timed_run(torch, ctx, step, steps, warmup, fence, notiming=False):
         ctx.set_timing(True)
         for _ in range(steps):
             step()
-        torch.cuda.synchronize()
+        sync()
         timers = ctx.timings()
         ctx.set_timing(False)
-        dominant = max(timers, key=lambda k: timers[k][0])
+        dominant = max((k for k in timers if not k.startswith("rccl_")), key=lambda k: timers[k][0])
         ctx.set_timing_filter(dominant)
         fence()
         ctx.set_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    fence()
+    elapsed = []
+    for _ in range(max(1, repeats)):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        elapsed.append(time.perf_counter() - t0)
+        fence()
     if not notiming:
         live = ctx.timings()
         ctx.set_timing(False)
         ctx.set_timing_filter(None)
-        timers[dominant] = live[dominant]
+        n = max(1, repeats)
+        timers[dominant] = (live[dominant][0] / n, live[dominant][1] // n)   # (per repeat: the table's other entries are one pass of `steps` steps)
+        if "rccl_allreduce" in live:
+            timers["rccl_allreduce"] = (live["rccl_allreduce"][0] / n, live["rccl_allreduce"][1] // n)
     return elapsed, timers
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
 
 # ---- cfg2 / cfg5: one contraction family, forward + backward ---------------------------------------------------------------
@@ -273,6 +293,20 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
             for k in ("gemm_nn", "gemm_nt", "gemm_tn"):
                 add(kf, k, 18 * unit)
                 add(kb, k, 4 * (18 * R * C + R * C))
+    # ... and the level's small kernels (per-(node, x) vectors, per-node scalars, the compact diagonal rows of the level below, the
+    # partial images of the weight gradients): bytes that must move per step, so that no kernel above 1 % of the step goes unpriced
+    if fused and c64 and split:
+        pairs = [net.level_pairs(l) for l in range(L + 1)]
+        for l in range(1, L + 1):
+            n_l, R, _ = sizes[l]
+            pr, pp = pairs[l], pairs[l - 1]
+            add(kb, "smpf_diag_gather", 4 * (2 * pp * C + 2 * pp * C))                     # f_{l-1}[w][p,p], [p,c_w] in; Fdc out
+            add(kb, "smpf_small_nn", 4 * (4 * pr * C + pr * C + 4 * n_l * C + n_l * C + 2 * pp * C + 2 * pp * C))   # Vt -> Vout, St -> Sout, Fdc -> Gc
+            add(kb, "smpf_small_nt", 4 * (pr * C + 4 * pr * C + n_l * C + 4 * n_l * C + 2 * pp * C + 2 * pp * C))   # dVout -> dVt, dSout -> dSt, dGc -> dFdc
+            add(kb, "smpf_small_tn", 4 * (4 * pr * C + pr * C + 4 * n_l * C + n_l * C + 4 * pp * C))                # Vt, dVout, St, dSout, Fdc, dGc in
+            add(kb, "smpf_diag_gather_bwd", 4 * (2 * present[l] * C + 2 * pp * C))          # dU[(a, b)], dU[(b, a)] of the rows with data in; dGc out
+            add(kb, "smpf_reduce_pairs", 4 * (2 * pr * C + n_l * C))                        # dSpart, dbpart in; dSout out
+            add(kb, "smpf_fold", 4 * (256 * 8 * C * C + 18 * C * C))                         # <= 256 row-range images of the eight products + the small ones
     step_bytes = sum(kb.values())
     step_flops = sum(kf.values())
     work = {"levels": [{"nodes": n, "rows_sum_s2": r, "ppos_sum_s3": s, "rows_with_data": p, "rows_covered": q} for (n, r, s), p, q in zip(sizes, present, covered)],
@@ -319,6 +353,15 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
                 if line.startswith(real[dom]) and "MFMA busy" in line:
                     roof["mfma_busy_pmc"] = float(line.rsplit("MFMA busy", 1)[1])
         roof["kernel"] = dom
+        # the same ranking with the template instantiations of ONE kernel summed (tables-forward runs as four size classes): the family
+        # with the largest time per step and its own fraction, beside the by-symbol line above
+        fam_dom = max((k for k in tot if not k.startswith("rccl_")), key=tot.get)
+        fam_bytes = kb.get(fam_dom, 0)
+        roof["dominant_by_family"] = {"kernel": fam_dom, "ms_per_step": round(tot[fam_dom], 4),
+                                      "achieved": round(fam_bytes / (tot[fam_dom] * 1e-3) / 1e9, 1) if fam_bytes else None, "unit": "GB/s",
+                                      "frac": round(fam_bytes / (tot[fam_dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if fam_bytes else None}
+        unpriced = {k: v for k, v in tot.items() if k not in kb and k not in kf and not k.startswith("rccl_")}
+        roof["unpriced_kernels_ms_per_step"] = round(sum(unpriced.values()), 4)   # kernels without an entry in the byte model (each < 1 % of the step)
         roof["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
         roof["kernel_ms_per_step"].update({k: round(v, 3) for k, v in sym.items() if k.startswith("smpf_tables_fwd_")})   # (its instantiations)
         roof["launches_per_step"] = round(sum(v[1] for v in timers.values() if v[1] > steps / 2) / steps, 1) if steps else None
@@ -399,6 +442,8 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
             n.prepare(batches[k % 4][0])
             n.forward(p, batches[k % 4][1])
             n.backward(p, grads)
+        if ctx.dist_world > 1:
+            ctx.dist_quiesce()
         torch.cuda.synchronize()
         ready = [threading.Semaphore(0) for _ in range(NH)]
         free = [threading.Semaphore(1) for _ in range(NH)]
@@ -431,6 +476,8 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
             cur.backward(p, grads)
             net.adam_step(p, grads, 1e-5, B * world)
             free[h].release()   # (gf_smp_prepare waits for the handle's own last launch before it recycles its buffers)
+        if ctx.dist_world > 1:
+            ctx.dist_quiesce()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         for th in threads:
@@ -499,9 +546,12 @@ def run_plumbing(args, world, rank):
     if rank == 0:
         print(json.dumps({"metric": "plumbing check (no kernels ran, nothing measured)", "value": 0.0, "unit": "molecules/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "none",
                           "config": {"workload": "plumbing: launcher + sharding + gloo all-reduce of %d floats" % n_params,
-                                     "shard_of_rank0": [lo, hi]}}), flush=True)
+                                     "shard_of_rank0": [lo, hi], "scaling_requested": args.scaling,
+                                     "per_rank_units": (args.batch or 8192) // world if args.scaling == "strong" else (args.batch or 1024)},
+                          "collective": {"rccl_ranks_seen": None, "gloo_ranks_seen": dist.get_world_size() if dist is not None else 1, "expected": world,
+                                         "allreduces_per_step": 1, "allreduce_ms_per_step": None}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -512,6 +562,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the line reports the median and the spread")
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--batch", type=int, default=0, help="graphs / molecules per GPU (default 256 for cfg2/cfg5, 1024 for cfg3)")
     ap.add_argument("--N", type=int, default=32)
@@ -563,8 +614,12 @@ def main():
         step, finish, cpu, meta, keep = setup_smp(args, torch, gf, dev, world, rank, ctx)
 
     notiming = bool(os.environ.get("GF_BENCH_NOTIMING"))
-    elapsed, timers = timed_run(torch, ctx, step, args.steps, args.warmup, fence, notiming)
-    elapsed = gd.max_over_ranks(elapsed, dist, dev)
+    quiesce = ctx.dist_quiesce if (world > 1 or force) else None   # bounded wait for the collectives ahead of every blocking synchronize
+    reps, timers = timed_run(torch, ctx, step, args.steps, args.warmup, fence, notiming, repeats=args.repeats, quiesce=quiesce)
+    # every repeat is the contract's timed region (exactly --steps steps between barrier + synchronize): MAX over ranks per repeat, the
+    # line's value is the MEDIAN repeat, the spread rides beside it
+    reps = [gd.max_over_ranks(e, dist, dev) for e in reps]
+    elapsed = median(reps)
 
     line = None
     if rank == 0:
@@ -574,8 +629,19 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                 "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": meta["config"], "roofline": finish(timers, ms_per_step, args.steps)}
+        line["timed_region"] = {"repeats": len(reps), "steps_each": args.steps, "reported": "median",
+                                "ms_per_step_min": round(1e3 * min(reps) / args.steps, 4), "ms_per_step_median": round(ms_per_step, 4),
+                                "ms_per_step_max": round(1e3 * max(reps) / args.steps, 4)}
         if ctx.dist_world > 1 or force:
             line["config"]["collective"] = "gf_dist_* (RCCL) world %d" % ctx.dist_world
+            ar = timers.get("rccl_allreduce")
+            # the exchange as the library saw it: ranks in ITS communicator (not torch's), and the all-reduces' own HIP-event time on
+            # the communicator's stream -- they run beside the reverse sweep, so this is not a share of ms_per_step
+            line["collective"] = {"rccl_ranks_seen": ctx.dist_world, "expected": world,
+                                  "allreduces_per_step": round(ar[1] / args.steps, 2) if ar else None,
+                                  "allreduce_ms_per_step": round(ar[0] / args.steps, 4) if ar else None,
+                                  "watchdog_s": float(os.environ.get("GF_DIST_TIMEOUT_S", "180")),
+                                  "note": "HIP events around each ncclAllReduce on the communicator's stream (rank 0), live inside the timed region"}
         line["roofline"]["timing"] = ("HIP events on the kernels' stream: the dominant kernel live inside the timed region, "
                                       "the other kernels in an identical pass of the same steps just before it")
     # the sections below run on every rank that takes part in them, outside the timed region
@@ -603,7 +669,8 @@ def main():
                 # f16 pipe with two-half operands: the same step without the operand-width caveat, under the same clock
                 from graphflow_amd import _lib
                 ctx.set_option(_lib.GF_OPT_SMP_FP32_PRODUCTS, 1)
-                el, _ = timed_run(torch, ctx, step, 20, 3, torch.cuda.synchronize, True)
+                els, _ = timed_run(torch, ctx, step, 20, 3, torch.cuda.synchronize, True, repeats=3)
+                el = median(els)
                 ctx.set_option(_lib.GF_OPT_SMP_FP32_PRODUCTS, 0)
                 extra["cfg3_fp32_products"] = {"metric": meta["metric"], "value": round(meta["units_per_step"] * 20 / el, 1), "unit": meta["unit"],
                                                "steps": 20, "warmup": 3, "ms_per_step": round(1e3 * el / 20, 4),
@@ -619,7 +686,8 @@ def main():
                     a32.C = Cx
                     c32 = gf.Context(dev.index)
                     s32, _, _, m32, k32 = setup_smp(a32, torch, gf, dev, 1, 0, c32)
-                    el, _ = timed_run(torch, c32, s32, 20, 3, torch.cuda.synchronize, True)
+                    els, _ = timed_run(torch, c32, s32, 20, 3, torch.cuda.synchronize, True, repeats=3)
+                    el = median(els)
                     extra["cfg3_C%d" % Cx] = {"metric": m32["metric"], "value": round(m32["units_per_step"] * 20 / el, 1), "unit": m32["unit"],
                                               "steps": 20, "warmup": 3, "ms_per_step": round(1e3 * el / 20, 4), "workload": m32["config"]["workload"]}
                     if k32 is not None:
@@ -628,7 +696,8 @@ def main():
             for wl in ("cfg2", "cfg5"):
                 ectx = gf.Context(dev.index)
                 estep, efinish, ecpu, emeta, _ = setup_contraction(wl, args, torch, gf, dev, 1, 0, ectx)
-                el, et = timed_run(torch, ectx, estep, 20, 3, torch.cuda.synchronize, notiming)
+                els, et = timed_run(torch, ectx, estep, 20, 3, torch.cuda.synchronize, notiming, repeats=3)
+                el = median(els)
                 ems = 1e3 * el / 20
                 extra[wl] = {"metric": emeta["metric"], "value": round(emeta["units_per_step"] * 20 / el, 1), "unit": emeta["unit"],
                              "steps": 20, "warmup": 3, "ms_per_step": round(ems, 4), "workload": emeta["config"]["workload"],

@@ -10,7 +10,7 @@ import subprocess
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libgf_hip.so")
 
-GF_OK, GF_ERR_INVALID, GF_ERR_HIP, GF_ERR_NOMEM, GF_ERR_UNSUPPORTED = range(5)
+GF_OK, GF_ERR_INVALID, GF_ERR_HIP, GF_ERR_NOMEM, GF_ERR_UNSUPPORTED, GF_ERR_TIMEOUT = range(6)
 GF_OPT_R18_GENERIC_KERNELS = 1
 GF_OPT_SMP_FP32_PRODUCTS = 2
 GF_DIST_ID_BYTES = 128
@@ -41,6 +41,7 @@ PROTOTYPES = {
     "gf_dist_world": (C.c_int, [_vp]),
     "gf_dist_allreduce_sum_f32": (C.c_int, [_vp, _vp, C.c_size_t]),
     "gf_dist_broadcast_f32": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
+    "gf_dist_quiesce": (C.c_int, [_vp]),
     "gf_contract_forward_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "gf_contract_backward_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gf_contract_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -112,6 +113,7 @@ PROTOTYPES.update({
     "gf_smp_read_reduced_adjacency": (C.c_longlong, [_vp, _i, _i, _i, _vp, C.c_size_t]),
     "gf_smp_level_sizes": (_i, [_vp, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "gf_smp_level_present_rows": (C.c_longlong, [_vp, _i]),
+    "gf_smp_level_pairs": (C.c_longlong, [_vp, _i]),
     "gf_smp_level_covered_rows": (C.c_longlong, [_vp, _i]),
     "gf_stack_forward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
     "gf_stack_backward_f32": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),

@@ -103,9 +103,10 @@ gf_status opt_in_lds_fn(gf_ctx *ctx, const void *kernel, size_t bytes) {
     return GF_OK;
 }
 
-LaunchTimer::LaunchTimer(gf_ctx *c, const char *name) : ctx(c) {
+LaunchTimer::LaunchTimer(gf_ctx *c, const char *name, hipStream_t on) : ctx(c), stream(on ? on : c->stream) {
     if (!c->timing) return;
-    if (c->timing_filter[0] && std::strcmp(c->timing_filter, name) != 0) return;
+    // (the collectives of a data-parallel step are timed whatever the filter says: a few events per step on their own stream)
+    if (c->timing_filter[0] && std::strcmp(c->timing_filter, name) != 0 && std::strncmp(name, "rccl_", 5) != 0) return;
     for (size_t i = 0; i < c->timers.size(); ++i)
         if (c->timers[i].name == name || std::strcmp(c->timers[i].name, name) == 0) slot = (int)i;
     if (slot < 0) {
@@ -124,18 +125,19 @@ LaunchTimer::LaunchTimer(gf_ctx *c, const char *name) : ctx(c) {
     }
     start = ev[0];
     stop = ev[1];
-    (void)hipEventRecord(start, c->stream);
+    (void)hipEventRecord(start, stream);
 }
 
 void LaunchTimer::done() {
     if (slot < 0) return;
-    (void)hipEventRecord(stop, ctx->stream);
+    (void)hipEventRecord(stop, stream);
     ctx->pending.push_back({slot, start, stop});
 }
 
 gf_status resolve_timers(gf_ctx *ctx) {
     if (ctx->pending.empty()) return GF_OK;
     GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (dist_active(ctx)) GF_HIP_TRY(ctx, hipStreamSynchronize(dist_stream(ctx)));   // (the collectives' events live on that stream)
     for (const auto &p : ctx->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {

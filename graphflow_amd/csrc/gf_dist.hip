@@ -12,9 +12,13 @@
 // that never go multi-GPU, and fails loudly -- GF_ERR_UNSUPPORTED with the dlerror text -- when RCCL is asked for and absent.
 #include <dlfcn.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 #include <rccl/rccl.h>
 
@@ -40,6 +44,10 @@ struct gf_dist_state {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;  // the collectives' own stream (overlaps the rest of the reverse sweep)
+    // watchdog bookkeeping: what the last collective handed to RCCL was (a rank stuck behind a peer that never arrives says which
+    // exchange it is waiting in instead of hanging the job: gf_dist_quiesce, the join of gf_smp_backward)
+    unsigned long long issued = 0;
+    char stage[96] = {0};
 };
 
 namespace gf {
@@ -94,12 +102,49 @@ gf_status bind_rccl(gf_ctx *ctx, const RcclApi **out) {
 bool dist_active(const gf_ctx *ctx) { return ctx && ctx->dist && ctx->dist->comm; }
 hipStream_t dist_stream(gf_ctx *ctx) { return dist_active(ctx) ? ctx->dist->stream : nullptr; }
 
-gf_status dist_allreduce_on(gf_ctx *ctx, float *buf, size_t n, hipStream_t stream) {
+// seconds a rank waits for its peers before it gives up with GF_ERR_TIMEOUT (GF_DIST_TIMEOUT_S; 0 = wait for ever, as RCCL does)
+double dist_timeout_s() {
+    const char *e = std::getenv("GF_DIST_TIMEOUT_S");
+    if (e && e[0]) {
+        const double v = std::atof(e);
+        return v < 0.0 ? 0.0 : v;
+    }
+    return 180.0;
+}
+
+gf_status dist_allreduce_on(gf_ctx *ctx, float *buf, size_t n, hipStream_t stream, const char *what) {
     if (!dist_active(ctx)) return fail(ctx, GF_ERR_INVALID, "gf_dist: no communicator on this context (gf_dist_init)");
     if (n == 0) return GF_OK;
     gf_dist_state *d = ctx->dist;
+    d->issued += 1;
+    std::snprintf(d->stage, sizeof d->stage, "all-reduce #%llu of %zu floats (%s)", d->issued, n, what ? what : "gf_dist_allreduce_sum_f32");
+    LaunchTimer lt(ctx, "rccl_allreduce", stream);   // (HIP events on the collective's own stream when the context's timing is on)
     GF_NCCL_TRY(ctx, d, d->api->AllReduce(buf, buf, n, ncclFloat32, ncclSum, d->comm, stream));
+    lt.done();
     return GF_OK;
+}
+
+// Bounded wait for `ev` (recorded behind collectives): polls instead of blocking, so that a peer that never joins the exchange turns
+// into an error that names this rank, the world and the exchange, not into a job that hangs until its scheduler kills it.
+gf_status dist_wait_event(gf_ctx *ctx, hipEvent_t ev, const char *where) {
+    if (!dist_active(ctx) || !ev) return GF_OK;
+    const double limit = dist_timeout_s();
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return GF_OK;
+        if (e != hipErrorNotReady) return fail(ctx, GF_ERR_HIP, "gf_dist: %s: %s", where, hipGetErrorString(e));
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (limit > 0.0 && waited > limit) {
+            const gf_dist_state *d = ctx->dist;
+            return fail(ctx, GF_ERR_TIMEOUT, "gf_dist: rank %d of %d (device %d) waited %.0f s in %s; last collective handed to RCCL: %s "
+                                              "-- a peer rank never joined it (GF_DIST_TIMEOUT_S sets the limit, 0 = none)",
+                        d->rank, d->world, ctx->device, waited, where, d->stage[0] ? d->stage : "none");
+        }
+        if (++spins < 2000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
 }
 
 void dist_teardown(gf_ctx *ctx) {
@@ -145,7 +190,45 @@ gf_status gf_dist_init(gf_ctx *ctx, const void *id, int rank, int world) {
     }
     ncclUniqueId uid;
     std::memcpy(uid.internal, id, GF_DIST_ID_BYTES);
-    ncclResult_t r = d->api->CommInitRank(&d->comm, world, uid, rank);
+    // ncclCommInitRank returns when EVERY rank of the world has called it.  It runs on a helper thread so that a rank whose peers
+    // never arrive (a crashed process, a wrong world size, a rank left on another id) fails after GF_DIST_TIMEOUT_S with its rank and
+    // world in gf_last_error instead of blocking for ever; on a timeout the helper is left behind (it owns its state) and the
+    // context stays without a communicator.
+    struct InitJob {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false;
+        ncclResult_t r = ncclSuccess;
+        ncclComm_t comm = nullptr;
+    };
+    std::shared_ptr<InitJob> job = std::make_shared<InitJob>();
+    const RcclApi *api = d->api;
+    const int device = ctx->device;
+    std::thread([job, api, uid, rank, world, device]() {
+        (void)hipSetDevice(device);
+        ncclComm_t c = nullptr;
+        const ncclResult_t r = api->CommInitRank(&c, world, uid, rank);
+        std::lock_guard<std::mutex> g(job->m);
+        job->r = r;
+        job->comm = c;
+        job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> lk(job->m);
+        const double limit = gf::dist_timeout_s();
+        const bool ok = limit > 0.0 ? job->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return job->done; })
+                                    : (job->cv.wait(lk, [&] { return job->done; }), true);
+        if (!ok) {
+            st = fail(ctx, GF_ERR_TIMEOUT, "gf_dist_init: rank %d of %d (device %d) waited %.0f s in ncclCommInitRank -- not every rank of the world "
+                                           "called gf_dist_init with this id (GF_DIST_TIMEOUT_S sets the limit, 0 = none)",
+                      rank, world, ctx->device, limit);
+            delete d;
+            return st;
+        }
+    }
+    d->comm = job->comm;
+    const ncclResult_t r = job->r;
     if (r != ncclSuccess) {
         st = fail(ctx, GF_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, ctx->device, d->api->GetErrorString(r));
         delete d;
@@ -175,7 +258,27 @@ int gf_dist_world(const gf_ctx *ctx) { return gf::dist_active(ctx) ? ctx->dist->
 gf_status gf_dist_allreduce_sum_f32(gf_ctx *ctx, float *buf, size_t n) {
     if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
     if (!buf && n) return fail(ctx, GF_ERR_INVALID, "gf_dist_allreduce_sum_f32: null buffer");
-    return gf::dist_allreduce_on(ctx, buf, n, ctx->stream);
+    return gf::dist_allreduce_on(ctx, buf, n, ctx->stream, nullptr);
+}
+
+gf_status gf_dist_quiesce(gf_ctx *ctx) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!gf::dist_active(ctx)) return GF_OK;
+    // an event behind everything handed to the communicator's stream and behind the context's stream (collectives issued through
+    // gf_dist_allreduce_sum_f32 run there), waited for with the watchdog's limit
+    hipEvent_t ev = nullptr;
+    GF_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    gf_status st = GF_OK;
+    hipStream_t streams[2] = {ctx->dist->stream, ctx->stream};
+    for (int i = 0; i < 2 && st == GF_OK; ++i) {
+        if (hipEventRecord(ev, streams[i]) != hipSuccess) {
+            st = fail(ctx, GF_ERR_HIP, "gf_dist_quiesce: hipEventRecord failed");
+            break;
+        }
+        st = gf::dist_wait_event(ctx, ev, i == 0 ? "gf_dist_quiesce (the communicator's stream)" : "gf_dist_quiesce (the context's stream)");
+    }
+    (void)hipEventDestroy(ev);
+    return st;
 }
 
 gf_status gf_dist_broadcast_f32(gf_ctx *ctx, float *buf, size_t n, int root) {
@@ -185,6 +288,8 @@ gf_status gf_dist_broadcast_f32(gf_ctx *ctx, float *buf, size_t n, int root) {
     gf_dist_state *d = ctx->dist;
     if (root < 0 || root >= d->world) return fail(ctx, GF_ERR_INVALID, "gf_dist_broadcast_f32: root %d of %d", root, d->world);
     if (n == 0) return GF_OK;
+    d->issued += 1;
+    std::snprintf(d->stage, sizeof d->stage, "broadcast #%llu of %zu floats from rank %d", d->issued, n, root);
     GF_NCCL_TRY(ctx, d, d->api->Broadcast(buf, buf, n, ncclFloat32, root, d->comm, ctx->stream));
     return GF_OK;
 }

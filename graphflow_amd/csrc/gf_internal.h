@@ -63,7 +63,9 @@ gf_status opt_in_lds(gf_ctx *ctx, Kern kern, size_t bytes) {
 }
 // data-parallel hooks (gf_dist.hip): is a communicator attached, and the collective on an explicit stream
 bool dist_active(const gf_ctx *ctx);
-gf_status dist_allreduce_on(gf_ctx *ctx, float *buf, size_t n, hipStream_t stream);
+gf_status dist_allreduce_on(gf_ctx *ctx, float *buf, size_t n, hipStream_t stream, const char *what = nullptr);
+// bounded wait (GF_DIST_TIMEOUT_S) for an event recorded behind collectives: GF_ERR_TIMEOUT names the rank, the world and the exchange
+gf_status dist_wait_event(gf_ctx *ctx, hipEvent_t ev, const char *where);
 hipStream_t dist_stream(gf_ctx *ctx);
 
 #define GF_HIP_TRY(ctx, expr)                                                                      \
@@ -86,7 +88,8 @@ struct LaunchTimer {
     gf_ctx *ctx;
     int slot = -1;
     hipEvent_t start = nullptr, stop = nullptr;
-    LaunchTimer(gf_ctx *c, const char *name);
+    hipStream_t stream = nullptr;   // where the bracketed work runs (default: the context's stream)
+    LaunchTimer(gf_ctx *c, const char *name, hipStream_t on = nullptr);
     void done();
 };
 gf_status resolve_timers(gf_ctx *ctx);

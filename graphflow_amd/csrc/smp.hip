@@ -989,7 +989,10 @@ gf_status smp_dp_level_done(gf_smp *s, int l) {
     hipStream_t comm = dist_stream(ctx);
     GF_HIP_TRY(ctx, hipEventRecord(s->ev_grad, ctx->stream));
     GF_HIP_TRY(ctx, hipStreamWaitEvent(comm, s->ev_grad, 0));
-    return dist_allreduce_on(ctx, seg, n, comm);
+    char what[64];
+    if (l >= 1) std::snprintf(what, sizeof what, "gf_smp_backward: gradient segment [K_%d | b_%d%s]", l, l, l == c.nLevels ? " | W" : "");
+    else std::snprintf(what, sizeof what, "gf_smp_backward: gradient segment [H]");
+    return dist_allreduce_on(ctx, seg, n, comm, what);
 }
 }  // namespace gf
 
@@ -1483,6 +1486,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                 }
                 st = gf::upload(s, &d.dzmax, nullptr, h.quad_node.size() * 64);
                 if (st != GF_OK) return st;
+                st = gf::upload(s, &d.fsign, nullptr, (size_t)h.rows * (C / 32));
+                if (st != GF_OK) return st;
                 st = gf::upload(s, &d.fwd_pan_node, nullptr, (size_t)np);
                 if (st != GF_OK) return st;
                 st = gf::upload(s, &d.fwd_goff, nullptr, (size_t)h.rows);
@@ -1537,6 +1542,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                 if (st != GF_OK) return st;
                 hipLaunchKernelGGL(gf::invert_cons_pair, dim3((unsigned)((h.pairs + 255) / 256)), dim3(256), 0, up, d.cons_pair, d.cons_of_pair,
                                    (long long)h.pairs);
+                GF_LAUNCH_CHECK(ctx, "invert_cons_pair");
                 hipLaunchKernelGGL(gf::build_node_tables, dim3(h.nNodes), dim3(128), lds_nt, up, d.node_s, d.node_mol, d.node_row, d.node_pair,
                                    d.field, s->lv[l - 1].field, d.pair_src_pair, d.pair_src_s, s->mol_nv, s->mol_adj_off, s->mol_adj, s->mol_coul,
                                    d.adj, d.rsum, d.node_scale, d.pi, d.node_present, swp, d.cons_of_pair, d.cons_inv_off, d.inv,
@@ -1703,10 +1709,17 @@ __global__ void crop_gradients(const float *__restrict__ padded, float *__restri
 static bool padded_channels(const gf_smp *s) { return s->cfg.nChanels != s->ucfg.nChanels || s->cfg.uniform != s->ucfg.uniform; }
 // the handle's padded copies of the caller's parameters / of the gradients of the running step
 static gf_status pad_buffers(gf_smp *s) {
-    if (s->pad_p) return GF_OK;
+    if (s->pad_p && s->pad_g) return GF_OK;
     const size_t n = param_count(s->cfg);
-    GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->pad_p), n * sizeof(float)));
-    GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->pad_g), n * sizeof(float)));
+    if (!s->pad_p) GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->pad_p), n * sizeof(float)));
+    if (!s->pad_g && hipMalloc(reinterpret_cast<void **>(&s->pad_g), n * sizeof(float)) != hipSuccess) {
+        // (both or neither: a later call must not find pad_p set and skip the gradient buffer)
+        (void)hipGetLastError();
+        s->pad_g = nullptr;
+        (void)hipFree(s->pad_p);
+        s->pad_p = nullptr;
+        return fail(s->ctx, GF_ERR_NOMEM, "padded gradient buffer: %zu bytes", n * sizeof(float));
+    }
     return GF_OK;
 }
 static gf_status pad_params_now(gf_smp *s, const float *params) {
@@ -1809,7 +1822,7 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)nV * C)), dim3(256), 0, s->lv[0].f,
               (const float *)nullptr, C, (size_t)nV * C);
-    for (int l = 0; l <= L; ++l) s->lv[l].psum_ready = s->lv[l].pmax_ready = false;
+    for (int l = 0; l <= L; ++l) s->lv[l].psum_ready = s->lv[l].pmax_ready = s->lv[l].fsign_ready = false;
     s->bwd_consumed = false;
     if (s->fused) {
         if (s->wbound && C == 64) GF_HIP_TRY(ctx, hipMemsetAsync(s->wbound, 0, sizeof(unsigned) * gf::smp_wgrad_bound_words() * (size_t)(L + 1), ctx->stream));
@@ -1969,6 +1982,14 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
     if (dp) {
         if (!s->ev_grad) GF_HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_grad, hipEventDisableTiming));
         if (!s->ev_comm) GF_HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
+        // Watchdog: the join of the PREVIOUS sweep's all-reduces is waited for here, by polling under GF_DIST_TIMEOUT_S -- a rank whose
+        // peers never joined an exchange fails with its rank, the world and the segment in gf_last_error instead of queueing work
+        // behind a collective that will never finish.  (The host may still run a whole forward pass ahead of the device.)
+        if (s->dp_join_pending) {
+            s->dp_join_pending = false;
+            gf_status stw = gf::dist_wait_event(ctx, s->ev_comm, "the join of the previous gf_smp_backward's gradient all-reduces");
+            if (stw != GF_OK) return stw;
+        }
         s->dp_grads = grads;
     }
     struct DpScope {  // whatever the exit path, the next call starts clean
@@ -2092,6 +2113,7 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
         if (st != GF_OK) return st;
         GF_HIP_TRY(ctx, hipEventRecord(s->ev_comm, gf::dist_stream(ctx)));
         GF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_comm, 0));
+        s->dp_join_pending = true;
     }
     gf::mark_used(s);
     return GF_OK;
@@ -2124,6 +2146,10 @@ gf_status gf_smp_backward_features(gf_smp *s, const float *params, float *grads,
     gf_ctx *ctx = s->ctx;
     if (!s->cfg.physics) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward_features needs a physics tower");
     if (!s->forwarded) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward before gf_smp_forward");
+    if (!params && !grads && s->own_p) {   // (the handle-owned model, as the unpadded path and gf_smp_backward take it)
+        params = s->own_p;
+        grads = s->own_g;
+    }
     if (!params || !grads) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: null argument");
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     gf_status st = gf::pad_params_now(s, params);
@@ -2244,6 +2270,10 @@ gf_status gf_smp_level_sizes(const gf_smp *s, int level, long long *nodes, long 
     if (rows) *rows = h.rows;
     if (ppos) *ppos = h.ppos;
     return GF_OK;
+}
+long long gf_smp_level_pairs(const gf_smp *s, int level) {
+    if (!s || !s->prepared || level < 0 || level > s->cfg.nLevels) return -1;
+    return s->lay.level[level].pairs;
 }
 long long gf_smp_level_covered_rows(const gf_smp *s, int level) {
     if (!s || !s->prepared || level < 0 || level > s->cfg.nLevels) return -1;

@@ -719,6 +719,8 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                                                             const long long *__restrict__ node_row,
                                                             const long long *__restrict__ node_pair, int C, int nwin,
                                                             const float *__restrict__ rsum, int ocols,
+                                                            const unsigned *__restrict__ fsign,  // or null: [rows][C / 32] sign bits of f_l (the
+                                                            // panel combine-forward's): the LeakyReLU slopes without reading F
                                                             float *__restrict__ dzmax) {  // or null: [workgroups][CW] largest |dz| per column
     // of this workgroup's rows (C = 64: the weight gradients' column exponents, smp_wgrad_column_bounds)
     constexpr int CW = 4 * LPC;
@@ -747,7 +749,13 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
             if (it < items) {
                 const int xi = it / N, y = it - xi * N;
                 const size_t row = rowbase + (size_t)(W.x0 + xi) * N + y;
-                fv[u] = ld4(F + row * C + fc);
+                if (fsign) {   // (uniform) the four columns' sign bits -> +-1 (only the sign is used below)
+                    const unsigned w = fsign[row * (size_t)(C >> 5) + (fc >> 5)] >> (fc & 31);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fv[u][j] = ((w >> j) & 1u) ? 1.f : -1.f;
+                } else {
+                    fv[u] = ld4(F + row * C + fc);
+                }
                 g[u] = !node_dF ? ld4(dF + row * C + fc) : dF ? gnode + ld4(dF + row * C + fc) : gnode;   // (a tower's level below the top: both)
             }
         }
@@ -1243,13 +1251,11 @@ __device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w, int chunk
     }
 }
 
-// ONE launch per level for every source up to 16 positions, molecule by molecule (gather_order): the rows (b, c) of a consumer are
-// re-read by each of its ~s sources, of whatever size -- launched per size class, a molecule's table gradients were fetched from
-// HBM once per class (rocprof: 1.24 -> 1.53 ms for the same kernel when the classes of the launch order were refined).  The
-// register budget is the largest path's (three waves per SIMD); each workgroup runs the path of its source's size.
-// Every wave of the grid takes one work item of the level's list (gfsmp::LevelLayout::gather_items: the sources above 16 positions
-// first -- as one 32-accumulator workgroup at one wave per SIMD they ran alone for 0.2 ms after everything else had finished --
-// then every other source molecule by molecule).  Waves are independent (no LDS, no barrier): a workgroup is just four
+// ONE launch per level, molecule by molecule (gfsmp::LevelLayout::gather_items): the rows (b, c) of a consumer are re-read by each of its
+// ~s sources, of whatever size -- launched per size class, a molecule's table gradients were fetched from HBM once per class (rocprof:
+// 1.24 -> 1.53 ms for the same kernel when the classes of the launch order were refined).  Every wave of the grid takes one work item
+// of the level's list: (source, 64-lane chunk of its (p, channel quad) rows, eight positions q) -- a source of more than eight positions
+// is several items, all sources molecule-major (smp_prep.cpp).  Waves are independent (no LDS, no barrier): a workgroup is just four
 // consecutive items, whatever their sources' sizes; nothing is launched for rows a source does not have (idle waves of a
 // workgroup-per-source grid cost 0.15 - 0.3 ms of wave launches per step).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void smp_bwd_gather_all(GF_GATHER_PARAMS,
@@ -1374,6 +1380,9 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     const int rows = (int)h.rows, pairs = (int)h.pairs, nodes = h.nNodes;
     float *T = d.Q, *O = d.Q + (size_t)h.rows * T_COLS * C;
     gf_status st;
+    // what this pass runs the level's products on decides the layout of O / dO (two or three blocks) at C = 32: the reverse sweep
+    // follows the forward's choice, not the option's value at the time it runs (round-4 advice)
+    s->lv[l].fwd_c64 = smp_c64_kernels(s);
     // The structurally-zero rows of the S_ab / T6 blocks (half of the rows at QM9 sizes, 0.73 GB of zeros a step at cfg3) are the
     // same rows every step of a prepared batch and nothing else writes there: their zeros go in once, tables-forward skips them.
     // Round 4: and they are not even written that once while every reader of T skips them -- the split product kernels and the packed
@@ -1474,7 +1483,9 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     {   // wave per row panel, the adjacency product on the matrix pipe; the top level leaves the readout's partial sums behind, the
         // others the per-channel maxima the level above scales its weight-gradient operands with
         float *psum = (l == s->cfg.nLevels || s->cfg.physics) ? d.psum : nullptr;   // (a tower reads every level out)
-        st = smp_combine_fwd_panels_c64(s, l, O, bl, psum, d.pmax);
+        unsigned *fsign = env_is("GF_SMP_SIGN_MASK", '0') ? nullptr : d.fsign;
+        st = smp_combine_fwd_panels_c64(s, l, O, bl, psum, d.pmax, fsign);
+        if (st == GF_OK && fsign) s->lv[l].fsign_ready = true;
         if (st == GF_OK && psum) s->lv[l].psum_ready = true;
         if (st == GF_OK && d.pmax) s->lv[l].pmax_ready = true;
         return st;
@@ -1519,7 +1530,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     float *colpart = s->colpart + (size_t)l * 256 * C;
     GF_LAUNCH(ctx, "smpf_reduce_pairs", smp_reduce_pairs, dim3(nb), dim3(256), 0, d.dSpart, d.dbpart, d.dSout, colpart, d.node_s,
               d.node_pair, C, nodes, npb);
-    const int ocols = smp_compact_o(s) ? 2 : O_COLS;
+    const int ocols = d.fwd_c64 ? 2 : O_COLS;
     GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, dO, d.dGc, pv.node_s, pv.node_pair,
               d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C, ocols);
     {
@@ -1541,7 +1552,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     float *ws = static_cast<float *>(ctx->ws);
     size_t ws_floats = ctx->ws_bytes / sizeof(float), used = 0;
     FoldGroup rowg;
-    const bool stationary = smp_c64_kernels(s);
+    const bool stationary = d.fwd_c64;
     if (stationary && C == 32) {   // smp_wgrad_direct<32>: one partial image of the eight products per workgroup
         const long long slices = ((long long)rows + 15) / 16;
         int splits = (int)(slices / 8 < 1 ? 1 : slices / 8 > 512 ? 512 : slices / 8);   // (116 registers: two workgroups per CU)
@@ -1653,7 +1664,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     st = smp_dp_level_done(s, l);  // data-parallel: dK_l and db_l are final -- their all-reduce runs beside what follows
     if (st != GF_OK) return st;
     // table gradients dT from dO
-    if (smp_c64_kernels(s)) {
+    if (d.fwd_c64) {
         // (with the consumer gather reading dT, the gradients of the structurally-zero S_ab / T6 rows have no reader: not written)
         st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows, ocols == 2 ? d.trow : nullptr, d.trowf,
                                        smp_fused_gather_enabled(s, l), d.wimg_ready ? d.wimg : nullptr, C);
@@ -1708,7 +1719,13 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
     float *dO = d.Q + (size_t)h.rows * T_COLS * C;
     gf_status st;
-    float *dzmax = (s->wbound && d.dzmax && smp_compact_o(s)) ? d.dzmax : (float *)nullptr;
+    // The forward pass wrote O in the layout of ITS product kernels; at C = 32 those exist on the split path only, so an option flipped
+    // between the two passes would make this sweep read dO in the other layout: refused instead of differentiated wrongly.
+    if (d.fwd_c64 != smp_c64_kernels(s))
+        return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: the product kernels' option (GF_OPT_SMP_FP32_PRODUCTS / GF_SMP_SPLIT / GF_SMP_ROWPANEL) "
+                                         "changed since the forward pass of level %d", l);
+    float *dzmax = (s->wbound && d.dzmax && d.fwd_c64) ? d.dzmax : (float *)nullptr;
+    const unsigned *fsign = (d.fsign && d.fsign_ready && C % 32 == 0) ? d.fsign : (const unsigned *)nullptr;
     if (smp_half_window(C)) {   // eight lanes per row (32-channel windows): at C = 32 every lane has channels
         const int nw8 = C / 32, N = h.buckets.back().s;
         // (the column maxima go through kThreads / 8 x 32 floats of the dz image: room for them whatever the field size)
@@ -1717,14 +1734,14 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<8>), dim3((unsigned)(h.quad_node.size() * nw8)), dim3(kThreads), lds, d.f,
                   dfrows, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
-                  nw8, d.rsum, smp_compact_o(s) ? 2 : O_COLS, dzmax);
+                  nw8, d.rsum, d.fwd_c64 ? 2 : O_COLS, fsign, dzmax);
     } else {
         const size_t lds = std::max(combine_lds<16>(h.buckets.back().s), sizeof(float) * ((size_t)adj_lds_floats(h.buckets.back().s) + 1024));
         st = opt_in_lds(ctx, smp_combine_bwd<16>, lds);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
                   dfrows, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
-                  nwin, d.rsum, smp_compact_o(s) ? 2 : O_COLS, dzmax);
+                  nwin, d.rsum, d.fwd_c64 ? 2 : O_COLS, fsign, dzmax);
     }
     (void)Kl;
     return smp_fused_backward_level_grouped(s, l, dKl, dbl);

@@ -107,6 +107,7 @@ struct gf_smp {
     int grad_allreduce = 1;
     float *dp_grads = nullptr;           // gradient buffer of the running gf_smp_backward, null when not data-parallel
     hipEvent_t ev_grad = nullptr, ev_comm = nullptr;
+    bool dp_join_pending = false;        // ev_comm was recorded behind the last sweep's all-reduces and nobody has waited for it on the host yet
     int fused = 1;  // use the fused level path where supported (gf_smp_set_fused)
     int bwd_gather = 0;  // fused levels: evaluate dP inside the consumer gather instead of materialising it (GF_SMP_BWD_GATHER)
     // device buffers (owned)
@@ -143,8 +144,11 @@ struct gf_smp {
         float *pmax = nullptr;     // [fwd_npanels][64] largest |f_l| of every row panel, left by combine-forward (levels below the top)
         float *dzmax = nullptr;    // [quads][64] largest |dz| of every workgroup of combine-backward
         bool pmax_ready = false;
+        unsigned *fsign = nullptr; // [rows][C / 32] sign bits of f_l (bit = f > 0), left by the panel combine-forward: the slopes of combine-backward
+        bool fsign_ready = false;  // ... written by this forward pass
         void *wimg = nullptr;  // the split product kernels' weight images of this pass (smp_split_build_images), C = 64
         bool wimg_ready = false;
+        bool fwd_c64 = false;  // the last forward ran this level's products on the dedicated row-panel kernels (compact O = [O_loc | U])
         int *trowf = nullptr;  // [rows] trow | bit 31: rowflag of the row | bit 30: rowflag of the transposed row (smp_rowpanel_split)
         float max_tot = 0.f, max_tr = 0.f;  // largest |tot|, |tr| of the level's row factors (split-operand weight gradients' column bounds)
         const unsigned *row_max = nullptr;  // the same two as float bits in device memory when the tables are built there
@@ -222,7 +226,8 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_build_tf_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream, bool gather_offsets = true);
-gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr, float *pmax = nullptr);
+gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr, float *pmax = nullptr,
+                                     unsigned *fsign = nullptr);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce

@@ -85,6 +85,11 @@ class Context:
     def dist_world(self):
         return self.lib.gf_dist_world(self.handle)
 
+    def dist_quiesce(self):
+        """Bounded wait (GF_DIST_TIMEOUT_S) until every collective issued so far has completed; raises with the rank, the world and
+        the exchange when a peer never joined -- call it before a blocking synchronize of a multi-rank run."""
+        self.check(self.lib.gf_dist_quiesce(self.handle))
+
     def allreduce_sum_(self, t):
         """In-place sum over ranks of a contiguous float32 CUDA tensor, ordered on the context's stream."""
         self.check(self.lib.gf_dist_allreduce_sum_f32(self.handle, _dev_f32(t, "tensor"), t.numel()))

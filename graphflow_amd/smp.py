@@ -189,6 +189,10 @@ class SMPOmega:
         """rows (a, b) of the level whose slab row is not structurally zero (gf_smp_level_present_rows)"""
         return int(self.lib.gf_smp_level_present_rows(self.handle, level))
 
+    def level_pairs(self, level):
+        """(node, neighbour) pairs of the level = sum of its receptive-field sizes (gf_smp_level_pairs)"""
+        return int(self.lib.gf_smp_level_pairs(self.handle, level))
+
     def level_covered_rows(self, level):
         """rows (b, c) of the level that some source covers (gf_smp_level_covered_rows)"""
         return int(self.lib.gf_smp_level_covered_rows(self.handle, level))

@@ -36,7 +36,8 @@ typedef enum {
     GF_ERR_INVALID = 1,     /* bad argument (null pointer, non-positive size, unknown K) */
     GF_ERR_HIP = 2,         /* a HIP runtime call or kernel launch failed */
     GF_ERR_NOMEM = 3,       /* workspace allocation failed */
-    GF_ERR_UNSUPPORTED = 4  /* shape outside what the kernels implement */
+    GF_ERR_UNSUPPORTED = 4, /* shape outside what the kernels implement */
+    GF_ERR_TIMEOUT = 5      /* a data-parallel rank waited longer than GF_DIST_TIMEOUT_S for its peers (gf_dist_*) */
 } gf_status;
 
 /* ---- context: device + stream + workspace ---------------------------------------------------------------------
@@ -97,6 +98,13 @@ int       gf_dist_rank(const gf_ctx *ctx);                 /* 0 when the context
 int       gf_dist_world(const gf_ctx *ctx);                /* 1 when the context has no communicator */
 gf_status gf_dist_allreduce_sum_f32(gf_ctx *ctx, float *buf, size_t n);
 gf_status gf_dist_broadcast_f32(gf_ctx *ctx, float *buf, size_t n, int root);
+/* Watchdog.  gf_dist_init, the join at the end of gf_smp_backward's overlapped all-reduces, and this call wait for the peers at most
+ * GF_DIST_TIMEOUT_S seconds (environment, default 180, 0 = for ever) and then fail with GF_ERR_TIMEOUT; gf_last_error names the
+ * rank, the world size, the device and the last collective handed to RCCL.  gf_dist_quiesce waits (by polling, under that limit)
+ * until everything issued so far on the communicator's stream and on the context's stream has completed: call it before a
+ * blocking hipStreamSynchronize / hipDeviceSynchronize that would otherwise hang on a peer that never joined.  No-op without a
+ * communicator. */
+gf_status gf_dist_quiesce(gf_ctx *ctx);
 
 /* ---- tensor contractions, mode B (device pointers, batched) -----------------------------------------------------
  * K selects the family: 4, 10, 18 or 50.
@@ -319,12 +327,16 @@ int       gf_smp_receptive_field(const gf_smp *smp, int mol, int level, int v, i
 long long gf_smp_read_activation(gf_smp *smp, int mol, int level, int v, float *host_out, size_t capacity);
 long long gf_smp_read_reduced_adjacency(gf_smp *smp, int mol, int level, int v, float *host_out, size_t capacity);
 gf_status gf_smp_level_sizes(const gf_smp *smp, int level, long long *nodes, long long *rows, long long *ppos);
+/* sum of the receptive-field sizes s over the level's nodes: the (node, neighbour) pairs = promoted tensors of the level
+ * (SMP_omega.h:641-647), and the rows of the per-(node, x) tables of the fused level; -1 on a bad argument */
+long long gf_smp_level_pairs(const gf_smp *smp, int level);
 /* Rows (a, b) of the level whose promoted slab row is not structurally zero -- vertex b lies inside the receptive field of a's
  * source (the selection matrices of SMP_omega.h:461-474 have a 1 in that column) -- out of gf_smp_level_sizes' `rows`.  The fused
  * level neither writes, reads nor back-propagates the other rows' S_ab / T6 table blocks; the bench prices its kernels with it. */
 long long gf_smp_level_present_rows(const gf_smp *smp, int level);
 /* ... and the rows (b, c) that SOME source covers (both vertices inside one source's field): the others' S_bc / T10 blocks are
- * structural zeros as well.  Equal to `rows` where the handle keeps no row flags (channel counts other than 64).
+ * structural zeros as well.  Equal to `rows` where the handle keeps no row flags (the flags exist for the channel counts the
+ * row-panel kernels serve: models computed at 32 or 64 channels, i.e. every nChanels <= 64 through gf_smp_create's padding).
  * Both calls are introspection for tests and the bench: the first call after a prepare blocks on a device-to-host copy (the
  * result is then cached until the next prepare), and neither may run concurrently with gf_smp_prepare / gf_smp_destroy on the
  * SAME handle (they read the tables prepare replaces).  Other handles of the context are unaffected. */

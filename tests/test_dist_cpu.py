@@ -72,3 +72,36 @@ def test_bench_refuses_a_world_that_disagrees_with_gpus():
     if not torch.cuda.is_available():   # asking for GPUs that are not there fails loudly instead of running fewer ranks
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
         assert r.returncode != 0 and "HIP device" in (r.stdout + r.stderr)
+
+
+def _bench_plumbing(n, extra=()):
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--plumbing", "--steps", "3", "--warmup", "1", *extra],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_8_plumbing_weak_and_strong():
+    """The driver's 8-GPU command line end to end on CPU: eight ranks started by bench.py itself, one line from rank 0, the weak and the
+    strong batch split, and the fields a multi-GPU line carries (`collective`, `scaling`)."""
+    out = _bench_plumbing(8)
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["per_rank_units"] == 1024
+    assert out["collective"]["gloo_ranks_seen"] == 8 and out["collective"]["expected"] == 8
+    assert out["config"]["shard_of_rank0"] == [0, 1024]
+    out = _bench_plumbing(8, ("--scaling", "strong"))
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["per_rank_units"] == 1024   # 8192 / 8
+    out = _bench_plumbing(4, ("--scaling", "strong", "--batch", "4096"))
+    assert out["n_gpus"] == 4 and out["config"]["per_rank_units"] == 1024
+
+
+def test_watchdog_entry_points_exist_and_are_no_ops_without_a_communicator():
+    """gf_dist_quiesce / GF_ERR_TIMEOUT are part of the ABI (include/gf_hip.h); the bounded waits themselves need RCCL and two GPUs
+    (tests/test_dist_gpu.py holds the one-rank path)."""
+    from graphflow_amd import _lib
+    assert _lib.GF_ERR_TIMEOUT == 5
+    hdr = open(os.path.join(ROOT, "include", "gf_hip.h")).read()
+    assert "GF_ERR_TIMEOUT = 5" in hdr and "gf_dist_quiesce" in hdr and "GF_DIST_TIMEOUT_S" in hdr

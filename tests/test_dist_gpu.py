@@ -118,3 +118,40 @@ def test_ranks_on_separate_gpus_sum_their_gradients(gf, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and "world 2" in line["config"]["collective"]
+
+
+def test_a_rank_whose_peer_never_arrives_times_out_with_its_rank_and_world(tmp_path):
+    """Watchdog (round 5): gf_dist_init for rank 0 of a world of TWO, with no second rank anywhere.  ncclCommInitRank would block for
+    ever; the call must come back with GF_ERR_TIMEOUT after GF_DIST_TIMEOUT_S and name the rank, the world and the call.  In a
+    subprocess: the helper thread stays inside RCCL's bootstrap."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "lonely_rank.py"
+    script.write_text(textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r)
+        import graphflow_amd as gf
+        from graphflow_amd import _lib
+        ctx = gf.Context(0)
+        uid = ctx.dist_unique_id()
+        t0 = time.time()
+        try:
+            ctx.dist_init(uid, 0, 2)
+        except gf.GraphFlowHipError as e:
+            msg = str(e)
+            assert "rank 0 of 2" in msg and "ncclCommInitRank" in msg and "GF_DIST_TIMEOUT_S" in msg, msg
+            assert 2.0 < time.time() - t0 < 60.0, time.time() - t0
+            assert ctx.dist_world == 1            # no half-made communicator left on the context
+            ctx.dist_quiesce()                    # a no-op without a communicator
+            print("timed out as it should:", msg)
+            sys.stdout.flush()
+            import os
+            os._exit(0)                           # (the helper thread is still blocked in RCCL's bootstrap)
+        raise SystemExit("gf_dist_init returned without its peer")
+    """ % root))
+    env = dict(os.environ, GF_DIST_TIMEOUT_S="4")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=180)
+    assert r.returncode == 0 and "timed out as it should" in r.stdout, r.stdout + r.stderr
