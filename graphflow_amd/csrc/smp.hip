@@ -1486,8 +1486,6 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                 }
                 st = gf::upload(s, &d.dzmax, nullptr, h.quad_node.size() * 64);
                 if (st != GF_OK) return st;
-                st = gf::upload(s, &d.fsign, nullptr, (size_t)h.rows * (C / 32));
-                if (st != GF_OK) return st;
                 st = gf::upload(s, &d.fwd_pan_node, nullptr, (size_t)np);
                 if (st != GF_OK) return st;
                 st = gf::upload(s, &d.fwd_goff, nullptr, (size_t)h.rows);
@@ -1822,7 +1820,7 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
     if (st != GF_OK) return st;
     GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)nV * C)), dim3(256), 0, s->lv[0].f,
               (const float *)nullptr, C, (size_t)nV * C);
-    for (int l = 0; l <= L; ++l) s->lv[l].psum_ready = s->lv[l].pmax_ready = s->lv[l].fsign_ready = false;
+    for (int l = 0; l <= L; ++l) s->lv[l].psum_ready = s->lv[l].pmax_ready = false;
     s->bwd_consumed = false;
     if (s->fused) {
         if (s->wbound && C == 64) GF_HIP_TRY(ctx, hipMemsetAsync(s->wbound, 0, sizeof(unsigned) * gf::smp_wgrad_bound_words() * (size_t)(L + 1), ctx->stream));

@@ -719,8 +719,6 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
                                                             const long long *__restrict__ node_row,
                                                             const long long *__restrict__ node_pair, int C, int nwin,
                                                             const float *__restrict__ rsum, int ocols,
-                                                            const unsigned *__restrict__ fsign,  // or null: [rows][C / 32] sign bits of f_l (the
-                                                            // panel combine-forward's): the LeakyReLU slopes without reading F
                                                             float *__restrict__ dzmax) {  // or null: [workgroups][CW] largest |dz| per column
     // of this workgroup's rows (C = 64: the weight gradients' column exponents, smp_wgrad_column_bounds)
     constexpr int CW = 4 * LPC;
@@ -749,13 +747,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
             if (it < items) {
                 const int xi = it / N, y = it - xi * N;
                 const size_t row = rowbase + (size_t)(W.x0 + xi) * N + y;
-                if (fsign) {   // (uniform) the four columns' sign bits -> +-1 (only the sign is used below)
-                    const unsigned w = fsign[row * (size_t)(C >> 5) + (fc >> 5)] >> (fc & 31);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) fv[u][j] = ((w >> j) & 1u) ? 1.f : -1.f;
-                } else {
-                    fv[u] = ld4(F + row * C + fc);
-                }
+                fv[u] = ld4(F + row * C + fc);
                 g[u] = !node_dF ? ld4(dF + row * C + fc) : dF ? gnode + ld4(dF + row * C + fc) : gnode;   // (a tower's level below the top: both)
             }
         }
@@ -1483,9 +1475,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     {   // wave per row panel, the adjacency product on the matrix pipe; the top level leaves the readout's partial sums behind, the
         // others the per-channel maxima the level above scales its weight-gradient operands with
         float *psum = (l == s->cfg.nLevels || s->cfg.physics) ? d.psum : nullptr;   // (a tower reads every level out)
-        unsigned *fsign = env_is("GF_SMP_SIGN_MASK", '0') ? nullptr : d.fsign;
-        st = smp_combine_fwd_panels_c64(s, l, O, bl, psum, d.pmax, fsign);
-        if (st == GF_OK && fsign) s->lv[l].fsign_ready = true;
+        st = smp_combine_fwd_panels_c64(s, l, O, bl, psum, d.pmax);
         if (st == GF_OK && psum) s->lv[l].psum_ready = true;
         if (st == GF_OK && d.pmax) s->lv[l].pmax_ready = true;
         return st;
@@ -1725,7 +1715,6 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: the product kernels' option (GF_OPT_SMP_FP32_PRODUCTS / GF_SMP_SPLIT / GF_SMP_ROWPANEL) "
                                          "changed since the forward pass of level %d", l);
     float *dzmax = (s->wbound && d.dzmax && d.fwd_c64) ? d.dzmax : (float *)nullptr;
-    const unsigned *fsign = (d.fsign && d.fsign_ready && C % 32 == 0) ? d.fsign : (const unsigned *)nullptr;
     if (smp_half_window(C)) {   // eight lanes per row (32-channel windows): at C = 32 every lane has channels
         const int nw8 = C / 32, N = h.buckets.back().s;
         // (the column maxima go through kThreads / 8 x 32 floats of the dz image: room for them whatever the field size)
@@ -1734,14 +1723,14 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<8>), dim3((unsigned)(h.quad_node.size() * nw8)), dim3(kThreads), lds, d.f,
                   dfrows, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
-                  nw8, d.rsum, d.fwd_c64 ? 2 : O_COLS, fsign, dzmax);
+                  nw8, d.rsum, d.fwd_c64 ? 2 : O_COLS, dzmax);
     } else {
         const size_t lds = std::max(combine_lds<16>(h.buckets.back().s), sizeof(float) * ((size_t)adj_lds_floats(h.buckets.back().s) + 1024));
         st = opt_in_lds(ctx, smp_combine_bwd<16>, lds);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, d.f,
                   dfrows, node_df, d.adj, dO, d.dVout, d.dSpart, d.dbpart, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C,
-                  nwin, d.rsum, d.fwd_c64 ? 2 : O_COLS, fsign, dzmax);
+                  nwin, d.rsum, d.fwd_c64 ? 2 : O_COLS, dzmax);
     }
     (void)Kl;
     return smp_fused_backward_level_grouped(s, l, dKl, dbl);

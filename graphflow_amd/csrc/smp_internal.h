@@ -144,8 +144,6 @@ struct gf_smp {
         float *pmax = nullptr;     // [fwd_npanels][64] largest |f_l| of every row panel, left by combine-forward (levels below the top)
         float *dzmax = nullptr;    // [quads][64] largest |dz| of every workgroup of combine-backward
         bool pmax_ready = false;
-        unsigned *fsign = nullptr; // [rows][C / 32] sign bits of f_l (bit = f > 0), left by the panel combine-forward: the slopes of combine-backward
-        bool fsign_ready = false;  // ... written by this forward pass
         void *wimg = nullptr;  // the split product kernels' weight images of this pass (smp_split_build_images), C = 64
         bool wimg_ready = false;
         bool fwd_c64 = false;  // the last forward ran this level's products on the dedicated row-panel kernels (compact O = [O_loc | U])
@@ -226,8 +224,7 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_build_tf_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream, bool gather_offsets = true);
-gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr, float *pmax = nullptr,
-                                     unsigned *fsign = nullptr);
+gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr, float *pmax = nullptr);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce

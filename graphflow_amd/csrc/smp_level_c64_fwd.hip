@@ -59,11 +59,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     const float *__restrict__ rsum, const float *__restrict__ Vout, long long pairs, const float *__restrict__ Sout,
     const float *__restrict__ bias, float *__restrict__ psum,   // psum (top level, or null): [npanels][64] column sums of the panel's
     // rows of f -- the readout's per-node sums (ShrinkTensor, SMP_omega.h:671-676) then read 22 MB of partials instead of f_L again
-    float *__restrict__ pmax,  // pmax (or null): [npanels][64] largest |f| per column of the panel's rows (the level above scales the
+    float *__restrict__ pmax) {  // pmax (or null): [npanels][64] largest |f| per column of the panel's rows (the level above scales the
     // columns of its weight-gradient operands with the level's per-channel maxima: smp_wgrad_column_bounds)
-    unsigned *__restrict__ fsign) {  // fsign (or null): [rows][CB / 32] bit c % 32 of word (row, c / 32) = f_l[row][c] > 0.  The reverse
-    // sweep needs f_l only for LeakyReLU's slope (LeakyReLU3D::backward, GraphFlow/LeakyReLU3D.h): combine-backward reads 8 bytes
-    // of signs per row instead of the row's 256 bytes of activations (0.73 GB a cfg3 step)
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     unsigned blk;
     {
@@ -164,28 +161,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
             }
         }
     }
-    if (fsign) {  // (uniform) the slopes' sign bits: a ballot per accumulator register is the 32 columns of two rows (the lane halves)
-        unsigned mine = 0u;   // lane j collects word (row j >> 1 of the panel, column half j & 1)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(m0[r] > 0.f);
-            const unsigned long long b1 = TWO ? __builtin_amdgcn_ballot_w64(m1[r] > 0.f) : 0ull;
-            const int ra = (r & 3) + 8 * (r >> 2);   // row of the low lane half; the high half holds row ra + 4
-            if constexpr (TWO) {
-                mine = __builtin_amdgcn_writelane((unsigned)b0, 2 * ra, mine);
-                mine = __builtin_amdgcn_writelane((unsigned)b1, 2 * ra + 1, mine);
-                mine = __builtin_amdgcn_writelane((unsigned)(b0 >> 32), 2 * (ra + 4), mine);
-                mine = __builtin_amdgcn_writelane((unsigned)(b1 >> 32), 2 * (ra + 4) + 1, mine);
-            } else {   // one word per row: lane j collects row j
-                mine = __builtin_amdgcn_writelane((unsigned)b0, ra, mine);
-                mine = __builtin_amdgcn_writelane((unsigned)(b0 >> 32), ra + 4, mine);
-            }
-        }
-        constexpr int WPR = CB / 32;   // words per row
-        const __amdgpu_buffer_rsrc_t rS = ff_rsrc(fsign, (size_t)rows * WPR * sizeof(unsigned));
-        const int vo = (lane / WPR) < nrows ? (P.x * WPR + lane) * 4 : kFfOor;
-        if (TWO || lane < 32) __builtin_amdgcn_raw_buffer_store_b32(mine, rS, vo, 0, 0);
-    }
     float c0 = 0.f, c1 = 0.f, x0m = 0.f, x1m = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -255,7 +230,7 @@ gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream, bool 
 }
 
 // f_l from the projected matrix O = [O_loc | U] (compact layout) of a fused level at C = 64: smp_combine_fwd_panels
-gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum, float *pmax, unsigned *fsign) {
+gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum, float *pmax) {
     gf_ctx *ctx = s->ctx;
     const gf_smp::DevLevel &d = s->lv[l];
     const gfsmp::LevelLayout &h = s->lay.level[l];
@@ -264,11 +239,11 @@ gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const flo
     if (s->cfg.nChanels == 64)
         GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels<64>, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
                   d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
-                  (long long)h.pairs, d.Sout, bias, psum, pmax, fsign);
+                  (long long)h.pairs, d.Sout, bias, psum, pmax);
     else
         GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels<32>, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
                   d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
-                  (long long)h.pairs, d.Sout, bias, psum, pmax, fsign);
+                  (long long)h.pairs, d.Sout, bias, psum, pmax);
     return GF_OK;
 }
 
