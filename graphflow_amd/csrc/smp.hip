@@ -1073,6 +1073,11 @@ gf_status gf_smp_destroy(gf_smp *s) {
     if (s->ev_last) (void)hipEventDestroy(s->ev_last);
     if (s->ev_grad) (void)hipEventDestroy(s->ev_grad);
     if (s->ev_comm) (void)hipEventDestroy(s->ev_comm);
+    if (s->ev_mask) {
+        (void)hipEventSynchronize(s->ev_mask);
+        (void)hipEventDestroy(s->ev_mask);
+    }
+    if (s->mask_stage) (void)hipHostFree(s->mask_stage);
     if (s->adam_m) (void)hipFree(s->adam_m);
     if (s->adam_v) (void)hipFree(s->adam_v);
     if (s->own_p) (void)hipFree(s->own_p);
@@ -1923,12 +1928,34 @@ gf_status gf_smp_dropout_masks(gf_smp *s, const unsigned *masks, float scale) {
     if (!s->prepared || !s->cfg.physics) return fail(ctx, GF_ERR_INVALID, "gf_smp_dropout_masks: needs a prepared physics tower");
     const gfsmp::BatchLayout &B = s->lay;
     const int totalV = B.mol_first_vertex[B.nMol];
-    std::vector<unsigned> by_node((size_t)totalV);
-    for (int l = 1; l <= s->cfg.nLevels; ++l) {
-        for (int gv = 0; gv < totalV; ++gv) by_node[(size_t)B.node_of_vertex[l][gv]] = masks[(size_t)(l - 1) * totalV + gv];
-        GF_HIP_TRY(ctx, hipMemcpyAsync(s->lv[l].keep_mask, by_node.data(), sizeof(unsigned) * totalV, hipMemcpyHostToDevice, ctx->stream));
-        GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // by_node is reused
+    // The masks go up through a page-locked staging table of the handle, all levels at once, behind an event: a pageable source makes
+    // every copy a blocking one and the old per-level hipStreamSynchronize drained the context's stream three times per tower and
+    // step (the host then drew the next masks -- a million rand() calls per 1024-sample step -- with the device idle).
+    const size_t need = (size_t)s->cfg.nLevels * totalV;
+    if (s->mask_stage_n < need) {
+        if (s->mask_stage) (void)hipHostFree(s->mask_stage);
+        s->mask_stage = nullptr;
+        s->mask_stage_n = 0;
+        GF_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&s->mask_stage), need * sizeof(unsigned), hipHostMallocDefault));
+        s->mask_stage_n = need;
     }
+    if (!s->ev_mask) GF_HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_mask, hipEventDisableTiming));
+    else GF_HIP_TRY(ctx, hipEventSynchronize(s->ev_mask));   // (the previous step's copies have left the table: long done)
+    for (int l = 1; l <= s->cfg.nLevels; ++l) {
+        unsigned *by_node = s->mask_stage + (size_t)(l - 1) * totalV;
+        for (int gv = 0; gv < totalV; ++gv) by_node[(size_t)B.node_of_vertex[l][gv]] = masks[(size_t)(l - 1) * totalV + gv];
+        GF_HIP_TRY(ctx, hipMemcpyAsync(s->lv[l].keep_mask, by_node, sizeof(unsigned) * totalV, hipMemcpyHostToDevice, ctx->stream));
+    }
+    GF_HIP_TRY(ctx, hipEventRecord(s->ev_mask, ctx->stream));
+    // the factor tables of the fused levels (smp_fused.hip: build_dropout_factors fills them at every forward): towers computed at 32 channels
+    if (s->cfg.square() && s->cfg.nChanels == 32)
+        for (int l = 1; l <= s->cfg.nLevels; ++l) {
+            gf_smp::DevLevel &d = s->lv[l];
+            if (d.nodefac && d.rowfac8) continue;
+            gf_status st = gf::upload(s, &d.nodefac, nullptr, (size_t)B.level[l].nNodes * 18);
+            if (st == GF_OK) st = gf::upload(s, &d.rowfac8, nullptr, (size_t)B.level[l].rows * 8);
+            if (st != GF_OK) return st;
+        }
     s->drop_on = true;
     s->drop_scale = scale;
     return GF_OK;

@@ -447,7 +447,9 @@ __global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict_
                                 const long long *__restrict__ prev_pair, const long long *__restrict__ cons_ptr,
                                 const long long *__restrict__ cons_row, const int *__restrict__ cons_s,
                                 const int *__restrict__ cons_a, const long long *__restrict__ cons_inv_off,
-                                const short *__restrict__ inv, int C, int ocols) {
+                                const short *__restrict__ inv, int C, int ocols,
+                                const float *__restrict__ nodefac,   // or null: slice-dropout factors [nodes][18] of the CONSUMERS' level
+                                const long long *__restrict__ cons_pair, const int *__restrict__ pair_node) {   // (with nodefac: consumer -> node)
     const int w = blockIdx.x;
     const int sw = prev_s[w], nl = C / 4;
     const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
@@ -468,6 +470,11 @@ __global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict_
                 const float *base = dO + (size_t)cons_row[e] * ldo + O_Z * C + 4 * fl;
                 u[j] = ld4(base + ((size_t)a * s + ix) * ldo);
                 v[j] = ld4(base + ((size_t)ix * s + a) * ldo);
+                if (nodefac) {   // (uniform) the consumer node's factors of slices 15 and 16
+                    const float *nf = nodefac + (size_t)pair_node[cons_pair[e]] * 18;
+                    u[j] = u[j] * nf[15];
+                    v[j] = v[j] * nf[16];
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -501,6 +508,43 @@ __global__ __launch_bounds__(256) void tables_zero_fill(float *__restrict__ T, c
         if (!(fl[p] & 1)) st4(T + row * (T_COLS * CB) + (q < NQ ? T_SAB * CB + 4 * q : T_T6 * CB + 4 * (q - NQ)), splat(0.f));
         if (!(fl[p] & 2)) st4(T + row * (T_COLS * CB) + (q < NQ ? T_SBC * CB + 4 * q : T_T10 * CB + 4 * (q - NQ)), splat(0.f));
     }
+}
+
+// ---- slice dropout on the fused level (round 5; RisiContraction_18_dropout, GraphFlow/RisiContraction_18_dropout.h:106-132, 465-471) ----
+// The reference zeroes (train) or scales by nKept / 18 (test) single slices k of a node's contraction output.  The factorised level never
+// forms a slice, but every slice is one block product K^(k) applied to one table, so a node's slice factor m_k is a per-node factor on that
+// product: the eight row products take it through an eight-column row-factor table (smp_rowpanel_split / smp_wgrad_direct, NF = 8), the
+// vector / scalar products through their operands (Vt, St and their gradients are scaled block by block), the two compact diagonal
+// products where the consumer gathers them (combine-forward, diag_gather_bwd).
+//   nodefac[n][k] = bit k of keep[n] ? scale : 0        rowfac8[row] = (tot m0, tot m2, tr m6, m5, m9, m8, m12, m11) of the row's node
+__global__ __launch_bounds__(64) void build_dropout_factors(const unsigned *__restrict__ keep, float scale, const float2 *__restrict__ node_scale,
+                                                            const int *__restrict__ node_s, const long long *__restrict__ node_row,
+                                                            float *__restrict__ nodefac, float *__restrict__ rowfac8) {
+    const int n = blockIdx.x, s = node_s[n];
+    const unsigned bits = keep[n];
+    auto m = [&](int k) { return ((bits >> k) & 1u) ? scale : 0.f; };
+    if (threadIdx.x < 18) nodefac[(size_t)n * 18 + threadIdx.x] = m((int)threadIdx.x);
+    const float2 tt = node_scale[n];
+    const f4 lo = {tt.x * m(0), tt.x * m(2), tt.y * m(6), m(5)}, hi = {m(9), m(8), m(12), m(11)};
+    float *dst = rowfac8 + (size_t)node_row[n] * 8;
+    for (int i = threadIdx.x; i < s * s; i += blockDim.x) {
+        st4(dst + (size_t)i * 8, lo);
+        st4(dst + (size_t)i * 8 + 4, hi);
+    }
+}
+// X [rows][4 C] *= the node's factors of slices (k0, k1, k2, k3), block by block; row_node == nullptr: row r belongs to node r
+__global__ void scale_node_blocks(float *__restrict__ X, const int *__restrict__ row_node, const float *__restrict__ nodefac, int k0, int k1,
+                                  int k2, int k3, int C, long long rows) {
+    const int nq = C / 4;   // float4 per block
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 4 * nq) return;
+    const long long row = i / (4 * nq);
+    const int blk = (int)(i % (4 * nq)) / nq;
+    const int node = row_node ? row_node[row] : (int)row;
+    const int k = blk == 0 ? k0 : blk == 1 ? k1 : blk == 2 ? k2 : k3;
+    const float f = nodefac[(size_t)node * 18 + k];
+    f4 v = ld4(X + i * 4);
+    st4(X + i * 4, v * f);
 }
 
 // stacked[p] = K^(kperm[p])  (gather; the gradients take the inverse permutation in smp_fold_level).  Block k of the level weight is
@@ -1357,9 +1401,15 @@ bool smp_fused_supported(const gf_smp *s, int l) {
     if (C % 4 != 0 || C > 1024) return false;
     if (s->cfg.nContractions != 18) return false;  // SMP_2D_ver6 / ver7 (_10 / _50): op-by-op levels
     if (!s->cfg.square()) return false;            // a tower at its own halving channel counts (GF_SMP_PAD_CHANNELS=0): op-by-op levels
-    if (s->drop_on) return false;                  // RisiContraction_18_dropout masks single slices of Q: op-by-op levels
     const gfsmp::LevelLayout &h = s->lay.level[l];
     if (h.buckets.empty()) return false;
+    if (s->drop_on) {   // RisiContraction_18_dropout: fused where the per-product row factors exist (round 5: the split row-panel kernels at
+        // 32 channels -- the towers' padded width -- with the panel combine-forward and the level's device-built statistics), else op by op
+        const gf_smp::DevLevel &d = s->lv[l];
+        if (!(C == 32 && smp_c64_kernels(s) && d.rowfac8 && d.nodefac && d.fwd_pan && d.dzmax && d.row_max && d.trow && s->bwd_gather) ||
+            env_is("GF_SMP_FUSED_DROPOUT", '0'))
+            return false;
+    }
     return h.buckets.back().s <= 32;  // 8 * PPW at LPC = 16
 }
 
@@ -1390,6 +1440,10 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     } else {
         s->lv[l].t_zeros = false;
     }
+    const bool drop = s->drop_on;   // (smp_fused_supported: only where the factor tables exist)
+    if (drop)
+        GF_LAUNCH(ctx, "smpf_dropout_factors", build_dropout_factors, dim3(nodes), dim3(64), 0, d.keep_mask, s->drop_scale,
+                  reinterpret_cast<const float2 *>(d.node_scale), d.node_s, d.node_row, d.nodefac, d.rowfac8);
     const bool lanes8 = smp_half_window(C) && smp_tables_fold_vectors(s);   // eight lanes per position (C = 32): classes of 8 NI positions
     const std::vector<SizeClass> cls = classes_of(h, lanes8 ? 8 : 4);
     for (const SizeClass &c : cls) {
@@ -1418,6 +1472,13 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(node_block(h, C)), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
                   d.node_pair, C, d.Fdc, d.pair_src_pair, d.pi);
     const size_t CC = (size_t)C * C;
+    if (drop) {   // the vector / scalar slices' factors ride on the operands: Vt blocks (1, 3, 7, 10), St blocks (4, 13, 14, 17)
+        const long long nv = (long long)pairs * C, ns = (long long)nodes * C;
+        GF_LAUNCH(ctx, "smpf_dropout_scale", scale_node_blocks, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, d.Vt, d.pair_node, d.nodefac, 1, 3, 7, 10, C,
+                  (long long)pairs);
+        GF_LAUNCH(ctx, "smpf_dropout_scale", scale_node_blocks, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, d.St, (const int *)nullptr, d.nodefac, 4, 13, 14,
+                  17, C, (long long)nodes);
+    }
     {
         // V = Vt [K1;K3;K7;K10], S = St [K4;K13;K14;K17], Gc = [Fd K15 | Fc K16]: the small products of the level, ONE launch
         const int prevPairs = (int)s->lay.level[l - 1].pairs;
@@ -1454,8 +1515,8 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
              {-1, -1, -1, -1}},
         };
         if (smp_c64_kernels(s)) {
-            st = smp_rowpanel_products_c64(ctx, true, T, d.rowscale, d.Wst, O, rows, d.trow, d.trowf, false,
-                                           d.wimg_ready ? d.wimg : nullptr, C);  // weights in LDS
+            st = smp_rowpanel_products_c64(ctx, true, T, drop ? d.rowfac8 : d.rowscale, d.Wst, O, rows, d.trow, d.trowf, false,
+                                           d.wimg_ready ? d.wimg : nullptr, C, drop ? 8 : 2);  // weights in LDS
             if (st != GF_OK) return st;
         } else if (gemm_grouped_supported(sp, 3, false, false)) {
             st = gemm_grouped_rows(ctx, false, false, sp, 3, rows);
@@ -1475,11 +1536,12 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     {   // wave per row panel, the adjacency product on the matrix pipe; the top level leaves the readout's partial sums behind, the
         // others the per-channel maxima the level above scales its weight-gradient operands with
         float *psum = (l == s->cfg.nLevels || s->cfg.physics) ? d.psum : nullptr;   // (a tower reads every level out)
-        st = smp_combine_fwd_panels_c64(s, l, O, bl, psum, d.pmax);
+        st = smp_combine_fwd_panels_c64(s, l, O, bl, psum, d.pmax, drop ? d.nodefac : nullptr);
         if (st == GF_OK && psum) s->lv[l].psum_ready = true;
         if (st == GF_OK && d.pmax) s->lv[l].pmax_ready = true;
         return st;
     }
+    if (drop) return fail(ctx, GF_ERR_UNSUPPORTED, "fused level %d: slice dropout needs the panel combine-forward", l);
     {
         const size_t lds = combine_lds<16>(h.buckets.back().s);
         st = opt_in_lds(ctx, smp_combine_fwd<16>, lds);
@@ -1521,8 +1583,10 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     GF_LAUNCH(ctx, "smpf_reduce_pairs", smp_reduce_pairs, dim3(nb), dim3(256), 0, d.dSpart, d.dbpart, d.dSout, colpart, d.node_s,
               d.node_pair, C, nodes, npb);
     const int ocols = d.fwd_c64 ? 2 : O_COLS;
+    const bool drop = s->drop_on;
     GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, dO, d.dGc, pv.node_s, pv.node_pair,
-              d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C, ocols);
+              d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C, ocols, drop ? d.nodefac : (const float *)nullptr, d.cons_pair,
+              d.pair_node);
     {
         const GemmSpec nt[4] = {spec(d.dGc, d.Wst + 8 * CC, d.dFdc, prevPairs, C, C, 2 * C, C, 2 * C),
                                 spec(d.dGc + C, d.Wst + 9 * CC, d.dFdc + C, prevPairs, C, C, 2 * C, C, 2 * C),
@@ -1536,6 +1600,13 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
         } else
         st = gemm_grouped_free(ctx, true, nt, 4, "smpf_small_nt");
         if (st != GF_OK) return st;
+    }
+    if (drop) {   // (the gradients of the scaled operands: the same factors once more)
+        const long long nv = (long long)pairs * C, ns = (long long)nodes * C;
+        GF_LAUNCH(ctx, "smpf_dropout_scale", scale_node_blocks, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, d.dVt, d.pair_node, d.nodefac, 1, 3, 7, 10, C,
+                  (long long)pairs);
+        GF_LAUNCH(ctx, "smpf_dropout_scale", scale_node_blocks, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, d.dSt, (const int *)nullptr, d.nodefac, 4, 13, 14,
+                  17, C, (long long)nodes);
     }
     FoldArgs fa;
     fa.ngroups = 6;
@@ -1564,8 +1635,8 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
             st = smp_fused_ensure_zero_fill(s, l);
             if (st != GF_OK) return st;
         }
-        st = smp_wgrad_partials_direct_c32(ctx, T, dO, d.rowscale, rows, splits, ws, d.trow, d.trowf, words, chan, (float)h.buckets.back().s,
-                                           d.row_max);
+        st = smp_wgrad_partials_direct_c32(ctx, T, dO, drop ? d.rowfac8 : d.rowscale, rows, splits, ws, d.trow, d.trowf, words, chan,
+                                           (float)h.buckets.back().s, d.row_max, drop ? 8 : 2);
         if (st != GF_OK) return st;
         rowg.part = ws;
         rowg.splits = splits;
@@ -1656,8 +1727,8 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     // table gradients dT from dO
     if (d.fwd_c64) {
         // (with the consumer gather reading dT, the gradients of the structurally-zero S_ab / T6 rows have no reader: not written)
-        st = smp_rowpanel_products_c64(ctx, false, dO, d.rowscale, d.Wst, dT, rows, ocols == 2 ? d.trow : nullptr, d.trowf,
-                                       smp_fused_gather_enabled(s, l), d.wimg_ready ? d.wimg : nullptr, C);
+        st = smp_rowpanel_products_c64(ctx, false, dO, drop ? d.rowfac8 : d.rowscale, d.Wst, dT, rows, ocols == 2 ? d.trow : nullptr, d.trowf,
+                                       smp_fused_gather_enabled(s, l), d.wimg_ready ? d.wimg : nullptr, C, drop ? 8 : 2);
         if (st != GF_OK) return st;
     } else {
         const long long oC = C, wCC = (long long)CC;
@@ -1709,6 +1780,12 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     const int C = s->cfg.nChanels, nwin = (C + 63) / 64;
     float *dO = d.Q + (size_t)h.rows * T_COLS * C;
     gf_status st;
+    // Slice dropout in TEST mode scales the forward values by nKept / 18 (RisiContraction_18_dropout.h:465-471) and its backward() does
+    // not (:480-): a reverse sweep there is neither a derivative nor something the reference's drivers ever run (Predict is forward only).
+    // The fused level carries one factor table per pass; the op-by-op levels reproduce that sweep (GF_SMP_FUSED_DROPOUT=0).
+    if (s->drop_on && s->drop_scale != 1.f)
+        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_backward: fused level %d under slice dropout in test mode (scale %.4f): set GF_SMP_FUSED_DROPOUT=0 "
+                                             "for the reference's unscaled test-mode sweep", l, (double)s->drop_scale);
     // The forward pass wrote O in the layout of ITS product kernels; at C = 32 those exist on the split path only, so an option flipped
     // between the two passes would make this sweep read dO in the other layout: refused instead of differentiated wrongly.
     if (d.fwd_c64 != smp_c64_kernels(s))

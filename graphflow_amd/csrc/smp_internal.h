@@ -41,19 +41,20 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
 // trowf (optional): the level's packed table with the presence bits of the S_ab / T6 blocks (DevLevel::trowf)
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
                                     int rows, const int *trow, const int *trowf = nullptr, bool skip_zero_grads = false,
-                                    const void *wimg = nullptr, int C = 64);   // C = 32 (round 4): split products with prebuilt images only
+                                    const void *wimg = nullptr, int C = 64,   // C = 32 (round 4): split products with prebuilt images only
+                                    int nf = 2);   // row factors per row of `rowscale`: 2 = (tot, tr); 8 = one per product (slice dropout, C = 32)
 // the compact-layout products on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip; GF_SMP_SPLIT=0: fp32 MFMA)
 bool smp_split_products(const gf_ctx *ctx);
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
                                  int rows, const int *trow, int cus, const int *trowf = nullptr, bool skip_zero_grads = false,
-                                 const void *wimg = nullptr, int C = 64);
+                                 const void *wimg = nullptr, int C = 64, int nf = 2);
 // the split kernels' weight images of a level (both directions), built once per forward pass (smp_level_c64_split.hip)
 size_t smp_split_image_bytes();
 gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n, int C = 64);
 // weight gradients of a fused level at C = 32 (smp_wgrad_direct<32>): partial images of 8 x 32 x 32 floats per workgroup
 gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int splits, float *part,
                                         const int *trow, const int *trowf, unsigned *words, const unsigned *chan = nullptr, float smax = 0.f,
-                                        const unsigned *row_max = nullptr);
+                                        const unsigned *row_max = nullptr, int nf = 2);
 gf_status smp_wgrad_channel_maxima_ld(gf_ctx *ctx, const float *fprev, long long prev_rows, int ld0, const float *dsrc, long long drows, int ld1, int C,
                                       unsigned *words);
 size_t smp_wgrad_direct_words_c32();
@@ -104,6 +105,9 @@ struct gf_smp {
     // all-reduced on the communicator's stream as soon as it is complete, beside the rest of the sweep
     bool drop_on = false;      // RisiContraction_18_dropout instead of RisiContraction_18 (SMP_sigma_pairgraphs)
     float drop_scale = 1.f;    // test mode: nKept / 18 on every slice
+    unsigned *mask_stage = nullptr;   // page-locked staging of the slice masks, [levels][vertices] in node order (gf_smp_dropout_masks)
+    size_t mask_stage_n = 0;
+    hipEvent_t ev_mask = nullptr;     // the last upload out of mask_stage
     int grad_allreduce = 1;
     float *dp_grads = nullptr;           // gradient buffer of the running gf_smp_backward, null when not data-parallel
     hipEvent_t ev_grad = nullptr, ev_comm = nullptr;
@@ -160,6 +164,7 @@ struct gf_smp {
         int *node_present = nullptr;  // [nodes] rows with data of the node (device-built tables)
         int *field = nullptr;  // [pairs] receptive fields back to back (device-built level tables: smp.hip build_level_rows)
         unsigned *keep_mask = nullptr;  // [nodes] slice masks of RisiContraction_18_dropout for this forward (gf_smp_dropout_masks)
+        float *nodefac = nullptr, *rowfac8 = nullptr;  // fused levels under slice dropout: [nodes][18] slice factors, [rows][8] per-product row factors
         // fused level (smp_fused.hip): small per-(node,x) / per-node tables and stacked weights
         float *Vt = nullptr, *dVt = nullptr;        // [pairs][4C]  rowsum_a | colsum_b | D8 | D11
         float *St = nullptr, *dSt = nullptr;        // [nodes][4C]  total | s14 | s15 | s18
@@ -224,7 +229,8 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K);
 gf_status smp_build_gather_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_build_tf_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream, bool gather_offsets = true);
-gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr, float *pmax = nullptr);
+gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr, float *pmax = nullptr,
+                                     const float *nodefac = nullptr);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce

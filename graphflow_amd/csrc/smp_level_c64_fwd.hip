@@ -59,8 +59,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     const float *__restrict__ rsum, const float *__restrict__ Vout, long long pairs, const float *__restrict__ Sout,
     const float *__restrict__ bias, float *__restrict__ psum,   // psum (top level, or null): [npanels][64] column sums of the panel's
     // rows of f -- the readout's per-node sums (ShrinkTensor, SMP_omega.h:671-676) then read 22 MB of partials instead of f_L again
-    float *__restrict__ pmax) {  // pmax (or null): [npanels][64] largest |f| per column of the panel's rows (the level above scales the
+    float *__restrict__ pmax,  // pmax (or null): [npanels][64] largest |f| per column of the panel's rows (the level above scales the
     // columns of its weight-gradient operands with the level's per-channel maxima: smp_wgrad_column_bounds)
+    const float *__restrict__ nodefac) {  // (or null) slice dropout: [nodes][18] factors; the compact products G15 / G16 take theirs here
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     unsigned blk;
     {
@@ -137,10 +138,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         g2[r] = TWO ? ff_ld1(rGc, v15 + 128) : 0.f;
         g3[r] = TWO ? ff_ld1(rGc, v16 + 128) : 0.f;
     }
+    const float c15 = nodefac ? nodefac[(size_t)node * 18 + 15] : 1.f, c16 = nodefac ? nodefac[(size_t)node * 18 + 16] : 1.f;   // (a panel is one node's)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        u0[r] += g0[r] + g1[r];
-        u1[r] += g2[r] + g3[r];
+        u0[r] += c15 * g0[r] + c16 * g1[r];
+        u1[r] += c15 * g2[r] + c16 * g3[r];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -230,7 +232,7 @@ gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream, bool 
 }
 
 // f_l from the projected matrix O = [O_loc | U] (compact layout) of a fused level at C = 64: smp_combine_fwd_panels
-gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum, float *pmax) {
+gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum, float *pmax, const float *nodefac) {
     gf_ctx *ctx = s->ctx;
     const gf_smp::DevLevel &d = s->lv[l];
     const gfsmp::LevelLayout &h = s->lay.level[l];
@@ -239,11 +241,11 @@ gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const flo
     if (s->cfg.nChanels == 64)
         GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels<64>, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
                   d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
-                  (long long)h.pairs, d.Sout, bias, psum, pmax);
+                  (long long)h.pairs, d.Sout, bias, psum, pmax, nodefac);
     else
         GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels<32>, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
                   d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
-                  (long long)h.pairs, d.Sout, bias, psum, pmax);
+                  (long long)h.pairs, d.Sout, bias, psum, pmax, nodefac);
     return GF_OK;
 }
 

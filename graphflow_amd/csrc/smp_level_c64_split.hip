@@ -155,7 +155,10 @@ __global__ __launch_bounds__(kSpThreads) void smp_split_weight_images(SplitImage
     }
 }
 
-template <bool FWD, bool MASK, int CB = 64>
+// NF (round 5): factors per row in `rs` -- 2: (tot, tr) of the row's node; 8: one factor per stacked product 0..7, i.e. (tot, tot, tr, 1, 1,
+// 1, 1, 1) times the node's slice-dropout factors of K0, K2, K6, K5, K9, K8, K12, K11 (RisiContraction_18_dropout: a dropped slice
+// of the contraction is a zero factor on its block product, GraphFlow/RisiContraction_18_dropout.h:106-132)
+template <bool FWD, bool MASK, int CB = 64, int NF = 2>
 __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float *__restrict__ A, const float *__restrict__ rs,
                                                                      const float *__restrict__ Wst, float *__restrict__ Out, int rows,
                                                                      const int *__restrict__ trow, int store_mask,
@@ -221,10 +224,22 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         const int row = p * 32 + li;
         return trow[row < rows ? row : rows - 1];
     };
+    struct RowFac {   // the eight products' row factors (NF == 2: the ones are compile-time constants)
+        float f[8];
+    };
     auto load_scale = [&](int p) {
         int row = p * 32 + li;
         row = row < rows ? row : rows - 1;
-        return *reinterpret_cast<const float2 *>(rs + (size_t)row * 2);
+        RowFac r;
+        if constexpr (NF == 8) {
+            const f4v a = *reinterpret_cast<const f4v *>(rs + (size_t)row * 8), b = *reinterpret_cast<const f4v *>(rs + (size_t)row * 8 + 4);
+            r.f[0] = a[0], r.f[1] = a[1], r.f[2] = a[2], r.f[3] = a[3], r.f[4] = b[0], r.f[5] = b[1], r.f[6] = b[2], r.f[7] = b[3];
+        } else {
+            const float2 t = *reinterpret_cast<const float2 *>(rs + (size_t)row * 2);
+            r.f[0] = r.f[1] = t.x, r.f[2] = t.y;
+            r.f[3] = r.f[4] = r.f[5] = r.f[6] = r.f[7] = 1.f;
+        }
+        return r;
     };
     // raw block -> halves at the row's exponent (one exponent for the 64 columns of the row: both lane halves agree on it);
     // MFMA c takes the lane's columns [8 c, 8 c + 8) as k = 8 (lane >> 5) + j
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         const int pn = p + nwaves;
         const int tcur = tnext;   // the transposed rows of this panel's rows (requested during the previous panel)
         tnext = fetch_trow(pn);
-        const float2 sc = load_scale(p);  // (used after the panel's first products)
+        const RowFac sc = load_scale(p);  // (used after the panel's first products)
         f16v acc0, acc1;
         Spl X, Y, Z;
         float iX, iY, iZ;
@@ -364,23 +379,23 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             split_blk(Rb, Z, iZ);
             load_raw(Rb, p, 2, t_own(tcur));         // T6
             clear(acc0, acc1);
-            prod(X, iX, 5, acc0, acc1);
-            prod(Z, iZ, 7, acc0, acc1);
+            prod(X, iX * sc.f[5], 5, acc0, acc1);
+            prod(Z, iZ * sc.f[7], 7, acc0, acc1);
             split_blk(Ra, Y, iY);
-            prod(Y, iY, 6, acc0, acc1);
+            prod(Y, iY * sc.f[6], 6, acc0, acc1);
             store_out(p, 1, acc0, acc1, full);
             clear(acc0, acc1);
-            prod(X, iX * sc.x, 0, acc0, acc1);
-            prod(X, iX * sc.y, 2, acc0, acc1);
-            prod(Y, iY * sc.x, 1, acc0, acc1);
+            prod(X, iX * sc.f[0], 0, acc0, acc1);
+            prod(X, iX * sc.f[2], 2, acc0, acc1);
+            prod(Y, iY * sc.f[1], 1, acc0, acc1);
             load_raw(Ra, p, 3, t_bc(tcur));          // T10, once X and Y are dead: with two requests beside them the panel spills,
                                                      // and a scratch reload waits for the whole memory queue
             split_blk(Rb, Z, iZ);
             load_raw_at(Rb, t_row(tnext), 0, t_tr(tnext));   // S_ab of the next panel at its transposed rows
-            prod(Z, iZ, 3, acc0, acc1);
+            prod(Z, iZ * sc.f[3], 3, acc0, acc1);
             split_blk(Ra, Z, iZ);
             load_raw(Ra, pn, 0, t_own(tnext));       // S_ab of the next panel
-            prod(Z, iZ, 4, acc0, acc1);
+            prod(Z, iZ * sc.f[4], 4, acc0, acc1);
             store_out(p, 0, acc0, acc1, full);
         } else {    // dO blocks: 0 L, 1 dU; outputs: 0 dS_ab, 1 dS_bc, 2 dT6, 3 dT10.  Entry: Ra = L, Rb = dU
             split_blk(Ra, X, iX);
@@ -391,14 +406,14 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             //  well cost the kernel fifteen spills and more than it saved, 0.84 -> 0.91 ms)
             const unsigned rowbits = (MASK && store_mask) ? (unsigned)__ballot(t_own(tcur)) : 0xffffffffu;
             clear(acc0, acc1);
-            prod(X, iX, 3, acc0, acc1);
+            prod(X, iX * sc.f[3], 3, acc0, acc1);
             store_out(p, 2, acc0, acc1, full, rowbits);
             clear(acc0, acc1);
-            prod(X, iX, 4, acc0, acc1);
+            prod(X, iX * sc.f[4], 4, acc0, acc1);
             store_out(p, 3, acc0, acc1, full);
             clear(acc0, acc1);
-            prod(X, iX * sc.x, 1, acc0, acc1);
-            prod(Y, iY, 6, acc0, acc1);
+            prod(X, iX * sc.f[1], 1, acc0, acc1);
+            prod(Y, iY * sc.f[6], 6, acc0, acc1);
             store_out(p, 1, acc0, acc1, full);
             // dU at the transposed rows: it only feeds dS_ab of this row, which is not stored where the row has no data.  (Requested
             // here, six products ahead of its use, not at the top of the panel: with the cross-product chain of round 4 the block's
@@ -407,12 +422,12 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             load_raw(Rb, pn, 1, !(MASK && store_mask) || t_bc(tnext));   // dU of the next panel (a row no source covers has nothing to
                                                                          // back-propagate: its whole dT row is a gradient of structural zeros)
             clear(acc0, acc1);
-            prod(X, iX * sc.x, 0, acc0, acc1);
-            prod(X, iX * sc.y, 2, acc0, acc1);
-            prod(Y, iY, 5, acc0, acc1);
+            prod(X, iX * sc.f[0], 0, acc0, acc1);
+            prod(X, iX * sc.f[2], 2, acc0, acc1);
+            prod(Y, iY * sc.f[5], 5, acc0, acc1);
             split_blk(Ra, Z, iZ);
             load_raw(Ra, pn, 0, !(MASK && store_mask) || t_bc(tnext));   // L of the next panel
-            prod(Z, iZ, 7, acc0, acc1);
+            prod(Z, iZ * sc.f[7], 7, acc0, acc1);
             store_out(p, 0, acc0, acc1, full, rowbits);
         }
     };
@@ -889,7 +904,9 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
                                                                    const int *__restrict__ trow, const unsigned *__restrict__ cmax,   // [9 CB] column bounds, or null:
                                                                    const unsigned *__restrict__ chan,   // [2 CB] max |f_{l-1}| | max |dz_l| per channel (see smp_wgrad_split)
                                                                    float smax, const unsigned *__restrict__ row_max,   // {max |tot|, max |tr|} (float bits)
-                                                                   int packed) {
+                                                                   int packed,
+                                                                   int nf) {  // 2: rs = [rows][2] (tot, tr); 8: rs = [rows][8], product w's own factor
+                                                                   // per row (slice dropout: see smp_rowpanel_split) -- every wave scales its B operand
     constexpr int NT = CB / 32, ACOLS = 4 * CB, BCOLS = 5 * CB;
     constexpr int TROW = 16 * CB, DROW = 8 * CB;   // bytes of a row of T, of dO
     __shared__ float sScale[ACOLS + BCOLS], sInv[ACOLS + BCOLS];
@@ -912,8 +929,8 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
 
     const int ablk = c_ws_ablk[wave], bblk = c_ws_bblk[wave];   // (uniform)
     const bool gathered = bblk == 4;
-    const int fsel = bblk == 2 ? 1 : 0;                         // the row factor a scaled copy of L takes: tot | tr
-    const bool scaled = bblk == 1 || bblk == 2;
+    const int fsel = nf == 8 ? wave : bblk == 2 ? 1 : 0;        // the row factor a scaled copy of L takes: tot | tr  (nf == 8: the product's own)
+    const bool scaled = nf == 8 || bblk == 1 || bblk == 2;
     const int abit = (ablk == 0 || ablk == 2) ? 31 : 29;        // presence bit of the wave's T block: S_ab / T6 | S_bc / T10
     float sa[NT], sb[NT];
 #pragma unroll
@@ -940,8 +957,9 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
     // (entries of rows past the end of the level read as 0 through the descriptors: no flag, factor 0 -- their operand rows are
     //  out of range anyway)
     const __amdgpu_buffer_rsrc_t rTr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(trow), 0, (unsigned)rows * 4u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rRs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rs), 0, (unsigned)rows * 8u, 0x00020000);
-    const int offF = scaled ? 64 * lg + 4 * fsel : kOut;   // (the other waves' requests return at once)
+    const int rsb = 4 * nf;   // bytes of a row of rs
+    const __amdgpu_buffer_rsrc_t rRs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rs), 0, (unsigned)rows * (unsigned)rsb, 0x00020000);
+    const int offF = scaled ? 8 * rsb * lg + 4 * fsel : kOut;   // (the other waves' requests return at once)
     auto ld1 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
     };
@@ -957,7 +975,7 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
         const long long k0 = slice_of(n) * kWsSlice;
         const int ks = k0 < rows ? (int)k0 : rows;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) F.f[j] = ld1(rRs, offF, ks * 8 + 8 * j);   // (the row in the scalar offset: one lane constant)
+        for (int j = 0; j < 8; ++j) F.f[j] = ld1(rRs, offF, (ks + j) * rsb);   // (the row in the scalar offset: one lane constant)
     };
     auto load_raw = [&](Raw &R, const Idx &I, int n) {
         const long long k0 = slice_of(n) * kWsSlice;
@@ -1249,7 +1267,7 @@ gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *con
 // level): forward O from T = [S_ab|S_bc|T6|T10], or backward dT from dO.  Every output element is produced by one wave in a
 // fixed order: results do not depend on the grid size.
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                 int rows, const int *trow, int cus, const int *trowf, bool skip_zero_grads, const void *wimg, int C) {
+                                 int rows, const int *trow, int cus, const int *trowf, bool skip_zero_grads, const void *wimg, int C, int nf) {
     const int per = kSpThreads / 64;
     const int npanels = (rows + 31) / 32;
     const int want = (npanels + per - 1) / per;
@@ -1259,16 +1277,26 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
     if (C != 64 && !wimg) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d channels need the level's prebuilt weight images", C);
     // packed table with the presence bits (see the kernel)
     const bool mask = trowf && rows < (1 << 29) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
-#define GF_SP_LAUNCH(F, M, CBv, name)                                                                                              \
+#define GF_SP_LAUNCH_NF(F, M, CBv, NFv, name)                                                                                      \
     do {                                                                                                                           \
         const size_t lds__ = 2 * (size_t)8 * (CBv / 32) * (CBv / 16) * 64 * 16 + 16 * sizeof(float) + (kSpThreads / 64) * 32 * sizeof(float); \
-        gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M, CBv>, lds__);                                                      \
+        gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M, CBv, NFv>, lds__);                                                 \
         if (st != GF_OK) return st;                                                                                                \
-        GF_LAUNCH(ctx, name, (smp_rowpanel_split<F, M, CBv>), dim3((unsigned)grid), dim3(kSpThreads), lds__, A, rowscale, Wst, Out, rows, \
+        GF_LAUNCH(ctx, name, (smp_rowpanel_split<F, M, CBv, NFv>), dim3((unsigned)grid), dim3(kSpThreads), lds__, A, rowscale, Wst, Out, rows, \
                   M ? trowf : trow, skip_zero_grads ? 1 : 0,                                                                       \
                   wimg ? static_cast<const uint4 *>(wimg) + (F ? 0 : kSpImgStride) : (const uint4 *)nullptr);                      \
     } while (0)
-    if (C == 64) {
+#define GF_SP_LAUNCH(F, M, CBv, name) GF_SP_LAUNCH_NF(F, M, CBv, 2, name)
+    if (nf != 2 && !(nf == 8 && C == 32)) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d row factors at %d channels", nf, C);
+    if (nf == 8) {   // (per-product row factors: the slice-dropout towers, computed at 32 channels)
+        if (forward) {
+            if (mask) GF_SP_LAUNCH_NF(true, true, 32, 8, "smpf_products_fwd");
+            else GF_SP_LAUNCH_NF(true, false, 32, 8, "smpf_products_fwd");
+        } else {
+            if (mask) GF_SP_LAUNCH_NF(false, true, 32, 8, "smpf_products_bwd");
+            else GF_SP_LAUNCH_NF(false, false, 32, 8, "smpf_products_bwd");
+        }
+    } else if (C == 64) {
         if (forward) {
             if (mask) GF_SP_LAUNCH(true, true, 64, "smpf_products_fwd");
             else GF_SP_LAUNCH(true, false, 64, "smpf_products_fwd");
@@ -1288,6 +1316,7 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
         return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d channels", C);
     }
 #undef GF_SP_LAUNCH
+#undef GF_SP_LAUNCH_NF
     return GF_OK;
 }
 
@@ -1310,12 +1339,12 @@ gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float 
 // column bounds taken from the operands themselves (one extra pass over T and dO; `words`: 512 + 9 * 32 scratch words).
 gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int splits, float *part,
                                         const int *trow, const int *trowf, unsigned *words, const unsigned *chan, float smax,
-                                        const unsigned *row_max) {
+                                        const unsigned *row_max, int nf) {
     constexpr int CB = 32;
     const bool mask = trowf && rows < (1 << 28) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
     if (chan && row_max) {
         GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<CB>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
-                  mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0);
+                  mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf);
         return GF_OK;
     }
     GF_HIP_TRY(ctx, hipMemsetAsync(words, 0, sizeof(unsigned) * 512, ctx->stream));
@@ -1324,10 +1353,11 @@ gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float
     // column maxima in chunks of 64 columns: T [rows][128] -> words [0, 128), dO [rows][64] -> words [256, 320)
     for (int k = 0; k < 4 * CB / 64; ++k) GF_LAUNCH(ctx, "smpf_colmax", col_absmax64, dim3(g), dim3(256), 0, T + 64 * k, (long long)rows, 4 * CB, words + 64 * k);
     for (int k = 0; k < 2 * CB / 64; ++k) GF_LAUNCH(ctx, "smpf_colmax", col_absmax64, dim3(g), dim3(256), 0, dO + 64 * k, (long long)rows, 2 * CB, words + 256 + 64 * k);
+    if (nf != 2) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_wgrad_direct: exact column bounds with per-product row factors");
     GF_LAUNCH(ctx, "smpf_colmax", rowscale_absmax, dim3(64), dim3(256), 0, rowscale, rows, words + 384);
     GF_LAUNCH(ctx, "smpf_colmax", wgrad_bounds_exact_cb, dim3(1), dim3(64), 0, words, words + 256, words + 384, words + 512, CB);
     GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<CB>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
-              mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0);
+              mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0, nf);
     return GF_OK;
 }
 size_t smp_wgrad_direct_words_c32() { return 512 + 9 * 32; }

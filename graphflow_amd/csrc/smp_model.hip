@@ -11,8 +11,10 @@
 // level (SMP_omega_pairgraphs.h:699-704).  The towers keep contiguous copies of their own parameters / gradients; segments
 // are copied device to device around every pass.
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
+#include "libc_random.h"
 #include "smp_internal.h"
 
 struct gf_smp_model {
@@ -123,8 +125,9 @@ gf_status gf_smp_model_create(gf_ctx *ctx, const gf_smp_model_config *cfg, gf_sm
     size_t toff[2] = {0, 0};
     for (int t = 0; t < m->nTowers; ++t) {
         gf_smp_config tc = {cfg->nLevels, cfg->nChanels, cfg->nFeatures[t], 0, cfg->max_receptive_field, 0, 18, 0, 1};
-        // (nKept > 0: RisiContraction_18_dropout keeps the levels op by op -- the towers then stay at their own halving widths)
-        gf_status st = gf::smp_create(ctx, &tc, /*pad_channels=*/cfg->nKept <= 0, &m->tower[t]);
+        // (nKept > 0, RisiContraction_18_dropout: towers of up to 32 channels run the fused levels with per-product slice factors since
+        //  round 5 -- padded like the others; wider ones keep their levels op by op, at their own halving widths)
+        gf_status st = gf::smp_create(ctx, &tc, /*pad_channels=*/cfg->nKept <= 0 || cfg->nChanels <= 32, &m->tower[t]);
         if (st != GF_OK) {
             gf_smp_model_destroy(m);
             return st;
@@ -265,7 +268,8 @@ gf_status gf_smp_model_forward(gf_smp_model *m, const float *params, const float
             totalV[t] = first[t][m->nMol];
             masks[t].assign((size_t)m->L * totalV[t], 0x3ffffu);
         }
-        if (m->train)
+        if (m->train) {
+            gf::LibcRandom rng(true);   // (libc's own stream, stepped inline; handed back when this scope ends)
             for (int i = 0; i < m->nMol; ++i)
                 for (int t = 0; t < m->nTowers; ++t)
                     for (int l = 1; l <= m->L; ++l)
@@ -273,7 +277,7 @@ gf_status gf_smp_model_forward(gf_smp_model *m, const float *params, const float
                             unsigned use = 0;
                             for (int k = 0; k < m->cfg.nKept; ++k)
                                 for (;;) {
-                                    const int j = rand() % 18;
+                                    const int j = rng.next() % 18;
                                     if (!((use >> j) & 1u)) {
                                         use |= 1u << j;
                                         break;
@@ -281,6 +285,7 @@ gf_status gf_smp_model_forward(gf_smp_model *m, const float *params, const float
                                 }
                             masks[t][(size_t)(l - 1) * totalV[t] + first[t][i] + v] = use;
                         }
+        }
         for (int t = 0; t < m->nTowers; ++t) {
             st = gf_smp_dropout_masks(m->tower[t], masks[t].data(), m->train ? 1.f : (float)m->cfg.nKept / 18.f);
             if (st != GF_OK) return st;

@@ -29,6 +29,13 @@ def test_op_headers_drop_into_the_real_reference_tree():
          "-Wl,-rpath,/opt/rocm/lib"])
 
 
+def test_inline_rand_stream_is_glibcs_rand_stream(bins):
+    """The slice masks of the dropout towers are drawn from libc's rand() stream (the reference's order); gf::LibcRandom steps that
+    stream inline (a million draws per 1024-sample step) and hands it back in step: tests/cpp/test_libc_random.cpp."""
+    r = subprocess.run([os.path.join(bins, "test_libc_random")], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_host_op_fails_loudly_without_a_gpu(bins):
     import torch
     if torch.cuda.is_available():

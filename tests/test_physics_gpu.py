@@ -114,3 +114,43 @@ def test_padded_towers_equal_the_towers_at_their_own_widths(gf, monkeypatch, tow
     print("towers %d C %d nKept %d: predict %.2e loss %.2e grads %.2e" % (towers, Cn, nKept, rel_err(p1, p0), rel_err(l1, l0), rel_err(g1, g0)))
     assert rel_err(p1, p0) <= 2e-6 and rel_err(l1, l0) <= 4e-6
     assert rel_err(g1, g0) <= TOL
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_levels_under_slice_dropout_equal_the_op_by_op_levels(gf, monkeypatch, train):
+    """Round 5: RisiContraction_18_dropout on the FUSED level.  A dropped slice k of a node's contraction is a zero factor on the block
+    product K^(k) (RisiContraction_18_dropout.h:106-132; test mode scales every slice by nKept / 18, :465-471), so the towers of
+    SMP_sigma_pairgraphs keep the fused level kernels with per-product row factors.  Same batch, same rand() sequence, against
+    GF_SMP_FUSED_DROPOUT=0 (the levels op by op with the slices of Q zeroed, as rounds 2-4 ran them)."""
+    from graphflow_amd.smp import SMPModel
+    from inputs import synthetic_molecule
+    L, cap, F, Cn, nKept = 3, 10, 5, 16, 7
+    mols = [synthetic_molecule(5100 + i, nV=4 + i % 9)[:2] for i in range(24)]
+    mols2 = [synthetic_molecule(5200 + i, nV=3 + i % 8)[:2] for i in range(24)]
+    tg = dev(np.array([synthetic_molecule(5100 + i)[2] for i in range(24)]))
+    got = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GF_SMP_FUSED_DROPOUT", mode)
+        net = SMPModel(L, Cn, cap, [F, F], nKept=nKept)
+        p = dev(np.random.default_rng(13).uniform(-0.3, 0.3, net.n_params))
+        net.prepare(mols, mols2)
+        net.set_mode(train)
+        C.CDLL(None).srand(9)
+        pred, loss = net.forward(p, tg)
+        g = torch.full((net.n_params,), float("nan"), device="cuda")
+        if train:
+            net.backward(p, g)
+        elif mode == "1":   # test mode scales the forward only (RisiContraction_18_dropout.h:465-471): the fused level refuses the sweep
+            with pytest.raises(Exception, match="test mode"):
+                net.backward(p, g)
+        got.append((pred.cpu().numpy().astype(np.float64), loss.cpu().numpy().astype(np.float64), g.cpu().numpy().astype(np.float64)))
+        net.close()
+    (p1, l1, g1), (p0, l0, g0) = got
+    if not train:
+        print("dropout fused vs op-by-op (test mode): predict %.2e loss %.2e" % (rel_err(p1, p0), rel_err(l1, l0)))
+        assert rel_err(p1, p0) <= 2e-6 and rel_err(l1, l0) <= 4e-6
+        return
+    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
+    print("dropout fused vs op-by-op (train %s): predict %.2e loss %.2e grads %.2e" % (train, rel_err(p1, p0), rel_err(l1, l0), rel_err(g1, g0)))
+    assert rel_err(p1, p0) <= 2e-6 and rel_err(l1, l0) <= 4e-6
+    assert rel_err(g1, g0) <= TOL
