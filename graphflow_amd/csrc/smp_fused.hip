@@ -752,7 +752,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
 // combine-backward.  Workgroup per (node, four consecutive x): from dF[x,:,:] produce dO[(x,y)] (the O_loc block), dZ[(x,e)],
 // dZ'[(e,x)] and the per-(node,x) partials dVout, dS-part, db-part.
 // ---------------------------------------------------------------------------------------------------------------
-template <int LPC>
+template <int LPC, int UB = 4>   // UB: rows whose loads a thread issues together, ahead of their stores (measured at cfg3: 2 -> 0.72, 4 -> 0.70, 8 -> 0.81 ms)
 __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restrict__ F, const float *__restrict__ dF,
                                                             const float *__restrict__ node_dF,  // [nodes][C] or null: (dF null) dF is
                                                             // the same C-vector at every (x,y) of a node (readout broadcast)
@@ -782,7 +782,6 @@ __global__ __launch_bounds__(kThreads) void smp_combine_bwd(const float *__restr
     const AdjLds L = load_adjacency_lite<true>(smem, A + rowbase, rsum + pairbase, N);  // L.A[e][y] = A+[y][e]; see the barrier below
     float *sDz = smem + adj_lds_floats(N);  // [kCombX][N][CW]
     const f4 gnode = node_dF ? ld4(node_dF + (size_t)W.node * C + fc) : splat(0.f);
-    constexpr int UB = 4;  // rows whose loads are issued together, ahead of their stores
     for (int it0 = grp; it0 < items; it0 += UB * NGRP) {
         f4 fv[UB], g[UB];
 #pragma unroll

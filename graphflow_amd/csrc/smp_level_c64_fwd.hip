@@ -138,7 +138,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         g2[r] = TWO ? ff_ld1(rGc, v15 + 128) : 0.f;
         g3[r] = TWO ? ff_ld1(rGc, v16 + 128) : 0.f;
     }
-    const float c15 = nodefac ? nodefac[(size_t)node * 18 + 15] : 1.f, c16 = nodefac ? nodefac[(size_t)node * 18 + 16] : 1.f;   // (a panel is one node's)
+    // (a panel is one node's.  Round 5: with these two run-time factors on the gathered operands the compiler stopped folding the gathers
+    //  into the sums as they arrive and keeps all 64 in registers: 180 + 16 registers instead of 132 + 16, two waves per SIMD instead of
+    //  three -- and the kernel went from 0.66 to 0.585 ms per cfg3 step, every request of a panel now being in flight at once.)
+    const float c15 = nodefac ? nodefac[(size_t)node * 18 + 15] : 1.f, c16 = nodefac ? nodefac[(size_t)node * 18 + 16] : 1.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         u0[r] += c15 * g0[r] + c16 * g1[r];
@@ -238,14 +241,13 @@ gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const flo
     const gfsmp::LevelLayout &h = s->lay.level[l];
     const int npanels = d.fwd_npanels;
     if (npanels < 1) return GF_OK;
-    if (s->cfg.nChanels == 64)
-        GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels<64>, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
-                  d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
-                  (long long)h.pairs, d.Sout, bias, psum, pmax, nodefac);
-    else
-        GF_LAUNCH(ctx, "smpf_combine_fwd", smp_combine_fwd_panels<32>, dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,
-                  d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,
-                  (long long)h.pairs, d.Sout, bias, psum, pmax, nodefac);
+#define GF_CFP_LAUNCH(CBv)                                                                                                               \
+    GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd_panels<CBv>), dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, O, d.f, d.fwd_pan,  \
+              d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,          \
+              (long long)h.pairs, d.Sout, bias, psum, pmax, nodefac)
+    if (s->cfg.nChanels == 64) GF_CFP_LAUNCH(64);
+    else GF_CFP_LAUNCH(32);
+#undef GF_CFP_LAUNCH
     return GF_OK;
 }
 
