@@ -1489,7 +1489,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                     st = gf::upload(s, &d.pmax, nullptr, (size_t)np * C);
                     if (st != GF_OK) return st;
                 }
-                st = gf::upload(s, &d.dzmax, nullptr, h.quad_node.size() * 64);
+                st = gf::upload(s, &d.dzmax, nullptr, std::max(h.quad_node.size(), (size_t)np) * 64);
                 if (st != GF_OK) return st;
                 st = gf::upload(s, &d.fwd_pan_node, nullptr, (size_t)np);
                 if (st != GF_OK) return st;

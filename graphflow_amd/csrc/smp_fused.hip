@@ -1626,7 +1626,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
             //  f_{l-1} itself was read for them: 94 MB at cfg3's level 3 -- or from f_0)
             const bool pm = pv.pmax && pv.pmax_ready;
             st = smp_wgrad_channel_maxima_ld(ctx, pm ? pv.pmax : pv.f, pm ? (long long)pv.fwd_npanels : (long long)s->lay.level[l - 1].rows, C, d.dzmax,
-                                             (long long)h.quad_node.size(), smp_half_window(C) ? 32 : 64, C, words);
+                                             d.dz_rows, smp_half_window(C) ? 32 : 64, C, words);
             if (st != GF_OK) return st;
             chan = words;
         }
@@ -1650,7 +1650,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
             // combine-backward -- 17 - 19 MB of partials at cfg3's level 3, reduced by one small launch
             const bool pm = pv.pmax && pv.pmax_ready;
             st = smp_wgrad_channel_maxima(ctx, pm ? pv.pmax : pv.f, pm ? (long long)pv.fwd_npanels : (long long)s->lay.level[l - 1].rows, d.dzmax,
-                                          (long long)h.quad_node.size(), wb);
+                                          d.dz_rows, wb);
             if (st != GF_OK) return st;
             sc.chan = wb;
             sc.smax = (float)h.buckets.back().s;
@@ -1791,6 +1791,16 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: the product kernels' option (GF_OPT_SMP_FP32_PRODUCTS / GF_SMP_SPLIT / GF_SMP_ROWPANEL) "
                                          "changed since the forward pass of level %d", l);
     float *dzmax = (s->wbound && d.dzmax && d.fwd_c64) ? d.dzmax : (float *)nullptr;
+    // round 5: on the forward's row panels where they exist (one wave per panel, every request up front; GF_SMP_COMBINE_BWD_PANELS=0: the
+    // workgroup-per-(node, four x) kernel below, which also serves every other channel count)
+    if (d.fwd_c64 && d.fwd_pan && (C == 64 || C == 32) && (long long)h.rows * 512 < 0x3fffffffll && !env_is("GF_SMP_COMBINE_BWD_PANELS", '0')) {
+        st = smp_combine_bwd_panels_c64(s, l, dfrows, node_df, dO, dzmax);
+        if (st != GF_OK) return st;
+        s->lv[l].dz_rows = d.fwd_npanels;
+        (void)Kl;
+        return smp_fused_backward_level_grouped(s, l, dKl, dbl);
+    }
+    s->lv[l].dz_rows = (long long)h.quad_node.size();
     if (smp_half_window(C)) {   // eight lanes per row (32-channel windows): at C = 32 every lane has channels
         const int nw8 = C / 32, N = h.buckets.back().s;
         // (the column maxima go through kThreads / 8 x 32 floats of the dz image: room for them whatever the field size)

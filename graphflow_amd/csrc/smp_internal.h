@@ -146,7 +146,8 @@ struct gf_smp {
         bool psum_ready = false;   // ... written by this forward pass
         // per-channel maxima for the weight gradients' column exponents (smp_level_c64_split.hip: smp_wgrad_column_bounds), C = 64:
         float *pmax = nullptr;     // [fwd_npanels][64] largest |f_l| of every row panel, left by combine-forward (levels below the top)
-        float *dzmax = nullptr;    // [quads][64] largest |dz| of every workgroup of combine-backward
+        float *dzmax = nullptr;    // [max(quads, row panels)][64] largest |dz| of every workgroup / panel of combine-backward
+        long long dz_rows = 0;     // ... rows of it the last combine-backward wrote
         bool pmax_ready = false;
         void *wimg = nullptr;  // the split product kernels' weight images of this pass (smp_split_build_images), C = 64
         bool wimg_ready = false;
@@ -231,6 +232,8 @@ gf_status smp_build_tf_records(gf_smp *s, int l, hipStream_t stream);
 gf_status smp_fwd_fused_build_tables(gf_smp *s, int l, hipStream_t stream, bool gather_offsets = true);
 gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const float *bias, float *psum = nullptr, float *pmax = nullptr,
                                      const float *nodefac = nullptr);
+// combine-backward on the forward's row panels (C = 64 / 32, compact dO): dzmax = [fwd_npanels][C] per-panel column maxima of |dz| or null
+gf_status smp_combine_bwd_panels_c64(gf_smp *s, int l, const float *dfrows, const float *node_df, float *dO, float *dzmax);
 gf_status ensure_P(gf_smp *s);
 size_t feature_width(const gfsmp::Config &c);  // physics tower: sum over the levels of their channel counts
 // level l's K_l / b_l gradients are complete on the context's CURRENT stream (l == 0: H): start their all-reduce

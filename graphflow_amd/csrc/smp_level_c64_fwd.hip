@@ -37,6 +37,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ff_rsrc(const void *base, size
     const unsigned n = bytes > 0xfffffffcull ? 0xfffffffcu : (unsigned)bytes;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000);
 }
+// (the value goes through a scalar first: __builtin_bit_cast applied directly to an element of an ext_vector -- bit_cast(unsigned, v[r]) --
+//  compiled to element 0 for every r with this hipcc: round 5, every row of a tile stored register 0)
+__device__ __forceinline__ void ff_st1(__amdgpu_buffer_rsrc_t r, int voff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
+}
 __device__ __forceinline__ float ff_ld1(__amdgpu_buffer_rsrc_t r, int voff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
 }
@@ -192,6 +197,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// combine-backward on the same row panels (round 5; it was a workgroup per (node, four x) with the adjacency image and the panel's dz
+// in LDS behind two barriers: 4.0 TB/s on its bytes).  One WAVE per panel, every request up front, C/D-tile registers throughout:
+//   dz[x, y]  = dF[x, y] * LeakyReLU'(f[x, y])                                   -> block L of dO  (and the level's bias / weight gradients)
+//   dU[x, e]  = sum_y A+[y, e] dz[x, y]                                           -> block dU of dO : sixteen fp32 MFMA steps per column
+//               half with A'^T (the panel's block-diagonal gated adjacency, transposed) as the A operand and dz as the B operand
+//   dVout[x]  = sum_y r[y] dz[x, y]     dSpart[x] = sum_y A+[x, y] dz[x, y]     dbpart[x] = sum_y dz[x, y]
+//               one more MFMA chain: output row (type t, group g) of a 32 x 32 tile takes weight  [row e in group g] * {r[y_e], A+[x_g, y_e], 1};
+//               the three weights of an input row are what ITS lane holds for the forward pass (r[y], A+[x, y]), read with v_readlane
+// and the per-column maxima of |dz| over the panel (the weight gradients' column exponents).  Same sums per output element as
+// smp_combine_bwd (fixed order: the MFMA's k order), held to it by the parity tests (GF_SMP_COMBINE_BWD_PANELS=0 selects it).
+// ---------------------------------------------------------------------------------------------------------------
+template <int CB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void smp_combine_bwd_panels(
+    const float *__restrict__ F, const float *__restrict__ dF,   // dF null: the gradient is node_dF's vector at every row of the node
+    const float *__restrict__ node_dF,                            // [nodes][CB] or null; with dF: both are added (a tower's level below the top)
+    float *__restrict__ dO, const int4 *__restrict__ pan, const int *__restrict__ pan_node, int npanels, int rows,
+    const float *__restrict__ adj, const float *__restrict__ rsum, long long pairs, float *__restrict__ dVout, float *__restrict__ dSpart,
+    float *__restrict__ dbpart, float *__restrict__ dzmax) {   // dzmax (or null): [npanels][CB]
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    unsigned blk;
+    {
+        const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8;
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8;
+    }
+    const int p = __builtin_amdgcn_readfirstlane((int)(blk * 4 + (threadIdx.x >> 6)));
+    if (p >= npanels) return;
+    auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const int4 Pv = pan[p];
+    const int4 P = make_int4(rfl(Pv.x), rfl(Pv.y), rfl(Pv.z), rfl(Pv.w));
+    const int node = rfl(pan_node[p]);
+    const int nrows = P.y & 0xff, s = (P.y >> 8) & 0xff, G = (P.y >> 16) & 0xff, x0 = (P.y >> 24) & 0xff;
+    const bool rowok = li < nrows;
+    const int row = P.x + (rowok ? li : nrows - 1);
+    constexpr bool TWO = CB == 64;
+    constexpr int OB = 2 * CB * 4, FB = CB * 4;
+    const __amdgpu_buffer_rsrc_t rF = ff_rsrc(F, (size_t)rows * CB * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rG = ff_rsrc(dF ? dF : F, dF ? (size_t)rows * CB * sizeof(float) : 0);   // (no dF: every load returns 0)
+    const __amdgpu_buffer_rsrc_t rAdj = ff_rsrc(adj, (size_t)rows * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rO = ff_rsrc(dO, (size_t)rows * 2 * CB * sizeof(float));
+    const int gs = (int)((li + 0.5f) * __builtin_amdgcn_rcpf((float)s));
+    const int y_li = li - gs * s;
+    // every operand of the panel, requested up front
+    f16v f0, f1, g0, g1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int vo = rr < nrows ? (P.x + rr) * FB + li * 4 : kFfOor;
+        f0[r] = ff_ld1(rF, vo);
+        g0[r] = ff_ld1(rG, vo);
+        if constexpr (TWO) {
+            f1[r] = ff_ld1(rF, vo + 128);
+            g1[r] = ff_ld1(rG, vo + 128);
+        } else {
+            f1[r] = g1[r] = 0.f;
+        }
+    }
+    float avT[16];   // A+[y_e, y_li] of the lane's group: the lane's half row of A'^T
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int er = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int e = er - gs * s;
+        const bool in = rowok && e >= 0 && e < s && er < nrows;
+        avT[r] = ff_ld1(rAdj, in ? (P.z + e * s + y_li) * 4 : kFfOor);
+    }
+    const float gn0 = node_dF ? node_dF[(size_t)node * CB + li] : 0.f, gn1 = (TWO && node_dF) ? node_dF[(size_t)node * CB + 32 + li] : 0.f;
+    const float axy_raw = rowok ? adj[row] : 0.f;
+    const float axy = axy_raw > 0.f ? axy_raw : 0.f;                  // A+[x, y] of the lane's own row
+    const float r_y = rowok ? rsum[(size_t)P.w + y_li] : 0.f;           // r[y] of the lane's own row
+    // dz in the C/D layout; rows past the panel are zeroed (a node-vector gradient would otherwise leak into them)
+    f16v z0, z1;
+    float x0m = 0.f, x1m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = rr < nrows;
+        const float a = (g0[r] + gn0) * (f0[r] > 0.f ? 1.f : kAlphaFf), b = (g1[r] + gn1) * (f1[r] > 0.f ? 1.f : kAlphaFf);
+        z0[r] = ok ? a : 0.f;
+        z1[r] = ok ? b : 0.f;
+        x0m = fmaxf(x0m, fabsf(z0[r]));
+        x1m = fmaxf(x1m, fabsf(z1[r]));
+        const int vo = ok ? (P.x + rr) * OB + li * 4 : kFfOor;
+        ff_st1(rO, vo, z0[r]);
+        if constexpr (TWO) ff_st1(rO, vo + 128, z1[r]);
+    }
+    // dU = A'^T dz
+    f16v u0, u1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u0[r] = u1[r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float a = avT[r] > 0.f ? avT[r] : 0.f;   // the gate of RisiContraction_18 (RisiContraction_18.h:345)
+        u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z0[r], u0, 0, 0, 0);
+        if constexpr (TWO) u1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z1[r], u1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int vo = rr < nrows ? (P.x + rr) * OB + FB + li * 4 : kFfOor;
+        ff_st1(rO, vo, u0[r]);
+        if constexpr (TWO) ff_st1(rO, vo + 128, u1[r]);
+    }
+    // the per-(node, x) partials: tile row (t, g) = 8 t + g, weight of input row e: [group of e == g] * {r[y_e], A+[x_g, y_e], 1}
+    f16v q0, q1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q0[r] = q1[r] = 0.f;
+    {
+        const int tt = li >> 3, tg = li & 7;   // the lane's output row as the A operand: (type, group)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ea = (r & 3) + 8 * (r >> 2);   // input row of the low lane half; the high half supplies row ea + 4
+            const int ga = __builtin_amdgcn_readlane(gs, ea), gb = __builtin_amdgcn_readlane(gs, ea + 4);
+            const float ra = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r_y), ea));
+            const float rb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r_y), ea + 4));
+            const float aa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, axy), ea));
+            const float ab = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, axy), ea + 4));
+            const int ge = lh ? gb : ga;
+            const float rv = lh ? rb : ra, av = lh ? ab : aa;
+            const bool hit = tg == ge && (ea + 4 * lh) < nrows && tg < G;
+            const float w = !hit ? 0.f : tt == 0 ? rv : tt == 1 ? av : tt == 2 ? 1.f : 0.f;
+            q0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, z0[r], q0, 0, 0, 0);
+            if constexpr (TWO) q1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, z1[r], q1, 0, 0, 0);
+        }
+    }
+    {
+        const __amdgpu_buffer_rsrc_t rV = ff_rsrc(dVout, (size_t)pairs * CB * sizeof(float));
+        const __amdgpu_buffer_rsrc_t rS = ff_rsrc(dSpart, (size_t)pairs * CB * sizeof(float));
+        const __amdgpu_buffer_rsrc_t rB = ff_rsrc(dbpart, (size_t)pairs * CB * sizeof(float));
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {   // tile rows (r & 3) + 8 (r >> 2) + 4 lh: type r >> 2, group (r & 3) + 4 lh
+            const int g = (r & 3) + 4 * lh;
+            const int vo = g < G ? (int)(((long long)P.w + x0 + g) * FB) + li * 4 : kFfOor;
+            const __amdgpu_buffer_rsrc_t rd = (r >> 2) == 0 ? rV : (r >> 2) == 1 ? rS : rB;
+            ff_st1(rd, vo, q0[r]);
+            if constexpr (TWO) ff_st1(rd, vo + 128, q1[r]);
+        }
+    }
+    if (dzmax) {  // (uniform)
+        x0m = fmaxf(x0m, __shfl_xor(x0m, 32));
+        x1m = fmaxf(x1m, __shfl_xor(x1m, 32));
+        if (TWO || lh == 0) dzmax[(size_t)p * CB + lane] = lh ? x1m : x0m;
+    }
+}
+
 // ---- per-level tables of the kernel above, built on the device at prepare time
 // node_panel[n] = first panel of node n; a node of size s has ceil(s / gpp) panels of gpp = max(1, 32 / s) row groups
 __global__ void build_fwd_panels(const int *__restrict__ node_s, const long long *__restrict__ node_row,
@@ -248,6 +397,22 @@ gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const flo
     if (s->cfg.nChanels == 64) GF_CFP_LAUNCH(64);
     else GF_CFP_LAUNCH(32);
 #undef GF_CFP_LAUNCH
+    return GF_OK;
+}
+
+// dO = [L | dU] and the per-(node, x) partials of a fused level from df_l (rows, a per-node vector, or both): smp_combine_bwd_panels
+gf_status smp_combine_bwd_panels_c64(gf_smp *s, int l, const float *dfrows, const float *node_df, float *dO, float *dzmax) {
+    gf_ctx *ctx = s->ctx;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const gfsmp::LevelLayout &h = s->lay.level[l];
+    const int npanels = d.fwd_npanels;
+    if (npanels < 1) return GF_OK;
+#define GF_CBP_LAUNCH(CBv)                                                                                                              \
+    GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd_panels<CBv>), dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, d.f, dfrows, node_df, dO, \
+              d.fwd_pan, d.fwd_pan_node, npanels, (int)h.rows, d.adj, d.rsum, (long long)h.pairs, d.dVout, d.dSpart, d.dbpart, dzmax)
+    if (s->cfg.nChanels == 64) GF_CBP_LAUNCH(64);
+    else GF_CBP_LAUNCH(32);
+#undef GF_CBP_LAUNCH
     return GF_OK;
 }
 
