@@ -20,7 +20,8 @@ def launch_name(k):
         return "fam_bwd_tables_col" if m.group(1) == "0" else "fam_bwd_tables_row"
     base = re.sub(r"[<(].*", "", k).split("::")[-1]
     table = {"smp_tables_fwd": "smpf_tables_fwd", "smp_tables_fwd_w": "smpf_tables_fwd", "smp_tables_bwd": "smpf_tables_bwd",
-             "smp_combine_fwd": "smpf_combine_fwd", "smp_combine_bwd": "smpf_combine_bwd", "promote_backward": "smp_promote_bwd",
+             "smp_combine_fwd": "smpf_combine_fwd", "smp_combine_bwd": "smpf_combine_bwd", "smp_combine_fwd_panels": "smpf_combine_fwd",
+             "smp_combine_bwd_panels": "smpf_combine_bwd", "smp_bwd_gather_all": "smpf_bwd_gather", "smp_small_split": "smpf_small_split", "promote_backward": "smp_promote_bwd",
              "smp_vectors": "smpf_vectors", "smp_bwd_gather": "smpf_bwd_gather", "smp_wgrad_c64": "smpf_wgrad", "smp_wgrad_split": "smpf_wgrad",
              "smp_reduce_pairs": "smpf_reduce_pairs", "smp_fold_level": "smpf_fold", "diag_gather_bwd": "smpf_diag_gather_bwd",
              "diag_gather_fwd": "smpf_diag_gather", "stack_weights_all": "smpf_stack_w", "readout_nodes_v": "smp_readout_nodes",

@@ -6,7 +6,7 @@ set -u
 TAG=${1:-r02}
 WL=${2:-cfg3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-ARGS="--workload $WL --no-cpu-baseline --no-extra"
+ARGS="--workload $WL --no-cpu-baseline --no-extra --repeats 1"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_${WL}_trace -o $WL -- python $R/bench.py --steps 20 --warmup 3 $ARGS > $R/gpurun_out/prof_${TAG}_${WL}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_${WL}_fetch -- python $R/bench.py --steps 2 --warmup 1 $ARGS > $R/gpurun_out/prof_${TAG}_${WL}_fetch.log 2>&1
