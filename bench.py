@@ -250,7 +250,7 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
     def add(d, k, v):
         d[k] = d.get(k, 0) + v
 
-    c64 = C in (64, 32)   # the dedicated product / weight-gradient kernels (row panels; C = 32 since round 4)
+    c64 = C in (64, 32, 16)   # the dedicated product / weight-gradient kernels (row panels; C = 32 since round 4, 16 since round 5)
     # projected matrix O / dO: [O_loc | U] (2C) when the three dedicated C = 64 product kernels run, else [O_loc | Z | Z'] (3C)
     oc = 2 if (c64 and os.environ.get("GF_SMP_ROWPANEL", "1") != "0") else 3
     # ... and then the three product kernels run on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip): 3 MFMA
@@ -679,7 +679,7 @@ def main():
                 # the same model at 32 channels (the reference runs any nChanels): the row-panel kernel family templated on the channel
                 # count, weight gradients on smp_wgrad_direct<32>; its own context and handle, same molecules
                 # ... and at 10 channels, the reference's own test models (tests/test_SMP_omega.cpp:22-34): computed with the channels
-                # zero-padded to 32 on the device, the caller's parameter / gradient layout kept at the C ABI
+                # zero-padded to 16 on the device (32 until round 5), the caller's parameter / gradient layout kept at the C ABI
                 import copy
                 for Cx in (32, 10):
                     a32 = copy.copy(args)

@@ -1006,7 +1006,7 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) { r
 
 // pad_channels = false: compute at the configuration's own channel counts (the towers of a model with RisiContraction_18_dropout --
 // SMP_sigma_pairgraphs -- whose levels run op by op, where a padded width only costs)
-gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channels, gf_smp **out) {
+gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channels, gf_smp **out, int min_pad) {
     if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
     if (!cfg || !out) return fail(ctx, GF_ERR_INVALID, "gf_smp_create: null argument");
     if (cfg->nLevels < 1 || cfg->nChanels < 1 || cfg->nFeatures < 1 || cfg->nDepth < 0 || cfg->max_receptive_field < 1)
@@ -1037,7 +1037,10 @@ gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channel
         const int C = s->cfg.nChanels;
         int Cc = C;
         if ((pad_channels || (e && e[0] == '2')) && !(e && e[0] == '0') && s->cfg.nContractions == 18 && s->cfg.nLevels < gf::kPadMaxLevels) {   // (2: tests)
-            if (C <= 32) Cc = 32;
+            // (round 5: a 16-channel build of the row-panel family -- the reference's own models have nChanels = 10; min_pad = 32 keeps a
+            //  tower that will run under slice dropout on the 32-channel kernels, the only ones with per-product row factors)
+            if (C <= 16 && min_pad <= 16 && !(e && e[0] == '3')) Cc = 16;   // GF_SMP_PAD_CHANNELS=3: pad to 32 as rounds 1-4 did (tests)
+            else if (C <= 32) Cc = 32;
             else if (C <= 64) Cc = 64;
             else Cc = (C + 3) & ~3;
             // a physics tower (channels halve per level, SMP_omega_physics.h:141-151) is computed at ONE width: K_l [18 C_{l-1}][C_l]
@@ -1463,7 +1466,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             st = gf::upload(s, &d.cons_qbase, h.cons_qbase.empty() ? nullptr : &h.cons_qbase[0], h.cons_qbase.size());
             if (st != GF_OK) return st;
         }
-        if (s->cfg.square() && (C == 64 || C == 32) && h.rows < 0x7fffffffll) {   // (C = 32: the split row-panel products, round 4)
+        if (s->cfg.square() && gf::smp_panel_channels(C) && h.rows < 0x7fffffffll) {   // (C = 32: the split row-panel products, round 4; 16: round 5)
             st = gf::upload(s, &d.trow, nullptr, (size_t)h.rows);
             if (st == GF_OK) st = gf::upload(s, &d.trowf, nullptr, (size_t)h.rows);
             if (st == GF_OK) {
@@ -1596,7 +1599,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     if (s->cfg.square() && C == 64) {
         st = gf::upload(s, &s->wbound, nullptr, gf::smp_wgrad_bound_words() * (size_t)(L + 1));
         if (st != GF_OK) return st;
-    } else if (s->cfg.square() && C == 32) {   // scratch words of the C = 32 weight-gradient kernel's exact column bounds
+    } else if (s->cfg.square() && (C == 32 || C == 16)) {   // scratch words of the C = 32 / 16 weight-gradient kernel's column bounds
         st = gf::upload(s, &s->wbound, nullptr, gf::smp_wgrad_direct_words_c32() * (size_t)(L + 1));
         if (st != GF_OK) return st;
     }
@@ -1874,6 +1877,9 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
             else if (l >= 1 && d.psum && d.psum_ready && Cc == 32)
                 GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<32>, dim3((unsigned)((B.level[l].nNodes + 7) / 8)), dim3(256), 0, d.psum,
                           d.node_panel, B.level[l].nNodes, d.fwd_npanels, d.sh, d.vf);
+            else if (l >= 1 && d.psum && d.psum_ready && Cc == 16)
+                GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<16>, dim3((unsigned)((B.level[l].nNodes + 15) / 16)), dim3(256), 0, d.psum,
+                          d.node_panel, B.level[l].nNodes, d.fwd_npanels, d.sh, d.vf);
             else if (Cc % 4 == 0 && Cc <= 1024)   // (workgroup per node, float4 lanes: a padded tower's levels)
                 GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(B.level[l].nNodes), dim3(256), 0, d.f, d.node_s, d.node_row, d.sh, d.vf, Cc);
             else
@@ -1896,6 +1902,9 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
                   s->lv[L].node_panel, top.nNodes, s->lv[L].fwd_npanels, s->sh, s->vf);
     } else if (C == 32 && s->lv[L].psum_ready) {
         GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<32>, dim3((unsigned)((top.nNodes + 7) / 8)), dim3(256), 0, s->lv[L].psum,
+                  s->lv[L].node_panel, top.nNodes, s->lv[L].fwd_npanels, s->sh, s->vf);
+    } else if (C == 16 && s->lv[L].psum_ready) {
+        GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<16>, dim3((unsigned)((top.nNodes + 15) / 16)), dim3(256), 0, s->lv[L].psum,
                   s->lv[L].node_panel, top.nNodes, s->lv[L].fwd_npanels, s->sh, s->vf);
     } else if (C % 4 == 0 && C <= 1024) {
         GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(top.nNodes), dim3(256), 0, s->lv[L].f, s->lv[L].node_s,

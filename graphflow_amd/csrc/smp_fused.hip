@@ -56,6 +56,14 @@ __device__ __forceinline__ f4 dpp_xor8(f4 v) {
     return r;
 }
 
+__device__ __forceinline__ f4 dpp_ror4(f4 v) {   // x of lane + 4 inside each 16-lane row (row_ror:4)
+    f4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), 0x124 /* row_ror:4 */, 0xf, 0xf, true));
+    return r;
+}
+
 constexpr float kAlphaF = 0.01f;
 __device__ __forceinline__ float lreluf(float z) { return z > 0.f ? z : kAlphaF * z; }
 
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
                                                              float *__restrict__ St) {  // VEC: [nodes][4C] per-node scalars
     static_assert(!VEC || ALLOK, "the folded vector sums need every lane to have channels");
     constexpr int PPW = 64 / LPC, CWIN = 4 * LPC;   // positions per wave load, channels per window
-    static_assert(LPC == 16 || (LPC == 8 && ALLOK), "eight lanes per position: whole 32-channel windows only");
+    static_assert(LPC == 16 || ((LPC == 8 || LPC == 4) && ALLOK), "eight / four lanes per position: whole 32- / 16-channel windows only");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = lane / LPC, fl = lane % LPC;
@@ -240,9 +248,13 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
             sab += v;
             t6 += rc[i] * v;
         }
-        if constexpr (LPC == 8) {   // the two c-groups of a 16-lane row first (lane ^ 8: a rotation by eight inside the row, on the VALU)
+        if constexpr (LPC <= 8) {   // the two c-groups of a 16-lane row first (lane ^ 8: a rotation by eight inside the row, on the VALU)
             sab += dpp_xor8(sab);
             t6 += dpp_xor8(t6);
+        }
+        if constexpr (LPC == 4) {   // ... four of them: the pairs' sums rotated by four (v[l] + v[l+8] + v[l+4] + v[l+12])
+            sab += dpp_ror4(sab);
+            t6 += dpp_ror4(t6);
         }
         const f4 both = fold_two_tables(sab, t6);  // even 16-lane rows: S_ab[a,b], odd rows: T6[a,b]
         dgsum += dcur;
@@ -1000,10 +1012,12 @@ Ragged ragged_for(const gf_smp::DevLevel &d, long long lo, int smax) {
 // channel counts that are whole 32-channel windows but not whole 64-channel ones (C = 32, 96): the workgroup-per-(node, x) kernels run
 // with eight lanes per row instead of sixteen half-idle ones
 static bool smp_half_window(int C) { return C % 32 == 0 && C % 64 != 0; }
+// ... and whole 16-channel windows only (C = 16, 48, ...): four lanes per position in tables-forward (round 5: the 16-channel kernel family)
+static bool smp_quarter_window(int C) { return C == 16; }
 
 // tables-forward keeps smp_vectors' sums itself (C % 64 == 0; GF_SMP_TF_VEC=0: the separate pass)
 static bool smp_tables_fold_vectors(const gf_smp *s) {
-    return ((s->cfg.nChanels & 63) == 0 || smp_half_window(s->cfg.nChanels)) && !env_is("GF_SMP_TF_VEC", '0');
+    return ((s->cfg.nChanels & 63) == 0 || smp_half_window(s->cfg.nChanels) || smp_quarter_window(s->cfg.nChanels)) && !env_is("GF_SMP_TF_VEC", '0');
 }
 
 // the eight-lanes-per-position classes (C % 32 == 0, C % 64 != 0): a wave load covers eight positions, NI = 1, 2, 4 for s <= 8, 16, 32
@@ -1013,22 +1027,23 @@ template <int NI>
 constexpr const char *tables_fwd_name() {
     return NI == 1 ? "smpf_tables_fwd_ni1" : NI == 2 ? "smpf_tables_fwd_ni2" : NI == 4 ? "smpf_tables_fwd_ni4" : "smpf_tables_fwd_ni8";
 }
-template <int NI>
-gf_status launch_tables_fwd_w8(gf_smp *s, int l, const SizeClass &c) {
+template <int NI, int LPC>   // LPC = 8 (32-channel windows) or 4 (16-channel windows): 64 / LPC positions per wave load
+gf_status launch_tables_fwd_wn(gf_smp *s, int l, const SizeClass &c) {
     gf_ctx *ctx = s->ctx;
     const gf_smp::DevLevel &d = s->lv[l];
     const gfsmp::LevelLayout &h = s->lay.level[l];
-    const int C = s->cfg.nChanels, nwin = C / 32;
+    const int C = s->cfg.nChanels, nwin = C / (4 * LPC);
+    constexpr int PPW = 64 / LPC;
     const int n_lo = h.pair_node[(size_t)c.lo], n_hi = (c.hi < (long long)h.pairs) ? h.pair_node[(size_t)c.hi] : h.nNodes;
     if (n_hi <= n_lo) return GF_OK;
-    const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + 16 * (size_t)c.smax + sizeof(int) * (size_t)c.smax * 8 * NI + 16 +
+    const size_t lds = sizeof(float) * ((c.smax + 3) & ~3) + 16 * (size_t)c.smax + sizeof(int) * (size_t)c.smax * PPW * NI + 16 +
                        (size_t)c.smax * c.smax + 16;
     const int nwv = kThreads / 64;
-    const size_t lds_v = ((lds + 15) & ~(size_t)15) + 16 + (size_t)nwv * ((size_t)c.smax * 256 + 256);
-    gf_status st = opt_in_lds(ctx, smp_tables_fwd_w<NI, true, true, 8>, lds_v);
+    const size_t lds_v = ((lds + 15) & ~(size_t)15) + 16 + (size_t)nwv * ((size_t)c.smax * (32 * LPC) + 32 * LPC);
+    gf_status st = opt_in_lds(ctx, smp_tables_fwd_w<NI, true, true, LPC>, lds_v);
     if (st != GF_OK) return st;
     const int flags = d.t_zeros ? 1 : 0;
-    GF_LAUNCH(ctx, tables_fwd_name<NI>(), (smp_tables_fwd_w<NI, true, true, 8>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3(kThreads), lds_v,
+    GF_LAUNCH(ctx, tables_fwd_name<NI>(), (smp_tables_fwd_w<NI, true, true, LPC>), dim3((unsigned)((n_hi - n_lo) * nwin)), dim3(kThreads), lds_v,
               s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal, d.pair_src_row, d.pair_src_s, d.pi, d.tf_recs + 2 * (size_t)n_lo, C, nwin,
               flags, flags ? d.rowflag : (const unsigned char *)nullptr, d.St);
     return GF_OK;
@@ -1339,7 +1354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // gradients on smp_wgrad_direct<32>); the fp32-pipe variants, the panel combine and the small-product kernels stay C = 64 only.
 static bool smp_c64_kernels(const gf_smp *s) {
     if (env_is("GF_SMP_ROWPANEL", '0')) return false;
-    return s->cfg.nChanels == 64 || (s->cfg.nChanels == 32 && smp_split_products(s->ctx) && s->wbound != nullptr);
+    return s->cfg.nChanels == 64 || ((s->cfg.nChanels == 32 || s->cfg.nChanels == 16) && smp_split_products(s->ctx) && s->wbound != nullptr);
 }
 // compact projected matrix O = [O_loc | U] (2C) instead of [O_loc | Z | Z'] (3C): the dedicated C = 64 product kernels gather the
 // transposed rows themselves; the tiled launches keep the three-block layout
@@ -1363,7 +1378,7 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K) {
     }
     // ... and the split product kernels' weight images of every level, both directions (the backward pass reuses them)
     for (int l = 1; l <= L; ++l) s->lv[l].wimg_ready = false;
-    if ((C == 64 || C == 32) && smp_compact_o(s) && smp_split_products(s->ctx)) {
+    if (smp_panel_channels(C) && smp_compact_o(s) && smp_split_products(s->ctx)) {
         std::vector<const float *> w;
         std::vector<void *> im;
         for (int l = 1; l <= L; ++l)
@@ -1385,7 +1400,10 @@ gf_status smp_fused_ensure_zero_fill(gf_smp *s, int l) {
     gf_smp::DevLevel &d = s->lv[l];
     if (!d.t_zeros || d.t_filled || !d.rowflag) return GF_OK;
     const long long rows = s->lay.level[l].rows;
-    if (s->cfg.nChanels == 64)
+    if (s->cfg.nChanels == 16)
+        GF_LAUNCH(s->ctx, "smpf_tables_fill", tables_zero_fill<16>, dim3((unsigned)((rows + kZeroFillRows - 1) / kZeroFillRows)), dim3(256), 0, d.Q,
+                  d.rowflag, rows);
+    else if (s->cfg.nChanels == 64)
         GF_LAUNCH(s->ctx, "smpf_tables_fill", tables_zero_fill<64>, dim3((unsigned)((rows + kZeroFillRows - 1) / kZeroFillRows)), dim3(256), 0, d.Q,
                   d.rowflag, rows);
     else
@@ -1429,7 +1447,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     // Round 4: and they are not even written that once while every reader of T skips them -- the split product kernels and the packed
     // weight-gradient kernel read an absent block from a page of zeros, the sums over b never visit one -- which is the default path; a
     // reader that does not mask (fp32 pipe, tiled GEMMs) gets the fill before it runs (here, or ensure_zero_fill in the reverse sweep).
-    if ((C == 64 || (C == 32 && smp_tables_fold_vectors(s))) && d.rowflag && !env_is("GF_SMP_MASK_ZEROS", '0')) {
+    if ((C == 64 || ((C == 32 || C == 16) && smp_tables_fold_vectors(s))) && d.rowflag && !env_is("GF_SMP_MASK_ZEROS", '0')) {
         s->lv[l].t_zeros = true;
         const bool readers_mask = smp_c64_kernels(s) && smp_split_products(ctx) && d.trowf && d.trow && (long long)rows < (1ll << 29);
         if (!readers_mask) {
@@ -1444,13 +1462,19 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         GF_LAUNCH(ctx, "smpf_dropout_factors", build_dropout_factors, dim3(nodes), dim3(64), 0, d.keep_mask, s->drop_scale,
                   reinterpret_cast<const float2 *>(d.node_scale), d.node_s, d.node_row, d.nodefac, d.rowfac8);
     const bool lanes8 = smp_half_window(C) && smp_tables_fold_vectors(s);   // eight lanes per position (C = 32): classes of 8 NI positions
-    const std::vector<SizeClass> cls = classes_of(h, lanes8 ? 8 : 4);
+    const bool lanes4 = smp_quarter_window(C) && smp_tables_fold_vectors(s);   // four (C = 16): classes of 16 NI positions
+    const std::vector<SizeClass> cls = classes_of(h, lanes4 ? 16 : lanes8 ? 8 : 4);
     for (const SizeClass &c : cls) {
-        if (lanes8) {
+        if (lanes4) {
             switch (c.ni) {
-                case 1: st = launch_tables_fwd_w8<1>(s, l, c); break;
-                case 2: st = launch_tables_fwd_w8<2>(s, l, c); break;
-                default: st = launch_tables_fwd_w8<4>(s, l, c); break;
+                case 1: st = launch_tables_fwd_wn<1, 4>(s, l, c); break;
+                default: st = launch_tables_fwd_wn<2, 4>(s, l, c); break;
+            }
+        } else if (lanes8) {
+            switch (c.ni) {
+                case 1: st = launch_tables_fwd_wn<1, 8>(s, l, c); break;
+                case 2: st = launch_tables_fwd_wn<2, 8>(s, l, c); break;
+                default: st = launch_tables_fwd_wn<4, 8>(s, l, c); break;
             }
         } else {
             switch (c.ni) {
@@ -1487,7 +1511,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             {d.Fdc, d.Wst + 8 * CC, d.Gc, prevPairs, C, C, 2 * C, C, 2 * C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
             {d.Fdc + C, d.Wst + 9 * CC, d.Gc + C, prevPairs, C, C, 2 * C, C, 2 * C, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}},
         };
-        if ((C == 64 || C == 32) && d.wimg_ready) {   // wave per 32-row panel on the f16 pipe (smp_small_split)
+        if (smp_panel_channels(C) && d.wimg_ready) {   // wave per 32-row panel on the f16 pipe (smp_small_split)
             const int prog[3] = {0, 2, 0}, nrows[3] = {pairs, prevPairs, nodes}, pos0[3] = {10, 8, 14};
             const float *in[3] = {d.Vt, d.Fdc, d.St};
             float *out[3] = {d.Vout, d.Gc, d.Sout};
@@ -1531,7 +1555,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             }
         }
     }
-    if ((C == 64 || C == 32) && ocols == 2 && d.fwd_pan && (long long)rows * 512 < 0x3fffffffll)
+    if (smp_panel_channels(C) && ocols == 2 && d.fwd_pan && (long long)rows * 512 < 0x3fffffffll)
     {   // wave per row panel, the adjacency product on the matrix pipe; the top level leaves the readout's partial sums behind, the
         // others the per-channel maxima the level above scales its weight-gradient operands with
         float *psum = (l == s->cfg.nLevels || s->cfg.physics) ? d.psum : nullptr;   // (a tower reads every level out)
@@ -1591,7 +1615,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
                                 spec(d.dGc + C, d.Wst + 9 * CC, d.dFdc + C, prevPairs, C, C, 2 * C, C, 2 * C),
                                 spec(d.dVout, d.Wst + 10 * CC, d.dVt, pairs, 4 * C, C, C, C, 4 * C),
                                 spec(d.dSout, d.Wst + 14 * CC, d.dSt, nodes, 4 * C, C, C, C, 4 * C)};
-        if ((C == 64 || C == 32) && d.wimg_ready) {
+        if (smp_panel_channels(C) && d.wimg_ready) {
             const int prog[3] = {1, 2, 1}, nrows[3] = {pairs, prevPairs, nodes}, pos0[3] = {10, 8, 14};
             const float *in[3] = {d.dVout, d.dGc, d.dSout};
             float *out[3] = {d.dVt, d.dFdc, d.dSt};
@@ -1613,11 +1637,11 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     size_t ws_floats = ctx->ws_bytes / sizeof(float), used = 0;
     FoldGroup rowg;
     const bool stationary = d.fwd_c64;
-    if (stationary && C == 32) {   // smp_wgrad_direct<32>: one partial image of the eight products per workgroup
+    if (stationary && (C == 32 || C == 16)) {   // smp_wgrad_direct<32 | 16>: one partial image of the eight products per workgroup
         const long long slices = ((long long)rows + 15) / 16;
         int splits = (int)(slices / 8 < 1 ? 1 : slices / 8 > 512 ? 512 : slices / 8);   // (116 registers: two workgroups per CU)
         if ((size_t)splits * 8 * CC > ws_floats) return fail(ctx, GF_ERR_NOMEM, "fused level: workspace too small for %d weight-gradient images", splits);
-        unsigned *words = s->wbound + (size_t)l * smp_wgrad_direct_words_c32();
+        unsigned *words = s->wbound + (size_t)l * smp_wgrad_direct_words_c32();   // (the same scratch layout at 16 channels)
         const unsigned *chan = nullptr;
         if (d.dzmax && d.row_max) {   // per-channel maxima of f_{l-1} and of this level's dz (combine-backward's per-workgroup maxima)
             GF_HIP_TRY(ctx, hipMemsetAsync(words, 0, sizeof(unsigned) * 64, ctx->stream));
@@ -1626,7 +1650,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
             //  f_{l-1} itself was read for them: 94 MB at cfg3's level 3 -- or from f_0)
             const bool pm = pv.pmax && pv.pmax_ready;
             st = smp_wgrad_channel_maxima_ld(ctx, pm ? pv.pmax : pv.f, pm ? (long long)pv.fwd_npanels : (long long)s->lay.level[l - 1].rows, C, d.dzmax,
-                                             d.dz_rows, smp_half_window(C) ? 32 : 64, C, words);
+                                             d.dz_rows, d.dz_ld, C, words);
             if (st != GF_OK) return st;
             chan = words;
         }
@@ -1635,7 +1659,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
             if (st != GF_OK) return st;
         }
         st = smp_wgrad_partials_direct_c32(ctx, T, dO, drop ? d.rowfac8 : d.rowscale, rows, splits, ws, d.trow, d.trowf, words, chan,
-                                           (float)h.buckets.back().s, d.row_max, drop ? 8 : 2);
+                                           (float)h.buckets.back().s, d.row_max, drop ? 8 : 2, C);
         if (st != GF_OK) return st;
         rowg.part = ws;
         rowg.splits = splits;
@@ -1793,14 +1817,16 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
     float *dzmax = (s->wbound && d.dzmax && d.fwd_c64) ? d.dzmax : (float *)nullptr;
     // round 5: on the forward's row panels where they exist (one wave per panel, every request up front; GF_SMP_COMBINE_BWD_PANELS=0: the
     // workgroup-per-(node, four x) kernel below, which also serves every other channel count)
-    if (d.fwd_c64 && d.fwd_pan && (C == 64 || C == 32) && (long long)h.rows * 512 < 0x3fffffffll && !env_is("GF_SMP_COMBINE_BWD_PANELS", '0')) {
+    if (d.fwd_c64 && d.fwd_pan && smp_panel_channels(C) && (long long)h.rows * 512 < 0x3fffffffll && !env_is("GF_SMP_COMBINE_BWD_PANELS", '0')) {
         st = smp_combine_bwd_panels_c64(s, l, dfrows, node_df, dO, dzmax);
         if (st != GF_OK) return st;
         s->lv[l].dz_rows = d.fwd_npanels;
+        s->lv[l].dz_ld = C;
         (void)Kl;
         return smp_fused_backward_level_grouped(s, l, dKl, dbl);
     }
     s->lv[l].dz_rows = (long long)h.quad_node.size();
+    s->lv[l].dz_ld = smp_half_window(C) ? 32 : 64;   // (the workgroup kernels write one row of their window's width)
     if (smp_half_window(C)) {   // eight lanes per row (32-channel windows): at C = 32 every lane has channels
         const int nw8 = C / 32, N = h.buckets.back().s;
         // (the column maxima go through kThreads / 8 x 32 floats of the dz image: room for them whatever the field size)

@@ -54,7 +54,7 @@ gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *con
 // weight gradients of a fused level at C = 32 (smp_wgrad_direct<32>): partial images of 8 x 32 x 32 floats per workgroup
 gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int splits, float *part,
                                         const int *trow, const int *trowf, unsigned *words, const unsigned *chan = nullptr, float smax = 0.f,
-                                        const unsigned *row_max = nullptr, int nf = 2);
+                                        const unsigned *row_max = nullptr, int nf = 2, int C = 32);   // C = 32 or (round 5) 16
 gf_status smp_wgrad_channel_maxima_ld(gf_ctx *ctx, const float *fprev, long long prev_rows, int ld0, const float *dsrc, long long drows, int ld1, int C,
                                       unsigned *words);
 size_t smp_wgrad_direct_words_c32();
@@ -84,7 +84,8 @@ gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, c
 
 
 namespace gf {
-gf_status smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channels, gf_smp **out);   // gf_smp_create = (.., true, ..)
+// min_pad: the smallest padded width the handle may compute at (32 for the towers of a slice-dropout model)
+gf_status smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channels, gf_smp **out, int min_pad = 0);   // gf_smp_create = (.., true, ..)
 constexpr int kPadMaxLevels = 15;   // levels a padded model's layout map holds (gf_smp_create: deeper models compute at nChanels)
 }
 struct gf_smp {
@@ -148,6 +149,7 @@ struct gf_smp {
         float *pmax = nullptr;     // [fwd_npanels][64] largest |f_l| of every row panel, left by combine-forward (levels below the top)
         float *dzmax = nullptr;    // [max(quads, row panels)][64] largest |dz| of every workgroup / panel of combine-backward
         long long dz_rows = 0;     // ... rows of it the last combine-backward wrote
+        int dz_ld = 64;            // ... and their width in floats
         bool pmax_ready = false;
         void *wimg = nullptr;  // the split product kernels' weight images of this pass (smp_split_build_images), C = 64
         bool wimg_ready = false;
@@ -219,6 +221,8 @@ struct gf_smp {
 };
 
 namespace gf {
+// channel counts the row-panel kernel family of the fused level is built for (models are padded to the next one: gf_smp_create)
+inline bool smp_panel_channels(int C) { return C == 64 || C == 32 || C == 16; }
 bool smp_fused_supported(const gf_smp *s, int l);
 gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float *bl);
 gf_status smp_fused_ensure_zero_fill(gf_smp *s, int l);

@@ -92,12 +92,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     const __amdgpu_buffer_rsrc_t rF = ff_rsrc(F, (size_t)rows * CB * sizeof(float));
     const int gs = (int)((li + 0.5f) * __builtin_amdgcn_rcpf((float)s));
     const int y_li = li - gs * s;
+    // byte offset of the lane's column inside a row block; CB = 16 (round 5): the lanes of columns 16..31 address nothing
+    const int colb = (CB >= 32 || li < CB) ? li * 4 : kFfOor;
     // operands that do not depend on the gather indices first
     f16v m0, m1, u0, u1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int vo = rr < nrows ? (P.x + rr) * OB + li * 4 : kFfOor;
+        const int vo = rr < nrows ? (P.x + rr) * OB + colb : kFfOor;
         m0[r] = ff_ld1(rO, vo);
         u0[r] = ff_ld1(rO, vo + FB);
         if constexpr (TWO) {
@@ -117,12 +119,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     }
     {
         const float *p0 = lh ? bias : Sout + (size_t)node * CB;
-        vb0[0] = p0[li];
+        vb0[0] = (CB >= 32 || li < CB) ? p0[CB >= 32 ? li : (li & (CB - 1))] : 0.f;
         vb1[0] = TWO ? p0[(TWO ? 32 : 0) + li] : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int g = 2 * t + lh;
-            const int vo = g < G ? (int)(((long long)P.w + x0 + g) * FB) + li * 4 : kFfOor;
+            const int vo = g < G ? (int)(((long long)P.w + x0 + g) * FB) + colb : kFfOor;
             vb0[t + 1] = ff_ld1(rV, vo);
             vb1[t + 1] = TWO ? ff_ld1(rV, vo + 128) : 0.f;
         }
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         const int a15 = __builtin_amdgcn_readlane(go.x, rr), b15 = __builtin_amdgcn_readlane(go.x, rr + 4);
         const int a16 = __builtin_amdgcn_readlane(go.y, rr), b16 = __builtin_amdgcn_readlane(go.y, rr + 4);
         const int i15 = lh ? b15 : a15, i16 = lh ? b16 : a16;
-        const int v15 = i15 < 0 ? kFfOor : i15 * OB + li * 4, v16 = i16 < 0 ? kFfOor : i16 * OB + FB + li * 4;
+        const int v15 = i15 < 0 ? kFfOor : i15 * OB + colb, v16 = i16 < 0 ? kFfOor : i16 * OB + FB + colb;
         g0[r] = ff_ld1(rGc, v15);
         g1[r] = ff_ld1(rGc, v16);
         g2[r] = TWO ? ff_ld1(rGc, v15 + 128) : 0.f;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int vo = rr < nrows ? (P.x + rr) * FB + li * 4 : kFfOor;
+        const int vo = rr < nrows ? (P.x + rr) * FB + colb : kFfOor;
         const float z0 = m0[r], z1 = m1[r];
         const float f0 = z0 > 0.f ? z0 : kAlphaFf * z0, f1 = z1 > 0.f ? z1 : kAlphaFf * z1;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f0), rF, vo, 0, 0);
@@ -188,12 +190,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     if (psum) {  // (uniform)
         c0 += __shfl_xor(c0, 32);
         c1 += __shfl_xor(c1, 32);
-        if (TWO || lh == 0) psum[(size_t)p * CB + lane] = lh ? c1 : c0;   // lane = 32 lh + li: columns li | 32 + li
+        if (TWO || lane < CB) psum[(size_t)p * CB + lane] = lh ? c1 : c0;   // lane = 32 lh + li: columns li | 32 + li
     }
     if (pmax) {  // (uniform)
         x0m = fmaxf(x0m, __shfl_xor(x0m, 32));
         x1m = fmaxf(x1m, __shfl_xor(x1m, 32));
-        if (TWO || lh == 0) pmax[(size_t)p * CB + lane] = lh ? x1m : x0m;
+        if (TWO || lane < CB) pmax[(size_t)p * CB + lane] = lh ? x1m : x0m;
     }
 }
 
@@ -239,12 +241,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     const __amdgpu_buffer_rsrc_t rO = ff_rsrc(dO, (size_t)rows * 2 * CB * sizeof(float));
     const int gs = (int)((li + 0.5f) * __builtin_amdgcn_rcpf((float)s));
     const int y_li = li - gs * s;
+    const bool colok = CB >= 32 || li < CB;   // (CB = 16: the lanes of columns 16..31 address nothing)
+    const int colb = colok ? li * 4 : kFfOor;
     // every operand of the panel, requested up front
     f16v f0, f1, g0, g1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int vo = rr < nrows ? (P.x + rr) * FB + li * 4 : kFfOor;
+        const int vo = rr < nrows ? (P.x + rr) * FB + colb : kFfOor;
         f0[r] = ff_ld1(rF, vo);
         g0[r] = ff_ld1(rG, vo);
         if constexpr (TWO) {
@@ -262,7 +266,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         const bool in = rowok && e >= 0 && e < s && er < nrows;
         avT[r] = ff_ld1(rAdj, in ? (P.z + e * s + y_li) * 4 : kFfOor);
     }
-    const float gn0 = node_dF ? node_dF[(size_t)node * CB + li] : 0.f, gn1 = (TWO && node_dF) ? node_dF[(size_t)node * CB + 32 + li] : 0.f;
+    const float gn0 = (node_dF && colok) ? node_dF[(size_t)node * CB + (CB >= 32 ? li : (li & (CB - 1)))] : 0.f;
+    const float gn1 = (TWO && node_dF) ? node_dF[(size_t)node * CB + 32 + li] : 0.f;
     const float axy_raw = rowok ? adj[row] : 0.f;
     const float axy = axy_raw > 0.f ? axy_raw : 0.f;                  // A+[x, y] of the lane's own row
     const float r_y = rowok ? rsum[(size_t)P.w + y_li] : 0.f;           // r[y] of the lane's own row
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         z1[r] = ok ? b : 0.f;
         x0m = fmaxf(x0m, fabsf(z0[r]));
         x1m = fmaxf(x1m, fabsf(z1[r]));
-        const int vo = ok ? (P.x + rr) * OB + li * 4 : kFfOor;
+        const int vo = ok ? (P.x + rr) * OB + colb : kFfOor;
         ff_st1(rO, vo, z0[r]);
         if constexpr (TWO) ff_st1(rO, vo + 128, z1[r]);
     }
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int vo = rr < nrows ? (P.x + rr) * OB + FB + li * 4 : kFfOor;
+        const int vo = rr < nrows ? (P.x + rr) * OB + FB + colb : kFfOor;
         ff_st1(rO, vo, u0[r]);
         if constexpr (TWO) ff_st1(rO, vo + 128, u1[r]);
     }
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
 #pragma unroll
         for (int r = 0; r < 12; ++r) {   // tile rows (r & 3) + 8 (r >> 2) + 4 lh: type r >> 2, group (r & 3) + 4 lh
             const int g = (r & 3) + 4 * lh;
-            const int vo = g < G ? (int)(((long long)P.w + x0 + g) * FB) + li * 4 : kFfOor;
+            const int vo = g < G ? (int)(((long long)P.w + x0 + g) * FB) + colb : kFfOor;
             const __amdgpu_buffer_rsrc_t rd = (r >> 2) == 0 ? rV : (r >> 2) == 1 ? rS : rB;
             ff_st1(rd, vo, q0[r]);
             if constexpr (TWO) ff_st1(rd, vo + 128, q1[r]);
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     if (dzmax) {  // (uniform)
         x0m = fmaxf(x0m, __shfl_xor(x0m, 32));
         x1m = fmaxf(x1m, __shfl_xor(x1m, 32));
-        if (TWO || lh == 0) dzmax[(size_t)p * CB + lane] = lh ? x1m : x0m;
+        if (TWO || lane < CB) dzmax[(size_t)p * CB + lane] = lh ? x1m : x0m;
     }
 }
 
@@ -395,6 +400,7 @@ gf_status smp_combine_fwd_panels_c64(gf_smp *s, int l, const float *O, const flo
               d.fwd_pan_node, npanels, (int)h.rows, d.fwd_goff, d.Gc, (long long)s->lay.level[l - 1].pairs, d.adj, d.rsum, d.Vout,          \
               (long long)h.pairs, d.Sout, bias, psum, pmax, nodefac)
     if (s->cfg.nChanels == 64) GF_CFP_LAUNCH(64);
+    else if (s->cfg.nChanels == 16) GF_CFP_LAUNCH(16);
     else GF_CFP_LAUNCH(32);
 #undef GF_CFP_LAUNCH
     return GF_OK;
@@ -411,6 +417,7 @@ gf_status smp_combine_bwd_panels_c64(gf_smp *s, int l, const float *dfrows, cons
     GF_LAUNCH(ctx, "smpf_combine_bwd", (smp_combine_bwd_panels<CBv>), dim3((unsigned)((npanels + 3) / 4)), dim3(256), 0, d.f, dfrows, node_df, dO, \
               d.fwd_pan, d.fwd_pan_node, npanels, (int)h.rows, d.adj, d.rsum, (long long)h.pairs, d.dVout, d.dSpart, d.dbpart, dzmax)
     if (s->cfg.nChanels == 64) GF_CBP_LAUNCH(64);
+    else if (s->cfg.nChanels == 16) GF_CBP_LAUNCH(16);
     else GF_CBP_LAUNCH(32);
 #undef GF_CBP_LAUNCH
     return GF_OK;

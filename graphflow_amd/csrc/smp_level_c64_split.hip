@@ -88,7 +88,7 @@ __device__ __attribute__((aligned(256))) float sp_dump[kSpDumpRows * 64];
 template <bool FWD, int NPOS, int CB = 64>
 __device__ __forceinline__ void build_weight_images(const float *__restrict__ Wst, uint4 *imgH, uint4 *imgL, float *winv, unsigned *wmax,
                                                     int tid) {
-    constexpr int NC = CB / 16, NH = CB / 32, E = NH * NC * 64;
+    constexpr int NC = CB / 16, NH = CB >= 32 ? CB / 32 : 1, E = NH * NC * 64;   // (CB = 16: one column half, columns 16..31 are zeros)
     if (tid < NPOS) wmax[tid] = 0u;
     __syncthreads();
 #pragma unroll 1
@@ -112,7 +112,7 @@ __device__ __forceinline__ void build_weight_images(const float *__restrict__ Ws
         const float *w = Wst + pos * CB * CB;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = FWD ? w[(k0 + j) * CB + n] : w[n * CB + k0 + j];
+        for (int j = 0; j < 8; ++j) v[j] = n >= CB ? 0.f : FWD ? w[(k0 + j) * CB + n] : w[n * CB + k0 + j];
         unsigned hw[4], lw[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -147,6 +147,11 @@ __global__ __launch_bounds__(kSpThreads) void smp_split_weight_images(SplitImage
             build_weight_images<true, 1, 64>(w, H, L, winv, wmax, threadIdx.x);
         else
             build_weight_images<false, 1, 64>(w, H, L, winv, wmax, threadIdx.x);
+    } else if (C == 16) {
+        if (blockIdx.x == 0)
+            build_weight_images<true, 1, 16>(w, H, L, winv, wmax, threadIdx.x);
+        else
+            build_weight_images<false, 1, 16>(w, H, L, winv, wmax, threadIdx.x);
     } else {
         if (blockIdx.x == 0)
             build_weight_images<true, 1, 32>(w, H, L, winv, wmax, threadIdx.x);
@@ -165,7 +170,9 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
                                                                      const uint4 *__restrict__ wimg) {  // or null: this direction's
                                                                      // images, built by smp_split_weight_images
     constexpr int LDA = FWD ? 4 * CB : 2 * CB, LDOUT = FWD ? 2 * CB : 4 * CB;
-    constexpr int VPL = CB / 2, NC = CB / 16, NH = CB / 32, E = NH * NC * 64;   // values per lane and block, k-chunks, column halves, fragment entries per block
+    // values per lane and block, k-chunks, column halves, fragment entries per block.  CB = 16 (round 5: models of up to 16 channels, the
+    // reference's own nChanels = 10): one k-chunk, one column half whose columns 16..31 are zero weights and are never stored
+    constexpr int VPL = CB / 2, NC = CB / 16, NH = CB >= 32 ? CB / 32 : 1, E = NH * NC * 64;
     auto t_row = [](int t) { return MASK ? (t & 0x1fffffff) : t; };
     auto t_own = [](int t) { return MASK ? t < 0 : true; };
     auto t_tr = [](int t) { return MASK ? ((t >> 30) & 1) != 0 : true; };
@@ -327,6 +334,8 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
     auto store_out = [&](int p, int o, const f16v &acc0, const f16v &acc1, auto full, unsigned rowbits = 0xffffffffu) {
         const int r0 = p * 32;
         float *out = Out + (size_t)(r0 + 4 * lh) * LDOUT + o * CB + li;
+        if constexpr (CB < 32)   // lanes of the zero columns store into the scratch rows (a select on the address: every store is issued)
+            out = li < CB ? out : sp_dump + (size_t)((r0 & 255) + 4 * lh) * 64 + li;
         if constexpr (MASK && !FWD && decltype(full)::value) {
             if (rowbits != 0xffffffffu) {  // (uniform; the blocks without structural zeros pass all ones)
                 // rows without data go to the scratch rows: a select on the address, every store is issued
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
-                if (r0 + 4 * lh + rr < rows) {
+                if (r0 + 4 * lh + rr < rows && li < CB) {
                     out[(size_t)rr * LDOUT] = acc0[r];
                     if constexpr (NH == 2) out[(size_t)rr * LDOUT + 32] = acc1[r];
                 }
@@ -466,7 +475,7 @@ __device__ __forceinline__ void small_split_body(const float *__restrict__ In, f
                                                  const uint4 *__restrict__ wimg, int pos0, int wg, int nwg) {
     constexpr int NPOS = PROG == 2 ? 2 : 4;
     constexpr int LDA = PROG == 0 ? 4 * CB : PROG == 1 ? CB : 2 * CB, LDOUT = PROG == 0 ? CB : PROG == 1 ? 4 * CB : 2 * CB;
-    constexpr int VPL = CB / 2, NC = CB / 16, NH = CB / 32, E = NH * NC * 64;   // (see smp_rowpanel_split)
+    constexpr int VPL = CB / 2, NC = CB / 16, NH = CB >= 32 ? CB / 32 : 1, E = NH * NC * 64;   // (see smp_rowpanel_split)
     constexpr int NIN = PROG == 1 ? 1 : NPOS;
     extern __shared__ __attribute__((aligned(16))) uint4 sm_smem[];
     uint4 *imgH = sm_smem, *imgL = sm_smem + NPOS * E;
@@ -570,7 +579,7 @@ __device__ __forceinline__ void small_split_body(const float *__restrict__ In, f
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
-                if (r0 + 4 * lh + rr < rows) {
+                if (r0 + 4 * lh + rr < rows && li < CB) {
                     out[(size_t)rr * LDOUT] = acc0[r];
                     if constexpr (NH == 2) out[(size_t)rr * LDOUT + 32] = acc1[r];
                 }
@@ -907,11 +916,18 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
                                                                    int packed,
                                                                    int nf) {  // 2: rs = [rows][2] (tot, tr); 8: rs = [rows][8], product w's own factor
                                                                    // per row (slice dropout: see smp_rowpanel_split) -- every wave scales its B operand
-    constexpr int NT = CB / 32, ACOLS = 4 * CB, BCOLS = 5 * CB;
+    // CB = 16 (round 5): a 32 x 32 tile has room for TWO 16-column operands, so a slice is 32 rows there and the lanes of columns 16..31 carry
+    // the operands of its second sixteen rows: the tile's diagonal quadrants are the two half-slices' products (the off-diagonal ones mix
+    // the halves and are ignored) and are added at the end -- half the instructions per row of a half-empty tile.
+    constexpr int NT = CB >= 32 ? CB / 32 : 1, ACOLS = 4 * CB, BCOLS = 5 * CB;
+    constexpr int SL = CB == 16 ? 2 * kWsSlice : kWsSlice;   // rows of a slice
     constexpr int TROW = 16 * CB, DROW = 8 * CB;   // bytes of a row of T, of dO
     __shared__ float sScale[ACOLS + BCOLS], sInv[ACOLS + BCOLS];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = (CB == 16 && li >= 16) ? 1 : 0;   // the lane works on the slice's second sixteen rows
+    const int lc = CB == 16 ? (li & 15) : li;         // ... on operand column lc
+    const int rb = 8 * lg + 16 * hi;                  // first of the lane's eight rows inside the slice
     if (cmax) {
         for (int c = tid; c < ACOLS + BCOLS; c += kWdThreads) pow2_scale_col(cmax[c], &sScale[c], &sInv[c]);
     } else {   // (the bounds of smp_wgrad_split, from the level's per-channel maxima)
@@ -935,14 +951,14 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
     float sa[NT], sb[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        sa[t] = sScale[CB * ablk + 32 * t + li];
-        sb[t] = sScale[ACOLS + CB * bblk + 32 * t + li];
+        sa[t] = sScale[CB * ablk + 32 * t + lc];
+        sb[t] = sScale[ACOLS + CB * bblk + 32 * t + lc];
     }
     constexpr int kOut = 0x40000000;   // an offset no descriptor of this kernel reaches
-    const int offA = (8 * lg) * TROW + (CB * ablk + li) * 4;
-    const int offB = (8 * lg) * DROW + ((bblk >= 3 ? CB : 0) + li) * 4;
-    const int offG = (CB + li) * 4;   // (gathered: the row comes from the table)
-    const long long nsl = ((long long)rows + kWsSlice - 1) / kWsSlice;
+    const int offA = rb * TROW + (CB * ablk + lc) * 4;
+    const int offB = rb * DROW + ((bblk >= 3 ? CB : 0) + lc) * 4;
+    const int offG = (CB + lc) * 4;   // (gathered: the row comes from the table)
+    const long long nsl = ((long long)rows + SL - 1) / SL;
     auto slice_of = [&](int n) { return (long long)blockIdx.x + (long long)n * gridDim.x; };
 
     struct Idx {      // a slice's table entries for the lane's eight rows
@@ -959,34 +975,34 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
     const __amdgpu_buffer_rsrc_t rTr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(trow), 0, (unsigned)rows * 4u, 0x00020000);
     const int rsb = 4 * nf;   // bytes of a row of rs
     const __amdgpu_buffer_rsrc_t rRs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rs), 0, (unsigned)rows * (unsigned)rsb, 0x00020000);
-    const int offF = scaled ? 8 * rsb * lg + 4 * fsel : kOut;   // (the other waves' requests return at once)
+    const int offF = scaled ? rsb * rb + 4 * fsel : kOut;   // (the other waves' requests return at once)
     auto ld1 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
     };
     auto load_idx = [&](Idx &I, int n) {
-        const long long k0 = slice_of(n) * kWsSlice;
+        const long long k0 = slice_of(n) * SL;
         const int ks = k0 < rows ? (int)k0 : rows;   // (past the end: every entry out of range)
         typedef int i4v __attribute__((ext_vector_type(4)));
-        const i4v t0 = __builtin_bit_cast(i4v, __builtin_amdgcn_raw_buffer_load_b128(rTr, 32 * lg, ks * 4, 0));
-        const i4v t1 = __builtin_bit_cast(i4v, __builtin_amdgcn_raw_buffer_load_b128(rTr, 32 * lg + 16, ks * 4, 0));
+        const i4v t0 = __builtin_bit_cast(i4v, __builtin_amdgcn_raw_buffer_load_b128(rTr, 4 * rb, ks * 4, 0));
+        const i4v t1 = __builtin_bit_cast(i4v, __builtin_amdgcn_raw_buffer_load_b128(rTr, 4 * rb + 16, ks * 4, 0));
         I.t[0] = t0[0], I.t[1] = t0[1], I.t[2] = t0[2], I.t[3] = t0[3], I.t[4] = t1[0], I.t[5] = t1[1], I.t[6] = t1[2], I.t[7] = t1[3];
     };
     auto load_fac = [&](Fac &F, int n) {
-        const long long k0 = slice_of(n) * kWsSlice;
+        const long long k0 = slice_of(n) * SL;
         const int ks = k0 < rows ? (int)k0 : rows;
 #pragma unroll
         for (int j = 0; j < 8; ++j) F.f[j] = ld1(rRs, offF, (ks + j) * rsb);   // (the row in the scalar offset: one lane constant)
     };
     auto load_raw = [&](Raw &R, const Idx &I, int n) {
-        const long long k0 = slice_of(n) * kWsSlice;
+        const long long k0 = slice_of(n) * SL;
         const bool live = k0 < rows;
-        // descriptors of this slice: T rows [k0, k0 + 16); dO rows [g0, min(rows, k0 + 16 + 1024)) with g0 = max(0, k0 - 1024)
+        // descriptors of this slice: T rows [k0, k0 + SL); dO rows [g0, min(rows, k0 + SL + 1024)) with g0 = max(0, k0 - 1024)
         long long left = (long long)rows - k0;
-        left = left < 0 ? 0 : left > kWsSlice ? kWsSlice : left;
+        left = left < 0 ? 0 : left > SL ? SL : left;
         const long long k0c = live ? k0 : 0;
         const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(T + (size_t)k0c * ACOLS), 0, (unsigned)(left * TROW), 0x00020000);
         const long long g0 = k0c > 1024 ? k0c - 1024 : 0;
-        long long g1 = k0c + kWsSlice + 1024;
+        long long g1 = k0c + SL + 1024;
         g1 = g1 > rows ? rows : g1;
         const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dO + (size_t)g0 * 2 * CB), 0, live ? (unsigned)((g1 - g0) * DROW) : 0u, 0x00020000);
         const int own = (int)(k0c - g0) * DROW;   // the slice's first row inside the dO window
@@ -1077,19 +1093,31 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
         }
     }
     // back to fp32 units: row k of the product is column k of its A block, column n column n of its B block
-    float *out = part + ((size_t)blockIdx.x * 8 + wave) * (CB * CB) + li;
+    float *out = part + ((size_t)blockIdx.x * 8 + wave) * (CB * CB) + lc;
     const float *ia = sInv + ablk * CB, *ib = sInv + ACOLS + bblk * CB;
+    if constexpr (CB == 16) {
+        // the two half-slices' products: tile rows / columns [0, 16) and [16, 32) -- register r + 8 of lane ^ 16 joins register r
+        const float ub = ib[lc];
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float ub = ib[32 * nt + li];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lg;
-                out[row * CB + 32 * nt] = acc[mt][nt][r] * (ia[row] * ub);
-            }
+        for (int r = 0; r < 8; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lg;   // 0 .. 15
+            const float second = acc[0][0][r + 8];
+            const float v = acc[0][0][r] + __shfl_xor(second, 16);
+            if (li < 16) out[row * CB] = v * (ia[row] * ub);
         }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float ub = ib[32 * nt + li];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                    out[row * CB + 32 * nt] = acc[mt][nt][r] * (ia[row] * ub);
+                }
+            }
+    }
 }
 
 // exact column bounds of the nine operand blocks of smp_wgrad_direct<CB> from the column maxima of T [rows][4 CB] (mt) and of
@@ -1234,8 +1262,12 @@ gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *pr
         total += jb.nwg[k];
     }
     if (total == 0) return GF_OK;
-    const size_t lds = 2 * (size_t)4 * (C / 32) * (C / 16) * 64 * 16 + 16 * sizeof(float) + (kSmThreads / 64) * 32 * sizeof(float);
-    if (C == 64) {
+    const size_t lds = 2 * (size_t)4 * (C >= 32 ? C / 32 : 1) * (C / 16) * 64 * 16 + 16 * sizeof(float) + (kSmThreads / 64) * 32 * sizeof(float);
+    if (C == 16) {
+        gf_status st = opt_in_lds(ctx, smp_small_split<16>, lds);
+        if (st != GF_OK) return st;
+        GF_LAUNCH(ctx, name, smp_small_split<16>, dim3((unsigned)total), dim3(kSmThreads), lds, jb, img);
+    } else if (C == 64) {
         gf_status st = opt_in_lds(ctx, smp_small_split<64>, lds);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, name, smp_small_split<64>, dim3((unsigned)total), dim3(kSmThreads), lds, jb, img);
@@ -1279,7 +1311,7 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
     const bool mask = trowf && rows < (1 << 29) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
 #define GF_SP_LAUNCH_NF(F, M, CBv, NFv, name)                                                                                      \
     do {                                                                                                                           \
-        const size_t lds__ = 2 * (size_t)8 * (CBv / 32) * (CBv / 16) * 64 * 16 + 16 * sizeof(float) + (kSpThreads / 64) * 32 * sizeof(float); \
+        const size_t lds__ = 2 * (size_t)8 * (CBv >= 32 ? CBv / 32 : 1) * (CBv / 16) * 64 * 16 + 16 * sizeof(float) + (kSpThreads / 64) * 32 * sizeof(float); \
         gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M, CBv, NFv>, lds__);                                                 \
         if (st != GF_OK) return st;                                                                                                \
         GF_LAUNCH(ctx, name, (smp_rowpanel_split<F, M, CBv, NFv>), dim3((unsigned)grid), dim3(kSpThreads), lds__, A, rowscale, Wst, Out, rows, \
@@ -1312,6 +1344,14 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
             if (mask) GF_SP_LAUNCH(false, true, 32, "smpf_products_bwd");
             else GF_SP_LAUNCH(false, false, 32, "smpf_products_bwd");
         }
+    } else if (C == 16) {
+        if (forward) {
+            if (mask) GF_SP_LAUNCH(true, true, 16, "smpf_products_fwd");
+            else GF_SP_LAUNCH(true, false, 16, "smpf_products_fwd");
+        } else {
+            if (mask) GF_SP_LAUNCH(false, true, 16, "smpf_products_bwd");
+            else GF_SP_LAUNCH(false, false, 16, "smpf_products_bwd");
+        }
     } else {
         return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d channels", C);
     }
@@ -1339,9 +1379,30 @@ gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float 
 // column bounds taken from the operands themselves (one extra pass over T and dO; `words`: 512 + 9 * 32 scratch words).
 gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int splits, float *part,
                                         const int *trow, const int *trowf, unsigned *words, const unsigned *chan, float smax,
-                                        const unsigned *row_max, int nf) {
-    constexpr int CB = 32;
+                                        const unsigned *row_max, int nf, int C) {
     const bool mask = trowf && rows < (1 << 28) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
+    if (C == 16) {   // (round 5)
+        if (chan && row_max) {
+            GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<16>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
+                      mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf);
+            return GF_OK;
+        }
+        // host-built level tables: exact column bounds from the operands themselves -- T [rows][64] and dO [rows][32] are one
+        // "channel maxima" pass each (words [0, 64) and [256, 288)), then the nine blocks' bounds (words [512, 512 + 144))
+        if (nf != 2) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_wgrad_direct: exact column bounds with per-product row factors");
+        GF_HIP_TRY(ctx, hipMemsetAsync(words, 0, sizeof(unsigned) * 512, ctx->stream));
+        const long long g0 = ((long long)rows + 63) / 64;
+        const unsigned g = (unsigned)(g0 < 1 ? 1 : g0 > 256 ? 256 : g0);
+        GF_LAUNCH(ctx, "smpf_colmax", level_channel_maxima_ld, dim3(g, 1), dim3(256), 0, T, (long long)rows, 64, (const float *)nullptr, 0ll, 0, 64, words);
+        GF_LAUNCH(ctx, "smpf_colmax", level_channel_maxima_ld, dim3(g, 1), dim3(256), 0, dO, (long long)rows, 32, (const float *)nullptr, 0ll, 0, 32, words + 256);
+        GF_LAUNCH(ctx, "smpf_colmax", rowscale_absmax, dim3(64), dim3(256), 0, rowscale, rows, words + 384);
+        GF_LAUNCH(ctx, "smpf_colmax", wgrad_bounds_exact_cb, dim3(1), dim3(64), 0, words, words + 256, words + 384, words + 512, 16);
+        GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<16>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
+                  mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0, nf);
+        return GF_OK;
+    }
+    if (C != 32) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_wgrad_direct: %d channels", C);
+    constexpr int CB = 32;
     if (chan && row_max) {
         GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<CB>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
                   mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf);
