@@ -1957,7 +1957,7 @@ gf_status gf_smp_dropout_masks(gf_smp *s, const unsigned *masks, float scale) {
     }
     GF_HIP_TRY(ctx, hipEventRecord(s->ev_mask, ctx->stream));
     // the factor tables of the fused levels (smp_fused.hip: build_dropout_factors fills them at every forward): towers computed at 32 channels
-    if (s->cfg.square() && s->cfg.nChanels == 32)
+    if (s->cfg.square() && (s->cfg.nChanels == 32 || s->cfg.nChanels == 16))
         for (int l = 1; l <= s->cfg.nLevels; ++l) {
             gf_smp::DevLevel &d = s->lv[l];
             if (d.nodefac && d.rowfac8) continue;

@@ -1421,9 +1421,9 @@ bool smp_fused_supported(const gf_smp *s, int l) {
     const gfsmp::LevelLayout &h = s->lay.level[l];
     if (h.buckets.empty()) return false;
     if (s->drop_on) {   // RisiContraction_18_dropout: fused where the per-product row factors exist (round 5: the split row-panel kernels at
-        // 32 channels -- the towers' padded width -- with the panel combine-forward and the level's device-built statistics), else op by op
+        // 32 / 16 channels -- the towers' padded widths -- with the panel combine-forward and the level's device-built statistics), else op by op
         const gf_smp::DevLevel &d = s->lv[l];
-        if (!(C == 32 && smp_c64_kernels(s) && d.rowfac8 && d.nodefac && d.fwd_pan && d.dzmax && d.row_max && d.trow && s->bwd_gather) ||
+        if (!((C == 32 || C == 16) && smp_c64_kernels(s) && d.rowfac8 && d.nodefac && d.fwd_pan && d.dzmax && d.row_max && d.trow && s->bwd_gather) ||
             env_is("GF_SMP_FUSED_DROPOUT", '0'))
             return false;
     }

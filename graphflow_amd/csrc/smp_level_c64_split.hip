@@ -1319,14 +1319,22 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
                   wimg ? static_cast<const uint4 *>(wimg) + (F ? 0 : kSpImgStride) : (const uint4 *)nullptr);                      \
     } while (0)
 #define GF_SP_LAUNCH(F, M, CBv, name) GF_SP_LAUNCH_NF(F, M, CBv, 2, name)
-    if (nf != 2 && !(nf == 8 && C == 32)) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d row factors at %d channels", nf, C);
-    if (nf == 8) {   // (per-product row factors: the slice-dropout towers, computed at 32 channels)
+    if (nf != 2 && !(nf == 8 && (C == 32 || C == 16))) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d row factors at %d channels", nf, C);
+    if (nf == 8 && C == 32) {   // (per-product row factors: the slice-dropout towers, computed at 32 or 16 channels)
         if (forward) {
             if (mask) GF_SP_LAUNCH_NF(true, true, 32, 8, "smpf_products_fwd");
             else GF_SP_LAUNCH_NF(true, false, 32, 8, "smpf_products_fwd");
         } else {
             if (mask) GF_SP_LAUNCH_NF(false, true, 32, 8, "smpf_products_bwd");
             else GF_SP_LAUNCH_NF(false, false, 32, 8, "smpf_products_bwd");
+        }
+    } else if (nf == 8) {
+        if (forward) {
+            if (mask) GF_SP_LAUNCH_NF(true, true, 16, 8, "smpf_products_fwd");
+            else GF_SP_LAUNCH_NF(true, false, 16, 8, "smpf_products_fwd");
+        } else {
+            if (mask) GF_SP_LAUNCH_NF(false, true, 16, 8, "smpf_products_bwd");
+            else GF_SP_LAUNCH_NF(false, false, 16, 8, "smpf_products_bwd");
         }
     } else if (C == 64) {
         if (forward) {

@@ -127,7 +127,7 @@ gf_status gf_smp_model_create(gf_ctx *ctx, const gf_smp_model_config *cfg, gf_sm
         gf_smp_config tc = {cfg->nLevels, cfg->nChanels, cfg->nFeatures[t], 0, cfg->max_receptive_field, 0, 18, 0, 1};
         // (nKept > 0, RisiContraction_18_dropout: towers of up to 32 channels run the fused levels with per-product slice factors since
         //  round 5 -- padded like the others; wider ones keep their levels op by op, at their own halving widths)
-        gf_status st = gf::smp_create(ctx, &tc, /*pad_channels=*/cfg->nKept <= 0 || cfg->nChanels <= 32, &m->tower[t], cfg->nKept > 0 ? 32 : 0);
+        gf_status st = gf::smp_create(ctx, &tc, /*pad_channels=*/cfg->nKept <= 0 || cfg->nChanels <= 32, &m->tower[t]);
         if (st != GF_OK) {
             gf_smp_model_destroy(m);
             return st;
