@@ -1047,6 +1047,13 @@ gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channel
             // sits in the corner of a square [18 Cc][Cc] block, the level features are cropped level by level
             if (s->cfg.physics) s->cfg.uniform = 1;
         }
+        // the `_10` / `_50` wirings (SMP_2D_ver6 / ver7: op-by-op levels): a channel count that is not a multiple of 4 runs the contraction
+        // kernels at one channel per lane; padded to the next multiple (10 -> 12) they take the float4 / one-stream-per-graph kernels
+        if (pad_channels && !(e && e[0] == '0') && s->cfg.nContractions != 18 && s->cfg.nLevels < gf::kPadMaxLevels && !s->cfg.physics) {
+            const char *m = std::getenv("GF_SMP_PAD_FAMILY");   // experiment: 0 = off, 4 / 8 / 16 = pad to that multiple
+            const int mult = m ? std::atoi(m) : 4;
+            if (mult > 0) Cc = (C + mult - 1) / mult * mult;
+        }
         s->cfg.nChanels = Cc;
     }
     if (s->cfg.physics && (s->cfg.nDepth != 0 || s->cfg.nContractions != 18 || s->cfg.custom_matmul)) {
