@@ -1638,8 +1638,7 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     FoldGroup rowg;
     const bool stationary = d.fwd_c64;
     if (stationary && (C == 32 || C == 16)) {   // smp_wgrad_direct<32 | 16>: one partial image of the eight products per workgroup
-        const long long slices = ((long long)rows + 15) / 16;
-        int splits = (int)(slices / 8 < 1 ? 1 : slices / 8 > 512 ? 512 : slices / 8);   // (116 registers: two workgroups per CU)
+        const int splits = smp_wgrad_direct_splits(ctx, rows);
         if ((size_t)splits * 8 * CC > ws_floats) return fail(ctx, GF_ERR_NOMEM, "fused level: workspace too small for %d weight-gradient images", splits);
         unsigned *words = s->wbound + (size_t)l * smp_wgrad_direct_words_c32();   // (the same scratch layout at 16 channels)
         const unsigned *chan = nullptr;

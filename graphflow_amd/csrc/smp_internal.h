@@ -58,6 +58,7 @@ gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float
 gf_status smp_wgrad_channel_maxima_ld(gf_ctx *ctx, const float *fprev, long long prev_rows, int ld0, const float *dsrc, long long drows, int ld1, int C,
                                       unsigned *words);
 size_t smp_wgrad_direct_words_c32();
+int smp_wgrad_direct_splits(gf_ctx *ctx, long long rows);
 gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *prog, const float *const *In, float *const *Out, const int *rows,
                               const int *pos0, const void *wimg, const char *name, int C = 64);
 // where the split-operand weight gradients take their per-column exponents from (smp_level_c64_split.hip: smp_wgrad_split): either

@@ -440,6 +440,80 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             store_out(p, 0, acc0, acc1, full, rowbits);
         }
     };
+    if constexpr (CB == 16) {
+        // Sixteen channels (round 5): an operand block is 2 KB per wave and eight registers per lane, so two blocks in flight per wave
+        // (what the schedule above keeps at 64 channels, where a block is 8 KB) leave the memory system idle -- 3 TB/s.  Here ALL of
+        // a panel's blocks are requested one panel ahead (five raw buffers forward, three backward: forty / twenty-four registers), and
+        // the transposed-row indices two panels ahead, so that no request waits behind the previous panel's stores.
+        constexpr int NB = FWD ? 5 : 3;
+        Raw R[NB];
+        int p = blockIdx.x * (kSpThreads / 64) + wave;
+        int t1 = tnext, t2 = fetch_trow(p + nwaves);   // of panel p, of the panel after it
+        auto request = [&](int q, int t) {   // every block of panel q, whose packed transposed-row entries are t
+            if constexpr (FWD) {
+                load_raw(R[0], q, 0, t_own(t));
+                load_raw_at(R[1], t_row(t), 0, t_tr(t));
+                load_raw(R[2], q, 1, t_bc(t));
+                load_raw(R[3], q, 2, t_own(t));
+                load_raw(R[4], q, 3, t_bc(t));
+            } else {
+                const bool all = !(MASK && store_mask);
+                load_raw(R[0], q, 0, all || t_bc(t));
+                load_raw(R[1], q, 1, all || t_bc(t));
+                load_raw_at(R[2], t_row(t), 1, all || t_own(t));
+            }
+        };
+        auto panel16 = [&](int q, auto full) {
+            const int qn = q + nwaves;
+            const int tcur = t1;
+            t1 = t2;
+            t2 = fetch_trow(qn + nwaves);
+            const RowFac sc = load_scale(q);
+            Spl S[NB];
+            float iv[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) split_blk(R[b], S[b], iv[b]);
+            request(qn, t1);
+            f16v acc0, acc1;
+            if constexpr (FWD) {   // S: S_ab, S_ab at the transposed rows, S_bc, T6, T10
+                clear(acc0, acc1);
+                prod(S[0], iv[0] * sc.f[5], 5, acc0, acc1);
+                prod(S[1], iv[1] * sc.f[7], 7, acc0, acc1);
+                prod(S[2], iv[2] * sc.f[6], 6, acc0, acc1);
+                store_out(q, 1, acc0, acc1, full);
+                clear(acc0, acc1);
+                prod(S[0], iv[0] * sc.f[0], 0, acc0, acc1);
+                prod(S[0], iv[0] * sc.f[2], 2, acc0, acc1);
+                prod(S[2], iv[2] * sc.f[1], 1, acc0, acc1);
+                prod(S[3], iv[3] * sc.f[3], 3, acc0, acc1);
+                prod(S[4], iv[4] * sc.f[4], 4, acc0, acc1);
+                store_out(q, 0, acc0, acc1, full);
+            } else {               // S: L, dU, dU at the transposed rows
+                const unsigned rowbits = (MASK && store_mask) ? (unsigned)__ballot(t_own(tcur)) : 0xffffffffu;
+                clear(acc0, acc1);
+                prod(S[0], iv[0] * sc.f[3], 3, acc0, acc1);
+                store_out(q, 2, acc0, acc1, full, rowbits);
+                clear(acc0, acc1);
+                prod(S[0], iv[0] * sc.f[4], 4, acc0, acc1);
+                store_out(q, 3, acc0, acc1, full);
+                clear(acc0, acc1);
+                prod(S[0], iv[0] * sc.f[1], 1, acc0, acc1);
+                prod(S[1], iv[1] * sc.f[6], 6, acc0, acc1);
+                store_out(q, 1, acc0, acc1, full);
+                clear(acc0, acc1);
+                prod(S[0], iv[0] * sc.f[0], 0, acc0, acc1);
+                prod(S[0], iv[0] * sc.f[2], 2, acc0, acc1);
+                prod(S[1], iv[1] * sc.f[5], 5, acc0, acc1);
+                prod(S[2], iv[2] * sc.f[7], 7, acc0, acc1);
+                store_out(q, 0, acc0, acc1, full, rowbits);
+            }
+        };
+        request(p, t1);
+        const int nfull16 = rows / 32;
+        for (; p < nfull16; p += nwaves) panel16(p, std::true_type{});
+        if (p < npanels) panel16(p, std::false_type{});
+        return;
+    }
     Raw R0, R1;
     int p = blockIdx.x * (kSpThreads / 64) + wave;
     load_raw(R0, p, 0, FWD ? t_own(tnext) : (!(MASK && store_mask) || t_bc(tnext)));
@@ -1120,6 +1194,243 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: the same products with ONE wave doing all eight for its slices (CB = 32 / 16).  smp_wgrad_direct gives every product a wave
+// of its own, so a slice's S_ab block is requested and split by four waves, L by five, S_bc and dU by two: sixteen block requests and
+// sixteen splits per slice for seven distinct blocks -- and the kernel is VALU-bound at these channel counts (SQ counters at C = 32:
+// 56 % of the SIMDs' issue slots are split instructions, half of the wave cycles wait for an issue slot).  Here a wave keeps the
+// eight accumulators (128 registers; one wave per SIMD, four per workgroup), requests the seven blocks of its slice once, splits nine
+// operands (four of T; L, tot L, tr L, dU, dU[trow] -- or eight factor-scaled ones under slice dropout, NF = 8) and runs the 24 MFMAs.
+// The four waves of a workgroup take its slices in turn; their images are added in wave order through LDS, so the partial-image
+// contract (one set of eight per workgroup, folded by smp_fold_level) is unchanged and the result does not depend on timing.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kW8Threads = 256;
+template <int CB, int NF>
+__global__ __launch_bounds__(kW8Threads, 1) void smp_wgrad_all(const float *__restrict__ T, const float *__restrict__ dO,
+                                                                const float *__restrict__ rs, int rows, float *__restrict__ part,
+                                                                const int *__restrict__ trow, const unsigned *__restrict__ cmax,
+                                                                const unsigned *__restrict__ chan, float smax,
+                                                                const unsigned *__restrict__ row_max, int packed) {
+    static_assert(CB == 32 || CB == 16, "one 32 x 32 tile per product");
+    constexpr int ACOLS = 4 * CB, BCOLS = 5 * CB;
+    constexpr int SL = CB == 16 ? 2 * kWsSlice : kWsSlice;   // rows of a slice (CB = 16: two half-slices per tile, see smp_wgrad_direct)
+    constexpr int TROW = 16 * CB, DROW = 8 * CB;             // bytes of a row of T, of dO
+    constexpr int NBF = NF == 8 ? 8 : 5;                     // B fragments per slice
+    __shared__ float sScale[ACOLS + BCOLS], sInv[ACOLS + BCOLS];
+    __shared__ float sImg[8 * CB * CB];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = (CB == 16 && li >= 16) ? 1 : 0;
+    const int lc = CB == 16 ? (li & 15) : li;
+    const int rb = 8 * lg + 16 * hi;
+    if (cmax) {
+        for (int c = tid; c < ACOLS + BCOLS; c += kW8Threads) pow2_scale_col(cmax[c], &sScale[c], &sInv[c]);
+    } else {
+        const float max_tot = __uint_as_float(row_max[0]), max_tr = __uint_as_float(row_max[1]);
+        for (int c = tid; c < ACOLS + BCOLS; c += kW8Threads) {
+            const bool isa = c < ACOLS;
+            const int blk = (isa ? c : c - ACOLS) / CB, ch = c % CB;
+            const float m = __uint_as_float(chan[(isa ? 0 : CB) + ch]);
+            const float fa = blk < 2 ? smax : max_tot;
+            const float fb = blk == 0 ? 1.f : blk == 2 ? max_tr : max_tot;
+            pow2_scale_col(__float_as_uint(m * (isa ? fa : fb)), &sScale[c], &sInv[c]);
+        }
+    }
+    __syncthreads();
+    float sa[4], sb[5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sa[k] = sScale[CB * k + lc];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sb[k] = sScale[ACOLS + CB * k + lc];
+
+    constexpr int kOut = 0x40000000;
+    const long long nsl = ((long long)rows + SL - 1) / SL;
+    auto slice_of = [&](int m) { return (long long)blockIdx.x + ((long long)wave + 4ll * m) * gridDim.x; };   // the wave's m-th slice
+    struct Idx {
+        int t[8];
+    };
+    struct Fac {
+        float f[8][NF == 8 ? 8 : 2];
+    };
+    struct Raw {
+        float a[4][8], l[8], u[8], g[8];   // S_ab, S_bc, T6, T10 | L | dU | dU[trow]
+    };
+    const __amdgpu_buffer_rsrc_t rTr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(trow), 0, (unsigned)rows * 4u, 0x00020000);
+    constexpr int rsb = 4 * NF;
+    const __amdgpu_buffer_rsrc_t rRs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rs), 0, (unsigned)rows * (unsigned)rsb, 0x00020000);
+    auto ld1 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    };
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    auto first_row = [&](int m) {
+        const long long k0 = slice_of(m) * SL;
+        return k0 < rows ? (int)k0 : rows;   // (past the end: every entry out of range)
+    };
+    auto load_idx = [&](Idx &I, int m) {
+        const int ks = first_row(m);
+        const i4v t0 = __builtin_bit_cast(i4v, __builtin_amdgcn_raw_buffer_load_b128(rTr, 4 * rb, ks * 4, 0));
+        const i4v t1 = __builtin_bit_cast(i4v, __builtin_amdgcn_raw_buffer_load_b128(rTr, 4 * rb + 16, ks * 4, 0));
+        I.t[0] = t0[0], I.t[1] = t0[1], I.t[2] = t0[2], I.t[3] = t0[3], I.t[4] = t1[0], I.t[5] = t1[1], I.t[6] = t1[2], I.t[7] = t1[3];
+    };
+    auto load_fac = [&](Fac &F, int m) {   // the lane's eight rows are consecutive: rsb bytes each
+        const int ks = first_row(m);
+#pragma unroll
+        for (int q = 0; q < 8 * NF / 4; ++q) {
+            const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rRs, rsb * rb + 16 * q, ks * rsb, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) F.f[(4 * q + e) / NF][(4 * q + e) % NF] = v[e];
+        }
+    };
+    auto load_raw = [&](Raw &R, const Idx &I, int m) {
+        const long long k0 = slice_of(m) * SL;
+        const bool live = k0 < rows;
+        long long left = (long long)rows - k0;
+        left = left < 0 ? 0 : left > SL ? SL : left;
+        const long long k0c = live ? k0 : 0;
+        const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(T + (size_t)k0c * ACOLS), 0, (unsigned)(left * TROW), 0x00020000);
+        const long long g0 = k0c > 1024 ? k0c - 1024 : 0;
+        long long g1 = k0c + SL + 1024;
+        g1 = g1 > rows ? rows : g1;
+        const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dO + (size_t)g0 * 2 * CB), 0, live ? (unsigned)((g1 - g0) * DROW) : 0u, 0x00020000);
+        const int own = (int)(k0c - g0) * DROW;
+        const int ig0 = (int)g0;
+        const int offA = rb * TROW + lc * 4, offL = rb * DROW + lc * 4, offU = offL + CB * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = I.t[j];
+            const bool p31 = !packed || ((t >> 31) & 1), p29 = !packed || ((t >> 29) & 1);
+            const int v31 = p31 ? offA : kOut, v29 = p29 ? offA : kOut;
+            const int tr = packed ? (t & 0x1fffffff) : t;
+            const int vg = p31 ? (tr - ig0) * DROW + (CB + lc) * 4 : kOut;   // dU[trow] only meets S_ab of ITS row
+            R.a[0][j] = ld1(rT, v31, j * TROW);
+            R.a[1][j] = ld1(rT, v29 + CB * 4, j * TROW);
+            R.a[2][j] = ld1(rT, v31 + 2 * CB * 4, j * TROW);
+            R.a[3][j] = ld1(rT, v29 + 3 * CB * 4, j * TROW);
+            R.l[j] = ld1(rD, offL, own + j * DROW);
+            R.u[j] = ld1(rD, offU, own + j * DROW);
+            R.g[j] = ld1(rD, vg, 0);
+        }
+    };
+    f16v acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    auto frag = [&](const float (&v)[8], float sc, const Fac *F, int col, h8 *H, h8 *L) {
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h2 h, l;
+            split_plain2(v[2 * i], v[2 * i + 1], F ? sc * F->f[2 * i][col] : sc, F ? sc * F->f[2 * i + 1][col] : sc, &h, &l);
+            hw[i] = __builtin_bit_cast(unsigned, h);
+            lw[i] = __builtin_bit_cast(unsigned, l);
+        }
+        *H = __builtin_bit_cast(h8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+        *L = __builtin_bit_cast(h8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+    };
+    // products 0..7: A block c_ws_ablk, B operand c_ws_bblk (0 L, 1 tot L, 2 tr L, 3 dU, 4 dU[trow]) -- compile-time copies
+    constexpr int kA[8] = {0, 1, 0, 2, 3, 0, 1, 0}, kB[8] = {1, 1, 2, 0, 0, 3, 3, 4};
+    const long long first = (long long)blockIdx.x + (long long)wave * gridDim.x;
+    if (first < nsl) {
+        const int mine = (int)((nsl - first + 4ll * gridDim.x - 1) / (4ll * gridDim.x));   // slices of this wave
+        Idx I0, I1;
+        Fac F0, F1;
+        Raw R0, R1;
+        load_idx(I0, 0);
+        load_idx(I1, 1);
+        load_fac(F0, 0);
+        load_raw(R0, I0, 0);
+        load_idx(I0, 2);
+        load_fac(F1, 1);
+        load_raw(R1, I1, 1);
+        // One slice: the B fragments first (they serve several products), then block after block of T -- split, multiply -- so that at
+        // most one A fragment is live beside them (with all nine fragments built before the first MFMA the wave needed more than its
+        // 256 VGPRs: the allocator parked values loaded by the requests IN FLIGHT in AGPRs, and every such copy waits for its load --
+        // the queue was drained once per pair of slices).  The next-but-one slice is requested as soon as the last raw register is free.
+        auto mfma3 = [&](int p, const h8 &ah, const h8 &al, const h8 &bh, const h8 &bl) {
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[p], 0, 0, 0);
+        };
+        auto step = [&](Raw &R, Fac &Fcur, Idx &Inext2, Idx &Inext3, int m) {
+            h8 bh[NBF], bl[NBF];
+            if constexpr (NF == 8) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) frag(kB[p] == 3 ? R.u : kB[p] == 4 ? R.g : R.l, sb[kB[p]], &Fcur, p, &bh[p], &bl[p]);
+            } else {
+                frag(R.l, sb[0], nullptr, 0, &bh[0], &bl[0]);
+                frag(R.l, sb[1], &Fcur, 0, &bh[1], &bl[1]);
+                frag(R.l, sb[2], &Fcur, 1, &bh[2], &bl[2]);
+                frag(R.u, sb[3], nullptr, 0, &bh[3], &bl[3]);
+                frag(R.g, sb[4], nullptr, 0, &bh[4], &bl[4]);
+            }
+#pragma unroll
+            for (int k = 0; k < NBF; ++k) asm volatile("" : "+v"(bh[k]), "+v"(bl[k]));
+            auto bsel = [&](int p) { return NF == 8 ? p : kB[p]; };
+            h8 ah, al;
+            frag(R.a[0], sa[0], nullptr, 0, &ah, &al);   // S_ab: products 0, 2, 5, 7
+            asm volatile("" : "+v"(ah), "+v"(al));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma3(0, ah, al, bh[bsel(0)], bl[bsel(0)]);
+            mfma3(2, ah, al, bh[bsel(2)], bl[bsel(2)]);
+            mfma3(5, ah, al, bh[bsel(5)], bl[bsel(5)]);
+            mfma3(7, ah, al, bh[bsel(7)], bl[bsel(7)]);
+            h8 ch, cl;
+            frag(R.a[1], sa[1], nullptr, 0, &ch, &cl);   // S_bc: products 1, 6
+            asm volatile("" : "+v"(ch), "+v"(cl));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma3(1, ch, cl, bh[bsel(1)], bl[bsel(1)]);
+            mfma3(6, ch, cl, bh[bsel(6)], bl[bsel(6)]);
+            h8 dh, dl, eh, el;
+            frag(R.a[2], sa[2], nullptr, 0, &dh, &dl);   // T6: product 3
+            frag(R.a[3], sa[3], nullptr, 0, &eh, &el);   // T10: product 4
+            asm volatile("" : "+v"(dh), "+v"(dl), "+v"(eh), "+v"(el));
+            __builtin_amdgcn_sched_barrier(0);
+            load_idx(Inext3, m + 3);
+            load_fac(Fcur, m + 2);
+            load_raw(R, Inext2, m + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma3(3, dh, dl, bh[bsel(3)], bl[bsel(3)]);
+            mfma3(4, eh, el, bh[bsel(4)], bl[bsel(4)]);
+        };
+        for (int m = 0; m < mine; m += 2) {
+            step(R0, F0, I0, I1, m);
+            step(R1, F1, I1, I0, m + 1);
+        }
+    }
+    // the four waves' images, added in wave order (back in fp32 units: row k of a product is column k of its A block, column n
+    // column n of its B block)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float *ia = sInv + kA[p] * CB, ub = sInv[ACOLS + kB[p] * CB + lc];
+                float *img = sImg + p * CB * CB + lc;
+                if constexpr (CB == 16) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lg;   // 0 .. 15
+                        const float second = acc[p][r + 8];
+                        const float v = (acc[p][r] + __shfl_xor(second, 16)) * (ia[row] * ub);
+                        if (li < 16) img[row * CB] = w == 0 ? v : img[row * CB] + v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lg;
+                        const float v = acc[p][r] * (ia[row] * ub);
+                        img[row * CB] = w == 0 ? v : img[row * CB] + v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *out = part + (size_t)blockIdx.x * 8 * (CB * CB);
+    for (int i = tid; i < 8 * CB * CB / 4; i += kW8Threads)
+        *reinterpret_cast<f4v *>(out + 4 * i) = *reinterpret_cast<const f4v *>(sImg + 4 * i);
+}
+
 // exact column bounds of the nine operand blocks of smp_wgrad_direct<CB> from the column maxima of T [rows][4 CB] (mt) and of
 // dO [rows][2 CB] (mo) and the largest |tot|, |tr| (mx): cmax [9 CB]
 __global__ void wgrad_bounds_exact_cb(const unsigned *__restrict__ mt, const unsigned *__restrict__ mo, const unsigned *__restrict__ mx,
@@ -1385,14 +1696,31 @@ gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float 
 // The eight row block products of a fused level at C = 32 (compact layout) as partial images of 8 x 32 x 32 floats: smp_wgrad_direct<32>.
 // Column exponents from the level's per-channel maxima (chan: [64] words, smax, row_max: see smp_wgrad_split), or -- chan null -- exact
 // column bounds taken from the operands themselves (one extra pass over T and dO; `words`: 512 + 9 * 32 scratch words).
+// one launch of the C = 32 / 16 weight-gradient kernel: smp_wgrad_all (a wave per slice, all eight products; round 5) unless
+// GF_SMP_WGRAD_ALL=0 selects smp_wgrad_direct (a wave per product)
+template <int CB>
+static gf_status launch_wgrad_direct(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int splits, float *part,
+                                     const int *tr, const unsigned *cmax, const unsigned *chan, float smax, const unsigned *row_max, int packed, int nf) {
+    const char *e = std::getenv("GF_SMP_WGRAD_ALL");
+    if (e && e[0] == '0') {
+        GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<CB>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part, tr, cmax, chan, smax,
+                  row_max, packed, nf);
+    } else if (nf == 8) {
+        GF_LAUNCH(ctx, "smpf_wgrad", (smp_wgrad_all<CB, 8>), dim3((unsigned)splits), dim3(kW8Threads), 0, T, dO, rowscale, rows, part, tr, cmax, chan, smax,
+                  row_max, packed);
+    } else {
+        GF_LAUNCH(ctx, "smpf_wgrad", (smp_wgrad_all<CB, 2>), dim3((unsigned)splits), dim3(kW8Threads), 0, T, dO, rowscale, rows, part, tr, cmax, chan, smax,
+                  row_max, packed);
+    }
+    return GF_OK;
+}
 gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int splits, float *part,
                                         const int *trow, const int *trowf, unsigned *words, const unsigned *chan, float smax,
                                         const unsigned *row_max, int nf, int C) {
     const bool mask = trowf && rows < (1 << 28) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
     if (C == 16) {   // (round 5)
         if (chan && row_max) {
-            GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<16>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
-                      mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf);
+            if (gf_status st_ = launch_wgrad_direct<16>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf); st_ != GF_OK) return st_;
             return GF_OK;
         }
         // host-built level tables: exact column bounds from the operands themselves -- T [rows][64] and dO [rows][32] are one
@@ -1405,15 +1733,13 @@ gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float
         GF_LAUNCH(ctx, "smpf_colmax", level_channel_maxima_ld, dim3(g, 1), dim3(256), 0, dO, (long long)rows, 32, (const float *)nullptr, 0ll, 0, 32, words + 256);
         GF_LAUNCH(ctx, "smpf_colmax", rowscale_absmax, dim3(64), dim3(256), 0, rowscale, rows, words + 384);
         GF_LAUNCH(ctx, "smpf_colmax", wgrad_bounds_exact_cb, dim3(1), dim3(64), 0, words, words + 256, words + 384, words + 512, 16);
-        GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<16>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
-                  mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0, nf);
+        if (gf_status st_ = launch_wgrad_direct<16>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0, nf); st_ != GF_OK) return st_;
         return GF_OK;
     }
     if (C != 32) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_wgrad_direct: %d channels", C);
     constexpr int CB = 32;
     if (chan && row_max) {
-        GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<CB>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
-                  mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf);
+        if (gf_status st_ = launch_wgrad_direct<CB>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf); st_ != GF_OK) return st_;
         return GF_OK;
     }
     GF_HIP_TRY(ctx, hipMemsetAsync(words, 0, sizeof(unsigned) * 512, ctx->stream));
@@ -1425,11 +1751,24 @@ gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float
     if (nf != 2) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_wgrad_direct: exact column bounds with per-product row factors");
     GF_LAUNCH(ctx, "smpf_colmax", rowscale_absmax, dim3(64), dim3(256), 0, rowscale, rows, words + 384);
     GF_LAUNCH(ctx, "smpf_colmax", wgrad_bounds_exact_cb, dim3(1), dim3(64), 0, words, words + 256, words + 384, words + 512, CB);
-    GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<CB>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part,
-              mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0, nf);
+    if (gf_status st_ = launch_wgrad_direct<CB>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0, nf); st_ != GF_OK) return st_;
     return GF_OK;
 }
 size_t smp_wgrad_direct_words_c32() { return 512 + 9 * 32; }
+// workgroups (= partial image sets) of the C = 32 / 16 weight-gradient launch for a level of `rows` rows.  smp_wgrad_all keeps one wave
+// per SIMD (its eight accumulators): ONE workgroup per CU -- measured at C = 32, cfg3: 0.44 ms with 256 workgroups, 0.53 with 512 (the
+// second half waits for whole CUs), 0.72 with 1024; smp_wgrad_direct (116 registers) ran two per CU.
+int smp_wgrad_direct_splits(gf_ctx *ctx, long long rows) {
+    static int cu_count[64] = {};
+    const int di = ctx->device & 63;
+    if (!cu_count[di]) {
+        if (hipDeviceGetAttribute(&cu_count[di], hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cu_count[di] < 1) cu_count[di] = 256;
+    }
+    const char *e = std::getenv("GF_SMP_WGRAD_ALL");
+    const long long cap = (e && e[0] == '0') ? 512 : cu_count[di];
+    const long long slices = (rows + 15) / 16, want = slices / 8;
+    return (int)(want < 1 ? 1 : want > cap ? cap : want);
+}
 
 size_t smp_wgrad_bound_words() { return 128; }
 // words: [0, 64) largest |f_{l-1}| per channel, [64, 128) largest |dz_l| per channel, accumulated here with atomicMax (the caller zeroes
