@@ -163,6 +163,9 @@ __global__ __launch_bounds__(kSpThreads) void smp_split_weight_images(SplitImage
 // NF (round 5): factors per row in `rs` -- 2: (tot, tr) of the row's node; 8: one factor per stacked product 0..7, i.e. (tot, tot, tr, 1, 1,
 // 1, 1, 1) times the node's slice-dropout factors of K0, K2, K6, K5, K9, K8, K12, K11 (RisiContraction_18_dropout: a dropped slice
 // of the contraction is a zero factor on its block product, GraphFlow/RisiContraction_18_dropout.h:106-132)
+#ifndef GF_SP_WHOLE_PANEL
+#define GF_SP_WHOLE_PANEL 16   // (32: products-forward 0.36 -> 0.39 ms at C = 32)
+#endif
 template <bool FWD, bool MASK, int CB = 64, int NF = 2>
 __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float *__restrict__ A, const float *__restrict__ rs,
                                                                      const float *__restrict__ Wst, float *__restrict__ Out, int rows,
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             store_out(p, 0, acc0, acc1, full, rowbits);
         }
     };
-    if constexpr (CB == 16) {
+    if constexpr (CB <= GF_SP_WHOLE_PANEL) {
         // Sixteen channels (round 5): an operand block is 2 KB per wave and eight registers per lane, so two blocks in flight per wave
         // (what the schedule above keeps at 64 channels, where a block is 8 KB) leave the memory system idle -- 3 TB/s.  Here ALL of
         // a panel's blocks are requested one panel ahead (five raw buffers forward, three backward: forty / twenty-four registers), and
@@ -1615,7 +1618,7 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
     const int npanels = (rows + 31) / 32;
     const int want = (npanels + per - 1) / per;
     // C = 64: one persistent workgroup per CU (the weight images take 128 KB of LDS); C = 32 (32 KB of images): two
-    const int slots = C == 64 ? cus : 2 * cus;
+    const int slots = C == 64 ? cus : 2 * cus;   // (C = 32 / 16: one or two per CU measured equal)
     const int grid = want < slots ? want : slots;
     if (C != 64 && !wimg) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d channels need the level's prebuilt weight images", C);
     // packed table with the presence bits (see the kernel)
