@@ -12,3 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r05_c10 -o c10 -- python $R/bench.py --C 10 --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
 cd $R; python tools/rocpd_summary.py gpurun_out/prof_r05_c10/*results.db > gpurun_out/r05_cfg3_C10_kernel_stats.txt; rm -rf gpurun_out/prof_r05_c10
 head -12 gpurun_out/r05_cfg3_C10_kernel_stats.txt | cut -c1-60,112-150
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r05_c32 -o c32 -- python $R/bench.py --C 32 --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+cd $R; python tools/rocpd_summary.py gpurun_out/prof_r05_c32/*results.db > gpurun_out/r05_cfg3_C32_kernel_stats.txt; rm -rf gpurun_out/prof_r05_c32
+{ python tools/ver67_time.py 10 10 1024; python tools/ver67_time.py 50 10 1024; } 2>/dev/null | grep nContractions > gpurun_out/r05_ver67_times.txt; cat gpurun_out/r05_ver67_times.txt
