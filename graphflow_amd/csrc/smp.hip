@@ -1047,9 +1047,18 @@ gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channel
             // sits in the corner of a square [18 Cc][Cc] block, the level features are cropped level by level
             if (s->cfg.physics) s->cfg.uniform = 1;
         }
+        // SMP_2D_ver6 (RisiContraction_10) embedded in the 18-slice fused level (see gf_smp::dup_channels): 2 C channels padded to 16 / 32 / 64.
+        // GF_SMP_VER6_FUSED=0: the `_10` contraction op by op.  gf_smp_prepare refuses an asymmetric adjacency in this mode.
+        if (pad_channels && !(e && e[0] == '0') && s->cfg.nContractions == 10 && 2 * C <= 64 && s->cfg.nLevels < gf::kPadMaxLevels && !s->cfg.physics &&
+            !(std::getenv("GF_SMP_VER6_FUSED") && std::getenv("GF_SMP_VER6_FUSED")[0] == '0')) {
+            s->dup_channels = C;
+            s->cfg.nContractions = 18;
+            s->cfg.custom_matmul = 0;   // (the device's own copy of the weights is in the [18 Cc][Cc] layout whatever the caller's is)
+            Cc = 2 * C <= 16 ? 16 : 2 * C <= 32 ? 32 : 64;
+        }
         // the `_10` / `_50` wirings (SMP_2D_ver6 / ver7: op-by-op levels): a channel count that is not a multiple of 4 runs the contraction
         // kernels at one channel per lane; padded to the next multiple (10 -> 12) they take the float4 / one-stream-per-graph kernels
-        if (pad_channels && !(e && e[0] == '0') && s->cfg.nContractions != 18 && s->cfg.nLevels < gf::kPadMaxLevels && !s->cfg.physics) {
+        if (pad_channels && !(e && e[0] == '0') && s->cfg.nContractions != 18 && !s->dup_channels && s->cfg.nLevels < gf::kPadMaxLevels && !s->cfg.physics) {
             const char *m = std::getenv("GF_SMP_PAD_FAMILY");   // experiment: 0 = off, 4 / 8 / 16 = pad to that multiple
             const int mult = m ? std::atoi(m) : 4;
             if (mult > 0) Cc = (C + mult - 1) / mult * mult;
@@ -1308,6 +1317,20 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     if (nMol <= 0 || !nVertices || !adj || !feature) return fail(ctx, GF_ERR_INVALID, "gf_smp_prepare: bad argument");
     for (int m = 0; m < nMol; ++m)
         if (nVertices[m] <= 0 || nVertices[m] > 4096) return fail(ctx, GF_ERR_INVALID, "molecule %d has %d vertices", m, nVertices[m]);
+    if (s->dup_channels) {   // SMP_2D_ver6 on the 18-slice level: the identities behind it need row sums = column sums
+        const int *a = adj;
+        const double *cm = coulomb;
+        for (int m = 0; m < nMol; ++m) {
+            const int V = nVertices[m];
+            for (int i = 0; i < V; ++i)
+                for (int j = i + 1; j < V; ++j)
+                    if (a[i * V + j] != a[j * V + i] || (cm && cm[i * V + j] != cm[j * V + i]))
+                        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare: molecule %d has an asymmetric adjacency (%d, %d); the fused RisiContraction_10 "
+                                    "level needs a symmetric one -- create the handle with GF_SMP_VER6_FUSED=0 for the op-by-op level", m, i, j);
+            a += (size_t)V * V;
+            if (cm) cm += (size_t)V * V;
+        }
+    }
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool prep_timing = std::getenv("GF_PREP_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
@@ -1719,6 +1742,99 @@ __global__ void crop_gradients(const float *__restrict__ padded, float *__restri
     const long long u = padded_to_user(i, m);
     if (u >= 0) user[u] = accumulate ? user[u] + padded[i] : padded[i];
 }
+// ---- SMP_2D_ver6 on the 18-slice level (gf_smp::dup_channels) --------------------------------------------------------------------
+// RisiContraction_10's slice k (RisiContraction_10.h:94-142 = cases 1..10 of RisiContraction_50.h) as (slot of RisiContraction_18, input
+// group 0 = f, 1 = f^T), for a SYMMETRIC reduced adjacency (row sums = column sums; checked numerically against the oracle, all 18 slots
+// on P and on P with b and c swapped):
+//   1 (a,b) -> slot 0 on f        2 (a,c) -> slot 0 on f^T      3 (a,d), 4 (a,e) -> slot 1 on f       5 (b,c) -> slot 2 on f
+//   6 (b,d), 7 (b,e) -> slot 3 on f          8 (c,d), 9 (c,e) -> slot 3 on f^T          10 (d,e) -> slot 4 on f
+// Two slices that share a slot share its padded weight block: the block holds their SUM (the level is linear in K), and both receive
+// the block's gradient.
+__device__ __forceinline__ void v6_slot(int k, int *slot, int *grp) {
+    const int sl[10] = {0, 0, 1, 1, 2, 3, 3, 3, 3, 4}, gr[10] = {0, 1, 0, 0, 0, 0, 0, 1, 1, 0};
+    *slot = sl[k];
+    *grp = gr[k];
+}
+// the caller's parameter u -> its (only) place in the padded [H | (K_l [18 Cc][Cc], b_l [Cc]) x L | W] vector
+__device__ __forceinline__ long long v6_user_to_padded(long long u, const PadMap &m) {
+    const int C = m.cu[0], Cc = m.Cc;
+    if (u < m.uoff[1]) return u;   // H: rows c < C first in both layouts
+    const long long hpad = (long long)Cc * m.FD, lvl_pad = 18ll * Cc * Cc + Cc;
+    for (int l = 1; l <= m.L; ++l) {
+        if (u >= m.uoff[l + 1]) continue;
+        const long long j = u - m.uoff[l], base = hpad + (l - 1) * lvl_pad;
+        if (j >= 10ll * C * C) return base + 18ll * Cc * Cc + (j - 10ll * C * C);   // bias
+        int k, ci, co;
+        if (m.custom) {   // [C][10 C]
+            co = (int)(j / (10 * C));
+            const int r = (int)(j % (10 * C));
+            k = r / C, ci = r % C;
+        } else {          // [10 C][C]
+            k = (int)(j / ((long long)C * C));
+            const int r = (int)(j % ((long long)C * C));
+            ci = r / C, co = r % C;
+        }
+        int slot, grp;
+        v6_slot(k, &slot, &grp);
+        return base + ((long long)slot * Cc + grp * C + ci) * Cc + co;
+    }
+    return hpad + m.L * lvl_pad + (u - m.uoff[m.L + 1]);   // W
+}
+__global__ void v6_pad_parameters(const float *__restrict__ user, float *__restrict__ padded, long long n_user, PadMap m) {
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_user) return;
+    atomicAdd(padded + v6_user_to_padded(u, m), user[u]);   // (padded starts at zero; at most two terms per entry: the order cannot matter)
+}
+__global__ void v6_crop_gradients(const float *__restrict__ padded, float *__restrict__ user, long long n_user, PadMap m, int accumulate) {
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_user) return;
+    const float g = padded[v6_user_to_padded(u, m)];
+    user[u] = accumulate ? user[u] + g : g;
+}
+// f [rows][Cc]: channels [C, 2C) of row (x, y) <- channels [0, C) of row (y, x) of the same node (trow; null: level 0, one row per node);
+// pmax [panels][Cc] (or null): the per-panel channel maxima combine-forward left, copied likewise (a level-wide maximum is all they serve)
+__global__ void dup_transposed_channels(float *__restrict__ f, const int *__restrict__ trow, long long rows, int C, int Cc, float *__restrict__ pmax,
+                                        long long panels) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * C) {
+        const long long r = i / C;
+        const int c = (int)(i % C);
+        const long long t = trow ? trow[r] : r;
+        f[r * Cc + C + c] = f[t * Cc + c];
+    } else if (pmax && i < rows * C + panels * C) {
+        const long long j = i - rows * C;
+        pmax[(j / C) * Cc + C + j % C] = pmax[(j / C) * Cc + j % C];
+    }
+}
+// the reverse: df[(x, y)][c] += df[(y, x)][C + c], and the upper channels (read exactly once, by this thread) are cleared
+__global__ void fold_transposed_channels(float *__restrict__ df, const int *__restrict__ trow, long long rows, int C, int Cc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    const long long r = i / C;
+    const int c = (int)(i % C);
+    const long long t = trow ? trow[r] : r;
+    df[r * Cc + c] += df[t * Cc + C + c];
+    df[t * Cc + C + c] = 0.f;
+}
+static gf_status dup_level(gf_smp *s, int l) {
+    if (!s->dup_channels) return GF_OK;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const long long rows = l == 0 ? s->lay.level[0].nNodes : s->lay.level[l].rows;
+    if (l > 0 && !d.trow) return fail(s->ctx, GF_ERR_UNSUPPORTED, "SMP_2D_ver6 on the fused level: level %d has no transposed-row table", l);
+    const bool pm = l > 0 && d.pmax && d.pmax_ready;
+    const long long panels = pm ? d.fwd_npanels : 0, n = (rows + panels) * s->dup_channels;
+    GF_LAUNCH(s->ctx, "smp_dup_transposed", dup_transposed_channels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d.f, l == 0 ? (const int *)nullptr : d.trow,
+              rows, s->dup_channels, s->cfg.nChanels, pm ? d.pmax : (float *)nullptr, panels);
+    return GF_OK;
+}
+static gf_status fold_level(gf_smp *s, int l) {
+    if (!s->dup_channels) return GF_OK;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const long long rows = l == 0 ? s->lay.level[0].nNodes : s->lay.level[l].rows, n = rows * s->dup_channels;
+    GF_LAUNCH(s->ctx, "smp_fold_transposed", fold_transposed_channels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d.df,
+              l == 0 ? (const int *)nullptr : d.trow, rows, s->dup_channels, s->cfg.nChanels);
+    return GF_OK;
+}
 static bool padded_channels(const gf_smp *s) { return s->cfg.nChanels != s->ucfg.nChanels || s->cfg.uniform != s->ucfg.uniform; }
 // the handle's padded copies of the caller's parameters / of the gradients of the running step
 static gf_status pad_buffers(gf_smp *s) {
@@ -1739,11 +1855,23 @@ static gf_status pad_params_now(gf_smp *s, const float *params) {
     gf_status st = pad_buffers(s);
     if (st != GF_OK) return st;
     const long long n = (long long)param_count(s->cfg);
+    if (s->dup_channels) {
+        const long long nu = (long long)param_count(s->ucfg);
+        GF_HIP_TRY(s->ctx, hipMemsetAsync(s->pad_p, 0, (size_t)n * sizeof(float), s->ctx->stream));
+        GF_LAUNCH(s->ctx, "smp_pad_params", v6_pad_parameters, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, params, s->pad_p, nu, pad_map(s->ucfg, s->cfg));
+        return GF_OK;
+    }
     GF_LAUNCH(s->ctx, "smp_pad_params", pad_parameters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, params, s->pad_p, n, pad_map(s->ucfg, s->cfg));
     return GF_OK;
 }
 static gf_status crop_grads_now(gf_smp *s, float *grads, int accumulate) {
     const long long n = (long long)param_count(s->cfg);
+    if (s->dup_channels) {
+        const long long nu = (long long)param_count(s->ucfg);
+        GF_LAUNCH(s->ctx, "smp_crop_grads", v6_crop_gradients, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s->pad_g, grads, nu, pad_map(s->ucfg, s->cfg),
+                  accumulate ? 1 : 0);
+        return GF_OK;
+    }
     GF_LAUNCH(s->ctx, "smp_crop_grads", crop_gradients, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->pad_g, grads, n, pad_map(s->ucfg, s->cfg),
               accumulate ? 1 : 0);
     return GF_OK;
@@ -1837,6 +1965,8 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
               (const float *)nullptr, C, (size_t)nV * C);
     for (int l = 0; l <= L; ++l) s->lv[l].psum_ready = s->lv[l].pmax_ready = false;
     s->bwd_consumed = false;
+    st = gf::dup_level(s, 0);   // (SMP_2D_ver6 on the 18-slice level: channels [C, 2C) <- the transposed matrices; level 0: copies)
+    if (st != GF_OK) return st;
     if (s->fused) {
         if (s->wbound && C == 64) GF_HIP_TRY(ctx, hipMemsetAsync(s->wbound, 0, sizeof(unsigned) * gf::smp_wgrad_bound_words() * (size_t)(L + 1), ctx->stream));
         st = gf::smp_fused_stack_all(s, K);
@@ -1847,6 +1977,8 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
         const gf_smp::DevLevel &d = s->lv[l];
         if (s->fused && gf::smp_fused_supported(s, l)) {
             st = gf::smp_fused_forward_level(s, l, K[l], b[l]);
+            if (st != GF_OK) return st;
+            if (l < L) st = gf::dup_level(s, l);
             if (st != GF_OK) return st;
             continue;
         }
@@ -1871,6 +2003,8 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)h.rows * Cc)), dim3(256), 0, d.f,
                   b[l], Cc, (size_t)h.rows * Cc);
+        if (l < L) st = gf::dup_level(s, l);
+        if (st != GF_OK) return st;
     }
     if (s->cfg.physics) {  // every level read out into its block of the feature row; the head (MLP, loss) is the caller's
         const int width = (int)gf::feature_width(s->cfg);
@@ -2077,6 +2211,10 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
     for (int l = L; l >= 1; --l) {
         const gfsmp::LevelLayout &h = B.level[l];
         const gf_smp::DevLevel &d = s->lv[l];
+        if (l < L) {   // (SMP_2D_ver6 on the 18-slice level: the gradient of the transposed copies joins the matrices')
+            st = gf::fold_level(s, l);
+            if (st != GF_OK) return st;
+        }
         if (s->fused && gf::smp_fused_supported(s, l)) {
             if (dfeat) {
                 st = feature_nodevec(l);
@@ -2141,6 +2279,8 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
         const int nV = B.level[0].nNodes;
         // (level 0 has no bias: the column sums are discarded, so small row blocks cost nothing downstream; colpart holds
         //  maxrows / 1024 + maxpairs / 256 + 2 rows and level 0 has at most maxpairs / 64 blocks... keep nb within it)
+        st = gf::fold_level(s, 0);
+        if (st != GF_OK) return st;
         int rpb = 64;
         while ((nV + rpb - 1) / rpb > (int)s->colpart_rows && rpb < 1024) rpb *= 2;
         const int nb = (nV + rpb - 1) / rpb;

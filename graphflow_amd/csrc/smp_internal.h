@@ -95,6 +95,11 @@ struct gf_smp {
     bool bwd_consumed = false;   // an op-by-op level's reverse sweep has overwritten its Q since the last forward
     gfsmp::Config ucfg;   // the caller's configuration: the layout of parameters, gradients, features and activations at the C ABI
     float *pad_p = nullptr, *pad_g = nullptr, *pad_feat = nullptr;   // padded copies (cfg.nChanels != ucfg.nChanels)
+    // Round 5, SMP_2D_ver6 (RisiContraction_10) on the fused RisiContraction_18 level: != 0 = the caller's channel count C.  With a symmetric
+    // reduced adjacency every one of the ten "1+1+1" slices is a slice of RisiContraction_18 applied to f_{l-1} or to its per-node
+    // TRANSPOSE (smp.hip: v6_slot), so the device computes an 18-slice model on [f | f^T | 0] channels: channels [C, 2C) of every level's
+    // activations hold the transposed matrices (dup_transposed_channels after each level, fold_transposed_channels in the reverse sweep)
+    int dup_channels = 0;
     size_t pad_feat_n = 0;
     gfsmp::BatchLayout lay;
     bool prepared = false, forwarded = false;

@@ -1023,7 +1023,7 @@ def test_smp_2d_ver6_wiring_runs_the_graph_stream_contractions(gf, monkeypatch):
         mols.append((adj, feat))
         tg.append(t)
 
-    def step():
+    def step(keep=False):
         net = SMPOmega(L, C, F, D, cap, True, nContractions=10, custom_matmul=True)
         rng = np.random.default_rng(8)
         params = f32exact(rng.uniform(-1, 1, net.n_params) / np.sqrt(10 * C))
@@ -1033,9 +1033,12 @@ def test_smp_2d_ver6_wiring_runs_the_graph_stream_contractions(gf, monkeypatch):
         grads = torch.empty(net.n_params, device="cuda")
         net.backward(p, grads)
         out = [x.cpu().numpy().astype(np.float64) for x in (pred, feat, grads)]
+        if keep:
+            return out + [net]
         net.close()
         return out
 
+    monkeypatch.setenv("GF_SMP_VER6_FUSED", "0")   # (the op-by-op `_10` level; the default since round 5 is the 18-slice fused level, below)
     a = step()
     monkeypatch.setenv("GF_FAM10_GRAPH", "0")
     b = step()
@@ -1044,6 +1047,68 @@ def test_smp_2d_ver6_wiring_runs_the_graph_stream_contractions(gf, monkeypatch):
     assert not np.array_equal(a[2], b[2])   # (the switch switches something)
     assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[1], b[1]) <= TOL_FWD
     assert rel_err(a[2], b[2]) <= TOL_GRAD
+    # Round 5: the same model on the FUSED level -- RisiContraction_10's slices as slices of RisiContraction_18 on [f | f^T] channels
+    # (gf_smp::dup_channels; 2 x 32 = 64 channels here) -- against the op-by-op `_10` level
+    b = step(keep=True)
+    monkeypatch.delenv("GF_SMP_VER6_FUSED")
+    monkeypatch.delenv("GF_FAM10_GRAPH")
+    c = step(keep=True)
+    note("ver6_c32_fused18_vs_op_by_op", pred=rel_err(c[0], b[0]), feat=rel_err(c[1], b[1]))
+    assert not np.array_equal(c[2], b[2])
+    assert rel_err(c[0], b[0]) <= TOL_FWD and rel_err(c[1], b[1]) <= TOL_FWD
+    assert_grads_agree_kink_aware("ver6_c32_fused18_vs_op_by_op", c[2], b[2], c[3], b[3], mols, L)
+    c[3].close(), b[3].close()
+
+
+@pytest.mark.parametrize("C,custom", [(10, True), (7, False), (16, True), (3, True)])
+def test_smp_2d_ver6_on_the_fused_level_equals_the_op_by_op_level(gf, monkeypatch, C, custom):
+    """RisiContraction_10 wiring at channel counts that pad to 32 (10, 16), 16 (7, 3 -> 14, 6 channels of [f | f^T]) with either weight layout,
+    three levels, edge molecules included: predictions, features, every gradient against the op-by-op `_10` level (pinned to the real
+    SMP_2D_ver6 by the goldens and the BatchLearn trajectory).  Then accumulate = 1 twice the gradient, and an asymmetric adjacency is refused."""
+    from graphflow_amd.smp import SMPOmega
+    from graphflow_amd import _lib
+    L, F, D, cap = 3, 5, 2, 9
+    mols, tg = [], []
+    for seed in range(24):
+        adj, feat, t = synthetic_molecule(7000 + seed, nV=1 + seed % 11)
+        mols.append((adj, feat))
+        tg.append(t)
+
+    def step(acc2=False):
+        net = SMPOmega(L, C, F, D, cap, True, nContractions=10, custom_matmul=custom)
+        rng = np.random.default_rng(18)
+        params = f32exact(rng.uniform(-1, 1, net.n_params) / np.sqrt(10 * C))
+        net.prepare(mols)
+        p = dev(params)
+        pred, loss, feat = net.forward(p, dev(np.array(tg)))
+        grads = torch.zeros(net.n_params, device="cuda")
+        net.backward(p, grads)
+        if acc2:
+            net.forward(p, dev(np.array(tg)))
+            net.backward(p, grads, accumulate=True)
+        return [x.cpu().numpy().astype(np.float64) for x in (pred, feat, grads)] + [net]
+
+    a = step()
+    a2 = step(acc2=True)
+    monkeypatch.setenv("GF_SMP_VER6_FUSED", "0")
+    b = step()
+    note("ver6_fused18_vs_op_by_op_C%d" % C, pred=rel_err(a[0], b[0]), feat=rel_err(a[1], b[1]))
+    assert np.isfinite(a[2]).all() and np.abs(a[2]).max() > 0 and not np.array_equal(a[2], b[2])
+    assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[1], b[1]) <= TOL_FWD
+    assert_grads_agree_kink_aware("ver6_fused18_vs_op_by_op_C%d" % C, a[2], b[2], a[3], b[3], mols, L)
+    assert rel_err(a2[2], 2 * a[2]) <= 1e-6
+    for r in (a, a2, b):
+        r[3].close()
+    monkeypatch.delenv("GF_SMP_VER6_FUSED")
+    net = SMPOmega(L, C, F, D, cap, True, nContractions=10, custom_matmul=custom)
+    adj, feat, _ = synthetic_molecule(7100, nV=6)
+    bad = np.array(adj).copy()
+    i, j = np.argwhere(bad > 0)[0]
+    bad[j, i] = 0 if i != j else bad[j, i]
+    if not np.array_equal(bad, bad.T):
+        with pytest.raises(Exception, match="asymmetric"):
+            net.prepare([(bad, feat)])
+    net.close()
 
 
 @pytest.mark.parametrize("C,fused,cap,coul", [(64, True, 29, False), (8, False, 6, False), (16, True, 12, True)])
