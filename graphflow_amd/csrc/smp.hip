@@ -992,7 +992,10 @@ gf_status smp_dp_level_done(gf_smp *s, int l) {
     char what[64];
     if (l >= 1) std::snprintf(what, sizeof what, "gf_smp_backward: gradient segment [K_%d | b_%d%s]", l, l, l == c.nLevels ? " | W" : "");
     else std::snprintf(what, sizeof what, "gf_smp_backward: gradient segment [H]");
-    return dist_allreduce_on(ctx, seg, n, comm, what);
+    gf_status st = dist_allreduce_on(ctx, seg, n, comm, what);
+    if (st == GF_OK && l == 0 && s->n_extra)   // (SMP_2D_ver7 on the 18-slice level: the extra products' blocks sit behind W; every level has written its own by now)
+        st = dist_allreduce_on(ctx, s->dp_grads + param_count(c), (size_t)c.nLevels * s->n_extra * C * C, comm, "gf_smp_backward: gradient segment [X_1 .. X_L]");
+    return st;
 }
 }  // namespace gf
 
@@ -1056,6 +1059,15 @@ gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channel
             s->cfg.custom_matmul = 0;   // (the device's own copy of the weights is in the [18 Cc][Cc] layout whatever the caller's is)
             Cc = 2 * C <= 16 ? 16 : 2 * C <= 32 ? 32 : 64;
         }
+        // SMP_2D_ver7 (RisiContraction_50) the same way, with three extra products per level (gf_smp::n_extra).  GF_SMP_VER7_FUSED=0: op by op.
+        if (pad_channels && !(e && e[0] == '0') && s->cfg.nContractions == 50 && 2 * C <= 64 && s->cfg.nLevels < gf::kPadMaxLevels && !s->cfg.physics &&
+            !(std::getenv("GF_SMP_VER7_FUSED") && std::getenv("GF_SMP_VER7_FUSED")[0] == '0')) {
+            s->dup_channels = C;
+            s->n_extra = 3;
+            s->cfg.nContractions = 18;
+            s->cfg.custom_matmul = 0;
+            Cc = 2 * C <= 16 ? 16 : 2 * C <= 32 ? 32 : 64;
+        }
         // the `_10` / `_50` wirings (SMP_2D_ver6 / ver7: op-by-op levels): a channel count that is not a multiple of 4 runs the contraction
         // kernels at one channel per lane; padded to the next multiple (10 -> 12) they take the float4 / one-stream-per-graph kernels
         if (pad_channels && !(e && e[0] == '0') && s->cfg.nContractions != 18 && !s->dup_channels && s->cfg.nLevels < gf::kPadMaxLevels && !s->cfg.physics) {
@@ -1086,6 +1098,7 @@ extern "C" {
 
 gf_status gf_smp_destroy(gf_smp *s) {
     if (!s) return GF_OK;
+    if (s->rs_inv) (void)hipFree(s->rs_inv);
     gf::release(s);
     gf::release_pool(s);
     if (s->upload) (void)hipStreamDestroy(s->upload);
@@ -1317,7 +1330,10 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     if (nMol <= 0 || !nVertices || !adj || !feature) return fail(ctx, GF_ERR_INVALID, "gf_smp_prepare: bad argument");
     for (int m = 0; m < nMol; ++m)
         if (nVertices[m] <= 0 || nVertices[m] > 4096) return fail(ctx, GF_ERR_INVALID, "molecule %d has %d vertices", m, nVertices[m]);
-    if (s->dup_channels) {   // SMP_2D_ver6 on the 18-slice level: the identities behind it need row sums = column sums
+    if (s->n_extra && coulomb)   // (SMP_2D_ver7 on the 18-slice level: cases 25, 41, 42, 45 are taken with the adjacency's diagonal = 1)
+        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare_coulomb: the fused RisiContraction_50 level needs the unit diagonal of a reduced adjacency "
+                    "-- create the handle with GF_SMP_VER7_FUSED=0 for the op-by-op level");
+    if (s->dup_channels) {   // SMP_2D_ver6 / ver7 on the 18-slice level: the identities behind it need row sums = column sums
         const int *a = adj;
         const double *cm = coulomb;
         for (int m = 0; m < nMol; ++m) {
@@ -1325,8 +1341,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             for (int i = 0; i < V; ++i)
                 for (int j = i + 1; j < V; ++j)
                     if (a[i * V + j] != a[j * V + i] || (cm && cm[i * V + j] != cm[j * V + i]))
-                        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare: molecule %d has an asymmetric adjacency (%d, %d); the fused RisiContraction_10 "
-                                    "level needs a symmetric one -- create the handle with GF_SMP_VER6_FUSED=0 for the op-by-op level", m, i, j);
+                        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare: molecule %d has an asymmetric adjacency (%d, %d); the fused RisiContraction_10 / _50 "
+                                    "level needs a symmetric one -- create the handle with GF_SMP_VER6_FUSED=0 / GF_SMP_VER7_FUSED=0 for the op-by-op level", m, i, j);
             a += (size_t)V * V;
             if (cm) cm += (size_t)V * V;
         }
@@ -1755,27 +1771,40 @@ __device__ __forceinline__ void v6_slot(int k, int *slot, int *grp) {
     *slot = sl[k];
     *grp = gr[k];
 }
-// the caller's parameter u -> its (only) place in the padded [H | (K_l [18 Cc][Cc], b_l [Cc]) x L | W] vector
+// RisiContraction_50's cases 1..50 (RisiContraction_50.h:94-430) the same way; slots 18, 19, 20 = the extra products (S_ab, 1), (S_bc, 1),
+// (S_bc, tr) of gf_smp::n_extra (cases 41 / 42, 45, 25 with the reduced adjacency's unit diagonal).  At most two cases share a block.
+__device__ __forceinline__ void v7_slot(int k, int *slot, int *grp) {
+    const signed char sl[50] = {0, 0, 1, 1, 2, 3, 3, 3, 3, 4,   5, 5, 6, 5, 5, 6, 7, 8, 8, 7,   8, 8, 9, 9, 20, 10, 11, 12, 10, 11,
+                                12, 10, 11, 12, 10, 11, 12, 13, 13, 14,   18, 18, 15, 15, 19, 16, 16, 16, 16, 17};
+    const signed char gr[50] = {0, 1, 0, 0, 0, 0, 0, 1, 1, 0,   0, 0, 0, 1, 1, 1, 0, 0, 1, 0,   0, 1, 0, 0, 0, 0, 0, 0, 0, 0,
+                                0, 1, 1, 1, 1, 1, 1, 0, 1, 0,   0, 1, 0, 0, 0, 0, 0, 1, 1, 0};
+    *slot = sl[k];
+    *grp = gr[k];
+}
+// the caller's parameter u -> its (only) place in the padded [H | (K_l [18 Cc][Cc], b_l [Cc]) x L | W | X_1 .. X_L] vector
 __device__ __forceinline__ long long v6_user_to_padded(long long u, const PadMap &m) {
-    const int C = m.cu[0], Cc = m.Cc;
+    const int C = m.cu[0], Cc = m.Cc, nK = m.nK;
     if (u < m.uoff[1]) return u;   // H: rows c < C first in both layouts
     const long long hpad = (long long)Cc * m.FD, lvl_pad = 18ll * Cc * Cc + Cc;
     for (int l = 1; l <= m.L; ++l) {
         if (u >= m.uoff[l + 1]) continue;
         const long long j = u - m.uoff[l], base = hpad + (l - 1) * lvl_pad;
-        if (j >= 10ll * C * C) return base + 18ll * Cc * Cc + (j - 10ll * C * C);   // bias
+        if (j >= (long long)nK * C * C) return base + 18ll * Cc * Cc + (j - (long long)nK * C * C);   // bias
         int k, ci, co;
-        if (m.custom) {   // [C][10 C]
-            co = (int)(j / (10 * C));
-            const int r = (int)(j % (10 * C));
+        if (m.custom) {   // [C][nK C]
+            co = (int)(j / (nK * C));
+            const int r = (int)(j % (nK * C));
             k = r / C, ci = r % C;
-        } else {          // [10 C][C]
+        } else {          // [nK C][C]
             k = (int)(j / ((long long)C * C));
             const int r = (int)(j % ((long long)C * C));
             ci = r / C, co = r % C;
         }
         int slot, grp;
-        v6_slot(k, &slot, &grp);
+        if (nK == 10) v6_slot(k, &slot, &grp);
+        else v7_slot(k, &slot, &grp);
+        if (slot >= 18)   // an extra product's block
+            return hpad + m.L * lvl_pad + Cc + ((long long)(l - 1) * 3 + (slot - 18)) * Cc * Cc + (long long)(grp * C + ci) * Cc + co;
         return base + ((long long)slot * Cc + grp * C + ci) * Cc + co;
     }
     return hpad + m.L * lvl_pad + (u - m.uoff[m.L + 1]);   // W
@@ -1835,11 +1864,78 @@ static gf_status fold_level(gf_smp *s, int l) {
               l == 0 ? (const int *)nullptr : d.trow, rows, s->dup_channels, s->cfg.nChanels);
     return GF_OK;
 }
+// ---- the extra products of SMP_2D_ver7 (gf_smp::n_extra) on an OP-BY-OP level: the tables are slices of Q -- slice 0 = tot S_ab, slice 2 =
+// tot S_bc (RisiContraction_18's cases 1 and 5) -- so the products take the row factors (1 / tot, tr / tot)
+__global__ void invert_rowscale(const float2 *__restrict__ rowscale, float2 *__restrict__ inv, long long rows) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float2 v = rowscale[i];
+    inv[i] = make_float2(1.f / v.x, v.y / v.x);   // (tot >= the trace >= 1: a reduced adjacency has a unit diagonal)
+}
+static gf_status extra_rs_inv(gf_smp *s, int l) {
+    const long long rows = s->lay.level[l].rows;
+    if (s->rs_inv_rows < (size_t)rows) {
+        if (s->rs_inv) (void)hipFree(s->rs_inv);
+        s->rs_inv = nullptr;
+        s->rs_inv_rows = 0;
+        GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->rs_inv), sizeof(float) * 2 * (size_t)rows));
+        s->rs_inv_rows = (size_t)rows;
+    }
+    GF_LAUNCH(s->ctx, "smp_extra_rowscale", invert_rowscale, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+              reinterpret_cast<const float2 *>(s->lv[l].rowscale), reinterpret_cast<float2 *>(s->rs_inv), rows);
+    return GF_OK;
+}
+// forward: f_l (before bias and LeakyReLU) += (Q_0 / tot) X_a + (Q_2 / tot) X_b + (tr Q_2 / tot) X_c
+static gf_status extra_products_forward(gf_smp *s, int l) {
+    if (!s->n_extra) return GF_OK;
+    gf_ctx *ctx = s->ctx;
+    if (!s->extra_w) return fail(ctx, GF_ERR_INVALID, "level %d: the extra products' weights are not bound", l);
+    gf_status st = extra_rs_inv(s, l);
+    if (st != GF_OK) return st;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const int C = s->cfg.nChanels, KC = 18 * C, rows = (int)s->lay.level[l].rows;
+    const float *X = s->extra_w + (size_t)(l - 1) * 3 * C * C;
+    st = gemm_rs(ctx, false, false, rows, C, C, d.Q, KC, 0, X, C, 0, d.f, C, 0, 1, 1, s->rs_inv, 2, 0);
+    if (st == GF_OK) st = gemm_rs(ctx, false, false, rows, C, C, d.Q + 2 * C, KC, 0, X + (size_t)C * C, C, 0, d.f, C, 0, 1, 1, s->rs_inv, 2, 0);
+    if (st == GF_OK) st = gemm_rs(ctx, false, false, rows, C, C, d.Q + 2 * C, KC, 0, X + 2 * (size_t)C * C, C, 0, d.f, C, 0, 1, 1, s->rs_inv, 2, 1);
+    return st;
+}
+// backward, first half (Q still holds the forward's slices, d.df = dZ): dX
+static gf_status extra_products_wgrad(gf_smp *s, int l) {
+    if (!s->n_extra) return GF_OK;
+    gf_ctx *ctx = s->ctx;
+    if (!s->extra_w || !s->extra_g) return fail(ctx, GF_ERR_INVALID, "level %d: the extra products' weights are not bound", l);
+    gf_status st = extra_rs_inv(s, l);
+    if (st != GF_OK) return st;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const int C = s->cfg.nChanels, KC = 18 * C, rows = (int)s->lay.level[l].rows;
+    float *dX = s->extra_g + (size_t)(l - 1) * 3 * C * C;
+    st = gemm_rs(ctx, true, false, C, C, rows, d.Q, KC, 0, d.df, C, 0, dX, C, 0, 1, 0, s->rs_inv, 2, 0);
+    if (st == GF_OK) st = gemm_rs(ctx, true, false, C, C, rows, d.Q + 2 * C, KC, 0, d.df, C, 0, dX + (size_t)C * C, C, 0, 1, 0, s->rs_inv, 2, 0);
+    if (st == GF_OK) st = gemm_rs(ctx, true, false, C, C, rows, d.Q + 2 * C, KC, 0, d.df, C, 0, dX + 2 * (size_t)C * C, C, 0, 1, 0, s->rs_inv, 2, 1);
+    return st;
+}
+// ... second half (Q now holds dQ): dQ_0 += (dZ / tot) X_a^T, dQ_2 += (dZ / tot) X_b^T + (tr dZ / tot) X_c^T
+static gf_status extra_products_backward(gf_smp *s, int l) {
+    if (!s->n_extra) return GF_OK;
+    gf_ctx *ctx = s->ctx;
+    const gf_smp::DevLevel &d = s->lv[l];
+    const int C = s->cfg.nChanels, KC = 18 * C, rows = (int)s->lay.level[l].rows;
+    const float *X = s->extra_w + (size_t)(l - 1) * 3 * C * C;
+    gf_status st = gemm_rs(ctx, false, true, rows, C, C, d.df, C, 0, X, C, 0, d.Q, KC, 0, 1, 1, s->rs_inv, 2, 0);
+    if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, d.df, C, 0, X + (size_t)C * C, C, 0, d.Q + 2 * C, KC, 0, 1, 1, s->rs_inv, 2, 0);
+    if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, d.df, C, 0, X + 2 * (size_t)C * C, C, 0, d.Q + 2 * C, KC, 0, 1, 1, s->rs_inv, 2, 1);
+    return st;
+}
 static bool padded_channels(const gf_smp *s) { return s->cfg.nChanels != s->ucfg.nChanels || s->cfg.uniform != s->ucfg.uniform; }
+// floats of the device's parameter / gradient vector (the extra products' blocks behind the padded layout: gf_smp::n_extra)
+static size_t padded_param_count(const gf_smp *s) {
+    return param_count(s->cfg) + (size_t)s->cfg.nLevels * s->n_extra * s->cfg.nChanels * s->cfg.nChanels;
+}
 // the handle's padded copies of the caller's parameters / of the gradients of the running step
 static gf_status pad_buffers(gf_smp *s) {
     if (s->pad_p && s->pad_g) return GF_OK;
-    const size_t n = param_count(s->cfg);
+    const size_t n = padded_param_count(s);
     if (!s->pad_p) GF_HIP_TRY(s->ctx, hipMalloc(reinterpret_cast<void **>(&s->pad_p), n * sizeof(float)));
     if (!s->pad_g && hipMalloc(reinterpret_cast<void **>(&s->pad_g), n * sizeof(float)) != hipSuccess) {
         // (both or neither: a later call must not find pad_p set and skip the gradient buffer)
@@ -1854,7 +1950,7 @@ static gf_status pad_buffers(gf_smp *s) {
 static gf_status pad_params_now(gf_smp *s, const float *params) {
     gf_status st = pad_buffers(s);
     if (st != GF_OK) return st;
-    const long long n = (long long)param_count(s->cfg);
+    const long long n = (long long)padded_param_count(s);
     if (s->dup_channels) {
         const long long nu = (long long)param_count(s->ucfg);
         GF_HIP_TRY(s->ctx, hipMemsetAsync(s->pad_p, 0, (size_t)n * sizeof(float), s->ctx->stream));
@@ -1957,6 +2053,7 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
     const float *H, *W;
     std::vector<const float *> K, b;
     gf::view_params<const float>(s->cfg, params, &H, &K, &b, &W);
+    s->extra_w = s->n_extra ? params + gf::param_count(s->cfg) : nullptr;   // (SMP_2D_ver7 on the 18-slice level: [.. W | X_1 .. X_L])
     // level 0: f_0 = LeakyReLU(X H^T)   (MatMul(H, x_v) per vertex, SMP_omega.h:618)
     const int nV = B.level[0].nNodes;
     st = gf::gemm(ctx, false, true, nV, C, FD, s->x, FD, 0, H, FD, 0, s->lv[0].f, C, 0, 1, 0);
@@ -2000,6 +2097,8 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
         const int KC = s->cfg.nContractions * Cp;
         st = s->cfg.custom_matmul ? gf::gemm(ctx, false, true, (int)h.rows, Cc, KC, d.Q, KC, 0, K[l], KC, 0, d.f, Cc, 0, 1, 0)
                                   : gf::gemm(ctx, false, false, (int)h.rows, Cc, KC, d.Q, KC, 0, K[l], Cc, 0, d.f, Cc, 0, 1, 0);
+        if (st != GF_OK) return st;
+        st = gf::extra_products_forward(s, l);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smp_bias_lrelu", gf::bias_lrelu_forward, dim3(gf::grid_for((size_t)h.rows * Cc)), dim3(256), 0, d.f,
                   b[l], Cc, (size_t)h.rows * Cc);
@@ -2147,6 +2246,8 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
     std::vector<float *> dK, db;
     gf::view_params<float>(s->cfg, grads, &dH, &dK, &db, &dW);
     const size_t np = gf::param_count(s->cfg);
+    s->extra_w = s->n_extra ? params + np : nullptr;
+    s->extra_g = s->n_extra ? grads + np : nullptr;   // (every level writes its own blocks: nothing to clear)
     const bool dp = gf::dist_active(ctx) && s->grad_allreduce && !s->cfg.physics;  // (towers: the composite model reduces its own flat buffer)
     if (dp && accumulate)
         return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: accumulate with a communicator would re-sum earlier global sums "
@@ -2234,6 +2335,8 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
             GF_LAUNCH(ctx, "smp_colsum", gf::colsum_finish, dim3(1), dim3(256), 0, s->colpart, db[l], Cc, nb);
             // dK_l += Q^T dZ   (MatMul::backward second operand), then dQ = dZ K_l^T overwrites Q (first operand)
             const int KC = s->cfg.nContractions * Cq;
+            st = gf::extra_products_wgrad(s, l);
+            if (st != GF_OK) return st;
             if (s->cfg.custom_matmul) {  // CustomMatMulTensor::backward (CustomMatMulTensor.h:70-85): dK_l [C, KC] += dZ^T Q, dQ = dZ K_l
                 st = gf::gemm(ctx, true, false, Cc, KC, (int)h.rows, d.df, Cc, 0, d.Q, KC, 0, dK[l], KC, 0, 1, 1);
                 if (st != GF_OK) return st;
@@ -2243,6 +2346,8 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
                 if (st != GF_OK) return st;
                 st = gf::gemm(ctx, false, true, (int)h.rows, KC, Cc, d.df, Cc, 0, K[l], Cc, 0, d.Q, KC, 0, 1, 0);
             }
+            if (st != GF_OK) return st;
+            st = gf::extra_products_backward(s, l);
             if (st != GF_OK) return st;
             st = gf::smp_dp_level_done(s, l);
             if (st != GF_OK) return st;

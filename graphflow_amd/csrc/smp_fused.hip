@@ -1555,6 +1555,17 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             }
         }
     }
+    if (s->n_extra) {   // SMP_2D_ver7 on the 18-slice level: O_loc += S_ab X_a + S_bc X_b + tr S_bc X_c (gf_smp::n_extra), plain fp32 GEMMs on T
+        if (!s->extra_w) return fail(ctx, GF_ERR_INVALID, "fused level %d: the extra products' weights are not bound", l);
+        st = smp_fused_ensure_zero_fill(s, l);   // (these readers do not mask the absent S_ab blocks)
+        if (st != GF_OK) return st;
+        const float *X = s->extra_w + (size_t)(l - 1) * 3 * CC;
+        const int ldO = ocols * C;
+        st = gemm_rs(ctx, false, false, rows, C, C, T + T_SAB * C, ldt, 0, X, C, 0, O + O_LOC * C, ldO, 0, 1, 1, nullptr, 0, -1);
+        if (st == GF_OK) st = gemm_rs(ctx, false, false, rows, C, C, T + T_SBC * C, ldt, 0, X + CC, C, 0, O + O_LOC * C, ldO, 0, 1, 1, nullptr, 0, -1);
+        if (st == GF_OK) st = gemm_rs(ctx, false, false, rows, C, C, T + T_SBC * C, ldt, 0, X + 2 * CC, C, 0, O + O_LOC * C, ldO, 0, 1, 1, d.rowscale, 2, 1);
+        if (st != GF_OK) return st;
+    }
     if (smp_panel_channels(C) && ocols == 2 && d.fwd_pan && (long long)rows * 512 < 0x3fffffffll)
     {   // wave per row panel, the adjacency product on the matrix pipe; the top level leaves the readout's partial sums behind, the
         // others the per-channel maxima the level above scales its weight-gradient operands with
@@ -1775,6 +1786,23 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
                 if (st != GF_OK) return st;
             }
         }
+    }
+    if (s->n_extra) {   // the extra products of SMP_2D_ver7 (see the forward): dX = T-block^T L, dT-blocks += L X^T
+        if (!s->extra_w || !s->extra_g) return fail(ctx, GF_ERR_INVALID, "fused level %d: the extra products' weights are not bound", l);
+        st = smp_fused_ensure_zero_fill(s, l);
+        if (st != GF_OK) return st;
+        const float *X = s->extra_w + (size_t)(l - 1) * 3 * CC;
+        float *dX = s->extra_g + (size_t)(l - 1) * 3 * CC;
+        const int ldO = ocols * C;
+        const float *Lg = dO + O_LOC * C;
+        st = gemm_rs(ctx, true, false, C, C, rows, T + T_SAB * C, ldt, 0, Lg, ldO, 0, dX, C, 0, 1, 0, nullptr, 0, -1);
+        if (st == GF_OK) st = gemm_rs(ctx, true, false, C, C, rows, T + T_SBC * C, ldt, 0, Lg, ldO, 0, dX + CC, C, 0, 1, 0, nullptr, 0, -1);
+        if (st == GF_OK) st = gemm_rs(ctx, true, false, C, C, rows, T + T_SBC * C, ldt, 0, Lg, ldO, 0, dX + 2 * CC, C, 0, 1, 0, d.rowscale, 2, 1);
+        // (the dS_ab rows of structural zeros were not written by the product kernel: what accumulates there is never read either)
+        if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, Lg, ldO, 0, X, C, 0, dT + T_SAB * C, ldt, 0, 1, 1, nullptr, 0, -1);
+        if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, Lg, ldO, 0, X + CC, C, 0, dT + T_SBC * C, ldt, 0, 1, 1, nullptr, 0, -1);
+        if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, Lg, ldO, 0, X + 2 * CC, C, 0, dT + T_SBC * C, ldt, 0, 1, 1, d.rowscale, 2, 1);
+        if (st != GF_OK) return st;
     }
     if (smp_fused_gather_enabled(s, l)) return GF_OK;  // dP is evaluated inside the consumer gather (smp_fused_gather_backward)
     st = ensure_P(s);

@@ -100,6 +100,15 @@ struct gf_smp {
     // TRANSPOSE (smp.hip: v6_slot), so the device computes an 18-slice model on [f | f^T | 0] channels: channels [C, 2C) of every level's
     // activations hold the transposed matrices (dup_transposed_channels after each level, fold_transposed_channels in the reverse sweep)
     int dup_channels = 0;
+    // ... and SMP_2D_ver7 (RisiContraction_50) likewise: 46 of its 50 slices are slices of RisiContraction_18 on f or f^T; the other four
+    // (cases 25, 41, 42, 45: S_bc tr and the three pair marginals weighted by the adjacency's diagonal, which is 1 in a reduced adjacency)
+    // are n_extra = 3 more C x C products on the level's tables -- (S_ab, 1), (S_bc, 1), (S_bc, tr) -- whose weights X_l sit BEHIND the
+    // padded parameter vector ([.. W | X_1 | .. | X_L], three [Cc][Cc] blocks per level) and run as plain fp32 GEMMs on T
+    int n_extra = 0;
+    const float *extra_w = nullptr;   // X of the running pass (set by gf_smp_forward / gf_smp_backward)
+    float *extra_g = nullptr;         // ... and its gradient
+    float *rs_inv = nullptr;          // [rows of the largest level][2] (1 / tot, tr / tot): the extra products of an op-by-op level
+    size_t rs_inv_rows = 0;
     size_t pad_feat_n = 0;
     gfsmp::BatchLayout lay;
     bool prepared = false, forwarded = false;

@@ -1000,14 +1000,54 @@ def test_smp_2d_ver7_wiring_at_32_channels_runs_the_matrix_pipe_contractions(gf,
         net.close()
         return out
 
+    monkeypatch.setenv("GF_SMP_VER7_FUSED", "0")   # (the op-by-op `_50` level; the default since round 5 is the 18-slice fused level, below)
     a = step()
     monkeypatch.setenv("GF_FAM_FWD_MFMA", "0")
     monkeypatch.setenv("GF_FAM_BWD_MFMA", "0")
     b = step()
     note("ver7_c32_mfma_vs_threads", pred=rel_err(a[0], b[0]), feat=rel_err(a[1], b[1]), grads=rel_err(a[2], b[2]))
     assert np.isfinite(a[2]).all() and np.abs(a[2]).max() > 0
+    assert not np.array_equal(a[2], b[2])   # (the switches switch something)
     assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[1], b[1]) <= TOL_FWD
     assert rel_err(a[2], b[2]) <= TOL_GRAD
+
+
+@pytest.mark.parametrize("C,custom,fused", [(10, False, True), (10, True, False), (6, False, True), (32, True, True), (3, False, False)])
+def test_smp_2d_ver7_on_the_fused_level_equals_the_op_by_op_level(gf, monkeypatch, C, custom, fused):
+    """RisiContraction_50 wiring on the 18-slice level (gf_smp::dup_channels + n_extra: 46 slices as RisiContraction_18 slices on f / f^T, the
+    other four as three extra products on the level's tables), with the fused kernels and with the op-by-op `_18` pipeline under them
+    (fused = False: the extra products on slices of Q), either weight layout, three levels, edge molecules: predictions, features, every
+    gradient against the op-by-op `_50` level, which the goldens pin to the real SMP_2D_ver7 (the embedded path runs those goldens too)."""
+    from graphflow_amd.smp import SMPOmega
+    L, F, D, cap = 3, 5, 2, 9
+    mols, tg = [], []
+    for seed in range(24):
+        adj, feat, t = synthetic_molecule(7300 + seed, nV=1 + seed % 11)
+        mols.append((adj, feat))
+        tg.append(t)
+
+    def step(fz):
+        net = SMPOmega(L, C, F, D, cap, True, nContractions=50, custom_matmul=custom)
+        if not fz:
+            net.set_fused(False)
+        rng = np.random.default_rng(19)
+        params = f32exact(rng.uniform(-1, 1, net.n_params) / np.sqrt(50 * C))
+        net.prepare(mols)
+        p = dev(params)
+        pred, loss, feat = net.forward(p, dev(np.array(tg)))
+        grads = torch.zeros(net.n_params, device="cuda")
+        net.backward(p, grads)
+        return [x.cpu().numpy().astype(np.float64) for x in (pred, feat, grads)] + [net]
+
+    a = step(fused)
+    monkeypatch.setenv("GF_SMP_VER7_FUSED", "0")
+    b = step(True)
+    name = "ver7_on_18_%s_vs_op_by_op_C%d" % ("fused" if fused else "unfused", C)
+    note(name, pred=rel_err(a[0], b[0]), feat=rel_err(a[1], b[1]))
+    assert np.isfinite(a[2]).all() and np.abs(a[2]).max() > 0 and not np.array_equal(a[2], b[2])
+    assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[1], b[1]) <= TOL_FWD
+    assert_grads_agree_kink_aware(name, a[2], b[2], a[3], b[3], mols, L)
+    a[3].close(), b[3].close()
 
 
 def test_smp_2d_ver6_wiring_runs_the_graph_stream_contractions(gf, monkeypatch):
