@@ -1561,8 +1561,8 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         if (st != GF_OK) return st;
         const float *X = s->extra_w + (size_t)(l - 1) * 3 * CC;
         const int ldO = ocols * C;
-        st = gemm_rs(ctx, false, false, rows, C, C, T + T_SAB * C, ldt, 0, X, C, 0, O + O_LOC * C, ldO, 0, 1, 1, nullptr, 0, -1);
-        if (st == GF_OK) st = gemm_rs(ctx, false, false, rows, C, C, T + T_SBC * C, ldt, 0, X + CC, C, 0, O + O_LOC * C, ldO, 0, 1, 1, nullptr, 0, -1);
+        static_assert(T_SBC == T_SAB + 1, "[S_ab | S_bc] [X_a; X_b] as one product of depth 2 C");
+        st = gemm_rs(ctx, false, false, rows, C, 2 * C, T + T_SAB * C, ldt, 0, X, C, 0, O + O_LOC * C, ldO, 0, 1, 1, nullptr, 0, -1);
         if (st == GF_OK) st = gemm_rs(ctx, false, false, rows, C, C, T + T_SBC * C, ldt, 0, X + 2 * CC, C, 0, O + O_LOC * C, ldO, 0, 1, 1, d.rowscale, 2, 1);
         if (st != GF_OK) return st;
     }
@@ -1795,12 +1795,11 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
         float *dX = s->extra_g + (size_t)(l - 1) * 3 * CC;
         const int ldO = ocols * C;
         const float *Lg = dO + O_LOC * C;
-        st = gemm_rs(ctx, true, false, C, C, rows, T + T_SAB * C, ldt, 0, Lg, ldO, 0, dX, C, 0, 1, 0, nullptr, 0, -1);
-        if (st == GF_OK) st = gemm_rs(ctx, true, false, C, C, rows, T + T_SBC * C, ldt, 0, Lg, ldO, 0, dX + CC, C, 0, 1, 0, nullptr, 0, -1);
+        // ([X_a; X_b] is one [2 C][C] matrix and [S_ab | S_bc] one [rows][2 C] operand: two products per direction instead of three)
+        st = gemm_rs(ctx, true, false, 2 * C, C, rows, T + T_SAB * C, ldt, 0, Lg, ldO, 0, dX, C, 0, 1, 0, nullptr, 0, -1);
         if (st == GF_OK) st = gemm_rs(ctx, true, false, C, C, rows, T + T_SBC * C, ldt, 0, Lg, ldO, 0, dX + 2 * CC, C, 0, 1, 0, d.rowscale, 2, 1);
         // (the dS_ab rows of structural zeros were not written by the product kernel: what accumulates there is never read either)
-        if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, Lg, ldO, 0, X, C, 0, dT + T_SAB * C, ldt, 0, 1, 1, nullptr, 0, -1);
-        if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, Lg, ldO, 0, X + CC, C, 0, dT + T_SBC * C, ldt, 0, 1, 1, nullptr, 0, -1);
+        if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, 2 * C, C, Lg, ldO, 0, X, C, 0, dT + T_SAB * C, ldt, 0, 1, 1, nullptr, 0, -1);
         if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, Lg, ldO, 0, X + 2 * CC, C, 0, dT + T_SBC * C, ldt, 0, 1, 1, d.rowscale, 2, 1);
         if (st != GF_OK) return st;
     }
