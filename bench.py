@@ -225,14 +225,18 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
         tg.append(t)
     if world > 1:   # N ranks share the host: each rank's two loader threads get their share of the cores for graph preparation
         os.environ.setdefault("GF_PREP_THREADS", str(max(2, min(32, (os.cpu_count() or 8) // (2 * world)))))
-    net = SMPOmega(L, C, F, D, cap, True, ctx=ctx)
+    nK = getattr(args, "nK", 18)   # (extra lines: the SMP_2D_ver6 / ver7 wirings, RisiContraction_10 / _50 with CustomMatMulTensor weights)
+    net = SMPOmega(L, C, F, D, cap, True, ctx=ctx, nContractions=nK, custom_matmul=(nK != 18))
     t0 = time.perf_counter()
     net.prepare(mols)
     prep_first_s = time.perf_counter() - t0   # includes the one-time device allocations (pooled afterwards)
     t0 = time.perf_counter()
     net.prepare(mols)
     prep_s = time.perf_counter() - t0         # steady state: what a training loop pays per new batch
-    params = torch.as_tensor(smp_params(C, F, D, L, 1).astype(np.float32)).to(dev)
+    if nK == 18:
+        params = torch.as_tensor(smp_params(C, F, D, L, 1).astype(np.float32)).to(dev)
+    else:
+        params = torch.as_tensor((np.random.default_rng(1).uniform(-1, 1, net.n_params) / np.sqrt(nK * C)).astype(np.float32)).to(dev)
     targets = torch.as_tensor(np.array(tg, dtype=np.float32)).to(dev)
     grads = torch.empty(net.n_params, device=dev)
     sizes = [net.level_sizes(l) for l in range(L + 1)]   # (nodes, rows = sum s^2, ppos = sum s^3)
@@ -693,6 +697,21 @@ def main():
                     if k32 is not None:
                         k32[0].close()
                     del s32, k32, c32
+                # ... and the RisiContraction_10 / _50 wirings (SMP_2D_ver6 / ver7) at the reference's 10 channels: since round 5 embedded in
+                # the fused 18-slice level on [f | f^T] channels
+                for name, nK in (("cfg3_ver6_C10", 10), ("cfg3_ver7_C10", 50)):
+                    a7 = copy.copy(args)
+                    a7.C, a7.nK = 10, nK
+                    c7 = gf.Context(dev.index)
+                    s7, _, _, m7, k7 = setup_smp(a7, torch, gf, dev, 1, 0, c7)
+                    els, _ = timed_run(torch, c7, s7, 20, 3, torch.cuda.synchronize, True, repeats=3)
+                    el = median(els)
+                    extra[name] = {"metric": "molecules/sec fwd+bwd, SMP_2D_ver%d wiring (RisiContraction_%d per node)" % (6 if nK == 10 else 7, nK),
+                                   "value": round(m7["units_per_step"] * 20 / el, 1), "unit": m7["unit"], "steps": 20, "warmup": 3,
+                                   "ms_per_step": round(1e3 * el / 20, 4), "workload": m7["config"]["workload"].replace("SMP_omega", "SMP_2D_ver%d" % (6 if nK == 10 else 7))}
+                    if k7 is not None:
+                        k7[0].close()
+                    del s7, k7, c7
             for wl in ("cfg2", "cfg5"):
                 ectx = gf.Context(dev.index)
                 estep, efinish, ecpu, emeta, _ = setup_contraction(wl, args, torch, gf, dev, 1, 0, ectx)
