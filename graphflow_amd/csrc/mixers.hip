@@ -520,7 +520,7 @@ bool gemm_grouped_supported(const GemmSpec *specs, int n, bool ta, bool tb) {
     return true;
 }
 
-gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows) {
+gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows, int accumulate) {
     GroupedArgs ga;
     ga.ngroups = n;
     ga.panel_is_split = 0;
@@ -530,6 +530,7 @@ gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs
     for (int i = 0; i < n; ++i) {
         if (specs[i].M != rows) return fail(ctx, GF_ERR_INVALID, "gemm_grouped_rows: group %d has M=%d, expected %d", i, specs[i].M, rows);
         fill_args(&ga.g[i], specs[i]);
+        ga.g[i].accumulate = accumulate;   // (C += : every element of C belongs to one tile of one group)
         ga.tile_prefix[i] = tiles;
         tiles += (specs[i].N + BN - 1) / BN;
     }

@@ -1562,8 +1562,16 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         const float *X = s->extra_w + (size_t)(l - 1) * 3 * CC;
         const int ldO = ocols * C;
         static_assert(T_SBC == T_SAB + 1, "[S_ab | S_bc] [X_a; X_b] as one product of depth 2 C");
-        st = gemm_rs(ctx, false, false, rows, C, 2 * C, T + T_SAB * C, ldt, 0, X, C, 0, O + O_LOC * C, ldO, 0, 1, 1, nullptr, 0, -1);
-        if (st == GF_OK) st = gemm_rs(ctx, false, false, rows, C, C, T + T_SBC * C, ldt, 0, X + 2 * CC, C, 0, O + O_LOC * C, ldO, 0, 1, 1, d.rowscale, 2, 1);
+        // ONE launch: three K pieces (S_ab X_a, S_bc X_b, tr S_bc X_c), accumulated into O_loc; two launches where the segmented form
+        // does not apply (16 channels: a piece is shorter than the GEMM's k-step)
+        const GemmSpec xs = {T, X, O + O_LOC * C, rows, C, 3 * C, ldt, C, ldO, 3, {(long long)T_SAB * C, (long long)T_SBC * C, (long long)T_SBC * C, 0},
+                             {0, (long long)CC, 2 * (long long)CC, 0}, {C, C, C, 0}, d.rowscale, 2, {-1, -1, 1, -1}};
+        if (gemm_grouped_supported(&xs, 1, false, false)) {
+            st = gemm_grouped_rows(ctx, false, false, &xs, 1, rows, 1);
+        } else {
+            st = gemm_rs(ctx, false, false, rows, C, 2 * C, T + T_SAB * C, ldt, 0, X, C, 0, O + O_LOC * C, ldO, 0, 1, 1, nullptr, 0, -1);
+            if (st == GF_OK) st = gemm_rs(ctx, false, false, rows, C, C, T + T_SBC * C, ldt, 0, X + 2 * CC, C, 0, O + O_LOC * C, ldO, 0, 1, 1, d.rowscale, 2, 1);
+        }
         if (st != GF_OK) return st;
     }
     if (smp_panel_channels(C) && ocols == 2 && d.fwd_pan && (long long)rows * 512 < 0x3fffffffll)
@@ -1796,11 +1804,26 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
         const int ldO = ocols * C;
         const float *Lg = dO + O_LOC * C;
         // ([X_a; X_b] is one [2 C][C] matrix and [S_ab | S_bc] one [rows][2 C] operand: two products per direction instead of three)
-        st = gemm_rs(ctx, true, false, 2 * C, C, rows, T + T_SAB * C, ldt, 0, Lg, ldO, 0, dX, C, 0, 1, 0, nullptr, 0, -1);
-        if (st == GF_OK) st = gemm_rs(ctx, true, false, C, C, rows, T + T_SBC * C, ldt, 0, Lg, ldO, 0, dX + 2 * CC, C, 0, 1, 0, d.rowscale, 2, 1);
-        // (the dS_ab rows of structural zeros were not written by the product kernel: what accumulates there is never read either)
-        if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, 2 * C, C, Lg, ldO, 0, X, C, 0, dT + T_SAB * C, ldt, 0, 1, 1, nullptr, 0, -1);
-        if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, Lg, ldO, 0, X + 2 * CC, C, 0, dT + T_SBC * C, ldt, 0, 1, 1, d.rowscale, 2, 1);
+        const GemmSpec none = {nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}};
+        GemmSpec wg[2] = {none, none};   // d[X_a; X_b] = [S_ab | S_bc]^T L and dX_c = (tr S_bc)^T L: one split launch over the rows, ordered fold
+        wg[0].A = T + T_SAB * C, wg[0].B = Lg, wg[0].M = 2 * C, wg[0].N = C, wg[0].K = rows, wg[0].lda = ldt, wg[0].ldb = ldO, wg[0].ldc = C;
+        wg[1] = wg[0];
+        wg[1].A = T + T_SBC * C, wg[1].M = C, wg[1].rs = d.rowscale, wg[1].rs_ld = 2, wg[1].scol[0] = 1;
+        GemmSpec bg[2] = {none, none};   // dT[S_ab] += L X_a^T; dT[S_bc] += L X_b^T + tr L X_c^T (two K pieces): one launch
+        bg[0].A = Lg, bg[0].B = X, bg[0].C = dT + T_SAB * C, bg[0].M = rows, bg[0].N = C, bg[0].K = C, bg[0].lda = ldO, bg[0].ldb = C, bg[0].ldc = ldt;
+        bg[1] = bg[0];
+        bg[1].C = dT + T_SBC * C, bg[1].K = 2 * C, bg[1].nseg = 2, bg[1].b_off[0] = (long long)CC, bg[1].b_off[1] = 2 * (long long)CC;
+        bg[1].klen[0] = bg[1].klen[1] = C, bg[1].rs = d.rowscale, bg[1].rs_ld = 2, bg[1].scol[0] = -1, bg[1].scol[1] = 1;
+        if (gemm_grouped_supported(wg, 2, true, false) && gemm_grouped_supported(bg, 2, false, true) && C <= 64) {
+            st = gemm_grouped_splitk(ctx, wg, 2, rows, dX, 0);
+            // (the dS_ab rows of structural zeros were not written by the product kernel: what accumulates there is never read either)
+            if (st == GF_OK) st = gemm_grouped_rows(ctx, false, true, bg, 2, rows, 1);
+        } else {
+            st = gemm_rs(ctx, true, false, 2 * C, C, rows, T + T_SAB * C, ldt, 0, Lg, ldO, 0, dX, C, 0, 1, 0, nullptr, 0, -1);
+            if (st == GF_OK) st = gemm_rs(ctx, true, false, C, C, rows, T + T_SBC * C, ldt, 0, Lg, ldO, 0, dX + 2 * CC, C, 0, 1, 0, d.rowscale, 2, 1);
+            if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, 2 * C, C, Lg, ldO, 0, X, C, 0, dT + T_SAB * C, ldt, 0, 1, 1, nullptr, 0, -1);
+            if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, Lg, ldO, 0, X + 2 * CC, C, 0, dT + T_SBC * C, ldt, 0, 1, 1, d.rowscale, 2, 1);
+        }
         if (st != GF_OK) return st;
     }
     if (smp_fused_gather_enabled(s, l)) return GF_OK;  // dP is evaluated inside the consumer gather (smp_fused_gather_backward)

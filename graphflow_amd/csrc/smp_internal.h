@@ -35,7 +35,7 @@ gf_status gemm_grouped_free(gf_ctx *ctx, bool tb, const GemmSpec *specs, int n, 
 gf_status gemm_grouped_free_tn(gf_ctx *ctx, const GemmSpec *specs, int n, float *part, size_t part_floats, FoldGroup *out,
                                const char *name);
 bool gemm_grouped_supported(const GemmSpec *specs, int n, bool ta, bool tb);
-gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows);
+gf_status gemm_grouped_rows(gf_ctx *ctx, bool ta, bool tb, const GemmSpec *specs, int n, int rows, int accumulate = 0);
 gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int rows, float *dest, int accumulate);
 // trow != nullptr: compact O / dO layout ([O_loc | U], 2C wide) with the transposed-row gather inside the product (see kernel)
 // trowf (optional): the level's packed table with the presence bits of the S_ab / T6 blocks (DevLevel::trowf)
