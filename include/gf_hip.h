@@ -226,7 +226,12 @@ typedef struct {
     /* The SMP_2D_ver6 / ver7 / ver8 wirings of the same DAG (GraphFlow/SMP_2D_ver6.h:456-560): contraction family
      * nContractions = 10 / 50 / 18 (0 means 18) and, with custom_matmul = 1, the level weight K_l stored [C][nContractions C]
      * and applied by CustomMatMulTensor instead of Reshape2D + MatMul on [nContractions C][C].  Zero-initialised trailing
-     * fields give SMP_omega.  Those models have no receptive-field cap: pass max_receptive_field = max_nVertices. */
+     * fields give SMP_omega.  Those models have no receptive-field cap: pass max_receptive_field = max_nVertices.
+     * Since round 5 the `_10` and `_50` families (nChanels <= 32) are computed on the fused RisiContraction_18 level: for a symmetric
+     * reduced adjacency with a unit diagonal their slices are slices of `_18` on the activations and on their per-node transposes (plus
+     * three extra products for `_50`); the parameter / gradient layout at this interface stays the caller's.  gf_smp_prepare then refuses
+     * an asymmetric adjacency -- and gf_smp_prepare_coulomb a `_50` model -- with GF_ERR_UNSUPPORTED; GF_SMP_VER6_FUSED=0 /
+     * GF_SMP_VER7_FUSED=0 at create time select the op-by-op `_10` / `_50` levels, which take any adjacency. */
     int nContractions, custom_matmul;
     /* physics = 1: one TOWER of the `_physics` / `_pairgraphs` models (GraphFlow/SMP_omega_physics.h:29-170, :480-606;
      * SMP_omega_pairgraphs.h builds two of them): raw vertex features (nDepth must be 0; no WL histogram or ordering, the
