@@ -1359,6 +1359,12 @@ static bool smp_c64_kernels(const gf_smp *s) {
 // compact projected matrix O = [O_loc | U] (2C) instead of [O_loc | Z | Z'] (3C): the dedicated C = 64 product kernels gather the
 // transposed rows themselves; the tiled launches keep the three-block layout
 bool smp_compact_o(const gf_smp *s) { return smp_c64_kernels(s); }
+// SMP_2D_ver7's extra products inside the row-panel kernels (32 / 16 channels, prebuilt images, no slice dropout); else as GEMMs on T
+static bool smp_extras_in_kernel(const gf_smp *s, int l) {
+    const int C = s->cfg.nChanels;
+    return s->n_extra && (C == 32 || C == 16) && smp_c64_kernels(s) && s->lv[l].wimg_ready && s->lv[l].wimg && !s->drop_on && smp_split_products(s->ctx) &&
+           s->lv[l].trow && !env_is("GF_SMP_EXTRAS_IN_KERNEL", '0');
+}
 gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *dbl);
 
 // every level's block-permuted weight copy in one launch (gf_smp_forward, before the first level)
@@ -1379,16 +1385,17 @@ gf_status smp_fused_stack_all(gf_smp *s, const std::vector<const float *> &K) {
     // ... and the split product kernels' weight images of every level, both directions (the backward pass reuses them)
     for (int l = 1; l <= L; ++l) s->lv[l].wimg_ready = false;
     if (smp_panel_channels(C) && smp_compact_o(s) && smp_split_products(s->ctx)) {
-        std::vector<const float *> w;
+        std::vector<const float *> w, x;
         std::vector<void *> im;
         for (int l = 1; l <= L; ++l)
             if (s->fused && smp_fused_supported(s, l) && s->lv[l].wimg) {
                 w.push_back(s->lv[l].Wst);
+                x.push_back((s->n_extra && s->extra_w) ? s->extra_w + (size_t)(l - 1) * 3 * C * C : nullptr);   // (images 18 .. 20: SMP_2D_ver7's extra products)
                 im.push_back(s->lv[l].wimg);
                 s->lv[l].wimg_ready = true;
             }
         if (!w.empty()) {
-            gf_status st = smp_split_build_images(s->ctx, w.data(), im.data(), (int)w.size(), C);
+            gf_status st = smp_split_build_images(s->ctx, w.data(), im.data(), (int)w.size(), C, x.data());
             if (st != GF_OK) return st;
         }
     }
@@ -1539,7 +1546,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         };
         if (smp_c64_kernels(s)) {
             st = smp_rowpanel_products_c64(ctx, true, T, drop ? d.rowfac8 : d.rowscale, d.Wst, O, rows, d.trow, d.trowf, false,
-                                           d.wimg_ready ? d.wimg : nullptr, C, drop ? 8 : 2);  // weights in LDS
+                                           d.wimg_ready ? d.wimg : nullptr, C, drop ? 8 : 2, smp_extras_in_kernel(s, l) ? 3 : 0);  // weights in LDS
             if (st != GF_OK) return st;
         } else if (gemm_grouped_supported(sp, 3, false, false)) {
             st = gemm_grouped_rows(ctx, false, false, sp, 3, rows);
@@ -1555,7 +1562,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             }
         }
     }
-    if (s->n_extra) {   // SMP_2D_ver7 on the 18-slice level: O_loc += S_ab X_a + S_bc X_b + tr S_bc X_c (gf_smp::n_extra), plain fp32 GEMMs on T
+    if (s->n_extra && !smp_extras_in_kernel(s, l)) {   // SMP_2D_ver7 on the 18-slice level: O_loc += S_ab X_a + S_bc X_b + tr S_bc X_c (gf_smp::n_extra), plain fp32 GEMMs on T
         if (!s->extra_w) return fail(ctx, GF_ERR_INVALID, "fused level %d: the extra products' weights are not bound", l);
         st = smp_fused_ensure_zero_fill(s, l);   // (these readers do not mask the absent S_ab blocks)
         if (st != GF_OK) return st;
@@ -1611,6 +1618,8 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     const int rows = (int)h.rows, pairs = (int)h.pairs, nodes = h.nNodes;
     const int prevNodes = s->lay.level[l - 1].nNodes, prevPairs = (int)s->lay.level[l - 1].pairs;
     float *T = d.Q, *dO = d.Q + (size_t)h.rows * T_COLS * C, *dT = dO + (size_t)h.rows * O_COLS * C;
+    bool x_wgrad_done = false;   // the extra products' weight gradients came out of the level's weight-gradient kernel
+    bool x_bwd_done = false;     // ... and their share of dT out of the backward row-panel kernel
     const size_t CC = (size_t)C * C;
     const int ldt = T_COLS * C, ldo = O_COLS * C;
     const GemmSpec none = {nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, nullptr, 0, {-1, -1, -1, -1}};
@@ -1659,6 +1668,12 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     if (stationary && (C == 32 || C == 16)) {   // smp_wgrad_direct<32 | 16>: one partial image of the eight products per workgroup
         const int splits = smp_wgrad_direct_splits(ctx, rows);
         if ((size_t)splits * 8 * CC > ws_floats) return fail(ctx, GF_ERR_NOMEM, "fused level: workspace too small for %d weight-gradient images", splits);
+        // SMP_2D_ver7 on the 18-slice level: its three extra products ride in the same kernel (their operands are fragments it already
+        // holds); three more images per workgroup behind the eight, folded straight into dX below
+        float *xpart = nullptr;
+        if (s->n_extra && s->extra_g && !drop && smp_wgrad_extra_supported(2) &&
+            (size_t)splits * 8 * CC + ((size_t)splits + (splits + 31) / 32) * 3 * CC <= ws_floats)
+            xpart = ws + (size_t)splits * 8 * CC;
         unsigned *words = s->wbound + (size_t)l * smp_wgrad_direct_words_c32();   // (the same scratch layout at 16 channels)
         const unsigned *chan = nullptr;
         if (d.dzmax && d.row_max) {   // per-channel maxima of f_{l-1} and of this level's dz (combine-backward's per-workgroup maxima)
@@ -1677,8 +1692,13 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
             if (st != GF_OK) return st;
         }
         st = smp_wgrad_partials_direct_c32(ctx, T, dO, drop ? d.rowfac8 : d.rowscale, rows, splits, ws, d.trow, d.trowf, words, chan,
-                                           (float)h.buckets.back().s, d.row_max, drop ? 8 : 2, C);
+                                           (float)h.buckets.back().s, d.row_max, drop ? 8 : 2, C, xpart);
         if (st != GF_OK) return st;
+        if (xpart) {
+            st = splitk_fold(ctx, xpart, s->extra_g + (size_t)(l - 1) * 3 * CC, 3 * CC, splits, 0);
+            if (st != GF_OK) return st;
+            x_wgrad_done = true;
+        }
         rowg.part = ws;
         rowg.splits = splits;
         rowg.n = 8 * CC;
@@ -1769,7 +1789,9 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     if (d.fwd_c64) {
         // (with the consumer gather reading dT, the gradients of the structurally-zero S_ab / T6 rows have no reader: not written)
         st = smp_rowpanel_products_c64(ctx, false, dO, drop ? d.rowfac8 : d.rowscale, d.Wst, dT, rows, ocols == 2 ? d.trow : nullptr, d.trowf,
-                                       smp_fused_gather_enabled(s, l), d.wimg_ready ? d.wimg : nullptr, C, drop ? 8 : 2);
+                                       smp_fused_gather_enabled(s, l), d.wimg_ready ? d.wimg : nullptr, C, drop ? 8 : 2,
+                                       (ocols == 2 && smp_extras_in_kernel(s, l)) ? 3 : 0);
+        x_bwd_done = ocols == 2 && smp_extras_in_kernel(s, l);
         if (st != GF_OK) return st;
     } else {
         const long long oC = C, wCC = (long long)CC;
@@ -1797,8 +1819,10 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     }
     if (s->n_extra) {   // the extra products of SMP_2D_ver7 (see the forward): dX = T-block^T L, dT-blocks += L X^T
         if (!s->extra_w || !s->extra_g) return fail(ctx, GF_ERR_INVALID, "fused level %d: the extra products' weights are not bound", l);
-        st = smp_fused_ensure_zero_fill(s, l);
-        if (st != GF_OK) return st;
+        if (!x_wgrad_done) {   // (the GEMM that reads T does not mask the absent S_ab blocks)
+            st = smp_fused_ensure_zero_fill(s, l);
+            if (st != GF_OK) return st;
+        }
         const float *X = s->extra_w + (size_t)(l - 1) * 3 * CC;
         float *dX = s->extra_g + (size_t)(l - 1) * 3 * CC;
         const int ldO = ocols * C;
@@ -1815,14 +1839,14 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
         bg[1].C = dT + T_SBC * C, bg[1].K = 2 * C, bg[1].nseg = 2, bg[1].b_off[0] = (long long)CC, bg[1].b_off[1] = 2 * (long long)CC;
         bg[1].klen[0] = bg[1].klen[1] = C, bg[1].rs = d.rowscale, bg[1].rs_ld = 2, bg[1].scol[0] = -1, bg[1].scol[1] = 1;
         if (gemm_grouped_supported(wg, 2, true, false) && gemm_grouped_supported(bg, 2, false, true) && C <= 64) {
-            st = gemm_grouped_splitk(ctx, wg, 2, rows, dX, 0);
+            st = x_wgrad_done ? GF_OK : gemm_grouped_splitk(ctx, wg, 2, rows, dX, 0);
             // (the dS_ab rows of structural zeros were not written by the product kernel: what accumulates there is never read either)
-            if (st == GF_OK) st = gemm_grouped_rows(ctx, false, true, bg, 2, rows, 1);
+            if (st == GF_OK && !x_bwd_done) st = gemm_grouped_rows(ctx, false, true, bg, 2, rows, 1);
         } else {
-            st = gemm_rs(ctx, true, false, 2 * C, C, rows, T + T_SAB * C, ldt, 0, Lg, ldO, 0, dX, C, 0, 1, 0, nullptr, 0, -1);
-            if (st == GF_OK) st = gemm_rs(ctx, true, false, C, C, rows, T + T_SBC * C, ldt, 0, Lg, ldO, 0, dX + 2 * CC, C, 0, 1, 0, d.rowscale, 2, 1);
-            if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, 2 * C, C, Lg, ldO, 0, X, C, 0, dT + T_SAB * C, ldt, 0, 1, 1, nullptr, 0, -1);
-            if (st == GF_OK) st = gemm_rs(ctx, false, true, rows, C, C, Lg, ldO, 0, X + 2 * CC, C, 0, dT + T_SBC * C, ldt, 0, 1, 1, d.rowscale, 2, 1);
+            st = x_wgrad_done ? GF_OK : gemm_rs(ctx, true, false, 2 * C, C, rows, T + T_SAB * C, ldt, 0, Lg, ldO, 0, dX, C, 0, 1, 0, nullptr, 0, -1);
+            if (st == GF_OK && !x_wgrad_done) st = gemm_rs(ctx, true, false, C, C, rows, T + T_SBC * C, ldt, 0, Lg, ldO, 0, dX + 2 * CC, C, 0, 1, 0, d.rowscale, 2, 1);
+            if (st == GF_OK && !x_bwd_done) st = gemm_rs(ctx, false, true, rows, 2 * C, C, Lg, ldO, 0, X, C, 0, dT + T_SAB * C, ldt, 0, 1, 1, nullptr, 0, -1);
+            if (st == GF_OK && !x_bwd_done) st = gemm_rs(ctx, false, true, rows, C, C, Lg, ldO, 0, X + 2 * CC, C, 0, dT + T_SBC * C, ldt, 0, 1, 1, d.rowscale, 2, 1);
         }
         if (st != GF_OK) return st;
     }

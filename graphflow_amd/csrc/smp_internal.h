@@ -42,19 +42,21 @@ gf_status gemm_grouped_splitk(gf_ctx *ctx, const GemmSpec *specs, int n, int row
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
                                     int rows, const int *trow, const int *trowf = nullptr, bool skip_zero_grads = false,
                                     const void *wimg = nullptr, int C = 64,   // C = 32 (round 4): split products with prebuilt images only
-                                    int nf = 2);   // row factors per row of `rowscale`: 2 = (tot, tr); 8 = one per product (slice dropout, C = 32)
+                                    int nf = 2, int nx = 0);   // row factors per row of `rowscale`: 2 = (tot, tr); 8 = one per product (slice dropout, C = 32)
 // the compact-layout products on the f16 matrix pipe with two-half fp32 operands (smp_level_c64_split.hip; GF_SMP_SPLIT=0: fp32 MFMA)
 bool smp_split_products(const gf_ctx *ctx);
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
                                  int rows, const int *trow, int cus, const int *trowf = nullptr, bool skip_zero_grads = false,
-                                 const void *wimg = nullptr, int C = 64, int nf = 2);
+                                 const void *wimg = nullptr, int C = 64, int nf = 2, int nx = 0);
 // the split kernels' weight images of a level (both directions), built once per forward pass (smp_level_c64_split.hip)
 size_t smp_split_image_bytes();
-gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n, int C = 64);
+gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n, int C = 64, const float *const *X = nullptr);
 // weight gradients of a fused level at C = 32 (smp_wgrad_direct<32>): partial images of 8 x 32 x 32 floats per workgroup
 gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int splits, float *part,
                                         const int *trow, const int *trowf, unsigned *words, const unsigned *chan = nullptr, float smax = 0.f,
-                                        const unsigned *row_max = nullptr, int nf = 2, int C = 32);   // C = 32 or (round 5) 16
+                                        const unsigned *row_max = nullptr, int nf = 2, int C = 32, float *xpart = nullptr);
+// C = 32 or (round 5) 16
+bool smp_wgrad_extra_supported(int nf);
 gf_status smp_wgrad_channel_maxima_ld(gf_ctx *ctx, const float *fprev, long long prev_rows, int ld0, const float *dsrc, long long drows, int ld1, int C,
                                       unsigned *words);
 size_t smp_wgrad_direct_words_c32();

@@ -455,7 +455,7 @@ gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, c
 // Row-panel products of a fused SMP level at C = 64 (see smp_rowpanel_c64): forward O from T, or backward dT from dO.
 // Every output element is produced by one wave in a fixed order: results do not depend on the grid size.
 gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                    int rows, const int *trow, const int *trowf, bool skip_zero_grads, const void *wimg, int C, int nf) {
+                                    int rows, const int *trow, const int *trowf, bool skip_zero_grads, const void *wimg, int C, int nf, int nx) {
     if (rows < 1) return GF_OK;
     static int cu_count[64] = {};
     const int di = ctx->device & 63;
@@ -464,8 +464,8 @@ gf_status smp_rowpanel_products_c64(gf_ctx *ctx, bool forward, const float *A, c
         if (cu_count[di] < 1) cu_count[di] = 256;
     }
     const int cus = cu_count[di];
-    if (trow && smp_split_products(ctx)) return smp_rowpanel_split_c64(ctx, forward, A, rowscale, Wst, Out, rows, trow, cus, trowf, skip_zero_grads, wimg, C, nf);
-    if (C != 64 || nf != 2) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_products: %d channels / %d row factors on the fp32 matrix pipe", C, nf);
+    if (trow && smp_split_products(ctx)) return smp_rowpanel_split_c64(ctx, forward, A, rowscale, Wst, Out, rows, trow, cus, trowf, skip_zero_grads, wimg, C, nf, nx);
+    if (C != 64 || nf != 2 || nx != 0) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_products: %d channels / %d row factors / %d extra products on the fp32 matrix pipe", C, nf, nx);
     const size_t lds = sizeof(float) * 8 * 2 * 2 * 32 * (size_t)kRpWRow;
     // forward: four waves per SIMD (measured equal to two); backward: two waves per SIMD with 256 registers -- the 128-register
     // build of the backward panel spills 100 B per lane and waits for one block request per panel (1.84 -> 1.66 ms at cfg3).

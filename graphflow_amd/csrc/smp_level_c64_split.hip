@@ -130,17 +130,20 @@ __device__ __forceinline__ void build_weight_images(const float *__restrict__ Ws
 // imgH [kSpAll] | imgL [kSpAll] | winv (kSpPos floats in five uint4) -- ALL eighteen stacked blocks: positions 0..7 are the row products'
 // (smp_rowpanel_split), 8..17 the per-(node,x) / per-node / compact products' (smp_small_split)
 constexpr int kSpImgLevels = 8;
-constexpr int kSpPos = 18, kSpAll = kSpPos * 512;
-constexpr int kSpImgStride = 2 * kSpAll + 5;   // uint4 per (level, direction)
+// (positions 18, 19, 20: the three extra products of SMP_2D_ver7 on the 18-slice level -- gf_smp::n_extra -- from their own weight blocks X)
+constexpr int kSpPos = 21, kSpStacked = 18, kSpAll = kSpPos * 512;
+constexpr int kSpImgStride = 2 * kSpAll + 6;   // uint4 per (level, direction): images, then kSpPos inverse scales in six uint4
 struct SplitImages {
     const float *Wst[kSpImgLevels];
+    const float *X[kSpImgLevels];   // or null: no extra products
     uint4 *img[kSpImgLevels];   // [2 directions][kSpImgStride]
 };
 __global__ __launch_bounds__(kSpThreads) void smp_split_weight_images(SplitImages a, int C) {  // workgroup (direction, level, position)
     __shared__ unsigned wmax[1];
     uint4 *out = a.img[blockIdx.y] + (size_t)blockIdx.x * kSpImgStride;
     float *winv = reinterpret_cast<float *>(out + 2 * kSpAll) + blockIdx.z;
-    const float *w = a.Wst[blockIdx.y] + (size_t)blockIdx.z * C * C;
+    if (blockIdx.z >= kSpStacked && !a.X[blockIdx.y]) return;   // (uniform)
+    const float *w = blockIdx.z < kSpStacked ? a.Wst[blockIdx.y] + (size_t)blockIdx.z * C * C : a.X[blockIdx.y] + (size_t)(blockIdx.z - kSpStacked) * C * C;
     uint4 *H = out + blockIdx.z * 512, *L = out + kSpAll + blockIdx.z * 512;
     if (C == 64) {
         if (blockIdx.x == 0)
@@ -166,7 +169,9 @@ __global__ __launch_bounds__(kSpThreads) void smp_split_weight_images(SplitImage
 #ifndef GF_SP_WHOLE_PANEL
 #define GF_SP_WHOLE_PANEL 16   // (32: products-forward 0.36 -> 0.39 ms at C = 32)
 #endif
-template <bool FWD, bool MASK, int CB = 64, int NF = 2>
+// NX = 3 (CB <= 32, NF = 2): the extra products of SMP_2D_ver7 on the 18-slice level ride on the panel's fragments -- forward O_loc +=
+// S_ab X_a + S_bc X_b + tr S_bc X_c, backward dS_ab += L X_a^T, dS_bc += L X_b^T + tr L X_c^T -- with the images of positions 18 .. 20
+template <bool FWD, bool MASK, int CB = 64, int NF = 2, int NX = 0>
 __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float *__restrict__ A, const float *__restrict__ rs,
                                                                      const float *__restrict__ Wst, float *__restrict__ Out, int rows,
                                                                      const int *__restrict__ trow, int store_mask,
@@ -180,22 +185,25 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
     auto t_own = [](int t) { return MASK ? t < 0 : true; };
     auto t_tr = [](int t) { return MASK ? ((t >> 30) & 1) != 0 : true; };
     auto t_bc = [](int t) { return MASK ? ((t >> 29) & 1) != 0 : true; };   // the row's S_bc / T10 blocks hold data
+    static_assert(NX == 0 || (NX == 3 && CB <= 32 && NF == 2), "the extra products: prebuilt images, plain row factors");
+    constexpr int NP = 8 + NX;   // weight images in LDS
     extern __shared__ __attribute__((aligned(16))) uint4 sp_smem[];
-    uint4 *imgH = sp_smem, *imgL = sp_smem + 8 * E;
-    float *winv = reinterpret_cast<float *>(sp_smem + 2 * 8 * E);  // [8] 2^-k of the weight blocks
-    unsigned *wmax = reinterpret_cast<unsigned *>(winv + 8);        // [8]
-    float *facs = winv + 16;                                        // [waves][32]: row factors on their way to the C layout
+    uint4 *imgH = sp_smem, *imgL = sp_smem + NP * E;
+    float *winv = reinterpret_cast<float *>(sp_smem + 2 * NP * E);  // [NP] 2^-k of the weight blocks (padded to 16 floats)
+    unsigned *wmax = reinterpret_cast<unsigned *>(winv + 16);       // [8]
+    float *facs = winv + 32;                                        // [waves][32]: row factors on their way to the C layout
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = tid >> 6;
 
     // ---- weight images (see build_weight_images): copied from the pass's prebuilt ones, or built here
     if (wimg) {
-        for (int t = tid; t < 8 * E; t += kSpThreads) {   // (512 entries apart per position in the prebuilt set, whatever CB is)
-            const int g = (t / E) * 512 + t % E;
+        for (int t = tid; t < NP * E; t += kSpThreads) {   // (512 entries apart per position in the prebuilt set, whatever CB is)
+            const int pos = t / E, g = (pos < 8 ? pos : kSpStacked + pos - 8) * 512 + t % E;
             imgH[t] = wimg[g];
             imgL[t] = wimg[kSpAll + g];
         }
         if (tid < 2) reinterpret_cast<uint4 *>(winv)[tid] = wimg[2 * kSpAll + tid];
+        if (NX > 0 && tid < NX) winv[8 + tid] = reinterpret_cast<const float *>(wimg + 2 * kSpAll)[kSpStacked + tid];
     } else {
         static_assert(E == 512 || true, "");
         if constexpr (CB == 64) build_weight_images<FWD, 8>(Wst, imgH, imgL, winv, wmax, tid);   // (other channel counts: prebuilt images only)
@@ -400,6 +408,11 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             prod(X, iX * sc.f[0], 0, acc0, acc1);
             prod(X, iX * sc.f[2], 2, acc0, acc1);
             prod(Y, iY * sc.f[1], 1, acc0, acc1);
+            if constexpr (NX == 3) {
+                prod(X, iX, 8, acc0, acc1);
+                prod(Y, iY, 9, acc0, acc1);
+                prod(Y, iY * sc.f[2], 10, acc0, acc1);
+            }
             load_raw(Ra, p, 3, t_bc(tcur));          // T10, once X and Y are dead: with two requests beside them the panel spills,
                                                      // and a scratch reload waits for the whole memory queue
             split_blk(Rb, Z, iZ);
@@ -426,6 +439,10 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             clear(acc0, acc1);
             prod(X, iX * sc.f[1], 1, acc0, acc1);
             prod(Y, iY * sc.f[6], 6, acc0, acc1);
+            if constexpr (NX == 3) {
+                prod(X, iX, 9, acc0, acc1);
+                prod(X, iX * sc.f[2], 10, acc0, acc1);
+            }
             store_out(p, 1, acc0, acc1, full);
             // dU at the transposed rows: it only feeds dS_ab of this row, which is not stored where the row has no data.  (Requested
             // here, six products ahead of its use, not at the top of the panel: with the cross-product chain of round 4 the block's
@@ -437,6 +454,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
             prod(X, iX * sc.f[0], 0, acc0, acc1);
             prod(X, iX * sc.f[2], 2, acc0, acc1);
             prod(Y, iY * sc.f[5], 5, acc0, acc1);
+            if constexpr (NX == 3) prod(X, iX, 8, acc0, acc1);
             split_blk(Ra, Z, iZ);
             load_raw(Ra, pn, 0, !(MASK && store_mask) || t_bc(tnext));   // L of the next panel
             prod(Z, iZ * sc.f[7], 7, acc0, acc1);
@@ -488,6 +506,11 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
                 prod(S[0], iv[0] * sc.f[0], 0, acc0, acc1);
                 prod(S[0], iv[0] * sc.f[2], 2, acc0, acc1);
                 prod(S[2], iv[2] * sc.f[1], 1, acc0, acc1);
+                if constexpr (NX == 3) {
+                    prod(S[0], iv[0], 8, acc0, acc1);
+                    prod(S[2], iv[2], 9, acc0, acc1);
+                    prod(S[2], iv[2] * sc.f[2], 10, acc0, acc1);
+                }
                 prod(S[3], iv[3] * sc.f[3], 3, acc0, acc1);
                 prod(S[4], iv[4] * sc.f[4], 4, acc0, acc1);
                 store_out(q, 0, acc0, acc1, full);
@@ -502,10 +525,15 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
                 clear(acc0, acc1);
                 prod(S[0], iv[0] * sc.f[1], 1, acc0, acc1);
                 prod(S[1], iv[1] * sc.f[6], 6, acc0, acc1);
+                if constexpr (NX == 3) {
+                    prod(S[0], iv[0], 9, acc0, acc1);
+                    prod(S[0], iv[0] * sc.f[2], 10, acc0, acc1);
+                }
                 store_out(q, 1, acc0, acc1, full);
                 clear(acc0, acc1);
                 prod(S[0], iv[0] * sc.f[0], 0, acc0, acc1);
                 prod(S[0], iv[0] * sc.f[2], 2, acc0, acc1);
+                if constexpr (NX == 3) prod(S[0], iv[0], 8, acc0, acc1);
                 prod(S[1], iv[1] * sc.f[5], 5, acc0, acc1);
                 prod(S[2], iv[2] * sc.f[7], 7, acc0, acc1);
                 store_out(q, 0, acc0, acc1, full, rowbits);
@@ -1208,19 +1236,23 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
 // contract (one set of eight per workgroup, folded by smp_fold_level) is unchanged and the result does not depend on timing.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kW8Threads = 256;
-template <int CB, int NF>
+// NX = 3 (SMP_2D_ver7 on the 18-slice level, gf_smp::n_extra): three more products on operands the slice already holds as fragments --
+// S_ab^T L, S_bc^T L, S_bc^T (tr L) -- whose images go to `xpart` (three per workgroup), folded by the caller into dX.
+template <int CB, int NF, int NX = 0>
 __global__ __launch_bounds__(kW8Threads, 1) void smp_wgrad_all(const float *__restrict__ T, const float *__restrict__ dO,
                                                                 const float *__restrict__ rs, int rows, float *__restrict__ part,
                                                                 const int *__restrict__ trow, const unsigned *__restrict__ cmax,
                                                                 const unsigned *__restrict__ chan, float smax,
-                                                                const unsigned *__restrict__ row_max, int packed) {
+                                                                const unsigned *__restrict__ row_max, int packed, float *__restrict__ xpart = nullptr) {
     static_assert(CB == 32 || CB == 16, "one 32 x 32 tile per product");
+    static_assert(NX == 0 || (NX == 3 && NF == 2), "the extra products take the plain (tot, tr) row factors");
+    constexpr int NP = 8 + NX;
     constexpr int ACOLS = 4 * CB, BCOLS = 5 * CB;
     constexpr int SL = CB == 16 ? 2 * kWsSlice : kWsSlice;   // rows of a slice (CB = 16: two half-slices per tile, see smp_wgrad_direct)
     constexpr int TROW = 16 * CB, DROW = 8 * CB;             // bytes of a row of T, of dO
     constexpr int NBF = NF == 8 ? 8 : 5;                     // B fragments per slice
     __shared__ float sScale[ACOLS + BCOLS], sInv[ACOLS + BCOLS];
-    __shared__ float sImg[8 * CB * CB];
+    __shared__ float sImg[NP * CB * CB];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = (CB == 16 && li >= 16) ? 1 : 0;
@@ -1314,9 +1346,9 @@ __global__ __launch_bounds__(kW8Threads, 1) void smp_wgrad_all(const float *__re
             R.g[j] = ld1(rD, vg, 0);
         }
     };
-    f16v acc[8];
+    f16v acc[NP];
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
     auto frag = [&](const float (&v)[8], float sc, const Fac *F, int col, h8 *H, h8 *L) {
@@ -1332,7 +1364,8 @@ __global__ __launch_bounds__(kW8Threads, 1) void smp_wgrad_all(const float *__re
         *L = __builtin_bit_cast(h8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
     };
     // products 0..7: A block c_ws_ablk, B operand c_ws_bblk (0 L, 1 tot L, 2 tr L, 3 dU, 4 dU[trow]) -- compile-time copies
-    constexpr int kA[8] = {0, 1, 0, 2, 3, 0, 1, 0}, kB[8] = {1, 1, 2, 0, 0, 3, 3, 4};
+    // (extra products 8, 9, 10: S_ab with L, S_bc with L, S_bc with tr L)
+    constexpr int kA[11] = {0, 1, 0, 2, 3, 0, 1, 0, 0, 1, 1}, kB[11] = {1, 1, 2, 0, 0, 3, 3, 4, 0, 0, 2};
     const long long first = (long long)blockIdx.x + (long long)wave * gridDim.x;
     if (first < nsl) {
         const int mine = (int)((nsl - first + 4ll * gridDim.x - 1) / (4ll * gridDim.x));   // slices of this wave
@@ -1378,12 +1411,17 @@ __global__ __launch_bounds__(kW8Threads, 1) void smp_wgrad_all(const float *__re
             mfma3(2, ah, al, bh[bsel(2)], bl[bsel(2)]);
             mfma3(5, ah, al, bh[bsel(5)], bl[bsel(5)]);
             mfma3(7, ah, al, bh[bsel(7)], bl[bsel(7)]);
+            if constexpr (NX == 3) mfma3(8, ah, al, bh[0], bl[0]);
             h8 ch, cl;
             frag(R.a[1], sa[1], nullptr, 0, &ch, &cl);   // S_bc: products 1, 6
             asm volatile("" : "+v"(ch), "+v"(cl));
             __builtin_amdgcn_sched_barrier(0);
             mfma3(1, ch, cl, bh[bsel(1)], bl[bsel(1)]);
             mfma3(6, ch, cl, bh[bsel(6)], bl[bsel(6)]);
+            if constexpr (NX == 3) {
+                mfma3(9, ch, cl, bh[0], bl[0]);
+                mfma3(10, ch, cl, bh[2], bl[2]);
+            }
             h8 dh, dl, eh, el;
             frag(R.a[2], sa[2], nullptr, 0, &dh, &dl);   // T6: product 3
             frag(R.a[3], sa[3], nullptr, 0, &eh, &el);   // T10: product 4
@@ -1406,7 +1444,7 @@ __global__ __launch_bounds__(kW8Threads, 1) void smp_wgrad_all(const float *__re
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const float *ia = sInv + kA[p] * CB, ub = sInv[ACOLS + kB[p] * CB + lc];
                 float *img = sImg + p * CB * CB + lc;
                 if constexpr (CB == 16) {
@@ -1432,6 +1470,11 @@ __global__ __launch_bounds__(kW8Threads, 1) void smp_wgrad_all(const float *__re
     float *out = part + (size_t)blockIdx.x * 8 * (CB * CB);
     for (int i = tid; i < 8 * CB * CB / 4; i += kW8Threads)
         *reinterpret_cast<f4v *>(out + 4 * i) = *reinterpret_cast<const f4v *>(sImg + 4 * i);
+    if constexpr (NX > 0) {
+        float *xo = xpart + (size_t)blockIdx.x * NX * (CB * CB);
+        for (int i = tid; i < NX * CB * CB / 4; i += kW8Threads)
+            *reinterpret_cast<f4v *>(xo + 4 * i) = *reinterpret_cast<const f4v *>(sImg + 8 * CB * CB + 4 * i);
+    }
 }
 
 // exact column bounds of the nine operand blocks of smp_wgrad_direct<CB> from the column maxima of T [rows][4 CB] (mt) and of
@@ -1596,12 +1639,13 @@ gf_status smp_small_split_c64(gf_ctx *ctx, bool transposed, int n, const int *pr
 }
 
 // the split weight images (both directions) of n levels' stacked weights in one launch; img[i]: smp_split_image_bytes() each
-gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n, int C) {
+gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *const *img, int n, int C, const float *const *X) {
     for (int i0 = 0; i0 < n; i0 += kSpImgLevels) {
         SplitImages a;
         const int m = n - i0 < kSpImgLevels ? n - i0 : kSpImgLevels;
         for (int i = 0; i < m; ++i) {
             a.Wst[i] = Wst[i0 + i];
+            a.X[i] = X ? X[i0 + i] : nullptr;
             a.img[i] = static_cast<uint4 *>(img[i0 + i]);
         }
         GF_LAUNCH(ctx, "smpf_stack_w", smp_split_weight_images, dim3(2, m, kSpPos), dim3(kSpThreads), 0, a, C);
@@ -1613,7 +1657,7 @@ gf_status smp_split_build_images(gf_ctx *ctx, const float *const *Wst, void *con
 // level): forward O from T = [S_ab|S_bc|T6|T10], or backward dT from dO.  Every output element is produced by one wave in a
 // fixed order: results do not depend on the grid size.
 gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, const float *rowscale, const float *Wst, float *Out,
-                                 int rows, const int *trow, int cus, const int *trowf, bool skip_zero_grads, const void *wimg, int C, int nf) {
+                                 int rows, const int *trow, int cus, const int *trowf, bool skip_zero_grads, const void *wimg, int C, int nf, int nx) {
     const int per = kSpThreads / 64;
     const int npanels = (rows + 31) / 32;
     const int want = (npanels + per - 1) / per;
@@ -1623,16 +1667,39 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
     if (C != 64 && !wimg) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d channels need the level's prebuilt weight images", C);
     // packed table with the presence bits (see the kernel)
     const bool mask = trowf && rows < (1 << 29) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
-#define GF_SP_LAUNCH_NF(F, M, CBv, NFv, name)                                                                                      \
+#define GF_SP_LAUNCH_NX(F, M, CBv, NFv, NXv, name)                                                                                 \
     do {                                                                                                                           \
-        const size_t lds__ = 2 * (size_t)8 * (CBv >= 32 ? CBv / 32 : 1) * (CBv / 16) * 64 * 16 + 16 * sizeof(float) + (kSpThreads / 64) * 32 * sizeof(float); \
-        gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M, CBv, NFv>, lds__);                                                 \
+        const size_t lds__ = 2 * (size_t)(8 + NXv) * (CBv >= 32 ? CBv / 32 : 1) * (CBv / 16) * 64 * 16 + 32 * sizeof(float) + (kSpThreads / 64) * 32 * sizeof(float); \
+        gf_status st = opt_in_lds(ctx, smp_rowpanel_split<F, M, CBv, NFv, NXv>, lds__);                                            \
         if (st != GF_OK) return st;                                                                                                \
-        GF_LAUNCH(ctx, name, (smp_rowpanel_split<F, M, CBv, NFv>), dim3((unsigned)grid), dim3(kSpThreads), lds__, A, rowscale, Wst, Out, rows, \
+        GF_LAUNCH(ctx, name, (smp_rowpanel_split<F, M, CBv, NFv, NXv>), dim3((unsigned)grid), dim3(kSpThreads), lds__, A, rowscale, Wst, Out, rows, \
                   M ? trowf : trow, skip_zero_grads ? 1 : 0,                                                                       \
                   wimg ? static_cast<const uint4 *>(wimg) + (F ? 0 : kSpImgStride) : (const uint4 *)nullptr);                      \
     } while (0)
+#define GF_SP_LAUNCH_NF(F, M, CBv, NFv, name) GF_SP_LAUNCH_NX(F, M, CBv, NFv, 0, name)
 #define GF_SP_LAUNCH(F, M, CBv, name) GF_SP_LAUNCH_NF(F, M, CBv, 2, name)
+    if (nx != 0) {   // the extra products of SMP_2D_ver7 on the 18-slice level (see the kernel)
+        if (nx != 3 || nf != 2 || !(C == 32 || C == 16) || !wimg)
+            return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d extra products at %d channels / %d row factors", nx, C, nf);
+        if (C == 32) {
+            if (forward) {
+                if (mask) GF_SP_LAUNCH_NX(true, true, 32, 2, 3, "smpf_products_fwd");
+                else GF_SP_LAUNCH_NX(true, false, 32, 2, 3, "smpf_products_fwd");
+            } else {
+                if (mask) GF_SP_LAUNCH_NX(false, true, 32, 2, 3, "smpf_products_bwd");
+                else GF_SP_LAUNCH_NX(false, false, 32, 2, 3, "smpf_products_bwd");
+            }
+        } else {
+            if (forward) {
+                if (mask) GF_SP_LAUNCH_NX(true, true, 16, 2, 3, "smpf_products_fwd");
+                else GF_SP_LAUNCH_NX(true, false, 16, 2, 3, "smpf_products_fwd");
+            } else {
+                if (mask) GF_SP_LAUNCH_NX(false, true, 16, 2, 3, "smpf_products_bwd");
+                else GF_SP_LAUNCH_NX(false, false, 16, 2, 3, "smpf_products_bwd");
+            }
+        }
+        return GF_OK;
+    }
     if (nf != 2 && !(nf == 8 && (C == 32 || C == 16))) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_rowpanel_split: %d row factors at %d channels", nf, C);
     if (nf == 8 && C == 32) {   // (per-product row factors: the slice-dropout towers, computed at 32 or 16 channels)
         if (forward) {
@@ -1679,6 +1746,7 @@ gf_status smp_rowpanel_split_c64(gf_ctx *ctx, bool forward, const float *A, cons
     }
 #undef GF_SP_LAUNCH
 #undef GF_SP_LAUNCH_NF
+#undef GF_SP_LAUNCH_NX
     return GF_OK;
 }
 
@@ -1703,8 +1771,15 @@ gf_status smp_wgrad_partials_split_c64(gf_ctx *ctx, const float *T, const float 
 // GF_SMP_WGRAD_ALL=0 selects smp_wgrad_direct (a wave per product)
 template <int CB>
 static gf_status launch_wgrad_direct(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int splits, float *part,
-                                     const int *tr, const unsigned *cmax, const unsigned *chan, float smax, const unsigned *row_max, int packed, int nf) {
+                                     const int *tr, const unsigned *cmax, const unsigned *chan, float smax, const unsigned *row_max, int packed, int nf,
+                                     float *xpart = nullptr) {
     const char *e = std::getenv("GF_SMP_WGRAD_ALL");
+    if (xpart) {   // with the three extra products of SMP_2D_ver7 (callers check smp_wgrad_extra_supported first)
+        if (nf != 2 || (e && e[0] == '0')) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_wgrad_all: extra products with %d row factors / GF_SMP_WGRAD_ALL=0", nf);
+        GF_LAUNCH(ctx, "smpf_wgrad", (smp_wgrad_all<CB, 2, 3>), dim3((unsigned)splits), dim3(kW8Threads), 0, T, dO, rowscale, rows, part, tr, cmax, chan, smax,
+                  row_max, packed, xpart);
+        return GF_OK;
+    }
     if (e && e[0] == '0') {
         GF_LAUNCH(ctx, "smpf_wgrad", smp_wgrad_direct<CB>, dim3((unsigned)splits), dim3(kWdThreads), 0, T, dO, rowscale, rows, part, tr, cmax, chan, smax,
                   row_max, packed, nf);
@@ -1717,13 +1792,17 @@ static gf_status launch_wgrad_direct(gf_ctx *ctx, const float *T, const float *d
     }
     return GF_OK;
 }
+bool smp_wgrad_extra_supported(int nf) {
+    const char *e = std::getenv("GF_SMP_WGRAD_ALL");
+    return nf == 2 && !(e && e[0] == '0');
+}
 gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float *dO, const float *rowscale, int rows, int splits, float *part,
                                         const int *trow, const int *trowf, unsigned *words, const unsigned *chan, float smax,
-                                        const unsigned *row_max, int nf, int C) {
+                                        const unsigned *row_max, int nf, int C, float *xpart) {
     const bool mask = trowf && rows < (1 << 28) && !(std::getenv("GF_SMP_MASK_ZEROS") && std::getenv("GF_SMP_MASK_ZEROS")[0] == '0');
     if (C == 16) {   // (round 5)
         if (chan && row_max) {
-            if (gf_status st_ = launch_wgrad_direct<16>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf); st_ != GF_OK) return st_;
+            if (gf_status st_ = launch_wgrad_direct<16>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf, xpart); st_ != GF_OK) return st_;
             return GF_OK;
         }
         // host-built level tables: exact column bounds from the operands themselves -- T [rows][64] and dO [rows][32] are one
@@ -1736,13 +1815,13 @@ gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float
         GF_LAUNCH(ctx, "smpf_colmax", level_channel_maxima_ld, dim3(g, 1), dim3(256), 0, dO, (long long)rows, 32, (const float *)nullptr, 0ll, 0, 32, words + 256);
         GF_LAUNCH(ctx, "smpf_colmax", rowscale_absmax, dim3(64), dim3(256), 0, rowscale, rows, words + 384);
         GF_LAUNCH(ctx, "smpf_colmax", wgrad_bounds_exact_cb, dim3(1), dim3(64), 0, words, words + 256, words + 384, words + 512, 16);
-        if (gf_status st_ = launch_wgrad_direct<16>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0, nf); st_ != GF_OK) return st_;
+        if (gf_status st_ = launch_wgrad_direct<16>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0, nf, xpart); st_ != GF_OK) return st_;
         return GF_OK;
     }
     if (C != 32) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_wgrad_direct: %d channels", C);
     constexpr int CB = 32;
     if (chan && row_max) {
-        if (gf_status st_ = launch_wgrad_direct<CB>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf); st_ != GF_OK) return st_;
+        if (gf_status st_ = launch_wgrad_direct<CB>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, (const unsigned *)nullptr, chan, smax, row_max, mask ? 1 : 0, nf, xpart); st_ != GF_OK) return st_;
         return GF_OK;
     }
     GF_HIP_TRY(ctx, hipMemsetAsync(words, 0, sizeof(unsigned) * 512, ctx->stream));
@@ -1754,7 +1833,7 @@ gf_status smp_wgrad_partials_direct_c32(gf_ctx *ctx, const float *T, const float
     if (nf != 2) return fail(ctx, GF_ERR_UNSUPPORTED, "smp_wgrad_direct: exact column bounds with per-product row factors");
     GF_LAUNCH(ctx, "smpf_colmax", rowscale_absmax, dim3(64), dim3(256), 0, rowscale, rows, words + 384);
     GF_LAUNCH(ctx, "smpf_colmax", wgrad_bounds_exact_cb, dim3(1), dim3(64), 0, words, words + 256, words + 384, words + 512, CB);
-    if (gf_status st_ = launch_wgrad_direct<CB>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0, nf); st_ != GF_OK) return st_;
+    if (gf_status st_ = launch_wgrad_direct<CB>(ctx, T, dO, rowscale, rows, splits, part, mask ? trowf : trow, words + 512, (const unsigned *)nullptr, 0.f, (const unsigned *)nullptr, mask ? 1 : 0, nf, xpart); st_ != GF_OK) return st_;
     return GF_OK;
 }
 size_t smp_wgrad_direct_words_c32() { return 512 + 9 * 32; }
