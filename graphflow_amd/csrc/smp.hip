@@ -1052,8 +1052,15 @@ gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channel
         }
         // SMP_2D_ver6 (RisiContraction_10) embedded in the 18-slice fused level (see gf_smp::dup_channels): 2 C channels padded to 16 / 32 / 64.
         // GF_SMP_VER6_FUSED=0: the `_10` contraction op by op.  gf_smp_prepare refuses an asymmetric adjacency in this mode.
+        // (only where every field fits the fused level -- max_receptive_field <= 32: on an op-by-op level the 18-slice model at 2 C padded
+        //  channels moves more than the `_10` / `_50` contraction at C; GF_SMP_VER6_FUSED=2 / GF_SMP_VER7_FUSED=2 embed at any cap)
+        auto embed = [&](const char *name) {
+            const char *v = std::getenv(name);
+            if (v && v[0] == '0') return false;
+            return s->cfg.max_receptive_field <= 32 || (v && v[0] == '2');
+        };
         if (pad_channels && !(e && e[0] == '0') && s->cfg.nContractions == 10 && 2 * C <= 64 && s->cfg.nLevels < gf::kPadMaxLevels && !s->cfg.physics &&
-            !(std::getenv("GF_SMP_VER6_FUSED") && std::getenv("GF_SMP_VER6_FUSED")[0] == '0')) {
+            embed("GF_SMP_VER6_FUSED")) {
             s->dup_channels = C;
             s->cfg.nContractions = 18;
             s->cfg.custom_matmul = 0;   // (the device's own copy of the weights is in the [18 Cc][Cc] layout whatever the caller's is)
@@ -1061,7 +1068,7 @@ gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channel
         }
         // SMP_2D_ver7 (RisiContraction_50) the same way, with three extra products per level (gf_smp::n_extra).  GF_SMP_VER7_FUSED=0: op by op.
         if (pad_channels && !(e && e[0] == '0') && s->cfg.nContractions == 50 && 2 * C <= 64 && s->cfg.nLevels < gf::kPadMaxLevels && !s->cfg.physics &&
-            !(std::getenv("GF_SMP_VER7_FUSED") && std::getenv("GF_SMP_VER7_FUSED")[0] == '0')) {
+            embed("GF_SMP_VER7_FUSED")) {
             s->dup_channels = C;
             s->n_extra = 3;
             s->cfg.nContractions = 18;
