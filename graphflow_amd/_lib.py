@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libgf_hip.so")
+LIB_PATH = os.environ.get("GF_HIP_LIBRARY") or os.path.join(_CSRC, "libgf_hip.so")   # (GF_HIP_LIBRARY: an experimental build, tools/ab_lib.sh)
 
 GF_OK, GF_ERR_INVALID, GF_ERR_HIP, GF_ERR_NOMEM, GF_ERR_UNSUPPORTED, GF_ERR_TIMEOUT = range(6)
 GF_OPT_R18_GENERIC_KERNELS = 1
