@@ -1345,6 +1345,12 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
         const double *cm = coulomb;
         for (int m = 0; m < nMol; ++m) {
             const int V = nVertices[m];
+            // (Coulomb mode: RisiContraction_18 drops the entries A <= 0 -- its `if (adj_value > 0)` -- and RisiContraction_10 does not)
+            if (cm)
+                for (int i = 0; i < V * V; ++i)
+                    if (!(cm[i] > 0.0))
+                        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare_coulomb: molecule %d has a Coulomb entry <= 0; the fused RisiContraction_10 "
+                                    "level (computed through the gated RisiContraction_18) needs positive ones -- create the handle with GF_SMP_VER6_FUSED=0", m);
             for (int i = 0; i < V; ++i)
                 for (int j = i + 1; j < V; ++j)
                     if (a[i * V + j] != a[j * V + i] || (cm && cm[i * V + j] != cm[j * V + i]))

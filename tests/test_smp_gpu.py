@@ -1148,7 +1148,28 @@ def test_smp_2d_ver6_on_the_fused_level_equals_the_op_by_op_level(gf, monkeypatc
     if not np.array_equal(bad, bad.T):
         with pytest.raises(Exception, match="asymmetric"):
             net.prepare([(bad, feat)])
+    # Coulomb mode: a positive symmetric matrix runs (RisiContraction_18's `A > 0` gate passes everything) and agrees with the op-by-op
+    # `_10` level; a signed one is refused (the gate would drop entries RisiContraction_10 keeps)
+    rng = np.random.default_rng(5)
+    cpos = rng.uniform(0.1, 2.0, (6, 6))
+    cpos = 0.5 * (cpos + cpos.T)
+    p = dev(f32exact(rng.uniform(-1, 1, net.n_params) / np.sqrt(10 * C)))
+    net.prepare([(adj, feat)], coulomb=[cpos])
+    pa, _, fa = net.forward(p, dev(np.array([1.0])))
+    ga = torch.zeros(net.n_params, device="cuda")
+    net.backward(p, ga)
+    with pytest.raises(Exception, match="Coulomb entry"):
+        net.prepare([(adj, feat)], coulomb=[cpos - 1.0])
     net.close()
+    monkeypatch.setenv("GF_SMP_VER6_FUSED", "0")
+    ref = SMPOmega(L, C, F, D, cap, True, nContractions=10, custom_matmul=custom)
+    ref.prepare([(adj, feat)], coulomb=[cpos])
+    pb, _, fb = ref.forward(p, dev(np.array([1.0])))
+    gb = torch.zeros(ref.n_params, device="cuda")
+    ref.backward(p, gb)
+    assert rel_err(pa.cpu().numpy(), pb.cpu().numpy()) <= TOL_FWD and rel_err(fa.cpu().numpy(), fb.cpu().numpy()) <= TOL_FWD
+    assert rel_err(ga.cpu().numpy(), gb.cpu().numpy()) <= TOL_SELF
+    ref.close()
 
 
 @pytest.mark.parametrize("C,fused,cap,coul", [(64, True, 29, False), (8, False, 6, False), (16, True, 12, True)])
