@@ -1353,8 +1353,8 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                                     "level (computed through the gated RisiContraction_18) needs positive ones -- create the handle with GF_SMP_VER6_FUSED=0", m);
             for (int i = 0; i < V; ++i)
                 for (int j = i + 1; j < V; ++j)
-                    if (a[i * V + j] != a[j * V + i] || (cm && cm[i * V + j] != cm[j * V + i]))
-                        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare: molecule %d has an asymmetric adjacency (%d, %d); the fused RisiContraction_10 / _50 "
+                    if (a[i * V + j] < 0 || a[i * V + j] != a[j * V + i] || (cm && cm[i * V + j] != cm[j * V + i]))
+                        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare: molecule %d has an asymmetric (or negative) adjacency entry (%d, %d); the fused RisiContraction_10 / _50 "
                                     "level needs a symmetric one -- create the handle with GF_SMP_VER6_FUSED=0 / GF_SMP_VER7_FUSED=0 for the op-by-op level", m, i, j);
             a += (size_t)V * V;
             if (cm) cm += (size_t)V * V;
