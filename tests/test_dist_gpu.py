@@ -73,6 +73,41 @@ def test_smp_backward_reduces_its_gradient_segments_on_the_communicator(gf, fuse
     ctx.close()
 
 
+@pytest.mark.parametrize("nK", [10, 50])
+def test_padded_and_embedded_models_reduce_their_segments_too(gf, nK):
+    """The SMP_2D_ver6 / ver7 wirings run as an 18-slice model on padded [f | f^T] channels: the gradient segments that are
+    all-reduced are those of the PADDED vector, ver7's extra products' blocks behind it included ([X_1 .. X_L], its own segment).  One rank:
+    bit-identical to the plain sweep, every caller-side gradient written."""
+    from graphflow_amd.smp import SMPOmega
+    L, C, F, D, cap = 3, 10, 5, 2, 12
+    mols, tg = [], []
+    for seed in range(16):
+        a, f, t = synthetic_molecule(4300 + seed, nV=3 + seed % 10)
+        mols.append((a, f))
+        tg.append(t)
+    t = torch.as_tensor(np.array(tg, dtype=np.float32)).cuda()
+
+    def grads(ctx):
+        net = SMPOmega(L, C, F, D, cap, True, ctx=ctx, nContractions=nK, custom_matmul=True)
+        p = torch.as_tensor((np.random.default_rng(3).uniform(-1, 1, net.n_params) / np.sqrt(nK * C)).astype(np.float32)).cuda()
+        net.prepare(mols)
+        g = torch.full((net.n_params,), float("nan"), device="cuda")
+        for _ in range(2):
+            net.forward(p, t)
+            net.backward(p, g)
+        torch.cuda.synchronize()
+        net.close()
+        return g.clone()
+
+    plain = grads(gf.Context(0))
+    ctx = gf.Context(0)
+    ctx.dist_init(ctx.dist_unique_id(), 0, 1)
+    reduced = grads(ctx)
+    assert bool(torch.isfinite(plain).all()) and float(plain.abs().max()) > 0
+    assert torch.equal(plain, reduced)
+    ctx.close()
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
