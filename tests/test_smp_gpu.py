@@ -1012,6 +1012,41 @@ def test_smp_2d_ver7_wiring_at_32_channels_runs_the_matrix_pipe_contractions(gf,
     assert rel_err(a[2], b[2]) <= TOL_GRAD
 
 
+@pytest.mark.parametrize("nK", [10, 50])
+def test_ver6_ver7_embedding_at_the_headline_sizes(gf, monkeypatch, nK):
+    """BASELINE configs[2]'s molecules (QM9-size, cap 29, three levels) at the reference's 10 channels, 192 of them: the `_10` / `_50` models on
+    the fused 18-slice level against their op-by-op levels -- fields up to 29, every size class of tables-forward and of the gather, the
+    in-kernel extra products of ver7 (32 padded channels)."""
+    from graphflow_amd.smp import SMPOmega
+    L, C, F, D, cap = 3, 10, 5, 2, 29
+    mols, tg = [], []
+    for i in range(192):
+        adj, feat, t = synthetic_molecule(i)
+        mols.append((adj, feat))
+        tg.append(t)
+
+    def step():
+        net = SMPOmega(L, C, F, D, cap, True, nContractions=nK, custom_matmul=True)
+        params = f32exact(np.random.default_rng(nK).uniform(-1, 1, net.n_params) / np.sqrt(nK * C))
+        net.prepare(mols)
+        p = dev(params)
+        pred, loss, feat = net.forward(p, dev(np.array(tg)))
+        grads = torch.zeros(net.n_params, device="cuda")
+        net.backward(p, grads)
+        return [x.cpu().numpy().astype(np.float64) for x in (pred, feat, grads)] + [net]
+
+    a = step()
+    monkeypatch.setenv("GF_SMP_VER6_FUSED", "0")
+    monkeypatch.setenv("GF_SMP_VER7_FUSED", "0")
+    b = step()
+    name = "ver%d_embedding_headline_sizes" % (6 if nK == 10 else 7)
+    note(name, pred=rel_err(a[0], b[0]), feat=rel_err(a[1], b[1]))
+    assert np.isfinite(a[2]).all() and not np.array_equal(a[2], b[2])
+    assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[1], b[1]) <= TOL_FWD
+    assert_grads_agree_kink_aware(name, a[2], b[2], a[3], b[3], mols, L)
+    a[3].close(), b[3].close()
+
+
 @pytest.mark.parametrize("C,custom,fused", [(10, False, True), (10, True, False), (6, False, True), (32, True, True), (3, False, False)])
 def test_smp_2d_ver7_on_the_fused_level_equals_the_op_by_op_level(gf, monkeypatch, C, custom, fused):
     """RisiContraction_50 wiring on the 18-slice level (gf_smp::dup_channels + n_extra: 46 slices as RisiContraction_18 slices on f / f^T, the
