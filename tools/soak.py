@@ -1,14 +1,17 @@
 """Soak: a training loop that prepares a NEW batch every step (varying size) on one handle; checks that device memory stays
-bounded (pooled buffers) and that nothing goes non-finite.  usage: python tools/soak.py [steps]"""
+bounded (pooled buffers) and that nothing goes non-finite.  usage: python tools/soak.py [steps] [C] [nContractions]"""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests/golden')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 import numpy as np, torch
 from inputs import synthetic_molecule, smp_params
 from graphflow_amd.smp import SMPOmega
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-L, C, F, D, cap = 3, 64, 5, 5, 29
-net = SMPOmega(L, C, F, D, cap, True)
-p = torch.as_tensor(smp_params(C, F, D, L, 1).astype(np.float32)).cuda()
+L, C, F, D, cap = 3, (int(sys.argv[2]) if len(sys.argv) > 2 else 64), 5, 5, 29
+nK = int(sys.argv[3]) if len(sys.argv) > 3 else 18
+net = SMPOmega(L, C, F, D, cap, True, nContractions=nK, custom_matmul=(nK != 18))
+p = torch.as_tensor((smp_params(C, F, D, L, 1) if nK == 18 else np.random.default_rng(1).uniform(-1, 1, net.n_params) / np.sqrt(nK * C)).astype(np.float32)).cuda()
 g = torch.empty_like(p)
 pool = [synthetic_molecule(i) for i in range(2048)]
 rng = np.random.default_rng(0)
