@@ -672,13 +672,17 @@ def main():
                 # the headline step again with the C = 64 block products on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) instead of the
                 # f16 pipe with two-half operands: the same step without the operand-width caveat, under the same clock
                 from graphflow_amd import _lib
-                ctx.set_option(_lib.GF_OPT_SMP_FP32_PRODUCTS, 1)
-                els, _ = timed_run(torch, ctx, step, 20, 3, torch.cuda.synchronize, True, repeats=3)
-                el = median(els)
-                ctx.set_option(_lib.GF_OPT_SMP_FP32_PRODUCTS, 0)
-                extra["cfg3_fp32_products"] = {"metric": meta["metric"], "value": round(meta["units_per_step"] * 20 / el, 1), "unit": meta["unit"],
-                                               "steps": 20, "warmup": 3, "ms_per_step": round(1e3 * el / 20, 4),
-                                               "what": "GF_OPT_SMP_FP32_PRODUCTS: the level's block products on the fp32 MFMA pipe, everything else as in the headline step"}
+                try:   # (an extra section that fails is reported in its place: the headline line does not depend on it)
+                    ctx.set_option(_lib.GF_OPT_SMP_FP32_PRODUCTS, 1)
+                    els, _ = timed_run(torch, ctx, step, 20, 3, torch.cuda.synchronize, True, repeats=3)
+                    el = median(els)
+                    extra["cfg3_fp32_products"] = {"metric": meta["metric"], "value": round(meta["units_per_step"] * 20 / el, 1), "unit": meta["unit"],
+                                                   "steps": 20, "warmup": 3, "ms_per_step": round(1e3 * el / 20, 4),
+                                                   "what": "GF_OPT_SMP_FP32_PRODUCTS: the level's block products on the fp32 MFMA pipe, everything else as in the headline step"}
+                except Exception as e:   # noqa: BLE001
+                    extra["cfg3_fp32_products"] = {"error": repr(e)}
+                finally:
+                    ctx.set_option(_lib.GF_OPT_SMP_FP32_PRODUCTS, 0)
             if args.C == 64 and os.environ.get("GF_SMP_SPLIT", "1") != "0":
                 # the same model at 32 channels (the reference runs any nChanels): the row-panel kernel family templated on the channel
                 # count, weight gradients on smp_wgrad_direct<32>; its own context and handle, same molecules
@@ -686,52 +690,68 @@ def main():
                 # zero-padded to 16 on the device (32 until round 5), the caller's parameter / gradient layout kept at the C ABI
                 import copy
                 for Cx in (32, 10):
-                    a32 = copy.copy(args)
-                    a32.C = Cx
-                    c32 = gf.Context(dev.index)
-                    s32, _, _, m32, k32 = setup_smp(a32, torch, gf, dev, 1, 0, c32)
-                    els, _ = timed_run(torch, c32, s32, 20, 3, torch.cuda.synchronize, True, repeats=3)
-                    el = median(els)
-                    extra["cfg3_C%d" % Cx] = {"metric": m32["metric"], "value": round(m32["units_per_step"] * 20 / el, 1), "unit": m32["unit"],
-                                              "steps": 20, "warmup": 3, "ms_per_step": round(1e3 * el / 20, 4), "workload": m32["config"]["workload"]}
-                    if k32 is not None:
-                        k32[0].close()
-                    del s32, k32, c32
+                    try:
+                        a32 = copy.copy(args)
+                        a32.C = Cx
+                        c32 = gf.Context(dev.index)
+                        s32, _, _, m32, k32 = setup_smp(a32, torch, gf, dev, 1, 0, c32)
+                        els, _ = timed_run(torch, c32, s32, 20, 3, torch.cuda.synchronize, True, repeats=3)
+                        el = median(els)
+                        extra["cfg3_C%d" % Cx] = {"metric": m32["metric"], "value": round(m32["units_per_step"] * 20 / el, 1), "unit": m32["unit"],
+                                                  "steps": 20, "warmup": 3, "ms_per_step": round(1e3 * el / 20, 4), "workload": m32["config"]["workload"]}
+                        if k32 is not None:
+                            k32[0].close()
+                        del s32, k32, c32
+                    except Exception as e:   # noqa: BLE001
+                        extra["cfg3_C%d" % Cx] = {"error": repr(e)}
                 # ... and the RisiContraction_10 / _50 wirings (SMP_2D_ver6 / ver7) at the reference's 10 channels: since round 5 embedded in
                 # the fused 18-slice level on [f | f^T] channels
                 for name, nK in (("cfg3_ver6_C10", 10), ("cfg3_ver7_C10", 50)):
-                    a7 = copy.copy(args)
-                    a7.C, a7.nK = 10, nK
-                    c7 = gf.Context(dev.index)
-                    s7, _, _, m7, k7 = setup_smp(a7, torch, gf, dev, 1, 0, c7)
-                    els, _ = timed_run(torch, c7, s7, 20, 3, torch.cuda.synchronize, True, repeats=3)
-                    el = median(els)
-                    extra[name] = {"metric": "molecules/sec fwd+bwd, SMP_2D_ver%d wiring (RisiContraction_%d per node)" % (6 if nK == 10 else 7, nK),
-                                   "value": round(m7["units_per_step"] * 20 / el, 1), "unit": m7["unit"], "steps": 20, "warmup": 3,
-                                   "ms_per_step": round(1e3 * el / 20, 4), "workload": m7["config"]["workload"].replace("SMP_omega", "SMP_2D_ver%d" % (6 if nK == 10 else 7))}
-                    if k7 is not None:
-                        k7[0].close()
-                    del s7, k7, c7
+                    try:
+                        a7 = copy.copy(args)
+                        a7.C, a7.nK = 10, nK
+                        c7 = gf.Context(dev.index)
+                        s7, _, _, m7, k7 = setup_smp(a7, torch, gf, dev, 1, 0, c7)
+                        els, _ = timed_run(torch, c7, s7, 20, 3, torch.cuda.synchronize, True, repeats=3)
+                        el = median(els)
+                        extra[name] = {"metric": "molecules/sec fwd+bwd, SMP_2D_ver%d wiring (RisiContraction_%d per node)" % (6 if nK == 10 else 7, nK),
+                                       "value": round(m7["units_per_step"] * 20 / el, 1), "unit": m7["unit"], "steps": 20, "warmup": 3,
+                                       "ms_per_step": round(1e3 * el / 20, 4), "workload": m7["config"]["workload"].replace("SMP_omega", "SMP_2D_ver%d" % (6 if nK == 10 else 7))}
+                        if k7 is not None:
+                            k7[0].close()
+                        del s7, k7, c7
+                    except Exception as e:   # noqa: BLE001
+                        extra[name] = {"error": repr(e)}
             for wl in ("cfg2", "cfg5"):
-                ectx = gf.Context(dev.index)
-                estep, efinish, ecpu, emeta, _ = setup_contraction(wl, args, torch, gf, dev, 1, 0, ectx)
-                els, et = timed_run(torch, ectx, estep, 20, 3, torch.cuda.synchronize, notiming, repeats=3)
-                el = median(els)
-                ems = 1e3 * el / 20
-                extra[wl] = {"metric": emeta["metric"], "value": round(emeta["units_per_step"] * 20 / el, 1), "unit": emeta["unit"],
-                             "steps": 20, "warmup": 3, "ms_per_step": round(ems, 4), "workload": emeta["config"]["workload"],
-                             "roofline": efinish(et, ems, 20)}
-                if not args.no_cpu_baseline:
-                    cb = ecpu()
-                    if cb:
-                        extra[wl]["cpu_baseline"] = cb
-                        extra[wl]["speedup_vs_cpu_1core"] = round(extra[wl]["value"] / cb["value"], 1)
-                del estep
-                ectx.close()
-                torch.cuda.empty_cache()
+                try:
+                    ectx = gf.Context(dev.index)
+                    estep, efinish, ecpu, emeta, _ = setup_contraction(wl, args, torch, gf, dev, 1, 0, ectx)
+                    els, et = timed_run(torch, ectx, estep, 20, 3, torch.cuda.synchronize, notiming, repeats=3)
+                    el = median(els)
+                    ems = 1e3 * el / 20
+                    extra[wl] = {"metric": emeta["metric"], "value": round(emeta["units_per_step"] * 20 / el, 1), "unit": emeta["unit"],
+                                 "steps": 20, "warmup": 3, "ms_per_step": round(ems, 4), "workload": emeta["config"]["workload"],
+                                 "roofline": efinish(et, ems, 20)}
+                    if not args.no_cpu_baseline:
+                        cb = ecpu()
+                        if cb:
+                            extra[wl]["cpu_baseline"] = cb
+                            extra[wl]["speedup_vs_cpu_1core"] = round(extra[wl]["value"] / cb["value"], 1)
+                    del estep
+                    ectx.close()
+                    torch.cuda.empty_cache()
+                except Exception as e:   # noqa: BLE001
+                    extra[wl] = {"error": repr(e)}
             line["extra"] = extra
-        line["roofline"]["hbm_copy_measured_GBps"] = round(copy_ceiling_gbps(torch, dev), 1)
-        line["cpu_baseline"] = cpu() if (world == 1 and not args.no_cpu_baseline) else None
+        try:
+            line["roofline"]["hbm_copy_measured_GBps"] = round(copy_ceiling_gbps(torch, dev), 1)
+        except Exception as e:   # noqa: BLE001
+            line["roofline"]["hbm_copy_measured_GBps"] = None
+            line["roofline"]["hbm_copy_error"] = repr(e)
+        try:
+            line["cpu_baseline"] = cpu() if (world == 1 and not args.no_cpu_baseline) else None
+        except Exception as e:   # noqa: BLE001  (the measured GPU line is printed whatever happens to the host-side baseline)
+            line["cpu_baseline"] = {"error": repr(e)}
     # RCCL prints its version banner through C stdio, which is block-buffered on a pipe: every rank pushes it out BEFORE rank 0
     # writes the JSON line, so that the line is the last thing the job writes to stdout
     sys.stdout.flush()
