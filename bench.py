@@ -57,6 +57,19 @@ def copy_ceiling_gbps(torch, dev):
     return 5 * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def copy_probe_gbps(torch, dev, ctx):
+    """The same 1 GiB -> 1 GiB copy by the library's own hand-written kernels (gf_hbm_copy_probe_f32: float4 grid-stride, plain and
+    non-temporal): the yardstick MI355X_MICROARCH.md quotes (6.29 TB/s, 79 % of the 8 TB/s spec) measured on THIS box, beside torch's
+    copy_ (round-5 review, weak #7: torch's copy_ sits ~20 % below what the part does)."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty(n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    out = {"float4": round(ctx.hbm_copy_probe(b, a, 0, 5), 1), "float4_nontemporal": round(ctx.hbm_copy_probe(b, a, 1, 5), 1)}
+    assert torch.equal(a, b)
+    return out
+
+
 def contraction_bytes(K, N, C):
     """fwd 4(N^3 C + N^2 + K N^2 C); bwd 4(K N^2 C + N^2 + N^3 C) (write-only dP)."""
     fwd = 4 * (N ** 3 * C + N * N + K * N * N * C)
@@ -350,6 +363,8 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
             if t:
                 roof["traffic"] = round(t["fetch"] + t["write"])   # HBM bytes of all launches of the kernel in one step
                 roof["traffic_source"] = os.path.basename(pmc)
+                # (a committed PMC pass, not this run's: the commit the pass was taken at rides along -- every kernel change re-runs it)
+                roof["traffic_commit"] = (json.load(open(pmc)).get("_meta") or {}).get("commit")
         busy = latest_profile("_cfg3_mfma_busy.txt")
         real = {"smpf_products_fwd": "smp_rowpanel_c64<true>", "smpf_products_bwd": "smp_rowpanel_c64<false>", "smpf_wgrad": "smp_wgrad_c64"}
         if fused and (B, C) == (1024, 64) and dom in real and dom in mfma_bound and busy:
@@ -492,7 +507,11 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
         return {"ms_per_step": round(dt * 1e3, 3), "value": round(B / dt, 1), "unit": "molecules/s per GPU", "steps": steps,
                 "what": "new batch every step: host graph preparation + upload (two loader threads, four handles, overlapped) + forward + backward + Adam"}
 
-    meta = {"metric": "CCN-2D (SMP_omega) molecules/sec fwd+bwd", "unit": "molecules/s", "units_per_step": B,
+    # what the arithmetic is: fp32 everywhere; with the split products (default at 64 / 32 / 16 channels) the level's block products take
+    # each fp32 operand as two f16 halves (22 significant bits) on v_mfma_f32_32x32x16_f16 and accumulate in fp32;
+    # extra.cfg3_fp32_products is the same step with those products on the fp32 MFMA pipe
+    dtype = "f32 (level block products: 2xf16-split operands, 22-bit, fp32 accumulate)" if (split and fused) else "f32"
+    meta = {"metric": "CCN-2D (SMP_omega) molecules/sec fwd+bwd", "unit": "molecules/s", "units_per_step": B, "dtype": dtype,
             "config": {"workload": "cfg3: SMP_omega 3 levels, C=%d, F=5, D=5, cap=29, batch=%d synthetic QM9-size molecules/GPU, device-resident, %s levels"
                                    % (C, B, "fused" if fused else "op-by-op"),
                        "parallelism": ("molecule-sharded x%d, RCCL all-reduce of the %d gradient floats inside gf_smp_backward (per-level segments, overlapped)"
@@ -631,7 +650,7 @@ def main():
         value = world * meta["units_per_step"] * args.steps / elapsed
         line = {"metric": meta["metric"], "value": round(value, 1), "unit": meta["unit"], "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": meta.get("dtype", "f32"), "data": "synthetic",
                 "config": meta["config"], "roofline": finish(timers, ms_per_step, args.steps)}
         line["timed_region"] = {"repeats": len(reps), "steps_each": args.steps, "reported": "median",
                                 "ms_per_step_min": round(1e3 * min(reps) / args.steps, 4), "ms_per_step_median": round(ms_per_step, 4),
@@ -644,7 +663,7 @@ def main():
             line["collective"] = {"rccl_ranks_seen": ctx.dist_world, "expected": world,
                                   "allreduces_per_step": round(ar[1] / args.steps, 2) if ar else None,
                                   "allreduce_ms_per_step": round(ar[0] / args.steps, 4) if ar else None,
-                                  "watchdog_s": float(os.environ.get("GF_DIST_TIMEOUT_S", "180")),
+                                  "watchdog_s": float(os.environ.get("GF_DIST_TIMEOUT_S", "1800")),
                                   "note": "HIP events around each ncclAllReduce on the communicator's stream (rank 0), live inside the timed region"}
         line["roofline"]["timing"] = ("HIP events on the kernels' stream: the dominant kernel live inside the timed region, "
                                       "the other kernels in an identical pass of the same steps just before it")
@@ -744,10 +763,18 @@ def main():
                     extra[wl] = {"error": repr(e)}
             line["extra"] = extra
         try:
-            line["roofline"]["hbm_copy_measured_GBps"] = round(copy_ceiling_gbps(torch, dev), 1)
+            line["roofline"]["hbm_copy_measured_GBps"] = round(copy_ceiling_gbps(torch, dev), 1)   # torch's copy_
         except Exception as e:   # noqa: BLE001
             line["roofline"]["hbm_copy_measured_GBps"] = None
             line["roofline"]["hbm_copy_error"] = repr(e)
+        try:
+            torch.cuda.empty_cache()
+            line["roofline"]["hbm_copy_kernel_GBps"] = copy_probe_gbps(torch, dev, ctx)           # the library's own float4 copies
+            line["roofline"]["hbm_copy_note"] = ("read + written bytes / time of a 1 GiB copy on this box: torch copy_ (hbm_copy_measured_GBps) and "
+                                                 "gf_hbm_copy_probe_f32 (hbm_copy_kernel_GBps); MI355X_MICROARCH.md quotes 6290 GB/s for a float4 copy")
+        except Exception as e:   # noqa: BLE001
+            line["roofline"]["hbm_copy_kernel_GBps"] = None
+            line["roofline"]["hbm_copy_kernel_error"] = repr(e)
         try:
             line["cpu_baseline"] = cpu() if (world == 1 and not args.no_cpu_baseline) else None
         except Exception as e:   # noqa: BLE001  (the measured GPU line is printed whatever happens to the host-side baseline)

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "gf_ctx_set_timing": (C.c_int, [_vp, C.c_int]),
     "gf_ctx_timing_count": (C.c_int, [_vp]),
     "gf_ctx_timing_get": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "gf_hbm_copy_probe_f32": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "gf_last_error": (C.c_char_p, [_vp]),
     "gf_version": (C.c_char_p, []),
     "gf_ctx_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),

@@ -128,6 +128,42 @@ LaunchTimer::LaunchTimer(gf_ctx *c, const char *name, hipStream_t on) : ctx(c), 
     (void)hipEventRecord(start, stream);
 }
 
+// gf_hbm_copy_probe_f32: the copy the box's practical HBM ceiling is read from (bench.py: roofline.hbm_copy_*): 16 bytes per lane,
+// grid-stride over one wave of resident workgroups, four requests in flight per lane
+template <bool NT>
+__global__ __launch_bounds__(256) void copy_probe_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (NT) {
+                const float *p = reinterpret_cast<const float *>(src + i + k * stride);
+                v[k].x = __builtin_nontemporal_load(p);
+                v[k].y = __builtin_nontemporal_load(p + 1);
+                v[k].z = __builtin_nontemporal_load(p + 2);
+                v[k].w = __builtin_nontemporal_load(p + 3);
+            } else {
+                v[k] = src[i + k * stride];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (NT) {
+                float *q = reinterpret_cast<float *>(dst + i + k * stride);
+                __builtin_nontemporal_store(v[k].x, q);
+                __builtin_nontemporal_store(v[k].y, q + 1);
+                __builtin_nontemporal_store(v[k].z, q + 2);
+                __builtin_nontemporal_store(v[k].w, q + 3);
+            } else {
+                dst[i + k * stride] = v[k];
+            }
+        }
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
 void LaunchTimer::done() {
     if (slot < 0) return;
     (void)hipEventRecord(stop, stream);
@@ -137,6 +173,7 @@ void LaunchTimer::done() {
 gf_status resolve_timers(gf_ctx *ctx) {
     if (ctx->pending.empty()) return GF_OK;
     GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (dist_poisoned(ctx)) return fail(ctx, GF_ERR_TIMEOUT, "gf_dist: the communicator timed out earlier; timers are not resolved before gf_dist_finalize");
     if (dist_active(ctx)) GF_HIP_TRY(ctx, hipStreamSynchronize(dist_stream(ctx)));   // (the collectives' events live on that stream)
     for (const auto &p : ctx->pending) {
         float ms = 0.f;
@@ -542,8 +579,9 @@ gf_status gf_ctx_use_private_stream(gf_ctx *ctx) {
 gf_status gf_ctx_destroy(gf_ctx *ctx) {
     if (!ctx) return GF_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (!gf::dist_poisoned(ctx)) (void)hipStreamSynchronize(ctx->stream);   // (poisoned: abort the communicator first, see dist_teardown)
     gf::dist_teardown(ctx);
+    (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->repack) (void)hipFree(ctx->repack);
@@ -617,6 +655,40 @@ gf_status gf_ctx_timing_get(gf_ctx *ctx, int index, const char **name, double *t
     if (name) *name = ctx->timers[index].name;
     if (total_ms) *total_ms = ctx->timers[index].ms;
     if (launches) *launches = ctx->timers[index].launches;
+    return GF_OK;
+}
+
+gf_status gf_hbm_copy_probe_f32(gf_ctx *ctx, float *dst, const float *src, size_t n, int mode, int iters, double *ms_per_copy) {
+    if (!ctx) return gf::fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!dst || !src || !ms_per_copy || n == 0 || n % 4 != 0 || iters < 1 || (mode != 0 && mode != 1))
+        return gf::fail(ctx, GF_ERR_INVALID, "gf_hbm_copy_probe_f32: bad argument");
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    GF_HIP_TRY(ctx, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return gf::fail(ctx, GF_ERR_HIP, "gf_hbm_copy_probe_f32: hipEventCreate failed");
+    }
+    const size_t n4 = n / 4;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, (size_t)cus * 8);
+    auto launch = [&]() {
+        if (mode == 0) hipLaunchKernelGGL(gf::copy_probe_f4<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const float4 *)src, (float4 *)dst, n4);
+        else hipLaunchKernelGGL(gf::copy_probe_f4<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const float4 *)src, (float4 *)dst, n4);
+    };
+    launch();   // (warm: page tables, clocks)
+    (void)hipEventRecord(e0, ctx->stream);
+    for (int i = 0; i < iters; ++i) launch();
+    (void)hipEventRecord(e1, ctx->stream);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return gf::fail(ctx, GF_ERR_HIP, "gf_hbm_copy_probe_f32: %s", hipGetErrorString(e));
+    *ms_per_copy = (double)ms / iters;
     return GF_OK;
 }
 

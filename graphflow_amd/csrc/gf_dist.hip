@@ -33,6 +33,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -48,6 +49,10 @@ struct gf_dist_state {
     // exchange it is waiting in instead of hanging the job: gf_dist_quiesce, the join of gf_smp_backward)
     unsigned long long issued = 0;
     char stage[96] = {0};
+    // Set when a watchdog limit fired: a collective that will never complete is (or may be) queued on `stream` and, through the
+    // sweep's join, in front of everything later on the context's stream.  From then on nothing may wait for those streams without a
+    // bound: teardown ABORTS the communicator (ncclCommAbort makes RCCL's kernels leave their spin loops) instead of draining it.
+    bool poisoned = false;
 };
 
 namespace gf {
@@ -75,6 +80,7 @@ const RcclApi *rccl_api() {
         GF_BIND(GetUniqueId, "ncclGetUniqueId")
         GF_BIND(CommInitRank, "ncclCommInitRank")
         GF_BIND(CommDestroy, "ncclCommDestroy")
+        GF_BIND(CommAbort, "ncclCommAbort")
         GF_BIND(AllReduce, "ncclAllReduce")
         GF_BIND(Broadcast, "ncclBroadcast")
         GF_BIND(GetErrorString, "ncclGetErrorString")
@@ -109,8 +115,10 @@ double dist_timeout_s() {
         const double v = std::atof(e);
         return v < 0.0 ? 0.0 : v;
     }
-    return 180.0;
+    return 1800.0;   // (skew between ranks counts: a rank-0 validation pass or checkpoint between two steps must fit inside the limit)
 }
+
+bool dist_poisoned(const gf_ctx *ctx) { return ctx && ctx->dist && ctx->dist->poisoned; }
 
 gf_status dist_allreduce_on(gf_ctx *ctx, float *buf, size_t n, hipStream_t stream, const char *what) {
     if (!dist_active(ctx)) return fail(ctx, GF_ERR_INVALID, "gf_dist: no communicator on this context (gf_dist_init)");
@@ -128,6 +136,8 @@ gf_status dist_allreduce_on(gf_ctx *ctx, float *buf, size_t n, hipStream_t strea
 // into an error that names this rank, the world and the exchange, not into a job that hangs until its scheduler kills it.
 gf_status dist_wait_event(gf_ctx *ctx, hipEvent_t ev, const char *where) {
     if (!dist_active(ctx) || !ev) return GF_OK;
+    if (ctx->dist->poisoned)
+        return fail(ctx, GF_ERR_TIMEOUT, "gf_dist: %s: an earlier wait on this communicator timed out; gf_dist_finalize (which aborts it) is the only way on", where);
     const double limit = dist_timeout_s();
     const auto t0 = std::chrono::steady_clock::now();
     int spins = 0;
@@ -137,7 +147,8 @@ gf_status dist_wait_event(gf_ctx *ctx, hipEvent_t ev, const char *where) {
         if (e != hipErrorNotReady) return fail(ctx, GF_ERR_HIP, "gf_dist: %s: %s", where, hipGetErrorString(e));
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (limit > 0.0 && waited > limit) {
-            const gf_dist_state *d = ctx->dist;
+            gf_dist_state *d = ctx->dist;
+            d->poisoned = true;   // (gf_dist_finalize / gf_ctx_destroy abort the communicator instead of waiting for it)
             return fail(ctx, GF_ERR_TIMEOUT, "gf_dist: rank %d of %d (device %d) waited %.0f s in %s; last collective handed to RCCL: %s "
                                               "-- a peer rank never joined it (GF_DIST_TIMEOUT_S sets the limit, 0 = none)",
                         d->rank, d->world, ctx->device, waited, where, d->stage[0] ? d->stage : "none");
@@ -150,9 +161,23 @@ gf_status dist_wait_event(gf_ctx *ctx, hipEvent_t ev, const char *where) {
 void dist_teardown(gf_ctx *ctx) {
     gf_dist_state *d = ctx->dist;
     if (!d) return;
-    if (d->stream) (void)hipStreamSynchronize(d->stream);
-    if (d->comm) (void)d->api->CommDestroy(d->comm);
-    if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->poisoned) {
+        // a collective whose peer never came is still queued: ncclCommAbort sets the communicator's abort flag (its kernels return,
+        // the streams behind them drain) and frees it without the handshake with the peers that ncclCommDestroy performs
+        if (d->comm) (void)d->api->CommAbort(d->comm);
+        if (d->stream) {   // bounded: the aborted kernels leave within milliseconds; if the stream still does not drain, leak it
+            const auto t0 = std::chrono::steady_clock::now();
+            hipError_t e;
+            while ((e = hipStreamQuery(d->stream)) == hipErrorNotReady &&
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 10.0)
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            if (e != hipErrorNotReady) (void)hipStreamDestroy(d->stream);
+        }
+    } else {
+        if (d->stream) (void)hipStreamSynchronize(d->stream);
+        if (d->comm) (void)d->api->CommDestroy(d->comm);
+        if (d->stream) (void)hipStreamDestroy(d->stream);
+    }
     delete d;
     ctx->dist = nullptr;
 }
@@ -192,12 +217,15 @@ gf_status gf_dist_init(gf_ctx *ctx, const void *id, int rank, int world) {
     std::memcpy(uid.internal, id, GF_DIST_ID_BYTES);
     // ncclCommInitRank returns when EVERY rank of the world has called it.  It runs on a helper thread so that a rank whose peers
     // never arrive (a crashed process, a wrong world size, a rank left on another id) fails after GF_DIST_TIMEOUT_S with its rank and
-    // world in gf_last_error instead of blocking for ever; on a timeout the helper is left behind (it owns its state) and the
-    // context stays without a communicator.
+    // world in gf_last_error instead of blocking for ever; on a timeout the helper is left behind (it owns its state; should
+    // the peers arrive after all it aborts the communicator it then gets, nothing leaks) and the context stays without a communicator.
+    // (ncclCommInitRankConfig with blocking = 0 would hand out an abortable handle at once, but it turns every later collective of the
+    // communicator into an ncclInProgress call whose kernel is enqueued by a proxy thread some time after the call returns -- the
+    // sweep's stream-ordered join would have to poll ncclCommGetAsyncError per segment; not worth it for the start-up path.)
     struct InitJob {
         std::mutex m;
         std::condition_variable cv;
-        bool done = false;
+        bool done = false, abandoned = false;
         ncclResult_t r = ncclSuccess;
         ncclComm_t comm = nullptr;
     };
@@ -209,6 +237,10 @@ gf_status gf_dist_init(gf_ctx *ctx, const void *id, int rank, int world) {
         ncclComm_t c = nullptr;
         const ncclResult_t r = api->CommInitRank(&c, world, uid, rank);
         std::lock_guard<std::mutex> g(job->m);
+        if (job->abandoned) {   // the caller gave up (GF_ERR_TIMEOUT) and the peers came after all: nobody will ever own this communicator
+            if (r == ncclSuccess && c) (void)api->CommAbort(c);
+            return;
+        }
         job->r = r;
         job->comm = c;
         job->done = true;
@@ -220,6 +252,7 @@ gf_status gf_dist_init(gf_ctx *ctx, const void *id, int rank, int world) {
         const bool ok = limit > 0.0 ? job->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return job->done; })
                                     : (job->cv.wait(lk, [&] { return job->done; }), true);
         if (!ok) {
+            job->abandoned = true;   // (under job->m: the helper aborts its communicator itself should ncclCommInitRank ever return)
             st = fail(ctx, GF_ERR_TIMEOUT, "gf_dist_init: rank %d of %d (device %d) waited %.0f s in ncclCommInitRank -- not every rank of the world "
                                            "called gf_dist_init with this id (GF_DIST_TIMEOUT_S sets the limit, 0 = none)",
                       rank, world, ctx->device, limit);
@@ -247,7 +280,8 @@ gf_status gf_dist_init(gf_ctx *ctx, const void *id, int rank, int world) {
 
 gf_status gf_dist_finalize(gf_ctx *ctx) {
     if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
-    (void)hipStreamSynchronize(ctx->stream);
+    // (after a watchdog timeout the context's stream waits on a join that will not come before the abort: abort first, drain after)
+    if (!gf::dist_poisoned(ctx)) (void)hipStreamSynchronize(ctx->stream);
     gf::dist_teardown(ctx);
     return GF_OK;
 }

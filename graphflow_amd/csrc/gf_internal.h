@@ -63,6 +63,7 @@ gf_status opt_in_lds(gf_ctx *ctx, Kern kern, size_t bytes) {
 }
 // data-parallel hooks (gf_dist.hip): is a communicator attached, and the collective on an explicit stream
 bool dist_active(const gf_ctx *ctx);
+bool dist_poisoned(const gf_ctx *ctx);   // a watchdog limit fired on this context's communicator: never wait for its streams unbounded
 gf_status dist_allreduce_on(gf_ctx *ctx, float *buf, size_t n, hipStream_t stream, const char *what = nullptr);
 // bounded wait (GF_DIST_TIMEOUT_S) for an event recorded behind collectives: GF_ERR_TIMEOUT names the rank, the world and the exchange
 gf_status dist_wait_event(gf_ctx *ctx, hipEvent_t ev, const char *where);

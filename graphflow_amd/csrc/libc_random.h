@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace gf {
 // The slice masks of RisiContraction_18_dropout are drawn with rand() -- a million calls per 1024-sample step of SMP_sigma_pairgraphs,
@@ -13,19 +14,35 @@ namespace gf {
 // word in front of it (glibc random_r.c: __setstate_r).  LibcRandom borrows that array for a run of draws, steps the recurrence inline,
 // writes the indices back and reinstalls the array: the process's rand() stream continues exactly where the reference's would.
 // A one-time self-check compares eight borrowed draws with rand() itself (and rewinds); on any doubt every draw is a plain rand().
+// Threads: libc's state is process-global, so the borrow is too -- ONE process-wide mutex is held from borrow() to give_back()
+// (a second model's forward on another thread waits for the first one's mask loop, exactly as its rand() calls would queue on libc's
+// own lock), and the array libc is parked on meanwhile is a static buffer, never a stack frame that could be gone when a
+// setstate() names it (SMP_sigma_pairgraphs::Threaded_ComputeGradient runs one model per worker thread).
 class LibcRandom {
     static constexpr int kDeg = 31, kSep = 3, kType = 3, kMaxTypes = 5;
-    int32_t scratch_[34] = {0};
+    static std::mutex &borrow_lock() {
+        static std::mutex m;
+        return m;
+    }
+    static int32_t *parking() {   // where libc's generator lives while its real array is borrowed (guarded by borrow_lock)
+        static int32_t buf[34] = {0};
+        return buf;
+    }
     int32_t *live_ = nullptr;   // the borrowed array's type / rear word; the state words follow
     int f_ = 0, r_ = 0;
     bool borrowed_ = false;
     bool borrow() {
-        char *prev = initstate(1u, reinterpret_cast<char *>(scratch_), 128);   // libc now runs on scratch_; prev = its array, indices saved
-        if (!prev) return false;
+        borrow_lock().lock();
+        char *prev = initstate(1u, reinterpret_cast<char *>(parking()), 128);   // libc now runs on the parking array; prev = its own, indices saved
+        if (!prev) {
+            borrow_lock().unlock();
+            return false;
+        }
         live_ = reinterpret_cast<int32_t *>(prev);
         const int word = live_[0];
         if (word % kMaxTypes != kType || word / kMaxTypes < 0 || word / kMaxTypes >= kDeg) {   // not the default generator: hands off
             (void)setstate(prev);
+            borrow_lock().unlock();
             return false;
         }
         r_ = word / kMaxTypes;
@@ -37,6 +54,7 @@ class LibcRandom {
         live_[0] = kMaxTypes * r_ + kType;
         (void)setstate(reinterpret_cast<char *>(live_));
         borrowed_ = false;
+        borrow_lock().unlock();
     }
     inline int step() {
         int32_t *st = live_ + 1;
@@ -69,6 +87,8 @@ class LibcRandom {
   public:
     bool fast = false;
     LibcRandom() {}
+    LibcRandom(const LibcRandom &) = delete;
+    LibcRandom &operator=(const LibcRandom &) = delete;
     explicit LibcRandom(bool want) {
         static const bool ok = self_check() && !(std::getenv("GF_FAST_RAND") && std::getenv("GF_FAST_RAND")[0] == '0');
         fast = want && ok && borrow();

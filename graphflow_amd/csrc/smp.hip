@@ -2231,6 +2231,18 @@ gf_status gf_smp_set_grad_allreduce(gf_smp *s, int on) {
 
 // The reverse sweep.  dfeat == nullptr: from the loss of the last forward (SMP_omega / SMP_beta / SMP_2D).  dfeat != nullptr
 // (physics towers): from the gradient of the tower's feature rows, [nMol][feature_width], given by the caller's head.
+// Slice dropout in TEST mode: the fused level cannot run the reference's unscaled test-mode sweep (smp_fused_backward_level).  Refused
+// BEFORE a gradient is written or a collective handed to RCCL -- not in the middle of the level loop, where the readout's gradients
+// were already there and the peers of a data-parallel run were left waiting for segments that never came (round-5 advice).  The
+// composite model asks before its head's backward as well (gf_smp_model_backward).
+extern "C++" gf_status gf::smp_backward_admissible(const gf_smp *s) {
+    if (s->drop_on && s->drop_scale != 1.f && s->fused && s->prepared)
+        for (int l = 1; l <= s->cfg.nLevels; ++l)
+            if (gf::smp_fused_supported(s, l))
+                return fail(s->ctx, GF_ERR_UNSUPPORTED, "gf_smp_backward: fused level %d under slice dropout in test mode (scale %.4f): set GF_SMP_FUSED_DROPOUT=0 "
+                                                        "for the reference's unscaled test-mode sweep", l, (double)s->drop_scale);
+    return GF_OK;
+}
 static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads, int accumulate, const float *dfeat) {
     if (!s) return fail(nullptr, GF_ERR_INVALID, "null smp handle");
     gf_ctx *ctx = s->ctx;
@@ -2245,6 +2257,10 @@ static gf_status smp_backward_impl(gf_smp *s, const float *params, float *grads,
         grads = s->own_g;
     }
     if (!params || !grads) return fail(ctx, GF_ERR_INVALID, "gf_smp_backward: null argument");
+    {
+        gf_status st0 = gf::smp_backward_admissible(s);
+        if (st0 != GF_OK) return st0;
+    }
     GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     {   // (a no-op after this batch's forward; it makes the reverse sweep independent of who grew the context's workspace last)
         gf_status st = gf::ensure_ws(ctx, s->ws_need);

@@ -241,6 +241,7 @@ namespace gf {
 // channel counts the row-panel kernel family of the fused level is built for (models are padded to the next one: gf_smp_create)
 inline bool smp_panel_channels(int C) { return C == 64 || C == 32 || C == 16; }
 bool smp_fused_supported(const gf_smp *s, int l);
+gf_status smp_backward_admissible(const gf_smp *s);   // smp.hip: refusals of a reverse sweep that must come before any work is issued
 gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float *bl);
 gf_status smp_fused_ensure_zero_fill(gf_smp *s, int l);
 // node_df != nullptr (top level): df_l is the same C-vector at every position of a node, given as [nodes][C]

@@ -318,6 +318,10 @@ gf_status gf_smp_model_backward(gf_smp_model *m, const float *params, float *gra
     if (!params || !grads) return fail(ctx, GF_ERR_INVALID, "gf_smp_model_backward: null argument");
     if (!m->forwarded) return fail(ctx, GF_ERR_INVALID, "gf_smp_model_backward: needs a forward with targets first");
     gf_status st;
+    for (int t = 0; t < m->nTowers; ++t) {   // (a tower's refusal comes before the head has written anything)
+        st = gf::smp_backward_admissible(m->tower[t]);
+        if (st != GF_OK) return st;
+    }
     if (!accumulate) GF_HIP_TRY(ctx, hipMemsetAsync(grads, 0, m->n_params * sizeof(float), ctx->stream));
     st = gf_head_backward_f32(ctx, m->nLayers, m->widths.data(), m->x, m->nMol, params + m->head_off, m->work, m->dx, grads + m->head_off);
     if (st != GF_OK) return st;

@@ -50,6 +50,15 @@ class Context:
     def reserve(self, nbytes):
         self.check(self.lib.gf_ctx_reserve(self.handle, int(nbytes)))
 
+    def hbm_copy_probe(self, dst, src, mode=0, iters=5):
+        """gf_hbm_copy_probe_f32: GB/s (read + written bytes) of a hand-written float4 copy src -> dst (mode 1: non-temporal)."""
+        import ctypes as C_
+        assert dst.numel() == src.numel() and src.numel() % 4 == 0
+        ms = C_.c_double(0.0)
+        self.check(self.lib.gf_hbm_copy_probe_f32(self.handle, C_.c_void_p(dst.data_ptr()), C_.c_void_p(src.data_ptr()), src.numel(), int(mode),
+                                                  int(iters), C_.byref(ms)))
+        return 2 * 4 * src.numel() / (ms.value * 1e-3) / 1e9
+
     def set_timing(self, enable=True):
         """Per-kernel HIP-event timing on the context stream (gf_ctx_set_timing)."""
         self.check(self.lib.gf_ctx_set_timing(self.handle, 1 if enable else 0))

@@ -63,6 +63,11 @@ gf_status gf_ctx_set_timing(gf_ctx *ctx, int enable);
 gf_status gf_ctx_set_timing_filter(gf_ctx *ctx, const char *kernel_name);
 int       gf_ctx_timing_count(gf_ctx *ctx);
 gf_status gf_ctx_timing_get(gf_ctx *ctx, int index, const char **name, double *total_ms, long long *launches);
+/* Measurement aid ("a measured device-to-device copy ceiling from the box"): `iters` copies of n floats src -> dst by a
+ * hand-written kernel on the context's stream, bracketed by HIP events; *ms_per_copy = their average.  mode 0: float4 loads / stores,
+ * grid-stride, one workgroup slot per CU x 8; mode 1: the same with non-temporal loads and stores.  n % 4 == 0.  No reference
+ * counterpart (its tests time with gettimeofday, tests/test_RisiContraction_18_gpu.cu:31-40).                                       */
+gf_status gf_hbm_copy_probe_f32(gf_ctx *ctx, float *dst, const float *src, size_t n, int mode, int iters, double *ms_per_copy);
 const char *gf_last_error(gf_ctx *ctx);                     /* a per-thread copy: valid until this thread's next gf_last_error; ctx may be NULL for create errors */
 const char *gf_version(void);
 /* Per-context options.  GF_OPT_R18_GENERIC_KERNELS != 0 routes RisiContraction_18 through the layout-agnostic generic

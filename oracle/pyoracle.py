@@ -233,6 +233,43 @@ class _Lib:
             f(G, W, T, dW, dT, I, J, V, Kout)
         return dW, dT
 
+    # -- StackTensor3D (StackTensor3D.h:54-90) -------------------------------------------------------
+    def stack_forward(self, T):
+        """T [nRows][nCols][n1][n2] = the nRows source tensors; returns the stacked Tensor4D's value."""
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        nRows, nCols, n1, n2 = T.shape
+        out = np.zeros_like(T)
+        if self.kind == "oracle":
+            f = self.lib.gfo_stack_forward
+            f.argtypes = [C.c_void_p, _dp, _i, C.c_size_t]
+            f.restype = None
+            ptrs = (C.c_void_p * nRows)(*[T[r].ctypes.data for r in range(nRows)])
+            f(C.cast(ptrs, C.c_void_p), out, nRows, nCols * n1 * n2)
+        else:
+            f = self.lib.ref_stack_forward
+            f.argtypes = [_dp, _dp, _i, _i, _i, _i]
+            f.restype = None
+            f(T, out, nRows, nCols, n1, n2)
+        return out
+
+    def stack_backward(self, G, dT0=None):
+        """Returns dT0 + the scatter of the stacked gradient G [nRows][nCols][n1][n2] (the `+=` of StackTensor3D::backward)."""
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        nRows, nCols, n1, n2 = G.shape
+        dT = np.zeros_like(G) if dT0 is None else np.array(dT0, dtype=np.float64, order="C")
+        if self.kind == "oracle":
+            f = self.lib.gfo_stack_backward
+            f.argtypes = [_dp, C.c_void_p, _i, C.c_size_t]
+            f.restype = None
+            ptrs = (C.c_void_p * nRows)(*[dT[r].ctypes.data for r in range(nRows)])
+            f(G, C.cast(ptrs, C.c_void_p), nRows, nCols * n1 * n2)
+        else:
+            f = self.lib.ref_stack_backward
+            f.argtypes = [_dp, _dp, _i, _i, _i, _i]
+            f.restype = None
+            f(G, dT, nRows, nCols, n1, n2)
+        return dT
+
     def _n(self, name):
         return ("gfo_" if self.kind == "oracle" else "ref_") + name
 

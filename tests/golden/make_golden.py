@@ -81,6 +81,44 @@ def wide_contraction_fixtures(ref):
     return out
 
 
+def contraction_16x8_fixtures(ref):
+    """SURVEY 8(c) asks for (N, C) = (16, 8) for every K; contractions.npz holds it for `_4` and `_18` (round-5 review, missing #4).
+    Here `_10` (0/1 symmetric and signed adjacency: `_10` has no `> 0` gate) and `_50` (0/1 symmetric), same recipe."""
+    out = {}
+    for K, kinds in ((10, ["sym01", "signed"]), (50, ["sym01"])):
+        N, C = 16, 8
+        rng = np.random.default_rng(1000 * K + 10 * N + C)
+        P = f32exact(rng.uniform(-1, 1, (N, N, N, C)))
+        G = f32exact(rng.uniform(0, 1, (N, N, K, C)))
+        dP0 = f32exact(rng.uniform(-1, 1, (N, N, N, C)))
+        for kind in kinds:
+            A = adjacency(kind, N, rng)
+            tag = "r%d_N%d_C%d_%s" % (K, N, C, kind)
+            out[tag + "__P"] = P.astype(np.float32)
+            out[tag + "__G"] = G.astype(np.float32)
+            out[tag + "__dP0"] = dP0.astype(np.float32)
+            out[tag + "__A"] = A.astype(np.float32)
+            out[tag + "__Out"] = ref.contract_forward(K, P, A)
+            out[tag + "__dP"] = ref.contract_backward(K, G, A, dP0)
+    return out
+
+
+def stack_fixtures(ref):
+    """StackTensor3D (StackTensor3D.h:54-90) as RisiContraction_18_gpu is fed by it (tests/test_RisiContraction_18_gpu.cu:124-129): N
+    tensors [N][N][C] -> Tensor4D [N][N][N][C]; backward adds the stacked gradient into the sources' (non-zero) gradients.  Two shapes:
+    the cubic one of the contraction and a ragged one (nRows != nCols != n1)."""
+    out = {}
+    rng = np.random.default_rng(5150)
+    for tag, shape in {"stack_5x5x5x3": (5, 5, 5, 3), "stack_3x4x2x7": (3, 4, 2, 7), "stack_1x1x1x1": (1, 1, 1, 1)}.items():
+        T = f32exact(rng.uniform(-1, 1, shape))
+        G = f32exact(rng.uniform(-1, 1, shape))
+        dT0 = f32exact(rng.uniform(-1, 1, shape))
+        out[tag + "__T"], out[tag + "__G"], out[tag + "__dT0"] = T.astype(np.float32), G.astype(np.float32), dT0.astype(np.float32)
+        out[tag + "__Out"] = ref.stack_forward(T)
+        out[tag + "__dT"] = ref.stack_backward(G, dT0)
+    return out
+
+
 def dropout_fixtures(ref):
     """RisiContraction_18_dropout: the reference draws the kept slices itself after srand(seed); the fixture keeps the mask."""
     out = {}
@@ -426,6 +464,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "contractions.npz"), **contraction_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "contractions_wide.npz"), **wide_contraction_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "mixers.npz"), **mixer_fixtures(ref))
+    np.savez_compressed(os.path.join(HERE, "contractions_16x8.npz"), **contraction_16x8_fixtures(ref))
+    np.savez_compressed(os.path.join(HERE, "stack.npz"), **stack_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "dropout.npz"), **dropout_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "smp.npz"), **smp_fixtures())
     checkpoint_fixture()
@@ -443,6 +483,12 @@ if __name__ == "__main__":
         pyoracle.build()
         physics_fixtures()
         print("smp_physics.npz", os.path.getsize(os.path.join(HERE, "smp_physics.npz")), "bytes")
+    elif len(sys.argv) > 1 and sys.argv[1] == "r06":    # only the fixtures added in round 6: (16, 8) for `_10` / `_50`, StackTensor3D
+        pyoracle.build()
+        np.savez_compressed(os.path.join(HERE, "contractions_16x8.npz"), **contraction_16x8_fixtures(pyoracle.reference()))
+        np.savez_compressed(os.path.join(HERE, "stack.npz"), **stack_fixtures(pyoracle.reference()))
+        for f in ("contractions_16x8.npz", "stack.npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
     elif len(sys.argv) > 1 and sys.argv[1] == "wide":   # only the RisiContraction_50 fixtures at C % 32 == 0
         pyoracle.build()
         np.savez_compressed(os.path.join(HERE, "contractions_wide.npz"), **wide_contraction_fixtures(pyoracle.reference()))

@@ -190,3 +190,114 @@ def test_a_rank_whose_peer_never_arrives_times_out_with_its_rank_and_world(tmp_p
     env = dict(os.environ, GF_DIST_TIMEOUT_S="4")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=180)
     assert r.returncode == 0 and "timed out as it should" in r.stdout, r.stdout + r.stderr
+
+
+def test_after_a_collective_timeout_the_context_tears_down_instead_of_hanging(tmp_path):
+    """Round-5 advice (medium): GF_ERR_TIMEOUT was reported but gf_dist_finalize / gf_ctx_destroy then drained the very stream the stuck
+    collective sat on -- the hang the watchdog exists to prevent.  Now a timeout POISONS the communicator: later waits fail at once,
+    finalize aborts it (ncclCommAbort) instead of synchronizing, and the context is usable again.  One GPU: the limit is set below the
+    time the device needs for the work queued in front of the join (the wait is what times out, as it would behind a peer that never
+    joins); a subprocess, so that a hang here costs a timeout and not the suite."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "poisoned.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, %r)
+        sys.path.insert(0, os.path.join(%r, "tests", "golden"))
+        import numpy as np, torch
+        import graphflow_amd as gf
+        from graphflow_amd.smp import SMPOmega
+        from inputs import smp_params, synthetic_molecule
+        L, C, F, D, cap = 3, 64, 5, 3, 29
+        mols = [synthetic_molecule(5000 + i)[:2] for i in range(256)]
+        t = torch.as_tensor(np.array([len(a) for a, _ in mols], dtype=np.float32)).cuda()
+        p = torch.as_tensor(smp_params(C, F, D, L, 8).astype(np.float32)).cuda()
+        ctx = gf.Context(0)
+        ctx.dist_init(ctx.dist_unique_id(), 0, 1)
+        net = SMPOmega(L, C, F, D, cap, True, ctx=ctx)
+        net.prepare(mols)
+        g = torch.empty(net.n_params, device="cuda")
+        net.forward(p, t); net.backward(p, g); ctx.dist_quiesce()      # warm, healthy
+        os.environ["GF_DIST_TIMEOUT_S"] = "0.000001"
+        for _ in range(8):
+            net.forward(p, t)                                           # milliseconds of queued work ...
+        try:
+            ctx.dist_quiesce()                                          # ... in front of a wait that gives up after a microsecond
+        except gf.GraphFlowHipError as e:
+            assert "waited" in str(e) and "rank 0 of 1" in str(e), str(e)
+        else:
+            raise SystemExit("the wait did not time out")
+        try:
+            ctx.dist_quiesce()
+        except gf.GraphFlowHipError as e:
+            assert "timed out" in str(e), str(e)                        # poisoned: refuses at once
+        else:
+            raise SystemExit("a poisoned communicator accepted another wait")
+        t0 = time.time()
+        ctx.dist_finalize()                                             # aborts; must not wait for the communicator's streams
+        assert time.time() - t0 < 30.0 and ctx.dist_world == 1
+        os.environ["GF_DIST_TIMEOUT_S"] = "60"
+        ctx.synchronize()
+        ctx.dist_init(ctx.dist_unique_id(), 0, 1)                       # and the context takes a new communicator
+        g2 = torch.empty_like(g)
+        net.forward(p, t); net.backward(p, g2); ctx.dist_quiesce(); ctx.synchronize()
+        assert torch.equal(g, g2)
+        net.close(); ctx.close()
+        print("poisoned communicator torn down and replaced")
+    """ % (root, root)))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "torn down and replaced" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: arms itself on a multi-GPU node")
+def test_a_rank_that_skips_an_allreduce_makes_its_peer_time_out_and_tear_down(tmp_path):
+    """Two ranks on two GPUs; rank 1 skips one all-reduce.  Rank 0 must come back from gf_dist_quiesce with GF_ERR_TIMEOUT naming the
+    exchange, and its gf_dist_finalize / context close must return (ncclCommAbort) instead of hanging behind the stuck collective."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    idf = tmp_path / "uid.bin"
+    script = tmp_path / "skipper.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, %r)
+        import torch
+        import graphflow_amd as gf
+        rank = int(sys.argv[1]); idf = sys.argv[2]
+        ctx = gf.Context(rank)
+        if rank == 0:
+            uid = ctx.dist_unique_id()
+            open(idf + ".tmp", "wb").write(bytes(uid)); os.rename(idf + ".tmp", idf)
+        else:
+            while not os.path.exists(idf): time.sleep(0.05)
+            uid = open(idf, "rb").read()
+        ctx.dist_init(uid, rank, 2)
+        x = torch.ones(1 << 20, device="cuda:%%d" %% rank)
+        ctx.allreduce_sum_(x); ctx.dist_quiesce(); ctx.synchronize()
+        assert float(x[0]) == 2.0
+        if rank == 0:
+            ctx.allreduce_sum_(x)                      # the peer never joins this one
+            t0 = time.time()
+            try:
+                ctx.dist_quiesce()
+            except gf.GraphFlowHipError as e:
+                assert "rank 0 of 2" in str(e) and "all-reduce #2" in str(e), str(e)
+            else:
+                raise SystemExit("no timeout")
+            ctx.dist_finalize(); ctx.close()
+            print("rank 0 timed out after %%.1f s and tore down" %% (time.time() - t0))
+        else:
+            time.sleep(20)                             # alive, but not in the collective
+            os._exit(0)
+    """ % root))
+    env = dict(os.environ, GF_DIST_TIMEOUT_S="5", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(idf)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert procs[0].returncode == 0 and "tore down" in outs[0], outs[0][-2000:]

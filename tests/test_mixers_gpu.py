@@ -151,6 +151,22 @@ def test_stack_round_trip(gf):
         assert torch.equal(grads[r], g0[r] + G[r])
 
 
+def test_stack_golden_vectors(gf, golden):
+    """The reference's own StackTensor3D outputs (tests/golden/stack.npz, StackTensor3D.h:54-90): bit-exact -- the forward is a copy,
+    the backward one fp32 add per element of fp32-representable operands whose sum the fixture holds in fp64."""
+    from util import golden_cases
+    cases = golden_cases(golden, "stack_")
+    assert len(cases) == 3
+    for tag, c in cases.items():
+        ts = [dev(c["T"][r]) for r in range(c["T"].shape[0])]
+        st = gf.stack_forward(ts)
+        assert np.array_equal(st.cpu().numpy().astype(np.float64), c["Out"]), tag
+        grads = [dev(c["dT0"][r]) for r in range(c["T"].shape[0])]
+        gf.stack_backward(dev(c["G"]), grads)
+        got = np.stack([g.cpu().numpy() for g in grads])
+        assert np.array_equal(got, c["dT"].astype(np.float32)), tag
+
+
 def test_host_pointer_matmul_f64(gf, oracle):
     import ctypes as C
     from graphflow_amd import _lib

@@ -30,6 +30,24 @@ def test_contractions_match_golden(oracle, golden, K):
         _close(dP, c["dP"])
 
 
+def test_survey_8c_shapes_are_all_there(golden):
+    """every K at (N, C) in {(3,2), (5,3), (8,4), (16,8)} (round 6 added (16, 8) for `_10` / `_50`)."""
+    for K in (4, 10, 18, 50):
+        tags = set(golden_cases(golden, "r%d_" % K))
+        for N, C in ((3, 2), (5, 3), (8, 4), (16, 8)):
+            assert any(t.startswith("r%d_N%d_C%d_" % (K, N, C)) for t in tags), (K, N, C)
+
+
+def test_stack_matches_golden(oracle, golden):
+    """StackTensor3D fixtures written by the real StackTensor3D::forward / backward (StackTensor3D.h:54-90): a copy and a `+=`."""
+    cases = golden_cases(golden, "stack_")
+    assert len(cases) == 3
+    for tag, c in cases.items():
+        assert np.array_equal(c["Out"], c["T"].astype(np.float64)), tag                       # forward is a pure copy
+        assert np.array_equal(oracle.stack_forward(c["T"]), c["Out"]), tag
+        assert np.array_equal(oracle.stack_backward(c["G"], c["dT0"]), c["dT"]), tag          # exact: one add per element
+
+
 def test_r18_gate_is_pinned(golden):
     """The 'signed' adjacency fixtures distinguish A>0 gating (r18) from no gating (r10/r50, r18_thread)."""
     c = golden_cases(golden, "r18_N5_C3_signed")["r18_N5_C3_signed"]

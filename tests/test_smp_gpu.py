@@ -800,6 +800,125 @@ def test_cfg3_full_size_spot_check_against_the_port(gf):
     assert worst["grads"] <= TOL_GRAD
 
 
+def _cfg3_batch(n=1024, first=0):
+    mols, tg = [], []
+    for seed in range(first, first + n):
+        adj, feat, t = synthetic_molecule(seed)
+        mols.append((adj, feat))
+        tg.append(t)
+    return mols, np.array(tg)
+
+
+@pytest.mark.parametrize("pick", ["random", "largest", "smallest"])
+def test_cfg3_full_batch_gradient_of_picked_molecules_against_the_port(gf, pick):
+    """Round-5 review, weak #1: the 1024-molecule backward (its own panel packing, split-K ranges and size-class mixes) had no
+    oracle-side check -- and a store-from-register-0 compiler bug once passed the 8-32-molecule batch gradient tests by cancellation.
+    In-batch gradient ISOLATION: the loss is (y - t)^2 / 2, so with the targets of all but eight molecules set to the device's own
+    predictions (bit-reproducible: dL/dy = 0 exactly there) the summed gradient gf_smp_backward returns IS those eight molecules'
+    gradient, computed inside the full batch's panels and size classes.  Held to the fp64 port of the reference (oracle/smp_port.c) at
+    1e-5, kink-aware as everywhere (slopes from the full batch's activations inside KINK_TOL, a sign that differs outside it fails).
+    Three disjoint picks: eight at random, the eight largest molecules, the eight smallest.  SMP_omega.h:808-820 (sum of per-molecule
+    gradients)."""
+    from graphflow_amd.smp import SMPOmega
+    from oracle import pyoracle
+    F, D, C, L, cap = 5, 5, 64, 3, 29
+    mols, tg = _cfg3_batch()
+    params = smp_params(C, F, D, L, 1)
+    nv = np.array([len(a) for a, _ in mols])
+    order = np.argsort(nv, kind="stable")
+    largest, smallest = [int(i) for i in order[-8:]], [int(i) for i in order[:8]]
+    rest = [int(i) for i in np.random.default_rng(6).permutation(1024) if int(i) not in largest and int(i) not in smallest]
+    picks = sorted({"random": rest[:8], "largest": largest, "smallest": smallest}[pick])
+    net = SMPOmega(L, C, F, D, cap, True)
+    net.prepare(mols)
+    p = dev(params)
+    pred0, _, _ = net.forward(p, dev(tg))
+    t2 = pred0.clone()                                   # dL/dy = y - t = 0 for everybody ...
+    t2[picks] = dev(tg)[picks]                            # ... but the picked eight
+    pred, loss, feat = net.forward(p, t2)
+    assert torch.equal(pred, pred0)                       # (bit-reproducible forward: the zeros are exact)
+    g = torch.full((net.n_params,), float("nan"), device="cuda")
+    net.backward(p, g)
+    g = g.cpu().numpy().astype(np.float64)
+    ref, n_over = 0.0, 0
+    for i in picks:
+        adj, ft = mols[i]
+        signs = [[net.activation(i, l, v) for v in range(len(adj))] for l in range(L + 1)]
+        o = pyoracle.port_smp_molecule(adj, ft, float(tg[i]), params, L, C, D, cap, True, ext_sign=signs, kink_tol=KINK_TOL)
+        assert o["n_conflict"] == 0, (i, o["n_conflict"])
+        assert abs(float(pred[i]) - o["predict"]) <= TOL_FWD * max(abs(o["predict"]), float(np.abs(o["graph_feature"]).max()), 1.0)
+        ref = ref + o["grads"]
+        n_over += o["n_override"]
+    e = rel_err(g, ref)
+    # per-block as well: a wrong block of a small parameter group must not hide behind the largest group's magnitude
+    C2, FD = C * C, F * (D + 1)
+    bounds = [0, C * FD]
+    for l in range(L):
+        bounds += [bounds[-1] + 18 * C2, bounds[-1] + 18 * C2 + C]
+    bounds.append(bounds[-1] + C)
+    eb = max(rel_err(g[a:b], ref[a:b]) for a, b in zip(bounds[:-1], bounds[1:]))
+    note("cfg3_in_batch_gradient_" + pick, grads=e, grads_per_block=eb)
+    print("cfg3 in-batch gradient (%s: molecules %s, %d..%d atoms): rel err %.2e, worst parameter block %.2e; %d slopes taken from the device"
+          % (pick, picks, min(nv[picks]), max(nv[picks]), e, eb, n_over))
+    assert np.isfinite(g).all() and e <= TOL_GRAD and eb <= 10 * TOL_GRAD
+    net.close()
+
+
+def test_cfg4_workload_as_eight_one_rank_shards(gf):
+    """BASELINE configs[3] (cfg4: 8192 molecules sharded 1024 per GPU with an RCCL all-reduce of the parameter gradients) on ONE GPU: the
+    eight shards graphflow_amd.dist.shard hands to ranks 0..7 of a strong-scaling run go, one after the other, through a context
+    with a (one-rank) RCCL communicator and gf_smp_set_grad_allreduce on -- the very calls every rank of the 8-GPU job makes -- and
+    their gradients are summed on the host, which is what the all-reduce over eight ranks returns.  Held against the same 8192
+    molecules as two 4096-molecule batches on a plain context (other panels, other split-K ranges, no communicator): predictions
+    bit-identical (a molecule does not see its batch mates), summed gradient to 1e-5.  Reference: Threaded_BatchLearn,
+    SMP_omega.h:750-792 (broadcast :771-773, serial add_gradient :784-786)."""
+    from graphflow_amd.dist import shard
+    from graphflow_amd.smp import SMPOmega
+    F, D, C, L, cap = 5, 5, 64, 3, 29
+    world, total = 8, 8192
+    mols, tg = _cfg3_batch(total)
+    params = smp_params(C, F, D, L, 1)
+    p = dev(params)
+    ctx = gf.Context(0)
+    ctx.dist_init(ctx.dist_unique_id(), 0, 1)
+    net = SMPOmega(L, C, F, D, cap, True, ctx=ctx)
+    net.set_grad_allreduce(True)
+    g_sum, preds, covered = np.zeros(net.n_params), [], 0
+    for rank in range(world):
+        lo, hi = shard(total, rank, world)
+        assert hi - lo == 1024 and lo == covered
+        covered = hi
+        net.prepare(mols[lo:hi])
+        pr, _, _ = net.forward(p, dev(tg[lo:hi]))
+        g = torch.full((net.n_params,), float("nan"), device="cuda")
+        net.backward(p, g)
+        ctx.dist_quiesce()
+        g_sum += g.cpu().numpy().astype(np.float64)
+        preds.append(pr.cpu().numpy())
+    assert covered == total
+    net.close()
+    ctx.close()
+    preds = np.concatenate(preds)
+    g_two, p_two = np.zeros_like(g_sum), []
+    big = SMPOmega(L, C, F, D, cap, True)
+    for lo in (0, 4096):
+        big.prepare(mols[lo:lo + 4096])
+        pr, _, _ = big.forward(p, dev(tg[lo:lo + 4096]))
+        g = torch.full((big.n_params,), float("nan"), device="cuda")
+        big.backward(p, g)
+        g_two += g.cpu().numpy().astype(np.float64)
+        p_two.append(pr.cpu().numpy())
+    big.close()
+    p_two = np.concatenate(p_two)
+    e = rel_err(g_sum, g_two)
+    note("cfg4_eight_shards_vs_two_halves", grads=e, pred=rel_err(preds.astype(np.float64), p_two.astype(np.float64)))
+    print("cfg4 workload: 8 x 1024 one-rank shards vs 2 x 4096: gradient rel err %.2e, predictions %s" %
+          (e, "bit-identical" if np.array_equal(preds, p_two) else "rel err %.2e" % rel_err(preds.astype(np.float64), p_two.astype(np.float64))))
+    assert np.isfinite(g_sum).all() and np.abs(g_sum).max() > 0
+    assert rel_err(preds.astype(np.float64), p_two.astype(np.float64)) <= 1e-6
+    assert e <= TOL_GRAD
+
+
 def test_text_checkpoint_is_interchangeable_with_the_reference(gf, golden, tmp_path):
     """tests/golden/smp_syn12_checkpoint.txt was written by the REAL SMP_omega::save_model (SMP_omega.h:1033-1042).
     load_model must read it, predict like the golden, and save_model must write the very same bytes back."""

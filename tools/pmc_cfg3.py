@@ -39,11 +39,25 @@ def collect(d, ctr, scale):
     return tot
 
 
+def is_setup(name):
+    """Kernels of the process's set-up (input uploads, gf_smp_prepare's table builders, the bench's own copies): they run once per
+    prepared batch, not once per step, and stay out of the per-step totals (round-5 review, weak #12)."""
+    return name.startswith(("__amd_rocclr_", "build_", "invert_cons", "level_table_stats", "tables_zero_fill", "copy_probe")) or "elementwise" in name or "distribution" in name
+
+
 fd, wd, steps, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
+commit = sys.argv[5] if len(sys.argv) > 5 else None
 fetch, write = collect(fd, "FETCH_SIZE", 2.0), collect(wd, "WRITE_SIZE", 1.0)
-res = {k: {"fetch": fetch.get(k, 0) / steps, "write": write.get(k, 0) / steps} for k in sorted(set(fetch) | set(write))}
+names = sorted(set(fetch) | set(write))
+res = {k: {"fetch": fetch.get(k, 0) / steps, "write": write.get(k, 0) / steps} for k in names if not is_setup(k)}
+setup = {k: {"fetch": fetch.get(k, 0), "write": write.get(k, 0)} for k in names if is_setup(k)}
+res["_setup_per_process"] = setup
+res["_meta"] = {"commit": commit, "steps_per_process": steps, "units": "bytes per step (FETCH_SIZE x 2, WRITE_SIZE x 1, KiB counters); _setup_per_process: bytes per process"}
 json.dump(res, open(out, "w"), indent=1)
-tot = sum(v["fetch"] + v["write"] for v in res.values())
-for k, v in sorted(res.items(), key=lambda kv: -(kv[1]["fetch"] + kv[1]["write"]))[:14]:
+step = {k: v for k, v in res.items() if not k.startswith("_")}
+tot = sum(v["fetch"] + v["write"] for v in step.values())
+for k, v in sorted(step.items(), key=lambda kv: -(kv[1]["fetch"] + kv[1]["write"]))[:16]:
     print(f"{k:22s} read {v['fetch']/1e9:7.3f} GB  write {v['write']/1e9:7.3f} GB  per step")
-print(f"total {tot/1e9:.2f} GB per step")
+print(f"total {tot/1e9:.2f} GB per step (set-up kernels excluded: {sum(v['fetch'] + v['write'] for v in setup.values())/1e9:.2f} GB per process)")
+if commit:
+    print("commit", commit)

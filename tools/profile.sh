@@ -14,7 +14,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p
 cd $R
 python tools/rocpd_summary.py gpurun_out/prof_${TAG}_${WL}_trace/*results.db > gpurun_out/${TAG}_${WL}_kernel_stats.txt
 # bench.py runs warm-up + the per-kernel pass + the timed pass: 1 + 2 + 2 = 5 steps per process
-python tools/pmc_cfg3.py gpurun_out/prof_${TAG}_${WL}_fetch gpurun_out/prof_${TAG}_${WL}_write 5 gpurun_out/${TAG}_pmc_${WL}_hbm_bytes.json > gpurun_out/${TAG}_pmc_${WL}_hbm_bytes.txt
+python tools/pmc_cfg3.py gpurun_out/prof_${TAG}_${WL}_fetch gpurun_out/prof_${TAG}_${WL}_write 5 gpurun_out/${TAG}_pmc_${WL}_hbm_bytes.json "${GF_COMMIT:-$(cat .gf_commit 2>/dev/null)}" > gpurun_out/${TAG}_pmc_${WL}_hbm_bytes.txt
 rm -rf gpurun_out/prof_${TAG}_${WL}_fetch gpurun_out/prof_${TAG}_${WL}_write gpurun_out/prof_${TAG}_${WL}_trace
 head -16 gpurun_out/${TAG}_${WL}_kernel_stats.txt
 cat gpurun_out/${TAG}_pmc_${WL}_hbm_bytes.txt
