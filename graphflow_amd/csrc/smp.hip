@@ -1007,26 +1007,12 @@ gf_status gf_smp_create(gf_ctx *ctx, const gf_smp_config *cfg, gf_smp **out) { r
 
 }  // extern "C"
 
-// pad_channels = false: compute at the configuration's own channel counts (the towers of a model with RisiContraction_18_dropout --
-// SMP_sigma_pairgraphs -- whose levels run op by op, where a padded width only costs)
-gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channels, gf_smp **out, int min_pad) {
-    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
-    if (!cfg || !out) return fail(ctx, GF_ERR_INVALID, "gf_smp_create: null argument");
-    if (cfg->nLevels < 1 || cfg->nChanels < 1 || cfg->nFeatures < 1 || cfg->nDepth < 0 || cfg->max_receptive_field < 1)
-        return fail(ctx, GF_ERR_INVALID, "gf_smp_create: bad configuration");
-    gfsmp::table_alloc = gf::pinned_table_alloc;   // (before the first table is built; idempotent)
-    gfsmp::table_free = gf::pinned_table_free;
-    gf_smp *s = new gf_smp();
-    s->ctx = ctx;
-    s->cfg.nLevels = cfg->nLevels;
-    s->cfg.nChanels = cfg->nChanels;
-    s->cfg.nFeatures = cfg->nFeatures;
-    s->cfg.nDepth = cfg->nDepth;
-    s->cfg.max_receptive_field = cfg->max_receptive_field;
-    s->cfg.has_WL_ordering = cfg->has_WL_ordering;
-    s->cfg.nContractions = cfg->nContractions ? cfg->nContractions : 18;
-    s->cfg.custom_matmul = cfg->custom_matmul ? 1 : 0;
-    s->cfg.physics = cfg->physics ? 1 : 0;
+// What the device computes with (gf_smp::cfg, dup_channels, n_extra), derived from the caller's configuration (gf_smp::ucfg).
+// allow_embed = false: the `_10` / `_50` families on their own op-by-op levels whatever the environment says -- gf_smp_prepare switches a
+// handle to that plan for a batch the embedding in the 18-slice level cannot take (an asymmetric adjacency, Coulomb entries <= 0, a `_50`
+// Coulomb batch) and back for the next batch it can (round-5 advice: the refusal used to surface mid-epoch, with an environment variable
+// read at create time as the only way out).  The caller's parameter layout does not depend on the plan.
+void gf::smp_derive_plan(gf_smp *s, bool allow_embed) {
     // Round 4: the channel count the DEVICE computes with.  The dedicated kernels of the fused level exist at 32 and 64 channels, the
     // generic fused level needs C % 4 == 0, and anything else ran the op-by-op level on the one-thread-per-element contraction kernels
     // (the reference's own tests use nChanels = 10: 35.8 ms per 1024-molecule step, against 8.0 ms at 12 channels and 4.1 ms at 32).
@@ -1034,7 +1020,11 @@ gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channel
     // features are zero, LeakyReLU(0) = 0 keeps them zero through every level, so the real channels see exactly the sums they saw
     // before (plus zero terms).  ucfg keeps the caller's layout: parameters, gradients, features and activations cross the C ABI in
     // it and are padded / cropped at the boundary (gf_smp_forward / gf_smp_backward).  GF_SMP_PAD_CHANNELS=0: compute at nChanels.
-    s->ucfg = s->cfg;
+    const bool pad_channels = s->req_pad_channels;
+    const int min_pad = s->req_min_pad;
+    s->cfg = s->ucfg;
+    s->dup_channels = 0;
+    s->n_extra = 0;
     {
         const char *e = std::getenv("GF_SMP_PAD_CHANNELS");
         const int C = s->cfg.nChanels;
@@ -1051,12 +1041,12 @@ gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channel
             if (s->cfg.physics) s->cfg.uniform = 1;
         }
         // SMP_2D_ver6 (RisiContraction_10) embedded in the 18-slice fused level (see gf_smp::dup_channels): 2 C channels padded to 16 / 32 / 64.
-        // GF_SMP_VER6_FUSED=0: the `_10` contraction op by op.  gf_smp_prepare refuses an asymmetric adjacency in this mode.
+        // GF_SMP_VER6_FUSED=0: the `_10` contraction op by op.  gf_smp_prepare switches to that plan by itself for a batch with an asymmetric adjacency.
         // (only where every field fits the fused level -- max_receptive_field <= 32: on an op-by-op level the 18-slice model at 2 C padded
         //  channels moves more than the `_10` / `_50` contraction at C; GF_SMP_VER6_FUSED=2 / GF_SMP_VER7_FUSED=2 embed at any cap)
         auto embed = [&](const char *name) {
             const char *v = std::getenv(name);
-            if (v && v[0] == '0') return false;
+            if (!allow_embed || (v && v[0] == '0')) return false;
             return s->cfg.max_receptive_field <= 32 || (v && v[0] == '2');
         };
         if (pad_channels && !(e && e[0] == '0') && s->cfg.nContractions == 10 && 2 * C <= 64 && s->cfg.nLevels < gf::kPadMaxLevels && !s->cfg.physics &&
@@ -1084,6 +1074,32 @@ gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channel
         }
         s->cfg.nChanels = Cc;
     }
+}
+
+// pad_channels = false: compute at the configuration's own channel counts (the towers of a model with RisiContraction_18_dropout --
+// SMP_sigma_pairgraphs -- whose levels run op by op, where a padded width only costs)
+gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channels, gf_smp **out, int min_pad) {
+    if (!ctx) return fail(nullptr, GF_ERR_INVALID, "null context");
+    if (!cfg || !out) return fail(ctx, GF_ERR_INVALID, "gf_smp_create: null argument");
+    if (cfg->nLevels < 1 || cfg->nChanels < 1 || cfg->nFeatures < 1 || cfg->nDepth < 0 || cfg->max_receptive_field < 1)
+        return fail(ctx, GF_ERR_INVALID, "gf_smp_create: bad configuration");
+    gfsmp::table_alloc = gf::pinned_table_alloc;   // (before the first table is built; idempotent)
+    gfsmp::table_free = gf::pinned_table_free;
+    gf_smp *s = new gf_smp();
+    s->ctx = ctx;
+    s->cfg.nLevels = cfg->nLevels;
+    s->cfg.nChanels = cfg->nChanels;
+    s->cfg.nFeatures = cfg->nFeatures;
+    s->cfg.nDepth = cfg->nDepth;
+    s->cfg.max_receptive_field = cfg->max_receptive_field;
+    s->cfg.has_WL_ordering = cfg->has_WL_ordering;
+    s->cfg.nContractions = cfg->nContractions ? cfg->nContractions : 18;
+    s->cfg.custom_matmul = cfg->custom_matmul ? 1 : 0;
+    s->cfg.physics = cfg->physics ? 1 : 0;
+    s->ucfg = s->cfg;
+    s->req_pad_channels = pad_channels;
+    s->req_min_pad = min_pad;
+    gf::smp_derive_plan(s, /*allow_embed=*/true);
     if (s->cfg.physics && (s->cfg.nDepth != 0 || s->cfg.nContractions != 18 || s->cfg.custom_matmul)) {
         delete s;
         return fail(ctx, GF_ERR_INVALID, "gf_smp_create: a physics tower has nDepth 0 (raw features), RisiContraction_18 and [18 C', C] weights");
@@ -1098,6 +1114,26 @@ gf_status gf::smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channel
         s->bwd_gather = (e && e[0] == '0') ? 0 : 1;
     }
     *out = s;
+    return GF_OK;
+}
+
+// Moves a handle between its two plans (see smp_derive_plan).  Everything sized by the device-side configuration goes: the batch's
+// buffers (release), the padded parameter / gradient / feature copies.  What is in the caller's layout stays: the handle-owned model,
+// the optimiser's moments, the pool of device blocks.
+gf_status gf::smp_switch_plan(gf_smp *s, bool embed) {
+    gf_ctx *ctx = s->ctx;
+    if (s->ev_last && s->used) GF_HIP_TRY(ctx, hipEventSynchronize(s->ev_last));   // (the handle's last launch: its padded buffers are about to go)
+    GF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    gf::release(s);
+    if (s->pad_p) (void)hipFree(s->pad_p);
+    if (s->pad_g) (void)hipFree(s->pad_g);
+    if (s->pad_feat) (void)hipFree(s->pad_feat);
+    s->pad_p = s->pad_g = s->pad_feat = nullptr;
+    s->pad_feat_n = 0;
+    s->extra_w = nullptr;
+    s->extra_g = nullptr;
+    gf::smp_derive_plan(s, embed);
+    s->embed_auto_off = !embed;
     return GF_OK;
 }
 
@@ -1337,30 +1373,34 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
     if (nMol <= 0 || !nVertices || !adj || !feature) return fail(ctx, GF_ERR_INVALID, "gf_smp_prepare: bad argument");
     for (int m = 0; m < nMol; ++m)
         if (nVertices[m] <= 0 || nVertices[m] > 4096) return fail(ctx, GF_ERR_INVALID, "molecule %d has %d vertices", m, nVertices[m]);
-    if (s->n_extra && coulomb)   // (SMP_2D_ver7 on the 18-slice level: cases 25, 41, 42, 45 are taken with the adjacency's diagonal = 1)
-        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare_coulomb: the fused RisiContraction_50 level needs the unit diagonal of a reduced adjacency "
-                    "-- create the handle with GF_SMP_VER7_FUSED=0 for the op-by-op level");
-    if (s->dup_channels) {   // SMP_2D_ver6 / ver7 on the 18-slice level: the identities behind it need row sums = column sums
+    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (s->dup_channels || s->embed_auto_off) {
+        // SMP_2D_ver6 / ver7 on the 18-slice level: the identities behind the embedding need a symmetric, non-negative adjacency (row sums =
+        // column sums), for `_50` the unit diagonal of a reduced adjacency (cases 25, 41, 42, 45: no Coulomb mode), and in Coulomb mode
+        // positive entries (RisiContraction_18 drops A <= 0 -- its `if (adj_value > 0)` -- and RisiContraction_10 does not).  A batch that
+        // does not qualify runs on the op-by-op `_10` / `_50` levels, which take anything the reference takes; the plan is per batch.
+        const bool is50 = s->ucfg.nContractions == 50;
+        bool embeddable = !(is50 && coulomb);
         const int *a = adj;
         const double *cm = coulomb;
-        for (int m = 0; m < nMol; ++m) {
+        for (int m = 0; m < nMol && embeddable; ++m) {
             const int V = nVertices[m];
-            // (Coulomb mode: RisiContraction_18 drops the entries A <= 0 -- its `if (adj_value > 0)` -- and RisiContraction_10 does not)
             if (cm)
-                for (int i = 0; i < V * V; ++i)
-                    if (!(cm[i] > 0.0))
-                        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare_coulomb: molecule %d has a Coulomb entry <= 0; the fused RisiContraction_10 "
-                                    "level (computed through the gated RisiContraction_18) needs positive ones -- create the handle with GF_SMP_VER6_FUSED=0", m);
-            for (int i = 0; i < V; ++i)
+                for (int i = 0; i < V * V && embeddable; ++i) embeddable = cm[i] > 0.0;
+            for (int i = 0; i < V && embeddable; ++i)
                 for (int j = i + 1; j < V; ++j)
-                    if (a[i * V + j] < 0 || a[i * V + j] != a[j * V + i] || (cm && cm[i * V + j] != cm[j * V + i]))
-                        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_smp_prepare: molecule %d has an asymmetric (or negative) adjacency entry (%d, %d); the fused RisiContraction_10 / _50 "
-                                    "level needs a symmetric one -- create the handle with GF_SMP_VER6_FUSED=0 / GF_SMP_VER7_FUSED=0 for the op-by-op level", m, i, j);
+                    if (a[i * V + j] < 0 || a[i * V + j] != a[j * V + i] || (cm && cm[i * V + j] != cm[j * V + i])) {
+                        embeddable = false;
+                        break;
+                    }
             a += (size_t)V * V;
             if (cm) cm += (size_t)V * V;
         }
+        if (embeddable != (s->dup_channels != 0)) {
+            gf_status stp = gf::smp_switch_plan(s, embeddable);
+            if (stp != GF_OK) return stp;
+        }
     }
-    GF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool prep_timing = std::getenv("GF_PREP_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     if (!s->upload) {

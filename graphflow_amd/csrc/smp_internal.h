@@ -89,6 +89,8 @@ gf_status smp_wgrad_partials_c64(gf_ctx *ctx, const float *T, const float *dO, c
 namespace gf {
 // min_pad: the smallest padded width the handle may compute at (32 for the towers of a slice-dropout model)
 gf_status smp_create(gf_ctx *ctx, const gf_smp_config *cfg, bool pad_channels, gf_smp **out, int min_pad = 0);   // gf_smp_create = (.., true, ..)
+void smp_derive_plan(gf_smp *s, bool allow_embed);
+gf_status smp_switch_plan(gf_smp *s, bool embed);
 constexpr int kPadMaxLevels = 15;   // levels a padded model's layout map holds (gf_smp_create: deeper models compute at nChanels)
 }
 struct gf_smp {
@@ -107,6 +109,10 @@ struct gf_smp {
     // are n_extra = 3 more C x C products on the level's tables -- (S_ab, 1), (S_bc, 1), (S_bc, tr) -- whose weights X_l sit BEHIND the
     // padded parameter vector ([.. W | X_1 | .. | X_L], three [Cc][Cc] blocks per level) and run as plain fp32 GEMMs on T
     int n_extra = 0;
+    // what gf_smp_create was asked for (smp_derive_plan re-derives cfg / dup_channels / n_extra from ucfg and these), and whether the handle
+    // currently runs its `_10` / `_50` levels op by op because the prepared batch cannot be embedded (gf_smp_prepare switches per batch)
+    bool req_pad_channels = true, embed_auto_off = false;
+    int req_min_pad = 0;
     const float *extra_w = nullptr;   // X of the running pass (set by gf_smp_forward / gf_smp_backward)
     float *extra_g = nullptr;         // ... and its gradient
     float *rs_inv = nullptr;          // [rows of the largest level][2] (1 / tot, tr / tot): the extra products of an op-by-op level

@@ -234,9 +234,10 @@ typedef struct {
      * fields give SMP_omega.  Those models have no receptive-field cap: pass max_receptive_field = max_nVertices.
      * Since round 5 the `_10` and `_50` families (nChanels <= 32) are computed on the fused RisiContraction_18 level: for a symmetric
      * reduced adjacency with a unit diagonal their slices are slices of `_18` on the activations and on their per-node transposes (plus
-     * three extra products for `_50`); the parameter / gradient layout at this interface stays the caller's.  gf_smp_prepare then refuses
-     * an asymmetric adjacency -- and gf_smp_prepare_coulomb a `_50` model, or a `_10` model with a Coulomb entry <= 0 -- with GF_ERR_UNSUPPORTED; GF_SMP_VER6_FUSED=0 /
-     * GF_SMP_VER7_FUSED=0 at create time select the op-by-op `_10` / `_50` levels, which take any adjacency. */
+     * three extra products for `_50`); the parameter / gradient layout at this interface stays the caller's.  A batch the embedding cannot
+     * take -- an asymmetric or negative adjacency, a `_50` Coulomb batch, a `_10` Coulomb batch with an entry <= 0 -- is computed on the
+     * op-by-op `_10` / `_50` levels instead: gf_smp_prepare picks the plan per batch (round 6; it used to refuse with GF_ERR_UNSUPPORTED),
+     * nothing changes at this interface.  GF_SMP_VER6_FUSED=0 / GF_SMP_VER7_FUSED=0 at create time select the op-by-op levels for every batch. */
     int nContractions, custom_matmul;
     /* physics = 1: one TOWER of the `_physics` / `_pairgraphs` models (GraphFlow/SMP_omega_physics.h:29-170, :480-606;
      * SMP_omega_pairgraphs.h builds two of them): raw vertex features (nDepth must be 0; no WL histogram or ordering, the

@@ -1294,36 +1294,44 @@ def test_smp_2d_ver6_on_the_fused_level_equals_the_op_by_op_level(gf, monkeypatc
     for r in (a, a2, b):
         r[3].close()
     monkeypatch.delenv("GF_SMP_VER6_FUSED")
+    # Round 6 (round-5 advice): a batch the embedding cannot take -- an asymmetric adjacency, a Coulomb matrix with entries <= 0 (`_18` gates
+    # A > 0, `_10` does not) -- is no longer refused at gf_smp_prepare: the handle computes it on the op-by-op `_10` levels and goes back to
+    # the fused level for the next batch that qualifies.  Held against a handle created op-by-op (GF_SMP_VER6_FUSED=0), bit for bit.
     net = SMPOmega(L, C, F, D, cap, True, nContractions=10, custom_matmul=custom)
     adj, feat, _ = synthetic_molecule(7100, nV=6)
     bad = np.array(adj).copy()
     i, j = np.argwhere(bad > 0)[0]
     bad[j, i] = 0 if i != j else bad[j, i]
-    if not np.array_equal(bad, bad.T):
-        with pytest.raises(Exception, match="asymmetric"):
-            net.prepare([(bad, feat)])
-    # Coulomb mode: a positive symmetric matrix runs (RisiContraction_18's `A > 0` gate passes everything) and agrees with the op-by-op
-    # `_10` level; a signed one is refused (the gate would drop entries RisiContraction_10 keeps)
+    assert not np.array_equal(bad, bad.T)
     rng = np.random.default_rng(5)
     cpos = rng.uniform(0.1, 2.0, (6, 6))
     cpos = 0.5 * (cpos + cpos.T)
     p = dev(f32exact(rng.uniform(-1, 1, net.n_params) / np.sqrt(10 * C)))
-    net.prepare([(adj, feat)], coulomb=[cpos])
-    pa, _, fa = net.forward(p, dev(np.array([1.0])))
-    ga = torch.zeros(net.n_params, device="cuda")
-    net.backward(p, ga)
-    with pytest.raises(Exception, match="Coulomb entry"):
-        net.prepare([(adj, feat)], coulomb=[cpos - 1.0])
+    one = dev(np.array([1.0]))
+
+    def run(h, mol, coulomb=None):
+        h.prepare([mol], coulomb=coulomb)
+        pr, _, ft = h.forward(p, one)
+        g = torch.full((h.n_params,), float("nan"), device="cuda")
+        h.backward(p, g)
+        return pr.cpu().numpy(), ft.cpu().numpy(), g.cpu().numpy()
+
+    first = run(net, (adj, feat))                       # fused (embedded) plan
+    asym = run(net, (bad, feat))                        # -> op-by-op plan, by itself
+    signed = run(net, (adj, feat), [cpos - 1.0])        # Coulomb entries <= 0: op-by-op as well
+    pos = run(net, (adj, feat), [cpos])                 # positive symmetric Coulomb matrix: back on the fused level
+    again = run(net, (adj, feat))                       # and the first batch once more: the same bits as before the detour
+    assert all(np.array_equal(x, y) for x, y in zip(first, again))
     net.close()
     monkeypatch.setenv("GF_SMP_VER6_FUSED", "0")
     ref = SMPOmega(L, C, F, D, cap, True, nContractions=10, custom_matmul=custom)
-    ref.prepare([(adj, feat)], coulomb=[cpos])
-    pb, _, fb = ref.forward(p, dev(np.array([1.0])))
-    gb = torch.zeros(ref.n_params, device="cuda")
-    ref.backward(p, gb)
-    assert rel_err(pa.cpu().numpy(), pb.cpu().numpy()) <= TOL_FWD and rel_err(fa.cpu().numpy(), fb.cpu().numpy()) <= TOL_FWD
-    assert rel_err(ga.cpu().numpy(), gb.cpu().numpy()) <= TOL_SELF
+    r_asym, r_signed, r_pos = run(ref, (bad, feat)), run(ref, (adj, feat), [cpos - 1.0]), run(ref, (adj, feat), [cpos])
     ref.close()
+    for got, want in ((asym, r_asym), (signed, r_signed)):
+        assert np.isfinite(got[2]).all() and all(np.array_equal(x, y) for x, y in zip(got, want))   # the same plan: the same bits
+    assert rel_err(pos[0], r_pos[0]) <= TOL_FWD and rel_err(pos[1], r_pos[1]) <= TOL_FWD
+    assert rel_err(pos[2], r_pos[2]) <= TOL_SELF
+    assert not np.array_equal(pos[2], r_pos[2])          # (really the other plan)
 
 
 @pytest.mark.parametrize("C,fused,cap,coul", [(64, True, 29, False), (8, False, 6, False), (16, True, 12, True)])
