@@ -23,6 +23,23 @@
 #include "gf_internal.h"
 #include "r18_device.h"
 
+// r18_bwd_slab's streaming accesses (A/B switches: -DGF_NT_BS_LD=0 / -DGF_NT_BS_ST=0)
+#ifndef GF_NT_BS_LD
+#define GF_NT_BS_LD 1
+#endif
+#ifndef GF_NT_BS_ST
+#define GF_NT_BS_ST 1
+#endif
+#if GF_NT_BS_LD
+#define BS_LD ld4_nt
+#else
+#define BS_LD ld4
+#endif
+#if GF_NT_BS_ST
+#define BS_ST st4_nt
+#else
+#define BS_ST st4
+#endif
 namespace gf {
 namespace {
 
@@ -46,8 +63,8 @@ template <int LPC, int NI, bool FULL>
 __device__ __forceinline__ void load_slab_row(__amdgpu_buffer_rsrc_t slab, int row_bytes, const SlabLane<LPC, NI> &ln,
                                               int dgoff_bytes, f4 (&v)[NI], f4 &dg) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) v[i] = buf_ld4(slab, ln.coff[i], row_bytes);
-    dg = buf_ld4(slab, dgoff_bytes, row_bytes);
+    for (int i = 0; i < NI; ++i) v[i] = buf_ld4_nt(slab, ln.coff[i], row_bytes);
+    dg = buf_ld4_nt(slab, dgoff_bytes, row_bytes);
 }
 
 template <int LPC, int NI, bool FULL>
@@ -133,14 +150,14 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
         const size_t wab = (rowbase + (size_t)a * N + b) * (size_t)C + f;         // ws[g][a][b][f]
         if (cg == 0) {
             if (fok) {
-                st4(Out + oab + 0 * C, sab * tot);  // k0  S_ab*tot
+                st4_nt(Out + oab + 0 * C, sab * tot);  // k0  S_ab*tot
                 st4(wsDbb + wab, dv);               // P[a,b,b] for F2
             }
         } else if (cg == 1) {
-            if (fok) st4(Out + oab + 6 * C, sab * tr);  // k6  S_ab*tr
+            if (fok) st4_nt(Out + oab + 6 * C, sab * tr);  // k6  S_ab*tr
             st4(sDac + a * CW + 4 * fl, dv);            // P[a,b,a]
         } else if (cg == 2) {
-            if (fok) st4(Out + oab + 5 * C, t6);  // k5  sum_c P[a,b,c] r[c]
+            if (fok) st4_nt(Out + oab + 5 * C, t6);  // k5  sum_c P[a,b,c] r[c]
         } else if (cg == 3) {
             if (fok) st4(wsSab + wab, sab);
             st4(sSab + a * CW + 4 * fl, sab);
@@ -182,8 +199,8 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
             cs += sv;
             st4(sSbc + c * CW + 4 * fl, sv);
             if (FULL || ln.cmask[i] != 0.f) {
-                st4(obc + (size_t)c * (kK * C) + 2 * C, sbc[i] * tot);  // k2  S_bc*tot
-                st4(obc + (size_t)c * (kK * C) + 9 * C, t10[i]);        // k9  sum_a r[a] P[a,b,c]
+                st4_nt(obc + (size_t)c * (kK * C) + 2 * C, sbc[i] * tot);  // k2  S_bc*tot
+                st4_nt(obc + (size_t)c * (kK * C) + 9 * C, t10[i]);        // k9  sum_a r[a] P[a,b,c]
             }
         }
         cs = reduce_cgroups<LPC>(cs);
@@ -209,11 +226,11 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_slab(const float *__restrict
         const float rd = L.r[d];
         if (fok) {
             float *o = Out + (rowbase + (size_t)b * N + d) * (size_t)(kK * C) + f;
-            st4(o + 3 * C, colsum * rd);   // k3   (sum_{a,c} P[a,b,c]) r[d]
-            st4(o + 10 * C, dactot * rd);  // k10  (sum_a P[a,b,a]) r[d]
-            st4(o + 11 * C, m[0]);         // k11  sum_e A[d,e] S_ab[e,b]
-            st4(o + 12 * C, m[1]);         // k12  sum_e A[d,e] S_bc[b,e]
-            st4(o + 16 * C, m[2]);         // k16  sum_e A[d,e] P[e,b,e]
+            st4_nt(o + 3 * C, colsum * rd);   // k3   (sum_{a,c} P[a,b,c]) r[d]
+            st4_nt(o + 10 * C, dactot * rd);  // k10  (sum_a P[a,b,a]) r[d]
+            st4_nt(o + 11 * C, m[0]);         // k11  sum_e A[d,e] S_ab[e,b]
+            st4_nt(o + 12 * C, m[1]);         // k12  sum_e A[d,e] S_bc[b,e]
+            st4_nt(o + 16 * C, m[2]);         // k16  sum_e A[d,e] P[e,b,e]
         }
     }
     if (grp == 0 && fok) {
@@ -306,14 +323,14 @@ __global__ __launch_bounds__(kThreads) void r18_fwd_rows(const float *__restrict
         const float ry = L.r[y], aay = L.at(a, y, N);
         if (fok) {
             float *o = Out + (rowbase + (size_t)a * N + y) * (size_t)(kK * C) + f;
-            st4(o + 1 * C, rowsum * ry);  // k1   (sum_{b,c} P[a,b,c]) r[d]
-            st4(o + 7 * C, d8 * ry);      // k7   (sum_b P[a,b,b]) r[d]
-            st4(o + 8 * C, m[0]);         // k8   sum_e A[d,e] S_ab[a,e]
-            st4(o + 15 * C, m[1]);        // k15  sum_e A[d,e] P[a,e,e]
-            st4(o + 4 * C, total * aay);  // k4   A[d,e] sum_{abc} P          (d = a, e = y)
-            st4(o + 13 * C, s14 * aay);   // k13  A[d,e] sum_{a,c} P[a,a,c]
-            st4(o + 14 * C, s15 * aay);   // k14  A[d,e] sum_{a,b} P[a,b,b]
-            st4(o + 17 * C, s18 * aay);   // k17  A[d,e] sum_a P[a,a,a]
+            st4_nt(o + 1 * C, rowsum * ry);  // k1   (sum_{b,c} P[a,b,c]) r[d]
+            st4_nt(o + 7 * C, d8 * ry);      // k7   (sum_b P[a,b,b]) r[d]
+            st4_nt(o + 8 * C, m[0]);         // k8   sum_e A[d,e] S_ab[a,e]
+            st4_nt(o + 15 * C, m[1]);        // k15  sum_e A[d,e] P[a,e,e]
+            st4_nt(o + 4 * C, total * aay);  // k4   A[d,e] sum_{abc} P          (d = a, e = y)
+            st4_nt(o + 13 * C, s14 * aay);   // k13  A[d,e] sum_{a,c} P[a,a,c]
+            st4_nt(o + 14 * C, s15 * aay);   // k14  A[d,e] sum_{a,b} P[a,b,b]
+            st4_nt(o + 17 * C, s18 * aay);   // k17  A[d,e] sum_a P[a,a,a]
         }
     }
 }
@@ -355,8 +372,8 @@ __global__ __launch_bounds__(kThreads) void r18_bwd_rows(const float *__restrict
 
     const float *Grow = G + (rowbase + (size_t)a * N) * (size_t)(kK * C) + f;  // + (y*18 + k)*C
     for (int d = grp; d < N; d += NGRP) {
-        st4(sT8 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 8) * C) : splat(0.f));
-        st4(sT15 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 15) * C) : splat(0.f));
+        st4(sT8 + d * CW + 4 * fl, fok ? ld4_nt(Grow + ((size_t)d * kK + 8) * C) : splat(0.f));
+        st4(sT15 + d * CW + 4 * fl, fok ? ld4_nt(Grow + ((size_t)d * kK + 15) * C) : splat(0.f));
     }
     {   // six length-N reductions, each split in two halves over 12 thread groups
         const int j = grp % 6, half = grp / 6;
@@ -445,9 +462,9 @@ __global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restr
 
     const float *Grow = G + (rowbase + (size_t)b * N) * (size_t)(kK * C) + f;  // G[g][b][y][k][f]
     for (int d = grp; d < N; d += NGRP) {
-        st4(sT11 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 11) * C) : splat(0.f));
-        st4(sT12 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 12) * C) : splat(0.f));
-        st4(sT16 + d * CW + 4 * fl, fok ? ld4(Grow + ((size_t)d * kK + 16) * C) : splat(0.f));
+        st4(sT11 + d * CW + 4 * fl, fok ? BS_LD(Grow + ((size_t)d * kK + 11) * C) : splat(0.f));
+        st4(sT12 + d * CW + 4 * fl, fok ? BS_LD(Grow + ((size_t)d * kK + 12) * C) : splat(0.f));
+        st4(sT16 + d * CW + 4 * fl, fok ? BS_LD(Grow + ((size_t)d * kK + 16) * C) : splat(0.f));
     }
     {   // six length-N reductions, each split in two halves over 12 thread groups
         const int j = grp % 6, half = grp / 6;
@@ -487,10 +504,10 @@ __global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restr
             small_matvec<3, CW>(L, N, yy, fl, T, m);  // V12[y], V13[y], V17[y]
             const int fc = fok ? f : 0;
             const float *gab = G + (rowbase + (size_t)yy * N + b) * (size_t)(kK * C) + fc;  // G[g][y][b][k][f]
-            const f4 g0 = ld4(gab + 0 * C), g6 = ld4(gab + 6 * C), g5 = ld4(gab + 5 * C);
+            const f4 g0 = BS_LD(gab + 0 * C), g6 = BS_LD(gab + 6 * C), g5 = BS_LD(gab + 5 * C);
             const size_t w = (rowbase + (size_t)yy * N + b) * (size_t)C + fc;
             const f4 wx = ld4(wsWX + w), wz = ld4(wsWZ + w);
-            const f4 g2 = ld4(G + (rowbase + (size_t)b * N + yy) * (size_t)(kK * C) + 2 * C + fc);
+            const f4 g2 = BS_LD(G + (rowbase + (size_t)b * N + yy) * (size_t)(kK * C) + 2 * C + fc);
             f4 x = tot * g0 + tr * g6 + wx + u4 + u5 + m[0];
             f4 z1 = wz + u15;
             if (yy == b) {
@@ -534,7 +551,7 @@ __global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restr
         coff[i] = cc * C + fld;
         rc[i] = L.r[cc];
         yv[i] = ld4(sY + cc * CW + 4 * fl);
-        g9[i] = ld4(G + (rowbase + (size_t)b * N + cc) * (size_t)(kK * C) + 9 * C + fld);
+        g9[i] = BS_LD(G + (rowbase + (size_t)b * N + cc) * (size_t)(kK * C) + 9 * C + fld);
     }
     const int ib = b / PPW, cgb = b % PPW;
     float *dPg = dP + pbase * C + (size_t)b * N * C;
@@ -557,7 +574,7 @@ __global__ __launch_bounds__(kThreads, 3) void r18_bwd_slab(const float *__restr
             if (i == ib) o += z1;  // wave-uniform conditions: scalar branches
             if (i == ia) o += z2;
             if (ACC) o += old[i];
-            if (FULL || live[i]) st4(row + coff[i], o);
+            if (FULL || live[i]) BS_ST(row + coff[i], o);
         }
     }
 }

@@ -34,6 +34,34 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff_bytes
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff_bytes, soff_bytes, 0);
 }
 
+// Streaming (non-temporal) forms for data that is touched ONCE by a kernel -- the big operands it streams in and the results it streams
+// out: `nt` on BOTH sides of a streaming kernel is worth 8 - 10 % of a copy's rate on MI355X (tools/micro/copy_probe.hip: 5.5 -> 6.0 - 6.3
+// TB/s; `nt` on the loads alone or on the stores alone: nothing), tables and workspaces that are re-read soon keep the default policy.
+// GF_NT=0 builds the plain forms (A/B runs: tools/ab_lib.sh).
+#ifndef GF_NT
+#define GF_NT 1
+#endif
+__device__ __forceinline__ f4 ld4_nt(const float *p) {
+#if GF_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+#else
+    return ld4(p);
+#endif
+}
+__device__ __forceinline__ void st4_nt(float *p, f4 v) {
+#if GF_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+#else
+    st4(p, v);
+#endif
+}
+__device__ __forceinline__ f4 buf_ld4_nt(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, GF_NT ? 2 : 0));   // (aux bit 1 = nt)
+}
+__device__ __forceinline__ void buf_st4_nt(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes, f4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff_bytes, soff_bytes, GF_NT ? 2 : 0);
+}
+
 __device__ __forceinline__ f4 shfl_xor4(f4 v, int m) {
     f4 r;
     r.x = __shfl_xor(v.x, m);
