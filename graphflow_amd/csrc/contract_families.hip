@@ -22,6 +22,11 @@
 #include "gf_internal.h"
 #include "r18_device.h"
 
+// Non-temporal stores of the families' big results (A/B: -DGF_NT_FAM=<mask>): 1 fam50_tables_out's fifteen slices of Out,
+// 2 fam50_forward_mfma's slices of Out, 4 fam_backward_rows' dP.  (r18_device.h: why `nt` on the streams pays.)
+#ifndef GF_NT_FAM
+#define GF_NT_FAM 7
+#endif
 namespace gf {
 namespace {
 
@@ -99,6 +104,8 @@ struct Vec<1> {
     using T = float;
     static __device__ __forceinline__ T ld(const float *p) { return *p; }
     static __device__ __forceinline__ void st(float *p, T v) { *p = v; }
+    template <int SITE>
+    static __device__ __forceinline__ void st_s(float *p, T v) { *p = v; }
     static __device__ __forceinline__ T zero() { return 0.f; }
 };
 template <>
@@ -106,6 +113,12 @@ struct Vec<4> {
     using T = vf4;
     static __device__ __forceinline__ T ld(const float *p) { return *reinterpret_cast<const vf4 *>(p); }
     static __device__ __forceinline__ void st(float *p, T v) { *reinterpret_cast<vf4 *>(p) = v; }
+    // results written once and read by a later kernel (GF_NT_FAM, below): non-temporal
+    template <int SITE>
+    static __device__ __forceinline__ void st_s(float *p, T v) {
+        if constexpr ((GF_NT_FAM & SITE) != 0) __builtin_nontemporal_store(v, reinterpret_cast<vf4 *>(p));
+        else *reinterpret_cast<vf4 *>(p) = v;
+    }
     static __device__ __forceinline__ T zero() { return vf4{0.f, 0.f, 0.f, 0.f}; }
 };
 
@@ -676,7 +689,7 @@ __global__ __launch_bounds__(256) void fam50_tables_out(const float *__restrict_
         Vec<4>::st(tg + 1 * NNC, acc[1]);
         Vec<4>::st(tg + 2 * NNC, acc[2]);
         float *o = Out + (((size_t)g * N + i) * N + j) * (size_t)(K * C) + f;
-#define OUTS(c, expr) Vec<4>::st(o + (size_t)((c) - 1) * C, (expr))
+#define OUTS(c, expr) Vec<4>::st_s<1>(o + (size_t)((c) - 1) * C, (expr))
         OUTS(1, acc[0] * tot);  OUTS(2, acc[1] * tot);  OUTS(5, acc[2] * tot);
         if constexpr (K == 50) {
             OUTS(11, acc[3]);       OUTS(12, acc[4]);       OUTS(13, acc[0] * tr);
@@ -912,6 +925,9 @@ __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned voff, un
 __device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
+__device__ __forceinline__ void bst_out(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {   // slices of Out (aux bit 1 = nt)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, (GF_NT_FAM & 2) ? 2 : 0);
+}
 
 template <int NS, bool SLIM>  // N <= 2 NS; SLIM: fam50_tables_out has written the fifteen slices that are tables already
 __global__ __launch_bounds__(256, 2) void fam50_forward_mfma(const float *__restrict__ P, const float *__restrict__ A,
@@ -952,7 +968,7 @@ __global__ __launch_bounds__(256, 2) void fam50_forward_mfma(const float *__rest
             const unsigned tY = y < uN ? (((unsigned)x * uN + y) * uC + (unsigned)f) * 4u : kOob;
             (void)tY;
             const float ry = r[yc], qy = q[yc], axy = Ag[x * N + (int)yc];
-#define OUTS(c, expr) bst(rO, oY[v], (unsigned)((c) - 1) * uC * 4u, (expr))
+#define OUTS(c, expr) bst_out(rO, oY[v], (unsigned)((c) - 1) * uC * 4u, (expr))
             if (!SLIM) {
                 float t[kNTab];
 #pragma unroll
@@ -998,8 +1014,8 @@ __global__ __launch_bounds__(256, 2) void fam50_forward_mfma(const float *__rest
         }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            bst(rO, oY[v], (unsigned)(c_yz - 1) * uC * 4u, d0[v]);
-            bst(rO, oY[v], (unsigned)(c_zy - 1) * uC * 4u, d1[v]);
+            bst_out(rO, oY[v], (unsigned)(c_yz - 1) * uC * 4u, d0[v]);
+            bst_out(rO, oY[v], (unsigned)(c_zy - 1) * uC * 4u, d1[v]);
         }
     };
     const unsigned xr = (unsigned)x * NC, xc = (unsigned)x * uC;
@@ -1496,7 +1512,7 @@ __global__ __launch_bounds__(256) void fam_backward_rows(const float *__restrict
                 if (a < N) {
                     float *out = dP + ((g * N + a) * N + b) * (size_t)N * C + (size_t)c * C + f;
                     if (ACC) v += Vec<VW>::ld(out);
-                    Vec<VW>::st(out, v);
+                    Vec<VW>::template st_s<4>(out, v);
                 }
             }
             cur = nxt;

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
             // every lane stores (c-groups 0/2 the S_ab block, 1/3 the T6 block; the pairs write identical values to the same
             // address): a store that all paths issue can be COUNTED by the compiler, so waiting for the next row's loads
             // (vmcnt is in order over loads and stores) need not include it; lane-conditional stores cannot (-5 %)
-            st4(tcol + a * tstep, both);  // table row (a, b)
+            gf_st_s<32>(reinterpret_cast<f4 *>(tcol + a * tstep), both);  // table row (a, b)
             if constexpr (VEC) {   // c-group 0 holds S_ab[a, b] and P[a, b, b]: into the wave's accumulators of row a
                 f4 *slot = (cg == 0) ? wacc + a * (2 * LPC) + fl : wdummy + fl;
                 const f4 r = slot[0] + both, d8 = slot[LPC] + dcur;
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
             cs += sbc[i];
             if (fok && (!skip_bc || (sFlag[b * N + cc[i]] & 2))) {
                 float *trow = T + (rowbase + (size_t)b * N + cc[i]) * (size_t)(T_COLS * C) + f;  // table row (b, c)
-                st4(trow + T_SBC * C, sbc[i]);
-                st4(trow + T_T10 * C, t10[i]);
+                gf_st_s<32>(reinterpret_cast<f4 *>(trow + T_SBC * C), sbc[i]);
+                gf_st_s<32>(reinterpret_cast<f4 *>(trow + T_T10 * C), t10[i]);
             }
         }
     }
@@ -1295,7 +1295,7 @@ __device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w, int chunk
                     f4 o = acc[q];
                     if (qoff + q == p) o += accd;
                     if (qoff + q == cw) o += accc;
-                    st4(dst + ((size_t)p * sw + qoff + q) * C + (f4b >> 2), o);
+                    gf_st_s<64>(reinterpret_cast<f4 *>(dst + ((size_t)p * sw + qoff + q) * C + (f4b >> 2)), o);
                 }
         }
     }

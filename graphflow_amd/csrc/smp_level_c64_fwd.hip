@@ -45,6 +45,13 @@ __device__ __forceinline__ void ff_st1(__amdgpu_buffer_rsrc_t r, int voff, float
 __device__ __forceinline__ float ff_ld1(__amdgpu_buffer_rsrc_t r, int voff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
 }
+// the streamed operands (O, f_l, df_l: read once) and results (f_l, dO: written once) -- aux bit 1 = nt (gf_internal.h: GF_NT_SITES 8 / 16)
+__device__ __forceinline__ float ff_ld1s(__amdgpu_buffer_rsrc_t r, int voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, (GF_NT_SITES & 8) ? 2 : 0));
+}
+__device__ __forceinline__ void ff_st1s(__amdgpu_buffer_rsrc_t r, int voff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, (GF_NT_SITES & 16) ? 2 : 0);
+}
 
 // pan[p] = {first row of the panel, rows | s << 8 | groups << 16 | x0 << 24, first row of the node, first pair of the node}
 // (x0 = index x of the panel's first row group inside its node); pan_node[p] = the node
@@ -100,11 +107,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int vo = rr < nrows ? (P.x + rr) * OB + colb : kFfOor;
-        m0[r] = ff_ld1(rO, vo);
-        u0[r] = ff_ld1(rO, vo + FB);
+        m0[r] = ff_ld1s(rO, vo);
+        u0[r] = ff_ld1s(rO, vo + FB);
         if constexpr (TWO) {
-            m1[r] = ff_ld1(rO, vo + 128);
-            u1[r] = ff_ld1(rO, vo + FB + 128);
+            m1[r] = ff_ld1s(rO, vo + 128);
+            u1[r] = ff_ld1s(rO, vo + FB + 128);
         } else {
             m1[r] = u1[r] = 0.f;
         }
@@ -180,8 +187,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         const int vo = rr < nrows ? (P.x + rr) * FB + colb : kFfOor;
         const float z0 = m0[r], z1 = m1[r];
         const float f0 = z0 > 0.f ? z0 : kAlphaFf * z0, f1 = z1 > 0.f ? z1 : kAlphaFf * z1;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f0), rF, vo, 0, 0);
-        if constexpr (TWO) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f1), rF, vo + 128, 0, 0);
+        ff_st1s(rF, vo, f0);
+        if constexpr (TWO) ff_st1s(rF, vo + 128, f1);
         if (rr < nrows) {   // (rows in register order: a fixed order)
             c0 += f0, c1 += f1;
             x0m = fmaxf(x0m, fabsf(f0)), x1m = fmaxf(x1m, fabsf(f1));
@@ -249,11 +256,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int vo = rr < nrows ? (P.x + rr) * FB + colb : kFfOor;
-        f0[r] = ff_ld1(rF, vo);
-        g0[r] = ff_ld1(rG, vo);
+        f0[r] = ff_ld1s(rF, vo);
+        g0[r] = ff_ld1s(rG, vo);
         if constexpr (TWO) {
-            f1[r] = ff_ld1(rF, vo + 128);
-            g1[r] = ff_ld1(rG, vo + 128);
+            f1[r] = ff_ld1s(rF, vo + 128);
+            g1[r] = ff_ld1s(rG, vo + 128);
         } else {
             f1[r] = g1[r] = 0.f;
         }
@@ -284,8 +291,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         x0m = fmaxf(x0m, fabsf(z0[r]));
         x1m = fmaxf(x1m, fabsf(z1[r]));
         const int vo = ok ? (P.x + rr) * OB + colb : kFfOor;
-        ff_st1(rO, vo, z0[r]);
-        if constexpr (TWO) ff_st1(rO, vo + 128, z1[r]);
+        ff_st1s(rO, vo, z0[r]);
+        if constexpr (TWO) ff_st1s(rO, vo + 128, z1[r]);
     }
     // dU = A'^T dz
     f16v u0, u1;
@@ -301,8 +308,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int vo = rr < nrows ? (P.x + rr) * OB + FB + colb : kFfOor;
-        ff_st1(rO, vo, u0[r]);
-        if constexpr (TWO) ff_st1(rO, vo + 128, u1[r]);
+        ff_st1s(rO, vo, u0[r]);
+        if constexpr (TWO) ff_st1s(rO, vo + 128, u1[r]);
     }
     // the per-(node, x) partials: tile row (t, g) = 8 t + g, weight of input row e: [group of e == g] * {r[y_e], A+[x_g, y_e], 1}
     f16v q0, q1;

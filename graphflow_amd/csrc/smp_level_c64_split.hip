@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
         const float *src = A + (size_t)src_row * LDA + blk * CB + VPL * lh;
         if constexpr (MASK) src = present ? src : sp_zero_page;  // (a select on the address: same requests, same registers)
 #pragma unroll
-        for (int q = 0; q < VPL / 4; ++q) R.a[q] = *reinterpret_cast<const f4v *>(src + 4 * q);
+        for (int q = 0; q < VPL / 4; ++q) R.a[q] = gf_ld_s<1>(reinterpret_cast<const f4v *>(src + 4 * q));
         __builtin_amdgcn_sched_barrier(0);
     };
     auto load_raw = [&](Raw &R, int p, int blk, bool present) {
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
                 for (int r = 0; r < 16; ++r) {
                     const int rr = (r & 3) + 8 * (r >> 2);
                     float *dst = ((mine >> rr) & 1u) ? out + (size_t)rr * LDOUT : dump + rr * 64;
-                    dst[0] = acc0[r];
-                    if constexpr (NH == 2) dst[32] = acc1[r];
+                    gf_st_s<2>(dst, acc0[r]);
+                    if constexpr (NH == 2) gf_st_s<2>(dst + 32, acc1[r]);
                 }
                 return;
             }
@@ -366,16 +366,16 @@ __global__ __launch_bounds__(kSpThreads, 1) void smp_rowpanel_split(const float 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
-                out[(size_t)rr * LDOUT] = acc0[r];
-                if constexpr (NH == 2) out[(size_t)rr * LDOUT + 32] = acc1[r];
+                gf_st_s<2>(out + (size_t)rr * LDOUT, acc0[r]);
+                if constexpr (NH == 2) gf_st_s<2>(out + (size_t)rr * LDOUT + 32, acc1[r]);
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
                 if (r0 + 4 * lh + rr < rows && li < CB) {
-                    out[(size_t)rr * LDOUT] = acc0[r];
-                    if constexpr (NH == 2) out[(size_t)rr * LDOUT + 32] = acc1[r];
+                    gf_st_s<2>(out + (size_t)rr * LDOUT, acc0[r]);
+                    if constexpr (NH == 2) gf_st_s<2>(out + (size_t)rr * LDOUT + 32, acc1[r]);
                 }
             }
         }
@@ -864,8 +864,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
         const long long last = kend - 1, kk = K(m) + 2 * pair;
         const int c0 = (int)(kk < last ? kk : last), c1 = (int)(kk + 1 < last ? kk + 1 : last);
         const float *t0 = T + (size_t)c0 * 256 + 4 * a_quad, *t1 = T + (size_t)c1 * 256 + 4 * a_quad;
-        S.ta.v0 = *reinterpret_cast<const f4v *>(z0 ? sp_zero_page + 4 * q_lo : t0);
-        S.ta.v1 = *reinterpret_cast<const f4v *>(z1 ? sp_zero_page + 4 * q_lo : t1);
+        S.ta.v0 = gf_ld_s<4>(reinterpret_cast<const f4v *>(z0 ? sp_zero_page + 4 * q_lo : t0));
+        S.ta.v1 = gf_ld_s<4>(reinterpret_cast<const f4v *>(z1 ? sp_zero_page + 4 * q_lo : t1));
 #pragma unroll
         for (int e = 0; e < NB; ++e) {
             const int blk = b_blk(e);  // (e == 1: 4 on waves 0 and 1, no block on the others)
@@ -876,8 +876,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
             const int ld = blk < 5 ? 128 : 256;
             // (the gathered dU row only meets S_ab of ITS row in product 7: a row without data skips the gather as well)
             const float *s0 = src + (size_t)(gathered ? g0 : c0) * ld, *s1 = src + (size_t)(gathered ? g1 : c1) * ld;
-            S.tb[e].v0 = *reinterpret_cast<const f4v *>((gathered && zg0) ? sp_zero_page + 4 * q_lo : s0);
-            S.tb[e].v1 = *reinterpret_cast<const f4v *>((gathered && zg1) ? sp_zero_page + 4 * q_lo : s1);
+            S.tb[e].v0 = gf_ld_s<4>(reinterpret_cast<const f4v *>((gathered && zg0) ? sp_zero_page + 4 * q_lo : s0));
+            S.tb[e].v1 = gf_ld_s<4>(reinterpret_cast<const f4v *>((gathered && zg1) ? sp_zero_page + 4 * q_lo : s1));
         }
     };
     // word (column col0 + j, pair) of the images <- halves of (row k, row k + 1) at column col0 + j
