@@ -62,9 +62,16 @@ struct SlabLane {
 template <int LPC, int NI, bool FULL>
 __device__ __forceinline__ void load_slab_row(__amdgpu_buffer_rsrc_t slab, int row_bytes, const SlabLane<LPC, NI> &ln,
                                               int dgoff_bytes, f4 (&v)[NI], f4 &dg) {
+#ifndef GF_R18_DG
+#define GF_R18_DG 1
+#endif
+    // (the two diagonal elements lie in lines the row loads fetch as well: A/B of their order / policy, GF_R18_DG)
+    if (GF_R18_DG == 1) dg = buf_ld4(slab, dgoff_bytes, row_bytes);
+    if (GF_R18_DG == 2) dg = buf_ld4_nt(slab, dgoff_bytes, row_bytes);
 #pragma unroll
     for (int i = 0; i < NI; ++i) v[i] = buf_ld4_nt(slab, ln.coff[i], row_bytes);
-    dg = buf_ld4_nt(slab, dgoff_bytes, row_bytes);
+    if (GF_R18_DG == 0) dg = buf_ld4_nt(slab, dgoff_bytes, row_bytes);
+    if (GF_R18_DG == 3) dg = buf_ld4(slab, dgoff_bytes, row_bytes);
 }
 
 template <int LPC, int NI, bool FULL>

@@ -42,7 +42,7 @@ def collect(d, ctr, scale):
 def is_setup(name):
     """Kernels of the process's set-up (input uploads, gf_smp_prepare's table builders, the bench's own copies): they run once per
     prepared batch, not once per step, and stay out of the per-step totals (round-5 review, weak #12)."""
-    return name.startswith(("__amd_rocclr_", "build_", "invert_cons", "level_table_stats", "tables_zero_fill", "copy_probe")) or "elementwise" in name or "distribution" in name
+    return name.startswith(("__amd_rocclr_", "build_", "invert_cons", "level_table_stats", "tables_zero_fill", "copy_probe", "reduce_kernel", "triu_tril")) or "elementwise" in name or "distribution" in name
 
 
 fd, wd, steps, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
