@@ -71,7 +71,7 @@ hipStream_t dist_stream(gf_ctx *ctx);
 
 // Streaming (non-temporal) accesses of the SMP level's kernels, selectable per site for A/B builds (-DGF_NT_SITES=<mask>):
 //   1 products: operand loads   2 products: stores   4 weight gradients: loads   8 combine: O / f / df loads   16 combine: stores
-//   32 tables-forward: T stores   64 consumer gather: df stores
+//   32 tables-forward: T stores   64 consumer gather: df stores   128 consumer gather: the S_ab / T6 gradient blocks (read once)
 // tools/micro/copy_probe.hip: `nt` on both sides of a streaming kernel is worth 8 - 10 % of a copy's rate.  Measured per site on the
 // cfg3 step (round 6, two passes each, one box: no `nt` 6.83 - 6.85 ms): 8 + 16 -> 6.73 - 6.75, 32 -> 6.74 - 6.75 (its readers gain
 // as much as tables-forward itself: the dirty lines of a plain store are written back while the NEXT kernel runs), 64 ~ 0.  NOT

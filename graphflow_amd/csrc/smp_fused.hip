@@ -1192,6 +1192,9 @@ __device__ __forceinline__ void s_wait(si4 (&r)[N]) {
     }
 }
 
+__device__ __forceinline__ f4 gbuf_ld4_once(__amdgpu_buffer_rsrc_t r, int voff_bytes) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, 0, (GF_NT_SITES & 128) ? 2 : 0));
+}
 constexpr int kOor = 0x40000000;  // a lane offset no consumer's tables reach (<= 32 x 32 rows of 16 C bytes): the load returns 0
 
 #define GF_GATHER_PARAMS                                                                                                          \
@@ -1252,7 +1255,9 @@ __device__ __forceinline__ void gather_source(GF_GATHER_PARAMS, int w, int chunk
                 const int va = has ? a * 4 * C4 + f4b : kOor, vb = has ? b * 4 * C4 + f4b : kOor;
                 const int vs = has ? f4b : kOor, vd = (has && p == cw) ? f4b : kOor;  // a == b  <=>  p is the source's own vertex
                 const int tb = has ? b * s * ldtb + f4b : kOor;                          // row (b, 0)
-                const f4 l0 = buf_ld4(rT, tab + T_SAB * C4, 0), g5 = buf_ld4(rT, tab + T_T6 * C4, 0);
+                // (the S_ab / T6 gradient blocks of row (a, b) are read by this source alone, once: streamed -- GF_NT_SITES 128 -- so that they
+                //  do not push the S_bc / T10 blocks, which every source of the consumer re-reads, out of the L2)
+                const f4 l0 = gbuf_ld4_once(rT, tab + T_SAB * C4), g5 = gbuf_ld4_once(rT, tab + T_T6 * C4);
                 const f4 l1 = buf_ld4(rV, va, 0), l4 = buf_ld4(rV, va + 2 * C4, 0);
                 const f4 l2 = buf_ld4(rV, vb + C4, 0), z2 = buf_ld4(rV, vb + 3 * C4, 0);
                 const f4 l3 = buf_ld4(rS, vs, 0), l5 = buf_ld4(rS, vs + 2 * C4, 0);
