@@ -128,40 +128,27 @@ LaunchTimer::LaunchTimer(gf_ctx *c, const char *name, hipStream_t on) : ctx(c), 
     (void)hipEventRecord(start, stream);
 }
 
-// gf_hbm_copy_probe_f32: the copy the box's practical HBM ceiling is read from (bench.py: roofline.hbm_copy_*): 16 bytes per lane,
-// grid-stride over one wave of resident workgroups, four requests in flight per lane
+// gf_hbm_copy_probe_f32: the copy the box's practical HBM ceiling is read from (bench.py: roofline.hbm_copy_*).  A workgroup walks
+// contiguous 16 KiB tiles (four 16-byte requests per lane, 4 KiB apart) -- the shape tools/micro/copy_probe.hip found fastest: 5.5 - 5.9
+// TB/s plain, 6.0 - 6.4 TB/s with `nt` on loads AND stores; a grid-stride copy whose four requests lie a whole grid apart gets 4.6.
 template <bool NT>
 __global__ __launch_bounds__(256) void copy_probe_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        float4 v[4];
+    using v4 = __attribute__((ext_vector_type(4))) float;
+    const v4 *s = reinterpret_cast<const v4 *>(src);
+    v4 *d = reinterpret_cast<v4 *>(dst);
+    const size_t tile = 4 * 256, ntiles = n4 / tile;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const size_t i = t * tile + threadIdx.x;
+        v4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = NT ? __builtin_nontemporal_load(s + i + k * 256) : s[i + k * 256];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (NT) {
-                const float *p = reinterpret_cast<const float *>(src + i + k * stride);
-                v[k].x = __builtin_nontemporal_load(p);
-                v[k].y = __builtin_nontemporal_load(p + 1);
-                v[k].z = __builtin_nontemporal_load(p + 2);
-                v[k].w = __builtin_nontemporal_load(p + 3);
-            } else {
-                v[k] = src[i + k * stride];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (NT) {
-                float *q = reinterpret_cast<float *>(dst + i + k * stride);
-                __builtin_nontemporal_store(v[k].x, q);
-                __builtin_nontemporal_store(v[k].y, q + 1);
-                __builtin_nontemporal_store(v[k].z, q + 2);
-                __builtin_nontemporal_store(v[k].w, q + 3);
-            } else {
-                dst[i + k * stride] = v[k];
-            }
+            if (NT) __builtin_nontemporal_store(v[k], d + i + k * 256);
+            else d[i + k * 256] = v[k];
         }
     }
-    for (; i < n4; i += stride) dst[i] = src[i];
+    for (size_t i = ntiles * tile + (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) d[i] = s[i];
 }
 
 void LaunchTimer::done() {
@@ -672,7 +659,7 @@ gf_status gf_hbm_copy_probe_f32(gf_ctx *ctx, float *dst, const float *src, size_
     const size_t n4 = n / 4;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, (size_t)cus * 8);
+    const unsigned blocks = (unsigned)std::min<size_t>((n4 + 1023) / 1024, (size_t)cus * 16);
     auto launch = [&]() {
         if (mode == 0) hipLaunchKernelGGL(gf::copy_probe_f4<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const float4 *)src, (float4 *)dst, n4);
         else hipLaunchKernelGGL(gf::copy_probe_f4<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const float4 *)src, (float4 *)dst, n4);
