@@ -793,6 +793,16 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
+    # tear the path's own communicator down while every rank is still here (ncclCommDestroy wants its peers alive), bounded by the
+    # watchdog; a rank that cannot is reported on stderr -- the line above is already out
+    if world > 1 or force:
+        try:
+            ctx.dist_quiesce()
+            ctx.dist_finalize()
+        except Exception as e:   # noqa: BLE001
+            print("bench.py: rank %d: tearing down the RCCL communicator failed: %r" % (rank, e), file=sys.stderr, flush=True)
+    if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1576,7 +1576,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             if (st != GF_OK) return st;
             st = gf::upload(s, &d.rowflag, nullptr, (size_t)h.rows);
             if (st != GF_OK) return st;
-            if (s->cfg.nContractions == 18 && h.rows * 256 < 0x3fffffffll && !h.buckets.empty() && h.buckets.back().s <= 32) {
+            if (s->cfg.nContractions == 18 && h.rows * 256 < 0x3fffffffll && !h.buckets.empty() && h.buckets.back().s <= gf::kFusedMaxField) {
                 // row panels of the fused forward level (smp_level_c64_fwd.hip): a node of size s has ceil(s / max(1, 32 / s)) panels
                 const int np = h.npanels;   // (page-locked table of the layout: no wait for the copy)
                 d.fwd_npanels = np;
@@ -1591,7 +1591,7 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
                     st = gf::upload(s, &d.pmax, nullptr, (size_t)np * C);
                     if (st != GF_OK) return st;
                 }
-                st = gf::upload(s, &d.dzmax, nullptr, std::max(h.quad_node.size(), (size_t)np) * 64);
+                st = gf::upload(s, &d.dzmax, nullptr, (h.quad_node.size() + (size_t)np) * 64);   // (panels, then the workgroups of the nodes above 32 positions)
                 if (st != GF_OK) return st;
                 st = gf::upload(s, &d.fwd_pan_node, nullptr, (size_t)np);
                 if (st != GF_OK) return st;
@@ -2193,6 +2193,16 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
     if (C == 64 && s->lv[L].psum_ready) {
         GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<64>, dim3((unsigned)((top.nNodes + 3) / 4)), dim3(256), 0, s->lv[L].psum,
                   s->lv[L].node_panel, top.nNodes, s->lv[L].fwd_npanels, s->sh, s->vf);
+        // (the nodes above 32 positions have no row panels -- an empty range above: theirs from the rows of f_L; nodes are numbered by size)
+        int n0 = top.nNodes;
+        for (const gfsmp::Bucket &bk : top.buckets)
+            if (bk.s > 32) {
+                n0 = bk.first_node;
+                break;
+            }
+        if (n0 < top.nNodes)
+            GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(top.nNodes - n0), dim3(256), 0, s->lv[L].f, s->lv[L].node_s + n0,
+                      s->lv[L].node_row + n0, s->sh + (size_t)n0 * C, s->vf + (size_t)n0 * C, C);
     } else if (C == 32 && s->lv[L].psum_ready) {
         GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<32>, dim3((unsigned)((top.nNodes + 7) / 8)), dim3(256), 0, s->lv[L].psum,
                   s->lv[L].node_panel, top.nNodes, s->lv[L].fwd_npanels, s->sh, s->vf);

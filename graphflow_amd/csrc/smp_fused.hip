@@ -389,6 +389,117 @@ __global__ __launch_bounds__(NI >= GF_TF_WIDE ? 2 * kThreads : kThreads, NI <= 4
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// tables-forward for the FEW nodes above 32 positions (33 .. 64; round 6): smp_tables_fwd_w keeps a wave's sums over a in registers by
+// consumer position -- 4 NI positions, NI <= 8 -- and a 48-atom molecule's level-3 fields reach 35.  One workgroup per (node, b), plain
+// loops, every sum in index order; the same outputs as smp_tables_fwd_w<NI, true, false> (the sums over b are smp_vectors', launched
+// over these nodes behind it):
+//   T[(a, b)] = [S_ab | . | T6 | .]  for the rows with an image (pi_a(b) >= 0; the others: zeros unless the level keeps them masked)
+//   T[(b, c)] = [. | S_bc | . | T10] for the rows some source covers (all of them when the level does not mask)
+//   Vt[(n, b)] blocks 1, 3 = sum_c S_bc[b, c], sum_a P[a, b, a];  scal[(n, b)] = {sum_c S_bc[b, c], S_ab[b, b], sum_a P[a, b, b], P[b, b, b]}
+// with P[a, b, c] = f_{l-1}[w_a][pi_a(b)][pi_a(c)] or 0 (SMP_omega.h:641-651, RisiContraction_18.h:98-322 factorised as in DESIGN.md 4.5).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kBigN = 64;
+__global__ __launch_bounds__(256) void smp_tables_fwd_big(const float *__restrict__ fprev, const float *__restrict__ rsum, float *__restrict__ T,
+                                                          float *__restrict__ Vt, float *__restrict__ scal,
+                                                          const long long *__restrict__ pair_src_row, const int *__restrict__ pair_src_s,
+                                                          const short *__restrict__ pi, const int *__restrict__ pair_node,
+                                                          const int *__restrict__ node_s, const long long *__restrict__ node_row,
+                                                          const long long *__restrict__ node_pair, long long pair0, int C, int zeros_kept,
+                                                          const unsigned char *__restrict__ rowflag) {
+    const long long e = pair0 + blockIdx.x;
+    const int n = pair_node[e], N = node_s[n];
+    const size_t rowbase = (size_t)node_row[n], pairbase = (size_t)node_pair[n];
+    const int b = (int)(e - (long long)pairbase), nl = C >> 2, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float big_smem[];
+    float *sBC = big_smem;                       // [N][C] S_bc[b, c], then: P[a, b, b]
+    float *sAC = sBC + (size_t)N * C;            // [N][C] P[a, b, a]
+    float *sR = sAC + (size_t)N * C;             // [N]
+    long long *sSrc = reinterpret_cast<long long *>(sR + ((N + 3) & ~3));   // [N] first float of f_{l-1}[w_a]
+    int *sSw = reinterpret_cast<int *>(sSrc + N);                           // [N]
+    short *sPi = reinterpret_cast<short *>(sSw + N);                        // [N][N] pi_a(x)
+    for (int i = tid; i < N; i += 256) {
+        sR[i] = rsum[pairbase + i];
+        sSrc[i] = pair_src_row[pairbase + i] * C;
+        sSw[i] = pair_src_s[pairbase + i];
+    }
+    for (int i = tid; i < N * N; i += 256) sPi[i] = pi[rowbase + i];
+    __syncthreads();
+    const bool skip_bc = zeros_kept && rowflag;
+    // rows (b, c): sums over the sources a
+    for (int it = tid; it < N * nl; it += 256) {
+        const int c = it / nl, f = 4 * (it - c * nl);
+        f4 sbc = splat(0.f), t10 = splat(0.f);
+        for (int a = 0; a < N; ++a) {
+            const int pb = sPi[a * N + b], pc = sPi[a * N + c];
+            if (pb >= 0 && pc >= 0) {
+                const f4 v = ld4(fprev + sSrc[a] + ((size_t)pb * sSw[a] + pc) * C + f);
+                sbc += v;
+                t10 += sR[a] * v;
+            }
+        }
+        st4(sBC + (size_t)c * C + f, sbc);
+        if (!skip_bc || (rowflag[rowbase + (size_t)b * N + c] & 2)) {
+            float *trow = T + (rowbase + (size_t)b * N + c) * (size_t)(T_COLS * C) + f;
+            st4(trow + T_SBC * C, sbc);
+            st4(trow + T_T10 * C, t10);
+        }
+    }
+    __syncthreads();
+    f4 cs = splat(0.f);
+    if (tid < nl)
+        for (int c = 0; c < N; ++c) cs += ld4(sBC + (size_t)c * C + 4 * tid);
+    __syncthreads();   // (sBC is reused below)
+    // rows (a, b): sums over c; the two diagonal elements of the row on the way
+    for (int it = tid; it < N * nl; it += 256) {
+        const int a = it / nl, f = 4 * (it - a * nl);
+        const int pb = sPi[a * N + b];
+        f4 sab = splat(0.f), t6 = splat(0.f), dbb = splat(0.f), dac = splat(0.f);
+        if (pb >= 0) {
+            const float *src = fprev + sSrc[a] + (size_t)pb * sSw[a] * C + f;
+            for (int c = 0; c < N; ++c) {
+                const int pc = sPi[a * N + c];
+                if (pc >= 0) {
+                    const f4 v = ld4(src + (size_t)pc * C);
+                    sab += v;
+                    t6 += sR[c] * v;
+                    if (c == b) dbb = v;
+                    if (c == a) dac = v;
+                }
+            }
+        }
+        if (pb >= 0 || !zeros_kept) {
+            float *trow = T + (rowbase + (size_t)a * N + b) * (size_t)(T_COLS * C) + f;
+            st4(trow + T_SAB * C, sab);
+            st4(trow + T_T6 * C, t6);
+        }
+        st4(sBC + (size_t)a * C + f, dbb);
+        st4(sAC + (size_t)a * C + f, dac);
+        if (a == b) {   // the node's own vertex: always present
+            st4(scal + ((pairbase + b) * 4 + 3) * (size_t)C + f, dbb);
+            st4(scal + ((pairbase + b) * 4 + 1) * (size_t)C + f, sab);
+        }
+    }
+    __syncthreads();
+    if (tid < nl) {
+        const int f = 4 * tid;
+        f4 dgsum = splat(0.f), dactot = splat(0.f);
+        for (int a = 0; a < N; ++a) {
+            dgsum += ld4(sBC + (size_t)a * C + f);
+            dactot += ld4(sAC + (size_t)a * C + f);
+        }
+        float *v = Vt + (pairbase + b) * 4 * (size_t)C + f;
+        st4(v + 1 * C, cs);
+        st4(v + 3 * C, dactot);
+        float *sc = scal + (pairbase + b) * 4 * (size_t)C + f;
+        st4(sc + 0 * C, cs);
+        st4(sc + 2 * C, dgsum);
+    }
+}
+static size_t tables_big_lds(int N, int C) {
+    return sizeof(float) * (2 * (size_t)N * C + ((N + 3) & ~3)) + sizeof(long long) * N + sizeof(int) * N + sizeof(short) * (size_t)N * N + 32;
+}
+
 // rowsum_a[x] = sum_b S_ab[x,b], D8[x] = sum_b Dbb[x,b] per (node, x); scalars per node = sum over b of the partials.
 // Items = (x, float4 lane); the s loads of an item are issued in batches of 8 (batched_sum).
 __global__ __launch_bounds__(256) void smp_vectors(const float *__restrict__ T, float *__restrict__ Vt,
@@ -689,7 +800,7 @@ __device__ __forceinline__ QuadWhere locate_quad(const int *quad_node, const int
     return w;
 }
 
-template <int LPC>
+template <int LPC, int MAXN = kFusedMaxN>   // MAXN: largest receptive field of the launch (64: the nodes above 32 positions, round 6)
 __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restrict__ O, const float *__restrict__ A,
                                                             const float *__restrict__ Vout, const float *__restrict__ Sout,
                                                             const float *__restrict__ bias, float *__restrict__ F,
@@ -716,7 +827,7 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
     float *sU = smem + adj_lds_floats(N);  // [kCombX][N][CW]  Z[x,e] + Z'[e,x] (+ compact terms)
     // Phase-2 item `it` = (xi, y) reads the O_loc block of the row whose U block phase-1 item `it` = (xi, e = y) reads:
     // both are fetched here, so a workgroup pays one HBM round trip instead of one either side of the barrier.
-    constexpr int MAXIT = (kCombX * kFusedMaxN + NGRP - 1) / NGRP;  // fused levels: N <= 32 (smp_fused_supported)
+    constexpr int MAXIT = (kCombX * MAXN + NGRP - 1) / NGRP;  // fused levels: N <= 32 (64 for the launch over the big nodes, smp_fused_supported)
     f4 oloc[MAXIT];
 #pragma unroll
     for (int k = 0; k < MAXIT; ++k) {
@@ -1002,6 +1113,33 @@ std::vector<SizeClass> classes_of(const gfsmp::LevelLayout &h, int ppw) {
         out.push_back(c);
     }
     return out;
+}
+
+// The nodes of a level above 32 positions (nodes are numbered by size: they come last), see kFusedMaxField: first node / row / pair /
+// workgroup-kernel quad of that range and its extents.  nodes == 0: none.
+struct BigPart {
+    int n0 = 0, nodes = 0, quad0 = 0, quads = 0, smax = 0;
+    long long row0 = 0, pair0 = 0, pairs = 0;
+};
+static BigPart big_part(const gfsmp::LevelLayout &h) {
+    BigPart b;
+    b.n0 = h.nNodes, b.row0 = h.rows, b.pair0 = h.pairs, b.quad0 = (int)h.quad_node.size();
+    long long q = 0;
+    for (const gfsmp::Bucket &bk : h.buckets) {
+        if (bk.s > 32) {
+            b.n0 = bk.first_node;
+            break;
+        }
+        q += (long long)bk.count * ((bk.s + 3) / 4);   // (quads are in node order, ceil(s / 4) per node: smp_prep.cpp)
+    }
+    if (b.n0 < h.nNodes) {
+        b.nodes = h.nNodes - b.n0;
+        b.row0 = h.node_row[(size_t)b.n0], b.pair0 = h.node_pair[(size_t)b.n0];
+        b.pairs = h.pairs - b.pair0;
+        b.quad0 = (int)q, b.quads = (int)h.quad_node.size() - (int)q;
+        b.smax = h.buckets.back().s;
+    }
+    return b;
 }
 
 Ragged ragged_for(const gf_smp::DevLevel &d, long long lo, int smax) {
@@ -1439,7 +1577,14 @@ bool smp_fused_supported(const gf_smp *s, int l) {
             env_is("GF_SMP_FUSED_DROPOUT", '0'))
             return false;
     }
-    return h.buckets.back().s <= 32;  // 8 * PPW at LPC = 16
+    if (h.buckets.back().s <= 32) return true;  // 8 * PPW at LPC = 16
+    // Round 6: fields of 33 .. 64 positions at C = 64 -- the nodes above 32 run tables-forward on smp_tables_fwd_big and the two combine steps
+    // on the workgroup kernels (big_part); the gather wants the SOURCES (level l - 1) within 32, the split row-panel products their packed tables
+    const gf_smp::DevLevel &d = s->lv[l];
+    const gfsmp::LevelLayout &hp = s->lay.level[l - 1];
+    return h.buckets.back().s <= kFusedMaxField && C == 64 && !s->drop_on && !s->cfg.physics && !s->dup_channels && smp_c64_kernels(s) &&
+           smp_split_products(s->ctx) && s->bwd_gather && !hp.buckets.empty() && hp.buckets.back().s <= kGatherMaxS && d.trow && d.trowf && d.rowflag &&
+           d.dzmax && d.row_max && d.fwd_pan && d.fwd_npanels > 0 && !env_is("GF_SMP_BIG_FIELDS", '0');
 }
 
 // Q buffer of the level ([rows][18C]) is carved as  T [rows][6C] | O / dO [rows][3C] | dT [rows][6C]
@@ -1498,6 +1643,16 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         }
         if (st != GF_OK) return st;
     }
+    const BigPart big = big_part(h);   // the nodes above 32 positions (none at QM9 sizes): their own tables-forward, see smp_tables_fwd_big
+    if (big.nodes > 0) {
+        const size_t lds_b = tables_big_lds(big.smax, C);
+        st = opt_in_lds(ctx, smp_tables_fwd_big, lds_b);
+        if (st != GF_OK) return st;
+        const int flags = (d.t_zeros && (C & 63) == 0) ? 1 : 0;
+        GF_LAUNCH(ctx, "smpf_tables_fwd_big", smp_tables_fwd_big, dim3((unsigned)big.pairs), dim3(256), lds_b, s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal,
+                  d.pair_src_row, d.pair_src_s, d.pi, d.pair_node, d.node_s, d.node_row, d.node_pair, big.pair0, C, flags,
+                  flags ? d.rowflag : (const unsigned char *)nullptr);
+    }
     {  // Fdc = [f[w][p,p] | f[w][p,c_w]] of the level below (read by smp_vectors and by the compact products)
         const gf_smp::DevLevel &pv = s->lv[l - 1];
         GF_LAUNCH(ctx, "smpf_diag_gather", diag_gather_fwd, dim3(s->lay.level[l - 1].nNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, pv.f, d.Fdc, pv.node_s,
@@ -1506,6 +1661,9 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
     if (!smp_tables_fold_vectors(s))
         GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(nodes), dim3(node_block(h, C)), 0, T, d.Vt, d.scal, d.St, d.node_s, d.node_row,
                   d.node_pair, C, d.Fdc, d.pair_src_pair, d.pi);
+    else if (big.nodes > 0)   // (smp_tables_fwd_w folds these sums itself; the big nodes' kernel leaves them to smp_vectors)
+        GF_LAUNCH(ctx, "smpf_vectors", smp_vectors, dim3(big.nodes), dim3(256), 0, T, d.Vt, d.scal, d.St + (size_t)big.n0 * 4 * C, d.node_s + big.n0,
+                  d.node_row + big.n0, d.node_pair + big.n0, C, d.Fdc, d.pair_src_pair, d.pi);
     const size_t CC = (size_t)C * C;
     if (drop) {   // the vector / scalar slices' factors ride on the operands: Vt blocks (1, 3, 7, 10), St blocks (4, 13, 14, 17)
         const long long nv = (long long)pairs * C, ns = (long long)nodes * C;
@@ -1592,12 +1750,28 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         float *psum = (l == s->cfg.nLevels || s->cfg.physics) ? d.psum : nullptr;   // (a tower reads every level out)
         st = smp_combine_fwd_panels_c64(s, l, O, bl, psum, d.pmax, drop ? d.nodefac : nullptr);
         if (st == GF_OK && psum) s->lv[l].psum_ready = true;
-        if (st == GF_OK && d.pmax) s->lv[l].pmax_ready = true;
+        if (st == GF_OK && d.pmax && big.nodes == 0) s->lv[l].pmax_ready = true;   // (maxima of the panels only: a level with bigger nodes is scanned)
+        if (st == GF_OK && big.nodes > 0) {   // the nodes above 32 positions: workgroup per (node, four x), a 64-position build
+            const size_t lds = combine_lds<16>(big.smax);
+            st = opt_in_lds(ctx, smp_combine_fwd<16, kFusedMaxField>, lds);
+            if (st != GF_OK) return st;
+            GF_LAUNCH(ctx, "smpf_combine_fwd_big", (smp_combine_fwd<16, kFusedMaxField>), dim3((unsigned)(big.quads * nwin)), dim3(kThreads), lds, O, d.adj,
+                      d.Vout, d.Sout, bl, d.f, d.quad_node + big.quad0, d.quad_b0 + big.quad0, d.node_s, d.node_row, d.node_pair, C, nwin, d.Gc,
+                      d.pair_src_pair, d.pi, d.rsum, ocols);
+        }
         return st;
     }
     if (drop) return fail(ctx, GF_ERR_UNSUPPORTED, "fused level %d: slice dropout needs the panel combine-forward", l);
-    {
+    {   // (a level beyond the panel kernel's 32-bit offsets, or another channel count: the workgroup kernel for every node)
         const size_t lds = combine_lds<16>(h.buckets.back().s);
+        if (big.nodes > 0) {   // (a 64-position build where the level has nodes above 32 positions)
+            st = opt_in_lds(ctx, smp_combine_fwd<16, kFusedMaxField>, lds);
+            if (st != GF_OK) return st;
+            GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd<16, kFusedMaxField>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, O,
+                      d.adj, d.Vout, d.Sout, bl, d.f, d.quad_node, d.quad_b0, d.node_s, d.node_row, d.node_pair, C, nwin, d.Gc,
+                      d.pair_src_pair, d.pi, d.rsum, ocols);
+            return GF_OK;
+        }
         st = opt_in_lds(ctx, smp_combine_fwd<16>, lds);
         if (st != GF_OK) return st;
         GF_LAUNCH(ctx, "smpf_combine_fwd", (smp_combine_fwd<16>), dim3((unsigned)(h.quad_node.size() * nwin)), dim3(kThreads), lds, O,
@@ -1900,6 +2074,16 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         if (st != GF_OK) return st;
         s->lv[l].dz_rows = d.fwd_npanels;
         s->lv[l].dz_ld = C;
+        const BigPart big = big_part(h);
+        if (big.nodes > 0) {   // the nodes above 32 positions (smp_fused_supported: C = 64): the workgroup kernel, its column maxima behind the panels'
+            const size_t lds = std::max(combine_lds<16>(big.smax), sizeof(float) * ((size_t)adj_lds_floats(big.smax) + 1024));
+            st = opt_in_lds(ctx, smp_combine_bwd<16>, lds);
+            if (st != GF_OK) return st;
+            GF_LAUNCH(ctx, "smpf_combine_bwd_big", (smp_combine_bwd<16>), dim3((unsigned)(big.quads * nwin)), dim3(kThreads), lds, d.f, dfrows, node_df, d.adj,
+                      dO, d.dVout, d.dSpart, d.dbpart, d.quad_node + big.quad0, d.quad_b0 + big.quad0, d.node_s, d.node_row, d.node_pair, C, nwin, d.rsum, 2,
+                      dzmax ? dzmax + (size_t)d.fwd_npanels * C : (float *)nullptr);
+            s->lv[l].dz_rows = d.fwd_npanels + big.quads;
+        }
         (void)Kl;
         return smp_fused_backward_level_grouped(s, l, dKl, dbl);
     }

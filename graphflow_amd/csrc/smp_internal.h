@@ -246,6 +246,10 @@ struct gf_smp {
 namespace gf {
 // channel counts the row-panel kernel family of the fused level is built for (models are padded to the next one: gf_smp_create)
 inline bool smp_panel_channels(int C) { return C == 64 || C == 32 || C == 16; }
+// Largest receptive field a fused level takes (round 6): up to 32 positions every kernel of the level; 33 .. 64 at C = 64 -- the few such
+// nodes of a level (a 48-atom molecule's level-3 fields reach 35) run tables-forward and the two combine steps on workgroup kernels,
+// everything else is row-based and does not care (smp_fused.hip: big_part)
+constexpr int kFusedMaxField = 64;
 bool smp_fused_supported(const gf_smp *s, int l);
 gf_status smp_backward_admissible(const gf_smp *s);   // smp.hip: refusals of a reverse sweep that must come before any work is issued
 gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float *bl);

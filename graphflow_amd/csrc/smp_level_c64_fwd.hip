@@ -359,6 +359,7 @@ __global__ void build_fwd_panels(const int *__restrict__ node_s, const long long
                                  const long long *__restrict__ node_pair, const int *__restrict__ node_panel, int4 *__restrict__ pan,
                                  int *__restrict__ pan_node) {
     const int n = blockIdx.x, s = node_s[n];
+    if (s > 32) return;   // (no panels: smp_prep.cpp)
     const int gpp = s >= 32 ? 1 : (32 / s > 8 ? 8 : 32 / s), np = (s + gpp - 1) / gpp;  // (at most eight groups: the rank-one slots)
     for (int j = threadIdx.x; j < np; j += blockDim.x) {
         const int x0 = j * gpp, g = (s - x0 < gpp) ? s - x0 : gpp;

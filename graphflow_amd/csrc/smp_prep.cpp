@@ -320,8 +320,10 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
         }
         lv.node_center.assign(totalV, 0);
         {  // counting sort of the nodes by (register class of s, molecule); stable, so size-major order survives inside a key
-            auto cls = [](int s) { return s <= 1 ? 0 : s <= 4 ? 1 : s <= 8 ? 2 : s <= 16 ? 3 : 4; };
-            std::vector<int> start((size_t)5 * nMol + 1, 0);
+            // (a class of their own for the nodes above 32 positions: tables-forward launches per register class over ranges of this
+            //  order, and those nodes run another kernel)
+            auto cls = [](int s) { return s <= 1 ? 0 : s <= 4 ? 1 : s <= 8 ? 2 : s <= 16 ? 3 : s <= 32 ? 4 : 5; };
+            std::vector<int> start((size_t)6 * nMol + 1, 0);
             for (int n = 0; n < totalV; ++n) start[(size_t)cls(lv.node_s[n]) * nMol + lv.node_mol[n] + 1] += 1;
             for (size_t k = 0; k + 1 < start.size(); ++k) start[k + 1] += start[k];
             lv.mol_order.assign(totalV, 0);
@@ -390,7 +392,9 @@ void build_batch(const Config &cfg, int nMol, const int *nVertices, const int *a
             for (int n = 0; n < lv.nNodes; ++n) {
                 lv.node_panel[(size_t)n] = np;
                 const int sz = lv.node_s[n], gpp = sz >= 32 ? 1 : std::min(8, 32 / (sz < 1 ? 1 : sz));
-                np += (sz + gpp - 1) / gpp;
+                // (a node of more than 32 positions has no row panels: its row groups do not fit the 32-row tiles of the panel kernels --
+                //  the workgroup kernels take it, smp_fused.hip: big_part; nodes are numbered by size, so those nodes come last)
+                if (sz <= 32) np += (sz + gpp - 1) / gpp;
             }
             lv.npanels = np;
         }

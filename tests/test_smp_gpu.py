@@ -919,6 +919,82 @@ def test_cfg4_workload_as_eight_one_rank_shards(gf):
     assert e <= TOL_GRAD
 
 
+@pytest.mark.parametrize("nV,L", [(40, 3), (48, 3), (64, 3)])
+def test_fields_above_32_run_the_fused_level(gf, nV, L, monkeypatch):
+    """SMP_beta (no receptive-field cap, SMP_beta.h) on molecules larger than QM9's: a 40- / 48- / 64-atom molecule's level-3 fields
+    reach 34 / 35 / 37 positions, beyond the 32 the fused level's register classes and 32-row panels take.  Since round 6 such a level
+    stays on the fused kernels at C = 64: its few nodes above 32 positions run tables-forward on smp_tables_fwd_big and the two combine
+    steps on the workgroup kernels (smp_fused.hip: big_part), everything else is row-based.  Held against (a) the op-by-op level
+    pipeline of the same batch (fused = False), kink-aware, (b) the fp64 port of the reference for one of the big molecules, and
+    (c) GF_SMP_BIG_FIELDS=0, which must reproduce round 5's behaviour (the level op by op: the promotion buffer is taken)."""
+    from oracle import pyoracle
+    C, F, D = 64, 5, 2
+    mols, tg = [], []
+    for seed in {40: (8003, 8017, 8026, 8001), 48: (8017, 8003, 8026, 8028, 8000), 64: (8005, 8003, 8001, 8007, 8000)}[nV]:
+        adj, feat, t = synthetic_molecule(seed, nV=nV)   # (seeds whose level-3 fields exceed 32: 35 / 34 / 37 ..., 41 / 36 / ..., 40 / 38 / ...)
+        mols.append((adj, feat))
+        tg.append(t)
+    for i in range(7):   # ... in one batch with ordinary molecules (the level's small size classes and panels beside the big nodes)
+        adj, feat, t = synthetic_molecule(8100 + i)
+        mols.append((adj, feat))
+        tg.append(t)
+    tg = np.array(tg)
+    params = smp_params(C, F, D, L, 11)
+    a = run_batch(gf, mols, tg, params, L, C, F, D, nV, fused=True)
+    sizes = [len(a[4].receptive_field(0, L, v)) for v in range(nV)]
+    assert max(sizes) > 32, sizes                       # the case this test is about
+    b = run_batch(gf, mols, tg, params, L, C, F, D, nV, fused=False)
+    note("big_fields_nV%d" % nV, pred=rel_err(a[0], b[0]), feat=rel_err(a[2], b[2]))
+    assert np.isfinite(a[3]).all() and np.abs(a[3]).max() > 0
+    assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[2], b[2]) <= TOL_FWD
+    assert_grads_agree_kink_aware("big_fields_nV%d" % nV, a[3], b[3], a[4], b[4], mols, L)
+    used_f, used_p = a[4].device_bytes()[0], b[4].device_bytes()[0]
+    ppos = b[4].level_sizes(L)[2]
+    assert used_p - used_f >= 4 * ppos * C * 0.9        # the fused level took no promotion buffer: it really ran
+    if nV == 40:   # the port (10 s per molecule of this size): one big molecule, prediction + Feature + gradient
+        adj, ft = mols[0]
+        one = run_batch(gf, [mols[0]], tg[:1], params, L, C, F, D, nV, fused=True)
+        signs = [[one[4].activation(0, l, v) for v in range(nV)] for l in range(L + 1)]
+        o = pyoracle.port_smp_molecule(adj, ft, float(tg[0]), params, L, C, D, nV, True, ext_sign=signs, kink_tol=KINK_TOL)
+        assert o["n_conflict"] == 0
+        e = dict(pred=abs(float(one[0][0]) - o["predict"]) / max(abs(o["predict"]), float(np.abs(o["graph_feature"]).max()), 1.0),
+                 feat=rel_err(one[2][0], o["graph_feature"]), grads=rel_err(one[3], o["grads"]))
+        note("big_fields_vs_port", **e)
+        print("fields above 32 (a %d-atom molecule, largest field %d) against the fp64 port: %s" % (nV, max(sizes), {k: "%.2e" % v for k, v in e.items()}))
+        assert e["pred"] <= TOL_FWD and e["feat"] <= TOL_FWD and e["grads"] <= TOL_GRAD
+        one[4].close()
+    monkeypatch.setenv("GF_SMP_BIG_FIELDS", "0")
+    c = run_batch(gf, mols, tg, params, L, C, F, D, nV, fused=True)
+    assert c[4].device_bytes()[0] > used_f                # (round 5's path: level L op by op)
+    assert rel_err(c[0], b[0]) <= TOL_FWD
+    for r in (a, b, c):
+        r[4].close()
+
+
+def test_fields_above_32_in_a_level_beyond_the_panel_kernels_offsets(gf, monkeypatch):
+    """The same with a level of more than 2^21 rows (200 molecules of 64 atoms: the panel combine kernels address O with 32-bit byte
+    offsets and hand such a level to the workgroup kernels -- with nodes above 32 positions, their 64-position build for every node):
+    predictions, features and the gradient against the op-by-op level (GF_SMP_BIG_FIELDS=0)."""
+    L, C, F, D, nV = 3, 64, 5, 2, 64
+    mols, tg = [], []
+    for seed in range(8000, 8200):
+        adj, feat, t = synthetic_molecule(seed, nV=nV)
+        mols.append((adj, feat))
+        tg.append(t)
+    tg = np.array(tg)
+    params = smp_params(C, F, D, L, 12)
+    a = run_batch(gf, mols, tg, params, L, C, F, D, nV, fused=True)
+    assert a[4].level_sizes(L)[1] * 512 >= 0x3fffffff
+    monkeypatch.setenv("GF_SMP_BIG_FIELDS", "0")
+    b = run_batch(gf, mols, tg, params, L, C, F, D, nV, fused=True)
+    assert b[4].device_bytes()[0] > a[4].device_bytes()[0]
+    note("big_fields_large_level", pred=rel_err(a[0], b[0]), feat=rel_err(a[2], b[2]))
+    assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[2], b[2]) <= TOL_FWD
+    assert_grads_agree_kink_aware("big_fields_large_level", a[3], b[3], a[4], b[4], mols, L)
+    a[4].close()
+    b[4].close()
+
+
 def test_text_checkpoint_is_interchangeable_with_the_reference(gf, golden, tmp_path):
     """tests/golden/smp_syn12_checkpoint.txt was written by the REAL SMP_omega::save_model (SMP_omega.h:1033-1042).
     load_model must read it, predict like the golden, and save_model must write the very same bytes back."""
