@@ -2193,16 +2193,6 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
     if (C == 64 && s->lv[L].psum_ready) {
         GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<64>, dim3((unsigned)((top.nNodes + 3) / 4)), dim3(256), 0, s->lv[L].psum,
                   s->lv[L].node_panel, top.nNodes, s->lv[L].fwd_npanels, s->sh, s->vf);
-        // (the nodes above 32 positions have no row panels -- an empty range above: theirs from the rows of f_L; nodes are numbered by size)
-        int n0 = top.nNodes;
-        for (const gfsmp::Bucket &bk : top.buckets)
-            if (bk.s > 32) {
-                n0 = bk.first_node;
-                break;
-            }
-        if (n0 < top.nNodes)
-            GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(top.nNodes - n0), dim3(256), 0, s->lv[L].f, s->lv[L].node_s + n0,
-                      s->lv[L].node_row + n0, s->sh + (size_t)n0 * C, s->vf + (size_t)n0 * C, C);
     } else if (C == 32 && s->lv[L].psum_ready) {
         GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_panels<32>, dim3((unsigned)((top.nNodes + 7) / 8)), dim3(256), 0, s->lv[L].psum,
                   s->lv[L].node_panel, top.nNodes, s->lv[L].fwd_npanels, s->sh, s->vf);
@@ -2215,6 +2205,19 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
     } else {
         GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes, dim3(gf::grid_for((size_t)top.nNodes * C)), dim3(256), 0,
                   s->lv[L].f, s->lv[L].node_s, s->lv[L].node_row, s->sh, s->vf, C, (size_t)top.nNodes * C);
+    }
+    if (s->lv[L].psum_ready && gf::smp_panel_channels(C)) {
+        // (the nodes above 32 positions have no row panels -- an empty range in the panel readout: theirs from the rows of f_L; nodes are
+        //  numbered by size)
+        int n0 = top.nNodes;
+        for (const gfsmp::Bucket &bk : top.buckets)
+            if (bk.s > 32) {
+                n0 = bk.first_node;
+                break;
+            }
+        if (n0 < top.nNodes)
+            GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(top.nNodes - n0), dim3(256), 0, s->lv[L].f, s->lv[L].node_s + n0,
+                      s->lv[L].node_row + n0, s->sh + (size_t)n0 * C, s->vf + (size_t)n0 * C, C);
     }
     GF_LAUNCH(ctx, "smp_readout_mol", gf::readout_molecules, dim3(B.nMol), dim3(256), 0, s->vf, s->mol_ptr, s->mol_nodes, W,
               targets, s->g, s->yhat, loss, s->dy, C);

@@ -1103,7 +1103,8 @@ std::vector<SizeClass> classes_of(const gfsmp::LevelLayout &h, int ppw) {
     for (int cls = 1; cls <= 8 && k < h.buckets.size(); cls *= 2) {
         const size_t k0 = k;
         int smax = 0;
-        while (k < h.buckets.size() && h.buckets[k].s <= cls * ppw) smax = h.buckets[k++].s;
+        // (never beyond 32 positions, whatever the lanes per position: the nodes above take smp_tables_fwd_big -- big_part)
+        while (k < h.buckets.size() && h.buckets[k].s <= cls * ppw && h.buckets[k].s <= 32) smax = h.buckets[k++].s;
         if (k == k0) continue;
         SizeClass c;
         c.lo = h.node_pair[h.buckets[k0].first_node];
@@ -1578,11 +1579,11 @@ bool smp_fused_supported(const gf_smp *s, int l) {
             return false;
     }
     if (h.buckets.back().s <= 32) return true;  // 8 * PPW at LPC = 16
-    // Round 6: fields of 33 .. 64 positions at C = 64 -- the nodes above 32 run tables-forward on smp_tables_fwd_big and the two combine steps
+    // Round 6: fields of 33 .. 64 positions at 64 / 32 / 16 (padded) channels -- the nodes above 32 run tables-forward on smp_tables_fwd_big and the two combine steps
     // on the workgroup kernels (big_part); the gather wants the SOURCES (level l - 1) within 32, the split row-panel products their packed tables
     const gf_smp::DevLevel &d = s->lv[l];
     const gfsmp::LevelLayout &hp = s->lay.level[l - 1];
-    return h.buckets.back().s <= kFusedMaxField && C == 64 && !s->drop_on && !s->cfg.physics && !s->dup_channels && smp_c64_kernels(s) &&
+    return h.buckets.back().s <= kFusedMaxField && smp_panel_channels(C) && smp_tables_fold_vectors(s) && !s->drop_on && !s->cfg.physics && !s->dup_channels && smp_c64_kernels(s) &&
            smp_split_products(s->ctx) && s->bwd_gather && !hp.buckets.empty() && hp.buckets.back().s <= kGatherMaxS && d.trow && d.trowf && d.rowflag &&
            d.dzmax && d.row_max && d.fwd_pan && d.fwd_npanels > 0 && !env_is("GF_SMP_BIG_FIELDS", '0');
 }
@@ -1648,7 +1649,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
         const size_t lds_b = tables_big_lds(big.smax, C);
         st = opt_in_lds(ctx, smp_tables_fwd_big, lds_b);
         if (st != GF_OK) return st;
-        const int flags = (d.t_zeros && (C & 63) == 0) ? 1 : 0;
+        const int flags = d.t_zeros ? 1 : 0;   // (as the launchers of smp_tables_fwd_w at these channel counts)
         GF_LAUNCH(ctx, "smpf_tables_fwd_big", smp_tables_fwd_big, dim3((unsigned)big.pairs), dim3(256), lds_b, s->lv[l - 1].f, d.rsum, d.Q, d.Vt, d.scal,
                   d.pair_src_row, d.pair_src_s, d.pi, d.pair_node, d.node_s, d.node_row, d.node_pair, big.pair0, C, flags,
                   flags ? d.rowflag : (const unsigned char *)nullptr);
@@ -1864,6 +1865,10 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
             st = smp_wgrad_channel_maxima_ld(ctx, pm ? pv.pmax : pv.f, pm ? (long long)pv.fwd_npanels : (long long)s->lay.level[l - 1].rows, C, d.dzmax,
                                              d.dz_rows, d.dz_ld, C, words);
             if (st != GF_OK) return st;
+            if (d.dz_rows2 > 0) {   // (the big nodes' workgroups: maxima of another row width, folded into the same words -- atomicMax)
+                st = smp_wgrad_channel_maxima_ld(ctx, pv.f, 0, C, d.dzmax + d.dz_off2, d.dz_rows2, d.dz_ld2, C, words);
+                if (st != GF_OK) return st;
+            }
             chan = words;
         }
         if (!chan) {   // (host-built tables: the exact column bounds are maxima over ALL of T -- the absent blocks need their zeros)
@@ -2074,20 +2079,37 @@ gf_status smp_fused_backward_level(gf_smp *s, int l, const float *Kl, float *dKl
         if (st != GF_OK) return st;
         s->lv[l].dz_rows = d.fwd_npanels;
         s->lv[l].dz_ld = C;
+        s->lv[l].dz_rows2 = 0;
         const BigPart big = big_part(h);
-        if (big.nodes > 0) {   // the nodes above 32 positions (smp_fused_supported: C = 64): the workgroup kernel, its column maxima behind the panels'
-            const size_t lds = std::max(combine_lds<16>(big.smax), sizeof(float) * ((size_t)adj_lds_floats(big.smax) + 1024));
-            st = opt_in_lds(ctx, smp_combine_bwd<16>, lds);
-            if (st != GF_OK) return st;
-            GF_LAUNCH(ctx, "smpf_combine_bwd_big", (smp_combine_bwd<16>), dim3((unsigned)(big.quads * nwin)), dim3(kThreads), lds, d.f, dfrows, node_df, d.adj,
-                      dO, d.dVout, d.dSpart, d.dbpart, d.quad_node + big.quad0, d.quad_b0 + big.quad0, d.node_s, d.node_row, d.node_pair, C, nwin, d.rsum, 2,
-                      dzmax ? dzmax + (size_t)d.fwd_npanels * C : (float *)nullptr);
-            s->lv[l].dz_rows = d.fwd_npanels + big.quads;
+        if (big.nodes > 0) {   // the nodes above 32 positions: the workgroup kernel, its column maxima behind the panels' (one row of ITS window's
+            // width per workgroup: at C = 64 the panels' width -- one table; at 32 / 16 channels a second set, dz_rows2)
+            float *dz2 = dzmax ? dzmax + (size_t)d.fwd_npanels * C : (float *)nullptr;
+            if (smp_half_window(C)) {
+                const size_t lds = std::max(combine_lds<8>(big.smax), sizeof(float) * ((size_t)adj_lds_floats(big.smax) + 1024));
+                st = opt_in_lds(ctx, smp_combine_bwd<8>, lds);
+                if (st != GF_OK) return st;
+                GF_LAUNCH(ctx, "smpf_combine_bwd_big", (smp_combine_bwd<8>), dim3((unsigned)(big.quads * (C / 32))), dim3(kThreads), lds, d.f, dfrows, node_df, d.adj,
+                          dO, d.dVout, d.dSpart, d.dbpart, d.quad_node + big.quad0, d.quad_b0 + big.quad0, d.node_s, d.node_row, d.node_pair, C, C / 32, d.rsum, 2, dz2);
+            } else {
+                const size_t lds = std::max(combine_lds<16>(big.smax), sizeof(float) * ((size_t)adj_lds_floats(big.smax) + 1024));
+                st = opt_in_lds(ctx, smp_combine_bwd<16>, lds);
+                if (st != GF_OK) return st;
+                GF_LAUNCH(ctx, "smpf_combine_bwd_big", (smp_combine_bwd<16>), dim3((unsigned)(big.quads * nwin)), dim3(kThreads), lds, d.f, dfrows, node_df, d.adj,
+                          dO, d.dVout, d.dSpart, d.dbpart, d.quad_node + big.quad0, d.quad_b0 + big.quad0, d.node_s, d.node_row, d.node_pair, C, nwin, d.rsum, 2, dz2);
+            }
+            if (C == 64) {
+                s->lv[l].dz_rows = d.fwd_npanels + big.quads;
+            } else {
+                s->lv[l].dz_rows2 = big.quads * (smp_half_window(C) ? C / 32 : nwin);
+                s->lv[l].dz_off2 = (long long)d.fwd_npanels * C;
+                s->lv[l].dz_ld2 = smp_half_window(C) ? 32 : 64;
+            }
         }
         (void)Kl;
         return smp_fused_backward_level_grouped(s, l, dKl, dbl);
     }
     s->lv[l].dz_rows = (long long)h.quad_node.size();
+    s->lv[l].dz_rows2 = 0;
     s->lv[l].dz_ld = smp_half_window(C) ? 32 : 64;   // (the workgroup kernels write one row of their window's width)
     if (smp_half_window(C)) {   // eight lanes per row (32-channel windows): at C = 32 every lane has channels
         const int nw8 = C / 32, N = h.buckets.back().s;

@@ -173,6 +173,8 @@ struct gf_smp {
         float *dzmax = nullptr;    // [max(quads, row panels)][64] largest |dz| of every workgroup / panel of combine-backward
         long long dz_rows = 0;     // ... rows of it the last combine-backward wrote
         int dz_ld = 64;            // ... and their width in floats
+        long long dz_rows2 = 0, dz_off2 = 0;   // a second set behind them (floats from dzmax), of another width: the workgroup kernel's rows for the
+        int dz_ld2 = 64;                       // nodes above 32 positions of a 32- / 16-channel level (panel rows are C floats wide, its rows 32 / 64)
         bool pmax_ready = false;
         void *wimg = nullptr;  // the split product kernels' weight images of this pass (smp_split_build_images), C = 64
         bool wimg_ready = false;

@@ -1003,7 +1003,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
 //   * Buffer addressing with the descriptor REBASED per slice (wave-uniform scalar arithmetic): lane offsets are constants, the row
 //     of a request rides in its scalar offset, rows past the end of the level are out of range (they load zeros), and a row whose
 //     block is structurally zero (packed table, see smp_rowpanel_split) gets an out-of-range offset.  The gathered rows dU[trow] lie
-//     inside the row's own node (< 1024 rows away): their descriptor starts 1024 rows below the slice.  Any level size.
+//     inside the row's own node (< s^2 <= 4096 rows away, kTrowWindow: 1024 until round 6, when nodes of up to 64 positions joined the
+//     fused level -- the gradient of K11 lost their far rows): their descriptor starts that many rows below the slice.  Any level size.
 //   * Two slices in flight per wave behind the one being multiplied; the slice's packed table entries and row factors are
 //     requested a slice earlier than its operands, BEFORE the previous slice's operand requests, so that waiting for them does not
 //     wait for those (loads return in order).  The fragments are pinned (an empty asm) ahead of the requests: left alone the split
@@ -1011,6 +1012,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
 //     copied into place behind a drained queue at the loop's end.
 //   * Same partial images (8 x CB x CB floats per workgroup), same fold as the staged kernel.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr long long kTrowWindow = (long long)kFusedMaxField * kFusedMaxField;   // rows a transposed row (e, x) lies from its row (x, e) at most
 constexpr int kWdThreads = 512;
 template <int CB>
 __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *__restrict__ T, const float *__restrict__ dO,
@@ -1101,13 +1103,13 @@ __global__ __launch_bounds__(kWdThreads, 1) void smp_wgrad_direct(const float *_
     auto load_raw = [&](Raw &R, const Idx &I, int n) {
         const long long k0 = slice_of(n) * SL;
         const bool live = k0 < rows;
-        // descriptors of this slice: T rows [k0, k0 + SL); dO rows [g0, min(rows, k0 + SL + 1024)) with g0 = max(0, k0 - 1024)
+        // descriptors of this slice: T rows [k0, k0 + SL); dO rows [g0, min(rows, k0 + SL + kTrowWindow)) with g0 = max(0, k0 - kTrowWindow)
         long long left = (long long)rows - k0;
         left = left < 0 ? 0 : left > SL ? SL : left;
         const long long k0c = live ? k0 : 0;
         const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(T + (size_t)k0c * ACOLS), 0, (unsigned)(left * TROW), 0x00020000);
-        const long long g0 = k0c > 1024 ? k0c - 1024 : 0;
-        long long g1 = k0c + SL + 1024;
+        const long long g0 = k0c > kTrowWindow ? k0c - kTrowWindow : 0;
+        long long g1 = k0c + SL + kTrowWindow;
         g1 = g1 > rows ? rows : g1;
         const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dO + (size_t)g0 * 2 * CB), 0, live ? (unsigned)((g1 - g0) * DROW) : 0u, 0x00020000);
         const int own = (int)(k0c - g0) * DROW;   // the slice's first row inside the dO window
@@ -1323,8 +1325,8 @@ __global__ __launch_bounds__(kW8Threads, 1) void smp_wgrad_all(const float *__re
         left = left < 0 ? 0 : left > SL ? SL : left;
         const long long k0c = live ? k0 : 0;
         const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(T + (size_t)k0c * ACOLS), 0, (unsigned)(left * TROW), 0x00020000);
-        const long long g0 = k0c > 1024 ? k0c - 1024 : 0;
-        long long g1 = k0c + SL + 1024;
+        const long long g0 = k0c > kTrowWindow ? k0c - kTrowWindow : 0;
+        long long g1 = k0c + SL + kTrowWindow;
         g1 = g1 > rows ? rows : g1;
         const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dO + (size_t)g0 * 2 * CB), 0, live ? (unsigned)((g1 - g0) * DROW) : 0u, 0x00020000);
         const int own = (int)(k0c - g0) * DROW;
