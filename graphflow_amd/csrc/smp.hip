@@ -2178,6 +2178,17 @@ static gf_status smp_forward_impl(gf_smp *s, const float *params, const float *t
             else
                 GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes, dim3(gf::grid_for((size_t)B.level[l].nNodes * Cc)), dim3(256), 0, d.f,
                           d.node_s, d.node_row, d.sh, d.vf, Cc, (size_t)B.level[l].nNodes * Cc);
+            if (l >= 1 && d.psum && d.psum_ready && gf::smp_panel_channels(Cc)) {   // (the nodes above 32 positions have no panels: from their rows)
+                int n0 = B.level[l].nNodes;
+                for (const gfsmp::Bucket &bk : B.level[l].buckets)
+                    if (bk.s > 32) {
+                        n0 = bk.first_node;
+                        break;
+                    }
+                if (n0 < B.level[l].nNodes)
+                    GF_LAUNCH(ctx, "smp_readout_nodes", gf::readout_nodes_v, dim3(B.level[l].nNodes - n0), dim3(256), 0, d.f, d.node_s + n0, d.node_row + n0,
+                              d.sh + (size_t)n0 * Cc, d.vf + (size_t)n0 * Cc, Cc);
+            }
             GF_LAUNCH(ctx, "smp_level_feature", gf::level_feature_sum, dim3(B.nMol), dim3(64), 0, d.vf, s->mol_ptr, d.node_of_vertex, s->g,
                       Cc, width, off);
             off += Cc;

@@ -154,3 +154,39 @@ def test_fused_levels_under_slice_dropout_equal_the_op_by_op_levels(gf, monkeypa
     print("dropout fused vs op-by-op (train %s): predict %.2e loss %.2e grads %.2e" % (train, rel_err(p1, p0), rel_err(l1, l0), rel_err(g1, g0)))
     assert rel_err(p1, p0) <= 2e-6 and rel_err(l1, l0) <= 4e-6
     assert rel_err(g1, g0) <= TOL
+
+
+@pytest.mark.parametrize("towers,Cn", [(1, 32), (2, 10)])
+def test_towers_with_fields_above_32_stay_on_the_fused_levels(gf, monkeypatch, towers, Cn):
+    """SMP_beta_physics / SMP_beta_pairgraphs have no receptive-field cap (SMP_beta_physics.h): 48-atom graphs reach 36 - 41 positions at level 3.
+    Round 6: such a level stays on the fused kernels (smp_fused.hip: big_part; every level of a tower is read out -- the nodes above
+    32 positions from their rows).  Against GF_SMP_BIG_FIELDS=0, the op-by-op level of round 5: predictions and every gradient."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from inputs import synthetic_molecule
+    from graphflow_amd.smp import SMPModel
+    L, cap = 3, 48
+    g1 = [synthetic_molecule(sd, nV=48)[:2] for sd in (8017, 8003, 8026)] + [synthetic_molecule(8100 + i)[:2] for i in range(3)]
+    g2 = [synthetic_molecule(sd, nV=48)[:2] for sd in (8028, 8000, 8005)] + [synthetic_molecule(8200 + i)[:2] for i in range(3)]
+    t = dev(np.arange(1.0, 7.0))
+
+    def step():
+        net = SMPModel(L, Cn, cap, [5] * towers)
+        rng = np.random.default_rng(21)
+        p = dev(rng.uniform(-1, 1, net.n_params) / np.sqrt(18 * Cn))
+        net.prepare(g1, g2 if towers == 2 else None)
+        pred = net.forward(p, t)[0].cpu().numpy().astype(np.float64)
+        g = torch.full((net.n_params,), float("nan"), device="cuda")
+        net.backward(p, g)
+        used = net.device_bytes() if hasattr(net, "device_bytes") else None
+        net.close()
+        return pred, g.cpu().numpy().astype(np.float64), used
+
+    a = step()
+    monkeypatch.setenv("GF_SMP_BIG_FIELDS", "0")
+    b = step()
+    e = (rel_err(a[0], b[0]), rel_err(a[1], b[1]))
+    print("towers %d C %d, fields above 32: fused vs op-by-op level: predict %.2e grads %.2e" % (towers, Cn, e[0], e[1]))
+    assert np.isfinite(a[1]).all() and np.abs(a[1]).max() > 0
+    assert e[0] <= TOL and e[1] <= 2 * TOL, e
+    assert not np.array_equal(a[1], b[1])   # (really two different paths)
