@@ -741,6 +741,44 @@ def main():
                         del s7, k7, c7
                     except Exception as e:   # noqa: BLE001
                         extra[name] = {"error": repr(e)}
+            if args.C == 64:
+                # SMP_beta (no receptive-field cap) on molecules larger than QM9's: 256 synthetic 44..48-atom molecules, whose level-3 fields
+                # reach 36 - 41 positions for one or two nodes each.  Round 6 keeps such a level on the fused kernels; the same
+                # step with GF_SMP_BIG_FIELDS=0 (the level op by op, as until round 5) rides beside it.
+                try:
+                    from graphflow_amd.smp import SMPOmega
+                    from inputs import smp_params, synthetic_molecule
+                    import numpy as np
+                    nvb, nb = 48, 256
+                    bm = [synthetic_molecule(i, nV=nvb - i % 5)[:2] for i in range(nb)]
+                    bctx = gf.Context(dev.index)
+                    bnet = SMPOmega(3, 64, 5, 5, nvb, True, ctx=bctx)
+                    bnet.prepare(bm)
+                    bp = torch.as_tensor(smp_params(64, 5, 5, 3, 1).astype(np.float32)).to(dev)
+                    bt = torch.as_tensor(np.array([float(len(a)) for a, _ in bm], dtype=np.float32)).to(dev)
+                    bg = torch.empty(bnet.n_params, device=dev)
+
+                    def bstep():
+                        bnet.forward(bp, bt)
+                        bnet.backward(bp, bg)
+
+                    els, _ = timed_run(torch, bctx, bstep, 20, 3, torch.cuda.synchronize, True, repeats=3)
+                    el = median(els)
+                    os.environ["GF_SMP_BIG_FIELDS"] = "0"
+                    try:
+                        els0, _ = timed_run(torch, bctx, bstep, 5, 2, torch.cuda.synchronize, True, repeats=1)
+                    finally:
+                        del os.environ["GF_SMP_BIG_FIELDS"]
+                    extra["beta_48_atoms"] = {"metric": "molecules/sec fwd+bwd, SMP_beta wiring (no receptive-field cap)", "value": round(nb * 20 / el, 1),
+                                              "unit": "molecules/s", "steps": 20, "warmup": 3, "ms_per_step": round(1e3 * el / 20, 4),
+                                              "ms_per_step_level_op_by_op": round(1e3 * median(els0) / 5, 4),
+                                              "workload": "SMP_beta 3 levels, C=64, F=5, D=5, no cap, batch=%d synthetic %d..%d-atom molecules (level sizes %s)"
+                                                          % (nb, nvb - 4, nvb, [bnet.level_sizes(l)[:2] for l in range(4)])}
+                    bnet.close()
+                    del bnet, bctx
+                    torch.cuda.empty_cache()
+                except Exception as e:   # noqa: BLE001
+                    extra["beta_48_atoms"] = {"error": repr(e)}
             for wl in ("cfg2", "cfg5"):
                 try:
                     ectx = gf.Context(dev.index)
