@@ -1244,7 +1244,7 @@ gf_status launch_tables_bwd(gf_smp *s, int l, const SizeClass &c, const float *d
 // q == c_w (the source's own vertex sits at position a of the consumer): they are summed over the consumers in two extra
 // accumulators, which start from the compact-path gradients of the same two positions, and join the row at the end.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kGatherMaxS = 32;
+constexpr int kGatherMaxS = 64;   // (32 until round 6)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Nothing but memory requests and sums inside the consumer loop (round 3).  Round 2's kernel (a workgroup per source, consumer lists
@@ -1486,7 +1486,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             else gather_source<4, 4, 12>(GF_GATHER_ARGS, w, chunk, 8);
             break;
         case 16: gather_source<8, 8, 16>(GF_GATHER_ARGS, w, chunk, 8 * qc); break;
-        default: gather_source<8, 8, 32>(GF_GATHER_ARGS, w, chunk, 8 * qc); break;
+        case 32: gather_source<8, 8, 32>(GF_GATHER_ARGS, w, chunk, 8 * qc); break;
+        default: gather_source<8, 8, 64>(GF_GATHER_ARGS, w, chunk, 8 * qc); break;   // (sources of 33 .. 64 positions: level 4 of a 48-atom molecule)
     }
 }
 
@@ -2182,7 +2183,7 @@ gf_status smp_fused_gather_backward(gf_smp *s, int l) {
     const int C = s->cfg.nChanels;
     const float *dT = d.Q + (size_t)h.rows * T_COLS * C + (size_t)h.rows * O_COLS * C;
     if (!d.cons_hdr) return fail(s->ctx, GF_ERR_INVALID, "smp_fused_gather_backward: level %d has no gather records", l);
-    if (!hp.buckets.empty() && hp.buckets.back().s > kGatherMaxS) return fail(s->ctx, GF_ERR_UNSUPPORTED, "smp_fused_gather_backward: receptive field > 32");
+    if (!hp.buckets.empty() && hp.buckets.back().s > kGatherMaxS) return fail(s->ctx, GF_ERR_UNSUPPORTED, "smp_fused_gather_backward: receptive field > 64");
     const gf_smp::DevLevel &pv = s->lv[l - 1];
     gf_ctx *ctx = s->ctx;
     const GatherTables G = {d.cons_hdr, d.cons_qrec};

@@ -135,7 +135,7 @@ struct LevelLayout {
 #define GF_PREP_HD
 #endif
 GF_PREP_HD inline int gather_pad(int s) {
-    return s <= 1 ? 1 : s <= 2 ? 2 : s <= 4 ? 4 : s <= 5 ? 5 : s <= 6 ? 6 : s <= 8 ? 8 : s <= 10 ? 10 : s <= 12 ? 12 : s <= 16 ? 16 : 32;
+    return s <= 1 ? 1 : s <= 2 ? 2 : s <= 4 ? 4 : s <= 5 ? 5 : s <= 6 ? 6 : s <= 8 ? 8 : s <= 10 ? 10 : s <= 12 ? 12 : s <= 16 ? 16 : s <= 32 ? 32 : 64;   // (64: round 6, sources of 33 .. 64 positions)
 }
 
 struct BatchLayout {

@@ -919,14 +919,15 @@ def test_cfg4_workload_as_eight_one_rank_shards(gf):
     assert e <= TOL_GRAD
 
 
-@pytest.mark.parametrize("nV,L,C", [(40, 3, 64), (48, 3, 64), (64, 3, 64), (48, 3, 32), (48, 3, 10), (40, 3, 16)])
+@pytest.mark.parametrize("nV,L,C", [(40, 3, 64), (48, 3, 64), (64, 3, 64), (48, 3, 32), (48, 3, 10), (40, 3, 16), (48, 4, 64), (48, 4, 10)])
 def test_fields_above_32_run_the_fused_level(gf, nV, L, C, monkeypatch):
     """SMP_beta (no receptive-field cap, SMP_beta.h) on molecules larger than QM9's: a 40- / 48- / 64-atom molecule's level-3 fields
     reach 34 / 35 / 37 positions, beyond the 32 the fused level's register classes and 32-row panels take.  Since round 6 such a level
     stays on the fused kernels at C = 64: its few nodes above 32 positions run tables-forward on smp_tables_fwd_big and the two combine
     steps on the workgroup kernels (smp_fused.hip: big_part), everything else is row-based.  Held against (a) the op-by-op level
     pipeline of the same batch (fused = False), kink-aware, (b) the fp64 port of the reference for one of the big molecules, and
-    (c) GF_SMP_BIG_FIELDS=0, which must reproduce round 5's behaviour (the level op by op: the promotion buffer is taken)."""
+    (c) GF_SMP_BIG_FIELDS=0, which must reproduce round 5's behaviour (the level op by op: the promotion buffer is taken).  L = 4: the
+    fields of level 4 reach 46 positions and its SOURCES (level 3) 41 -- the consumer gather's 64-record class (smp_bwd_gather_all)."""
     from oracle import pyoracle
     F, D = 5, 2
     mols, tg = [], []
