@@ -184,3 +184,18 @@ def test_host_pointer_matmul_f64(gf, oracle):
     a0, b0 = dA.copy(), dB.copy()
     ctx.check(lib.gf_matmul_backward_host_f64(ctx.handle, p(dC), p(A), p(B), p(dA), p(dB), M, K, N))
     assert rel_err(dA, a0 + dC @ B.T) <= REL_TOL_F32 and rel_err(dB, b0 + A.T @ dC) <= REL_TOL_F32
+
+
+@pytest.mark.parametrize("n", [4, 1024, 4096 + 8, (1 << 22) + 12])
+def test_hbm_copy_probe_copies(gf, n):
+    """gf_hbm_copy_probe_f32 (the bench's practical-ceiling probe): both kernels copy exactly -- whole 16 KiB tiles and the ragged tail --
+    and report a positive rate; bad arguments are refused."""
+    ctx = gf.Context(0)
+    src = torch.arange(n, dtype=torch.float32, device="cuda") * 0.5 + 1.0
+    for mode in (0, 1):
+        dst = torch.zeros(n, device="cuda")
+        rate = ctx.hbm_copy_probe(dst, src, mode, iters=2)
+        assert rate > 0 and torch.equal(dst, src), (n, mode)
+    with pytest.raises(gf.GraphFlowHipError):
+        ctx.hbm_copy_probe(torch.zeros(8, device="cuda"), torch.zeros(8, device="cuda"), 2, 1)
+    ctx.close()
