@@ -1042,12 +1042,12 @@ void gf::smp_derive_plan(gf_smp *s, bool allow_embed) {
         }
         // SMP_2D_ver6 (RisiContraction_10) embedded in the 18-slice fused level (see gf_smp::dup_channels): 2 C channels padded to 16 / 32 / 64.
         // GF_SMP_VER6_FUSED=0: the `_10` contraction op by op.  gf_smp_prepare switches to that plan by itself for a batch with an asymmetric adjacency.
-        // (only where every field fits the fused level -- max_receptive_field <= 32: on an op-by-op level the 18-slice model at 2 C padded
+        // (only where every field fits the fused level -- max_receptive_field <= 64 (32 until round 6): on an op-by-op level the 18-slice model at 2 C padded
         //  channels moves more than the `_10` / `_50` contraction at C; GF_SMP_VER6_FUSED=2 / GF_SMP_VER7_FUSED=2 embed at any cap)
         auto embed = [&](const char *name) {
             const char *v = std::getenv(name);
             if (!allow_embed || (v && v[0] == '0')) return false;
-            return s->cfg.max_receptive_field <= 32 || (v && v[0] == '2');
+            return s->cfg.max_receptive_field <= gf::kFusedMaxField || (v && v[0] == '2');   // (64 since round 6: fields of 33 .. 64 positions stay fused)
         };
         if (pad_channels && !(e && e[0] == '0') && s->cfg.nContractions == 10 && 2 * C <= 64 && s->cfg.nLevels < gf::kPadMaxLevels && !s->cfg.physics &&
             embed("GF_SMP_VER6_FUSED")) {

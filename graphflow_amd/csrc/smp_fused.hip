@@ -1584,7 +1584,7 @@ bool smp_fused_supported(const gf_smp *s, int l) {
     // on the workgroup kernels (big_part); the gather wants the SOURCES (level l - 1) within 32, the split row-panel products their packed tables
     const gf_smp::DevLevel &d = s->lv[l];
     const gfsmp::LevelLayout &hp = s->lay.level[l - 1];
-    return h.buckets.back().s <= kFusedMaxField && smp_panel_channels(C) && smp_tables_fold_vectors(s) && !s->drop_on && !s->dup_channels && smp_c64_kernels(s) &&
+    return h.buckets.back().s <= kFusedMaxField && smp_panel_channels(C) && smp_tables_fold_vectors(s) && !s->drop_on && smp_c64_kernels(s) &&
            smp_split_products(s->ctx) && s->bwd_gather && !hp.buckets.empty() && hp.buckets.back().s <= kGatherMaxS && d.trow && d.trowf && d.rowflag &&
            d.dzmax && d.row_max && d.fwd_pan && d.fwd_npanels > 0 && !env_is("GF_SMP_BIG_FIELDS", '0');
 }

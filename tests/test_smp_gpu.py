@@ -985,6 +985,48 @@ def test_fields_above_32_run_the_fused_level(gf, nV, L, C, monkeypatch):
         r[4].close()
 
 
+@pytest.mark.parametrize("nK,C", [(10, 10), (50, 10), (10, 16)])
+def test_smp_2d_ver6_ver7_with_fields_above_32(gf, monkeypatch, nK, C):
+    """SMP_2D_ver6 / ver7 have no receptive-field cap: on 48-atom molecules (level-3 fields up to 41 positions) the `_10` / `_50` levels stay
+    embedded in the fused 18-slice level since round 6 (a cap of up to 64; 32 before).  Against the op-by-op `_10` / `_50` levels
+    (GF_SMP_VER6_FUSED=0 / GF_SMP_VER7_FUSED=0), which the goldens pin to the real SMP_2D_ver6 / ver7."""
+    from graphflow_amd.smp import SMPOmega
+    L, F, D, nV = 3, 5, 2, 48
+    mols, tg = [], []
+    for seed in (8017, 8003, 8026, 8028):
+        adj, feat, t = synthetic_molecule(seed, nV=nV)
+        mols.append((adj, feat))
+        tg.append(t)
+    for i in range(6):
+        adj, feat, t = synthetic_molecule(8100 + i)
+        mols.append((adj, feat))
+        tg.append(t)
+    tg = np.array(tg)
+
+    def step():
+        net = SMPOmega(L, C, F, D, nV, True, nContractions=nK, custom_matmul=True)
+        params = f32exact(np.random.default_rng(19).uniform(-1, 1, net.n_params) / np.sqrt(nK * C))
+        net.prepare(mols)
+        p = dev(params)
+        pred, loss, feat = net.forward(p, dev(tg))
+        g = torch.full((net.n_params,), float("nan"), device="cuda")
+        net.backward(p, g)
+        return [x.cpu().numpy().astype(np.float64) for x in (pred, feat, g)] + [net]
+
+    a = step()
+    assert max(len(a[3].receptive_field(0, L, v)) for v in range(nV)) > 32
+    monkeypatch.setenv("GF_SMP_VER6_FUSED", "0")
+    monkeypatch.setenv("GF_SMP_VER7_FUSED", "0")
+    b = step()
+    name = "ver%d_big_fields_C%d" % (6 if nK == 10 else 7, C)
+    note(name, pred=rel_err(a[0], b[0]), feat=rel_err(a[1], b[1]))
+    assert np.isfinite(a[2]).all() and not np.array_equal(a[2], b[2])
+    assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[1], b[1]) <= TOL_FWD
+    assert_grads_agree_kink_aware(name, a[2], b[2], a[3], b[3], mols, L)
+    a[3].close()
+    b[3].close()
+
+
 def test_fields_above_32_in_a_level_beyond_the_panel_kernels_offsets(gf, monkeypatch):
     """The same with a level of more than 2^21 rows (200 molecules of 64 atoms: the panel combine kernels address O with 32-bit byte
     offsets and hand such a level to the workgroup kernels -- with nodes above 32 positions, their 64-position build for every node):
