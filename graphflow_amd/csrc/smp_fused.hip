@@ -809,7 +809,9 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
                                                             const long long *__restrict__ node_pair, int C, int nwin,
                                                             const float *__restrict__ Gc, const long long *__restrict__ pair_src_pair,
                                                             const short *__restrict__ pi, const float *__restrict__ rsum,
-                                                            int ocols) {  // 3: O = [O_loc | Z | Z']; 2: O = [O_loc | U], U = Z + Z'^T
+                                                            int ocols,  // 3: O = [O_loc | Z | Z']; 2: O = [O_loc | U], U = Z + Z'^T
+                                                            const float *__restrict__ nodefac = nullptr) {  // (or null) slice dropout: [nodes][18]
+    // factors; the compact products G15 / G16 take theirs here (as smp_combine_fwd_panels)
     constexpr int CW = 4 * LPC;
     const size_t ldo = (size_t)ocols * C;
     constexpr int NGRP = kThreads / LPC;
@@ -842,8 +844,9 @@ __global__ __launch_bounds__(kThreads) void smp_combine_fwd(const float *__restr
             const int pxe = pi[rowbase + (size_t)x * N + e], pex = pi[rowbase + (size_t)e * N + x];
             const f4 g15 = ld4(Gc + (size_t)(pair_src_pair[pairbase + x] + (pxe >= 0 ? pxe : 0)) * 2 * C + fc);
             const f4 g16 = ld4(Gc + (size_t)(pair_src_pair[pairbase + e] + (pex >= 0 ? pex : 0)) * 2 * C + C + fc);
-            if (pxe >= 0) u += g15;
-            if (pex >= 0) u += g16;
+            const float c15 = nodefac ? nodefac[(size_t)W.node * 18 + 15] : 1.f, c16 = nodefac ? nodefac[(size_t)W.node * 18 + 16] : 1.f;
+            if (pxe >= 0) u += c15 * g15;
+            if (pex >= 0) u += c16 * g16;
         }
         st4(sU + (size_t)it * CW + 4 * fl, fok ? u : splat(0.f));
     }
@@ -1584,7 +1587,7 @@ bool smp_fused_supported(const gf_smp *s, int l) {
     // on the workgroup kernels (big_part); the gather wants the SOURCES (level l - 1) within 32, the split row-panel products their packed tables
     const gf_smp::DevLevel &d = s->lv[l];
     const gfsmp::LevelLayout &hp = s->lay.level[l - 1];
-    return h.buckets.back().s <= kFusedMaxField && smp_panel_channels(C) && smp_tables_fold_vectors(s) && !s->drop_on && smp_c64_kernels(s) &&
+    return h.buckets.back().s <= kFusedMaxField && smp_panel_channels(C) && smp_tables_fold_vectors(s) && smp_c64_kernels(s) &&
            smp_split_products(s->ctx) && s->bwd_gather && !hp.buckets.empty() && hp.buckets.back().s <= kGatherMaxS && d.trow && d.trowf && d.rowflag &&
            d.dzmax && d.row_max && d.fwd_pan && d.fwd_npanels > 0 && !env_is("GF_SMP_BIG_FIELDS", '0');
 }
@@ -1759,7 +1762,7 @@ gf_status smp_fused_forward_level(gf_smp *s, int l, const float *Kl, const float
             if (st != GF_OK) return st;
             GF_LAUNCH(ctx, "smpf_combine_fwd_big", (smp_combine_fwd<16, kFusedMaxField>), dim3((unsigned)(big.quads * nwin)), dim3(kThreads), lds, O, d.adj,
                       d.Vout, d.Sout, bl, d.f, d.quad_node + big.quad0, d.quad_b0 + big.quad0, d.node_s, d.node_row, d.node_pair, C, nwin, d.Gc,
-                      d.pair_src_pair, d.pi, d.rsum, ocols);
+                      d.pair_src_pair, d.pi, d.rsum, ocols, drop ? d.nodefac : (const float *)nullptr);
         }
         return st;
     }

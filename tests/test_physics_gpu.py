@@ -156,8 +156,8 @@ def test_fused_levels_under_slice_dropout_equal_the_op_by_op_levels(gf, monkeypa
     assert rel_err(g1, g0) <= TOL
 
 
-@pytest.mark.parametrize("towers,Cn", [(1, 32), (2, 10)])
-def test_towers_with_fields_above_32_stay_on_the_fused_levels(gf, monkeypatch, towers, Cn):
+@pytest.mark.parametrize("towers,Cn,nKept", [(1, 32, 0), (2, 10, 0), (2, 10, 9), (2, 32, 12)])
+def test_towers_with_fields_above_32_stay_on_the_fused_levels(gf, monkeypatch, towers, Cn, nKept):
     """SMP_beta_physics / SMP_beta_pairgraphs have no receptive-field cap (SMP_beta_physics.h): 48-atom graphs reach 36 - 41 positions at level 3.
     Round 6: such a level stays on the fused kernels (smp_fused.hip: big_part; every level of a tower is read out -- the nodes above
     32 positions from their rows).  Against GF_SMP_BIG_FIELDS=0, the op-by-op level of round 5: predictions and every gradient."""
@@ -171,7 +171,10 @@ def test_towers_with_fields_above_32_stay_on_the_fused_levels(gf, monkeypatch, t
     t = dev(np.arange(1.0, 7.0))
 
     def step():
-        net = SMPModel(L, Cn, cap, [5] * towers)
+        net = SMPModel(L, Cn, cap, [5] * towers, nKept=nKept)
+        if nKept:   # (SMP_sigma_pairgraphs: slice dropout -- the same rand() stream for both runs)
+            net.set_mode(True)
+            C.CDLL(None).srand(4242)
         rng = np.random.default_rng(21)
         p = dev(rng.uniform(-1, 1, net.n_params) / np.sqrt(18 * Cn))
         net.prepare(g1, g2 if towers == 2 else None)
@@ -186,7 +189,7 @@ def test_towers_with_fields_above_32_stay_on_the_fused_levels(gf, monkeypatch, t
     monkeypatch.setenv("GF_SMP_BIG_FIELDS", "0")
     b = step()
     e = (rel_err(a[0], b[0]), rel_err(a[1], b[1]))
-    print("towers %d C %d, fields above 32: fused vs op-by-op level: predict %.2e grads %.2e" % (towers, Cn, e[0], e[1]))
+    print("towers %d C %d nKept %d, fields above 32: fused vs op-by-op level: predict %.2e grads %.2e" % (towers, Cn, nKept, e[0], e[1]))
     assert np.isfinite(a[1]).all() and np.abs(a[1]).max() > 0
     assert e[0] <= TOL and e[1] <= 2 * TOL, e
     assert not np.array_equal(a[1], b[1])   # (really two different paths)
