@@ -31,7 +31,7 @@ def reference():
 @pytest.fixture(scope="session")
 def golden():
     g = {}
-    for name in ("contractions", "contractions_wide", "contractions_16x8", "stack", "mixers", "smp", "dropout"):
+    for name in ("contractions", "contractions_wide", "contractions_16x8", "stack", "mixers", "smp", "smp_big", "dropout"):
         path = os.path.join(ROOT, "tests", "golden", name + ".npz")
         with np.load(path) as z:
             g.update({k: z[k] for k in z.files})

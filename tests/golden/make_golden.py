@@ -295,6 +295,33 @@ def smp_fixtures():
     return out
 
 
+def big_field_fixtures():
+    """Round 6: SMP_beta (no receptive-field cap) on a 40-atom molecule whose level-3 fields reach 35 positions -- beyond the 32 the fused
+    level's register classes and row panels take, the case smp_fused.hip's big_part serves -- from the REAL SMP_beta (fields from SMP_omega
+    with the cap at max_nVertices, as for smp_beta_syn13), at 8 channels (computed at 16 padded) and at 32."""
+    out = {}
+    adj, feat, tgt = synthetic_molecule(8003, 40)
+    L, D = 3, 2
+    V = len(adj)
+    for C in (8, 32):
+        params = smp_params(C, feat.shape[1], D, L, 140 + C)
+        rb = pyoracle.reference_smp_beta(adj, feat, tgt, params, L, C, D, True, V)
+        ro = pyoracle.reference_smp_omega(adj, feat, tgt, params, L, C, D, V, has_wl=True, max_nVertices=V)
+        phi = np.full((L + 1, V, V + 1), -1, dtype=np.int32)
+        for l in range(L + 1):
+            for v in range(V):
+                phi[l, v, 0] = len(ro["phi"][l][v])
+                phi[l, v, 1:1 + len(ro["phi"][l][v])] = ro["phi"][l][v]
+        assert phi[L, :, 0].max() > 32
+        p = "smp_beta_big40_C%d" % C
+        out[p + "__adj"], out[p + "__feature"], out[p + "__target"] = adj.astype(np.int32), feat, np.array([tgt])
+        out[p + "__cfg"] = np.array([L, C, D, V, 1], dtype=np.int32)
+        out[p + "__params"] = params.astype(np.float32)
+        out[p + "__phi"], out[p + "__graph_feature"] = phi, rb["graph_feature"]
+        out[p + "__predict"], out[p + "__loss"], out[p + "__grads"] = np.array([rb["predict"]]), np.array([rb["loss"]]), rb["grads"]
+    return out
+
+
 def train_fixture():
     """Three SMP_omega::BatchLearn steps of the real reference on the four toy molecules of tests/test_SMP_omega.cpp as one batch,
     starting from the weights its own constructor draws after srand(7) (weights_initialization)."""
@@ -468,6 +495,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "stack.npz"), **stack_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "dropout.npz"), **dropout_fixtures(ref))
     np.savez_compressed(os.path.join(HERE, "smp.npz"), **smp_fixtures())
+    np.savez_compressed(os.path.join(HERE, "smp_big.npz"), **big_field_fixtures())
     checkpoint_fixture()
     train_fixture()
     physics_fixtures()
@@ -487,7 +515,8 @@ if __name__ == "__main__":
         pyoracle.build()
         np.savez_compressed(os.path.join(HERE, "contractions_16x8.npz"), **contraction_16x8_fixtures(pyoracle.reference()))
         np.savez_compressed(os.path.join(HERE, "stack.npz"), **stack_fixtures(pyoracle.reference()))
-        for f in ("contractions_16x8.npz", "stack.npz"):
+        np.savez_compressed(os.path.join(HERE, "smp_big.npz"), **big_field_fixtures())
+        for f in ("contractions_16x8.npz", "stack.npz", "smp_big.npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
     elif len(sys.argv) > 1 and sys.argv[1] == "wide":   # only the RisiContraction_50 fixtures at C % 32 == 0
         pyoracle.build()
