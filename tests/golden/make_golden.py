@@ -474,6 +474,43 @@ def physics_fixtures():
     np.savez_compressed(os.path.join(HERE, "smp_physics.npz"), **out)
 
 
+def physics_big_fixtures():
+    """Round 6: the real SMP_beta_physics and SMP_sigma_pairgraphs (slice dropout, train mode) on 40-atom graphs whose level-3 fields exceed
+    32 positions -- the towers' fused levels with nodes above 32 (smp_fused.hip: big_part).  Same recipe as physics_fixtures."""
+    out = {}
+    rng = np.random.default_rng(8304)
+    g40a, g40b = synthetic_molecule(8003, 40), synthetic_molecule(8017, 40)
+    L, C, cap = 3, 8, 40
+    adj, feat, tgt = g40a
+    F = feat.shape[1]
+    width = sum(pyoracle.physics_channels(C, L))
+    nh = width // 2
+    params = f32exact(rng.uniform(-0.3, 0.3, pyoracle.physics_tower_param_count(C, F, L) + nh * width + nh))
+    r = pyoracle.reference_smp_physics(adj, feat, tgt, params, L, C, cap, beta=True, max_nVertices=len(adj))
+    assert int(np.asarray(r["phi"])[L, :, 0].max()) > 32
+    p = "physics_phys_beta_big40"
+    out[p + "__adj"], out[p + "__feature"], out[p + "__target"] = adj.astype(np.int32), feat, np.array([tgt])
+    out[p + "__cfg"] = np.array([1, L, C, cap, 0, 1], dtype=np.int32)
+    out[p + "__params"] = params.astype(np.float32)
+    out[p + "__phi"], out[p + "__graph_feature"] = r["phi"], r["graph_feature"]
+    out[p + "__predict"], out[p + "__loss"], out[p + "__grads"] = np.array([r["predict"]]), np.array([r["loss"]]), r["grads"]
+    nKept, seed = 9, 5
+    nTot = 2 * width
+    h1 = max(nTot // 2, 10)
+    h2 = max(h1 // 2, 10)
+    params = f32exact(rng.uniform(-0.3, 0.3, 2 * pyoracle.physics_tower_param_count(C, F, L) + h1 * nTot + h2 * h1 + h2))
+    r = pyoracle.reference_smp_pairgraphs(2, g40a[:2], g40b[:2], g40a[2], params, L, C, cap, nKept=nKept, train=True, seed=seed, maxV=40)
+    p = "physics_pair_sigma_big40_train"
+    out[p + "__adj"], out[p + "__feature"], out[p + "__target"] = g40a[0].astype(np.int32), g40a[1], np.array([g40a[2]])
+    out[p + "__adj2"], out[p + "__feature2"] = g40b[0].astype(np.int32), g40b[1]
+    out[p + "__cfg"] = np.array([2, L, C, cap, nKept, 1], dtype=np.int32)
+    out[p + "__seed"] = np.array([seed], dtype=np.int32)
+    out[p + "__params"] = params.astype(np.float32)
+    out[p + "__phi"], out[p + "__phi2"], out[p + "__graph_feature"] = r["phi1"], r["phi2"], r["graph_feature"]
+    out[p + "__predict"], out[p + "__loss"], out[p + "__grads"] = np.array([r["predict"]]), np.array([r["loss"]]), r["grads"]
+    np.savez_compressed(os.path.join(HERE, "smp_physics_big.npz"), **out)
+
+
 def checkpoint_fixture():
     """smp_syn12's parameters as SMP_omega::save_model writes them (SMP_omega.h:1033-1042): a data file, 6 significant digits."""
     for i, (tag, adj, feat, tgt, (L, C, D, cap, wl, maxV)) in enumerate(smp_cases()):
@@ -499,6 +536,7 @@ def main():
     checkpoint_fixture()
     train_fixture()
     physics_fixtures()
+    physics_big_fixtures()
     headline_fixture()
     with open(os.path.join(HERE, "structural_50.json"), "w") as fh:
         json.dump(structural_50(), fh, indent=1)
@@ -516,7 +554,8 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "contractions_16x8.npz"), **contraction_16x8_fixtures(pyoracle.reference()))
         np.savez_compressed(os.path.join(HERE, "stack.npz"), **stack_fixtures(pyoracle.reference()))
         np.savez_compressed(os.path.join(HERE, "smp_big.npz"), **big_field_fixtures())
-        for f in ("contractions_16x8.npz", "stack.npz", "smp_big.npz"):
+        physics_big_fixtures()
+        for f in ("contractions_16x8.npz", "stack.npz", "smp_big.npz", "smp_physics_big.npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
     elif len(sys.argv) > 1 and sys.argv[1] == "wide":   # only the RisiContraction_50 fixtures at C % 32 == 0
         pyoracle.build()

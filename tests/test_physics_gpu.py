@@ -15,8 +15,11 @@ TOL = 1e-5
 
 
 def cases():
-    with np.load(os.path.join(os.path.dirname(__file__), "golden", "smp_physics.npz")) as z:
-        return golden_cases({k: z[k] for k in z.files}, "physics_")
+    g = {}
+    for name in ("smp_physics.npz", "smp_physics_big.npz"):   # (the second: round 6, 40-atom graphs with fields above 32 positions)
+        with np.load(os.path.join(os.path.dirname(__file__), "golden", name)) as z:
+            g.update({k: z[k] for k in z.files})
+    return golden_cases(g, "physics_")
 
 
 def dev(x):
@@ -43,7 +46,7 @@ def run(c):
 
 def test_physics_and_pairgraphs_goldens(gf):
     cs = cases()
-    assert len(cs) >= 7
+    assert len(cs) >= 9
     for tag, c in cs.items():
         pred, loss, grads, net = run(c)
         e = (rel_err(pred, c["predict"]), rel_err(loss, c["loss"]))
