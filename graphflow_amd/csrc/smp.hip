@@ -1579,21 +1579,22 @@ gf_status gf_smp_prepare_coulomb(gf_smp *s, int nMol, const int *nVertices, cons
             if (s->cfg.nContractions == 18 && h.rows * 256 < 0x3fffffffll && !h.buckets.empty() && h.buckets.back().s <= gf::kFusedMaxField) {
                 // row panels of the fused forward level (smp_level_c64_fwd.hip): a node of size s has ceil(s / max(1, 32 / s)) panels
                 const int np = h.npanels;   // (page-locked table of the layout: no wait for the copy)
+                const size_t np1 = (size_t)(np > 0 ? np : 1);   // (a level whose nodes are ALL above 32 positions has no panel: the tables exist all the same)
                 d.fwd_npanels = np;
                 UP(d.node_panel, h.node_panel);
-                st = gf::upload(s, &d.fwd_pan, nullptr, (size_t)np);
+                st = gf::upload(s, &d.fwd_pan, nullptr, np1);
                 if (st != GF_OK) return st;
                 if (l == L || s->cfg.physics) {   // (the top level -- every level of a tower: the readout's partial sums)
-                    st = gf::upload(s, &d.psum, nullptr, (size_t)np * C);
+                    st = gf::upload(s, &d.psum, nullptr, np1 * C);
                     if (st != GF_OK) return st;
                 }
                 if (l < L) {   // (below the top level: the per-panel channel maxima the level above scales its weight-gradient operands with)
-                    st = gf::upload(s, &d.pmax, nullptr, (size_t)np * C);
+                    st = gf::upload(s, &d.pmax, nullptr, np1 * C);
                     if (st != GF_OK) return st;
                 }
-                st = gf::upload(s, &d.dzmax, nullptr, (h.quad_node.size() + (size_t)np) * 64);   // (panels, then the workgroups of the nodes above 32 positions)
+                st = gf::upload(s, &d.dzmax, nullptr, (h.quad_node.size() + np1) * 64);   // (panels, then the workgroups of the nodes above 32 positions)
                 if (st != GF_OK) return st;
-                st = gf::upload(s, &d.fwd_pan_node, nullptr, (size_t)np);
+                st = gf::upload(s, &d.fwd_pan_node, nullptr, np1);
                 if (st != GF_OK) return st;
                 st = gf::upload(s, &d.fwd_goff, nullptr, (size_t)h.rows);
                 if (st != GF_OK) return st;

@@ -1589,7 +1589,7 @@ bool smp_fused_supported(const gf_smp *s, int l) {
     const gfsmp::LevelLayout &hp = s->lay.level[l - 1];
     return h.buckets.back().s <= kFusedMaxField && smp_panel_channels(C) && smp_tables_fold_vectors(s) && smp_c64_kernels(s) &&
            smp_split_products(s->ctx) && s->bwd_gather && !hp.buckets.empty() && hp.buckets.back().s <= kGatherMaxS && d.trow && d.trowf && d.rowflag &&
-           d.dzmax && d.row_max && d.fwd_pan && d.fwd_npanels > 0 && !env_is("GF_SMP_BIG_FIELDS", '0');
+           d.dzmax && d.row_max && d.fwd_pan && !env_is("GF_SMP_BIG_FIELDS", '0');
 }
 
 // Q buffer of the level ([rows][18C]) is carved as  T [rows][6C] | O / dO [rows][3C] | dT [rows][6C]

@@ -1027,6 +1027,39 @@ def test_smp_2d_ver6_ver7_with_fields_above_32(gf, monkeypatch, nK, C):
     b[3].close()
 
 
+@pytest.mark.parametrize("C,mixed", [(64, False), (64, True), (10, False)])
+def test_dense_graphs_whose_fields_are_all_above_32(gf, C, mixed):
+    """An Erdos-Renyi graph of 50 vertices (the size tests/test_graph_permutation_invariant.cu runs): from level 2 on EVERY receptive
+    field is (nearly) the whole graph -- a level without a single row panel, whose sources are above 32 positions as well (the consumer
+    gather's 64-record class).  Alone in the batch, and beside QM9-size molecules.  Fused against the op-by-op levels."""
+    from inputs import er_graph
+    L, F, D, V = 3, 5, 2, 50
+    mols, tg = [], []
+    for seed in (3, 4):   # (p = 0.2: levels 2 AND 3 without a node within 32 positions -- 33 .. 50 and 50)
+        adj, feat = er_graph(V, 0.2, F, seed)
+        mols.append((adj, feat))
+        tg.append(1.5)
+    if mixed:
+        for i in range(5):
+            adj, feat, t = synthetic_molecule(8300 + i)
+            mols.append((adj, feat))
+            tg.append(t)
+    tg = np.array(tg)
+    params = smp_params(C, F, D, L, 13) * 0.1   # (dense fields: keep the activations of level 3 in range)
+    a = run_batch(gf, mols, tg, params, L, C, F, D, V, fused=True)
+    s2, s3 = ([len(a[4].receptive_field(0, l, v)) for v in range(V)] for l in (2, 3))
+    assert min(s2) > 32 and min(s3) > 32, (s2, s3)   # not one node within 32 positions at levels 2 and 3; level 3's sources above 32 as well
+    b = run_batch(gf, mols, tg, params, L, C, F, D, V, fused=False)
+    name = "dense_er50_C%d%s" % (C, "_mixed" if mixed else "")
+    note(name, pred=rel_err(a[0], b[0]), feat=rel_err(a[2], b[2]))
+    assert np.isfinite(a[3]).all() and np.abs(a[3]).max() > 0
+    assert rel_err(a[0], b[0]) <= TOL_FWD and rel_err(a[2], b[2]) <= TOL_FWD
+    assert_grads_agree_kink_aware(name, a[3], b[3], a[4], b[4], mols, L)
+    assert a[4].device_bytes()[0] < b[4].device_bytes()[0]   # (no promoted stack: the fused levels ran)
+    a[4].close()
+    b[4].close()
+
+
 def test_fields_above_32_in_a_level_beyond_the_panel_kernels_offsets(gf, monkeypatch):
     """The same with a level of more than 2^21 rows (200 molecules of 64 atoms: the panel combine kernels address O with 32-bit byte
     offsets and hand such a level to the workgroup kernels -- with nodes above 32 positions, their 64-position build for every node):
