@@ -322,7 +322,8 @@ def setup_smp(args, torch, gf, dev, world, rank, ctx):
             add(kb, "smpf_small_nt", 4 * (pr * C + 4 * pr * C + n_l * C + 4 * n_l * C + 2 * pp * C + 2 * pp * C))   # dVout -> dVt, dSout -> dSt, dGc -> dFdc
             add(kb, "smpf_small_tn", 4 * (4 * pr * C + pr * C + 4 * n_l * C + n_l * C + 4 * pp * C))                # Vt, dVout, St, dSout, Fdc, dGc in
             add(kb, "smpf_diag_gather_bwd", 4 * (2 * present[l] * C + 2 * pp * C))          # dU[(a, b)], dU[(b, a)] of the rows with data in; dGc out
-            add(kb, "smpf_reduce_pairs", 4 * (2 * pr * C + n_l * C))                        # dSpart, dbpart in; dSout out
+            # dSpart, dbpart in; dSout out -- since round 6 in ONE launch with the diagonal gather (GF_SMP_FUSE_SMALL=0: its own)
+            add(kb, "smpf_reduce_pairs" if os.environ.get("GF_SMP_FUSE_SMALL", "1") == "0" else "smpf_diag_gather_bwd", 4 * (2 * pr * C + n_l * C))
             add(kb, "smpf_fold", 4 * (256 * 8 * C * C + 18 * C * C))                         # <= 256 row-range images of the eight products + the small ones
     step_bytes = sum(kb.values())
     step_flops = sum(kf.values())

@@ -566,14 +566,16 @@ __global__ void diag_gather_fwd(const float *__restrict__ fprev, float *__restri
 
 // dGc[pr] = [ sum_cons dU_n[a, inv(p)] | sum_cons dU_n[inv(p), a] ]  over the consumers (n, a) of source node w, in consumer
 // order (deterministic).  dU_n[x, e] is the Z block of dO at row (x, e) (written by combine-backward).
-__global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict__ dGc, const int *__restrict__ prev_s,
-                                const long long *__restrict__ prev_pair, const long long *__restrict__ cons_ptr,
-                                const long long *__restrict__ cons_row, const int *__restrict__ cons_s,
-                                const int *__restrict__ cons_a, const long long *__restrict__ cons_inv_off,
-                                const short *__restrict__ inv, int C, int ocols,
-                                const float *__restrict__ nodefac,   // or null: slice-dropout factors [nodes][18] of the CONSUMERS' level
-                                const long long *__restrict__ cons_pair, const int *__restrict__ pair_node) {   // (with nodefac: consumer -> node)
-    const int w = blockIdx.x;
+// (individual __restrict__ kernel parameters, also for the launch that shares this body with smp_reduce_pairs: handed over in a struct the
+//  pointers lose their no-alias guarantee -- measured in round 6: 0.20 -> 0.26 ms per cfg3 step for this kernel)
+#define GF_DIAGB_PARAMS                                                                                                               \
+    const float *__restrict__ dO, float *__restrict__ dGc, const int *__restrict__ prev_s, const long long *__restrict__ prev_pair,       \
+        const long long *__restrict__ cons_ptr, const long long *__restrict__ cons_row, const int *__restrict__ cons_s,                  \
+        const int *__restrict__ cons_a, const long long *__restrict__ cons_inv_off, const short *__restrict__ inv, int C, int ocols,     \
+        const float *__restrict__ nodefac, /* or null: slice-dropout factors [nodes][18] of the CONSUMERS' level */                       \
+        const long long *__restrict__ cons_pair, const int *__restrict__ pair_node /* (with nodefac: consumer -> node) */
+#define GF_DIAGB_ARGS dO, dGc, prev_s, prev_pair, cons_ptr, cons_row, cons_s, cons_a, cons_inv_off, inv, C, ocols, nodefac, cons_pair, pair_node
+__device__ __forceinline__ void diag_gather_bwd_body(GF_DIAGB_PARAMS, int w) {
     const int sw = prev_s[w], nl = C / 4;
     const long long c0 = cons_ptr[w], c1 = cons_ptr[w + 1];
     const size_t ldo = (size_t)ocols * C;
@@ -610,6 +612,7 @@ __global__ void diag_gather_bwd(const float *__restrict__ dO, float *__restrict_
         st4(dst + (size_t)p * 2 * C + C + 4 * fl, a16);
     }
 }
+__global__ void diag_gather_bwd(GF_DIAGB_PARAMS) { diag_gather_bwd_body(GF_DIAGB_ARGS, (int)blockIdx.x); }
 
 // zeros into the S_ab / T6 blocks of the rows (a, b), and the S_bc / T10 blocks of the rows (b, c), that tables-forward never
 // writes: once per prepared batch (DevLevel::t_zeros; rowflag bits 0 / 1 = the row has data in the first / second pair of blocks)
@@ -696,12 +699,13 @@ __global__ void stack_weights_all(StackAll a, int C, int custom) {
 //   dSout[n] = sum_x dSpart[(n,x)]
 //   colpart[block] = sum over the block's pairs of dbpart    (folded in order by smp_fold_level)
 // 256 threads = row groups x C/4 float4 lanes (C % 4 == 0, C <= 1024); the groups are folded through LDS in a fixed order.
-__global__ __launch_bounds__(256) void smp_reduce_pairs(const float *__restrict__ dSpart, const float *__restrict__ dbpart,
-                                                        float *__restrict__ dSout, float *__restrict__ colpart,
-                                                        const int *__restrict__ node_s, const long long *__restrict__ node_pair,
-                                                        int C, int nodes, int nodes_per_block) {
-    __shared__ __attribute__((aligned(16))) float red[1024];
-    const int n0 = blockIdx.x * nodes_per_block, n1 = (n0 + nodes_per_block < nodes) ? n0 + nodes_per_block : nodes;
+#define GF_REDP_PARAMS                                                                                                              \
+    const float *__restrict__ dSpart, const float *__restrict__ dbpart, float *__restrict__ dSout, float *__restrict__ colpart,          \
+        const int *__restrict__ node_s, const long long *__restrict__ node_pair, int Cr, int nodes, int nodes_per_block
+#define GF_REDP_ARGS dSpart, dbpart, dSout, colpart, node_s, node_pair, Cr, nodes, nodes_per_block
+__device__ __forceinline__ void reduce_pairs_body(GF_REDP_PARAMS, int bid, float *red) {
+    const int C = Cr;
+    const int n0 = bid * nodes_per_block, n1 = (n0 + nodes_per_block < nodes) ? n0 + nodes_per_block : nodes;
     const int nl = C / 4, ng = 256 / nl;
     const int g = threadIdx.x / nl, fl = threadIdx.x % nl;
     const auto one = [](int) { return 1.f; };
@@ -716,8 +720,19 @@ __global__ __launch_bounds__(256) void smp_reduce_pairs(const float *__restrict_
     if (g == 0) {
         f4 t = ld4(red + 4 * fl);
         for (int k = 1; k < ng; ++k) t += ld4(red + k * C + 4 * fl);
-        st4(colpart + (size_t)blockIdx.x * C + 4 * fl, t);
+        st4(colpart + (size_t)bid * C + 4 * fl, t);
     }
+}
+__global__ __launch_bounds__(256) void smp_reduce_pairs(GF_REDP_PARAMS) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    reduce_pairs_body(GF_REDP_ARGS, (int)blockIdx.x, red);
+}
+// Both in ONE launch (round 6): they are independent (each reads what combine-backward left), small and latency-bound -- the column
+// partials' workgroups first, then a workgroup per source node of the level below.  GF_SMP_FUSE_SMALL=0: two launches.
+__global__ __launch_bounds__(256) void smp_reduce_pairs_and_diag_gather(GF_REDP_PARAMS, int nb, GF_DIAGB_PARAMS) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    if ((int)blockIdx.x < nb) reduce_pairs_body(GF_REDP_ARGS, (int)blockIdx.x, red);
+    else diag_gather_bwd_body(GF_DIAGB_ARGS, (int)blockIdx.x - nb);
 }
 
 // End of a level's reverse sweep: every partial image of its weight and bias gradients folded in ONE launch, in a fixed
@@ -1815,13 +1830,19 @@ gf_status smp_fused_backward_level_grouped(gf_smp *s, int l, float *dKl, float *
     gf_status st;
     const int npb = (nodes + 255) / 256, nb = (nodes + npb - 1) / npb;   // <= 256 column partials per level
     float *colpart = s->colpart + (size_t)l * 256 * C;
-    GF_LAUNCH(ctx, "smpf_reduce_pairs", smp_reduce_pairs, dim3(nb), dim3(256), 0, d.dSpart, d.dbpart, d.dSout, colpart, d.node_s,
-              d.node_pair, C, nodes, npb);
     const int ocols = d.fwd_c64 ? 2 : O_COLS;
     const bool drop = s->drop_on;
-    GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, dO, d.dGc, pv.node_s, pv.node_pair,
-              d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C, ocols, drop ? d.nodefac : (const float *)nullptr, d.cons_pair,
-              d.pair_node);
+    const float *nfac = drop ? d.nodefac : (const float *)nullptr;
+    if (!env_is("GF_SMP_FUSE_SMALL", '0') && prevNodes > 0) {
+        GF_LAUNCH(ctx, "smpf_diag_gather_bwd", smp_reduce_pairs_and_diag_gather, dim3((unsigned)(nb + prevNodes)), dim3(256), 0, d.dSpart, d.dbpart, d.dSout,
+                  colpart, d.node_s, d.node_pair, C, nodes, npb, nb, dO, d.dGc, pv.node_s, pv.node_pair, d.cons_ptr, d.cons_row, d.cons_s, d.cons_a,
+                  d.cons_inv_off, d.inv, C, ocols, nfac, d.cons_pair, d.pair_node);
+    } else {
+        GF_LAUNCH(ctx, "smpf_reduce_pairs", smp_reduce_pairs, dim3(nb), dim3(256), 0, d.dSpart, d.dbpart, d.dSout, colpart, d.node_s,
+                  d.node_pair, C, nodes, npb);
+        GF_LAUNCH(ctx, "smpf_diag_gather_bwd", diag_gather_bwd, dim3(prevNodes), dim3(node_block(s->lay.level[l - 1], C)), 0, dO, d.dGc, pv.node_s, pv.node_pair,
+                  d.cons_ptr, d.cons_row, d.cons_s, d.cons_a, d.cons_inv_off, d.inv, C, ocols, nfac, d.cons_pair, d.pair_node);
+    }
     {
         const GemmSpec nt[4] = {spec(d.dGc, d.Wst + 8 * CC, d.dFdc, prevPairs, C, C, 2 * C, C, 2 * C),
                                 spec(d.dGc + C, d.Wst + 9 * CC, d.dFdc + C, prevPairs, C, C, 2 * C, C, 2 * C),
