@@ -1,3 +1,5 @@
+"""Fused vs op-by-op gradients of a batch with fields above 32 positions, PARAMETER BLOCK BY BLOCK (H, the 18 slices of every K_l, b_l, W):
+the comparison that found the lost rows of K_3 slice 11 in round 6 (NOTES.md) -- the global norm hid them.  usage: python tools/grad_blocks.py [C]"""
 import sys, os, numpy as np, torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, os.path.join(ROOT, "tests"))
