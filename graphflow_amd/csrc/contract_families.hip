@@ -23,9 +23,10 @@
 #include "r18_device.h"
 
 // Non-temporal stores of the families' big results (A/B: -DGF_NT_FAM=<mask>): 1 fam50_tables_out's fifteen slices of Out,
-// 2 fam50_forward_mfma's slices of Out, 4 fam_backward_rows' dP.  (r18_device.h: why `nt` on the streams pays.)
+// 2 fam50_forward_mfma's slices of Out, 4 fam_backward_rows' dP, 8 the `_4` slab kernels' streams (P, G in; Out, dP out), 16 the `_10`
+// one-stream-per-graph kernels' streams.  (r18_device.h: why `nt` on the streams pays.)
 #ifndef GF_NT_FAM
-#define GF_NT_FAM 7
+#define GF_NT_FAM 31
 #endif
 namespace gf {
 namespace {
@@ -119,6 +120,11 @@ struct Vec<4> {
         if constexpr ((GF_NT_FAM & SITE) != 0) __builtin_nontemporal_store(v, reinterpret_cast<vf4 *>(p));
         else *reinterpret_cast<vf4 *>(p) = v;
     }
+    template <int SITE>
+    static __device__ __forceinline__ T ld_s(const float *p) {
+        if constexpr ((GF_NT_FAM & SITE) != 0) return __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(p));
+        else return *reinterpret_cast<const vf4 *>(p);
+    }
     static __device__ __forceinline__ T zero() { return vf4{0.f, 0.f, 0.f, 0.f}; }
 };
 
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void r4_fwd_slab(const float *__restrict__ P, 
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int c = i * ppw + cg;
-            v[i] = c < N ? Vec<4>::ld(row + (size_t)c * C) : vf4{0.f, 0.f, 0.f, 0.f};
+            v[i] = c < N ? Vec<4>::ld_s<8>(row + (size_t)c * C) : vf4{0.f, 0.f, 0.f, 0.f};
         }
         vf4 sab = vf4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -170,12 +176,12 @@ __global__ __launch_bounds__(256) void r4_fwd_slab(const float *__restrict__ P, 
             sab[3] += __shfl_xor(sab[3], m);
         }
         float *o = outg + ((size_t)a * N + b) * 4 * C;
-        if (cg == 0) Vec<4>::st(o + 0 * C, sab);                       // Out[a,b,0]
+        if (cg == 0) Vec<4>::st_s<8>(o + 0 * C, sab);                       // Out[a,b,0]
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int c = i * ppw + cg;
-            if (c == b) Vec<4>::st(o + 3 * C, v[i]);                    // Out[a,b,3] = P[a,b,b]
-            if (a == b && c < N) Vec<4>::st(outg + ((size_t)b * N + c) * 4 * C + 2 * C, v[i]);   // Out[b,c,2] = P[b,b,c]
+            if (c == b) Vec<4>::st_s<8>(o + 3 * C, v[i]);                    // Out[a,b,3] = P[a,b,b]
+            if (a == b && c < N) Vec<4>::st_s<8>(outg + ((size_t)b * N + c) * 4 * C + 2 * C, v[i]);   // Out[b,c,2] = P[b,b,c]
         }
     }
     // S_bc[b,c] = sum_a: the four waves' partials in wave order
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void r4_fwd_slab(const float *__restrict__ P, 
         vf4 t = part[i];
         for (int w = 1; w < 4; ++w) t += part[(size_t)w * N * lpc + i];
         const int c = i / lpc, q = i % lpc;
-        Vec<4>::st(Out + g * (size_t)N * N * 4 * C + ((size_t)b * N + c) * 4 * C + 1 * C + 4 * q, t);   // Out[b,c,1]
+        Vec<4>::st_s<8>(Out + g * (size_t)N * N * 4 * C + ((size_t)b * N + c) * 4 * C + 1 * C + 4 * q, t);   // Out[b,c,1]
     }
 }
 
@@ -210,12 +216,12 @@ __global__ __launch_bounds__(256) void r4_bwd_slab(const float *__restrict__ G, 
     for (int i = 0; i < SLOTS; ++i) {
         const int c = i * ppw + cg;
         const float *gc = Gg + ((size_t)b * N + (c < N ? c : 0)) * 4 * C;
-        y[i] = Vec<4>::ld(gc + 1 * C);
-        y2[i] = y[i] + Vec<4>::ld(gc + 2 * C);
+        y[i] = Vec<4>::ld_s<8>(gc + 1 * C);
+        y2[i] = y[i] + Vec<4>::ld_s<8>(gc + 2 * C);
     }
     for (int a = wave; a < N; a += 4) {
         const float *ga = Gg + ((size_t)a * N + b) * 4 * C;
-        const vf4 g0 = Vec<4>::ld(ga), g3 = Vec<4>::ld(ga + 3 * C);
+        const vf4 g0 = Vec<4>::ld_s<8>(ga), g3 = Vec<4>::ld_s<8>(ga + 3 * C);
         float *row = slab + (size_t)a * N * NC;
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256) void r4_bwd_slab(const float *__restrict__ G, 
                 vf4 v = g0 + (a == b ? y2[i] : y[i]);
                 if (c == b) v += g3;
                 if (ACC) v += Vec<4>::ld(row + (size_t)c * C);
-                Vec<4>::st(row + (size_t)c * C, v);
+                Vec<4>::st_s<8>(row + (size_t)c * C, v);
             }
         }
     }
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(MAXT) void r10_fwd_graph(const float *__restrict__ 
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i) {
                 const int c = i * ppw + cg;
-                v[rb][i] = (okb[rb] && c < N) ? Vec<4>::ld(row + (size_t)c * C) : zero;
+                v[rb][i] = (okb[rb] && c < N) ? Vec<4>::ld_s<16>(row + (size_t)c * C) : zero;
             }
         }
     };
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(MAXT) void r10_fwd_graph(const float *__restrict__ 
             sab = r10_butterfly(sab, lpc);
             vbacc[rb] += sab;
             vap += sab;
-            if (cg == 0 && okb[rb]) Vec<4>::st(Outg + (((size_t)a * N + brow[rb]) * 10 + 0) * C + 4 * fl, tot * sab);   // S_ab tot
+            if (cg == 0 && okb[rb]) Vec<4>::st_s<16>(Outg + (((size_t)a * N + brow[rb]) * 10 + 0) * C + 4 * fl, tot * sab);   // S_ab tot
         }
         const int buf = a & 1;
 #pragma unroll
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(MAXT) void r10_fwd_graph(const float *__restrict__ 
             vf4 t = pac[((size_t)buf * nw) * N * lpc + tid];
             for (int w = 1; w < nw; ++w) t += pac[((size_t)buf * nw + w) * N * lpc + tid];
             vcacc += t;
-            Vec<4>::st(Outg + (((size_t)a * N + tid / lpc) * 10 + 1) * C + 4 * (tid % lpc), tot * t);
+            Vec<4>::st_s<16>(Outg + (((size_t)a * N + tid / lpc) * 10 + 1) * C + 4 * (tid % lpc), tot * t);
         }
         if (wave == nw - 1 && lane < lpc) {   // Va[a] = sum_b S_ab[a, b]
             vf4 t = pva[((size_t)buf * nw) * lpc + lane];
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(MAXT) void r10_fwd_graph(const float *__restrict__ 
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int c = i * ppw + cg;
-            if (okb[rb] && c < N) Vec<4>::st(Outg + (((size_t)brow[rb] * N + c) * 10 + 4) * C + 4 * fl, tot * sbc[rb][i]);
+            if (okb[rb] && c < N) Vec<4>::st_s<16>(Outg + (((size_t)brow[rb] * N + c) * 10 + 4) * C + 4 * fl, tot * sbc[rb][i]);
         }
         if (cg == 0 && okb[rb]) sVb[(size_t)brow[rb] * lpc + fl] = vbacc[rb];
     }
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(MAXT) void r10_fwd_graph(const float *__restrict__ 
         const float w = j == 6 ? sA[x * N + y] : (j & 1) ? sq[y] : sr[y];
         const vf4 v = (j == 6 ? sS[q] : vec[(size_t)x * lpc + q]) * w;
         const int k = j < 2 ? 2 + j : 3 + j;   // 2, 3 | 5, 6, 7, 8, 9
-        Vec<4>::st(Outg + ((size_t)row * 10 + k) * C + 4 * q, v);
+        Vec<4>::st_s<16>(Outg + ((size_t)row * 10 + k) * C + 4 * q, v);
     }
 }
 
@@ -456,10 +462,10 @@ __global__ __launch_bounds__(MAXT) void r10_bwd_graph(const float *__restrict__ 
                 if (y < N) {
                     const float *row = Gg + ((size_t)x * N + y) * 10 * C;
                     const float ry = sr[y], qy = sq[y], axy = sA[x * N + y];
-                    xa += Vec<4>::ld(row + 2 * C) * ry + Vec<4>::ld(row + 3 * C) * qy;
-                    xb += Vec<4>::ld(row + 5 * C) * ry + Vec<4>::ld(row + 6 * C) * qy;
-                    xc += Vec<4>::ld(row + 7 * C) * ry + Vec<4>::ld(row + 8 * C) * qy;
-                    xs += Vec<4>::ld(row + 9 * C) * axy;
+                    xa += Vec<4>::ld_s<16>(row + 2 * C) * ry + Vec<4>::ld_s<16>(row + 3 * C) * qy;
+                    xb += Vec<4>::ld_s<16>(row + 5 * C) * ry + Vec<4>::ld_s<16>(row + 6 * C) * qy;
+                    xc += Vec<4>::ld_s<16>(row + 7 * C) * ry + Vec<4>::ld_s<16>(row + 8 * C) * qy;
+                    xs += Vec<4>::ld_s<16>(row + 9 * C) * axy;
                 }
             }
             xa = r10_butterfly(xa, lpc), xb = r10_butterfly(xb, lpc), xc = r10_butterfly(xc, lpc), xs = r10_butterfly(xs, lpc);
@@ -487,16 +493,16 @@ __global__ __launch_bounds__(MAXT) void r10_bwd_graph(const float *__restrict__ 
         for (int i = 0; i < SLOTS; ++i) {
             const int c = i * ppw + cg, b = okb[rb] ? brow[rb] : brow[0];
             const int cc = c < N ? c : 0;
-            base[rb][i] = tot * Vec<4>::ld(Gg + (((size_t)b * N + cc) * 10 + 4) * C) + sxb[(size_t)b * lpc + fl] + sxc[(size_t)cc * lpc + fl] + sS[fl];
+            base[rb][i] = tot * Vec<4>::ld_s<16>(Gg + (((size_t)b * N + cc) * 10 + 4) * C) + sxb[(size_t)b * lpc + fl] + sxc[(size_t)cc * lpc + fl] + sS[fl];
         }
     float *dPg = dP + g * NC * N * N + 4 * fl;
     auto load_a = [&](int a, vf4(&ga)[2], vf4(&g1)[SLOTS]) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) ga[rb] = Vec<4>::ld(Gg + (((size_t)a * N + (okb[rb] ? brow[rb] : brow[0])) * 10 + 0) * C);
+        for (int rb = 0; rb < 2; ++rb) ga[rb] = Vec<4>::ld_s<16>(Gg + (((size_t)a * N + (okb[rb] ? brow[rb] : brow[0])) * 10 + 0) * C);
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int c = i * ppw + cg;
-            g1[i] = Vec<4>::ld(Gg + (((size_t)a * N + (c < N ? c : 0)) * 10 + 1) * C);
+            g1[i] = Vec<4>::ld_s<16>(Gg + (((size_t)a * N + (c < N ? c : 0)) * 10 + 1) * C);
         }
     };
     vf4 ga[2], g1[SLOTS], gan[2], g1n[SLOTS];
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(MAXT) void r10_bwd_graph(const float *__restrict__ 
                 if (c < N) {
                     vf4 v = base[rb][i] + u + tot * g1[i];
                     if (ACC) v += Vec<4>::ld(row + (size_t)c * C);
-                    Vec<4>::st(row + (size_t)c * C, v);
+                    Vec<4>::st_s<16>(row + (size_t)c * C, v);
                 }
             }
         }
