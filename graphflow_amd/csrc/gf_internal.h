@@ -70,15 +70,16 @@ gf_status dist_wait_event(gf_ctx *ctx, hipEvent_t ev, const char *where);
 hipStream_t dist_stream(gf_ctx *ctx);
 
 // Streaming (non-temporal) accesses of the SMP level's kernels, selectable per site for A/B builds (-DGF_NT_SITES=<mask>):
-//   1 products: operand loads   2 products: stores   4 weight gradients: loads   8 combine: O / f / df loads   16 combine: stores
+//   1 products: operand loads   2 products: stores   4 weight gradients: A-operand (T) loads   256: their B-operand loads   8 combine: O / f / df loads   16 combine: stores
 //   32 tables-forward: T stores   64 consumer gather: df stores   128 consumer gather: the S_ab / T6 gradient blocks (read once)
 // tools/micro/copy_probe.hip: `nt` on both sides of a streaming kernel is worth 8 - 10 % of a copy's rate.  Measured per site on the
 // cfg3 step (round 6, two passes each, one box: no `nt` 6.83 - 6.85 ms): 8 + 16 -> 6.73 - 6.75, 32 -> 6.74 - 6.75 (its readers gain
 // as much as tables-forward itself: the dirty lines of a plain store are written back while the NEXT kernel runs), 64 ~ 0.  NOT
 // everywhere: 1 doubles the product kernels' time (a lane reads its 128-byte row segment as eight 16-byte requests -- with `nt`
-// the line is gone again before the second one), 2 and 4 cost 1 - 3 % of their kernels.  Default: 8 | 16 | 32 | 64.
+// the line is gone again before the second one), 2 and 256 cost 1 - 3 % of their kernels; 4 alone (a whole 1 KB row of T per request)
+// -0.01 ms.  Default: 4 | 8 | 16 | 32 | 64.
 #ifndef GF_NT_SITES
-#define GF_NT_SITES 120
+#define GF_NT_SITES 124
 #endif
 #if defined(__HIPCC__)
 template <int SITE, typename V>

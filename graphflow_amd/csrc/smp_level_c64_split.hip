@@ -876,8 +876,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void smp_wgrad_split(const float *__
             const int ld = blk < 5 ? 128 : 256;
             // (the gathered dU row only meets S_ab of ITS row in product 7: a row without data skips the gather as well)
             const float *s0 = src + (size_t)(gathered ? g0 : c0) * ld, *s1 = src + (size_t)(gathered ? g1 : c1) * ld;
-            S.tb[e].v0 = gf_ld_s<4>(reinterpret_cast<const f4v *>((gathered && zg0) ? sp_zero_page + 4 * q_lo : s0));
-            S.tb[e].v1 = gf_ld_s<4>(reinterpret_cast<const f4v *>((gathered && zg1) ? sp_zero_page + 4 * q_lo : s1));
+            S.tb[e].v0 = gf_ld_s<256>(reinterpret_cast<const f4v *>((gathered && zg0) ? sp_zero_page + 4 * q_lo : s0));
+            S.tb[e].v1 = gf_ld_s<256>(reinterpret_cast<const f4v *>((gathered && zg1) ? sp_zero_page + 4 * q_lo : s1));
         }
     };
     // word (column col0 + j, pair) of the images <- halves of (row k, row k + 1) at column col0 + j
