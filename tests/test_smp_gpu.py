@@ -1084,6 +1084,24 @@ def test_fields_above_32_in_a_level_beyond_the_panel_kernels_offsets(gf, monkeyp
     b[4].close()
 
 
+def test_fused_small_launch_equals_the_two_launches(gf, monkeypatch):
+    """Round 6: smp_reduce_pairs and diag_gather_bwd run as ONE launch (smp_reduce_pairs_and_diag_gather); GF_SMP_FUSE_SMALL=0 keeps
+    the two.  Same bodies, same summation order: predictions and gradients bit for bit."""
+    F, D, C, L, cap = 5, 3, 64, 3, 29
+    mols, tg = [], []
+    for seed in range(40):
+        adj, feat, t = synthetic_molecule(9100 + seed)
+        mols.append((adj, feat))
+        tg.append(t)
+    params = smp_params(C, F, D, L, 5)
+    a = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    monkeypatch.setenv("GF_SMP_FUSE_SMALL", "0")
+    b = run_batch(gf, mols, np.array(tg), params, L, C, F, D, cap)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+    a[4].close()
+    b[4].close()
+
+
 def test_text_checkpoint_is_interchangeable_with_the_reference(gf, golden, tmp_path):
     """tests/golden/smp_syn12_checkpoint.txt was written by the REAL SMP_omega::save_model (SMP_omega.h:1033-1042).
     load_model must read it, predict like the golden, and save_model must write the very same bytes back."""
