@@ -531,7 +531,7 @@ def free_port():
 
 def self_spawn(args):
     """`python bench.py --gpus N` outside a launcher: re-run this script as N ranks on this node."""
-    if not args.plumbing:
+    if not args.plumbing and not os.environ.get("GF_BENCH_ONE_GPU"):
         import torch
         have = torch.cuda.device_count()
         if have < args.gpus:
@@ -612,15 +612,20 @@ def main():
     import torch
     import graphflow_amd as gf
 
-    if torch.cuda.device_count() < (local + 1 if world > 1 else 1):
+    # GF_BENCH_ONE_GPU=1 (TEST HOOK, tests/test_dist_gpu.py): every rank on device 0, torch's side channel on gloo, the path's exchange on
+    # whatever GF_RCCL_LIBRARY names (the shared-memory mock: RCCL refuses two ranks on one device) -- this entry point's N > 1 code on a
+    # one-GPU box; the line says so and its numbers mean nothing
+    one_gpu = bool(os.environ.get("GF_BENCH_ONE_GPU")) and world > 1
+    if not one_gpu and torch.cuda.device_count() < (local + 1 if world > 1 else 1):
         sys.exit("bench.py: rank %d needs HIP device %d, %d visible" % (rank, local, torch.cuda.device_count()))
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local if (world > 1 and not one_gpu) else 0)
     torch.cuda.set_device(dev)
+    side = "cpu" if one_gpu else dev   # where the tensors of torch.distributed's own collectives live
     force = bool(os.environ.get("GF_FORCE_DIST"))
-    dist = gd.init(backend="nccl", device=dev) if world > 1 else None   # torch.distributed: barrier + max-over-ranks only
+    dist = (gd.init(backend="gloo") if one_gpu else gd.init(backend="nccl", device=dev)) if world > 1 else None   # torch.distributed: barrier + max-over-ranks only
     ctx = gf.Context(dev.index)
     if world > 1 or force:   # the path's own exchange lives behind the C ABI: one RCCL communicator on the context
-        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        uid = torch.zeros(128, dtype=torch.uint8, device=side)
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(ctx.dist_unique_id()), dtype=torch.uint8))
         if dist is not None:
@@ -642,7 +647,7 @@ def main():
     reps, timers = timed_run(torch, ctx, step, args.steps, args.warmup, fence, notiming, repeats=args.repeats, quiesce=quiesce)
     # every repeat is the contract's timed region (exactly --steps steps between barrier + synchronize): MAX over ranks per repeat, the
     # line's value is the MEDIAN repeat, the spread rides beside it
-    reps = [gd.max_over_ranks(e, dist, dev) for e in reps]
+    reps = [gd.max_over_ranks(e, dist, side) for e in reps]
     elapsed = median(reps)
 
     line = None
@@ -656,6 +661,8 @@ def main():
         line["timed_region"] = {"repeats": len(reps), "steps_each": args.steps, "reported": "median",
                                 "ms_per_step_min": round(1e3 * min(reps) / args.steps, 4), "ms_per_step_median": round(ms_per_step, 4),
                                 "ms_per_step_max": round(1e3 * max(reps) / args.steps, 4)}
+        if one_gpu:
+            line["data"] = "synthetic; TEST HOOK GF_BENCH_ONE_GPU: %d ranks share one GPU through a mock transport -- plumbing only, not a measurement" % world
         if ctx.dist_world > 1 or force:
             line["config"]["collective"] = "gf_dist_* (RCCL) world %d" % ctx.dist_world
             ar = timers.get("rccl_allreduce")
@@ -679,7 +686,7 @@ def main():
             # the ranks step together: the reported time is the slowest rank's
             e2e = end_to_end(min(40, max(8, args.steps)))
             if world > 1:
-                dt = gd.max_over_ranks(e2e["ms_per_step"], dist, dev)
+                dt = gd.max_over_ranks(e2e["ms_per_step"], dist, side)
                 e2e.update(ms_per_step=round(dt, 3), value=round(world * meta["units_per_step"] / (dt * 1e-3), 1), unit="molecules/s, all %d GPUs" % world,
                            host_threads_per_rank=os.environ.get("GF_PREP_THREADS"))
     if rank == 0:

@@ -393,3 +393,31 @@ def test_world_of_several_ranks_on_one_gpu_through_the_mock_transport(gf, tmp_pa
     print("world %d on one GPU (mock transport), C = %d: summed gradient vs one context: %.2e" % (world, C, e))
     assert np.isfinite(gs[0]).all() and e <= 2e-6
     net.close()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_entry_point_with_two_ranks_on_one_gpu(gf, scaling):
+    """`python bench.py --gpus 2` -- the driver's multi-GPU entry point: self-spawn through torch.distributed.run, the unique id's
+    broadcast, gf_dist_init on every rank, sharding, the timed region with the bounded waits, max over ranks, the end-to-end loop with
+    its loader threads and collectives inside backward, the `collective` block of the line, teardown -- with both ranks on device 0
+    (GF_BENCH_ONE_GPU, torch's side channel on gloo) and the exchange on the mock transport.  One JSON line, n_gpus 2, the library's
+    communicator reporting a world of two, four all-reduces per step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GF_BENCH_ONE_GPU="1", GF_RCCL_LIBRARY=MOCK_RCCL, GF_DIST_TIMEOUT_S="120", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--repeats", "2", "--batch",
+                        "96" if scaling == "weak" else "192", "--scaling", scaling, "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
+    assert "world 2" in line["config"]["collective"] and "TEST HOOK" in line["data"]
+    c = line["collective"]
+    assert c["rccl_ranks_seen"] == 2 and c["expected"] == 2 and abs(c["allreduces_per_step"] - 4.0) < 1e-9   # [K_3 b_3 W], [K_2 b_2], [K_1 b_1], [H]
+    assert line["end_to_end"]["value"] > 0 and "all 2 GPUs" in line["end_to_end"]["unit"]
+    assert "96 synthetic" in line["config"]["workload"]   # weak: 96 per rank; strong: 192 split over the two
