@@ -421,3 +421,62 @@ def test_bench_entry_point_with_two_ranks_on_one_gpu(gf, scaling):
     assert c["rccl_ranks_seen"] == 2 and c["expected"] == 2 and abs(c["allreduces_per_step"] - 4.0) < 1e-9   # [K_3 b_3 W], [K_2 b_2], [K_1 b_1], [H]
     assert line["end_to_end"]["value"] > 0 and "all 2 GPUs" in line["end_to_end"]["unit"]
     assert "96 synthetic" in line["config"]["workload"]   # weak: 96 per rank; strong: 192 split over the two
+
+
+def test_a_rank_that_skips_an_allreduce_on_one_gpu_through_the_mock_transport(tmp_path):
+    """Round-5 advice (medium), the scenario it asked for, on ONE GPU: two rank processes on device 0 over the mock transport (whose
+    collectives hold their stream until every rank has joined, as RCCL's kernels do).  Rank 1 skips an all-reduce.  Rank 0 must come back
+    from gf_dist_quiesce with GF_ERR_TIMEOUT naming the exchange, and gf_dist_finalize / gf_ctx_destroy must RETURN -- ncclCommAbort frees
+    the stuck stream -- instead of hanging behind the collective; the context then still computes."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.exists(MOCK_RCCL)
+    idf = tmp_path / "uid.bin"
+    script = tmp_path / "skipper.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, %r)
+        import torch
+        import graphflow_amd as gf
+        rank = int(sys.argv[1]); idf = sys.argv[2]
+        ctx = gf.Context(0)
+        if rank == 0:
+            uid = ctx.dist_unique_id()
+            open(idf + ".tmp", "wb").write(bytes(uid)); os.rename(idf + ".tmp", idf)
+        else:
+            while not os.path.exists(idf): time.sleep(0.02)
+            uid = open(idf, "rb").read()
+        ctx.dist_init(uid, rank, 2)
+        x = torch.ones(1 << 16, device="cuda")
+        ctx.allreduce_sum_(x); ctx.dist_quiesce(); ctx.synchronize()
+        assert float(x[0]) == 2.0
+        if rank == 0:
+            ctx.allreduce_sum_(x)                      # the peer never joins this one: the context's stream is stuck behind it
+            t0 = time.time()
+            try:
+                ctx.dist_quiesce()
+            except gf.GraphFlowHipError as e:
+                assert "rank 0 of 2" in str(e) and "all-reduce #2" in str(e), str(e)
+            else:
+                raise SystemExit("no timeout")
+            waited = time.time() - t0
+            t1 = time.time()
+            ctx.dist_finalize()                        # aborts the communicator: must not wait for the stuck stream
+            ctx.synchronize()                          # ... which drains once the collective has been released
+            assert time.time() - t1 < 20.0
+            y = (torch.arange(8, device="cuda") * 2).sum()
+            assert int(y) == 56
+            ctx.close()
+            print("rank 0 timed out after %%.1f s, tore down in %%.2f s" %% (waited, time.time() - t1))
+        else:
+            time.sleep(12)                             # alive, but not in the collective
+            os._exit(0)
+    """ % root))
+    env = dict(os.environ, GF_DIST_TIMEOUT_S="4", GF_RCCL_LIBRARY=MOCK_RCCL)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(idf)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert procs[0].returncode == 0 and "tore down" in outs[0], outs[0][-3000:]
